@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json's metric on BASELINE.json's config.
+
+  metric   million rows/s (+ achieved HBM GB/s in `roofline`) of the 10-expression float64
+           Projector with 10 % nulls per column (config C2), 2^28 rows PER GPU.
+  step     one Projector::Evaluate over the HBM-resident batch = one launch of the fused
+           projection kernel (inputs/outputs resident and pre-touched; no PCIe in the
+           timed region).
+  N GPUs   one process per GPU (torch.distributed / RCCL used only for the timing barrier);
+           rows are range-sharded, every rank evaluates its own 2^28-row shard, no
+           data-path collective -> weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      algorithmic bytes (113.75 B/row: every input read once, every output
+                written once, bitmaps at 1 bit/row) / mean kernel time measured with HIP
+                events on the launch stream, against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU restatement (oracle/, "port") timed on this host's cores on a
+                bounded prefix of the same workload.
+
+Other workloads (not the bench line; for profiling):  --workload c3  (filter, 10^9 rows)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
+    p.add_argument("--cpu-rows", type=int, default=1 << 24, help="rows of the cpu_baseline sample")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline_c2(rows):
+    """Oracle ("port"), expression-at-a-time like the reference, all host cores."""
+    from gandiva_amd import workloads as W
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    batch = W.c2_batch(rows)
+    exprs = W.c2_expressions()
+    oracle.project(exprs[:1], batch.slice(0, 1 << 16), threads=cores)  # warm up / build
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle.project(exprs, batch, threads=cores)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    return {
+        "value": round(rows * reps / el / 1e6, 2),
+        "unit": "million rows/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{reps} passes over the first {rows} rows of the C2 generator (same "
+                  f"expressions, 10% nulls), oracle/gdv_oracle.c -O3 -march=native, "
+                  f"{cores} threads, {el:.1f} s",
+    }
+
+
+def cpu_baseline_c3(rows):
+    from gandiva_amd import workloads as W
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    batch = W.c3_batch(rows)
+    cond = W.c3_condition()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle.filter_indices(cond, batch, "int32", threads=cores)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    return {"value": round(rows * reps / el / 1e6, 2), "unit": "million rows/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{reps} passes over {rows} rows of the C3 generator, predicate on {cores} "
+                      f"threads + serial bitmap->selection walk, {el:.1f} s"}
+
+
+def load_traffic(tag):
+    """HBM bytes per launch from the committed PMC pass (tools/pmc_traffic.py), if any."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{tag}.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import gandiva_amd as gandiva
+    from gandiva_amd import workloads as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: gandiva_amd has no CPU evaluation path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c2":
+        rows = args.rows or (1 << 28)
+        dbatch = W.c2_device_batch(rows)
+        proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
+        outs = proj.evaluate_device(dbatch)  # allocates + first touch
+        bytes_per_row = W.C2_BYTES_PER_ROW
+
+        def step():
+            proj.evaluate_device(dbatch, outputs=outs, sync=False)
+        kernel_desc = "fused 10-expression projection kernel (1 launch per step)"
+    else:
+        rows = args.rows or 1_000_000_000
+        dbatch = W.c3_device_batch(rows)
+        flt = gandiva.make_filter(W.c3_schema(), W.c3_condition())
+        out = torch.empty(rows, dtype=torch.int32, device="cuda")
+        sel = flt.evaluate_device(dbatch, "int32", out=out)
+        bytes_per_row = 16 + 4 * sel.num_slots / rows
+
+        def step():
+            flt.evaluate_device(dbatch, "int32", out=out)
+        kernel_desc = "predicate+ballot kernel, offsets scan (3 launches), index emit"
+
+    for _ in range(args.warmup):
+        step()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()
+        step()
+        ends[i].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    mean_dev_ms = sum(dev_ms) / len(dev_ms)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    k = torch.tensor([mean_dev_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    mean_dev_ms = float(k.item())
+
+    if rank == 0:
+        total_rows = rows * world
+        value = total_rows * args.steps / elapsed / 1e6
+        achieved = bytes_per_row * rows / (mean_dev_ms * 1e-3) / 1e9
+        line = {
+            "metric": "million rows/sec, 10-expr float64 Projector (10% nulls)" if args.workload == "c2"
+                      else "million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)",
+            "value": round(value, 1),
+            "unit": "million rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.workload == "c2" else "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per "
+                             "column" if args.workload == "c2" else
+                             "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector"),
+                "rows_per_gpu": rows,
+                "total_rows": total_rows,
+                "sharding": f"row-range x{world}, no collective",
+                "residency": "inputs and outputs in HBM (zero-copy C-ABI path)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": load_traffic(args.workload),
+                "kernel": kernel_desc,
+                "algorithmic_bytes_per_row": round(bytes_per_row, 3),
+                "kernel_ms": round(mean_dev_ms, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = (cpu_baseline_c2 if args.workload == "c2" else cpu_baseline_c3)(args.cpu_rows)
+            except Exception as e:  # the baseline must never take the bench line down
+                line["cpu_baseline"] = {"value": None, "unit": "million rows/s", "cores": 0,
+                                        "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+"""gandiva_amd — MI355X-native Projector / Filter evaluator for Arrow record batches.
+
+Package layout (only what the hot path needs):
+  csrc/        C++ core, HIP device-function library, AOT kernels, C ABI
+  _capi.py     ctypes declarations of include/gandiva_amd.h
+  gandiva.py   mirror of the reference lineage's `pyarrow.gandiva` Python API
+  shard.py     row-range sharding across the GPUs of a node (one process per GPU)
+"""
+from .gandiva import (  # noqa: F401
+    Condition, Configuration, DeviceBatch, DeviceColumn, Expression, Filter, FunctionSignature,
+    GandivaError, Node, Projector, SelectionVector, TreeExprBuilder,
+    get_registered_function_signatures, make_filter, make_projector,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI declared in include/gandiva_amd.h.
+
+Nothing here computes: it loads libgandiva_amd.so (built in-tree by
+``make -C gandiva_amd/csrc`` / ``__graft_entry__.build()``) and declares prototypes.  A
+missing library is a hard error — there is no Python or CPU fallback for evaluation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgandiva_amd.so")
+
+
+class gdv_type_t(C.Structure):
+    _fields_ = [("id", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32)]
+
+
+class gdv_config_t(C.Structure):
+    _fields_ = [("optimize", C.c_int32), ("dump_ir", C.c_int32)]
+
+
+class gdv_column_t(C.Structure):
+    _fields_ = [
+        ("validity", C.c_void_p), ("validity_size", C.c_int64),
+        ("data", C.c_void_p), ("data_size", C.c_int64),
+        ("offsets", C.c_void_p), ("offsets_size", C.c_int64),
+        ("offset", C.c_int64),
+    ]
+
+
+class gdv_out_column_t(C.Structure):
+    _fields_ = [
+        ("validity", C.c_void_p), ("validity_size", C.c_int64),
+        ("data", C.c_void_p), ("data_size", C.c_int64),
+    ]
+
+
+class gdv_selection_t(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("indices", C.c_void_p), ("num_slots", C.c_int64)]
+
+
+# every symbol include/gandiva_amd.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+PROTOTYPES = [
+    ("gdv_last_error", C.c_char_p, []),
+    ("gdv_version", C.c_char_p, []),
+    ("gdv_free_string", None, [_P]),
+    ("gdv_schema_new", _P, []),
+    ("gdv_schema_add_field", C.c_int, [_P, C.c_char_p, gdv_type_t, C.c_int]),
+    ("gdv_schema_num_fields", C.c_int, [_P]),
+    ("gdv_schema_free", None, [_P]),
+    ("gdv_node_field", _P, [C.c_char_p, gdv_type_t]),
+    ("gdv_node_literal", _P, [gdv_type_t, _P, C.c_int]),
+    ("gdv_node_literal_bytes", _P, [gdv_type_t, C.c_char_p, C.c_int64, C.c_int]),
+    ("gdv_node_function", _P, [C.c_char_p, C.POINTER(_P), C.c_int, gdv_type_t]),
+    ("gdv_node_if", _P, [_P, _P, _P, gdv_type_t]),
+    ("gdv_node_and", _P, [C.POINTER(_P), C.c_int]),
+    ("gdv_node_or", _P, [C.POINTER(_P), C.c_int]),
+    ("gdv_node_in", _P, [_P, gdv_type_t, _P, C.c_int]),
+    ("gdv_node_in_bytes", _P, [_P, gdv_type_t, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int]),
+    ("gdv_node_to_string", _P, [_P]),
+    ("gdv_node_return_type", gdv_type_t, [_P]),
+    ("gdv_node_free", None, [_P]),
+    ("gdv_expression_new", _P, [_P, C.c_char_p, gdv_type_t]),
+    ("gdv_condition_new", _P, [_P]),
+    ("gdv_expression_to_string", _P, [_P]),
+    ("gdv_expression_result_type", gdv_type_t, [_P]),
+    ("gdv_expression_free", None, [_P]),
+    ("gdv_projector_make", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(gdv_config_t), C.POINTER(_P)]),
+    ("gdv_projector_num_outputs", C.c_int, [_P]),
+    ("gdv_projector_output_type", gdv_type_t, [_P, C.c_int]),
+    ("gdv_projector_output_sizes", C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("gdv_projector_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_selection_t), C.POINTER(gdv_out_column_t), C.c_int, C.c_int, _P, C.c_uint32]),
+    ("gdv_projector_dump_ir", _P, [_P]),
+    ("gdv_projector_free", None, [_P]),
+    ("gdv_filter_make", C.c_int, [_P, _P, C.POINTER(gdv_config_t), C.POINTER(_P)]),
+    ("gdv_filter_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), C.c_int, _P]),
+    ("gdv_filter_dump_ir", _P, [_P]),
+    ("gdv_filter_free", None, [_P]),
+    ("gdv_registry_size", C.c_int, []),
+    ("gdv_registry_get", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(gdv_type_t), C.POINTER(gdv_type_t), C.c_int, C.POINTER(C.c_int)]),
+    ("gdv_device_count", C.c_int, []),
+    ("gdv_device_num_cus", C.c_int, []),
+    ("gdv_device_arch", C.c_char_p, []),
+    ("gdv_device_alloc", C.c_int, [C.c_int64, C.POINTER(_P)]),
+    ("gdv_device_free", C.c_int, [_P]),
+    ("gdv_memcpy_h2d", C.c_int, [_P, _P, C.c_int64]),
+    ("gdv_memcpy_d2h", C.c_int, [_P, _P, C.c_int64]),
+    ("gdv_device_synchronize", C.c_int, []),
+    ("gdv_precompile_projector", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
+    ("gdv_precompile_filter", C.c_int, [_P, _P]),
+]
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library (loaded once; raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C gandiva_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. gandiva_amd has no "
+                "CPU/Python fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in PROTOTYPES:
+            fn = getattr(l, name)  # AttributeError = header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = l
+    return _lib
+
+
+def take_string(ptr):
+    """Copy and free a malloc'ed C string returned by the library."""
+    if not ptr:
+        return None
+    s = C.string_at(ptr).decode("utf-8", errors="replace")
+    lib().gdv_free_string(ptr)
+    return s
+
+
+def last_error():
+    return lib().gdv_last_error().decode("utf-8", errors="replace")

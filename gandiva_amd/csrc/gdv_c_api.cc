@@ -1,0 +1,387 @@
+// extern "C" boundary (include/gandiva_amd.h) over the C++ core.
+#include "../../include/gandiva_amd.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gdv_engine.h"
+
+using namespace gdv;
+
+struct gdv_schema { Schema fields; };
+struct gdv_node { NodePtr node; };
+struct gdv_expression { ExpressionPtr expr; };
+struct gdv_projector { std::shared_ptr<Projector> p; };
+struct gdv_filter { std::shared_ptr<Filter> f; };
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int Fail(const Status& s) {
+  g_last_error = s.ToString();
+  return static_cast<int>(s.code);
+}
+int Check(const Status& s) {
+  if (s.ok()) return GDV_OK;
+  return Fail(s);
+}
+template <typename T>
+T* FailPtr(const std::string& msg) {
+  g_last_error = "Invalid: " + msg;
+  return nullptr;
+}
+
+bool ToType(gdv_type_t t, DataType* out) {
+  switch (t.id) {
+    case kBool: case kUInt8: case kInt8: case kUInt16: case kInt16: case kUInt32: case kInt32:
+    case kUInt64: case kInt64: case kFloat: case kDouble: case kString: case kBinary:
+    case kDate32: case kDate64: case kTimestamp: case kTime32: case kTime64: case kDecimal128:
+      *out = DataType(static_cast<TypeId>(t.id), t.precision, t.scale);
+      return true;
+    default:
+      return false;
+  }
+}
+gdv_type_t FromType(const DataType& t) { return gdv_type_t{t.id, t.precision, t.scale}; }
+
+char* DupString(const std::string& s) {
+  char* p = static_cast<char*>(malloc(s.size() + 1));
+  if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+bool CollectChildren(gdv_node_t* const* children, int n, NodeVector* out) {
+  if (n < 0 || (n > 0 && children == nullptr)) return false;
+  for (int i = 0; i < n; i++) {
+    if (children[i] == nullptr || !children[i]->node) return false;
+    out->push_back(children[i]->node);
+  }
+  return true;
+}
+
+std::vector<ColumnBuffers> ToColumns(const gdv_column_t* cols, int n) {
+  std::vector<ColumnBuffers> v(n > 0 ? n : 0);
+  for (int i = 0; i < n; i++) {
+    v[i].validity = cols[i].validity;
+    v[i].validity_size = cols[i].validity_size;
+    v[i].data = cols[i].data;
+    v[i].data_size = cols[i].data_size;
+    v[i].offsets = cols[i].offsets;
+    v[i].offsets_size = cols[i].offsets_size;
+    v[i].offset = cols[i].offset;
+  }
+  return v;
+}
+
+bool ToSelectionMode(int m, SelectionMode* out) {
+  if (m < 0 || m > 3) return false;
+  *out = static_cast<SelectionMode>(m);
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gdv_last_error(void) { return g_last_error.c_str(); }
+const char* gdv_version(void) { return "gandiva_amd 0.1.0 (gfx950)"; }
+void gdv_free_string(char* s) { free(s); }
+
+// ---------------------------------------------------------------- schema
+gdv_schema_t* gdv_schema_new(void) { return new gdv_schema(); }
+int gdv_schema_add_field(gdv_schema_t* schema, const char* name, gdv_type_t type, int nullable) {
+  DataType t;
+  if (!schema || !name) return Fail(Status::Invalid("null schema or field name"));
+  if (!ToType(type, &t)) return Fail(Status::Invalid("unsupported type id " + std::to_string(type.id)));
+  schema->fields.push_back(Field{name, t, nullable != 0});
+  return GDV_OK;
+}
+int gdv_schema_num_fields(const gdv_schema_t* schema) {
+  return schema ? static_cast<int>(schema->fields.size()) : 0;
+}
+void gdv_schema_free(gdv_schema_t* schema) { delete schema; }
+
+// ---------------------------------------------------------------- nodes
+gdv_node_t* gdv_node_field(const char* name, gdv_type_t type) {
+  DataType t;
+  if (!name) return FailPtr<gdv_node_t>("field name is null");
+  if (!ToType(type, &t)) return FailPtr<gdv_node_t>("unsupported type id");
+  return new gdv_node{std::make_shared<FieldNode>(Field{name, t, true})};
+}
+
+gdv_node_t* gdv_node_literal(gdv_type_t type, const void* value, int is_null) {
+  DataType t;
+  if (!ToType(type, &t)) return FailPtr<gdv_node_t>("unsupported type id");
+  if (t.is_varlen()) return FailPtr<gdv_node_t>("use gdv_node_literal_bytes for var-len types");
+  Literal lit;
+  lit.is_null = is_null != 0;
+  if (!lit.is_null) {
+    if (!value) return FailPtr<gdv_node_t>("literal value is null");
+    int w = t.id == kBool ? 1 : t.byte_width();
+    unsigned char raw[16] = {0};
+    std::memcpy(raw, value, w);
+    std::memcpy(&lit.lo, raw, 8);
+    std::memcpy(&lit.hi, raw + 8, 8);
+    if (t.id == kBool) lit.lo = raw[0] ? 1 : 0;
+    // sign-extend narrow signed integers so the payload is the value's int64 image
+    if (t.id == kInt8) lit.lo = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int8_t>(raw[0])));
+    if (t.id == kInt16) { int16_t v; std::memcpy(&v, raw, 2); lit.lo = static_cast<uint64_t>(static_cast<int64_t>(v)); }
+    if (t.id == kInt32 || t.id == kDate32 || t.id == kTime32) {
+      int32_t v; std::memcpy(&v, raw, 4); lit.lo = static_cast<uint64_t>(static_cast<int64_t>(v));
+    }
+  }
+  return new gdv_node{std::make_shared<LiteralNode>(t, lit)};
+}
+
+gdv_node_t* gdv_node_literal_bytes(gdv_type_t type, const char* data, int64_t len, int is_null) {
+  DataType t;
+  if (!ToType(type, &t) || !t.is_varlen()) return FailPtr<gdv_node_t>("type must be string or binary");
+  Literal lit;
+  lit.is_null = is_null != 0;
+  if (!lit.is_null) {
+    if (len < 0 || (len > 0 && !data)) return FailPtr<gdv_node_t>("bad literal bytes");
+    lit.bytes.assign(data ? data : "", static_cast<size_t>(len));
+  }
+  return new gdv_node{std::make_shared<LiteralNode>(t, lit)};
+}
+
+gdv_node_t* gdv_node_function(const char* name, gdv_node_t* const* children, int num_children,
+                              gdv_type_t return_type) {
+  DataType t;
+  NodeVector kids;
+  if (!name) return FailPtr<gdv_node_t>("function name is null");
+  if (!ToType(return_type, &t)) return FailPtr<gdv_node_t>("unsupported return type id");
+  if (!CollectChildren(children, num_children, &kids)) return FailPtr<gdv_node_t>("null child node");
+  return new gdv_node{std::make_shared<FunctionNode>(name, std::move(kids), t)};
+}
+
+gdv_node_t* gdv_node_if(gdv_node_t* c, gdv_node_t* t, gdv_node_t* e, gdv_type_t return_type) {
+  DataType rt;
+  if (!c || !t || !e || !c->node || !t->node || !e->node) return FailPtr<gdv_node_t>("null child node");
+  if (!ToType(return_type, &rt)) return FailPtr<gdv_node_t>("unsupported return type id");
+  return new gdv_node{std::make_shared<IfNode>(c->node, t->node, e->node, rt)};
+}
+
+gdv_node_t* gdv_node_and(gdv_node_t* const* children, int n) {
+  NodeVector kids;
+  if (!CollectChildren(children, n, &kids)) return FailPtr<gdv_node_t>("null child node");
+  return new gdv_node{std::make_shared<BooleanNode>(BooleanNode::kAnd, std::move(kids))};
+}
+
+gdv_node_t* gdv_node_or(gdv_node_t* const* children, int n) {
+  NodeVector kids;
+  if (!CollectChildren(children, n, &kids)) return FailPtr<gdv_node_t>("null child node");
+  return new gdv_node{std::make_shared<BooleanNode>(BooleanNode::kOr, std::move(kids))};
+}
+
+gdv_node_t* gdv_node_in(gdv_node_t* node, gdv_type_t value_type, const void* values, int n) {
+  DataType t;
+  if (!node || !node->node) return FailPtr<gdv_node_t>("null child node");
+  if (!ToType(value_type, &t) || t.is_varlen()) return FailPtr<gdv_node_t>("bad IN value type");
+  if (n < 0 || (n > 0 && !values)) return FailPtr<gdv_node_t>("bad IN values");
+  const int w = t.byte_width();
+  if (w == 0) return FailPtr<gdv_node_t>("IN over this type is not supported");
+  std::vector<Literal> lits(n);
+  const char* p = static_cast<const char*>(values);
+  for (int i = 0; i < n; i++) {
+    unsigned char raw[16] = {0};
+    std::memcpy(raw, p + static_cast<size_t>(i) * w, w);
+    std::memcpy(&lits[i].lo, raw, 8);
+    std::memcpy(&lits[i].hi, raw + 8, 8);
+  }
+  return new gdv_node{std::make_shared<InNode>(node->node, t, std::move(lits))};
+}
+
+gdv_node_t* gdv_node_in_bytes(gdv_node_t* node, gdv_type_t value_type, const char* const* values,
+                              const int64_t* lengths, int n) {
+  DataType t;
+  if (!node || !node->node) return FailPtr<gdv_node_t>("null child node");
+  if (!ToType(value_type, &t) || !t.is_varlen()) return FailPtr<gdv_node_t>("bad IN value type");
+  if (n < 0 || (n > 0 && (!values || !lengths))) return FailPtr<gdv_node_t>("bad IN values");
+  std::vector<Literal> lits(n);
+  for (int i = 0; i < n; i++) lits[i].bytes.assign(values[i] ? values[i] : "", static_cast<size_t>(lengths[i]));
+  return new gdv_node{std::make_shared<InNode>(node->node, t, std::move(lits))};
+}
+
+char* gdv_node_to_string(const gdv_node_t* node) {
+  return node && node->node ? DupString(node->node->ToString()) : nullptr;
+}
+gdv_type_t gdv_node_return_type(const gdv_node_t* node) {
+  return node && node->node ? FromType(node->node->return_type()) : gdv_type_t{0, 0, 0};
+}
+void gdv_node_free(gdv_node_t* node) { delete node; }
+
+gdv_expression_t* gdv_expression_new(gdv_node_t* root, const char* result_name, gdv_type_t rt) {
+  DataType t;
+  if (!root || !root->node) return FailPtr<gdv_expression_t>("root node is null");
+  if (!result_name) return FailPtr<gdv_expression_t>("result field is null");
+  if (!ToType(rt, &t)) return FailPtr<gdv_expression_t>("unsupported result type id");
+  return new gdv_expression{std::make_shared<Expression>(root->node, Field{result_name, t, true})};
+}
+gdv_expression_t* gdv_condition_new(gdv_node_t* root) {
+  if (!root || !root->node) return FailPtr<gdv_expression_t>("root node is null");
+  return new gdv_expression{std::make_shared<Expression>(root->node, Field{"cond", boolean(), true})};
+}
+char* gdv_expression_to_string(const gdv_expression_t* e) {
+  return e && e->expr ? DupString(e->expr->ToString()) : nullptr;
+}
+gdv_type_t gdv_expression_result_type(const gdv_expression_t* e) {
+  return e && e->expr ? FromType(e->expr->result().type) : gdv_type_t{0, 0, 0};
+}
+void gdv_expression_free(gdv_expression_t* e) { delete e; }
+
+// ---------------------------------------------------------------- projector
+static bool CollectExprs(gdv_expression_t* const* exprs, int n, std::vector<ExpressionPtr>* out) {
+  if (n < 0 || (n > 0 && !exprs)) return false;
+  for (int i = 0; i < n; i++) {
+    if (!exprs[i] || !exprs[i]->expr) return false;
+    out->push_back(exprs[i]->expr);
+  }
+  return true;
+}
+
+int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs,
+                       int selection_mode, const gdv_config_t* config, gdv_projector_t** out) {
+  if (!schema || !out) return Fail(Status::Invalid("null schema or output pointer"));
+  std::vector<ExpressionPtr> ex;
+  if (!CollectExprs(exprs, num_exprs, &ex)) return Fail(Status::Invalid("null expression"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  Configuration cfg;
+  if (config) { cfg.optimize = config->optimize != 0; cfg.dump_ir = config->dump_ir != 0; }
+  std::shared_ptr<Projector> p;
+  Status s = Projector::Make(schema->fields, ex, mode, cfg, &p);
+  if (!s.ok()) return Fail(s);
+  *out = new gdv_projector{p};
+  return GDV_OK;
+}
+int gdv_projector_num_outputs(const gdv_projector_t* p) { return p ? p->p->num_outputs() : 0; }
+gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i) {
+  if (!p || i < 0 || i >= p->p->num_outputs()) return gdv_type_t{0, 0, 0};
+  return FromType(p->p->output_type(i));
+}
+int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, int mem_kind,
+                               int64_t* validity_bytes, int64_t* data_bytes) {
+  if (!p || i < 0 || i >= p->p->num_outputs() || rows < 0) return Fail(Status::Invalid("bad argument"));
+  const DataType& t = p->p->output_type(i);
+  const bool dev = mem_kind == GDV_MEM_DEVICE;
+  if (validity_bytes) *validity_bytes = dev ? Projector::ValidityBytes(rows) : (rows + 7) / 8;
+  if (data_bytes)
+    *data_bytes = t.id == kBool ? (dev ? Projector::ValidityBytes(rows) : (rows + 7) / 8)
+                                : Projector::DataBytes(t, rows);
+  return GDV_OK;
+}
+int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
+                           int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
+                           int num_outs, int mem_kind, void* stream, uint32_t flags) {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
+  if (!outs) return Fail(Status::Invalid("Output array vector cannot be null"));
+  std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+  std::vector<OutputBuffers> o(num_outs > 0 ? num_outs : 0);
+  for (int i = 0; i < num_outs; i++) {
+    o[i].validity = outs[i].validity;
+    o[i].validity_size = outs[i].validity_size;
+    o[i].data = outs[i].data;
+    o[i].data_size = outs[i].data_size;
+  }
+  SelectionView sv;
+  if (sel) {
+    if (!ToSelectionMode(sel->mode, &sv.mode)) return Fail(Status::Invalid("bad selection mode"));
+    sv.indices = sel->indices;
+    sv.num_slots = sel->num_slots;
+  }
+  return Check(p->p->Evaluate(num_rows, c.data(), num_cols, sel ? &sv : nullptr, o.data(),
+                              num_outs, mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
+                              static_cast<hipStream_t>(stream), flags));
+}
+char* gdv_projector_dump_ir(const gdv_projector_t* p) { return p ? DupString(p->p->DumpIR()) : nullptr; }
+void gdv_projector_free(gdv_projector_t* p) { delete p; }
+
+// ---------------------------------------------------------------- filter
+int gdv_filter_make(const gdv_schema_t* schema, gdv_expression_t* condition,
+                    const gdv_config_t* config, gdv_filter_t** out) {
+  if (!schema || !out) return Fail(Status::Invalid("null schema or output pointer"));
+  if (!condition || !condition->expr) return Fail(Status::Invalid("Condition cannot be null"));
+  Configuration cfg;
+  if (config) { cfg.optimize = config->optimize != 0; cfg.dump_ir = config->dump_ir != 0; }
+  std::shared_ptr<Filter> f;
+  Status s = Filter::Make(schema->fields, condition->expr, cfg, &f);
+  if (!s.ok()) return Fail(s);
+  *out = new gdv_filter{f};
+  return GDV_OK;
+}
+int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols,
+                        int num_cols, int selection_mode, void* out_indices, int64_t max_slots,
+                        int64_t* num_selected, int mem_kind, void* stream) {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+  return Check(f->f->Evaluate(num_rows, c.data(), num_cols, mode, out_indices, max_slots,
+                              num_selected, mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
+                              static_cast<hipStream_t>(stream)));
+}
+char* gdv_filter_dump_ir(const gdv_filter_t* f) { return f ? DupString(f->f->DumpIR()) : nullptr; }
+void gdv_filter_free(gdv_filter_t* f) { delete f; }
+
+// ---------------------------------------------------------------- registry
+int gdv_registry_size(void) { return static_cast<int>(FunctionRegistry::Get().all().size()); }
+int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_type_t* params,
+                     int max_params, int* num_params) {
+  auto& all = FunctionRegistry::Get().all();
+  if (index < 0 || index >= static_cast<int>(all.size())) return Fail(Status::Invalid("index out of range"));
+  const FunctionDef& d = all[index];
+  if (name) *name = d.name.c_str();
+  if (return_type) *return_type = FromType(d.ret);
+  if (num_params) *num_params = static_cast<int>(d.params.size());
+  for (int i = 0; params && i < max_params && i < static_cast<int>(d.params.size()); i++)
+    params[i] = FromType(d.params[i]);
+  return GDV_OK;
+}
+
+// ---------------------------------------------------------------- device helpers
+int gdv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+int gdv_device_num_cus(void) { return Runtime::Get().num_cus(); }
+const char* gdv_device_arch(void) { return Runtime::Get().arch().c_str(); }
+int gdv_device_alloc(int64_t bytes, void** ptr) {
+  if (!ptr || bytes < 0) return Fail(Status::Invalid("bad argument"));
+  return Check(Runtime::Get().Alloc(static_cast<size_t>(bytes ? bytes : 1), ptr));
+}
+int gdv_device_free(void* ptr) { Runtime::Get().Free(ptr); return GDV_OK; }
+int gdv_memcpy_h2d(void* dst, const void* src, int64_t bytes) {
+  hipError_t e = hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyHostToDevice);
+  return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+}
+int gdv_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
+  hipError_t e = hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost);
+  return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+}
+int gdv_device_synchronize(void) {
+  hipError_t e = hipDeviceSynchronize();
+  return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+}
+
+// ---------------------------------------------------------------- build support
+int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
+                             int num_exprs, int selection_mode) {
+  if (!schema) return Fail(Status::Invalid("null schema"));
+  std::vector<ExpressionPtr> ex;
+  if (!CollectExprs(exprs, num_exprs, &ex)) return Fail(Status::Invalid("null expression"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  return Check(PrecompileProjector(schema->fields, ex, mode));
+}
+int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* condition) {
+  if (!schema || !condition || !condition->expr) return Fail(Status::Invalid("null argument"));
+  return Check(PrecompileFilter(schema->fields, condition->expr));
+}
+
+}  // extern "C"

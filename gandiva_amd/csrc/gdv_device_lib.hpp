@@ -1,0 +1,543 @@
+// gandiva_amd device function library (gfx950 / CDNA4, wave64).
+//
+// This header is the fixed library the fused kernels are assembled from: it replaces the
+// reference's `precompiled/*.cc` bitcode library and
+// `BitMapAccumulator` / `bitmap.cc` helpers (rows 8, 13).  It is embedded verbatim in
+// libgandiva_amd.so and handed to the runtime compiler together with the kernel body the
+// planner emits for one Projector / Filter (gdv_planner.cc).  Function names follow the
+// reference's `<name>_<type>_<type>` convention so a plan dump reads like the
+// reference's IR.  Everything is written for 64-wide wavefronts: one wavefront handles
+// 64 consecutive rows per sub-tile, i.e. exactly one 64-bit Arrow validity word
+// (LSB-first bit order: pyarrow/include/arrow/util/bit_util.h:173-175).
+//
+// Build flags that are part of the semantics: -ffp-contract=off (no FMA fusion: results
+// must be bit-identical to separate IEEE mul + add), correctly rounded f32 divide/sqrt.
+#pragma once
+
+typedef signed char gdv_int8;
+typedef short gdv_int16;
+typedef int gdv_int32;
+typedef long long gdv_int64;
+typedef unsigned char gdv_uint8;
+typedef unsigned short gdv_uint16;
+typedef unsigned int gdv_uint32;
+typedef unsigned long long gdv_uint64;
+typedef float gdv_float32;
+typedef double gdv_float64;
+typedef __int128 gdv_int128;
+typedef unsigned __int128 gdv_uint128;
+typedef bool gdv_boolean;
+typedef gdv_int32 gdv_date32;
+typedef gdv_int64 gdv_date64;
+typedef gdv_int64 gdv_timestamp;
+typedef gdv_int32 gdv_time32;
+typedef gdv_int64 gdv_time64;
+
+#define GDV_DEV static __device__ __forceinline__
+#define GDV_WAVE 64
+
+// Error bits a kernel can raise (-> Status::ExecutionError on the host).
+#define GDV_ERR_DIV_ZERO 1u
+#define GDV_ERR_OVERFLOW 2u
+#define GDV_ERR_BAD_ARG 4u
+
+struct gdv_ctx {
+  gdv_uint32* err;
+};
+GDV_DEV void gdv_raise(gdv_ctx ctx, gdv_uint32 bit) { atomicOr(ctx.err, bit); }
+
+// ------------------------------------------------------------------ memory access
+//
+// Values buffers are streamed exactly once: loads are plain coalesced loads (one row per
+// lane -> 64*sizeof(T) contiguous bytes per wave instruction), stores are non-temporal
+// so the written lines do not displace input lines in L2 / Infinity Cache.
+template <typename T>
+GDV_DEV T gdv_ld(const T* p, gdv_int64 i) { return p[i]; }
+template <typename T>
+GDV_DEV T gdv_ldnt(const T* p, gdv_int64 i) { return __builtin_nontemporal_load(p + i); }
+template <typename T>
+GDV_DEV void gdv_st(T* p, gdv_int64 i, T v) { p[i] = v; }
+template <typename T>
+GDV_DEV void gdv_stnt(T* p, gdv_int64 i, T v) { __builtin_nontemporal_store(v, p + i); }
+
+// A bitmap as the kernels see it: 8-byte aligned word pointer + a bit shift < 64 (Arrow
+// array offsets and unaligned buffers are folded into these two by the host) + the
+// number of words that may be read (>= 1).  A column without a validity buffer is bound to
+// a one-word all-ones bitmap (nwords == 1): indices are clamped, never branched on, so
+// the load phase of a tile contains no control flow and all loads issue back to back.
+struct gdv_bitmap {
+  const gdv_uint64* p;
+  gdv_int32 shift;
+  gdv_int64 nwords;
+};
+
+// The GDV_U validity words of one wave tile, fetched with ONE vector load: lane u
+// (u < nsub) returns the 64 bits covering rows [64*(wbase+u), 64*(wbase+u)+64).  Words past
+// the end of the buffer are clamped to the last word: they only cover rows >= n, which
+// the caller masks with its live-row mask.
+GDV_DEV gdv_uint64 gdv_bitmap_tile(const gdv_bitmap& bm, gdv_int64 wbase, int lane, int nsub) {
+  // No exec masking: lanes >= nsub re-read word nsub-1 (same cache line, result unused),
+  // so the two loads carry no control dependence and overlap with the value loads.
+  const int l = lane < nsub ? lane : nsub - 1;
+  const gdv_int64 last = bm.nwords - 1;
+  gdv_int64 i0 = wbase + l;
+  gdv_int64 i1 = i0 + 1;
+  i0 = i0 < last ? i0 : last;
+  i1 = i1 < last ? i1 : last;
+  const gdv_uint64 lo = bm.p[i0];
+  const gdv_uint64 hi = bm.p[i1];
+  // funnel shift that is also correct for shift == 0 (no shift-by-64)
+  return (lo >> bm.shift) | ((hi << 1) << (63 - bm.shift));
+}
+
+// Word `u` of a tile fetched by gdv_bitmap_tile, as a wave-uniform value (SGPR pair):
+// merging the validity of several columns is then s_and_b64, not per-lane work.
+GDV_DEV gdv_uint64 gdv_tile_word(gdv_uint64 tile, int u) {
+  gdv_uint32 lo = __builtin_amdgcn_readlane((gdv_uint32)tile, u);
+  gdv_uint32 hi = __builtin_amdgcn_readlane((gdv_uint32)(tile >> 32), u);
+  return ((gdv_uint64)hi << 32) | lo;
+}
+
+// Deposit the wave-uniform `word` into lane `u` of the accumulator: after GDV_U deposits
+// lanes 0..GDV_U-1 hold the wave's output words and store them with one coalesced store.
+GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int lane) {
+  return (lane == u) ? word : acc;  // v_cndmask with a scalar source
+}
+
+// Bit of an arbitrary row (selection-vector path: rows are gathered, no word structure).
+GDV_DEV bool gdv_bitmap_bit(const gdv_bitmap& bm, gdv_int64 row) {
+  gdv_int64 pos = row + bm.shift;
+  gdv_int64 i = pos >> 6;
+  i = i < bm.nwords - 1 ? i : bm.nwords - 1;
+  return (bm.p[i] >> (pos & 63)) & 1ull;
+}
+
+GDV_DEV bool gdv_lane_bit(gdv_uint64 word, int lane) { return (word >> lane) & 1ull; }
+
+// ------------------------------------------------------------------ arithmetic
+// Integer arithmetic wraps (two's complement); done in the unsigned domain so that the
+// wrap is defined behaviour.  Names: <op>_<type>_<type>, as in the reference's
+// precompiled arithmetic_ops.cc.
+
+#define GDV_INT_TYPES(X) \
+  X(int8, uint8) X(int16, uint16) X(int32, uint32) X(int64, uint64) \
+  X(uint8, uint8) X(uint16, uint16) X(uint32, uint32) X(uint64, uint64)
+#define GDV_FLOAT_TYPES(X) X(float32) X(float64)
+#define GDV_NUMERIC_TYPES(X) \
+  X(int8) X(int16) X(int32) X(int64) X(uint8) X(uint16) X(uint32) X(uint64) X(float32) X(float64)
+
+#define GDV_INT_ARITH(T, U)                                                                      \
+  GDV_DEV gdv_##T add_##T##_##T(gdv_##T a, gdv_##T b) {                                          \
+    return (gdv_##T)(gdv_##U)((gdv_##U)a + (gdv_##U)b);                                          \
+  }                                                                                              \
+  GDV_DEV gdv_##T subtract_##T##_##T(gdv_##T a, gdv_##T b) {                                     \
+    return (gdv_##T)(gdv_##U)((gdv_##U)a - (gdv_##U)b);                                          \
+  }                                                                                              \
+  GDV_DEV gdv_##T multiply_##T##_##T(gdv_##T a, gdv_##T b) {                                     \
+    return (gdv_##T)(gdv_##U)((gdv_##U)a * (gdv_##U)b);                                          \
+  }                                                                                              \
+  /* x / 0 raises "divide by zero error" and yields 0; MIN / -1 wraps to MIN. */                 \
+  GDV_DEV gdv_##T divide_##T##_##T(gdv_ctx ctx, gdv_##T a, gdv_##T b) {                          \
+    if (b == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }                                  \
+    if ((gdv_##T)(-1) < 0 && b == (gdv_##T)(-1)) return (gdv_##T)(gdv_##U)(0 - (gdv_##U)a);      \
+    return (gdv_##T)(a / b);                                                                     \
+  }
+GDV_INT_TYPES(GDV_INT_ARITH)
+
+#define GDV_FLOAT_ARITH(T)                                                                       \
+  GDV_DEV gdv_##T add_##T##_##T(gdv_##T a, gdv_##T b) { return a + b; }                          \
+  GDV_DEV gdv_##T subtract_##T##_##T(gdv_##T a, gdv_##T b) { return a - b; }                     \
+  GDV_DEV gdv_##T multiply_##T##_##T(gdv_##T a, gdv_##T b) { return a * b; }                     \
+  GDV_DEV gdv_##T divide_##T##_##T(gdv_ctx ctx, gdv_##T a, gdv_##T b) {                          \
+    if (b == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }                                  \
+    return a / b;                                                                                \
+  }
+GDV_FLOAT_TYPES(GDV_FLOAT_ARITH)
+
+// mod: a zero divisor returns the dividend unchanged (integer) / raises (float64).
+GDV_DEV gdv_int32 mod_int64_int32(gdv_int64 a, gdv_int32 b) {
+  if (b == 0) return (gdv_int32)a;
+  if (b == -1) return 0;
+  return (gdv_int32)(a % b);
+}
+GDV_DEV gdv_int64 mod_int64_int64(gdv_int64 a, gdv_int64 b) {
+  if (b == 0) return a;
+  if (b == -1) return 0;
+  return a % b;
+}
+GDV_DEV gdv_int32 mod_int32_int32(gdv_int32 a, gdv_int32 b) {
+  if (b == 0) return a;
+  if (b == -1) return 0;
+  return a % b;
+}
+GDV_DEV gdv_float64 mod_float64_float64(gdv_ctx ctx, gdv_float64 a, gdv_float64 b) {
+  if (b == 0.0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0.0; }
+  return fmod(a, b);
+}
+
+GDV_DEV gdv_int32 negative_int32(gdv_int32 a) { return (gdv_int32)(0u - (gdv_uint32)a); }
+GDV_DEV gdv_int64 negative_int64(gdv_int64 a) { return (gdv_int64)(0ull - (gdv_uint64)a); }
+GDV_DEV gdv_float32 negative_float32(gdv_float32 a) { return -a; }
+GDV_DEV gdv_float64 negative_float64(gdv_float64 a) { return -a; }
+GDV_DEV gdv_int32 abs_int32(gdv_int32 a) { return a < 0 ? negative_int32(a) : a; }
+GDV_DEV gdv_int64 abs_int64(gdv_int64 a) { return a < 0 ? negative_int64(a) : a; }
+GDV_DEV gdv_float32 abs_float32(gdv_float32 a) { return fabsf(a); }
+GDV_DEV gdv_float64 abs_float64(gdv_float64 a) { return fabs(a); }
+
+// ------------------------------------------------------------------ relational
+
+#define GDV_RELOPS(T)                                                                         \
+  GDV_DEV bool equal_##T##_##T(gdv_##T a, gdv_##T b) { return a == b; }                       \
+  GDV_DEV bool not_equal_##T##_##T(gdv_##T a, gdv_##T b) { return a != b; }                   \
+  GDV_DEV bool less_than_##T##_##T(gdv_##T a, gdv_##T b) { return a < b; }                    \
+  GDV_DEV bool less_than_or_equal_to_##T##_##T(gdv_##T a, gdv_##T b) { return a <= b; }       \
+  GDV_DEV bool greater_than_##T##_##T(gdv_##T a, gdv_##T b) { return a > b; }                 \
+  GDV_DEV bool greater_than_or_equal_to_##T##_##T(gdv_##T a, gdv_##T b) { return a >= b; }
+GDV_NUMERIC_TYPES(GDV_RELOPS)
+GDV_RELOPS(boolean)
+GDV_RELOPS(date32)
+GDV_RELOPS(date64)
+GDV_RELOPS(timestamp)
+GDV_RELOPS(time32)
+GDV_RELOPS(time64)
+
+GDV_DEV bool not_boolean(bool a) { return !a; }
+
+// null-aware predicates: the value function sees (value, validity) pairs
+template <typename T>
+GDV_DEV bool gdv_isnull(T, bool valid) { return !valid; }
+template <typename T>
+GDV_DEV bool gdv_isnotnull(T, bool valid) { return valid; }
+template <typename T>
+GDV_DEV bool gdv_is_distinct_from(T a, bool av, T b, bool bv) {
+  if (av != bv) return true;
+  if (!av) return false;
+  return a != b;
+}
+template <typename T>
+GDV_DEV bool gdv_is_not_distinct_from(T a, bool av, T b, bool bv) {
+  return !gdv_is_distinct_from(a, av, b, bv);
+}
+
+// IN-lists compare zero-extended bit images, so one sorted uint64 table serves every
+// fixed-width type.
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int8 v) { return (gdv_uint8)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint8 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int16 v) { return (gdv_uint16)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint16 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int32 v) { return (gdv_uint32)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint32 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int64 v) { return (gdv_uint64)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint64 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_float32 v) { return __float_as_uint(v); }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_float64 v) { return (gdv_uint64)__double_as_longlong(v); }
+GDV_DEV bool gdv_in_sorted(gdv_uint64 x, const gdv_uint64* tab, int n) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (tab[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo < n && tab[lo] == x;
+}
+GDV_DEV gdv_int128 gdv_make_int128(gdv_uint64 hi, gdv_uint64 lo) {
+  return (gdv_int128)(((gdv_uint128)hi << 64) | lo);
+}
+
+// min/max style helpers of later reference versions
+#define GDV_MINMAX(T)                                                                 \
+  GDV_DEV gdv_##T greatest_##T##_##T(gdv_##T a, gdv_##T b) { return a > b ? a : b; }  \
+  GDV_DEV gdv_##T least_##T##_##T(gdv_##T a, gdv_##T b) { return a < b ? a : b; }
+GDV_MINMAX(int32) GDV_MINMAX(int64) GDV_MINMAX(float32) GDV_MINMAX(float64)
+
+// ------------------------------------------------------------------ casts
+GDV_DEV gdv_int64 castBIGINT_int32(gdv_int32 a) { return (gdv_int64)a; }
+GDV_DEV gdv_int32 castINT_int64(gdv_int64 a) { return (gdv_int32)(gdv_uint32)(gdv_uint64)a; }
+GDV_DEV gdv_float32 castFLOAT4_int32(gdv_int32 a) { return (gdv_float32)a; }
+GDV_DEV gdv_float32 castFLOAT4_int64(gdv_int64 a) { return (gdv_float32)a; }
+GDV_DEV gdv_float32 castFLOAT4_float64(gdv_float64 a) { return (gdv_float32)a; }
+GDV_DEV gdv_float64 castFLOAT8_int32(gdv_int32 a) { return (gdv_float64)a; }
+GDV_DEV gdv_float64 castFLOAT8_int64(gdv_int64 a) { return (gdv_float64)a; }
+GDV_DEV gdv_float64 castFLOAT8_float32(gdv_float32 a) { return (gdv_float64)a; }
+// float -> integer casts round half away from zero and saturate (out-of-range and NaN
+// inputs are undefined on the reference's CPU path; saturation / 0 keeps them defined).
+GDV_DEV gdv_int64 gdv_sat_i64(gdv_float64 r) {
+  if (r != r) return 0;
+  if (r >= 9223372036854775808.0) return 0x7fffffffffffffffLL;
+  if (r <= -9223372036854775808.0) return (gdv_int64)0x8000000000000000ULL;
+  return (gdv_int64)r;
+}
+GDV_DEV gdv_int32 gdv_sat_i32(gdv_float64 r) {
+  if (r != r) return 0;
+  if (r >= 2147483647.0) return 2147483647;
+  if (r <= -2147483648.0) return (gdv_int32)0x80000000u;
+  return (gdv_int32)r;
+}
+GDV_DEV gdv_int64 castBIGINT_float32(gdv_float32 a) { return gdv_sat_i64(round((gdv_float64)a)); }
+GDV_DEV gdv_int64 castBIGINT_float64(gdv_float64 a) { return gdv_sat_i64(round(a)); }
+GDV_DEV gdv_int32 castINT_float32(gdv_float32 a) { return gdv_sat_i32(round((gdv_float64)a)); }
+GDV_DEV gdv_int32 castINT_float64(gdv_float64 a) { return gdv_sat_i32(round(a)); }
+
+GDV_DEV gdv_date64 castDATE_int64(gdv_int64 a) { return a; }
+GDV_DEV gdv_timestamp castTIMESTAMP_int64(gdv_int64 a) { return a; }
+GDV_DEV gdv_timestamp castTIMESTAMP_date64(gdv_date64 a) { return a; }
+GDV_DEV gdv_int64 castBIGINT_date64(gdv_date64 a) { return a; }
+GDV_DEV gdv_int64 castBIGINT_timestamp(gdv_timestamp a) { return a; }
+
+// ------------------------------------------------------------------ extended math
+GDV_DEV gdv_float64 cbrt_float64(gdv_float64 a) { return cbrt(a); }
+GDV_DEV gdv_float64 exp_float64(gdv_float64 a) { return exp(a); }
+GDV_DEV gdv_float64 log_float64(gdv_float64 a) { return log(a); }
+GDV_DEV gdv_float64 log10_float64(gdv_float64 a) { return log10(a); }
+GDV_DEV gdv_float64 sqrt_float64(gdv_float64 a) { return sqrt(a); }
+GDV_DEV gdv_float64 power_float64_float64(gdv_float64 a, gdv_float64 b) { return pow(a, b); }
+GDV_DEV gdv_float64 log_float64_float64(gdv_ctx ctx, gdv_float64 base, gdv_float64 v) {
+  gdv_float64 lb = log(base);
+  if (lb == 0.0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0.0; }
+  return log(v) / lb;
+}
+GDV_DEV gdv_float64 floor_float64(gdv_float64 a) { return floor(a); }
+GDV_DEV gdv_float64 ceil_float64(gdv_float64 a) { return ceil(a); }
+GDV_DEV gdv_float64 round_float64(gdv_float64 a) { return round(a); }
+GDV_DEV gdv_float64 truncate_float64(gdv_float64 a) { return trunc(a); }
+
+// ------------------------------------------------------------------ hash
+// Murmur3-derived hashes over the 8-byte image of the value as a double (every numeric
+// type is first converted to double).  A null input hashes to the seed (0 without seed).
+GDV_DEV gdv_uint64 gdv_rotl64(gdv_uint64 v, int d) { return (v << d) | (v >> (64 - d)); }
+GDV_DEV gdv_uint64 gdv_fmix64(gdv_uint64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+GDV_DEV gdv_int64 gdv_murmur3_64(gdv_uint64 val, gdv_int32 seed) {
+  gdv_uint64 h1 = (gdv_uint64)(gdv_int64)seed;
+  gdv_uint64 h2 = (gdv_uint64)(gdv_int64)seed;
+  const gdv_uint64 c1 = 0x87c37b91114253d5ULL;
+  const gdv_uint64 c2 = 0x4cf5ad432745937fULL;
+  const gdv_uint64 length = 8;
+  gdv_uint64 k1 = val;
+  k1 *= c1;
+  k1 = gdv_rotl64(k1, 31);
+  k1 *= c2;
+  h1 ^= k1;
+  h1 ^= length;
+  h2 ^= length;
+  h1 += h2;
+  h2 += h1;
+  h1 = gdv_fmix64(h1);
+  h2 = gdv_fmix64(h2);
+  h1 += h2;
+  return (gdv_int64)h1;
+}
+GDV_DEV gdv_int32 gdv_murmur3_32(gdv_uint64 val, gdv_int32 seed) {
+  const gdv_uint32 c1 = 0xcc9e2d51u;
+  const gdv_uint32 c2 = 0x1b873593u;
+  gdv_uint32 h = (gdv_uint32)seed;
+  for (int i = 0; i < 2; i++) {
+    gdv_uint32 k = (gdv_uint32)(val >> (i * 32));
+    k *= c1;
+    k = (k << 15) | (k >> 17);
+    k *= c2;
+    h ^= k;
+    h = (h << 13) | (h >> 19);
+    h = h * 5u + 0xe6546b64u;
+  }
+  h ^= 8u;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return (gdv_int32)h;
+}
+GDV_DEV gdv_uint64 gdv_double_bits(gdv_float64 v) { return (gdv_uint64)__double_as_longlong(v); }
+
+#define GDV_HASH(T)                                                                              \
+  GDV_DEV gdv_int32 hash32_##T(gdv_##T v, bool valid) {                                          \
+    return valid ? gdv_murmur3_32(gdv_double_bits((gdv_float64)v), 0) : 0;                       \
+  }                                                                                              \
+  GDV_DEV gdv_int32 hash32_##T##_int32(gdv_##T v, bool valid, gdv_int32 seed, bool sv) {         \
+    gdv_int32 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_32(gdv_double_bits((gdv_float64)v), s) : s;                       \
+  }                                                                                              \
+  GDV_DEV gdv_int64 hash64_##T(gdv_##T v, bool valid) {                                          \
+    return valid ? gdv_murmur3_64(gdv_double_bits((gdv_float64)v), 0) : 0;                       \
+  }                                                                                              \
+  GDV_DEV gdv_int64 hash64_##T##_int64(gdv_##T v, bool valid, gdv_int64 seed, bool sv) {         \
+    gdv_int64 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_64(gdv_double_bits((gdv_float64)v), (gdv_int32)s) : s;            \
+  }
+GDV_NUMERIC_TYPES(GDV_HASH)
+GDV_HASH(boolean)
+GDV_HASH(date32)
+GDV_HASH(date64)
+GDV_HASH(timestamp)
+GDV_HASH(time32)
+
+// ------------------------------------------------------------------ date / time
+// Civil-calendar arithmetic on day counts since 1970-01-01 (proleptic Gregorian), the
+// public-domain algorithms of H. Hinnant's date library that the reference vendors
+// (present here as pyarrow/include/arrow/vendored/datetime/date.h).
+#define GDV_MILLIS_IN_DAY 86400000LL
+
+GDV_DEV gdv_int64 gdv_floor_div(gdv_int64 a, gdv_int64 b) {
+  gdv_int64 q = a / b;
+  return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+GDV_DEV gdv_int64 gdv_floor_mod(gdv_int64 a, gdv_int64 b) { return a - gdv_floor_div(a, b) * b; }
+
+struct gdv_ymd {
+  gdv_int64 y;
+  gdv_int32 m;  // 1..12
+  gdv_int32 d;  // 1..31
+};
+GDV_DEV gdv_ymd gdv_civil_from_days(gdv_int64 z) {
+  z += 719468;
+  const gdv_int64 era = (z >= 0 ? z : z - 146096) / 146097;
+  const gdv_uint32 doe = (gdv_uint32)(z - era * 146097);
+  const gdv_uint32 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const gdv_int64 y = (gdv_int64)yoe + era * 400;
+  const gdv_uint32 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const gdv_uint32 mp = (5 * doy + 2) / 153;
+  const gdv_uint32 d = doy - (153 * mp + 2) / 5 + 1;
+  const gdv_uint32 m = mp < 10 ? mp + 3 : mp - 9;
+  gdv_ymd r;
+  r.y = y + (m <= 2);
+  r.m = (gdv_int32)m;
+  r.d = (gdv_int32)d;
+  return r;
+}
+GDV_DEV gdv_int64 gdv_days_from_civil(gdv_int64 y, gdv_int32 m, gdv_int32 d) {
+  y -= m <= 2;
+  const gdv_int64 era = (y >= 0 ? y : y - 399) / 400;
+  const gdv_uint32 yoe = (gdv_uint32)(y - era * 400);
+  const gdv_uint32 doy = (153 * (m > 2 ? m - 3 : m + 9) + 2) / 5 + d - 1;
+  const gdv_uint32 doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + (gdv_int64)doe - 719468;
+}
+GDV_DEV bool gdv_is_leap(gdv_int64 y) { return (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0); }
+GDV_DEV gdv_int32 gdv_last_day_of_month(gdv_int64 y, gdv_int32 m) {
+  const gdv_int32 t[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  return (m == 2 && gdv_is_leap(y)) ? 29 : t[m - 1];
+}
+
+#define GDV_EXTRACT(T, TO_MILLIS)                                                                 \
+  GDV_DEV gdv_int64 extractYear_##T(gdv_##T v) {                                                  \
+    return gdv_civil_from_days(gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY)).y;                 \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractMonth_##T(gdv_##T v) {                                                 \
+    return gdv_civil_from_days(gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY)).m;                 \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractDay_##T(gdv_##T v) {                                                   \
+    return gdv_civil_from_days(gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY)).d;                 \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractQuarter_##T(gdv_##T v) { return (extractMonth_##T(v) - 1) / 3 + 1; }   \
+  GDV_DEV gdv_int64 extractDoy_##T(gdv_##T v) {                                                   \
+    gdv_int64 days = gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY);                              \
+    return days - gdv_days_from_civil(gdv_civil_from_days(days).y, 1, 1) + 1;                     \
+  }                                                                                               \
+  /* 1 = Sunday … 7 = Saturday */                                                                 \
+  GDV_DEV gdv_int64 extractDow_##T(gdv_##T v) {                                                   \
+    gdv_int64 days = gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY);                              \
+    return gdv_floor_mod(days + 4, 7) + 1;                                                        \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractHour_##T(gdv_##T v) {                                                  \
+    return gdv_floor_mod(TO_MILLIS(v), GDV_MILLIS_IN_DAY) / 3600000LL;                            \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractMinute_##T(gdv_##T v) {                                                \
+    return (gdv_floor_mod(TO_MILLIS(v), GDV_MILLIS_IN_DAY) / 60000LL) % 60;                       \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractSecond_##T(gdv_##T v) {                                                \
+    return (gdv_floor_mod(TO_MILLIS(v), GDV_MILLIS_IN_DAY) / 1000LL) % 60;                        \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractEpoch_##T(gdv_##T v) { return gdv_floor_div(TO_MILLIS(v), 1000LL); }   \
+  GDV_DEV gdv_int64 extractDecade_##T(gdv_##T v) { return extractYear_##T(v) / 10; }              \
+  GDV_DEV gdv_int64 extractCentury_##T(gdv_##T v) { return (extractYear_##T(v) - 1) / 100 + 1; }  \
+  GDV_DEV gdv_int64 extractMillennium_##T(gdv_##T v) {                                            \
+    return (extractYear_##T(v) - 1) / 1000 + 1;                                                   \
+  }
+#define GDV_MS_IDENT(v) ((gdv_int64)(v))
+#define GDV_MS_FROM_DAYS(v) ((gdv_int64)(v) * GDV_MILLIS_IN_DAY)
+GDV_EXTRACT(date64, GDV_MS_IDENT)
+GDV_EXTRACT(timestamp, GDV_MS_IDENT)
+GDV_EXTRACT(date32, GDV_MS_FROM_DAYS)
+
+GDV_DEV gdv_int64 extractHour_time32(gdv_time32 v) { return (gdv_int64)v / 3600000; }
+GDV_DEV gdv_int64 extractMinute_time32(gdv_time32 v) { return ((gdv_int64)v / 60000) % 60; }
+GDV_DEV gdv_int64 extractSecond_time32(gdv_time32 v) { return ((gdv_int64)v / 1000) % 60; }
+
+// Month arithmetic clamps the day to the last day of the target month.
+GDV_DEV gdv_int64 gdv_add_months_ms(gdv_int64 millis, gdv_int64 months) {
+  gdv_int64 days = gdv_floor_div(millis, GDV_MILLIS_IN_DAY);
+  gdv_int64 tod = millis - days * GDV_MILLIS_IN_DAY;
+  gdv_ymd c = gdv_civil_from_days(days);
+  gdv_int64 total = c.y * 12 + (c.m - 1) + months;
+  gdv_int64 ny = gdv_floor_div(total, 12);
+  gdv_int32 nm = (gdv_int32)(total - ny * 12) + 1;
+  gdv_int32 last = gdv_last_day_of_month(ny, nm);
+  gdv_int32 nd = c.d > last ? last : c.d;
+  return gdv_days_from_civil(ny, nm, nd) * GDV_MILLIS_IN_DAY + tod;
+}
+
+#define GDV_TSADD(T)                                                                              \
+  GDV_DEV gdv_##T timestampaddSecond_int64_##T(gdv_int64 c, gdv_##T v) { return v + c * 1000LL; } \
+  GDV_DEV gdv_##T timestampaddMinute_int64_##T(gdv_int64 c, gdv_##T v) { return v + c * 60000LL; }\
+  GDV_DEV gdv_##T timestampaddHour_int64_##T(gdv_int64 c, gdv_##T v) { return v + c * 3600000LL; }\
+  GDV_DEV gdv_##T timestampaddDay_int64_##T(gdv_int64 c, gdv_##T v) {                             \
+    return v + c * GDV_MILLIS_IN_DAY;                                                             \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddWeek_int64_##T(gdv_int64 c, gdv_##T v) {                            \
+    return v + c * 7 * GDV_MILLIS_IN_DAY;                                                         \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddMonth_int64_##T(gdv_int64 c, gdv_##T v) {                           \
+    return gdv_add_months_ms(v, c);                                                               \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddQuarter_int64_##T(gdv_int64 c, gdv_##T v) {                         \
+    return gdv_add_months_ms(v, c * 3);                                                           \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddYear_int64_##T(gdv_int64 c, gdv_##T v) {                            \
+    return gdv_add_months_ms(v, c * 12);                                                          \
+  }                                                                                               \
+  GDV_DEV gdv_##T date_add_##T##_int64(gdv_##T v, gdv_int64 c) { return v + c * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_sub_##T##_int64(gdv_##T v, gdv_int64 c) { return v - c * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_add_##T##_int32(gdv_##T v, gdv_int32 c) { return v + c * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_sub_##T##_int32(gdv_##T v, gdv_int32 c) { return v - c * GDV_MILLIS_IN_DAY; }
+GDV_TSADD(date64)
+GDV_TSADD(timestamp)
+
+// Differences.  timestampdiff<Unit>(start, end) = whole units from start to end, truncated
+// toward zero; datediff(end, start) = calendar days (Hive semantics).
+#define GDV_TSDIFF(T)                                                                             \
+  GDV_DEV gdv_int32 timestampdiffSecond_##T##_##T(gdv_##T s, gdv_##T e) {                         \
+    return (gdv_int32)((e - s) / 1000LL);                                                         \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffMinute_##T##_##T(gdv_##T s, gdv_##T e) {                         \
+    return (gdv_int32)((e - s) / 60000LL);                                                        \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffHour_##T##_##T(gdv_##T s, gdv_##T e) {                           \
+    return (gdv_int32)((e - s) / 3600000LL);                                                      \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffDay_##T##_##T(gdv_##T s, gdv_##T e) {                            \
+    return (gdv_int32)((e - s) / GDV_MILLIS_IN_DAY);                                              \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffWeek_##T##_##T(gdv_##T s, gdv_##T e) {                           \
+    return (gdv_int32)((e - s) / (7 * GDV_MILLIS_IN_DAY));                                        \
+  }                                                                                               \
+  GDV_DEV gdv_int32 datediff_##T##_##T(gdv_##T e, gdv_##T s) {                                    \
+    return (gdv_int32)(gdv_floor_div(e, GDV_MILLIS_IN_DAY) - gdv_floor_div(s, GDV_MILLIS_IN_DAY)); \
+  }
+GDV_TSDIFF(date64)
+GDV_TSDIFF(timestamp)
+GDV_DEV gdv_int32 datediff_date32_date32(gdv_date32 e, gdv_date32 s) {
+  return (gdv_int32)((gdv_uint32)e - (gdv_uint32)s);
+}
+GDV_DEV gdv_date64 castDATE_date32(gdv_date32 d) { return (gdv_int64)d * GDV_MILLIS_IN_DAY; }
+GDV_DEV gdv_date32 castDATE32_date64(gdv_date64 d) {
+  return (gdv_date32)gdv_floor_div(d, GDV_MILLIS_IN_DAY);
+}
+GDV_DEV gdv_date64 castDATE_timestamp(gdv_timestamp t) {
+  return gdv_floor_div(t, GDV_MILLIS_IN_DAY) * GDV_MILLIS_IN_DAY;
+}

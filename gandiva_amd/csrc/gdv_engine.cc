@@ -1,0 +1,456 @@
+#include "gdv_engine.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <list>
+#include <unordered_map>
+
+#include "gdv_kernels.h"
+
+namespace gdv {
+
+namespace {
+
+// ------------------------------------------------------------------ LRU cache of built modules
+// (the reference keeps a process-wide, mutex-guarded LRU of compiled modules keyed on
+// schema + expressions + configuration: SURVEY.md §2 row 12)
+template <typename T>
+class LruCache {
+ public:
+  explicit LruCache(size_t cap) : cap_(cap) {}
+  std::shared_ptr<T> Get(const std::string& key) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = map_.find(key);
+    if (it == map_.end()) return nullptr;
+    order_.splice(order_.begin(), order_, it->second.second);
+    return it->second.first;
+  }
+  void Put(const std::string& key, std::shared_ptr<T> v) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (map_.count(key)) return;
+    order_.push_front(key);
+    map_[key] = {std::move(v), order_.begin()};
+    if (map_.size() > cap_) {
+      map_.erase(order_.back());
+      order_.pop_back();
+    }
+  }
+
+ private:
+  size_t cap_;
+  std::mutex mu_;
+  std::list<std::string> order_;
+  std::unordered_map<std::string,
+                     std::pair<std::shared_ptr<T>, std::list<std::string>::iterator>>
+      map_;
+};
+
+std::string SchemaKey(const Schema& s) {
+  std::string k;
+  for (auto& f : s) k += f.name + ":" + f.type.ToString() + ";";
+  return k;
+}
+
+// ------------------------------------------------------------------ argument block
+
+struct HostBitmap {
+  const uint64_t* p = nullptr;
+  int32_t shift = 0;
+  int32_t pad = 0;
+  int64_t nwords = 0;
+};
+static_assert(sizeof(HostBitmap) == 24, "must match struct gdv_bitmap in gdv_device_lib.hpp");
+
+class ArgBlock {
+ public:
+  explicit ArgBlock(const ArgLayout& l) : layout_(l), buf_(l.total(), 0) {}
+  void Set64(int off, uint64_t v) { std::memcpy(&buf_[off], &v, 8); }
+  void SetPtr(int off, const void* p) { Set64(off, reinterpret_cast<uint64_t>(p)); }
+  void SetInData(int k, const void* p) { SetPtr(layout_.in_base() + k * ArgLayout::kInStride, p); }
+  void SetInValid(int k, const HostBitmap& b) {
+    std::memcpy(&buf_[layout_.in_base() + k * ArgLayout::kInStride + 8], &b, 24);
+  }
+  void SetInBits(int k, const HostBitmap& b) {
+    std::memcpy(&buf_[layout_.in_base() + k * ArgLayout::kInStride + 32], &b, 24);
+  }
+  void SetInOffsets(int k, const void* p) {
+    SetPtr(layout_.in_base() + k * ArgLayout::kInStride + 56, p);
+  }
+  void SetOutData(int e, void* p) { SetPtr(layout_.out_base() + e * ArgLayout::kOutStride, p); }
+  void SetOutValid(int e, void* p) {
+    SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 8, p);
+  }
+  const void* data() const { return buf_.data(); }
+  size_t size() const { return buf_.size(); }
+
+ private:
+  ArgLayout layout_;
+  std::vector<char> buf_;
+};
+
+// Folds buffer misalignment and the Arrow array offset into (8-byte aligned word pointer,
+// shift < 64, readable words).  The buffer must be readable up to the next 8-byte boundary
+// (Arrow pads buffers to 64 bytes: pyarrow/include/arrow/type_fwd.h:759).
+HostBitmap FoldBitmap(const void* ptr, int64_t size, int64_t bit_offset) {
+  HostBitmap b;
+  if (ptr == nullptr) return b;
+  uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  uintptr_t aligned = a & ~uintptr_t(7);
+  int64_t lead = static_cast<int64_t>(a & 7) * 8 + bit_offset;
+  uintptr_t p = aligned + static_cast<uintptr_t>(lead >> 6) * 8;
+  b.p = reinterpret_cast<const uint64_t*>(p);
+  b.shift = static_cast<int32_t>(lead & 63);
+  int64_t bytes = static_cast<int64_t>(a + size - p);
+  b.nwords = bytes > 0 ? (bytes + 7) / 8 : 0;
+  return b;
+}
+
+int64_t BytesForBits(int64_t bits) { return (bits + 7) / 8; }
+
+struct Staging {
+  std::deque<DeviceBuffer> buffers;  // deque: references stay valid across Add()
+  DeviceBuffer& Add() {
+    buffers.emplace_back();
+    return buffers.back();
+  }
+};
+
+// host bitmap bytes covering bits [off, off+rows) -> zero-padded device words
+Status StageBitmap(const void* host, int64_t off, int64_t rows, hipStream_t stream,
+                   Staging* st, HostBitmap* out) {
+  const int64_t first = off / 8;
+  const int64_t len = BytesForBits(off + rows) - first;
+  const int64_t words = (len + 7) / 8 + 1;
+  DeviceBuffer& d = st->Add();
+  GDV_RETURN_NOT_OK(d.Allocate(words * 8));
+  GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(d.get(), 0, words * 8, stream));
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(d.get(), static_cast<const char*>(host) + first, len,
+                                       hipMemcpyHostToDevice, stream));
+  out->p = d.as<uint64_t>();
+  out->shift = static_cast<int32_t>(off % 8);
+  out->nwords = words;
+  return Status::OK();
+}
+
+Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuffers* cols,
+                  int num_cols, int64_t num_rows, MemKind mem, hipStream_t stream,
+                  ArgBlock* args, Staging* st) {
+  if (num_cols != static_cast<int>(schema.size()))
+    return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
+                           ") does not match the schema (" + std::to_string(schema.size()) + ")");
+  for (size_t k = 0; k < plan.input_fields.size(); k++) {
+    const int idx = plan.input_fields[k];
+    const ColumnBuffers& c = cols[idx];
+    const DataType& t = schema[idx].type;
+    const std::string& name = schema[idx].name;
+    if (plan.input_needs_values[k]) {
+      if (c.data == nullptr && num_rows > 0)
+        return Status::Invalid("column '" + name + "' has no data buffer");
+      if (t.id == kBool) {
+        if (c.data_size < BytesForBits(c.offset + num_rows))
+          return Status::Invalid("column '" + name + "': data buffer too small");
+        HostBitmap b;
+        if (mem == MemKind::kHost) {
+          GDV_RETURN_NOT_OK(StageBitmap(c.data, c.offset, num_rows, stream, st, &b));
+        } else {
+          b = FoldBitmap(c.data, c.data_size, c.offset);
+        }
+        args->SetInBits(static_cast<int>(k), b);
+      } else {
+        const int w = t.byte_width();
+        if (c.data_size < (c.offset + num_rows) * w)
+          return Status::Invalid("column '" + name + "': data buffer too small (" +
+                                 std::to_string(c.data_size) + " bytes for " +
+                                 std::to_string(c.offset + num_rows) + " rows)");
+        const char* src = static_cast<const char*>(c.data) + c.offset * w;
+        if (mem == MemKind::kHost) {
+          DeviceBuffer& d = st->Add();
+          GDV_RETURN_NOT_OK(d.Allocate(num_rows * w));
+          GDV_HIP_RETURN_NOT_OK(
+              hipMemcpyAsync(d.get(), src, num_rows * w, hipMemcpyHostToDevice, stream));
+          args->SetInData(static_cast<int>(k), d.get());
+        } else {
+          args->SetInData(static_cast<int>(k), src);
+        }
+      }
+    }
+    if (plan.input_needs_validity[k] && c.validity != nullptr) {
+      if (c.validity_size < BytesForBits(c.offset + num_rows))
+        return Status::Invalid("column '" + name + "': validity buffer too small");
+      HostBitmap b;
+      if (mem == MemKind::kHost) {
+        GDV_RETURN_NOT_OK(StageBitmap(c.validity, c.offset, num_rows, stream, st, &b));
+      } else {
+        b = FoldBitmap(c.validity, c.validity_size, c.offset);
+      }
+      args->SetInValid(static_cast<int>(k), b);
+    }
+  }
+  return Status::OK();
+}
+
+int64_t GridFor(const KernelPlan& plan, int64_t rows) {
+  const int64_t nwords = (rows + 63) / 64;
+  const int64_t per_tile = static_cast<int64_t>(plan.opts.subtiles) * plan.opts.waves;
+  int64_t ntiles = (nwords + per_tile - 1) / per_tile;
+  int blocks_per_cu = std::max(1, 32 / plan.opts.waves);
+  if (const char* s = std::getenv("GDV_GRID_MULT")) blocks_per_cu = std::max(1, atoi(s));
+  int64_t cap = static_cast<int64_t>(Runtime::Get().num_cus()) * blocks_per_cu;
+  return std::max<int64_t>(1, std::min(ntiles, cap));
+}
+
+std::string ErrorMessage(uint32_t bits) {
+  std::string m;
+  if (bits & 1u) m += "divide by zero error";
+  if (bits & 2u) m += (m.empty() ? "" : "; ") + std::string("overflow");
+  if (bits & 4u) m += (m.empty() ? "" : "; ") + std::string("invalid argument");
+  return m.empty() ? "execution error" : m;
+}
+
+LruCache<Projector>& ProjectorCache() {
+  static LruCache<Projector> c(500);
+  return c;
+}
+LruCache<Filter>& FilterCache() {
+  static LruCache<Filter> c(500);
+  return c;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ Projector
+
+Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                       SelectionMode mode, const Configuration& config,
+                       std::shared_ptr<Projector>* out) {
+  if (out == nullptr) return Status::Invalid("Projector::Make: null output pointer");
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  CodegenOptions opts = CodegenOptions::FromEnv();
+  std::string key = "P|" + SchemaKey(schema) + "|";
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    key += e->ToString() + "->" + e->result().type.ToString() + ";";
+  }
+  key += "|m" + std::to_string(static_cast<int>(mode)) + "|" + opts.Key() +
+         (config.optimize ? "|O" : "|o");
+  if (auto hit = ProjectorCache().Get(key)) {
+    *out = hit;
+    return Status::OK();
+  }
+  auto p = std::make_shared<Projector>();
+  p->schema_ = schema;
+  GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, opts, &p->plan_));
+  GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.source, p->plan_.kernel_name, &p->kernel_));
+  ProjectorCache().Put(key, p);
+  *out = p;
+  return Status::OK();
+}
+
+Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
+                           const SelectionView* sel, OutputBuffers* outs, int num_outs,
+                           MemKind mem, hipStream_t stream, uint32_t flags) const {
+  if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (outs == nullptr) return Status::Invalid("Output array vector cannot be null");
+  if (num_outs != num_outputs())
+    return Status::Invalid("number of output buffers (" + std::to_string(num_outs) +
+                           ") does not match the number of expressions (" +
+                           std::to_string(num_outputs()) + ")");
+  const bool has_sel = sel != nullptr && sel->mode != SelectionMode::kNone;
+  if (has_sel != (plan_.mode != SelectionMode::kNone) || (has_sel && sel->mode != plan_.mode))
+    return Status::Invalid("selection vector type does not match the mode the projector was built for");
+  const int64_t out_rows = has_sel ? sel->num_slots : num_rows;
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+
+  ArgBlock args(plan_.layout);
+  Staging st;
+  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
+
+  if (has_sel) {
+    const int w = plan_.mode == SelectionMode::kUInt16 ? 2 : plan_.mode == SelectionMode::kUInt32 ? 4 : 8;
+    if (out_rows > 0 && sel->indices == nullptr) return Status::Invalid("selection vector has no buffer");
+    if (mem == MemKind::kHost) {
+      DeviceBuffer& d = st.Add();
+      GDV_RETURN_NOT_OK(d.Allocate(std::max<int64_t>(out_rows, 1) * w));
+      if (out_rows > 0)
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(d.get(), sel->indices, out_rows * w,
+                                             hipMemcpyHostToDevice, stream));
+      args.SetPtr(ArgLayout::kOffSel, d.get());
+    } else {
+      args.SetPtr(ArgLayout::kOffSel, sel->indices);
+    }
+  }
+
+  // outputs
+  std::vector<void*> dev_data(num_outs), dev_valid(num_outs);
+  for (int e = 0; e < num_outs; e++) {
+    const DataType& t = plan_.output_types[e];
+    const int64_t need_valid_dev = ValidityBytes(out_rows);
+    const int64_t need_data_dev = DataBytes(t, out_rows);
+    if (mem == MemKind::kHost) {
+      const int64_t need_data_host = t.id == kBool ? BytesForBits(out_rows) : need_data_dev;
+      if (outs[e].validity_size < BytesForBits(out_rows) || outs[e].data_size < need_data_host ||
+          (out_rows > 0 && (outs[e].validity == nullptr || outs[e].data == nullptr)))
+        return Status::Invalid("output buffer " + std::to_string(e) + " too small");
+      DeviceBuffer& dv = st.Add();
+      GDV_RETURN_NOT_OK(dv.Allocate(std::max<int64_t>(need_valid_dev, 8)));
+      DeviceBuffer& dd = st.Add();
+      GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(need_data_dev, 8)));
+      dev_valid[e] = dv.get();
+      dev_data[e] = dd.get();
+    } else {
+      if (outs[e].validity_size < need_valid_dev || outs[e].data_size < need_data_dev)
+        return Status::Invalid("output buffer " + std::to_string(e) +
+                               " too small (device buffers need 8-byte word granularity: " +
+                               std::to_string(need_valid_dev) + " validity bytes, " +
+                               std::to_string(need_data_dev) + " data bytes)");
+      dev_valid[e] = outs[e].validity;
+      dev_data[e] = outs[e].data;
+    }
+    args.SetOutData(e, dev_data[e]);
+    args.SetOutValid(e, dev_valid[e]);
+  }
+
+  DeviceBuffer err;
+  if (plan_.can_raise) {
+    GDV_RETURN_NOT_OK(err.Allocate(8));
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+    args.SetPtr(ArgLayout::kOffErr, err.get());
+  }
+
+  if (out_rows > 0) {
+    GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, out_rows), plan_.opts.waves * 64,
+                                args.data(), args.size(), stream));
+  }
+
+  uint32_t err_bits = 0;
+  if (plan_.can_raise)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+  if (mem == MemKind::kHost) {
+    for (int e = 0; e < num_outs; e++) {
+      const DataType& t = plan_.output_types[e];
+      const int64_t vbytes = BytesForBits(out_rows);
+      const int64_t dbytes = t.id == kBool ? vbytes : DataBytes(t, out_rows);
+      if (out_rows == 0) continue;
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].validity, dev_valid[e], vbytes,
+                                           hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(
+          hipMemcpyAsync(outs[e].data, dev_data[e], dbytes, hipMemcpyDeviceToHost, stream));
+    }
+  }
+  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync);
+  if (must_sync) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ Filter
+
+Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
+                    const Configuration& config, std::shared_ptr<Filter>* out) {
+  if (out == nullptr) return Status::Invalid("Filter::Make: null output pointer");
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  CodegenOptions opts = CodegenOptions::FromEnv();
+  std::string key = "F|" + SchemaKey(schema) + "|" + condition->ToString() + "|" + opts.Key() +
+                    (config.optimize ? "|O" : "|o");
+  if (auto hit = FilterCache().Get(key)) {
+    *out = hit;
+    return Status::OK();
+  }
+  auto f = std::make_shared<Filter>();
+  f->schema_ = schema;
+  GDV_RETURN_NOT_OK(PlanFilter(schema, condition, opts, &f->plan_));
+  GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(f->plan_.source, f->plan_.kernel_name, &f->kernel_));
+  FilterCache().Put(key, f);
+  *out = f;
+  return Status::OK();
+}
+
+Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
+                        SelectionMode mode, void* out_indices, int64_t max_slots,
+                        int64_t* num_selected, MemKind mem, hipStream_t stream) const {
+  if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (out_indices == nullptr || num_selected == nullptr)
+    return Status::Invalid("Selection vector cannot be null");
+  if (mode == SelectionMode::kNone) return Status::Invalid("Selection vector type cannot be NONE");
+  if (max_slots < num_rows)
+    return Status::Invalid("Selection vector too small: max slots " + std::to_string(max_slots) +
+                           " < rows " + std::to_string(num_rows));
+  const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
+  if (w == 2 && num_rows > 65536)
+    return Status::Invalid("uint16 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  if (w == 4 && num_rows > (int64_t(1) << 32))
+    return Status::Invalid("uint32 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+
+  ArgBlock args(plan_.layout);
+  Staging st;
+  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
+
+  const int64_t nwords = (num_rows + 63) / 64;
+  const int64_t m = (nwords + plan_.opts.subtiles - 1) / plan_.opts.subtiles;  // wave tiles
+  DeviceBuffer mask, counts, offsets, chunk_sums, total, err;
+  GDV_RETURN_NOT_OK(mask.Allocate(nwords * 8));
+  GDV_RETURN_NOT_OK(counts.Allocate(m * 4 + 64));
+  GDV_RETURN_NOT_OK(offsets.Allocate(m * 8));
+  GDV_RETURN_NOT_OK(chunk_sums.Allocate(ScanChunks(m) * 8));
+  GDV_RETURN_NOT_OK(total.Allocate(8));
+  args.SetPtr(ArgLayout::kOffMask, mask.get());
+  args.SetPtr(ArgLayout::kOffCounts, counts.get());
+  if (plan_.can_raise) {
+    GDV_RETURN_NOT_OK(err.Allocate(8));
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+    args.SetPtr(ArgLayout::kOffErr, err.get());
+  }
+
+  GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, num_rows), plan_.opts.waves * 64,
+                              args.data(), args.size(), stream));
+  GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>(), m, chunk_sums.as<uint64_t>(),
+                                          offsets.as<uint64_t>(), total.as<uint64_t>(), stream));
+  void* dev_out = out_indices;
+  DeviceBuffer staged_out;
+  if (mem == MemKind::kHost) {
+    GDV_RETURN_NOT_OK(staged_out.Allocate(num_rows * w));
+    dev_out = staged_out.get();
+  }
+  GDV_HIP_RETURN_NOT_OK(LaunchEmitIndices(mask.as<uint64_t>(), offsets.as<uint64_t>(), nwords,
+                                          plan_.opts.subtiles, 0, w, dev_out, rt.num_cus(),
+                                          stream));
+  uint64_t count = 0;
+  uint32_t err_bits = 0;
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&count, total.get(), 8, hipMemcpyDeviceToHost, stream));
+  if (plan_.can_raise)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+  GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  if (mem == MemKind::kHost && count > 0) {
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(out_indices, dev_out, count * w, hipMemcpyDeviceToHost, stream));
+    GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  }
+  *num_selected = static_cast<int64_t>(count);
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ precompile (no device)
+
+Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                           SelectionMode mode) {
+  KernelPlan plan;
+  GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));
+  std::vector<char> code;
+  return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
+}
+
+Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition) {
+  KernelPlan plan;
+  GDV_RETURN_NOT_OK(PlanFilter(schema, condition, CodegenOptions::FromEnv(), &plan));
+  std::vector<char> code;
+  return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
+}
+
+}  // namespace gdv

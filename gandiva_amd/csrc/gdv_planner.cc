@@ -1,0 +1,747 @@
+#include "gdv_planner.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <sstream>
+
+namespace gdv {
+
+// ------------------------------------------------------------------ options
+
+CodegenOptions CodegenOptions::FromEnv() {
+  CodegenOptions o;
+  if (const char* s = std::getenv("GDV_U")) o.subtiles = std::max(1, std::min(16, atoi(s)));
+  if (const char* s = std::getenv("GDV_WAVES")) o.waves = std::max(1, std::min(16, atoi(s)));
+  if (const char* s = std::getenv("GDV_NT")) o.nontemporal = atoi(s) != 0;
+  return o;
+}
+
+std::string CodegenOptions::Key() const {
+  return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "");
+}
+
+// ------------------------------------------------------------------ validation
+
+namespace {
+
+Status ValidateNode(const Schema& schema, const Node& node);
+
+Status ValidateField(const Schema& schema, const FieldNode& n) {
+  for (auto& f : schema) {
+    if (f.name == n.field().name) {
+      if (f.type != n.field().type) {
+        return Status::ValidationError("Field definition in schema " + f.name + ": " +
+                                       f.type.ToString() + " different from field in expression " +
+                                       n.field().name + ": " + n.field().type.ToString());
+      }
+      return Status::OK();
+    }
+  }
+  return Status::ValidationError("Field " + n.field().name + " not in schema.");
+}
+
+bool ResolveFunction(const FunctionNode& n, const FunctionDef** def, DataType* ret) {
+  std::vector<DataType> params;
+  for (auto& c : n.children()) params.push_back(c->return_type());
+  const FunctionDef* d = FunctionRegistry::Get().Lookup(n.name(), params);
+  if (d == nullptr) return false;
+  *def = d;
+  *ret = d->ret;
+  if (d->flags & kDecimalResult) {
+    DecimalOp op = DecimalOp::kAdd;
+    if (n.name() == "subtract") op = DecimalOp::kSubtract;
+    else if (n.name() == "multiply") op = DecimalOp::kMultiply;
+    else if (n.name() == "divide") op = DecimalOp::kDivide;
+    else if (n.name() == "mod") op = DecimalOp::kMod;
+    *ret = DecimalResultType(op, params[0], params[1]);
+  }
+  return true;
+}
+
+Status ValidateFunction(const Schema& schema, const FunctionNode& n) {
+  for (auto& c : n.children()) GDV_RETURN_NOT_OK(ValidateNode(schema, *c));
+  const FunctionDef* def = nullptr;
+  DataType ret;
+  if (!ResolveFunction(n, &def, &ret)) {
+    return Status::ValidationError("Function " + n.ToString() + " not supported yet. ");
+  }
+  if (ret != n.return_type()) {
+    // decimal results declared by the caller win when only precision/scale differ
+    if (!(ret.id == kDecimal128 && n.return_type().id == kDecimal128 &&
+          !(def->flags & kDecimalResult))) {
+      return Status::ValidationError("Function " + n.name() + " returns " + ret.ToString() +
+                                     " but the expression declares " +
+                                     n.return_type().ToString());
+    }
+  }
+  if (def->flags & kPatternArg) {
+    if (n.children().back()->kind() != NodeKind::kLiteral) {
+      return Status::ValidationError("'" + n.name() + "' function requires a literal as the last parameter");
+    }
+  }
+  return Status::OK();
+}
+
+Status ValidateNode(const Schema& schema, const Node& node) {
+  switch (node.kind()) {
+    case NodeKind::kField:
+      return ValidateField(schema, static_cast<const FieldNode&>(node));
+    case NodeKind::kLiteral:
+      return Status::OK();
+    case NodeKind::kFunction:
+      return ValidateFunction(schema, static_cast<const FunctionNode&>(node));
+    case NodeKind::kIf: {
+      auto& n = static_cast<const IfNode&>(node);
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.condition()));
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.then_node()));
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.else_node()));
+      if (n.condition()->return_type().id != kBool)
+        return Status::ValidationError("condition must be of boolean type, found type " +
+                                       n.condition()->return_type().ToString());
+      if (n.then_node()->return_type() != n.return_type())
+        return Status::ValidationError("return type of if " + n.return_type().ToString() +
+                                       " and then " + n.then_node()->return_type().ToString() +
+                                       " not matching.");
+      if (n.else_node()->return_type() != n.return_type())
+        return Status::ValidationError("return type of if " + n.return_type().ToString() +
+                                       " and else " + n.else_node()->return_type().ToString() +
+                                       " not matching.");
+      return Status::OK();
+    }
+    case NodeKind::kBoolean: {
+      auto& n = static_cast<const BooleanNode&>(node);
+      if (n.children().size() < 2)
+        return Status::ValidationError("Boolean expression has " +
+                                       std::to_string(n.children().size()) +
+                                       " children, expected atleast two");
+      for (auto& c : n.children()) {
+        GDV_RETURN_NOT_OK(ValidateNode(schema, *c));
+        if (c->return_type().id != kBool)
+          return Status::ValidationError("Boolean expression has a child with return type " +
+                                         c->return_type().ToString() + ", expected return type boolean");
+      }
+      return Status::OK();
+    }
+    case NodeKind::kIn: {
+      auto& n = static_cast<const InNode&>(node);
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.eval()));
+      if (n.eval()->return_type() != n.value_type())
+        // message fragment pinned by test_gandiva.py:160-161
+        return Status::ValidationError("Evaluation expression for IN clause returns " +
+                                       n.eval()->return_type().ToString() +
+                                       " values are of type" + n.value_type().ToString());
+      return Status::OK();
+    }
+  }
+  return Status::OK();
+}
+
+}  // namespace
+
+Status ValidateExpression(const Schema& schema, const Expression& expr) {
+  if (!expr.root()) return Status::ValidationError("Root node cannot be null");
+  GDV_RETURN_NOT_OK(ValidateNode(schema, *expr.root()));
+  if (expr.root()->return_type() != expr.result().type) {
+    return Status::ValidationError("Return type of root node " +
+                                   expr.root()->return_type().ToString() +
+                                   " does not match that of expression " +
+                                   expr.result().type.ToString());
+  }
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ code generation
+
+namespace {
+
+std::string Hex64(uint64_t v) {
+  char buf[32];
+  snprintf(buf, sizeof(buf), "0x%llxull", static_cast<unsigned long long>(v));
+  return buf;
+}
+
+uint64_t Fnv1a(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+std::string LiteralExpr(const DataType& t, const Literal& v) {
+  switch (t.id) {
+    case kBool: return v.lo ? "true" : "false";
+    case kFloat: return "__uint_as_float(" + Hex64(v.lo & 0xffffffffull) + ")";
+    case kDouble: return "__longlong_as_double((long long)" + Hex64(v.lo) + ")";
+    case kDecimal128:
+      return "gdv_make_int128(" + Hex64(v.hi) + ", " + Hex64(v.lo) + ")";
+    default: {
+      uint64_t mask = t.byte_width() >= 8 ? ~0ull : ((1ull << (8 * t.byte_width())) - 1);
+      return "((" + t.CType() + ")" + Hex64(v.lo & mask) + ")";
+    }
+  }
+}
+
+// A value inside the generated row body: a C++ expression plus its validity, split the way
+// the reference's ValueValidityPair splits it — the set of input columns whose validity
+// words intersect, and an optional per-lane predicate for value-dependent validity
+// (if/else, SQL three-valued AND/OR, functions that produce nulls themselves).
+struct Val {
+  std::string v;
+  DataType type;
+  std::set<int> vcols;
+  std::string vlane;
+  bool never_null() const { return vcols.empty() && vlane.empty(); }
+};
+
+class CodeGen {
+ public:
+  CodeGen(const Schema& schema, SelectionMode mode, const CodegenOptions& opts)
+      : schema_(schema), sel_mode_(mode), opts_(opts) {}
+
+  bool selection() const { return sel_mode_ != SelectionMode::kNone; }
+
+  Status Gen(const Node& node, const std::string& active, Val* out);
+
+  // ---- emission helpers
+  std::string Tmp(const std::string& ctype, const std::string& rhs) {
+    std::string key = ctype + "|" + rhs;
+    auto it = cse_.find(key);
+    if (it != cse_.end()) return it->second;
+    std::string name = "t" + std::to_string(next_tmp_++);
+    body_ << "      const " << ctype << " " << name << " = " << rhs << ";\n";
+    cse_[key] = name;
+    return name;
+  }
+  void Stmt(const std::string& s) { body_ << "      " << s << "\n"; }
+
+  // conjunction of per-lane predicates; "" stands for "always true"
+  static std::string AndExpr(const std::string& a, const std::string& b) {
+    if (a.empty() || a == "true") return (b == "true") ? "" : b;
+    if (b.empty() || b == "true") return a;
+    return "(" + a + " && " + b + ")";
+  }
+
+  // per-lane validity of a value ("true" when it can never be null)
+  std::string LaneValid(const Val& val) {
+    std::string cols;
+    if (!val.vcols.empty()) {
+      if (selection()) {
+        for (int k : val.vcols) cols = AndExpr(cols, "b" + std::to_string(k) + "[u]");
+      } else {
+        cols = Tmp("bool", "gdv_lane_bit(" + WordExpr(val.vcols) + ", lane)");
+      }
+    }
+    std::string r = AndExpr(cols, val.vlane);
+    return r.empty() ? "true" : r;
+  }
+
+  // wave-uniform AND of the validity words of a set of input columns (row mode only)
+  std::string WordExpr(const std::set<int>& cols) {
+    if (cols.empty()) return "~0ull";
+    std::string s;
+    for (int k : cols) {
+      if (!s.empty()) s += " & ";
+      s += "v" + std::to_string(k);
+    }
+    if (cols.size() > 1) s = Tmp("gdv_uint64", s);
+    return s;
+  }
+
+  int SlotFor(const FieldNode& f, bool values, bool validity) {
+    int idx = -1;
+    for (size_t i = 0; i < schema_.size(); i++)
+      if (schema_[i].name == f.field().name) idx = static_cast<int>(i);
+    int slot;
+    auto it = slot_of_field_.find(idx);
+    if (it == slot_of_field_.end()) {
+      slot = static_cast<int>(input_fields_.size());
+      slot_of_field_[idx] = slot;
+      input_fields_.push_back(idx);
+      needs_values_.push_back(false);
+      needs_validity_.push_back(false);
+    } else {
+      slot = it->second;
+    }
+    if (values) needs_values_[slot] = true;
+    if (validity) needs_validity_[slot] = true;
+    return slot;
+  }
+
+  const Schema& schema_;
+  SelectionMode sel_mode_;
+  CodegenOptions opts_;
+  std::ostringstream body_;
+  std::map<std::string, std::string> cse_;
+  int next_tmp_ = 0;
+  std::map<int, int> slot_of_field_;
+  std::vector<int> input_fields_;
+  std::vector<bool> needs_values_, needs_validity_;
+  bool can_raise_ = false;
+  std::ostringstream prelude_;  // file-scope constants (IN tables, patterns)
+  int next_const_ = 0;
+};
+
+Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
+  switch (node.kind()) {
+    case NodeKind::kField: {
+      auto& f = static_cast<const FieldNode&>(node);
+      if (f.return_type().is_varlen() || f.return_type().is_decimal())
+        return Status::CodeGenError("type " + f.return_type().ToString() +
+                                    " is not supported by the HIP backend yet");
+      int slot = SlotFor(f, true, true);
+      out->type = f.return_type();
+      std::string k = std::to_string(slot);
+      if (f.return_type().id == kBool) {
+        out->v = selection() ? "x" + k + "[u]" : Tmp("bool", "gdv_lane_bit(d" + k + ", lane)");
+      } else {
+        out->v = "c" + k + "[u]";
+      }
+      out->vcols = {slot};
+      out->vlane.clear();
+      return Status::OK();
+    }
+    case NodeKind::kLiteral: {
+      auto& l = static_cast<const LiteralNode&>(node);
+      if (l.return_type().is_varlen())
+        return Status::CodeGenError("string literals are not supported in this position yet");
+      out->type = l.return_type();
+      out->v = LiteralExpr(l.return_type(), l.value());
+      out->vcols.clear();
+      out->vlane = l.is_null() ? "false" : "";
+      return Status::OK();
+    }
+    case NodeKind::kFunction: {
+      auto& fn = static_cast<const FunctionNode&>(node);
+      const FunctionDef* def = nullptr;
+      DataType ret;
+      if (!ResolveFunction(fn, &def, &ret))
+        return Status::CodeGenError("Function " + fn.ToString() + " not supported yet. ");
+      std::vector<Val> args(fn.children().size());
+      for (size_t i = 0; i < args.size(); i++)
+        GDV_RETURN_NOT_OK(Gen(*fn.children()[i], active, &args[i]));
+      out->type = fn.return_type();
+      out->vcols.clear();
+      out->vlane.clear();
+      const std::string ctype = out->type.CType();
+      std::string call = def->symbol + "(";
+      bool first = true;
+      auto push = [&](const std::string& a) {
+        if (!first) call += ", ";
+        call += a;
+        first = false;
+      };
+      if (def->flags & kNeedsContext) {
+        push("ctx");
+        can_raise_ = true;
+      }
+      if (def->policy == NullPolicy::kNullIfNull) {
+        std::string lanes;
+        for (auto& a : args) {
+          push(a.v);
+          out->vcols.insert(a.vcols.begin(), a.vcols.end());
+          lanes = AndExpr(lanes, a.vlane);
+        }
+        out->vlane = lanes;
+        call += ")";
+        if (def->flags & kNeedsContext) {
+          // Functions that can raise run only on rows where every argument is valid and
+          // the enclosing if/else / short-circuit path is live — otherwise a guarded
+          // `if (b != 0) a / b` would raise on the rows it guards against.
+          std::string guard = AndExpr(AndExpr("live", active), LaneValid(*out));
+          out->v = Tmp(ctype, guard + " ? " + call + " : (" + ctype + ")0");
+        } else {
+          out->v = Tmp(ctype, call);
+        }
+      } else if (def->policy == NullPolicy::kNullNever) {
+        for (auto& a : args) {
+          push(a.v);
+          push(LaneValid(a));
+        }
+        call += ")";
+        out->v = Tmp(ctype, call);
+      } else {
+        for (auto& a : args) {
+          push(a.v);
+          push(LaneValid(a));
+        }
+        std::string ov = "ov" + std::to_string(next_tmp_++);
+        Stmt("bool " + ov + " = false;");
+        push("&" + ov);
+        call += ")";
+        out->v = Tmp(ctype, call);
+        out->vlane = ov;
+      }
+      return Status::OK();
+    }
+    case NodeKind::kIf: {
+      auto& n = static_cast<const IfNode&>(node);
+      Val c, t, e;
+      GDV_RETURN_NOT_OK(Gen(*n.condition(), active, &c));
+      // a null condition selects the else branch
+      std::string take = Tmp("bool", AndExpr(LaneValid(c), c.v));
+      GDV_RETURN_NOT_OK(Gen(*n.then_node(), AndExpr(active, take), &t));
+      GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
+      out->type = n.return_type();
+      const std::string ctype = out->type.CType();
+      out->v = Tmp(ctype, take + " ? " + t.v + " : " + e.v);
+      out->vcols.clear();
+      if (t.never_null() && e.never_null()) {
+        out->vlane.clear();
+      } else {
+        out->vlane = Tmp("bool", take + " ? " + LaneValid(t) + " : " + LaneValid(e));
+      }
+      return Status::OK();
+    }
+    case NodeKind::kBoolean: {
+      // SQL three-valued logic with left-to-right short circuit:
+      //   AND: false if any child is (valid, false); else null if any child is null; else true
+      //   OR : true  if any child is (valid, true);  else null if any child is null; else false
+      auto& n = static_cast<const BooleanNode&>(node);
+      const bool is_and = n.op() == BooleanNode::kAnd;
+      std::string decided;    // some earlier child already fixed the result
+      std::string all_valid;  // every child so far valid
+      std::string live_path = active;
+      for (auto& child : n.children()) {
+        Val c;
+        GDV_RETURN_NOT_OK(Gen(*child, live_path, &c));
+        std::string cvalid = LaneValid(c);
+        std::string hit = AndExpr(cvalid, is_and ? "!" + c.v : c.v);
+        hit = Tmp("bool", hit);
+        decided = decided.empty() ? hit : Tmp("bool", "(" + decided + " || " + hit + ")");
+        all_valid = AndExpr(all_valid, cvalid);
+        live_path = AndExpr(active, "!" + decided);
+      }
+      out->type = boolean();
+      out->vcols.clear();
+      if (all_valid.empty() || all_valid == "true") {
+        out->vlane.clear();
+        out->v = Tmp("bool", is_and ? "!" + decided : decided);
+      } else {
+        std::string av = Tmp("bool", all_valid);
+        out->vlane = Tmp("bool", "(" + decided + " || " + av + ")");
+        // value bit under a null result is defined as false
+        out->v = Tmp("bool", is_and ? "(!" + decided + " && " + av + ")" : decided);
+      }
+      return Status::OK();
+    }
+    case NodeKind::kIn: {
+      auto& n = static_cast<const InNode&>(node);
+      if (n.value_type().is_varlen() || n.value_type().is_decimal())
+        return Status::CodeGenError("IN over " + n.value_type().ToString() +
+                                    " is not supported by the HIP backend yet");
+      Val x;
+      GDV_RETURN_NOT_OK(Gen(*n.eval(), active, &x));
+      out->type = boolean();
+      out->vcols = x.vcols;
+      out->vlane = x.vlane;
+      const std::string ctype = n.value_type().CType();
+      std::vector<uint64_t> vals;
+      uint64_t mask = n.value_type().byte_width() >= 8
+                          ? ~0ull
+                          : ((1ull << (8 * n.value_type().byte_width())) - 1);
+      for (auto& l : n.values()) vals.push_back(l.lo & mask);
+      std::sort(vals.begin(), vals.end());
+      vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+      if (vals.empty()) {
+        out->v = "false";
+      } else if (vals.size() <= 8) {
+        std::string e;
+        for (auto v : vals) {
+          if (!e.empty()) e += " || ";
+          e += "(gdv_bits64(" + x.v + ") == " + Hex64(v) + ")";
+        }
+        out->v = Tmp("bool", e);
+      } else {
+        // sorted constant table + branch-free binary search on the value's bit image
+        std::string name = "gdv_in_tab" + std::to_string(next_const_++);
+        prelude_ << "__constant__ gdv_uint64 " << name << "[" << vals.size() << "] = {";
+        for (size_t i = 0; i < vals.size(); i++) prelude_ << (i ? ", " : "") << Hex64(vals[i]);
+        prelude_ << "};\n";
+        out->v = Tmp("bool", "gdv_in_sorted(gdv_bits64(" + x.v + "), " + name + ", " +
+                                 std::to_string(vals.size()) + ")");
+      }
+      return Status::OK();
+    }
+  }
+  return Status::CodeGenError("unknown node kind");
+}
+
+// Assembles the translation unit around the generated row body.
+struct Assembler {
+  CodeGen& cg;
+  KernelPlan* plan;
+  std::ostringstream src;
+
+  void Header(const std::vector<std::string>& expr_strings) {
+    src << "// generated by gandiva_amd (gdv_planner.cc) — fused "
+        << (plan->kind == KernelKind::kFilter ? "filter" : "projection") << " kernel for gfx950\n";
+    for (size_t i = 0; i < expr_strings.size(); i++)
+      src << "// @expr_" << i << " = " << expr_strings[i] << "\n";
+    src << "#include \"gdv_device_lib.hpp\"\n";
+    src << "#define GDV_U " << plan->opts.subtiles << "\n";
+    src << "#define GDV_WAVES " << plan->opts.waves << "\n";
+    const int nin = std::max<int>(1, plan->input_fields.size());
+    const int nout = std::max<int>(1, plan->output_types.size());
+    src << "struct gdv_in_slot { const void* data; gdv_bitmap valid; gdv_bitmap bits; const gdv_int32* offsets; };\n";
+    src << "struct gdv_out_slot { void* data; gdv_uint64* valid; gdv_int32* offsets; };\n";
+    src << "struct gdv_args {\n"
+        << "  gdv_int64 n; gdv_uint32* err; const void* sel; gdv_uint64* mask; gdv_uint32* counts;\n"
+        << "  gdv_int64 aux0, aux1, aux2;\n"
+        << "  gdv_in_slot in[" << nin << "];\n"
+        << "  gdv_out_slot out[" << nout << "];\n"
+        << "};\n";
+    src << cg.prelude_.str();
+  }
+};
+
+std::string SelCType(SelectionMode m) {
+  switch (m) {
+    case SelectionMode::kUInt16: return "gdv_uint16";
+    case SelectionMode::kUInt32: return "gdv_uint32";
+    default: return "gdv_uint64";
+  }
+}
+
+// Output bitmap words are accumulated per wave tile: word u is deposited into lane u of an
+// accumulator register, so the tile's GDV_U words leave with one coalesced store.  Outputs
+// whose word expressions are textually identical share one accumulator.
+struct WordAccumulators {
+  std::map<std::string, std::string> by_expr;  // word expression -> accumulator name
+  std::vector<std::string> names;
+  std::string Get(CodeGen& cg, const std::string& word_expr) {
+    auto it = by_expr.find(word_expr);
+    if (it != by_expr.end()) return it->second;
+    std::string name = "acc" + std::to_string(names.size());
+    names.push_back(name);
+    by_expr[word_expr] = name;
+    cg.Stmt(name + " = gdv_deposit_word(" + name + ", u, " + word_expr + ", lane);");
+    return name;
+  }
+};
+
+std::string WordStore(const std::string& acc, const std::string& dst) {
+  return "  if (lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) " + dst +
+         "[wbase + lane] = " + acc + ";\n";
+}
+
+Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
+                const WordAccumulators& accs, const std::string& decls_before_loop,
+                const std::string& epilogue_after_loop) {
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = cg.can_raise_;
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+
+  Assembler as{cg, plan, {}};
+  as.Header(expr_strings);
+  std::ostringstream& s = as.src;
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
+
+  s << "template <bool FULL>\n"
+    << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane) {\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id != kBool && cg.needs_values_[k])
+      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType()
+        << "*)A.in[" << k << "].data;\n";
+  }
+  for (size_t e = 0; e < plan->output_types.size(); e++) {
+    const DataType& t = plan->output_types[e];
+    if (t.id != kBool)
+      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out["
+        << e << "].data;\n";
+  }
+  if (sel)
+    s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const "
+      << SelCType(cg.sel_mode_) << "*)A.sel;\n";
+
+  // ---- phase 1: every load of the tile, no control flow in between
+  s << "  // ---- phase 1: all loads of this wave's GDV_U sub-tiles, issued back to back\n";
+  if (sel) s << "  gdv_int64 srow[GDV_U];\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k]) {
+        if (sel) s << "  bool x" << k << "[GDV_U];\n";
+        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k
+               << "].bits, wbase, lane, GDV_U);\n";
+      }
+    } else if (cg.needs_values_[k]) {
+      s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
+    }
+    if (cg.needs_validity_[k]) {
+      if (sel) s << "  bool b" << k << "[GDV_U];\n";
+      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k
+             << "].valid, wbase, lane, GDV_U);\n";
+    }
+  }
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "    const bool live = FULL || row < n;\n"
+    << "    (void)live;\n";
+  if (sel) {
+    s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool) {
+        if (cg.needs_values_[k])
+          s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+      } else if (cg.needs_values_[k]) {
+        s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+      }
+      if (cg.needs_validity_[k])
+        s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+    }
+  } else {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id != kBool && cg.needs_values_[k])
+        s << "    c" << k << "[u] = live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0;\n";
+    }
+  }
+  s << "  }\n";
+
+  // ---- phase 2: row body
+  s << "  // ---- phase 2: fused expression bodies (value for every row, validity per word)\n";
+  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
+  s << decls_before_loop;
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    {\n"
+    << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "      const bool live = FULL || row < n;\n"
+    << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
+    << "      (void)livemask; (void)row;\n";
+  if (!sel) {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k])
+        s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
+      if (cg.needs_validity_[k])
+        s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+    }
+  }
+  s << cg.body_.str();
+  s << "    }\n  }\n";
+  s << epilogue_after_loop;
+  s << "}\n\n";
+  // ---- kernel: grid-stride over workgroup tiles; wave w of a workgroup owns GDV_U
+  // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
+  // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
+  // each bitmap.
+  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) " << "GDV_KERNEL_NAME"
+    << "(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
+    << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
+    << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
+    << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nfull;\n"
+    << "       wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
+    << "    gdv_tile<true>(A, wt * GDV_U, lane);\n"
+    // The single partial wave tile is handled after the loop, not in an if/else next to
+    // the full-tile body: side by side, the compiler hoists the two bodies' common bitmap
+    // loads above the branch and serialises them in front of the value loads.
+    << "  if (nwt > nfull && wave == (int)(nfull % GDV_WAVES) &&\n"
+    << "      blockIdx.x == (unsigned)((nfull / GDV_WAVES) % gridDim.x))\n"
+    << "    gdv_tile<false>(A, nfull * GDV_U, lane);\n"
+    << "}\n";
+
+  std::string text = s.str();
+  uint64_t h = Fnv1a(text);
+  char name[64];
+  snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+  plan->kernel_name = name;
+  size_t pos = text.find("GDV_KERNEL_NAME");
+  text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
+  plan->source = text;
+  plan->ir = text;
+  return Status::OK();
+}
+
+}  // namespace
+
+Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan) {
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+  }
+  plan->kind = KernelKind::kProject;
+  plan->mode = mode;
+  plan->opts = opts;
+  CodeGen cg(schema, mode, opts);
+  WordAccumulators accs;
+  std::ostringstream after_loop;
+  std::vector<std::string> strings;
+  const std::string st = opts.nontemporal ? "gdv_stnt" : "gdv_st";
+  for (size_t e = 0; e < exprs.size(); e++) {
+    Val v;
+    cg.Stmt("// @expr_" + std::to_string(e));
+    GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "", &v));
+    const DataType& t = exprs[e]->result().type;
+    if (t.is_varlen() || t.is_decimal())
+      return Status::CodeGenError("output type " + t.ToString() +
+                                  " is not supported by the HIP backend yet");
+    plan->output_types.push_back(t);
+    strings.push_back(exprs[e]->ToString());
+    const std::string E = std::to_string(e);
+    if (t.id == kBool) {
+      std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
+      after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)");
+    } else {
+      cg.Stmt("if (live) " + st + "(out" + E + ", row, (" + t.CType() + ")" + v.v + ");");
+    }
+    // validity word of the 64 rows of this sub-tile
+    std::string word;
+    if (cg.selection()) {
+      word = "__ballot(" + CodeGen::AndExpr("live", cg.LaneValid(v)) + ")";
+    } else {
+      word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
+      if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
+    }
+    after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid");
+  }
+  return Assemble(cg, plan, strings, accs, "", after_loop.str());
+}
+
+Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
+                  const CodegenOptions& opts, KernelPlan* plan) {
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
+  if (condition->root()->return_type().id != kBool)
+    return Status::ValidationError("Filter condition must be of type boolean");
+  plan->kind = KernelKind::kFilter;
+  plan->mode = SelectionMode::kNone;
+  plan->opts = opts;
+  CodeGen cg(schema, SelectionMode::kNone, opts);
+  WordAccumulators accs;
+  Val v;
+  cg.Stmt("// @expr_0 (filter condition)");
+  GDV_RETURN_NOT_OK(cg.Gen(*condition->root(), "", &v));
+  // a null predicate does not select the row
+  std::string pass = CodeGen::AndExpr(cg.LaneValid(v), v.v);
+  cg.Stmt("const gdv_uint64 fm = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
+  cg.Stmt("fcount += (gdv_uint32)__popcll(fm);");
+  std::string acc = accs.Get(cg, "fm");
+  std::ostringstream after;
+  after << WordStore(acc, "A.mask");
+  // one selected-row count per wave tile feeds the offsets scan (gdv_kernels.hip)
+  after << "  if (lane == 0) A.counts[wbase / GDV_U] = fcount;\n";
+  return Assemble(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n",
+                  after.str());
+}
+
+}  // namespace gdv

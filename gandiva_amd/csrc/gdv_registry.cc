@@ -1,0 +1,243 @@
+#include "gdv_registry.h"
+
+#include <algorithm>
+
+namespace gdv {
+
+std::string FunctionDef::SignatureString() const {
+  std::string s = ret.ToString() + " " + name + "(";
+  for (size_t i = 0; i < params.size(); i++) {
+    if (i) s += ", ";
+    s += params[i].ToString();
+  }
+  return s + ")";
+}
+
+void FunctionRegistry::Add(FunctionDef def) {
+  by_name_.emplace(def.name, defs_.size());
+  defs_.push_back(std::move(def));
+}
+
+const FunctionRegistry& FunctionRegistry::Get() {
+  static FunctionRegistry reg;
+  return reg;
+}
+
+static bool ParamMatches(const DataType& want, const DataType& got) {
+  if (want.id != got.id) return false;
+  if (want.id == kDecimal128) return true;
+  if (want.id == kTimestamp || want.id == kTime32 || want.id == kTime64)
+    return want.precision == got.precision;
+  return true;
+}
+
+const FunctionDef* FunctionRegistry::Lookup(const std::string& name,
+                                            const std::vector<DataType>& params) const {
+  auto range = by_name_.equal_range(name);
+  for (auto it = range.first; it != range.second; ++it) {
+    const FunctionDef& d = defs_[it->second];
+    if (d.params.size() != params.size()) continue;
+    bool ok = true;
+    for (size_t i = 0; i < params.size() && ok; i++) ok = ParamMatches(d.params[i], params[i]);
+    if (ok) return &d;
+  }
+  return nullptr;
+}
+
+namespace {
+
+std::string Sym(const std::string& name, const std::vector<DataType>& params) {
+  std::string s = name;
+  for (auto& p : params) s += "_" + p.Suffix();
+  return s;
+}
+
+}  // namespace
+
+FunctionRegistry::FunctionRegistry() {
+  const std::vector<DataType> ints = {int8(),  int16(),  int32(),  int64(),
+                                      uint8(), uint16(), uint32(), uint64()};
+  const std::vector<DataType> floats = {float32(), float64()};
+  std::vector<DataType> numerics = ints;
+  numerics.insert(numerics.end(), floats.begin(), floats.end());
+  const std::vector<DataType> dates = {date32(), date64(), timestamp(), time32(), time64()};
+
+  auto add = [&](const std::string& name, std::vector<DataType> params, DataType ret,
+                 NullPolicy policy = NullPolicy::kNullIfNull, uint32_t flags = 0,
+                 std::string symbol = "") {
+    FunctionDef d;
+    d.name = name;
+    d.params = std::move(params);
+    d.ret = ret;
+    d.policy = policy;
+    d.flags = flags;
+    d.symbol = symbol.empty() ? Sym(name, d.params) : symbol;
+    Add(std::move(d));
+  };
+
+  // arithmetic
+  for (auto& t : numerics) {
+    add("add", {t, t}, t);
+    add("subtract", {t, t}, t);
+    add("multiply", {t, t}, t);
+    add("divide", {t, t}, t, NullPolicy::kNullIfNull, kNeedsContext);
+  }
+  add("mod", {int64(), int32()}, int32());
+  add("mod", {int64(), int64()}, int64());
+  add("mod", {int32(), int32()}, int32());
+  add("mod", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, kNeedsContext);
+  for (auto& t : {int32(), int64(), float32(), float64()}) {
+    add("negative", {t}, t);
+    add("abs", {t}, t);
+    add("greatest", {t, t}, t);
+    add("least", {t, t}, t);
+  }
+
+  // relational
+  std::vector<DataType> comparable = numerics;
+  comparable.push_back(boolean());
+  comparable.insert(comparable.end(), dates.begin(), dates.end());
+  for (auto& t : comparable) {
+    for (const char* op : {"equal", "not_equal", "less_than", "less_than_or_equal_to",
+                           "greater_than", "greater_than_or_equal_to"}) {
+      add(op, {t, t}, boolean());
+    }
+    // aliases of the reference registry
+    add("eq", {t, t}, boolean(), NullPolicy::kNullIfNull, 0, Sym("equal", {t, t}));
+    add("same", {t, t}, boolean(), NullPolicy::kNullIfNull, 0, Sym("equal", {t, t}));
+  }
+  add("not", {boolean()}, boolean());
+
+  // null handling: value functions see validity
+  std::vector<DataType> all_fixed = comparable;
+  for (auto& t : all_fixed) {
+    add("isnull", {t}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnull");
+    add("isnotnull", {t}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
+    add("is_distinct_from", {t, t}, boolean(), NullPolicy::kNullNever, 0, "gdv_is_distinct_from");
+    add("is_not_distinct_from", {t, t}, boolean(), NullPolicy::kNullNever, 0,
+        "gdv_is_not_distinct_from");
+  }
+  for (auto& t : numerics) {
+    add("isnumeric", {t}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
+  }
+
+  // casts
+  add("castBIGINT", {int32()}, int64());
+  add("castINT", {int64()}, int32());
+  add("castFLOAT4", {int32()}, float32());
+  add("castFLOAT4", {int64()}, float32());
+  add("castFLOAT4", {float64()}, float32());
+  add("castFLOAT8", {int32()}, float64());
+  add("castFLOAT8", {int64()}, float64());
+  add("castFLOAT8", {float32()}, float64());
+  add("castBIGINT", {float32()}, int64());
+  add("castBIGINT", {float64()}, int64());
+  add("castINT", {float32()}, int32());
+  add("castINT", {float64()}, int32());
+  add("castDATE", {int64()}, date64());
+  add("castDATE", {date32()}, date64());
+  add("castDATE", {timestamp()}, date64());
+  add("castDATE32", {date64()}, date32());
+  add("castTIMESTAMP", {int64()}, timestamp());
+  add("castTIMESTAMP", {date64()}, timestamp());
+  add("castBIGINT", {date64()}, int64());
+  add("castBIGINT", {timestamp()}, int64());
+
+  // extended math
+  for (const char* f : {"cbrt", "exp", "log", "log10", "sqrt", "floor", "ceil", "round",
+                        "truncate"}) {
+    add(f, {float64()}, float64());
+  }
+  add("power", {float64(), float64()}, float64());
+  add("pow", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, 0,
+      "power_float64_float64");
+  add("log", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, kNeedsContext);
+
+  // hash family: never null, null input hashes to the seed
+  std::vector<DataType> hashable = numerics;
+  hashable.push_back(boolean());
+  for (auto& t : {date32(), date64(), timestamp(), time32()}) hashable.push_back(t);
+  for (auto& t : hashable) {
+    add("hash", {t}, int32(), NullPolicy::kNullNever, 0, Sym("hash32", {t}));
+    add("hash32", {t}, int32(), NullPolicy::kNullNever);
+    add("hash32AsDouble", {t}, int32(), NullPolicy::kNullNever, 0, Sym("hash32", {t}));
+    add("hash64", {t}, int64(), NullPolicy::kNullNever);
+    add("hash64AsDouble", {t}, int64(), NullPolicy::kNullNever, 0, Sym("hash64", {t}));
+    add("hash32", {t, int32()}, int32(), NullPolicy::kNullNever);
+    add("hash32AsDouble", {t, int32()}, int32(), NullPolicy::kNullNever, 0,
+        Sym("hash32", {t, int32()}));
+    add("hash64", {t, int64()}, int64(), NullPolicy::kNullNever);
+    add("hash64AsDouble", {t, int64()}, int64(), NullPolicy::kNullNever, 0,
+        Sym("hash64", {t, int64()}));
+  }
+
+  // date / time
+  for (auto& t : {date32(), date64(), timestamp()}) {
+    for (const char* f : {"extractYear", "extractMonth", "extractDay", "extractQuarter",
+                          "extractDoy", "extractDow", "extractHour", "extractMinute",
+                          "extractSecond", "extractEpoch", "extractDecade", "extractCentury",
+                          "extractMillennium"}) {
+      add(f, {t}, int64());
+    }
+  }
+  for (const char* f : {"extractHour", "extractMinute", "extractSecond"}) {
+    add(f, {time32()}, int64());
+  }
+  for (auto& t : {date64(), timestamp()}) {
+    for (const char* f : {"timestampaddSecond", "timestampaddMinute", "timestampaddHour",
+                          "timestampaddDay", "timestampaddWeek", "timestampaddMonth",
+                          "timestampaddQuarter", "timestampaddYear"}) {
+      add(f, {int64(), t}, t);
+    }
+    add("date_add", {t, int64()}, t);
+    add("date_sub", {t, int64()}, t);
+    add("date_add", {t, int32()}, t);
+    add("date_sub", {t, int32()}, t);
+    for (const char* f : {"timestampdiffSecond", "timestampdiffMinute", "timestampdiffHour",
+                          "timestampdiffDay", "timestampdiffWeek"}) {
+      add(f, {t, t}, int32());
+    }
+    add("datediff", {t, t}, int32());
+    add("date_diff", {t, t}, int32(), NullPolicy::kNullIfNull, 0, Sym("datediff", {t, t}));
+  }
+  add("datediff", {date32(), date32()}, int32());
+  add("date_diff", {date32(), date32()}, int32(), NullPolicy::kNullIfNull, 0,
+      "datediff_date32_date32");
+}
+
+// ------------------------------------------------------------------ decimal result types
+
+DataType DecimalResultType(DecimalOp op, const DataType& a, const DataType& b) {
+  const int32_t kMaxPrecision = 38;
+  const int32_t kMinAdjustedScale = 6;
+  int32_t p1 = a.precision, s1 = a.scale, p2 = b.precision, s2 = b.scale;
+  int32_t scale = 0, precision = 0;
+  switch (op) {
+    case DecimalOp::kAdd:
+    case DecimalOp::kSubtract:
+      scale = std::max(s1, s2);
+      precision = std::max(p1 - s1, p2 - s2) + scale + 1;
+      break;
+    case DecimalOp::kMultiply:
+      scale = s1 + s2;
+      precision = p1 + p2 + 1;
+      break;
+    case DecimalOp::kDivide:
+      scale = std::max(kMinAdjustedScale, s1 + p2 + 1);
+      precision = p1 - s1 + s2 + scale;
+      break;
+    case DecimalOp::kMod:
+      scale = std::max(s1, s2);
+      precision = std::min(p1 - s1, p2 - s2) + scale;
+      break;
+  }
+  if (precision > kMaxPrecision) {
+    int32_t delta = precision - kMaxPrecision;
+    int32_t min_scale = std::min(scale, kMinAdjustedScale);
+    precision = kMaxPrecision;
+    scale = std::max(scale - delta, min_scale);
+  }
+  return decimal128(precision, scale);
+}
+
+}  // namespace gdv

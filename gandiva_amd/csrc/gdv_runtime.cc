@@ -1,0 +1,256 @@
+#include "gdv_runtime.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace gdv {
+
+Runtime& Runtime::Get() {
+  static Runtime rt;
+  return rt;
+}
+
+void Runtime::Probe() {
+  if (probed_) return;
+  probed_ = true;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    has_device_ = false;
+    if (const char* a = std::getenv("GDV_ARCH")) arch_ = a;
+    return;
+  }
+  has_device_ = true;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    num_cus_ = prop.multiProcessorCount;
+    std::string a = prop.gcnArchName;  // e.g. "gfx950:sramecc+:xnack-"
+    size_t colon = a.find(':');
+    arch_ = colon == std::string::npos ? a : a.substr(0, colon);
+  }
+}
+
+bool Runtime::has_device() {
+  std::lock_guard<std::mutex> g(mu_);
+  Probe();
+  return has_device_;
+}
+
+Status Runtime::EnsureDevice() {
+  if (!has_device())
+    return Status::ExecutionError(
+        "no HIP device available: gandiva_amd evaluates on the GPU only (there is no CPU "
+        "fallback)");
+  return Status::OK();
+}
+
+int Runtime::num_cus() {
+  std::lock_guard<std::mutex> g(mu_);
+  Probe();
+  return num_cus_;
+}
+
+const std::string& Runtime::arch() {
+  std::lock_guard<std::mutex> g(mu_);
+  Probe();
+  return arch_;
+}
+
+static bool DirWritable(const std::string& d) {
+  mkdir(d.c_str(), 0755);
+  return access(d.c_str(), W_OK) == 0;
+}
+
+std::string Runtime::cache_dir() {
+  if (const char* e = std::getenv("GANDIVA_AMD_CACHE_DIR")) {
+    std::string d = e;
+    if (DirWritable(d)) return d;
+  }
+  // in-tree cache next to the shared library: travels with the repo snapshot
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&gdv_device_lib_src), &info) && info.dli_fname) {
+    std::string so = info.dli_fname;
+    size_t slash = so.rfind('/');
+    std::string d = (slash == std::string::npos ? std::string(".") : so.substr(0, slash)) +
+                    "/_kcache";
+    if (DirWritable(d)) return d;
+  }
+  std::string d = "/tmp/gandiva_amd_kcache";
+  DirWritable(d);
+  return d;
+}
+
+static uint64_t Fnv(const char* s, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; i++) {
+    h ^= static_cast<unsigned char>(s[i]);
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+Status Runtime::CompileToCodeObject(const std::string& source, const std::string& kernel_name,
+                                    std::vector<char>* code, bool* from_cache) {
+  const std::string a = arch();
+  static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
+  char tag[40];
+  snprintf(tag, sizeof(tag), "%016llx", static_cast<unsigned long long>(lib_hash));
+  const std::string path = cache_dir() + "/" + kernel_name + "." + tag + "." + a + ".hsaco";
+  const bool use_disk = std::getenv("GDV_NO_DISK_CACHE") == nullptr;
+  if (use_disk) {
+    std::ifstream f(path, std::ios::binary);
+    if (f) {
+      code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      if (!code->empty()) {
+        if (from_cache) *from_cache = true;
+        return Status::OK();
+      }
+    }
+  }
+  if (from_cache) *from_cache = false;
+  if (std::getenv("GDV_DUMP_SOURCE")) {
+    std::ofstream f(cache_dir() + "/" + kernel_name + ".hip");
+    f << source;
+  }
+
+  hiprtcProgram prog;
+  const char* hdr_src[] = {gdv_device_lib_src};
+  const char* hdr_name[] = {"gdv_device_lib.hpp"};
+  if (hiprtcCreateProgram(&prog, source.c_str(), (kernel_name + ".hip").c_str(), 1, hdr_src,
+                          hdr_name) != HIPRTC_SUCCESS)
+    return Status::CodeGenError("hiprtcCreateProgram failed");
+  std::string arch_opt = "--offload-arch=" + a;
+  // -ffp-contract=off is part of the semantics (bit-exact vs separate mul/add)
+  const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off",
+                        "-fhip-fp32-correctly-rounded-divide-sqrt"};
+  hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    return Status::CodeGenError("kernel compilation failed:\n" + log);
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code->resize(n);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  if (use_disk) {
+    std::string tmp = path + ".tmp." + std::to_string(getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) {
+      f.write(code->data(), static_cast<std::streamsize>(code->size()));
+      f.close();
+      rename(tmp.c_str(), path.c_str());
+    }
+  }
+  return Status::OK();
+}
+
+Status Runtime::GetKernel(const std::string& source, const std::string& kernel_name,
+                          const CompiledKernel** out) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = kernels_.find(kernel_name);
+    if (it != kernels_.end()) {
+      *out = it->second.get();
+      return Status::OK();
+    }
+  }
+  std::vector<char> code;
+  GDV_RETURN_NOT_OK(CompileToCodeObject(source, kernel_name, &code));
+  auto k = std::make_unique<CompiledKernel>();
+  k->name = kernel_name;
+  GDV_HIP_RETURN_NOT_OK(hipModuleLoadData(&k->module, code.data()));
+  GDV_HIP_RETURN_NOT_OK(hipModuleGetFunction(&k->function, k->module, kernel_name.c_str()));
+  std::lock_guard<std::mutex> g(mu_);
+  auto& slot = kernels_[kernel_name];
+  if (!slot) slot = std::move(k);
+  *out = slot.get();
+  return Status::OK();
+}
+
+static size_t RoundSize(size_t b) {
+  if (b < 256) return 256;
+  if (b < (1u << 20)) {
+    size_t p = 256;
+    while (p < b) p <<= 1;
+    return p;
+  }
+  const size_t g = 2u << 20;
+  return (b + g - 1) / g * g;
+}
+
+Status Runtime::Alloc(size_t bytes, void** ptr) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  size_t sz = RoundSize(bytes);
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = free_blocks_.find(sz);
+    if (it != free_blocks_.end()) {
+      *ptr = it->second;
+      free_blocks_.erase(it);
+      cached_bytes_ -= sz;
+      live_blocks_[*ptr] = sz;
+      return Status::OK();
+    }
+  }
+  hipError_t e = hipMalloc(ptr, sz);
+  if (e != hipSuccess) {
+    TrimPool();
+    e = hipMalloc(ptr, sz);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::OutOfMemory("hipMalloc of " + std::to_string(sz) + " bytes failed");
+  }
+  std::lock_guard<std::mutex> g(mu_);
+  live_blocks_[*ptr] = sz;
+  return Status::OK();
+}
+
+void Runtime::Free(void* ptr) {
+  if (!ptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  auto it = live_blocks_.find(ptr);
+  if (it == live_blocks_.end()) return;
+  size_t sz = it->second;
+  live_blocks_.erase(it);
+  free_blocks_.emplace(sz, ptr);
+  cached_bytes_ += sz;
+}
+
+void Runtime::TrimPool() {
+  std::multimap<size_t, void*> blocks;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    blocks.swap(free_blocks_);
+    cached_bytes_ = 0;
+  }
+  for (auto& b : blocks) (void)hipFree(b.second);
+}
+
+Status Runtime::Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
+                       size_t arg_bytes, hipStream_t stream) {
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
+                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END};
+  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(k.function, static_cast<unsigned>(grid), 1, 1,
+                                              static_cast<unsigned>(block), 1, 1, 0, stream,
+                                              nullptr, config));
+  return Status::OK();
+}
+
+}  // namespace gdv

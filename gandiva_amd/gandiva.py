@@ -1,0 +1,640 @@
+"""Python mirror of ``pyarrow.gandiva`` on top of the gandiva_amd C ABI.
+
+Same names, argument meaning and error behaviour as the reference lineage's Python binding
+(pyarrow/gandiva.pyx: TreeExprBuilder :296-627, make_projector :629-674, make_filter
+:677-705, Projector.evaluate :199-226, Filter.evaluate :247-280, SelectionVector :127-160,
+Configuration :707-742, get_registered_function_signatures :745-764), so that parity tests
+read like pyarrow/tests/test_gandiva.py.  All evaluation happens in HIP kernels behind
+``gdv_projector_evaluate`` / ``gdv_filter_evaluate``; this module only marshals Arrow
+buffers.  Two extra entry points expose the HBM-resident path the benchmark measures:
+``DeviceBatch`` and ``Projector.evaluate_device`` / ``Filter.evaluate_device``.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+import pyarrow as pa
+
+from . import _capi
+from ._capi import gdv_type_t, gdv_column_t, gdv_out_column_t, gdv_selection_t, gdv_config_t
+
+GDV_MEM_HOST, GDV_MEM_DEVICE = 0, 1
+GDV_EVAL_ASYNC = 1
+
+_TIME_UNITS = {"s": 0, "ms": 1, "us": 2, "ns": 3}
+_TIME_UNIT_NAMES = {v: k for k, v in _TIME_UNITS.items()}
+
+
+class GandivaError(pa.lib.ArrowException):
+    """CodeGenError / ExpressionValidationError / ExecutionError (arrow status 40/41/42)."""
+
+
+def _raise_status(code):
+    msg = _capi.last_error()
+    if code == 4:
+        raise pa.ArrowInvalid(msg)
+    if code == 10:
+        raise pa.ArrowNotImplementedError(msg)
+    if code == 1:
+        raise pa.ArrowMemoryError(msg)
+    raise GandivaError(msg)
+
+
+def _check(code):
+    if code != 0:
+        _raise_status(code)
+
+
+# ---------------------------------------------------------------------------- types
+
+def ensure_type(dtype):
+    if dtype is None:
+        raise TypeError("dtype must not be None")
+    if isinstance(dtype, pa.DataType):
+        return dtype
+    if isinstance(dtype, str):
+        return pa.type_for_alias(dtype)
+    raise TypeError(f"cannot interpret {dtype!r} as a DataType")
+
+
+def to_gdv_type(t):
+    t = ensure_type(t)
+    if pa.types.is_boolean(t): return gdv_type_t(1, 0, 0)
+    if pa.types.is_uint8(t): return gdv_type_t(2, 0, 0)
+    if pa.types.is_int8(t): return gdv_type_t(3, 0, 0)
+    if pa.types.is_uint16(t): return gdv_type_t(4, 0, 0)
+    if pa.types.is_int16(t): return gdv_type_t(5, 0, 0)
+    if pa.types.is_uint32(t): return gdv_type_t(6, 0, 0)
+    if pa.types.is_int32(t): return gdv_type_t(7, 0, 0)
+    if pa.types.is_uint64(t): return gdv_type_t(8, 0, 0)
+    if pa.types.is_int64(t): return gdv_type_t(9, 0, 0)
+    if pa.types.is_float32(t): return gdv_type_t(11, 0, 0)
+    if pa.types.is_float64(t): return gdv_type_t(12, 0, 0)
+    if pa.types.is_string(t): return gdv_type_t(13, 0, 0)
+    if pa.types.is_binary(t): return gdv_type_t(14, 0, 0)
+    if pa.types.is_date32(t): return gdv_type_t(16, 0, 0)
+    if pa.types.is_date64(t): return gdv_type_t(17, 0, 0)
+    if pa.types.is_timestamp(t): return gdv_type_t(18, _TIME_UNITS[t.unit], 0)
+    if pa.types.is_time32(t): return gdv_type_t(19, _TIME_UNITS[t.unit], 0)
+    if pa.types.is_time64(t): return gdv_type_t(20, _TIME_UNITS[t.unit], 0)
+    if pa.types.is_decimal128(t): return gdv_type_t(23, t.precision, t.scale)
+    raise pa.ArrowNotImplementedError(f"type {t} is not supported by gandiva_amd")
+
+
+def from_gdv_type(g):
+    simple = {1: pa.bool_(), 2: pa.uint8(), 3: pa.int8(), 4: pa.uint16(), 5: pa.int16(),
+              6: pa.uint32(), 7: pa.int32(), 8: pa.uint64(), 9: pa.int64(), 11: pa.float32(),
+              12: pa.float64(), 13: pa.string(), 14: pa.binary(), 16: pa.date32(),
+              17: pa.date64()}
+    if g.id in simple: return simple[g.id]
+    if g.id == 18: return pa.timestamp(_TIME_UNIT_NAMES[g.precision])
+    if g.id == 19: return pa.time32(_TIME_UNIT_NAMES[g.precision])
+    if g.id == 20: return pa.time64(_TIME_UNIT_NAMES[g.precision])
+    if g.id == 23: return pa.decimal128(g.precision, g.scale)
+    raise ValueError(f"unknown gdv type id {g.id}")
+
+
+_FIXED_PACK = {1: "<B", 2: "<B", 3: "<b", 4: "<H", 5: "<h", 6: "<I", 7: "<i", 8: "<Q", 9: "<q",
+               11: "<f", 12: "<d", 16: "<i", 17: "<q", 18: "<q", 19: "<i", 20: "<q"}
+
+
+def _pack_fixed(gt, value):
+    if gt.id == 23:
+        v = int(value) & ((1 << 128) - 1)
+        return v.to_bytes(16, "little")
+    return struct.pack(_FIXED_PACK[gt.id], value)
+
+
+# ---------------------------------------------------------------------------- tree nodes
+
+class Node:
+    """A node of an expression tree (gandiva::Node).  Keeps a plain-Python description
+    (kind / name / children / dtype / value) next to the native handle; tests hand that
+    description to the CPU oracle, the library never reads it."""
+
+    def __init__(self, handle, kind, dtype, **desc):
+        if not handle:
+            raise GandivaError(_capi.last_error())
+        self._h = handle
+        self.kind = kind
+        self.dtype = dtype
+        self.desc = desc
+
+    def __del__(self):
+        try:
+            _capi.lib().gdv_node_free(self._h)
+        except Exception:
+            pass
+
+    def __str__(self):
+        return _capi.take_string(_capi.lib().gdv_node_to_string(self._h))
+
+    def return_type(self):
+        return from_gdv_type(_capi.lib().gdv_node_return_type(self._h))
+
+
+class Expression:
+    def __init__(self, handle, root, result_field):
+        if not handle:
+            raise GandivaError(_capi.last_error())
+        self._h = handle
+        self._root = root
+        self._result = result_field
+
+    def __del__(self):
+        try:
+            _capi.lib().gdv_expression_free(self._h)
+        except Exception:
+            pass
+
+    def __str__(self):
+        return _capi.take_string(_capi.lib().gdv_expression_to_string(self._h))
+
+    def root(self):
+        return self._root
+
+    def result(self):
+        return self._result
+
+
+class Condition(Expression):
+    pass
+
+
+def _node_array(nodes):
+    for n in nodes:
+        if not isinstance(n, Node):
+            raise TypeError(f"expected a gandiva Node, got {type(n).__name__}")
+    arr = (C.c_void_p * max(len(nodes), 1))(*[n._h for n in nodes])
+    return arr
+
+
+class TreeExprBuilder:
+    """Mirror of pyarrow.gandiva.TreeExprBuilder (gandiva::TreeExprBuilder,
+    libgandiva.pxd:110-212)."""
+
+    def make_literal(self, value, dtype):
+        t = ensure_type(dtype)
+        gt = to_gdv_type(t)
+        lib = _capi.lib()
+        if gt.id in (13, 14):
+            if gt.id == 13:
+                if not isinstance(value, str):
+                    raise TypeError(f"expected str for {t}, got {type(value).__name__}")
+                raw = value.encode("utf-8")
+            else:
+                if not isinstance(value, (bytes, bytearray)):
+                    raise TypeError(f"expected bytes for {t}, got {type(value).__name__}")
+                raw = bytes(value)
+            h = lib.gdv_node_literal_bytes(gt, raw, len(raw), 0)
+            return Node(h, "literal", t, value=raw, is_null=False)
+        if gt.id == 1:
+            if not isinstance(value, (bool, np.bool_)):
+                raise TypeError(f"expected bool for {t}, got {type(value).__name__}")
+        elif gt.id in (11, 12):
+            if isinstance(value, (str, bytes)) or not isinstance(value, (int, float, np.number)):
+                raise TypeError(f"expected a number for {t}, got {type(value).__name__}")
+            value = float(value)
+        else:
+            if isinstance(value, (bool, str, bytes, float)) and not isinstance(value, (int, np.integer)):
+                raise TypeError(f"expected an integer for {t}, got {type(value).__name__}")
+            if not isinstance(value, (int, np.integer)):
+                raise TypeError(f"expected an integer for {t}, got {type(value).__name__}")
+            value = int(value)
+        try:
+            raw = _pack_fixed(gt, value)
+        except struct.error as e:
+            raise TypeError(str(e))
+        h = lib.gdv_node_literal(gt, raw, 0)
+        return Node(h, "literal", t, value=value, is_null=False)
+
+    def make_null(self, dtype):
+        t = ensure_type(dtype)
+        gt = to_gdv_type(t)
+        lib = _capi.lib()
+        if gt.id in (13, 14):
+            h = lib.gdv_node_literal_bytes(gt, None, 0, 1)
+        else:
+            h = lib.gdv_node_literal(gt, None, 1)
+        return Node(h, "literal", t, value=None, is_null=True)
+
+    def make_field(self, field):
+        if not isinstance(field, pa.Field):
+            raise TypeError("make_field expects a pyarrow.Field")
+        h = _capi.lib().gdv_node_field(field.name.encode(), to_gdv_type(field.type))
+        return Node(h, "field", field.type, name=field.name)
+
+    def make_function(self, name, children, return_type):
+        children = list(children)
+        arr = _node_array(children)
+        t = ensure_type(return_type)
+        h = _capi.lib().gdv_node_function(name.encode(), arr, len(children), to_gdv_type(t))
+        return Node(h, "function", t, name=name, children=children)
+
+    def make_if(self, condition, this_node, else_node, return_type):
+        for n in (condition, this_node, else_node):
+            if not isinstance(n, Node):
+                raise TypeError("make_if expects gandiva Nodes")
+        t = ensure_type(return_type)
+        h = _capi.lib().gdv_node_if(condition._h, this_node._h, else_node._h, to_gdv_type(t))
+        return Node(h, "if", t, children=[condition, this_node, else_node])
+
+    def make_and(self, children):
+        children = list(children)
+        arr = _node_array(children)
+        return Node(_capi.lib().gdv_node_and(arr, len(children)), "and", pa.bool_(),
+                    children=children)
+
+    def make_or(self, children):
+        children = list(children)
+        arr = _node_array(children)
+        return Node(_capi.lib().gdv_node_or(arr, len(children)), "or", pa.bool_(),
+                    children=children)
+
+    def make_in_expression(self, node, values, dtype):
+        if not isinstance(node, Node):
+            raise TypeError("make_in_expression expects a gandiva Node")
+        t = ensure_type(dtype)
+        gt = to_gdv_type(t)
+        values = list(values)
+        lib = _capi.lib()
+        if gt.id in (13, 14):
+            raws = [v.encode("utf-8") if isinstance(v, str) else bytes(v) for v in values]
+            arr = (C.c_char_p * max(len(raws), 1))(*raws)
+            lens = (C.c_int64 * max(len(raws), 1))(*[len(r) for r in raws])
+            h = lib.gdv_node_in_bytes(node._h, gt, arr, lens, len(raws))
+            return Node(h, "in", pa.bool_(), children=[node], values=raws, value_type=t)
+        ints = [_to_storage_int(v, t) for v in values]
+        raw = b"".join(_pack_fixed(gt, v) for v in ints)
+        h = lib.gdv_node_in(node._h, gt, raw, len(ints))
+        return Node(h, "in", pa.bool_(), children=[node], values=ints, value_type=t)
+
+    def make_expression(self, root_node, return_field):
+        if not isinstance(root_node, Node):
+            raise TypeError("make_expression expects a gandiva Node")
+        if not isinstance(return_field, pa.Field):
+            raise TypeError("make_expression expects a pyarrow.Field")
+        h = _capi.lib().gdv_expression_new(root_node._h, return_field.name.encode(),
+                                           to_gdv_type(return_field.type))
+        return Expression(h, root_node, return_field)
+
+    def make_condition(self, condition):
+        if not isinstance(condition, Node):
+            raise TypeError("make_condition expects a gandiva Node")
+        h = _capi.lib().gdv_condition_new(condition._h)
+        return Condition(h, condition, pa.field("cond", pa.bool_()))
+
+
+def _to_storage_int(v, t):
+    """IN-list value -> the integer stored in the Arrow values buffer."""
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    return int(pa.scalar(v, type=t).cast(pa.int64() if t.bit_width == 64 else pa.int32()).as_py())
+
+
+# ---------------------------------------------------------------------------- configuration
+
+class Configuration:
+    def __init__(self, optimize=True, dump_ir=False):
+        self.optimize = bool(optimize)
+        self.dump_ir = bool(dump_ir)
+
+    def _c(self):
+        return gdv_config_t(int(self.optimize), int(self.dump_ir))
+
+
+_SEL_MODES = {"NONE": 0, "UINT16": 1, "UINT32": 2, "UINT64": 3}
+_SEL_DTYPE = {1: (pa.uint16(), np.uint16), 2: (pa.uint32(), np.uint32), 3: (pa.uint64(), np.uint64)}
+
+
+def _selection_mode(name):
+    up = str(name).upper()
+    if up not in _SEL_MODES:
+        raise ValueError(f"Invalid value for Selection Mode: {name!r}")
+    return _SEL_MODES[up]
+
+
+def _make_schema(schema):
+    if not isinstance(schema, pa.Schema):
+        raise TypeError("expected a pyarrow.Schema")
+    lib = _capi.lib()
+    h = lib.gdv_schema_new()
+    for f in schema:
+        _check(lib.gdv_schema_add_field(h, f.name.encode(), to_gdv_type(f.type), int(f.nullable)))
+    return h
+
+
+# ---------------------------------------------------------------------------- batches
+
+def _buf(b):
+    return (b.address, b.size) if b is not None else (None, 0)
+
+
+def _column_of_array(arr):
+    """pyarrow.Array (host) -> gdv_column_t, plus the objects that must stay alive."""
+    bufs = arr.buffers()
+    col = gdv_column_t()
+    col.validity, col.validity_size = _buf(bufs[0])
+    if pa.types.is_string(arr.type) or pa.types.is_binary(arr.type):
+        col.offsets, col.offsets_size = _buf(bufs[1])
+        col.data, col.data_size = _buf(bufs[2])
+        if col.data is None:
+            col.data, col.data_size = 0, 0
+    else:
+        col.data, col.data_size = _buf(bufs[1])
+    col.offset = arr.offset
+    return col
+
+
+class DeviceColumn:
+    """One HBM-resident Arrow array: torch uint8 tensors own the buffers."""
+
+    def __init__(self, type, length, validity, data, offsets=None, offset=0):
+        self.type, self.length = type, length
+        self.validity, self.data, self.offsets, self.offset = validity, data, offsets, offset
+
+    def _c(self):
+        col = gdv_column_t()
+        if self.validity is not None:
+            col.validity, col.validity_size = self.validity.data_ptr(), self.validity.numel()
+        if self.data is not None:
+            col.data, col.data_size = self.data.data_ptr(), self.data.numel()
+        if self.offsets is not None:
+            col.offsets, col.offsets_size = self.offsets.data_ptr(), self.offsets.numel()
+        col.offset = self.offset
+        return col
+
+    def to_arrow(self):
+        """Copy back to a host pyarrow.Array."""
+        bufs = [None if self.validity is None else pa.py_buffer(self.validity.cpu().numpy())]
+        if self.offsets is not None:
+            bufs.append(pa.py_buffer(self.offsets.cpu().numpy()))
+        bufs.append(pa.py_buffer(self.data.cpu().numpy()))
+        return pa.Array.from_buffers(self.type, self.length, bufs, offset=self.offset)
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class DeviceBatch:
+    """A record batch resident in the HBM of the current device (Arrow layout, buffers
+    padded to 64 bytes).  Build with ``DeviceBatch.from_arrow`` (uploads) or directly from
+    DeviceColumns produced on the GPU."""
+
+    def __init__(self, schema, columns, num_rows):
+        self.schema, self.columns, self.num_rows = schema, columns, num_rows
+
+    @staticmethod
+    def from_arrow(batch, device="cuda"):
+        import torch
+        cols = []
+        for arr in batch.columns:
+            bufs = arr.buffers()
+
+            def up(b):
+                if b is None:
+                    return None
+                host = np.frombuffer(b, dtype=np.uint8)
+                t = torch.zeros(_pad64(max(host.size, 1)), dtype=torch.uint8, device=device)
+                if host.size:
+                    t[:host.size] = torch.from_numpy(host.copy()).to(device)
+                return t
+            if pa.types.is_string(arr.type) or pa.types.is_binary(arr.type):
+                cols.append(DeviceColumn(arr.type, len(arr), up(bufs[0]), up(bufs[2]) if bufs[2] is not None else torch.zeros(64, dtype=torch.uint8, device=device), up(bufs[1]), arr.offset))
+            else:
+                cols.append(DeviceColumn(arr.type, len(arr), up(bufs[0]), up(bufs[1]), None, arr.offset))
+        return DeviceBatch(batch.schema, cols, batch.num_rows)
+
+
+class SelectionVector:
+    """gandiva::SelectionVector (libgandiva.pxd:43-71): host numpy indices or, on the
+    device path, a torch tensor of indices plus the slot count."""
+
+    def __init__(self, mode, indices, num_slots, device=False):
+        self.mode, self.indices, self.num_slots, self.device = mode, indices, num_slots, device
+
+    def to_array(self):
+        atype, ntype = _SEL_DTYPE[self.mode]
+        if self.device:
+            host = self.indices[:self.num_slots].cpu().numpy()
+        else:
+            host = self.indices[:self.num_slots]
+        return pa.array(host.astype(ntype, copy=False), type=atype)
+
+    def _c(self):
+        s = gdv_selection_t()
+        s.mode = self.mode
+        s.num_slots = self.num_slots
+        s.indices = self.indices.data_ptr() if self.device else self.indices.ctypes.data
+        return s
+
+
+def _check_batch(batch, schema):
+    if not isinstance(batch, pa.RecordBatch):
+        raise TypeError("expected a pyarrow.RecordBatch")
+    if not batch.schema.equals(schema, check_metadata=False):
+        raise pa.ArrowInvalid("Schema in RecordBatch must match schema in Make()")
+
+
+# ---------------------------------------------------------------------------- Projector
+
+class Projector:
+    def __init__(self, handle, schema, mode, exprs):
+        self._h = handle
+        self._schema = schema
+        self._mode = mode
+        self._exprs = exprs
+        lib = _capi.lib()
+        self._out_types = [from_gdv_type(lib.gdv_projector_output_type(handle, i))
+                           for i in range(lib.gdv_projector_num_outputs(handle))]
+
+    def __del__(self):
+        try:
+            _capi.lib().gdv_projector_free(self._h)
+        except Exception:
+            pass
+
+    @property
+    def llvm_ir(self):
+        """DumpIR(): the generated HIP source of the fused kernel (contains `@expr_N`)."""
+        return _capi.take_string(_capi.lib().gdv_projector_dump_ir(self._h))
+
+    def evaluate(self, batch, selection=None):
+        """Host-buffer path: stages the batch through HBM, returns host pyarrow arrays."""
+        _check_batch(batch, self._schema)
+        lib = _capi.lib()
+        cols = (gdv_column_t * max(batch.num_columns, 1))(*[_column_of_array(a) for a in batch.columns])
+        out_rows = selection.num_slots if selection is not None else batch.num_rows
+        n_out = len(self._out_types)
+        outs = (gdv_out_column_t * n_out)()
+        holders = []
+        for i, t in enumerate(self._out_types):
+            vb, db = C.c_int64(), C.c_int64()
+            _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_HOST, vb, db))
+            v = pa.allocate_buffer(_pad64(max(vb.value, 1)))
+            d = pa.allocate_buffer(_pad64(max(db.value, 1)))
+            holders.append((v, d))
+            outs[i].validity, outs[i].validity_size = v.address, v.size
+            outs[i].data, outs[i].data_size = d.address, d.size
+        sel_c = None
+        if selection is not None:
+            if selection.device:
+                raise TypeError("device selection vector passed to the host evaluate()")
+            s = selection._c()
+            sel_c = C.byref(s)
+        _check(lib.gdv_projector_evaluate(self._h, batch.num_rows, cols, batch.num_columns, sel_c,
+                                          outs, n_out, GDV_MEM_HOST, None, 0))
+        return [pa.Array.from_buffers(t, out_rows, [v, d]) for t, (v, d) in zip(self._out_types, holders)]
+
+    def evaluate_device(self, dbatch, selection=None, outputs=None, stream=None, sync=True):
+        """HBM-resident path (zero-copy): inputs are a DeviceBatch, outputs DeviceColumns
+        (allocated here unless ``outputs`` from a previous call are passed back in)."""
+        import torch
+        lib = _capi.lib()
+        cols = (gdv_column_t * max(len(dbatch.columns), 1))(*[c._c() for c in dbatch.columns])
+        out_rows = selection.num_slots if selection is not None else dbatch.num_rows
+        n_out = len(self._out_types)
+        if outputs is None:
+            outputs = []
+            for i, t in enumerate(self._out_types):
+                vb, db = C.c_int64(), C.c_int64()
+                _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_DEVICE, vb, db))
+                outputs.append(DeviceColumn(
+                    t, out_rows,
+                    torch.empty(_pad64(max(vb.value, 1)), dtype=torch.uint8, device="cuda"),
+                    torch.empty(_pad64(max(db.value, 1)), dtype=torch.uint8, device="cuda")))
+        outs = (gdv_out_column_t * n_out)()
+        for i, o in enumerate(outputs):
+            outs[i].validity, outs[i].validity_size = o.validity.data_ptr(), o.validity.numel()
+            outs[i].data, outs[i].data_size = o.data.data_ptr(), o.data.numel()
+        sel_c = None
+        if selection is not None:
+            s = selection._c()
+            sel_c = C.byref(s)
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _check(lib.gdv_projector_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c,
+                                          outs, n_out, GDV_MEM_DEVICE, C.c_void_p(stream),
+                                          0 if sync else GDV_EVAL_ASYNC))
+        return outputs
+
+
+def make_projector(schema, children, pool=None, selection_mode="NONE", configuration=None):
+    children = list(children)
+    for c in children:
+        if not isinstance(c, Expression):
+            raise TypeError("make_projector expects gandiva Expressions")
+    mode = _selection_mode(selection_mode)
+    lib = _capi.lib()
+    sh = _make_schema(schema)
+    try:
+        arr = (C.c_void_p * max(len(children), 1))(*[c._h for c in children])
+        out = C.c_void_p()
+        cfg = (configuration or Configuration())._c()
+        _check(lib.gdv_projector_make(sh, arr, len(children), mode, C.byref(cfg), C.byref(out)))
+    finally:
+        lib.gdv_schema_free(sh)
+    return Projector(out, schema, mode, children)
+
+
+# ---------------------------------------------------------------------------- Filter
+
+class Filter:
+    def __init__(self, handle, schema, condition):
+        self._h = handle
+        self._schema = schema
+        self._condition = condition
+
+    def __del__(self):
+        try:
+            _capi.lib().gdv_filter_free(self._h)
+        except Exception:
+            pass
+
+    @property
+    def llvm_ir(self):
+        return _capi.take_string(_capi.lib().gdv_filter_dump_ir(self._h))
+
+    @staticmethod
+    def _mode_of(dtype):
+        t = ensure_type(dtype)
+        if pa.types.is_int16(t) or pa.types.is_uint16(t): return 1
+        if pa.types.is_int32(t) or pa.types.is_uint32(t): return 2
+        if pa.types.is_int64(t) or pa.types.is_uint64(t): return 3
+        raise ValueError("'dtype' of the selection vector should be one of 'int16', 'int32' and 'int64'.")
+
+    def evaluate(self, batch, pool=None, dtype="int32"):
+        _check_batch(batch, self._schema)
+        mode = self._mode_of(dtype)
+        lib = _capi.lib()
+        cols = (gdv_column_t * max(batch.num_columns, 1))(*[_column_of_array(a) for a in batch.columns])
+        idx = np.empty(max(batch.num_rows, 1), dtype=_SEL_DTYPE[mode][1])
+        count = C.c_int64(0)
+        _check(lib.gdv_filter_evaluate(self._h, batch.num_rows, cols, batch.num_columns, mode,
+                                       idx.ctypes.data, batch.num_rows, C.byref(count),
+                                       GDV_MEM_HOST, None))
+        return SelectionVector(mode, idx, count.value, device=False)
+
+    def evaluate_device(self, dbatch, dtype="int32", out=None, stream=None):
+        import torch
+        mode = self._mode_of(dtype)
+        lib = _capi.lib()
+        cols = (gdv_column_t * max(len(dbatch.columns), 1))(*[c._c() for c in dbatch.columns])
+        tdt = {1: torch.int16, 2: torch.int32, 3: torch.int64}[mode]
+        if out is None:
+            out = torch.empty(max(dbatch.num_rows, 1), dtype=tdt, device="cuda")
+        count = C.c_int64(0)
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _check(lib.gdv_filter_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), mode,
+                                       C.c_void_p(out.data_ptr()), out.numel(), C.byref(count),
+                                       GDV_MEM_DEVICE, C.c_void_p(stream)))
+        return SelectionVector(mode, out, count.value, device=True)
+
+
+def make_filter(schema, condition, configuration=None):
+    if not isinstance(condition, Condition):
+        raise TypeError("make_filter expects a gandiva Condition")
+    lib = _capi.lib()
+    sh = _make_schema(schema)
+    try:
+        out = C.c_void_p()
+        cfg = (configuration or Configuration())._c()
+        _check(lib.gdv_filter_make(sh, condition._h, C.byref(cfg), C.byref(out)))
+    finally:
+        lib.gdv_schema_free(sh)
+    return Filter(out, schema, condition)
+
+
+# ---------------------------------------------------------------------------- registry
+
+class FunctionSignature:
+    def __init__(self, name, return_type, param_types):
+        self._name, self._ret, self._params = name, return_type, param_types
+
+    def return_type(self):
+        return self._ret
+
+    def param_types(self):
+        return list(self._params)
+
+    def name(self):
+        return self._name
+
+    def __repr__(self):
+        return f"FunctionSignature({self._ret} {self._name}({', '.join(map(str, self._params))}))"
+
+
+def get_registered_function_signatures():
+    lib = _capi.lib()
+    out = []
+    for i in range(lib.gdv_registry_size()):
+        name = C.c_char_p()
+        ret = gdv_type_t()
+        params = (gdv_type_t * 8)()
+        n = C.c_int()
+        _check(lib.gdv_registry_get(i, C.byref(name), C.byref(ret), params, 8, C.byref(n)))
+        out.append(FunctionSignature(name.value.decode(), from_gdv_type(ret),
+                                     [from_gdv_type(params[j]) for j in range(n.value)]))
+    return out

@@ -1,0 +1,691 @@
+/*
+ * oracle/gdv_oracle.c — CPU restatement of the reference's Projector / Filter evaluation.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under gandiva_amd/ or include/ links, imports or
+ * executes this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may use it, and only as the checker / timed CPU baseline.
+ *
+ * PARITY STATUS.  /root/reference contains no source, so this file cannot
+ * cite reference file:line for its algorithm.  What it follows:
+ *   - execution shape [SURVEY.md §3.2, recalled]: one expression at a time; the VALUE is
+ *     computed for every row; the VALIDITY of null-if-null functions is the AND of the input
+ *     validity; if/else and AND/OR use per-row ("local bitmap") validity; Filter = value AND
+ *     validity, then SelectionVector::PopulateFromBitMap = per 64-bit word ctz / clear-lowest
+ *     bit walk (§3.3).
+ *   - Arrow memory format [pinned]: LSB-first bitmaps (pyarrow/include/arrow/util/
+ *     bit_util.h:173-175), ArrayData offset (array/data.h:88-90).
+ *   - IEEE-754 / two's-complement wrap for arithmetic and compare [self-evident].
+ * Pinned by golden vectors: the eight data-bearing tests of pyarrow/tests/test_gandiva.py
+ * (tests/test_reference_kats.py runs them against this oracle AND the HIP path).
+ * Everything else (hash, date/time, casts, divide-by-zero behaviour, 3-valued AND/OR with
+ * null operands) is "parity unpinned": restated from memory of the reference, cross-checked
+ * against pyarrow.compute where semantics coincide (tests/test_oracle_crosscheck.py).
+ *
+ * Program format (whitespace separated, prefix order):
+ *   F <col>                               field: column index
+ *   L <type> <is_null> <lo_hex> <hi_hex>  fixed-width literal (128-bit payload)
+ *   C <name> <ret_type> <nargs> e...      function call
+ *   I <ret_type> cond then else           if / else
+ *   A <n> e...   |   O <n> e...           SQL AND / OR
+ *   N <type> <n> <hex>... e               IN list over fixed-width values (bit images)
+ * <type> = arrow type id (gandiva_amd.h gdv_type_id).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHUNK 1024
+
+enum {
+  T_BOOL = 1, T_U8 = 2, T_I8 = 3, T_U16 = 4, T_I16 = 5, T_U32 = 6, T_I32 = 7, T_U64 = 8,
+  T_I64 = 9, T_F32 = 11, T_F64 = 12, T_DATE32 = 16, T_DATE64 = 17, T_TS = 18, T_TIME32 = 19,
+  T_TIME64 = 20
+};
+
+typedef struct {
+  int32_t type;
+  const uint8_t* validity; /* may be NULL */
+  const void* data;
+  int64_t offset; /* Arrow array offset */
+} or_column;
+
+/* A chunk of evaluated values: every value widened to a 64-bit slot. */
+typedef struct {
+  int32_t type;
+  union { int64_t i; uint64_t u; double d; float f; } v[CHUNK];
+  uint8_t valid[CHUNK];
+} vec;
+
+typedef struct node {
+  char kind;       /* F L C I A O N */
+  int32_t type;    /* result type */
+  int col;
+  int is_null;
+  uint64_t lo, hi;
+  char name[48];
+  int nargs;
+  struct node** args;
+  int nvals;
+  uint64_t* vals;
+} node;
+
+typedef struct {
+  const or_column* cols;
+  int ncols;
+  int err; /* 1 = divide by zero */
+} ctx;
+
+/* ---------------------------------------------------------------- parsing */
+static const char* next_tok(const char** p, char* buf, size_t cap) {
+  while (**p == ' ' || **p == '\n' || **p == '\t') (*p)++;
+  size_t n = 0;
+  while (**p && **p != ' ' && **p != '\n' && **p != '\t') {
+    if (n + 1 < cap) buf[n++] = **p;
+    (*p)++;
+  }
+  buf[n] = 0;
+  return n ? buf : NULL;
+}
+
+static node* parse(const char** p, const or_column* cols) {
+  char t[128];
+  if (!next_tok(p, t, sizeof t)) return NULL;
+  node* n = (node*)calloc(1, sizeof(node));
+  n->kind = t[0];
+  switch (t[0]) {
+    case 'F':
+      next_tok(p, t, sizeof t);
+      n->col = atoi(t);
+      n->type = cols[n->col].type;
+      break;
+    case 'L':
+      next_tok(p, t, sizeof t); n->type = atoi(t);
+      next_tok(p, t, sizeof t); n->is_null = atoi(t);
+      next_tok(p, t, sizeof t); n->lo = strtoull(t, NULL, 16);
+      next_tok(p, t, sizeof t); n->hi = strtoull(t, NULL, 16);
+      break;
+    case 'C':
+      next_tok(p, t, sizeof t); snprintf(n->name, sizeof n->name, "%s", t);
+      next_tok(p, t, sizeof t); n->type = atoi(t);
+      next_tok(p, t, sizeof t); n->nargs = atoi(t);
+      n->args = (node**)calloc(n->nargs ? n->nargs : 1, sizeof(node*));
+      for (int i = 0; i < n->nargs; i++) n->args[i] = parse(p, cols);
+      break;
+    case 'I':
+      next_tok(p, t, sizeof t); n->type = atoi(t);
+      n->nargs = 3;
+      n->args = (node**)calloc(3, sizeof(node*));
+      for (int i = 0; i < 3; i++) n->args[i] = parse(p, cols);
+      break;
+    case 'A': case 'O':
+      n->type = T_BOOL;
+      next_tok(p, t, sizeof t); n->nargs = atoi(t);
+      n->args = (node**)calloc(n->nargs, sizeof(node*));
+      for (int i = 0; i < n->nargs; i++) n->args[i] = parse(p, cols);
+      break;
+    case 'N':
+      n->type = T_BOOL;
+      next_tok(p, t, sizeof t); /* value type: implied by child */
+      next_tok(p, t, sizeof t); n->nvals = atoi(t);
+      n->vals = (uint64_t*)calloc(n->nvals ? n->nvals : 1, sizeof(uint64_t));
+      for (int i = 0; i < n->nvals; i++) { next_tok(p, t, sizeof t); n->vals[i] = strtoull(t, NULL, 16); }
+      n->nargs = 1;
+      n->args = (node**)calloc(1, sizeof(node*));
+      n->args[0] = parse(p, cols);
+      break;
+    default:
+      free(n);
+      return NULL;
+  }
+  return n;
+}
+
+static void free_node(node* n) {
+  if (!n) return;
+  for (int i = 0; i < n->nargs; i++) free_node(n->args[i]);
+  free(n->args);
+  free(n->vals);
+  free(n);
+}
+
+/* ---------------------------------------------------------------- helpers */
+static int width_of(int t) {
+  switch (t) {
+    case T_U8: case T_I8: return 1;
+    case T_U16: case T_I16: return 2;
+    case T_U32: case T_I32: case T_F32: case T_DATE32: case T_TIME32: return 4;
+    case T_BOOL: return 0;
+    default: return 8;
+  }
+}
+static int is_float(int t) { return t == T_F32 || t == T_F64; }
+static int is_signed(int t) {
+  return t == T_I8 || t == T_I16 || t == T_I32 || t == T_I64 || t == T_DATE32 || t == T_DATE64 ||
+         t == T_TS || t == T_TIME32 || t == T_TIME64;
+}
+static int get_bit(const uint8_t* b, int64_t i) { return (b[i >> 3] >> (i & 7)) & 1; }
+
+/* wrap a 64-bit integer result to the width/signedness of type t */
+static int64_t wrap_int(int t, uint64_t x) {
+  switch (t) {
+    case T_I8: return (int8_t)x;
+    case T_U8: return (uint8_t)x;
+    case T_I16: return (int16_t)x;
+    case T_U16: return (uint16_t)x;
+    case T_I32: case T_DATE32: case T_TIME32: return (int32_t)x;
+    case T_U32: return (uint32_t)x;
+    default: return (int64_t)x;
+  }
+}
+
+static void load_column(const or_column* c, int64_t row0, int n, vec* out) {
+  out->type = c->type;
+  for (int i = 0; i < n; i++) {
+    int64_t r = c->offset + row0 + i;
+    out->valid[i] = c->validity ? (uint8_t)get_bit(c->validity, r) : 1;
+    switch (c->type) {
+      case T_BOOL: out->v[i].i = get_bit((const uint8_t*)c->data, r); break;
+      case T_I8: out->v[i].i = ((const int8_t*)c->data)[r]; break;
+      case T_U8: out->v[i].i = ((const uint8_t*)c->data)[r]; break;
+      case T_I16: out->v[i].i = ((const int16_t*)c->data)[r]; break;
+      case T_U16: out->v[i].i = ((const uint16_t*)c->data)[r]; break;
+      case T_I32: case T_DATE32: case T_TIME32: out->v[i].i = ((const int32_t*)c->data)[r]; break;
+      case T_U32: out->v[i].i = ((const uint32_t*)c->data)[r]; break;
+      case T_F32: out->v[i].f = ((const float*)c->data)[r]; break;
+      case T_F64: out->v[i].d = ((const double*)c->data)[r]; break;
+      default: out->v[i].i = ((const int64_t*)c->data)[r]; break;
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- date helpers (Hinnant) */
+#define MS_DAY 86400000LL
+static int64_t floor_div(int64_t a, int64_t b) {
+  int64_t q = a / b;
+  return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+static int64_t floor_mod(int64_t a, int64_t b) { return a - floor_div(a, b) * b; }
+static void civil_from_days(int64_t z, int64_t* y, int* m, int* d) {
+  z += 719468;
+  int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  unsigned doe = (unsigned)(z - era * 146097);
+  unsigned yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  int64_t yy = (int64_t)yoe + era * 400;
+  unsigned doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  unsigned mp = (5 * doy + 2) / 153;
+  *d = (int)(doy - (153 * mp + 2) / 5 + 1);
+  *m = (int)(mp < 10 ? mp + 3 : mp - 9);
+  *y = yy + (*m <= 2);
+}
+static int64_t days_from_civil(int64_t y, int m, int d) {
+  y -= m <= 2;
+  int64_t era = (y >= 0 ? y : y - 399) / 400;
+  unsigned yoe = (unsigned)(y - era * 400);
+  unsigned doy = (unsigned)((153 * (m > 2 ? m - 3 : m + 9) + 2) / 5 + d - 1);
+  unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + (int64_t)doe - 719468;
+}
+static int last_dom(int64_t y, int m) {
+  static const int t[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  int leap = (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0);
+  return (m == 2 && leap) ? 29 : t[m - 1];
+}
+static int64_t add_months(int64_t ms, int64_t months) {
+  int64_t days = floor_div(ms, MS_DAY), tod = ms - days * MS_DAY, y;
+  int m, d;
+  civil_from_days(days, &y, &m, &d);
+  int64_t total = y * 12 + (m - 1) + months;
+  int64_t ny = floor_div(total, 12);
+  int nm = (int)(total - ny * 12) + 1;
+  int last = last_dom(ny, nm);
+  return days_from_civil(ny, nm, d > last ? last : d) * MS_DAY + tod;
+}
+static int64_t to_millis(int t, int64_t v) { return t == T_DATE32 ? v * MS_DAY : v; }
+
+/* ---------------------------------------------------------------- hash (murmur3 variants) */
+static uint64_t rotl64(uint64_t v, int d) { return (v << d) | (v >> (64 - d)); }
+static uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+static int64_t murmur3_64(uint64_t val, int32_t seed) {
+  uint64_t h1 = (uint64_t)(int64_t)seed, h2 = h1;
+  uint64_t k1 = val * 0x87c37b91114253d5ULL;
+  k1 = rotl64(k1, 31) * 0x4cf5ad432745937fULL;
+  h1 ^= k1; h1 ^= 8; h2 ^= 8; h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return (int64_t)(h1 + h2);
+}
+static int32_t murmur3_32(uint64_t val, int32_t seed) {
+  uint32_t h = (uint32_t)seed;
+  for (int i = 0; i < 2; i++) {
+    uint32_t k = (uint32_t)(val >> (i * 32));
+    k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u;
+    h ^= k; h = (h << 13) | (h >> 19); h = h * 5u + 0xe6546b64u;
+  }
+  h ^= 8u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (int32_t)h;
+}
+static double as_double(int t, const vec* a, int i) {
+  if (t == T_F64) return a->v[i].d;
+  if (t == T_F32) return (double)a->v[i].f;
+  if (t == T_U64) return (double)a->v[i].u;
+  return (double)a->v[i].i;
+}
+static uint64_t dbits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+
+/* ---------------------------------------------------------------- evaluation */
+static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active, vec* out);
+
+static double rnd(double x) { return round(x); }
+static int64_t sat_i64(double r) {
+  if (r != r) return 0;
+  if (r >= 9223372036854775808.0) return INT64_MAX;
+  if (r <= -9223372036854775808.0) return INT64_MIN;
+  return (int64_t)r;
+}
+static int32_t sat_i32(double r) {
+  if (r != r) return 0;
+  if (r >= 2147483647.0) return INT32_MAX;
+  if (r <= -2147483648.0) return INT32_MIN;
+  return (int32_t)r;
+}
+
+static int cmp_op(const char* name) {
+  if (!strcmp(name, "equal") || !strcmp(name, "eq") || !strcmp(name, "same")) return 0;
+  if (!strcmp(name, "not_equal")) return 1;
+  if (!strcmp(name, "less_than")) return 2;
+  if (!strcmp(name, "less_than_or_equal_to")) return 3;
+  if (!strcmp(name, "greater_than")) return 4;
+  if (!strcmp(name, "greater_than_or_equal_to")) return 5;
+  return -1;
+}
+#define CMP(op, a, b) ((op) == 0 ? (a) == (b) : (op) == 1 ? (a) != (b) : (op) == 2 ? (a) < (b) : \
+                       (op) == 3 ? (a) <= (b) : (op) == 4 ? (a) > (b) : (a) >= (b))
+
+static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active,
+                          vec* out) {
+  const char* f = n->name;
+  vec* a = (vec*)malloc(sizeof(vec) * (n->nargs ? n->nargs : 1));
+  for (int k = 0; k < n->nargs; k++) eval(n->args[k], c, row0, cnt, active, &a[k]);
+  out->type = n->type;
+  const int t0 = n->nargs > 0 ? a[0].type : 0;
+  /* default null policy: null if any argument is null */
+  for (int i = 0; i < cnt; i++) {
+    uint8_t v = 1;
+    for (int k = 0; k < n->nargs; k++) v &= a[k].valid[i];
+    out->valid[i] = v;
+  }
+  int op;
+  if ((!strcmp(f, "add") || !strcmp(f, "subtract") || !strcmp(f, "multiply")) && n->nargs == 2) {
+    int which = f[0] == 'a' ? 0 : f[0] == 's' ? 1 : 2;
+    for (int i = 0; i < cnt; i++) {
+      if (t0 == T_F64) {
+        double x = a[0].v[i].d, y = a[1].v[i].d;
+        out->v[i].d = which == 0 ? x + y : which == 1 ? x - y : x * y;
+      } else if (t0 == T_F32) {
+        float x = a[0].v[i].f, y = a[1].v[i].f;
+        out->v[i].f = which == 0 ? x + y : which == 1 ? x - y : x * y;
+      } else {
+        uint64_t x = a[0].v[i].u, y = a[1].v[i].u;
+        out->v[i].i = wrap_int(t0, which == 0 ? x + y : which == 1 ? x - y : x * y);
+      }
+    }
+  } else if (!strcmp(f, "divide")) {
+    /* runs only on live rows with valid arguments; x / 0 raises and yields 0 */
+    for (int i = 0; i < cnt; i++) {
+      int live = out->valid[i] && (!active || active[i]);
+      if (t0 == T_F64) {
+        if (!live) { out->v[i].d = 0; continue; }
+        if (a[1].v[i].d == 0) { c->err |= 1; out->v[i].d = 0; } else out->v[i].d = a[0].v[i].d / a[1].v[i].d;
+      } else if (t0 == T_F32) {
+        if (!live) { out->v[i].f = 0; continue; }
+        if (a[1].v[i].f == 0) { c->err |= 1; out->v[i].f = 0; } else out->v[i].f = a[0].v[i].f / a[1].v[i].f;
+      } else {
+        if (!live) { out->v[i].i = 0; continue; }
+        if (a[1].v[i].i == 0) { c->err |= 1; out->v[i].i = 0; }
+        else if (is_signed(t0)) {
+          if (a[1].v[i].i == -1) out->v[i].i = wrap_int(t0, 0 - a[0].v[i].u);
+          else out->v[i].i = wrap_int(t0, (uint64_t)(a[0].v[i].i / a[1].v[i].i));
+        } else out->v[i].i = wrap_int(t0, a[0].v[i].u / a[1].v[i].u);
+      }
+    }
+  } else if (!strcmp(f, "mod")) {
+    for (int i = 0; i < cnt; i++) {
+      if (t0 == T_F64) {
+        int live = out->valid[i] && (!active || active[i]);
+        if (!live) { out->v[i].d = 0; continue; }
+        if (a[1].v[i].d == 0) { c->err |= 1; out->v[i].d = 0; } else out->v[i].d = fmod(a[0].v[i].d, a[1].v[i].d);
+      } else {
+        int64_t x = a[0].v[i].i, y = a[1].v[i].i;
+        out->v[i].i = wrap_int(n->type, (uint64_t)(y == 0 ? x : y == -1 ? 0 : x % y));
+      }
+    }
+  } else if ((op = cmp_op(f)) >= 0 && n->nargs == 2) {
+    for (int i = 0; i < cnt; i++) {
+      if (t0 == T_F64) out->v[i].i = CMP(op, a[0].v[i].d, a[1].v[i].d);
+      else if (t0 == T_F32) out->v[i].i = CMP(op, a[0].v[i].f, a[1].v[i].f);
+      else if (t0 == T_U64) out->v[i].i = CMP(op, a[0].v[i].u, a[1].v[i].u);
+      else out->v[i].i = CMP(op, a[0].v[i].i, a[1].v[i].i);
+    }
+  } else if (!strcmp(f, "not")) {
+    for (int i = 0; i < cnt; i++) out->v[i].i = !a[0].v[i].i;
+  } else if (!strcmp(f, "isnull") || !strcmp(f, "isnotnull") || !strcmp(f, "isnumeric")) {
+    int neg = !strcmp(f, "isnull");
+    for (int i = 0; i < cnt; i++) { out->v[i].i = neg ? !a[0].valid[i] : a[0].valid[i]; out->valid[i] = 1; }
+  } else if (!strcmp(f, "is_distinct_from") || !strcmp(f, "is_not_distinct_from")) {
+    int neg = f[3] == 'n';
+    for (int i = 0; i < cnt; i++) {
+      int r;
+      if (a[0].valid[i] != a[1].valid[i]) r = 1;
+      else if (!a[0].valid[i]) r = 0;
+      else if (t0 == T_F64) r = a[0].v[i].d != a[1].v[i].d;
+      else if (t0 == T_F32) r = a[0].v[i].f != a[1].v[i].f;
+      else r = a[0].v[i].i != a[1].v[i].i;
+      out->v[i].i = neg ? !r : r;
+      out->valid[i] = 1;
+    }
+  } else if (!strcmp(f, "negative") || !strcmp(f, "abs")) {
+    int ab = f[0] == 'a';
+    for (int i = 0; i < cnt; i++) {
+      if (t0 == T_F64) out->v[i].d = ab ? fabs(a[0].v[i].d) : -a[0].v[i].d;
+      else if (t0 == T_F32) out->v[i].f = ab ? fabsf(a[0].v[i].f) : -a[0].v[i].f;
+      else out->v[i].i = wrap_int(t0, (ab && a[0].v[i].i >= 0) ? a[0].v[i].u : 0 - a[0].v[i].u);
+    }
+  } else if (!strcmp(f, "greatest") || !strcmp(f, "least")) {
+    int g = f[0] == 'g';
+    for (int i = 0; i < cnt; i++) {
+      if (t0 == T_F64) { double x = a[0].v[i].d, y = a[1].v[i].d; out->v[i].d = g ? (x > y ? x : y) : (x < y ? x : y); }
+      else if (t0 == T_F32) { float x = a[0].v[i].f, y = a[1].v[i].f; out->v[i].f = g ? (x > y ? x : y) : (x < y ? x : y); }
+      else { int64_t x = a[0].v[i].i, y = a[1].v[i].i; out->v[i].i = g ? (x > y ? x : y) : (x < y ? x : y); }
+    }
+  } else if (!strncmp(f, "cast", 4)) {
+    for (int i = 0; i < cnt; i++) {
+      const int rt = n->type;
+      if (rt == T_F64) out->v[i].d = t0 == T_F32 ? (double)a[0].v[i].f : (double)a[0].v[i].i;
+      else if (rt == T_F32) out->v[i].f = t0 == T_F64 ? (float)a[0].v[i].d : (float)a[0].v[i].i;
+      else if (is_float(t0)) {
+        double x = t0 == T_F64 ? a[0].v[i].d : (double)a[0].v[i].f;
+        out->v[i].i = rt == T_I32 ? sat_i32(rnd(x)) : sat_i64(rnd(x));
+      } else if (rt == T_DATE64 && t0 == T_DATE32) out->v[i].i = a[0].v[i].i * MS_DAY;
+      else if (rt == T_DATE32 && t0 == T_DATE64) out->v[i].i = floor_div(a[0].v[i].i, MS_DAY);
+      else if (rt == T_DATE64 && t0 == T_TS) out->v[i].i = floor_div(a[0].v[i].i, MS_DAY) * MS_DAY;
+      else out->v[i].i = wrap_int(rt, a[0].v[i].u);
+    }
+  } else if (!strcmp(f, "cbrt") || !strcmp(f, "exp") || !strcmp(f, "log10") || !strcmp(f, "sqrt") ||
+             !strcmp(f, "floor") || !strcmp(f, "ceil") || !strcmp(f, "round") || !strcmp(f, "truncate") ||
+             (!strcmp(f, "log") && n->nargs == 1)) {
+    for (int i = 0; i < cnt; i++) {
+      double x = a[0].v[i].d;
+      out->v[i].d = !strcmp(f, "cbrt") ? cbrt(x) : !strcmp(f, "exp") ? exp(x) : !strcmp(f, "log10") ? log10(x)
+                  : !strcmp(f, "sqrt") ? sqrt(x) : !strcmp(f, "floor") ? floor(x) : !strcmp(f, "ceil") ? ceil(x)
+                  : !strcmp(f, "round") ? round(x) : !strcmp(f, "truncate") ? trunc(x) : log(x);
+    }
+  } else if (!strcmp(f, "power") || !strcmp(f, "pow")) {
+    for (int i = 0; i < cnt; i++) out->v[i].d = pow(a[0].v[i].d, a[1].v[i].d);
+  } else if (!strcmp(f, "log") && n->nargs == 2) {
+    for (int i = 0; i < cnt; i++) {
+      int live = out->valid[i] && (!active || active[i]);
+      if (!live) { out->v[i].d = 0; continue; }
+      double lb = log(a[0].v[i].d);
+      if (lb == 0) { c->err |= 1; out->v[i].d = 0; } else out->v[i].d = log(a[1].v[i].d) / lb;
+    }
+  } else if (!strncmp(f, "hash", 4)) {
+    int is64 = strstr(f, "64") != NULL;
+    for (int i = 0; i < cnt; i++) {
+      int64_t seed = 0;
+      if (n->nargs == 2) seed = a[1].valid[i] ? a[1].v[i].i : 0;
+      uint64_t bits = dbits(as_double(t0, &a[0], i));
+      if (is64) out->v[i].i = a[0].valid[i] ? murmur3_64(bits, (int32_t)seed) : seed;
+      else out->v[i].i = a[0].valid[i] ? murmur3_32(bits, (int32_t)seed) : (int32_t)seed;
+      out->valid[i] = 1;
+    }
+  } else if (!strncmp(f, "extract", 7)) {
+    const char* part = f + 7;
+    for (int i = 0; i < cnt; i++) {
+      int64_t ms = t0 == T_TIME32 ? a[0].v[i].i : to_millis(t0, a[0].v[i].i);
+      int64_t days = floor_div(ms, MS_DAY), tod = floor_mod(ms, MS_DAY), y;
+      int m, d;
+      civil_from_days(days, &y, &m, &d);
+      int64_t r = 0;
+      if (!strcmp(part, "Year")) r = y;
+      else if (!strcmp(part, "Month")) r = m;
+      else if (!strcmp(part, "Day")) r = d;
+      else if (!strcmp(part, "Quarter")) r = (m - 1) / 3 + 1;
+      else if (!strcmp(part, "Doy")) r = days - days_from_civil(y, 1, 1) + 1;
+      else if (!strcmp(part, "Dow")) r = floor_mod(days + 4, 7) + 1;
+      else if (!strcmp(part, "Hour")) r = tod / 3600000;
+      else if (!strcmp(part, "Minute")) r = (tod / 60000) % 60;
+      else if (!strcmp(part, "Second")) r = (tod / 1000) % 60;
+      else if (!strcmp(part, "Epoch")) r = floor_div(ms, 1000);
+      else if (!strcmp(part, "Decade")) r = y / 10;
+      else if (!strcmp(part, "Century")) r = (y - 1) / 100 + 1;
+      else if (!strcmp(part, "Millennium")) r = (y - 1) / 1000 + 1;
+      out->v[i].i = r;
+    }
+  } else if (!strncmp(f, "timestampadd", 12)) {
+    const char* unit = f + 12;
+    for (int i = 0; i < cnt; i++) {
+      int64_t k = a[0].v[i].i, v = a[1].v[i].i, r;
+      if (!strcmp(unit, "Second")) r = v + k * 1000;
+      else if (!strcmp(unit, "Minute")) r = v + k * 60000;
+      else if (!strcmp(unit, "Hour")) r = v + k * 3600000;
+      else if (!strcmp(unit, "Day")) r = v + k * MS_DAY;
+      else if (!strcmp(unit, "Week")) r = v + k * 7 * MS_DAY;
+      else if (!strcmp(unit, "Month")) r = add_months(v, k);
+      else if (!strcmp(unit, "Quarter")) r = add_months(v, k * 3);
+      else r = add_months(v, k * 12);
+      out->v[i].i = r;
+    }
+  } else if (!strcmp(f, "date_add") || !strcmp(f, "date_sub")) {
+    int sign = f[5] == 'a' ? 1 : -1;
+    for (int i = 0; i < cnt; i++) out->v[i].i = a[0].v[i].i + sign * a[1].v[i].i * MS_DAY;
+  } else if (!strncmp(f, "timestampdiff", 13)) {
+    const char* unit = f + 13;
+    int64_t div = !strcmp(unit, "Second") ? 1000 : !strcmp(unit, "Minute") ? 60000
+                : !strcmp(unit, "Hour") ? 3600000 : !strcmp(unit, "Day") ? MS_DAY : 7 * MS_DAY;
+    for (int i = 0; i < cnt; i++) out->v[i].i = (int32_t)((a[1].v[i].i - a[0].v[i].i) / div);
+  } else if (!strcmp(f, "datediff") || !strcmp(f, "date_diff")) {
+    for (int i = 0; i < cnt; i++) {
+      if (t0 == T_DATE32) out->v[i].i = (int32_t)((uint32_t)a[0].v[i].i - (uint32_t)a[1].v[i].i);
+      else out->v[i].i = (int32_t)(floor_div(a[0].v[i].i, MS_DAY) - floor_div(a[1].v[i].i, MS_DAY));
+    }
+  } else {
+    fprintf(stderr, "gdv_oracle: unknown function %s\n", f);
+    c->err |= 0x100;
+    for (int i = 0; i < cnt; i++) { out->v[i].i = 0; out->valid[i] = 0; }
+  }
+  free(a);
+}
+
+static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active, vec* out) {
+  switch (n->kind) {
+    case 'F':
+      load_column(&c->cols[n->col], row0, cnt, out);
+      return;
+    case 'L':
+      out->type = n->type;
+      for (int i = 0; i < cnt; i++) {
+        out->valid[i] = !n->is_null;
+        if (n->type == T_F32) { uint32_t b = (uint32_t)n->lo; memcpy(&out->v[i].f, &b, 4); }
+        else out->v[i].u = n->lo;
+        if (n->type != T_F32 && n->type != T_F64) out->v[i].i = wrap_int(n->type, n->lo);
+      }
+      return;
+    case 'C':
+      eval_function(n, c, row0, cnt, active, out);
+      return;
+    case 'I': {
+      /* a null condition takes the else branch; branches see their own "active" rows so a
+         guarded divide does not raise on the rows the guard excludes */
+      vec* cnd = (vec*)malloc(sizeof(vec) * 3);
+      vec *th = cnd + 1, *el = cnd + 2;
+      uint8_t act_t[CHUNK], act_e[CHUNK];
+      eval(n->args[0], c, row0, cnt, active, cnd);
+      for (int i = 0; i < cnt; i++) {
+        int take = cnd->valid[i] && cnd->v[i].i;
+        int live = !active || active[i];
+        act_t[i] = (uint8_t)(live && take);
+        act_e[i] = (uint8_t)(live && !take);
+      }
+      eval(n->args[1], c, row0, cnt, act_t, th);
+      eval(n->args[2], c, row0, cnt, act_e, el);
+      out->type = n->type;
+      for (int i = 0; i < cnt; i++) {
+        int take = cnd->valid[i] && cnd->v[i].i;
+        out->v[i] = take ? th->v[i] : el->v[i];
+        out->valid[i] = take ? th->valid[i] : el->valid[i];
+      }
+      free(cnd);
+      return;
+    }
+    case 'A': case 'O': {
+      /* SQL 3-valued logic, left-to-right short circuit */
+      const int is_and = n->kind == 'A';
+      uint8_t decided[CHUNK], all_valid[CHUNK], act[CHUNK];
+      for (int i = 0; i < cnt; i++) { decided[i] = 0; all_valid[i] = 1; act[i] = !active || active[i]; }
+      vec* ch = (vec*)malloc(sizeof(vec));
+      for (int k = 0; k < n->nargs; k++) {
+        eval(n->args[k], c, row0, cnt, act, ch);
+        for (int i = 0; i < cnt; i++) {
+          int hit = ch->valid[i] && (is_and ? !ch->v[i].i : ch->v[i].i);
+          decided[i] |= (uint8_t)hit;
+          all_valid[i] &= ch->valid[i];
+          act[i] = (uint8_t)((!active || active[i]) && !decided[i]);
+        }
+      }
+      free(ch);
+      out->type = T_BOOL;
+      for (int i = 0; i < cnt; i++) {
+        out->valid[i] = (uint8_t)(decided[i] || all_valid[i]);
+        out->v[i].i = is_and ? (!decided[i] && all_valid[i]) : decided[i];
+      }
+      return;
+    }
+    case 'N': {
+      vec* x = (vec*)malloc(sizeof(vec));
+      eval(n->args[0], c, row0, cnt, active, x);
+      out->type = T_BOOL;
+      const int w = width_of(x->type);
+      const uint64_t mask = w >= 8 ? ~0ull : ((1ull << (8 * w)) - 1);
+      for (int i = 0; i < cnt; i++) {
+        uint64_t bits = x->v[i].u & mask;
+        if (x->type == T_F32) { uint32_t b; memcpy(&b, &x->v[i].f, 4); bits = b; }
+        int hit = 0;
+        for (int k = 0; k < n->nvals; k++) hit |= (n->vals[k] & mask) == bits;
+        out->v[i].i = hit;
+        out->valid[i] = x->valid[i];
+      }
+      free(x);
+      return;
+    }
+  }
+}
+
+static void store_chunk(int type, const vec* r, int64_t row0, int cnt, void* data, uint8_t* validity) {
+  for (int i = 0; i < cnt; i++) {
+    int64_t row = row0 + i;
+    if (r->valid[i]) validity[row >> 3] |= (uint8_t)(1u << (row & 7));
+    switch (type) {
+      case T_BOOL: if (r->v[i].i) ((uint8_t*)data)[row >> 3] |= (uint8_t)(1u << (row & 7)); break;
+      case T_I8: case T_U8: ((uint8_t*)data)[row] = (uint8_t)r->v[i].u; break;
+      case T_I16: case T_U16: ((uint16_t*)data)[row] = (uint16_t)r->v[i].u; break;
+      case T_I32: case T_U32: case T_DATE32: case T_TIME32: ((uint32_t*)data)[row] = (uint32_t)r->v[i].u; break;
+      case T_F32: ((float*)data)[row] = r->v[i].f; break;
+      case T_F64: ((double*)data)[row] = r->v[i].d; break;
+      default: ((uint64_t*)data)[row] = r->v[i].u; break;
+    }
+  }
+}
+
+typedef struct {
+  const node* root;
+  const or_column* cols;
+  int ncols;
+  int64_t row_lo, row_hi;
+  void* data;
+  uint8_t* validity;
+  int err;
+} job;
+
+static void* run_job(void* arg) {
+  job* j = (job*)arg;
+  ctx c = {j->cols, j->ncols, 0};
+  vec* r = (vec*)malloc(sizeof(vec));
+  for (int64_t row = j->row_lo; row < j->row_hi; row += CHUNK) {
+    int cnt = (int)((j->row_hi - row) < CHUNK ? (j->row_hi - row) : CHUNK);
+    eval(j->root, &c, row, cnt, NULL, r);
+    store_chunk(j->root->type, r, row, cnt, j->data, j->validity);
+  }
+  free(r);
+  j->err = c.err;
+  return NULL;
+}
+
+/*
+ * Evaluates ONE expression over n rows (the reference's per-expression row loop).
+ * out_data / out_validity must be zero-initialised by the caller (bits are OR-ed in).
+ * threads > 1 splits the row range at multiples of CHUNK (bitmap bytes never shared).
+ * Returns 0, or an error bit mask (1 = divide by zero, 0x100 = unknown function, 0x200 = parse).
+ */
+int gdv_oracle_project(const char* program, const or_column* cols, int ncols, int64_t n,
+                       void* out_data, uint8_t* out_validity, int threads) {
+  const char* p = program;
+  node* root = parse(&p, cols);
+  if (!root) return 0x200;
+  if (threads < 1) threads = 1;
+  int64_t chunks = (n + CHUNK - 1) / CHUNK;
+  if (threads > chunks) threads = (int)(chunks ? chunks : 1);
+  job* jobs = (job*)calloc(threads, sizeof(job));
+  pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
+  int64_t per = (chunks + threads - 1) / threads * CHUNK;
+  int err = 0;
+  for (int t = 0; t < threads; t++) {
+    int64_t lo = per * t, hi = lo + per;
+    if (lo > n) lo = n;
+    if (hi > n) hi = n;
+    jobs[t] = (job){root, cols, ncols, lo, hi, out_data, out_validity, 0};
+    if (threads == 1) run_job(&jobs[t]);
+    else pthread_create(&th[t], NULL, run_job, &jobs[t]);
+  }
+  for (int t = 0; t < threads; t++) {
+    if (threads > 1) pthread_join(th[t], NULL);
+    err |= jobs[t].err;
+  }
+  free(jobs);
+  free(th);
+  free_node(root);
+  return err;
+}
+
+/*
+ * SelectionVector::PopulateFromBitMap restated: walk the AND of the value and validity
+ * bitmaps 64 bits at a time, emit the position of every set bit in ascending order.
+ * index_bytes = 2 / 4 / 8.  Returns the number of slots, or -1 if max_slots is exceeded.
+ */
+int64_t gdv_oracle_bitmap_to_selection(const uint8_t* value_bits, const uint8_t* validity_bits,
+                                       int64_t n, int index_bytes, void* out, int64_t max_slots) {
+  int64_t k = 0;
+  for (int64_t base = 0; base < n; base += 64) {
+    uint64_t w = 0;
+    int lim = (int)((n - base) < 64 ? (n - base) : 64);
+    for (int b = 0; b < lim; b++) {
+      int64_t r = base + b;
+      if (get_bit(value_bits, r) && get_bit(validity_bits, r)) w |= 1ull << b;
+    }
+    while (w) {
+      int i = __builtin_ctzll(w);
+      if (k >= max_slots) return -1;
+      int64_t pos = base + i;
+      if (index_bytes == 2) ((uint16_t*)out)[k] = (uint16_t)pos;
+      else if (index_bytes == 4) ((uint32_t*)out)[k] = (uint32_t)pos;
+      else ((uint64_t*)out)[k] = (uint64_t)pos;
+      k++;
+      w &= w - 1;
+    }
+  }
+  return k;
+}

@@ -1,0 +1,312 @@
+"""HIP path vs CPU oracle on identical seeded batches (bit-exact), through the C ABI.
+
+Covers the hot path of SURVEY.md §8a: fused projection with validity-word merging, if/else
+and three-valued AND/OR (per-lane validity), bool outputs (ballot-packed), array offsets
+(misaligned bitmaps), ragged lengths around the 64-row word and the workgroup tile, null
+densities 0/10/50/100 %, IEEE specials, integer wrap, filter -> selection vector for all
+three index widths, selection-vector-driven projection, and execution errors.
+"""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import gandiva_amd as gandiva
+from gandiva_amd import workloads as W
+from oracle import oracle
+from helpers import assert_bit_exact, assert_within_ulp, random_array
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [1, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4099, 100003]
+
+
+def _batch(rng, types, n, null_fraction, names=None):
+    names = names or [chr(ord('a') + i) for i in range(len(types))]
+    cols = [random_array(rng, t, n, null_fraction) for t in types]
+    return pa.RecordBatch.from_arrays(cols, names=names)
+
+
+def _check_project(exprs, batch, sel_mode="NONE"):
+    proj = gandiva.make_projector(batch.schema, exprs, pa.default_memory_pool(), sel_mode)
+    got = proj.evaluate(batch)
+    want = oracle.project(exprs, batch)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert_bit_exact(g, w, f"expr {i}: {exprs[i]}")
+    return got
+
+
+# ------------------------------------------------------------------ BASELINE configs
+
+@pytest.mark.parametrize("n", [1 << 10, (1 << 16) + 13])
+def test_c1_int32_plumbing(n):
+    _check_project(W.c1_expressions(), W.c1_batch(n))
+
+
+@pytest.mark.parametrize("n", LENGTHS + [1 << 20])
+def test_c2_ten_float64_expressions(n):
+    _check_project(W.c2_expressions(), W.c2_batch(n))
+
+
+@pytest.mark.parametrize("n", LENGTHS + [(1 << 20) + 77])
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_c3_filter(n, nulls):
+    batch = W.c3_batch(n, nulls)
+    cond = W.c3_condition()
+    flt = gandiva.make_filter(batch.schema, cond)
+    for dtype in ("int32", "int64"):
+        got = flt.evaluate(batch, pa.default_memory_pool(), dtype).to_array()
+        want = oracle.filter_indices(cond, batch, dtype)
+        assert got.equals(want), f"{dtype}: {len(got)} vs {len(want)} slots"
+    if n <= 65536:
+        got = flt.evaluate(batch, pa.default_memory_pool(), "int16").to_array()
+        assert got.equals(oracle.filter_indices(cond, batch, "int16"))
+
+
+# ------------------------------------------------------------------ arithmetic over all types
+
+NUMERIC = [pa.int8(), pa.int16(), pa.int32(), pa.int64(), pa.uint8(), pa.uint16(), pa.uint32(),
+           pa.uint64(), pa.float32(), pa.float64()]
+
+
+@pytest.mark.parametrize("t", NUMERIC, ids=str)
+@pytest.mark.parametrize("nulls", [0.0, 0.1, 0.5, 1.0])
+def test_arithmetic_and_compare(t, nulls):
+    rng = np.random.default_rng(hash((str(t), nulls)) & 0xffff)
+    n = 2999
+    batch = _batch(rng, [t, t], n, nulls)
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = []
+    for name in ("add", "subtract", "multiply"):
+        exprs.append(b.make_expression(b.make_function(name, [fa, fb], t), pa.field(name, t)))
+    for name in ("equal", "not_equal", "less_than", "less_than_or_equal_to", "greater_than",
+                 "greater_than_or_equal_to"):
+        exprs.append(b.make_expression(b.make_function(name, [fa, fb], pa.bool_()),
+                                       pa.field(name, pa.bool_())))
+    _check_project(exprs, batch)
+
+
+@pytest.mark.parametrize("offset", [1, 7, 8, 63, 64, 65, 500])
+def test_array_offsets(offset):
+    """Sliced batches: validity bits start mid-word, values pointers are only 8-byte aligned."""
+    rng = np.random.default_rng(offset)
+    full = _batch(rng, [pa.float64(), pa.float64(), pa.int32(), pa.bool_()], 3000, 0.2)
+    batch = full.slice(offset, 1717)
+    b = gandiva.TreeExprBuilder()
+    f = [b.make_field(batch.schema.field(i)) for i in range(4)]
+    e0 = b.make_expression(b.make_function("add", [f[0], f[1]], pa.float64()), pa.field("s", pa.float64()))
+    k = b.make_literal(3, pa.int32())
+    e1 = b.make_expression(b.make_function("multiply", [f[2], k], pa.int32()), pa.field("m", pa.int32()))
+    e2 = b.make_expression(b.make_function("not", [f[3]], pa.bool_()), pa.field("n", pa.bool_()))
+    e3 = b.make_expression(b.make_if(f[3], f[0], f[1], pa.float64()), pa.field("i", pa.float64()))
+    _check_project([e0, e1, e2, e3], batch)
+
+
+@pytest.mark.parametrize("n", [5, 64, 1000, 70001])
+def test_if_else_and_boolean_3vl(n):
+    rng = np.random.default_rng(n)
+    batch = _batch(rng, [pa.int64(), pa.int64(), pa.float64(), pa.bool_()], n, 0.3)
+    b = gandiva.TreeExprBuilder()
+    a, c, d, z = (b.make_field(batch.schema.field(i)) for i in range(4))
+    zero = b.make_literal(0, pa.int64())
+    gt = b.make_function("greater_than", [a, c], pa.bool_())
+    lt = b.make_function("less_than", [a, zero], pa.bool_())
+    nested = b.make_if(gt, a, b.make_if(lt, c, zero, pa.int64()), pa.int64())
+    exprs = [
+        b.make_expression(nested, pa.field("nested", pa.int64())),
+        b.make_expression(b.make_and([gt, z]), pa.field("and", pa.bool_())),
+        b.make_expression(b.make_or([gt, z, lt]), pa.field("or", pa.bool_())),
+        b.make_expression(b.make_and([b.make_or([gt, z]), b.make_function("not", [lt], pa.bool_())]),
+                          pa.field("mix", pa.bool_())),
+        b.make_expression(b.make_function("isnull", [d], pa.bool_()), pa.field("isnull", pa.bool_())),
+        b.make_expression(b.make_function("isnotnull", [a], pa.bool_()), pa.field("isnotnull", pa.bool_())),
+        b.make_expression(b.make_function("is_distinct_from", [a, c], pa.bool_()), pa.field("idf", pa.bool_())),
+        b.make_expression(b.make_if(b.make_function("isnull", [a], pa.bool_()), c, a, pa.int64()),
+                          pa.field("coalesce", pa.int64())),
+        b.make_expression(b.make_null(pa.int64()), pa.field("null", pa.int64())),
+    ]
+    _check_project(exprs, batch)
+
+
+def test_casts_hash_and_dates():
+    rng = np.random.default_rng(11)
+    n = 5000
+    batch = _batch(rng, [pa.int32(), pa.int64(), pa.float32(), pa.float64(), pa.date64(),
+                         pa.timestamp('ms'), pa.date32()], n, 0.15)
+    b = gandiva.TreeExprBuilder()
+    i32, i64, f32, f64, d64, ts, d32 = (b.make_field(batch.schema.field(i)) for i in range(7))
+
+    def ex(name, args, t):
+        return b.make_expression(b.make_function(name, args, t), pa.field(name + str(len(exprs)), t))
+    exprs = []
+    exprs += [ex("castBIGINT", [i32], pa.int64()), ex("castINT", [i64], pa.int32()),
+              ex("castFLOAT4", [i32], pa.float32()), ex("castFLOAT4", [i64], pa.float32()),
+              ex("castFLOAT4", [f64], pa.float32()), ex("castFLOAT8", [i32], pa.float64()),
+              ex("castFLOAT8", [i64], pa.float64()), ex("castFLOAT8", [f32], pa.float64()),
+              ex("castBIGINT", [f64], pa.int64()), ex("castINT", [f32], pa.int32())]
+    for t, node in ((pa.int32(), i32), (pa.int64(), i64), (pa.float32(), f32), (pa.float64(), f64),
+                    (pa.date64(), d64), (pa.timestamp('ms'), ts)):
+        exprs += [ex("hash32", [node], pa.int32()), ex("hash64", [node], pa.int64()),
+                  ex("hash", [node], pa.int32())]
+    exprs += [ex("hash64", [f64, i64], pa.int64()), ex("hash32", [i64, i32], pa.int32())]
+    for part in ("Year", "Month", "Day", "Quarter", "Doy", "Dow", "Hour", "Minute", "Second",
+                 "Epoch", "Decade", "Century", "Millennium"):
+        exprs += [ex("extract" + part, [d64], pa.int64()), ex("extract" + part, [ts], pa.int64())]
+    for part in ("Year", "Month", "Day", "Doy", "Dow"):
+        exprs.append(ex("extract" + part, [d32], pa.int64()))
+    seven = b.make_literal(7, pa.int64())
+    for unit in ("Second", "Minute", "Hour", "Day", "Week", "Month", "Quarter", "Year"):
+        exprs.append(ex("timestampadd" + unit, [seven, ts], pa.timestamp('ms')))
+    exprs += [ex("date_add", [d64, seven], pa.date64()), ex("date_sub", [ts, seven], pa.timestamp('ms')),
+              ex("timestampdiffDay", [ts, ts], pa.int32()), ex("datediff", [d64, d64], pa.int32()),
+              ex("castDATE", [ts], pa.date64()), ex("castDATE", [d32], pa.date64())]
+    d32b = b.make_literal(10561, pa.date32())  # 1998-12-01
+    exprs.append(ex("datediff", [d32b, d32], pa.int32()))
+    _check_project(exprs, batch)
+
+
+def test_math_functions_within_one_ulp():
+    """exp/log/pow/cbrt come from the device math library: <= 1 ulp vs the host libm
+    (north_star tolerance for floating point); everything else in this file is bit-exact."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    x = pa.array(rng.random(n) * 100 + 0.01)
+    y = pa.array(rng.random(n) * 3)
+    batch = pa.RecordBatch.from_arrays([x, y], names=["x", "y"])
+    b = gandiva.TreeExprBuilder()
+    fx, fy = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    f64 = pa.float64()
+    exprs = [b.make_expression(b.make_function(nm, [fx], f64), pa.field(nm, f64))
+             for nm in ("exp", "log", "log10", "cbrt", "sqrt")]
+    exprs[0] = b.make_expression(b.make_function("exp", [fy], f64), pa.field("exp", f64))
+    exprs.append(b.make_expression(b.make_function("power", [fx, fy], f64), pa.field("pow", f64)))
+    proj = gandiva.make_projector(batch.schema, exprs, pa.default_memory_pool())
+    got = proj.evaluate(batch)
+    want = oracle.project(exprs, batch)
+    for g, w, e in zip(got, want, exprs):
+        assert_within_ulp(g, w, 1, str(e))
+
+
+def test_divide_by_zero_is_an_execution_error_but_guards_work():
+    a = pa.array([10, 20, 30, None], type=pa.int64())
+    z = pa.array([2, 0, 5, 0], type=pa.int64())
+    batch = pa.RecordBatch.from_arrays([a, z], names=["a", "z"])
+    b = gandiva.TreeExprBuilder()
+    fa, fz = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    div = b.make_function("divide", [fa, fz], pa.int64())
+    proj = gandiva.make_projector(batch.schema, [b.make_expression(div, pa.field("q", pa.int64()))],
+                                  pa.default_memory_pool())
+    with pytest.raises(pa.lib.ArrowException, match="divide by zero"):
+        proj.evaluate(batch)
+    with pytest.raises(oracle.OracleError, match="divide by zero"):
+        oracle.project([b.make_expression(div, pa.field("q", pa.int64()))], batch)
+    # `if (z != 0) a / z else -1` must not raise: the divide only runs on the taken branch
+    zero = b.make_literal(0, pa.int64())
+    guard = b.make_function("not_equal", [fz, zero], pa.bool_())
+    safe = b.make_if(guard, div, b.make_literal(-1, pa.int64()), pa.int64())
+    _check_project([b.make_expression(safe, pa.field("q", pa.int64()))], batch)
+    # a null divisor row does not raise either (functions that can fail run on valid rows only)
+    z2 = pa.array([2, None, 5, 1], type=pa.int64())
+    _check_project([b.make_expression(div, pa.field("q", pa.int64()))],
+                   pa.RecordBatch.from_arrays([a, z2], names=["a", "z"]))
+
+
+@pytest.mark.parametrize("n", [10, 1000, 100000])
+@pytest.mark.parametrize("dtype,mode", [("int16", "UINT16"), ("int32", "UINT32"), ("int64", "UINT64")])
+def test_filter_then_project_with_selection_vector(n, dtype, mode):
+    if dtype == "int16" and n > 65536:
+        pytest.skip("uint16 selection vectors address at most 65536 rows")
+    rng = np.random.default_rng(n)
+    batch = _batch(rng, [pa.int32(), pa.int32(), pa.float64()], n, 0.2)
+    b = gandiva.TreeExprBuilder()
+    a, c, d = (b.make_field(batch.schema.field(i)) for i in range(3))
+    cond = b.make_condition(b.make_function("greater_than", [a, c], pa.bool_()))
+    e0 = b.make_expression(b.make_if(b.make_function("less_than", [a, c], pa.bool_()), a, c, pa.int32()),
+                           pa.field("m", pa.int32()))
+    e1 = b.make_expression(b.make_function("multiply", [d, d], pa.float64()), pa.field("sq", pa.float64()))
+    e2 = b.make_expression(b.make_function("isnull", [d], pa.bool_()), pa.field("nul", pa.bool_()))
+    flt = gandiva.make_filter(batch.schema, cond)
+    proj = gandiva.make_projector(batch.schema, [e0, e1, e2], pa.default_memory_pool(), mode)
+    sel = flt.evaluate(batch, pa.default_memory_pool(), dtype)
+    want_sel = oracle.filter_indices(cond, batch, dtype)
+    assert sel.to_array().equals(want_sel)
+    if sel.num_slots == 0:
+        return
+    got = proj.evaluate(batch, sel)
+    want = oracle.project([e0, e1, e2], oracle.take_rows(batch, want_sel.to_numpy()))
+    for g, w in zip(got, want):
+        assert_bit_exact(g, w)
+
+
+def test_in_expression_large_list():
+    rng = np.random.default_rng(3)
+    batch = _batch(rng, [pa.int64(), pa.int32()], 10000, 0.1)
+    b = gandiva.TreeExprBuilder()
+    a, c = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    big = [int(v) for v in rng.integers(-1000, 1000, 300)]
+    small = [-3, 0, 7]
+    for node, vals, t in ((a, big, pa.int64()), (c, small, pa.int32()), (c, big, pa.int32())):
+        cond = b.make_condition(b.make_in_expression(node, vals, t))
+        got = gandiva.make_filter(batch.schema, cond).evaluate(batch, None).to_array()
+        assert got.equals(oracle.filter_indices(cond, batch, "int32"))
+
+
+def test_device_resident_batches_match_host_path():
+    """Zero-copy HBM path == staged host path == oracle."""
+    import torch
+    n = 200003
+    batch = W.c2_batch(n)
+    exprs = W.c2_expressions()
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    dbatch = gandiva.DeviceBatch.from_arrow(batch)
+    outs = proj.evaluate_device(dbatch)
+    torch.cuda.synchronize()
+    want = oracle.project(exprs, batch)
+    for o, w in zip(outs, want):
+        assert_bit_exact(o.to_arrow(), w)
+    cond = W.c3_condition()
+    b3 = W.c3_batch(n, 0.1)
+    flt = gandiva.make_filter(b3.schema, cond)
+    sel = flt.evaluate_device(gandiva.DeviceBatch.from_arrow(b3), "int32")
+    assert sel.to_array().equals(oracle.filter_indices(cond, b3, "int32"))
+
+
+def test_full_size_properties_c2():
+    """BASELINE C2 at a size the oracle cannot hold: size-independent properties.
+    (a) linearity of validity: popcount(valid(e0)) == popcount(valid(a) & valid(b));
+    (b) e0 + e1 == 2a bit-exactly where all valid and finite (a+b + a-b need not be exact,
+        so instead check the exact identities) e2 == a*b recomputed by torch in fp64;
+    (c) a prefix slice copied to the host is bit-exact against the oracle."""
+    import torch
+    n = 1 << 26
+    dbatch = W.c2_device_batch(n)
+    exprs = W.c2_expressions()
+    proj = gandiva.make_projector(W.c2_schema(), exprs, None)
+    outs = proj.evaluate_device(dbatch)
+    torch.cuda.synchronize()
+    a = dbatch.columns[0].data.view(torch.float64)
+    bcol = dbatch.columns[1].data.view(torch.float64)
+    e0 = outs[0].data.view(torch.float64)[:n]
+    e2 = outs[2].data.view(torch.float64)[:n]
+    assert torch.equal(e0.view(torch.int64), (a + bcol).view(torch.int64))
+    assert torch.equal(e2.view(torch.int64), (a * bcol).view(torch.int64))
+    nb = (n + 7) // 8
+    va, vb = dbatch.columns[0].validity[:nb], dbatch.columns[1].validity[:nb]
+    assert torch.equal(outs[0].validity[:nb], va & vb)
+    assert torch.equal(outs[1].validity[:nb], va & vb)
+    vc, vd = dbatch.columns[2].validity[:nb], dbatch.columns[3].validity[:nb]
+    assert torch.equal(outs[9].validity[:nb], va & vb & vc & vd)
+    # prefix vs oracle
+    m = 100000
+    host_cols = []
+    for c in dbatch.columns:
+        host_cols.append(pa.Array.from_buffers(pa.float64(), m, [
+            pa.py_buffer(c.validity[:(m + 7) // 8 + 8].cpu().numpy()),
+            pa.py_buffer(c.data[:m * 8].cpu().numpy())]))
+    hb = pa.RecordBatch.from_arrays(host_cols, schema=W.c2_schema())
+    want = oracle.project(exprs, hb)
+    for o, w in zip(outs, want):
+        got = pa.Array.from_buffers(pa.float64(), m, [
+            pa.py_buffer(o.validity[:(m + 7) // 8 + 8].cpu().numpy()),
+            pa.py_buffer(o.data[:m * 8].cpu().numpy())])
+        assert_bit_exact(got, w)
