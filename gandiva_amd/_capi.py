@@ -103,6 +103,14 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C gandiva_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`. gandiva_amd has no "
                 "CPU/Python fallback.")
+        # ONE HIP runtime per process: PyTorch wheels bundle their own libamdhip64 (same
+        # SONAME as /opt/rocm's).  If torch is going to be used in this process it must be
+        # loaded first, so this library binds to the runtime torch already brought in;
+        # loading ours first would leave two runtimes and torch then finds "no HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, restype, argtypes in PROTOTYPES:
             fn = getattr(l, name)  # AttributeError = header/library mismatch

@@ -176,14 +176,21 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
         }
       }
     }
-    if (plan.input_needs_validity[k] && c.validity != nullptr) {
-      if (c.validity_size < BytesForBits(c.offset + num_rows))
-        return Status::Invalid("column '" + name + "': validity buffer too small");
+    if (plan.input_needs_validity[k]) {
       HostBitmap b;
-      if (mem == MemKind::kHost) {
-        GDV_RETURN_NOT_OK(StageBitmap(c.validity, c.offset, num_rows, stream, st, &b));
+      if (c.validity == nullptr) {
+        // no validity buffer = no nulls: bind the one-word all-ones bitmap (index clamped)
+        GDV_RETURN_NOT_OK(Runtime::Get().AllOnesWord(&b.p));
+        b.shift = 0;
+        b.nwords = 1;
       } else {
-        b = FoldBitmap(c.validity, c.validity_size, c.offset);
+        if (c.validity_size < BytesForBits(c.offset + num_rows))
+          return Status::Invalid("column '" + name + "': validity buffer too small");
+        if (mem == MemKind::kHost) {
+          GDV_RETURN_NOT_OK(StageBitmap(c.validity, c.offset, num_rows, stream, st, &b));
+        } else {
+          b = FoldBitmap(c.validity, c.validity_size, c.offset);
+        }
       }
       args->SetInValid(static_cast<int>(k), b);
     }

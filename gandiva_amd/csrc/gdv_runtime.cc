@@ -243,6 +243,19 @@ void Runtime::TrimPool() {
   for (auto& b : blocks) (void)hipFree(b.second);
 }
 
+Status Runtime::AllOnesWord(const uint64_t** ptr) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  std::lock_guard<std::mutex> g(mu_);
+  if (all_ones_ == nullptr) {
+    void* p = nullptr;
+    GDV_HIP_RETURN_NOT_OK(hipMalloc(&p, 256));
+    GDV_HIP_RETURN_NOT_OK(hipMemset(p, 0xff, 256));
+    all_ones_ = static_cast<uint64_t*>(p);
+  }
+  *ptr = all_ones_;
+  return Status::OK();
+}
+
 Status Runtime::Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
                        size_t arg_bytes, hipStream_t stream) {
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),

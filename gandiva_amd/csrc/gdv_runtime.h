@@ -53,6 +53,10 @@ class Runtime {
   void Free(void* ptr);
   void TrimPool();
 
+  // Device-resident bitmap word with all 64 bits set: what a column WITHOUT a validity
+  // (or with an elided all-valid) buffer is bound to, so kernels never branch on "has nulls".
+  Status AllOnesWord(const uint64_t** ptr);
+
   Status Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
                 size_t arg_bytes, hipStream_t stream);
 
@@ -69,6 +73,7 @@ class Runtime {
   std::multimap<size_t, void*> free_blocks_;
   std::map<void*, size_t> live_blocks_;
   size_t cached_bytes_ = 0;
+  uint64_t* all_ones_ = nullptr;
   void Probe();
 };
 

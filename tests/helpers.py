@@ -34,10 +34,31 @@ def assert_bit_exact(got, want, what=""):
         bad = np.flatnonzero(gv != wv)
         raise AssertionError(f"{what}: validity differs at {len(bad)} rows, first {bad[:8]}")
     gb, wb = values_bits_np(got)[wv], values_bits_np(want)[wv]
+    if pa.types.is_floating(got.type):
+        # every NaN is the same value: sign and payload of a generated NaN are not part of
+        # IEEE-754 arithmetic semantics (x86 SSE yields -qNaN for inf-inf, CDNA4 +qNaN)
+        ft = np.float32 if pa.types.is_float32(got.type) else np.float64
+        gnan, wnan = np.isnan(gb.view(ft)), np.isnan(wb.view(ft))
+        if not np.array_equal(gnan, wnan):
+            bad = np.flatnonzero(gnan != wnan)
+            raise AssertionError(f"{what}: NaN-ness differs at {len(bad)} valid rows, first {bad[:8]}")
+        gb, wb = gb[~gnan], wb[~wnan]
     if not np.array_equal(gb, wb):
         bad = np.flatnonzero(gb != wb)
         raise AssertionError(f"{what}: values differ at {len(bad)} valid rows, first idx {bad[:8]}: "
                              f"{gb[bad[:4]]} vs {wb[bad[:4]]}")
+
+
+def ulp_distance(g, w):
+    """max distance in units of last place between two float64 numpy arrays."""
+    both_nan = np.isnan(g) & np.isnan(w)
+    gi = np.ascontiguousarray(g).view(np.int64)
+    wi = np.ascontiguousarray(w).view(np.int64)
+    gi = np.where(gi < 0, np.int64(-2**63) - gi, gi)
+    wi = np.where(wi < 0, np.int64(-2**63) - wi, wi)
+    d = np.abs(gi - wi)
+    d[both_nan] = 0
+    return int(d.max(initial=0))
 
 
 def assert_within_ulp(got, want, ulps=1, what=""):

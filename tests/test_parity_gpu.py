@@ -166,25 +166,37 @@ def test_casts_hash_and_dates():
 
 
 def test_math_functions_within_one_ulp():
-    """exp/log/pow/cbrt come from the device math library: <= 1 ulp vs the host libm
-    (north_star tolerance for floating point); everything else in this file is bit-exact."""
+    """exp/log/pow/cbrt come from math libraries on both sides (ROCm device libs / host
+    libm), so they are not bit-comparable with each other.  north_star's tolerance is 1 ulp:
+    the HIP result must be within 1 ulp of the correctly rounded value, computed here in x87
+    extended precision (numpy longdouble) and rounded once; the oracle (host libm) is held to
+    its own documented bound."""
+    from helpers import ulp_distance
     rng = np.random.default_rng(5)
     n = 20000
-    x = pa.array(rng.random(n) * 100 + 0.01)
-    y = pa.array(rng.random(n) * 3)
-    batch = pa.RecordBatch.from_arrays([x, y], names=["x", "y"])
+    xs = rng.random(n) * 100 + 0.01
+    ys = rng.random(n) * 3
+    batch = pa.RecordBatch.from_arrays([pa.array(xs), pa.array(ys)], names=["x", "y"])
     b = gandiva.TreeExprBuilder()
     fx, fy = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
     f64 = pa.float64()
-    exprs = [b.make_expression(b.make_function(nm, [fx], f64), pa.field(nm, f64))
-             for nm in ("exp", "log", "log10", "cbrt", "sqrt")]
-    exprs[0] = b.make_expression(b.make_function("exp", [fy], f64), pa.field("exp", f64))
-    exprs.append(b.make_expression(b.make_function("power", [fx, fy], f64), pa.field("pow", f64)))
+    lx, ly = xs.astype(np.longdouble), ys.astype(np.longdouble)
+    cases = [("exp", [fy], np.exp(ly)), ("log", [fx], np.log(lx)), ("log10", [fx], np.log10(lx)),
+             ("cbrt", [fx], np.cbrt(lx)), ("sqrt", [fx], np.sqrt(lx)),
+             ("power", [fx, fy], np.power(lx, ly))]
+    exprs = [b.make_expression(b.make_function(nm, args, f64), pa.field(nm, f64)) for nm, args, _ in cases]
     proj = gandiva.make_projector(batch.schema, exprs, pa.default_memory_pool())
     got = proj.evaluate(batch)
     want = oracle.project(exprs, batch)
-    for g, w, e in zip(got, want, exprs):
-        assert_within_ulp(g, w, 1, str(e))
+    report = {}
+    for (nm, _, exact), g, w in zip(cases, got, want):
+        ref = exact.astype(np.float64)
+        report[nm] = (ulp_distance(g.to_numpy(), ref), ulp_distance(w.to_numpy(), ref))
+    print("max ulp (hip, oracle) vs correctly rounded:", report)
+    for nm, (hip_ulp, cpu_ulp) in report.items():
+        assert hip_ulp <= 1, f"{nm}: HIP result {hip_ulp} ulp from the correctly rounded value"
+        # the host libm is not the product: glibc documents up to 4 ulp for cbrt
+        assert cpu_ulp <= 4, f"{nm}: oracle result {cpu_ulp} ulp from the correctly rounded value"
 
 
 def test_divide_by_zero_is_an_execution_error_but_guards_work():
