@@ -1,0 +1,213 @@
+"""Host-side behaviour of the API mirror and of the C-ABI boundary (no GPU needed).
+
+Pins from pyarrow/tests/test_gandiva.py: test_literals (:255-292), test_to_string
+(:376-393), test_rejects_none (:396-434), test_get_registered_function_signatures
+(:319-326); plus: every symbol include/gandiva_amd.h declares is exported, plans for every
+node kind compile to gfx950 code objects offline, and evaluation fails loudly (no CPU
+fallback) when there is no HIP device.
+"""
+import ctypes as C
+import os
+import re
+
+import pyarrow as pa
+import pytest
+
+import gandiva_amd as gandiva
+from gandiva_amd import _capi, gandiva as gg, workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    return _capi.lib().gdv_device_count() > 0
+
+
+def test_header_symbols_are_exported_and_declared():
+    text = open(os.path.join(ROOT, "include", "gandiva_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(gdv_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) > 40
+    lib = C.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in gandiva_amd.h but not exported"
+    assert declared == {p[0] for p in _capi.PROTOTYPES}, "ctypes prototypes out of sync with the header"
+    assert b"gandiva_amd" in _capi.lib().gdv_version()
+
+
+def test_literals():  # test_gandiva.py:255-292
+    builder = gandiva.TreeExprBuilder()
+    for v, t in [(True, pa.bool_()), (0, pa.uint8()), (1, pa.uint16()), (2, pa.uint32()),
+                 (3, pa.uint64()), (4, pa.int8()), (5, pa.int16()), (6, pa.int32()),
+                 (7, pa.int64()), (8.0, pa.float32()), (9.0, pa.float64()),
+                 ("hello", pa.string()), (b"world", pa.binary())]:
+        builder.make_literal(v, t)
+    for v, t in [(True, "bool"), (0, "uint8"), (1, "uint16"), (2, "uint32"), (3, "uint64"),
+                 (4, "int8"), (5, "int16"), (6, "int32"), (7, "int64"), (8.0, "float32"),
+                 (9.0, "float64"), ("hello", "string"), (b"world", "binary")]:
+        builder.make_literal(v, t)
+    with pytest.raises(TypeError):
+        builder.make_literal("hello", pa.int64())
+    with pytest.raises(TypeError):
+        builder.make_literal(True, None)
+
+
+def test_to_string():  # test_gandiva.py:376-393
+    builder = gandiva.TreeExprBuilder()
+    assert str(builder.make_literal(2.0, pa.float64())).startswith('(const double) 2 raw(')
+    assert str(builder.make_literal(2, pa.int64())) == '(const int64) 2'
+    assert str(builder.make_field(pa.field('x', pa.float64()))) == '(double) x'
+    assert str(builder.make_field(pa.field('y', pa.string()))) == '(string) y'
+    field_z = builder.make_field(pa.field('z', pa.bool_()))
+    func_node = builder.make_function('not', [field_z], pa.bool_())
+    assert str(func_node) == 'bool not((bool) z)'
+    field_y = builder.make_field(pa.field('y', pa.bool_()))
+    and_node = builder.make_and([func_node, field_y])
+    assert str(and_node) == 'bool not((bool) z) && (bool) y'
+    # not pinned by the reference tests, but stable renderings of the remaining node kinds
+    a = builder.make_field(pa.field('a', pa.int32()))
+    assert str(builder.make_if(func_node, a, a, pa.int32())) == \
+        'if (bool not((bool) z)) { (int32) a } else { (int32) a }'
+    assert str(builder.make_or([func_node, field_y])) == 'bool not((bool) z) || (bool) y'
+    assert str(builder.make_in_expression(a, [1, 2], pa.int32())) == '(int32) a IN (1, 2)'
+
+
+def test_rejects_none():  # test_gandiva.py:396-434
+    builder = gandiva.TreeExprBuilder()
+    field_x = pa.field('x', pa.int32())
+    schema = pa.schema([field_x])
+    literal_true = builder.make_literal(True, pa.bool_())
+    with pytest.raises(TypeError):
+        builder.make_field(None)
+    with pytest.raises(TypeError):
+        builder.make_if(literal_true, None, None, None)
+    with pytest.raises(TypeError):
+        builder.make_and([literal_true, None])
+    with pytest.raises(TypeError):
+        builder.make_or([None, literal_true])
+    with pytest.raises(TypeError):
+        builder.make_in_expression(None, [1, 2, 3], pa.int32())
+    with pytest.raises(TypeError):
+        builder.make_expression(None, field_x)
+    with pytest.raises(TypeError):
+        builder.make_condition(None)
+    with pytest.raises(TypeError):
+        builder.make_function('less_than', [literal_true, None], pa.bool_())
+    with pytest.raises(TypeError):
+        gandiva.make_projector(schema, [None])
+    with pytest.raises(TypeError):
+        gandiva.make_filter(schema, None)
+
+
+def test_get_registered_function_signatures():  # test_gandiva.py:319-326
+    signatures = gandiva.get_registered_function_signatures()
+    assert isinstance(signatures[0].return_type(), pa.DataType)
+    assert type(signatures[0].param_types()) is list
+    assert hasattr(signatures[0], "name")
+    names = {s.name() for s in signatures}
+    for expected in ("add", "subtract", "multiply", "divide", "less_than", "greater_than", "equal",
+                     "not", "isnull", "castBIGINT", "castFLOAT8", "hash32", "hash64",
+                     "extractYear", "timestampaddMonth", "datediff"):
+        assert expected in names
+
+
+def test_node_accessors():
+    builder = gandiva.TreeExprBuilder()
+    fa = pa.field('a', pa.int32())
+    na = builder.make_field(fa)
+    assert na.return_type() == pa.int32()
+    cond = builder.make_function("greater_than", [na, na], pa.bool_())
+    expr = builder.make_expression(builder.make_if(cond, na, na, pa.int32()), pa.field('res', pa.int32()))
+    assert expr.result().type == pa.int32()
+    assert builder.make_condition(cond).result().type == pa.bool_()
+    assert builder.make_field(pa.field('t', pa.timestamp('ms'))).return_type() == pa.timestamp('ms')
+    with pytest.raises(ValueError):
+        gandiva.make_projector(pa.schema([fa]), [expr], None, "UINT128")
+
+
+def _precompile_projector(schema, exprs, mode=0):
+    lib = _capi.lib()
+    sh = gg._make_schema(schema)
+    try:
+        arr = (C.c_void_p * len(exprs))(*[e._h for e in exprs])
+        return lib.gdv_precompile_projector(sh, arr, len(exprs), mode), _capi.last_error()
+    finally:
+        lib.gdv_schema_free(sh)
+
+
+def test_validation_errors_carry_reference_status_codes():
+    b = gandiva.TreeExprBuilder()
+    schema = pa.schema([pa.field('a', pa.int32()), pa.field('s', pa.float64())])
+    a, s = b.make_field(schema.field(0)), b.make_field(schema.field(1))
+    # unknown function / signature
+    bad = b.make_expression(b.make_function("add", [a, s], pa.int32()), pa.field('r', pa.int32()))
+    rc, msg = _precompile_projector(schema, [bad])
+    assert rc == 41 and "not supported yet" in msg          # ExpressionValidationError
+    # wrong declared return type
+    bad = b.make_expression(b.make_function("add", [a, a], pa.int64()), pa.field('r', pa.int64()))
+    assert _precompile_projector(schema, [bad])[0] == 41
+    # field not in schema
+    z = b.make_field(pa.field('zz', pa.int32()))
+    bad = b.make_expression(b.make_function("add", [z, a], pa.int32()), pa.field('r', pa.int32()))
+    rc, msg = _precompile_projector(schema, [bad])
+    assert rc == 41 and "not in schema" in msg
+    # if-condition must be bool; IN list type must match (message fragment: test_gandiva.py:160)
+    bad = b.make_expression(b.make_if(a, a, a, pa.int32()), pa.field('r', pa.int32()))
+    assert _precompile_projector(schema, [bad])[0] == 41
+    bad = b.make_expression(b.make_in_expression(a, [1, 2], pa.int64()), pa.field('r', pa.bool_()))
+    rc, msg = _precompile_projector(schema, [bad])
+    assert rc == 41 and "Evaluation expression for IN clause returns" in msg
+    # root type vs result field
+    bad = b.make_expression(a, pa.field('r', pa.int64()))
+    assert _precompile_projector(schema, [bad])[0] == 41
+    # empty expression list is Invalid (4)
+    assert _precompile_projector(schema, [])[0] == 4
+
+
+def test_plans_for_every_node_kind_compile_for_gfx950_without_a_gpu():
+    """Planner + device library + hipRTC, end to end, offline (code objects are cached)."""
+    b = gandiva.TreeExprBuilder()
+    schema = pa.schema([pa.field('a', pa.int64()), pa.field('b', pa.int64()),
+                        pa.field('x', pa.float64()), pa.field('z', pa.bool_()),
+                        pa.field('t', pa.timestamp('ms'))])
+    a, bb, x, z, t = (b.make_field(schema.field(i)) for i in range(5))
+    zero = b.make_literal(0, pa.int64())
+    gt = b.make_function("greater_than", [a, bb], pa.bool_())
+    guard = b.make_function("not_equal", [bb, zero], pa.bool_())
+    exprs = [
+        b.make_expression(b.make_if(guard, b.make_function("divide", [a, bb], pa.int64()), zero, pa.int64()),
+                          pa.field("safe_div", pa.int64())),
+        b.make_expression(b.make_and([gt, z, b.make_function("isnotnull", [x], pa.bool_())]),
+                          pa.field("and3", pa.bool_())),
+        b.make_expression(b.make_or([gt, z]), pa.field("or2", pa.bool_())),
+        b.make_expression(b.make_in_expression(a, list(range(40)), pa.int64()), pa.field("in40", pa.bool_())),
+        b.make_expression(b.make_function("hash64", [x], pa.int64()), pa.field("h", pa.int64())),
+        b.make_expression(b.make_function("extractYear", [t], pa.int64()), pa.field("y", pa.int64())),
+        b.make_expression(b.make_function("castFLOAT8", [a], pa.float64()), pa.field("c", pa.float64())),
+        b.make_expression(b.make_null(pa.float64()), pa.field("n", pa.float64())),
+    ]
+    for mode in (0, 1, 2, 3):
+        rc, msg = _precompile_projector(schema, exprs, mode)
+        assert rc == 0, msg
+    lib = _capi.lib()
+    sh = gg._make_schema(schema)
+    cond = b.make_condition(b.make_and([gt, guard]))
+    assert lib.gdv_precompile_filter(sh, cond._h) == 0, _capi.last_error()
+    lib.gdv_schema_free(sh)
+
+
+def test_dump_ir_is_reachable_through_precompile_cache():
+    # the BASELINE workloads plan + compile (what build() pre-populates)
+    rc, msg = _precompile_projector(W.c2_schema(), W.c2_expressions())
+    assert rc == 0, msg
+    rc, msg = _precompile_projector(W.c1_schema(), W.c1_expressions())
+    assert rc == 0, msg
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a HIP device")
+def test_no_cpu_fallback_evaluation_fails_loudly_without_a_device():
+    batch = W.c1_batch(128)
+    with pytest.raises(pa.lib.ArrowException, match="no HIP device"):
+        gandiva.make_projector(batch.schema, W.c1_expressions(), None)
+    with pytest.raises(pa.lib.ArrowException, match="no HIP device"):
+        gandiva.make_filter(W.c3_schema(), W.c3_condition())
