@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    p.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
     p.add_argument("--cpu-rows", type=int, default=1 << 24, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,6 +90,27 @@ def cpu_baseline_c3(rows):
                       f"threads + serial bitmap->selection walk, {el:.1f} s"}
 
 
+def cpu_baseline_c4(rows):
+    from gandiva_amd import workloads as W
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    rows = min(rows, 1 << 22)
+    batch = W.c4_batch(rows)
+    exprs = W.c4_expressions()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle.project(exprs, batch, threads=cores)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    return {"value": round(rows * reps / el / 1e6, 2), "unit": "million rows/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{reps} passes over {rows} rows of the C4 generator (3 expressions), "
+                      f"{cores} threads, {el:.1f} s"}
+
+
 def load_traffic(tag):
     """HBM bytes per launch from the committed PMC pass (tools/pmc_traffic.py), if any."""
     path = os.path.join(ROOT, "profiles", f"pmc_{tag}.json")
@@ -133,6 +154,16 @@ def main():
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
         kernel_desc = "fused 10-expression projection kernel (1 launch per step)"
+    elif args.workload == "c4":
+        rows = args.rows or 750_000_000
+        dbatch = W.c4_device_batch(rows)
+        proj = gandiva.make_projector(W.c4_schema(), W.c4_expressions(), None)
+        outs = proj.evaluate_device(dbatch)
+        bytes_per_row = 3 * 16 + 4 + 2 * 16 + 4 + 3 / 8  # inputs carry no validity buffers here
+
+        def step():
+            proj.evaluate_device(dbatch, outputs=outs, sync=False)
+        kernel_desc = "fused decimal128 x2 + datediff projection kernel (1 launch per step)"
     else:
         rows = args.rows or 1_000_000_000
         dbatch = W.c3_device_batch(rows)
@@ -173,8 +204,9 @@ def main():
         value = total_rows * args.steps / elapsed / 1e6
         achieved = bytes_per_row * rows / (mean_dev_ms * 1e-3) / 1e9
         line = {
-            "metric": "million rows/sec, 10-expr float64 Projector (10% nulls)" if args.workload == "c2"
-                      else "million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)",
+            "metric": {"c2": "million rows/sec, 10-expr float64 Projector (10% nulls)",
+                       "c3": "million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)",
+                       "c4": "million rows/sec, TPC-H Q1 projections (decimal128 + datediff)"}[args.workload],
             "value": round(value, 1),
             "unit": "million rows/s",
             "n_gpus": world,
@@ -184,12 +216,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if args.workload == "c2" else "int64",
+            "dtype": {"c2": "f64", "c3": "int64", "c4": "decimal128"}[args.workload],
             "data": "synthetic",
             "config": {
-                "workload": ("C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per "
-                             "column" if args.workload == "c2" else
-                             "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector"),
+                "workload": {"c2": "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column",
+                             "c3": "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector",
+                             "c4": "C4: ep*(1-disc), ep*(1-disc)*(1+tax) decimal128(15,2) inputs, "
+                                   "datediff(1998-12-01, shipdate date32)"}[args.workload],
                 "rows_per_gpu": rows,
                 "total_rows": total_rows,
                 "sharding": f"row-range x{world}, no collective",
@@ -209,7 +242,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = (cpu_baseline_c2 if args.workload == "c2" else cpu_baseline_c3)(args.cpu_rows)
+                fn = {"c2": cpu_baseline_c2, "c3": cpu_baseline_c3, "c4": cpu_baseline_c4}[args.workload]
+                line["cpu_baseline"] = fn(args.cpu_rows)
             except Exception as e:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"value": None, "unit": "million rows/s", "cores": 0,
                                         "kind": "port", "sample": f"failed: {e}"}

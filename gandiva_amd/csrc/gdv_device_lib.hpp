@@ -541,3 +541,157 @@ GDV_DEV gdv_date32 castDATE32_date64(gdv_date64 d) {
 GDV_DEV gdv_date64 castDATE_timestamp(gdv_timestamp t) {
   return gdv_floor_div(t, GDV_MILLIS_IN_DAY) * GDV_MILLIS_IN_DAY;
 }
+
+// ------------------------------------------------------------------ decimal128
+// Arrow decimal128 = 128-bit two's complement integer + (precision, scale) in the type.
+// Precision and scale of the operands and of the result are PLAN constants: the planner passes
+// them as literals, every call is inlined, and the branches below fold away, leaving for the
+// common case (no down-scaling, e.g. dec(15,2) * dec(15,2) -> dec(31,4)) a bare 128-bit
+// multiply or add.  Result-type rules: DecimalResultType in gdv_registry.cc.  When the rules
+// had to cut the scale (precision capped at 38) the exact result is divided by 10^delta and
+// rounded half away from zero.  A result that does not fit 38 digits yields 0.
+GDV_DEV gdv_int128 gdv_pow10_128(int e) {
+  gdv_int128 r = 1;
+  for (int i = 0; i < e; i++) r *= 10;
+  return r;
+}
+GDV_DEV gdv_int128 gdv_dec_max38() { return gdv_pow10_128(38) - 1; }
+GDV_DEV gdv_int128 gdv_dec_clip38(gdv_int128 v) {
+  const gdv_int128 m = gdv_dec_max38();
+  return (v > m || v < -m) ? (gdv_int128)0 : v;
+}
+// v / 10^e rounded half away from zero
+GDV_DEV gdv_int128 gdv_dec_reduce(gdv_int128 v, int e) {
+  if (e <= 0) return v;
+  const gdv_int128 d = gdv_pow10_128(e);
+  gdv_int128 q = v / d, r = v % d;
+  if (r < 0) r = -r;
+  if (2 * r >= d) q += (v < 0) ? -1 : 1;
+  return q;
+}
+
+struct gdv_u256 { gdv_uint64 w[4]; };  // little-endian limbs
+GDV_DEV gdv_u256 gdv_mul_128x128(gdv_uint128 a, gdv_uint128 b) {
+  const gdv_uint64 a0 = (gdv_uint64)a, a1 = (gdv_uint64)(a >> 64);
+  const gdv_uint64 b0 = (gdv_uint64)b, b1 = (gdv_uint64)(b >> 64);
+  const gdv_uint128 p00 = (gdv_uint128)a0 * b0, p01 = (gdv_uint128)a0 * b1;
+  const gdv_uint128 p10 = (gdv_uint128)a1 * b0, p11 = (gdv_uint128)a1 * b1;
+  gdv_u256 r;
+  r.w[0] = (gdv_uint64)p00;
+  gdv_uint128 mid = (p00 >> 64) + (gdv_uint64)p01 + (gdv_uint64)p10;
+  r.w[1] = (gdv_uint64)mid;
+  gdv_uint128 hi = (mid >> 64) + (p01 >> 64) + (p10 >> 64) + (gdv_uint64)p11;
+  r.w[2] = (gdv_uint64)hi;
+  r.w[3] = (gdv_uint64)((hi >> 64) + (p11 >> 64));
+  return r;
+}
+// in-place divide by a 64-bit divisor, returns the remainder
+GDV_DEV gdv_uint64 gdv_divmod_u256_u64(gdv_u256& v, gdv_uint64 d) {
+  gdv_uint128 rem = 0;
+  for (int i = 3; i >= 0; i--) {
+    gdv_uint128 cur = (rem << 64) | v.w[i];
+    v.w[i] = (gdv_uint64)(cur / d);
+    rem = cur % d;
+  }
+  return (gdv_uint64)rem;
+}
+
+GDV_DEV gdv_int128 gdv_dec_rescale_up(gdv_int128 v, int by) { return by > 0 ? v * gdv_pow10_128(by) : v; }
+
+GDV_DEV gdv_int128 add_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp, int ys,
+                                             int op, int os) {
+  const int hs = xs > ys ? xs : ys;  // exact result scale
+  gdv_int128 sum = gdv_dec_rescale_up(x, hs - xs) + gdv_dec_rescale_up(y, hs - ys);
+  return gdv_dec_clip38(gdv_dec_reduce(sum, hs - os));
+}
+GDV_DEV gdv_int128 subtract_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,
+                                                  int ys, int op, int os) {
+  return add_decimal128_decimal128(x, xp, xs, -y, yp, ys, op, os);
+}
+GDV_DEV gdv_int128 multiply_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,
+                                                  int ys, int op, int os) {
+  const int delta = xs + ys - os;  // digits the result-type rule cut from the scale
+  if (xp + yp <= 38 && delta == 0) return x * y;  // cannot overflow 38 digits
+  const bool neg = (x < 0) != (y < 0);
+  const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  gdv_u256 p = gdv_mul_128x128(ax, ay);
+  // divide by 10^delta in chunks of <= 10^18 (least significant digits first).  The last
+  // chunk removed holds the most significant removed digits and alone decides the rounding:
+  // 2*R >= 10^delta  <=>  2*last_rem >= last_div  (last_div is even, so lower chunks can
+  // neither create nor break the tie).
+  gdv_uint64 last_rem = 0, last_div = 1;
+  int left = delta;
+  while (left > 0) {
+    const int step = left > 18 ? 18 : left;
+    gdv_uint64 d = 1;
+    for (int i = 0; i < step; i++) d *= 10;
+    last_rem = gdv_divmod_u256_u64(p, d);
+    last_div = d;
+    left -= step;
+  }
+  if (delta > 0 && 2 * (gdv_uint128)last_rem >= (gdv_uint128)last_div) {
+    for (int i = 0; i < 4; i++) { if (++p.w[i] != 0) break; }
+  }
+  if (p.w[3] != 0 || p.w[2] != 0) return 0;  // overflow
+  gdv_uint128 mag = ((gdv_uint128)p.w[1] << 64) | p.w[0];
+  if (mag > (gdv_uint128)gdv_dec_max38()) return 0;
+  return neg ? -(gdv_int128)mag : (gdv_int128)mag;
+}
+
+// comparisons bring both sides to the larger scale (exact: |v| < 10^38 and the scale
+// difference keeps 10^38 * 10^diff inside 256 bits only for small diffs, so compare via
+// 256-bit products when the rescale could overflow 128 bits)
+GDV_DEV int gdv_dec_compare(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp, int ys) {
+  if (xs == ys) return x < y ? -1 : (x > y ? 1 : 0);
+  const bool xneg = x < 0, yneg = y < 0;
+  if (xneg != yneg) return xneg ? -1 : 1;
+  const gdv_uint128 ax = xneg ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = yneg ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  gdv_u256 a = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(ys > xs ? ys - xs : 0));
+  gdv_u256 b = gdv_mul_128x128(ay, (gdv_uint128)gdv_pow10_128(xs > ys ? xs - ys : 0));
+  int c = 0;
+  for (int i = 3; i >= 0 && c == 0; i--) c = a.w[i] < b.w[i] ? -1 : (a.w[i] > b.w[i] ? 1 : 0);
+  return xneg ? -c : c;
+}
+#define GDV_DEC_REL(name, expr)                                                                    \
+  GDV_DEV bool name##_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,   \
+                                            int ys, int op, int os) {                              \
+    const int c = gdv_dec_compare(x, xp, xs, y, yp, ys);                                           \
+    return expr;                                                                                   \
+  }
+GDV_DEC_REL(equal, c == 0)
+GDV_DEC_REL(not_equal, c != 0)
+GDV_DEC_REL(less_than, c < 0)
+GDV_DEC_REL(less_than_or_equal_to, c <= 0)
+GDV_DEC_REL(greater_than, c > 0)
+GDV_DEC_REL(greater_than_or_equal_to, c >= 0)
+
+GDV_DEV gdv_int128 negative_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return -x; }
+GDV_DEV gdv_int128 abs_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return x < 0 ? -x : x; }
+// int64 -> decimal(op, os): value * 10^os (0 on overflow of the declared precision)
+GDV_DEV gdv_int128 castDECIMAL_int64(gdv_int64 v, int op, int os) {
+  gdv_int128 r = (gdv_int128)v * gdv_pow10_128(os);
+  const gdv_int128 lim = gdv_pow10_128(op);
+  return (r >= lim || r <= -lim) ? (gdv_int128)0 : r;
+}
+GDV_DEV gdv_int128 castDECIMAL_int32(gdv_int32 v, int op, int os) { return castDECIMAL_int64(v, op, os); }
+// decimal -> decimal with another (precision, scale): rescale, round half away from zero
+GDV_DEV gdv_int128 castDECIMAL_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
+  gdv_int128 r = os >= xs ? gdv_dec_rescale_up(x, os - xs) : gdv_dec_reduce(x, xs - os);
+  const gdv_int128 lim = gdv_pow10_128(op);
+  return (r >= lim || r <= -lim) ? (gdv_int128)0 : r;
+}
+GDV_DEV gdv_float64 castFLOAT8_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
+  // two correctly rounded steps: int128 -> double, then divide by the exact power of ten
+  // (10^k is exact in binary64 for k <= 22; larger scales lose at most 1 ulp more)
+  gdv_float64 p = 1.0;
+  for (int i = 0; i < xs; i++) p *= 10.0;
+  const gdv_uint128 mag = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_float64 m = (gdv_float64)(gdv_uint64)(mag >> 64) * 18446744073709551616.0 +
+                        (gdv_float64)(gdv_uint64)mag;
+  return (x < 0 ? -m : m) / p;
+}
+GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
+  return (gdv_int64)gdv_dec_reduce(x, xs);
+}

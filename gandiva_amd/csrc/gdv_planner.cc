@@ -289,7 +289,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
   switch (node.kind()) {
     case NodeKind::kField: {
       auto& f = static_cast<const FieldNode&>(node);
-      if (f.return_type().is_varlen() || f.return_type().is_decimal())
+      if (f.return_type().is_varlen())
         return Status::CodeGenError("type " + f.return_type().ToString() +
                                     " is not supported by the HIP backend yet");
       int slot = SlotFor(f, true, true);
@@ -342,8 +342,16 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         std::string lanes;
         for (auto& a : args) {
           push(a.v);
+          if ((def->flags & kDecimalArgs) && a.type.is_decimal()) {
+            push(std::to_string(a.type.precision));
+            push(std::to_string(a.type.scale));
+          }
           out->vcols.insert(a.vcols.begin(), a.vcols.end());
           lanes = AndExpr(lanes, a.vlane);
+        }
+        if (def->flags & kDecimalArgs) {
+          push(std::to_string(out->type.precision));
+          push(std::to_string(out->type.scale));
         }
         out->vlane = lanes;
         call += ")";
@@ -692,7 +700,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     cg.Stmt("// @expr_" + std::to_string(e));
     GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "", &v));
     const DataType& t = exprs[e]->result().type;
-    if (t.is_varlen() || t.is_decimal())
+    if (t.is_varlen())
       return Status::CodeGenError("output type " + t.ToString() +
                                   " is not supported by the HIP backend yet");
     plan->output_types.push_back(t);

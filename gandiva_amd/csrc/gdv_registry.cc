@@ -200,6 +200,24 @@ FunctionRegistry::FunctionRegistry() {
     add("datediff", {t, t}, int32());
     add("date_diff", {t, t}, int32(), NullPolicy::kNullIfNull, 0, Sym("datediff", {t, t}));
   }
+  // decimal128: precision/scale are wildcards in the parameter match
+  {
+    const DataType dec = decimal128(0, 0);
+    for (const char* f : {"add", "subtract", "multiply"})
+      add(f, {dec, dec}, dec, NullPolicy::kNullIfNull, kDecimalResult | kDecimalArgs);
+    for (const char* f : {"equal", "not_equal", "less_than", "less_than_or_equal_to", "greater_than",
+                          "greater_than_or_equal_to"})
+      add(f, {dec, dec}, boolean(), NullPolicy::kNullIfNull, kDecimalArgs);
+    add("negative", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    add("abs", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    add("castDECIMAL", {int64()}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    add("castDECIMAL", {int32()}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    add("castDECIMAL", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    add("castFLOAT8", {dec}, float64(), NullPolicy::kNullIfNull, kDecimalArgs);
+    add("castBIGINT", {dec}, int64(), NullPolicy::kNullIfNull, kDecimalArgs);
+    add("isnull", {dec}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnull");
+    add("isnotnull", {dec}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
+  }
   add("datediff", {date32(), date32()}, int32());
   add("date_diff", {date32(), date32()}, int32(), NullPolicy::kNullIfNull, 0,
       "datediff_date32_date32");

@@ -25,6 +25,8 @@ enum FunctionFlags : uint32_t {
   kDecimalResult = 2u,   // return precision/scale follow the decimal result-type rules
   kPatternArg = 4u,      // last argument must be a literal compiled at Make time (like)
   kVarlenResult = 8u,    // returns utf8/binary: two-pass (length, then copy) evaluation
+  kDecimalArgs = 16u,    // device function takes (precision, scale) after every decimal
+                         // argument and the result's (precision, scale) last
 };
 
 struct FunctionDef {

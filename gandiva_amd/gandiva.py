@@ -195,6 +195,13 @@ class TreeExprBuilder:
             if isinstance(value, (str, bytes)) or not isinstance(value, (int, float, np.number)):
                 raise TypeError(f"expected a number for {t}, got {type(value).__name__}")
             value = float(value)
+        elif gt.id == 23:
+            import decimal
+            if isinstance(value, decimal.Decimal):
+                value = int(value.scaleb(t.scale).to_integral_exact())
+            elif not isinstance(value, (int, np.integer)) or isinstance(value, bool):
+                raise TypeError(f"expected a Decimal or an unscaled integer for {t}")
+            value = int(value)
         else:
             if isinstance(value, (bool, str, bytes, float)) and not isinstance(value, (int, np.integer)):
                 raise TypeError(f"expected an integer for {t}, got {type(value).__name__}")

@@ -147,3 +147,79 @@ def c3_device_batch(n, device="cuda", chunk=1 << 26):
             data[lo:hi].random_(0, 1000, generator=g)
         cols.append(gdv.DeviceColumn(pa.int64(), n, None, data.view(torch.uint8)))
     return gdv.DeviceBatch(c3_schema(), cols, n)
+
+
+# ------------------------------------------------------------------------------- C4
+# TPC-H lineitem Q1 projections: ep*(1-disc), ep*(1-disc)*(1+tax) in decimal128, and the
+# day difference 1998-12-01 - l_shipdate (date32).
+
+C4_BYTES_PER_ROW = 3 * 16 + 4 + 4 / 8 + 2 * 16 + 4 + 3 / 8  # 88.875: 52.5 read + 36.375 written
+C4_DATE_1998_12_01 = 10561  # days since 1970-01-01
+
+
+def c4_schema():
+    d = pa.decimal128(15, 2)
+    return pa.schema([pa.field("l_extendedprice", d), pa.field("l_discount", d),
+                      pa.field("l_tax", d), pa.field("l_shipdate", pa.date32())])
+
+
+def c4_expressions(builder=None):
+    b = builder or gdv.TreeExprBuilder()
+    s = c4_schema()
+    ep, disc, tax, ship = (b.make_field(s.field(i)) for i in range(4))
+    d152 = pa.decimal128(15, 2)
+    one = b.make_literal(100, d152)                                   # 1.00
+    one_minus = b.make_function("subtract", [one, disc], pa.decimal128(16, 2))
+    disc_price = b.make_function("multiply", [ep, one_minus], pa.decimal128(32, 4))
+    one_plus = b.make_function("add", [one, tax], pa.decimal128(16, 2))
+    charge = b.make_function("multiply", [disc_price, one_plus], pa.decimal128(38, 6))
+    cutoff = b.make_literal(C4_DATE_1998_12_01, pa.date32())
+    days = b.make_function("datediff", [cutoff, ship], pa.int32())
+    return [b.make_expression(disc_price, pa.field("disc_price", pa.decimal128(32, 4))),
+            b.make_expression(charge, pa.field("charge", pa.decimal128(38, 6))),
+            b.make_expression(days, pa.field("days", pa.int32()))]
+
+
+def _decimal_array(unscaled, t, mask=None):
+    """int64 numpy unscaled values -> decimal128 pyarrow array (sign-extended 16-byte slots)."""
+    n = len(unscaled)
+    raw = np.empty((n, 2), dtype=np.int64)
+    raw[:, 0] = unscaled
+    raw[:, 1] = unscaled >> 63
+    validity = None
+    if mask is not None:
+        validity = pa.py_buffer(np.packbits(~mask, bitorder="little"))
+    return pa.Array.from_buffers(t, n, [validity, pa.py_buffer(raw)])
+
+
+def c4_batch(n, null_fraction=0.0):
+    d = pa.decimal128(15, 2)
+    ep = np.random.Generator(np.random.PCG64(11)).integers(90000, 10500000, n, dtype=np.int64)
+    disc = np.random.Generator(np.random.PCG64(12)).integers(0, 11, n, dtype=np.int64)
+    tax = np.random.Generator(np.random.PCG64(13)).integers(0, 9, n, dtype=np.int64)
+    ship = np.random.Generator(np.random.PCG64(14)).integers(8036, 10562, n, dtype=np.int32)
+    masks = [None] * 4
+    if null_fraction > 0:
+        masks = [np.random.Generator(np.random.PCG64(111 + k)).random(n) < null_fraction for k in range(4)]
+    cols = [_decimal_array(ep, d, masks[0]), _decimal_array(disc, d, masks[1]),
+            _decimal_array(tax, d, masks[2]),
+            pa.array(ship, type=pa.int32(), mask=masks[3]).cast(pa.date32())]
+    return pa.RecordBatch.from_arrays(cols, schema=c4_schema())
+
+
+def c4_device_batch(n, device="cuda", chunk=1 << 25):
+    import torch
+    g = torch.Generator(device=device)
+    cols = []
+    for seed, lo, hi in ((11, 90000, 10500000), (12, 0, 11), (13, 0, 9)):
+        g.manual_seed(seed)
+        data = torch.zeros(n, 2, dtype=torch.int64, device=device)  # high words stay 0 (values >= 0)
+        for a in range(0, n, chunk):
+            z = min(n, a + chunk)
+            data[a:z, 0].random_(lo, hi, generator=g)
+        cols.append(gdv.DeviceColumn(pa.decimal128(15, 2), n, None, data.view(torch.uint8).reshape(-1)))
+    g.manual_seed(14)
+    ship = torch.empty(n, dtype=torch.int32, device=device)
+    ship.random_(8036, 10562, generator=g)
+    cols.append(gdv.DeviceColumn(pa.date32(), n, None, ship.view(torch.uint8)))
+    return gdv.DeviceBatch(c4_schema(), cols, n)

@@ -42,26 +42,31 @@
 enum {
   T_BOOL = 1, T_U8 = 2, T_I8 = 3, T_U16 = 4, T_I16 = 5, T_U32 = 6, T_I32 = 7, T_U64 = 8,
   T_I64 = 9, T_F32 = 11, T_F64 = 12, T_DATE32 = 16, T_DATE64 = 17, T_TS = 18, T_TIME32 = 19,
-  T_TIME64 = 20
+  T_TIME64 = 20, T_DEC = 23
 };
+typedef __int128 i128;
+typedef unsigned __int128 u128;
 
 typedef struct {
   int32_t type;
   const uint8_t* validity; /* may be NULL */
   const void* data;
   int64_t offset; /* Arrow array offset */
+  int32_t precision, scale; /* decimal128 only */
 } or_column;
 
 /* A chunk of evaluated values: every value widened to a 64-bit slot. */
 typedef struct {
   int32_t type;
-  union { int64_t i; uint64_t u; double d; float f; } v[CHUNK];
+  int32_t prec, scale; /* decimal128 values */
+  union { int64_t i; uint64_t u; double d; float f; i128 q; } v[CHUNK];
   uint8_t valid[CHUNK];
 } vec;
 
 typedef struct node {
   char kind;       /* F L C I A O N */
   int32_t type;    /* result type */
+  int32_t prec, scale; /* decimal128 result precision / scale */
   int col;
   int is_null;
   uint64_t lo, hi;
@@ -90,6 +95,13 @@ static const char* next_tok(const char** p, char* buf, size_t cap) {
   return n ? buf : NULL;
 }
 
+/* <type> token: id or id:precision:scale */
+static void parse_type(const char* t, int32_t* id, int32_t* prec, int32_t* scale) {
+  *id = atoi(t); *prec = 0; *scale = 0;
+  const char* c = strchr(t, ':');
+  if (c) { *prec = atoi(c + 1); c = strchr(c + 1, ':'); if (c) *scale = atoi(c + 1); }
+}
+
 static node* parse(const char** p, const or_column* cols) {
   char t[128];
   if (!next_tok(p, t, sizeof t)) return NULL;
@@ -100,22 +112,24 @@ static node* parse(const char** p, const or_column* cols) {
       next_tok(p, t, sizeof t);
       n->col = atoi(t);
       n->type = cols[n->col].type;
+      n->prec = cols[n->col].precision;
+      n->scale = cols[n->col].scale;
       break;
     case 'L':
-      next_tok(p, t, sizeof t); n->type = atoi(t);
+      next_tok(p, t, sizeof t); parse_type(t, &n->type, &n->prec, &n->scale);
       next_tok(p, t, sizeof t); n->is_null = atoi(t);
       next_tok(p, t, sizeof t); n->lo = strtoull(t, NULL, 16);
       next_tok(p, t, sizeof t); n->hi = strtoull(t, NULL, 16);
       break;
     case 'C':
       next_tok(p, t, sizeof t); snprintf(n->name, sizeof n->name, "%s", t);
-      next_tok(p, t, sizeof t); n->type = atoi(t);
+      next_tok(p, t, sizeof t); parse_type(t, &n->type, &n->prec, &n->scale);
       next_tok(p, t, sizeof t); n->nargs = atoi(t);
       n->args = (node**)calloc(n->nargs ? n->nargs : 1, sizeof(node*));
       for (int i = 0; i < n->nargs; i++) n->args[i] = parse(p, cols);
       break;
     case 'I':
-      next_tok(p, t, sizeof t); n->type = atoi(t);
+      next_tok(p, t, sizeof t); parse_type(t, &n->type, &n->prec, &n->scale);
       n->nargs = 3;
       n->args = (node**)calloc(3, sizeof(node*));
       for (int i = 0; i < 3; i++) n->args[i] = parse(p, cols);
@@ -158,6 +172,7 @@ static int width_of(int t) {
     case T_U16: case T_I16: return 2;
     case T_U32: case T_I32: case T_F32: case T_DATE32: case T_TIME32: return 4;
     case T_BOOL: return 0;
+    case T_DEC: return 16;
     default: return 8;
   }
 }
@@ -183,6 +198,8 @@ static int64_t wrap_int(int t, uint64_t x) {
 
 static void load_column(const or_column* c, int64_t row0, int n, vec* out) {
   out->type = c->type;
+  out->prec = c->precision;
+  out->scale = c->scale;
   for (int i = 0; i < n; i++) {
     int64_t r = c->offset + row0 + i;
     out->valid[i] = c->validity ? (uint8_t)get_bit(c->validity, r) : 1;
@@ -196,6 +213,7 @@ static void load_column(const or_column* c, int64_t row0, int n, vec* out) {
       case T_U32: out->v[i].i = ((const uint32_t*)c->data)[r]; break;
       case T_F32: out->v[i].f = ((const float*)c->data)[r]; break;
       case T_F64: out->v[i].d = ((const double*)c->data)[r]; break;
+      case T_DEC: memcpy(&out->v[i].q, (const char*)c->data + 16 * r, 16); break;
       default: out->v[i].i = ((const int64_t*)c->data)[r]; break;
     }
   }
@@ -306,12 +324,111 @@ static int cmp_op(const char* name) {
 #define CMP(op, a, b) ((op) == 0 ? (a) == (b) : (op) == 1 ? (a) != (b) : (op) == 2 ? (a) < (b) : \
                        (op) == 3 ? (a) <= (b) : (op) == 4 ? (a) > (b) : (a) >= (b))
 
+/* ---------------------------------------------------------------- decimal128
+ * Exact arithmetic on 256-bit magnitudes (4 x 64-bit limbs), scale reduction one decimal
+ * digit at a time, rounding half away from zero on the most significant removed digit.
+ * A result that does not fit 38 digits is 0. */
+typedef struct { uint64_t w[4]; } u256;
+static u256 u256_from(u128 v) { u256 r = {{(uint64_t)v, (uint64_t)(v >> 64), 0, 0}}; return r; }
+static u256 u256_mul(u128 a, u128 b) {
+  uint64_t x[2] = {(uint64_t)a, (uint64_t)(a >> 64)}, y[2] = {(uint64_t)b, (uint64_t)(b >> 64)};
+  u256 r = {{0, 0, 0, 0}};
+  for (int i = 0; i < 2; i++) {
+    u128 carry = 0;
+    for (int j = 0; j < 2; j++) {
+      u128 cur = (u128)x[i] * y[j] + r.w[i + j] + carry;
+      r.w[i + j] = (uint64_t)cur;
+      carry = cur >> 64;
+    }
+    r.w[i + 2] += (uint64_t)carry;
+  }
+  return r;
+}
+static int u256_div10(u256* v) { /* returns the removed digit */
+  u128 rem = 0;
+  for (int i = 3; i >= 0; i--) {
+    u128 cur = (rem << 64) | v->w[i];
+    v->w[i] = (uint64_t)(cur / 10);
+    rem = cur % 10;
+  }
+  return (int)rem;
+}
+static void u256_inc(u256* v) { for (int i = 0; i < 4; i++) if (++v->w[i] != 0) break; }
+static void u256_mul10(u256* v) {
+  u128 carry = 0;
+  for (int i = 0; i < 4; i++) { u128 cur = (u128)v->w[i] * 10 + carry; v->w[i] = (uint64_t)cur; carry = cur >> 64; }
+}
+static int u256_cmp(const u256* a, const u256* b) {
+  for (int i = 3; i >= 0; i--) if (a->w[i] != b->w[i]) return a->w[i] < b->w[i] ? -1 : 1;
+  return 0;
+}
+static i128 pow10_128(int e) { i128 r = 1; while (e-- > 0) r *= 10; return r; }
+/* signed magnitude -> decimal128 with `cut` low digits removed (rounded) */
+static i128 dec_finish(u256 mag, int neg, int cut) {
+  int last = 0;
+  for (int k = 0; k < cut; k++) last = u256_div10(&mag);
+  if (cut > 0 && last >= 5) u256_inc(&mag);
+  if (mag.w[3] || mag.w[2]) return 0;
+  u128 m = ((u128)mag.w[1] << 64) | mag.w[0];
+  if (m > (u128)(pow10_128(38) - 1)) return 0;
+  return neg ? -(i128)m : (i128)m;
+}
+static u128 mag128(i128 v) { return v < 0 ? (u128)(-v) : (u128)v; }
+static i128 dec_add(i128 x, int xs, i128 y, int ys, int os) {
+  int hs = xs > ys ? xs : ys;
+  /* |x|,|y| < 10^38 and hs - xs <= 38: the rescaled operands fit 256 bits */
+  u256 a = u256_from(mag128(x)), b = u256_from(mag128(y));
+  for (int k = xs; k < hs; k++) u256_mul10(&a);
+  for (int k = ys; k < hs; k++) u256_mul10(&b);
+  int an = x < 0, bn = y < 0, neg;
+  u256 r;
+  if (an == bn) {
+    u128 carry = 0;
+    for (int i = 0; i < 4; i++) { u128 cur = (u128)a.w[i] + b.w[i] + carry; r.w[i] = (uint64_t)cur; carry = cur >> 64; }
+    neg = an;
+  } else {
+    int c = u256_cmp(&a, &b);
+    const u256* big = c >= 0 ? &a : &b;
+    const u256* small = c >= 0 ? &b : &a;
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 cur = (u128)big->w[i] - small->w[i] - borrow;
+      r.w[i] = (uint64_t)cur;
+      borrow = (uint64_t)((cur >> 64) & 1);
+    }
+    neg = c >= 0 ? an : bn;
+    if (c == 0) neg = 0;
+  }
+  return dec_finish(r, neg, hs - os);
+}
+static i128 dec_mul(i128 x, int xs, i128 y, int ys, int os) {
+  return dec_finish(u256_mul(mag128(x), mag128(y)), (x < 0) != (y < 0), xs + ys - os);
+}
+static int dec_cmp(i128 x, int xs, i128 y, int ys) {
+  int xn = x < 0, yn = y < 0;
+  if (xn != yn) return xn ? -1 : 1;
+  u256 a = u256_from(mag128(x)), b = u256_from(mag128(y));
+  for (int k = xs; k < ys; k++) u256_mul10(&a);
+  for (int k = ys; k < xs; k++) u256_mul10(&b);
+  int c = u256_cmp(&a, &b);
+  return xn ? -c : c;
+}
+static i128 dec_rescale(i128 x, int xs, int op, int os) {
+  i128 r;
+  if (os >= xs) r = x * pow10_128(os - xs);
+  else { r = dec_finish(u256_from(mag128(x)), x < 0, xs - os); }
+  i128 lim = pow10_128(op);
+  return (r >= lim || r <= -lim) ? 0 : r;
+}
+
 static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active,
                           vec* out) {
   const char* f = n->name;
   vec* a = (vec*)malloc(sizeof(vec) * (n->nargs ? n->nargs : 1));
   for (int k = 0; k < n->nargs; k++) eval(n->args[k], c, row0, cnt, active, &a[k]);
   out->type = n->type;
+  out->prec = n->prec;
+  out->scale = n->scale;
   const int t0 = n->nargs > 0 ? a[0].type : 0;
   /* default null policy: null if any argument is null */
   for (int i = 0; i < cnt; i++) {
@@ -320,7 +437,32 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
     out->valid[i] = v;
   }
   int op;
-  if ((!strcmp(f, "add") || !strcmp(f, "subtract") || !strcmp(f, "multiply")) && n->nargs == 2) {
+  if (t0 == T_DEC || n->type == T_DEC) {
+    const int two = n->nargs == 2;
+    for (int i = 0; i < cnt; i++) {
+      i128 x = a[0].v[i].q, y = two ? a[1].v[i].q : 0;
+      int xs = a[0].scale, ys = two ? a[1].scale : 0;
+      if (!strcmp(f, "add")) out->v[i].q = dec_add(x, xs, y, ys, n->scale);
+      else if (!strcmp(f, "subtract")) out->v[i].q = dec_add(x, xs, -y, ys, n->scale);
+      else if (!strcmp(f, "multiply")) out->v[i].q = dec_mul(x, xs, y, ys, n->scale);
+      else if ((op = cmp_op(f)) >= 0) { int cc = dec_cmp(x, xs, y, ys); out->v[i].i = CMP(op, cc, 0); }
+      else if (!strcmp(f, "negative")) out->v[i].q = -x;
+      else if (!strcmp(f, "abs")) out->v[i].q = x < 0 ? -x : x;
+      else if (!strcmp(f, "castDECIMAL")) {
+        if (t0 == T_DEC) out->v[i].q = dec_rescale(x, xs, n->prec, n->scale);
+        else out->v[i].q = dec_rescale((i128)a[0].v[i].i, 0, n->prec, n->scale);
+      } else if (!strcmp(f, "castFLOAT8")) {
+        double p10 = 1.0;
+        for (int k = 0; k < xs; k++) p10 *= 10.0;
+        u128 m = mag128(x);
+        double md = (double)(uint64_t)(m >> 64) * 18446744073709551616.0 + (double)(uint64_t)m;
+        out->v[i].d = (x < 0 ? -md : md) / p10;
+      } else if (!strcmp(f, "castBIGINT")) out->v[i].i = (int64_t)dec_finish(u256_from(mag128(x)), x < 0, xs);
+      else if (!strcmp(f, "isnull")) { out->v[i].i = !a[0].valid[i]; out->valid[i] = 1; }
+      else if (!strcmp(f, "isnotnull")) { out->v[i].i = a[0].valid[i]; out->valid[i] = 1; }
+      else { c->err |= 0x100; }
+    }
+  } else if ((!strcmp(f, "add") || !strcmp(f, "subtract") || !strcmp(f, "multiply")) && n->nargs == 2) {
     int which = f[0] == 'a' ? 0 : f[0] == 's' ? 1 : 2;
     for (int i = 0; i < cnt; i++) {
       if (t0 == T_F64) {
@@ -508,8 +650,11 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
       return;
     case 'L':
       out->type = n->type;
+      out->prec = n->prec;
+      out->scale = n->scale;
       for (int i = 0; i < cnt; i++) {
         out->valid[i] = !n->is_null;
+        if (n->type == T_DEC) { out->v[i].q = (i128)(((u128)n->hi << 64) | n->lo); continue; }
         if (n->type == T_F32) { uint32_t b = (uint32_t)n->lo; memcpy(&out->v[i].f, &b, 4); }
         else out->v[i].u = n->lo;
         if (n->type != T_F32 && n->type != T_F64) out->v[i].i = wrap_int(n->type, n->lo);
@@ -534,6 +679,8 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
       eval(n->args[1], c, row0, cnt, act_t, th);
       eval(n->args[2], c, row0, cnt, act_e, el);
       out->type = n->type;
+      out->prec = n->prec;
+      out->scale = n->scale;
       for (int i = 0; i < cnt; i++) {
         int take = cnd->valid[i] && cnd->v[i].i;
         out->v[i] = take ? th->v[i] : el->v[i];
@@ -596,6 +743,7 @@ static void store_chunk(int type, const vec* r, int64_t row0, int cnt, void* dat
       case T_I32: case T_U32: case T_DATE32: case T_TIME32: ((uint32_t*)data)[row] = (uint32_t)r->v[i].u; break;
       case T_F32: ((float*)data)[row] = r->v[i].f; break;
       case T_F64: ((double*)data)[row] = r->v[i].d; break;
+      case T_DEC: memcpy((char*)data + 16 * row, &r->v[i].q, 16); break;
       default: ((uint64_t*)data)[row] = r->v[i].u; break;
     }
   }

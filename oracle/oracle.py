@@ -31,7 +31,7 @@ def build(force=False):
 
 class _Column(C.Structure):
     _fields_ = [("type", C.c_int32), ("validity", C.c_void_p), ("data", C.c_void_p),
-                ("offset", C.c_int64)]
+                ("offset", C.c_int64), ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 def lib():
@@ -57,7 +57,7 @@ _TYPE_IDS = [
     (pa.types.is_int16, 5), (pa.types.is_uint32, 6), (pa.types.is_int32, 7), (pa.types.is_uint64, 8),
     (pa.types.is_int64, 9), (pa.types.is_float32, 11), (pa.types.is_float64, 12),
     (pa.types.is_date32, 16), (pa.types.is_date64, 17), (pa.types.is_timestamp, 18),
-    (pa.types.is_time32, 19), (pa.types.is_time64, 20),
+    (pa.types.is_time32, 19), (pa.types.is_time64, 20), (pa.types.is_decimal128, 23),
 ]
 _PACK = {1: "<B", 2: "<B", 3: "<b", 4: "<H", 5: "<h", 6: "<I", 7: "<i", 8: "<Q", 9: "<q",
          11: "<f", 12: "<d", 16: "<i", 17: "<q", 18: "<q", 19: "<i", 20: "<q"}
@@ -71,8 +71,15 @@ def type_id(t):
 
 
 def _bits(tid, value):
+    if tid == 23:
+        return int(value) & ((1 << 128) - 1)
     raw = struct.pack(_PACK[tid], value)
     return int.from_bytes(raw, "little")
+
+
+def type_token(t):
+    tid = type_id(t)
+    return f"{tid}:{t.precision}:{t.scale}" if tid == 23 else str(tid)
 
 
 def serialize(node, schema):
@@ -82,15 +89,17 @@ def serialize(node, schema):
         return f"F {schema.get_field_index(node.desc['name'])}"
     if k == "literal":
         tid = type_id(node.dtype)
+        tok = type_token(node.dtype)
         if node.desc["is_null"]:
-            return f"L {tid} 1 0 0"
-        return f"L {tid} 0 {_bits(tid, node.desc['value']):x} 0"
+            return f"L {tok} 1 0 0"
+        bits = _bits(tid, node.desc['value'])
+        return f"L {tok} 0 {bits & ((1 << 64) - 1):x} {bits >> 64:x}"
     if k == "function":
         kids = node.desc["children"]
-        return " ".join([f"C {node.desc['name']} {type_id(node.dtype)} {len(kids)}"] +
+        return " ".join([f"C {node.desc['name']} {type_token(node.dtype)} {len(kids)}"] +
                         [serialize(c, schema) for c in kids])
     if k == "if":
-        return " ".join([f"I {type_id(node.dtype)}"] + [serialize(c, schema) for c in node.desc["children"]])
+        return " ".join([f"I {type_token(node.dtype)}"] + [serialize(c, schema) for c in node.desc["children"]])
     if k in ("and", "or"):
         kids = node.desc["children"]
         return " ".join([f"{'A' if k == 'and' else 'O'} {len(kids)}"] + [serialize(c, schema) for c in kids])
@@ -114,6 +123,8 @@ def _columns(batch):
         cols[i].validity = bufs[0].address if bufs[0] is not None else None
         cols[i].data = bufs[1].address if len(bufs) > 1 and bufs[1] is not None else None
         cols[i].offset = arr.offset
+        if tid == 23:
+            cols[i].precision, cols[i].scale = arr.type.precision, arr.type.scale
         keep.append(bufs)
     return cols, keep
 

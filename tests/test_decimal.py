@@ -1,0 +1,146 @@
+"""decimal128 (BASELINE config C4).  Parity status: UNPINNED — the mounted reference has no
+decimal code at all; result-type rules and round-half-up follow the
+Arrow-era reference from memory.  What is checked:
+  CPU: the oracle against Python's `decimal` module (exact arithmetic, ROUND_HALF_UP) and
+       against pyarrow.compute where no scale adjustment happens;
+  GPU: the HIP path bit-exact against the oracle, including scale-reduced multiplies,
+       mixed scales, negatives, nulls, overflow -> 0."""
+import decimal
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+import gandiva_amd as gandiva
+from gandiva_amd import workloads as W
+from oracle import oracle
+from helpers import assert_bit_exact
+
+CTX = decimal.Context(prec=100, rounding=decimal.ROUND_HALF_UP)
+
+
+def _dec_array(rng, t, n, digits, null_fraction=0.1):
+    lim = 10 ** digits
+    vals = [int(rng.integers(-lim, lim)) if digits <= 18 else
+            int(rng.integers(-10**18, 10**18)) * 10 ** (digits - 18) + int(rng.integers(0, 10**9))
+            for _ in range(n)]
+    mask = rng.random(n) < null_fraction
+    py = [None if m else decimal.Decimal(v).scaleb(-t.scale, CTX) for v, m in zip(vals, mask)]
+    return pa.array(py, type=t)
+
+
+def _result_type(op, a, b):
+    p1, s1, p2, s2 = a.precision, a.scale, b.precision, b.scale
+    if op in ("add", "subtract"):
+        s = max(s1, s2); p = max(p1 - s1, p2 - s2) + s + 1
+    else:
+        s = s1 + s2; p = p1 + p2 + 1
+    if p > 38:
+        delta = p - 38
+        s = max(s - delta, min(s, 6)); p = 38
+    return pa.decimal128(p, s)
+
+
+def _python_expected(op, xs, ys, rt):
+    q = decimal.Decimal(1).scaleb(-rt.scale)
+    lim = decimal.Decimal(10) ** (38 - rt.scale)
+    out = []
+    for x, y in zip(xs, ys):
+        if x is None or y is None:
+            out.append(None); continue
+        v = {"add": CTX.add, "subtract": CTX.subtract, "multiply": CTX.multiply}[op](x, y)
+        v = v.quantize(q, rounding=decimal.ROUND_HALF_UP, context=CTX)
+        out.append(decimal.Decimal(0).quantize(q) if abs(v) >= lim else v)
+    return out
+
+
+CASES = [  # (type a, digits a, type b, digits b)
+    (pa.decimal128(15, 2), 12, pa.decimal128(15, 2), 12),
+    (pa.decimal128(10, 0), 9, pa.decimal128(12, 5), 11),
+    (pa.decimal128(38, 10), 30, pa.decimal128(38, 4), 25),   # multiply cuts the scale, rounds
+    (pa.decimal128(30, 8), 28, pa.decimal128(20, 12), 18),
+    (pa.decimal128(38, 6), 36, pa.decimal128(38, 6), 36),    # multiply overflows -> 0
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[2]}")
+def test_oracle_matches_python_decimal(case):
+    ta, da, tb, db = case
+    rng = np.random.default_rng(da * 100 + db)
+    n = 400
+    a, bcol = _dec_array(rng, ta, n, da), _dec_array(rng, tb, n, db)
+    batch = pa.RecordBatch.from_arrays([a, bcol], names=["a", "b"])
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    for op in ("add", "subtract", "multiply"):
+        rt = _result_type(op, ta, tb)
+        got = oracle.project_one(b.make_function(op, [fa, fb], rt), rt, batch)
+        want = _python_expected(op, a.to_pylist(), bcol.to_pylist(), rt)
+        assert got.to_pylist() == want, f"{op} {ta} {tb} -> {rt}"
+    for op, fn in (("less_than", lambda x, y: x < y), ("equal", lambda x, y: x == y),
+                   ("greater_than_or_equal_to", lambda x, y: x >= y)):
+        got = oracle.project_one(b.make_function(op, [fa, fb], pa.bool_()), pa.bool_(), batch)
+        want = [None if x is None or y is None else fn(x, y) for x, y in zip(a.to_pylist(), bcol.to_pylist())]
+        assert got.to_pylist() == want, op
+
+
+def test_oracle_c4_matches_arrow_and_python():
+    batch = W.c4_batch(3000, 0.1)
+    out = oracle.project(W.c4_expressions(), batch)
+    ep, disc, tax, ship = batch.columns
+    one = pa.scalar(decimal.Decimal("1.00"), pa.decimal128(15, 2))
+    assert out[0].equals(pc.multiply(ep, pc.subtract(one, disc)).cast(out[0].type))
+    want = []
+    for e, d, t in zip(ep.to_pylist(), disc.to_pylist(), tax.to_pylist()):
+        if e is None or d is None or t is None:
+            want.append(None); continue
+        v = CTX.multiply(CTX.multiply(e, CTX.subtract(decimal.Decimal(1), d)), CTX.add(decimal.Decimal(1), t))
+        want.append(v.quantize(decimal.Decimal("0.000001"), rounding=decimal.ROUND_HALF_UP, context=CTX))
+    assert out[1].to_pylist() == want
+    days = pc.subtract(pa.scalar(W.C4_DATE_1998_12_01, pa.int32()), ship.cast(pa.int32()))
+    assert out[2].equals(days)
+
+
+# ------------------------------------------------------------------ GPU parity
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 100003])
+@pytest.mark.parametrize("nulls", [0.0, 0.1])
+def test_hip_c4_matches_oracle(n, nulls):
+    batch = W.c4_batch(n, nulls)
+    exprs = W.c4_expressions()
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        assert_bit_exact(g, w, str(e))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[2]}")
+def test_hip_decimal_ops_match_oracle(case):
+    ta, da, tb, db = case
+    rng = np.random.default_rng(da * 100 + db + 1)
+    n = 3000
+    a, bcol = _dec_array(rng, ta, n, da), _dec_array(rng, tb, n, db)
+    i64 = pa.array(rng.integers(-10**6, 10**6, n))
+    batch = pa.RecordBatch.from_arrays([a, bcol, i64], names=["a", "b", "i"])
+    b = gandiva.TreeExprBuilder()
+    fa, fb, fi = (b.make_field(batch.schema.field(k)) for k in range(3))
+    exprs = []
+    for op in ("add", "subtract", "multiply"):
+        rt = _result_type(op, ta, tb)
+        exprs.append(b.make_expression(b.make_function(op, [fa, fb], rt), pa.field(op, rt)))
+    for op in ("equal", "not_equal", "less_than", "less_than_or_equal_to", "greater_than",
+               "greater_than_or_equal_to"):
+        exprs.append(b.make_expression(b.make_function(op, [fa, fb], pa.bool_()), pa.field(op, pa.bool_())))
+    exprs.append(b.make_expression(b.make_function("castFLOAT8", [fa], pa.float64()), pa.field("f", pa.float64())))
+    exprs.append(b.make_expression(b.make_function("castDECIMAL", [fi], pa.decimal128(20, 4)),
+                                   pa.field("d", pa.decimal128(20, 4))))
+    exprs.append(b.make_expression(b.make_function("castDECIMAL", [fa], pa.decimal128(38, 1)),
+                                   pa.field("r", pa.decimal128(38, 1))))
+    exprs.append(b.make_expression(b.make_function("abs", [fa], ta), pa.field("abs", ta)))
+    sel = b.make_if(b.make_function("less_than", [fa, fb], pa.bool_()), fa, b.make_function("negative", [fa], ta), ta)
+    exprs.append(b.make_expression(sel, pa.field("sel", ta)))
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        assert_bit_exact(g, w, str(e))
