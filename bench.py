@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    p.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
     p.add_argument("--cpu-rows", type=int, default=1 << 24, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,6 +111,25 @@ def cpu_baseline_c4(rows):
                       f"{cores} threads, {el:.1f} s"}
 
 
+def cpu_baseline_c5(rows):
+    from gandiva_amd import workloads as W
+    from oracle import oracle
+    rows = min(rows, 1 << 21)
+    batch = W.c5_batch(rows)
+    exprs = W.c5_expressions()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        oracle.project(exprs, batch)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 20:
+            break
+    return {"value": round(rows * reps / el / 1e6, 2), "unit": "million rows/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{reps} passes over {rows} rows of the C5 generator (3 expressions), 1 thread, {el:.1f} s"}
+
+
 def load_traffic(tag):
     """HBM bytes per launch from the committed PMC pass (tools/pmc_traffic.py), if any."""
     path = os.path.join(ROOT, "profiles", f"pmc_{tag}.json")
@@ -164,6 +183,18 @@ def main():
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
         kernel_desc = "fused decimal128 x2 + datediff projection kernel (1 launch per step)"
+    elif args.workload == "c5":
+        rows = args.rows or 100_000_000
+        dbatch = W.c5_device_batch(rows)
+        proj = gandiva.make_projector(W.c5_schema(), W.c5_expressions(), None)
+        outs = proj.evaluate_device(dbatch)
+        in_bytes = 4 * (rows + 1) + int(sum(o.data_used for o in outs[2:]))  # offsets + data (upper preserves bytes)
+        out_bytes = rows / 8 + sum(4 * (rows + 1) + o.data_used for o in outs[1:]) + 3 * rows / 8
+        bytes_per_row = (in_bytes + out_bytes) / rows
+
+        def step():
+            proj.evaluate_device(dbatch, outputs=outs, sync=False)
+        kernel_desc = "fused like/substr/upper kernel, 2 launches (lengths, bytes) + 2 offset scans"
     else:
         rows = args.rows or 1_000_000_000
         dbatch = W.c3_device_batch(rows)
@@ -206,7 +237,8 @@ def main():
         line = {
             "metric": {"c2": "million rows/sec, 10-expr float64 Projector (10% nulls)",
                        "c3": "million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)",
-                       "c4": "million rows/sec, TPC-H Q1 projections (decimal128 + datediff)"}[args.workload],
+                       "c4": "million rows/sec, TPC-H Q1 projections (decimal128 + datediff)",
+                       "c5": "million rows/sec, utf8 like/substr/upper"}[args.workload],
             "value": round(value, 1),
             "unit": "million rows/s",
             "n_gpus": world,
@@ -216,13 +248,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"c2": "f64", "c3": "int64", "c4": "decimal128"}[args.workload],
+            "dtype": {"c2": "f64", "c3": "int64", "c4": "decimal128", "c5": "u8"}[args.workload],
             "data": "synthetic",
             "config": {
                 "workload": {"c2": "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column",
                              "c3": "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector",
                              "c4": "C4: ep*(1-disc), ep*(1-disc)*(1+tax) decimal128(15,2) inputs, "
-                                   "datediff(1998-12-01, shipdate date32)"}[args.workload],
+                                   "datediff(1998-12-01, shipdate date32)",
+                             "c5": "C5: like '%spark%', substr(s,2,5), upper(s) over utf8 lengths U[4,20]"}[args.workload],
                 "rows_per_gpu": rows,
                 "total_rows": total_rows,
                 "sharding": f"row-range x{world}, no collective",
@@ -242,7 +275,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                fn = {"c2": cpu_baseline_c2, "c3": cpu_baseline_c3, "c4": cpu_baseline_c4}[args.workload]
+                fn = {"c2": cpu_baseline_c2, "c3": cpu_baseline_c3, "c4": cpu_baseline_c4,
+                      "c5": cpu_baseline_c5}[args.workload]
                 line["cpu_baseline"] = fn(args.cpu_rows)
             except Exception as e:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"value": None, "unit": "million rows/s", "cores": 0,

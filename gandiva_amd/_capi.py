@@ -32,6 +32,7 @@ class gdv_out_column_t(C.Structure):
     _fields_ = [
         ("validity", C.c_void_p), ("validity_size", C.c_int64),
         ("data", C.c_void_p), ("data_size", C.c_int64),
+        ("offsets", C.c_void_p), ("offsets_size", C.c_int64),
     ]
 
 

@@ -268,6 +268,10 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
   const DataType& t = p->p->output_type(i);
   const bool dev = mem_kind == GDV_MEM_DEVICE;
   if (validity_bytes) *validity_bytes = dev ? Projector::ValidityBytes(rows) : (rows + 7) / 8;
+  if (data_bytes && t.is_varlen()) {
+    *data_bytes = 0;
+    return GDV_OK;
+  }
   if (data_bytes)
     *data_bytes = t.id == kBool ? (dev ? Projector::ValidityBytes(rows) : (rows + 7) / 8)
                                 : Projector::DataBytes(t, rows);
@@ -286,6 +290,8 @@ int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv
     o[i].validity_size = outs[i].validity_size;
     o[i].data = outs[i].data;
     o[i].data_size = outs[i].data_size;
+    o[i].offsets = outs[i].offsets;
+    o[i].offsets_size = outs[i].offsets_size;
   }
   SelectionView sv;
   if (sel) {
@@ -293,9 +299,11 @@ int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv
     sv.indices = sel->indices;
     sv.num_slots = sel->num_slots;
   }
-  return Check(p->p->Evaluate(num_rows, c.data(), num_cols, sel ? &sv : nullptr, o.data(),
-                              num_outs, mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
-                              static_cast<hipStream_t>(stream), flags));
+  Status st = p->p->Evaluate(num_rows, c.data(), num_cols, sel ? &sv : nullptr, o.data(), num_outs,
+                             mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
+                             static_cast<hipStream_t>(stream), flags);
+  for (int i = 0; i < num_outs; i++) outs[i].data_size = o[i].data_size;  // var-len: bytes produced / needed
+  return Check(st);
 }
 char* gdv_projector_dump_ir(const gdv_projector_t* p) { return p ? DupString(p->p->DumpIR()) : nullptr; }
 void gdv_projector_free(gdv_projector_t* p) { delete p; }

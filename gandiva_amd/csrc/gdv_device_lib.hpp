@@ -695,3 +695,153 @@ GDV_DEV gdv_float64 castFLOAT8_decimal128(gdv_int128 x, int xp, int xs, int op, 
 GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
   return (gdv_int64)gdv_dec_reduce(x, xs);
 }
+
+// ------------------------------------------------------------------ utf8 / binary
+// A string value inside a kernel is a VIEW: pointer + byte length into an input data buffer
+// (or a literal in constant memory) plus a byte map applied on read (0 none, 1 ASCII upper,
+// 2 ASCII lower).  substr / trim produce narrower views, upper / lower set the map, so no
+// per-row scratch is ever needed; the bytes are materialised exactly once, by the copy pass
+// of a var-len output (gdv_str_copy), or consumed in place by predicates (like, equal …).
+struct gdv_str {
+  const gdv_uint8* p;
+  gdv_int32 len;
+  gdv_int32 map;
+};
+GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end) {
+  gdv_str s;
+  s.p = base + begin;
+  s.len = end - begin;
+  s.map = 0;
+  return s;
+}
+GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
+  if (map == 1) return (c >= 'a' && c <= 'z') ? (gdv_uint8)(c - 32) : c;
+  if (map == 2) return (c >= 'A' && c <= 'Z') ? (gdv_uint8)(c + 32) : c;
+  return c;
+}
+GDV_DEV gdv_uint8 gdv_str_at(const gdv_str& s, gdv_int32 i) { return gdv_map_byte(s.p[i], s.map); }
+GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
+  for (gdv_int32 i = 0; i < s.len; i++) dst[i] = gdv_str_at(s, i);
+}
+GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
+GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
+  gdv_int32 n = 0;
+  for (gdv_int32 i = 0; i < s.len; i++) n += gdv_is_utf8_lead(s.p[i]) ? 1 : 0;
+  return n;
+}
+
+GDV_DEV gdv_int32 octet_length_utf8(gdv_str s) { return s.len; }
+GDV_DEV gdv_int32 bit_length_utf8(gdv_str s) { return s.len * 8; }
+GDV_DEV gdv_int32 char_length_utf8(gdv_str s) { return gdv_utf8_count(s); }
+GDV_DEV gdv_str upper_utf8(gdv_str s) { s.map = 1; return s; }
+GDV_DEV gdv_str lower_utf8(gdv_str s) { s.map = 2; return s; }
+
+GDV_DEV int gdv_str_compare(const gdv_str& a, const gdv_str& b) {
+  const gdv_int32 n = a.len < b.len ? a.len : b.len;
+  for (gdv_int32 i = 0; i < n; i++) {
+    const gdv_uint8 x = gdv_str_at(a, i), y = gdv_str_at(b, i);
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return a.len < b.len ? -1 : (a.len > b.len ? 1 : 0);
+}
+GDV_DEV bool equal_utf8_utf8(gdv_str a, gdv_str b) { return a.len == b.len && gdv_str_compare(a, b) == 0; }
+GDV_DEV bool not_equal_utf8_utf8(gdv_str a, gdv_str b) { return !equal_utf8_utf8(a, b); }
+GDV_DEV bool less_than_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) < 0; }
+GDV_DEV bool less_than_or_equal_to_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) <= 0; }
+GDV_DEV bool greater_than_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) > 0; }
+GDV_DEV bool greater_than_or_equal_to_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) >= 0; }
+GDV_DEV bool starts_with_utf8_utf8(gdv_str s, gdv_str prefix) {
+  if (prefix.len > s.len) return false;
+  for (gdv_int32 i = 0; i < prefix.len; i++)
+    if (gdv_str_at(s, i) != gdv_str_at(prefix, i)) return false;
+  return true;
+}
+GDV_DEV bool ends_with_utf8_utf8(gdv_str s, gdv_str suffix) {
+  if (suffix.len > s.len) return false;
+  const gdv_int32 d = s.len - suffix.len;
+  for (gdv_int32 i = 0; i < suffix.len; i++)
+    if (gdv_str_at(s, d + i) != gdv_str_at(suffix, i)) return false;
+  return true;
+}
+
+// substr(s, from, len): 1-based character positions (UTF-8 aware); from < 0 counts from the
+// end; from == 0 behaves like 1; len <= 0 or a start outside the string give "".
+GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 count) {
+  gdv_str r = s;
+  r.len = 0;
+  if (count <= 0 || s.len <= 0) return r;
+  const gdv_int64 glyphs = gdv_utf8_count(s);
+  gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? glyphs + from : 0);
+  if (start < 0 || start >= glyphs) return r;
+  gdv_int64 stop = start + count < glyphs ? start + count : glyphs;
+  gdv_int32 g = 0, b0 = s.len, b1 = s.len;
+  for (gdv_int32 i = 0; i < s.len; i++) {
+    if (gdv_is_utf8_lead(s.p[i])) {
+      if (g == start) b0 = i;
+      if (g == stop) { b1 = i; break; }
+      g++;
+    }
+  }
+  r.p = s.p + b0;
+  r.len = b1 - b0;
+  return r;
+}
+GDV_DEV gdv_str substr_utf8_int64(gdv_str s, gdv_int64 from) {
+  return substr_utf8_int64_int64(s, from, 0x7fffffff);
+}
+GDV_DEV bool gdv_is_space(gdv_uint8 c) { return c == ' '; }
+GDV_DEV gdv_str ltrim_utf8(gdv_str s) {
+  while (s.len > 0 && gdv_is_space(s.p[0])) { s.p++; s.len--; }
+  return s;
+}
+GDV_DEV gdv_str rtrim_utf8(gdv_str s) {
+  while (s.len > 0 && gdv_is_space(s.p[s.len - 1])) s.len--;
+  return s;
+}
+GDV_DEV gdv_str btrim_utf8(gdv_str s) { return rtrim_utf8(ltrim_utf8(s)); }
+
+// SQL LIKE.  The pattern is compiled at Make time (gdv_planner.cc) into parallel arrays in
+// constant memory: kind[i] = 0 literal byte, 1 '_' (exactly one UTF-8 character),
+// 2 '%' (any run, possibly empty); byte[i] = the literal.  Matching is the classic
+// two-cursor wildcard walk with a single backtrack point (the last '%'): O(len * plen) worst
+// case, O(len) for the usual '%needle%' / 'prefix%' shapes.  The whole string must match.
+GDV_DEV bool gdv_like(const gdv_str& s, const gdv_uint8* pbyte, const gdv_uint8* pkind, gdv_int32 plen) {
+  gdv_int32 i = 0, j = 0, star_j = -1, star_i = 0;
+  while (i < s.len) {
+    if (j < plen && pkind[j] == 2) {
+      star_j = j++;
+      star_i = i;
+    } else if (j < plen && pkind[j] == 1) {
+      i++;
+      while (i < s.len && !gdv_is_utf8_lead(s.p[i])) i++;  // swallow continuation bytes
+      j++;
+    } else if (j < plen && pkind[j] == 0 && gdv_str_at(s, i) == pbyte[j]) {
+      i++;
+      j++;
+    } else if (star_j >= 0) {
+      j = star_j + 1;
+      star_i++;
+      while (star_i < s.len && !gdv_is_utf8_lead(s.p[star_i])) star_i++;
+      i = star_i;
+    } else {
+      return false;
+    }
+  }
+  while (j < plen && pkind[j] == 2) j++;
+  return j == plen;
+}
+
+// IN over strings: linear probe of the literal list (lists are short in practice)
+GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_int32* offs, gdv_int32 n) {
+  for (gdv_int32 k = 0; k < n; k++) {
+    const gdv_int32 len = offs[k + 1] - offs[k];
+    if (len != s.len) continue;
+    bool eq = true;
+    for (gdv_int32 i = 0; i < len && eq; i++) eq = gdv_str_at(s, i) == bytes[offs[k] + i];
+    if (eq) return true;
+  }
+  return false;
+}
+
+// hash of the string bytes: murmur3 x64-128 style reduction is restated in hash64_utf8
+GDV_DEV gdv_int64 gdv_castBIGINT_len(gdv_str s) { return s.len; }

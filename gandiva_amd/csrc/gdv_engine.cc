@@ -82,6 +82,9 @@ class ArgBlock {
   void SetOutValid(int e, void* p) {
     SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 8, p);
   }
+  void SetOutOffsets(int e, void* p) {
+    SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 16, p);
+  }
   const void* data() const { return buf_.data(); }
   size_t size() const { return buf_.size(); }
 
@@ -146,9 +149,31 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
     const DataType& t = schema[idx].type;
     const std::string& name = schema[idx].name;
     if (plan.input_needs_values[k]) {
-      if (c.data == nullptr && num_rows > 0)
+      if (c.data == nullptr && num_rows > 0 && !t.is_varlen())
         return Status::Invalid("column '" + name + "' has no data buffer");
-      if (t.id == kBool) {
+      if (t.is_varlen()) {
+        // int32 offsets (rows + 1 of them, from the array offset) + the whole byte buffer
+        const int64_t need = (c.offset + num_rows + 1) * 4;
+        if (c.offsets == nullptr || c.offsets_size < need)
+          return Status::Invalid("column '" + name + "': offsets buffer too small");
+        const char* osrc = static_cast<const char*>(c.offsets) + c.offset * 4;
+        if (mem == MemKind::kHost) {
+          DeviceBuffer& dof = st->Add();
+          GDV_RETURN_NOT_OK(dof.Allocate((num_rows + 1) * 4));
+          GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dof.get(), osrc, (num_rows + 1) * 4,
+                                               hipMemcpyHostToDevice, stream));
+          DeviceBuffer& dd = st->Add();
+          GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(c.data_size, 8)));
+          if (c.data_size > 0)
+            GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dd.get(), c.data, c.data_size,
+                                                 hipMemcpyHostToDevice, stream));
+          args->SetInOffsets(static_cast<int>(k), dof.get());
+          args->SetInData(static_cast<int>(k), dd.get());
+        } else {
+          args->SetInOffsets(static_cast<int>(k), osrc);
+          args->SetInData(static_cast<int>(k), c.data);
+        }
+      } else if (t.id == kBool) {
         if (c.data_size < BytesForBits(c.offset + num_rows))
           return Status::Invalid("column '" + name + "': data buffer too small");
         HostBitmap b;
@@ -292,22 +317,32 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
 
   // outputs
-  std::vector<void*> dev_data(num_outs), dev_valid(num_outs);
+  std::vector<void*> dev_data(num_outs, nullptr), dev_valid(num_outs), dev_offs(num_outs, nullptr);
   for (int e = 0; e < num_outs; e++) {
     const DataType& t = plan_.output_types[e];
     const int64_t need_valid_dev = ValidityBytes(out_rows);
-    const int64_t need_data_dev = DataBytes(t, out_rows);
+    const int64_t need_data_dev = t.is_varlen() ? 0 : DataBytes(t, out_rows);
+    const int64_t need_offs = t.is_varlen() ? (out_rows + 1) * 4 : 0;
+    if (t.is_varlen() && (outs[e].offsets == nullptr || outs[e].offsets_size < need_offs))
+      return Status::Invalid("output buffer " + std::to_string(e) + ": offsets buffer too small (" +
+                             std::to_string(need_offs) + " bytes needed)");
     if (mem == MemKind::kHost) {
       const int64_t need_data_host = t.id == kBool ? BytesForBits(out_rows) : need_data_dev;
       if (outs[e].validity_size < BytesForBits(out_rows) || outs[e].data_size < need_data_host ||
-          (out_rows > 0 && (outs[e].validity == nullptr || outs[e].data == nullptr)))
+          (out_rows > 0 && (outs[e].validity == nullptr || (outs[e].data == nullptr && !t.is_varlen()))))
         return Status::Invalid("output buffer " + std::to_string(e) + " too small");
       DeviceBuffer& dv = st.Add();
       GDV_RETURN_NOT_OK(dv.Allocate(std::max<int64_t>(need_valid_dev, 8)));
-      DeviceBuffer& dd = st.Add();
-      GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(need_data_dev, 8)));
       dev_valid[e] = dv.get();
-      dev_data[e] = dd.get();
+      if (t.is_varlen()) {
+        DeviceBuffer& dof = st.Add();
+        GDV_RETURN_NOT_OK(dof.Allocate(need_offs));
+        dev_offs[e] = dof.get();
+      } else {
+        DeviceBuffer& dd = st.Add();
+        GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(need_data_dev, 8)));
+        dev_data[e] = dd.get();
+      }
     } else {
       if (outs[e].validity_size < need_valid_dev || outs[e].data_size < need_data_dev)
         return Status::Invalid("output buffer " + std::to_string(e) +
@@ -316,9 +351,12 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
                                std::to_string(need_data_dev) + " data bytes)");
       dev_valid[e] = outs[e].validity;
       dev_data[e] = outs[e].data;
+      dev_offs[e] = outs[e].offsets;
     }
     args.SetOutData(e, dev_data[e]);
     args.SetOutValid(e, dev_valid[e]);
+    args.SetOutOffsets(e, dev_offs[e]);
+    if (t.is_varlen()) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_offs[e], 0, 4, stream));
   }
 
   DeviceBuffer err;
@@ -328,9 +366,51 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     args.SetPtr(ArgLayout::kOffErr, err.get());
   }
 
+  const int64_t grid = GridFor(plan_, out_rows);
+  args.Set64(ArgLayout::kOffAux0, 0);
   if (out_rows > 0) {
-    GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, out_rows), plan_.opts.waves * 64,
-                                args.data(), args.size(), stream));
+    GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
+                                stream));
+  }
+
+  // var-len outputs: lengths -> offsets (in-place scan), size the byte buffers, second pass
+  std::vector<uint64_t> totals(num_outs, 0);
+  if (plan_.has_varlen_output) {
+    DeviceBuffer sums, total_dev;
+    GDV_RETURN_NOT_OK(sums.Allocate(ScanChunks(out_rows + 1) * 8));
+    GDV_RETURN_NOT_OK(total_dev.Allocate(8 * num_outs));
+    for (int e = 0; e < num_outs; e++) {
+      if (!plan_.output_types[e].is_varlen()) continue;
+      GDV_HIP_RETURN_NOT_OK(LaunchInclusiveScanI32(static_cast<int32_t*>(dev_offs[e]), out_rows + 1,
+                                                   sums.as<uint64_t>(),
+                                                   total_dev.as<uint64_t>() + e, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&totals[e], total_dev.as<uint64_t>() + e, 8,
+                                           hipMemcpyDeviceToHost, stream));
+    }
+    GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+    Status capacity = Status::OK();
+    for (int e = 0; e < num_outs; e++) {
+      if (!plan_.output_types[e].is_varlen()) continue;
+      if (totals[e] > 0x7fffffffull)
+        return Status::Invalid("var-len output " + std::to_string(e) + " exceeds 2 GiB");
+      const int64_t have = outs[e].data_size;
+      outs[e].data_size = static_cast<int64_t>(totals[e]);  // bytes needed / produced
+      if (have < static_cast<int64_t>(totals[e]) || (totals[e] > 0 && outs[e].data == nullptr))
+        capacity = Status::Invalid("output buffer " + std::to_string(e) + ": data capacity " +
+                                   std::to_string(have) + " < " + std::to_string(totals[e]) +
+                                   " bytes needed (data_size updated; retry with a larger buffer)");
+      if (mem == MemKind::kHost) {
+        DeviceBuffer& dd = st.Add();
+        GDV_RETURN_NOT_OK(dd.Allocate(std::max<uint64_t>(totals[e], 8)));
+        dev_data[e] = dd.get();
+        args.SetOutData(e, dev_data[e]);
+      }
+    }
+    GDV_RETURN_NOT_OK(capacity);
+    args.Set64(ArgLayout::kOffAux0, 1);
+    if (out_rows > 0)
+      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
+                                  stream));
   }
 
   uint32_t err_bits = 0;
@@ -340,12 +420,20 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     for (int e = 0; e < num_outs; e++) {
       const DataType& t = plan_.output_types[e];
       const int64_t vbytes = BytesForBits(out_rows);
-      const int64_t dbytes = t.id == kBool ? vbytes : DataBytes(t, out_rows);
       if (out_rows == 0) continue;
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].validity, dev_valid[e], vbytes,
                                            hipMemcpyDeviceToHost, stream));
-      GDV_HIP_RETURN_NOT_OK(
-          hipMemcpyAsync(outs[e].data, dev_data[e], dbytes, hipMemcpyDeviceToHost, stream));
+      if (t.is_varlen()) {
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].offsets, dev_offs[e], (out_rows + 1) * 4,
+                                             hipMemcpyDeviceToHost, stream));
+        if (totals[e] > 0)
+          GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
+                                               hipMemcpyDeviceToHost, stream));
+      } else {
+        const int64_t dbytes = t.id == kBool ? vbytes : DataBytes(t, out_rows);
+        GDV_HIP_RETURN_NOT_OK(
+            hipMemcpyAsync(outs[e].data, dev_data[e], dbytes, hipMemcpyDeviceToHost, stream));
+      }
     }
   }
   const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync);

@@ -34,8 +34,10 @@ struct ColumnBuffers {
 struct OutputBuffers {
   void* validity = nullptr;  // >= 8 * ceil(rows / 64) bytes
   int64_t validity_size = 0;
-  void* data = nullptr;      // >= rows * width bytes (bool: 8 * ceil(rows / 64))
-  int64_t data_size = 0;
+  void* data = nullptr;      // >= rows * width bytes (bool: 8 * ceil(rows / 64)); var-len: bytes
+  int64_t data_size = 0;     // var-len: capacity in; bytes needed out (also on failure)
+  void* offsets = nullptr;   // var-len outputs only: (rows + 1) int32 offsets
+  int64_t offsets_size = 0;
 };
 
 struct SelectionView {

@@ -118,6 +118,27 @@ ScanApply(const uint32_t* __restrict__ counts, int64_t m, const uint64_t* __rest
   }
 }
 
+// In-place inclusive scan of int32 lengths -> Arrow var-len offsets (data[i] becomes
+// sum(data[0..i])); `sums` holds the exclusive prefix of every chunk (ScanSpine output).
+__global__ void __launch_bounds__(kScanThreads)
+ScanApplyInclusiveI32(int32_t* __restrict__ data, int64_t m, const uint64_t* __restrict__ sums) {
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t c[kScanPerThread];
+  uint64_t local = 0;
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    c[i] = (base + i < m) ? static_cast<uint32_t>(data[base + i]) : 0u;
+    local += c[i];
+  }
+  uint64_t total;
+  uint64_t prefix = BlockExclusiveScan(local, &total) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    prefix += c[i];
+    if (base + i < m) data[base + i] = static_cast<int32_t>(prefix);
+  }
+}
+
 // One wavefront per wave tile (`subtiles` consecutive 64-row match words).
 template <typename IndexT>
 __global__ void __launch_bounds__(256)
@@ -156,6 +177,18 @@ hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_
   hipLaunchKernelGGL(ScanSpine, dim3(1), dim3(kScanThreads), 0, stream, chunk_sums, nb, total);
   hipLaunchKernelGGL(ScanApply, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, counts, m,
                      chunk_sums, offsets);
+  return hipGetLastError();
+}
+
+hipError_t LaunchInclusiveScanI32(int32_t* data, int64_t m, uint64_t* chunk_sums, uint64_t* total,
+                                  hipStream_t stream) {
+  if (m <= 0) return hipMemsetAsync(total, 0, sizeof(uint64_t), stream);
+  const int64_t nb = ScanChunks(m);
+  hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb), dim3(kScanThreads), 0, stream,
+                     reinterpret_cast<const uint32_t*>(data), m, chunk_sums);
+  hipLaunchKernelGGL(ScanSpine, dim3(1), dim3(kScanThreads), 0, stream, chunk_sums, nb, total);
+  hipLaunchKernelGGL(ScanApplyInclusiveI32, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, data,
+                     m, chunk_sums);
   return hipGetLastError();
 }
 

@@ -77,7 +77,7 @@ Status ValidateFunction(const Schema& schema, const FunctionNode& n) {
     }
   }
   if (def->flags & kPatternArg) {
-    if (n.children().back()->kind() != NodeKind::kLiteral) {
+    if (n.children().size() < 2 || n.children()[1]->kind() != NodeKind::kLiteral) {
       return Status::ValidationError("'" + n.name() + "' function requires a literal as the last parameter");
     }
   }
@@ -251,6 +251,50 @@ class CodeGen {
     return s;
   }
 
+  // bytes -> `__constant__` array in the prelude; returns the array name
+  std::string ByteTable(const std::string& bytes, const char* ctype = "gdv_uint8") {
+    std::string name = "gdv_cst" + std::to_string(next_const_++);
+    prelude_ << "__constant__ " << ctype << " " << name << "[" << std::max<size_t>(bytes.size(), 1)
+             << "] = {";
+    for (size_t i = 0; i < bytes.size(); i++)
+      prelude_ << (i ? "," : "") << static_cast<unsigned>(static_cast<unsigned char>(bytes[i]));
+    if (bytes.empty()) prelude_ << "0";
+    prelude_ << "};\n";
+    return name;
+  }
+  std::string StringConstant(const std::string& bytes) {
+    return "gdv_make_str(" + ByteTable(bytes) + ", 0, " + std::to_string(bytes.size()) + ")";
+  }
+  // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
+  static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
+                            std::string* kinds) {
+    for (size_t i = 0; i < pat.size(); i++) {
+      unsigned char c = static_cast<unsigned char>(pat[i]);
+      if (escape >= 0 && c == static_cast<unsigned char>(escape)) {
+        if (i + 1 >= pat.size())
+          return Status::Invalid("like pattern must not end with the escape character");
+        unsigned char nx = static_cast<unsigned char>(pat[i + 1]);
+        if (nx != '%' && nx != '_' && nx != static_cast<unsigned char>(escape))
+          return Status::Invalid("invalid escape sequence in like pattern");
+        bytes->push_back(static_cast<char>(nx));
+        kinds->push_back(0);
+        i++;
+      } else if (c == '%') {
+        if (kinds->empty() || kinds->back() != 2) {  // collapse runs of %
+          bytes->push_back(0);
+          kinds->push_back(2);
+        }
+      } else if (c == '_') {
+        bytes->push_back(0);
+        kinds->push_back(1);
+      } else {
+        bytes->push_back(static_cast<char>(c));
+        kinds->push_back(0);
+      }
+    }
+    return Status::OK();
+  }
+
   int SlotFor(const FieldNode& f, bool values, bool validity) {
     int idx = -1;
     for (size_t i = 0; i < schema_.size(); i++)
@@ -289,13 +333,12 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
   switch (node.kind()) {
     case NodeKind::kField: {
       auto& f = static_cast<const FieldNode&>(node);
-      if (f.return_type().is_varlen())
-        return Status::CodeGenError("type " + f.return_type().ToString() +
-                                    " is not supported by the HIP backend yet");
       int slot = SlotFor(f, true, true);
       out->type = f.return_type();
       std::string k = std::to_string(slot);
-      if (f.return_type().id == kBool) {
+      if (f.return_type().is_varlen()) {
+        out->v = "s" + k;  // per-iteration view built from the two offsets (phase 2 prologue)
+      } else if (f.return_type().id == kBool) {
         out->v = selection() ? "x" + k + "[u]" : Tmp("bool", "gdv_lane_bit(d" + k + ", lane)");
       } else {
         out->v = "c" + k + "[u]";
@@ -306,9 +349,13 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
     }
     case NodeKind::kLiteral: {
       auto& l = static_cast<const LiteralNode&>(node);
-      if (l.return_type().is_varlen())
-        return Status::CodeGenError("string literals are not supported in this position yet");
       out->type = l.return_type();
+      if (l.return_type().is_varlen()) {
+        out->v = StringConstant(l.value().bytes);
+        out->vcols.clear();
+        out->vlane = l.is_null() ? "false" : "";
+        return Status::OK();
+      }
       out->v = LiteralExpr(l.return_type(), l.value());
       out->vcols.clear();
       out->vlane = l.is_null() ? "false" : "";
@@ -327,6 +374,33 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->vcols.clear();
       out->vlane.clear();
       const std::string ctype = out->type.CType();
+      if (def->flags & kPatternArg) {
+        // like(s, 'pattern'[, 'escape']): the pattern is compiled here, at Make time, the way
+        // the reference's LikeHolder compiles it to a regex once per expression
+        auto& pat = static_cast<const LiteralNode&>(*fn.children()[1]);
+        int escape = -1;
+        if (fn.children().size() == 3) {
+          if (fn.children()[2]->kind() != NodeKind::kLiteral)
+            return Status::ValidationError("'like' function requires a literal as the escape character");
+          auto& esc = static_cast<const LiteralNode&>(*fn.children()[2]);
+          if (esc.value().bytes.size() != 1)
+            return Status::Invalid("The length of escape char in like function must be 1");
+          escape = static_cast<unsigned char>(esc.value().bytes[0]);
+        }
+        if (pat.is_null()) {
+          out->v = "false";
+          out->vlane = "false";
+          return Status::OK();
+        }
+        std::string bytes, kinds;
+        GDV_RETURN_NOT_OK(CompileLike(pat.value().bytes, escape, &bytes, &kinds));
+        std::string pb = ByteTable(bytes), pk = ByteTable(kinds);
+        out->vcols = args[0].vcols;
+        out->vlane = args[0].vlane;
+        out->v = Tmp("bool", "gdv_like(" + args[0].v + ", " + pb + ", " + pk + ", " +
+                                 std::to_string(kinds.size()) + ")");
+        return Status::OK();
+      }
       std::string call = def->symbol + "(";
       bool first = true;
       auto push = [&](const std::string& a) {
@@ -438,7 +512,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
     }
     case NodeKind::kIn: {
       auto& n = static_cast<const InNode&>(node);
-      if (n.value_type().is_varlen() || n.value_type().is_decimal())
+      if (n.value_type().is_decimal())
         return Status::CodeGenError("IN over " + n.value_type().ToString() +
                                     " is not supported by the HIP backend yet");
       Val x;
@@ -446,6 +520,19 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->type = boolean();
       out->vcols = x.vcols;
       out->vlane = x.vlane;
+      if (n.value_type().is_varlen()) {
+        std::string bytes;
+        std::string name = "gdv_cst" + std::to_string(next_const_++);
+        prelude_ << "__constant__ gdv_int32 " << name << "[" << n.values().size() + 1 << "] = {0";
+        for (auto& l : n.values()) {
+          bytes += l.bytes;
+          prelude_ << "," << bytes.size();
+        }
+        prelude_ << "};\n";
+        out->v = Tmp("bool", "gdv_in_strings(" + x.v + ", " + ByteTable(bytes) + ", " + name + ", " +
+                                 std::to_string(n.values().size()) + ")");
+        return Status::OK();
+      }
       const std::string ctype = n.value_type().CType();
       std::vector<uint64_t> vals;
       uint64_t mask = n.value_type().byte_width() >= 8
@@ -531,9 +618,10 @@ struct WordAccumulators {
   }
 };
 
-std::string WordStore(const std::string& acc, const std::string& dst) {
-  return "  if (lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) " + dst +
-         "[wbase + lane] = " + acc + ";\n";
+std::string WordStore(const std::string& acc, const std::string& dst, bool two_pass = false) {
+  return std::string("  if (") + (two_pass ? "pass == 0 && " : "") +
+         "lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) " + dst + "[wbase + lane] = " +
+         acc + ";\n";
 }
 
 Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
@@ -560,16 +648,26 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "  const gdv_int64 rbase = wbase * 64;\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
-    if (t.id != kBool && cg.needs_values_[k])
+    if (t.is_varlen() && cg.needs_values_[k]) {
+      s << "  const gdv_uint8* __restrict__ sd" << k << " = (const gdv_uint8*)A.in[" << k
+        << "].data;\n"
+        << "  const gdv_int32* __restrict__ so" << k << " = A.in[" << k << "].offsets;\n";
+    } else if (t.id != kBool && cg.needs_values_[k]) {
       s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType()
         << "*)A.in[" << k << "].data;\n";
+    }
   }
   for (size_t e = 0; e < plan->output_types.size(); e++) {
     const DataType& t = plan->output_types[e];
-    if (t.id != kBool)
+    if (t.is_varlen()) {
+      s << "  gdv_uint8* __restrict__ outd" << e << " = (gdv_uint8*)A.out[" << e << "].data;\n"
+        << "  gdv_int32* __restrict__ outo" << e << " = A.out[" << e << "].offsets;\n";
+    } else if (t.id != kBool) {
       s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out["
         << e << "].data;\n";
+    }
   }
+  if (plan->has_varlen_output) s << "  const int pass = (int)A.aux0;  // 0 lengths, 1 bytes\n";
   if (sel)
     s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const "
       << SelCType(cg.sel_mode_) << "*)A.sel;\n";
@@ -585,6 +683,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
         else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k
                << "].bits, wbase, lane, GDV_U);\n";
       }
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k]) s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
@@ -605,6 +705,10 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
       if (t.id == kBool) {
         if (cg.needs_values_[k])
           s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+      } else if (t.is_varlen()) {
+        if (cg.needs_values_[k])
+          s << "    oa" << k << "[u] = so" << k << "[srow[u]]; ob" << k << "[u] = so" << k
+            << "[srow[u] + 1];\n";
       } else if (cg.needs_values_[k]) {
         s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
       }
@@ -614,8 +718,13 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   } else {
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
-      if (t.id != kBool && cg.needs_values_[k])
+      if (t.is_varlen()) {
+        if (cg.needs_values_[k])
+          s << "    oa" << k << "[u] = live ? so" << k << "[row] : 0; ob" << k << "[u] = live ? so"
+            << k << "[row + 1] : 0;\n";
+      } else if (t.id != kBool && cg.needs_values_[k]) {
         s << "    c" << k << "[u] = live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0;\n";
+      }
     }
   }
   s << "  }\n";
@@ -630,6 +739,12 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "      const bool live = FULL || row < n;\n"
     << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
     << "      (void)livemask; (void)row;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.is_varlen() && cg.needs_values_[k])
+      s << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "[u], ob" << k
+        << "[u]);\n";
+  }
   if (!sel) {
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
@@ -695,22 +810,29 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   std::ostringstream after_loop;
   std::vector<std::string> strings;
   const std::string st = opts.nontemporal ? "gdv_stnt" : "gdv_st";
+  for (auto& e : exprs) plan->has_varlen_output |= e->result().type.is_varlen();
+  const bool two = plan->has_varlen_output;
+  const std::string p0 = two ? "pass == 0 && " : "";
   for (size_t e = 0; e < exprs.size(); e++) {
     Val v;
     cg.Stmt("// @expr_" + std::to_string(e));
     GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "", &v));
     const DataType& t = exprs[e]->result().type;
-    if (t.is_varlen())
-      return Status::CodeGenError("output type " + t.ToString() +
-                                  " is not supported by the HIP backend yet");
     plan->output_types.push_back(t);
     strings.push_back(exprs[e]->ToString());
     const std::string E = std::to_string(e);
-    if (t.id == kBool) {
+    if (t.is_varlen()) {
+      // pass 0: byte length of every row (0 for nulls) into offsets[row + 1]; the host
+      // turns them into offsets with an in-place scan; pass 1: the bytes at offsets[row]
+      const std::string ok = CodeGen::AndExpr("live", cg.LaneValid(v));
+      cg.Stmt("if (pass == 0) { if (live) outo" + E + "[row + 1] = (" + ok + ") ? (" + v.v +
+              ").len : 0; }");
+      cg.Stmt("else if (" + ok + ") gdv_str_copy(outd" + E + " + outo" + E + "[row], " + v.v + ");");
+    } else if (t.id == kBool) {
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
-      after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)");
+      after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)", two);
     } else {
-      cg.Stmt("if (live) " + st + "(out" + E + ", row, (" + t.CType() + ")" + v.v + ");");
+      cg.Stmt("if (" + p0 + "live) " + st + "(out" + E + ", row, (" + t.CType() + ")" + v.v + ");");
     }
     // validity word of the 64 rows of this sub-tile
     std::string word;
@@ -720,7 +842,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
       if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
     }
-    after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid");
+    after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid", two);
   }
   return Assemble(cg, plan, strings, accs, "", after_loop.str());
 }

@@ -62,6 +62,9 @@ struct KernelPlan {
   std::vector<DataType> output_types;  // one per expression (filter: none)
   ArgLayout layout;
   bool can_raise = false;          // kernel may set error bits
+  // Some output is utf8/binary: the kernel is launched twice (aux0 = 0: lengths into the
+  // offsets buffers + all fixed-width outputs; aux0 = 1: bytes, after the offsets scan).
+  bool has_varlen_output = false;
   int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
 };
 

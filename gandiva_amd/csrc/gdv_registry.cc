@@ -218,6 +218,35 @@ FunctionRegistry::FunctionRegistry() {
     add("isnull", {dec}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnull");
     add("isnotnull", {dec}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
   }
+  // utf8 / binary
+  for (auto& t : {utf8(), binary()}) {
+    for (const char* op : {"equal", "not_equal", "less_than", "less_than_or_equal_to",
+                           "greater_than", "greater_than_or_equal_to"})
+      add(op, {t, t}, boolean(), NullPolicy::kNullIfNull, 0, std::string(op) + "_utf8_utf8");
+    add("isnull", {t}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnull");
+    add("isnotnull", {t}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
+    add("octet_length", {t}, int32(), NullPolicy::kNullIfNull, 0, "octet_length_utf8");
+    add("bit_length", {t}, int32(), NullPolicy::kNullIfNull, 0, "bit_length_utf8");
+  }
+  add("starts_with", {utf8(), utf8()}, boolean());
+  add("ends_with", {utf8(), utf8()}, boolean());
+  add("char_length", {utf8()}, int32());
+  add("length", {utf8()}, int32(), NullPolicy::kNullIfNull, 0, "char_length_utf8");
+  add("lengthUtf8", {binary()}, int32(), NullPolicy::kNullIfNull, 0, "char_length_utf8");
+  add("like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
+  add("like", {utf8(), utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
+  add("upper", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("lower", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("substr", {utf8(), int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("substring", {utf8(), int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult,
+      "substr_utf8_int64_int64");
+  add("substr", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("substring", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult,
+      "substr_utf8_int64");
+  add("ltrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("rtrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("btrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("trim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "btrim_utf8");
   add("datediff", {date32(), date32()}, int32());
   add("date_diff", {date32(), date32()}, int32(), NullPolicy::kNullIfNull, 0,
       "datediff_date32_date32");

@@ -376,7 +376,9 @@ class DeviceColumn:
         bufs = [None if self.validity is None else pa.py_buffer(self.validity.cpu().numpy())]
         if self.offsets is not None:
             bufs.append(pa.py_buffer(self.offsets.cpu().numpy()))
-        bufs.append(pa.py_buffer(self.data.cpu().numpy()))
+        used = getattr(self, "data_used", None)
+        data = self.data if used is None else self.data[:used]
+        bufs.append(pa.py_buffer(data.cpu().numpy()))
         return pa.Array.from_buffers(self.type, self.length, bufs, offset=self.offset)
 
 
@@ -475,24 +477,55 @@ class Projector:
         out_rows = selection.num_slots if selection is not None else batch.num_rows
         n_out = len(self._out_types)
         outs = (gdv_out_column_t * n_out)()
-        holders = []
+        holders = [None] * n_out
+        varlen = [pa.types.is_string(t) or pa.types.is_binary(t) for t in self._out_types]
+        # first guess for var-len byte capacity: the bytes of all var-len inputs
+        guess = 64 + sum(a.buffers()[2].size for a in batch.columns
+                         if (pa.types.is_string(a.type) or pa.types.is_binary(a.type))
+                         and a.buffers()[2] is not None)
         for i, t in enumerate(self._out_types):
             vb, db = C.c_int64(), C.c_int64()
             _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_HOST, vb, db))
             v = pa.allocate_buffer(_pad64(max(vb.value, 1)))
-            d = pa.allocate_buffer(_pad64(max(db.value, 1)))
-            holders.append((v, d))
+            d = pa.allocate_buffer(_pad64(guess if varlen[i] else max(db.value, 1)))
+            o = pa.allocate_buffer(_pad64((out_rows + 1) * 4)) if varlen[i] else None
+            holders[i] = [v, d, o]
             outs[i].validity, outs[i].validity_size = v.address, v.size
             outs[i].data, outs[i].data_size = d.address, d.size
+            if o is not None:
+                outs[i].offsets, outs[i].offsets_size = o.address, o.size
         sel_c = None
         if selection is not None:
             if selection.device:
                 raise TypeError("device selection vector passed to the host evaluate()")
             s = selection._c()
             sel_c = C.byref(s)
-        _check(lib.gdv_projector_evaluate(self._h, batch.num_rows, cols, batch.num_columns, sel_c,
-                                          outs, n_out, GDV_MEM_HOST, None, 0))
-        return [pa.Array.from_buffers(t, out_rows, [v, d]) for t, (v, d) in zip(self._out_types, holders)]
+        for attempt in range(2):
+            caps = [outs[i].data_size for i in range(n_out)]
+            rc = lib.gdv_projector_evaluate(self._h, batch.num_rows, cols, batch.num_columns, sel_c,
+                                            outs, n_out, GDV_MEM_HOST, None, 0)
+            grown = False
+            if rc == 4 and attempt == 0:
+                # a var-len byte buffer was too small: data_size now holds the bytes needed
+                for i in range(n_out):
+                    if varlen[i] and outs[i].data_size > caps[i]:
+                        d = pa.allocate_buffer(_pad64(outs[i].data_size))
+                        holders[i][1] = d
+                        outs[i].data, outs[i].data_size = d.address, d.size
+                        grown = True
+                    elif varlen[i]:
+                        outs[i].data_size = caps[i]
+            if not grown:
+                _check(rc)
+                break
+        result = []
+        for i, t in enumerate(self._out_types):
+            v, d, o = holders[i]
+            if varlen[i]:
+                result.append(pa.Array.from_buffers(t, out_rows, [v, o, d.slice(0, outs[i].data_size)]))
+            else:
+                result.append(pa.Array.from_buffers(t, out_rows, [v, d]))
+        return result
 
     def evaluate_device(self, dbatch, selection=None, outputs=None, stream=None, sync=True):
         """HBM-resident path (zero-copy): inputs are a DeviceBatch, outputs DeviceColumns
@@ -502,28 +535,53 @@ class Projector:
         cols = (gdv_column_t * max(len(dbatch.columns), 1))(*[c._c() for c in dbatch.columns])
         out_rows = selection.num_slots if selection is not None else dbatch.num_rows
         n_out = len(self._out_types)
+        varlen = [pa.types.is_string(t) or pa.types.is_binary(t) for t in self._out_types]
         if outputs is None:
             outputs = []
+            guess = 64 + sum(c.data.numel() for c in dbatch.columns if c.offsets is not None)
             for i, t in enumerate(self._out_types):
                 vb, db = C.c_int64(), C.c_int64()
                 _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_DEVICE, vb, db))
                 outputs.append(DeviceColumn(
                     t, out_rows,
                     torch.empty(_pad64(max(vb.value, 1)), dtype=torch.uint8, device="cuda"),
-                    torch.empty(_pad64(max(db.value, 1)), dtype=torch.uint8, device="cuda")))
+                    torch.empty(_pad64(guess if varlen[i] else max(db.value, 1)), dtype=torch.uint8,
+                                device="cuda"),
+                    torch.empty(_pad64((out_rows + 1) * 4), dtype=torch.uint8, device="cuda")
+                    if varlen[i] else None))
         outs = (gdv_out_column_t * n_out)()
         for i, o in enumerate(outputs):
             outs[i].validity, outs[i].validity_size = o.validity.data_ptr(), o.validity.numel()
             outs[i].data, outs[i].data_size = o.data.data_ptr(), o.data.numel()
+            if o.offsets is not None:
+                outs[i].offsets, outs[i].offsets_size = o.offsets.data_ptr(), o.offsets.numel()
         sel_c = None
         if selection is not None:
             s = selection._c()
             sel_c = C.byref(s)
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        _check(lib.gdv_projector_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c,
-                                          outs, n_out, GDV_MEM_DEVICE, C.c_void_p(stream),
-                                          0 if sync else GDV_EVAL_ASYNC))
+        for attempt in range(2):
+            caps = [outs[i].data_size for i in range(n_out)]
+            rc = lib.gdv_projector_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c,
+                                            outs, n_out, GDV_MEM_DEVICE, C.c_void_p(stream),
+                                            0 if sync else GDV_EVAL_ASYNC)
+            grown = False
+            if rc == 4 and attempt == 0:
+                for i in range(n_out):
+                    if varlen[i] and outs[i].data_size > caps[i]:
+                        outputs[i].data = torch.empty(_pad64(outs[i].data_size), dtype=torch.uint8,
+                                                      device="cuda")
+                        outs[i].data, outs[i].data_size = outputs[i].data.data_ptr(), outputs[i].data.numel()
+                        grown = True
+                    elif varlen[i]:
+                        outs[i].data_size = caps[i]
+            if not grown:
+                _check(rc)
+                break
+        for i in range(n_out):
+            if varlen[i]:
+                outputs[i].data_used = outs[i].data_size
         return outputs
 
 

@@ -223,3 +223,57 @@ def c4_device_batch(n, device="cuda", chunk=1 << 25):
     ship.random_(8036, 10562, generator=g)
     cols.append(gdv.DeviceColumn(pa.date32(), n, None, ship.view(torch.uint8)))
     return gdv.DeviceBatch(c4_schema(), cols, n)
+
+
+# ------------------------------------------------------------------------------- C5
+# utf8 like / substr / upper over a var-len column: lengths U[4,20], ASCII letters, 5 % of the
+# rows contain "spark".
+
+def c5_schema():
+    return pa.schema([pa.field("s", pa.string())])
+
+
+def c5_expressions(builder=None):
+    b = builder or gdv.TreeExprBuilder()
+    s = b.make_field(c5_schema().field(0))
+    like = b.make_function("like", [s, b.make_literal("%spark%", pa.string())], pa.bool_())
+    sub = b.make_function("substr", [s, b.make_literal(2, pa.int64()), b.make_literal(5, pa.int64())],
+                          pa.string())
+    up = b.make_function("upper", [s], pa.string())
+    return [b.make_expression(like, pa.field("is_spark", pa.bool_())),
+            b.make_expression(sub, pa.field("sub", pa.string())),
+            b.make_expression(up, pa.field("up", pa.string()))]
+
+
+def c5_numpy(n, seed=21, null_fraction=0.0):
+    """(offsets int32[n+1], bytes uint8[total], null mask or None)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = rng.integers(4, 21, n).astype(np.int64)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ", dtype=np.uint8)
+    data = letters[rng.integers(0, len(letters), int(offsets[-1]))].copy()
+    # plant "spark" in ~5 % of the rows that are long enough
+    pick = np.flatnonzero((rng.random(n) < 0.05) & (lens >= 5))
+    pos = offsets[pick] + (rng.random(len(pick)) * (lens[pick] - 4)).astype(np.int64)
+    for k, ch in enumerate(b"spark"):
+        data[pos + k] = ch
+    mask = (rng.random(n) < null_fraction) if null_fraction > 0 else None
+    return offsets.astype(np.int32), data, mask
+
+
+def c5_batch(n, null_fraction=0.0):
+    offsets, data, mask = c5_numpy(n, null_fraction=null_fraction)
+    validity = None if mask is None else pa.py_buffer(np.packbits(~mask, bitorder="little"))
+    arr = pa.Array.from_buffers(pa.string(), n, [validity, pa.py_buffer(offsets), pa.py_buffer(data)])
+    return pa.RecordBatch.from_arrays([arr], schema=c5_schema())
+
+
+def c5_device_batch(n, device="cuda"):
+    import torch
+    offsets, data, _ = c5_numpy(n)
+    pad = lambda t: torch.cat([t, torch.zeros((-t.numel()) % 64 + 64, dtype=torch.uint8)])
+    off_t = pad(torch.from_numpy(offsets.view(np.uint8).copy())).to(device)
+    dat_t = pad(torch.from_numpy(data)).to(device)
+    col = gdv.DeviceColumn(pa.string(), n, None, dat_t, off_t)
+    return gdv.DeviceBatch(c5_schema(), [col], n)

@@ -137,8 +137,10 @@ typedef struct {
 typedef struct {
   void* validity;
   int64_t validity_size;
-  void* data;
-  int64_t data_size;
+  void* data;        /* fixed-width values | bool bits | var-len bytes */
+  int64_t data_size; /* var-len: capacity in; bytes produced (or needed, on GDV_INVALID) out */
+  void* offsets;     /* var-len outputs only: (rows + 1) int32 offsets; NULL otherwise */
+  int64_t offsets_size;
 } gdv_out_column_t;
 
 typedef struct {
@@ -207,6 +209,11 @@ gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i);
  * are written in whole 64-bit bitmap words: validity (and bool data) = 8 * ceil(rows/64). */
 int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, int mem_kind,
                                int64_t* validity_bytes, int64_t* data_bytes);
+/* var-len (utf8/binary) outputs: offsets need (rows + 1) * 4 bytes; *data_bytes above is
+ * reported as 0 — the byte total is only known after the length pass: call evaluate with any
+ * capacity; when it is too small the call fails with GDV_INVALID and data_size is updated to
+ * the bytes needed (the reference's JNI path grows its buffer through an expander callback
+ * for the same reason). */
 /* cols: one entry per schema field, in schema order.  sel: NULL, or the selection vector
  * (mode must equal the mode given to make).  Output row count = sel ? sel->num_slots
  * : num_rows.  stream: hipStream_t as void* (NULL = default stream). */

@@ -41,7 +41,7 @@
 
 enum {
   T_BOOL = 1, T_U8 = 2, T_I8 = 3, T_U16 = 4, T_I16 = 5, T_U32 = 6, T_I32 = 7, T_U64 = 8,
-  T_I64 = 9, T_F32 = 11, T_F64 = 12, T_DATE32 = 16, T_DATE64 = 17, T_TS = 18, T_TIME32 = 19,
+  T_I64 = 9, T_F32 = 11, T_F64 = 12, T_STR = 13, T_BIN = 14, T_DATE32 = 16, T_DATE64 = 17, T_TS = 18, T_TIME32 = 19,
   T_TIME64 = 20, T_DEC = 23
 };
 typedef __int128 i128;
@@ -53,6 +53,7 @@ typedef struct {
   const void* data;
   int64_t offset; /* Arrow array offset */
   int32_t precision, scale; /* decimal128 only */
+  const int32_t* offsets;   /* utf8 / binary only */
 } or_column;
 
 /* A chunk of evaluated values: every value widened to a 64-bit slot. */
@@ -61,6 +62,10 @@ typedef struct {
   int32_t prec, scale; /* decimal128 values */
   union { int64_t i; uint64_t u; double d; float f; i128 q; } v[CHUNK];
   uint8_t valid[CHUNK];
+  /* utf8 / binary values are views (pointer, length) + a byte map (0 none, 1 upper, 2 lower) */
+  const uint8_t* sp[CHUNK];
+  int32_t sl[CHUNK];
+  int smap;
 } vec;
 
 typedef struct node {
@@ -75,6 +80,9 @@ typedef struct node {
   struct node** args;
   int nvals;
   uint64_t* vals;
+  uint8_t* sbytes; /* string literal / concatenated IN strings */
+  int32_t slen;
+  int32_t* soffs;  /* IN strings: nvals + 1 offsets into sbytes */
 } node;
 
 typedef struct {
@@ -121,6 +129,39 @@ static node* parse(const char** p, const or_column* cols) {
       next_tok(p, t, sizeof t); n->lo = strtoull(t, NULL, 16);
       next_tok(p, t, sizeof t); n->hi = strtoull(t, NULL, 16);
       break;
+    case 'S': { /* S <type> <is_null> <len> <hex bytes | -> */
+      next_tok(p, t, sizeof t); parse_type(t, &n->type, &n->prec, &n->scale);
+      next_tok(p, t, sizeof t); n->is_null = atoi(t);
+      next_tok(p, t, sizeof t); n->slen = atoi(t);
+      n->sbytes = (uint8_t*)calloc(n->slen + 1, 1);
+      char* hex = (char*)malloc(2 * (size_t)n->slen + 8);
+      next_tok(p, hex, 2 * (size_t)n->slen + 8);
+      for (int i = 0; i < n->slen; i++) { unsigned v; sscanf(hex + 2 * i, "%2x", &v); n->sbytes[i] = (uint8_t)v; }
+      free(hex);
+      n->kind = 'L';
+      break;
+    }
+    case 'M': { /* M <n> (<len> <hex|->)... e : IN over strings */
+      n->type = T_BOOL;
+      next_tok(p, t, sizeof t); n->nvals = atoi(t);
+      n->soffs = (int32_t*)calloc(n->nvals + 1, sizeof(int32_t));
+      size_t cap = 16;
+      n->sbytes = (uint8_t*)malloc(cap);
+      for (int k = 0; k < n->nvals; k++) {
+        next_tok(p, t, sizeof t);
+        int len = atoi(t);
+        char* hex = (char*)malloc(2 * (size_t)len + 8);
+        next_tok(p, hex, 2 * (size_t)len + 8);
+        while ((size_t)n->soffs[k] + len + 1 > cap) { cap *= 2; n->sbytes = (uint8_t*)realloc(n->sbytes, cap); }
+        for (int i = 0; i < len; i++) { unsigned v; sscanf(hex + 2 * i, "%2x", &v); n->sbytes[n->soffs[k] + i] = (uint8_t)v; }
+        n->soffs[k + 1] = n->soffs[k] + len;
+        free(hex);
+      }
+      n->nargs = 1;
+      n->args = (node**)calloc(1, sizeof(node*));
+      n->args[0] = parse(p, cols);
+      break;
+    }
     case 'C':
       next_tok(p, t, sizeof t); snprintf(n->name, sizeof n->name, "%s", t);
       next_tok(p, t, sizeof t); parse_type(t, &n->type, &n->prec, &n->scale);
@@ -162,6 +203,8 @@ static void free_node(node* n) {
   for (int i = 0; i < n->nargs; i++) free_node(n->args[i]);
   free(n->args);
   free(n->vals);
+  free(n->sbytes);
+  free(n->soffs);
   free(n);
 }
 
@@ -214,6 +257,11 @@ static void load_column(const or_column* c, int64_t row0, int n, vec* out) {
       case T_F32: out->v[i].f = ((const float*)c->data)[r]; break;
       case T_F64: out->v[i].d = ((const double*)c->data)[r]; break;
       case T_DEC: memcpy(&out->v[i].q, (const char*)c->data + 16 * r, 16); break;
+      case T_STR: case T_BIN:
+        out->sp[i] = (const uint8_t*)c->data + c->offsets[r];
+        out->sl[i] = c->offsets[r + 1] - c->offsets[r];
+        out->smap = 0;
+        break;
       default: out->v[i].i = ((const int64_t*)c->data)[r]; break;
     }
   }
@@ -323,6 +371,84 @@ static int cmp_op(const char* name) {
 }
 #define CMP(op, a, b) ((op) == 0 ? (a) == (b) : (op) == 1 ? (a) != (b) : (op) == 2 ? (a) < (b) : \
                        (op) == 3 ? (a) <= (b) : (op) == 4 ? (a) > (b) : (a) >= (b))
+
+/* ---------------------------------------------------------------- utf8 / binary */
+static uint8_t map_byte(uint8_t c, int map) {
+  if (map == 1) return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c;
+  if (map == 2) return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
+  return c;
+}
+static int is_lead(uint8_t c) { return (c & 0xC0) != 0x80; }
+static int str_cmp(const uint8_t* a, int al, int am, const uint8_t* b, int bl, int bm) {
+  int n = al < bl ? al : bl;
+  for (int i = 0; i < n; i++) {
+    uint8_t x = map_byte(a[i], am), y = map_byte(b[i], bm);
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return al < bl ? -1 : (al > bl ? 1 : 0);
+}
+/* SQL LIKE by dynamic programming over (pattern tokens) x (characters): independent of the
+ * device library's two-cursor matcher.  '%' any run, '_' one UTF-8 character, esc optional. */
+static int like_match(const uint8_t* s, int sl, int smap, const uint8_t* pat, int pl, int esc) {
+  /* tokenise */
+  uint8_t* tb = (uint8_t*)malloc(pl + 1);
+  uint8_t* tk = (uint8_t*)malloc(pl + 1);
+  int nt = 0;
+  for (int i = 0; i < pl; i++) {
+    if (esc >= 0 && pat[i] == esc && i + 1 < pl) { tb[nt] = pat[++i]; tk[nt++] = 0; }
+    else if (pat[i] == '%') { tb[nt] = 0; tk[nt++] = 2; }
+    else if (pat[i] == '_') { tb[nt] = 0; tk[nt++] = 1; }
+    else { tb[nt] = pat[i]; tk[nt++] = 0; }
+  }
+  /* character start positions */
+  int* cs = (int*)malloc(sizeof(int) * (sl + 2));
+  int nc = 0;
+  for (int i = 0; i < sl; i++) if (is_lead(s[i]) || i == 0) cs[nc++] = i;
+  cs[nc] = sl;
+  /* literal tokens match BYTES; walk bytes, but '_' consumes a whole character.
+     dp over byte positions: reach[j][b] = pattern[0..j) matches s[0..b) */
+  uint8_t* cur = (uint8_t*)calloc(sl + 1, 1);
+  uint8_t* nxt = (uint8_t*)calloc(sl + 1, 1);
+  cur[0] = 1;
+  for (int j = 0; j < nt; j++) {
+    memset(nxt, 0, sl + 1);
+    if (tk[j] == 2) {
+      int seen = 0;
+      for (int b = 0; b <= sl; b++) {
+        if (cur[b]) seen = 1;
+        /* '%' may end only on a character boundary or at the end */
+        if (seen && (b == sl || is_lead(s[b]))) nxt[b] = 1;
+      }
+    } else if (tk[j] == 1) {
+      for (int c = 0; c < nc; c++) if (cur[cs[c]]) nxt[cs[c + 1]] = 1;
+    } else {
+      for (int b = 0; b < sl; b++) if (cur[b] && map_byte(s[b], smap) == tb[j]) nxt[b + 1] = 1;
+    }
+    uint8_t* t = cur; cur = nxt; nxt = t;
+  }
+  int ok = cur[sl];
+  free(tb); free(tk); free(cs); free(cur); free(nxt);
+  return ok;
+}
+static void substr_view(const uint8_t* s, int sl, int64_t from, int64_t count, const uint8_t** op, int32_t* ol) {
+  *op = s; *ol = 0;
+  if (count <= 0 || sl <= 0) return;
+  int64_t glyphs = 0;
+  for (int i = 0; i < sl; i++) glyphs += is_lead(s[i]);
+  int64_t start = from > 0 ? from - 1 : (from < 0 ? glyphs + from : 0);
+  if (start < 0 || start >= glyphs) return;
+  int64_t stop = start + count < glyphs ? start + count : glyphs;
+  int64_t g = 0; int b0 = sl, b1 = sl;
+  for (int i = 0; i < sl; i++) {
+    if (is_lead(s[i])) {
+      if (g == start) b0 = i;
+      if (g == stop) { b1 = i; break; }
+      g++;
+    }
+  }
+  *op = s + b0; *ol = b1 - b0;
+}
+static int is_str(int t) { return t == T_STR || t == T_BIN; }
 
 /* ---------------------------------------------------------------- decimal128
  * Exact arithmetic on 256-bit magnitudes (4 x 64-bit limbs), scale reduction one decimal
@@ -437,7 +563,40 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
     out->valid[i] = v;
   }
   int op;
-  if (t0 == T_DEC || n->type == T_DEC) {
+  if (is_str(t0)) {
+    const int two_str = n->nargs >= 2 && is_str(a[1].type);
+    out->smap = 0;
+    for (int i = 0; i < cnt; i++) {
+      const uint8_t* x = a[0].sp[i]; int xl = a[0].sl[i], xm = a[0].smap;
+      const uint8_t* y = two_str ? a[1].sp[i] : NULL; int yl = two_str ? a[1].sl[i] : 0, ym = two_str ? a[1].smap : 0;
+      if ((op = cmp_op(f)) >= 0) { int c3 = str_cmp(x, xl, xm, y, yl, ym); out->v[i].i = CMP(op, c3, 0); }
+      else if (!strcmp(f, "isnull")) { out->v[i].i = !a[0].valid[i]; out->valid[i] = 1; }
+      else if (!strcmp(f, "isnotnull")) { out->v[i].i = a[0].valid[i]; out->valid[i] = 1; }
+      else if (!strcmp(f, "octet_length")) out->v[i].i = xl;
+      else if (!strcmp(f, "bit_length")) out->v[i].i = xl * 8;
+      else if (!strcmp(f, "char_length") || !strcmp(f, "length") || !strcmp(f, "lengthUtf8")) {
+        int g = 0; for (int k = 0; k < xl; k++) g += is_lead(x[k]); out->v[i].i = g;
+      } else if (!strcmp(f, "starts_with")) {
+        out->v[i].i = yl <= xl && str_cmp(x, yl, xm, y, yl, ym) == 0;
+      } else if (!strcmp(f, "ends_with")) {
+        out->v[i].i = yl <= xl && str_cmp(x + (xl - yl), yl, xm, y, yl, ym) == 0;
+      } else if (!strcmp(f, "like")) {
+        int esc = n->nargs == 3 ? a[2].sp[i][0] : -1;
+        out->v[i].i = like_match(x, xl, xm, y, yl, esc);
+      } else if (!strcmp(f, "upper") || !strcmp(f, "lower")) {
+        out->sp[i] = x; out->sl[i] = xl; out->smap = f[0] == 'u' ? 1 : 2;
+      } else if (!strcmp(f, "substr") || !strcmp(f, "substring")) {
+        int64_t cntc = n->nargs == 3 ? a[2].v[i].i : 0x7fffffff;
+        substr_view(x, xl, a[1].v[i].i, cntc, &out->sp[i], &out->sl[i]);
+        out->smap = xm;
+      } else if (!strcmp(f, "ltrim") || !strcmp(f, "rtrim") || !strcmp(f, "btrim") || !strcmp(f, "trim")) {
+        int lo = 0, hi = xl;
+        if (f[0] != 'r') while (lo < hi && x[lo] == ' ') lo++;
+        if (f[0] != 'l') while (hi > lo && x[hi - 1] == ' ') hi--;
+        out->sp[i] = x + lo; out->sl[i] = hi - lo; out->smap = xm;
+      } else { c->err |= 0x100; }
+    }
+  } else if (t0 == T_DEC || n->type == T_DEC) {
     const int two = n->nargs == 2;
     for (int i = 0; i < cnt; i++) {
       i128 x = a[0].v[i].q, y = two ? a[1].v[i].q : 0;
@@ -654,6 +813,7 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
       out->scale = n->scale;
       for (int i = 0; i < cnt; i++) {
         out->valid[i] = !n->is_null;
+        if (is_str(n->type)) { out->sp[i] = n->sbytes; out->sl[i] = n->slen; out->smap = 0; continue; }
         if (n->type == T_DEC) { out->v[i].q = (i128)(((u128)n->hi << 64) | n->lo); continue; }
         if (n->type == T_F32) { uint32_t b = (uint32_t)n->lo; memcpy(&out->v[i].f, &b, 4); }
         else out->v[i].u = n->lo;
@@ -685,6 +845,11 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
         int take = cnd->valid[i] && cnd->v[i].i;
         out->v[i] = take ? th->v[i] : el->v[i];
         out->valid[i] = take ? th->valid[i] : el->valid[i];
+        if (is_str(n->type)) {
+          out->sp[i] = take ? th->sp[i] : el->sp[i];
+          out->sl[i] = take ? th->sl[i] : el->sl[i];
+          out->smap = th->smap; /* branches with different byte maps are not restated */
+        }
       }
       free(cnd);
       return;
@@ -710,6 +875,22 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
         out->valid[i] = (uint8_t)(decided[i] || all_valid[i]);
         out->v[i].i = is_and ? (!decided[i] && all_valid[i]) : decided[i];
       }
+      return;
+    }
+    case 'M': {
+      vec* x = (vec*)malloc(sizeof(vec));
+      eval(n->args[0], c, row0, cnt, active, x);
+      out->type = T_BOOL;
+      for (int i = 0; i < cnt; i++) {
+        int hit = 0;
+        for (int k = 0; k < n->nvals && !hit; k++) {
+          int len = n->soffs[k + 1] - n->soffs[k];
+          hit = len == x->sl[i] && str_cmp(x->sp[i], x->sl[i], x->smap, n->sbytes + n->soffs[k], len, 0) == 0;
+        }
+        out->v[i].i = hit;
+        out->valid[i] = x->valid[i];
+      }
+      free(x);
       return;
     }
     case 'N': {
@@ -836,4 +1017,37 @@ int64_t gdv_oracle_bitmap_to_selection(const uint8_t* value_bits, const uint8_t*
     }
   }
   return k;
+}
+
+
+/*
+ * Var-len (utf8 / binary) result of ONE expression: offsets[0..n] and the bytes.  Null rows
+ * have length 0.  Returns the total byte count; bytes are written only while they fit `cap`
+ * (call again with a larger buffer when the return value exceeds it), or -1 on error.
+ */
+int64_t gdv_oracle_project_str(const char* program, const or_column* cols, int ncols, int64_t n,
+                               int32_t* offsets, uint8_t* data, int64_t cap, uint8_t* out_validity) {
+  const char* p = program;
+  node* root = parse(&p, cols);
+  if (!root) return -1;
+  ctx c = {cols, ncols, 0};
+  vec* r = (vec*)malloc(sizeof(vec));
+  int64_t total = 0;
+  offsets[0] = 0;
+  for (int64_t row = 0; row < n; row += CHUNK) {
+    int cnt = (int)((n - row) < CHUNK ? (n - row) : CHUNK);
+    eval(root, &c, row, cnt, NULL, r);
+    for (int i = 0; i < cnt; i++) {
+      int64_t rr = row + i;
+      int len = r->valid[i] ? r->sl[i] : 0;
+      if (r->valid[i]) out_validity[rr >> 3] |= (uint8_t)(1u << (rr & 7));
+      if (total + len <= cap)
+        for (int k = 0; k < len; k++) data[total + k] = map_byte(r->sp[i][k], r->smap);
+      total += len;
+      offsets[rr + 1] = (int32_t)total;
+    }
+  }
+  free(r);
+  free_node(root);
+  return c.err ? -1 : total;
 }

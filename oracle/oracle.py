@@ -31,7 +31,8 @@ def build(force=False):
 
 class _Column(C.Structure):
     _fields_ = [("type", C.c_int32), ("validity", C.c_void_p), ("data", C.c_void_p),
-                ("offset", C.c_int64), ("precision", C.c_int32), ("scale", C.c_int32)]
+                ("offset", C.c_int64), ("precision", C.c_int32), ("scale", C.c_int32),
+                ("offsets", C.c_void_p)]
 
 
 def lib():
@@ -48,6 +49,9 @@ def lib():
         l.gdv_oracle_bitmap_to_selection.restype = C.c_int64
         l.gdv_oracle_bitmap_to_selection.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                      C.c_void_p, C.c_int64]
+        l.gdv_oracle_project_str.restype = C.c_int64
+        l.gdv_oracle_project_str.argtypes = [C.c_char_p, C.POINTER(_Column), C.c_int, C.c_int64,
+                                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = l
     return _lib
 
@@ -56,6 +60,7 @@ _TYPE_IDS = [
     (pa.types.is_boolean, 1), (pa.types.is_uint8, 2), (pa.types.is_int8, 3), (pa.types.is_uint16, 4),
     (pa.types.is_int16, 5), (pa.types.is_uint32, 6), (pa.types.is_int32, 7), (pa.types.is_uint64, 8),
     (pa.types.is_int64, 9), (pa.types.is_float32, 11), (pa.types.is_float64, 12),
+    (pa.types.is_string, 13), (pa.types.is_binary, 14),
     (pa.types.is_date32, 16), (pa.types.is_date64, 17), (pa.types.is_timestamp, 18),
     (pa.types.is_time32, 19), (pa.types.is_time64, 20), (pa.types.is_decimal128, 23),
 ]
@@ -90,6 +95,9 @@ def serialize(node, schema):
     if k == "literal":
         tid = type_id(node.dtype)
         tok = type_token(node.dtype)
+        if tid in (13, 14):
+            raw = b"" if node.desc["is_null"] else node.desc["value"]
+            return f"S {tok} {int(node.desc['is_null'])} {len(raw)} {raw.hex() or '-'}"
         if node.desc["is_null"]:
             return f"L {tok} 1 0 0"
         bits = _bits(tid, node.desc['value'])
@@ -103,6 +111,12 @@ def serialize(node, schema):
     if k in ("and", "or"):
         kids = node.desc["children"]
         return " ".join([f"{'A' if k == 'and' else 'O'} {len(kids)}"] + [serialize(c, schema) for c in kids])
+    if k == "in" and type_id(node.desc["value_type"]) in (13, 14):
+        vals = node.desc["values"]
+        parts = [f"M {len(vals)}"]
+        for v in vals:
+            parts += [str(len(v)), v.hex() or "-"]
+        return " ".join(parts + [serialize(node.desc["children"][0], schema)])
     if k == "in":
         tid = type_id(node.desc["value_type"])
         vals = [f"{_bits(tid, v):x}" for v in node.desc["values"]]
@@ -121,7 +135,11 @@ def _columns(batch):
         bufs = arr.buffers()
         cols[i].type = tid
         cols[i].validity = bufs[0].address if bufs[0] is not None else None
-        cols[i].data = bufs[1].address if len(bufs) > 1 and bufs[1] is not None else None
+        if tid in (13, 14):
+            cols[i].offsets = bufs[1].address
+            cols[i].data = bufs[2].address if bufs[2] is not None else None
+        else:
+            cols[i].data = bufs[1].address if len(bufs) > 1 and bufs[1] is not None else None
         cols[i].offset = arr.offset
         if tid == 23:
             cols[i].precision, cols[i].scale = arr.type.precision, arr.type.scale
@@ -143,6 +161,8 @@ def project_one(root, result_type, batch, threads=1):
     """Evaluate one expression tree over the batch -> pyarrow.Array (host)."""
     n = batch.num_rows
     tid = type_id(result_type)
+    if tid in (13, 14):
+        return _project_str(root, result_type, batch)
     width = 0 if tid == 1 else result_type.bit_width // 8
     vbytes = (n + 7) // 8
     validity = np.zeros(max(vbytes, 1), dtype=np.uint8)
@@ -154,6 +174,26 @@ def project_one(root, result_type, batch, threads=1):
     if err:
         _raise(err)
     return pa.Array.from_buffers(result_type, n, [pa.py_buffer(validity), pa.py_buffer(data)])
+
+
+def _project_str(root, result_type, batch):
+    n = batch.num_rows
+    cols, keep = _columns(batch)
+    prog = serialize(root, batch.schema).encode()
+    cap = 1 << 16
+    while True:
+        validity = np.zeros(max((n + 7) // 8, 1), dtype=np.uint8)
+        offsets = np.zeros(n + 1, dtype=np.int32)
+        data = np.zeros(max(cap, 1), dtype=np.uint8)
+        total = lib().gdv_oracle_project_str(prog, cols, batch.num_columns, n, offsets.ctypes.data,
+                                             data.ctypes.data, cap, validity.ctypes.data)
+        if total < 0:
+            raise OracleError("oracle string evaluation failed")
+        if total <= cap:
+            break
+        cap = int(total)
+    return pa.Array.from_buffers(result_type, n, [pa.py_buffer(validity), pa.py_buffer(offsets),
+                                                  pa.py_buffer(data[:max(total, 0)])])
 
 
 def project(expressions, batch, threads=1):

@@ -49,6 +49,28 @@ def kat_filter():  # test_gandiva.py:93-114
     return "filter", table.to_batches()[0], condition, pa.array(range(1000), type=pa.uint32())
 
 
+def kat_in_utf8():  # test_gandiva.py:117-129
+    arr = pa.array(["ga", "an", "nd", "di", "iv", "va"])
+    table = pa.Table.from_arrays([arr], ["a"])
+    builder = gandiva.TreeExprBuilder()
+    node_a = builder.make_field(table.schema.field("a"))
+    cond = builder.make_in_expression(node_a, ["an", "nd"], pa.string())
+    return "filter", table.to_batches()[0], builder.make_condition(cond), \
+        pa.array([1, 2], type=pa.uint32())
+
+
+def kat_regex():  # test_gandiva.py:295-316
+    elements = ["park", "sparkle", "bright spark and fire", "spark"]
+    data = pa.array(elements, type=pa.string())
+    table = pa.Table.from_arrays([data], names=['a'])
+    builder = gandiva.TreeExprBuilder()
+    node_a = builder.make_field(table.schema.field("a"))
+    regex = builder.make_literal("%spark%", pa.string())
+    like = builder.make_function("like", [node_a, regex], pa.bool_())
+    expr = builder.make_expression(like, pa.field("b", pa.bool_()))
+    return "project", table.to_batches()[0], [expr], [pa.array([False, True, True, True], type=pa.bool_())]
+
+
 def kat_in_int32():  # test_gandiva.py:131-140
     arr = pa.array([3, 1, 4, 1, 5, 9, 2, 6, 5, 4])
     table = pa.Table.from_arrays([arr.cast(pa.int32())], ["a"])
@@ -104,8 +126,8 @@ def kat_filter_project():  # test_gandiva.py:329-373
         [pa.array([1, -21, None], pa.int32())]
 
 
-KATS = [kat_tree_exp_builder, kat_table, kat_filter, kat_in_int32, kat_in_int64, kat_boolean,
-        kat_filter_project]
+KATS = [kat_tree_exp_builder, kat_table, kat_filter, kat_in_utf8, kat_in_int32, kat_in_int64,
+        kat_boolean, kat_regex, kat_filter_project]
 
 
 # ------------------------------------------------------------------ oracle pins (CPU)
