@@ -202,7 +202,7 @@ FunctionRegistry::FunctionRegistry() {
   }
   // decimal128: precision/scale are wildcards in the parameter match
   {
-    const DataType dec = decimal128(0, 0);
+    const DataType dec = decimal128(38, 0);  // enumerated like the reference's decimal128()
     for (const char* f : {"add", "subtract", "multiply"})
       add(f, {dec, dec}, dec, NullPolicy::kNullIfNull, kDecimalResult | kDecimalArgs);
     for (const char* f : {"equal", "not_equal", "less_than", "less_than_or_equal_to", "greater_than",
