@@ -139,25 +139,41 @@ ScanApplyInclusiveI32(int32_t* __restrict__ data, int64_t m, const uint64_t* __r
   }
 }
 
-// One wavefront per wave tile (`subtiles` consecutive 64-row match words).
+// Index emission, LDS-staged.  One wavefront owns 64 consecutive match words (4096 rows):
+// lane i takes word i, a wave-level exclusive scan of the popcounts gives every lane its
+// slot range, the lane walks its word's set bits (ctz / clear-lowest) into the wave's
+// private LDS window, and the wave then streams the window to HBM with fully coalesced
+// stores.  (Writing straight from the bit walk would emit ~8 indices = 32 B per 64-lane
+// store instruction at C3's selectivity: measured 0.82 ms for 10^9 rows vs the ~0.15 ms
+// the 0.66 GB of traffic costs.)  `offsets` holds the selected-row count before every group
+// of `subtiles` words (subtiles divides 64), so the wave's base is offsets[first group].
+constexpr int kEmitWords = 64;
+
 template <typename IndexT>
 __global__ void __launch_bounds__(256)
 EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offsets,
             int64_t nwords, int subtiles, int64_t row_base, IndexT* __restrict__ out) {
+  __shared__ IndexT stage[4][kEmitWords * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t ntiles = (nwords + subtiles - 1) / subtiles;
-  const uint64_t lt = (1ull << lane) - 1ull;
-  for (int64_t wt = (int64_t)blockIdx.x * 4 + wave; wt < ntiles; wt += (int64_t)gridDim.x * 4) {
-    uint64_t off = offsets[wt];
-    for (int u = 0; u < subtiles; u++) {
-      const int64_t w = wt * subtiles + u;
-      if (w >= nwords) break;
-      const uint64_t m = mask[w];
-      if ((m >> lane) & 1ull)
-        out[off + __popcll(m & lt)] = static_cast<IndexT>(row_base + w * 64 + lane);
-      off += __popcll(m);
+  IndexT* buf = stage[wave];
+  const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t w = t * kEmitWords + lane;
+    uint64_t m = (w < nwords) ? mask[w] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(m);
+    const uint32_t incl = (uint32_t)WaveInclusiveScan(c, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t slot = incl - c;
+    const int64_t row0 = row_base + w * 64;
+    while (m) {
+      buf[slot++] = static_cast<IndexT>(row0 + __builtin_ctzll(m));
+      m &= m - 1;
     }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t base = offsets[(t * kEmitWords) / subtiles];
+    for (uint32_t j = lane; j < total; j += 64) out[base + j] = buf[j];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -196,9 +212,10 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
                              int subtiles, int64_t row_base, int index_bytes, void* out,
                              int num_cus, hipStream_t stream) {
   if (nwords <= 0) return hipSuccess;
-  const int64_t ntiles = (nwords + subtiles - 1) / subtiles;
+  if (subtiles <= 0 || kEmitWords % subtiles != 0) return hipErrorInvalidValue;
+  const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
   int64_t grid = (ntiles + 3) / 4;
-  const int64_t cap = (int64_t)num_cus * 8;
+  const int64_t cap = (int64_t)num_cus * 4;
   if (grid > cap) grid = cap;
   switch (index_bytes) {
     case 2:

@@ -12,7 +12,12 @@ namespace gdv {
 
 CodegenOptions CodegenOptions::FromEnv() {
   CodegenOptions o;
-  if (const char* s = std::getenv("GDV_U")) o.subtiles = std::max(1, std::min(16, atoi(s)));
+  if (const char* s = std::getenv("GDV_U")) {
+    // powers of two only: the index-emission kernel walks 64-word groups (gdv_kernels.hip)
+    int u = std::max(1, std::min(16, atoi(s)));
+    while (u & (u - 1)) u &= u - 1;
+    o.subtiles = u;
+  }
   if (const char* s = std::getenv("GDV_WAVES")) o.waves = std::max(1, std::min(16, atoi(s)));
   if (const char* s = std::getenv("GDV_NT")) o.nontemporal = atoi(s) != 0;
   return o;
@@ -640,7 +645,9 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   const bool sel = cg.selection();
   const int nin = plan->layout.n_in;
 
-  s << "template <bool FULL>\n"
+  // PASS is a template parameter so that the byte pass of a var-len projection drops, at
+  // compile time, everything only the fixed-width outputs need (and vice versa)
+  s << "template <bool FULL, int PASS>\n"
     << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane) {\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
@@ -667,7 +674,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
         << e << "].data;\n";
     }
   }
-  if (plan->has_varlen_output) s << "  const int pass = (int)A.aux0;  // 0 lengths, 1 bytes\n";
+  if (plan->has_varlen_output) s << "  constexpr int pass = PASS;  // 0 lengths, 1 bytes\n";
   if (sel)
     s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const "
       << SelCType(cg.sel_mode_) << "*)A.sel;\n";
@@ -762,24 +769,31 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
   // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
   // each bitmap.
-  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) " << "GDV_KERNEL_NAME"
-    << "(const gdv_args A) {\n"
-    << "  const int lane = threadIdx.x & 63;\n"
-    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+  s << "template <int PASS>\n"
+    << "GDV_DEV void gdv_run(const gdv_args& A, const int lane, const int wave) {\n"
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
     << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
     << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
     << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nfull;\n"
     << "       wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
-    << "    gdv_tile<true>(A, wt * GDV_U, lane);\n"
+    << "    gdv_tile<true, PASS>(A, wt * GDV_U, lane);\n"
     // The single partial wave tile is handled after the loop, not in an if/else next to
     // the full-tile body: side by side, the compiler hoists the two bodies' common bitmap
     // loads above the branch and serialises them in front of the value loads.
     << "  if (nwt > nfull && wave == (int)(nfull % GDV_WAVES) &&\n"
     << "      blockIdx.x == (unsigned)((nfull / GDV_WAVES) % gridDim.x))\n"
-    << "    gdv_tile<false>(A, nfull * GDV_U, lane);\n"
-    << "}\n";
+    << "    gdv_tile<false, PASS>(A, nfull * GDV_U, lane);\n"
+    << "}\n\n";
+  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) " << "GDV_KERNEL_NAME"
+    << "(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
+  if (plan->has_varlen_output)
+    s << "  if (A.aux0 == 0) gdv_run<0>(A, lane, wave);\n  else gdv_run<1>(A, lane, wave);\n";
+  else
+    s << "  gdv_run<0>(A, lane, wave);\n";
+  s << "}\n";
 
   std::string text = s.str();
   uint64_t h = Fnv1a(text);
@@ -866,6 +880,18 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
   cg.Stmt("const gdv_uint64 fm = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
   cg.Stmt("fcount += (gdv_uint32)__popcll(fm);");
   std::string acc = accs.Get(cg, "fm");
+  // A predicate kernel keeps nothing but its input values live, so it can afford many more
+  // loads in flight per wave than a projection: measured on C3 (2 x int64, 10^9 rows) the
+  // predicate pass goes from 5.2 TB/s at GDV_U = 4 to 5.9 TB/s at 16 (profiles/r01_c3_sweep).
+  // Budget: <= 512 bytes of input values per lane, i.e. <= 128 VGPRs of loads.
+  if (std::getenv("GDV_U") == nullptr) {
+    int in_bytes = 0;
+    for (size_t k = 0; k < cg.input_fields_.size(); k++)
+      if (cg.needs_values_[k]) in_bytes += std::max(4, schema[cg.input_fields_[k]].type.byte_width());
+    int u = 16;
+    while (u > 4 && u * std::max(in_bytes, 1) > 512) u >>= 1;
+    plan->opts.subtiles = u;
+  }
   std::ostringstream after;
   after << WordStore(acc, "A.mask");
   // one selected-row count per wave tile feeds the offsets scan (gdv_kernels.hip)

@@ -19,6 +19,9 @@ def values_bits_np(arr):
         bits = np.unpackbits(np.frombuffer(arr.buffers()[1], dtype=np.uint8), bitorder="little")
         return bits[arr.offset: arr.offset + len(arr)]
     w = t.bit_width // 8
+    if w == 16:  # decimal128: compare as (lo, hi) pairs packed into one structured value
+        raw = np.frombuffer(arr.buffers()[1], dtype=np.dtype([("lo", np.uint64), ("hi", np.uint64)]))
+        return raw[arr.offset: arr.offset + len(arr)]
     dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]
     raw = np.frombuffer(arr.buffers()[1], dtype=dt)
     return raw[arr.offset: arr.offset + len(arr)]
