@@ -1,0 +1,603 @@
+// libgandiva.so — the reference's public C++ API (namespace gandiva, signatures pinned by
+// pyarrow/includes/libgandiva.pxd:27-298) implemented as a thin marshalling layer over the
+// C ABI of libgandiva_amd.so (include/gandiva_amd.h).  Nothing is evaluated here: trees are
+// forwarded to gdv_node_*, Evaluate hands raw Arrow buffer addresses to
+// gdv_projector_evaluate / gdv_filter_evaluate, which launch the HIP kernels.
+#include <cstring>
+
+#include "arrow/api.h"
+#include "arrow/device.h"
+#include "gandiva/condition.h"
+#include "gandiva/configuration.h"
+#include "gandiva/expression_registry.h"
+#include "gandiva/filter.h"
+#include "gandiva/function_signature.h"
+#include "gandiva/node.h"
+#include "gandiva/projector.h"
+#include "gandiva/selection_vector.h"
+#include "gandiva/tree_expr_builder.h"
+#include "gandiva_amd.h"
+
+namespace gandiva {
+
+namespace {
+
+Status LastError(int rc) {
+  std::string msg = gdv_last_error();
+  size_t colon = msg.find(": ");  // drop the code name: arrow::Status prints its own
+  if (colon != std::string::npos) msg = msg.substr(colon + 2);
+  return Status(static_cast<arrow::StatusCode>(rc), msg);
+}
+#define GDV_CXX_RETURN_NOT_OK(rc)            \
+  do {                                       \
+    int _rc = (rc);                          \
+    if (_rc != GDV_OK) return LastError(_rc); \
+  } while (0)
+
+bool ToGdvType(const arrow::DataType& t, gdv_type_t* out) {
+  out->id = static_cast<int32_t>(t.id());
+  out->precision = 0;
+  out->scale = 0;
+  switch (t.id()) {
+    case arrow::Type::BOOL: case arrow::Type::UINT8: case arrow::Type::INT8:
+    case arrow::Type::UINT16: case arrow::Type::INT16: case arrow::Type::UINT32:
+    case arrow::Type::INT32: case arrow::Type::UINT64: case arrow::Type::INT64:
+    case arrow::Type::FLOAT: case arrow::Type::DOUBLE: case arrow::Type::STRING:
+    case arrow::Type::BINARY: case arrow::Type::DATE32: case arrow::Type::DATE64:
+      return true;
+    case arrow::Type::TIMESTAMP:
+      out->precision = static_cast<int32_t>(static_cast<const arrow::TimestampType&>(t).unit());
+      return true;
+    case arrow::Type::TIME32:
+      out->precision = static_cast<int32_t>(static_cast<const arrow::Time32Type&>(t).unit());
+      return true;
+    case arrow::Type::TIME64:
+      out->precision = static_cast<int32_t>(static_cast<const arrow::Time64Type&>(t).unit());
+      return true;
+    case arrow::Type::DECIMAL128: {
+      auto& d = static_cast<const arrow::Decimal128Type&>(t);
+      out->precision = d.precision();
+      out->scale = d.scale();
+      return true;
+    }
+    default:
+      return false;
+  }
+}
+
+DataTypePtr FromGdvType(gdv_type_t g) {
+  switch (g.id) {
+    case GDV_TYPE_BOOL: return arrow::boolean();
+    case GDV_TYPE_UINT8: return arrow::uint8();
+    case GDV_TYPE_INT8: return arrow::int8();
+    case GDV_TYPE_UINT16: return arrow::uint16();
+    case GDV_TYPE_INT16: return arrow::int16();
+    case GDV_TYPE_UINT32: return arrow::uint32();
+    case GDV_TYPE_INT32: return arrow::int32();
+    case GDV_TYPE_UINT64: return arrow::uint64();
+    case GDV_TYPE_INT64: return arrow::int64();
+    case GDV_TYPE_FLOAT: return arrow::float32();
+    case GDV_TYPE_DOUBLE: return arrow::float64();
+    case GDV_TYPE_STRING: return arrow::utf8();
+    case GDV_TYPE_BINARY: return arrow::binary();
+    case GDV_TYPE_DATE32: return arrow::date32();
+    case GDV_TYPE_DATE64: return arrow::date64();
+    case GDV_TYPE_TIMESTAMP: return arrow::timestamp(static_cast<arrow::TimeUnit::type>(g.precision));
+    case GDV_TYPE_TIME32: return arrow::time32(static_cast<arrow::TimeUnit::type>(g.precision));
+    case GDV_TYPE_TIME64: return arrow::time64(static_cast<arrow::TimeUnit::type>(g.precision));
+    case GDV_TYPE_DECIMAL128: return arrow::decimal128(g.precision, g.scale);
+    default: return arrow::null();
+  }
+}
+
+// An unsupported type still yields a node: the error surfaces at Make() as a validation
+// error, which is where the reference reports unsupported signatures.
+gdv_type_t GdvTypeOrNull(const DataTypePtr& t) {
+  gdv_type_t g{0, 0, 0};
+  if (t) ToGdvType(*t, &g);
+  return g;
+}
+
+bool IsVarlen(const arrow::DataType& t) {
+  return t.id() == arrow::Type::STRING || t.id() == arrow::Type::BINARY;
+}
+
+template <typename T>
+NodePtr FixedLiteral(TreeExprBuilder*, DataTypePtr type, T value);
+
+const void* BufAddr(const std::shared_ptr<arrow::Buffer>& b) {
+  return b ? reinterpret_cast<const void*>(b->address()) : nullptr;
+}
+int64_t BufSize(const std::shared_ptr<arrow::Buffer>& b) { return b ? b->size() : 0; }
+
+// Arrow array -> raw buffers; *device becomes true if any buffer is not CPU-accessible
+Status ToColumn(const arrow::ArrayData& d, gdv_column_t* col, bool* device,
+                std::shared_ptr<arrow::MemoryManager>* mm) {
+  std::memset(col, 0, sizeof(*col));
+  const bool varlen = IsVarlen(*d.type);
+  const size_t need = varlen ? 3 : 2;
+  if (d.buffers.size() < need) {
+    // NullArray-like or unsupported layouts are only a problem if the column is referenced
+    return Status::OK();
+  }
+  col->validity = BufAddr(d.buffers[0]);
+  col->validity_size = BufSize(d.buffers[0]);
+  if (varlen) {
+    col->offsets = BufAddr(d.buffers[1]);
+    col->offsets_size = BufSize(d.buffers[1]);
+    col->data = BufAddr(d.buffers[2]);
+    col->data_size = BufSize(d.buffers[2]);
+  } else {
+    col->data = BufAddr(d.buffers[1]);
+    col->data_size = BufSize(d.buffers[1]);
+  }
+  col->offset = d.offset;
+  for (auto& b : d.buffers) {
+    if (b && !b->is_cpu()) {
+      *device = true;
+      if (mm && !*mm) *mm = b->memory_manager();
+    }
+  }
+  return Status::OK();
+}
+
+Status MarshalBatch(const arrow::RecordBatch& batch, const SchemaPtr& schema,
+                    std::vector<gdv_column_t>* cols, bool* device,
+                    std::shared_ptr<arrow::MemoryManager>* mm) {
+  if (!batch.schema()->Equals(*schema, /*check_metadata=*/false))
+    return Status::Invalid("Schema in RecordBatch must match schema in Make()");
+  if (batch.num_rows() == 0) return Status::Invalid("RecordBatch must be non-empty.");
+  cols->resize(batch.num_columns());
+  for (int i = 0; i < batch.num_columns(); i++)
+    ARROW_RETURN_NOT_OK(ToColumn(*batch.column_data(i), &(*cols)[i], device, mm));
+  return Status::OK();
+}
+
+arrow::Result<std::shared_ptr<arrow::Buffer>> AllocOut(int64_t bytes, bool device,
+                                                       arrow::MemoryPool* pool,
+                                                       const std::shared_ptr<arrow::MemoryManager>& mm) {
+  if (bytes < 8) bytes = 8;
+  if (device) {
+    if (!mm) return Status::Invalid("device-resident batch without a MemoryManager");
+    ARROW_ASSIGN_OR_RAISE(auto b, mm->AllocateBuffer(bytes));
+    return std::shared_ptr<arrow::Buffer>(std::move(b));
+  }
+  ARROW_ASSIGN_OR_RAISE(auto b, arrow::AllocateBuffer(bytes, pool ? pool : arrow::default_memory_pool()));
+  std::memset(b->mutable_data(), 0, static_cast<size_t>(b->size()));
+  return std::shared_ptr<arrow::Buffer>(std::move(b));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ Node / Expression
+
+Node::~Node() { gdv_node_free(handle_); }
+std::string Node::ToString() const {
+  char* s = gdv_node_to_string(handle_);
+  std::string r = s ? s : "";
+  gdv_free_string(s);
+  return r;
+}
+Expression::~Expression() { gdv_expression_free(handle_); }
+
+// ------------------------------------------------------------------ TreeExprBuilder
+
+#define GDV_LITERAL(CTYPE, ARROW_TYPE)                                         \
+  NodePtr TreeExprBuilder::MakeLiteral(CTYPE value) {                          \
+    auto t = ARROW_TYPE;                                                       \
+    gdv_node* h = gdv_node_literal(GdvTypeOrNull(t), &value, 0);               \
+    return h ? NodePtr(new Node(h, t)) : nullptr;                              \
+  }
+NodePtr TreeExprBuilder::MakeLiteral(bool value) {
+  uint8_t v = value ? 1 : 0;
+  gdv_node* h = gdv_node_literal(GdvTypeOrNull(arrow::boolean()), &v, 0);
+  return h ? NodePtr(new Node(h, arrow::boolean())) : nullptr;
+}
+GDV_LITERAL(uint8_t, arrow::uint8())
+GDV_LITERAL(uint16_t, arrow::uint16())
+GDV_LITERAL(uint32_t, arrow::uint32())
+GDV_LITERAL(uint64_t, arrow::uint64())
+GDV_LITERAL(int8_t, arrow::int8())
+GDV_LITERAL(int16_t, arrow::int16())
+GDV_LITERAL(int32_t, arrow::int32())
+GDV_LITERAL(int64_t, arrow::int64())
+GDV_LITERAL(float, arrow::float32())
+GDV_LITERAL(double, arrow::float64())
+
+NodePtr TreeExprBuilder::MakeStringLiteral(const std::string& value) {
+  gdv_node* h = gdv_node_literal_bytes(GdvTypeOrNull(arrow::utf8()), value.data(),
+                                       static_cast<int64_t>(value.size()), 0);
+  return h ? NodePtr(new Node(h, arrow::utf8())) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeBinaryLiteral(const std::string& value) {
+  gdv_node* h = gdv_node_literal_bytes(GdvTypeOrNull(arrow::binary()), value.data(),
+                                       static_cast<int64_t>(value.size()), 0);
+  return h ? NodePtr(new Node(h, arrow::binary())) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeDecimalLiteral(int64_t high, uint64_t low, int32_t precision,
+                                            int32_t scale) {
+  auto t = arrow::decimal128(precision, scale);
+  uint64_t words[2] = {low, static_cast<uint64_t>(high)};
+  gdv_node* h = gdv_node_literal(GdvTypeOrNull(t), words, 0);
+  return h ? NodePtr(new Node(h, t)) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeNull(DataTypePtr data_type) {
+  if (!data_type) return nullptr;
+  gdv_type_t g = GdvTypeOrNull(data_type);
+  gdv_node* h = IsVarlen(*data_type) ? gdv_node_literal_bytes(g, nullptr, 0, 1) : gdv_node_literal(g, nullptr, 1);
+  return h ? NodePtr(new Node(h, data_type)) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeField(FieldPtr field) {
+  if (!field) return nullptr;
+  gdv_node* h = gdv_node_field(field->name().c_str(), GdvTypeOrNull(field->type()));
+  return h ? NodePtr(new Node(h, field->type())) : nullptr;
+}
+static bool Handles(const NodeVector& v, std::vector<gdv_node*>* out) {
+  for (auto& n : v) {
+    if (!n) return false;
+    out->push_back(n->handle());
+  }
+  return true;
+}
+NodePtr TreeExprBuilder::MakeFunction(const std::string& name, const NodeVector& params,
+                                      DataTypePtr return_type) {
+  std::vector<gdv_node*> hs;
+  if (!return_type || !Handles(params, &hs)) return nullptr;
+  gdv_node* h = gdv_node_function(name.c_str(), hs.data(), static_cast<int>(hs.size()),
+                                  GdvTypeOrNull(return_type));
+  return h ? NodePtr(new Node(h, return_type)) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeIf(NodePtr condition, NodePtr then_node, NodePtr else_node,
+                                DataTypePtr result_type) {
+  if (!condition || !then_node || !else_node || !result_type) return nullptr;
+  gdv_node* h = gdv_node_if(condition->handle(), then_node->handle(), else_node->handle(),
+                            GdvTypeOrNull(result_type));
+  return h ? NodePtr(new Node(h, result_type)) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeAnd(const NodeVector& children) {
+  std::vector<gdv_node*> hs;
+  if (!Handles(children, &hs)) return nullptr;
+  gdv_node* h = gdv_node_and(hs.data(), static_cast<int>(hs.size()));
+  return h ? NodePtr(new Node(h, arrow::boolean())) : nullptr;
+}
+NodePtr TreeExprBuilder::MakeOr(const NodeVector& children) {
+  std::vector<gdv_node*> hs;
+  if (!Handles(children, &hs)) return nullptr;
+  gdv_node* h = gdv_node_or(hs.data(), static_cast<int>(hs.size()));
+  return h ? NodePtr(new Node(h, arrow::boolean())) : nullptr;
+}
+ExpressionPtr TreeExprBuilder::MakeExpression(NodePtr root_node, FieldPtr result_field) {
+  if (!root_node || !result_field) return nullptr;
+  gdv_expression* h = gdv_expression_new(root_node->handle(), result_field->name().c_str(),
+                                         GdvTypeOrNull(result_field->type()));
+  return h ? ExpressionPtr(new Expression(h, root_node, result_field)) : nullptr;
+}
+ExpressionPtr TreeExprBuilder::MakeExpression(const std::string& function,
+                                              const FieldVector& in_fields, FieldPtr out_field) {
+  if (!out_field) return nullptr;
+  NodeVector args;
+  for (auto& f : in_fields) args.push_back(MakeField(f));
+  return MakeExpression(MakeFunction(function, args, out_field->type()), out_field);
+}
+ConditionPtr TreeExprBuilder::MakeCondition(NodePtr root_node) {
+  if (!root_node) return nullptr;
+  gdv_expression* h = gdv_condition_new(root_node->handle());
+  return h ? ConditionPtr(new Condition(h, root_node)) : nullptr;
+}
+ConditionPtr TreeExprBuilder::MakeCondition(const std::string& function,
+                                            const FieldVector& in_fields) {
+  NodeVector args;
+  for (auto& f : in_fields) args.push_back(MakeField(f));
+  return MakeCondition(MakeFunction(function, args, arrow::boolean()));
+}
+
+template <typename T>
+static NodePtr MakeInFixed(NodePtr node, const std::unordered_set<T>& constants, DataTypePtr type,
+                           NodePtr (*wrap)(gdv_node*, DataTypePtr)) {
+  if (!node) return nullptr;
+  std::vector<T> vals(constants.begin(), constants.end());
+  gdv_node* h = gdv_node_in(node->handle(), GdvTypeOrNull(type), vals.data(), static_cast<int>(vals.size()));
+  return wrap(h, arrow::boolean());
+}
+#define GDV_IN_FIXED(NAME, CTYPE, ARROW_TYPE)                                                        \
+  NodePtr TreeExprBuilder::NAME(NodePtr node, const std::unordered_set<CTYPE>& constants) {          \
+    if (!node) return nullptr;                                                                       \
+    std::vector<CTYPE> vals(constants.begin(), constants.end());                                     \
+    gdv_node* h = gdv_node_in(node->handle(), GdvTypeOrNull(ARROW_TYPE), vals.data(),                \
+                              static_cast<int>(vals.size()));                                        \
+    return h ? NodePtr(new Node(h, arrow::boolean())) : nullptr;                                     \
+  }
+GDV_IN_FIXED(MakeInExpressionInt32, int32_t, arrow::int32())
+GDV_IN_FIXED(MakeInExpressionInt64, int64_t, arrow::int64())
+GDV_IN_FIXED(MakeInExpressionDate32, int32_t, arrow::date32())
+GDV_IN_FIXED(MakeInExpressionDate64, int64_t, arrow::date64())
+GDV_IN_FIXED(MakeInExpressionTime32, int32_t, arrow::time32(arrow::TimeUnit::MILLI))
+GDV_IN_FIXED(MakeInExpressionTime64, int64_t, arrow::time64(arrow::TimeUnit::MICRO))
+GDV_IN_FIXED(MakeInExpressionTimeStamp, int64_t, arrow::timestamp(arrow::TimeUnit::MILLI))
+
+#define GDV_IN_BYTES(NAME, ARROW_TYPE)                                                               \
+  NodePtr TreeExprBuilder::NAME(NodePtr node, const std::unordered_set<std::string>& constants) {    \
+    if (!node) return nullptr;                                                                       \
+    std::vector<const char*> ptrs;                                                                   \
+    std::vector<int64_t> lens;                                                                       \
+    for (auto& s : constants) { ptrs.push_back(s.data()); lens.push_back(static_cast<int64_t>(s.size())); } \
+    gdv_node* h = gdv_node_in_bytes(node->handle(), GdvTypeOrNull(ARROW_TYPE), ptrs.data(),          \
+                                    lens.data(), static_cast<int>(ptrs.size()));                     \
+    return h ? NodePtr(new Node(h, arrow::boolean())) : nullptr;                                     \
+  }
+GDV_IN_BYTES(MakeInExpressionString, arrow::utf8())
+GDV_IN_BYTES(MakeInExpressionBinary, arrow::binary())
+
+// ------------------------------------------------------------------ SelectionVector
+
+static Status MakeSel(SelectionVector::Mode mode, int bytes, int64_t max_slots, arrow::MemoryPool* pool,
+                      std::shared_ptr<SelectionVector>* out) {
+  if (!out) return Status::Invalid("selection vector output cannot be null");
+  if (max_slots < 0) return Status::Invalid("max_slots cannot be negative");
+  ARROW_ASSIGN_OR_RAISE(auto buf, arrow::AllocateBuffer(std::max<int64_t>(max_slots, 1) * bytes,
+                                                        pool ? pool : arrow::default_memory_pool()));
+  return SelectionVector::Make(mode, max_slots, std::shared_ptr<arrow::Buffer>(std::move(buf)), out);
+}
+Status SelectionVector::Make(Mode mode, int64_t max_slots, std::shared_ptr<arrow::Buffer> buffer,
+                             std::shared_ptr<SelectionVector>* out) {
+  if (!out || !buffer) return Status::Invalid("selection vector buffer cannot be null");
+  const int w = mode == MODE_UINT16 ? 2 : mode == MODE_UINT32 ? 4 : 8;
+  if (mode == MODE_NONE) return Status::Invalid("selection vector mode cannot be NONE");
+  if (buffer->size() < max_slots * w) return Status::Invalid("buffer too small for max_slots");
+  if (mode == MODE_UINT16 && max_slots > 65536)
+    return Status::Invalid("max_slots cannot exceed 65536 for a 16-bit selection vector");
+  *out = std::shared_ptr<SelectionVector>(new SelectionVector(mode, max_slots, std::move(buffer)));
+  return Status::OK();
+}
+Status SelectionVector::MakeInt16(int64_t n, arrow::MemoryPool* pool, std::shared_ptr<SelectionVector>* out) {
+  return MakeSel(MODE_UINT16, 2, n, pool, out);
+}
+Status SelectionVector::MakeInt32(int64_t n, arrow::MemoryPool* pool, std::shared_ptr<SelectionVector>* out) {
+  return MakeSel(MODE_UINT32, 4, n, pool, out);
+}
+Status SelectionVector::MakeInt64(int64_t n, arrow::MemoryPool* pool, std::shared_ptr<SelectionVector>* out) {
+  return MakeSel(MODE_UINT64, 8, n, pool, out);
+}
+uint64_t SelectionVector::GetIndex(int64_t i) const {
+  const uint8_t* p = buffer_->data();
+  switch (mode_) {
+    case MODE_UINT16: return reinterpret_cast<const uint16_t*>(p)[i];
+    case MODE_UINT32: return reinterpret_cast<const uint32_t*>(p)[i];
+    default: return reinterpret_cast<const uint64_t*>(p)[i];
+  }
+}
+void SelectionVector::SetIndex(int64_t i, uint64_t v) {
+  uint8_t* p = buffer_->mutable_data();
+  switch (mode_) {
+    case MODE_UINT16: reinterpret_cast<uint16_t*>(p)[i] = static_cast<uint16_t>(v); break;
+    case MODE_UINT32: reinterpret_cast<uint32_t*>(p)[i] = static_cast<uint32_t>(v); break;
+    default: reinterpret_cast<uint64_t*>(p)[i] = v; break;
+  }
+}
+ArrayPtr SelectionVector::ToArray() const {
+  DataTypePtr t = mode_ == MODE_UINT16 ? arrow::uint16() : mode_ == MODE_UINT32 ? arrow::uint32() : arrow::uint64();
+  auto data = arrow::ArrayData::Make(t, num_slots_, {nullptr, buffer_}, /*null_count=*/0);
+  return arrow::MakeArray(data);
+}
+
+// ------------------------------------------------------------------ Projector
+
+static gdv_schema_t* MakeSchema(const SchemaPtr& schema, Status* st) {
+  gdv_schema_t* h = gdv_schema_new();
+  for (auto& f : schema->fields()) {
+    gdv_type_t g;
+    if (!ToGdvType(*f->type(), &g)) {
+      // unsupported column types are fine as long as no expression references them
+      g = gdv_type_t{GDV_TYPE_BINARY, 0, 0};
+    }
+    int rc = gdv_schema_add_field(h, f->name().c_str(), g, f->nullable());
+    if (rc != GDV_OK) {
+      *st = LastError(rc);
+      gdv_schema_free(h);
+      return nullptr;
+    }
+  }
+  return h;
+}
+
+Projector::~Projector() { gdv_projector_free(handle_); }
+
+Status Projector::Make(SchemaPtr schema, const ExpressionVector& exprs,
+                       std::shared_ptr<Projector>* projector) {
+  return Make(schema, exprs, SelectionVector::MODE_NONE, ConfigurationBuilder::DefaultConfiguration(), projector);
+}
+Status Projector::Make(SchemaPtr schema, const ExpressionVector& exprs,
+                       std::shared_ptr<Configuration> configuration,
+                       std::shared_ptr<Projector>* projector) {
+  return Make(schema, exprs, SelectionVector::MODE_NONE, configuration, projector);
+}
+Status Projector::Make(SchemaPtr schema, const ExpressionVector& exprs,
+                       SelectionVector::Mode mode, std::shared_ptr<Configuration> configuration,
+                       std::shared_ptr<Projector>* projector) {
+  if (!schema) return Status::Invalid("Schema cannot be null");
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  if (!configuration) return Status::Invalid("Configuration cannot be null");
+  if (!projector) return Status::Invalid("Projector output cannot be null");
+  std::vector<gdv_expression*> hs;
+  FieldVector outs;
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    hs.push_back(e->handle());
+    outs.push_back(e->result());
+  }
+  Status st;
+  gdv_schema_t* sh = MakeSchema(schema, &st);
+  if (!sh) return st;
+  gdv_config_t cfg{configuration->optimize(), configuration->dump_ir()};
+  gdv_projector* h = nullptr;
+  int rc = gdv_projector_make(sh, hs.data(), static_cast<int>(hs.size()), static_cast<int>(mode), &cfg, &h);
+  gdv_schema_free(sh);
+  GDV_CXX_RETURN_NOT_OK(rc);
+  *projector = std::shared_ptr<Projector>(new Projector(h, schema, outs, mode));
+  return Status::OK();
+}
+
+Status Projector::Evaluate(const arrow::RecordBatch& batch, arrow::MemoryPool* pool,
+                           ArrayVector* output) const {
+  return Evaluate(batch, nullptr, pool, output);
+}
+
+Status Projector::Evaluate(const arrow::RecordBatch& batch, const SelectionVector* selection,
+                           arrow::MemoryPool* pool, ArrayVector* output) const {
+  if (!output) return Status::Invalid("Output array vector cannot be null");
+  std::vector<gdv_column_t> cols;
+  bool device = false;
+  std::shared_ptr<arrow::MemoryManager> mm;
+  ARROW_RETURN_NOT_OK(MarshalBatch(batch, schema_, &cols, &device, &mm));
+  const int64_t out_rows = selection ? selection->GetNumSlots() : batch.num_rows();
+  gdv_selection_t sel;
+  if (selection) {
+    sel.mode = static_cast<int32_t>(selection->GetMode());
+    sel.indices = reinterpret_cast<const void*>(selection->GetBuffer().address());
+    sel.num_slots = selection->GetNumSlots();
+    if (!selection->GetBuffer().is_cpu()) device = true;
+  }
+  const int n_out = static_cast<int>(output_fields_.size());
+  const int mem = device ? GDV_MEM_DEVICE : GDV_MEM_HOST;
+  std::vector<gdv_out_column_t> outs(n_out);
+  std::vector<std::shared_ptr<arrow::Buffer>> vbuf(n_out), dbuf(n_out), obuf(n_out);
+  int64_t varlen_guess = 64;
+  for (auto& c : cols) if (c.offsets) varlen_guess += c.data_size;
+  for (int e = 0; e < n_out; e++) {
+    const bool varlen = IsVarlen(*output_fields_[e]->type());
+    int64_t vbytes = 0, dbytes = 0;
+    GDV_CXX_RETURN_NOT_OK(gdv_projector_output_sizes(handle_, e, out_rows, mem, &vbytes, &dbytes));
+    if (varlen) dbytes = varlen_guess;
+    ARROW_ASSIGN_OR_RAISE(vbuf[e], AllocOut(vbytes, device, pool, mm));
+    ARROW_ASSIGN_OR_RAISE(dbuf[e], AllocOut(dbytes, device, pool, mm));
+    std::memset(&outs[e], 0, sizeof(outs[e]));
+    outs[e].validity = reinterpret_cast<void*>(vbuf[e]->address());
+    outs[e].validity_size = vbuf[e]->size();
+    outs[e].data = reinterpret_cast<void*>(dbuf[e]->address());
+    outs[e].data_size = dbuf[e]->size();
+    if (varlen) {
+      ARROW_ASSIGN_OR_RAISE(obuf[e], AllocOut((out_rows + 1) * 4, device, pool, mm));
+      outs[e].offsets = reinterpret_cast<void*>(obuf[e]->address());
+      outs[e].offsets_size = obuf[e]->size();
+    }
+  }
+  for (int attempt = 0;; attempt++) {
+    std::vector<int64_t> caps(n_out);
+    for (int e = 0; e < n_out; e++) caps[e] = outs[e].data_size;
+    int rc = gdv_projector_evaluate(handle_, batch.num_rows(), cols.data(), static_cast<int>(cols.size()),
+                                    selection ? &sel : nullptr, outs.data(), n_out, mem, nullptr, 0);
+    bool grown = false;
+    if (rc == GDV_INVALID && attempt == 0) {
+      // a var-len byte buffer was too small: data_size now carries the bytes needed
+      for (int e = 0; e < n_out; e++) {
+        if (!obuf[e]) continue;
+        if (outs[e].data_size > caps[e]) {
+          ARROW_ASSIGN_OR_RAISE(dbuf[e], AllocOut(outs[e].data_size, device, pool, mm));
+          outs[e].data = reinterpret_cast<void*>(dbuf[e]->address());
+          outs[e].data_size = dbuf[e]->size();
+          grown = true;
+        } else {
+          outs[e].data_size = caps[e];
+        }
+      }
+    }
+    if (grown) continue;
+    GDV_CXX_RETURN_NOT_OK(rc);
+    break;
+  }
+  for (int e = 0; e < n_out; e++) {
+    std::vector<std::shared_ptr<arrow::Buffer>> bufs;
+    if (obuf[e]) {
+      bufs = {vbuf[e], obuf[e], arrow::SliceBuffer(dbuf[e], 0, outs[e].data_size)};
+    } else {
+      bufs = {vbuf[e], dbuf[e]};
+    }
+    output->push_back(arrow::MakeArray(arrow::ArrayData::Make(output_fields_[e]->type(), out_rows, std::move(bufs))));
+  }
+  return Status::OK();
+}
+
+std::string Projector::DumpIR() {
+  char* s = gdv_projector_dump_ir(handle_);
+  std::string r = s ? s : "";
+  gdv_free_string(s);
+  return r;
+}
+
+// ------------------------------------------------------------------ Filter
+
+Filter::~Filter() { gdv_filter_free(handle_); }
+
+Status Filter::Make(SchemaPtr schema, ConditionPtr condition, std::shared_ptr<Filter>* filter) {
+  return Make(schema, condition, ConfigurationBuilder::DefaultConfiguration(), filter);
+}
+Status Filter::Make(SchemaPtr schema, ConditionPtr condition,
+                    std::shared_ptr<Configuration> configuration, std::shared_ptr<Filter>* filter) {
+  if (!schema) return Status::Invalid("Schema cannot be null");
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  if (!configuration) return Status::Invalid("Configuration cannot be null");
+  if (!filter) return Status::Invalid("Filter output cannot be null");
+  Status st;
+  gdv_schema_t* sh = MakeSchema(schema, &st);
+  if (!sh) return st;
+  gdv_config_t cfg{configuration->optimize(), configuration->dump_ir()};
+  gdv_filter* h = nullptr;
+  int rc = gdv_filter_make(sh, condition->handle(), &cfg, &h);
+  gdv_schema_free(sh);
+  GDV_CXX_RETURN_NOT_OK(rc);
+  *filter = std::shared_ptr<Filter>(new Filter(h, schema));
+  return Status::OK();
+}
+
+Status Filter::Evaluate(const arrow::RecordBatch& batch, std::shared_ptr<SelectionVector> out) {
+  if (!out) return Status::Invalid("Selection vector cannot be null");
+  std::vector<gdv_column_t> cols;
+  bool device = false;
+  std::shared_ptr<arrow::MemoryManager> mm;
+  ARROW_RETURN_NOT_OK(MarshalBatch(batch, schema_, &cols, &device, &mm));
+  if (out->GetMaxSlots() < batch.num_rows())
+    return Status::Invalid("Selection vector too small: max slots ", out->GetMaxSlots(),
+                           " < number of rows ", batch.num_rows());
+  const bool out_device = !out->GetBuffer().is_cpu();
+  if (out_device != device)
+    return Status::Invalid("batch and selection vector must live in the same memory domain");
+  int64_t count = 0;
+  GDV_CXX_RETURN_NOT_OK(gdv_filter_evaluate(
+      handle_, batch.num_rows(), cols.data(), static_cast<int>(cols.size()), static_cast<int>(out->GetMode()),
+      reinterpret_cast<void*>(out->GetBuffer().address()), out->GetMaxSlots(), &count,
+      device ? GDV_MEM_DEVICE : GDV_MEM_HOST, nullptr));
+  out->SetNumSlots(count);
+  return Status::OK();
+}
+
+std::string Filter::DumpIR() {
+  char* s = gdv_filter_dump_ir(handle_);
+  std::string r = s ? s : "";
+  gdv_free_string(s);
+  return r;
+}
+
+// ------------------------------------------------------------------ registry
+
+std::string FunctionSignature::ToString() const {
+  std::string s = ret_type_->ToString() + " " + base_name_ + "(";
+  for (size_t i = 0; i < param_types_.size(); i++) s += (i ? ", " : "") + param_types_[i]->ToString();
+  return s + ")";
+}
+
+std::vector<std::shared_ptr<FunctionSignature>> GetRegisteredFunctionSignatures() {
+  std::vector<std::shared_ptr<FunctionSignature>> out;
+  const int n = gdv_registry_size();
+  for (int i = 0; i < n; i++) {
+    const char* name = nullptr;
+    gdv_type_t ret, params[8];
+    int np = 0;
+    if (gdv_registry_get(i, &name, &ret, params, 8, &np) != GDV_OK) continue;
+    DataTypeVector ps;
+    for (int k = 0; k < np && k < 8; k++) ps.push_back(FromGdvType(params[k]));
+    out.push_back(std::make_shared<FunctionSignature>(name, ps, FromGdvType(ret)));
+  }
+  return out;
+}
+
+}  // namespace gandiva

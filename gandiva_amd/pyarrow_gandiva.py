@@ -1,0 +1,41 @@
+"""`pyarrow.gandiva` — the reference lineage's own Cython binding — on the HIP backend.
+
+pyarrow ships gandiva.pyx but no compiled module (the wheel is built without Gandiva).
+`load()` builds that file against gandiva_amd's C++ API if needed
+(gandiva_amd/cxx/build_pyarrow_gandiva.py) and registers the result as `pyarrow.gandiva`, so
+existing code — `import pyarrow.gandiva as gandiva` — runs unchanged on MI355X.
+"""
+import importlib.machinery
+import importlib.util
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(build=True):
+    if "pyarrow.gandiva" in sys.modules:
+        return sys.modules["pyarrow.gandiva"]
+    try:
+        import torch  # noqa: F401  (one HIP runtime per process: see _capi.lib)
+    except ImportError:
+        pass
+    import pyarrow  # noqa: F401
+    sys.path.insert(0, os.path.join(_HERE, "cxx"))
+    try:
+        import build_pyarrow_gandiva as b
+    finally:
+        sys.path.pop(0)
+    path = b.build() if build else os.path.join(b.OUT_DIR, "gandiva" + __import__("sysconfig").get_config_var("EXT_SUFFIX"))
+    loader = importlib.machinery.ExtensionFileLoader("pyarrow.gandiva", path)
+    spec = importlib.util.spec_from_file_location("pyarrow.gandiva", path, loader=loader)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["pyarrow.gandiva"] = mod
+    try:
+        loader.exec_module(mod)
+    except BaseException:
+        del sys.modules["pyarrow.gandiva"]
+        raise
+    import pyarrow as pa
+    pa.gandiva = mod
+    return mod
