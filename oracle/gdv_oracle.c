@@ -930,6 +930,51 @@ static void store_chunk(int type, const vec* r, int64_t row0, int cnt, void* dat
   }
 }
 
+/* ---------------------------------------------------------------- float64 fast path
+ * The reference's generated code for an arithmetic expression is a tight, auto-vectorised
+ * row loop over raw doubles plus a 64-bit-word intersection of the input validity bitmaps
+ * (SURVEY.md §3.2 hot loops #1 and #2).  The generic evaluator above models semantics, not
+ * speed; trees made only of float64 fields / literals / add / subtract / multiply take this
+ * path instead so that the timed CPU baseline has the reference's execution shape.  Both
+ * paths must agree bit for bit (tests/test_oracle_crosscheck.py::test_fast_path_...). */
+static int g_force_generic = 0;
+static int f64_fast_ok(const node* n, const or_column* cols) {
+  if (n->kind == 'F') return n->type == T_F64 && (cols[n->col].offset & 7) == 0;
+  if (n->kind == 'L') return n->type == T_F64 && !n->is_null;
+  if (n->kind == 'C' && n->type == T_F64 && n->nargs == 2 &&
+      (!strcmp(n->name, "add") || !strcmp(n->name, "subtract") || !strcmp(n->name, "multiply")))
+    return f64_fast_ok(n->args[0], cols) && f64_fast_ok(n->args[1], cols);
+  return 0;
+}
+static const double* f64_eval(const node* n, const or_column* cols, int64_t row0, int cnt,
+                              double* scratch, int* depth) {
+  if (n->kind == 'F') return (const double*)cols[n->col].data + cols[n->col].offset + row0;
+  double* out = scratch + (size_t)(*depth)++ * CHUNK;
+  if (n->kind == 'L') {
+    double v; memcpy(&v, &n->lo, 8);
+    for (int i = 0; i < cnt; i++) out[i] = v;
+    return out;
+  }
+  const double* a = f64_eval(n->args[0], cols, row0, cnt, scratch, depth);
+  const double* b = f64_eval(n->args[1], cols, row0, cnt, scratch, depth);
+  if (n->name[0] == 'a') for (int i = 0; i < cnt; i++) out[i] = a[i] + b[i];
+  else if (n->name[0] == 's') for (int i = 0; i < cnt; i++) out[i] = a[i] - b[i];
+  else for (int i = 0; i < cnt; i++) out[i] = a[i] * b[i];
+  return out;
+}
+static int f64_nodes(const node* n) {
+  int k = 1;
+  for (int i = 0; i < n->nargs; i++) k += f64_nodes(n->args[i]);
+  return k;
+}
+static void f64_fields(const node* n, int* cols_used, int* nused) {
+  if (n->kind == 'F') {
+    for (int i = 0; i < *nused; i++) if (cols_used[i] == n->col) return;
+    if (*nused < 64) cols_used[(*nused)++] = n->col;
+  }
+  for (int i = 0; i < n->nargs; i++) f64_fields(n->args[i], cols_used, nused);
+}
+
 typedef struct {
   const node* root;
   const or_column* cols;
@@ -943,6 +988,33 @@ typedef struct {
 static void* run_job(void* arg) {
   job* j = (job*)arg;
   ctx c = {j->cols, j->ncols, 0};
+  if (!g_force_generic && f64_fast_ok(j->root, j->cols)) {
+    double* scratch = (double*)malloc(sizeof(double) * CHUNK * (size_t)f64_nodes(j->root));
+    int used[64], nused = 0;
+    f64_fields(j->root, used, &nused);
+    double* outp = (double*)j->data;
+    for (int64_t row = j->row_lo; row < j->row_hi; row += CHUNK) {
+      int cnt = (int)((j->row_hi - row) < CHUNK ? (j->row_hi - row) : CHUNK);
+      int depth = 0;
+      const double* res = f64_eval(j->root, j->cols, row, cnt, scratch, &depth);
+      memcpy(outp + row, res, sizeof(double) * (size_t)cnt);
+      /* validity = AND of the input bitmaps (row is a multiple of CHUNK: byte aligned) */
+      int nbytes = (cnt + 7) / 8;
+      uint8_t* dst = j->validity + (row >> 3);
+      for (int b = 0; b < nbytes; b++) {
+        uint8_t w = 0xff;
+        for (int k = 0; k < nused; k++) {
+          const or_column* col = &j->cols[used[k]];
+          if (col->validity) w &= col->validity[((col->offset + row) >> 3) + b];
+        }
+        if (b == nbytes - 1 && (cnt & 7)) w &= (uint8_t)((1u << (cnt & 7)) - 1);
+        dst[b] |= w;
+      }
+    }
+    free(scratch);
+    j->err = 0;
+    return NULL;
+  }
   vec* r = (vec*)malloc(sizeof(vec));
   for (int64_t row = j->row_lo; row < j->row_hi; row += CHUNK) {
     int cnt = (int)((j->row_hi - row) < CHUNK ? (j->row_hi - row) : CHUNK);
@@ -960,6 +1032,8 @@ static void* run_job(void* arg) {
  * threads > 1 splits the row range at multiples of CHUNK (bitmap bytes never shared).
  * Returns 0, or an error bit mask (1 = divide by zero, 0x100 = unknown function, 0x200 = parse).
  */
+void gdv_oracle_force_generic(int on) { g_force_generic = on; }
+
 int gdv_oracle_project(const char* program, const or_column* cols, int ncols, int64_t n,
                        void* out_data, uint8_t* out_validity, int threads) {
   const char* p = program;

@@ -49,6 +49,8 @@ def lib():
         l.gdv_oracle_bitmap_to_selection.restype = C.c_int64
         l.gdv_oracle_bitmap_to_selection.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                                      C.c_void_p, C.c_int64]
+        l.gdv_oracle_force_generic.restype = None
+        l.gdv_oracle_force_generic.argtypes = [C.c_int]
         l.gdv_oracle_project_str.restype = C.c_int64
         l.gdv_oracle_project_str.argtypes = [C.c_char_p, C.POINTER(_Column), C.c_int, C.c_int64,
                                              C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -157,16 +159,29 @@ def _raise(err):
     raise OracleError(f"oracle error bits {err:#x}")
 
 
-def project_one(root, result_type, batch, threads=1):
-    """Evaluate one expression tree over the batch -> pyarrow.Array (host)."""
+def force_generic(on):
+    """Disable (True) / enable (False) the float64 fast path: for the agreement test."""
+    lib().gdv_oracle_force_generic(int(bool(on)))
+
+
+def project_one(root, result_type, batch, threads=1, out=None):
+    """Evaluate one expression tree over the batch -> pyarrow.Array (host).
+    `out` = (validity uint8 array, data uint8 array) to reuse across calls (timing runs):
+    they are re-zeroed here, so repeated passes do not pay first-touch page faults."""
     n = batch.num_rows
     tid = type_id(result_type)
     if tid in (13, 14):
         return _project_str(root, result_type, batch)
     width = 0 if tid == 1 else result_type.bit_width // 8
     vbytes = (n + 7) // 8
-    validity = np.zeros(max(vbytes, 1), dtype=np.uint8)
-    data = np.zeros(max(vbytes if tid == 1 else n * width, 1), dtype=np.uint8)
+    if out is None:
+        validity = np.zeros(max(vbytes, 1), dtype=np.uint8)
+        data = np.zeros(max(vbytes if tid == 1 else n * width, 1), dtype=np.uint8)
+    else:
+        validity, data = out
+        validity[:] = 0
+        if tid == 1:
+            data[:] = 0
     cols, keep = _columns(batch)
     prog = serialize(root, batch.schema).encode()
     err = lib().gdv_oracle_project(prog, cols, batch.num_columns, n, data.ctypes.data,
@@ -196,9 +211,22 @@ def _project_str(root, result_type, batch):
                                                   pa.py_buffer(data[:max(total, 0)])])
 
 
-def project(expressions, batch, threads=1):
+def project(expressions, batch, threads=1, out=None):
     """Reference execution shape: one pass over the batch PER expression."""
-    return [project_one(e.root(), e.result().type, batch, threads) for e in expressions]
+    return [project_one(e.root(), e.result().type, batch, threads, None if out is None else out[i])
+            for i, e in enumerate(expressions)]
+
+
+def alloc_outputs(expressions, n):
+    """Pre-touched output buffers for repeated timing passes of `project`."""
+    outs = []
+    for e in expressions:
+        t = e.result().type
+        tid = type_id(t)
+        vbytes = max((n + 7) // 8, 1)
+        data = np.ones(max(vbytes if tid == 1 else n * (t.bit_width // 8), 1), dtype=np.uint8)
+        outs.append((np.ones(vbytes, dtype=np.uint8), data))
+    return outs
 
 
 def filter_indices(condition, batch, dtype="int32", threads=1):

@@ -173,3 +173,21 @@ def test_selection_walk_matches_arrow_indices_nonzero():
         got = oracle.filter_indices(cond, batch, "int64")
         want = pc.indices_nonzero(pc.fill_null(v, False))
         assert got.equals(want)
+
+
+def test_fast_path_agrees_with_generic_evaluator():
+    """The float64 add/subtract/multiply fast path (the timed cpu_baseline) and the generic
+    per-row evaluator are two restatements inside the oracle: they must agree bit for bit,
+    including sliced (offset % 8 == 0) inputs, ragged tails and multi-threaded splits."""
+    from gandiva_amd import workloads as W
+    exprs = W.c2_expressions()
+    for batch in (W.c2_batch(1), W.c2_batch(1023), W.c2_batch(70001), W.c2_batch(70001).slice(1024, 3001),
+                  W.c2_batch(5000).slice(7, 100)):   # offset 7: not byte aligned -> generic path
+        fast = oracle.project(exprs, batch, threads=3)
+        oracle.force_generic(True)
+        try:
+            slow = oracle.project(exprs, batch)
+        finally:
+            oracle.force_generic(False)
+        for f, s in zip(fast, slow):
+            assert_bit_exact(f, s)
