@@ -272,6 +272,8 @@ def main():
                 "kernel": kernel_desc,
                 "algorithmic_bytes_per_row": round(bytes_per_row, 3),
                 "kernel_ms": round(mean_dev_ms, 4),
+                "kernel_ms_min": round(min(dev_ms), 4),
+                "kernel_ms_max": round(max(dev_ms), 4),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

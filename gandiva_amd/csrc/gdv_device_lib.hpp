@@ -706,12 +706,15 @@ struct gdv_str {
   const gdv_uint8* p;
   gdv_int32 len;
   gdv_int32 map;
+  const gdv_uint8* lim;  // end of the readable buffer p points into (8-byte loads stop here)
 };
-GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end) {
+GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
+                             const gdv_uint8* lim) {
   gdv_str s;
   s.p = base + begin;
   s.len = end - begin;
   s.map = 0;
+  s.lim = lim;
   return s;
 }
 GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
@@ -720,14 +723,76 @@ GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
   return c;
 }
 GDV_DEV gdv_uint8 gdv_str_at(const gdv_str& s, gdv_int32 i) { return gdv_map_byte(s.p[i], s.map); }
+
+// ---- word-at-a-time (SWAR) primitives: strings are processed 8 bytes per step with one
+// unaligned 8-byte load instead of 8 dependent byte loads; ASCII case mapping, UTF-8
+// continuation-byte counting and substring search all work on the 64-bit word.
+#define GDV_B80 0x8080808080808080ull
+#define GDV_B7F 0x7f7f7f7f7f7f7f7full
+GDV_DEV gdv_uint64 gdv_load8(const gdv_uint8* p, const gdv_uint8* lim) {
+  gdv_uint64 w = 0;
+  if (p + 8 <= lim) {
+    __builtin_memcpy(&w, p, 8);
+  } else {
+    for (int k = 0; k < 8 && p + k < lim; k++) w |= (gdv_uint64)p[k] << (8 * k);
+  }
+  return w;
+}
+GDV_DEV gdv_uint64 gdv_low_bytes_mask(gdv_int32 nbytes) {  // nbytes in [0, 8]
+  return nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1ull);
+}
+GDV_DEV gdv_uint64 gdv_map8(gdv_uint64 w, gdv_int32 map) {
+  if (map == 0) return w;
+  const gdv_uint64 h = w & GDV_B7F;
+  const gdv_uint64 ascii = ~w & GDV_B80;
+  // top bit of each byte: h >= lo  and  h > hi, computed without cross-byte carries
+  const gdv_uint64 lo = map == 1 ? 0x1f1f1f1f1f1f1f1full : 0x3f3f3f3f3f3f3f3full;  // 0x80 - 'a' | 0x80 - 'A'
+  const gdv_uint64 hi = map == 1 ? 0x0505050505050505ull : 0x2525252525252525ull;  // 0x7f - 'z' | 0x7f - 'Z'
+  const gdv_uint64 in_range = (h + lo) & ~(h + hi) & ascii;
+  return w ^ (in_range >> 2);  // toggle bit 5 (0x20) of the letters in range
+}
+// mapped bytes [i, i+8) of the string (bytes past the buffer limit read as 0)
+GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
+  return gdv_map8(gdv_load8(s.p + i, s.lim), s.map);
+}
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
-  for (gdv_int32 i = 0; i < s.len; i++) dst[i] = gdv_str_at(s, i);
+  gdv_int32 i = 0;
+  for (; i + 8 <= s.len; i += 8) {
+    const gdv_uint64 w = gdv_word_at(s, i);
+    __builtin_memcpy(dst + i, &w, 8);
+  }
+  if (i < s.len) {
+    gdv_uint64 w = gdv_word_at(s, i);
+    gdv_int32 left = s.len - i;
+    if (left >= 4) { const gdv_uint32 x = (gdv_uint32)w; __builtin_memcpy(dst + i, &x, 4); w >>= 32; i += 4; left -= 4; }
+    if (left >= 2) { const gdv_uint16 x = (gdv_uint16)w; __builtin_memcpy(dst + i, &x, 2); w >>= 16; i += 2; left -= 2; }
+    if (left >= 1) dst[i] = (gdv_uint8)w;
+  }
 }
 GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
+// number of UTF-8 characters = bytes that are not continuation bytes (10xxxxxx)
 GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
-  gdv_int32 n = 0;
-  for (gdv_int32 i = 0; i < s.len; i++) n += gdv_is_utf8_lead(s.p[i]) ? 1 : 0;
-  return n;
+  gdv_int32 cont = 0;
+  for (gdv_int32 i = 0; i < s.len; i += 8) {
+    gdv_uint64 w = gdv_load8(s.p + i, s.lim) & gdv_low_bytes_mask(s.len - i);
+    cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
+  }
+  return s.len - cont;
+}
+GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
+  gdv_uint64 acc = 0;
+  for (gdv_int32 i = 0; i < s.len; i += 8)
+    acc |= gdv_load8(s.p + i, s.lim) & gdv_low_bytes_mask(s.len - i);
+  return (acc & GDV_B80) == 0;
+}
+// bytes [i, i+n) of s equal the n bytes at q (n >= 0; q readable up to qlim)
+GDV_DEV bool gdv_bytes_equal(const gdv_str& s, gdv_int32 i, const gdv_uint8* q, const gdv_uint8* qlim,
+                             gdv_int32 n) {
+  for (gdv_int32 k = 0; k < n; k += 8) {
+    const gdv_uint64 m = gdv_low_bytes_mask(n - k);
+    if (((gdv_word_at(s, i + k) ^ gdv_load8(q + k, qlim)) & m) != 0) return false;
+  }
+  return true;
 }
 
 GDV_DEV gdv_int32 octet_length_utf8(gdv_str s) { return s.len; }
@@ -770,6 +835,14 @@ GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 cou
   gdv_str r = s;
   r.len = 0;
   if (count <= 0 || s.len <= 0) return r;
+  if (gdv_str_is_ascii(s)) {  // character index == byte index
+    gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? (gdv_int64)s.len + from : 0);
+    if (start < 0 || start >= s.len) return r;
+    gdv_int64 stop = start + count < s.len ? start + count : s.len;
+    r.p = s.p + start;
+    r.len = (gdv_int32)(stop - start);
+    return r;
+  }
   const gdv_int64 glyphs = gdv_utf8_count(s);
   gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? glyphs + from : 0);
   if (start < 0 || start >= glyphs) return r;
@@ -831,6 +904,43 @@ GDV_DEV bool gdv_like(const gdv_str& s, const gdv_uint8* pbyte, const gdv_uint8*
   return j == plen;
 }
 
+// LIKE shapes the planner recognises at Make time and routes around the general matcher:
+//   'literal'      -> gdv_like_equal       'literal%'  -> gdv_like_prefix
+//   '%literal'     -> gdv_like_suffix      '%literal%' -> gdv_like_contains
+// `nb` holds the literal (m bytes, readable 8 bytes past its end).
+GDV_DEV bool gdv_like_prefix(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  return m <= s.len && gdv_bytes_equal(s, 0, nb, nb + m + 8, m);
+}
+GDV_DEV bool gdv_like_suffix(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  return m <= s.len && gdv_bytes_equal(s, s.len - m, nb, nb + m + 8, m);
+}
+GDV_DEV bool gdv_like_equal(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  return m == s.len && gdv_bytes_equal(s, 0, nb, nb + m + 8, m);
+}
+// substring search on a sliding 64-bit window: per candidate position two shifts, an OR,
+// an AND and a compare against the needle's first (up to) 8 bytes — no byte loads
+GDV_DEV bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  if (m == 0) return true;
+  if (m > s.len) return false;
+  const gdv_uint64 mask = gdv_low_bytes_mask(m);
+  const gdv_uint64 first = gdv_load8(nb, nb + m + 8) & mask;
+  const gdv_int32 last = s.len - m;  // last candidate start
+  gdv_uint64 cur = gdv_word_at(s, 0);
+  for (gdv_int32 base = 0; base <= last; base += 8) {
+    const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (base + k > last) break;
+      const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
+      if ((win & mask) == first &&
+          (m <= 8 || gdv_bytes_equal(s, base + k + 8, nb + 8, nb + m + 8, m - 8)))
+        return true;
+    }
+    cur = nxt;
+  }
+  return false;
+}
+
 // IN over strings: linear probe of the literal list (lists are short in practice)
 GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_int32* offs, gdv_int32 n) {
   for (gdv_int32 k = 0; k < n; k++) {
@@ -843,5 +953,3 @@ GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_
   return false;
 }
 
-// hash of the string bytes: murmur3 x64-128 style reduction is restated in hash64_utf8
-GDV_DEV gdv_int64 gdv_castBIGINT_len(gdv_str s) { return s.len; }

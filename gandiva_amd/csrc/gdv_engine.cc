@@ -173,6 +173,10 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
           args->SetInOffsets(static_cast<int>(k), osrc);
           args->SetInData(static_cast<int>(k), c.data);
         }
+        // readable extent of the byte buffer (the kernels' 8-byte loads stop at this limit)
+        HostBitmap extent;
+        extent.nwords = c.data_size;
+        args->SetInBits(static_cast<int>(k), extent);
       } else if (t.id == kBool) {
         if (c.data_size < BytesForBits(c.offset + num_rows))
           return Status::Invalid("column '" + name + "': data buffer too small");

@@ -259,16 +259,16 @@ class CodeGen {
   // bytes -> `__constant__` array in the prelude; returns the array name
   std::string ByteTable(const std::string& bytes, const char* ctype = "gdv_uint8") {
     std::string name = "gdv_cst" + std::to_string(next_const_++);
-    prelude_ << "__constant__ " << ctype << " " << name << "[" << std::max<size_t>(bytes.size(), 1)
-             << "] = {";
+    prelude_ << "__constant__ " << ctype << " " << name << "[" << bytes.size() + 8 << "] = {";
     for (size_t i = 0; i < bytes.size(); i++)
-      prelude_ << (i ? "," : "") << static_cast<unsigned>(static_cast<unsigned char>(bytes[i]));
-    if (bytes.empty()) prelude_ << "0";
-    prelude_ << "};\n";
+      prelude_ << static_cast<unsigned>(static_cast<unsigned char>(bytes[i])) << ",";
+    prelude_ << "0,0,0,0,0,0,0,0};\n";  // 8-byte loads may run past the literal's end
     return name;
   }
   std::string StringConstant(const std::string& bytes) {
-    return "gdv_make_str(" + ByteTable(bytes) + ", 0, " + std::to_string(bytes.size()) + ")";
+    std::string t = ByteTable(bytes);
+    return "gdv_make_str(" + t + ", 0, " + std::to_string(bytes.size()) + ", " + t + " + " +
+           std::to_string(bytes.size() + 8) + ")";
   }
   // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
   static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
@@ -399,9 +399,23 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         }
         std::string bytes, kinds;
         GDV_RETURN_NOT_OK(CompileLike(pat.value().bytes, escape, &bytes, &kinds));
-        std::string pb = ByteTable(bytes), pk = ByteTable(kinds);
         out->vcols = args[0].vcols;
         out->vlane = args[0].vlane;
+        // common shapes skip the general matcher: literal | literal% | %literal | %literal%
+        const size_t nk = kinds.size();
+        const bool lead = nk > 0 && kinds.front() == 2, trail = nk > 0 && kinds.back() == 2;
+        const size_t lo = lead ? 1 : 0, hi = nk - ((trail && nk > lo) ? 1 : 0);
+        bool plain = true;
+        for (size_t i = lo; i < hi; i++) plain = plain && kinds[i] == 0;
+        if (plain && !(nk == 1 && lead)) {
+          const std::string lit = bytes.substr(lo, hi - lo);
+          const char* fnname = lead && trail ? "gdv_like_contains" : lead ? "gdv_like_suffix"
+                               : trail ? "gdv_like_prefix" : "gdv_like_equal";
+          out->v = Tmp("bool", std::string(fnname) + "(" + args[0].v + ", " + ByteTable(lit) + ", " +
+                                   std::to_string(lit.size()) + ")");
+          return Status::OK();
+        }
+        std::string pb = ByteTable(bytes), pk = ByteTable(kinds);
         out->v = Tmp("bool", "gdv_like(" + args[0].v + ", " + pb + ", " + pk + ", " +
                                  std::to_string(kinds.size()) + ")");
         return Status::OK();
@@ -750,7 +764,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
     if (t.is_varlen() && cg.needs_values_[k])
       s << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "[u], ob" << k
-        << "[u]);\n";
+        << "[u], sd" << k << " + A.in[" << k << "].bits.nwords);\n";
   }
   if (!sel) {
     for (int k = 0; k < nin; k++) {
