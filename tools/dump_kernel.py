@@ -26,7 +26,8 @@ def plan_source(which):
         cond = W.c3_condition()
         rc = lib.gdv_precompile_filter(sh, cond._h)
     else:
-        schema, exprs = {"c1": (W.c1_schema, W.c1_expressions), "c2": (W.c2_schema, W.c2_expressions)}[which]
+        schema, exprs = {"c1": (W.c1_schema, W.c1_expressions), "c2": (W.c2_schema, W.c2_expressions),
+                         "c4": (W.c4_schema, W.c4_expressions), "c5": (W.c5_schema, W.c5_expressions)}[which]
         ex = exprs()
         sh = gg._make_schema(schema())
         arr = (C.c_void_p * len(ex))(*[e._h for e in ex])
