@@ -702,11 +702,18 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 // 2 ASCII lower).  substr / trim produce narrower views, upper / lower set the map, so no
 // per-row scratch is ever needed; the bytes are materialised exactly once, by the copy pass
 // of a var-len output (gdv_str_copy), or consumed in place by predicates (like, equal …).
+#define GDV_NPRE 4  // 8-byte words of every input string prefetched into registers (32 bytes)
 struct gdv_str {
   const gdv_uint8* p;
   gdv_int32 len;
   gdv_int32 map;
   const gdv_uint8* lim;  // end of the readable buffer p points into (8-byte loads stop here)
+  // Register cache of the first GDV_NPRE words at `cp` (nullptr: no cache).  The words of ALL
+  // sub-tiles of a wave tile are loaded together, right after the offsets arrive (phase 1b of
+  // the generated kernel): without it every string function walks memory with one dependent
+  // load at a time and the kernel is bound by ~20 serialised round trips per tile.
+  const gdv_uint8* cp;
+  gdv_uint64 pre[GDV_NPRE];
 };
 GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
                              const gdv_uint8* lim) {
@@ -715,6 +722,17 @@ GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 e
   s.len = end - begin;
   s.map = 0;
   s.lim = lim;
+  s.cp = nullptr;
+#pragma unroll
+  for (int j = 0; j < GDV_NPRE; j++) s.pre[j] = 0;
+  return s;
+}
+GDV_DEV gdv_str gdv_make_str_cached(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
+                                    const gdv_uint8* lim, const gdv_uint64* pre) {
+  gdv_str s = gdv_make_str(base, begin, end, lim);
+  s.cp = s.p;
+#pragma unroll
+  for (int j = 0; j < GDV_NPRE; j++) s.pre[j] = pre[j];
   return s;
 }
 GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
@@ -751,9 +769,28 @@ GDV_DEV gdv_uint64 gdv_map8(gdv_uint64 w, gdv_int32 map) {
   const gdv_uint64 in_range = (h + lo) & ~(h + hi) & ascii;
   return w ^ (in_range >> 2);  // toggle bit 5 (0x20) of the letters in range
 }
+GDV_DEV gdv_uint64 gdv_pre_word(const gdv_str& s, gdv_int32 j) {  // j may be any value
+  gdv_uint64 w = 0;
+#pragma unroll
+  for (int k = 0; k < GDV_NPRE; k++) w = (j == k) ? s.pre[k] : w;
+  return w;
+}
+// raw bytes [i, i+8) of the string: from the register cache when they lie inside it
+GDV_DEV gdv_uint64 gdv_raw_word_at(const gdv_str& s, gdv_int32 i) {
+  if (s.cp != nullptr) {
+    const gdv_int64 d = (gdv_int64)(s.p - s.cp) + i;
+    if (d >= 0 && d + 8 <= 8 * GDV_NPRE) {
+      const gdv_int32 j = (gdv_int32)(d >> 3), sh = (gdv_int32)(d & 7) * 8;
+      const gdv_uint64 lo = gdv_pre_word(s, j);
+      if (sh == 0) return lo;
+      return (lo >> sh) | (gdv_pre_word(s, j + 1) << (64 - sh));
+    }
+  }
+  return gdv_load8(s.p + i, s.lim);
+}
 // mapped bytes [i, i+8) of the string (bytes past the buffer limit read as 0)
 GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
-  return gdv_map8(gdv_load8(s.p + i, s.lim), s.map);
+  return gdv_map8(gdv_raw_word_at(s, i), s.map);
 }
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
   gdv_int32 i = 0;
@@ -774,7 +811,7 @@ GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
 GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
   gdv_int32 cont = 0;
   for (gdv_int32 i = 0; i < s.len; i += 8) {
-    gdv_uint64 w = gdv_load8(s.p + i, s.lim) & gdv_low_bytes_mask(s.len - i);
+    gdv_uint64 w = gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
     cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
   }
   return s.len - cont;
@@ -782,7 +819,7 @@ GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
 GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
   gdv_uint64 acc = 0;
   for (gdv_int32 i = 0; i < s.len; i += 8)
-    acc |= gdv_load8(s.p + i, s.lim) & gdv_low_bytes_mask(s.len - i);
+    acc |= gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
   return (acc & GDV_B80) == 0;
 }
 // bytes [i, i+n) of s equal the n bytes at q (n >= 0; q readable up to qlim)
@@ -917,19 +954,25 @@ GDV_DEV bool gdv_like_suffix(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m)
 GDV_DEV bool gdv_like_equal(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
   return m == s.len && gdv_bytes_equal(s, 0, nb, nb + m + 8, m);
 }
-// substring search on a sliding 64-bit window: per candidate position two shifts, an OR,
-// an AND and a compare against the needle's first (up to) 8 bytes — no byte loads
+// substring search, 8 candidate positions per step: a SWAR zero-byte test on
+// (word ^ first-needle-byte) yields the positions whose byte equals the needle's first byte;
+// only those are verified, on a 64-bit window assembled from the current and next word.
+// (The zero-byte test can flag a byte above a true match — harmless, it is verified too.)
 GDV_DEV bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
   if (m == 0) return true;
   if (m > s.len) return false;
   const gdv_uint64 mask = gdv_low_bytes_mask(m);
   const gdv_uint64 first = gdv_load8(nb, nb + m + 8) & mask;
+  const gdv_uint64 splat = (first & 0xffull) * 0x0101010101010101ull;
   const gdv_int32 last = s.len - m;  // last candidate start
   gdv_uint64 cur = gdv_word_at(s, 0);
   for (gdv_int32 base = 0; base <= last; base += 8) {
     const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
+    const gdv_uint64 x = cur ^ splat;
+    gdv_uint64 cand = (x - 0x0101010101010101ull) & ~x & GDV_B80;
+    while (cand) {
+      const int k = __builtin_ctzll(cand) >> 3;
+      cand &= cand - 1;
       if (base + k > last) break;
       const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
       if ((win & mask) == first &&

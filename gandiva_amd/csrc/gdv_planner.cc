@@ -715,10 +715,16 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
              << "].valid, wbase, lane, GDV_U);\n";
     }
   }
+  for (size_t e = 0; e < plan->output_types.size(); e++)
+    if (plan->output_types[e].is_varlen()) s << "  gdv_int32 oo" << e << "[GDV_U];\n";
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
     << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
     << "    const bool live = FULL || row < n;\n"
     << "    (void)live;\n";
+  // byte pass: where each row's bytes go (issued with the input loads, not after them)
+  for (size_t e = 0; e < plan->output_types.size(); e++)
+    if (plan->output_types[e].is_varlen())
+      s << "    oo" << e << "[u] = (PASS == 1 && live) ? outo" << e << "[row] : 0;\n";
   if (sel) {
     s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
     for (int k = 0; k < nin; k++) {
@@ -749,6 +755,19 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     }
   }
   s << "  }\n";
+  // phase 1b: the first GDV_NPRE 8-byte words of every input string of every sub-tile, all
+  // issued together once the offsets are known (reads past a short string stay inside the
+  // buffer limit and are ignored)
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.is_varlen() && cg.needs_values_[k]) {
+      s << "  gdv_uint64 sw" << k << "[GDV_U][GDV_NPRE];\n"
+        << "  const gdv_uint8* slim" << k << " = sd" << k << " + A.in[" << k << "].bits.nwords;\n"
+        << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+        << "#pragma unroll\n    for (int j = 0; j < GDV_NPRE; j++) sw" << k
+        << "[u][j] = gdv_load8(sd" << k << " + oa" << k << "[u] + 8 * j, slim" << k << ");\n  }\n";
+    }
+  }
 
   // ---- phase 2: row body
   s << "  // ---- phase 2: fused expression bodies (value for every row, validity per word)\n";
@@ -763,8 +782,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
     if (t.is_varlen() && cg.needs_values_[k])
-      s << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "[u], ob" << k
-        << "[u], sd" << k << " + A.in[" << k << "].bits.nwords);\n";
+      s << "      const gdv_str s" << k << " = gdv_make_str_cached(sd" << k << ", oa" << k << "[u], ob"
+        << k << "[u], slim" << k << ", sw" << k << "[u]);\n";
   }
   if (!sel) {
     for (int k = 0; k < nin; k++) {
@@ -855,7 +874,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       const std::string ok = CodeGen::AndExpr("live", cg.LaneValid(v));
       cg.Stmt("if (pass == 0) { if (live) outo" + E + "[row + 1] = (" + ok + ") ? (" + v.v +
               ").len : 0; }");
-      cg.Stmt("else if (" + ok + ") gdv_str_copy(outd" + E + " + outo" + E + "[row], " + v.v + ");");
+      cg.Stmt("else if (" + ok + ") gdv_str_copy(outd" + E + " + oo" + E + "[u], " + v.v + ");");
     } else if (t.id == kBool) {
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
       after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)", two);

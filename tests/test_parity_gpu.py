@@ -322,3 +322,84 @@ def test_full_size_properties_c2():
             pa.py_buffer(o.validity[:(m + 7) // 8 + 8].cpu().numpy()),
             pa.py_buffer(o.data[:m * 8].cpu().numpy())])
         assert_bit_exact(got, w)
+
+
+def test_concurrent_evaluate_is_reentrant():
+    """The reference's bindings are `nogil`: Evaluate on ONE projector/filter from many threads
+    at once (per-call scratch only).  8 threads x 20 evaluations on distinct batches."""
+    import threading
+    exprs = W.c2_expressions()
+    proj = gandiva.make_projector(W.c2_schema(), exprs, None)
+    cond = W.c3_condition()
+    flt = gandiva.make_filter(W.c3_schema(), cond)
+    batches = [W.c2_batch(5000 + 997 * i, seed_offset=i) for i in range(8)]
+    fbatches = [W.c3_batch(7000 + 313 * i, 0.1) for i in range(8)]
+    want = [oracle.project(exprs, b) for b in batches]
+    fwant = [oracle.filter_indices(cond, b, "int32") for b in fbatches]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                got = proj.evaluate(batches[i])
+                for g, w in zip(got, want[i]):
+                    assert_bit_exact(g, w)
+                assert flt.evaluate(fbatches[i], None).to_array().equals(fwant[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_wide_projection_many_columns():
+    """64 input columns, 48 outputs: the by-value kernel argument block is ~5 KB."""
+    rng = np.random.default_rng(64)
+    n = 3001
+    ncol = 64
+    cols = [random_array(rng, pa.int64(), n, 0.1, special=False) for _ in range(ncol)]
+    batch = pa.RecordBatch.from_arrays(cols, names=[f"c{i}" for i in range(ncol)])
+    b = gandiva.TreeExprBuilder()
+    f = [b.make_field(batch.schema.field(i)) for i in range(ncol)]
+    exprs = []
+    for i in range(48):
+        node = b.make_function("add", [f[i], b.make_function("multiply", [f[(i + 7) % ncol], f[(i + 13) % ncol]],
+                                                             pa.int64())], pa.int64())
+        exprs.append(b.make_expression(node, pa.field(f"o{i}", pa.int64())))
+    _check_project(exprs, batch)
+
+
+def test_uint_and_narrow_types_in_filters():
+    rng = np.random.default_rng(77)
+    n = 20001
+    batch = _batch(rng, [pa.uint8(), pa.int16(), pa.uint32(), pa.float32(), pa.date32()], n, 0.2)
+    b = gandiva.TreeExprBuilder()
+    u8, i16, u32, f32, d32 = (b.make_field(batch.schema.field(i)) for i in range(5))
+    conds = [
+        b.make_function("greater_than", [u8, b.make_literal(100, pa.uint8())], pa.bool_()),
+        b.make_function("less_than", [i16, b.make_literal(-5, pa.int16())], pa.bool_()),
+        b.make_function("not_equal", [u32, b.make_literal(7, pa.uint32())], pa.bool_()),
+        b.make_function("less_than_or_equal_to", [f32, b.make_literal(0.5, pa.float32())], pa.bool_()),
+        b.make_function("greater_than_or_equal_to", [d32, b.make_literal(10000, pa.date32())], pa.bool_()),
+    ]
+    for c in conds + [b.make_and(conds[:3]), b.make_or(conds[2:])]:
+        cond = b.make_condition(c)
+        got = gandiva.make_filter(batch.schema, cond).evaluate(batch, None, "int64").to_array()
+        assert got.equals(oracle.filter_indices(cond, batch, "int64"))
+
+
+def test_make_is_cached_and_invalid_inputs_are_rejected():
+    exprs = W.c1_expressions()
+    schema = W.c1_schema()
+    p1 = gandiva.make_projector(schema, exprs, None)
+    p2 = gandiva.make_projector(schema, W.c1_expressions(), None)   # same key -> cached plan
+    assert p1.llvm_ir == p2.llvm_ir
+    with pytest.raises(pa.ArrowInvalid):                            # empty batch
+        p1.evaluate(W.c1_batch(8).slice(0, 0))
+    with pytest.raises(pa.ArrowInvalid):                            # schema mismatch
+        p1.evaluate(W.c2_batch(8))
+    with pytest.raises(pa.ArrowInvalid):                            # selection on a NONE-mode projector
+        p1.evaluate(W.c1_batch(8), gandiva.SelectionVector(2, np.zeros(4, np.uint32), 4))
