@@ -377,6 +377,112 @@ int gdv_device_synchronize(void) {
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
 }
 
+// ---------------------------------------------------------------- C device data interface
+namespace {
+
+// struct array (one child per field) -> gdv_column_t[]; sizes are derived from
+// offset + length and the field type because the C data interface carries no buffer sizes
+Status ImportBatch(const Schema& schema, const ArrowDeviceArray* batch, hipStream_t stream,
+                   std::vector<ColumnBuffers>* cols, MemKind* mem, int64_t* num_rows) {
+  if (batch == nullptr) return Status::Invalid("null ArrowDeviceArray");
+  const ArrowArray& a = batch->array;
+  if (a.release == nullptr) return Status::Invalid("ArrowDeviceArray was already released");
+  if (a.n_children != static_cast<int64_t>(schema.size()))
+    return Status::Invalid("ArrowDeviceArray has " + std::to_string(a.n_children) +
+                           " children, the schema has " + std::to_string(schema.size()) + " fields");
+  if (a.offset != 0) return Status::Invalid("struct-level offset is not supported");
+  switch (batch->device_type) {
+    case ARROW_DEVICE_ROCM: *mem = MemKind::kDevice; break;
+    case ARROW_DEVICE_CPU: case ARROW_DEVICE_ROCM_HOST: *mem = MemKind::kHost; break;
+    default: return Status::Invalid("unsupported ArrowDeviceType " + std::to_string(batch->device_type));
+  }
+  if (batch->sync_event != nullptr && *mem == MemKind::kDevice)
+    GDV_HIP_RETURN_NOT_OK(hipStreamWaitEvent(stream, *static_cast<hipEvent_t*>(batch->sync_event), 0));
+  *num_rows = a.length;
+  cols->assign(schema.size(), ColumnBuffers());
+  for (size_t i = 0; i < schema.size(); i++) {
+    const ArrowArray* c = a.children[i];
+    if (c == nullptr) return Status::Invalid("null child array");
+    if (c->length != a.length) return Status::Invalid("child length differs from the batch length");
+    const DataType& t = schema[i].type;
+    ColumnBuffers& col = (*cols)[i];
+    const int64_t rows = c->offset + c->length;
+    col.offset = c->offset;
+    const int64_t want = t.is_varlen() ? 3 : 2;
+    if (c->n_buffers < want) continue;  // e.g. a null-type child: fails later only if referenced
+    col.validity = c->buffers[0];
+    col.validity_size = col.validity ? (rows + 7) / 8 : 0;
+    if (t.is_varlen()) {
+      col.offsets = c->buffers[1];
+      col.offsets_size = (rows + 1) * 4;
+      col.data = c->buffers[2];
+      int32_t last = 0;  // byte extent = the last offset
+      if (col.offsets != nullptr && rows >= 0) {
+        const char* src = static_cast<const char*>(col.offsets) + rows * 4;
+        if (*mem == MemKind::kDevice) {
+          GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&last, src, 4, hipMemcpyDeviceToHost, stream));
+          GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+        } else {
+          std::memcpy(&last, src, 4);
+        }
+      }
+      col.data_size = last;
+    } else {
+      col.data = c->buffers[1];
+      col.data_size = t.id == kBool ? (rows + 7) / 8 : rows * t.byte_width();
+    }
+  }
+  return Status::OK();
+}
+
+}  // namespace
+
+int gdv_projector_evaluate_device_array(const gdv_projector_t* p, const ArrowDeviceArray* batch,
+                                        const gdv_selection_t* sel, gdv_out_column_t* outs,
+                                        int num_outs, void* stream, uint32_t flags) {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (!outs) return Fail(Status::Invalid("Output array vector cannot be null"));
+  std::vector<ColumnBuffers> cols;
+  MemKind mem;
+  int64_t rows = 0;
+  Status st = ImportBatch(p->p->schema(), batch, static_cast<hipStream_t>(stream), &cols, &mem, &rows);
+  if (!st.ok()) return Fail(st);
+  std::vector<OutputBuffers> o(num_outs > 0 ? num_outs : 0);
+  for (int i = 0; i < num_outs; i++) {
+    o[i].validity = outs[i].validity;
+    o[i].validity_size = outs[i].validity_size;
+    o[i].data = outs[i].data;
+    o[i].data_size = outs[i].data_size;
+    o[i].offsets = outs[i].offsets;
+    o[i].offsets_size = outs[i].offsets_size;
+  }
+  SelectionView sv;
+  if (sel) {
+    if (!ToSelectionMode(sel->mode, &sv.mode)) return Fail(Status::Invalid("bad selection mode"));
+    sv.indices = sel->indices;
+    sv.num_slots = sel->num_slots;
+  }
+  st = p->p->Evaluate(rows, cols.data(), static_cast<int>(cols.size()), sel ? &sv : nullptr, o.data(),
+                      num_outs, mem, static_cast<hipStream_t>(stream), flags);
+  for (int i = 0; i < num_outs; i++) outs[i].data_size = o[i].data_size;
+  return Check(st);
+}
+
+int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const ArrowDeviceArray* batch,
+                                     int selection_mode, void* out_indices, int64_t max_slots,
+                                     int64_t* num_selected, void* stream) {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<ColumnBuffers> cols;
+  MemKind mem;
+  int64_t rows = 0;
+  Status st = ImportBatch(f->f->schema(), batch, static_cast<hipStream_t>(stream), &cols, &mem, &rows);
+  if (!st.ok()) return Fail(st);
+  return Check(f->f->Evaluate(rows, cols.data(), static_cast<int>(cols.size()), mode, out_indices,
+                              max_slots, num_selected, mem, static_cast<hipStream_t>(stream)));
+}
+
 // ---------------------------------------------------------------- build support
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
                              int num_exprs, int selection_mode) {

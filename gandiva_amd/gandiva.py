@@ -527,6 +527,13 @@ class Projector:
                 result.append(pa.Array.from_buffers(t, out_rows, [v, d]))
         return result
 
+    def evaluate_device_array(self, array_address, num_rows, on_device):
+        """Evaluate a batch handed over through the Arrow C Device Data Interface:
+        `array_address` is the address of a `struct ArrowDeviceArray` (struct array, one child
+        per schema field).  ARROW_DEVICE_ROCM arrays are used in place and the outputs are
+        DeviceColumns; CPU arrays take the staged path and return pyarrow arrays."""
+        return _evaluate_device_array(self, array_address, num_rows, on_device)
+
     def evaluate_device(self, dbatch, selection=None, outputs=None, stream=None, sync=True):
         """HBM-resident path (zero-copy): inputs are a DeviceBatch, outputs DeviceColumns
         (allocated here unless ``outputs`` from a previous call are passed back in)."""
@@ -583,6 +590,38 @@ class Projector:
             if varlen[i]:
                 outputs[i].data_used = outs[i].data_size
         return outputs
+
+
+def _evaluate_device_array(projector, array_address, num_rows, on_device):
+    """Shared body of Projector.evaluate_device_array: fixed-width outputs only."""
+    lib = _capi.lib()
+    n_out = len(projector._out_types)
+    outs = (gdv_out_column_t * n_out)()
+    mem = GDV_MEM_DEVICE if on_device else GDV_MEM_HOST
+    holders = []
+    for i, t in enumerate(projector._out_types):
+        if pa.types.is_string(t) or pa.types.is_binary(t):
+            raise pa.ArrowNotImplementedError("var-len outputs: use evaluate / evaluate_device")
+        vb, db = C.c_int64(), C.c_int64()
+        _check(lib.gdv_projector_output_sizes(projector._h, i, num_rows, mem, vb, db))
+        if on_device:
+            import torch
+            v = torch.empty(_pad64(max(vb.value, 1)), dtype=torch.uint8, device="cuda")
+            d = torch.empty(_pad64(max(db.value, 1)), dtype=torch.uint8, device="cuda")
+            outs[i].validity, outs[i].validity_size = v.data_ptr(), v.numel()
+            outs[i].data, outs[i].data_size = d.data_ptr(), d.numel()
+            holders.append(DeviceColumn(t, num_rows, v, d))
+        else:
+            v = pa.allocate_buffer(_pad64(max(vb.value, 1)))
+            d = pa.allocate_buffer(_pad64(max(db.value, 1)))
+            outs[i].validity, outs[i].validity_size = v.address, v.size
+            outs[i].data, outs[i].data_size = d.address, d.size
+            holders.append((t, v, d))
+    _check(lib.gdv_projector_evaluate_device_array(projector._h, C.c_void_p(array_address), None, outs,
+                                                   n_out, None, 0))
+    if on_device:
+        return holders
+    return [pa.Array.from_buffers(t, num_rows, [v, d]) for t, v, d in holders]
 
 
 def make_projector(schema, children, pool=None, selection_mode="NONE", configuration=None):

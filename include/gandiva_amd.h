@@ -252,6 +252,64 @@ int gdv_memcpy_h2d(void* dst_device, const void* src_host, int64_t bytes);
 int gdv_memcpy_d2h(void* dst_host, const void* src_device, int64_t bytes);
 int gdv_device_synchronize(void);
 
+/* ---- Arrow C Device Data Interface (the step BEFORE the path: other ROCm producers) --- */
+/* The ABI-stable structs of the Arrow C data / C device data interfaces
+ * (pyarrow/include/arrow/c/abi.h).  Declared here under the spec's own include guards so
+ * this header can be used with or without Arrow's. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+#ifndef ARROW_C_DEVICE_DATA_INTERFACE
+#define ARROW_C_DEVICE_DATA_INTERFACE
+typedef int32_t ArrowDeviceType;
+#define ARROW_DEVICE_CPU 1
+#define ARROW_DEVICE_ROCM 10
+#define ARROW_DEVICE_ROCM_HOST 11
+struct ArrowDeviceArray {
+  struct ArrowArray array;
+  int64_t device_id;
+  ArrowDeviceType device_type;
+  void* sync_event; /* hipEvent_t* for ROCM arrays, or NULL */
+  int64_t reserved[3];
+};
+#endif
+/* Evaluate over a record batch handed over as an ArrowDeviceArray: a struct array with one
+ * child per schema field (what arrow::ExportDeviceRecordBatch / pyarrow's
+ * RecordBatch._export_to_c_device produce).  device_type ARROW_DEVICE_ROCM is used in
+ * place (zero-copy; outputs must be HBM buffers); ARROW_DEVICE_CPU / ROCM_HOST take the
+ * staged host path.  A non-NULL sync_event is waited for on `stream` before the kernel.
+ * The batch is borrowed: it is NOT released by these calls. */
+int gdv_projector_evaluate_device_array(const gdv_projector_t* p,
+                                        const struct ArrowDeviceArray* batch,
+                                        const gdv_selection_t* sel, gdv_out_column_t* outs,
+                                        int num_outs, void* stream, uint32_t flags);
+int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const struct ArrowDeviceArray* batch,
+                                     int selection_mode, void* out_indices, int64_t max_slots,
+                                     int64_t* num_selected, void* stream);
+
 /* ---- build support ----------------------------------------------------------------- */
 /* Plan + compile to a gfx950 code object without a device; fills the on-disk kernel cache. */
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
