@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    p.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
     p.add_argument("--cpu-rows", type=int, default=1 << 24, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,6 +174,23 @@ def main():
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
         kernel_desc = "fused 10-expression projection kernel (1 launch per step)"
+    elif args.workload == "c1":
+        rows = args.rows or (1 << 28)
+        g = torch.Generator(device="cuda")
+        cols = []
+        for k in range(3):
+            g.manual_seed(1 + k)
+            data = torch.empty(rows, dtype=torch.int32, device="cuda")
+            data.random_(-(1 << 15), 1 << 15, generator=g)
+            cols.append(gandiva.DeviceColumn(W.c1_schema().field(k).type, rows, None, data.view(torch.uint8)))
+        dbatch = gandiva.DeviceBatch(W.c1_schema(), cols, rows)
+        proj = gandiva.make_projector(W.c1_schema(), W.c1_expressions(), None)
+        outs = proj.evaluate_device(dbatch)
+        bytes_per_row = 16 + 1 / 8
+
+        def step():
+            proj.evaluate_device(dbatch, outputs=outs, sync=False)
+        kernel_desc = "fused (a+b)*c int32 projection kernel"
     elif args.workload == "c4":
         rows = args.rows or 750_000_000
         dbatch = W.c4_device_batch(rows)
@@ -236,7 +253,8 @@ def main():
         value = total_rows * args.steps / elapsed / 1e6
         achieved = bytes_per_row * rows / (mean_dev_ms * 1e-3) / 1e9
         line = {
-            "metric": {"c2": "million rows/sec, 10-expr float64 Projector (10% nulls)",
+            "metric": {"c1": "million rows/sec, (a+b)*c int32 Projector",
+                       "c2": "million rows/sec, 10-expr float64 Projector (10% nulls)",
                        "c3": "million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)",
                        "c4": "million rows/sec, TPC-H Q1 projections (decimal128 + datediff)",
                        "c5": "million rows/sec, utf8 like/substr/upper"}[args.workload],
@@ -249,10 +267,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"c2": "f64", "c3": "int64", "c4": "decimal128", "c5": "u8"}[args.workload],
+            "dtype": {"c1": "int32", "c2": "f64", "c3": "int64", "c4": "decimal128", "c5": "u8"}[args.workload],
             "data": "synthetic",
             "config": {
-                "workload": {"c2": "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column",
+                "workload": {"c1": "C1 shape at scale: (a+b)*c over int32, no nulls",
+                             "c2": "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column",
                              "c3": "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector",
                              "c4": "C4: ep*(1-disc), ep*(1-disc)*(1+tax) decimal128(15,2) inputs, "
                                    "datediff(1998-12-01, shipdate date32)",
@@ -278,7 +297,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                fn = {"c2": cpu_baseline_c2, "c3": cpu_baseline_c3, "c4": cpu_baseline_c4,
+                fn = {"c1": lambda r: {"value": None, "unit": "million rows/s", "cores": 0, "kind": "port",
+                                       "sample": "not timed for c1"},
+                      "c2": cpu_baseline_c2, "c3": cpu_baseline_c3, "c4": cpu_baseline_c4,
                       "c5": cpu_baseline_c5}[args.workload]
                 line["cpu_baseline"] = fn(args.cpu_rows)
             except Exception as e:  # the baseline must never take the bench line down

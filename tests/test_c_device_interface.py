@@ -31,22 +31,27 @@ class ArrowDeviceArray(C.Structure):
                 ("sync_event", C.c_void_p), ("reserved", C.c_int64 * 3)]
 
 
+class ArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p),
+                ("flags", C.c_int64), ("n_children", C.c_int64), ("children", C.c_void_p),
+                ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 def test_cpu_device_array_exported_by_pyarrow():
-    from pyarrow.cffi import ffi
     batch = W.c2_batch(50021)
     exprs = W.c2_expressions()
     proj = gandiva.make_projector(batch.schema, exprs, None)
-    c_arr = ffi.new("struct ArrowDeviceArray*")
-    c_schema = ffi.new("struct ArrowSchema*")
-    batch._export_to_c_device(int(ffi.cast("uintptr_t", c_arr)), int(ffi.cast("uintptr_t", c_schema)))
+    c_arr, c_schema = ArrowDeviceArray(), ArrowSchema()
+    batch._export_to_c_device(C.addressof(c_arr), C.addressof(c_schema))
     try:
         assert c_arr.device_type == 1  # ARROW_DEVICE_CPU
-        got = proj.evaluate_device_array(int(ffi.cast("uintptr_t", c_arr)), batch.num_rows, on_device=False)
+        assert c_arr.array.n_children == 4 and c_arr.array.length == batch.num_rows
+        got = proj.evaluate_device_array(C.addressof(c_arr), batch.num_rows, on_device=False)
     finally:
-        if c_arr.array.release != ffi.NULL:
-            c_arr.array.release(ffi.addressof(c_arr.array))
-        if c_schema.release != ffi.NULL:
-            c_schema.release(c_schema)
+        if c_arr.array.release:
+            C.CFUNCTYPE(None, C.c_void_p)(c_arr.array.release)(C.addressof(c_arr.array))
+        if c_schema.release:
+            C.CFUNCTYPE(None, C.c_void_p)(c_schema.release)(C.addressof(c_schema))
     for g, w in zip(got, oracle.project(exprs, batch)):
         assert_bit_exact(g, w)
 

@@ -403,3 +403,41 @@ def test_make_is_cached_and_invalid_inputs_are_rejected():
         p1.evaluate(W.c2_batch(8))
     with pytest.raises(pa.ArrowInvalid):                            # selection on a NONE-mode projector
         p1.evaluate(W.c1_batch(8), gandiva.SelectionVector(2, np.zeros(4, np.uint32), 4))
+
+
+def test_device_path_with_array_offsets_and_misaligned_bitmaps():
+    """Zero-copy path: Arrow array offsets (bit offset inside the validity word) and a
+    validity buffer that does not start on an 8-byte boundary (FoldBitmap, gdv_engine.cc)."""
+    import torch
+    rng = np.random.default_rng(123)
+    n_full = 9000
+    full = _batch(rng, [pa.float64(), pa.int64(), pa.bool_()], n_full, 0.25, names=["x", "y", "z"])
+    b = gandiva.TreeExprBuilder()
+    x, y, z = (b.make_field(full.schema.field(i)) for i in range(3))
+    exprs = [
+        b.make_expression(b.make_function("multiply", [x, x], pa.float64()), pa.field("sq", pa.float64())),
+        b.make_expression(b.make_if(z, y, b.make_function("negative", [y], pa.int64()), pa.int64()),
+                          pa.field("sel", pa.int64())),
+        b.make_expression(b.make_and([z, b.make_function("greater_than", [y, b.make_literal(0, pa.int64())],
+                                                         pa.bool_())]), pa.field("p", pa.bool_())),
+    ]
+    proj = gandiva.make_projector(full.schema, exprs, None)
+    base = gandiva.DeviceBatch.from_arrow(full)
+    for off, length in ((1, 4000), (63, 1234), (64, 8000), (777, 8223)):
+        cols = []
+        for c in base.columns:
+            # shift every bitmap by 3 bytes so its address is not 8-byte aligned: copy into a
+            # padded tensor at byte offset 3 and move the array offset back by 24 bits
+            def shifted(t):
+                s = torch.zeros(t.numel() + 64, dtype=torch.uint8, device="cuda")
+                s[3:3 + t.numel()] = t
+                return s[3:]
+            validity = shifted(c.validity) if c.validity is not None else None
+            data = shifted(c.data) if pa.types.is_boolean(c.type) else c.data
+            cols.append(gandiva.DeviceColumn(c.type, length, validity, data, None, off))
+        dbatch = gandiva.DeviceBatch(full.schema, cols, length)
+        outs = proj.evaluate_device(dbatch)
+        torch.cuda.synchronize()
+        want = oracle.project(exprs, full.slice(off, length))
+        for o, w in zip(outs, want):
+            assert_bit_exact(o.to_arrow(), w, f"offset {off}")
