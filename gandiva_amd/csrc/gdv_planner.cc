@@ -891,6 +891,24 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     }
     after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid", two);
   }
+  // Loads in flight: aim for >= 8 KiB of input values per wave tile (64 lanes x GDV_U rows x
+  // input bytes/row), within a budget of 512 input bytes per lane.  Wide plans (C2: 32 B/row,
+  // ten outputs) stay at 4 — measured optimum, more sub-tiles cost occupancy — narrow plans
+  // (C1: 12 B/row) go to 16 (+3 % measured).  Var-len plans keep 4: they prefetch string words.
+  if (std::getenv("GDV_U") == nullptr && !plan->has_varlen_output) {
+    int in_bytes = 0;
+    bool any_varlen = false;
+    for (size_t k = 0; k < cg.input_fields_.size(); k++) {
+      const DataType& t = schema[cg.input_fields_[k]].type;
+      any_varlen |= t.is_varlen();
+      if (cg.needs_values_[k]) in_bytes += std::max(1, t.byte_width());
+    }
+    if (!any_varlen && in_bytes > 0) {
+      int u = 4;
+      while (u < 16 && 64 * u * in_bytes < 8192 && 2 * u * in_bytes <= 512) u <<= 1;
+      plan->opts.subtiles = u;
+    }
+  }
   return Assemble(cg, plan, strings, accs, "", after_loop.str());
 }
 
