@@ -792,18 +792,30 @@ GDV_DEV gdv_uint64 gdv_raw_word_at(const gdv_str& s, gdv_int32 i) {
 GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
   return gdv_map8(gdv_raw_word_at(s, i), s.map);
 }
+// Copy with as few (scattered) store instructions as possible: whole words, then ONE
+// overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
+// 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
-  gdv_int32 i = 0;
-  for (; i + 8 <= s.len; i += 8) {
-    const gdv_uint64 w = gdv_word_at(s, i);
-    __builtin_memcpy(dst + i, &w, 8);
-  }
-  if (i < s.len) {
-    gdv_uint64 w = gdv_word_at(s, i);
-    gdv_int32 left = s.len - i;
-    if (left >= 4) { const gdv_uint32 x = (gdv_uint32)w; __builtin_memcpy(dst + i, &x, 4); w >>= 32; i += 4; left -= 4; }
-    if (left >= 2) { const gdv_uint16 x = (gdv_uint16)w; __builtin_memcpy(dst + i, &x, 2); w >>= 16; i += 2; left -= 2; }
-    if (left >= 1) dst[i] = (gdv_uint8)w;
+  if (s.len >= 8) {
+    gdv_int32 i = 0;
+    for (; i + 8 <= s.len; i += 8) {
+      const gdv_uint64 w = gdv_word_at(s, i);
+      __builtin_memcpy(dst + i, &w, 8);
+    }
+    if (i < s.len) {
+      const gdv_uint64 w = gdv_word_at(s, s.len - 8);
+      __builtin_memcpy(dst + s.len - 8, &w, 8);
+    }
+  } else if (s.len >= 4) {
+    const gdv_uint64 w = gdv_word_at(s, 0);
+    const gdv_uint32 lo = (gdv_uint32)w, hi = (gdv_uint32)(w >> (8 * (s.len - 4)));
+    __builtin_memcpy(dst, &lo, 4);
+    __builtin_memcpy(dst + s.len - 4, &hi, 4);
+  } else if (s.len > 0) {
+    const gdv_uint64 w = gdv_word_at(s, 0);
+    dst[0] = (gdv_uint8)w;
+    if (s.len > 1) dst[1] = (gdv_uint8)(w >> 8);
+    if (s.len > 2) dst[2] = (gdv_uint8)(w >> 16);
   }
 }
 GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }

@@ -764,8 +764,11 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
       s << "  gdv_uint64 sw" << k << "[GDV_U][GDV_NPRE];\n"
         << "  const gdv_uint8* slim" << k << " = sd" << k << " + A.in[" << k << "].bits.nwords;\n"
         << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
-        << "#pragma unroll\n    for (int j = 0; j < GDV_NPRE; j++) sw" << k
-        << "[u][j] = gdv_load8(sd" << k << " + oa" << k << "[u] + 8 * j, slim" << k << ");\n  }\n";
+        // lanes whose string ends before word j sit the load out: scattered 8-byte loads
+        // are priced per active lane in the texture addresser, not per instruction
+        << "#pragma unroll\n    for (int j = 0; j < GDV_NPRE; j++) sw" << k << "[u][j] = (8 * j < ob"
+        << k << "[u] - oa" << k << "[u]) ? gdv_load8(sd" << k << " + oa" << k << "[u] + 8 * j, slim"
+        << k << ") : 0ull;\n  }\n";
     }
   }
 

@@ -15,11 +15,17 @@
  *   - Arrow memory format [pinned]: LSB-first bitmaps (pyarrow/include/arrow/util/
  *     bit_util.h:173-175), ArrayData offset (array/data.h:88-90).
  *   - IEEE-754 / two's-complement wrap for arithmetic and compare [self-evident].
- * Pinned by golden vectors: the eight data-bearing tests of pyarrow/tests/test_gandiva.py
- * (tests/test_reference_kats.py runs them against this oracle AND the HIP path).
- * Everything else (hash, date/time, casts, divide-by-zero behaviour, 3-valued AND/OR with
- * null operands) is "parity unpinned": restated from memory of the reference, cross-checked
- * against pyarrow.compute where semantics coincide (tests/test_oracle_crosscheck.py).
+ * Pinned by golden vectors: all nine data-bearing tests of pyarrow/tests/test_gandiva.py
+ * (if/greater_than, add, less_than filter, IN over utf8/int32/int64, AND/OR, like '%spark%',
+ * filter->project with a null): tests/test_reference_kats.py runs them against this oracle
+ * AND the HIP path.
+ * PARITY UNPINNED (no reference implementation or vector exists in the container to compare
+ * with): hash32/hash64, date/time extraction and arithmetic, casts, divide-by-zero
+ * behaviour, 3-valued AND/OR with null operands, decimal128 result-type / rounding /
+ * overflow rules, substr / upper / trim / like-escape edge cases.  These are restated from
+ * memory of the reference lineage and cross-checked against INDEPENDENT CPU engines where
+ * semantics coincide — pyarrow.compute and Python's decimal module
+ * (tests/test_oracle_crosscheck.py, test_decimal.py, test_strings.py).
  *
  * Program format (whitespace separated, prefix order):
  *   F <col>                               field: column index
@@ -28,7 +34,9 @@
  *   I <ret_type> cond then else           if / else
  *   A <n> e...   |   O <n> e...           SQL AND / OR
  *   N <type> <n> <hex>... e               IN list over fixed-width values (bit images)
- * <type> = arrow type id (gandiva_amd.h gdv_type_id).
+ *   S <type> <is_null> <len> <hex|->      utf8 / binary literal
+ *   M <n> (<len> <hex|->)... e            IN list over strings
+ * <type> = arrow type id (gandiva_amd.h gdv_type_id), decimal128 as 23:precision:scale.
  */
 #include <math.h>
 #include <pthread.h>
