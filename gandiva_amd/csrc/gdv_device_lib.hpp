@@ -249,6 +249,25 @@ GDV_DEV gdv_int128 gdv_make_int128(gdv_uint64 hi, gdv_uint64 lo) {
   GDV_DEV gdv_##T least_##T##_##T(gdv_##T a, gdv_##T b) { return a < b ? a : b; }
 GDV_MINMAX(int32) GDV_MINMAX(int64) GDV_MINMAX(float32) GDV_MINMAX(float64)
 
+// ------------------------------------------------------------------ bitwise / boolean tests / nvl
+#define GDV_BITWISE(T)                                                                       \
+  GDV_DEV gdv_##T bitwise_and_##T##_##T(gdv_##T a, gdv_##T b) { return (gdv_##T)(a & b); }   \
+  GDV_DEV gdv_##T bitwise_or_##T##_##T(gdv_##T a, gdv_##T b) { return (gdv_##T)(a | b); }    \
+  GDV_DEV gdv_##T bitwise_xor_##T##_##T(gdv_##T a, gdv_##T b) { return (gdv_##T)(a ^ b); }   \
+  GDV_DEV gdv_##T bitwise_not_##T(gdv_##T a) { return (gdv_##T)(~a); }
+GDV_BITWISE(int32) GDV_BITWISE(int64) GDV_BITWISE(uint32) GDV_BITWISE(uint64)
+// null-aware boolean tests: never null themselves
+GDV_DEV bool istrue_boolean(bool v, bool valid) { return valid && v; }
+GDV_DEV bool isfalse_boolean(bool v, bool valid) { return valid && !v; }
+GDV_DEV bool isnottrue_boolean(bool v, bool valid) { return !(valid && v); }
+GDV_DEV bool isnotfalse_boolean(bool v, bool valid) { return !(valid && !v); }
+// nvl(a, b): a when a is valid, else b; null only when both are null
+template <typename T>
+GDV_DEV T gdv_nvl(T a, bool av, T b, bool bv, bool* out_valid) {
+  *out_valid = av || bv;
+  return av ? a : b;
+}
+
 // ------------------------------------------------------------------ casts
 GDV_DEV gdv_int64 castBIGINT_int32(gdv_int32 a) { return (gdv_int64)a; }
 GDV_DEV gdv_int32 castINT_int64(gdv_int64 a) { return (gdv_int32)(gdv_uint32)(gdv_uint64)a; }

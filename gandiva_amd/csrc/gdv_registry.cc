@@ -121,6 +121,17 @@ FunctionRegistry::FunctionRegistry() {
     add("isnumeric", {t}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
   }
 
+  // bitwise, boolean tests, nvl
+  for (auto& t : {int32(), int64(), uint32(), uint64()}) {
+    add("bitwise_and", {t, t}, t);
+    add("bitwise_or", {t, t}, t);
+    add("bitwise_xor", {t, t}, t);
+    add("bitwise_not", {t}, t);
+  }
+  for (const char* f : {"istrue", "isfalse", "isnottrue", "isnotfalse"})
+    add(f, {boolean()}, boolean(), NullPolicy::kNullNever);
+  for (auto& t : all_fixed) add("nvl", {t, t}, t, NullPolicy::kNullInternal, 0, "gdv_nvl");
+
   // casts
   add("castBIGINT", {int32()}, int64());
   add("castINT", {int64()}, int32());

@@ -697,6 +697,24 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       out->v[i].i = neg ? !r : r;
       out->valid[i] = 1;
     }
+  } else if (!strncmp(f, "bitwise_", 8)) {
+    for (int i = 0; i < cnt; i++) {
+      uint64_t x = a[0].v[i].u, y = n->nargs == 2 ? a[1].v[i].u : 0;
+      uint64_t r = !strcmp(f, "bitwise_and") ? (x & y) : !strcmp(f, "bitwise_or") ? (x | y)
+                 : !strcmp(f, "bitwise_xor") ? (x ^ y) : ~x;
+      out->v[i].i = wrap_int(t0, r);
+    }
+  } else if (!strcmp(f, "istrue") || !strcmp(f, "isfalse") || !strcmp(f, "isnottrue") || !strcmp(f, "isnotfalse")) {
+    for (int i = 0; i < cnt; i++) {
+      int t = a[0].valid[i] && a[0].v[i].i, fl = a[0].valid[i] && !a[0].v[i].i;
+      out->v[i].i = !strcmp(f, "istrue") ? t : !strcmp(f, "isfalse") ? fl : !strcmp(f, "isnottrue") ? !t : !fl;
+      out->valid[i] = 1;
+    }
+  } else if (!strcmp(f, "nvl")) {
+    for (int i = 0; i < cnt; i++) {
+      out->v[i] = a[0].valid[i] ? a[0].v[i] : a[1].v[i];
+      out->valid[i] = (uint8_t)(a[0].valid[i] || a[1].valid[i]);
+    }
   } else if (!strcmp(f, "negative") || !strcmp(f, "abs")) {
     int ab = f[0] == 'a';
     for (int i = 0; i < cnt; i++) {

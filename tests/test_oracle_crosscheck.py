@@ -191,3 +191,20 @@ def test_fast_path_agrees_with_generic_evaluator():
             oracle.force_generic(False)
         for f, s in zip(fast, slow):
             assert_bit_exact(f, s)
+
+
+def test_bitwise_istrue_nvl_match_arrow():
+    rng = np.random.default_rng(8)
+    n = 3000
+    x, y = random_array(rng, pa.int64(), n, 0.2), random_array(rng, pa.int64(), n, 0.2)
+    z = random_array(rng, pa.bool_(), n, 0.3)
+    batch = pa.RecordBatch.from_arrays([x, y, z], names=["x", "y", "z"])
+    b = gandiva.TreeExprBuilder()
+    fx, fy, fz = (b.make_field(batch.schema.field(i)) for i in range(3))
+    assert_bit_exact(_one(b.make_function("bitwise_and", [fx, fy], pa.int64()), pa.int64(), batch), pc.bit_wise_and(x, y))
+    assert_bit_exact(_one(b.make_function("bitwise_or", [fx, fy], pa.int64()), pa.int64(), batch), pc.bit_wise_or(x, y))
+    assert_bit_exact(_one(b.make_function("bitwise_xor", [fx, fy], pa.int64()), pa.int64(), batch), pc.bit_wise_xor(x, y))
+    assert_bit_exact(_one(b.make_function("bitwise_not", [fx], pa.int64()), pa.int64(), batch), pc.bit_wise_not(x))
+    assert_bit_exact(_one(b.make_function("istrue", [fz], pa.bool_()), pa.bool_(), batch), pc.fill_null(z, False))
+    assert_bit_exact(_one(b.make_function("isnotfalse", [fz], pa.bool_()), pa.bool_(), batch), pc.fill_null(z, True))
+    assert_bit_exact(_one(b.make_function("nvl", [fx, fy], pa.int64()), pa.int64(), batch), pc.coalesce(x, y))

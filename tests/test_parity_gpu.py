@@ -441,3 +441,25 @@ def test_device_path_with_array_offsets_and_misaligned_bitmaps():
         want = oracle.project(exprs, full.slice(off, length))
         for o, w in zip(outs, want):
             assert_bit_exact(o.to_arrow(), w, f"offset {off}")
+
+
+def test_bitwise_boolean_tests_and_nvl():
+    rng = np.random.default_rng(31)
+    n = 7001
+    batch = _batch(rng, [pa.int64(), pa.int64(), pa.uint32(), pa.uint32(), pa.bool_(), pa.float64(), pa.float64()],
+                   n, 0.3)
+    b = gandiva.TreeExprBuilder()
+    i1, i2, u1, u2, z, f1, f2 = (b.make_field(batch.schema.field(i)) for i in range(7))
+    exprs = []
+    for name in ("bitwise_and", "bitwise_or", "bitwise_xor"):
+        exprs.append(b.make_expression(b.make_function(name, [i1, i2], pa.int64()), pa.field(name, pa.int64())))
+        exprs.append(b.make_expression(b.make_function(name, [u1, u2], pa.uint32()), pa.field(name + "u", pa.uint32())))
+    exprs.append(b.make_expression(b.make_function("bitwise_not", [i1], pa.int64()), pa.field("not", pa.int64())))
+    for name in ("istrue", "isfalse", "isnottrue", "isnotfalse"):
+        exprs.append(b.make_expression(b.make_function(name, [z], pa.bool_()), pa.field(name, pa.bool_())))
+    exprs.append(b.make_expression(b.make_function("nvl", [f1, f2], pa.float64()), pa.field("nvl", pa.float64())))
+    exprs.append(b.make_expression(b.make_function("nvl", [i1, b.make_literal(-1, pa.int64())], pa.int64()),
+                                   pa.field("nvl_lit", pa.int64())))
+    exprs.append(b.make_expression(b.make_function("add", [b.make_function("nvl", [i1, i2], pa.int64()), i2],
+                                                   pa.int64()), pa.field("nvl_add", pa.int64())))
+    _check_project(exprs, batch)
