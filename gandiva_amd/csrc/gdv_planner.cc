@@ -20,11 +20,13 @@ CodegenOptions CodegenOptions::FromEnv() {
   }
   if (const char* s = std::getenv("GDV_WAVES")) o.waves = std::max(1, std::min(16, atoi(s)));
   if (const char* s = std::getenv("GDV_NT")) o.nontemporal = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
   return o;
 }
 
 std::string CodegenOptions::Key() const {
-  return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "");
+  return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
+         (nt_loads ? "ntl" : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -750,7 +752,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
           s << "    oa" << k << "[u] = live ? so" << k << "[row] : 0; ob" << k << "[u] = live ? so"
             << k << "[row + 1] : 0;\n";
       } else if (t.id != kBool && cg.needs_values_[k]) {
-        s << "    c" << k << "[u] = live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0;\n";
+        s << "    c" << k << "[u] = live ? " << (plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld") << "(in" << k
+          << ", row) : (" << t.CType() << ")0;\n";
       }
     }
   }

@@ -29,6 +29,8 @@ struct CodegenOptions {
   int subtiles = 4;        // 64-row sub-tiles each wavefront handles per tile (loads in flight)
   int waves = 4;           // wavefronts per workgroup
   bool nontemporal = true; // non-temporal stores for output value buffers
+  bool nt_loads = true;    // non-temporal loads of input value buffers: every value is read
+                           // exactly once (+3 % on C2, +7 % on C1, neutral on C3; GDV_NTLOAD=0)
   static CodegenOptions FromEnv();
   std::string Key() const;
 };
