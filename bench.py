@@ -166,7 +166,7 @@ def main():
 
     if args.workload == "c2":
         rows = args.rows or (1 << 28)
-        dbatch = W.c2_device_batch(rows)
+        dbatch = W.c2_device_batch(rows, seed_offset=1000 * rank)  # every rank: its own shard
         proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
         outs = proj.evaluate_device(dbatch)  # allocates + first touch
         bytes_per_row = W.C2_BYTES_PER_ROW

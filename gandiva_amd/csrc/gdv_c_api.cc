@@ -2,6 +2,8 @@
 #include "../../include/gandiva_amd.h"
 
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -73,6 +75,21 @@ std::vector<ColumnBuffers> ToColumns(const gdv_column_t* cols, int n) {
     v[i].offset = cols[i].offset;
   }
   return v;
+}
+
+// No C++ exception may cross the C boundary (std::bad_alloc from a vector, a std::string
+// length_error …): entry points that allocate run through this guard.
+template <typename F>
+int Guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return Fail(Status::OutOfMemory("host allocation failed"));
+  } catch (const std::exception& e) {
+    return Fail(Status::ExecutionError(std::string("internal error: ") + e.what()));
+  } catch (...) {
+    return Fail(Status::ExecutionError("internal error: unknown exception"));
+  }
 }
 
 bool ToSelectionMode(int m, SelectionMode* out) {
@@ -244,6 +261,7 @@ static bool CollectExprs(gdv_expression_t* const* exprs, int n, std::vector<Expr
 
 int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs,
                        int selection_mode, const gdv_config_t* config, gdv_projector_t** out) {
+  return Guarded([&]() -> int {
   if (!schema || !out) return Fail(Status::Invalid("null schema or output pointer"));
   std::vector<ExpressionPtr> ex;
   if (!CollectExprs(exprs, num_exprs, &ex)) return Fail(Status::Invalid("null expression"));
@@ -256,6 +274,7 @@ int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* expr
   if (!s.ok()) return Fail(s);
   *out = new gdv_projector{p};
   return GDV_OK;
+  });
 }
 int gdv_projector_num_outputs(const gdv_projector_t* p) { return p ? p->p->num_outputs() : 0; }
 gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i) {
@@ -280,6 +299,7 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
 int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
                            int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
                            int num_outs, int mem_kind, void* stream, uint32_t flags) {
+  return Guarded([&]() -> int {
   if (!p) return Fail(Status::Invalid("null projector"));
   if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
   if (!outs) return Fail(Status::Invalid("Output array vector cannot be null"));
@@ -304,6 +324,7 @@ int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv
                              static_cast<hipStream_t>(stream), flags);
   for (int i = 0; i < num_outs; i++) outs[i].data_size = o[i].data_size;  // var-len: bytes produced / needed
   return Check(st);
+  });
 }
 char* gdv_projector_dump_ir(const gdv_projector_t* p) { return p ? DupString(p->p->DumpIR()) : nullptr; }
 void gdv_projector_free(gdv_projector_t* p) { delete p; }
@@ -311,6 +332,7 @@ void gdv_projector_free(gdv_projector_t* p) { delete p; }
 // ---------------------------------------------------------------- filter
 int gdv_filter_make(const gdv_schema_t* schema, gdv_expression_t* condition,
                     const gdv_config_t* config, gdv_filter_t** out) {
+  return Guarded([&]() -> int {
   if (!schema || !out) return Fail(Status::Invalid("null schema or output pointer"));
   if (!condition || !condition->expr) return Fail(Status::Invalid("Condition cannot be null"));
   Configuration cfg;
@@ -320,10 +342,12 @@ int gdv_filter_make(const gdv_schema_t* schema, gdv_expression_t* condition,
   if (!s.ok()) return Fail(s);
   *out = new gdv_filter{f};
   return GDV_OK;
+  });
 }
 int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols,
                         int num_cols, int selection_mode, void* out_indices, int64_t max_slots,
                         int64_t* num_selected, int mem_kind, void* stream) {
+  return Guarded([&]() -> int {
   if (!f) return Fail(Status::Invalid("null filter"));
   if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
   SelectionMode mode;
@@ -332,6 +356,7 @@ int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_colum
   return Check(f->f->Evaluate(num_rows, c.data(), num_cols, mode, out_indices, max_slots,
                               num_selected, mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
                               static_cast<hipStream_t>(stream)));
+  });
 }
 char* gdv_filter_dump_ir(const gdv_filter_t* f) { return f ? DupString(f->f->DumpIR()) : nullptr; }
 void gdv_filter_free(gdv_filter_t* f) { delete f; }

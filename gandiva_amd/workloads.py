@@ -77,7 +77,7 @@ def c2_batch(n, seed_offset=0):
     return pa.RecordBatch.from_arrays(cols, schema=c2_schema())
 
 
-def c2_device_batch(n, device="cuda", chunk=1 << 24):
+def c2_device_batch(n, device="cuda", chunk=1 << 24, seed_offset=0):
     """C2 inputs generated directly in HBM (torch Philox RNG: same distributions as
     c2_batch, different stream — parity at full size is checked through properties, and
     bit-exactly against the oracle on c2_batch-sized prefixes copied back to the host)."""
@@ -86,7 +86,7 @@ def c2_device_batch(n, device="cuda", chunk=1 << 24):
     cols = []
     nbytes_valid = (n + 63) // 64 * 8
     for k in range(4):
-        g.manual_seed(42 + k)
+        g.manual_seed(42 + k + seed_offset)
         data = torch.empty(n, dtype=torch.float64, device=device)
         valid = torch.zeros(nbytes_valid, dtype=torch.uint8, device=device)
         for lo in range(0, n, chunk):
