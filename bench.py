@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
-    p.add_argument("--cpu-rows", type=int, default=1 << 24, help="rows of the cpu_baseline sample")
+    p.add_argument("--cpu-rows", type=int, default=1 << 26, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
@@ -58,7 +58,7 @@ def cpu_baseline_c2(rows):
         oracle.project(exprs, batch, threads=cores, out=outs)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
+        if el > 10.0 or reps >= 200:
             break
     return {
         "value": round(rows * reps / el / 1e6, 2),
