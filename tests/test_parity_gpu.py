@@ -463,3 +463,53 @@ def test_bitwise_boolean_tests_and_nvl():
     exprs.append(b.make_expression(b.make_function("add", [b.make_function("nvl", [i1, i2], pa.int64()), i2],
                                                    pa.int64()), pa.field("nvl_add", pa.int64())))
     _check_project(exprs, batch)
+
+
+def test_more_than_2_to_32_rows_device_resident():
+    """Maximum sizes: a batch of 2^32 + 4099 int8 rows (row indices need 64 bits).
+    Projection: add(a, b) wraps like two's complement, checked against torch on the GPU.
+    Filter: a > 100 with a uint64 selection vector — count, ascending order, and the head /
+    tail windows against torch.nonzero."""
+    import torch
+    n = (1 << 32) + 4099
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    a = torch.empty(n, dtype=torch.int8, device="cuda")
+    bcol = torch.empty(n, dtype=torch.int8, device="cuda")
+    chunk = 1 << 30
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        a[lo:hi] = torch.randint(-128, 128, (hi - lo,), dtype=torch.int8, device="cuda", generator=g)
+        bcol[lo:hi] = torch.randint(-128, 128, (hi - lo,), dtype=torch.int8, device="cuda", generator=g)
+    schema = pa.schema([pa.field("a", pa.int8()), pa.field("b", pa.int8())])
+    dbatch = gandiva.DeviceBatch(schema, [
+        gandiva.DeviceColumn(pa.int8(), n, None, a.view(torch.uint8)),
+        gandiva.DeviceColumn(pa.int8(), n, None, bcol.view(torch.uint8))], n)
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(schema.field(0)), b.make_field(schema.field(1))
+    proj = gandiva.make_projector(schema, [b.make_expression(b.make_function("add", [fa, fb], pa.int8()),
+                                                              pa.field("s", pa.int8()))], None)
+    out, = proj.evaluate_device(dbatch)
+    torch.cuda.synchronize()
+    got = out.data[:n].view(torch.int8)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        assert torch.equal(got[lo:hi], a[lo:hi] + bcol[lo:hi])
+    nb = (n + 7) // 8
+    assert bool((out.validity[:nb - 1] == 255).all()) and int(out.validity[nb - 1]) == (1 << (n % 8)) - 1
+    del out, got
+    cond = b.make_condition(b.make_function("greater_than", [fa, b.make_literal(100, pa.int8())], pa.bool_()))
+    flt = gandiva.make_filter(schema, cond)
+    idx = torch.empty(n, dtype=torch.int64, device="cuda")
+    sel = flt.evaluate_device(dbatch, "int64", out=idx)
+    k = sel.num_slots
+    want_count = sum(int((a[lo:min(n, lo + chunk)] > 100).sum()) for lo in range(0, n, chunk))
+    assert k == want_count
+    ids = idx[:k]
+    assert bool((ids[1:] > ids[:-1]).all())
+    head = torch.nonzero(a[:1 << 20] > 100).flatten()
+    assert torch.equal(ids[:head.numel()], head)
+    tail_lo = n - (1 << 20)
+    tail = torch.nonzero(a[tail_lo:] > 100).flatten() + tail_lo
+    assert torch.equal(ids[k - tail.numel():], tail)
+    assert int(ids[-1]) >= (1 << 32) - 4096  # indices really exceed 32 bits' reach
