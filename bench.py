@@ -153,10 +153,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: gandiva_amd has no CPU evaluation path")
-    torch.cuda.set_device(local_rank)
+    # GDV_BENCH_BACKEND=gloo lets the N>1 control flow (rendezvous, barrier, max-over-ranks
+    # aggregation) be exercised on a single-GPU box with several ranks sharing cuda:0; the
+    # driver's multi-GPU runs use the default, nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("GDV_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -240,8 +249,8 @@ def main():
     dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     mean_dev_ms = sum(dev_ms) / len(dev_ms)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    k = torch.tensor([mean_dev_ms], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+    k = torch.tensor([mean_dev_ms], dtype=torch.float64, device=reduce_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
@@ -287,7 +296,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": load_traffic(args.workload),
+                # PMC passes were taken at the BASELINE size: only quote them for that size
+                "traffic": load_traffic(args.workload) if not args.rows else None,
                 "kernel": kernel_desc,
                 "algorithmic_bytes_per_row": round(bytes_per_row, 3),
                 "kernel_ms": round(mean_dev_ms, 4),
