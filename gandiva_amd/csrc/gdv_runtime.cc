@@ -229,6 +229,16 @@ void Runtime::Free(void* ptr) {
   if (it == live_blocks_.end()) return;
   size_t sz = it->second;
   live_blocks_.erase(it);
+  // keep at most kPoolCapBytes of idle blocks (staging buffers of the host path can be tens
+  // of GB); beyond that, blocks go straight back to the driver
+  static const size_t cap = [] {
+    const char* e = std::getenv("GDV_POOL_CAP_MB");
+    return (e ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(16384)) << 20;
+  }();
+  if (cached_bytes_ + sz > cap) {
+    (void)hipFree(ptr);
+    return;
+  }
   free_blocks_.emplace(sz, ptr);
   cached_bytes_ += sz;
 }
