@@ -112,6 +112,16 @@ HostBitmap FoldBitmap(const void* ptr, int64_t size, int64_t bit_offset) {
 
 int64_t BytesForBits(int64_t bits) { return (bits + 7) / 8; }
 
+// Error paths must not hand staging blocks back to the pool while copies or kernels that
+// use them are still queued: declared AFTER the Staging object, this drains the stream first.
+struct StreamDrain {
+  hipStream_t stream;
+  bool armed;
+  ~StreamDrain() {
+    if (armed) (void)hipStreamSynchronize(stream);
+  }
+};
+
 struct Staging {
   std::deque<DeviceBuffer> buffers;  // deque: references stay valid across Add()
   DeviceBuffer& Add() {
@@ -302,6 +312,8 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
 
   ArgBlock args(plan_.layout);
   Staging st;
+  DeviceBuffer err;
+  StreamDrain drain{stream, mem == MemKind::kHost};  // declared last: drains first
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
 
@@ -363,7 +375,6 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (t.is_varlen()) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_offs[e], 0, 4, stream));
   }
 
-  DeviceBuffer err;
   if (plan_.can_raise) {
     GDV_RETURN_NOT_OK(err.Allocate(8));
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
@@ -488,12 +499,13 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
 
   ArgBlock args(plan_.layout);
   Staging st;
+  DeviceBuffer mask, counts, offsets, chunk_sums, total, err, staged_out;
+  StreamDrain drain{stream, true};  // declared last: drains before any pooled block is freed
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 
   const int64_t nwords = (num_rows + 63) / 64;
   const int64_t m = (nwords + plan_.opts.subtiles - 1) / plan_.opts.subtiles;  // wave tiles
-  DeviceBuffer mask, counts, offsets, chunk_sums, total, err;
   GDV_RETURN_NOT_OK(mask.Allocate(nwords * 8));
   GDV_RETURN_NOT_OK(counts.Allocate(m * 4 + 64));
   GDV_RETURN_NOT_OK(offsets.Allocate(m * 8));
@@ -512,7 +524,6 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>(), m, chunk_sums.as<uint64_t>(),
                                           offsets.as<uint64_t>(), total.as<uint64_t>(), stream));
   void* dev_out = out_indices;
-  DeviceBuffer staged_out;
   if (mem == MemKind::kHost) {
     GDV_RETURN_NOT_OK(staged_out.Allocate(num_rows * w));
     dev_out = staged_out.get();
