@@ -604,6 +604,16 @@ GDV_DEV gdv_u256 gdv_mul_128x128(gdv_uint128 a, gdv_uint128 b) {
   r.w[3] = (gdv_uint64)((hi >> 64) + (p11 >> 64));
   return r;
 }
+GDV_DEV gdv_u256 gdv_mul_128x64(gdv_uint128 a, gdv_uint64 b) {
+  const gdv_uint128 p0 = (gdv_uint128)(gdv_uint64)a * b, p1 = (gdv_uint128)(gdv_uint64)(a >> 64) * b;
+  gdv_u256 r;
+  r.w[0] = (gdv_uint64)p0;
+  const gdv_uint128 mid = (p0 >> 64) + (gdv_uint64)p1;
+  r.w[1] = (gdv_uint64)mid;
+  r.w[2] = (gdv_uint64)((mid >> 64) + (p1 >> 64));
+  r.w[3] = 0;
+  return r;
+}
 // in-place divide by a 64-bit divisor, returns the remainder
 GDV_DEV gdv_uint64 gdv_divmod_u256_u64(gdv_u256& v, gdv_uint64 d) {
   gdv_uint128 rem = 0;
@@ -630,11 +640,20 @@ GDV_DEV gdv_int128 subtract_decimal128_decimal128(gdv_int128 x, int xp, int xs, 
 GDV_DEV gdv_int128 multiply_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,
                                                   int ys, int op, int os) {
   const int delta = xs + ys - os;  // digits the result-type rule cut from the scale
-  if (xp + yp <= 38 && delta == 0) return x * y;  // cannot overflow 38 digits
+  // Everything below is decided from the operand PRECISIONS, i.e. at compile time (they are
+  // literals in the generated kernel): no per-row branch is added.
+  if (xp + yp <= 38 && delta == 0) {  // cannot overflow 38 digits
+    // <= 18 digits fits int64 by type: one signed 64x64->128 multiply instead of 128x128
+    if (xp <= 18 && yp <= 18) return (gdv_int128)(gdv_int64)x * (gdv_int128)(gdv_int64)y;
+    return x * y;
+  }
   const bool neg = (x < 0) != (y < 0);
   const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
   const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
-  gdv_u256 p = gdv_mul_128x128(ax, ay);
+  // a factor of <= 18 digits has a zero high word: half of the partial products vanish
+  gdv_u256 p = yp <= 18   ? gdv_mul_128x64(ax, (gdv_uint64)ay)
+               : xp <= 18 ? gdv_mul_128x64(ay, (gdv_uint64)ax)
+                          : gdv_mul_128x128(ax, ay);
   // divide by 10^delta in chunks of <= 10^18 (least significant digits first).  The last
   // chunk removed holds the most significant removed digits and alone decides the rounding:
   // 2*R >= 10^delta  <=>  2*last_rem >= last_div  (last_div is even, so lower chunks can
