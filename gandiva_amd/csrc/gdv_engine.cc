@@ -1,6 +1,7 @@
 #include "gdv_engine.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -120,6 +121,43 @@ struct StreamDrain {
   ~StreamDrain() {
     if (armed) (void)hipStreamSynchronize(stream);
   }
+};
+
+// GDV_TRACE=1: one line per Evaluate on stderr (kind, kernel, rows, device time between two
+// HIP events on the launch stream, rows/s).  The reference has no tracing of its own
+// (SURVEY.md §5); this is the hook its micro-benchmarks' std::chrono timers stood in for.
+// Tracing synchronises the stream, so it also serialises asynchronous evaluations.
+class EvalTrace {
+ public:
+  EvalTrace(const char* kind, const std::string& kernel, int64_t rows, hipStream_t stream)
+      : kind_(kind), kernel_(kernel), rows_(rows), stream_(stream) {
+    static const bool on = std::getenv("GDV_TRACE") != nullptr;
+    on_ = on;
+    if (on_ && hipEventCreate(&t0_) == hipSuccess && hipEventCreate(&t1_) == hipSuccess) {
+      (void)hipEventRecord(t0_, stream_);
+    } else {
+      on_ = false;
+    }
+  }
+  ~EvalTrace() {
+    if (!on_) return;
+    (void)hipEventRecord(t1_, stream_);
+    (void)hipEventSynchronize(t1_);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, t0_, t1_);
+    fprintf(stderr, "[gdv] %s %s rows=%lld device_ms=%.4f Mrows/s=%.1f\n", kind_, kernel_.c_str(),
+            static_cast<long long>(rows_), ms, ms > 0 ? rows_ / (ms * 1e3) : 0.0);
+    (void)hipEventDestroy(t0_);
+    (void)hipEventDestroy(t1_);
+  }
+
+ private:
+  const char* kind_;
+  std::string kernel_;
+  int64_t rows_;
+  hipStream_t stream_;
+  bool on_ = false;
+  hipEvent_t t0_ = nullptr, t1_ = nullptr;
 };
 
 struct Staging {
@@ -382,6 +420,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
 
   const int64_t grid = GridFor(plan_, out_rows);
+  EvalTrace trace("project", plan_.kernel_name, out_rows, stream);
   args.Set64(ArgLayout::kOffAux0, 0);
   if (out_rows > 0) {
     GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
@@ -519,6 +558,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     args.SetPtr(ArgLayout::kOffErr, err.get());
   }
 
+  EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
   GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, num_rows), plan_.opts.waves * 64,
                               args.data(), args.size(), stream));
   GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>(), m, chunk_sums.as<uint64_t>(),

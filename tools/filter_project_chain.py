@@ -1,0 +1,32 @@
+"""Filter -> SelectionVector -> Projector chain (pyarrow/tests/test_gandiva.py:329-373 shape) at
+C3 scale, device-resident: time of each stage."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pyarrow as pa
+import gandiva_amd as gandiva
+from gandiva_amd import workloads as W
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
+db = W.c3_device_batch(n)
+flt = gandiva.make_filter(W.c3_schema(), W.c3_condition())
+b = gandiva.TreeExprBuilder()
+a, c = (b.make_field(W.c3_schema().field(i)) for i in range(2))
+expr = b.make_expression(b.make_function("add", [a, c], pa.int64()), pa.field("s", pa.int64()))
+proj = gandiva.make_projector(W.c3_schema(), [expr], None, "UINT32")
+out = torch.empty(n, dtype=torch.int32, device="cuda")
+sel = flt.evaluate_device(db, "int32", out=out)
+outs = proj.evaluate_device(db, selection=sel)
+torch.cuda.synchronize()
+for name, fn in (("filter", lambda: flt.evaluate_device(db, "int32", out=out)),
+                 ("project(selection)", lambda: proj.evaluate_device(db, selection=sel, outputs=outs))):
+    t = time.perf_counter()
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / 5 * 1e3
+    print(f"{name:20s} {ms:7.3f} ms   selected {sel.num_slots} of {n}")
+k = sel.num_slots
+want = (db.columns[0].data.view(torch.int64) + db.columns[1].data.view(torch.int64))[out[:k].long()]
+assert torch.equal(outs[0].data[:8 * k].view(torch.int64), want)
+print("gather result verified against torch")
