@@ -677,6 +677,77 @@ GDV_DEV gdv_int128 multiply_decimal128_decimal128(gdv_int128 x, int xp, int xs, 
   return neg ? -(gdv_int128)mag : (gdv_int128)mag;
 }
 
+// ---- 256-bit helpers for divide / mod: binary long division (256 shift-subtract steps).
+// Decimal division is expected to be slow; it is exact.
+GDV_DEV int gdv_u256_cmp(const gdv_u256& a, const gdv_u256& b) {
+  for (int i = 3; i >= 0; i--)
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+  return 0;
+}
+GDV_DEV void gdv_u256_sub(gdv_u256& a, const gdv_u256& b) {  // a -= b (a >= b)
+  gdv_uint64 borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    const gdv_uint128 d = (gdv_uint128)a.w[i] - b.w[i] - borrow;
+    a.w[i] = (gdv_uint64)d;
+    borrow = (gdv_uint64)(d >> 64) & 1;
+  }
+}
+GDV_DEV void gdv_u256_shl1(gdv_u256& a, gdv_uint64 in_bit) {
+  for (int i = 3; i > 0; i--) a.w[i] = (a.w[i] << 1) | (a.w[i - 1] >> 63);
+  a.w[0] = (a.w[0] << 1) | in_bit;
+}
+GDV_DEV bool gdv_u256_is_zero(const gdv_u256& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+GDV_DEV void gdv_u256_divmod(const gdv_u256& num, const gdv_u256& den, gdv_u256* q, gdv_u256* r) {
+  gdv_u256 quo = {{0, 0, 0, 0}}, rem = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; bit--) {
+    gdv_u256_shl1(rem, (num.w[bit >> 6] >> (bit & 63)) & 1ull);
+    gdv_u256_shl1(quo, 0);
+    if (gdv_u256_cmp(rem, den) >= 0) {
+      gdv_u256_sub(rem, den);
+      quo.w[0] |= 1ull;
+    }
+  }
+  *q = quo;
+  *r = rem;
+}
+GDV_DEV gdv_u256 gdv_u256_from_u128(gdv_uint128 v) {
+  gdv_u256 r = {{(gdv_uint64)v, (gdv_uint64)(v >> 64), 0, 0}};
+  return r;
+}
+GDV_DEV gdv_int128 gdv_dec_from_mag(const gdv_u256& mag, bool neg) {  // 0 when it needs > 38 digits
+  if (mag.w[3] != 0 || mag.w[2] != 0) return 0;
+  const gdv_uint128 m = ((gdv_uint128)mag.w[1] << 64) | mag.w[0];
+  if (m > (gdv_uint128)gdv_dec_max38()) return 0;
+  return neg ? -(gdv_int128)m : (gdv_int128)m;
+}
+// x / y at the result scale `os`: round_half_away(x * 10^(os - xs + ys) / y).  y == 0 raises.
+GDV_DEV gdv_int128 divide_decimal128_decimal128(gdv_ctx ctx, gdv_int128 x, int xp, int xs, gdv_int128 y,
+                                                int yp, int ys, int op, int os) {
+  if (y == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }
+  const int delta = os - xs + ys;  // >= 0 for every result type the rules produce
+  const bool neg = (x < 0) != (y < 0);
+  const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  gdv_u256 num = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(delta > 0 ? delta : 0));
+  gdv_u256 den = gdv_u256_from_u128(ay), q, r;
+  gdv_u256_divmod(num, den, &q, &r);
+  gdv_u256_shl1(r, 0);                       // 2 * remainder (den < 2^127, no overflow)
+  if (gdv_u256_cmp(r, den) >= 0) { for (int i = 0; i < 4; i++) if (++q.w[i] != 0) break; }
+  return gdv_dec_from_mag(q, neg);
+}
+// x mod y at scale max(xs, ys), sign of the dividend.  y == 0 raises.
+GDV_DEV gdv_int128 mod_decimal128_decimal128(gdv_ctx ctx, gdv_int128 x, int xp, int xs, gdv_int128 y,
+                                             int yp, int ys, int op, int os) {
+  if (y == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }
+  const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  gdv_u256 a = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(ys > xs ? ys - xs : 0));
+  gdv_u256 b = gdv_mul_128x128(ay, (gdv_uint128)gdv_pow10_128(xs > ys ? xs - ys : 0));
+  gdv_u256 q, r;
+  gdv_u256_divmod(a, b, &q, &r);
+  return gdv_dec_from_mag(r, x < 0);
+}
+
 // comparisons bring both sides to the larger scale (exact: |v| < 10^38 and the scale
 // difference keeps 10^38 * 10^diff inside 256 bits only for small diffs, so compare via
 // 256-bit products when the rescale could overflow 128 bits)

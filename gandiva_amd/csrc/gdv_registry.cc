@@ -216,6 +216,8 @@ FunctionRegistry::FunctionRegistry() {
     const DataType dec = decimal128(38, 0);  // enumerated like the reference's decimal128()
     for (const char* f : {"add", "subtract", "multiply"})
       add(f, {dec, dec}, dec, NullPolicy::kNullIfNull, kDecimalResult | kDecimalArgs);
+    for (const char* f : {"divide", "mod"})
+      add(f, {dec, dec}, dec, NullPolicy::kNullIfNull, kDecimalResult | kDecimalArgs | kNeedsContext);
     for (const char* f : {"equal", "not_equal", "less_than", "less_than_or_equal_to", "greater_than",
                           "greater_than_or_equal_to"})
       add(f, {dec, dec}, boolean(), NullPolicy::kNullIfNull, kDecimalArgs);

@@ -538,6 +538,44 @@ static i128 dec_add(i128 x, int xs, i128 y, int ys, int os) {
 static i128 dec_mul(i128 x, int xs, i128 y, int ys, int os) {
   return dec_finish(u256_mul(mag128(x), mag128(y)), (x < 0) != (y < 0), xs + ys - os);
 }
+/* 256-bit / 256-bit by schoolbook restoring division, one bit at a time */
+static void u256_divmod(const u256* num, const u256* den, u256* q, u256* r) {
+  u256 quo = {{0, 0, 0, 0}}, rem = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; bit--) {
+    for (int i = 3; i > 0; i--) rem.w[i] = (rem.w[i] << 1) | (rem.w[i - 1] >> 63);
+    rem.w[0] = (rem.w[0] << 1) | ((num->w[bit >> 6] >> (bit & 63)) & 1);
+    for (int i = 3; i > 0; i--) quo.w[i] = (quo.w[i] << 1) | (quo.w[i - 1] >> 63);
+    quo.w[0] <<= 1;
+    if (u256_cmp(&rem, den) >= 0) {
+      uint64_t borrow = 0;
+      for (int i = 0; i < 4; i++) {
+        u128 cur = (u128)rem.w[i] - den->w[i] - borrow;
+        rem.w[i] = (uint64_t)cur;
+        borrow = (uint64_t)((cur >> 64) & 1);
+      }
+      quo.w[0] |= 1;
+    }
+  }
+  *q = quo; *r = rem;
+}
+static i128 dec_div(i128 x, int xs, i128 y, int ys, int os) {
+  u256 num = u256_from(mag128(x)), den = u256_from(mag128(y)), q, r;
+  for (int k = 0; k < os - xs + ys; k++) u256_mul10(&num);
+  u256_divmod(&num, &den, &q, &r);
+  /* round half away from zero: 2 * r >= den */
+  u256 twice = r;
+  for (int i = 3; i > 0; i--) twice.w[i] = (twice.w[i] << 1) | (twice.w[i - 1] >> 63);
+  twice.w[0] <<= 1;
+  if (u256_cmp(&twice, &den) >= 0) u256_inc(&q);
+  return dec_finish(q, (x < 0) != (y < 0), 0);
+}
+static i128 dec_mod(i128 x, int xs, i128 y, int ys) {
+  u256 a = u256_from(mag128(x)), b = u256_from(mag128(y)), q, r;
+  for (int k = xs; k < ys; k++) u256_mul10(&a);
+  for (int k = ys; k < xs; k++) u256_mul10(&b);
+  u256_divmod(&a, &b, &q, &r);
+  return dec_finish(r, x < 0, 0);
+}
 static int dec_cmp(i128 x, int xs, i128 y, int ys) {
   int xn = x < 0, yn = y < 0;
   if (xn != yn) return xn ? -1 : 1;
@@ -612,6 +650,12 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       if (!strcmp(f, "add")) out->v[i].q = dec_add(x, xs, y, ys, n->scale);
       else if (!strcmp(f, "subtract")) out->v[i].q = dec_add(x, xs, -y, ys, n->scale);
       else if (!strcmp(f, "multiply")) out->v[i].q = dec_mul(x, xs, y, ys, n->scale);
+      else if (!strcmp(f, "divide") || !strcmp(f, "mod")) {
+        int live = out->valid[i] && (!active || active[i]);
+        if (!live) { out->v[i].q = 0; continue; }
+        if (y == 0) { c->err |= 1; out->v[i].q = 0; continue; }
+        out->v[i].q = f[0] == 'd' ? dec_div(x, xs, y, ys, n->scale) : dec_mod(x, xs, y, ys);
+      }
       else if ((op = cmp_op(f)) >= 0) { int cc = dec_cmp(x, xs, y, ys); out->v[i].i = CMP(op, cc, 0); }
       else if (!strcmp(f, "negative")) out->v[i].q = -x;
       else if (!strcmp(f, "abs")) out->v[i].q = x < 0 ? -x : x;

@@ -34,8 +34,12 @@ def _result_type(op, a, b):
     p1, s1, p2, s2 = a.precision, a.scale, b.precision, b.scale
     if op in ("add", "subtract"):
         s = max(s1, s2); p = max(p1 - s1, p2 - s2) + s + 1
-    else:
+    elif op == "multiply":
         s = s1 + s2; p = p1 + p2 + 1
+    elif op == "divide":
+        s = max(6, s1 + p2 + 1); p = p1 - s1 + s2 + s
+    else:  # mod
+        s = max(s1, s2); p = min(p1 - s1, p2 - s2) + s
     if p > 38:
         delta = p - 38
         s = max(s - delta, min(s, 6)); p = 38
@@ -102,6 +106,66 @@ def test_oracle_c4_matches_arrow_and_python():
     assert out[2].equals(days)
 
 
+def _nonzero(arr):
+    one = decimal.Decimal(1).scaleb(-arr.type.scale)
+    return pa.array([one if v is not None and v == 0 else v for v in arr.to_pylist()], type=arr.type)
+
+
+def _python_divmod_expected(op, xs, ys, rt):
+    q = decimal.Decimal(1).scaleb(-rt.scale)
+    lim = decimal.Decimal(10) ** (38 - rt.scale)
+    out = []
+    for x, y in zip(xs, ys):
+        if x is None or y is None:
+            out.append(None); continue
+        if op == "divide":
+            v = CTX.divide(x, y)
+            # CTX.divide is already rounded to 100 digits: redo exactly with integers
+            sx, sy = -x.as_tuple().exponent, -y.as_tuple().exponent
+            ix, iy = int(x.scaleb(sx)), int(y.scaleb(sy))
+            num = abs(ix) * 10 ** (rt.scale - sx + sy)
+            quo, rem = divmod(num, abs(iy))
+            if 2 * rem >= abs(iy):
+                quo += 1
+            v = decimal.Decimal(quo if (ix < 0) == (iy < 0) else -quo).scaleb(-rt.scale, CTX)
+        else:
+            v = CTX.remainder(x, y)          # sign of the dividend, like C
+            v = v.quantize(q, context=CTX)
+        out.append(decimal.Decimal(0).quantize(q) if abs(v) >= lim else v)
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[2]}")
+def test_oracle_divide_mod_match_python(case):
+    ta, da, tb, db = case
+    rng = np.random.default_rng(da * 100 + db + 7)
+    n = 400
+    a, bcol = _dec_array(rng, ta, n, da), _nonzero(_dec_array(rng, tb, n, db))
+    batch = pa.RecordBatch.from_arrays([a, bcol], names=["a", "b"])
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    for op in ("divide", "mod"):
+        rt = _result_type(op, ta, tb)
+        got = oracle.project_one(b.make_function(op, [fa, fb], rt), rt, batch)
+        want = _python_divmod_expected(op, a.to_pylist(), bcol.to_pylist(), rt)
+        assert got.to_pylist() == want, f"{op} {ta} {tb} -> {rt}"
+
+
+def test_oracle_decimal_divide_by_zero_raises():
+    t = pa.decimal128(10, 2)
+    batch = pa.RecordBatch.from_arrays(
+        [pa.array([decimal.Decimal("1.00"), None], type=t), pa.array([decimal.Decimal("0.00"), decimal.Decimal("0.00")], type=t)],
+        names=["a", "b"])
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    rt = _result_type("divide", t, t)
+    with pytest.raises(Exception, match="divide by zero"):
+        oracle.project_one(b.make_function("divide", [fa, fb], rt), rt, batch)
+    # a null dividend over a zero divisor is a null row, not an error
+    ok = oracle.project_one(b.make_function("divide", [fa, fb], rt), rt, batch.slice(1))
+    assert ok.to_pylist() == [None]
+
+
 # ------------------------------------------------------------------ GPU parity
 
 @pytest.mark.gpu
@@ -144,3 +208,44 @@ def test_hip_decimal_ops_match_oracle(case):
     got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
     for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
         assert_bit_exact(g, w, str(e))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}x{c[2]}")
+def test_hip_decimal_divide_mod_match_oracle(case):
+    ta, da, tb, db = case
+    rng = np.random.default_rng(da * 100 + db + 9)
+    n = 3000
+    a, bcol = _dec_array(rng, ta, n, da), _nonzero(_dec_array(rng, tb, n, db))
+    batch = pa.RecordBatch.from_arrays([a, bcol], names=["a", "b"])
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = []
+    for op in ("divide", "mod"):
+        rt = _result_type(op, ta, tb)
+        exprs.append(b.make_expression(b.make_function(op, [fa, fb], rt), pa.field(op, rt)))
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        assert_bit_exact(g, w, str(e))
+    # and against exact integer arithmetic
+    for g, e, op in zip(got, exprs, ("divide", "mod")):
+        assert g.to_pylist() == _python_divmod_expected(op, a.to_pylist(), bcol.to_pylist(), g.type), op
+
+
+@pytest.mark.gpu
+def test_hip_decimal_divide_by_zero():
+    t = pa.decimal128(10, 2)
+    D = decimal.Decimal
+    batch = pa.RecordBatch.from_arrays(
+        [pa.array([D("1.00"), None, D("3.00")], type=t), pa.array([D("0.00"), D("0.00"), D("2.00")], type=t)],
+        names=["a", "b"])
+    b = gandiva.TreeExprBuilder()
+    fa, fb = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    for op in ("divide", "mod"):
+        rt = _result_type(op, t, t)
+        p = gandiva.make_projector(batch.schema, [b.make_expression(b.make_function(op, [fa, fb], rt), pa.field("r", rt))], None)
+        with pytest.raises(Exception, match="divide by zero"):
+            p.evaluate(batch)
+        got, = p.evaluate(batch.slice(1))
+        want = [None, D("1.50000000000000") if op == "divide" else D("1.00")]
+        assert got.to_pylist() == [None if w is None else w.quantize(D(1).scaleb(-rt.scale)) for w in want]
