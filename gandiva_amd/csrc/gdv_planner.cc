@@ -232,6 +232,12 @@ class CodeGen {
     return "(" + a + " && " + b + ")";
   }
 
+  // same, spelled out: never the empty string (for use as a full expression)
+  static std::string AndFull(const std::string& a, const std::string& b) {
+    std::string r = AndExpr(a, b);
+    return r.empty() ? "true" : r;
+  }
+
   // per-lane validity of a value ("true" when it can never be null)
   std::string LaneValid(const Val& val) {
     std::string cols;
@@ -485,7 +491,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       Val c, t, e;
       GDV_RETURN_NOT_OK(Gen(*n.condition(), active, &c));
       // a null condition selects the else branch
-      std::string take = Tmp("bool", AndExpr(LaneValid(c), c.v));
+      std::string take = Tmp("bool", AndFull(LaneValid(c), c.v));
       GDV_RETURN_NOT_OK(Gen(*n.then_node(), AndExpr(active, take), &t));
       GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
       out->type = n.return_type();
@@ -512,7 +518,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         Val c;
         GDV_RETURN_NOT_OK(Gen(*child, live_path, &c));
         std::string cvalid = LaneValid(c);
-        std::string hit = AndExpr(cvalid, is_and ? "!" + c.v : c.v);
+        std::string hit = AndFull(cvalid, is_and ? "!" + c.v : c.v);
         hit = Tmp("bool", hit);
         decided = decided.empty() ? hit : Tmp("bool", "(" + decided + " || " + hit + ")");
         all_valid = AndExpr(all_valid, cvalid);
