@@ -90,9 +90,42 @@ PROTOTYPES = [
     ("gdv_device_synchronize", C.c_int, []),
     ("gdv_projector_evaluate_device_array", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_uint32]),
     ("gdv_filter_evaluate_device_array", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
+    ("gdv_projector_evaluate_export", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), _P, _P, _P]),
     ("gdv_precompile_projector", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_precompile_filter", C.c_int, [_P, _P]),
 ]
+
+
+
+# ABI-stable structs of the Arrow C data / C device data interfaces (arrow/c/abi.h)
+class ArrowArray(C.Structure):
+    pass
+
+
+ArrowArray._fields_ = [
+    ("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64),
+    ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+    ("buffers", C.POINTER(C.c_void_p)), ("children", C.POINTER(C.POINTER(ArrowArray))),
+    ("dictionary", C.POINTER(ArrowArray)), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowDeviceArray(C.Structure):
+    _fields_ = [("array", ArrowArray), ("device_id", C.c_int64), ("device_type", C.c_int32),
+                ("sync_event", C.c_void_p), ("reserved", C.c_int64 * 3)]
+
+
+class ArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p),
+                ("flags", C.c_int64), ("n_children", C.c_int64), ("children", C.c_void_p),
+                ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+def release_c_struct(struct):
+    """Calls the release callback of an ArrowArray / ArrowSchema / ArrowDeviceArray, if set."""
+    target = struct.array if isinstance(struct, ArrowDeviceArray) else struct
+    if target.release:
+        C.CFUNCTYPE(None, C.c_void_p)(target.release)(C.addressof(target))
+
 
 _lib = None
 

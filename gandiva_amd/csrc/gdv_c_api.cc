@@ -1,7 +1,10 @@
 // extern "C" boundary (include/gandiva_amd.h) over the C++ core.
 #include "../../include/gandiva_amd.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <exception>
 #include <new>
 #include <string>
@@ -14,7 +17,10 @@ using namespace gdv;
 struct gdv_schema { Schema fields; };
 struct gdv_node { NodePtr node; };
 struct gdv_expression { ExpressionPtr expr; };
-struct gdv_projector { std::shared_ptr<Projector> p; };
+struct gdv_projector {
+  std::shared_ptr<Projector> p;
+  std::vector<std::string> output_names;  // result field names, for the C data export
+};
 struct gdv_filter { std::shared_ptr<Filter> f; };
 
 namespace {
@@ -272,7 +278,9 @@ int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* expr
   std::shared_ptr<Projector> p;
   Status s = Projector::Make(schema->fields, ex, mode, cfg, &p);
   if (!s.ok()) return Fail(s);
-  *out = new gdv_projector{p};
+  std::vector<std::string> names;
+  for (auto& e : ex) names.push_back(e->result().name);
+  *out = new gdv_projector{p, std::move(names)};
   return GDV_OK;
   });
 }
@@ -506,6 +514,233 @@ int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const ArrowDeviceArr
   if (!st.ok()) return Fail(st);
   return Check(f->f->Evaluate(rows, cols.data(), static_cast<int>(cols.size()), mode, out_indices,
                               max_slots, num_selected, mem, static_cast<hipStream_t>(stream)));
+}
+
+// ---------------------------------------------------------------- C device data export
+namespace {
+
+// Buffers of one exported batch: owned jointly by the parent array and every child (a
+// consumer may move children out and release them on their own).
+struct ExportBlock {
+  MemKind mem = MemKind::kHost;
+  std::vector<void*> bufs;
+  hipEvent_t event = nullptr;
+  ~ExportBlock() {
+    for (void* b : bufs) {
+      if (mem == MemKind::kDevice) Runtime::Get().Free(b); else std::free(b);
+    }
+    if (event != nullptr) (void)hipEventDestroy(event);
+  }
+  Status Allocate(int64_t bytes, void** out) {
+    const size_t padded = static_cast<size_t>((std::max<int64_t>(bytes, 1) + 63) / 64 * 64);
+    if (mem == MemKind::kDevice) {
+      GDV_RETURN_NOT_OK(Runtime::Get().Alloc(padded, out));
+    } else {
+      *out = std::aligned_alloc(64, padded);
+      if (*out == nullptr) return Status::OutOfMemory("host allocation of " + std::to_string(padded) + " bytes failed");
+    }
+    bufs.push_back(*out);
+    return Status::OK();
+  }
+  void Drop(void* b) {  // give one buffer back early (var-len data regrown)
+    for (auto it = bufs.begin(); it != bufs.end(); ++it)
+      if (*it == b) { bufs.erase(it); break; }
+    if (mem == MemKind::kDevice) Runtime::Get().Free(b); else std::free(b);
+  }
+};
+
+struct ExportNode {  // private_data of an exported ArrowArray
+  std::shared_ptr<ExportBlock> block;
+  const void* buffers[3] = {nullptr, nullptr, nullptr};
+  std::vector<ArrowArray*> children;
+};
+
+void ReleaseExportedArray(ArrowArray* a) {
+  if (a == nullptr || a->release == nullptr) return;
+  auto* node = static_cast<ExportNode*>(a->private_data);
+  for (ArrowArray* c : node->children) {
+    if (c->release != nullptr) c->release(c);
+    delete c;
+  }
+  delete node;
+  a->release = nullptr;
+}
+
+struct SchemaNode {  // private_data of an exported ArrowSchema
+  std::string format, name;
+  std::vector<ArrowSchema*> children;
+};
+
+void ReleaseExportedSchema(ArrowSchema* s) {
+  if (s == nullptr || s->release == nullptr) return;
+  auto* node = static_cast<SchemaNode*>(s->private_data);
+  for (ArrowSchema* c : node->children) {
+    if (c->release != nullptr) c->release(c);
+    delete c;
+  }
+  delete node;
+  s->release = nullptr;
+}
+
+// Arrow C data interface format string (pyarrow/include/arrow/c/abi.h; format spec §"Data
+// type description")
+std::string FormatOf(const DataType& t) {
+  static const char* const units = "smun";
+  switch (t.id) {
+    case kBool: return "b";
+    case kInt8: return "c";
+    case kUInt8: return "C";
+    case kInt16: return "s";
+    case kUInt16: return "S";
+    case kInt32: return "i";
+    case kUInt32: return "I";
+    case kInt64: return "l";
+    case kUInt64: return "L";
+    case kFloat: return "f";
+    case kDouble: return "g";
+    case kString: return "u";
+    case kBinary: return "z";
+    case kDate32: return "tdD";
+    case kDate64: return "tdm";
+    case kTimestamp: return std::string("ts") + units[t.precision & 3] + ":";
+    case kTime32: return std::string("tt") + units[t.precision & 3];
+    case kTime64: return std::string("tt") + units[t.precision & 3];
+    case kDecimal128: return "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale);
+    default: return "n";
+  }
+}
+
+void FillSchema(ArrowSchema* s, const std::string& format, const std::string& name, int64_t flags) {
+  auto* node = new SchemaNode{format, name, {}};
+  std::memset(s, 0, sizeof(*s));
+  s->format = node->format.c_str();
+  s->name = node->name.c_str();
+  s->flags = flags;
+  s->private_data = node;
+  s->release = ReleaseExportedSchema;
+}
+
+}  // namespace
+
+int gdv_projector_evaluate_export(const gdv_projector_t* p, const ArrowDeviceArray* batch,
+                                  const gdv_selection_t* sel, void* stream_ptr,
+                                  ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  return Guarded([&]() -> int {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (!out) return Fail(Status::Invalid("null output ArrowDeviceArray"));
+  hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+  std::vector<ColumnBuffers> cols;
+  MemKind mem;
+  int64_t rows = 0;
+  Status st = ImportBatch(p->p->schema(), batch, stream, &cols, &mem, &rows);
+  if (!st.ok()) return Fail(st);
+  SelectionView sv;
+  if (sel) {
+    if (!ToSelectionMode(sel->mode, &sv.mode)) return Fail(Status::Invalid("bad selection mode"));
+    sv.indices = sel->indices;
+    sv.num_slots = sel->num_slots;
+  }
+  const int64_t out_rows = sel ? sel->num_slots : rows;
+  const int n_out = p->p->num_outputs();
+  const bool dev = mem == MemKind::kDevice;
+  auto block = std::make_shared<ExportBlock>();
+  block->mem = mem;
+  std::vector<OutputBuffers> o(n_out);
+  int64_t varlen_guess = 64;
+  for (auto& c : cols) if (c.offsets != nullptr) varlen_guess += c.data_size;
+  for (int e = 0; e < n_out; e++) {
+    const DataType& t = p->p->output_type(e);
+    o[e].validity_size = dev ? Projector::ValidityBytes(out_rows) : (out_rows + 7) / 8;
+    if (t.is_varlen()) {
+      o[e].offsets_size = (out_rows + 1) * 4;
+      o[e].data_size = varlen_guess;
+      st = block->Allocate(o[e].offsets_size, &o[e].offsets);
+      if (!st.ok()) return Fail(st);
+    } else {
+      o[e].data_size = t.id == kBool ? o[e].validity_size : Projector::DataBytes(t, out_rows);
+    }
+    st = block->Allocate(o[e].validity_size, &o[e].validity);
+    if (st.ok()) st = block->Allocate(o[e].data_size, &o[e].data);
+    if (!st.ok()) return Fail(st);
+  }
+  for (int attempt = 0; attempt < 2; attempt++) {
+    std::vector<int64_t> caps(n_out);
+    for (int e = 0; e < n_out; e++) caps[e] = o[e].data_size;
+    st = p->p->Evaluate(rows, cols.data(), static_cast<int>(cols.size()), sel ? &sv : nullptr, o.data(),
+                        n_out, mem, stream, 0);
+    if (st.ok() || attempt == 1) break;
+    bool grown = false;  // a var-len output needed more bytes than guessed: regrow once
+    for (int e = 0; e < n_out; e++) {
+      if (!p->p->output_type(e).is_varlen()) continue;
+      if (o[e].data_size > caps[e]) {
+        block->Drop(o[e].data);
+        Status a = block->Allocate(o[e].data_size, &o[e].data);
+        if (!a.ok()) return Fail(a);
+        grown = true;
+      } else {
+        o[e].data_size = caps[e];
+      }
+    }
+    if (!grown) break;
+  }
+  if (!st.ok()) return Fail(st);
+  if (dev) {
+    hipError_t he = hipEventCreateWithFlags(&block->event, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventRecord(block->event, stream);
+    if (he != hipSuccess) return Fail(Status::ExecutionError(hipGetErrorString(he)));
+  }
+  // ---- assemble the struct array
+  auto* parent = new ExportNode();
+  parent->block = block;
+  for (int e = 0; e < n_out; e++) {
+    const DataType& t = p->p->output_type(e);
+    auto* node = new ExportNode();
+    node->block = block;
+    auto* child = new ArrowArray();
+    std::memset(child, 0, sizeof(*child));
+    child->length = out_rows;
+    child->null_count = -1;  // not computed
+    node->buffers[0] = o[e].validity;
+    if (t.is_varlen()) {
+      node->buffers[1] = o[e].offsets;
+      node->buffers[2] = o[e].data;
+      child->n_buffers = 3;
+    } else {
+      node->buffers[1] = o[e].data;
+      child->n_buffers = 2;
+    }
+    child->buffers = node->buffers;
+    child->private_data = node;
+    child->release = ReleaseExportedArray;
+    parent->children.push_back(child);
+  }
+  std::memset(out, 0, sizeof(*out));
+  out->array.length = out_rows;
+  out->array.null_count = 0;
+  out->array.n_buffers = 1;
+  out->array.buffers = parent->buffers;  // {NULL}: a struct array without a validity bitmap
+  out->array.n_children = n_out;
+  out->array.children = parent->children.data();
+  out->array.private_data = parent;
+  out->array.release = ReleaseExportedArray;
+  int device_id = 0;
+  if (dev) (void)hipGetDevice(&device_id);
+  out->device_id = dev ? device_id : -1;
+  out->device_type = dev ? ARROW_DEVICE_ROCM : ARROW_DEVICE_CPU;
+  out->sync_event = dev ? static_cast<void*>(&block->event) : nullptr;
+  if (out_schema != nullptr) {
+    FillSchema(out_schema, "+s", "", 0);
+    auto* sn = static_cast<SchemaNode*>(out_schema->private_data);
+    for (int e = 0; e < n_out; e++) {
+      auto* cs = new ArrowSchema();
+      FillSchema(cs, FormatOf(p->p->output_type(e)), p->output_names[e], /*ARROW_FLAG_NULLABLE*/ 2);
+      sn->children.push_back(cs);
+    }
+    out_schema->n_children = n_out;
+    out_schema->children = sn->children.data();
+  }
+  return GDV_OK;
+  });
 }
 
 // ---------------------------------------------------------------- build support

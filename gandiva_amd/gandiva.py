@@ -534,6 +534,22 @@ class Projector:
         DeviceColumns; CPU arrays take the staged path and return pyarrow arrays."""
         return _evaluate_device_array(self, array_address, num_rows, on_device)
 
+    def evaluate_export(self, array_address, selection=None, stream=None):
+        """Evaluate a batch handed over as `struct ArrowDeviceArray` and hand the results on
+        the same way (Arrow C Device Data Interface export): returns the ctypes structs
+        ``(ArrowDeviceArray, ArrowSchema)``; buffers are allocated by the library (HBM for
+        ARROW_DEVICE_ROCM inputs, host memory otherwise) and owned by the consumer, who
+        releases both through their release callbacks (`_capi.release_c_struct`)."""
+        out, schema = _capi.ArrowDeviceArray(), _capi.ArrowSchema()
+        sel_c = None
+        if selection is not None:
+            s = selection._c()
+            sel_c = C.byref(s)
+        _check(_capi.lib().gdv_projector_evaluate_export(
+            self._h, C.c_void_p(array_address), sel_c, C.c_void_p(stream or 0),
+            C.addressof(out), C.addressof(schema)))
+        return out, schema
+
     def evaluate_device(self, dbatch, selection=None, outputs=None, stream=None, sync=True):
         """HBM-resident path (zero-copy): inputs are a DeviceBatch, outputs DeviceColumns
         (allocated here unless ``outputs`` from a previous call are passed back in)."""

@@ -310,6 +310,19 @@ int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const struct ArrowDe
                                      int selection_mode, void* out_indices, int64_t max_slots,
                                      int64_t* num_selected, void* stream);
 
+/* The step AFTER the path: evaluate and hand the results on as an ArrowDeviceArray (a struct
+ * array, one child per expression; what arrow::ImportDeviceRecordBatch /
+ * pyarrow.RecordBatch._import_from_c_device consume).  The library allocates the result
+ * buffers: in HBM when `batch` is ARROW_DEVICE_ROCM (out->device_type ARROW_DEVICE_ROCM,
+ * out->sync_event = hipEvent_t* recorded on `stream` after the last kernel), in 64-byte
+ * aligned host memory (ARROW_DEVICE_CPU) otherwise.  `out_schema` (may be NULL) receives the
+ * matching ArrowSchema (field names = the expressions' result fields).  Both are owned by
+ * the consumer and freed through their release callbacks; children may be moved out and
+ * released independently (buffers are reference-counted). */
+int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDeviceArray* batch,
+                                  const gdv_selection_t* sel, void* stream,
+                                  struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
 /* ---- build support ----------------------------------------------------------------- */
 /* Plan + compile to a gfx950 code object without a device; fills the on-disk kernel cache. */
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,

@@ -36,6 +36,15 @@ def assert_bit_exact(got, want, what=""):
     if not np.array_equal(gv, wv):
         bad = np.flatnonzero(gv != wv)
         raise AssertionError(f"{what}: validity differs at {len(bad)} rows, first {bad[:8]}")
+    if pa.types.is_string(got.type) or pa.types.is_binary(got.type):
+        # var-len: the bytes of every valid row (offsets themselves may legitimately differ
+        # under nulls); cast to binary so invalid UTF-8 cannot hide behind a decode error
+        g, w = got.cast(pa.binary()).to_pylist(), want.cast(pa.binary()).to_pylist()
+        if g != w:
+            bad = [i for i, (x, y) in enumerate(zip(g, w)) if x != y]
+            raise AssertionError(f"{what}: bytes differ at {len(bad)} rows, first {bad[:8]}: "
+                                 f"{g[bad[0]]!r} vs {w[bad[0]]!r}")
+        return
     gb, wb = values_bits_np(got)[wv], values_bits_np(want)[wv]
     if pa.types.is_floating(got.type):
         # every NaN is the same value: sign and payload of a generated NaN are not part of
