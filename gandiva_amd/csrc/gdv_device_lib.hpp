@@ -100,6 +100,28 @@ GDV_DEV gdv_uint64 gdv_tile_word(gdv_uint64 tile, int u) {
 
 // Deposit the wave-uniform `word` into lane `u` of the accumulator: after GDV_U deposits
 // lanes 0..GDV_U-1 hold the wave's output words and store them with one coalesced store.
+// ---- wave-level prefix sum / sum of a 32-bit value (64 lanes), on the DPP data path:
+// row_shr 1,2,3 + row_shr 4/8 with bank masks, then row_bcast 15 / 31 across the four rows
+// (the classic GCN/CDNA scan; no LDS traffic, no cross-lane permute instructions).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+GDV_DEV gdv_int32 gdv_dpp_add(gdv_int32 acc, gdv_int32 src) {
+  // lanes the masks disable, and lanes whose source falls outside the row, contribute 0
+  return acc + __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+GDV_DEV gdv_int32 gdv_wave_scan_incl(gdv_int32 v) {
+  gdv_int32 r = v;
+  r = gdv_dpp_add<0x111, 0xf, 0xf>(r, v);  // row_shr:1
+  r = gdv_dpp_add<0x112, 0xf, 0xf>(r, v);  // row_shr:2
+  r = gdv_dpp_add<0x113, 0xf, 0xf>(r, v);  // row_shr:3
+  r = gdv_dpp_add<0x114, 0xf, 0xe>(r, r);  // row_shr:4, banks 1-3
+  r = gdv_dpp_add<0x118, 0xf, 0xc>(r, r);  // row_shr:8, banks 2-3
+  r = gdv_dpp_add<0x142, 0xa, 0xf>(r, r);  // row_bcast:15 into rows 1 and 3
+  r = gdv_dpp_add<0x143, 0xc, 0xf>(r, r);  // row_bcast:31 into rows 2 and 3
+  return r;
+}
+GDV_DEV gdv_int32 gdv_wave_last(gdv_int32 v) { return __builtin_amdgcn_readlane(v, 63); }
+GDV_DEV gdv_int32 gdv_wave_sum(gdv_int32 v) { return gdv_wave_last(gdv_wave_scan_incl(v)); }
+
 GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int lane) {
   return (lane == u) ? word : acc;  // v_cndmask with a scalar source
 }
@@ -952,6 +974,72 @@ GDV_DEV bool gdv_bytes_equal(const gdv_str& s, gdv_int32 i, const gdv_uint8* q, 
   }
   return true;
 }
+
+// ---- hash of var-len values: MurmurHash3 over the (mapped) bytes, 8 bytes per load.
+// x64_128 variant, first 64 bits of the digest (hash64) and x86_32 variant (hash32); both
+// seeds start h1 (= h2) as the numeric variants above do.  Null hashes to the seed.
+GDV_DEV gdv_int64 gdv_murmur3_64_buf(const gdv_str& s, gdv_int32 seed) {
+  const gdv_uint64 c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  gdv_uint64 h1 = (gdv_uint64)(gdv_int64)seed, h2 = h1;
+  gdv_int32 i = 0;
+  for (; i + 16 <= s.len; i += 16) {
+    gdv_uint64 k1 = gdv_word_at(s, i), k2 = gdv_word_at(s, i + 8);
+    k1 *= c1; k1 = gdv_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = gdv_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = gdv_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = gdv_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const gdv_int32 rem = s.len - i;  // 0..15 tail bytes, zero-extended into (k1, k2)
+  if (rem > 8) {
+    gdv_uint64 k2 = gdv_word_at(s, i + 8) & gdv_low_bytes_mask(rem - 8);
+    k2 *= c2; k2 = gdv_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+  }
+  if (rem > 0) {
+    gdv_uint64 k1 = gdv_word_at(s, i) & gdv_low_bytes_mask(rem);
+    k1 *= c1; k1 = gdv_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  }
+  h1 ^= (gdv_uint64)s.len; h2 ^= (gdv_uint64)s.len;
+  h1 += h2; h2 += h1;
+  h1 = gdv_fmix64(h1); h2 = gdv_fmix64(h2);
+  h1 += h2;
+  return (gdv_int64)h1;
+}
+GDV_DEV gdv_uint32 gdv_mm32_block(gdv_uint32 h, gdv_uint32 k) {
+  k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u;
+  h ^= k; h = (h << 13) | (h >> 19);
+  return h * 5u + 0xe6546b64u;
+}
+GDV_DEV gdv_uint32 gdv_mm32_tail(gdv_uint32 h, gdv_uint32 k) {
+  k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u;
+  return h ^ k;
+}
+GDV_DEV gdv_int32 gdv_murmur3_32_buf(const gdv_str& s, gdv_int32 seed) {
+  gdv_uint32 h = (gdv_uint32)seed;
+  for (gdv_int32 i = 0; i < s.len; i += 8) {
+    const gdv_int32 rem = s.len - i;
+    const gdv_uint64 w = gdv_word_at(s, i) & gdv_low_bytes_mask(rem);
+    const gdv_uint32 lo = (gdv_uint32)w, hi = (gdv_uint32)(w >> 32);
+    h = rem >= 4 ? gdv_mm32_block(h, lo) : gdv_mm32_tail(h, lo);
+    if (rem >= 8) h = gdv_mm32_block(h, hi);
+    else if (rem > 4) h = gdv_mm32_tail(h, hi);
+  }
+  h ^= (gdv_uint32)s.len;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (gdv_int32)h;
+}
+#define GDV_HASH_BUF(T)                                                                          \
+  GDV_DEV gdv_int32 hash32_##T(gdv_str v, bool valid) { return valid ? gdv_murmur3_32_buf(v, 0) : 0; } \
+  GDV_DEV gdv_int32 hash32_##T##_int32(gdv_str v, bool valid, gdv_int32 seed, bool sv) {         \
+    gdv_int32 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_32_buf(v, s) : s;                                                 \
+  }                                                                                              \
+  GDV_DEV gdv_int64 hash64_##T(gdv_str v, bool valid) { return valid ? gdv_murmur3_64_buf(v, 0) : 0; } \
+  GDV_DEV gdv_int64 hash64_##T##_int64(gdv_str v, bool valid, gdv_int64 seed, bool sv) {         \
+    gdv_int64 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_64_buf(v, (gdv_int32)s) : s;                                      \
+  }
+GDV_HASH_BUF(utf8)
+GDV_HASH_BUF(binary)
 
 GDV_DEV gdv_int32 octet_length_utf8(gdv_str s) { return s.len; }
 GDV_DEV gdv_int32 bit_length_utf8(gdv_str s) { return s.len * 8; }

@@ -351,7 +351,10 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   ArgBlock args(plan_.layout);
   Staging st;
   DeviceBuffer err;
-  StreamDrain drain{stream, mem == MemKind::kHost};  // declared last: drains first
+  // var-len outputs: per wave tile, the bytes it produces (pass 0) and where they start (pass 1)
+  DeviceBuffer tile_counts, tile_starts;
+  // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
+  StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
 
@@ -419,6 +422,16 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     args.SetPtr(ArgLayout::kOffErr, err.get());
   }
 
+  const int64_t nwt = (((out_rows + 63) >> 6) + plan_.opts.subtiles - 1) / plan_.opts.subtiles;
+  if (plan_.has_varlen_output) {
+    int nv = 0;
+    for (auto& t : plan_.output_types) nv += t.is_varlen();
+    GDV_RETURN_NOT_OK(tile_counts.Allocate(std::max<int64_t>(nv * nwt, 1) * 4));
+    GDV_RETURN_NOT_OK(tile_starts.Allocate(std::max<int64_t>(nv * nwt, 1) * 8));
+    args.SetPtr(ArgLayout::kOffCounts, tile_counts.get());
+    args.SetPtr(ArgLayout::kOffMask, tile_starts.get());
+  }
+
   const int64_t grid = GridFor(plan_, out_rows);
   EvalTrace trace("project", plan_.kernel_name, out_rows, stream);
   args.Set64(ArgLayout::kOffAux0, 0);
@@ -430,16 +443,21 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   // var-len outputs: lengths -> offsets (in-place scan), size the byte buffers, second pass
   std::vector<uint64_t> totals(num_outs, 0);
   if (plan_.has_varlen_output) {
+    // byte totals per wave tile -> exclusive scan -> where every tile's bytes start
     DeviceBuffer sums, total_dev;
-    GDV_RETURN_NOT_OK(sums.Allocate(ScanChunks(out_rows + 1) * 8));
+    GDV_RETURN_NOT_OK(sums.Allocate(ScanChunks(nwt) * 8));
     GDV_RETURN_NOT_OK(total_dev.Allocate(8 * num_outs));
+    int v = 0;
     for (int e = 0; e < num_outs; e++) {
       if (!plan_.output_types[e].is_varlen()) continue;
-      GDV_HIP_RETURN_NOT_OK(LaunchInclusiveScanI32(static_cast<int32_t*>(dev_offs[e]), out_rows + 1,
-                                                   sums.as<uint64_t>(),
-                                                   total_dev.as<uint64_t>() + e, stream));
-      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&totals[e], total_dev.as<uint64_t>() + e, 8,
-                                           hipMemcpyDeviceToHost, stream));
+      if (out_rows > 0) {
+        GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(tile_counts.as<uint32_t>() + v * nwt, nwt,
+                                                sums.as<uint64_t>(), tile_starts.as<uint64_t>() + v * nwt,
+                                                total_dev.as<uint64_t>() + e, stream));
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&totals[e], total_dev.as<uint64_t>() + e, 8,
+                                             hipMemcpyDeviceToHost, stream));
+      }
+      v++;
     }
     GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
     Status capacity = Status::OK();
@@ -465,6 +483,11 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (out_rows > 0)
       GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
                                   stream));
+    for (int e = 0; e < num_outs; e++)  // the closing offset: offsets[out_rows] = total bytes
+      if (plan_.output_types[e].is_varlen())
+        GDV_HIP_RETURN_NOT_OK(hipMemsetD32Async(
+            reinterpret_cast<hipDeviceptr_t>(static_cast<int32_t*>(dev_offs[e]) + out_rows),
+            static_cast<int>(totals[e]), 1, stream));
   }
 
   uint32_t err_bits = 0;

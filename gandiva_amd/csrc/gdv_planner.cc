@@ -723,16 +723,10 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
              << "].valid, wbase, lane, GDV_U);\n";
     }
   }
-  for (size_t e = 0; e < plan->output_types.size(); e++)
-    if (plan->output_types[e].is_varlen()) s << "  gdv_int32 oo" << e << "[GDV_U];\n";
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
     << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
     << "    const bool live = FULL || row < n;\n"
     << "    (void)live;\n";
-  // byte pass: where each row's bytes go (issued with the input loads, not after them)
-  for (size_t e = 0; e < plan->output_types.size(); e++)
-    if (plan->output_types[e].is_varlen())
-      s << "    oo" << e << "[u] = (PASS == 1 && live) ? outo" << e << "[row] : 0;\n";
   if (sel) {
     s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
     for (int k = 0; k < nin; k++) {
@@ -866,7 +860,8 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   plan->opts = opts;
   CodeGen cg(schema, mode, opts);
   WordAccumulators accs;
-  std::ostringstream after_loop;
+  std::ostringstream after_loop, before_loop;
+  int num_varlen = 0;
   std::vector<std::string> strings;
   const std::string st = opts.nontemporal ? "gdv_stnt" : "gdv_st";
   for (auto& e : exprs) plan->has_varlen_output |= e->result().type.is_varlen();
@@ -881,12 +876,27 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     strings.push_back(exprs[e]->ToString());
     const std::string E = std::to_string(e);
     if (t.is_varlen()) {
-      // pass 0: byte length of every row (0 for nulls) into offsets[row + 1]; the host
-      // turns them into offsets with an in-place scan; pass 1: the bytes at offsets[row]
+      // pass 0: bytes produced per wave tile -> A.counts[]; the host scans those (one value
+      // per GDV_U*64 rows) into A.mask[]; pass 1 recomputes the lengths, prefix-sums them
+      // inside the wave (DPP) and writes offsets[row] and the bytes in the same sweep
       const std::string ok = CodeGen::AndExpr("live", cg.LaneValid(v));
-      cg.Stmt("if (pass == 0) { if (live) outo" + E + "[row + 1] = (" + ok + ") ? (" + v.v +
-              ").len : 0; }");
-      cg.Stmt("else if (" + ok + ") gdv_str_copy(outd" + E + " + oo" + E + "[u], " + v.v + ");");
+      const std::string V = std::to_string(num_varlen++);
+      // which wave tile this is, among all wave tiles of the launch
+      const std::string tile = V + " * ((((n + 63) >> 6) + GDV_U - 1) / GDV_U) + wbase / GDV_U";
+      before_loop << "  gdv_int32 tl" << E << " = 0;  // pass 0: bytes this tile produces\n"
+                  << "  gdv_int32 vb" << E << " = 0;  // pass 1: where the next sub-tile's bytes start\n"
+                  << "  if (PASS == 1) vb" << E << " = (gdv_int32)A.mask[" << tile << "];\n";
+      cg.Stmt("const gdv_int32 ln" + E + " = (" + ok + ") ? (" + v.v + ").len : 0;");
+      cg.Stmt("if (pass == 0) tl" + E + " += ln" + E + ";");
+      cg.Stmt("else {");
+      cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + ");");
+      cg.Stmt("  const gdv_int32 off = vb" + E + " + inc - ln" + E + ";");
+      cg.Stmt("  vb" + E + " += gdv_wave_last(inc);");
+      cg.Stmt("  if (live) outo" + E + "[row] = off;");
+      cg.Stmt("  if (" + ok + ") gdv_str_copy(outd" + E + " + off, " + v.v + ");");
+      cg.Stmt("}");
+      after_loop << "  if (pass == 0) { const gdv_int32 t = gdv_wave_sum(tl" << E << "); if (lane == 0) A.counts["
+                 << tile << "] = (gdv_uint32)t; }\n";
     } else if (t.id == kBool) {
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
       after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)", two);
@@ -921,7 +931,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       plan->opts.subtiles = u;
     }
   }
-  return Assemble(cg, plan, strings, accs, "", after_loop.str());
+  return Assemble(cg, plan, strings, accs, before_loop.str(), after_loop.str());
 }
 
 Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,

@@ -64,8 +64,9 @@ struct KernelPlan {
   std::vector<DataType> output_types;  // one per expression (filter: none)
   ArgLayout layout;
   bool can_raise = false;          // kernel may set error bits
-  // Some output is utf8/binary: the kernel is launched twice (aux0 = 0: lengths into the
-  // offsets buffers + all fixed-width outputs; aux0 = 1: bytes, after the offsets scan).
+  // Some output is utf8/binary: the kernel is launched twice (aux0 = 0: byte totals per wave
+  // tile into `counts` + all fixed-width outputs; aux0 = 1: offsets and bytes, after the
+  // scan of the tile totals into `mask`).
   bool has_varlen_output = false;
   int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
 };

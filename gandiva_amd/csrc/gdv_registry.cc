@@ -168,6 +168,7 @@ FunctionRegistry::FunctionRegistry() {
   std::vector<DataType> hashable = numerics;
   hashable.push_back(boolean());
   for (auto& t : {date32(), date64(), timestamp(), time32()}) hashable.push_back(t);
+  for (auto& t : {utf8(), binary()}) hashable.push_back(t);  // MurmurHash3 over the bytes
   for (auto& t : hashable) {
     add("hash", {t}, int32(), NullPolicy::kNullNever, 0, Sym("hash32", {t}));
     add("hash32", {t}, int32(), NullPolicy::kNullNever);

@@ -343,6 +343,56 @@ static int32_t murmur3_32(uint64_t val, int32_t seed) {
   h ^= 8u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return (int32_t)h;
 }
+/* MurmurHash3 over a byte string (Appleby's public-domain reference formulation: x64_128,
+ * first 64 bits of the digest; x86_32), bytes seen through the value's case map */
+static uint8_t map_byte(uint8_t c, int map);
+static int64_t murmur3_64_buf(const uint8_t* p, int len, int map, int32_t seed) {
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = (uint64_t)(int64_t)seed, h2 = h1;
+  int nblocks = len / 16;
+  for (int b = 0; b < nblocks; b++) {
+    uint64_t k1 = 0, k2 = 0;
+    for (int j = 0; j < 8; j++) {
+      k1 |= (uint64_t)map_byte(p[b * 16 + j], map) << (8 * j);
+      k2 |= (uint64_t)map_byte(p[b * 16 + 8 + j], map) << (8 * j);
+    }
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const uint8_t* tail = p + nblocks * 16;
+  uint64_t k1 = 0, k2 = 0;
+  for (int j = (len & 15) - 1; j >= 8; j--) k2 ^= (uint64_t)map_byte(tail[j], map) << (8 * (j - 8));
+  if ((len & 15) > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+  for (int j = ((len & 15) > 8 ? 8 : (len & 15)) - 1; j >= 0; j--) k1 ^= (uint64_t)map_byte(tail[j], map) << (8 * j);
+  if ((len & 15) > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+  h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return (int64_t)(h1 + h2);
+}
+static int32_t murmur3_32_buf(const uint8_t* p, int len, int map, int32_t seed) {
+  uint32_t h = (uint32_t)seed;
+  int nblocks = len / 4;
+  for (int b = 0; b < nblocks; b++) {
+    uint32_t k = 0;
+    for (int j = 0; j < 4; j++) k |= (uint32_t)map_byte(p[b * 4 + j], map) << (8 * j);
+    k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u;
+    h ^= k; h = (h << 13) | (h >> 19); h = h * 5u + 0xe6546b64u;
+  }
+  const uint8_t* tail = p + nblocks * 4;
+  uint32_t k = 0;
+  switch (len & 3) {
+    case 3: k ^= (uint32_t)map_byte(tail[2], map) << 16; /* fallthrough */
+    case 2: k ^= (uint32_t)map_byte(tail[1], map) << 8;  /* fallthrough */
+    case 1: k ^= map_byte(tail[0], map);
+            k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u; h ^= k;
+  }
+  h ^= (uint32_t)len;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (int32_t)h;
+}
 static double as_double(int t, const vec* a, int i) {
   if (t == T_F64) return a->v[i].d;
   if (t == T_F32) return (double)a->v[i].f;
@@ -618,6 +668,13 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       if ((op = cmp_op(f)) >= 0) { int c3 = str_cmp(x, xl, xm, y, yl, ym); out->v[i].i = CMP(op, c3, 0); }
       else if (!strcmp(f, "isnull")) { out->v[i].i = !a[0].valid[i]; out->valid[i] = 1; }
       else if (!strcmp(f, "isnotnull")) { out->v[i].i = a[0].valid[i]; out->valid[i] = 1; }
+      else if (!strncmp(f, "hash", 4)) { /* never null; a null value hashes to the seed */
+        int64_t seed = n->nargs == 2 && a[1].valid[i] ? a[1].v[i].i : 0;
+        if (!a[0].valid[i]) out->v[i].i = strstr(f, "64") ? seed : (int32_t)seed;
+        else if (strstr(f, "64")) out->v[i].i = murmur3_64_buf(x, xl, xm, (int32_t)seed);
+        else out->v[i].i = murmur3_32_buf(x, xl, xm, (int32_t)seed);
+        out->valid[i] = 1;
+      }
       else if (!strcmp(f, "octet_length")) out->v[i].i = xl;
       else if (!strcmp(f, "bit_length")) out->v[i].i = xl * 8;
       else if (!strcmp(f, "char_length") || !strcmp(f, "length") || !strcmp(f, "lengthUtf8")) {

@@ -163,3 +163,95 @@ def test_hip_c5_matches_oracle_host_and_device_paths(nulls):
     want2 = oracle.project(exprs[1:], oracle.take_rows(batch, sel.to_array().to_numpy()))
     for g, w in zip(got, want2):
         assert g.equals(w)
+
+
+# ------------------------------------------------------------------ hash over var-len values
+
+def _py_murmur3_x64_128_h1(data: bytes, seed: int) -> int:
+    """Independent pure-Python MurmurHash3_x64_128, first 64 bits (signed)."""
+    M = (1 << 64) - 1
+    c1, c2 = 0x87c37b91114253d5, 0x4cf5ad432745937f
+    rotl = lambda v, d: ((v << d) | (v >> (64 - d))) & M
+
+    def fmix(k):
+        k ^= k >> 33; k = k * 0xff51afd7ed558ccd & M; k ^= k >> 33
+        k = k * 0xc4ceb9fe1a85ec53 & M; k ^= k >> 33
+        return k
+    h1 = h2 = seed & M
+    nblocks = len(data) // 16
+    for b in range(nblocks):
+        k1 = int.from_bytes(data[16 * b: 16 * b + 8], "little")
+        k2 = int.from_bytes(data[16 * b + 8: 16 * b + 16], "little")
+        k1 = k1 * c1 & M; k1 = rotl(k1, 31); k1 = k1 * c2 & M; h1 ^= k1
+        h1 = rotl(h1, 27); h1 = (h1 + h2) & M; h1 = (h1 * 5 + 0x52dce729) & M
+        k2 = k2 * c2 & M; k2 = rotl(k2, 33); k2 = k2 * c1 & M; h2 ^= k2
+        h2 = rotl(h2, 31); h2 = (h2 + h1) & M; h2 = (h2 * 5 + 0x38495ab5) & M
+    tail = data[16 * nblocks:]
+    if len(tail) > 8:
+        k2 = int.from_bytes(tail[8:], "little")
+        k2 = k2 * c2 & M; k2 = rotl(k2, 33); k2 = k2 * c1 & M; h2 ^= k2
+    if tail:
+        k1 = int.from_bytes(tail[:8], "little")
+        k1 = k1 * c1 & M; k1 = rotl(k1, 31); k1 = k1 * c2 & M; h1 ^= k1
+    h1 ^= len(data); h2 ^= len(data)
+    h1 = (h1 + h2) & M; h2 = (h2 + h1) & M
+    h1, h2 = fmix(h1), fmix(h2)
+    h1 = (h1 + h2) & M
+    return h1 - (1 << 64) if h1 >> 63 else h1
+
+
+def _hash_exprs(b, s, k):
+    out = []
+
+    def add(name, node, t):
+        out.append(b.make_expression(node, pa.field(name, t)))
+    add("h32", b.make_function("hash32", [s], pa.int32()), pa.int32())
+    add("h64", b.make_function("hash64", [s], pa.int64()), pa.int64())
+    add("h32s", b.make_function("hash32", [s, b.make_literal(17, pa.int32())], pa.int32()), pa.int32())
+    add("h64s", b.make_function("hash64", [s, k], pa.int64()), pa.int64())
+    return out
+
+
+def test_oracle_string_hashes_match_independent_murmur3():
+    from sklearn.utils import murmurhash3_32
+    rng = np.random.default_rng(5)
+    n = 600
+    s = _strings(rng, n)
+    k = pa.array(rng.integers(-1000, 1000, n), pa.int64())
+    batch = pa.RecordBatch.from_arrays([s, k], names=["s", "k"])
+    b = gandiva.TreeExprBuilder()
+    fs, fk = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    h32, h64, h32s, h64s = oracle.project(_hash_exprs(b, fs, fk), batch)
+    assert h32.null_count == 0 and h64.null_count == 0          # hash is never null
+    for i, (v, seed) in enumerate(zip(s.to_pylist(), k.to_pylist())):
+        if v is None:   # null hashes to the seed
+            assert (h32[i].as_py(), h64[i].as_py(), h32s[i].as_py(), h64s[i].as_py()) == (0, 0, 17, seed)
+            continue
+        raw = v.encode()
+        assert h32[i].as_py() == murmurhash3_32(raw, seed=0, positive=False), v
+        assert h32s[i].as_py() == murmurhash3_32(raw, seed=17, positive=False), v
+        assert h64[i].as_py() == _py_murmur3_x64_128_h1(raw, 0), v
+        # the seed is narrowed to int32, then sign-extended into both lanes
+        assert h64s[i].as_py() == _py_murmur3_x64_128_h1(raw, seed), v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 30011])
+def test_hip_string_hashes_match_oracle(n):
+    from helpers import assert_bit_exact
+    rng = np.random.default_rng(n + 77)
+    s = _strings(rng, n)
+    k = pa.array(rng.integers(-1000, 1000, n), pa.int64())
+    batch = pa.RecordBatch.from_arrays([s, k, s.cast(pa.binary())], names=["s", "k", "raw"])
+    b = gandiva.TreeExprBuilder()
+    fs, fk, fr = (b.make_field(batch.schema.field(i)) for i in range(3))
+    exprs = _hash_exprs(b, fs, fk)
+    exprs += [b.make_expression(b.make_function("hash64", [fr], pa.int64()), pa.field("hb", pa.int64())),
+              b.make_expression(b.make_function("hash32", [b.make_function("upper", [fs], pa.string())],
+                                                pa.int32()), pa.field("hup", pa.int32())),
+              b.make_expression(b.make_function("hash64", [b.make_function(
+                  "substr", [fs, b.make_literal(2, pa.int64()), b.make_literal(20, pa.int64())], pa.string())],
+                  pa.int64()), pa.field("hsub", pa.int64()))]
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        assert_bit_exact(g, w, str(e))
