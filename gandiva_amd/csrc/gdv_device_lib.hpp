@@ -878,13 +878,23 @@ GDV_DEV gdv_uint8 gdv_str_at(const gdv_str& s, gdv_int32 i) { return gdv_map_byt
 // continuation-byte counting and substring search all work on the 64-bit word.
 #define GDV_B80 0x8080808080808080ull
 #define GDV_B7F 0x7f7f7f7f7f7f7f7full
+// 8 bytes at p; bytes at or past `lim` read as 0.  In the last 8 bytes of the buffer the load
+// is moved back to end exactly at `lim` and shifted (one load, no byte loop).  Precondition
+// (the engine and the literal tables guarantee it): at least 8 readable bytes end at `lim`.
 GDV_DEV gdv_uint64 gdv_load8(const gdv_uint8* p, const gdv_uint8* lim) {
-  gdv_uint64 w = 0;
+  gdv_uint64 w;
   if (p + 8 <= lim) {
     __builtin_memcpy(&w, p, 8);
-  } else {
-    for (int k = 0; k < 8 && p + k < lim; k++) w |= (gdv_uint64)p[k] << (8 * k);
+    return w;
   }
+  const gdv_int64 over = (gdv_int64)(p - lim) + 8;  // 1.. bytes of [p, p+8) past lim
+  __builtin_memcpy(&w, lim - 8, 8);
+  return over >= 8 ? 0ull : w >> (8 * over);
+}
+// the same without the limit check, for loads a wave-uniform test proved in range
+GDV_DEV gdv_uint64 gdv_load8_raw(const gdv_uint8* p) {
+  gdv_uint64 w;
+  __builtin_memcpy(&w, p, 8);
   return w;
 }
 GDV_DEV gdv_uint64 gdv_low_bytes_mask(gdv_int32 nbytes) {  // nbytes in [0, 8]
@@ -949,6 +959,32 @@ GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
     if (s.len > 2) dst[2] = (gdv_uint8)(w >> 16);
   }
 }
+// ---- LDS staging of var-len output bytes.  Every lane writes its row's bytes into the
+// wave's private LDS window at the row's offset inside the sub-tile (byte-granular, unaligned
+// ds_write_b64: cheap), then the wave streams the window to HBM as consecutive 16-byte pieces
+// — one coalesced store instruction per KiB instead of several scattered 8-byte stores per
+// row.  The last piece is shifted back to end exactly at `cnt` (it overlaps its neighbour with
+// identical bytes), so no byte ladder is needed; windows under 16 bytes go out bytewise.
+#define GDV_OUT_WIN 2048
+GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gdv_int32 cnt, int lane) {
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: ordering only
+  if (cnt >= 16) {
+#pragma unroll
+    for (int i = 0; i < GDV_OUT_WIN / 1024; i++) {
+      const gdv_int32 c = lane * 16 + i * 1024;
+      if (c < cnt) {
+        const gdv_int32 c2 = c + 16 <= cnt ? c : cnt - 16;
+        gdv_uint64 w[2];
+        __builtin_memcpy(w, win + c2, 16);
+        __builtin_memcpy(dst + c2, w, 16);
+      }
+    }
+  } else if (lane < cnt) {
+    dst[lane] = win[lane];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
 // number of UTF-8 characters = bytes that are not continuation bytes (10xxxxxx)
 GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
@@ -1173,12 +1209,19 @@ GDV_DEV bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 
   const gdv_uint64 mask = gdv_low_bytes_mask(m);
   const gdv_uint64 first = gdv_load8(nb, nb + m + 8) & mask;
   const gdv_uint64 splat = (first & 0xffull) * 0x0101010101010101ull;
+  const gdv_uint64 splat2 = ((first >> 8) & 0xffull) * 0x0101010101010101ull;
   const gdv_int32 last = s.len - m;  // last candidate start
   gdv_uint64 cur = gdv_word_at(s, 0);
   for (gdv_int32 base = 0; base <= last; base += 8) {
     const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
     const gdv_uint64 x = cur ^ splat;
     gdv_uint64 cand = (x - 0x0101010101010101ull) & ~x & GDV_B80;
+    if (m >= 2) {
+      // second needle byte at the next position as well: with 64 lanes x 8 positions a
+      // one-byte filter lets some lane into the verification loop on nearly every word
+      const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat2;
+      cand &= (y - 0x0101010101010101ull) & ~y & GDV_B80;
+    }
     while (cand) {
       const int k = __builtin_ctzll(cand) >> 3;
       cand &= cand - 1;

@@ -212,10 +212,22 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
                                                hipMemcpyHostToDevice, stream));
           DeviceBuffer& dd = st->Add();
           GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(c.data_size, 8)));
+          if (c.data_size < 8) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dd.get(), 0, 8, stream));
           if (c.data_size > 0)
             GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dd.get(), c.data, c.data_size,
                                                  hipMemcpyHostToDevice, stream));
           args->SetInOffsets(static_cast<int>(k), dof.get());
+          args->SetInData(static_cast<int>(k), dd.get());
+        } else if (c.data_size < 8) {
+          // the kernels' 8-byte loads need 8 readable bytes ending at the limit: a tiny
+          // buffer is copied into a zero-padded one
+          DeviceBuffer& dd = st->Add();
+          GDV_RETURN_NOT_OK(dd.Allocate(8));
+          GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dd.get(), 0, 8, stream));
+          if (c.data_size > 0)
+            GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dd.get(), c.data, c.data_size,
+                                                 hipMemcpyDeviceToDevice, stream));
+          args->SetInOffsets(static_cast<int>(k), osrc);
           args->SetInData(static_cast<int>(k), dd.get());
         } else {
           args->SetInOffsets(static_cast<int>(k), osrc);
@@ -223,7 +235,7 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
         }
         // readable extent of the byte buffer (the kernels' 8-byte loads stop at this limit)
         HostBitmap extent;
-        extent.nwords = c.data_size;
+        extent.nwords = std::max<int64_t>(c.data_size, 8);
         args->SetInBits(static_cast<int>(k), extent);
       } else if (t.id == kBool) {
         if (c.data_size < BytesForBits(c.offset + num_rows))
@@ -413,7 +425,9 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     args.SetOutData(e, dev_data[e]);
     args.SetOutValid(e, dev_valid[e]);
     args.SetOutOffsets(e, dev_offs[e]);
-    if (t.is_varlen()) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_offs[e], 0, 4, stream));
+    // offsets[0] = 0 is written by the byte pass with every other offset; an empty selection
+    // launches nothing (the closing offset comes from the scan launcher)
+    if (t.is_varlen() && out_rows == 0) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_offs[e], 0, 4, stream));
   }
 
   if (plan_.can_raise) {
@@ -423,13 +437,15 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
 
   const int64_t nwt = (((out_rows + 63) >> 6) + plan_.opts.subtiles - 1) / plan_.opts.subtiles;
+  const int64_t seg_stride = (nwt + 3) & ~int64_t{3};  // per-output segment, 16-byte aligned
   if (plan_.has_varlen_output) {
     int nv = 0;
     for (auto& t : plan_.output_types) nv += t.is_varlen();
-    GDV_RETURN_NOT_OK(tile_counts.Allocate(std::max<int64_t>(nv * nwt, 1) * 4));
-    GDV_RETURN_NOT_OK(tile_starts.Allocate(std::max<int64_t>(nv * nwt, 1) * 8));
+    GDV_RETURN_NOT_OK(tile_counts.Allocate(std::max<int64_t>(nv * seg_stride, 1) * 4));
+    GDV_RETURN_NOT_OK(tile_starts.Allocate(std::max<int64_t>(nv * seg_stride, 1) * 8));
     args.SetPtr(ArgLayout::kOffCounts, tile_counts.get());
     args.SetPtr(ArgLayout::kOffMask, tile_starts.get());
+    args.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
   }
 
   const int64_t grid = GridFor(plan_, out_rows);
@@ -443,23 +459,28 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   // var-len outputs: lengths -> offsets (in-place scan), size the byte buffers, second pass
   std::vector<uint64_t> totals(num_outs, 0);
   if (plan_.has_varlen_output) {
-    // byte totals per wave tile -> exclusive scan -> where every tile's bytes start
+    // byte totals per wave tile -> exclusive scan -> where every tile's bytes start; all
+    // var-len outputs share one set of (three) launches, which also writes the closing offset
     DeviceBuffer sums, total_dev;
-    GDV_RETURN_NOT_OK(sums.Allocate(ScanChunks(nwt) * 8));
-    GDV_RETURN_NOT_OK(total_dev.Allocate(8 * num_outs));
-    int v = 0;
-    for (int e = 0; e < num_outs; e++) {
-      if (!plan_.output_types[e].is_varlen()) continue;
-      if (out_rows > 0) {
-        GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(tile_counts.as<uint32_t>() + v * nwt, nwt,
-                                                sums.as<uint64_t>(), tile_starts.as<uint64_t>() + v * nwt,
-                                                total_dev.as<uint64_t>() + e, stream));
-        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&totals[e], total_dev.as<uint64_t>() + e, 8,
-                                             hipMemcpyDeviceToHost, stream));
-      }
-      v++;
+    std::vector<int> vl;
+    for (int e = 0; e < num_outs; e++)
+      if (plan_.output_types[e].is_varlen()) vl.push_back(e);
+    const int nv = static_cast<int>(vl.size());
+    GDV_RETURN_NOT_OK(sums.Allocate(std::max<int64_t>(ScanChunks(nwt), 1) * 8 * kMaxScanSegments));
+    GDV_RETURN_NOT_OK(total_dev.Allocate(8 * nv));
+    std::vector<uint64_t> seg_totals(nv, 0);
+    for (int v0 = 0; v0 < nv; v0 += kMaxScanSegments) {
+      const int cnt = std::min(kMaxScanSegments, nv - v0);
+      int32_t* closing[kMaxScanSegments];
+      for (int i = 0; i < cnt; i++) closing[i] = static_cast<int32_t*>(dev_offs[vl[v0 + i]]) + out_rows;
+      GDV_HIP_RETURN_NOT_OK(LaunchSegmentedOffsetsScan(
+          tile_counts.as<uint32_t>() + v0 * seg_stride, nwt, seg_stride, cnt, sums.as<uint64_t>(),
+          tile_starts.as<uint64_t>() + v0 * seg_stride, total_dev.as<uint64_t>() + v0, closing, stream));
     }
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(seg_totals.data(), total_dev.get(), 8 * nv,
+                                         hipMemcpyDeviceToHost, stream));
     GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+    for (int v = 0; v < nv; v++) totals[vl[v]] = seg_totals[v];
     Status capacity = Status::OK();
     for (int e = 0; e < num_outs; e++) {
       if (!plan_.output_types[e].is_varlen()) continue;
@@ -483,11 +504,6 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (out_rows > 0)
       GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
                                   stream));
-    for (int e = 0; e < num_outs; e++)  // the closing offset: offsets[out_rows] = total bytes
-      if (plan_.output_types[e].is_varlen())
-        GDV_HIP_RETURN_NOT_OK(hipMemsetD32Async(
-            reinterpret_cast<hipDeviceptr_t>(static_cast<int32_t*>(dev_offs[e]) + out_rows),
-            static_cast<int>(totals[e]), 1, stream));
   }
 
   uint32_t err_bits = 0;

@@ -13,9 +13,14 @@ int64_t ScanChunks(int64_t m);
 hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
                              uint64_t* offsets, uint64_t* total, hipStream_t stream);
 
-// data[i] = sum(data[0..i]) in place (int32 lengths -> var-len offsets); *total = grand sum.
-hipError_t LaunchInclusiveScanI32(int32_t* data, int64_t m, uint64_t* chunk_sums, uint64_t* total,
-                                  hipStream_t stream);
+// The same for `nseg` (<= 16) independent segments in one set of launches: segment s reads
+// counts[s*stride .. s*stride+m), writes offsets[s*stride ..), totals[s], and — when
+// closing[s] is not null — *closing[s] = (int32) totals[s] (the closing entry of an Arrow
+// var-len offsets buffer).  chunk_sums needs nseg * ScanChunks(m) entries.
+constexpr int kMaxScanSegments = 16;
+hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t stride, int nseg,
+                                      uint64_t* chunk_sums, uint64_t* offsets, uint64_t* totals,
+                                      int32_t* const* closing, hipStream_t stream);
 
 // Writes row_base + (position of every set bit of mask[0..nwords)) in ascending order to
 // out[]; offsets[] holds, per group of `subtiles` words, the number of set bits before it.

@@ -52,8 +52,13 @@ __device__ __forceinline__ uint64_t BlockExclusiveScan(uint64_t v, uint64_t* tot
   return base + incl - v;
 }
 
+struct ClosingOffsets { int32_t* p[kMaxScanSegments]; };
+
 __global__ void __launch_bounds__(kScanThreads)
-ScanReduce(const uint32_t* __restrict__ counts, int64_t m, uint64_t* __restrict__ sums) {
+ScanReduce(const uint32_t* __restrict__ counts, int64_t m, uint64_t* __restrict__ sums,
+           int64_t stride) {
+  counts += (int64_t)blockIdx.y * stride;  // segment (one per var-len output; 0 for filters)
+  sums += (int64_t)blockIdx.y * gridDim.x;
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanPerThread;
   uint64_t local = 0;
   if (base + kScanPerThread <= m) {
@@ -74,7 +79,10 @@ ScanReduce(const uint32_t* __restrict__ counts, int64_t m, uint64_t* __restrict_
 
 // Single workgroup: exclusive scan of the chunk sums in place; grand total -> *total.
 __global__ void __launch_bounds__(kScanThreads)
-ScanSpine(uint64_t* __restrict__ sums, int64_t nb, uint64_t* __restrict__ total_out) {
+ScanSpine(uint64_t* __restrict__ sums, int64_t nb, uint64_t* __restrict__ total_out,
+          ClosingOffsets closing) {
+  sums += (int64_t)blockIdx.x * nb;  // one workgroup per segment
+  total_out += blockIdx.x;
   const int64_t per = (nb + kScanThreads - 1) / kScanThreads;
   const int64_t lo = (int64_t)threadIdx.x * per;
   const int64_t hi = lo + per < nb ? lo + per : nb;
@@ -87,12 +95,19 @@ ScanSpine(uint64_t* __restrict__ sums, int64_t nb, uint64_t* __restrict__ total_
     sums[i] = prefix;
     prefix += c;
   }
-  if (threadIdx.x == 0) *total_out = total;
+  if (threadIdx.x == 0) {
+    *total_out = total;
+    // var-len outputs: the closing entry of the Arrow offsets buffer is the byte total
+    if (closing.p[blockIdx.x] != nullptr) *closing.p[blockIdx.x] = static_cast<int32_t>(total);
+  }
 }
 
 __global__ void __launch_bounds__(kScanThreads)
 ScanApply(const uint32_t* __restrict__ counts, int64_t m, const uint64_t* __restrict__ sums,
-          uint64_t* __restrict__ offsets) {
+          uint64_t* __restrict__ offsets, int64_t stride) {
+  counts += (int64_t)blockIdx.y * stride;
+  offsets += (int64_t)blockIdx.y * stride;
+  sums += (int64_t)blockIdx.y * gridDim.x;
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanPerThread;
   uint32_t c[kScanPerThread];
   uint64_t local = 0;
@@ -115,43 +130,6 @@ ScanApply(const uint32_t* __restrict__ counts, int64_t m, const uint64_t* __rest
   for (int i = 0; i < kScanPerThread; i++) {
     if (base + i < m) offsets[base + i] = prefix;
     prefix += c[i];
-  }
-}
-
-// In-place inclusive scan of int32 lengths -> Arrow var-len offsets (data[i] becomes
-// sum(data[0..i])); `sums` holds the exclusive prefix of every chunk (ScanSpine output).
-// Each wavefront owns 1024 consecutive elements and walks them 64 at a time (lane = element
-// within the 64-group), so every load and store is a fully coalesced 256-byte access; the
-// running total is carried between groups through lane 63.  (The first version read 16
-// consecutive elements per thread — 64 cache lines per wave instruction — and ran at
-// 1.6 TB/s; this form is bandwidth-bound.)
-__global__ void __launch_bounds__(kScanThreads)
-ScanApplyInclusiveI32(int32_t* __restrict__ data, int64_t m, const uint64_t* __restrict__ sums) {
-  __shared__ uint64_t wave_sums[kScanThreads / 64];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  constexpr int kPerWave = kScanChunk / (kScanThreads / 64);  // 1024
-  const int64_t wbase = (int64_t)blockIdx.x * kScanChunk + (int64_t)wave * kPerWave;
-  uint32_t v[kPerWave / 64];
-  uint64_t local = 0;
-#pragma unroll
-  for (int j = 0; j < kPerWave / 64; j++) {
-    const int64_t i = wbase + j * 64 + lane;
-    v[j] = (i < m) ? static_cast<uint32_t>(data[i]) : 0u;
-    local += v[j];
-  }
-  // wave total -> exclusive prefix of this wave inside the chunk
-  uint64_t wtotal = WaveInclusiveScan(local, lane);
-  if (lane == 63) wave_sums[wave] = wtotal;
-  __syncthreads();
-  uint64_t carry = sums[blockIdx.x];
-  for (int w = 0; w < wave; w++) carry += wave_sums[w];
-#pragma unroll
-  for (int j = 0; j < kPerWave / 64; j++) {
-    const uint64_t incl = WaveInclusiveScan(v[j], lane) + carry;
-    const int64_t i = wbase + j * 64 + lane;
-    if (i < m) data[i] = static_cast<int32_t>(incl);
-    carry = __shfl(incl, 63, 64);
   }
 }
 
@@ -200,28 +178,32 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
 
 int64_t ScanChunks(int64_t m) { return (m + kScanChunk - 1) / kScanChunk; }
 
-hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
-                             uint64_t* offsets, uint64_t* total, hipStream_t stream) {
-  if (m <= 0) return hipMemsetAsync(total, 0, sizeof(uint64_t), stream);
+hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t stride, int nseg,
+                                      uint64_t* chunk_sums, uint64_t* offsets, uint64_t* totals,
+                                      int32_t* const* closing, hipStream_t stream) {
+  if (nseg <= 0) return hipSuccess;
+  if (nseg > kMaxScanSegments) return hipErrorInvalidValue;
+  ClosingOffsets c;
+  for (int i = 0; i < kMaxScanSegments; i++) c.p[i] = (closing != nullptr && i < nseg) ? closing[i] : nullptr;
+  if (m <= 0) {
+    hipError_t e = hipMemsetAsync(totals, 0, sizeof(uint64_t) * nseg, stream);
+    for (int i = 0; e == hipSuccess && i < nseg; i++)
+      if (c.p[i] != nullptr) e = hipMemsetAsync(c.p[i], 0, sizeof(int32_t), stream);
+    return e;
+  }
   const int64_t nb = ScanChunks(m);
-  hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, counts, m,
-                     chunk_sums);
-  hipLaunchKernelGGL(ScanSpine, dim3(1), dim3(kScanThreads), 0, stream, chunk_sums, nb, total);
-  hipLaunchKernelGGL(ScanApply, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, counts, m,
-                     chunk_sums, offsets);
+  hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
+                     counts, m, chunk_sums, stride);
+  hipLaunchKernelGGL(ScanSpine, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, chunk_sums, nb,
+                     totals, c);
+  hipLaunchKernelGGL(ScanApply, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
+                     counts, m, chunk_sums, offsets, stride);
   return hipGetLastError();
 }
 
-hipError_t LaunchInclusiveScanI32(int32_t* data, int64_t m, uint64_t* chunk_sums, uint64_t* total,
-                                  hipStream_t stream) {
-  if (m <= 0) return hipMemsetAsync(total, 0, sizeof(uint64_t), stream);
-  const int64_t nb = ScanChunks(m);
-  hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb), dim3(kScanThreads), 0, stream,
-                     reinterpret_cast<const uint32_t*>(data), m, chunk_sums);
-  hipLaunchKernelGGL(ScanSpine, dim3(1), dim3(kScanThreads), 0, stream, chunk_sums, nb, total);
-  hipLaunchKernelGGL(ScanApplyInclusiveI32, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, data,
-                     m, chunk_sums);
-  return hipGetLastError();
+hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
+                             uint64_t* offsets, uint64_t* total, hipStream_t stream) {
+  return LaunchSegmentedOffsetsScan(counts, m, m, 1, chunk_sums, offsets, total, nullptr, stream);
 }
 
 hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int64_t nwords,

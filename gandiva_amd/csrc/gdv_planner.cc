@@ -670,7 +670,9 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   // PASS is a template parameter so that the byte pass of a var-len projection drops, at
   // compile time, everything only the fixed-width outputs need (and vice versa)
   s << "template <bool FULL, int PASS>\n"
-    << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane) {\n"
+    << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane, gdv_uint8* lds) {\n"
+    << "  gdv_uint8* const lds_out = lds;  // var-len output staging window (GDV_OUT_WIN + 16 bytes)\n"
+    << "  (void)lds_out;\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
     << "  const gdv_int64 n = A.n;\n"
@@ -766,12 +768,20 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     if (t.is_varlen() && cg.needs_values_[k]) {
       s << "  gdv_uint64 sw" << k << "[GDV_U][GDV_NPRE];\n"
         << "  const gdv_uint8* slim" << k << " = sd" << k << " + A.in[" << k << "].bits.nwords;\n"
-        << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
         // lanes whose string ends before word j sit the load out: scattered 8-byte loads
-        // are priced per active lane in the texture addresser, not per instruction
-        << "#pragma unroll\n    for (int j = 0; j < GDV_NPRE; j++) sw" << k << "[u][j] = (8 * j < ob"
+        // are priced per active lane in the texture addresser, not per instruction.  A full
+        // tile in row order ends at its last row's end offset: one wave-uniform compare
+        // proves every prefetch load in range and the per-lane limit checks go away.
+        << "  if (" << (sel ? "false" : "FULL") << " && sd" << k << " + __builtin_amdgcn_readlane(ob" << k
+        << "[GDV_U - 1], 63) + 8 * GDV_NPRE <= slim" << k << ") {\n"
+        << "#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
+        << "#pragma unroll\n      for (int j = 0; j < GDV_NPRE; j++) sw" << k << "[u][j] = (8 * j < ob"
+        << k << "[u] - oa" << k << "[u]) ? gdv_load8_raw(sd" << k << " + oa" << k << "[u] + 8 * j) : 0ull;\n"
+        << "    }\n  } else {\n"
+        << "#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
+        << "#pragma unroll\n      for (int j = 0; j < GDV_NPRE; j++) sw" << k << "[u][j] = (8 * j < ob"
         << k << "[u] - oa" << k << "[u]) ? gdv_load8(sd" << k << " + oa" << k << "[u] + 8 * j, slim"
-        << k << ") : 0ull;\n  }\n";
+        << k << ") : 0ull;\n    }\n  }\n";
     }
   }
 
@@ -809,29 +819,33 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
   // each bitmap.
   s << "template <int PASS>\n"
-    << "GDV_DEV void gdv_run(const gdv_args& A, const int lane, const int wave) {\n"
+    << "GDV_DEV void gdv_run(const gdv_args& A, const int lane, const int wave, gdv_uint8* lds) {\n"
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
     << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
     << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
     << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nfull;\n"
     << "       wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
-    << "    gdv_tile<true, PASS>(A, wt * GDV_U, lane);\n"
+    << "    gdv_tile<true, PASS>(A, wt * GDV_U, lane, lds);\n"
     // The single partial wave tile is handled after the loop, not in an if/else next to
     // the full-tile body: side by side, the compiler hoists the two bodies' common bitmap
     // loads above the branch and serialises them in front of the value loads.
     << "  if (nwt > nfull && wave == (int)(nfull % GDV_WAVES) &&\n"
     << "      blockIdx.x == (unsigned)((nfull / GDV_WAVES) % gridDim.x))\n"
-    << "    gdv_tile<false, PASS>(A, nfull * GDV_U, lane);\n"
+    << "    gdv_tile<false, PASS>(A, nfull * GDV_U, lane, lds);\n"
     << "}\n\n";
   s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) " << "GDV_KERNEL_NAME"
     << "(const gdv_args A) {\n"
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
-  if (plan->has_varlen_output)
-    s << "  if (A.aux0 == 0) gdv_run<0>(A, lane, wave);\n  else gdv_run<1>(A, lane, wave);\n";
-  else
-    s << "  gdv_run<0>(A, lane, wave);\n";
+  if (plan->has_varlen_output) {
+    // wave-private LDS: the staging window of the var-len byte pass
+    s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds[GDV_WAVES][GDV_OUT_WIN + 16];\n"
+      << "  if (A.aux0 == 0) gdv_run<0>(A, lane, wave, gdv_lds[wave]);\n"
+      << "  else gdv_run<1>(A, lane, wave, gdv_lds[wave]);\n";
+  } else {
+    s << "  gdv_run<0>(A, lane, wave, nullptr);\n";
+  }
   s << "}\n";
 
   std::string text = s.str();
@@ -882,7 +896,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       const std::string ok = CodeGen::AndExpr("live", cg.LaneValid(v));
       const std::string V = std::to_string(num_varlen++);
       // which wave tile this is, among all wave tiles of the launch
-      const std::string tile = V + " * ((((n + 63) >> 6) + GDV_U - 1) / GDV_U) + wbase / GDV_U";
+      const std::string tile = V + " * A.aux1 + wbase / GDV_U";  // aux1: tiles per output segment
       before_loop << "  gdv_int32 tl" << E << " = 0;  // pass 0: bytes this tile produces\n"
                   << "  gdv_int32 vb" << E << " = 0;  // pass 1: where the next sub-tile's bytes start\n"
                   << "  if (PASS == 1) vb" << E << " = (gdv_int32)A.mask[" << tile << "];\n";
@@ -890,10 +904,13 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       cg.Stmt("if (pass == 0) tl" + E + " += ln" + E + ";");
       cg.Stmt("else {");
       cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + ");");
-      cg.Stmt("  const gdv_int32 off = vb" + E + " + inc - ln" + E + ";");
-      cg.Stmt("  vb" + E + " += gdv_wave_last(inc);");
-      cg.Stmt("  if (live) outo" + E + "[row] = off;");
-      cg.Stmt("  if (" + ok + ") gdv_str_copy(outd" + E + " + off, " + v.v + ");");
+      cg.Stmt("  const gdv_int32 cnt = gdv_wave_last(inc), loc = inc - ln" + E + ";");
+      cg.Stmt("  if (live) outo" + E + "[row] = vb" + E + " + loc;");
+      cg.Stmt("  if (cnt <= GDV_OUT_WIN) {  // wave-uniform: stage through LDS, store coalesced");
+      cg.Stmt("    if (" + ok + ") gdv_str_copy(lds_out + loc, " + v.v + ");");
+      cg.Stmt("    gdv_flush_out(outd" + E + " + vb" + E + ", lds_out, cnt, lane);");
+      cg.Stmt("  } else if (" + ok + ") gdv_str_copy(outd" + E + " + vb" + E + " + loc, " + v.v + ");");
+      cg.Stmt("  vb" + E + " += cnt;");
       cg.Stmt("}");
       after_loop << "  if (pass == 0) { const gdv_int32 t = gdv_wave_sum(tl" << E << "); if (lane == 0) A.counts["
                  << tile << "] = (gdv_uint32)t; }\n";
