@@ -70,10 +70,10 @@ typedef struct {
   int32_t prec, scale; /* decimal128 values */
   union { int64_t i; uint64_t u; double d; float f; i128 q; } v[CHUNK];
   uint8_t valid[CHUNK];
-  /* utf8 / binary values are views (pointer, length) + a byte map (0 none, 1 upper, 2 lower) */
+  /* utf8 / binary values are views (pointer, length) + a per-row byte map (0 none, 1 upper, 2 lower) */
   const uint8_t* sp[CHUNK];
   int32_t sl[CHUNK];
-  int smap;
+  uint8_t sm[CHUNK]; /* per-row byte map: if/else may merge differently mapped branches */
 } vec;
 
 typedef struct node {
@@ -268,7 +268,7 @@ static void load_column(const or_column* c, int64_t row0, int n, vec* out) {
       case T_STR: case T_BIN:
         out->sp[i] = (const uint8_t*)c->data + c->offsets[r];
         out->sl[i] = c->offsets[r + 1] - c->offsets[r];
-        out->smap = 0;
+        out->sm[i] = 0;
         break;
       default: out->v[i].i = ((const int64_t*)c->data)[r]; break;
     }
@@ -661,10 +661,10 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
   int op;
   if (is_str(t0)) {
     const int two_str = n->nargs >= 2 && is_str(a[1].type);
-    out->smap = 0;
     for (int i = 0; i < cnt; i++) {
-      const uint8_t* x = a[0].sp[i]; int xl = a[0].sl[i], xm = a[0].smap;
-      const uint8_t* y = two_str ? a[1].sp[i] : NULL; int yl = two_str ? a[1].sl[i] : 0, ym = two_str ? a[1].smap : 0;
+      const uint8_t* x = a[0].sp[i]; int xl = a[0].sl[i], xm = a[0].sm[i];
+      const uint8_t* y = two_str ? a[1].sp[i] : NULL; int yl = two_str ? a[1].sl[i] : 0, ym = two_str ? a[1].sm[i] : 0;
+      out->sm[i] = 0;
       if ((op = cmp_op(f)) >= 0) { int c3 = str_cmp(x, xl, xm, y, yl, ym); out->v[i].i = CMP(op, c3, 0); }
       else if (!strcmp(f, "isnull")) { out->v[i].i = !a[0].valid[i]; out->valid[i] = 1; }
       else if (!strcmp(f, "isnotnull")) { out->v[i].i = a[0].valid[i]; out->valid[i] = 1; }
@@ -687,16 +687,16 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
         int esc = n->nargs == 3 ? a[2].sp[i][0] : -1;
         out->v[i].i = like_match(x, xl, xm, y, yl, esc);
       } else if (!strcmp(f, "upper") || !strcmp(f, "lower")) {
-        out->sp[i] = x; out->sl[i] = xl; out->smap = f[0] == 'u' ? 1 : 2;
+        out->sp[i] = x; out->sl[i] = xl; out->sm[i] = f[0] == 'u' ? 1 : 2;
       } else if (!strcmp(f, "substr") || !strcmp(f, "substring")) {
         int64_t cntc = n->nargs == 3 ? a[2].v[i].i : 0x7fffffff;
         substr_view(x, xl, a[1].v[i].i, cntc, &out->sp[i], &out->sl[i]);
-        out->smap = xm;
+        out->sm[i] = (uint8_t)xm;
       } else if (!strcmp(f, "ltrim") || !strcmp(f, "rtrim") || !strcmp(f, "btrim") || !strcmp(f, "trim")) {
         int lo = 0, hi = xl;
         if (f[0] != 'r') while (lo < hi && x[lo] == ' ') lo++;
         if (f[0] != 'l') while (hi > lo && x[hi - 1] == ' ') hi--;
-        out->sp[i] = x + lo; out->sl[i] = hi - lo; out->smap = xm;
+        out->sp[i] = x + lo; out->sl[i] = hi - lo; out->sm[i] = (uint8_t)xm;
       } else { c->err |= 0x100; }
     }
   } else if (t0 == T_DEC || n->type == T_DEC) {
@@ -940,7 +940,7 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
       out->scale = n->scale;
       for (int i = 0; i < cnt; i++) {
         out->valid[i] = !n->is_null;
-        if (is_str(n->type)) { out->sp[i] = n->sbytes; out->sl[i] = n->slen; out->smap = 0; continue; }
+        if (is_str(n->type)) { out->sp[i] = n->sbytes; out->sl[i] = n->slen; out->sm[i] = 0; continue; }
         if (n->type == T_DEC) { out->v[i].q = (i128)(((u128)n->hi << 64) | n->lo); continue; }
         if (n->type == T_F32) { uint32_t b = (uint32_t)n->lo; memcpy(&out->v[i].f, &b, 4); }
         else out->v[i].u = n->lo;
@@ -975,7 +975,7 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
         if (is_str(n->type)) {
           out->sp[i] = take ? th->sp[i] : el->sp[i];
           out->sl[i] = take ? th->sl[i] : el->sl[i];
-          out->smap = th->smap; /* branches with different byte maps are not restated */
+          out->sm[i] = take ? th->sm[i] : el->sm[i];
         }
       }
       free(cnd);
@@ -1012,7 +1012,7 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
         int hit = 0;
         for (int k = 0; k < n->nvals && !hit; k++) {
           int len = n->soffs[k + 1] - n->soffs[k];
-          hit = len == x->sl[i] && str_cmp(x->sp[i], x->sl[i], x->smap, n->sbytes + n->soffs[k], len, 0) == 0;
+          hit = len == x->sl[i] && str_cmp(x->sp[i], x->sl[i], x->sm[i], n->sbytes + n->soffs[k], len, 0) == 0;
         }
         out->v[i].i = hit;
         out->valid[i] = x->valid[i];
@@ -1243,7 +1243,7 @@ int64_t gdv_oracle_project_str(const char* program, const or_column* cols, int n
       int len = r->valid[i] ? r->sl[i] : 0;
       if (r->valid[i]) out_validity[rr >> 3] |= (uint8_t)(1u << (rr & 7));
       if (total + len <= cap)
-        for (int k = 0; k < len; k++) data[total + k] = map_byte(r->sp[i][k], r->smap);
+        for (int k = 0; k < len; k++) data[total + k] = map_byte(r->sp[i][k], r->sm[i]);
       total += len;
       offsets[rr + 1] = (int32_t)total;
     }

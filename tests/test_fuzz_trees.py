@@ -146,3 +146,126 @@ def test_fuzzed_projector_and_filter_match_oracle(seed):
         got_sel = psel.evaluate(batch, sv)
         for g, w, e in zip(got_sel, want, exprs):
             assert_bit_exact(g, oracle.take_rows(w, sel), f"seed {seed} (selection): {e}")
+
+
+# ------------------------------------------------------------------ string trees
+
+STR = pa.string()
+STR_WORDS = ["", "a", "spark", "Sparkle", "bright spark and fire", "park", "  padded  ", "ünïcödé spark",
+             "日本語テキスト", "a_b%c", "100%", "MiXeD CaSe 123", "x" * 70, "tail  ", "  head"]
+PATTERNS = ["%spark%", "spark%", "%spark", "s_ark%", "%", "", "%a%b%", "_%_", "%ar%", "MiXeD%", "%é%"]
+
+
+def _string_batch(seed, n):
+    rng = np.random.default_rng(20_000 + seed)
+
+    def col(null_fraction):
+        vals = [STR_WORDS[i] if rng.random() < 0.6 else
+                "".join(rng.choice(list("abspark_% XYZé"), size=rng.integers(0, 40)))
+                for i in rng.integers(0, len(STR_WORDS), n)]
+        mask = rng.random(n) < null_fraction
+        return pa.array([None if m else v for v, m in zip(vals, mask)], type=STR)
+    return pa.RecordBatch.from_arrays(
+        [col(0.1), col(0.0), pa.array(rng.integers(-6, 12, n), pa.int64()),
+         random_array(rng, BOOL, n, 0.1)], names=["s", "t", "k", "z"])
+
+
+class StringTreeGen:
+    """Typed generator over {utf8, bool, int32, int64}: views (substr/trim/upper/lower),
+    predicates (like shapes, compares, starts/ends_with, IN), lengths, hashes, if/and/or."""
+
+    def __init__(self, schema, seed):
+        self.rng = np.random.default_rng(seed)
+        self.b = gandiva.TreeExprBuilder()
+        self.f = {f.name: self.b.make_field(f) for f in schema}
+
+    def pick(self, xs):
+        return xs[int(self.rng.integers(0, len(xs)))]
+
+    def string(self, depth):
+        b, r = self.b, self.rng
+        if depth == 0 or r.random() < 0.25:
+            return self.pick([self.f["s"], self.f["t"], b.make_literal(self.pick(STR_WORDS[:8]), STR)])
+        roll = r.random()
+        if roll < 0.3:
+            return b.make_function(self.pick(["upper", "lower", "ltrim", "rtrim", "btrim"]),
+                                   [self.string(depth - 1)], STR)
+        if roll < 0.6:
+            args = [self.string(depth - 1), b.make_literal(int(r.integers(-5, 8)), I64)]
+            if r.random() < 0.7:
+                args.append(b.make_literal(int(r.integers(0, 12)), I64))
+            return b.make_function("substr", args, STR)
+        if roll < 0.8:
+            return b.make_if(self.boolean(depth - 1), self.string(depth - 1), self.string(depth - 1), STR)
+        return self.pick([self.f["s"], self.f["t"]])
+
+    def boolean(self, depth):
+        b, r = self.b, self.rng
+        if depth == 0:
+            return self.f["z"]
+        roll = r.random()
+        if roll < 0.35:
+            return b.make_function("like", [self.string(depth - 1), b.make_literal(self.pick(PATTERNS), STR)], BOOL)
+        if roll < 0.5:
+            op = self.pick(["equal", "not_equal", "less_than", "greater_than_or_equal_to"])
+            return b.make_function(op, [self.string(depth - 1), self.string(depth - 1)], BOOL)
+        if roll < 0.6:
+            return b.make_function(self.pick(["starts_with", "ends_with"]),
+                                   [self.string(depth - 1), b.make_literal(self.pick(["s", "spa", "rk", ""]), STR)], BOOL)
+        if roll < 0.7:
+            return b.make_in_expression(self.string(depth - 1), ["spark", "park", "", "SPARK"], STR)
+        if roll < 0.8:
+            return b.make_function(self.pick(["isnull", "isnotnull"]), [self.string(depth - 1)], BOOL)
+        if roll < 0.9:
+            kids = [self.boolean(depth - 1) for _ in range(2)]
+            return b.make_and(kids) if r.random() < 0.5 else b.make_or(kids)
+        return b.make_function("greater_than", [self.integer(depth - 1), b.make_literal(3, I32)], BOOL)
+
+    def integer(self, depth):
+        return self.b.make_function(self.pick(["octet_length", "char_length", "hash32"]),
+                                    [self.string(max(depth - 1, 0))], I32)
+
+
+def _string_expressions(seed):
+    g = StringTreeGen(_string_batch(0, 1).schema, 500 + seed)
+    exprs = [g.b.make_expression(g.string(3), pa.field("s0", STR)),
+             g.b.make_expression(g.boolean(3), pa.field("b0", BOOL)),
+             g.b.make_expression(g.string(2), pa.field("s1", STR)),
+             g.b.make_expression(g.integer(2), pa.field("i0", I32)),
+             g.b.make_expression(g.b.make_function("hash64", [g.string(2)], I64), pa.field("h0", I64))]
+    return exprs, g.b.make_condition(g.boolean(3))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_generated_string_trees_validate_and_compile(seed):
+    from gandiva_amd import _capi, gandiva as gg
+    exprs, cond = _string_expressions(seed)
+    lib = _capi.lib()
+    schema = _string_batch(0, 1).schema
+    sh = gg._make_schema(schema)
+    arr = (C.c_void_p * len(exprs))(*[e._h for e in exprs])
+    assert lib.gdv_precompile_projector(sh, arr, len(exprs), 0) == 0, _capi.last_error()
+    assert lib.gdv_precompile_filter(sh, cond._h) == 0, _capi.last_error()
+    got = oracle.project(exprs, _string_batch(seed, 129))
+    assert [len(g) for g in got] == [129] * len(exprs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzzed_string_trees_match_oracle(seed):
+    exprs, cond = _string_expressions(seed)
+    n = [1, 63, 64, 65, 257, 1000, 4097, 30011][seed % 8]
+    batch = _string_batch(seed, n)
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    want = oracle.project(exprs, batch)
+    for g, w, e in zip(got, want, exprs):
+        g.validate(full=True)
+        assert_bit_exact(g, w, f"seed {seed}: {e}")
+    flt = gandiva.make_filter(batch.schema, cond)
+    sv = flt.evaluate(batch, pa.default_memory_pool(), "int32")
+    sel = sv.to_array()
+    assert sel.equals(oracle.filter_indices(cond, batch, "int32")), f"seed {seed}: {cond}"
+    if len(sel) and seed % 2 == 1:   # gather mode: var-len outputs through a selection vector
+        got_sel = gandiva.make_projector(batch.schema, exprs, None, "UINT32").evaluate(batch, sv)
+        for g, w, e in zip(got_sel, want, exprs):
+            assert_bit_exact(g, oracle.take_rows(w, sel), f"seed {seed} (selection): {e}")
