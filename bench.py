@@ -60,7 +60,7 @@ def cpu_baseline_c2(rows):
         el = time.perf_counter() - t0
         if el > 10.0 or reps >= 200:
             break
-    return {
+    out = {
         "value": round(rows * reps / el / 1e6, 2),
         "unit": "million rows/s",
         "cores": cores,
@@ -69,6 +69,34 @@ def cpu_baseline_c2(rows):
                   f"expressions, 10% nulls), oracle/gdv_oracle.c -O3 -march=native, "
                   f"{cores} threads, {el:.1f} s",
     }
+    try:
+        out["second_engine"] = pyarrow_compute_c2(batch.slice(0, min(rows, 1 << 24)))
+    except Exception as e:  # indicative only
+        out["second_engine"] = {"engine": "pyarrow.compute", "value": None, "note": f"failed: {e}"}
+    return out
+
+
+def pyarrow_compute_c2(batch):
+    """An independent CPU engine on the same data: pyarrow.compute's
+    vectorised kernels, one call per operator, common sub-expressions shared by hand."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    a, b, c, d = batch.columns
+
+    def once():
+        e0, e1, e2, e3, e4 = pc.add(a, b), pc.subtract(a, b), pc.multiply(a, b), pc.add(c, d), pc.multiply(c, d)
+        return [e0, e1, e2, e3, e4, pc.multiply(e0, c), pc.multiply(e1, d), pc.add(e2, e4),
+                pc.multiply(e0, pc.subtract(c, d)), pc.multiply(pc.multiply(e2, c), d)]
+    once()
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 4.0 and reps < 50:
+        once()
+        reps += 1
+    el = time.perf_counter() - t0
+    return {"engine": f"pyarrow.compute {pa.__version__}, 13 kernel calls per pass, 1 thread",
+            "value": round(batch.num_rows * reps / el / 1e6, 2), "unit": "million rows/s",
+            "sample": f"{reps} passes over {batch.num_rows} rows, {el:.1f} s"}
 
 
 def cpu_baseline_c3(rows):

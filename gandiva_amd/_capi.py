@@ -90,6 +90,11 @@ PROTOTYPES = [
     ("gdv_device_synchronize", C.c_int, []),
     ("gdv_projector_evaluate_device_array", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_uint32]),
     ("gdv_filter_evaluate_device_array", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), _P]),
+    ("gdv_projector_evaluate_flat", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
+                                              C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_int64), C.c_int, C.c_int]),
+    ("gdv_filter_evaluate_flat", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
+                                           C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     ("gdv_projector_evaluate_export", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), _P, _P, _P]),
     ("gdv_precompile_projector", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_precompile_filter", C.c_int, [_P, _P]),

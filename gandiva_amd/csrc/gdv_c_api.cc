@@ -369,6 +369,99 @@ int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_colum
 char* gdv_filter_dump_ir(const gdv_filter_t* f) { return f ? DupString(f->f->DumpIR()) : nullptr; }
 void gdv_filter_free(gdv_filter_t* f) { delete f; }
 
+// ---------------------------------------------------------------- JNI-shaped flat entry points
+namespace {
+// validity, [offsets,] data per field, in schema order
+Status UnflattenInputs(const Schema& schema, const int64_t* addrs, const int64_t* sizes, int num_bufs,
+                       std::vector<ColumnBuffers>* cols) {
+  int want = 0;
+  for (auto& f : schema) want += f.type.is_varlen() ? 3 : 2;
+  if (num_bufs != want || (want > 0 && (addrs == nullptr || sizes == nullptr)))
+    return Status::Invalid("expected " + std::to_string(want) + " input buffers (validity, [offsets,] data per field), got " +
+                           std::to_string(num_bufs));
+  cols->assign(schema.size(), ColumnBuffers());
+  int b = 0;
+  for (size_t i = 0; i < schema.size(); i++) {
+    ColumnBuffers& c = (*cols)[i];
+    c.validity = reinterpret_cast<const void*>(addrs[b]);
+    c.validity_size = c.validity ? sizes[b] : 0;
+    b++;
+    if (schema[i].type.is_varlen()) {
+      c.offsets = reinterpret_cast<const void*>(addrs[b]);
+      c.offsets_size = sizes[b];
+      b++;
+    }
+    c.data = reinterpret_cast<const void*>(addrs[b]);
+    c.data_size = sizes[b];
+    b++;
+  }
+  return Status::OK();
+}
+}  // namespace
+
+int gdv_projector_evaluate_flat(const gdv_projector_t* p, int64_t num_rows, const int64_t* buf_addrs,
+                                const int64_t* buf_sizes, int num_bufs, int sel_mode,
+                                int64_t sel_addr, int64_t sel_slots, const int64_t* out_addrs,
+                                int64_t* out_sizes, int num_out_bufs, int mem_kind) {
+  return Guarded([&]() -> int {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  std::vector<ColumnBuffers> cols;
+  Status st = UnflattenInputs(p->p->schema(), buf_addrs, buf_sizes, num_bufs, &cols);
+  if (!st.ok()) return Fail(st);
+  const int n_out = p->p->num_outputs();
+  int want = 0;
+  for (int e = 0; e < n_out; e++) want += p->p->output_type(e).is_varlen() ? 3 : 2;
+  if (num_out_bufs != want || out_addrs == nullptr || out_sizes == nullptr)
+    return Fail(Status::Invalid("expected " + std::to_string(want) + " output buffers, got " +
+                                std::to_string(num_out_bufs)));
+  std::vector<OutputBuffers> o(n_out);
+  std::vector<int> data_slot(n_out);
+  int b = 0;
+  for (int e = 0; e < n_out; e++) {
+    o[e].validity = reinterpret_cast<void*>(out_addrs[b]);
+    o[e].validity_size = out_sizes[b];
+    b++;
+    if (p->p->output_type(e).is_varlen()) {
+      o[e].offsets = reinterpret_cast<void*>(out_addrs[b]);
+      o[e].offsets_size = out_sizes[b];
+      b++;
+    }
+    o[e].data = reinterpret_cast<void*>(out_addrs[b]);
+    o[e].data_size = out_sizes[b];
+    data_slot[e] = b++;
+  }
+  SelectionView sv;
+  if (!ToSelectionMode(sel_mode, &sv.mode)) return Fail(Status::Invalid("bad selection mode"));
+  sv.indices = reinterpret_cast<const void*>(sel_addr);
+  sv.num_slots = sel_slots;
+  const bool has_sel = sv.mode != SelectionMode::kNone;
+  st = p->p->Evaluate(num_rows, cols.data(), static_cast<int>(cols.size()), has_sel ? &sv : nullptr,
+                      o.data(), n_out, mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
+                      nullptr, 0);
+  for (int e = 0; e < n_out; e++)
+    if (p->p->output_type(e).is_varlen()) out_sizes[data_slot[e]] = o[e].data_size;
+  return Check(st);
+  });
+}
+
+int gdv_filter_evaluate_flat(const gdv_filter_t* f, int64_t num_rows, const int64_t* buf_addrs,
+                             const int64_t* buf_sizes, int num_bufs, int sel_mode, int64_t out_addr,
+                             int64_t out_size_bytes, int64_t* num_selected, int mem_kind) {
+  return Guarded([&]() -> int {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  SelectionMode mode;
+  if (!ToSelectionMode(sel_mode, &mode) || mode == SelectionMode::kNone)
+    return Fail(Status::Invalid("bad selection mode"));
+  std::vector<ColumnBuffers> cols;
+  Status st = UnflattenInputs(f->f->schema(), buf_addrs, buf_sizes, num_bufs, &cols);
+  if (!st.ok()) return Fail(st);
+  const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
+  return Check(f->f->Evaluate(num_rows, cols.data(), static_cast<int>(cols.size()), mode,
+                              reinterpret_cast<void*>(out_addr), out_size_bytes / w, num_selected,
+                              mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost, nullptr));
+  });
+}
+
 // ---------------------------------------------------------------- registry
 int gdv_registry_size(void) { return static_cast<int>(FunctionRegistry::Get().all().size()); }
 int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_type_t* params,

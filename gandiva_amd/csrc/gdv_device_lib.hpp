@@ -1144,6 +1144,75 @@ GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 cou
 GDV_DEV gdv_str substr_utf8_int64(gdv_str s, gdv_int64 from) {
   return substr_utf8_int64_int64(s, from, 0x7fffffff);
 }
+// byte offset of the character with 0-based index `ci` (s.len when the string is shorter)
+GDV_DEV gdv_int32 gdv_utf8_byte_pos(const gdv_str& s, gdv_int32 ci) {
+  if (ci <= 0) return 0;
+  gdv_int32 g = 0;
+  for (gdv_int32 i = 0; i < s.len; i++) {
+    if (gdv_is_utf8_lead(s.p[i])) {
+      if (g == ci) return i;
+      g++;
+    }
+  }
+  return s.len;
+}
+GDV_DEV gdv_str gdv_empty_str() { return gdv_make_str(nullptr, 0, 0, nullptr); }
+// left(s, n): the first n characters; n < 0: all but the last |n|
+GDV_DEV gdv_str left_utf8_int32(gdv_str s, gdv_int32 n) {
+  gdv_str r = s;
+  r.len = 0;
+  if (n == 0 || s.len <= 0) return r;
+  const gdv_int32 chars = gdv_utf8_count(s);
+  const gdv_int32 end = n > 0 ? (n < chars ? n : chars) : (chars + n > 0 ? chars + n : 0);
+  r.len = gdv_utf8_byte_pos(s, end);
+  return r;
+}
+// right(s, n): the last n characters; n < 0: all but the first |n|
+GDV_DEV gdv_str right_utf8_int32(gdv_str s, gdv_int32 n) {
+  gdv_str r = s;
+  r.len = 0;
+  if (n == 0 || s.len <= 0) return r;
+  const gdv_int32 chars = gdv_utf8_count(s);
+  const gdv_int32 start = n > 0 ? chars - (n < chars ? n : chars) : (-(gdv_int64)n < chars ? -n : chars);
+  const gdv_int32 b = gdv_utf8_byte_pos(s, start);
+  r.p = s.p + b;
+  r.len = s.len - b;
+  return r;
+}
+// castVARCHAR(s, n): s cut to at most n characters; n < 0 is an execution error
+GDV_DEV gdv_str castVARCHAR_utf8_int64(gdv_ctx ctx, gdv_str s, gdv_int64 n) {
+  gdv_str r = s;
+  if (n < 0) { gdv_raise(ctx, GDV_ERR_BAD_ARG); r.len = 0; return r; }
+  if (n >= s.len) return r;  // bytes >= characters
+  r.len = gdv_utf8_byte_pos(s, (gdv_int32)n);
+  return r;
+}
+// locate(sub, str[, start]): 1-based character position of the first occurrence of sub in
+// str at or after character `start`; 0 when absent or when either string is empty
+GDV_DEV gdv_int32 locate_utf8_utf8_int32(gdv_ctx ctx, gdv_str sub, gdv_str str, gdv_int32 start) {
+  if (start < 1) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return 0; }
+  if (str.len <= 0 || sub.len <= 0) return 0;
+  const gdv_int32 b = gdv_utf8_byte_pos(str, start - 1);
+  for (gdv_int32 i = b; i + sub.len <= str.len; i++) {
+    bool eq = true;
+    for (gdv_int32 k = 0; k < sub.len && eq; k++) eq = gdv_str_at(str, i + k) == gdv_str_at(sub, k);
+    if (eq) {
+      gdv_str head = str;
+      head.len = i;
+      return gdv_utf8_count(head) + 1;
+    }
+  }
+  return 0;
+}
+GDV_DEV gdv_int32 locate_utf8_utf8(gdv_ctx ctx, gdv_str sub, gdv_str str) {
+  return locate_utf8_utf8_int32(ctx, sub, str, 1);
+}
+GDV_DEV gdv_int32 strpos_utf8_utf8(gdv_ctx ctx, gdv_str str, gdv_str sub) {
+  return locate_utf8_utf8_int32(ctx, sub, str, 1);
+}
+// ascii(s): the first byte as a signed char (0 for the empty string)
+GDV_DEV gdv_int32 ascii_utf8(gdv_str s) { return s.len > 0 ? (gdv_int32)(gdv_int8)gdv_str_at(s, 0) : 0; }
+
 GDV_DEV bool gdv_is_space(gdv_uint8 c) { return c == ' '; }
 GDV_DEV gdv_str ltrim_utf8(gdv_str s) {
   while (s.len > 0 && gdv_is_space(s.p[0])) { s.p++; s.len--; }

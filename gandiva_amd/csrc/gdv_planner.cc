@@ -461,7 +461,8 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
           // the enclosing if/else / short-circuit path is live — otherwise a guarded
           // `if (b != 0) a / b` would raise on the rows it guards against.
           std::string guard = AndExpr(AndExpr("live", active), LaneValid(*out));
-          out->v = Tmp(ctype, guard + " ? " + call + " : (" + ctype + ")0");
+          const std::string idle = out->type.is_varlen() ? "gdv_empty_str()" : "(" + ctype + ")0";
+          out->v = Tmp(ctype, guard + " ? " + call + " : " + idle);
         } else {
           out->v = Tmp(ctype, call);
         }

@@ -257,6 +257,13 @@ FunctionRegistry::FunctionRegistry() {
   add("substr", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("substring", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult,
       "substr_utf8_int64");
+  add("left", {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("right", {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  add("castVARCHAR", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("locate", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
+  add("locate", {utf8(), utf8(), int32()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
+  add("strpos", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
+  add("ascii", {utf8()}, int32());
   add("ltrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("rtrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("btrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);

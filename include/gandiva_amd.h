@@ -252,6 +252,23 @@ int gdv_memcpy_h2d(void* dst_device, const void* src_host, int64_t bytes);
 int gdv_memcpy_d2h(void* dst_host, const void* src_device, int64_t bytes);
 int gdv_device_synchronize(void);
 
+/* ---- JNI-shaped flat entry points --------------------------------- */
+/* What the reference's JNI layer receives from Java (JniWrapper.evaluateProjector /
+ * evaluateFilter: long[] bufAddrs, long[] bufSizes, long[] outAddrs, long[] outSizes) and
+ * would forward unchanged: every field's buffers flattened in schema order — validity,
+ * then offsets (utf8/binary only), then data — as raw addresses and byte sizes; outputs the
+ * same way, one group per expression.  Array offsets are 0 (Java's vectors have none).
+ * sel_mode/sel_addr/sel_slots describe an optional selection vector (GDV_SEL_NONE: none).
+ * A var-len output whose data capacity is too small fails with GDV_INVALID and
+ * out_sizes[data slot] is updated to the bytes needed (the JNI expander callback's role). */
+int gdv_projector_evaluate_flat(const gdv_projector_t* p, int64_t num_rows, const int64_t* buf_addrs,
+                                const int64_t* buf_sizes, int num_bufs, int sel_mode,
+                                int64_t sel_addr, int64_t sel_slots, const int64_t* out_addrs,
+                                int64_t* out_sizes, int num_out_bufs, int mem_kind);
+int gdv_filter_evaluate_flat(const gdv_filter_t* f, int64_t num_rows, const int64_t* buf_addrs,
+                             const int64_t* buf_sizes, int num_bufs, int sel_mode, int64_t out_addr,
+                             int64_t out_size_bytes, int64_t* num_selected, int mem_kind);
+
 /* ---- Arrow C Device Data Interface (the step BEFORE the path: other ROCm producers) --- */
 /* The ABI-stable structs of the Arrow C data / C device data interfaces
  * (pyarrow/include/arrow/c/abi.h).  Declared here under the spec's own include guards so

@@ -506,6 +506,19 @@ static void substr_view(const uint8_t* s, int sl, int64_t from, int64_t count, c
   }
   *op = s + b0; *ol = b1 - b0;
 }
+/* byte offset of the character with 0-based index ci (sl when the string is shorter) */
+static int utf8_byte_pos(const uint8_t* s, int sl, int64_t ci) {
+  int64_t g = 0;
+  if (ci <= 0) return 0;
+  for (int i = 0; i < sl; i++)
+    if (is_lead(s[i])) { if (g == ci) return i; g++; }
+  return sl;
+}
+static int utf8_chars(const uint8_t* s, int sl) {
+  int g = 0;
+  for (int i = 0; i < sl; i++) g += is_lead(s[i]);
+  return g;
+}
 static int is_str(int t) { return t == T_STR || t == T_BIN; }
 
 /* ---------------------------------------------------------------- decimal128
@@ -692,6 +705,42 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
         int64_t cntc = n->nargs == 3 ? a[2].v[i].i : 0x7fffffff;
         substr_view(x, xl, a[1].v[i].i, cntc, &out->sp[i], &out->sl[i]);
         out->sm[i] = (uint8_t)xm;
+      } else if (!strcmp(f, "left") || !strcmp(f, "right")) {
+        int64_t k = a[1].v[i].i; int chars = utf8_chars(x, xl);
+        out->sp[i] = x; out->sl[i] = 0; out->sm[i] = (uint8_t)xm;
+        if (k != 0 && xl > 0) {
+          if (f[0] == 'l') {
+            int64_t end = k > 0 ? (k < chars ? k : chars) : (chars + k > 0 ? chars + k : 0);
+            out->sl[i] = utf8_byte_pos(x, xl, end);
+          } else {
+            int64_t start = k > 0 ? chars - (k < chars ? k : chars) : (-k < chars ? -k : chars);
+            int b = utf8_byte_pos(x, xl, start);
+            out->sp[i] = x + b; out->sl[i] = xl - b;
+          }
+        }
+      } else if (!strcmp(f, "castVARCHAR")) {
+        int64_t k = a[1].v[i].i;
+        int live = out->valid[i] && (!active || active[i]);
+        out->sp[i] = x; out->sl[i] = xl; out->sm[i] = (uint8_t)xm;
+        if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
+        else if (k < xl) out->sl[i] = utf8_byte_pos(x, xl, k);
+      } else if (!strcmp(f, "locate") || !strcmp(f, "strpos")) {
+        /* locate(sub, str[, start]) / strpos(str, sub) */
+        const int swap = f[0] == 's';
+        const uint8_t* sub = swap ? y : x; int subl = swap ? yl : xl, subm = swap ? ym : xm;
+        const uint8_t* str = swap ? x : y; int strl = swap ? xl : yl, strm = swap ? xm : ym;
+        int64_t start = n->nargs == 3 ? a[2].v[i].i : 1;
+        int live = out->valid[i] && (!active || active[i]);
+        out->v[i].i = 0;
+        if (start < 1) { if (live) c->err |= 4; continue; }
+        if (strl <= 0 || subl <= 0) continue;
+        for (int p0 = utf8_byte_pos(str, strl, start - 1); p0 + subl <= strl; p0++) {
+          int eq = 1;
+          for (int k = 0; k < subl && eq; k++) eq = map_byte(str[p0 + k], strm) == map_byte(sub[k], subm);
+          if (eq) { out->v[i].i = utf8_chars(str, p0) + 1; break; }
+        }
+      } else if (!strcmp(f, "ascii")) {
+        out->v[i].i = xl > 0 ? (int8_t)map_byte(x[0], xm) : 0;
       } else if (!strcmp(f, "ltrim") || !strcmp(f, "rtrim") || !strcmp(f, "btrim") || !strcmp(f, "trim")) {
         int lo = 0, hi = xl;
         if (f[0] != 'r') while (lo < hi && x[lo] == ' ') lo++;
@@ -1250,5 +1299,5 @@ int64_t gdv_oracle_project_str(const char* program, const or_column* cols, int n
   }
   free(r);
   free_node(root);
-  return c.err ? -1 : total;
+  return c.err ? -(int64_t)(0x1000 + c.err) : total;  /* -(0x1000 + error bits) */
 }

@@ -156,6 +156,8 @@ class OracleError(Exception):
 def _raise(err):
     if err & 1:
         raise OracleError("divide by zero error")
+    if err & 4:
+        raise OracleError("invalid argument")
     raise OracleError(f"oracle error bits {err:#x}")
 
 
@@ -202,6 +204,8 @@ def _project_str(root, result_type, batch):
         data = np.zeros(max(cap, 1), dtype=np.uint8)
         total = lib().gdv_oracle_project_str(prog, cols, batch.num_columns, n, offsets.ctypes.data,
                                              data.ctypes.data, cap, validity.ctypes.data)
+        if total <= -0x1000:
+            _raise(-total - 0x1000)
         if total < 0:
             raise OracleError("oracle string evaluation failed")
         if total <= cap:

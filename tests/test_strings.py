@@ -255,3 +255,98 @@ def test_hip_string_hashes_match_oracle(n):
     got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
     for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
         assert_bit_exact(g, w, str(e))
+
+
+# ------------------------------------------------------------------ left / right / castVARCHAR / locate / strpos / ascii
+
+def _position_exprs(b, s, t):
+    i32, i64 = pa.int32(), pa.int64()
+    out = []
+
+    def add(name, node, typ):
+        out.append(b.make_expression(node, pa.field(name, typ)))
+    for k in (0, 1, 3, 100, -1, -4, -100):
+        add(f"left{k}", b.make_function("left", [s, b.make_literal(k, i32)], pa.string()), pa.string())
+        add(f"right{k}", b.make_function("right", [s, b.make_literal(k, i32)], pa.string()), pa.string())
+    for k in (0, 2, 7, 1000):
+        add(f"cast{k}", b.make_function("castVARCHAR", [s, b.make_literal(k, i64)], pa.string()), pa.string())
+    for sub in ("spark", "a", "é", "日本", ""):
+        add(f"locate_{sub}", b.make_function("locate", [b.make_literal(sub, pa.string()), s], i32), i32)
+        add(f"strpos_{sub}", b.make_function("strpos", [s, b.make_literal(sub, pa.string())], i32), i32)
+    add("locate_from3", b.make_function("locate", [b.make_literal("a", pa.string()), s, b.make_literal(3, i32)], i32), i32)
+    add("locate_col", b.make_function("locate", [t, s], i32), i32)
+    add("ascii", b.make_function("ascii", [s], i32), i32)
+    add("ascii_up", b.make_function("ascii", [b.make_function("upper", [s], pa.string())], i32), i32)
+    return out
+
+
+def _python_positions(vals, subs):
+    """The same expressions in plain Python (str = sequence of characters)."""
+    cols = []
+
+    def col(fn):
+        cols.append([None if v is None else fn(v) for v in vals])
+    for k in (0, 1, 3, 100, -1, -4, -100):
+        col(lambda v, k=k: "" if k == 0 else (v[:k] if k > 0 else v[:max(len(v) + k, 0)]))
+        col(lambda v, k=k: "" if k == 0 else (v[max(len(v) - k, 0):] if k > 0 else v[min(-k, len(v)):]))
+    for k in (0, 2, 7, 1000):
+        col(lambda v, k=k: v[:k])
+    for sub in ("spark", "a", "é", "日本", ""):
+        f = lambda v, sub=sub: 0 if not v or not sub else v.find(sub) + 1
+        col(f)
+        col(f)
+    col(lambda v: 0 if not v else v.find("a", 2) + 1)
+    cols.append([None if v is None or t is None else (0 if not v or not t else v.find(t) + 1)
+                 for v, t in zip(vals, subs)])
+    first = lambda v: 0 if not v else int(np.int8(np.uint8(v.encode()[0])))
+    col(first)
+    col(lambda v: 0 if not v else int(np.int8(np.uint8(v.encode()[0] - 32 if "a" <= v[0] <= "z" else v.encode()[0]))))
+    return cols
+
+
+def _position_batch(n, seed):
+    rng = np.random.default_rng(seed)
+    s = _strings(rng, n)
+    t = pa.array([None if rng.random() < 0.1 else ["a", "spark", "rk", "é", ""][int(rng.integers(0, 5))]
+                  for _ in range(n)], pa.string())
+    return pa.RecordBatch.from_arrays([s, t], names=["s", "t"])
+
+
+def test_oracle_position_functions_match_python():
+    batch = _position_batch(700, 9)
+    b = gandiva.TreeExprBuilder()
+    exprs = _position_exprs(b, b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1)))
+    got = oracle.project(exprs, batch)
+    want = _python_positions(batch.column(0).to_pylist(), batch.column(1).to_pylist())
+    for g, w, e in zip(got, want, exprs):
+        assert g.to_pylist() == w, e.result().name
+
+
+def test_oracle_position_functions_raise_on_bad_arguments():
+    batch = _position_batch(10, 1)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    for node in (b.make_function("castVARCHAR", [s, b.make_literal(-1, pa.int64())], pa.string()),
+                 b.make_function("locate", [b.make_literal("a", pa.string()), s, b.make_literal(0, pa.int32())],
+                                 pa.int32())):
+        with pytest.raises(Exception, match="invalid argument"):
+            oracle.project_one(node, node.return_type(), batch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 20011])
+def test_hip_position_functions_match_oracle(n):
+    from helpers import assert_bit_exact
+    batch = _position_batch(n, n + 3)
+    b = gandiva.TreeExprBuilder()
+    s, t = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = _position_exprs(b, s, t)
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        assert_bit_exact(g, w, e.result().name)
+    for node in (b.make_function("castVARCHAR", [s, b.make_literal(-1, pa.int64())], pa.string()),
+                 b.make_function("locate", [b.make_literal("a", pa.string()), s, b.make_literal(0, pa.int32())],
+                                 pa.int32())):
+        p = gandiva.make_projector(batch.schema, [b.make_expression(node, pa.field("r", node.return_type()))], None)
+        with pytest.raises(Exception, match="invalid argument"):
+            p.evaluate(batch)
