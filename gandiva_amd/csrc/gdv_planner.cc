@@ -201,6 +201,10 @@ struct Val {
   DataType type;
   std::set<int> vcols;
   std::string vlane;
+  // concat results are not a view: they are the list of their argument views, written one
+  // after the other by the output copy (piece expression, per-lane "piece present"
+  // predicate or "" for always).  Only an output expression or another concat can take one.
+  std::vector<std::pair<std::string, std::string>> pieces;
   bool never_null() const { return vcols.empty() && vlane.empty(); }
 };
 
@@ -386,7 +390,38 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->type = fn.return_type();
       out->vcols.clear();
       out->vlane.clear();
+      out->pieces.clear();
       const std::string ctype = out->type.CType();
+      const bool is_concat = fn.name() == "concat" || fn.name() == "concatOperator";
+      for (auto& a : args)
+        if (!a.pieces.empty() && !is_concat)
+          return Status::CodeGenError("Function " + fn.ToString() +
+                                      " not supported yet: a concat result can only be an output "
+                                      "expression or an argument of concat in the HIP backend. ");
+      if (is_concat) {
+        // concat: a null argument is the empty string, the result is never null;
+        // concatOperator (||): null if any argument is null
+        const bool never_null = fn.name() == "concat";
+        std::string lanes;
+        for (auto& a : args) {
+          const std::string present = never_null ? LaneValid(a) : "";
+          if (a.pieces.empty()) {
+            out->pieces.emplace_back(a.v, present == "true" ? "" : present);
+          } else {
+            for (auto& pc : a.pieces) {
+              std::string pv = AndExpr(pc.second, present);
+              out->pieces.emplace_back(pc.first, pv);
+            }
+          }
+          if (!never_null) {
+            out->vcols.insert(a.vcols.begin(), a.vcols.end());
+            lanes = AndExpr(lanes, a.vlane);
+          }
+        }
+        out->vlane = lanes;
+        out->v = "gdv_empty_str()";  // never read: consumers use the pieces
+        return Status::OK();
+      }
       if (def->flags & kPatternArg) {
         // like(s, 'pattern'[, 'escape']): the pattern is compiled here, at Make time, the way
         // the reference's LikeHolder compiles it to a regex once per expression
@@ -495,8 +530,11 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       std::string take = Tmp("bool", AndFull(LaneValid(c), c.v));
       GDV_RETURN_NOT_OK(Gen(*n.then_node(), AndExpr(active, take), &t));
       GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
+      if (!t.pieces.empty() || !e.pieces.empty())
+        return Status::CodeGenError("if/else over a concat result is not supported by the HIP backend yet");
       out->type = n.return_type();
       const std::string ctype = out->type.CType();
+      out->pieces.clear();
       out->v = Tmp(ctype, take + " ? " + t.v + " : " + e.v);
       out->vcols.clear();
       if (t.never_null() && e.never_null()) {
@@ -545,6 +583,9 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
                                     " is not supported by the HIP backend yet");
       Val x;
       GDV_RETURN_NOT_OK(Gen(*n.eval(), active, &x));
+      if (!x.pieces.empty())
+        return Status::CodeGenError("IN over a concat result is not supported by the HIP backend yet");
+      out->pieces.clear();
       out->type = boolean();
       out->vcols = x.vcols;
       out->vlane = x.vlane;
@@ -901,16 +942,37 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       before_loop << "  gdv_int32 tl" << E << " = 0;  // pass 0: bytes this tile produces\n"
                   << "  gdv_int32 vb" << E << " = 0;  // pass 1: where the next sub-tile's bytes start\n"
                   << "  if (PASS == 1) vb" << E << " = (gdv_int32)A.mask[" << tile << "];\n";
-      cg.Stmt("const gdv_int32 ln" + E + " = (" + ok + ") ? (" + v.v + ").len : 0;");
+      // the row's bytes: one view, or the pieces of a concat written back to back
+      std::vector<std::pair<std::string, std::string>> pieces = v.pieces;
+      if (pieces.empty()) pieces.emplace_back(v.v, "");
+      std::string total;
+      std::vector<std::string> plen;
+      for (size_t q = 0; q < pieces.size(); q++) {
+        const std::string name = "pl" + E + "_" + std::to_string(q);
+        cg.Stmt("const gdv_int32 " + name + " = (" + CodeGen::AndFull(ok, pieces[q].second) + ") ? (" +
+                pieces[q].first + ").len : 0;");
+        plen.push_back(name);
+        total += (q ? " + " : "") + name;
+      }
+      cg.Stmt("const gdv_int32 ln" + E + " = " + total + ";");
+      auto copy_to = [&](const std::string& dst, const std::string& indent) {
+        std::string at = dst;
+        for (size_t q = 0; q < pieces.size(); q++) {
+          cg.Stmt(indent + "if (" + plen[q] + " > 0) gdv_str_copy(" + at + ", " + pieces[q].first + ");");
+          at += " + " + plen[q];
+        }
+      };
       cg.Stmt("if (pass == 0) tl" + E + " += ln" + E + ";");
       cg.Stmt("else {");
       cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + ");");
       cg.Stmt("  const gdv_int32 cnt = gdv_wave_last(inc), loc = inc - ln" + E + ";");
       cg.Stmt("  if (live) outo" + E + "[row] = vb" + E + " + loc;");
       cg.Stmt("  if (cnt <= GDV_OUT_WIN) {  // wave-uniform: stage through LDS, store coalesced");
-      cg.Stmt("    if (" + ok + ") gdv_str_copy(lds_out + loc, " + v.v + ");");
+      copy_to("lds_out + loc", "    ");
       cg.Stmt("    gdv_flush_out(outd" + E + " + vb" + E + ", lds_out, cnt, lane);");
-      cg.Stmt("  } else if (" + ok + ") gdv_str_copy(outd" + E + " + vb" + E + " + loc, " + v.v + ");");
+      cg.Stmt("  } else {");
+      copy_to("outd" + E + " + vb" + E + " + loc", "    ");
+      cg.Stmt("  }");
       cg.Stmt("  vb" + E + " += cnt;");
       cg.Stmt("}");
       after_loop << "  if (pass == 0) { const gdv_int32 t = gdv_wave_sum(tl" << E << "); if (lane == 0) A.counts["

@@ -257,6 +257,13 @@ FunctionRegistry::FunctionRegistry() {
   add("substr", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("substring", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult,
       "substr_utf8_int64");
+  // concat (null argument = empty string, never null) and || (null if any argument is null),
+  // 2..6 arguments; planned as a list of pieces, not as a call (gdv_planner.cc)
+  for (int nargs = 2; nargs <= 6; nargs++) {
+    std::vector<DataType> ps(nargs, utf8());
+    add("concat", ps, utf8(), NullPolicy::kNullNever, kVarlenResult, "gdv_concat");
+    add("concatOperator", ps, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_concat");
+  }
   add("left", {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("right", {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("castVARCHAR", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);

@@ -93,11 +93,27 @@ typedef struct node {
   int32_t* soffs;  /* IN strings: nvals + 1 offsets into sbytes */
 } node;
 
+typedef struct arena_block { struct arena_block* next; size_t used, cap; uint8_t bytes[]; } arena_block;
 typedef struct {
   const or_column* cols;
   int ncols;
-  int err; /* 1 = divide by zero */
+  int err; /* 1 = divide by zero, 4 = invalid argument */
+  arena_block* arena; /* bytes of materialised strings (concat) of the chunk being evaluated */
 } ctx;
+static uint8_t* arena_alloc(ctx* c, size_t n) {
+  if (!c->arena || c->arena->used + n > c->arena->cap) {
+    size_t cap = n > (1u << 16) ? n : (1u << 16);
+    arena_block* b = (arena_block*)malloc(sizeof(arena_block) + cap);
+    b->next = c->arena; b->used = 0; b->cap = cap;
+    c->arena = b;
+  }
+  uint8_t* p = c->arena->bytes + c->arena->used;
+  c->arena->used += n;
+  return p;
+}
+static void arena_reset(ctx* c) {
+  while (c->arena) { arena_block* nx = c->arena->next; free(c->arena); c->arena = nx; }
+}
 
 /* ---------------------------------------------------------------- parsing */
 static const char* next_tok(const char** p, char* buf, size_t cap) {
@@ -672,7 +688,24 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
     out->valid[i] = v;
   }
   int op;
-  if (is_str(t0)) {
+  if (is_str(t0) && !strncmp(f, "concat", 6)) {
+    /* concat: a null argument is the empty string, never null; concatOperator (||): null if
+     * any argument is null.  The bytes are materialised (byte maps applied) in the chunk arena. */
+    const int never_null = f[6] == '\0';
+    for (int i = 0; i < cnt; i++) {
+      if (never_null) out->valid[i] = 1;
+      size_t total = 0;
+      for (int k = 0; k < n->nargs; k++) if (a[k].valid[i]) total += (size_t)a[k].sl[i];
+      if (!out->valid[i]) total = 0;
+      uint8_t* dst = arena_alloc(c, total ? total : 1);
+      size_t at = 0;
+      for (int k = 0; k < n->nargs && total; k++) {
+        if (!a[k].valid[i]) continue;
+        for (int b = 0; b < a[k].sl[i]; b++) dst[at++] = map_byte(a[k].sp[i][b], a[k].sm[i]);
+      }
+      out->sp[i] = dst; out->sl[i] = (int32_t)total; out->sm[i] = 0;
+    }
+  } else if (is_str(t0)) {
     const int two_str = n->nargs >= 2 && is_str(a[1].type);
     for (int i = 0; i < cnt; i++) {
       const uint8_t* x = a[0].sp[i]; int xl = a[0].sl[i], xm = a[0].sm[i];
@@ -1163,7 +1196,7 @@ typedef struct {
 
 static void* run_job(void* arg) {
   job* j = (job*)arg;
-  ctx c = {j->cols, j->ncols, 0};
+  ctx c = {j->cols, j->ncols, 0, NULL};
   if (!g_force_generic && f64_fast_ok(j->root, j->cols)) {
     double* scratch = (double*)malloc(sizeof(double) * CHUNK * (size_t)f64_nodes(j->root));
     int used[64], nused = 0;
@@ -1196,6 +1229,7 @@ static void* run_job(void* arg) {
     int cnt = (int)((j->row_hi - row) < CHUNK ? (j->row_hi - row) : CHUNK);
     eval(j->root, &c, row, cnt, NULL, r);
     store_chunk(j->root->type, r, row, cnt, j->data, j->validity);
+    arena_reset(&c);
   }
   free(r);
   j->err = c.err;
@@ -1280,7 +1314,7 @@ int64_t gdv_oracle_project_str(const char* program, const or_column* cols, int n
   const char* p = program;
   node* root = parse(&p, cols);
   if (!root) return -1;
-  ctx c = {cols, ncols, 0};
+  ctx c = {cols, ncols, 0, NULL};
   vec* r = (vec*)malloc(sizeof(vec));
   int64_t total = 0;
   offsets[0] = 0;
@@ -1296,6 +1330,7 @@ int64_t gdv_oracle_project_str(const char* program, const or_column* cols, int n
       total += len;
       offsets[rr + 1] = (int32_t)total;
     }
+    arena_reset(&c);
   }
   free(r);
   free_node(root);

@@ -350,3 +350,81 @@ def test_hip_position_functions_match_oracle(n):
         p = gandiva.make_projector(batch.schema, [b.make_expression(node, pa.field("r", node.return_type()))], None)
         with pytest.raises(Exception, match="invalid argument"):
             p.evaluate(batch)
+
+
+# ------------------------------------------------------------------ concat / ||
+
+def _concat_exprs(b, s, t):
+    lit = lambda v: b.make_literal(v, pa.string())
+    S = pa.string()
+    out = []
+
+    def add(name, node):
+        out.append(b.make_expression(node, pa.field(name, S)))
+    add("concat2", b.make_function("concat", [s, t], S))
+    add("pipes2", b.make_function("concatOperator", [s, t], S))
+    add("concat3", b.make_function("concat", [s, lit(" - "), b.make_function("upper", [t], S)], S))
+    add("pipes3", b.make_function("concatOperator", [b.make_function("substr", [s, b.make_literal(2, pa.int64()),
+                                                                              b.make_literal(3, pa.int64())], S),
+                                                 lit("|"), b.make_function("lower", [s], S)], S))
+    add("nested", b.make_function("concat", [b.make_function("concatOperator", [s, t], S), lit("."),
+                                             b.make_function("concat", [t, t], S)], S))
+    add("six", b.make_function("concat", [s, t, s, lit(""), t, lit("日本")], S))
+    return out
+
+
+def _python_concat(ss, ts):
+    e = lambda v: "" if v is None else v
+    cols = [[e(s) + e(t) for s, t in zip(ss, ts)],
+            [None if s is None or t is None else s + t for s, t in zip(ss, ts)],
+            [e(s) + " - " + ("" if t is None else _ascii_upper(t)) for s, t in zip(ss, ts)],
+            [None if s is None else s[1:4] + "|" + _ascii_lower(s) for s in ss],
+            [("" if s is None or t is None else s + t) + "." + e(t) + e(t) for s, t in zip(ss, ts)],
+            [e(s) + e(t) + e(s) + e(t) + "日本" for s, t in zip(ss, ts)]]
+    return cols
+
+
+def _ascii_upper(v):
+    return "".join(chr(ord(c) - 32) if "a" <= c <= "z" else c for c in v)
+
+
+def _ascii_lower(v):
+    return "".join(chr(ord(c) + 32) if "A" <= c <= "Z" else c for c in v)
+
+
+def test_oracle_concat_matches_python():
+    batch = _position_batch(500, 21)
+    b = gandiva.TreeExprBuilder()
+    exprs = _concat_exprs(b, b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1)))
+    got = oracle.project(exprs, batch)
+    want = _python_concat(batch.column(0).to_pylist(), batch.column(1).to_pylist())
+    for g, w, e in zip(got, want, exprs):
+        assert g.to_pylist() == w, e.result().name
+
+
+def test_concat_results_cannot_feed_other_functions_yet():
+    from gandiva_amd import _capi, gandiva as gg
+    import ctypes as C
+    schema = pa.schema([("s", pa.string())])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(schema.field(0))
+    cc = b.make_function("concat", [s, s], pa.string())
+    e = b.make_expression(b.make_function("like", [cc, b.make_literal("%a%", pa.string())], pa.bool_()),
+                          pa.field("r", pa.bool_()))
+    arr = (C.c_void_p * 1)(e._h)
+    rc = _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 0)
+    assert rc == 40 and "concat" in _capi.last_error()      # CodeGenError, said plainly
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 20011])
+def test_hip_concat_matches_oracle(n):
+    from helpers import assert_bit_exact
+    batch = _position_batch(n, n + 5)
+    b = gandiva.TreeExprBuilder()
+    s, t = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = _concat_exprs(b, s, t)
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        g.validate(full=True)
+        assert_bit_exact(g, w, e.result().name)
