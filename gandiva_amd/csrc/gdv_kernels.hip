@@ -147,10 +147,12 @@ template <typename IndexT>
 __global__ void __launch_bounds__(256)
 EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offsets,
             int64_t nwords, int subtiles, int64_t row_base, IndexT* __restrict__ out) {
-  __shared__ IndexT stage[4][kEmitWords * 64];
+  // positions inside the wave's 4096-row tile fit 12 bits: staging them as uint16 keeps the
+  // window at 8 KiB per wave (32 KiB per workgroup, 5 workgroups per CU) whatever IndexT is
+  __shared__ uint16_t stage[4][kEmitWords * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  IndexT* buf = stage[wave];
+  uint16_t* buf = stage[wave];
   const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
     const int64_t w = t * kEmitWords + lane;
@@ -159,14 +161,14 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
     const uint32_t incl = (uint32_t)WaveInclusiveScan(c, lane);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     uint32_t slot = incl - c;
-    const int64_t row0 = row_base + w * 64;
+    const int64_t tile_row0 = row_base + t * (int64_t)(kEmitWords * 64);
     while (m) {
-      buf[slot++] = static_cast<IndexT>(row0 + __builtin_ctzll(m));
+      buf[slot++] = static_cast<uint16_t>((lane << 6) + __builtin_ctzll(m));
       m &= m - 1;
     }
     __builtin_amdgcn_wave_barrier();
     const uint64_t base = offsets[(t * kEmitWords) / subtiles];
-    for (uint32_t j = lane; j < total; j += 64) out[base + j] = buf[j];
+    for (uint32_t j = lane; j < total; j += 64) out[base + j] = static_cast<IndexT>(tile_row0 + buf[j]);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -213,7 +215,7 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
   if (subtiles <= 0 || kEmitWords % subtiles != 0) return hipErrorInvalidValue;
   const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
   int64_t grid = (ntiles + 3) / 4;
-  const int64_t cap = (int64_t)num_cus * 4;
+  const int64_t cap = (int64_t)num_cus * 5;  // LDS allows 5 workgroups per CU
   if (grid > cap) grid = cap;
   switch (index_bytes) {
     case 2:
