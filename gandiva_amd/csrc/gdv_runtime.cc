@@ -31,6 +31,7 @@ void Runtime::Probe() {
   has_device_ = true;
   int dev = 0;
   (void)hipGetDevice(&dev);
+  device_ = dev;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
     num_cus_ = prop.multiProcessorCount;
@@ -51,6 +52,18 @@ Status Runtime::EnsureDevice() {
     return Status::ExecutionError(
         "no HIP device available: gandiva_amd evaluates on the GPU only (there is no CPU "
         "fallback)");
+  // One device per process (the deployment model: one process per GPU).  Code objects, the
+  // buffer pool and the all-ones word belong to the device that was current at first use.
+  // A thread that never chose a device starts on device 0: switch it to ours rather than run
+  // on the wrong GPU.
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev != device_) {
+    hipError_t e = hipSetDevice(device_);
+    if (e != hipSuccess)
+      return Status::ExecutionError("gandiva_amd is bound to HIP device " + std::to_string(device_) +
+                                    " (current at first use) and could not switch the calling thread to it: " +
+                                    hipGetErrorString(e));
+  }
   return Status::OK();
 }
 

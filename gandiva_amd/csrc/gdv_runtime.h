@@ -68,6 +68,7 @@ class Runtime {
   bool probed_ = false;
   bool has_device_ = false;
   int num_cus_ = 256;
+  int device_ = 0;  // the device that was current at first use
   std::string arch_ = "gfx950";
   std::map<std::string, std::unique_ptr<CompiledKernel>> kernels_;
   std::multimap<size_t, void*> free_blocks_;
