@@ -160,12 +160,112 @@ class EvalTrace {
   hipEvent_t t0_ = nullptr, t1_ = nullptr;
 };
 
+// Host-buffer path.  Large batches: one device buffer and one copy per Arrow buffer (the
+// copies are PCIe-bound anyway).  Small batches (<= kPackRows rows, while they fit the
+// block): every staged input and every fixed-size output shares ONE device block mirrored by
+// ONE pinned host block — one H2D before the launches, one D2H after them — because a
+// pageable hipMemcpyAsync costs 10-25 us however small it is and a ten-expression projection
+// would issue ~30 of them (C2 at 1024 rows: 397 -> 74 us per Evaluate).
 struct Staging {
+  static constexpr int64_t kPackRows = 131072;
   std::deque<DeviceBuffer> buffers;  // deque: references stay valid across Add()
   DeviceBuffer& Add() {
     buffers.emplace_back();
     return buffers.back();
   }
+  ~Staging() {
+    if (pin_ != nullptr) Runtime::Get().ReleasePinned(pin_);
+  }
+
+  Status EnablePacked() {
+    GDV_RETURN_NOT_OK(Runtime::Get().AcquirePinned(&pin_));
+    GDV_RETURN_NOT_OK(block_.Allocate(Runtime::kPinnedBlock));
+    packed_ = true;
+    return Status::OK();
+  }
+
+  // device copy of n host bytes, readable (zero-filled) up to `alloc` bytes
+  Status In(const void* src, size_t n, size_t alloc, hipStream_t stream, void** dev) {
+    if (alloc < n) alloc = n;
+    size_t off = 0;
+    if (packed_ && !flushed_ && Reserve(alloc, &off)) {
+      if (n > 0) std::memcpy(pin_ + off, src, n);
+      if (alloc > n) std::memset(pin_ + off + n, 0, alloc - n);
+      *dev = block_.as<char>() + off;
+      in_end_ = used_;
+      return Status::OK();
+    }
+    DeviceBuffer& d = Add();
+    GDV_RETURN_NOT_OK(d.Allocate(std::max<size_t>(alloc, 8)));
+    if (alloc > n) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(d.get(), 0, alloc, stream));
+    if (n > 0) GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(d.get(), src, n, hipMemcpyHostToDevice, stream));
+    *dev = d.get();
+    return Status::OK();
+  }
+  // all In() regions -> device with one copy; call once, before the first launch
+  Status FlushIn(hipStream_t stream) {
+    flushed_ = true;
+    if (packed_ && in_end_ > 0)
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(block_.get(), pin_, in_end_, hipMemcpyHostToDevice, stream));
+    return Status::OK();
+  }
+  // device region of `alloc` bytes whose first `copy` bytes FetchOut/Deliver bring to `user`
+  Status Out(size_t alloc, size_t copy, void* user, void** dev) {
+    size_t off = 0;
+    OutCopy oc{user, nullptr, 0, copy, false};
+    if (packed_ && Reserve(alloc, &off)) {
+      oc.off = off;
+      oc.packed = true;
+      *dev = block_.as<char>() + off;
+    } else {
+      DeviceBuffer& d = Add();
+      GDV_RETURN_NOT_OK(d.Allocate(std::max<size_t>(alloc, 8)));
+      oc.dev = d.get();
+      *dev = d.get();
+    }
+    outs_.push_back(oc);
+    return Status::OK();
+  }
+  Status FetchOut(hipStream_t stream) {
+    size_t lo = used_, hi = 0;
+    for (auto& o : outs_) {
+      if (o.n == 0) continue;
+      if (o.packed) {
+        lo = std::min(lo, o.off);
+        hi = std::max(hi, o.off + o.n);
+      } else {
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(o.user, o.dev, o.n, hipMemcpyDeviceToHost, stream));
+      }
+    }
+    if (hi > lo)
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(pin_ + lo, block_.as<char>() + lo, hi - lo,
+                                           hipMemcpyDeviceToHost, stream));
+    return Status::OK();
+  }
+  void Deliver() {  // after the stream is drained
+    for (auto& o : outs_)
+      if (o.packed && o.n > 0) std::memcpy(o.user, pin_ + o.off, o.n);
+  }
+
+ private:
+  struct OutCopy {
+    void* user;
+    void* dev;
+    size_t off, n;
+    bool packed;
+  };
+  bool Reserve(size_t bytes, size_t* off) {
+    const size_t at = (used_ + 255) & ~size_t{255};
+    if (at + bytes > Runtime::kPinnedBlock) return false;
+    *off = at;
+    used_ = at + bytes;
+    return true;
+  }
+  bool packed_ = false, flushed_ = false;
+  DeviceBuffer block_;
+  char* pin_ = nullptr;
+  size_t used_ = 0, in_end_ = 0;
+  std::vector<OutCopy> outs_;
 };
 
 // host bitmap bytes covering bits [off, off+rows) -> zero-padded device words
@@ -174,12 +274,9 @@ Status StageBitmap(const void* host, int64_t off, int64_t rows, hipStream_t stre
   const int64_t first = off / 8;
   const int64_t len = BytesForBits(off + rows) - first;
   const int64_t words = (len + 7) / 8 + 1;
-  DeviceBuffer& d = st->Add();
-  GDV_RETURN_NOT_OK(d.Allocate(words * 8));
-  GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(d.get(), 0, words * 8, stream));
-  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(d.get(), static_cast<const char*>(host) + first, len,
-                                       hipMemcpyHostToDevice, stream));
-  out->p = d.as<uint64_t>();
+  void* dev = nullptr;
+  GDV_RETURN_NOT_OK(st->In(static_cast<const char*>(host) + first, len, words * 8, stream, &dev));
+  out->p = static_cast<const uint64_t*>(dev);
   out->shift = static_cast<int32_t>(off % 8);
   out->nwords = words;
   return Status::OK();
@@ -206,18 +303,11 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
           return Status::Invalid("column '" + name + "': offsets buffer too small");
         const char* osrc = static_cast<const char*>(c.offsets) + c.offset * 4;
         if (mem == MemKind::kHost) {
-          DeviceBuffer& dof = st->Add();
-          GDV_RETURN_NOT_OK(dof.Allocate((num_rows + 1) * 4));
-          GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dof.get(), osrc, (num_rows + 1) * 4,
-                                               hipMemcpyHostToDevice, stream));
-          DeviceBuffer& dd = st->Add();
-          GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(c.data_size, 8)));
-          if (c.data_size < 8) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dd.get(), 0, 8, stream));
-          if (c.data_size > 0)
-            GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dd.get(), c.data, c.data_size,
-                                                 hipMemcpyHostToDevice, stream));
-          args->SetInOffsets(static_cast<int>(k), dof.get());
-          args->SetInData(static_cast<int>(k), dd.get());
+          void *dof = nullptr, *dd = nullptr;
+          GDV_RETURN_NOT_OK(st->In(osrc, (num_rows + 1) * 4, (num_rows + 1) * 4, stream, &dof));
+          GDV_RETURN_NOT_OK(st->In(c.data, c.data_size, std::max<int64_t>(c.data_size, 8), stream, &dd));
+          args->SetInOffsets(static_cast<int>(k), dof);
+          args->SetInData(static_cast<int>(k), dd);
         } else if (c.data_size < 8) {
           // the kernels' 8-byte loads need 8 readable bytes ending at the limit: a tiny
           // buffer is copied into a zero-padded one
@@ -255,11 +345,9 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
                                  std::to_string(c.offset + num_rows) + " rows)");
         const char* src = static_cast<const char*>(c.data) + c.offset * w;
         if (mem == MemKind::kHost) {
-          DeviceBuffer& d = st->Add();
-          GDV_RETURN_NOT_OK(d.Allocate(num_rows * w));
-          GDV_HIP_RETURN_NOT_OK(
-              hipMemcpyAsync(d.get(), src, num_rows * w, hipMemcpyHostToDevice, stream));
-          args->SetInData(static_cast<int>(k), d.get());
+          void* d = nullptr;
+          GDV_RETURN_NOT_OK(st->In(src, num_rows * w, num_rows * w, stream, &d));
+          args->SetInData(static_cast<int>(k), d);
         } else {
           args->SetInData(static_cast<int>(k), src);
         }
@@ -367,6 +455,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   DeviceBuffer tile_counts, tile_starts;
   // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
   StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
+  if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
 
@@ -374,12 +463,9 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     const int w = plan_.mode == SelectionMode::kUInt16 ? 2 : plan_.mode == SelectionMode::kUInt32 ? 4 : 8;
     if (out_rows > 0 && sel->indices == nullptr) return Status::Invalid("selection vector has no buffer");
     if (mem == MemKind::kHost) {
-      DeviceBuffer& d = st.Add();
-      GDV_RETURN_NOT_OK(d.Allocate(std::max<int64_t>(out_rows, 1) * w));
-      if (out_rows > 0)
-        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(d.get(), sel->indices, out_rows * w,
-                                             hipMemcpyHostToDevice, stream));
-      args.SetPtr(ArgLayout::kOffSel, d.get());
+      void* d = nullptr;
+      GDV_RETURN_NOT_OK(st.In(sel->indices, out_rows * w, std::max<int64_t>(out_rows, 1) * w, stream, &d));
+      args.SetPtr(ArgLayout::kOffSel, d);
     } else {
       args.SetPtr(ArgLayout::kOffSel, sel->indices);
     }
@@ -400,17 +486,13 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       if (outs[e].validity_size < BytesForBits(out_rows) || outs[e].data_size < need_data_host ||
           (out_rows > 0 && (outs[e].validity == nullptr || (outs[e].data == nullptr && !t.is_varlen()))))
         return Status::Invalid("output buffer " + std::to_string(e) + " too small");
-      DeviceBuffer& dv = st.Add();
-      GDV_RETURN_NOT_OK(dv.Allocate(std::max<int64_t>(need_valid_dev, 8)));
-      dev_valid[e] = dv.get();
+      const int64_t vbytes = out_rows > 0 ? BytesForBits(out_rows) : 0;
+      GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_valid_dev, 8), vbytes, outs[e].validity, &dev_valid[e]));
       if (t.is_varlen()) {
-        DeviceBuffer& dof = st.Add();
-        GDV_RETURN_NOT_OK(dof.Allocate(need_offs));
-        dev_offs[e] = dof.get();
+        GDV_RETURN_NOT_OK(st.Out(need_offs, out_rows > 0 ? need_offs : 0, outs[e].offsets, &dev_offs[e]));
       } else {
-        DeviceBuffer& dd = st.Add();
-        GDV_RETURN_NOT_OK(dd.Allocate(std::max<int64_t>(need_data_dev, 8)));
-        dev_data[e] = dd.get();
+        const int64_t dbytes = out_rows == 0 ? 0 : (t.id == kBool ? vbytes : need_data_dev);
+        GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_data_dev, 8), dbytes, outs[e].data, &dev_data[e]));
       }
     } else {
       if (outs[e].validity_size < need_valid_dev || outs[e].data_size < need_data_dev)
@@ -448,6 +530,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     args.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
   }
 
+  GDV_RETURN_NOT_OK(st.FlushIn(stream));
   const int64_t grid = GridFor(plan_, out_rows);
   EvalTrace trace("project", plan_.kernel_name, out_rows, stream);
   args.Set64(ArgLayout::kOffAux0, 0);
@@ -510,28 +593,16 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   if (plan_.can_raise)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
   if (mem == MemKind::kHost) {
-    for (int e = 0; e < num_outs; e++) {
-      const DataType& t = plan_.output_types[e];
-      const int64_t vbytes = BytesForBits(out_rows);
-      if (out_rows == 0) continue;
-      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].validity, dev_valid[e], vbytes,
-                                           hipMemcpyDeviceToHost, stream));
-      if (t.is_varlen()) {
-        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].offsets, dev_offs[e], (out_rows + 1) * 4,
+    GDV_RETURN_NOT_OK(st.FetchOut(stream));  // validity, fixed-width values, offsets
+    for (int e = 0; e < num_outs; e++)       // var-len bytes: sized after the length pass
+      if (plan_.output_types[e].is_varlen() && out_rows > 0 && totals[e] > 0)
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
                                              hipMemcpyDeviceToHost, stream));
-        if (totals[e] > 0)
-          GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
-                                               hipMemcpyDeviceToHost, stream));
-      } else {
-        const int64_t dbytes = t.id == kBool ? vbytes : DataBytes(t, out_rows);
-        GDV_HIP_RETURN_NOT_OK(
-            hipMemcpyAsync(outs[e].data, dev_data[e], dbytes, hipMemcpyDeviceToHost, stream));
-      }
-    }
   }
   const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync);
   if (must_sync) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  if (mem == MemKind::kHost) st.Deliver();
   return Status::OK();
 }
 
@@ -579,7 +650,9 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   Staging st;
   DeviceBuffer mask, counts, offsets, chunk_sums, total, err, staged_out;
   StreamDrain drain{stream, true};  // declared last: drains before any pooled block is freed
+  if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  GDV_RETURN_NOT_OK(st.FlushIn(stream));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 
   const int64_t nwords = (num_rows + 63) / 64;

@@ -235,6 +235,35 @@ Status Runtime::Alloc(size_t bytes, void** ptr) {
   return Status::OK();
 }
 
+Status Runtime::AcquirePinned(char** p) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!pinned_free_.empty()) {
+      *p = pinned_free_.back();
+      pinned_free_.pop_back();
+      return Status::OK();
+    }
+  }
+  void* q = nullptr;
+  if (hipHostMalloc(&q, kPinnedBlock, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::OutOfMemory("hipHostMalloc of the pinned staging block failed");
+  }
+  *p = static_cast<char*>(q);
+  return Status::OK();
+}
+
+void Runtime::ReleasePinned(char* p) {
+  if (p == nullptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (pinned_free_.size() < 8) {
+    pinned_free_.push_back(p);
+  } else {
+    (void)hipHostFree(p);
+  }
+}
+
 void Runtime::Free(void* ptr) {
   if (!ptr) return;
   std::lock_guard<std::mutex> g(mu_);

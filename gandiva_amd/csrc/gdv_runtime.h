@@ -53,6 +53,12 @@ class Runtime {
   void Free(void* ptr);
   void TrimPool();
 
+  // Page-locked host blocks of kPinnedBlock bytes (small-batch host path: one H2D and one
+  // D2H per Evaluate instead of one per buffer).  Returned blocks are kept for reuse.
+  static constexpr size_t kPinnedBlock = 16u << 20;
+  Status AcquirePinned(char** p);
+  void ReleasePinned(char* p);
+
   // Device-resident bitmap word with all 64 bits set: what a column WITHOUT a validity
   // (or with an elided all-valid) buffer is bound to, so kernels never branch on "has nulls".
   Status AllOnesWord(const uint64_t** ptr);
@@ -73,6 +79,7 @@ class Runtime {
   std::map<std::string, std::unique_ptr<CompiledKernel>> kernels_;
   std::multimap<size_t, void*> free_blocks_;
   std::map<void*, size_t> live_blocks_;
+  std::vector<char*> pinned_free_;
   size_t cached_bytes_ = 0;
   uint64_t* all_ones_ = nullptr;
   void Probe();
