@@ -35,7 +35,9 @@
  * the current HIP device and are used in place (zero-copy; this is the measured path);
  * `GDV_MEM_HOST` buffers are staged through HBM by the library (correctness path).
  * There is no CPU evaluation path: without a HIP device every evaluate call fails with
- * GDV_EXECUTION_ERROR.
+ * GDV_EXECUTION_ERROR.  The library binds to the HIP device that is current at its first
+ * use (one device per process, the one-process-per-GPU deployment model); threads calling
+ * in with another current device are switched to it.
  *
  * Threading: all functions may be called concurrently; evaluate is re-entrant on one
  * handle (per-call state only), as the reference's `nogil` bindings require (PA:27-279).
@@ -107,7 +109,9 @@ typedef enum {
 typedef enum { GDV_MEM_HOST = 0, GDV_MEM_DEVICE = 1 } gdv_mem_kind;
 
 /* gdv_projector_evaluate flags */
-#define GDV_EVAL_ASYNC 1u /* device buffers: enqueue on `stream` and return without waiting */
+#define GDV_EVAL_ASYNC 1u /* device buffers: enqueue on `stream` and return without waiting
+                           * (plans that can raise, or that produce utf8/binary, wait anyway:
+                           * the error word / byte totals are read back) */
 
 typedef struct gdv_schema gdv_schema_t;
 typedef struct gdv_node gdv_node_t;
