@@ -1244,6 +1244,53 @@ static void* run_job(void* arg) {
  */
 void gdv_oracle_force_generic(int on) { g_force_generic = on; }
 
+/* Persistent worker pool for the timed baseline: creating a thread per row range per
+ * expression costs more than the arithmetic once the host has hundreds of cores. */
+static struct {
+  pthread_mutex_t mu, caller;
+  pthread_cond_t work, done;
+  job* jobs;
+  int njobs, next, finished, nworkers;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER,
+            PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, 0};
+
+static void* pool_worker(void* arg) {
+  (void)arg;
+  pthread_mutex_lock(&g_pool.mu);
+  for (;;) {
+    while (g_pool.next >= g_pool.njobs) pthread_cond_wait(&g_pool.work, &g_pool.mu);
+    job* j = &g_pool.jobs[g_pool.next++];
+    pthread_mutex_unlock(&g_pool.mu);
+    run_job(j);
+    pthread_mutex_lock(&g_pool.mu);
+    if (++g_pool.finished == g_pool.njobs) pthread_cond_signal(&g_pool.done);
+  }
+  return NULL;
+}
+
+static void pool_run(job* jobs, int njobs, int threads) {
+  pthread_mutex_lock(&g_pool.caller); /* one parallel evaluation at a time */
+  pthread_mutex_lock(&g_pool.mu);
+  while (g_pool.nworkers < threads) {
+    pthread_t th;
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+    if (pthread_create(&th, &at, pool_worker, NULL) != 0) break;
+    g_pool.nworkers++;
+  }
+  g_pool.jobs = jobs;
+  g_pool.njobs = njobs;
+  g_pool.next = 0;
+  g_pool.finished = 0;
+  pthread_cond_broadcast(&g_pool.work);
+  while (g_pool.finished < njobs) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+  g_pool.njobs = 0;
+  g_pool.next = 0;
+  pthread_mutex_unlock(&g_pool.mu);
+  pthread_mutex_unlock(&g_pool.caller);
+}
+
 int gdv_oracle_project(const char* program, const or_column* cols, int ncols, int64_t n,
                        void* out_data, uint8_t* out_validity, int threads) {
   const char* p = program;
@@ -1252,24 +1299,22 @@ int gdv_oracle_project(const char* program, const or_column* cols, int ncols, in
   if (threads < 1) threads = 1;
   int64_t chunks = (n + CHUNK - 1) / CHUNK;
   if (threads > chunks) threads = (int)(chunks ? chunks : 1);
-  job* jobs = (job*)calloc(threads, sizeof(job));
-  pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
-  int64_t per = (chunks + threads - 1) / threads * CHUNK;
+  /* row ranges (multiples of CHUNK): a few per thread so stragglers even out */
+  int njobs = threads == 1 ? 1 : threads * 4;
+  if (njobs > chunks) njobs = (int)(chunks ? chunks : 1);
+  job* jobs = (job*)calloc(njobs, sizeof(job));
+  int64_t per = (chunks + njobs - 1) / njobs * CHUNK;
   int err = 0;
-  for (int t = 0; t < threads; t++) {
+  for (int t = 0; t < njobs; t++) {
     int64_t lo = per * t, hi = lo + per;
     if (lo > n) lo = n;
     if (hi > n) hi = n;
     jobs[t] = (job){root, cols, ncols, lo, hi, out_data, out_validity, 0};
-    if (threads == 1) run_job(&jobs[t]);
-    else pthread_create(&th[t], NULL, run_job, &jobs[t]);
   }
-  for (int t = 0; t < threads; t++) {
-    if (threads > 1) pthread_join(th[t], NULL);
-    err |= jobs[t].err;
-  }
+  if (threads == 1) run_job(&jobs[0]);
+  else pool_run(jobs, njobs, threads);
+  for (int t = 0; t < njobs; t++) err |= jobs[t].err;
   free(jobs);
-  free(th);
   free_node(root);
   return err;
 }
