@@ -43,11 +43,36 @@ def parse():
     return p.parse_args()
 
 
+def effective_cores():
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU
+    quota (a 256-CPU host with cpu.max = 16 CPUs runs 16 threads at full speed and 256
+    threads at a fraction of it — measured, tools/cpu_scaling.py)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, -(-int(quota) // int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, -(-q // per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline_c2(rows):
     """Oracle ("port"), expression-at-a-time like the reference, all host cores."""
     from gandiva_amd import workloads as W
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     batch = W.c2_batch(rows)
     exprs = W.c2_expressions()
     outs = oracle.alloc_outputs(exprs, rows)          # pre-touched, reused by every pass
@@ -102,7 +127,7 @@ def pyarrow_compute_c2(batch):
 def cpu_baseline_c3(rows):
     from gandiva_amd import workloads as W
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     batch = W.c3_batch(rows)
     cond = W.c3_condition()
     t0 = time.perf_counter()
@@ -122,7 +147,7 @@ def cpu_baseline_c3(rows):
 def cpu_baseline_c4(rows):
     from gandiva_amd import workloads as W
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     rows = min(rows, 1 << 22)
     batch = W.c4_batch(rows)
     exprs = W.c4_expressions()
@@ -207,6 +232,7 @@ def main():
         proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
         outs = proj.evaluate_device(dbatch)  # allocates + first touch
         bytes_per_row = W.C2_BYTES_PER_ROW
+        read_per_row = 4 * 8 + 4 / 8
 
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
@@ -224,7 +250,7 @@ def main():
         proj = gandiva.make_projector(W.c1_schema(), W.c1_expressions(), None)
         outs = proj.evaluate_device(dbatch)
         bytes_per_row = 16 + 1 / 8
-
+        read_per_row = 12
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
         kernel_desc = "fused (a+b)*c int32 projection kernel"
@@ -234,6 +260,7 @@ def main():
         proj = gandiva.make_projector(W.c4_schema(), W.c4_expressions(), None)
         outs = proj.evaluate_device(dbatch)
         bytes_per_row = 3 * 16 + 4 + 2 * 16 + 4 + 3 / 8  # inputs carry no validity buffers here
+        read_per_row = 3 * 16 + 4
 
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
@@ -246,6 +273,7 @@ def main():
         in_bytes = 4 * (rows + 1) + int(sum(o.data_used for o in outs[2:]))  # offsets + data (upper preserves bytes)
         out_bytes = rows / 8 + sum(4 * (rows + 1) + o.data_used for o in outs[1:]) + 3 * rows / 8
         bytes_per_row = (in_bytes + out_bytes) / rows
+        read_per_row = in_bytes / rows
 
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
@@ -257,6 +285,7 @@ def main():
         out = torch.empty(rows, dtype=torch.int32, device="cuda")
         sel = flt.evaluate_device(dbatch, "int32", out=out)
         bytes_per_row = 16 + 4 * sel.num_slots / rows
+        read_per_row = 16
 
         def step():
             flt.evaluate_device(dbatch, "int32", out=out)
@@ -328,6 +357,11 @@ def main():
                 "traffic": load_traffic(args.workload) if not args.rows else None,
                 "kernel": kernel_desc,
                 "algorithmic_bytes_per_row": round(bytes_per_row, 3),
+                # the read and write shares of `achieved`, separately
+                "read_bytes_per_row": round(read_per_row, 3),
+                "write_bytes_per_row": round(bytes_per_row - read_per_row, 3),
+                "achieved_read": round(achieved * read_per_row / bytes_per_row, 1),
+                "achieved_write": round(achieved * (1 - read_per_row / bytes_per_row), 1),
                 "kernel_ms": round(mean_dev_ms, 4),
                 "kernel_ms_min": round(min(dev_ms), 4),
                 "kernel_ms_max": round(max(dev_ms), 4),

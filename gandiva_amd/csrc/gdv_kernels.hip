@@ -133,6 +133,34 @@ ScanApply(const uint32_t* __restrict__ counts, int64_t m, const uint64_t* __rest
   }
 }
 
+// The whole scan in one launch when a segment fits one workgroup's chunk (m <= 4096 counts,
+// i.e. batches up to ~10^6 rows): small batches are launch-bound, two launches fewer matter.
+__global__ void __launch_bounds__(kScanThreads)
+ScanSmall(const uint32_t* __restrict__ counts, int64_t m, int64_t stride,
+          uint64_t* __restrict__ offsets, uint64_t* __restrict__ total_out, ClosingOffsets closing) {
+  counts += (int64_t)blockIdx.x * stride;
+  offsets += (int64_t)blockIdx.x * stride;
+  const int64_t base = (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t c[kScanPerThread];
+  uint64_t local = 0;
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    c[i] = (base + i < m) ? counts[base + i] : 0u;
+    local += c[i];
+  }
+  uint64_t total;
+  uint64_t prefix = BlockExclusiveScan(local, &total);
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    if (base + i < m) offsets[base + i] = prefix;
+    prefix += c[i];
+  }
+  if (threadIdx.x == 0) {
+    total_out[blockIdx.x] = total;
+    if (closing.p[blockIdx.x] != nullptr) *closing.p[blockIdx.x] = static_cast<int32_t>(total);
+  }
+}
+
 // Index emission, LDS-staged.  One wavefront owns 64 consecutive match words (4096 rows):
 // lane i takes word i, a wave-level exclusive scan of the popcounts gives every lane its
 // slot range, the lane walks its word's set bits (ctz / clear-lowest) into the wave's
@@ -194,6 +222,11 @@ hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t
     return e;
   }
   const int64_t nb = ScanChunks(m);
+  if (nb == 1) {
+    hipLaunchKernelGGL(ScanSmall, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, counts, m, stride,
+                       offsets, totals, c);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
                      counts, m, chunk_sums, stride);
   hipLaunchKernelGGL(ScanSpine, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, chunk_sums, nb,
