@@ -428,3 +428,46 @@ def test_hip_concat_matches_oracle(n):
     for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
         g.validate(full=True)
         assert_bit_exact(g, w, e.result().name)
+
+
+# ------------------------------------------------------------------ var-len edge cases
+
+@pytest.mark.gpu
+def test_varlen_outputs_with_an_empty_selection():
+    batch = W.c5_batch(5000, 0.1)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    none = b.make_condition(b.make_function("like", [s, b.make_literal("no such thing%", pa.string())], pa.bool_()))
+    sv = gandiva.make_filter(batch.schema, none).evaluate(batch, None, "int32")
+    assert sv.num_slots == 0
+    proj = gandiva.make_projector(batch.schema, W.c5_expressions(), None, "UINT32")
+    got = proj.evaluate(batch, sv)
+    assert [len(g) for g in got] == [0, 0, 0]
+    for g in got:
+        g.validate(full=True)
+
+
+@pytest.mark.gpu
+def test_varlen_multi_chunk_tile_scan_matches_oracle():
+    """> 4096 wave tiles per output: the three-launch segmented scan (small batches take the
+    single-launch form)."""
+    n = 3_000_017
+    batch = W.c5_batch(n, 0.05)
+    exprs = W.c5_expressions()
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w in zip(got, oracle.project(exprs, batch)):
+        assert g.equals(w)
+
+
+@pytest.mark.gpu
+def test_varlen_output_over_2_gib_is_rejected():
+    import torch
+    n = 100_000_000
+    db = W.c5_device_batch(n)                    # 1.2 GB of string bytes
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(W.c5_schema().field(0))
+    big = b.make_expression(b.make_function("concat", [s, s], pa.string()), pa.field("ss", pa.string()))
+    proj = gandiva.make_projector(W.c5_schema(), [big], None)
+    with pytest.raises(pa.ArrowInvalid, match="2 GiB"):
+        proj.evaluate_device(db)
+    torch.cuda.synchronize()
