@@ -211,3 +211,35 @@ def test_no_cpu_fallback_evaluation_fails_loudly_without_a_device():
         gandiva.make_projector(batch.schema, W.c1_expressions(), None)
     with pytest.raises(pa.lib.ArrowException, match="no HIP device"):
         gandiva.make_filter(W.c3_schema(), W.c3_condition())
+
+
+# ------------------------------------------------------------------ the header from plain C
+
+def _build_c_kat(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_kat")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+           os.path.join(root, "tests", "c", "c_abi_kat.c"), "-o", exe,
+           "-L", os.path.join(root, "gandiva_amd"), "-lgandiva_amd",
+           "-Wl,-rpath," + os.path.join(root, "gandiva_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_strict_c99_and_usable_from_c(tmp_path):
+    """include/gandiva_amd.h compiles as C99 (-pedantic -Werror); a C program builds the
+    reference's first KAT tree, renders it and compiles its kernel without a device."""
+    import subprocess
+    r = subprocess.run([_build_c_kat(tmp_path), "--host-only"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("ok")
+
+
+@pytest.mark.gpu
+def test_c_program_evaluates_the_reference_kat(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_kat(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "10 15 15 17" in r.stdout
