@@ -185,6 +185,7 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
     const int64_t w = t * kEmitWords + lane;
     uint64_t m = (w < nwords) ? mask[w] : 0ull;
+    const uint64_t base = offsets[(t * kEmitWords) / subtiles];  // issued with the mask load
     const uint32_t c = (uint32_t)__popcll(m);
     const uint32_t incl = (uint32_t)WaveInclusiveScan(c, lane);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -195,7 +196,6 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
       m &= m - 1;
     }
     __builtin_amdgcn_wave_barrier();
-    const uint64_t base = offsets[(t * kEmitWords) / subtiles];
     for (uint32_t j = lane; j < total; j += 64) out[base + j] = static_cast<IndexT>(tile_row0 + buf[j]);
     __builtin_amdgcn_wave_barrier();
   }
