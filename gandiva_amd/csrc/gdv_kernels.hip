@@ -182,10 +182,23 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint16_t* buf = stage[wave];
   const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  // the next tile's mask word and base are loaded while the current tile is walked
+  uint64_t m_next = 0, base_next = 0;
+  if (t < ntiles) {
     const int64_t w = t * kEmitWords + lane;
-    uint64_t m = (w < nwords) ? mask[w] : 0ull;
-    const uint64_t base = offsets[(t * kEmitWords) / subtiles];  // issued with the mask load
+    m_next = (w < nwords) ? mask[w] : 0ull;
+    base_next = offsets[(t * kEmitWords) / subtiles];
+  }
+  for (; t < ntiles; t += stride) {
+    uint64_t m = m_next;
+    const uint64_t base = base_next;
+    if (t + stride < ntiles) {
+      const int64_t w = (t + stride) * kEmitWords + lane;
+      m_next = (w < nwords) ? mask[w] : 0ull;
+      base_next = offsets[((t + stride) * kEmitWords) / subtiles];
+    }
     const uint32_t c = (uint32_t)__popcll(m);
     const uint32_t incl = (uint32_t)WaveInclusiveScan(c, lane);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -196,7 +209,20 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
       m &= m - 1;
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < total; j += 64) out[base + j] = static_cast<IndexT>(tile_row0 + buf[j]);
+    // four indices per lane per step: one 8-byte LDS read, one 4*sizeof(IndexT) store
+    IndexT* dst = out + base;
+    for (uint32_t j = (uint32_t)lane * 4; j < total; j += 256) {
+      if (j + 4 <= total) {
+        uint16_t q[4];
+        __builtin_memcpy(q, buf + j, 8);
+        IndexT v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = static_cast<IndexT>(tile_row0 + q[k]);
+        __builtin_memcpy(dst + j, v, sizeof(v));
+      } else {
+        for (uint32_t k = j; k < total; k++) dst[k] = static_cast<IndexT>(tile_row0 + buf[k]);
+      }
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
