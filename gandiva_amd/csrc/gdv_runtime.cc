@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 
 namespace gdv {
 
@@ -136,6 +137,10 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
     f << source;
   }
 
+  // one compilation at a time: they are rare (cached in memory and on disk) and comgr's
+  // temporary-file handling has no need to be exercised concurrently
+  static std::mutex compile_mu;
+  std::lock_guard<std::mutex> compile_guard(compile_mu);
   hiprtcProgram prog;
   const char* hdr_src[] = {gdv_device_lib_src};
   const char* hdr_name[] = {"gdv_device_lib.hpp"};
