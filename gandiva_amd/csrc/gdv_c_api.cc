@@ -98,6 +98,18 @@ int Guarded(F&& body) {
   }
 }
 
+template <typename F>
+auto GuardedPtr(F&& body) -> decltype(body()) {
+  try {
+    return body();
+  } catch (const std::exception& e) {
+    g_last_error = std::string("ExecutionError: internal error: ") + e.what();
+  } catch (...) {
+    g_last_error = "ExecutionError: internal error: unknown exception";
+  }
+  return nullptr;
+}
+
 bool ToSelectionMode(int m, SelectionMode* out) {
   if (m < 0 || m > 3) return false;
   *out = static_cast<SelectionMode>(m);
@@ -115,11 +127,13 @@ void gdv_free_string(char* s) { free(s); }
 // ---------------------------------------------------------------- schema
 gdv_schema_t* gdv_schema_new(void) { return new gdv_schema(); }
 int gdv_schema_add_field(gdv_schema_t* schema, const char* name, gdv_type_t type, int nullable) {
+  return Guarded([&]() -> int {
   DataType t;
   if (!schema || !name) return Fail(Status::Invalid("null schema or field name"));
   if (!ToType(type, &t)) return Fail(Status::Invalid("unsupported type id " + std::to_string(type.id)));
   schema->fields.push_back(Field{name, t, nullable != 0});
   return GDV_OK;
+  });
 }
 int gdv_schema_num_fields(const gdv_schema_t* schema) {
   return schema ? static_cast<int>(schema->fields.size()) : 0;
@@ -128,13 +142,16 @@ void gdv_schema_free(gdv_schema_t* schema) { delete schema; }
 
 // ---------------------------------------------------------------- nodes
 gdv_node_t* gdv_node_field(const char* name, gdv_type_t type) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType t;
   if (!name) return FailPtr<gdv_node_t>("field name is null");
   if (!ToType(type, &t)) return FailPtr<gdv_node_t>("unsupported type id");
   return new gdv_node{std::make_shared<FieldNode>(Field{name, t, true})};
+  });
 }
 
 gdv_node_t* gdv_node_literal(gdv_type_t type, const void* value, int is_null) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType t;
   if (!ToType(type, &t)) return FailPtr<gdv_node_t>("unsupported type id");
   if (t.is_varlen()) return FailPtr<gdv_node_t>("use gdv_node_literal_bytes for var-len types");
@@ -156,9 +173,11 @@ gdv_node_t* gdv_node_literal(gdv_type_t type, const void* value, int is_null) {
     }
   }
   return new gdv_node{std::make_shared<LiteralNode>(t, lit)};
+  });
 }
 
 gdv_node_t* gdv_node_literal_bytes(gdv_type_t type, const char* data, int64_t len, int is_null) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType t;
   if (!ToType(type, &t) || !t.is_varlen()) return FailPtr<gdv_node_t>("type must be string or binary");
   Literal lit;
@@ -168,38 +187,48 @@ gdv_node_t* gdv_node_literal_bytes(gdv_type_t type, const char* data, int64_t le
     lit.bytes.assign(data ? data : "", static_cast<size_t>(len));
   }
   return new gdv_node{std::make_shared<LiteralNode>(t, lit)};
+  });
 }
 
 gdv_node_t* gdv_node_function(const char* name, gdv_node_t* const* children, int num_children,
                               gdv_type_t return_type) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType t;
   NodeVector kids;
   if (!name) return FailPtr<gdv_node_t>("function name is null");
   if (!ToType(return_type, &t)) return FailPtr<gdv_node_t>("unsupported return type id");
   if (!CollectChildren(children, num_children, &kids)) return FailPtr<gdv_node_t>("null child node");
   return new gdv_node{std::make_shared<FunctionNode>(name, std::move(kids), t)};
+  });
 }
 
 gdv_node_t* gdv_node_if(gdv_node_t* c, gdv_node_t* t, gdv_node_t* e, gdv_type_t return_type) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType rt;
   if (!c || !t || !e || !c->node || !t->node || !e->node) return FailPtr<gdv_node_t>("null child node");
   if (!ToType(return_type, &rt)) return FailPtr<gdv_node_t>("unsupported return type id");
   return new gdv_node{std::make_shared<IfNode>(c->node, t->node, e->node, rt)};
+  });
 }
 
 gdv_node_t* gdv_node_and(gdv_node_t* const* children, int n) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   NodeVector kids;
   if (!CollectChildren(children, n, &kids)) return FailPtr<gdv_node_t>("null child node");
   return new gdv_node{std::make_shared<BooleanNode>(BooleanNode::kAnd, std::move(kids))};
+  });
 }
 
 gdv_node_t* gdv_node_or(gdv_node_t* const* children, int n) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   NodeVector kids;
   if (!CollectChildren(children, n, &kids)) return FailPtr<gdv_node_t>("null child node");
   return new gdv_node{std::make_shared<BooleanNode>(BooleanNode::kOr, std::move(kids))};
+  });
 }
 
 gdv_node_t* gdv_node_in(gdv_node_t* node, gdv_type_t value_type, const void* values, int n) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType t;
   if (!node || !node->node) return FailPtr<gdv_node_t>("null child node");
   if (!ToType(value_type, &t) || t.is_varlen()) return FailPtr<gdv_node_t>("bad IN value type");
@@ -215,10 +244,12 @@ gdv_node_t* gdv_node_in(gdv_node_t* node, gdv_type_t value_type, const void* val
     std::memcpy(&lits[i].hi, raw + 8, 8);
   }
   return new gdv_node{std::make_shared<InNode>(node->node, t, std::move(lits))};
+  });
 }
 
 gdv_node_t* gdv_node_in_bytes(gdv_node_t* node, gdv_type_t value_type, const char* const* values,
                               const int64_t* lengths, int n) {
+  return GuardedPtr([&]() -> gdv_node_t* {
   DataType t;
   if (!node || !node->node) return FailPtr<gdv_node_t>("null child node");
   if (!ToType(value_type, &t) || !t.is_varlen()) return FailPtr<gdv_node_t>("bad IN value type");
@@ -226,10 +257,13 @@ gdv_node_t* gdv_node_in_bytes(gdv_node_t* node, gdv_type_t value_type, const cha
   std::vector<Literal> lits(n);
   for (int i = 0; i < n; i++) lits[i].bytes.assign(values[i] ? values[i] : "", static_cast<size_t>(lengths[i]));
   return new gdv_node{std::make_shared<InNode>(node->node, t, std::move(lits))};
+  });
 }
 
 char* gdv_node_to_string(const gdv_node_t* node) {
+  return GuardedPtr([&]() -> char* {
   return node && node->node ? DupString(node->node->ToString()) : nullptr;
+  });
 }
 gdv_type_t gdv_node_return_type(const gdv_node_t* node) {
   return node && node->node ? FromType(node->node->return_type()) : gdv_type_t{0, 0, 0};
@@ -237,18 +271,24 @@ gdv_type_t gdv_node_return_type(const gdv_node_t* node) {
 void gdv_node_free(gdv_node_t* node) { delete node; }
 
 gdv_expression_t* gdv_expression_new(gdv_node_t* root, const char* result_name, gdv_type_t rt) {
+  return GuardedPtr([&]() -> gdv_expression_t* {
   DataType t;
   if (!root || !root->node) return FailPtr<gdv_expression_t>("root node is null");
   if (!result_name) return FailPtr<gdv_expression_t>("result field is null");
   if (!ToType(rt, &t)) return FailPtr<gdv_expression_t>("unsupported result type id");
   return new gdv_expression{std::make_shared<Expression>(root->node, Field{result_name, t, true})};
+  });
 }
 gdv_expression_t* gdv_condition_new(gdv_node_t* root) {
+  return GuardedPtr([&]() -> gdv_expression_t* {
   if (!root || !root->node) return FailPtr<gdv_expression_t>("root node is null");
   return new gdv_expression{std::make_shared<Expression>(root->node, Field{"cond", boolean(), true})};
+  });
 }
 char* gdv_expression_to_string(const gdv_expression_t* e) {
+  return GuardedPtr([&]() -> char* {
   return e && e->expr ? DupString(e->expr->ToString()) : nullptr;
+  });
 }
 gdv_type_t gdv_expression_result_type(const gdv_expression_t* e) {
   return e && e->expr ? FromType(e->expr->result().type) : gdv_type_t{0, 0, 0};
@@ -466,6 +506,7 @@ int gdv_filter_evaluate_flat(const gdv_filter_t* f, int64_t num_rows, const int6
 int gdv_registry_size(void) { return static_cast<int>(FunctionRegistry::Get().all().size()); }
 int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_type_t* params,
                      int max_params, int* num_params) {
+  return Guarded([&]() -> int {
   auto& all = FunctionRegistry::Get().all();
   if (index < 0 || index >= static_cast<int>(all.size())) return Fail(Status::Invalid("index out of range"));
   const FunctionDef& d = all[index];
@@ -475,6 +516,7 @@ int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_
   for (int i = 0; params && i < max_params && i < static_cast<int>(d.params.size()); i++)
     params[i] = FromType(d.params[i]);
   return GDV_OK;
+  });
 }
 
 // ---------------------------------------------------------------- device helpers
@@ -566,6 +608,7 @@ Status ImportBatch(const Schema& schema, const ArrowDeviceArray* batch, hipStrea
 int gdv_projector_evaluate_device_array(const gdv_projector_t* p, const ArrowDeviceArray* batch,
                                         const gdv_selection_t* sel, gdv_out_column_t* outs,
                                         int num_outs, void* stream, uint32_t flags) {
+  return Guarded([&]() -> int {
   if (!p) return Fail(Status::Invalid("null projector"));
   if (!outs) return Fail(Status::Invalid("Output array vector cannot be null"));
   std::vector<ColumnBuffers> cols;
@@ -592,11 +635,13 @@ int gdv_projector_evaluate_device_array(const gdv_projector_t* p, const ArrowDev
                       num_outs, mem, static_cast<hipStream_t>(stream), flags);
   for (int i = 0; i < num_outs; i++) outs[i].data_size = o[i].data_size;
   return Check(st);
+  });
 }
 
 int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const ArrowDeviceArray* batch,
                                      int selection_mode, void* out_indices, int64_t max_slots,
                                      int64_t* num_selected, void* stream) {
+  return Guarded([&]() -> int {
   if (!f) return Fail(Status::Invalid("null filter"));
   SelectionMode mode;
   if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
@@ -607,6 +652,7 @@ int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const ArrowDeviceArr
   if (!st.ok()) return Fail(st);
   return Check(f->f->Evaluate(rows, cols.data(), static_cast<int>(cols.size()), mode, out_indices,
                               max_slots, num_selected, mem, static_cast<hipStream_t>(stream)));
+  });
 }
 
 // ---------------------------------------------------------------- C device data export
@@ -839,16 +885,20 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const ArrowDeviceArr
 // ---------------------------------------------------------------- build support
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
                              int num_exprs, int selection_mode) {
+  return Guarded([&]() -> int {
   if (!schema) return Fail(Status::Invalid("null schema"));
   std::vector<ExpressionPtr> ex;
   if (!CollectExprs(exprs, num_exprs, &ex)) return Fail(Status::Invalid("null expression"));
   SelectionMode mode;
   if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
   return Check(PrecompileProjector(schema->fields, ex, mode));
+  });
 }
 int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* condition) {
+  return Guarded([&]() -> int {
   if (!schema || !condition || !condition->expr) return Fail(Status::Invalid("null argument"));
   return Check(PrecompileFilter(schema->fields, condition->expr));
+  });
 }
 
 }  // extern "C"
