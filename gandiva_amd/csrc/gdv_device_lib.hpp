@@ -937,6 +937,29 @@ GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
 // overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
 // 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
+  // Whole, unsliced string inside the register cache (an input column passed through or
+  // case-mapped — the test folds at compile time for such views): straight-line stores of
+  // the cached words with constant indices, no cache selects, no limit arithmetic, then a
+  // 4/2/1 ladder for the last partial word.
+  if (s.cp != nullptr && s.p == s.cp && s.len <= 8 * GDV_NPRE) {
+#pragma unroll
+    for (int j = 0; j < GDV_NPRE; j++) {
+      if (8 * j + 8 <= s.len) {
+        const gdv_uint64 w = gdv_map8(s.pre[j], s.map);
+        __builtin_memcpy(dst + 8 * j, &w, 8);
+      }
+    }
+    const gdv_int32 r = s.len & 7;
+    if (r != 0) {
+      const gdv_int32 at = s.len & ~7;
+      gdv_uint64 w = gdv_map8(gdv_pre_word(s, s.len >> 3), s.map);
+      gdv_int32 o = at;
+      if (r & 4) { const gdv_uint32 v = (gdv_uint32)w; __builtin_memcpy(dst + o, &v, 4); o += 4; w >>= 32; }
+      if (r & 2) { const gdv_uint16 v = (gdv_uint16)w; __builtin_memcpy(dst + o, &v, 2); o += 2; w >>= 16; }
+      if (r & 1) dst[o] = (gdv_uint8)w;
+    }
+    return;
+  }
   if (s.len >= 8) {
     gdv_int32 i = 0;
     for (; i + 8 <= s.len; i += 8) {
