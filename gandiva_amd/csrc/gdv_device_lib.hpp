@@ -1010,8 +1010,25 @@ GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gd
 
 GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
 // number of UTF-8 characters = bytes that are not continuation bytes (10xxxxxx)
+// The whole string is the (unsliced) register cache: its words can be used with constant
+// indices.  For views made straight from an input column the first two tests fold at
+// compile time.
+GDV_DEV bool gdv_str_in_cache(const gdv_str& s) {
+  return s.cp != nullptr && s.p == s.cp && s.len <= 8 * GDV_NPRE;
+}
+GDV_DEV gdv_uint64 gdv_mask_upto(gdv_int32 nbytes) {  // any nbytes: <= 0 -> 0, >= 8 -> all ones
+  return nbytes <= 0 ? 0ull : gdv_low_bytes_mask(nbytes);
+}
 GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
   gdv_int32 cont = 0;
+  if (gdv_str_in_cache(s)) {
+#pragma unroll
+    for (int j = 0; j < GDV_NPRE; j++) {
+      const gdv_uint64 w = s.pre[j] & gdv_mask_upto(s.len - 8 * j);
+      cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
+    }
+    return s.len - cont;
+  }
   for (gdv_int32 i = 0; i < s.len; i += 8) {
     gdv_uint64 w = gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
     cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
@@ -1020,6 +1037,11 @@ GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
 }
 GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
   gdv_uint64 acc = 0;
+  if (gdv_str_in_cache(s)) {
+#pragma unroll
+    for (int j = 0; j < GDV_NPRE; j++) acc |= s.pre[j] & gdv_mask_upto(s.len - 8 * j);
+    return (acc & GDV_B80) == 0;
+  }
   for (gdv_int32 i = 0; i < s.len; i += 8)
     acc |= gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
   return (acc & GDV_B80) == 0;
@@ -1303,6 +1325,32 @@ GDV_DEV bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 
   const gdv_uint64 splat = (first & 0xffull) * 0x0101010101010101ull;
   const gdv_uint64 splat2 = ((first >> 8) & 0xffull) * 0x0101010101010101ull;
   const gdv_int32 last = s.len - m;  // last candidate start
+  if (gdv_str_in_cache(s) && m <= 8) {
+    // cached words with constant indices: no selects, no loads, the loop unrolls fully
+    bool hit = false;
+#pragma unroll
+    for (int j = 0; j < GDV_NPRE; j++) {
+      const gdv_int32 base = 8 * j;
+      if (base <= last && !hit) {
+        const gdv_uint64 cur = gdv_map8(s.pre[j], s.map);
+        const gdv_uint64 nxt = j + 1 < GDV_NPRE ? gdv_map8(s.pre[j + 1], s.map) : 0ull;
+        const gdv_uint64 x = cur ^ splat;
+        gdv_uint64 cand = (x - 0x0101010101010101ull) & ~x & GDV_B80;
+        if (m >= 2) {
+          const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat2;
+          cand &= (y - 0x0101010101010101ull) & ~y & GDV_B80;
+        }
+        while (cand) {
+          const int k = __builtin_ctzll(cand) >> 3;
+          cand &= cand - 1;
+          if (base + k > last) break;
+          const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
+          if ((win & mask) == first) { hit = true; break; }
+        }
+      }
+    }
+    return hit;
+  }
   gdv_uint64 cur = gdv_word_at(s, 0);
   for (gdv_int32 base = 0; base <= last; base += 8) {
     const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
