@@ -700,6 +700,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   plan->input_needs_values = cg.needs_values_;
   plan->input_needs_validity = cg.needs_validity_;
   plan->can_raise = cg.can_raise_;
+  for (size_t k = 0; k < plan->input_fields.size(); k++)
+    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
   plan->layout.n_in = static_cast<int>(plan->input_fields.size());
   plan->layout.n_out = static_cast<int>(plan->output_types.size());
 

@@ -68,6 +68,7 @@ struct KernelPlan {
   // tile into `counts` + all fixed-width outputs; aux0 = 1: offsets and bytes, after the
   // scan of the tile totals into `mask`).
   bool has_varlen_output = false;
+  bool has_varlen_input = false;   // some expression reads utf8/binary bytes
   int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
 };
 
