@@ -1038,8 +1038,12 @@ GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
 GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
   gdv_uint64 acc = 0;
   if (gdv_str_in_cache(s)) {
+    // Conservative on purpose: words that start inside the string are ORed whole, so up to 7
+    // bytes of the NEXT string take part.  A false "not ASCII" only sends the caller down its
+    // general UTF-8 path (same result); building the exact byte mask costs more vector
+    // instructions than everything else in this function.
 #pragma unroll
-    for (int j = 0; j < GDV_NPRE; j++) acc |= s.pre[j] & gdv_mask_upto(s.len - 8 * j);
+    for (int j = 0; j < GDV_NPRE; j++) acc |= (8 * j < s.len) ? s.pre[j] : 0ull;
     return (acc & GDV_B80) == 0;
   }
   for (gdv_int32 i = 0; i < s.len; i += 8)
