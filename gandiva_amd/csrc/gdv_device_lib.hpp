@@ -120,6 +120,20 @@ GDV_DEV gdv_int32 gdv_wave_scan_incl(gdv_int32 v) {
   return r;
 }
 GDV_DEV gdv_int32 gdv_wave_last(gdv_int32 v) { return __builtin_amdgcn_readlane(v, 63); }
+// Byte totals of a wave tile must not wrap: a few very long strings (or a concat of them) can
+// exceed 2^31 bytes inside one tile.  Lanes accumulate with saturation, the wave sum is taken
+// on 16-bit halves, and a total of 2^31 or more is reported as exactly 2^31 — enough for the
+// host's "var-len output exceeds 2 GiB" check, which then never launches the byte pass.
+GDV_DEV gdv_int32 gdv_sat_add31(gdv_int32 a, gdv_int32 b) {
+  const gdv_uint32 s = (gdv_uint32)a + (gdv_uint32)b;
+  return s > 0x7fffffffu ? 0x7fffffff : (gdv_int32)s;
+}
+GDV_DEV gdv_uint32 gdv_tile_total(gdv_int32 lane_total) {  // lane_total in [0, 2^31)
+  const gdv_uint64 lo = (gdv_uint32)__builtin_amdgcn_readlane(gdv_wave_scan_incl(lane_total & 0xffff), 63);
+  const gdv_uint64 hi = (gdv_uint32)__builtin_amdgcn_readlane(gdv_wave_scan_incl(lane_total >> 16), 63);
+  const gdv_uint64 t = lo + (hi << 16);
+  return t >= 0x80000000ull ? 0x80000000u : (gdv_uint32)t;
+}
 GDV_DEV gdv_int32 gdv_wave_sum(gdv_int32 v) { return gdv_wave_last(gdv_wave_scan_incl(v)); }
 
 GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int lane) {

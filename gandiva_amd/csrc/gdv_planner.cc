@@ -964,7 +964,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
           at += " + " + plen[q];
         }
       };
-      cg.Stmt("if (pass == 0) tl" + E + " += ln" + E + ";");
+      cg.Stmt("if (pass == 0) tl" + E + " = gdv_sat_add31(tl" + E + ", ln" + E + ");");
       cg.Stmt("else {");
       cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + ");");
       cg.Stmt("  const gdv_int32 cnt = gdv_wave_last(inc), loc = inc - ln" + E + ";");
@@ -977,8 +977,8 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       cg.Stmt("  }");
       cg.Stmt("  vb" + E + " += cnt;");
       cg.Stmt("}");
-      after_loop << "  if (pass == 0) { const gdv_int32 t = gdv_wave_sum(tl" << E << "); if (lane == 0) A.counts["
-                 << tile << "] = (gdv_uint32)t; }\n";
+      after_loop << "  if (pass == 0) { const gdv_uint32 t = gdv_tile_total(tl" << E << "); if (lane == 0) A.counts["
+                 << tile << "] = t; }\n";
     } else if (t.id == kBool) {
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
       after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)", two);
