@@ -1146,32 +1146,40 @@ GDV_DEV gdv_int32 char_length_utf8(gdv_str s) { return gdv_utf8_count(s); }
 GDV_DEV gdv_str upper_utf8(gdv_str s) { s.map = 1; return s; }
 GDV_DEV gdv_str lower_utf8(gdv_str s) { s.map = 2; return s; }
 
+// Comparisons work on 8-byte words (from the register cache where the view has one), not on
+// single bytes.  Bytes are compared as unsigned values in memory order, which is the little-end
+// byte of the first differing word.
 GDV_DEV int gdv_str_compare(const gdv_str& a, const gdv_str& b) {
   const gdv_int32 n = a.len < b.len ? a.len : b.len;
-  for (gdv_int32 i = 0; i < n; i++) {
-    const gdv_uint8 x = gdv_str_at(a, i), y = gdv_str_at(b, i);
-    if (x != y) return x < y ? -1 : 1;
+  for (gdv_int32 i = 0; i < n; i += 8) {
+    const gdv_uint64 m = gdv_low_bytes_mask(n - i);
+    const gdv_uint64 wa = gdv_word_at(a, i) & m, wb = gdv_word_at(b, i) & m;
+    const gdv_uint64 x = wa ^ wb;
+    if (x != 0) {
+      const int sh = __builtin_ctzll(x) & ~7;
+      return ((wa >> sh) & 0xffull) < ((wb >> sh) & 0xffull) ? -1 : 1;
+    }
   }
   return a.len < b.len ? -1 : (a.len > b.len ? 1 : 0);
 }
-GDV_DEV bool equal_utf8_utf8(gdv_str a, gdv_str b) { return a.len == b.len && gdv_str_compare(a, b) == 0; }
+GDV_DEV bool gdv_str_equal_words(const gdv_str& a, gdv_int32 at, const gdv_str& b, gdv_int32 n) {
+  for (gdv_int32 i = 0; i < n; i += 8) {  // bytes [at, at+n) of a against bytes [0, n) of b
+    const gdv_uint64 m = gdv_low_bytes_mask(n - i);
+    if (((gdv_word_at(a, at + i) ^ gdv_word_at(b, i)) & m) != 0) return false;
+  }
+  return true;
+}
+GDV_DEV bool equal_utf8_utf8(gdv_str a, gdv_str b) { return a.len == b.len && gdv_str_equal_words(a, 0, b, a.len); }
 GDV_DEV bool not_equal_utf8_utf8(gdv_str a, gdv_str b) { return !equal_utf8_utf8(a, b); }
 GDV_DEV bool less_than_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) < 0; }
 GDV_DEV bool less_than_or_equal_to_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) <= 0; }
 GDV_DEV bool greater_than_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) > 0; }
 GDV_DEV bool greater_than_or_equal_to_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) >= 0; }
 GDV_DEV bool starts_with_utf8_utf8(gdv_str s, gdv_str prefix) {
-  if (prefix.len > s.len) return false;
-  for (gdv_int32 i = 0; i < prefix.len; i++)
-    if (gdv_str_at(s, i) != gdv_str_at(prefix, i)) return false;
-  return true;
+  return prefix.len <= s.len && gdv_str_equal_words(s, 0, prefix, prefix.len);
 }
 GDV_DEV bool ends_with_utf8_utf8(gdv_str s, gdv_str suffix) {
-  if (suffix.len > s.len) return false;
-  const gdv_int32 d = s.len - suffix.len;
-  for (gdv_int32 i = 0; i < suffix.len; i++)
-    if (gdv_str_at(s, d + i) != gdv_str_at(suffix, i)) return false;
-  return true;
+  return suffix.len <= s.len && gdv_str_equal_words(s, s.len - suffix.len, suffix, suffix.len);
 }
 
 // substr(s, from, len): 1-based character positions (UTF-8 aware); from < 0 counts from the
@@ -1399,8 +1407,9 @@ GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_
   for (gdv_int32 k = 0; k < n; k++) {
     const gdv_int32 len = offs[k + 1] - offs[k];
     if (len != s.len) continue;
-    bool eq = true;
-    for (gdv_int32 i = 0; i < len && eq; i++) eq = gdv_str_at(s, i) == bytes[offs[k] + i];
+    bool eq = true;  // word-wise; the literal table is readable 8 bytes past its last byte
+    for (gdv_int32 i = 0; i < len && eq; i += 8)
+      eq = ((gdv_word_at(s, i) ^ gdv_load8_raw(bytes + offs[k] + i)) & gdv_low_bytes_mask(len - i)) == 0;
     if (eq) return true;
   }
   return false;
