@@ -22,10 +22,13 @@
  * PARITY UNPINNED (no reference implementation or vector exists in the container to compare
  * with): hash32/hash64, date/time extraction and arithmetic, casts, divide-by-zero
  * behaviour, 3-valued AND/OR with null operands, decimal128 result-type / rounding /
- * overflow rules, substr / upper / trim / like-escape edge cases.  These are restated from
- * memory of the reference lineage and cross-checked against INDEPENDENT CPU engines where
- * semantics coincide — pyarrow.compute and Python's decimal module
- * (tests/test_oracle_crosscheck.py, test_decimal.py, test_strings.py).
+ * overflow rules (incl. divide / mod), substr / left / right / upper / trim / like-escape edge
+ * cases, locate / strpos / castVARCHAR / ascii, concat and ||, hashes of strings.  These are
+ * restated from memory of the reference lineage and cross-checked against INDEPENDENT CPU
+ * engines where semantics coincide — pyarrow.compute, Python's decimal module and exact
+ * integer arithmetic, plain Python str / re, sklearn's and a pure-Python MurmurHash3 — per
+ * function (tests/test_oracle_crosscheck.py, test_decimal.py, test_strings.py) and over random
+ * expression trees (tests/test_oracle_vs_arrow_trees.py, test_oracle_vs_python_strings.py).
  *
  * Program format (whitespace separated, prefix order):
  *   F <col>                               field: column index
