@@ -190,7 +190,7 @@ static node* parse(const char** p, const or_column* cols) {
       break;
     }
     case 'C':
-      next_tok(p, t, sizeof t); snprintf(n->name, sizeof n->name, "%s", t);
+      next_tok(p, t, sizeof t); snprintf(n->name, sizeof n->name, "%.*s", (int)sizeof n->name - 1, t);
       next_tok(p, t, sizeof t); parse_type(t, &n->type, &n->prec, &n->scale);
       next_tok(p, t, sizeof t); n->nargs = atoi(t);
       n->args = (node**)calloc(n->nargs ? n->nargs : 1, sizeof(node*));
