@@ -621,7 +621,7 @@ GDV_DEV gdv_int128 gdv_dec_reduce(gdv_int128 v, int e) {
   const gdv_int128 d = gdv_pow10_128(e);
   gdv_int128 q = v / d, r = v % d;
   if (r < 0) r = -r;
-  if (2 * r >= d) q += (v < 0) ? -1 : 1;
+  if (r >= d - r) q += (v < 0) ? -1 : 1;  // 2r >= d without forming 2r (d can be 10^38)
   return q;
 }
 
@@ -661,11 +661,36 @@ GDV_DEV gdv_uint64 gdv_divmod_u256_u64(gdv_u256& v, gdv_uint64 d) {
   return (gdv_uint64)rem;
 }
 
+// p /= 10^delta, rounded half away from zero, in chunks of <= 10^18 (least significant digits
+// first).  The last chunk removed holds the most significant removed digits and alone decides
+// the rounding: 2*R >= 10^delta  <=>  2*last_rem >= last_div  (last_div is even, so lower
+// chunks can neither create nor break the tie).
+GDV_DEV void gdv_u256_div_pow10_round(gdv_u256& p, int delta) {
+  gdv_uint64 last_rem = 0, last_div = 1;
+  int left = delta;
+  while (left > 0) {
+    const int step = left > 18 ? 18 : left;
+    gdv_uint64 d = 1;
+    for (int i = 0; i < step; i++) d *= 10;
+    last_rem = gdv_divmod_u256_u64(p, d);
+    last_div = d;
+    left -= step;
+  }
+  if (delta > 0 && 2 * (gdv_uint128)last_rem >= (gdv_uint128)last_div) {
+    for (int i = 0; i < 4; i++) { if (++p.w[i] != 0) break; }
+  }
+}
+
 GDV_DEV gdv_int128 gdv_dec_rescale_up(gdv_int128 v, int by) { return by > 0 ? v * gdv_pow10_128(by) : v; }
 
+GDV_DEV gdv_int128 gdv_dec_add_large(gdv_int128 x, int xs, gdv_int128 y, int ys, int os);
 GDV_DEV gdv_int128 add_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp, int ys,
                                              int op, int os) {
   const int hs = xs > ys ? xs : ys;  // exact result scale
+  // Digits the operands can have once aligned to that scale — a compile-time fact.  Up to 37
+  // the aligned values and their sum fit 128 bits; beyond, the sum is formed in 256 bits.
+  const int xd = xp + hs - xs, yd = yp + hs - ys;
+  if ((xd > yd ? xd : yd) > 37) return gdv_dec_add_large(x, xs, y, ys, os);
   gdv_int128 sum = gdv_dec_rescale_up(x, hs - xs) + gdv_dec_rescale_up(y, hs - ys);
   return gdv_dec_clip38(gdv_dec_reduce(sum, hs - os));
 }
@@ -690,23 +715,7 @@ GDV_DEV gdv_int128 multiply_decimal128_decimal128(gdv_int128 x, int xp, int xs, 
   gdv_u256 p = yp <= 18   ? gdv_mul_128x64(ax, (gdv_uint64)ay)
                : xp <= 18 ? gdv_mul_128x64(ay, (gdv_uint64)ax)
                           : gdv_mul_128x128(ax, ay);
-  // divide by 10^delta in chunks of <= 10^18 (least significant digits first).  The last
-  // chunk removed holds the most significant removed digits and alone decides the rounding:
-  // 2*R >= 10^delta  <=>  2*last_rem >= last_div  (last_div is even, so lower chunks can
-  // neither create nor break the tie).
-  gdv_uint64 last_rem = 0, last_div = 1;
-  int left = delta;
-  while (left > 0) {
-    const int step = left > 18 ? 18 : left;
-    gdv_uint64 d = 1;
-    for (int i = 0; i < step; i++) d *= 10;
-    last_rem = gdv_divmod_u256_u64(p, d);
-    last_div = d;
-    left -= step;
-  }
-  if (delta > 0 && 2 * (gdv_uint128)last_rem >= (gdv_uint128)last_div) {
-    for (int i = 0; i < 4; i++) { if (++p.w[i] != 0) break; }
-  }
+  gdv_u256_div_pow10_round(p, delta);
   if (p.w[3] != 0 || p.w[2] != 0) return 0;  // overflow
   gdv_uint128 mag = ((gdv_uint128)p.w[1] << 64) | p.w[0];
   if (mag > (gdv_uint128)gdv_dec_max38()) return 0;
@@ -756,6 +765,29 @@ GDV_DEV gdv_int128 gdv_dec_from_mag(const gdv_u256& mag, bool neg) {  // 0 when 
   if (m > (gdv_uint128)gdv_dec_max38()) return 0;
   return neg ? -(gdv_int128)m : (gdv_int128)m;
 }
+// x + y when the aligned operands can exceed 37 digits: signed-magnitude sum in 256 bits,
+// then the scale reduction (round half away from zero) and the 38-digit check
+GDV_DEV void gdv_u256_add(gdv_u256& a, const gdv_u256& b) {
+  gdv_uint64 carry = 0;
+  for (int i = 0; i < 4; i++) {
+    const gdv_uint128 t = (gdv_uint128)a.w[i] + b.w[i] + carry;
+    a.w[i] = (gdv_uint64)t;
+    carry = (gdv_uint64)(t >> 64);
+  }
+}
+GDV_DEV gdv_int128 gdv_dec_add_large(gdv_int128 x, int xs, gdv_int128 y, int ys, int os) {
+  const int hs = xs > ys ? xs : ys;
+  const bool xneg = x < 0, yneg = y < 0;
+  const gdv_u256 X = gdv_mul_128x128(xneg ? (gdv_uint128)(-x) : (gdv_uint128)x, (gdv_uint128)gdv_pow10_128(hs - xs));
+  const gdv_u256 Y = gdv_mul_128x128(yneg ? (gdv_uint128)(-y) : (gdv_uint128)y, (gdv_uint128)gdv_pow10_128(hs - ys));
+  gdv_u256 sum;
+  bool neg;
+  if (xneg == yneg) { sum = X; gdv_u256_add(sum, Y); neg = xneg; }
+  else if (gdv_u256_cmp(X, Y) >= 0) { sum = X; gdv_u256_sub(sum, Y); neg = xneg; }
+  else { sum = Y; gdv_u256_sub(sum, X); neg = yneg; }
+  gdv_u256_div_pow10_round(sum, hs - os);
+  return gdv_dec_from_mag(sum, neg);
+}
 // x / y at the result scale `os`: round_half_away(x * 10^(os - xs + ys) / y).  y == 0 raises.
 GDV_DEV gdv_int128 divide_decimal128_decimal128(gdv_ctx ctx, gdv_int128 x, int xp, int xs, gdv_int128 y,
                                                 int yp, int ys, int op, int os) {
@@ -764,7 +796,22 @@ GDV_DEV gdv_int128 divide_decimal128_decimal128(gdv_ctx ctx, gdv_int128 x, int x
   const bool neg = (x < 0) != (y < 0);
   const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
   const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
-  gdv_u256 num = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(delta > 0 ? delta : 0));
+  // numerator = |x| * 10^delta; delta can exceed 38 (e.g. dec(38,0) / dec(38,37)), so the
+  // power of ten is applied in two steps and a numerator that leaves 256 bits means a
+  // quotient of more than 38 digits: overflow -> 0
+  const int d1 = delta > 38 ? 38 : (delta > 0 ? delta : 0);
+  gdv_u256 num = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(d1));
+  for (int left = delta - d1; left > 0; left -= 18) {
+    gdv_uint64 m = 1;
+    for (int i = 0; i < (left > 18 ? 18 : left); i++) m *= 10;
+    gdv_uint64 carry = 0;
+    for (int i = 0; i < 4; i++) {
+      const gdv_uint128 t = (gdv_uint128)num.w[i] * m + carry;
+      num.w[i] = (gdv_uint64)t;
+      carry = (gdv_uint64)(t >> 64);
+    }
+    if (carry != 0) return 0;
+  }
   gdv_u256 den = gdv_u256_from_u128(ay), q, r;
   gdv_u256_divmod(num, den, &q, &r);
   gdv_u256_shl1(r, 0);                       // 2 * remainder (den < 2^127, no overflow)
@@ -816,14 +863,25 @@ GDV_DEV gdv_int128 negative_decimal128(gdv_int128 x, int xp, int xs, int op, int
 GDV_DEV gdv_int128 abs_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return x < 0 ? -x : x; }
 // int64 -> decimal(op, os): value * 10^os (0 on overflow of the declared precision)
 GDV_DEV gdv_int128 castDECIMAL_int64(gdv_int64 v, int op, int os) {
-  gdv_int128 r = (gdv_int128)v * gdv_pow10_128(os);
-  const gdv_int128 lim = gdv_pow10_128(op);
-  return (r >= lim || r <= -lim) ? (gdv_int128)0 : r;
+  // |v| must stay below 10^(op - os); checked BEFORE scaling so the product cannot wrap
+  if (v == 0) return 0;
+  if (op - os <= 0) return 0;
+  const gdv_int128 lim = gdv_pow10_128(op - os);
+  if ((gdv_int128)v >= lim || (gdv_int128)v <= -lim) return 0;
+  return (gdv_int128)v * gdv_pow10_128(os);
 }
 GDV_DEV gdv_int128 castDECIMAL_int32(gdv_int32 v, int op, int os) { return castDECIMAL_int64(v, op, os); }
 // decimal -> decimal with another (precision, scale): rescale, round half away from zero
 GDV_DEV gdv_int128 castDECIMAL_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
-  gdv_int128 r = os >= xs ? gdv_dec_rescale_up(x, os - xs) : gdv_dec_reduce(x, xs - os);
+  if (os >= xs) {  // scale up: |x| must stay below 10^(op - (os - xs)), checked before scaling
+    const int by = os - xs;
+    if (x == 0) return 0;
+    if (op - by <= 0) return 0;
+    const gdv_int128 lim_in = gdv_pow10_128(op - by);
+    if (x >= lim_in || x <= -lim_in) return 0;
+    return x * gdv_pow10_128(by);
+  }
+  const gdv_int128 r = gdv_dec_reduce(x, xs - os);
   const gdv_int128 lim = gdv_pow10_128(op);
   return (r >= lim || r <= -lim) ? (gdv_int128)0 : r;
 }
