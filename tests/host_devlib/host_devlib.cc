@@ -70,4 +70,111 @@ int host_decimal_compare(const void* xv, int xp, int xs, const void* yv, int yp,
   return 0;
 }
 
+// ---------------------------------------------------------------- utf8 / binary
+// A column is (int32 offsets, bytes, byte count); the byte buffer must be readable up to
+// max(size, 8) bytes (the engine guarantees the same).  Row views are built exactly as the
+// generated kernels build them: first GDV_NPRE words prefetched into the register cache.
+struct HostCol { const int* off; const unsigned char* data; long size; };
+static gdv_str host_row(const HostCol& c, long i) {
+  const gdv_uint8* lim = c.data + (c.size < 8 ? 8 : c.size);
+  gdv_uint64 pre[GDV_NPRE];
+  const int len = c.off[i + 1] - c.off[i];
+  for (int j = 0; j < GDV_NPRE; j++) pre[j] = (8 * j < len) ? gdv_load8(c.data + c.off[i] + 8 * j, lim) : 0ull;
+  return gdv_make_str_cached(c.data, c.off[i], c.off[i + 1], lim, pre);
+}
+static gdv_str host_lit(const unsigned char* lit, int len) { return gdv_make_str(lit, 0, len, lit + len + 8); }
+
+// predicates against a literal (readable 8 bytes past its end)
+void host_str_pred_lit(int fn, const int* off, const unsigned char* data, long size, long n,
+                       const unsigned char* lit, int litlen, int map, unsigned char* out) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    s.map = map;
+    const gdv_str l = host_lit(lit, litlen);
+    bool r = false;
+    switch (fn) {
+      case 0: r = gdv_like_contains(s, lit, litlen); break;
+      case 1: r = gdv_like_prefix(s, lit, litlen); break;
+      case 2: r = gdv_like_suffix(s, lit, litlen); break;
+      case 3: r = gdv_like_equal(s, lit, litlen); break;
+      case 4: r = equal_utf8_utf8(s, l); break;
+      case 5: r = less_than_utf8_utf8(s, l); break;
+      case 6: r = starts_with_utf8_utf8(s, l); break;
+      case 7: r = ends_with_utf8_utf8(s, l); break;
+      case 8: r = greater_than_or_equal_to_utf8_utf8(s, l); break;
+      default: break;
+    }
+    out[i] = r;
+  }
+}
+// predicates between two columns
+void host_str_pred_col(int fn, const int* offa, const unsigned char* da, long sa, const int* offb,
+                       const unsigned char* db, long sb, long n, unsigned char* out) {
+  HostCol a{offa, da, sa}, b{offb, db, sb};
+  for (long i = 0; i < n; i++) {
+    const gdv_str x = host_row(a, i), y = host_row(b, i);
+    out[i] = fn == 0 ? equal_utf8_utf8(x, y) : fn == 1 ? less_than_utf8_utf8(x, y)
+           : fn == 2 ? starts_with_utf8_utf8(x, y) : ends_with_utf8_utf8(x, y);
+  }
+}
+// integer-valued functions
+void host_str_int(int fn, const int* off, const unsigned char* data, long size, long n,
+                  const unsigned char* lit, int litlen, int map, long long* out) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    s.map = map;
+    switch (fn) {
+      case 0: out[i] = octet_length_utf8(s); break;
+      case 1: out[i] = char_length_utf8(s); break;
+      case 2: out[i] = hash32_utf8(s, true); break;
+      case 3: out[i] = hash64_utf8(s, true); break;
+      case 4: out[i] = ascii_utf8(s); break;
+      case 5: out[i] = locate_utf8_utf8(ctx, host_lit(lit, litlen), s); break;
+      case 6: out[i] = gdv_str_is_ascii(s) ? 1 : 0; break;
+      default: out[i] = 0; break;
+    }
+  }
+}
+// view-producing functions, materialised with gdv_str_copy the way the byte pass does
+long host_str_view(int fn, const int* off, const unsigned char* data, long size, long n, long long a,
+                   long long b, int map, int* out_off, unsigned char* out_data) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    gdv_str r = s;
+    switch (fn) {
+      case 0: r = s; break;
+      case 1: r = substr_utf8_int64_int64(s, a, b); break;
+      case 2: r = ltrim_utf8(s); break;
+      case 3: r = rtrim_utf8(s); break;
+      case 4: r = btrim_utf8(s); break;
+      case 5: r = left_utf8_int32(s, (int)a); break;
+      case 6: r = right_utf8_int32(s, (int)a); break;
+      case 7: r = castVARCHAR_utf8_int64(ctx, s, a); break;
+      case 8: r = substr_utf8_int64(s, a); break;
+      default: break;
+    }
+    if (map == 1) r = upper_utf8(r);
+    if (map == 2) r = lower_utf8(r);
+    gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  return at;
+}
+// IN over a literal list (concatenated bytes readable 8 past the end, n+1 offsets)
+void host_str_in(const int* off, const unsigned char* data, long size, long n, const unsigned char* bytes,
+                 const int* loffs, int nlits, unsigned char* out) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) out[i] = gdv_in_strings(host_row(c, i), bytes, loffs, nlits);
+}
+
 }  // extern "C"

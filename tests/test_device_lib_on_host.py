@@ -120,3 +120,117 @@ def test_device_decimal_casts_and_compares_on_dense_digits(hostlib, seed):
                                  xb.ctypes.data_as(C.c_void_p), tb.precision, tb.scale,
                                  cmp.ctypes.data_as(C.c_void_p), C.c_long(n))
     assert cmp.tolist() == [(x > y) - (x < y) for x, y in zip(av, bv)], f"compare {ta} {tb}"
+
+
+# ------------------------------------------------------------------ utf8 functions on the host build
+
+import gandiva_amd as gandiva
+from oracle import oracle
+import test_strings as S
+
+
+def _col(arr):
+    """(offsets int32, data uint8 padded by 8 zero bytes, true size) of a utf8 array, nulls emptied."""
+    vals = ["" if v is None else v for v in arr.to_pylist()]
+    raw = [v.encode() for v in vals]
+    off = np.zeros(len(raw) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(r) for r in raw])
+    data = np.frombuffer(b"".join(raw) + b"\0" * 16, dtype=np.uint8).copy()
+    return off, data, int(off[-1])
+
+
+def _lit(text):
+    raw = text.encode()
+    return np.frombuffer(raw + b"\0" * 8, dtype=np.uint8).copy(), len(raw)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_string_functions_match_oracle_on_host(hostlib, seed):
+    rng = np.random.default_rng(4100 + seed)
+    n = 1500
+    s_arr = S._strings(rng, n, null_fraction=0.0)
+    t_arr = pa.array([["a", "spark", "rk", "é", "", "Sp", "bright spark and fire"][int(rng.integers(0, 7))]
+                      for _ in range(n)], pa.string())
+    batch = pa.RecordBatch.from_arrays([s_arr, t_arr], names=["s", "t"])
+    b = gandiva.TreeExprBuilder()
+    s, t = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    off, data, size = _col(s_arr)
+    offt, datat, sizet = _col(t_arr)
+    i64, i32, STR, BOOL = pa.int64(), pa.int32(), pa.string(), pa.bool_()
+    lit = lambda v: b.make_literal(v, STR)
+
+    def oracle_of(node, typ):
+        return oracle.project_one(node, typ, batch).to_pylist()
+
+    # predicates against literals, also through the upper() byte map
+    for fn, name, needle in [(0, "%{}%", "spark"), (0, "%{}%", "a"), (0, "%{}%", "日本"), (1, "{}%", "spa"),
+                             (2, "%{}", "rk"), (3, "{}", "spark"), (0, "%{}%", "xxxxxxxxxxxx")]:
+        lb, ll = _lit(needle)
+        for mp, wrap in ((0, lambda x: x), (1, lambda x: b.make_function("upper", [x], STR))):
+            pat = name.format(needle.upper() if mp else needle)
+            lb2, ll2 = _lit(needle.upper() if mp else needle)
+            out = np.zeros(n, dtype=np.uint8)
+            hostlib.host_str_pred_lit(fn, _p(off), _p(data), C.c_long(size), C.c_long(n), _p(lb2), ll2, mp, _p(out))
+            want = oracle_of(b.make_function("like", [wrap(s), lit(pat)], BOOL), BOOL)
+            assert out.astype(bool).tolist() == want, (fn, pat, mp)
+    for fn, op, v in [(4, "equal", "spark"), (5, "less_than", "park"), (6, "starts_with", "spa"),
+                      (7, "ends_with", "rk"), (8, "greater_than_or_equal_to", "a_b%c"), (4, "equal", ""),
+                      (5, "less_than", "ünïcödé spark"), (4, "equal", "x" * 300)]:
+        lb, ll = _lit(v)
+        out = np.zeros(n, dtype=np.uint8)
+        hostlib.host_str_pred_lit(fn, _p(off), _p(data), C.c_long(size), C.c_long(n), _p(lb), ll, 0, _p(out))
+        assert out.astype(bool).tolist() == oracle_of(b.make_function(op, [s, lit(v)], BOOL), BOOL), (op, v)
+    # column against column
+    for fn, op in [(0, "equal"), (1, "less_than"), (2, "starts_with"), (3, "ends_with")]:
+        out = np.zeros(n, dtype=np.uint8)
+        hostlib.host_str_pred_col(fn, _p(off), _p(data), C.c_long(size), _p(offt), _p(datat), C.c_long(sizet),
+                                  C.c_long(n), _p(out))
+        assert out.astype(bool).tolist() == oracle_of(b.make_function(op, [s, t], BOOL), BOOL), op
+    # integer-valued functions
+    lb, ll = _lit("ar")
+    for fn, node, typ in [(0, b.make_function("octet_length", [s], i32), i32),
+                          (1, b.make_function("char_length", [s], i32), i32),
+                          (2, b.make_function("hash32", [s], i32), i32),
+                          (3, b.make_function("hash64", [s], i64), i64),
+                          (4, b.make_function("ascii", [s], i32), i32),
+                          (5, b.make_function("locate", [lit("ar"), s], i32), i32)]:
+        out = np.zeros(n, dtype=np.int64)
+        hostlib.host_str_int(fn, _p(off), _p(data), C.c_long(size), C.c_long(n), _p(lb), ll, 0, _p(out))
+        assert out.tolist() == oracle_of(node, typ), fn
+    out = np.zeros(n, dtype=np.int64)   # hash of the upper-cased view
+    hostlib.host_str_int(3, _p(off), _p(data), C.c_long(size), C.c_long(n), _p(lb), ll, 1, _p(out))
+    assert out.tolist() == oracle_of(b.make_function("hash64", [b.make_function("upper", [s], STR)], i64), i64)
+    # views, materialised by gdv_str_copy
+    K = lambda v, tt=i64: b.make_literal(v, tt)
+    cases = [(0, 0, 0, 0, s), (0, 0, 0, 1, b.make_function("upper", [s], STR)),
+             (0, 0, 0, 2, b.make_function("lower", [s], STR)),
+             (2, 0, 0, 0, b.make_function("ltrim", [s], STR)), (3, 0, 0, 0, b.make_function("rtrim", [s], STR)),
+             (4, 0, 0, 1, b.make_function("upper", [b.make_function("btrim", [s], STR)], STR)),
+             (7, 7, 0, 0, b.make_function("castVARCHAR", [s, K(7)], STR)), (8, 3, 0, 0, b.make_function("substr", [s, K(3)], STR))]
+    for frm, cnt in [(2, 5), (1, 1), (-3, 2), (0, 4), (5, 100), (50, 2), (-400, 3), (9, 30)]:
+        cases.append((1, frm, cnt, 0, b.make_function("substr", [s, K(frm), K(cnt)], STR)))
+        cases.append((1, frm, cnt, 1, b.make_function("upper", [b.make_function("substr", [s, K(frm), K(cnt)], STR)], STR)))
+    for k in (0, 1, 3, 100, -1, -4, -100):
+        cases.append((5, k, 0, 0, b.make_function("left", [s, K(k, i32)], STR)))
+        cases.append((6, k, 0, 0, b.make_function("right", [s, K(k, i32)], STR)))
+    for fn, a1, a2, mp, node in cases:
+        out_off = np.zeros(n + 1, dtype=np.int32)
+        out_data = np.zeros(size + 64, dtype=np.uint8)
+        total = hostlib.host_str_view(fn, _p(off), _p(data), C.c_long(size), C.c_long(n), C.c_longlong(a1),
+                                      C.c_longlong(a2), mp, _p(out_off), _p(out_data))
+        got = [bytes(out_data[out_off[i]:out_off[i + 1]]).decode() for i in range(n)]
+        assert total == out_off[-1]
+        assert got == oracle_of(node, STR), (fn, a1, a2, mp)
+    # IN over a literal list
+    lits = ["spark", "park", "", "日本語テキスト", "bright spark and fire", "x" * 300]
+    raw = b"".join(v.encode() for v in lits)
+    loffs = np.zeros(len(lits) + 1, dtype=np.int32)
+    loffs[1:] = np.cumsum([len(v.encode()) for v in lits])
+    lbytes = np.frombuffer(raw + b"\0" * 8, dtype=np.uint8).copy()
+    out = np.zeros(n, dtype=np.uint8)
+    hostlib.host_str_in(_p(off), _p(data), C.c_long(size), C.c_long(n), _p(lbytes), _p(loffs), len(lits), _p(out))
+    assert out.astype(bool).tolist() == oracle_of(b.make_in_expression(s, lits, STR), BOOL)
