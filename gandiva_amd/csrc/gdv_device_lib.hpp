@@ -1339,6 +1339,44 @@ GDV_DEV gdv_int32 locate_utf8_utf8(gdv_ctx ctx, gdv_str sub, gdv_str str) {
 GDV_DEV gdv_int32 strpos_utf8_utf8(gdv_ctx ctx, gdv_str str, gdv_str sub) {
   return locate_utf8_utf8_int32(ctx, sub, str, 1);
 }
+// castINT / castBIGINT from text: blanks trimmed on both sides, an optional '-', one or more
+// decimal digits, nothing else; anything that is not such a number or does not fit the type is
+// an execution error (the reference: "Failed to cast the string ... to int32").
+GDV_DEV bool gdv_parse_int64(const gdv_str& s, gdv_int64 min_value, gdv_int64 max_value, gdv_int64* out) {
+  gdv_int32 lo = 0, hi = s.len;
+  while (lo < hi && gdv_str_at(s, lo) == ' ') lo++;
+  while (hi > lo && gdv_str_at(s, hi - 1) == ' ') hi--;
+  bool neg = false;
+  if (lo < hi && gdv_str_at(s, lo) == '-') { neg = true; lo++; }
+  if (lo >= hi) return false;
+  // accumulate as a NEGATIVE number so that the most negative value parses without overflow
+  gdv_int64 acc = 0;
+  const gdv_int64 floor_value = neg ? min_value : -max_value;
+  for (gdv_int32 i = lo; i < hi; i++) {
+    const gdv_int32 d = (gdv_int32)gdv_str_at(s, i) - '0';
+    if (d < 0 || d > 9) return false;
+    if (acc < (floor_value + d) / 10) return false;  // acc * 10 - d would pass the floor
+    acc = acc * 10 - d;
+  }
+  *out = neg ? acc : -acc;
+  return true;
+}
+GDV_DEV gdv_int64 castBIGINT_utf8(gdv_ctx ctx, gdv_str s) {
+  gdv_int64 v = 0;
+  if (!gdv_parse_int64(s, (gdv_int64)(-9223372036854775807LL - 1), 9223372036854775807LL, &v)) {
+    gdv_raise(ctx, GDV_ERR_BAD_ARG);
+    return 0;
+  }
+  return v;
+}
+GDV_DEV gdv_int32 castINT_utf8(gdv_ctx ctx, gdv_str s) {
+  gdv_int64 v = 0;
+  if (!gdv_parse_int64(s, -2147483648LL, 2147483647LL, &v)) {
+    gdv_raise(ctx, GDV_ERR_BAD_ARG);
+    return 0;
+  }
+  return (gdv_int32)v;
+}
 // ascii(s): the first byte as a signed char (0 for the empty string)
 GDV_DEV gdv_int32 ascii_utf8(gdv_str s) { return s.len > 0 ? (gdv_int32)(gdv_int8)gdv_str_at(s, 0) : 0; }
 

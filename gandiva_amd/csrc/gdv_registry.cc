@@ -271,6 +271,8 @@ FunctionRegistry::FunctionRegistry() {
   add("locate", {utf8(), utf8(), int32()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
   add("strpos", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
   add("ascii", {utf8()}, int32());
+  add("castINT", {utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
+  add("castBIGINT", {utf8()}, int64(), NullPolicy::kNullIfNull, kNeedsContext);
   add("ltrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("rtrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("btrim", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);

@@ -775,6 +775,27 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
           for (int k = 0; k < subl && eq; k++) eq = map_byte(str[p0 + k], strm) == map_byte(sub[k], subm);
           if (eq) { out->v[i].i = utf8_chars(str, p0) + 1; break; }
         }
+      } else if (!strcmp(f, "castINT") || !strcmp(f, "castBIGINT")) {
+        /* text -> integer: blanks trimmed, optional '-', digits only, must fit the type */
+        int live = out->valid[i] && (!active || active[i]);
+        int lo = 0, hi = xl, neg = 0, ok = 1;
+        out->v[i].i = 0;
+        if (!live) continue;
+        while (lo < hi && map_byte(x[lo], xm) == ' ') lo++;
+        while (hi > lo && map_byte(x[hi - 1], xm) == ' ') hi--;
+        if (lo < hi && map_byte(x[lo], xm) == '-') { neg = 1; lo++; }
+        if (lo >= hi) ok = 0;
+        while (ok && lo < hi - 1 && map_byte(x[lo], xm) == '0') lo++; /* leading zeros */
+        i128 acc = 0;
+        for (int k = lo; k < hi && ok; k++) {
+          int d = map_byte(x[k], xm) - '0';
+          if (d < 0 || d > 9 || hi - lo > 30) ok = 0; else acc = acc * 10 + d;
+        }
+        if (neg) acc = -acc;
+        if (ok && f[4] == 'I') ok = acc >= -(i128)2147483648LL && acc <= (i128)2147483647LL;
+        if (ok && f[4] == 'B') ok = acc >= -(i128)9223372036854775807LL - 1 && acc <= (i128)9223372036854775807LL;
+        if (!ok) { c->err |= 4; continue; }
+        out->v[i].i = (int64_t)acc;
       } else if (!strcmp(f, "ascii")) {
         out->v[i].i = xl > 0 ? (int8_t)map_byte(x[0], xm) : 0;
       } else if (!strcmp(f, "ltrim") || !strcmp(f, "rtrim") || !strcmp(f, "btrim") || !strcmp(f, "trim")) {

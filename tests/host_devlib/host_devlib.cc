@@ -135,6 +135,8 @@ void host_str_int(int fn, const int* off, const unsigned char* data, long size, 
       case 4: out[i] = ascii_utf8(s); break;
       case 5: out[i] = locate_utf8_utf8(ctx, host_lit(lit, litlen), s); break;
       case 6: out[i] = gdv_str_is_ascii(s) ? 1 : 0; break;
+      case 7: err = 0; out[i] = castINT_utf8(ctx, s); if (err) out[i] = (1LL << 40); break;     // marker: raised
+      case 8: err = 0; out[i] = castBIGINT_utf8(ctx, s); if (err) out[i] = -1234567890123456789LL; break;
       default: out[i] = 0; break;
     }
   }

@@ -234,3 +234,15 @@ def test_device_string_functions_match_oracle_on_host(hostlib, seed):
     out = np.zeros(n, dtype=np.uint8)
     hostlib.host_str_in(_p(off), _p(data), C.c_long(size), C.c_long(n), _p(lbytes), _p(loffs), len(lits), _p(out))
     assert out.astype(bool).tolist() == oracle_of(b.make_in_expression(s, lits, STR), BOOL)
+
+
+def test_device_text_to_integer_casts_on_host(hostlib):
+    texts = S.NUMBER_TEXTS
+    arr = pa.array(texts, pa.string())
+    off, data, size = _col(arr)
+    lb, ll = _lit("")
+    for fn, bits, marker in ((7, 32, 1 << 40), (8, 64, -1234567890123456789)):
+        out = np.zeros(len(texts), dtype=np.int64)
+        hostlib.host_str_int(fn, _p(off), _p(data), C.c_long(size), C.c_long(len(texts)), _p(lb), ll, 0, _p(out))
+        want = [marker if S._python_parse(t, bits) == "error" else S._python_parse(t, bits) for t in texts]
+        assert out.tolist() == want, bits
