@@ -172,6 +172,16 @@ long host_str_view(int fn, const int* off, const unsigned char* data, long size,
   }
   return at;
 }
+// general LIKE matcher over a pattern compiled the way gdv_planner.cc compiles it
+void host_str_like(const int* off, const unsigned char* data, long size, long n, const unsigned char* pbyte,
+                   const unsigned char* pkind, int plen, int map, unsigned char* out) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    s.map = map;
+    out[i] = gdv_like(s, pbyte, pkind, plen);
+  }
+}
 // IN over a literal list (concatenated bytes readable 8 past the end, n+1 offsets)
 void host_str_in(const int* off, const unsigned char* data, long size, long n, const unsigned char* bytes,
                  const int* loffs, int nlits, unsigned char* out) {

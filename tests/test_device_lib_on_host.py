@@ -246,3 +246,45 @@ def test_device_text_to_integer_casts_on_host(hostlib):
         hostlib.host_str_int(fn, _p(off), _p(data), C.c_long(size), C.c_long(len(texts)), _p(lb), ll, 0, _p(out))
         want = [marker if S._python_parse(t, bits) == "error" else S._python_parse(t, bits) for t in texts]
         assert out.tolist() == want, bits
+
+
+def _compile_like(pattern, escape=None):
+    """(bytes, kinds) as CodeGen::CompileLike builds them: kind 0 literal byte, 1 '_', 2 '%' (runs collapsed)."""
+    raw = pattern.encode()
+    esc = escape.encode()[0] if escape else None
+    pb, pk, i = bytearray(), bytearray(), 0
+    while i < len(raw):
+        c = raw[i]
+        if esc is not None and c == esc:
+            pb.append(raw[i + 1]); pk.append(0); i += 2
+            continue
+        if c == ord("%"):
+            if not pk or pk[-1] != 2:
+                pb.append(0); pk.append(2)
+        elif c == ord("_"):
+            pb.append(0); pk.append(1)
+        else:
+            pb.append(c); pk.append(0)
+        i += 1
+    return (np.frombuffer(bytes(pb) + b"\0" * 8, dtype=np.uint8).copy(),
+            np.frombuffer(bytes(pk) + b"\0" * 8, dtype=np.uint8).copy(), len(pk))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_device_general_like_matcher_on_host(hostlib, seed):
+    rng = np.random.default_rng(5200 + seed)
+    n = 2000
+    s_arr = S._strings(rng, n, null_fraction=0.0)
+    batch = pa.RecordBatch.from_arrays([s_arr], names=["s"])
+    off, data, size = _col(s_arr)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    for pattern, escape in [("s_ark%", None), ("%a%b%", None), ("_%_", None), ("%_ark", None), ("a_b%c", None),
+                            ("%", None), ("", None), ("__", None), ("%é%", None), ("_本%", None), ("%spa_k%fire", None),
+                            ("100#%", "#"), ("a\\_b\\%c", "\\"), ("%#_%", "#"), ("%%%a%%", None)]:
+        pb, pk, plen = _compile_like(pattern, escape)
+        out = np.zeros(n, dtype=np.uint8)
+        hostlib.host_str_like(_p(off), _p(data), C.c_long(size), C.c_long(n), _p(pb), _p(pk), plen, 0, _p(out))
+        args = [s, b.make_literal(pattern, pa.string())] + ([b.make_literal(escape, pa.string())] if escape else [])
+        want = oracle.project_one(b.make_function("like", args, pa.bool_()), pa.bool_(), batch).to_pylist()
+        assert out.astype(bool).tolist() == want, (pattern, escape)
