@@ -288,3 +288,28 @@ def test_device_general_like_matcher_on_host(hostlib, seed):
         args = [s, b.make_literal(pattern, pa.string())] + ([b.make_literal(escape, pa.string())] if escape else [])
         want = oracle.project_one(b.make_function("like", args, pa.bool_()), pa.bool_(), batch).to_pylist()
         assert out.astype(bool).tolist() == want, (pattern, escape)
+
+
+def test_device_decimal_functions_reproduce_the_c4_golden_fixture(hostlib):
+    """The TPC-H Q1 projections of BASELINE config C4, operator by operator, through the
+    host-built device functions: must reproduce tests/golden/c4.arrow."""
+    import test_golden as G
+    ins, outs = G.load("c4")
+    ep, disc, tax, _ = ins
+    n = len(ep)
+
+    def call(code, xa, ta, xb, tb, rt):
+        out = np.zeros(2 * n, dtype=np.uint64)
+        err = hostlib.host_decimal_binary(code, _p(xa), ta[0], ta[1], _p(xb), tb[0], tb[1], rt[0], rt[1], _p(out),
+                                          C.c_long(n))
+        assert err == 0
+        return out
+    one = np.zeros(2 * n, dtype=np.uint64)
+    one[0::2] = 100                                                       # 1.00 as decimal(15,2)
+    one_minus = call(1, one, (15, 2), _raw128(disc), (15, 2), (16, 2))
+    disc_price = call(2, _raw128(ep), (15, 2), one_minus, (16, 2), (32, 4))
+    one_plus = call(0, one, (15, 2), _raw128(tax), (15, 2), (16, 2))
+    charge = call(2, disc_price, (32, 4), one_plus, (16, 2), (38, 6))
+    for raw, want in ((disc_price, outs[0]), (charge, outs[1])):
+        valid = [v is not None for v in want.to_pylist()]
+        assert _from_raw128(raw, want.type, valid) == want.to_pylist()
