@@ -1,6 +1,8 @@
 #include "gdv_engine.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,7 +52,7 @@ class LruCache {
 
 std::string SchemaKey(const Schema& s) {
   std::string k;
-  for (auto& f : s) k += f.name + ":" + f.type.ToString() + ";";
+  for (auto& f : s) k += std::to_string(f.name.size()) + ":" + f.name + ":" + f.type.ToString() + ";";
   return k;
 }
 
@@ -419,7 +421,7 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
   std::string key = "P|" + SchemaKey(schema) + "|";
   for (auto& e : exprs) {
     if (!e) return Status::Invalid("Expression cannot be null");
-    key += e->ToString() + "->" + e->result().type.ToString() + ";";
+    key += e->CacheKey() + ";";
   }
   key += "|m" + std::to_string(static_cast<int>(mode)) + "|" + opts.Key() +
          (config.optimize ? "|O" : "|o");
@@ -449,6 +451,14 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   if (has_sel != (plan_.mode != SelectionMode::kNone) || (has_sel && sel->mode != plan_.mode))
     return Status::Invalid("selection vector type does not match the mode the projector was built for");
   const int64_t out_rows = has_sel ? sel->num_slots : num_rows;
+  if (has_sel) {
+    // what the selection vector's index type can address bounds its slot count
+    const int64_t cap = sel->mode == SelectionMode::kUInt16 ? 65536
+                        : sel->mode == SelectionMode::kUInt32 ? (int64_t{1} << 32)
+                                                              : INT64_MAX;
+    if (sel->num_slots < 0 || sel->num_slots > cap)
+      return Status::Invalid("selection vector: invalid slot count " + std::to_string(sel->num_slots));
+  }
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
 
@@ -461,6 +471,9 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  // pooled staging blocks (e.g. the zero-padded copy of a tiny var-len buffer) go back to the
+  // pool when this call returns: an asynchronous evaluation must not outlive them
+  drain.armed = drain.armed || !st.buffers.empty();
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
 
   if (has_sel) {
@@ -617,7 +630,7 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   if (out == nullptr) return Status::Invalid("Filter::Make: null output pointer");
   if (!condition) return Status::Invalid("Condition cannot be null");
   CodegenOptions opts = CodegenOptions::FromEnv();
-  std::string key = "F|" + SchemaKey(schema) + "|" + condition->ToString() + "|" + opts.Key() +
+  std::string key = "F|" + SchemaKey(schema) + "|" + condition->CacheKey() + "|" + opts.Key() +
                     (config.optimize ? "|O" : "|o");
   if (auto hit = FilterCache().Get(key)) {
     *out = hit;

@@ -1,5 +1,6 @@
 #include "gdv_node.h"
 
+#include <cstdio>
 #include <cstring>
 #include <sstream>
 
@@ -209,6 +210,79 @@ std::string InNode::ToString() const {
     first = false;
   }
   return s + ")";
+}
+
+// ---------------------------------------------------------------- cache keys
+
+static void KeyBytes(std::string* out, const std::string& b) {
+  *out += std::to_string(b.size());
+  *out += ':';
+  *out += b;
+}
+
+static void KeyLiteral(std::string* out, const DataType& t, const Literal& v) {
+  if (v.is_null) {
+    *out += "null;";
+  } else if (t.is_varlen()) {
+    KeyBytes(out, v.bytes);
+    *out += ';';
+  } else {
+    char buf[48];
+    snprintf(buf, sizeof(buf), "%llx.%llx;", static_cast<unsigned long long>(v.hi),
+             static_cast<unsigned long long>(v.lo));
+    *out += buf;
+  }
+}
+
+void FieldNode::AppendKey(std::string* out) const {
+  *out += "F[";
+  KeyBytes(out, field_.name);
+  *out += ' ' + return_type().ToString() + ']';
+}
+
+void LiteralNode::AppendKey(std::string* out) const {
+  *out += "L[" + return_type().ToString() + ' ';
+  KeyLiteral(out, return_type(), value_);
+  *out += ']';
+}
+
+void FunctionNode::AppendKey(std::string* out) const {
+  *out += "f[";
+  KeyBytes(out, name_);
+  *out += ' ' + return_type().ToString() + ' ' + std::to_string(children_.size());
+  for (auto& c : children_) {
+    *out += ' ';
+    c->AppendKey(out);
+  }
+  *out += ']';
+}
+
+void IfNode::AppendKey(std::string* out) const {
+  *out += "I[" + return_type().ToString() + ' ';
+  cond_->AppendKey(out);
+  *out += ' ';
+  then_->AppendKey(out);
+  *out += ' ';
+  else_->AppendKey(out);
+  *out += ']';
+}
+
+void BooleanNode::AppendKey(std::string* out) const {
+  *out += (op_ == kAnd) ? "A[" : "O[";
+  *out += std::to_string(children_.size());
+  for (auto& c : children_) {
+    *out += ' ';
+    c->AppendKey(out);
+  }
+  *out += ']';
+}
+
+void InNode::AppendKey(std::string* out) const {
+  *out += "N[" + value_type_.ToString() + ' ';
+  eval_->AppendKey(out);
+  *out += ' ' + std::to_string(values_.size()) + ' ';
+  for (auto& v : values_) KeyLiteral(out, value_type_, v);
+  *out += ']';
 }
 
 }  // namespace gdv

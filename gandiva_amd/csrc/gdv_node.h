@@ -32,6 +32,11 @@ class Node {
   NodeKind kind() const { return kind_; }
   const DataType& return_type() const { return type_; }
   virtual std::string ToString() const = 0;
+  // Unambiguous serialisation for the plan caches: ToString() is pinned by the reference's
+  // tests (no parentheses around nested AND/OR, string literals unescaped), so two different
+  // trees can render alike; this one length-prefixes names and literal bytes and brackets
+  // every node.
+  virtual void AppendKey(std::string* out) const = 0;
 
  private:
   NodeKind kind_;
@@ -43,6 +48,7 @@ class FieldNode : public Node {
   explicit FieldNode(Field f) : Node(NodeKind::kField, f.type), field_(std::move(f)) {}
   const Field& field() const { return field_; }
   std::string ToString() const override;
+  void AppendKey(std::string* out) const override;
 
  private:
   Field field_;
@@ -54,6 +60,7 @@ class LiteralNode : public Node {
   const Literal& value() const { return value_; }
   bool is_null() const { return value_.is_null; }
   std::string ToString() const override;
+  void AppendKey(std::string* out) const override;
 
  private:
   Literal value_;
@@ -66,6 +73,7 @@ class FunctionNode : public Node {
   const std::string& name() const { return name_; }
   const NodeVector& children() const { return children_; }
   std::string ToString() const override;
+  void AppendKey(std::string* out) const override;
 
  private:
   std::string name_;
@@ -80,6 +88,7 @@ class IfNode : public Node {
   const NodePtr& then_node() const { return then_; }
   const NodePtr& else_node() const { return else_; }
   std::string ToString() const override;
+  void AppendKey(std::string* out) const override;
 
  private:
   NodePtr cond_, then_, else_;
@@ -93,6 +102,7 @@ class BooleanNode : public Node {
   Op op() const { return op_; }
   const NodeVector& children() const { return children_; }
   std::string ToString() const override;
+  void AppendKey(std::string* out) const override;
 
  private:
   Op op_;
@@ -111,6 +121,7 @@ class InNode : public Node {
   const DataType& value_type() const { return value_type_; }
   const std::vector<Literal>& values() const { return values_; }
   std::string ToString() const override;
+  void AppendKey(std::string* out) const override;
 
  private:
   NodePtr eval_;
@@ -126,6 +137,11 @@ class Expression {
   const NodePtr& root() const { return root_; }
   const Field& result() const { return result_; }
   std::string ToString() const { return root_->ToString(); }
+  std::string CacheKey() const {
+    std::string k;
+    root_->AppendKey(&k);
+    return k + "->" + result_.type.ToString();
+  }
 
  private:
   NodePtr root_;

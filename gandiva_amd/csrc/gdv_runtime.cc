@@ -85,6 +85,16 @@ static bool DirWritable(const std::string& d) {
   return access(d.c_str(), W_OK) == 0;
 }
 
+// A cache directory outside the installation is trusted only if it is ours and nobody else
+// can write to it: code objects found there are loaded and run against the caller's HBM.
+static bool PrivateDir(const std::string& d) {
+  mkdir(d.c_str(), 0700);
+  struct stat st;
+  if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) return false;
+  return access(d.c_str(), W_OK) == 0;
+}
+
 std::string Runtime::cache_dir() {
   if (const char* e = std::getenv("GANDIVA_AMD_CACHE_DIR")) {
     std::string d = e;
@@ -99,9 +109,19 @@ std::string Runtime::cache_dir() {
                     "/_kcache";
     if (DirWritable(d)) return d;
   }
-  std::string d = "/tmp/gandiva_amd_kcache";
-  DirWritable(d);
-  return d;
+  // per-user cache: $XDG_CACHE_HOME or ~/.cache, created 0700 and verified; as a last
+  // resort a per-uid directory under /tmp with the same checks.  "" = no disk cache.
+  std::string base;
+  if (const char* x = std::getenv("XDG_CACHE_HOME")) base = x;
+  else if (const char* h = std::getenv("HOME")) base = std::string(h) + "/.cache";
+  if (!base.empty()) {
+    mkdir(base.c_str(), 0700);
+    std::string d = base + "/gandiva_amd_kcache";
+    if (PrivateDir(d)) return d;
+  }
+  std::string d = "/tmp/gandiva_amd_kcache_" + std::to_string(static_cast<long>(geteuid()));
+  if (PrivateDir(d)) return d;
+  return "";
 }
 
 static uint64_t Fnv(const char* s, size_t n) {
@@ -114,14 +134,17 @@ static uint64_t Fnv(const char* s, size_t n) {
 }
 
 Status Runtime::CompileToCodeObject(const std::string& source, const std::string& kernel_name,
-                                    std::vector<char>* code, bool* from_cache) {
+                                    std::vector<char>* code, bool* from_cache,
+                                    bool ignore_cached) {
   const std::string a = arch();
   static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
   char tag[40];
   snprintf(tag, sizeof(tag), "%016llx", static_cast<unsigned long long>(lib_hash));
-  const std::string path = cache_dir() + "/" + kernel_name + "." + tag + "." + a + ".hsaco";
-  const bool use_disk = std::getenv("GDV_NO_DISK_CACHE") == nullptr;
-  if (use_disk) {
+  const std::string dir = cache_dir();
+  const std::string path = dir + "/" + kernel_name + "." + tag + "." + a + ".hsaco";
+  const bool use_disk = !dir.empty() && std::getenv("GDV_NO_DISK_CACHE") == nullptr;
+  if (use_disk && ignore_cached) unlink(path.c_str());  // stale or corrupt: recompiled below
+  if (use_disk && !ignore_cached) {
     std::ifstream f(path, std::ios::binary);
     if (f) {
       code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -133,7 +156,7 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
   }
   if (from_cache) *from_cache = false;
   if (std::getenv("GDV_DUMP_SOURCE")) {
-    std::ofstream f(cache_dir() + "/" + kernel_name + ".hip");
+    std::ofstream f((dir.empty() ? std::string("/tmp") : dir) + "/" + kernel_name + ".hip");
     f << source;
   }
 
@@ -189,11 +212,24 @@ Status Runtime::GetKernel(const std::string& source, const std::string& kernel_n
     }
   }
   std::vector<char> code;
-  GDV_RETURN_NOT_OK(CompileToCodeObject(source, kernel_name, &code));
+  bool from_cache = false;
+  GDV_RETURN_NOT_OK(CompileToCodeObject(source, kernel_name, &code, &from_cache));
   auto k = std::make_unique<CompiledKernel>();
   k->name = kernel_name;
-  GDV_HIP_RETURN_NOT_OK(hipModuleLoadData(&k->module, code.data()));
-  GDV_HIP_RETURN_NOT_OK(hipModuleGetFunction(&k->function, k->module, kernel_name.c_str()));
+  hipError_t le = hipModuleLoadData(&k->module, code.data());
+  if (le == hipSuccess) le = hipModuleGetFunction(&k->function, k->module, kernel_name.c_str());
+  if (le != hipSuccess && from_cache) {
+    // a cached code object that does not load (truncated, built by another toolchain): drop
+    // the file and compile afresh instead of failing every Make from now on
+    (void)hipGetLastError();
+    if (k->module != nullptr) (void)hipModuleUnload(k->module);
+    k->module = nullptr;
+    GDV_RETURN_NOT_OK(CompileToCodeObject(source, kernel_name, &code, nullptr, true));
+    le = hipModuleLoadData(&k->module, code.data());
+    if (le == hipSuccess) le = hipModuleGetFunction(&k->function, k->module, kernel_name.c_str());
+  }
+  if (le != hipSuccess)
+    return Status::ExecutionError(std::string("loading the compiled kernel failed: ") + hipGetErrorString(le));
   std::lock_guard<std::mutex> g(mu_);
   auto& slot = kernels_[kernel_name];
   if (!slot) slot = std::move(k);

@@ -43,7 +43,8 @@ class Runtime {
   // Compiles `source` (which #includes "gdv_device_lib.hpp") for arch() and returns the
   // code object; cached on disk by kernel name (= hash of the source) + library hash.
   Status CompileToCodeObject(const std::string& source, const std::string& kernel_name,
-                             std::vector<char>* code, bool* from_cache = nullptr);
+                             std::vector<char>* code, bool* from_cache = nullptr,
+                             bool ignore_cached = false);
   // CompileToCodeObject + hipModuleLoadData; cached per process.
   Status GetKernel(const std::string& source, const std::string& kernel_name,
                    const CompiledKernel** out);

@@ -285,9 +285,6 @@ def test_hip_decimal_divide_by_zero():
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("GDV_RUN_UNVERIFIED") != "1",
-                    reason="added after round 1's GPU budget was spent: the same device functions are verified on "
-                           "the host build (tests/test_device_lib_on_host.py); enable once it has run on a GPU")
 @pytest.mark.parametrize("seed", range(6))
 def test_hip_decimal_ops_on_dense_random_digits(seed):
     rng = np.random.default_rng(900 + seed)

@@ -513,3 +513,30 @@ def test_more_than_2_to_32_rows_device_resident():
     tail = torch.nonzero(a[tail_lo:] > 100).flatten() + tail_lo
     assert torch.equal(ids[k - tail.numel():], tail)
     assert int(ids[-1]) >= (1 << 32) - 4096  # indices really exceed 32 bits' reach
+
+
+def test_plan_cache_distinguishes_trees_that_render_alike():
+    """The reference's ToString() is pinned without parentheses around nested AND/OR and with
+    unescaped string literals, so different trees can render to the same text.  The plan cache
+    must not confuse them (round-1 advisor finding): both nestings built in ONE process, each
+    against the oracle; same for an IN list whose quoting is ambiguous."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    batch = _batch(rng, [pa.bool_(), pa.bool_(), pa.bool_()], n, 0.2)
+    b = gandiva.TreeExprBuilder()
+    x, y, z = (b.make_field(batch.schema.field(i)) for i in range(3))
+    left = b.make_or([b.make_and([x, y]), z])     # (x AND y) OR z
+    right = b.make_and([x, b.make_or([y, z])])    # x AND (y OR z)
+    assert str(left) == str(right)
+    for tree in (left, right):
+        _check_project([b.make_expression(tree, pa.field("r", pa.bool_()))], batch)
+        cond = b.make_condition(tree)
+        got = gandiva.make_filter(batch.schema, cond).evaluate(batch, None)
+        assert got.to_array().equals(oracle.filter_indices(cond, batch, "int32"))
+    sb = pa.RecordBatch.from_arrays([pa.array(["a", "b", "a', 'b", None, "c"])], names=["s"])
+    s = b.make_field(sb.schema.field(0))
+    two = b.make_in_expression(s, ["a", "b"], pa.string())
+    one = b.make_in_expression(s, ["a', 'b"], pa.string())
+    assert str(two) == str(one)
+    for tree in (two, one):
+        _check_project([b.make_expression(tree, pa.field("r", pa.bool_()))], sb)

@@ -520,8 +520,6 @@ def test_text_to_integer_casts_compile_for_gfx950():
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("GDV_RUN_UNVERIFIED") != "1",
-                    reason="added after round 1's GPU budget was spent (host-verified: test_device_lib_on_host.py)")
 def test_hip_text_to_integer_casts_match_oracle():
     from helpers import assert_bit_exact
     good = [t for t in NUMBER_TEXTS if _python_parse(t, 32) != "error"]
