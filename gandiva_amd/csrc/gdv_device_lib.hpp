@@ -140,6 +140,25 @@ GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int 
   return (lane == u) ? word : acc;  // v_cndmask with a scalar source
 }
 
+// Per-sub-tile register arrays inside a loop that is NOT unrolled: the current sub-tile's
+// element is always index 0 and every array rotates left by one at the end of an iteration
+// (static indices only: the arrays stay in registers; after GDV_U iterations they are back in
+// their original order, and a value written at [0] in iteration u ends up at [u]).
+#ifdef GDV_UNROLL_ROWS
+#define GDV_ROW_LOOP _Pragma("unroll")
+#else
+#define GDV_ROW_LOOP _Pragma("nounroll")
+#endif
+#ifdef GDV_U
+template <typename T>
+GDV_DEV void gdv_rot(T (&a)[GDV_U]) {
+  const T t = a[0];
+#pragma unroll
+  for (int k = 0; k + 1 < GDV_U; k++) a[k] = a[k + 1];
+  a[GDV_U - 1] = t;
+}
+#endif
+
 // Bit of an arbitrary row (selection-vector path: rows are gathered, no word structure).
 GDV_DEV bool gdv_bitmap_bit(const gdv_bitmap& bm, gdv_int64 row) {
   gdv_int64 pos = row + bm.shift;
@@ -901,41 +920,35 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 
 // ------------------------------------------------------------------ utf8 / binary
 // A string value inside a kernel is a VIEW: pointer + byte length into an input data buffer
-// (or a literal in constant memory) plus a byte map applied on read (0 none, 1 ASCII upper,
-// 2 ASCII lower).  substr / trim produce narrower views, upper / lower set the map, so no
-// per-row scratch is ever needed; the bytes are materialised exactly once, by the copy pass
-// of a var-len output (gdv_str_copy), or consumed in place by predicates (like, equal …).
-#define GDV_NPRE 4  // 8-byte words of every input string prefetched into registers (32 bytes)
+// (or a literal in the plan's constant block) plus a byte map applied on read (0 none, 1 ASCII
+// upper, 2 ASCII lower).  substr / trim produce narrower views, upper / lower set the map, so no
+// per-row scratch is ever needed; the bytes are materialised exactly once, by the copy stage of
+// a var-len output, or consumed in place by predicates (like, equal ...).
+//
+// Round 2: views carry no register cache any more.  Kernels over var-len columns first SWEEP the
+// contiguous byte span of a wave tile with lanes over BYTES (16 B/lane, coalesced): that pass
+// answers the tile-wide questions byte-parallel (is every byte ASCII?  where does '%needle%'
+// match?) and leaves the lines in L2 / L1 for the per-row functions below.
+#define GDV_STR_ASCII 1  // flags: every byte of the buffer range this view came from is < 0x80
+#define GDV_STR_INBUF 2  // flags: 8-byte loads starting anywhere inside the view stay inside its buffer
+// (out-of-line device functions fault on this stack — measured, profiles/r02_c5_codesize.txt —
+// so cold paths stay inline and the row loop of string kernels is simply not unrolled)
+#define GDV_COLD __forceinline__
 struct gdv_str {
   const gdv_uint8* p;
   gdv_int32 len;
   gdv_int32 map;
   const gdv_uint8* lim;  // end of the readable buffer p points into (8-byte loads stop here)
-  // Register cache of the first GDV_NPRE words at `cp` (nullptr: no cache).  The words of ALL
-  // sub-tiles of a wave tile are loaded together, right after the offsets arrive (phase 1b of
-  // the generated kernel): without it every string function walks memory with one dependent
-  // load at a time and the kernel is bound by ~20 serialised round trips per tile.
-  const gdv_uint8* cp;
-  gdv_uint64 pre[GDV_NPRE];
+  gdv_int32 flags;
 };
 GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
-                             const gdv_uint8* lim) {
+                             const gdv_uint8* lim, gdv_int32 flags = 0) {
   gdv_str s;
   s.p = base + begin;
   s.len = end - begin;
   s.map = 0;
   s.lim = lim;
-  s.cp = nullptr;
-#pragma unroll
-  for (int j = 0; j < GDV_NPRE; j++) s.pre[j] = 0;
-  return s;
-}
-GDV_DEV gdv_str gdv_make_str_cached(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
-                                    const gdv_uint8* lim, const gdv_uint64* pre) {
-  gdv_str s = gdv_make_str(base, begin, end, lim);
-  s.cp = s.p;
-#pragma unroll
-  for (int j = 0; j < GDV_NPRE; j++) s.pre[j] = pre[j];
+  s.flags = flags;
   return s;
 }
 GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
@@ -982,23 +995,10 @@ GDV_DEV gdv_uint64 gdv_map8(gdv_uint64 w, gdv_int32 map) {
   const gdv_uint64 in_range = (h + lo) & ~(h + hi) & ascii;
   return w ^ (in_range >> 2);  // toggle bit 5 (0x20) of the letters in range
 }
-GDV_DEV gdv_uint64 gdv_pre_word(const gdv_str& s, gdv_int32 j) {  // j may be any value
-  gdv_uint64 w = 0;
-#pragma unroll
-  for (int k = 0; k < GDV_NPRE; k++) w = (j == k) ? s.pre[k] : w;
-  return w;
-}
-// raw bytes [i, i+8) of the string: from the register cache when they lie inside it
+// raw bytes [i, i+8) of the string (bytes past the buffer limit read as 0)
 GDV_DEV gdv_uint64 gdv_raw_word_at(const gdv_str& s, gdv_int32 i) {
-  if (s.cp != nullptr) {
-    const gdv_int64 d = (gdv_int64)(s.p - s.cp) + i;
-    if (d >= 0 && d + 8 <= 8 * GDV_NPRE) {
-      const gdv_int32 j = (gdv_int32)(d >> 3), sh = (gdv_int32)(d & 7) * 8;
-      const gdv_uint64 lo = gdv_pre_word(s, j);
-      if (sh == 0) return lo;
-      return (lo >> sh) | (gdv_pre_word(s, j + 1) << (64 - sh));
-    }
-  }
+  // INBUF is wave-uniform (one range test per tile / literal tables are padded): a scalar branch
+  if (s.flags & GDV_STR_INBUF) return gdv_load8_raw(s.p + i);
   return gdv_load8(s.p + i, s.lim);
 }
 // mapped bytes [i, i+8) of the string (bytes past the buffer limit read as 0)
@@ -1009,29 +1009,6 @@ GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
 // overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
 // 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
-  // Whole, unsliced string inside the register cache (an input column passed through or
-  // case-mapped — the test folds at compile time for such views): straight-line stores of
-  // the cached words with constant indices, no cache selects, no limit arithmetic, then a
-  // 4/2/1 ladder for the last partial word.
-  if (s.cp != nullptr && s.p == s.cp && s.len <= 8 * GDV_NPRE) {
-#pragma unroll
-    for (int j = 0; j < GDV_NPRE; j++) {
-      if (8 * j + 8 <= s.len) {
-        const gdv_uint64 w = gdv_map8(s.pre[j], s.map);
-        __builtin_memcpy(dst + 8 * j, &w, 8);
-      }
-    }
-    const gdv_int32 r = s.len & 7;
-    if (r != 0) {
-      const gdv_int32 at = s.len & ~7;
-      gdv_uint64 w = gdv_map8(gdv_pre_word(s, s.len >> 3), s.map);
-      gdv_int32 o = at;
-      if (r & 4) { const gdv_uint32 v = (gdv_uint32)w; __builtin_memcpy(dst + o, &v, 4); o += 4; w >>= 32; }
-      if (r & 2) { const gdv_uint16 v = (gdv_uint16)w; __builtin_memcpy(dst + o, &v, 2); o += 2; w >>= 16; }
-      if (r & 1) dst[o] = (gdv_uint8)w;
-    }
-    return;
-  }
   if (s.len >= 8) {
     gdv_int32 i = 0;
     for (; i + 8 <= s.len; i += 8) {
@@ -1054,73 +1031,98 @@ GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
     if (s.len > 2) dst[2] = (gdv_uint8)(w >> 16);
   }
 }
-// ---- LDS staging of var-len output bytes.  Every lane writes its row's bytes into the
-// wave's private LDS window at the row's offset inside the sub-tile (byte-granular, unaligned
-// ds_write_b64: cheap), then the wave streams the window to HBM as consecutive 16-byte pieces
-// — one coalesced store instruction per KiB instead of several scattered 8-byte stores per
-// row.  The last piece is shifted back to end exactly at `cnt` (it overlaps its neighbour with
-// identical bytes), so no byte ladder is needed; windows under 16 bytes go out bytewise.
-#define GDV_OUT_WIN 2048
+#ifndef GDV_HOST_BUILD
+// One row's bytes into the wave's LDS staging window: whole words, then a 4/2/1 ladder.
+typedef __attribute__((address_space(3))) gdv_uint8 gdv_lds_u8;
+GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
+  const gdv_int32 len = s.len;
+  gdv_int32 i = 0;
+  for (; i + 8 <= len; i += 8) {
+    const gdv_uint64 w = gdv_word_at(s, i);
+    __builtin_memcpy(dst + i, &w, 8);
+  }
+  const gdv_int32 r = len - i;
+  if (r > 0) {
+    gdv_uint64 w = gdv_word_at(s, i);  // bytes past the view are never stored
+    if (r & 4) { const gdv_uint32 v = (gdv_uint32)w; __builtin_memcpy(dst + i, &v, 4); i += 4; w >>= 32; }
+    if (r & 2) { const gdv_uint16 v = (gdv_uint16)w; __builtin_memcpy(dst + i, &v, 2); i += 2; w >>= 16; }
+    if (r & 1) dst[i] = (gdv_uint8)w;
+  }
+}
+#endif
+// the same out of line: rows that bypass the LDS staging window (wave tiles whose bytes do not
+// fit it) — rare, and inlining it at every sub-tile of every output doubles the kernel
+static __device__ GDV_COLD void gdv_str_copy_direct(gdv_uint8* dst, const gdv_uint8* p, gdv_int32 len, gdv_int32 map,
+                                                   const gdv_uint8* lim) {
+  gdv_str s;
+  s.p = p; s.len = len; s.map = map; s.lim = lim; s.flags = 0;
+  gdv_str_copy(dst, s);
+}
+// ---- LDS staging of var-len output bytes.  Every lane writes its row's bytes into the wave's
+// private LDS window at the row's offset inside the wave tile (byte-granular, unaligned LDS
+// writes: cheap), then the wave streams the window to HBM as 16-byte pieces aligned in the
+// OUTPUT buffer (head and tail bytes singly) — one coalesced store instruction per KiB instead of
+// several scattered stores per row.
+#define GDV_OUT_WIN (GDV_U * 64 * 8)  // staged bytes per wave tile and output: 8 per row on average
+#ifndef GDV_HOST_BUILD
 GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gdv_int32 cnt, int lane) {
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: ordering only
-  if (cnt >= 16) {
-#pragma unroll
-    for (int i = 0; i < GDV_OUT_WIN / 1024; i++) {
-      const gdv_int32 c = lane * 16 + i * 1024;
-      if (c < cnt) {
-        const gdv_int32 c2 = c + 16 <= cnt ? c : cnt - 16;
-        gdv_uint64 w[2];
-        __builtin_memcpy(w, win + c2, 16);
-        __builtin_memcpy(dst + c2, w, 16);
-      }
-    }
-  } else if (lane < cnt) {
-    dst[lane] = win[lane];
+  gdv_int32 head = (gdv_int32)((16 - ((gdv_uint64)dst & 15)) & 15);
+  head = head < cnt ? head : cnt;
+  if (lane < head) dst[lane] = win[lane];
+  const gdv_int32 body = (cnt - head) & ~15;
+  for (gdv_int32 i = lane * 16; i < body; i += 1024) {
+    gdv_uint64 w[2];
+    __builtin_memcpy(w, win + head + i, 16);
+    __builtin_memcpy(__builtin_assume_aligned(dst + head + i, 16), w, 16);
   }
+  const gdv_int32 t0 = head + body;
+  if (t0 + lane < cnt) dst[t0 + lane] = win[t0 + lane];
   __builtin_amdgcn_wave_barrier();
 }
+// The output bytes of a wave tile ARE the (mapped) bytes of a contiguous input span (an input
+// column passed through, upper(col), lower(col) with no row dropped): stream them, lanes over
+// bytes, 16 B per lane, stores aligned in the output buffer.
+GDV_DEV void gdv_flat_copy(gdv_uint8* __restrict__ dst, const gdv_uint8* __restrict__ src, gdv_int32 cnt,
+                           gdv_int32 map, int lane) {
+  gdv_int32 head = (gdv_int32)((16 - ((gdv_uint64)dst & 15)) & 15);
+  head = head < cnt ? head : cnt;
+  if (lane < head) dst[lane] = gdv_map_byte(src[lane], map);
+  const gdv_int32 body = (cnt - head) & ~15;
+  for (gdv_int32 i = lane * 16; i < body; i += 1024) {
+    gdv_uint64 w[2];
+    __builtin_memcpy(w, src + head + i, 16);
+    w[0] = gdv_map8(w[0], map);
+    w[1] = gdv_map8(w[1], map);
+    __builtin_memcpy(__builtin_assume_aligned(dst + head + i, 16), w, 16);
+  }
+  const gdv_int32 t0 = head + body;
+  if (t0 + lane < cnt) dst[t0 + lane] = gdv_map_byte(src[t0 + lane], map);
+}
+#endif
 
 GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
 // number of UTF-8 characters = bytes that are not continuation bytes (10xxxxxx)
-// The whole string is the (unsliced) register cache: its words can be used with constant
-// indices.  For views made straight from an input column the first two tests fold at
-// compile time.
-GDV_DEV bool gdv_str_in_cache(const gdv_str& s) {
-  return s.cp != nullptr && s.p == s.cp && s.len <= 8 * GDV_NPRE;
-}
 GDV_DEV gdv_uint64 gdv_mask_upto(gdv_int32 nbytes) {  // any nbytes: <= 0 -> 0, >= 8 -> all ones
   return nbytes <= 0 ? 0ull : gdv_low_bytes_mask(nbytes);
 }
 GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
+  if (s.flags & GDV_STR_ASCII) return s.len;
   gdv_int32 cont = 0;
-  if (gdv_str_in_cache(s)) {
-#pragma unroll
-    for (int j = 0; j < GDV_NPRE; j++) {
-      const gdv_uint64 w = s.pre[j] & gdv_mask_upto(s.len - 8 * j);
-      cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
-    }
-    return s.len - cont;
-  }
   for (gdv_int32 i = 0; i < s.len; i += 8) {
     gdv_uint64 w = gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
     cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
   }
   return s.len - cont;
 }
-GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
+static __device__ GDV_COLD bool gdv_bytes_are_ascii(const gdv_uint8* p, gdv_int32 len, const gdv_uint8* lim) {
   gdv_uint64 acc = 0;
-  if (gdv_str_in_cache(s)) {
-    // Conservative on purpose: words that start inside the string are ORed whole, so up to 7
-    // bytes of the NEXT string take part.  A false "not ASCII" only sends the caller down its
-    // general UTF-8 path (same result); building the exact byte mask costs more vector
-    // instructions than everything else in this function.
-#pragma unroll
-    for (int j = 0; j < GDV_NPRE; j++) acc |= (8 * j < s.len) ? s.pre[j] : 0ull;
-    return (acc & GDV_B80) == 0;
-  }
-  for (gdv_int32 i = 0; i < s.len; i += 8)
-    acc |= gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
+  for (gdv_int32 i = 0; i < len; i += 8) acc |= gdv_load8(p + i, lim) & gdv_low_bytes_mask(len - i);
   return (acc & GDV_B80) == 0;
+}
+GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
+  if (s.flags & GDV_STR_ASCII) return true;  // answered for the whole tile by the byte sweep
+  return gdv_bytes_are_ascii(s.p, s.len, s.lim);
 }
 // bytes [i, i+n) of s equal the n bytes at q (n >= 0; q readable up to qlim)
 GDV_DEV bool gdv_bytes_equal(const gdv_str& s, gdv_int32 i, const gdv_uint8* q, const gdv_uint8* qlim,
@@ -1240,20 +1242,10 @@ GDV_DEV bool ends_with_utf8_utf8(gdv_str s, gdv_str suffix) {
   return suffix.len <= s.len && gdv_str_equal_words(s, s.len - suffix.len, suffix, suffix.len);
 }
 
-// substr(s, from, len): 1-based character positions (UTF-8 aware); from < 0 counts from the
-// end; from == 0 behaves like 1; len <= 0 or a start outside the string give "".
-GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 count) {
+// the general (non-ASCII) substr: walks UTF-8 lead bytes; out of line, tiles of pure ASCII never call it
+static __device__ GDV_COLD gdv_str gdv_substr_utf8_general(gdv_str s, gdv_int64 from, gdv_int64 count) {
   gdv_str r = s;
   r.len = 0;
-  if (count <= 0 || s.len <= 0) return r;
-  if (gdv_str_is_ascii(s)) {  // character index == byte index
-    gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? (gdv_int64)s.len + from : 0);
-    if (start < 0 || start >= s.len) return r;
-    gdv_int64 stop = start + count < s.len ? start + count : s.len;
-    r.p = s.p + start;
-    r.len = (gdv_int32)(stop - start);
-    return r;
-  }
   const gdv_int64 glyphs = gdv_utf8_count(s);
   gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? glyphs + from : 0);
   if (start < 0 || start >= glyphs) return r;
@@ -1270,22 +1262,43 @@ GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 cou
   r.len = b1 - b0;
   return r;
 }
+
+// substr(s, from, len): 1-based character positions (UTF-8 aware); from < 0 counts from the
+// end; from == 0 behaves like 1; len <= 0 or a start outside the string give "".
+GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 count) {
+  gdv_str r = s;
+  r.len = 0;
+  if (count <= 0 || s.len <= 0) return r;
+  if (gdv_str_is_ascii(s)) {  // character index == byte index
+    gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? (gdv_int64)s.len + from : 0);
+    if (start < 0 || start >= s.len) return r;
+    gdv_int64 stop = start + count < s.len ? start + count : s.len;
+    r.p = s.p + start;
+    r.len = (gdv_int32)(stop - start);
+    return r;
+  }
+  return gdv_substr_utf8_general(s, from, count);
+}
 GDV_DEV gdv_str substr_utf8_int64(gdv_str s, gdv_int64 from) {
   return substr_utf8_int64_int64(s, from, 0x7fffffff);
 }
 // byte offset of the character with 0-based index `ci` (s.len when the string is shorter)
-GDV_DEV gdv_int32 gdv_utf8_byte_pos(const gdv_str& s, gdv_int32 ci) {
-  if (ci <= 0) return 0;
+static __device__ GDV_COLD gdv_int32 gdv_utf8_byte_pos_general(const gdv_uint8* p, gdv_int32 len, gdv_int32 ci) {
   gdv_int32 g = 0;
-  for (gdv_int32 i = 0; i < s.len; i++) {
-    if (gdv_is_utf8_lead(s.p[i])) {
+  for (gdv_int32 i = 0; i < len; i++) {
+    if (gdv_is_utf8_lead(p[i])) {
       if (g == ci) return i;
       g++;
     }
   }
-  return s.len;
+  return len;
 }
-GDV_DEV gdv_str gdv_empty_str() { return gdv_make_str(nullptr, 0, 0, nullptr); }
+GDV_DEV gdv_int32 gdv_utf8_byte_pos(const gdv_str& s, gdv_int32 ci) {
+  if (ci <= 0) return 0;
+  if (s.flags & GDV_STR_ASCII) return ci < s.len ? ci : s.len;
+  return gdv_utf8_byte_pos_general(s.p, s.len, ci);
+}
+GDV_DEV gdv_str gdv_empty_str() { return gdv_make_str(nullptr, 0, 0, nullptr, GDV_STR_ASCII | GDV_STR_INBUF); }
 // left(s, n): the first n characters; n < 0: all but the last |n|
 GDV_DEV gdv_str left_utf8_int32(gdv_str s, gdv_int32 n) {
   gdv_str r = s;
@@ -1396,7 +1409,7 @@ GDV_DEV gdv_str btrim_utf8(gdv_str s) { return rtrim_utf8(ltrim_utf8(s)); }
 // 2 '%' (any run, possibly empty); byte[i] = the literal.  Matching is the classic
 // two-cursor wildcard walk with a single backtrack point (the last '%'): O(len * plen) worst
 // case, O(len) for the usual '%needle%' / 'prefix%' shapes.  The whole string must match.
-GDV_DEV bool gdv_like(const gdv_str& s, const gdv_uint8* pbyte, const gdv_uint8* pkind, gdv_int32 plen) {
+static __device__ GDV_COLD bool gdv_like(const gdv_str& s, const gdv_uint8* pbyte, const gdv_uint8* pkind, gdv_int32 plen) {
   gdv_int32 i = 0, j = 0, star_j = -1, star_i = 0;
   while (i < s.len) {
     if (j < plen && pkind[j] == 2) {
@@ -1439,7 +1452,7 @@ GDV_DEV bool gdv_like_equal(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) 
 // (word ^ first-needle-byte) yields the positions whose byte equals the needle's first byte;
 // only those are verified, on a 64-bit window assembled from the current and next word.
 // (The zero-byte test can flag a byte above a true match — harmless, it is verified too.)
-GDV_DEV bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+static __device__ GDV_COLD bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
   if (m == 0) return true;
   if (m > s.len) return false;
   const gdv_uint64 mask = gdv_low_bytes_mask(m);
@@ -1447,32 +1460,6 @@ GDV_DEV bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 
   const gdv_uint64 splat = (first & 0xffull) * 0x0101010101010101ull;
   const gdv_uint64 splat2 = ((first >> 8) & 0xffull) * 0x0101010101010101ull;
   const gdv_int32 last = s.len - m;  // last candidate start
-  if (gdv_str_in_cache(s) && m <= 8) {
-    // cached words with constant indices: no selects, no loads, the loop unrolls fully
-    bool hit = false;
-#pragma unroll
-    for (int j = 0; j < GDV_NPRE; j++) {
-      const gdv_int32 base = 8 * j;
-      if (base <= last && !hit) {
-        const gdv_uint64 cur = gdv_map8(s.pre[j], s.map);
-        const gdv_uint64 nxt = j + 1 < GDV_NPRE ? gdv_map8(s.pre[j + 1], s.map) : 0ull;
-        const gdv_uint64 x = cur ^ splat;
-        gdv_uint64 cand = (x - 0x0101010101010101ull) & ~x & GDV_B80;
-        if (m >= 2) {
-          const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat2;
-          cand &= (y - 0x0101010101010101ull) & ~y & GDV_B80;
-        }
-        while (cand) {
-          const int k = __builtin_ctzll(cand) >> 3;
-          cand &= cand - 1;
-          if (base + k > last) break;
-          const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
-          if ((win & mask) == first) { hit = true; break; }
-        }
-      }
-    }
-    return hit;
-  }
   gdv_uint64 cur = gdv_word_at(s, 0);
   for (gdv_int32 base = 0; base <= last; base += 8) {
     const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
@@ -1511,3 +1498,175 @@ GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_
   return false;
 }
 
+
+// ------------------------------------------------------------------ var-len kernels: byte sweep
+// The rows of a wave tile occupy ONE contiguous span of the column's data buffer.  The sweep
+// walks that span with lanes over bytes (16 B per lane and step, coalesced) and answers
+// tile-wide questions once per byte instead of once per row and word:
+//   * is any byte >= 0x80?  (ASCII tiles skip every UTF-8 walk: substr, left, length ...)
+//   * where does a '%needle%' pattern match?  One bit per span byte in an LDS bitmap; a row then
+//     tests its own byte range with two word reads (gdv_range_any) — no per-row search loop.
+#define GDV_B01 0x0101010101010101ull
+#define GDV_SPAN_MAX (GDV_U * 64 * 32)  // bytes of span the LDS match bitmaps cover (32 per row)
+// bit k of the result: the m-byte needle (`first` = its bytes, `mask` = low m bytes set;
+// 2 <= m <= 8) starts at byte k of `cur` (its bytes continue in `nxt`).  Two-byte SWAR filter
+// (zero-byte tests on word ^ splat), exact verification of the few candidates.
+GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, gdv_uint64 mask,
+                              gdv_uint64 splat0, gdv_uint64 splat1) {
+  const gdv_uint64 x = cur ^ splat0;
+  gdv_uint64 cand = (x - GDV_B01) & ~x & GDV_B80;
+  const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat1;
+  cand &= (y - GDV_B01) & ~y & GDV_B80;
+  gdv_uint32 m = 0;
+  while (cand) {
+    const int k = __builtin_ctzll(cand) >> 3;
+    cand &= cand - 1;
+    const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
+    if ((win & mask) == first) m |= 1u << k;
+  }
+  return m;
+}
+// any bit set in [lo, hi) of the bitmap (hi <= lo: empty range)
+GDV_DEV bool gdv_range_any(const gdv_uint64* bm, gdv_int32 lo, gdv_int32 hi) {
+  if (hi <= lo) return false;
+  gdv_int32 w = lo >> 6;
+  const gdv_int32 wend = (hi - 1) >> 6;
+  const gdv_uint64 tailmask = ~0ull >> (63 - ((hi - 1) & 63));
+  const gdv_uint64 first = bm[w] & (~0ull << (lo & 63));
+  if (w == wend) return (first & tailmask) != 0;
+  if (first) return true;
+  for (++w; w < wend; ++w)
+    if (bm[w]) return true;
+  return (bm[wend] & tailmask) != 0;
+}
+
+#ifndef GDV_HOST_BUILD
+// the value the NEXT lane holds (lane 63 gets 0): DPP wave_shl:1, no LDS traffic
+GDV_DEV gdv_uint64 gdv_next_lane(gdv_uint64 v) {
+  const gdv_uint32 lo = (gdv_uint32)__builtin_amdgcn_update_dpp(0, (int)(gdv_uint32)v, 0x130, 0xf, 0xf, false);
+  const gdv_uint32 hi = (gdv_uint32)__builtin_amdgcn_update_dpp(0, (int)(gdv_uint32)(v >> 32), 0x130, 0xf, 0xf, false);
+  return ((gdv_uint64)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------ var-len kernels: output offsets
+// ONE launch produces offsets and bytes: a workgroup tile (GDV_WAVES x GDV_U x 64 rows) needs the
+// byte total of every tile before it.  Workers post their tile's totals as an 8-byte granule and
+// poll ONE granule for the answer; a single scanner wave (workgroup 0) is the only reader of the
+// posted totals: it resolves the longest posted run in bulk and writes every tile's exclusive
+// prefix.  (Measured on MI355X, profiles/r02_k4_singlepass_proto.txt: agent-scope granule
+// accesses are priced per lane-access at the fabric, so classic decoupled look-back — every
+// tile polling up to 64 predecessors — costs more than the second pass it replaces.)
+// Granule: bits 63..62 status (0 nothing, 1 posted), bits 61..31 and 30..0 two 31-bit values
+// (two var-len outputs share a granule; Arrow offsets are int32, sums saturate at 2^31-1 and
+// the host rejects such a total).  Relaxed agent-scope atomics: the granule is its own flag.
+typedef __attribute__((address_space(1))) unsigned long long gdv_gu64;
+#define GDV_LB_POSTED (1ull << 62)
+#define GDV_LB_M31 0x7fffffffull
+#define GDV_ERR_STALL 8u
+GDV_DEV void gdv_lb_store(gdv_uint64* p, gdv_uint64 v) {
+  __hip_atomic_store((gdv_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+GDV_DEV gdv_uint64 gdv_lb_load(const gdv_uint64* p) {
+  return __hip_atomic_load((gdv_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+GDV_DEV gdv_uint64 gdv_sat31(gdv_uint64 v) { return v > GDV_LB_M31 ? GDV_LB_M31 : v; }
+GDV_DEV gdv_uint64 gdv_wave_excl_scan_u64(gdv_uint64 v, int lane, gdv_uint64* total) {
+  gdv_uint64 incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const gdv_uint64 o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  *total = __shfl(incl, 63, 64);
+  return incl - v;
+}
+// Scanner wave.  agg/pre: NG granule arrays of `ntiles` entries each (array g at g * ntiles).
+// totals[2 * g], totals[2 * g + 1]: grand totals of the two values of granule g.
+// Bounded: if nothing is posted for a very long time the scanner raises GDV_ERR_STALL and
+// leaves (the host then re-runs the batch in the serial-safe configuration).
+template <int NG>
+GDV_DEV void gdv_scanner(const gdv_uint64* agg, gdv_uint64* pre, gdv_int64 ntiles, gdv_uint64* totals,
+                         gdv_uint32* err, int lane) {
+  constexpr int K = 8;
+  gdv_int64 pos[NG];
+  gdv_uint64 c0[NG], c1[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) { pos[g] = 0; c0[g] = 0; c1[g] = 0; }
+  gdv_uint32 idle = 0;
+  for (;;) {
+    bool all_done = true, progressed = false;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      if (pos[g] >= ntiles) continue;
+      all_done = false;
+      const gdv_uint64* a = agg + (gdv_int64)g * ntiles;
+      gdv_uint64 s[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const gdv_int64 idx = pos[g] + (gdv_int64)lane * K + k;
+        s[k] = idx < ntiles ? gdv_lb_load(a + idx) : 0ull;
+      }
+      int lead = 0;
+      bool run = true;
+      gdv_uint64 a0 = 0, a1 = 0;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        run = run && (s[k] >> 62) == 1;
+        if (run) { lead++; a0 += s[k] & GDV_LB_M31; a1 += (s[k] >> 31) & GDV_LB_M31; }
+      }
+      const gdv_uint64 fullmask = __ballot(lead == K);
+      const int nf = fullmask == ~0ull ? 64 : __builtin_ctzll(~fullmask);
+      const int part = nf < 64 ? __builtin_amdgcn_readlane(lead, nf) : 0;
+      const int total_run = nf * K + part;
+      if (total_run == 0) continue;
+      progressed = true;
+      const int consumed = lane < nf ? K : (lane == nf ? part : 0);
+      gdv_uint64 t0, t1;
+      gdv_uint64 e0 = gdv_wave_excl_scan_u64(lane <= nf ? a0 : 0ull, lane, &t0) + c0[g];
+      gdv_uint64 e1 = gdv_wave_excl_scan_u64(lane <= nf ? a1 : 0ull, lane, &t1) + c1[g];
+      gdv_uint64* p = pre + (gdv_int64)g * ntiles + pos[g] + (gdv_int64)lane * K;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if (k < consumed) {
+          gdv_lb_store(p + k, GDV_LB_POSTED | (gdv_sat31(e1) << 31) | gdv_sat31(e0));
+          e0 += s[k] & GDV_LB_M31;
+          e1 += (s[k] >> 31) & GDV_LB_M31;
+        }
+      }
+      c0[g] += t0;
+      c1[g] += t1;
+      pos[g] += total_run;
+    }
+    if (all_done) break;
+    if (progressed) {
+      idle = 0;
+    } else {
+      __builtin_amdgcn_s_sleep(2);
+      if (++idle > (1u << 24)) {
+        if (lane == 0) atomicOr(err, GDV_ERR_STALL);
+        return;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < NG; g++) { totals[2 * g] = c0[g]; totals[2 * g + 1] = c1[g]; }
+  }
+}
+// Worker side, ONE thread: post the tile's granule g, later wait for its exclusive prefix.
+GDV_DEV void gdv_lb_post(gdv_uint64* agg, gdv_int64 ntiles, gdv_int64 tile, int g, gdv_uint64 v0, gdv_uint64 v1) {
+  gdv_lb_store(agg + (gdv_int64)g * ntiles + tile, GDV_LB_POSTED | (gdv_sat31(v1) << 31) | gdv_sat31(v0));
+}
+GDV_DEV gdv_uint64 gdv_lb_wait(const gdv_uint64* pre, gdv_int64 ntiles, gdv_int64 tile, int g, gdv_uint32* err) {
+  const gdv_uint64* p = pre + (gdv_int64)g * ntiles + tile;
+  for (gdv_uint32 spins = 0;; spins++) {
+    const gdv_uint64 v = gdv_lb_load(p);
+    if ((v >> 62) == 1) return v;
+    __builtin_amdgcn_s_sleep(4);
+    if (spins > (1u << 24)) {
+      atomicOr(err, GDV_ERR_STALL);
+      return 0;
+    }
+  }
+}
+#endif  // GDV_HOST_BUILD

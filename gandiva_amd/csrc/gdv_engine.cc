@@ -88,6 +88,9 @@ class ArgBlock {
   void SetOutOffsets(int e, void* p) {
     SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 16, p);
   }
+  void SetOutCap(int e, int64_t bytes) {
+    Set64(layout_.out_base() + e * ArgLayout::kOutStride + 24, static_cast<uint64_t>(bytes));
+  }
   const void* data() const { return buf_.data(); }
   size_t size() const { return buf_.size(); }
 
@@ -378,6 +381,11 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
 }
 
 int64_t GridFor(const KernelPlan& plan, int64_t rows) {
+  if (plan.string_skeleton) {
+    // one workgroup per tile (+ the scanner workgroup when there are var-len outputs)
+    const int64_t ntiles = (rows + plan.rows_per_tile() - 1) / plan.rows_per_tile();
+    return std::max<int64_t>(1, ntiles) + (plan.num_varlen_outputs > 0 ? 1 : 0);
+  }
   const int64_t nwords = (rows + 63) / 64;
   const int64_t per_tile = static_cast<int64_t>(plan.opts.subtiles) * plan.opts.waves;
   int64_t ntiles = (nwords + per_tile - 1) / per_tile;
@@ -396,6 +404,7 @@ std::string ErrorMessage(uint32_t bits) {
   if (bits & 1u) m += "divide by zero error";
   if (bits & 2u) m += (m.empty() ? "" : "; ") + std::string("overflow");
   if (bits & 4u) m += (m.empty() ? "" : "; ") + std::string("invalid argument");
+  if (bits & 8u) m += (m.empty() ? "" : "; ") + std::string("device scan stalled");
   return m.empty() ? "execution error" : m;
 }
 
@@ -465,7 +474,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   ArgBlock args(plan_.layout);
   Staging st;
   DeviceBuffer err;
-  // var-len outputs: per wave tile, the bytes it produces (pass 0) and where they start (pass 1)
+  // var-len outputs: grand totals / per-tile granules of the in-kernel offsets scan
   DeviceBuffer tile_counts, tile_starts;
   // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
   StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
@@ -529,62 +538,67 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (t.is_varlen() && out_rows == 0) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_offs[e], 0, 4, stream));
   }
 
-  if (plan_.can_raise) {
+  const int nv = plan_.num_varlen_outputs;
+  const bool has_err = plan_.can_raise || nv > 0;  // var-len plans can report a stalled scan
+  if (has_err) {
     GDV_RETURN_NOT_OK(err.Allocate(8));
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
     args.SetPtr(ArgLayout::kOffErr, err.get());
   }
 
-  const int64_t nwt = (((out_rows + 63) >> 6) + plan_.opts.subtiles - 1) / plan_.opts.subtiles;
-  const int64_t seg_stride = (nwt + 3) & ~int64_t{3};  // per-output segment, 16-byte aligned
-  if (plan_.has_varlen_output) {
-    int nv = 0;
-    for (auto& t : plan_.output_types) nv += t.is_varlen();
-    GDV_RETURN_NOT_OK(tile_counts.Allocate(std::max<int64_t>(nv * seg_stride, 1) * 4));
-    GDV_RETURN_NOT_OK(tile_starts.Allocate(std::max<int64_t>(nv * seg_stride, 1) * 8));
-    args.SetPtr(ArgLayout::kOffCounts, tile_counts.get());
-    args.SetPtr(ArgLayout::kOffMask, tile_starts.get());
-    args.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
-  }
-
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
-  const int64_t grid = GridFor(plan_, out_rows);
   EvalTrace trace("project", plan_.kernel_name, out_rows, stream);
-  args.Set64(ArgLayout::kOffAux0, 0);
-  if (out_rows > 0) {
-    GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
-                                stream));
-  }
-
-  // var-len outputs: lengths -> offsets (in-place scan), size the byte buffers, second pass
   std::vector<uint64_t> totals(num_outs, 0);
-  if (plan_.has_varlen_output) {
-    // byte totals per wave tile -> exclusive scan -> where every tile's bytes start; all
-    // var-len outputs share one set of (three) launches, which also writes the closing offset
-    DeviceBuffer sums, total_dev;
+  uint32_t err_bits = 0;
+  if (nv == 0) {
+    if (out_rows > 0)
+      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
+                                  args.size(), stream));
+  } else if (out_rows > 0) {
+    // Single launch: workgroup 0 scans the tile totals (granules: tile_starts; grand totals:
+    // tile_counts), workers post one granule and poll one.  Device buffers: the caller's
+    // capacities are honoured inside the kernel (tiles that do not fit skip their bytes) and
+    // the totals say what was needed.  Host buffers: a first launch with capacity 0 sizes the
+    // device byte buffers, a second one fills them (the path is PCIe-bound anyway).
+    const int ng = (nv + 1) / 2;
+    const int64_t ntiles = (out_rows + plan_.rows_per_tile() - 1) / plan_.rows_per_tile();
+    GDV_RETURN_NOT_OK(tile_starts.Allocate(static_cast<size_t>(2 * ng * ntiles) * 8));
+    GDV_RETURN_NOT_OK(tile_counts.Allocate(static_cast<size_t>(2 * ng) * 8));
+    args.SetPtr(ArgLayout::kOffMask, tile_starts.get());
+    args.SetPtr(ArgLayout::kOffCounts, tile_counts.get());
     std::vector<int> vl;
     for (int e = 0; e < num_outs; e++)
       if (plan_.output_types[e].is_varlen()) vl.push_back(e);
-    const int nv = static_cast<int>(vl.size());
-    GDV_RETURN_NOT_OK(sums.Allocate(std::max<int64_t>(ScanChunks(nwt), 1) * 8 * kMaxScanSegments));
-    GDV_RETURN_NOT_OK(total_dev.Allocate(8 * nv));
-    std::vector<uint64_t> seg_totals(nv, 0);
-    for (int v0 = 0; v0 < nv; v0 += kMaxScanSegments) {
-      const int cnt = std::min(kMaxScanSegments, nv - v0);
-      int32_t* closing[kMaxScanSegments];
-      for (int i = 0; i < cnt; i++) closing[i] = static_cast<int32_t*>(dev_offs[vl[v0 + i]]) + out_rows;
-      GDV_HIP_RETURN_NOT_OK(LaunchSegmentedOffsetsScan(
-          tile_counts.as<uint32_t>() + v0 * seg_stride, nwt, seg_stride, cnt, sums.as<uint64_t>(),
-          tile_starts.as<uint64_t>() + v0 * seg_stride, total_dev.as<uint64_t>() + v0, closing, stream));
-    }
-    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(seg_totals.data(), total_dev.get(), 8 * nv,
-                                         hipMemcpyDeviceToHost, stream));
-    GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
-    for (int v = 0; v < nv; v++) totals[vl[v]] = seg_totals[v];
+    std::vector<uint64_t> seg(2 * ng, 0);
+    auto run = [&](int64_t grid) -> Status {
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(tile_starts.get(), 0, static_cast<size_t>(2 * ng * ntiles) * 8, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(tile_counts.get(), 0, static_cast<size_t>(2 * ng) * 8, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(seg.data(), tile_counts.get(), 8 * 2 * ng, hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+      return Status::OK();
+    };
+    auto launch = [&]() -> Status {
+      GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
+      if (err_bits & 8u) {
+        // The scan made no progress for a very long time: some workgroup of the grid was not
+        // scheduled while later ones waited for it.  Never observed (workgroups start in index
+        // order); the serial-safe configuration — scanner + ONE worker workgroup walking all
+        // tiles in order — cannot wait on anything unscheduled.
+        GDV_RETURN_NOT_OK(run(2));
+        if (err_bits & 8u) return Status::ExecutionError("var-len projection: device scan stalled");
+      }
+      return Status::OK();
+    };
+    for (int v = 0; v < nv; v++) args.SetOutCap(vl[v], mem == MemKind::kHost ? 0 : outs[vl[v]].data_size);
+    GDV_RETURN_NOT_OK(launch());
     Status capacity = Status::OK();
-    for (int e = 0; e < num_outs; e++) {
-      if (!plan_.output_types[e].is_varlen()) continue;
-      if (totals[e] > 0x7fffffffull)
+    for (int v = 0; v < nv; v++) {
+      const int e = vl[v];
+      totals[e] = seg[v];
+      if (totals[e] >= 0x7fffffffull)
         return Status::Invalid("var-len output " + std::to_string(e) + " exceeds 2 GiB");
       const int64_t have = outs[e].data_size;
       outs[e].data_size = static_cast<int64_t>(totals[e]);  // bytes needed / produced
@@ -592,22 +606,28 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
         capacity = Status::Invalid("output buffer " + std::to_string(e) + ": data capacity " +
                                    std::to_string(have) + " < " + std::to_string(totals[e]) +
                                    " bytes needed (data_size updated; retry with a larger buffer)");
-      if (mem == MemKind::kHost) {
+    }
+    if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+    GDV_RETURN_NOT_OK(capacity);
+    if (mem == MemKind::kHost) {
+      bool any = false;
+      for (int v = 0; v < nv; v++) {
+        const int e = vl[v];
         DeviceBuffer& dd = st.Add();
         GDV_RETURN_NOT_OK(dd.Allocate(std::max<uint64_t>(totals[e], 8)));
         dev_data[e] = dd.get();
         args.SetOutData(e, dev_data[e]);
+        args.SetOutCap(e, static_cast<int64_t>(totals[e]));
+        any |= totals[e] > 0;
       }
+      if (any) GDV_RETURN_NOT_OK(launch());
     }
-    GDV_RETURN_NOT_OK(capacity);
-    args.Set64(ArgLayout::kOffAux0, 1);
-    if (out_rows > 0)
-      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(),
-                                  stream));
+  } else {
+    for (int e = 0; e < num_outs; e++)
+      if (plan_.output_types[e].is_varlen()) outs[e].data_size = 0;
   }
 
-  uint32_t err_bits = 0;
-  if (plan_.can_raise)
+  if (plan_.can_raise && nv == 0)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
   if (mem == MemKind::kHost) {
     GDV_RETURN_NOT_OK(st.FetchOut(stream));  // validity, fixed-width values, offsets

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <regex>
 #include <sstream>
 
 namespace gdv {
@@ -205,7 +206,28 @@ struct Val {
   // after the other by the output copy (piece expression, per-lane "piece present"
   // predicate or "" for always).  Only an output expression or another concat can take one.
   std::vector<std::pair<std::string, std::string>> pieces;
+  // A string value that IS the row of input slot `col_slot` (whole, unsliced), read through the
+  // static byte map `col_map` (0 none, 1 upper, 2 lower): candidates for the byte-parallel
+  // paths (sweep-answered '%needle%', flat output copy).  -1: anything else.
+  int col_slot = -1;
+  int col_map = 0;
   bool never_null() const { return vcols.empty() && vlane.empty(); }
+};
+
+// '%needle%' predicate answered by the byte sweep of input slot `slot` (bytes read through `map`)
+struct ContainsHook {
+  int slot;
+  int map;
+  std::string needle;
+};
+
+// One var-len output of a projector: its row value as 1+ pieces (views written back to back),
+// each with the name of the per-sub-tile register array holding it.
+struct VarlenOut {
+  int e = 0;                      // output index
+  int flat_slot = -1;             // >= 0: the row is input slot flat_slot's whole row ...
+  int flat_map = 0;               // ... read through this byte map
+  int window = -1;                // >= 0: LDS staging window of this output (non-flat outputs)
 };
 
 class CodeGen {
@@ -279,8 +301,10 @@ class CodeGen {
   }
   std::string StringConstant(const std::string& bytes) {
     std::string t = ByteTable(bytes);
+    bool ascii = true;
+    for (unsigned char c : bytes) ascii = ascii && c < 0x80;
     return "gdv_make_str(" + t + ", 0, " + std::to_string(bytes.size()) + ", " + t + " + " +
-           std::to_string(bytes.size() + 8) + ")";
+           std::to_string(bytes.size() + 8) + (ascii ? ", GDV_STR_ASCII | GDV_STR_INBUF)" : ", GDV_STR_INBUF)");
   }
   // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
   static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
@@ -310,6 +334,35 @@ class CodeGen {
       }
     }
     return Status::OK();
+  }
+
+  // input slots of every var-len field below `node`
+  std::set<int> StringSlotsOf(const Node& node) {
+    std::set<int> r;
+    std::function<void(const Node&)> walk = [&](const Node& n) {
+      switch (n.kind()) {
+        case NodeKind::kField: {
+          auto& f = static_cast<const FieldNode&>(n);
+          if (f.return_type().is_varlen()) r.insert(SlotFor(f, true, true));
+          break;
+        }
+        case NodeKind::kFunction:
+          for (auto& c : static_cast<const FunctionNode&>(n).children()) walk(*c);
+          break;
+        case NodeKind::kIf: {
+          auto& i = static_cast<const IfNode&>(n);
+          walk(*i.condition()); walk(*i.then_node()); walk(*i.else_node());
+          break;
+        }
+        case NodeKind::kBoolean:
+          for (auto& c : static_cast<const BooleanNode&>(n).children()) walk(*c);
+          break;
+        case NodeKind::kIn: walk(*static_cast<const InNode&>(n).eval()); break;
+        default: break;
+      }
+    };
+    walk(node);
+    return r;
   }
 
   int SlotFor(const FieldNode& f, bool values, bool validity) {
@@ -344,7 +397,25 @@ class CodeGen {
   bool can_raise_ = false;
   std::ostringstream prelude_;  // file-scope constants (IN tables, patterns)
   int next_const_ = 0;
+  // string plans
+  std::vector<ContainsHook> contains_hooks_;
+  std::set<int> ascii_slots_;     // input slots whose tile-wide ASCII flag some function consults
+  std::vector<VarlenOut> varlen_outs_;
+  int HookFor(int slot, int map, const std::string& needle) {
+    for (size_t h = 0; h < contains_hooks_.size(); h++)
+      if (contains_hooks_[h].slot == slot && contains_hooks_[h].map == map && contains_hooks_[h].needle == needle)
+        return static_cast<int>(h);
+    contains_hooks_.push_back({slot, map, needle});
+    return static_cast<int>(contains_hooks_.size()) - 1;
+  }
 };
+
+// functions whose fast path is "the string is pure ASCII" (character index == byte index)
+bool WantsAsciiHint(const std::string& name) {
+  static const std::set<std::string> k = {"substr", "substring", "left", "right", "char_length", "length",
+                                          "lengthUtf8", "castVARCHAR", "locate", "strpos", "like"};
+  return k.count(name) != 0;
+}
 
 Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
   switch (node.kind()) {
@@ -354,7 +425,9 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->type = f.return_type();
       std::string k = std::to_string(slot);
       if (f.return_type().is_varlen()) {
-        out->v = "s" + k;  // per-iteration view built from the two offsets (phase 2 prologue)
+        out->v = "s" + k;  // per-iteration view built from the two offsets (row phase prologue)
+        out->col_slot = slot;
+        out->col_map = 0;
       } else if (f.return_type().id == kBool) {
         out->v = selection() ? "x" + k + "[u]" : Tmp("bool", "gdv_lane_bit(d" + k + ", lane)");
       } else {
@@ -367,6 +440,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
     case NodeKind::kLiteral: {
       auto& l = static_cast<const LiteralNode&>(node);
       out->type = l.return_type();
+      out->col_slot = -1;
       if (l.return_type().is_varlen()) {
         out->v = StringConstant(l.value().bytes);
         out->vcols.clear();
@@ -391,6 +465,16 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->vcols.clear();
       out->vlane.clear();
       out->pieces.clear();
+      out->col_slot = -1;
+      out->col_map = 0;
+      if ((fn.name() == "upper" || fn.name() == "lower") && args.size() == 1 && args[0].col_slot >= 0) {
+        out->col_slot = args[0].col_slot;
+        out->col_map = fn.name() == "upper" ? 1 : 2;
+      }
+      if (WantsAsciiHint(fn.name()))
+        for (size_t i = 0; i < args.size(); i++)
+          if (args[i].type.is_varlen())
+            for (int k : StringSlotsOf(*fn.children()[i])) ascii_slots_.insert(k);
       const std::string ctype = out->type.CType();
       const bool is_concat = fn.name() == "concat" || fn.name() == "concatOperator";
       for (auto& a : args)
@@ -454,8 +538,20 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
           const std::string lit = bytes.substr(lo, hi - lo);
           const char* fnname = lead && trail ? "gdv_like_contains" : lead ? "gdv_like_suffix"
                                : trail ? "gdv_like_prefix" : "gdv_like_equal";
-          out->v = Tmp("bool", std::string(fnname) + "(" + args[0].v + ", " + ByteTable(lit) + ", " +
-                                   std::to_string(lit.size()) + ")");
+          const std::string per_row = std::string(fnname) + "(" + args[0].v + ", " + ByteTable(lit) + ", " +
+                                      std::to_string(lit.size()) + ")";
+          if (lead && trail && lit.size() >= 2 && lit.size() <= 8 && args[0].col_slot >= 0 && !selection()) {
+            // '%needle%' over a whole input row: the byte sweep has marked every match position
+            // of the tile's span in an LDS bitmap; the row tests its own byte range.  Spans too
+            // long for the bitmap (wave-uniform) take the per-row search.
+            const int h = HookFor(args[0].col_slot, args[0].col_map, lit);
+            const std::string k = std::to_string(args[0].col_slot);
+            out->v = Tmp("bool", "(hm_ok" + k + " ? gdv_range_any(hit" + std::to_string(h) + ", oa" + k +
+                                     "[u] - sb" + k + ", ob" + k + "[u] - sb" + k + " - " +
+                                     std::to_string(lit.size() - 1) + ") : " + per_row + ")");
+            return Status::OK();
+          }
+          out->v = Tmp("bool", per_row);
           return Status::OK();
         }
         std::string pb = ByteTable(bytes), pk = ByteTable(kinds);
@@ -535,6 +631,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->type = n.return_type();
       const std::string ctype = out->type.CType();
       out->pieces.clear();
+      out->col_slot = -1;
       out->v = Tmp(ctype, take + " ? " + t.v + " : " + e.v);
       out->vcols.clear();
       if (t.never_null() && e.never_null()) {
@@ -565,6 +662,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       }
       out->type = boolean();
       out->vcols.clear();
+      out->col_slot = -1;
       if (all_valid.empty() || all_valid == "true") {
         out->vlane.clear();
         out->v = Tmp("bool", is_and ? "!" + decided : decided);
@@ -586,6 +684,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       if (!x.pieces.empty())
         return Status::CodeGenError("IN over a concat result is not supported by the HIP backend yet");
       out->pieces.clear();
+      out->col_slot = -1;
       out->type = boolean();
       out->vcols = x.vcols;
       out->vlane = x.vlane;
@@ -645,13 +744,13 @@ struct Assembler {
         << (plan->kind == KernelKind::kFilter ? "filter" : "projection") << " kernel for gfx950\n";
     for (size_t i = 0; i < expr_strings.size(); i++)
       src << "// @expr_" << i << " = " << expr_strings[i] << "\n";
-    src << "#include \"gdv_device_lib.hpp\"\n";
     src << "#define GDV_U " << plan->opts.subtiles << "\n";
     src << "#define GDV_WAVES " << plan->opts.waves << "\n";
+    src << "#include \"gdv_device_lib.hpp\"\n";
     const int nin = std::max<int>(1, plan->input_fields.size());
     const int nout = std::max<int>(1, plan->output_types.size());
     src << "struct gdv_in_slot { const void* data; gdv_bitmap valid; gdv_bitmap bits; const gdv_int32* offsets; };\n";
-    src << "struct gdv_out_slot { void* data; gdv_uint64* valid; gdv_int32* offsets; };\n";
+    src << "struct gdv_out_slot { void* data; gdv_uint64* valid; gdv_int32* offsets; gdv_int64 cap; };\n";
     src << "struct gdv_args {\n"
         << "  gdv_int64 n; gdv_uint32* err; const void* sel; gdv_uint64* mask; gdv_uint32* counts;\n"
         << "  gdv_int64 aux0, aux1, aux2;\n"
@@ -687,10 +786,9 @@ struct WordAccumulators {
   }
 };
 
-std::string WordStore(const std::string& acc, const std::string& dst, bool two_pass = false) {
-  return std::string("  if (") + (two_pass ? "pass == 0 && " : "") +
-         "lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) " + dst + "[wbase + lane] = " +
-         acc + ";\n";
+std::string WordStore(const std::string& acc, const std::string& dst) {
+  return std::string("  if (lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) ") + dst +
+         "[wbase + lane] = " + acc + ";\n";
 }
 
 Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
@@ -904,6 +1002,361 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   return Status::OK();
 }
 
+
+// ------------------------------------------------------------------ string plans
+// Kernels that read or write var-len columns use their own skeleton (round 2):
+//   tile     one workgroup = GDV_WAVES waves x GDV_U sub-tiles x 64 rows; a wave's rows occupy ONE
+//            contiguous span of each var-len input's data buffer
+//   sweep    lanes over the BYTES of that span: tile-wide ASCII flag, '%needle%' match bitmaps
+//   rows     lane = row: the fused expression bodies; var-len results are kept as views
+//   offsets  per-wave DPP scan of the lengths -> workgroup totals -> ONE granule posted to the
+//            scanner wave (workgroup 0), ONE granule polled for the tile's exclusive prefix
+//   bytes    staged in LDS while waiting, flushed coalesced; or streamed flat when the output
+//            IS the (mapped) input span
+// Single launch, inputs read once (round 1: two passes, 1.43 x the algorithmic traffic).
+Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
+                       const WordAccumulators& accs, const std::string& decls_before_loop,
+                       const std::string& epilogue_after_loop) {
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = cg.can_raise_;
+  plan->string_skeleton = true;
+  for (size_t k = 0; k < plan->input_fields.size(); k++)
+    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const int nv = static_cast<int>(cg.varlen_outs_.size());
+  const int ng = (nv + 1) / 2;
+  int nstage = 0;                              // LDS staging windows per wave
+  for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());
+  plan->num_varlen_outputs = nv;
+
+  Assembler as{cg, plan, {}};
+  as.Header(expr_strings);
+  std::ostringstream& s = as.src;
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
+  s << "#define GDV_NV " << nv << "\n#define GDV_NG " << ng << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
+    << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
+    << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
+    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n";
+
+  s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
+    << "                      const int wave, gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint32 (*lds_tot)[GDV_NV > 0 ? GDV_NV : 1],\n"
+    << "                      gdv_uint64* lds_base) {\n"
+    << "  (void)lds_out; (void)lds_hit; (void)lds_tot; (void)lds_base; (void)ntiles;\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n";
+  if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.is_varlen() && cg.needs_values_[k]) {
+      s << "  const gdv_uint8* __restrict__ sd" << k << " = (const gdv_uint8*)A.in[" << k << "].data;\n"
+        << "  const gdv_int32* __restrict__ so" << k << " = A.in[" << k << "].offsets;\n"
+        << "  const gdv_uint8* slim" << k << " = sd" << k << " + A.in[" << k << "].bits.nwords;\n";
+    } else if (t.id != kBool && cg.needs_values_[k]) {
+      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType() << "*)A.in[" << k
+        << "].data;\n";
+    }
+  }
+  for (size_t e = 0; e < plan->output_types.size(); e++) {
+    const DataType& t = plan->output_types[e];
+    if (t.is_varlen()) {
+      s << "  gdv_uint8* __restrict__ outd" << e << " = (gdv_uint8*)A.out[" << e << "].data;\n"
+        << "  gdv_int32* __restrict__ outo" << e << " = A.out[" << e << "].offsets;\n";
+    } else if (t.id != kBool) {
+      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
+    }
+  }
+  if (sel)
+    s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const " << SelCType(cg.sel_mode_)
+      << "*)A.sel;\n";
+
+  // ---- loads: offsets, fixed-width values, validity / bool words
+  s << "  // ---- loads of this wave's GDV_U sub-tiles, issued back to back\n";
+  if (sel) s << "  gdv_int64 srow[GDV_U];\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k]) {
+        if (sel) s << "  bool x" << k << "[GDV_U];\n";
+        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      }
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k]) s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
+    } else if (cg.needs_values_[k]) {
+      s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
+    }
+    if (cg.needs_validity_[k]) {
+      if (sel) s << "  bool b" << k << "[GDV_U];\n";
+      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+    }
+  }
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "    const bool live = row < n;\n"
+    << "    (void)live;\n";
+  if (sel) {
+    s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool) {
+        if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+      } else if (t.is_varlen()) {
+        if (cg.needs_values_[k])
+          s << "    oa" << k << "[u] = so" << k << "[srow[u]]; ob" << k << "[u] = so" << k << "[srow[u] + 1];\n";
+      } else if (cg.needs_values_[k]) {
+        s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+      }
+      if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+    }
+  } else {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.is_varlen()) {
+        // rows past the end take the closing offset: length 0, and the span stays contiguous
+        if (cg.needs_values_[k])
+          s << "    oa" << k << "[u] = so" << k << "[live ? row : n]; ob" << k << "[u] = so" << k
+            << "[row + 1 < n ? row + 1 : n];\n";
+      } else if (t.id != kBool && cg.needs_values_[k]) {
+        s << "    c" << k << "[u] = live ? " << (plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld") << "(in" << k
+          << ", row) : (" << t.CType() << ")0;\n";
+      }
+    }
+  }
+  s << "  }\n";
+
+  // ---- sweep: lanes over the bytes of each var-len input's span
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+    std::vector<int> hooks;
+    for (int h = 0; h < nhook; h++)
+      if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
+    const bool want_ascii = cg.ascii_slots_.count(k) != 0;
+    const std::string K = std::to_string(k);
+    if (sel) {
+      s << "  const gdv_int32 sfl" << K << " = 0;\n";
+      continue;
+    }
+    // one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
+    s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
+      << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    if (hooks.empty() && !want_ascii) {
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+      continue;
+    }
+    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n"
+      << "  const gdv_int32 sp0" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+      << "  const gdv_int32 sp1" << K << " = __builtin_amdgcn_readlane(ob" << K << "[GDV_U - 1], 63);\n"
+      << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
+      << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
+      << "  (void)hm_ok" << K << ";\n"
+      << "  gdv_uint64 sacc" << K << " = 0;\n";
+    for (int h : hooks)
+      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n";
+    s << "  for (gdv_int32 c = sb" << K << "; c < sp1" << K << "; c += 1024) {\n"
+      << "    const gdv_int32 a = c + 16 * lane;\n"
+      << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
+      << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+      << "    sacc" << K << " |= w[0] | w[1];\n";
+    if (!hooks.empty()) {
+      s << "    gdv_uint64 tail = 0;  // lane 63's halo: the first 8 bytes of the next step\n"
+        << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
+      for (int h : hooks) {
+        const ContainsHook& hk = cg.contains_hooks_[h];
+        uint64_t first = 0;
+        for (size_t i = 0; i < hk.needle.size(); i++)
+          first |= static_cast<uint64_t>(static_cast<unsigned char>(hk.needle[i])) << (8 * i);
+        const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+        const uint64_t sp0 = (first & 0xff) * 0x0101010101010101ull, sp1 = ((first >> 8) & 0xff) * 0x0101010101010101ull;
+        const std::string H = std::to_string(h), M = std::to_string(hk.map);
+        s << "    {\n"
+          << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
+          << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
+          << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
+          << "      const gdv_uint32 m = gdv_match8(lo, hi, " << Hex64(first) << ", " << Hex64(mask) << ", " << Hex64(sp0)
+          << ", " << Hex64(sp1) << ") |\n"
+          << "                           (gdv_match8(hi, nx, " << Hex64(first) << ", " << Hex64(mask) << ", " << Hex64(sp0)
+          << ", " << Hex64(sp1) << ") << 8);\n"
+          << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
+          << ") >> 4] = (gdv_uint16)m;\n"
+          << "    }\n";
+      }
+    }
+    s << "  }\n";
+    if (want_ascii)
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | (__ballot((sacc" << K
+        << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
+    else
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+    if (!hooks.empty()) s << "  __builtin_amdgcn_wave_barrier();\n";
+  }
+
+  // ---- row phase
+  s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
+  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
+  s << decls_before_loop;
+  if (nv > 0)
+    s << "  bool need_direct = false;\n"
+      << "  // pass 0: lengths, offsets, staged / flat bytes.  pass 1 (rare): rows of outputs whose bytes\n"
+      << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
+      << "  for (int pass = 0; pass < 2; pass++) {\n"
+      << "  if (pass == 1 && !need_direct) break;\n";
+  else
+    s << "  constexpr int pass = 0;\n  (void)pass;\n";
+  // The row loop is NOT unrolled: the per-sub-tile registers are read and written through
+  // gdv_pick / gdv_put (selects on the wave-uniform u), so the fused body exists once — a
+  // quarter of the code, the compile time and the VGPRs of the unrolled form.
+  s << "GDV_ROW_LOOP\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    {\n"
+    << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "      const bool live = row < n;\n"
+    << "      const gdv_uint64 livemask = __ballot(live);\n"
+    << "      (void)livemask; (void)row;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k] && sel) s << "      const bool x" << k << "_u = x" << k << "[0];\n";
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k])
+        s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0], ob" << k << "_u = ob" << k << "[0];\n"
+          << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
+          << ", sfl" << k << ");\n";
+    } else if (cg.needs_values_[k]) {
+      s << "      const " << t.CType() << " c" << k << "_u = c" << k << "[0];\n";
+    }
+    if (cg.needs_validity_[k] && sel) s << "      const bool b" << k << "_u = b" << k << "[0];\n";
+  }
+  if (!sel) {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k])
+        s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+    }
+  }
+  {
+    // the body addresses per-sub-tile inputs as NAME[u]: here they are the NAME_u picked above
+    static const std::regex per_u("\\b(oa|ob|c|x|b)([0-9]+)\\[u\\]");
+    s << std::regex_replace(cg.body_.str(), per_u, "$1$2_u");
+  }
+  s << "    }\n    // next sub-tile to the front\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k] && sel) s << "    gdv_rot(x" << k << ");\n";
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k]) s << "    gdv_rot(oa" << k << "); gdv_rot(ob" << k << ");\n";
+    } else if (cg.needs_values_[k]) {
+      s << "    gdv_rot(c" << k << ");\n";
+    }
+    if (cg.needs_validity_[k] && sel) s << "    gdv_rot(b" << k << ");\n";
+  }
+  for (auto& vo : cg.varlen_outs_) s << "    gdv_rot(lc" << vo.e << ");\n";
+  s << "  }\n";
+  if (nv > 0) s << "  if (pass == 1) break;\n";
+  s << epilogue_after_loop;
+
+  // ---- var-len outputs
+  if (nv > 0) {
+    s << "  // ---- var-len outputs: workgroup totals -> one granule to the scanner\n"
+      << "  if (lane == 0) {\n";
+    for (int v = 0; v < nv; v++)
+      s << "    lds_tot[wave][" << v << "] = (gdv_uint32)run" << cg.varlen_outs_[v].e << ";\n";
+    s << "  }\n  __syncthreads();\n"
+      << "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n"
+      << "#pragma unroll\n  for (int v = 0; v < GDV_NV; v++) { before[v] = 0; all[v] = 0; }\n"
+      << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
+      << "#pragma unroll\n    for (int v = 0; v < GDV_NV; v++) {\n"
+      << "      const gdv_uint32 t = lds_tot[w][v];\n      all[v] += t;\n      before[v] += w < wave ? t : 0u;\n    }\n  }\n"
+      << "  gdv_uint64* const lb_agg = A.mask;\n"
+      << "  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n"
+      << "  if (threadIdx.x == 0) {\n";
+    for (int g = 0; g < ng; g++)
+      s << "    gdv_lb_post(lb_agg, ntiles, tile, " << g << ", all[" << 2 * g << "], "
+        << (2 * g + 1 < nv ? "all[" + std::to_string(2 * g + 1) + "]" : std::string("0ull")) << ");\n";
+    s << "  }\n";
+    s << "  if (threadIdx.x == 0) {\n"
+      << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
+      << "  }\n  __syncthreads();\n";
+    for (int v = 0; v < nv; v++) {
+      const VarlenOut& vo = cg.varlen_outs_[v];
+      const std::string E = std::to_string(vo.e);
+      s << "  {\n"
+        << "    const gdv_int64 base = (gdv_int64)((lds_base[" << v / 2 << "] >> " << 31 * (v % 2)
+        << ") & GDV_LB_M31) + (gdv_int64)before[" << v << "];\n"
+        << "    const bool fits = run" << E << " < 0x7fffffff && base + run" << E << " <= A.out[" << E << "].cap;\n"
+        << "#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
+        << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+        << "      if (row < n) outo" << E << "[row] = (gdv_int32)(base + lc" << E << "[u]);\n"
+        << "    }\n"
+        << "    if (fits) {\n";
+      if (vo.flat_slot >= 0) {
+        const std::string K = std::to_string(vo.flat_slot);
+        s << "      if (fb" << E << " == 0) {  // no row dropped: the output IS the mapped input span\n"
+          << "        gdv_flat_copy(outd" << E << " + base, sd" << K << " + __builtin_amdgcn_readfirstlane(oa" << K
+          << "[0]), run" << E << ", " << vo.flat_map << ", lane);\n"
+          << "      } else {\n";
+      } else if (vo.window >= 0) {
+        s << "      if (run" << E << " <= GDV_OUT_WIN) {\n"
+          << "        gdv_flush_out(outd" << E << " + base, win" << E << ", run" << E << ", lane);\n"
+          << "      } else {\n";
+      } else {
+        s << "      {\n";
+      }
+      s << "        dir" << E << " = true;\n        dbase" << E << " = base;\n        need_direct = true;\n"
+        << "      }\n    }\n  }\n";
+    }
+    s << "  __syncthreads();  // the LDS hand-off words are reused by the next tile (serial-safe launches)\n"
+      << "  }  // pass\n";
+  }
+  s << "}\n\n";
+
+  // ---- kernel
+  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+    << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
+    << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
+    << "  __shared__ gdv_uint32 gdv_lds_tot[GDV_WAVES][GDV_NV > 0 ? GDV_NV : 1];\n"
+    << "  __shared__ gdv_uint64 gdv_lds_base[GDV_NG > 0 ? GDV_NG : 1];\n"
+    << "  const gdv_int64 ntiles = (A.n + 64 * GDV_U * GDV_WAVES - 1) / (64 * GDV_U * GDV_WAVES);\n";
+  if (nv > 0) {
+    s << "  // workgroup 0 is the scanner of the tile totals; workers are workgroups 1..\n"
+      << "  if (blockIdx.x == 0) {\n"
+      << "    if (wave == 0) {\n"
+      << "      gdv_uint64* const totals = (gdv_uint64*)A.counts;\n"
+      << "      gdv_scanner<GDV_NG>(A.mask, A.mask + (gdv_int64)GDV_NG * ntiles, ntiles, totals, A.err, lane);\n"
+      << "      if (lane == 0) {\n";
+    for (int v = 0; v < nv; v++)
+      s << "        A.out[" << cg.varlen_outs_[v].e << "].offsets[A.n] = (gdv_int32)(totals[" << v
+        << "] > GDV_LB_M31 ? GDV_LB_M31 : totals[" << v << "]);\n";
+    s << "      }\n    }\n    return;\n  }\n"
+      << "  for (gdv_int64 tile = (gdv_int64)blockIdx.x - 1; tile < ntiles; tile += (gdv_int64)gridDim.x - 1)\n";
+  } else {
+    s << "  for (gdv_int64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x)\n";
+  }
+  s << "    gdv_tile(A, tile, ntiles, lane, wave, gdv_lds_out[wave], gdv_lds_hit[wave], gdv_lds_tot, gdv_lds_base);\n"
+    << "}\n";
+
+  std::string text = s.str();
+  uint64_t h = Fnv1a(text);
+  char name[64];
+  snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+  plan->kernel_name = name;
+  size_t pos = text.find("GDV_KERNEL_NAME");
+  text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
+  plan->source = text;
+  plan->ir = text;
+  return Status::OK();
+}
+
 }  // namespace
 
 Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
@@ -919,12 +1372,10 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   CodeGen cg(schema, mode, opts);
   WordAccumulators accs;
   std::ostringstream after_loop, before_loop;
-  int num_varlen = 0;
   std::vector<std::string> strings;
+  int num_staged = 0;
   const std::string st = opts.nontemporal ? "gdv_stnt" : "gdv_st";
   for (auto& e : exprs) plan->has_varlen_output |= e->result().type.is_varlen();
-  const bool two = plan->has_varlen_output;
-  const std::string p0 = two ? "pass == 0 && " : "";
   for (size_t e = 0; e < exprs.size(); e++) {
     Val v;
     cg.Stmt("// @expr_" + std::to_string(e));
@@ -934,56 +1385,72 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     strings.push_back(exprs[e]->ToString());
     const std::string E = std::to_string(e);
     if (t.is_varlen()) {
-      // pass 0: bytes produced per wave tile -> A.counts[]; the host scans those (one value
-      // per GDV_U*64 rows) into A.mask[]; pass 1 recomputes the lengths, prefix-sums them
-      // inside the wave (DPP) and writes offsets[row] and the bytes in the same sweep
-      const std::string ok = CodeGen::AndExpr("live", cg.LaneValid(v));
-      const std::string V = std::to_string(num_varlen++);
-      // which wave tile this is, among all wave tiles of the launch
-      const std::string tile = V + " * A.aux1 + wbase / GDV_U";  // aux1: tiles per output segment
-      before_loop << "  gdv_int32 tl" << E << " = 0;  // pass 0: bytes this tile produces\n"
-                  << "  gdv_int32 vb" << E << " = 0;  // pass 1: where the next sub-tile's bytes start\n"
-                  << "  if (PASS == 1) vb" << E << " = (gdv_int32)A.mask[" << tile << "];\n";
-      // the row's bytes: one view, or the pieces of a concat written back to back
+      // The row's bytes are one view, or the pieces of a concat written back to back.  Views
+      // are kept per sub-tile (registers) until the tile's base offset is known; lengths are
+      // prefix-summed inside the wave on the DPP data path.
+      const std::string ok = cg.Tmp("bool", CodeGen::AndFull("live", cg.LaneValid(v)));
+      VarlenOut vo;
+      vo.e = static_cast<int>(e);
+      const int vidx = static_cast<int>(cg.varlen_outs_.size());
+      const bool flat_cand = v.pieces.empty() && v.col_slot >= 0 && !cg.selection();
+      const bool has_window = !flat_cand && num_staged < 3;  // LDS staging windows per wave
       std::vector<std::pair<std::string, std::string>> pieces = v.pieces;
       if (pieces.empty()) pieces.emplace_back(v.v, "");
       std::string total;
-      std::vector<std::string> plen;
+      std::vector<std::string> pv;
       for (size_t q = 0; q < pieces.size(); q++) {
-        const std::string name = "pl" + E + "_" + std::to_string(q);
-        cg.Stmt("const gdv_int32 " + name + " = (" + CodeGen::AndFull(ok, pieces[q].second) + ") ? (" +
-                pieces[q].first + ").len : 0;");
-        plen.push_back(name);
-        total += (q ? " + " : "") + name;
+        const std::string name = "pv" + E + "_" + std::to_string(q);
+        pv.push_back(name);
+        cg.Stmt("gdv_str " + name + " = " + pieces[q].first + ";");
+        cg.Stmt("if (!(" + CodeGen::AndFull(ok, pieces[q].second) + ")) " + name + ".len = 0;");
+        total += (q ? " + " : "") + name + ".len";
       }
-      cg.Stmt("const gdv_int32 ln" + E + " = " + total + ";");
-      auto copy_to = [&](const std::string& dst, const std::string& indent) {
-        std::string at = dst;
-        for (size_t q = 0; q < pieces.size(); q++) {
-          cg.Stmt(indent + "if (" + plen[q] + " > 0) gdv_str_copy(" + at + ", " + pieces[q].first + ");");
-          at += " + " + plen[q];
+      before_loop << "  gdv_int32 lc" << E << "[GDV_U] = {};  // where each row's bytes start inside the wave tile\n"
+                  << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n"
+                  << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM at dbase" << E << "\n"
+                  << "  gdv_int64 dbase" << E << " = 0;\n";
+      cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+      cg.Stmt("if (pass == 0) {");
+      cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
+      cg.Stmt("  lc" + E + "[0] = run" + E + " + inc - ln" + E + "_u;");
+      // 64 lengths below 2^25 cannot wrap the 32-bit scan; otherwise the total is taken on
+      // 16-bit halves and saturates (the host rejects outputs of 2 GiB or more)
+      cg.Stmt("  const gdv_uint32 t = __builtin_expect(__ballot(ln" + E + "_u >= (1 << 25)) != 0, 0) ? gdv_tile_total(ln" + E +
+              "_u) : (gdv_uint32)gdv_wave_last(inc);");
+      cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t));");
+      if (flat_cand) {
+        vo.flat_slot = v.col_slot;
+        vo.flat_map = v.col_map;
+        const std::string K = std::to_string(v.col_slot);
+        before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
+        cg.Stmt("  fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+      }
+      if (has_window) {
+        vo.window = num_staged++;
+        before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
+        // stage while the view is at hand (rows that fall outside the window are skipped: the
+        // tile then takes the second, direct pass)
+        cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
+        for (auto& name : pv) {
+          cg.Stmt("  if (" + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
+                  " + at), " + name + ");");
+          cg.Stmt("  at += " + name + ".len;");
         }
-      };
-      cg.Stmt("if (pass == 0) tl" + E + " = gdv_sat_add31(tl" + E + ", ln" + E + ");");
-      cg.Stmt("else {");
-      cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + ");");
-      cg.Stmt("  const gdv_int32 cnt = gdv_wave_last(inc), loc = inc - ln" + E + ";");
-      cg.Stmt("  if (live) outo" + E + "[row] = vb" + E + " + loc;");
-      cg.Stmt("  if (cnt <= GDV_OUT_WIN) {  // wave-uniform: stage through LDS, store coalesced");
-      copy_to("lds_out + loc", "    ");
-      cg.Stmt("    gdv_flush_out(outd" + E + " + vb" + E + ", lds_out, cnt, lane);");
-      cg.Stmt("  } else {");
-      copy_to("outd" + E + " + vb" + E + " + loc", "    ");
-      cg.Stmt("  }");
-      cg.Stmt("  vb" + E + " += cnt;");
+      }
+      cg.Stmt("} else if (dir" + E + ") {");
+      cg.Stmt("  gdv_uint8* at = outd" + E + " + dbase" + E + " + lc" + E + "[0];");
+      for (auto& name : pv) {
+        cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");
+        cg.Stmt("  at += " + name + ".len;");
+      }
       cg.Stmt("}");
-      after_loop << "  if (pass == 0) { const gdv_uint32 t = gdv_tile_total(tl" << E << "); if (lane == 0) A.counts["
-                 << tile << "] = t; }\n";
+      (void)vidx;
+      cg.varlen_outs_.push_back(vo);
     } else if (t.id == kBool) {
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
-      after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)", two);
+      after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)");
     } else {
-      cg.Stmt("if (" + p0 + "live) " + st + "(out" + E + ", row, (" + t.CType() + ")" + v.v + ");");
+      cg.Stmt("if (live) " + st + "(out" + E + ", row, (" + t.CType() + ")" + v.v + ");");
     }
     // validity word of the 64 rows of this sub-tile
     std::string word;
@@ -993,13 +1460,22 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
       if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
     }
-    after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid", two);
+    after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid");
   }
   // Loads in flight: aim for >= 8 KiB of input values per wave tile (64 lanes x GDV_U rows x
   // input bytes/row), within a budget of 512 input bytes per lane.  Wide plans (C2: 32 B/row,
   // ten outputs) stay at 4 — measured optimum, more sub-tiles cost occupancy — narrow plans
-  // (C1: 12 B/row) go to 16 (+3 % measured).  Var-len plans keep 4: they prefetch string words.
-  if (std::getenv("GDV_U") == nullptr && !plan->has_varlen_output) {
+  // (C1: 12 B/row) go to 16 (+3 % measured).
+  bool string_plan = plan->has_varlen_output;
+  for (size_t k = 0; k < cg.input_fields_.size(); k++)
+    string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
+  if (string_plan) {
+    // workgroup tile = 4 waves x 4 sub-tiles x 64 rows (profiles/r02_k4_singlepass_proto.txt)
+    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = 4;
+    if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
+  }
+  if (std::getenv("GDV_U") == nullptr) {
     int in_bytes = 0;
     bool any_varlen = false;
     for (size_t k = 0; k < cg.input_fields_.size(); k++) {
@@ -1051,6 +1527,15 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
   after << WordStore(acc, "A.mask");
   // one selected-row count per wave tile feeds the offsets scan (gdv_kernels.hip)
   after << "  if (lane == 0) A.counts[wbase / GDV_U] = fcount;\n";
+  bool string_plan = false;
+  for (size_t k = 0; k < cg.input_fields_.size(); k++)
+    string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
+  if (string_plan) {
+    // the index-emission kernel walks groups of 64 match words: sub-tiles stay a power of two
+    plan->opts.subtiles = 4;
+    if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    return AssembleStrings(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n", after.str());
+  }
   return Assemble(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n",
                   after.str());
 }

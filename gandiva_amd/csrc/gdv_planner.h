@@ -44,8 +44,8 @@ struct ArgLayout {
   int n_in = 0, n_out = 0;
   // per input slot: data ptr (8) | validity gdv_bitmap (24) | value-bits gdv_bitmap (24) | offsets ptr (8)
   static constexpr int kInStride = 64;
-  // per output slot: data ptr (8) | validity ptr (8) | offsets ptr (8)
-  static constexpr int kOutStride = 24;
+  // per output slot: data ptr (8) | validity ptr (8) | offsets ptr (8) | capacity (8)
+  static constexpr int kOutStride = 32;  // ... | byte capacity of a var-len data buffer (8)
   int in_base() const { return kHeaderBytes; }
   int out_base() const { return kHeaderBytes + std::max(n_in, 1) * kInStride; }
   int total() const { return out_base() + std::max(n_out, 1) * kOutStride; }
@@ -64,11 +64,12 @@ struct KernelPlan {
   std::vector<DataType> output_types;  // one per expression (filter: none)
   ArgLayout layout;
   bool can_raise = false;          // kernel may set error bits
-  // Some output is utf8/binary: the kernel is launched twice (aux0 = 0: byte totals per wave
-  // tile into `counts` + all fixed-width outputs; aux0 = 1: offsets and bytes, after the
-  // scan of the tile totals into `mask`).
+  // Some output is utf8/binary: single launch, workgroup 0 scans the tile totals (granules in
+  // `mask`, grand totals in `counts`); workers are workgroups 1.. (gdv_planner.cc, string plans)
   bool has_varlen_output = false;
   bool has_varlen_input = false;   // some expression reads utf8/binary bytes
+  bool string_skeleton = false;    // tile = workgroup (waves x subtiles x 64 rows), no grid-stride
+  int num_varlen_outputs = 0;
   int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
 };
 

@@ -172,9 +172,12 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
     return Status::CodeGenError("hiprtcCreateProgram failed");
   std::string arch_opt = "--offload-arch=" + a;
   // -ffp-contract=off is part of the semantics (bit-exact vs separate mul/add)
-  const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off",
-                        "-fhip-fp32-correctly-rounded-divide-sqrt"};
-  hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+  std::vector<const char*> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off",
+                                   "-fhip-fp32-correctly-rounded-divide-sqrt"};
+  // GDV_RTC_OPT: one extra compiler option for experiments (e.g. -DGDV_COLD= inlines the cold
+  // paths); not part of the cache key, so combine it with GDV_NO_DISK_CACHE=1
+  if (const char* extra = std::getenv("GDV_RTC_OPT")) opts.push_back(extra);
+  hiprtcResult r = hiprtcCompileProgram(prog, static_cast<int>(opts.size()), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 
+#define GDV_HOST_BUILD 1
 #define __device__
 #define __forceinline__ inline
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p |= v; return o; }
@@ -73,14 +74,11 @@ int host_decimal_compare(const void* xv, int xp, int xs, const void* yv, int yp,
 // ---------------------------------------------------------------- utf8 / binary
 // A column is (int32 offsets, bytes, byte count); the byte buffer must be readable up to
 // max(size, 8) bytes (the engine guarantees the same).  Row views are built exactly as the
-// generated kernels build them: first GDV_NPRE words prefetched into the register cache.
+// generated kernels build them.
 struct HostCol { const int* off; const unsigned char* data; long size; };
 static gdv_str host_row(const HostCol& c, long i) {
   const gdv_uint8* lim = c.data + (c.size < 8 ? 8 : c.size);
-  gdv_uint64 pre[GDV_NPRE];
-  const int len = c.off[i + 1] - c.off[i];
-  for (int j = 0; j < GDV_NPRE; j++) pre[j] = (8 * j < len) ? gdv_load8(c.data + c.off[i] + 8 * j, lim) : 0ull;
-  return gdv_make_str_cached(c.data, c.off[i], c.off[i + 1], lim, pre);
+  return gdv_make_str(c.data, c.off[i], c.off[i + 1], lim);
 }
 static gdv_str host_lit(const unsigned char* lit, int len) { return gdv_make_str(lit, 0, len, lit + len + 8); }
 
