@@ -88,6 +88,7 @@ class ArgBlock {
   void SetOutOffsets(int e, void* p) {
     SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 16, p);
   }
+  void SetLit(int i, uint64_t v) { Set64(layout_.lit_base() + i * 8, v); }
   void SetOutCap(int e, int64_t bytes) {
     Set64(layout_.out_base() + e * ArgLayout::kOutStride + 24, static_cast<uint64_t>(bytes));
   }
@@ -408,6 +409,20 @@ std::string ErrorMessage(uint32_t bits) {
   return m.empty() ? "execution error" : m;
 }
 
+// String literals, LIKE patterns and IN tables of a plan live in one small device block that the
+// kernel reaches through gdv_args::aux0 (uploaded once, at Make).
+Status UploadConstBlock(const KernelPlan& plan, DeviceBuffer* out) {
+  if (plan.const_block.empty()) return Status::OK();
+  GDV_RETURN_NOT_OK(out->Allocate(plan.const_block.size() + 16));
+  GDV_HIP_RETURN_NOT_OK(hipMemcpy(out->get(), plan.const_block.data(), plan.const_block.size(), hipMemcpyHostToDevice));
+  return Status::OK();
+}
+
+void BindLiterals(const KernelPlan& plan, const DeviceBuffer& consts, ArgBlock* args) {
+  for (size_t i = 0; i < plan.literals.size(); i++) args->SetLit(static_cast<int>(i), plan.literals[i]);
+  args->SetPtr(ArgLayout::kOffAux0, consts.get());
+}
+
 LruCache<Projector>& ProjectorCache() {
   static LruCache<Projector> c(500);
   return c;
@@ -442,6 +457,7 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
   p->schema_ = schema;
   GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, opts, &p->plan_));
   GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.source, p->plan_.kernel_name, &p->kernel_));
+  GDV_RETURN_NOT_OK(UploadConstBlock(p->plan_, &p->consts_));
   ProjectorCache().Put(key, p);
   *out = p;
   return Status::OK();
@@ -480,6 +496,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  BindLiterals(plan_, consts_, &args);
   // pooled staging blocks (e.g. the zero-padded copy of a tiny var-len buffer) go back to the
   // pool when this call returns: an asynchronous evaluation must not outlive them
   drain.armed = drain.armed || !st.buffers.empty();
@@ -660,6 +677,7 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   f->schema_ = schema;
   GDV_RETURN_NOT_OK(PlanFilter(schema, condition, opts, &f->plan_));
   GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(f->plan_.source, f->plan_.kernel_name, &f->kernel_));
+  GDV_RETURN_NOT_OK(UploadConstBlock(f->plan_, &f->consts_));
   FilterCache().Put(key, f);
   *out = f;
   return Status::OK();
@@ -689,6 +707,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   StreamDrain drain{stream, true};  // declared last: drains before any pooled block is freed
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  BindLiterals(plan_, consts_, &args);
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 

@@ -82,6 +82,7 @@ class Projector {
   Schema schema_;
   KernelPlan plan_;
   const CompiledKernel* kernel_ = nullptr;
+  DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
 };
 
 class Filter {
@@ -103,6 +104,7 @@ class Filter {
   Schema schema_;
   KernelPlan plan_;
   const CompiledKernel* kernel_ = nullptr;
+  DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
 };
 
 // Builds the plan and compiles it to a gfx950 code object without touching a device

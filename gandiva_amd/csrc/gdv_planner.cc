@@ -170,6 +170,20 @@ std::string Hex64(uint64_t v) {
   return buf;
 }
 
+// The kernel's identity is its code: the "// @expr_N = ..." header lines render the expressions
+// WITH their literal values (DumpIR shows them), the code below them does not depend on the values.
+std::string HashableSource(const std::string& text) {
+  std::string out;
+  size_t pos = 0;
+  while (pos < text.size()) {
+    size_t eol = text.find('\n', pos);
+    if (eol == std::string::npos) eol = text.size();
+    if (text.compare(pos, 9, "// @expr_") != 0) out.append(text, pos, eol - pos + 1);
+    pos = eol + 1;
+  }
+  return out;
+}
+
 uint64_t Fnv1a(const std::string& s) {
   uint64_t h = 1469598103934665603ull;
   for (unsigned char c : s) {
@@ -177,20 +191,6 @@ uint64_t Fnv1a(const std::string& s) {
     h *= 1099511628211ull;
   }
   return h;
-}
-
-std::string LiteralExpr(const DataType& t, const Literal& v) {
-  switch (t.id) {
-    case kBool: return v.lo ? "true" : "false";
-    case kFloat: return "__uint_as_float(" + Hex64(v.lo & 0xffffffffull) + ")";
-    case kDouble: return "__longlong_as_double((long long)" + Hex64(v.lo) + ")";
-    case kDecimal128:
-      return "gdv_make_int128(" + Hex64(v.hi) + ", " + Hex64(v.lo) + ")";
-    default: {
-      uint64_t mask = t.byte_width() >= 8 ? ~0ull : ((1ull << (8 * t.byte_width())) - 1);
-      return "((" + t.CType() + ")" + Hex64(v.lo & mask) + ")";
-    }
-  }
 }
 
 // A value inside the generated row body: a C++ expression plus its validity, split the way
@@ -290,14 +290,46 @@ class CodeGen {
     return s;
   }
 
-  // bytes -> `__constant__` array in the prelude; returns the array name
+  // ---- literals are kernel ARGUMENTS, not source text (round 2): `a > 499` and `a > 500`, or
+  // like '%spark%' and like '%flink%', share one compiled kernel; only the shape (types, list
+  // sizes, pattern form and needle length) is compiled in.
+  // Fixed-width literal -> 8-byte slot of gdv_args::lit (decimal128: two slots, low word first)
+  int LitSlot(uint64_t v) {
+    for (size_t i = 0; i < lits_.size(); i++)
+      if (lits_[i] == v && !lit_pair_tail_[i]) return static_cast<int>(i);
+    lits_.push_back(v);
+    lit_pair_tail_.push_back(false);
+    return static_cast<int>(lits_.size()) - 1;
+  }
+  std::string LiteralExpr(const DataType& t, const Literal& v) {
+    auto slot = [&](uint64_t x) { return "A.lit[" + std::to_string(LitSlot(x)) + "]"; };
+    switch (t.id) {
+      case kBool: return v.lo ? "true" : "false";
+      case kFloat: return "__uint_as_float((gdv_uint32)" + slot(v.lo & 0xffffffffull) + ")";
+      case kDouble: return "__longlong_as_double((long long)" + slot(v.lo) + ")";
+      case kDecimal128: {
+        // two consecutive slots that are never shared with single-word literals
+        lits_.push_back(v.lo);
+        lit_pair_tail_.push_back(true);
+        lits_.push_back(v.hi);
+        lit_pair_tail_.push_back(true);
+        const std::string i = std::to_string(lits_.size() - 2), j = std::to_string(lits_.size() - 1);
+        return "gdv_make_int128(A.lit[" + j + "], A.lit[" + i + "])";
+      }
+      default: {
+        uint64_t mask = t.byte_width() >= 8 ? ~0ull : ((1ull << (8 * t.byte_width())) - 1);
+        return "((" + t.CType() + ")" + slot(v.lo & mask) + ")";
+      }
+    }
+  }
+  // bytes -> the plan's constant block (device memory, bound through gdv_args::aux0); returns a
+  // pointer expression.  Every table starts 16-byte aligned and is readable 8 bytes past its end.
   std::string ByteTable(const std::string& bytes, const char* ctype = "gdv_uint8") {
-    std::string name = "gdv_cst" + std::to_string(next_const_++);
-    prelude_ << "__constant__ " << ctype << " " << name << "[" << bytes.size() + 8 << "] = {";
-    for (size_t i = 0; i < bytes.size(); i++)
-      prelude_ << static_cast<unsigned>(static_cast<unsigned char>(bytes[i])) << ",";
-    prelude_ << "0,0,0,0,0,0,0,0};\n";  // 8-byte loads may run past the literal's end
-    return name;
+    while (blob_.size() % 16 != 0) blob_.push_back('\0');
+    const size_t off = blob_.size();
+    blob_ += bytes;
+    blob_.append(8, '\0');  // 8-byte loads may run past the table's end
+    return "((const " + std::string(ctype) + "*)(gdv_cst + " + std::to_string(off) + "))";
   }
   std::string StringConstant(const std::string& bytes) {
     std::string t = ByteTable(bytes);
@@ -395,10 +427,12 @@ class CodeGen {
   std::vector<int> input_fields_;
   std::vector<bool> needs_values_, needs_validity_;
   bool can_raise_ = false;
-  std::ostringstream prelude_;  // file-scope constants (IN tables, patterns)
-  int next_const_ = 0;
+  std::vector<uint64_t> lits_;        // gdv_args::lit
+  std::vector<bool> lit_pair_tail_;   // slots of two-word literals (not shared)
+  std::string blob_;                  // constant block: string literals, patterns, IN tables
   // string plans
   std::vector<ContainsHook> contains_hooks_;
+  std::vector<std::string> hook_tables_;  // needle bytes in the constant block
   std::set<int> ascii_slots_;     // input slots whose tile-wide ASCII flag some function consults
   std::vector<VarlenOut> varlen_outs_;
   int HookFor(int slot, int map, const std::string& needle) {
@@ -406,6 +440,7 @@ class CodeGen {
       if (contains_hooks_[h].slot == slot && contains_hooks_[h].map == map && contains_hooks_[h].needle == needle)
         return static_cast<int>(h);
     contains_hooks_.push_back({slot, map, needle});
+    hook_tables_.push_back(ByteTable(needle));
     return static_cast<int>(contains_hooks_.size()) - 1;
   }
 };
@@ -689,42 +724,52 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->vcols = x.vcols;
       out->vlane = x.vlane;
       if (n.value_type().is_varlen()) {
-        std::string bytes;
-        std::string name = "gdv_cst" + std::to_string(next_const_++);
-        prelude_ << "__constant__ gdv_int32 " << name << "[" << n.values().size() + 1 << "] = {0";
+        std::string bytes, offs;
+        auto put32 = [&](uint32_t v) { offs.append(reinterpret_cast<const char*>(&v), 4); };
+        put32(0);
         for (auto& l : n.values()) {
           bytes += l.bytes;
-          prelude_ << "," << bytes.size();
+          put32(static_cast<uint32_t>(bytes.size()));
         }
-        prelude_ << "};\n";
-        out->v = Tmp("bool", "gdv_in_strings(" + x.v + ", " + ByteTable(bytes) + ", " + name + ", " +
+        const std::string tab = ByteTable(offs, "gdv_int32");
+        out->v = Tmp("bool", "gdv_in_strings(" + x.v + ", " + ByteTable(bytes) + ", " + tab + ", " +
                                  std::to_string(n.values().size()) + ")");
         return Status::OK();
       }
-      const std::string ctype = n.value_type().CType();
       std::vector<uint64_t> vals;
-      uint64_t mask = n.value_type().byte_width() >= 8
-                          ? ~0ull
-                          : ((1ull << (8 * n.value_type().byte_width())) - 1);
-      for (auto& l : n.values()) vals.push_back(l.lo & mask);
+      const DataType& vt = n.value_type();
+      uint64_t mask = vt.byte_width() >= 8 ? ~0ull : ((1ull << (8 * vt.byte_width())) - 1);
+      const bool is_fp = vt.id == kFloat || vt.id == kDouble;
+      for (auto& l : n.values()) {
+        uint64_t bits = l.lo & mask;
+        if (is_fp) {
+          // value equality, as a hash set of floats gives it: -0.0 and +0.0 are one value,
+          // a NaN equals nothing (the probe adds +0.0, which maps -0.0 to +0.0 and keeps NaNs NaN)
+          const bool nan = vt.id == kFloat ? ((bits & 0x7f800000u) == 0x7f800000u && (bits & 0x7fffffu) != 0)
+                                           : ((bits & 0x7ff0000000000000ull) == 0x7ff0000000000000ull &&
+                                              (bits & 0xfffffffffffffull) != 0);
+          if (nan) continue;
+          if (bits == (vt.id == kFloat ? 0x80000000ull : 0x8000000000000000ull)) bits = 0;
+        }
+        vals.push_back(bits);
+      }
       std::sort(vals.begin(), vals.end());
       vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+      const std::string probe = is_fp ? "gdv_bits64(" + x.v + " + (" + vt.CType() + ")0)" : "gdv_bits64(" + x.v + ")";
       if (vals.empty()) {
         out->v = "false";
       } else if (vals.size() <= 8) {
+        const std::string xb = Tmp("gdv_uint64", probe);
         std::string e;
         for (auto v : vals) {
           if (!e.empty()) e += " || ";
-          e += "(gdv_bits64(" + x.v + ") == " + Hex64(v) + ")";
+          e += "(" + xb + " == A.lit[" + std::to_string(LitSlot(v)) + "])";
         }
         out->v = Tmp("bool", e);
       } else {
-        // sorted constant table + branch-free binary search on the value's bit image
-        std::string name = "gdv_in_tab" + std::to_string(next_const_++);
-        prelude_ << "__constant__ gdv_uint64 " << name << "[" << vals.size() << "] = {";
-        for (size_t i = 0; i < vals.size(); i++) prelude_ << (i ? ", " : "") << Hex64(vals[i]);
-        prelude_ << "};\n";
-        out->v = Tmp("bool", "gdv_in_sorted(gdv_bits64(" + x.v + "), " + name + ", " +
+        // sorted table in the constant block + branch-free binary search on the value's bit image
+        std::string tab(reinterpret_cast<const char*>(vals.data()), vals.size() * 8);
+        out->v = Tmp("bool", "gdv_in_sorted(" + probe + ", " + ByteTable(tab, "gdv_uint64") + ", " +
                                  std::to_string(vals.size()) + ")");
       }
       return Status::OK();
@@ -756,8 +801,11 @@ struct Assembler {
         << "  gdv_int64 aux0, aux1, aux2;\n"
         << "  gdv_in_slot in[" << nin << "];\n"
         << "  gdv_out_slot out[" << nout << "];\n"
+        << "  gdv_uint64 lit[" << std::max<size_t>(1, cg.lits_.size()) << "];  // fixed-width literals of the plan\n"
         << "};\n";
-    src << cg.prelude_.str();
+    plan->literals = cg.lits_;
+    plan->const_block = cg.blob_;
+    plan->layout.n_lit = static_cast<int>(cg.lits_.size());
   }
 };
 
@@ -817,6 +865,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "  (void)lds_out;\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 rbase = wbase * 64;\n";
   for (int k = 0; k < nin; k++) {
@@ -991,7 +1041,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   s << "}\n";
 
   std::string text = s.str();
-  uint64_t h = Fnv1a(text);
+  uint64_t h = Fnv1a(HashableSource(text));
   char name[64];
   snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
   plan->kernel_name = name;
@@ -1049,6 +1099,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "  (void)lds_out; (void)lds_hit; (void)lds_tot; (void)lds_base; (void)ntiles;\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
     << "  const gdv_int64 rbase = wbase * 64;\n";
@@ -1158,8 +1210,15 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
       << "  (void)hm_ok" << K << ";\n"
       << "  gdv_uint64 sacc" << K << " = 0;\n";
-    for (int h : hooks)
-      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
+        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
+        << ";  // the needle: a runtime constant\n"
+        << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
+        << " >> 8) & 0xffull) * GDV_B01;\n";
+    }
     s << "  for (gdv_int32 c = sb" << K << "; c < sp1" << K << "; c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
       << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
@@ -1170,20 +1229,15 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
         << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
       for (int h : hooks) {
         const ContainsHook& hk = cg.contains_hooks_[h];
-        uint64_t first = 0;
-        for (size_t i = 0; i < hk.needle.size(); i++)
-          first |= static_cast<uint64_t>(static_cast<unsigned char>(hk.needle[i])) << (8 * i);
         const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
-        const uint64_t sp0 = (first & 0xff) * 0x0101010101010101ull, sp1 = ((first >> 8) & 0xff) * 0x0101010101010101ull;
         const std::string H = std::to_string(h), M = std::to_string(hk.map);
         s << "    {\n"
           << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
           << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
           << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-          << "      const gdv_uint32 m = gdv_match8(lo, hi, " << Hex64(first) << ", " << Hex64(mask) << ", " << Hex64(sp0)
-          << ", " << Hex64(sp1) << ") |\n"
-          << "                           (gdv_match8(hi, nx, " << Hex64(first) << ", " << Hex64(mask) << ", " << Hex64(sp0)
-          << ", " << Hex64(sp1) << ") << 8);\n"
+          << "      const gdv_uint32 m = gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+          << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
+          << ") << 8);\n"
           << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
           << ") >> 4] = (gdv_uint16)m;\n"
           << "    }\n";
@@ -1346,7 +1400,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "}\n";
 
   std::string text = s.str();
-  uint64_t h = Fnv1a(text);
+  uint64_t h = Fnv1a(HashableSource(text));
   char name[64];
   snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
   plan->kernel_name = name;

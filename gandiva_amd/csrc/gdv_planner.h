@@ -41,14 +41,15 @@ struct ArgLayout {
   static constexpr int kHeaderBytes = 64;  // n, err, sel, mask, counts, aux0..2
   static constexpr int kOffN = 0, kOffErr = 8, kOffSel = 16, kOffMask = 24, kOffCounts = 32,
                        kOffAux0 = 40, kOffAux1 = 48, kOffAux2 = 56;
-  int n_in = 0, n_out = 0;
+  int n_in = 0, n_out = 0, n_lit = 0;
   // per input slot: data ptr (8) | validity gdv_bitmap (24) | value-bits gdv_bitmap (24) | offsets ptr (8)
   static constexpr int kInStride = 64;
   // per output slot: data ptr (8) | validity ptr (8) | offsets ptr (8) | capacity (8)
   static constexpr int kOutStride = 32;  // ... | byte capacity of a var-len data buffer (8)
   int in_base() const { return kHeaderBytes; }
   int out_base() const { return kHeaderBytes + std::max(n_in, 1) * kInStride; }
-  int total() const { return out_base() + std::max(n_out, 1) * kOutStride; }
+  int lit_base() const { return out_base() + std::max(n_out, 1) * kOutStride; }
+  int total() const { return lit_base() + std::max(n_lit, 1) * 8; }
 };
 
 struct KernelPlan {
@@ -63,6 +64,8 @@ struct KernelPlan {
   std::vector<bool> input_needs_validity;
   std::vector<DataType> output_types;  // one per expression (filter: none)
   ArgLayout layout;
+  std::vector<uint64_t> literals;  // fixed-width literal values -> gdv_args::lit (kernel arguments)
+  std::string const_block;         // string literals, LIKE patterns, IN tables -> device memory (aux0)
   bool can_raise = false;          // kernel may set error bits
   // Some output is utf8/binary: single launch, workgroup 0 scans the tile totals (granules in
   // `mask`, grand totals in `counts`); workers are workgroups 1.. (gdv_planner.cc, string plans)

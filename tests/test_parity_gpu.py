@@ -540,3 +540,29 @@ def test_plan_cache_distinguishes_trees_that_render_alike():
     assert str(two) == str(one)
     for tree in (two, one):
         _check_project([b.make_expression(tree, pa.field("r", pa.bool_()))], sb)
+
+
+def test_literals_are_kernel_arguments_not_source_text():
+    """`a > 499` / `a > 500`, IN lists of equal size and LIKE needles of equal length share ONE
+    compiled kernel (round-1 verdict: every distinct constant was a fresh hipRTC compile); each
+    instance still computes with its own values."""
+    import re
+    rng = np.random.default_rng(77)
+    n = 5000
+    batch = pa.RecordBatch.from_arrays(
+        [pa.array(rng.integers(0, 1000, n)), pa.array(rng.standard_normal(n)),
+         pa.array([["spark", "flink", "a spark b", "xflinky", None][int(i)] for i in rng.integers(0, 5, n)])],
+        names=["a", "x", "s"])
+    b = gandiva.TreeExprBuilder()
+    a, x, s = (b.make_field(batch.schema.field(i)) for i in range(3))
+    names = set()
+    for k, f, pat, inl in ((499, 0.25, "%spark%", [1, 5, 9]), (500, -1.5, "%flink%", [2, 500, 777])):
+        cond = b.make_condition(b.make_and([
+            b.make_function("greater_than", [a, b.make_literal(k, pa.int64())], pa.bool_()),
+            b.make_or([b.make_function("less_than", [x, b.make_literal(f, pa.float64())], pa.bool_()),
+                       b.make_function("like", [s, b.make_literal(pat, pa.string())], pa.bool_()),
+                       b.make_in_expression(a, inl, pa.int64())])]))
+        flt = gandiva.make_filter(batch.schema, cond)
+        names.add(re.search(r"gdv_k_[0-9a-f]{16}", flt.llvm_ir).group(0))
+        assert flt.evaluate(batch, None).to_array().equals(oracle.filter_indices(cond, batch, "int32"))
+    assert len(names) == 1, names
