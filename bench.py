@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
     p.add_argument("--cpu-rows", type=int, default=1 << 26, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak: --rows per GPU (default); strong: ONE logical batch of --rows rows "
+                        "row-sharded across the ranks by gandiva_amd.shard (c2 only)")
     return p.parse_args()
 
 
@@ -184,14 +187,26 @@ def cpu_baseline_c5(rows):
             "sample": f"{reps} passes over {rows} rows of the C5 generator (3 expressions), 1 thread, {el:.1f} s"}
 
 
-def load_traffic(tag):
-    """HBM bytes per launch from the committed PMC pass (tools/pmc_traffic.py), if any."""
+def load_traffic(tag, running_kernel):
+    """HBM bytes per launch from the committed PMC passes (tools/summarize_prof.py pmc) — quoted
+    ONLY when they were taken on the very kernel that is running now (same source hash);
+    returns (bytes or None, where the figure comes from)."""
     path = os.path.join(ROOT, "profiles", f"pmc_{tag}.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            d = json.load(f)
     except Exception:
-        return None
+        return None, "no PMC pass committed for this workload"
+    if running_kernel is None or d.get("kernel") != running_kernel:
+        return None, (f"profiles/pmc_{tag}.json was taken on {d.get('kernel')}, this run is "
+                      f"{running_kernel}: not quoted")
+    return d.get("hbm_bytes_per_launch"), f"profiles/pmc_{tag}.json@{d.get('kernel')}"
+
+
+def kernel_name_of(obj):
+    import re
+    m = re.search(r"gdv_k_[0-9a-f]{16}", obj.llvm_ir)
+    return m.group(0) if m else None
 
 
 def main():
@@ -226,8 +241,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    strong = args.scaling == "strong" and args.workload == "c2"
+    logical_rows = None
     if args.workload == "c2":
         rows = args.rows or (1 << 28)
+        if strong:
+            # ONE logical batch of `rows` rows, row-sharded on 1024-row boundaries: this rank
+            # generates and evaluates only its own range (no collective on the data path)
+            from gandiva_amd import shard
+            logical_rows = rows
+            lo, hi = shard.shard_bounds(logical_rows, world, rank)
+            rows = max(hi - lo, 1)
         dbatch = W.c2_device_batch(rows, seed_offset=1000 * rank)  # every rank: its own shard
         proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
         outs = proj.evaluate_device(dbatch)  # allocates + first touch
@@ -277,7 +301,8 @@ def main():
 
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
-        kernel_desc = "fused like/substr/upper kernel, 2 launches (lengths, bytes) + 2 offset scans"
+        kernel_desc = ("single-pass var-len kernel, 1 launch: byte sweep, scanner-wave offsets, "
+                       "flat / LDS-staged copies")
     else:
         rows = args.rows or 1_000_000_000
         dbatch = W.c3_device_batch(rows)
@@ -314,8 +339,11 @@ def main():
     elapsed = float(t.item())
     mean_dev_ms = float(k.item())
 
+    running_kernel = kernel_name_of(flt if args.workload == "c3" else proj)
     if rank == 0:
-        total_rows = rows * world
+        total_rows = logical_rows if strong else rows * world
+        traffic, traffic_source = (load_traffic(args.workload, running_kernel) if not args.rows
+                                   else (None, "PMC passes are taken at the BASELINE size only"))
         value = total_rows * args.steps / elapsed / 1e6
         achieved = bytes_per_row * rows / (mean_dev_ms * 1e-3) / 1e9
         line = {
@@ -331,7 +359,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": {"c1": "int32", "c2": "f64", "c3": "int64", "c4": "decimal128", "c5": "u8"}[args.workload],
             "data": "synthetic",
@@ -353,8 +381,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # PMC passes were taken at the BASELINE size: only quote them for that size
-                "traffic": load_traffic(args.workload) if not args.rows else None,
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                "kernel_name": running_kernel,
                 "kernel": kernel_desc,
                 "algorithmic_bytes_per_row": round(bytes_per_row, 3),
                 # the read and write shares of `achieved`, separately

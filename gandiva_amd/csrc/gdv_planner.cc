@@ -294,14 +294,21 @@ class CodeGen {
   // like '%spark%' and like '%flink%', share one compiled kernel; only the shape (types, list
   // sizes, pattern form and needle length) is compiled in.
   // Fixed-width literal -> 8-byte slot of gdv_args::lit (decimal128: two slots, low word first)
+  // (slots are never shared by VALUE — the code must not depend on which constants happen to be
+  // equal — only by node identity: a literal node used in several places is one slot, so common
+  // sub-expressions built from shared nodes still merge)
   int LitSlot(uint64_t v) {
-    for (size_t i = 0; i < lits_.size(); i++)
-      if (lits_[i] == v && !lit_pair_tail_[i]) return static_cast<int>(i);
     lits_.push_back(v);
-    lit_pair_tail_.push_back(false);
     return static_cast<int>(lits_.size()) - 1;
   }
-  std::string LiteralExpr(const DataType& t, const Literal& v) {
+  std::string LiteralExpr(const DataType& t, const Literal& v, const void* node) {
+    auto it = lit_of_node_.find(node);
+    if (it != lit_of_node_.end()) return it->second;
+    std::string e = LiteralExprNew(t, v);
+    lit_of_node_[node] = e;
+    return e;
+  }
+  std::string LiteralExprNew(const DataType& t, const Literal& v) {
     auto slot = [&](uint64_t x) { return "A.lit[" + std::to_string(LitSlot(x)) + "]"; };
     switch (t.id) {
       case kBool: return v.lo ? "true" : "false";
@@ -310,9 +317,7 @@ class CodeGen {
       case kDecimal128: {
         // two consecutive slots that are never shared with single-word literals
         lits_.push_back(v.lo);
-        lit_pair_tail_.push_back(true);
         lits_.push_back(v.hi);
-        lit_pair_tail_.push_back(true);
         const std::string i = std::to_string(lits_.size() - 2), j = std::to_string(lits_.size() - 1);
         return "gdv_make_int128(A.lit[" + j + "], A.lit[" + i + "])";
       }
@@ -428,7 +433,7 @@ class CodeGen {
   std::vector<bool> needs_values_, needs_validity_;
   bool can_raise_ = false;
   std::vector<uint64_t> lits_;        // gdv_args::lit
-  std::vector<bool> lit_pair_tail_;   // slots of two-word literals (not shared)
+  std::map<const void*, std::string> lit_of_node_;
   std::string blob_;                  // constant block: string literals, patterns, IN tables
   // string plans
   std::vector<ContainsHook> contains_hooks_;
@@ -482,7 +487,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         out->vlane = l.is_null() ? "false" : "";
         return Status::OK();
       }
-      out->v = LiteralExpr(l.return_type(), l.value());
+      out->v = LiteralExpr(l.return_type(), l.value(), &node);
       out->vcols.clear();
       out->vlane = l.is_null() ? "false" : "";
       return Status::OK();

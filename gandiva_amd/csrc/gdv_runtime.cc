@@ -14,8 +14,10 @@
 namespace gdv {
 
 Runtime& Runtime::Get() {
-  static Runtime rt;
-  return rt;
+  // never destroyed: cached Projectors / Filters (process-wide LRUs) own pooled device blocks and
+  // hand them back during static destruction, in an order this singleton must outlive
+  static Runtime* rt = new Runtime;
+  return *rt;
 }
 
 void Runtime::Probe() {

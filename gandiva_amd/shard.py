@@ -70,6 +70,49 @@ def concat_selection(per_rank_indices, per_rank_bases):
     return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
 
 
-def concat_arrays(per_rank_arrays):
-    """Projector outputs stay sharded; this is the logical (chunked) concatenation."""
-    return pa.chunked_array(list(per_rank_arrays))
+def concat_arrays(per_rank_arrays, contiguous=False):
+    """Projector outputs stay sharded: the logical concatenation is a chunked array.  With
+    ``contiguous=True`` the shards are joined into ONE array; for utf8/binary that rebases every
+    shard's int32 offsets by the bytes of the shards before it."""
+    parts = list(per_rank_arrays)
+    if not contiguous:
+        return pa.chunked_array(parts)
+    return pa.concat_arrays([p.combine_chunks() if isinstance(p, pa.ChunkedArray) else p for p in parts])
+
+
+def shard_device_batch(dbatch, world_size, rank):
+    """Zero-copy slice of an HBM-resident DeviceBatch for `rank` (+ its row base).  Boundaries are
+    multiples of 1024 rows, so validity / bool bitmaps slice at whole bytes (array offset 0 for
+    the kernel) and fixed-width buffers at whole rows; a var-len column keeps the WHOLE byte
+    buffer and slices only its offsets (they stay absolute)."""
+    from . import gandiva as gdv
+    lo, hi = shard_bounds(dbatch.num_rows, world_size, rank)
+    cols = []
+    for c in dbatch.columns:
+        if c.offset != 0:
+            raise ValueError("shard_device_batch expects columns without an Arrow array offset")
+        validity = None if c.validity is None else c.validity[lo // 8:]
+        if c.offsets is not None:
+            cols.append(gdv.DeviceColumn(c.type, hi - lo, validity, c.data, c.offsets[lo * 4:], 0))
+        elif pa.types.is_boolean(c.type):
+            cols.append(gdv.DeviceColumn(c.type, hi - lo, validity, c.data[lo // 8:], None, 0))
+        else:
+            w = c.type.bit_width // 8
+            cols.append(gdv.DeviceColumn(c.type, hi - lo, validity, c.data[lo * w:], None, 0))
+    return gdv.DeviceBatch(dbatch.schema, cols, hi - lo), lo
+
+
+def concat_varlen_device(per_rank_outputs):
+    """Joins the var-len output shards of consecutive ranks ON THE DEVICE: offsets of shard r are
+    rebased by the byte total of shards 0..r-1, bytes are laid end to end.  Returns
+    (offsets int32 tensor of rows+1 entries, bytes uint8 tensor)."""
+    import torch
+    offs, data, base = [], [], 0
+    for i, o in enumerate(per_rank_outputs):
+        n = o.length
+        local = o.offsets.view(torch.int32)[:n + 1].to(torch.int64)
+        used = int(local[n].item())
+        offs.append((local[:n] if i + 1 < len(per_rank_outputs) else local) + base)
+        data.append(o.data[:used])
+        base += used
+    return torch.cat(offs).to(torch.int32), torch.cat(data)

@@ -1,0 +1,135 @@
+"""HIP-side multi-rank check (SURVEY.md §8e, round-1 verdict item 6): N ranks, ONE logical
+HBM-resident batch, every rank evaluates its `shard.shard_bounds` row range through the HIP
+path (C ABI), and the rank-ordered concatenation must equal the unsharded oracle.
+
+  * C2 projection: outputs stay sharded, validity bitmaps never straddle shards;
+  * C3 filter: local indices + row_base rebasing + the count exchange (gloo all_gather);
+  * C5 var-len: per-shard offsets rebased on concatenation (shard.concat_varlen_device).
+
+There is one GPU on the test box, so the ranks are processes sharing cuda:0 over gloo — the
+same rendezvous, barrier and exchange code the driver's multi-GPU run uses with nccl."""
+import os
+import socket
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from gandiva_amd import shard, workloads as W
+from helpers import assert_bit_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, tmpdir):
+    import torch
+    import torch.distributed as dist
+    import gandiva_amd as gandiva
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        # ---- C2: every rank holds the logical batch in HBM and evaluates only its row range
+        d2 = gandiva.DeviceBatch.from_arrow(W.c2_batch(n))
+        mine, _ = shard.shard_device_batch(d2, world, rank)
+        exprs = W.c2_expressions()
+        if mine.num_rows:
+            outs = gandiva.make_projector(W.c2_schema(), exprs, None).evaluate_device(mine)
+            torch.cuda.synchronize()
+            arrays = [o.to_arrow() for o in outs]
+            with pa.ipc.new_file(os.path.join(tmpdir, f"c2_{rank}.arrow"),
+                                 pa.schema([(f"e{i}", pa.float64()) for i in range(len(arrays))])) as w:
+                w.write_batch(pa.RecordBatch.from_arrays(arrays, names=[f"e{i}" for i in range(len(arrays))]))
+        # ---- C3: local selection + base, counts exchanged on the host
+        d3 = gandiva.DeviceBatch.from_arrow(W.c3_batch(n, 0.1))
+        m3, base = shard.shard_device_batch(d3, world, rank)
+        if m3.num_rows:
+            sel = gandiva.make_filter(W.c3_schema(), W.c3_condition()).evaluate_device(m3, "int32")
+            idx = sel.indices[:sel.num_slots].cpu().numpy().view(np.uint32)
+        else:
+            idx = np.zeros(0, np.uint32)
+        counts = shard.exchange_counts(len(idx))
+        np.save(os.path.join(tmpdir, f"c3_idx{rank}.npy"), shard.rebase_indices(idx, base))
+        np.save(os.path.join(tmpdir, f"c3_off{rank}.npy"), shard.global_offsets(counts))
+        # ---- C5: var-len outputs per shard (offsets local to the shard)
+        d5 = gandiva.DeviceBatch.from_arrow(W.c5_batch(n, 0.1))
+        m5, _ = shard.shard_device_batch(d5, world, rank)
+        if m5.num_rows:
+            outs = gandiva.make_projector(W.c5_schema(), W.c5_expressions(), None).evaluate_device(m5)
+            torch.cuda.synchronize()
+            arrays = [o.to_arrow() for o in outs]
+            with pa.ipc.new_file(os.path.join(tmpdir, f"c5_{rank}.arrow"),
+                                 pa.schema([("like", pa.bool_()), ("sub", pa.string()), ("up", pa.string())])) as w:
+                w.write_batch(pa.RecordBatch.from_arrays(arrays, names=["like", "sub", "up"]))
+            if rank == 0 and world > 1:
+                # the device-side join of two shards' var-len outputs, checked against pyarrow's
+                torch.save({"off": outs[2].offsets.cpu(), "dat": outs[2].data[:outs[2].data_used].cpu(),
+                            "n": outs[2].length}, os.path.join(tmpdir, "c5_up0.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 70001), (8, 200_003)])
+def test_row_sharded_hip_evaluation_matches_unsharded_oracle(world, n, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    ranks = [r for r in range(world) if shard.shard_bounds(n, world, r)[1] > shard.shard_bounds(n, world, r)[0]]
+    # C2: rank-ordered concatenation == unsharded evaluation
+    exprs = W.c2_expressions()
+    full = oracle.project(exprs, W.c2_batch(n))
+    chunks = [pa.ipc.open_file(tmp_path / f"c2_{r}.arrow").read_all() for r in ranks]
+    for e in range(len(exprs)):
+        cat = shard.concat_arrays([c.column(e) for c in chunks], contiguous=True)
+        assert_bit_exact(cat, full[e], f"c2 e{e}")
+    # C3: globally ascending indices, agreed offsets
+    parts = [np.load(tmp_path / f"c3_idx{r}.npy") for r in range(world)]
+    offs = np.load(tmp_path / "c3_off0.npy")
+    for r in range(1, world):
+        assert np.array_equal(offs, np.load(tmp_path / f"c3_off{r}.npy"))
+    assert [len(p) for p in parts] == list(np.diff(offs))
+    got = np.concatenate(parts)
+    want = oracle.filter_indices(W.c3_condition(), W.c3_batch(n, 0.1), "int64").to_numpy()
+    assert np.array_equal(got, want.astype(np.int64)) and np.all(np.diff(got) > 0)
+    # C5: var-len shards joined with rebased offsets
+    ex5 = W.c5_expressions()
+    full5 = oracle.project(ex5, W.c5_batch(n, 0.1))
+    chunks = [pa.ipc.open_file(tmp_path / f"c5_{r}.arrow").read_all() for r in ranks]
+    for e in range(3):
+        cat = shard.concat_arrays([c.column(e) for c in chunks], contiguous=True)
+        assert_bit_exact(cat, full5[e], f"c5 output {e}")
+
+
+def test_device_side_join_of_varlen_shards():
+    """shard.concat_varlen_device: offsets of shard r rebased by the bytes of shards < r."""
+    import torch
+    import gandiva_amd as gandiva
+    from oracle import oracle
+    n = 50_000
+    batch = W.c5_batch(n, 0.1)
+    d5 = gandiva.DeviceBatch.from_arrow(batch)
+    proj = gandiva.make_projector(W.c5_schema(), W.c5_expressions(), None)
+    shards = []
+    for r in range(3):
+        m, _ = shard.shard_device_batch(d5, 3, r)
+        shards.append(proj.evaluate_device(m))
+    torch.cuda.synchronize()
+    want = oracle.project(W.c5_expressions(), batch)
+    for e in (1, 2):
+        off, dat = shard.concat_varlen_device([s[e] for s in shards])
+        assert off.numel() == n + 1 and int(off[-1]) == dat.numel()
+        valid = np.concatenate([np.unpackbits(s[e].validity.cpu().numpy(), bitorder="little")[:s[e].length]
+                                for s in shards]).astype(bool)
+        got = pa.Array.from_buffers(pa.string(), n, [pa.py_buffer(np.packbits(valid, bitorder="little")),
+                                                     pa.py_buffer(off.cpu().numpy()), pa.py_buffer(dat.cpu().numpy())])
+        assert_bit_exact(got, want[e], f"output {e}")
