@@ -1378,7 +1378,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   s << "}\n\n";
 
   // ---- kernel
-  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+  s << "#ifndef GDV_STRING_KERNEL_ATTR\n#define GDV_STRING_KERNEL_ATTR\n#endif\n"
+    << "extern \"C\" __global__ void GDV_STRING_KERNEL_ATTR __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
     << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"

@@ -1,22 +1,33 @@
 #!/bin/bash
-# end-of-round evidence: full GPU suite, smoke, default bench, rocprof of the same command,
-# PMC passes (separate, kernel-trace only), the other workloads' bench lines + kernel stats
+# End-of-round evidence, regenerated in ONE go from the tree as it is (round-1 verdict item 2):
+# full GPU suite, smoke, the default bench line, rocprofv3 kernel stats of the same command,
+# PMC passes (FETCH_SIZE / WRITE_SIZE, separate, kernel-trace only) on the FINAL kernels of
+# C2..C5, the other workloads' bench lines + kernel stats, Make latency, micro-benchmarks.
+# Raw output: gpurun_out/r02/ ; condensed into profiles/ by tools/r02_summarize.py.
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out; mkdir -p $OUT
-python -m pytest tests -m gpu -q --timeout 1800 2>&1 > $OUT/pytest_gpu_full.log
-grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu_full.log | tail -10
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-2300 $OUT/bench_c2.json
-rocprofv3 --kernel-trace --stats -d $OUT/prof_c2 -o c2 --output-format csv -- python bench.py --no-cpu-baseline > $OUT/prof_c2_bench.json 2> /dev/null
-grep -E "^\"?(gdv_k)" $OUT/prof_c2/c2_kernel_stats.csv | cut -c1-200
-for w in c2 c5; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r02; rm -rf $OUT; mkdir -p $OUT
+cd $R
+python -m pytest tests -m gpu -q --timeout 1800 > $OUT/pytest_gpu_full.log 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu_full.log | tail -5
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.log
+python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-600 $OUT/bench_c2.json
+for w in c1 c3 c4 c5; do python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2>$OUT/bench_$w.err; done
+for w in c3 c4 c5; do python bench.py --workload $w --steps 3 --warmup 1 > $OUT/bench_${w}_cpu.json 2>/dev/null; done
+cd /tmp
+for w in c2 c3 c4 c5; do
+  rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o $w --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline > $OUT/prof_${w}_bench.json 2> /dev/null
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
-for w in c3 c4 c5 c1; do python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2>/dev/null; python -c "import json; d=json.load(open('$OUT/bench_$w.json')); print('$w', d['ms_per_step'], d['value'], d['roofline']['achieved'], d['roofline']['frac'])"; done
-for w in c3 c5; do
-  rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o $w --output-format csv -- python bench.py --workload $w --no-cpu-baseline > $OUT/prof_${w}_bench.json 2> /dev/null
-  grep -E "gdv|Scan|Emit" $OUT/prof_$w/${w}_kernel_stats.csv | cut -c1-160
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_c5_$tag -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
-find $OUT -name "*.csv" -size +2000k -delete   # raw traces are large; the stats/counter files stay
-ls $OUT
+cd $R
+python tools/make_latency.py > $OUT/make_latency.txt 2>&1
+python tools/micro_benchmarks.py > $OUT/micro_benchmarks.txt 2>&1
+python tools/latency_sweep.py > $OUT/latency_sweep.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -size +1000k -delete   # raw traces are large; stats / counters stay
+find $OUT -name "*.csv" -size +8000k -delete
+du -sh $OUT; ls $OUT | head -50
