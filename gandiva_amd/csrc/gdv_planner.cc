@@ -308,6 +308,18 @@ class CodeGen {
     lit_of_node_[node] = e;
     return e;
   }
+  static std::string InlineLiteral(const DataType& t, const Literal& v) {
+    switch (t.id) {
+      case kBool: return v.lo ? "true" : "false";
+      case kFloat: return "__uint_as_float(" + Hex64(v.lo & 0xffffffffull) + ")";
+      case kDouble: return "__longlong_as_double((long long)" + Hex64(v.lo) + ")";
+      case kDecimal128: return "gdv_make_int128(" + Hex64(v.hi) + ", " + Hex64(v.lo) + ")";
+      default: {
+        uint64_t mask = t.byte_width() >= 8 ? ~0ull : ((1ull << (8 * t.byte_width())) - 1);
+        return "((" + t.CType() + ")" + Hex64(v.lo & mask) + ")";
+      }
+    }
+  }
   std::string LiteralExprNew(const DataType& t, const Literal& v) {
     auto slot = [&](uint64_t x) { return "A.lit[" + std::to_string(LitSlot(x)) + "]"; };
     switch (t.id) {
@@ -498,9 +510,25 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       DataType ret;
       if (!ResolveFunction(fn, &def, &ret))
         return Status::CodeGenError("Function " + fn.ToString() + " not supported yet. ");
+      // Integer literals handed to a function over strings (substr positions, left / right
+      // counts, castVARCHAR lengths ...) are part of the query's SHAPE: compiled in, so the
+      // position arithmetic folds (C5: +0.2 ms when they were kernel arguments).  Everything
+      // else — comparison constants, arithmetic operands, IN lists, LIKE needles — is an argument.
+      bool over_strings = false;
+      for (auto& c : fn.children()) over_strings |= c->return_type().is_varlen();
       std::vector<Val> args(fn.children().size());
-      for (size_t i = 0; i < args.size(); i++)
-        GDV_RETURN_NOT_OK(Gen(*fn.children()[i], active, &args[i]));
+      for (size_t i = 0; i < args.size(); i++) {
+        const Node& child = *fn.children()[i];
+        if (over_strings && child.kind() == NodeKind::kLiteral && !child.return_type().is_varlen() &&
+            std::getenv("GDV_NO_INLINE_STRING_ARGS") == nullptr) {
+          auto& l = static_cast<const LiteralNode&>(child);
+          args[i].type = l.return_type();
+          args[i].v = InlineLiteral(l.return_type(), l.value());
+          args[i].vlane = l.is_null() ? "false" : "";
+          continue;
+        }
+        GDV_RETURN_NOT_OK(Gen(child, active, &args[i]));
+      }
       out->type = fn.return_type();
       out->vcols.clear();
       out->vlane.clear();
@@ -851,23 +879,43 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   plan->input_needs_values = cg.needs_values_;
   plan->input_needs_validity = cg.needs_validity_;
   plan->can_raise = cg.can_raise_;
-  for (size_t k = 0; k < plan->input_fields.size(); k++)
-    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
   plan->layout.n_in = static_cast<int>(plan->input_fields.size());
   plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
+  const std::string body = cg.body_.str();
+
+  // WIDE layout (round 2): a lane owns 4 CONSECUTIVE rows of a 256-row group instead of one
+  // row of each 64-row sub-tile, so every column moves with 16-byte-per-lane instructions
+  // whatever its width (int32: one dwordx4 per 4 rows instead of four dword loads of 256 B per
+  // wave).  Element u of a lane is row  rbase + (u / 4) * 256 + 4 * lane + (u % 4).  Validity
+  // stays word-wise (word u = rows 64u .. 64u+63), which is independent of the lane mapping —
+  // so the layout applies to plans whose validity is a pure intersection of input words and
+  // whose values never look at a lane's validity bit: no bool columns, no if/else or 3-valued
+  // logic, nothing that can raise.  Those keep the one-row-per-lane layout.
+  // MEASURED (profiles/r02_wide_layout.txt): no gain for int32 (C1-shape 0.73 either way) and a
+  // large loss for 8- and 16-byte types, whose per-lane runs of 32 / 64 bytes make every wave
+  // instruction touch only half / a quarter of each line.  Off by default; GDV_WIDE=1 enables it
+  // for plans whose columns are all <= 4 bytes wide.
+  bool wide = !sel && plan->kind == KernelKind::kProject && !cg.can_raise_ && plan->opts.subtiles % 4 == 0 &&
+              std::getenv("GDV_WIDE") != nullptr && body.find("gdv_lane_bit") == std::string::npos &&
+              body.find("__ballot") == std::string::npos;
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    wide = wide && t.id != kBool && t.byte_width() <= 4;
+  }
+  for (auto& t : plan->output_types) wide = wide && t.id != kBool && t.byte_width() <= 4;
 
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
   std::ostringstream& s = as.src;
-  const bool sel = cg.selection();
-  const int nin = plan->layout.n_in;
+  if (wide)
+    s << "#define GDV_OUT(e, v) res##e[u] = (v)\n";
+  else
+    s << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
 
-  // PASS is a template parameter so that the byte pass of a var-len projection drops, at
-  // compile time, everything only the fixed-width outputs need (and vice versa)
-  s << "template <bool FULL, int PASS>\n"
-    << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane, gdv_uint8* lds) {\n"
-    << "  gdv_uint8* const lds_out = lds;  // var-len output staging window (GDV_OUT_WIN + 16 bytes)\n"
-    << "  (void)lds_out;\n"
+  s << "template <bool FULL>\n"
+    << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane) {\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
@@ -876,29 +924,19 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "  const gdv_int64 rbase = wbase * 64;\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
-    if (t.is_varlen() && cg.needs_values_[k]) {
-      s << "  const gdv_uint8* __restrict__ sd" << k << " = (const gdv_uint8*)A.in[" << k
-        << "].data;\n"
-        << "  const gdv_int32* __restrict__ so" << k << " = A.in[" << k << "].offsets;\n";
-    } else if (t.id != kBool && cg.needs_values_[k]) {
-      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType()
-        << "*)A.in[" << k << "].data;\n";
-    }
+    if (t.id != kBool && cg.needs_values_[k])
+      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType() << "*)A.in[" << k
+        << "].data;\n";
   }
   for (size_t e = 0; e < plan->output_types.size(); e++) {
     const DataType& t = plan->output_types[e];
-    if (t.is_varlen()) {
-      s << "  gdv_uint8* __restrict__ outd" << e << " = (gdv_uint8*)A.out[" << e << "].data;\n"
-        << "  gdv_int32* __restrict__ outo" << e << " = A.out[" << e << "].offsets;\n";
-    } else if (t.id != kBool) {
-      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out["
-        << e << "].data;\n";
-    }
+    if (t.id != kBool)
+      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
+    if (wide) s << "  " << t.CType() << " res" << e << "[GDV_U];\n";
   }
-  if (plan->has_varlen_output) s << "  constexpr int pass = PASS;  // 0 lengths, 1 bytes\n";
   if (sel)
-    s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const "
-      << SelCType(cg.sel_mode_) << "*)A.sel;\n";
+    s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const " << SelCType(cg.sel_mode_)
+      << "*)A.sel;\n";
 
   // ---- phase 1: every load of the tile, no control flow in between
   s << "  // ---- phase 1: all loads of this wave's GDV_U sub-tiles, issued back to back\n";
@@ -908,78 +946,53 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     if (t.id == kBool) {
       if (cg.needs_values_[k]) {
         if (sel) s << "  bool x" << k << "[GDV_U];\n";
-        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k
-               << "].bits, wbase, lane, GDV_U);\n";
+        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
       }
-    } else if (t.is_varlen()) {
-      if (cg.needs_values_[k]) s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
     if (cg.needs_validity_[k]) {
       if (sel) s << "  bool b" << k << "[GDV_U];\n";
-      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k
-             << "].valid, wbase, lane, GDV_U);\n";
+      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
   }
-  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
-    << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
-    << "    const bool live = FULL || row < n;\n"
-    << "    (void)live;\n";
-  if (sel) {
-    s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
+  const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
+  if (wide) {
+    s << "  if (FULL) {\n#pragma unroll\n    for (int g = 0; g < GDV_U / 4; g++) {\n"
+      << "      const gdv_int64 row0 = rbase + g * 256 + 4 * lane;\n";
+    for (int k = 0; k < nin; k++)
+      if (cg.needs_values_[k]) s << "      gdv_ld4<" << (plan->opts.nt_loads ? "true" : "false") << ">(in" << k << " + row0, &c" << k << "[4 * g]);\n";
+    s << "    }\n  } else {\n#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
+      << "      const gdv_int64 row = rbase + (u >> 2) * 256 + 4 * lane + (u & 3);\n";
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
-      if (t.id == kBool) {
-        if (cg.needs_values_[k])
-          s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
-      } else if (t.is_varlen()) {
-        if (cg.needs_values_[k])
-          s << "    oa" << k << "[u] = so" << k << "[srow[u]]; ob" << k << "[u] = so" << k
-            << "[srow[u] + 1];\n";
-      } else if (cg.needs_values_[k]) {
-        s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
-      }
-      if (cg.needs_validity_[k])
-        s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+      if (cg.needs_values_[k]) s << "      c" << k << "[u] = row < n ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0;\n";
     }
+    s << "    }\n  }\n";
   } else {
-    for (int k = 0; k < nin; k++) {
-      const DataType& t = cg.schema_[plan->input_fields[k]].type;
-      if (t.is_varlen()) {
-        if (cg.needs_values_[k])
-          s << "    oa" << k << "[u] = live ? so" << k << "[row] : 0; ob" << k << "[u] = live ? so"
-            << k << "[row + 1] : 0;\n";
-      } else if (t.id != kBool && cg.needs_values_[k]) {
-        s << "    c" << k << "[u] = live ? " << (plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld") << "(in" << k
-          << ", row) : (" << t.CType() << ")0;\n";
+    s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+      << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "    const bool live = FULL || row < n;\n"
+      << "    (void)live;\n";
+    if (sel) {
+      s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
+      for (int k = 0; k < nin; k++) {
+        const DataType& t = cg.schema_[plan->input_fields[k]].type;
+        if (t.id == kBool) {
+          if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+        } else if (cg.needs_values_[k]) {
+          s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+        }
+        if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+      }
+    } else {
+      for (int k = 0; k < nin; k++) {
+        const DataType& t = cg.schema_[plan->input_fields[k]].type;
+        if (t.id != kBool && cg.needs_values_[k])
+          s << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
       }
     }
-  }
-  s << "  }\n";
-  // phase 1b: the first GDV_NPRE 8-byte words of every input string of every sub-tile, all
-  // issued together once the offsets are known (reads past a short string stay inside the
-  // buffer limit and are ignored)
-  for (int k = 0; k < nin; k++) {
-    const DataType& t = cg.schema_[plan->input_fields[k]].type;
-    if (t.is_varlen() && cg.needs_values_[k]) {
-      s << "  gdv_uint64 sw" << k << "[GDV_U][GDV_NPRE];\n"
-        << "  const gdv_uint8* slim" << k << " = sd" << k << " + A.in[" << k << "].bits.nwords;\n"
-        // lanes whose string ends before word j sit the load out: scattered 8-byte loads
-        // are priced per active lane in the texture addresser, not per instruction.  A full
-        // tile in row order ends at its last row's end offset: one wave-uniform compare
-        // proves every prefetch load in range and the per-lane limit checks go away.
-        << "  if (" << (sel ? "false" : "FULL") << " && sd" << k << " + __builtin_amdgcn_readlane(ob" << k
-        << "[GDV_U - 1], 63) + 8 * GDV_NPRE <= slim" << k << ") {\n"
-        << "#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
-        << "#pragma unroll\n      for (int j = 0; j < GDV_NPRE; j++) sw" << k << "[u][j] = (8 * j < ob"
-        << k << "[u] - oa" << k << "[u]) ? gdv_load8_raw(sd" << k << " + oa" << k << "[u] + 8 * j) : 0ull;\n"
-        << "    }\n  } else {\n"
-        << "#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
-        << "#pragma unroll\n      for (int j = 0; j < GDV_NPRE; j++) sw" << k << "[u][j] = (8 * j < ob"
-        << k << "[u] - oa" << k << "[u]) ? gdv_load8(sd" << k << " + oa" << k << "[u] + 8 * j, slim"
-        << k << ") : 0ull;\n    }\n  }\n";
-    }
+    s << "  }\n";
   }
 
   // ---- phase 2: row body
@@ -987,63 +1000,62 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
   s << decls_before_loop;
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
-    << "    {\n"
-    << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
-    << "      const bool live = FULL || row < n;\n"
-    << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
-    << "      (void)livemask; (void)row;\n";
-  for (int k = 0; k < nin; k++) {
-    const DataType& t = cg.schema_[plan->input_fields[k]].type;
-    if (t.is_varlen() && cg.needs_values_[k])
-      s << "      const gdv_str s" << k << " = gdv_make_str_cached(sd" << k << ", oa" << k << "[u], ob"
-        << k << "[u], slim" << k << ", sw" << k << "[u]);\n";
+    << "    {\n";
+  if (wide) {
+    s << "      const gdv_int64 row = rbase + (u >> 2) * 256 + 4 * lane + (u & 3);   // this lane's element u\n"
+      << "      const bool live = FULL || row < n;\n"
+      << "      const gdv_uint64 livemask = FULL ? ~0ull : gdv_live_word(rbase + 64 * u, n);  // validity WORD u\n";
+  } else {
+    s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "      const bool live = FULL || row < n;\n"
+      << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n";
   }
+  s << "      (void)livemask; (void)row; (void)live;\n";
   if (!sel) {
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.id == kBool && cg.needs_values_[k])
         s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
-      if (cg.needs_validity_[k])
-        s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
     }
   }
-  s << cg.body_.str();
+  s << body;
   s << "    }\n  }\n";
+  if (wide) {
+    s << "  // ---- stores: 4 consecutive rows per lane and instruction\n"
+      << "#pragma unroll\n  for (int g = 0; g < GDV_U / 4; g++) {\n"
+      << "    const gdv_int64 row0 = rbase + g * 256 + 4 * lane;\n";
+    for (size_t e = 0; e < plan->output_types.size(); e++) {
+      s << "    if (FULL || row0 + 4 <= n) gdv_st4<" << (plan->opts.nontemporal ? "true" : "false") << ">(out" << e
+        << " + row0, &res" << e << "[4 * g]);\n"
+        << "    else {\n#pragma unroll\n      for (int i = 0; i < 4; i++) if (row0 + i < n) out" << e << "[row0 + i] = res" << e
+        << "[4 * g + i];\n    }\n";
+    }
+    s << "  }\n";
+  }
   s << epilogue_after_loop;
   s << "}\n\n";
   // ---- kernel: grid-stride over workgroup tiles; wave w of a workgroup owns GDV_U
   // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
   // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
   // each bitmap.
-  s << "template <int PASS>\n"
-    << "GDV_DEV void gdv_run(const gdv_args& A, const int lane, const int wave, gdv_uint8* lds) {\n"
+  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
     << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
     << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
     << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nfull;\n"
     << "       wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
-    << "    gdv_tile<true, PASS>(A, wt * GDV_U, lane, lds);\n"
+    << "    gdv_tile<true>(A, wt * GDV_U, lane);\n"
     // The single partial wave tile is handled after the loop, not in an if/else next to
     // the full-tile body: side by side, the compiler hoists the two bodies' common bitmap
     // loads above the branch and serialises them in front of the value loads.
     << "  if (nwt > nfull && wave == (int)(nfull % GDV_WAVES) &&\n"
     << "      blockIdx.x == (unsigned)((nfull / GDV_WAVES) % gridDim.x))\n"
-    << "    gdv_tile<false, PASS>(A, nfull * GDV_U, lane, lds);\n"
-    << "}\n\n";
-  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) " << "GDV_KERNEL_NAME"
-    << "(const gdv_args A) {\n"
-    << "  const int lane = threadIdx.x & 63;\n"
-    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
-  if (plan->has_varlen_output) {
-    // wave-private LDS: the staging window of the var-len byte pass
-    s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds[GDV_WAVES][GDV_OUT_WIN + 16];\n"
-      << "  if (A.aux0 == 0) gdv_run<0>(A, lane, wave, gdv_lds[wave]);\n"
-      << "  else gdv_run<1>(A, lane, wave, gdv_lds[wave]);\n";
-  } else {
-    s << "  gdv_run<0>(A, lane, wave, nullptr);\n";
-  }
-  s << "}\n";
+    << "    gdv_tile<false>(A, nfull * GDV_U, lane);\n"
+    << "}\n";
 
   std::string text = s.str();
   uint64_t h = Fnv1a(HashableSource(text));
@@ -1096,7 +1108,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   s << "#define GDV_NV " << nv << "\n#define GDV_NG " << ng << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
     << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
-    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n";
+    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
+    << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
 
   s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
     << "                      const int wave, gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint32 (*lds_tot)[GDV_NV > 0 ? GDV_NV : 1],\n"
@@ -1510,7 +1523,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
       after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)");
     } else {
-      cg.Stmt("if (live) " + st + "(out" + E + ", row, (" + t.CType() + ")" + v.v + ");");
+      cg.Stmt("GDV_OUT(" + E + ", (" + t.CType() + ")" + v.v + ");");
     }
     // validity word of the 64 rows of this sub-tile
     std::string word;
@@ -1530,8 +1543,10 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   for (size_t k = 0; k < cg.input_fields_.size(); k++)
     string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
   if (string_plan) {
-    // workgroup tile = 4 waves x 4 sub-tiles x 64 rows (profiles/r02_k4_singlepass_proto.txt)
-    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = 4;
+    // workgroup tile = 4 waves x 8 sub-tiles x 64 rows: the row loop is rolled, so more sub-tiles
+    // cost no code, and fewer, larger tiles mean fewer scanner hand-offs (U4 2.01 ms, U8 1.93 ms,
+    // U2 2.40 ms on the same box; LDS staging windows and match bitmaps scale with U)
+    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = plan->has_varlen_output ? 8 : 4;
     if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
     return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
   }

@@ -1,6 +1,9 @@
 export GDV_NO_DISK_CACHE=1
-for w in "" 4 5 6 7 8; do
-  if [ -z "$w" ]; then opt=""; else opt="-DGDV_STRING_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu($w,8)))"; fi
-  echo "--- waves_per_eu=$w"
-  GDV_RTC_OPT="$opt" GDV_TRACE=1 python bench.py --workload c5 --no-cpu-baseline --steps 6 --warmup 2 2>&1 | grep "^\[gdv\]" | tail -2 | cut -c1-90
-done
+run() { echo "--- $1"; env $2 GDV_TRACE=1 python bench.py --workload c5 --no-cpu-baseline --steps 6 --warmup 2 2>&1 | grep -E "^\[gdv\]|rror" | tail -1 | cut -c1-100; }
+run "U4 W4 (default)" "X=1"
+run "U2 W8" "GDV_U=2 GDV_WAVES=8"
+run "U4 W8" "GDV_U=4 GDV_WAVES=8"
+run "U2 W4" "GDV_U=2 GDV_WAVES=4"
+run "U8 W4" "GDV_U=8 GDV_WAVES=4"
+run "U4 W2" "GDV_U=4 GDV_WAVES=2"
+run "U4 W4 again" "X=1"
