@@ -29,6 +29,23 @@
  * integer arithmetic, plain Python str / re, sklearn's and a pure-Python MurmurHash3 — per
  * function (tests/test_oracle_crosscheck.py, test_decimal.py, test_strings.py) and over random
  * expression trees (tests/test_oracle_vs_arrow_trees.py, test_oracle_vs_python_strings.py).
+ * Status per family after round 2 (still "parity unpinned": agreement of independent engines
+ * is not knowledge of the reference's rule):
+ *   DOUBLE-CHECKED by >= 2 independent engines
+ *     decimal128 add / subtract / multiply / divide incl. result-scale reduction, round half
+ *       away from zero, overflow -> 0: Python decimal + exact integers (test_decimal.py) AND
+ *       Arrow's own BasicDecimal256 primitives in C++ (tests/cxx_pins, test_arrow_pins.py);
+ *     extractYear / Month / Day / Doy / Dow, timestampaddMonth: pyarrow.compute / datetime AND
+ *       the vendored Hinnant date.h (tests/cxx_pins);
+ *     arithmetic, compares, Kleene AND/OR, casts between numeric types, temporal extraction:
+ *       pyarrow.compute over random trees; strings: Python str / bytes / re; MurmurHash3:
+ *       sklearn + a pure-Python implementation.
+ *   PURE RECOLLECTION (one opinion, mine): round(float64) = C round() (the reference may round
+ *       via trunc(x +- 0.5), which differs at 0.49999999999999994); LIKE '_' and '%' match a
+ *       newline; float -> integer casts saturate and send NaN to 0; divide / mod by zero raise
+ *       "divide by zero error"; integer mod by zero returns the dividend; the decimal
+ *       result-type rule (precision > 38 -> scale cut to max(s - delta, min(s, 6))); castINT /
+ *       castBIGINT from text accept only [blank]* '-'? digit+ [blank]*; hash of null = seed.
  *
  * Program format (whitespace separated, prefix order):
  *   F <col>                               field: column index
