@@ -1562,6 +1562,22 @@ GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, 
   }
   return m;
 }
+// One 16-byte piece of the byte sweep, written to a FLAT output as it is read (optimistic flat
+// mode: the output's bytes are the input's, so its offsets are the input's minus the first one
+// and need no scan).  Bytes [lo, hi) of the piece lie inside this wave's span; only those are
+// stored (neighbouring tiles write their own), and nothing at or past `cap`.
+GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
+                             gdv_int32 lo, gdv_int32 hi, gdv_int64 cap) {
+  const gdv_uint64 m0 = gdv_map8(w[0], map), m1 = gdv_map8(w[1], map);
+  if (lo <= 0 && hi >= 16 && doff + 16 <= cap) {
+    gdv_uint64 q[2] = {m0, m1};
+    __builtin_memcpy(dst + doff, q, 16);
+  } else {
+    const gdv_int32 k0 = lo > 0 ? lo : 0, k1 = hi < 16 ? hi : 16;
+    for (gdv_int32 k = k0; k < k1; k++)
+      if (doff + k < cap) dst[doff + k] = (gdv_uint8)((k < 8 ? m0 : m1) >> (8 * (k & 7)));
+  }
+}
 // any bit set in [lo, hi) of the bitmap (hi <= lo: empty range)
 GDV_DEV bool gdv_range_any(const gdv_uint64* bm, gdv_int32 lo, gdv_int32 hi) {
   if (hi <= lo) return false;
@@ -1599,6 +1615,7 @@ typedef __attribute__((address_space(1))) unsigned long long gdv_gu64;
 #define GDV_LB_POSTED (1ull << 62)
 #define GDV_LB_M31 0x7fffffffull
 #define GDV_ERR_STALL 8u
+#define GDV_ERR_NOTFLAT 16u  // an optimistic flat output met a null row that carries bytes: host re-runs
 GDV_DEV void gdv_lb_store(gdv_uint64* p, gdv_uint64 v) {
   __hip_atomic_store((gdv_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -597,8 +597,21 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
       return Status::OK();
     };
+    // Outputs that are an input column's (mapped) bytes — a column passed through, upper(col),
+    // lower(col) — are first evaluated OPTIMISTICALLY: bytes copied by the byte sweep as they
+    // are read, offsets = input offsets rebased, no scan.  That holds unless a NULL row carries
+    // bytes (Arrow allows it, producers rarely do it); the kernel then raises NOTFLAT and the
+    // batch is re-run with those outputs on the general path.
+    bool optimistic = plan_.has_flat_output && std::getenv("GDV_NO_OPTFLAT") == nullptr;
     auto launch = [&]() -> Status {
+      args.Set64(ArgLayout::kOffAux1, optimistic ? 1 : 0);
       GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
+      if (optimistic && (err_bits & 16u)) {
+        optimistic = false;
+        args.Set64(ArgLayout::kOffAux1, 0);
+        GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
+      }
+      err_bits &= ~16u;
       if (err_bits & 8u) {
         // The scan made no progress for a very long time: some workgroup of the grid was not
         // scheduled while later ones waited for it.  Never observed (workgroups start in index

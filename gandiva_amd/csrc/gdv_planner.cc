@@ -1099,6 +1099,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
   const int nhook = static_cast<int>(cg.contains_hooks_.size());
   plan->num_varlen_outputs = nv;
+  for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
 
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
@@ -1121,7 +1122,9 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "  (void)gdv_cst;\n"
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
-    << "  const gdv_int64 rbase = wbase * 64;\n";
+    << "  const gdv_int64 rbase = wbase * 64;\n"
+    << "  const bool optflat = (A.aux1 & 1) != 0;  // flat outputs copy in the sweep, offsets = input offsets\n"
+    << "  (void)optflat;\n";
   if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
@@ -1209,6 +1212,9 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     for (int h = 0; h < nhook; h++)
       if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
     const bool want_ascii = cg.ascii_slots_.count(k) != 0;
+    std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
+    for (auto& vo : cg.varlen_outs_)
+      if (vo.flat_slot == k) flats.push_back(&vo);
     const std::string K = std::to_string(k);
     if (sel) {
       s << "  const gdv_int32 sfl" << K << " = 0;\n";
@@ -1217,7 +1223,9 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     // one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
     s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
       << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
-    if (hooks.empty() && !want_ascii) {
+    if (!flats.empty())
+      s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
+    if (hooks.empty() && !want_ascii && flats.empty()) {
       s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
       continue;
     }
@@ -1262,6 +1270,13 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       }
     }
     s << "  }\n";
+    // optimistic flat outputs: their place in the output is known from the input offsets alone, so
+    // the span is copied right here, while the sweep's lines are still in L2 / L1 — no scanner
+    // hand-off, no second trip to HBM
+    for (auto* vo : flats)
+      s << "  if (optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
+        << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
+        << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
     if (want_ascii)
       s << "  const gdv_int32 sfl" << K << " = inb" << K << " | (__ballot((sacc" << K
         << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
@@ -1333,6 +1348,9 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   for (auto& vo : cg.varlen_outs_) s << "    gdv_rot(lc" << vo.e << ");\n";
   s << "  }\n";
   if (nv > 0) s << "  if (pass == 1) break;\n";
+  for (auto& vo : cg.varlen_outs_)
+    if (vo.flat_slot >= 0)
+      s << "  if (optflat && fb" << vo.e << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n";
   s << epilogue_after_loop;
 
   // ---- var-len outputs
@@ -1360,7 +1378,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     for (int v = 0; v < nv; v++) {
       const VarlenOut& vo = cg.varlen_outs_[v];
       const std::string E = std::to_string(vo.e);
-      s << "  {\n"
+      s << (vo.flat_slot >= 0 ? "  if (!optflat) {\n" : "  {\n")
         << "    const gdv_int64 base = (gdv_int64)((lds_base[" << v / 2 << "] >> " << 31 * (v % 2)
         << ") & GDV_LB_M31) + (gdv_int64)before[" << v << "];\n"
         << "    const bool fits = run" << E << " < 0x7fffffff && base + run" << E << " <= A.out[" << E << "].cap;\n"
@@ -1407,9 +1425,14 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       << "      gdv_uint64* const totals = (gdv_uint64*)A.counts;\n"
       << "      gdv_scanner<GDV_NG>(A.mask, A.mask + (gdv_int64)GDV_NG * ntiles, ntiles, totals, A.err, lane);\n"
       << "      if (lane == 0) {\n";
-    for (int v = 0; v < nv; v++)
-      s << "        A.out[" << cg.varlen_outs_[v].e << "].offsets[A.n] = (gdv_int32)(totals[" << v
+    for (int v = 0; v < nv; v++) {
+      const VarlenOut& vo = cg.varlen_outs_[v];
+      if (vo.flat_slot >= 0)
+        s << "        if ((A.aux1 & 1) != 0) { const gdv_int32* so = A.in[" << vo.flat_slot << "].offsets; totals[" << v
+          << "] = (gdv_uint64)(so[A.n] - so[0]); }\n";
+      s << "        A.out[" << vo.e << "].offsets[A.n] = (gdv_int32)(totals[" << v
         << "] > GDV_LB_M31 ? GDV_LB_M31 : totals[" << v << "]);\n";
+    }
     s << "      }\n    }\n    return;\n  }\n"
       << "  for (gdv_int64 tile = (gdv_int64)blockIdx.x - 1; tile < ntiles; tile += (gdv_int64)gridDim.x - 1)\n";
   } else {
@@ -1482,7 +1505,15 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
                   << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n"
                   << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM at dbase" << E << "\n"
                   << "  gdv_int64 dbase" << E << " = 0;\n";
-      cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+      if (flat_cand) {
+        // optimistic flat mode: the bytes were written by the sweep and the offsets are the
+        // input's (rebased): nothing of this output goes through the scanner
+        const std::string K = std::to_string(v.col_slot);
+        cg.Stmt("const gdv_int32 ln" + E + "_u = optflat ? 0 : (" + total + ");");
+        cg.Stmt("if (optflat && live && pass == 0) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
+      } else {
+        cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+      }
       cg.Stmt("if (pass == 0) {");
       cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
       cg.Stmt("  lc" + E + "[0] = run" + E + " + inc - ln" + E + "_u;");

@@ -73,6 +73,7 @@ struct KernelPlan {
   bool has_varlen_input = false;   // some expression reads utf8/binary bytes
   bool string_skeleton = false;    // tile = workgroup (waves x subtiles x 64 rows), no grid-stride
   int num_varlen_outputs = 0;
+  bool has_flat_output = false;    // some var-len output is an input column's (mapped) bytes
   int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
 };
 
