@@ -538,3 +538,38 @@ def test_hip_text_to_integer_casts_match_oracle():
     bad = pa.RecordBatch.from_arrays([pa.array(["12", "x1"], pa.string())], names=["s"])
     with pytest.raises(Exception, match="invalid argument"):
         gandiva.make_projector(bad.schema, exprs, None).evaluate(bad)
+
+
+@pytest.mark.gpu
+def test_flat_outputs_fall_back_when_null_rows_carry_bytes():
+    """`upper(s)` / pass-through outputs are evaluated optimistically flat (offsets = input offsets,
+    bytes = mapped input span).  Arrow allows a NULL row to own bytes; then the flat copy would
+    emit them: the kernel must notice (NOTFLAT) and the batch is re-run on the general path."""
+    from helpers import assert_bit_exact
+    rng = np.random.default_rng(31)
+    n = 3000
+    lens = rng.integers(0, 12, n)
+    offsets = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=offsets[1:])
+    data = rng.integers(97, 123, int(offsets[-1])).astype(np.uint8)
+    nulls = rng.random(n) < 0.2                       # null rows KEEP their bytes
+    arr = pa.Array.from_buffers(pa.string(), n, [pa.py_buffer(np.packbits(~nulls, bitorder="little")),
+                                                 pa.py_buffer(offsets), pa.py_buffer(data)])
+    assert any(nulls[i] and lens[i] > 0 for i in range(n))
+    batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    exprs = [b.make_expression(b.make_function("upper", [s], pa.string()), pa.field("up", pa.string())),
+             b.make_expression(s, pa.field("same", pa.string())),
+             b.make_expression(b.make_function("substr", [s, b.make_literal(2, pa.int64()), b.make_literal(3, pa.int64())],
+                                               pa.string()), pa.field("sub", pa.string()))]
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    for bt in (batch, batch.slice(1024, 1500)):
+        got = proj.evaluate(bt)
+        for g, w in zip(got, oracle.project(exprs, bt)):
+            g.validate(full=True)
+            assert_bit_exact(g, w)
+    # and the common case right after it on the same projector: no nulls with bytes -> flat
+    clean = pa.RecordBatch.from_arrays([pa.array([None if m else "abcXYZ"[:int(k)] for m, k in zip(nulls, lens % 7)])], names=["s"])
+    for g, w in zip(proj.evaluate(clean), oracle.project(exprs, clean)):
+        assert_bit_exact(g, w)
