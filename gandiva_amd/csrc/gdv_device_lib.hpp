@@ -1614,6 +1614,9 @@ GDV_DEV gdv_uint64 gdv_next_lane(gdv_uint64 v) {
 typedef __attribute__((address_space(1))) unsigned long long gdv_gu64;
 #define GDV_LB_POSTED (1ull << 62)
 #define GDV_LB_M31 0x7fffffffull
+#ifndef GDV_LB_WSLEEP
+#define GDV_LB_WSLEEP 4  // worker poll pace, in units of 64 clocks (sweep: profiles/r02_c5_poll_pace.txt)
+#endif
 #define GDV_ERR_STALL 8u
 #define GDV_ERR_NOTFLAT 16u  // an optimistic flat output met a null row that carries bytes: host re-runs
 GDV_DEV void gdv_lb_store(gdv_uint64* p, gdv_uint64 v) {
@@ -1715,7 +1718,7 @@ GDV_DEV gdv_uint64 gdv_lb_wait(const gdv_uint64* pre, gdv_int64 ntiles, gdv_int6
   for (gdv_uint32 spins = 0;; spins++) {
     const gdv_uint64 v = gdv_lb_load(p);
     if ((v >> 62) == 1) return v;
-    __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_s_sleep(GDV_LB_WSLEEP);
     if (spins > (1u << 24)) {
       atomicOr(err, GDV_ERR_STALL);
       return 0;
