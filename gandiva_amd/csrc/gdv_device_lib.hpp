@@ -1578,18 +1578,29 @@ GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const 
       if (doff + k < cap) dst[doff + k] = (gdv_uint8)((k < 8 ? m0 : m1) >> (8 * (k & 7)));
   }
 }
-// any bit set in [lo, hi) of the bitmap (hi <= lo: empty range)
+// any bit set in [lo, hi) of the bitmap (hi <= lo: empty range).  Branch-free for ranges of up
+// to 64 positions (rows up to 64 + needle bytes long): two adjacent words, one funnel shift, one
+// mask — the round-2 ablation (tools/c5_ablation.sh) priced the branchy word walk at 142 VALU
+// per 64 rows, a third of the kernel.  The bitmap is readable one word past any position.
 GDV_DEV bool gdv_range_any(const gdv_uint64* bm, gdv_int32 lo, gdv_int32 hi) {
-  if (hi <= lo) return false;
-  gdv_int32 w = lo >> 6;
-  const gdv_int32 wend = (hi - 1) >> 6;
-  const gdv_uint64 tailmask = ~0ull >> (63 - ((hi - 1) & 63));
-  const gdv_uint64 first = bm[w] & (~0ull << (lo & 63));
-  if (w == wend) return (first & tailmask) != 0;
-  if (first) return true;
-  for (++w; w < wend; ++w)
-    if (bm[w]) return true;
-  return (bm[wend] & tailmask) != 0;
+  const gdv_int32 nbits = hi - lo;
+  const gdv_int32 w = lo >> 6, s = lo & 63;
+  const gdv_uint64 x = (bm[w] >> s) | ((bm[w + 1] << 1) << (63 - s));  // positions lo .. lo+63
+  const gdv_uint64 m = nbits >= 64 ? ~0ull : ((1ull << (nbits > 0 ? nbits : 0)) - 1ull);
+  bool any = nbits > 0 && (x & m) != 0;
+  if (nbits > 64 && !any) {  // long rows: walk the remaining words
+    gdv_int32 p = lo + 64;
+    for (; p + 64 <= hi && !any; p += 64) {
+      const gdv_int32 pw = p >> 6, ps = p & 63;
+      any = ((bm[pw] >> ps) | ((bm[pw + 1] << 1) << (63 - ps))) != 0;
+    }
+    if (!any && p < hi) {
+      const gdv_int32 pw = p >> 6, ps = p & 63;
+      const gdv_uint64 y = (bm[pw] >> ps) | ((bm[pw + 1] << 1) << (63 - ps));
+      any = (y & ((1ull << (hi - p)) - 1ull)) != 0;
+    }
+  }
+  return any;
 }
 
 #ifndef GDV_HOST_BUILD

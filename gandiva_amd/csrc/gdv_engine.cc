@@ -587,11 +587,12 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     for (int e = 0; e < num_outs; e++)
       if (plan_.output_types[e].is_varlen()) vl.push_back(e);
     std::vector<uint64_t> seg(2 * ng, 0);
+    const CompiledKernel* active = kernel_;
     auto run = [&](int64_t grid) -> Status {
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(tile_starts.get(), 0, static_cast<size_t>(2 * ng * ntiles) * 8, stream));
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(tile_counts.get(), 0, static_cast<size_t>(2 * ng) * 8, stream));
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
-      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_RETURN_NOT_OK(rt.Launch(*active, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(seg.data(), tile_counts.get(), 8 * 2 * ng, hipMemcpyDeviceToHost, stream));
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
       GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
@@ -603,12 +604,22 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     // bytes (Arrow allows it, producers rarely do it); the kernel then raises NOTFLAT and the
     // batch is re-run with those outputs on the general path.
     bool optimistic = plan_.has_flat_output && std::getenv("GDV_NO_OPTFLAT") == nullptr;
+    auto general_kernel = [&]() -> Status {
+      if (kernel_general_.load() == nullptr) {
+        const CompiledKernel* k = nullptr;
+        GDV_RETURN_NOT_OK(rt.GetKernel(plan_.source_general, plan_.kernel_name_general, &k));
+        kernel_general_.store(k);
+      }
+      return Status::OK();
+    };
     auto launch = [&]() -> Status {
-      args.Set64(ArgLayout::kOffAux1, optimistic ? 1 : 0);
+      if (plan_.has_flat_output && !optimistic) GDV_RETURN_NOT_OK(general_kernel());
+      active = (plan_.has_flat_output && !optimistic) ? kernel_general_.load() : kernel_;
       GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
       if (optimistic && (err_bits & 16u)) {
         optimistic = false;
-        args.Set64(ArgLayout::kOffAux1, 0);
+        GDV_RETURN_NOT_OK(general_kernel());
+        active = kernel_general_.load();
         GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
       }
       err_bits &= ~16u;

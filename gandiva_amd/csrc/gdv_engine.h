@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
@@ -82,6 +83,7 @@ class Projector {
   Schema schema_;
   KernelPlan plan_;
   const CompiledKernel* kernel_ = nullptr;
+  mutable std::atomic<const CompiledKernel*> kernel_general_{nullptr};  // without the optimistic flat path (lazy)
   DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
 };
 

@@ -614,7 +614,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
             // long for the bitmap (wave-uniform) take the per-row search.
             const int h = HookFor(args[0].col_slot, args[0].col_map, lit);
             const std::string k = std::to_string(args[0].col_slot);
-            out->v = Tmp("bool", "(hm_ok" + k + " ? gdv_range_any(hit" + std::to_string(h) + ", oa" + k +
+            out->v = Tmp("bool", "((GDV_ABL & 2) ? (ob" + k + "[u] - oa" + k + "[u] > 19) : hm_ok" + k + " ? gdv_range_any(hit" + std::to_string(h) + ", oa" + k +
                                      "[u] - sb" + k + ", ob" + k + "[u] - sb" + k + " - " +
                                      std::to_string(lit.size() - 1) + ") : " + per_row + ")");
             return Status::OK();
@@ -1110,6 +1110,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
     << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
+    << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
+    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
     << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
 
   s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
@@ -1123,7 +1125,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "  const gdv_int64 n = A.n;\n"
     << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
     << "  const gdv_int64 rbase = wbase * 64;\n"
-    << "  const bool optflat = (A.aux1 & 1) != 0;  // flat outputs copy in the sweep, offsets = input offsets\n"
+    << "  constexpr bool optflat = GDV_OPTFLAT != 0;  // flat outputs: offsets = input offsets, bytes copied after the sweep\n"
     << "  (void)optflat;\n";
   if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
   for (int k = 0; k < nin; k++) {
@@ -1261,7 +1263,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
           << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
           << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
           << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-          << "      const gdv_uint32 m = gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+          << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
           << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
           << ") << 8);\n"
           << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
@@ -1274,7 +1276,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     // the span is copied right here, while the sweep's lines are still in L2 / L1 — no scanner
     // hand-off, no second trip to HBM
     for (auto* vo : flats)
-      s << "  if (optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
+      s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
         << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
         << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
     if (want_ascii)
@@ -1395,7 +1397,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
           << "      } else {\n";
       } else if (vo.window >= 0) {
         s << "      if (run" << E << " <= GDV_OUT_WIN) {\n"
-          << "        gdv_flush_out(outd" << E << " + base, win" << E << ", run" << E << ", lane);\n"
+          << "        if (!(GDV_ABL & 16)) gdv_flush_out(outd" << E << " + base, win" << E << ", run" << E << ", lane);\n"
           << "      } else {\n";
       } else {
         s << "      {\n";
@@ -1428,7 +1430,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     for (int v = 0; v < nv; v++) {
       const VarlenOut& vo = cg.varlen_outs_[v];
       if (vo.flat_slot >= 0)
-        s << "        if ((A.aux1 & 1) != 0) { const gdv_int32* so = A.in[" << vo.flat_slot << "].offsets; totals[" << v
+        s << "        if (GDV_OPTFLAT) { const gdv_int32* so = A.in[" << vo.flat_slot << "].offsets; totals[" << v
           << "] = (gdv_uint64)(so[A.n] - so[0]); }\n";
       s << "        A.out[" << vo.e << "].offsets[A.n] = (gdv_int32)(totals[" << v
         << "] > GDV_LB_M31 ? GDV_LB_M31 : totals[" << v << "]);\n";
@@ -1441,15 +1443,25 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   s << "    gdv_tile(A, tile, ntiles, lane, wave, gdv_lds_out[wave], gdv_lds_hit[wave], gdv_lds_tot, gdv_lds_base);\n"
     << "}\n";
 
-  std::string text = s.str();
-  uint64_t h = Fnv1a(HashableSource(text));
-  char name[64];
-  snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
-  plan->kernel_name = name;
-  size_t pos = text.find("GDV_KERNEL_NAME");
-  text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
-  plan->source = text;
-  plan->ir = text;
+  // Two variants of the same text: GDV_OPTFLAT = 1 (flat outputs taken optimistically; the one
+  // that runs) and, for plans that have flat outputs, GDV_OPTFLAT = 0 (every output through the
+  // scan; compiled only if a batch ever raises NOTFLAT).
+  auto finish = [&](const std::string& tmpl, const char* optflat, std::string* name_out, std::string* src_out) {
+    std::string text = tmpl;
+    size_t p0 = text.find("GDV_OPTFLAT_VALUE");
+    text.replace(p0, strlen("GDV_OPTFLAT_VALUE"), optflat);
+    uint64_t h = Fnv1a(HashableSource(text));
+    char name[64];
+    snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+    size_t pos = text.find("GDV_KERNEL_NAME");
+    text.replace(pos, strlen("GDV_KERNEL_NAME"), name);
+    *name_out = name;
+    *src_out = text;
+  };
+  const std::string tmpl = s.str();
+  finish(tmpl, plan->has_flat_output ? "1" : "0", &plan->kernel_name, &plan->source);
+  if (plan->has_flat_output) finish(tmpl, "0", &plan->kernel_name_general, &plan->source_general);
+  plan->ir = plan->source;
   return Status::OK();
 }
 
@@ -1506,14 +1518,20 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
                   << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM at dbase" << E << "\n"
                   << "  gdv_int64 dbase" << E << " = 0;\n";
       if (flat_cand) {
-        // optimistic flat mode: the bytes were written by the sweep and the offsets are the
-        // input's (rebased): nothing of this output goes through the scanner
+        vo.flat_slot = v.col_slot;
+        vo.flat_map = v.col_map;
         const std::string K = std::to_string(v.col_slot);
-        cg.Stmt("const gdv_int32 ln" + E + "_u = optflat ? 0 : (" + total + ");");
-        cg.Stmt("if (optflat && live && pass == 0) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
-      } else {
-        cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+        before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
+        // optimistic flat variant of the kernel (compile-time): the bytes are copied after the
+        // sweep and the offsets are the input's, rebased: nothing of this output is scanned
+        cg.Stmt("if (optflat) {");
+        cg.Stmt("  if (pass == 0) {");
+        cg.Stmt("    if (live) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
+        cg.Stmt("    fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+        cg.Stmt("  }");
+        cg.Stmt("} else {");
       }
+      cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
       cg.Stmt("if (pass == 0) {");
       cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
       cg.Stmt("  lc" + E + "[0] = run" + E + " + inc - ln" + E + "_u;");
@@ -1523,10 +1541,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
               "_u) : (gdv_uint32)gdv_wave_last(inc);");
       cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t));");
       if (flat_cand) {
-        vo.flat_slot = v.col_slot;
-        vo.flat_map = v.col_map;
         const std::string K = std::to_string(v.col_slot);
-        before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
         cg.Stmt("  fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
       }
       if (has_window) {
@@ -1536,7 +1551,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
         // tile then takes the second, direct pass)
         cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
         for (auto& name : pv) {
-          cg.Stmt("  if (" + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
+          cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
                   " + at), " + name + ");");
           cg.Stmt("  at += " + name + ".len;");
         }
@@ -1548,6 +1563,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
         cg.Stmt("  at += " + name + ".len;");
       }
       cg.Stmt("}");
+      if (flat_cand) cg.Stmt("}");
       (void)vidx;
       cg.varlen_outs_.push_back(vo);
     } else if (t.id == kBool) {
@@ -1574,10 +1590,11 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   for (size_t k = 0; k < cg.input_fields_.size(); k++)
     string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
   if (string_plan) {
-    // workgroup tile = 4 waves x 8 sub-tiles x 64 rows: the row loop is rolled, so more sub-tiles
-    // cost no code, and fewer, larger tiles mean fewer scanner hand-offs (U4 2.01 ms, U8 1.93 ms,
-    // U2 2.40 ms on the same box; LDS staging windows and match bitmaps scale with U)
-    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = plan->has_varlen_output ? 8 : 4;
+    // workgroup tile = 4 waves x 4 sub-tiles x 64 rows.  Sub-tiles cost registers, not code (the
+    // row loop is rolled): 8 were better while the kernel carried 130 VGPRs either way; with the
+    // branch-free range test and the compile-time flat variant 4 sub-tiles fit 95 VGPRs (5 waves
+    // per SIMD) and win: 1.70 vs 1.83 ms (profiles/r02_c5_tuning.txt)
+    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = 4;
     if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
     return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
   }

@@ -59,6 +59,8 @@ struct KernelPlan {
   std::string kernel_name;
   std::string source;              // complete HIP translation unit (minus the library header)
   std::string ir;                  // human-readable plan dump (DumpIR)
+  // plans with flat var-len outputs: the variant without the optimistic flat path (compiled on demand)
+  std::string kernel_name_general, source_general;
   std::vector<int> input_fields;   // input slot -> index into the schema
   std::vector<bool> input_needs_values;
   std::vector<bool> input_needs_validity;
