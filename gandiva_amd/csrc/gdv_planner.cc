@@ -1247,7 +1247,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
         << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
         << " >> 8) & 0xffull) * GDV_B01;\n";
     }
-    s << "  for (gdv_int32 c = sb" << K << "; c < sp1" << K << "; c += 1024) {\n"
+    s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
       << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
       << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
@@ -1273,8 +1273,9 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     }
     s << "  }\n";
     // optimistic flat outputs: their place in the output is known from the input offsets alone, so
-    // the span is copied right here, while the sweep's lines are still in L2 / L1 — no scanner
-    // hand-off, no second trip to HBM
+    // the span is copied right here, while the sweep's lines are still in L2 / L1.  (Moving the copy
+    // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
+    // slower: 1.90 vs 1.78 ms, same box, profiles/r02_c5_tuning.txt.)
     for (auto* vo : flats)
       s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
         << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
@@ -1375,7 +1376,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
         << (2 * g + 1 < nv ? "all[" + std::to_string(2 * g + 1) + "]" : std::string("0ull")) << ");\n";
     s << "  }\n";
     s << "  if (threadIdx.x == 0) {\n"
-      << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
+      << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = (GDV_ABL & 32) ? (gdv_uint64)tile * 4000 : gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
       << "  }\n  __syncthreads();\n";
     for (int v = 0; v < nv; v++) {
       const VarlenOut& vo = cg.varlen_outs_[v];

@@ -5,7 +5,7 @@ export TMPDIR=/tmp GDV_NO_DISK_CACHE=1
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/abl; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-for abl in 0 1 2 4 8 16 31; do
+for abl in ${ABLS:-0 1 2 4 8 16 31}; do
   GDV_RTC_OPT="-DGDV_ABL=$abl" rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --kernel-trace -d $OUT/a$abl -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   t=$(GDV_RTC_OPT="-DGDV_ABL=$abl" GDV_TRACE=1 python $R/bench.py --workload c5 --no-cpu-baseline --steps 6 --warmup 2 2>&1 | grep "^\[gdv\]" | tail -1 | sed 's/.*device_ms=\([0-9.]*\).*/\1/')
   python3 - $OUT/a$abl $abl $t <<'PY'
