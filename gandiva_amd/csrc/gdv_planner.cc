@@ -1406,7 +1406,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       s << "        dir" << E << " = true;\n        dbase" << E << " = base;\n        need_direct = true;\n"
         << "      }\n    }\n  }\n";
     }
-    s << "  __syncthreads();  // the LDS hand-off words are reused by the next tile (serial-safe launches)\n"
+    s << "  if ((gdv_int64)gridDim.x - 1 < ntiles) __syncthreads();  // serial-safe launches only: the LDS hand-off words are reused by the next tile\n"
       << "  }  // pass\n";
   }
   s << "}\n\n";
