@@ -126,6 +126,25 @@ GDV_DEV gdv_uint64 gdv_bitmap_tile(const gdv_bitmap& bm, gdv_int64 wbase, int la
   return (lo >> bm.shift) | ((hi << 1) << (63 - bm.shift));
 }
 
+// Word `w` (wave-uniform index) of a bitmap, through the SCALAR data path: the input bitmaps are
+// read-only for the kernel, so they are addressed as constant memory (address space 4) and the
+// two 8-byte loads become one s_load — no VGPRs, no vmcnt slot, nothing the value loads of the
+// tile have to queue behind (round 2: the vector-load + readlane form made the compiler wait for
+// the bitmap words in the middle of the value loads: 7 of 32 loads in flight in the C3 kernel).
+#ifdef GDV_HOST_BUILD
+typedef const gdv_uint64 gdv_cu64;
+#else
+typedef const __attribute__((address_space(4))) gdv_uint64 gdv_cu64;
+#endif
+GDV_DEV gdv_uint64 gdv_bitmap_word(const gdv_bitmap& bm, gdv_int64 w) {
+  const gdv_int64 last = bm.nwords - 1;
+  const gdv_int64 i0 = w < last ? w : last;
+  const gdv_int64 i1 = w + 1 < last ? w + 1 : last;
+  gdv_cu64* q = (gdv_cu64*)bm.p;
+  const gdv_uint64 lo = q[i0], hi = q[i1];
+  return (lo >> bm.shift) | ((hi << 1) << (63 - bm.shift));  // also correct for shift == 0
+}
+
 // Word `u` of a tile fetched by gdv_bitmap_tile, as a wave-uniform value (SGPR pair):
 // merging the validity of several columns is then s_and_b64, not per-lane work.
 GDV_DEV gdv_uint64 gdv_tile_word(gdv_uint64 tile, int u) {

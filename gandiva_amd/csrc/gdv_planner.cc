@@ -22,12 +22,14 @@ CodegenOptions CodegenOptions::FromEnv() {
   if (const char* s = std::getenv("GDV_WAVES")) o.waves = std::max(1, std::min(16, atoi(s)));
   if (const char* s = std::getenv("GDV_NT")) o.nontemporal = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_SCALAR_BITMAPS")) o.scalar_bitmaps = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
   return o;
 }
 
 std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
-         (nt_loads ? "ntl" : "");
+         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -946,14 +948,14 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     if (t.id == kBool) {
       if (cg.needs_values_[k]) {
         if (sel) s << "  bool x" << k << "[GDV_U];\n";
-        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+        else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
       }
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
     if (cg.needs_validity_[k]) {
       if (sel) s << "  bool b" << k << "[GDV_U];\n";
-      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+      else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
   }
   const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
@@ -996,6 +998,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   }
 
   // ---- phase 2: row body
+  if (plan->opts.load_fence)
+    s << "  __builtin_amdgcn_sched_barrier(0);  // keep every load of the tile ahead of the first use\n";
   s << "  // ---- phase 2: fused expression bodies (value for every row, validity per word)\n";
   for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
   s << decls_before_loop;
@@ -1015,8 +1019,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.id == kBool && cg.needs_values_[k])
-        s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+        s << "      const gdv_uint64 d" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].bits, wbase + u)" : "gdv_tile_word(dw" + std::to_string(k) + ", u)") << ";\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].valid, wbase + u)" : "gdv_tile_word(vw" + std::to_string(k) + ", u)") << ";\n";
     }
   }
   s << body;
@@ -1160,7 +1164,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     if (t.id == kBool) {
       if (cg.needs_values_[k]) {
         if (sel) s << "  bool x" << k << "[GDV_U];\n";
-        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+        else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
       }
     } else if (t.is_varlen()) {
       if (cg.needs_values_[k]) s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
@@ -1169,7 +1173,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     }
     if (cg.needs_validity_[k]) {
       if (sel) s << "  bool b" << k << "[GDV_U];\n";
-      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+      else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
   }
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
@@ -1327,8 +1331,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.id == kBool && cg.needs_values_[k])
-        s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+        s << "      const gdv_uint64 d" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].bits, wbase + u)" : "gdv_tile_word(dw" + std::to_string(k) + ", u)") << ";\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].valid, wbase + u)" : "gdv_tile_word(vw" + std::to_string(k) + ", u)") << ";\n";
     }
   }
   {

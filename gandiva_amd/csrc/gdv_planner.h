@@ -31,6 +31,10 @@ struct CodegenOptions {
   bool nontemporal = true; // non-temporal stores for output value buffers
   bool nt_loads = true;    // non-temporal loads of input value buffers: every value is read
                            // exactly once (+3 % on C2, +7 % on C1, neutral on C3; GDV_NTLOAD=0)
+  // validity / bool words through the scalar data path instead of one vector load per column +
+  // readlane: measured no gain on C2/C3 and a loss on C1/C4 (SGPR spills), profiles/r02_k1_k2_experiments.txt
+  bool scalar_bitmaps = false;
+  bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
   static CodegenOptions FromEnv();
   std::string Key() const;
 };

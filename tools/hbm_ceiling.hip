@@ -1,0 +1,103 @@
+// What a plain streaming kernel reaches on this box: read-only, write-only and copy rates at the
+// sizes of the BASELINE workloads.  Context for the roofline fractions in DESIGN.md §4 (the
+// microarch guide quotes 6.29 TB/s for a float4 copy).  hipcc --offload-arch=gfx950 -O3 -o hbm_ceiling hbm_ceiling.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+template <int U>
+__global__ void __launch_bounds__(256) k_read(const u64x2* __restrict__ p, size_t n, u64* out) {
+  u64 acc = 0;
+  size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (; i + 256 * (U - 1) < n; i += stride) {
+    u64x2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(p + i + 256 * u);
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += v[u].x ^ v[u].y;
+  }
+  if (acc == 0x1234567) out[0] = acc;
+}
+template <int U>
+__global__ void __launch_bounds__(256) k_read8(const u64* __restrict__ p, size_t n, u64* out) {  // 8 B per lane
+  u64 acc = 0;
+  size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (; i + 256 * (U - 1) < n; i += stride) {
+    u64 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(p + i + 256 * u);
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += v[u];
+  }
+  if (acc == 0x1234567) out[0] = acc;
+}
+// two columns, 8 B per lane each, one wave = 64 consecutive rows per sub-tile (the filter's shape)
+template <int U>
+__global__ void __launch_bounds__(256) k_read8x2(const u64* __restrict__ p, const u64* __restrict__ q, size_t n, u64* out) {
+  u64 acc = 0;
+  size_t i = (size_t)blockIdx.x * 256 * U + (threadIdx.x >> 6) * 64 * U + (threadIdx.x & 63);
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (; i + 64 * (U - 1) < n; i += stride) {
+    u64 v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = __builtin_nontemporal_load(p + i + 64 * u); w[u] = __builtin_nontemporal_load(q + i + 64 * u); }
+#pragma unroll
+    for (int u = 0; u < U; u++) acc += v[u] ^ w[u];
+  }
+  if (acc == 0x1234567) out[0] = acc;
+}
+template <int U>
+__global__ void __launch_bounds__(256) k_write(u64x2* __restrict__ p, size_t n, u64 val) {
+  size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  u64x2 v; v.x = val; v.y = val + 1;
+  for (; i + 256 * (U - 1) < n; i += stride) {
+#pragma unroll
+    for (int u = 0; u < U; u++) __builtin_nontemporal_store(v, p + i + 256 * u);
+  }
+}
+template <int U>
+__global__ void __launch_bounds__(256) k_copy(const u64x2* __restrict__ a, u64x2* __restrict__ b, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  for (; i + 256 * (U - 1) < n; i += stride) {
+    u64x2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(a + i + 256 * u);
+#pragma unroll
+    for (int u = 0; u < U; u++) __builtin_nontemporal_store(v[u], b + i + 256 * u);
+  }
+}
+template <typename F>
+double timeit(F f) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9;
+  for (int it = 0; it < 7; it++) {
+    CK(hipEventRecord(e0)); f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 2 && ms < best) best = ms;
+  }
+  return best;
+}
+int main() {
+  const size_t bytes = (size_t)16 << 30, n = bytes / 16;
+  u64x2 *a, *b; u64* out;
+  CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&out, 8));
+  CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+  for (int g : {2048, 4096, 8192}) {
+    double r = timeit([&] { hipLaunchKernelGGL((k_read<8>), dim3(g), dim3(256), 0, 0, a, n, out); });
+    double w = timeit([&] { hipLaunchKernelGGL((k_write<8>), dim3(g), dim3(256), 0, 0, b, n, 7ull); });
+    double c = timeit([&] { hipLaunchKernelGGL((k_copy<8>), dim3(g), dim3(256), 0, 0, a, b, n); });
+    double r8 = timeit([&] { hipLaunchKernelGGL((k_read8<16>), dim3(g), dim3(256), 0, 0, (const u64*)a, n * 2, out); });
+    double r82 = timeit([&] { hipLaunchKernelGGL((k_read8x2<16>), dim3(g), dim3(256), 0, 0, (const u64*)a, (const u64*)b, n * 2, out); });
+    printf("grid %5d: 8 B/lane x16 read %.3f ms = %.2f TB/s | two columns 8 B/lane x16, wave-contiguous %.3f ms = %.2f TB/s\n", g, r8, bytes / r8 / 1e9, r82, 2.0 * bytes / r82 / 1e9);
+    printf("grid %5d x 256, 8 x 16 B per lane in flight, 16 GiB: read %.3f ms = %.2f TB/s | write %.3f ms = %.2f TB/s | copy %.3f ms = %.2f TB/s (read+write bytes)\n",
+           g, r, bytes / r / 1e9, w, bytes / w / 1e9, c, 2.0 * bytes / c / 1e9);
+  }
+  return 0;
+}

@@ -1,7 +1,7 @@
 export GDV_NO_DISK_CACHE=1
-run() { echo "--- $1"; env $2 GDV_TRACE=1 python bench.py --workload c5 --no-cpu-baseline --steps 8 --warmup 2 2>&1 | grep -E "^\[gdv\]|rror" | tail -1 | cut -c1-100; }
-for i in 1 2; do
-run "U4 W4" "X=1"
-run "U4 W8" "GDV_WAVES=8"
-run "U4 W16" "GDV_WAVES=16"
+one() { env $2 python bench.py --workload $1 --no-cpu-baseline --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'], d['roofline']['frac'])"; }
+for w in c3 c2 c1 c4; do
+  for i in 1 2; do
+    echo "$w default: $(one $w X=1)   load fence: $(one $w GDV_LOAD_FENCE=1)"
+  done
 done
