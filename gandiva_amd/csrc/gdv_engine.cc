@@ -556,7 +556,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
 
   const int nv = plan_.num_varlen_outputs;
-  const bool has_err = plan_.can_raise || nv > 0;  // var-len plans can report a stalled scan
+  const bool has_err = plan_.can_raise && nv == 0;  // var-len plans keep the error word in their scan-state block
   if (has_err) {
     GDV_RETURN_NOT_OK(err.Allocate(8));
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
@@ -579,23 +579,27 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     // device byte buffers, a second one fills them (the path is PCIe-bound anyway).
     const int ng = (nv + 1) / 2;
     const int64_t ntiles = (out_rows + plan_.rows_per_tile() - 1) / plan_.rows_per_tile();
-    GDV_RETURN_NOT_OK(tile_starts.Allocate(static_cast<size_t>(2 * ng * ntiles) * 8));
-    GDV_RETURN_NOT_OK(tile_counts.Allocate(static_cast<size_t>(2 * ng) * 8));
-    args.SetPtr(ArgLayout::kOffMask, tile_starts.get());
-    args.SetPtr(ArgLayout::kOffCounts, tile_counts.get());
+    // one block, one memset and one read-back per launch: [error word | grand totals | granules]
+    const size_t totals_bytes = static_cast<size_t>(2 * ng) * 8;
+    const size_t state_bytes = 8 + totals_bytes + static_cast<size_t>(2 * ng * ntiles) * 8;
+    GDV_RETURN_NOT_OK(tile_starts.Allocate(state_bytes));
+    char* const state = tile_starts.as<char>();
+    args.SetPtr(ArgLayout::kOffErr, state);
+    args.SetPtr(ArgLayout::kOffCounts, state + 8);
+    args.SetPtr(ArgLayout::kOffMask, state + 8 + totals_bytes);
+    std::vector<uint64_t> back(1 + 2 * ng, 0);
     std::vector<int> vl;
     for (int e = 0; e < num_outs; e++)
       if (plan_.output_types[e].is_varlen()) vl.push_back(e);
     std::vector<uint64_t> seg(2 * ng, 0);
     const CompiledKernel* active = kernel_;
     auto run = [&](int64_t grid) -> Status {
-      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(tile_starts.get(), 0, static_cast<size_t>(2 * ng * ntiles) * 8, stream));
-      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(tile_counts.get(), 0, static_cast<size_t>(2 * ng) * 8, stream));
-      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(state, 0, state_bytes, stream));
       GDV_RETURN_NOT_OK(rt.Launch(*active, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
-      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(seg.data(), tile_counts.get(), 8 * 2 * ng, hipMemcpyDeviceToHost, stream));
-      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), state, 8 + totals_bytes, hipMemcpyDeviceToHost, stream));
       GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+      err_bits = static_cast<uint32_t>(back[0]);
+      for (int i = 0; i < 2 * ng; i++) seg[i] = back[1 + i];
       return Status::OK();
     };
     // Outputs that are an input column's (mapped) bytes — a column passed through, upper(col),
@@ -785,7 +789,11 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
   KernelPlan plan;
   GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));
   std::vector<char> code;
-  return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
+  GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code));
+  // the variant without the optimistic flat path is otherwise compiled only when a batch needs it
+  if (!plan.source_general.empty() && std::getenv("GDV_PRECOMPILE_SKIP_GENERAL") == nullptr)
+    GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source_general, plan.kernel_name_general, &code));
+  return Status::OK();
 }
 
 Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition) {

@@ -1,0 +1,72 @@
+"""Planner properties that need no GPU: the generated kernels are compiled for gfx950 by hipRTC
+right here (cross-compile), and their source is dumped next to the code object."""
+import ctypes as C
+import os
+import re
+
+import pyarrow as pa
+
+import gandiva_amd as gandiva
+from gandiva_amd import _capi, gandiva as gg, workloads as W
+
+
+def _precompile(monkeypatch, tmp_path, schema, exprs=None, cond=None):
+    monkeypatch.setenv("GDV_NO_DISK_CACHE", "1")
+    monkeypatch.setenv("GDV_DUMP_SOURCE", "1")
+    monkeypatch.setenv("GANDIVA_AMD_CACHE_DIR", str(tmp_path))
+    lib = _capi.lib()
+    sh = gg._make_schema(schema)
+    try:
+        if cond is not None:
+            rc = lib.gdv_precompile_filter(sh, cond._h)
+        else:
+            arr = (C.c_void_p * len(exprs))(*[e._h for e in exprs])
+            rc = lib.gdv_precompile_projector(sh, arr, len(exprs), 0)
+        assert rc == 0, _capi.last_error()
+    finally:
+        lib.gdv_schema_free(sh)
+    return sorted(f for f in os.listdir(tmp_path) if f.endswith(".hip"))
+
+
+def test_plans_that_differ_only_in_constants_share_one_kernel(monkeypatch, tmp_path):
+    """Fixed-width literals, IN values and LIKE needles are kernel arguments / constant-block
+    bytes: two filters with different constants must generate the SAME source (same kernel name);
+    a different needle LENGTH is a different shape and may not."""
+    b = gandiva.TreeExprBuilder()
+    sch = pa.schema([pa.field("a", pa.int64()), pa.field("x", pa.float64()), pa.field("s", pa.string())])
+    a, x, s = (b.make_field(sch.field(i)) for i in range(3))
+
+    def cond(k, f, pat, inl):
+        return b.make_condition(b.make_and([
+            b.make_function("greater_than", [a, b.make_literal(k, pa.int64())], pa.bool_()),
+            b.make_or([b.make_function("less_than", [x, b.make_literal(f, pa.float64())], pa.bool_()),
+                       b.make_function("like", [s, b.make_literal(pat, pa.string())], pa.bool_()),
+                       b.make_in_expression(a, inl, pa.int64())])]))
+    _precompile(monkeypatch, tmp_path, sch, cond=cond(499, 0.25, "%spark%", [1, 5, 9]))
+    files = _precompile(monkeypatch, tmp_path, sch, cond=cond(500, -1.5, "%flink%", [500, 2, 777]))
+    assert len(files) == 1, files
+    files = _precompile(monkeypatch, tmp_path, sch, cond=cond(500, -1.5, "%sparks%", [500, 2, 777]))
+    assert len(files) == 2, files
+    text = open(tmp_path / files[0]).read()
+    assert "499" not in re.sub(r"^// @expr_.*$", "", text, flags=re.M)   # constants only in the header comment
+
+
+def test_string_projection_builds_an_optimistic_and_a_general_variant(monkeypatch, tmp_path):
+    """A plan with a flat var-len output (upper(col)) has two compile-time variants; both must
+    compile for gfx950 at build time, not on the first batch that needs the general one."""
+    monkeypatch.delenv("GDV_PRECOMPILE_SKIP_GENERAL", raising=False)
+    files = _precompile(monkeypatch, tmp_path, W.c5_schema(), exprs=W.c5_expressions())
+    assert len(files) == 2, files
+    defs = sorted(re.search(r"#define GDV_OPTFLAT (\d)", open(tmp_path / f).read()).group(1) for f in files)
+    assert defs == ["0", "1"]
+    for f in files:
+        text = open(tmp_path / f).read()
+        assert "@expr_2 = string upper((string) s)" in text        # DumpIR keeps the readable header
+        assert "gdv_scanner<GDV_NG>" in text and "gdv_flat_copy" in text
+
+
+def test_fixed_width_plans_have_one_variant_and_a_literal_free_body(monkeypatch, tmp_path):
+    files = _precompile(monkeypatch, tmp_path, W.c4_schema(), exprs=W.c4_expressions())
+    assert len(files) == 1
+    text = open(tmp_path / files[0]).read()
+    assert "A.lit[" in text and "gdv_make_int128(A.lit[" in text
