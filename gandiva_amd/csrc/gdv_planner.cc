@@ -746,9 +746,6 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
     }
     case NodeKind::kIn: {
       auto& n = static_cast<const InNode&>(node);
-      if (n.value_type().is_decimal())
-        return Status::CodeGenError("IN over " + n.value_type().ToString() +
-                                    " is not supported by the HIP backend yet");
       Val x;
       GDV_RETURN_NOT_OK(Gen(*n.eval(), active, &x));
       if (!x.pieces.empty())
@@ -771,8 +768,23 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
                                  std::to_string(n.values().size()) + ")");
         return Status::OK();
       }
-      std::vector<uint64_t> vals;
       const DataType& vt = n.value_type();
+      if (vt.is_decimal()) {
+        // 16-byte values: equality against two argument slots each (lists are short in practice)
+        if (n.values().size() > 64)
+          return Status::CodeGenError("IN over decimal128 with more than 64 values is not supported by the HIP backend yet");
+        std::string e;
+        for (auto& l : n.values()) {
+          lits_.push_back(l.lo);
+          lits_.push_back(l.hi);
+          const std::string i = std::to_string(lits_.size() - 2), j = std::to_string(lits_.size() - 1);
+          if (!e.empty()) e += " || ";
+          e += "(" + x.v + " == gdv_make_int128(A.lit[" + j + "], A.lit[" + i + "]))";
+        }
+        out->v = e.empty() ? std::string("false") : Tmp("bool", e);
+        return Status::OK();
+      }
+      std::vector<uint64_t> vals;
       uint64_t mask = vt.byte_width() >= 8 ? ~0ull : ((1ull << (8 * vt.byte_width())) - 1);
       const bool is_fp = vt.id == kFloat || vt.id == kDouble;
       for (auto& l : n.values()) {

@@ -294,6 +294,11 @@ class TreeExprBuilder:
 
 def _to_storage_int(v, t):
     """IN-list value -> the integer stored in the Arrow values buffer."""
+    if pa.types.is_decimal(t):
+        import decimal
+        return int(decimal.Decimal(v).scaleb(t.scale).to_integral_exact())
+    if pa.types.is_floating(t):
+        return float(v)
     if isinstance(v, (int, np.integer)):
         return int(v)
     return int(pa.scalar(v, type=t).cast(pa.int64() if t.bit_width == 64 else pa.int32()).as_py())

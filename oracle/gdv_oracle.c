@@ -108,6 +108,7 @@ typedef struct node {
   struct node** args;
   int nvals;
   uint64_t* vals;
+  uint64_t* vals_hi; /* IN over decimal128: high words */
   uint8_t* sbytes; /* string literal / concatenated IN strings */
   int32_t slen;
   int32_t* soffs;  /* IN strings: nvals + 1 offsets into sbytes */
@@ -230,7 +231,18 @@ static node* parse(const char** p, const or_column* cols) {
       next_tok(p, t, sizeof t); /* value type: implied by child */
       next_tok(p, t, sizeof t); n->nvals = atoi(t);
       n->vals = (uint64_t*)calloc(n->nvals ? n->nvals : 1, sizeof(uint64_t));
-      for (int i = 0; i < n->nvals; i++) { next_tok(p, t, sizeof t); n->vals[i] = strtoull(t, NULL, 16); }
+      n->vals_hi = (uint64_t*)calloc(n->nvals ? n->nvals : 1, sizeof(uint64_t));
+      for (int i = 0; i < n->nvals; i++) {  /* up to 32 hex digits: 128-bit bit images */
+        next_tok(p, t, sizeof t);
+        size_t len = strlen(t);
+        if (len > 16) {
+          n->vals[i] = strtoull(t + len - 16, NULL, 16);
+          t[len - 16] = 0;
+          n->vals_hi[i] = strtoull(t, NULL, 16);
+        } else {
+          n->vals[i] = strtoull(t, NULL, 16);
+        }
+      }
       n->nargs = 1;
       n->args = (node**)calloc(1, sizeof(node*));
       n->args[0] = parse(p, cols);
@@ -247,6 +259,7 @@ static void free_node(node* n) {
   for (int i = 0; i < n->nargs; i++) free_node(n->args[i]);
   free(n->args);
   free(n->vals);
+  free(n->vals_hi);
   free(n->sbytes);
   free(n->soffs);
   free(n);
@@ -1150,10 +1163,23 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
       const int w = width_of(x->type);
       const uint64_t mask = w >= 8 ? ~0ull : ((1ull << (8 * w)) - 1);
       for (int i = 0; i < cnt; i++) {
-        uint64_t bits = x->v[i].u & mask;
-        if (x->type == T_F32) { uint32_t b; memcpy(&b, &x->v[i].f, 4); bits = b; }
         int hit = 0;
-        for (int k = 0; k < n->nvals; k++) hit |= (n->vals[k] & mask) == bits;
+        if (x->type == T_DEC) {
+          for (int k = 0; k < n->nvals; k++)
+            hit |= x->v[i].q == (i128)(((u128)n->vals_hi[k] << 64) | n->vals[k]);
+        } else if (x->type == T_F32 || x->type == T_F64) {
+          /* value equality, as a hash set of floats gives it: -0.0 == +0.0, a NaN equals nothing */
+          const double xv = x->type == T_F32 ? (double)x->v[i].f : x->v[i].d;
+          for (int k = 0; k < n->nvals; k++) {
+            double lv;
+            if (x->type == T_F32) { uint32_t b = (uint32_t)n->vals[k]; float f; memcpy(&f, &b, 4); lv = f; }
+            else memcpy(&lv, &n->vals[k], 8);
+            hit |= xv == lv;
+          }
+        } else {
+          const uint64_t bits = x->v[i].u & mask;
+          for (int k = 0; k < n->nvals; k++) hit |= (n->vals[k] & mask) == bits;
+        }
         out->v[i].i = hit;
         out->valid[i] = x->valid[i];
       }

@@ -301,3 +301,45 @@ def test_hip_decimal_ops_on_dense_random_digits(seed):
     got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
     for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
         assert_bit_exact(g, w, str(e))
+
+
+def _in_batch():
+    import decimal as D
+    t = pa.decimal128(20, 4)
+    vals = [D.Decimal("1.5000"), D.Decimal("-99999999999999.9999"), None, D.Decimal("0.0000"), D.Decimal("7.2500"),
+            D.Decimal("1234567890123456.7891")] * 40
+    f = [0.0, -0.0, float("nan"), 1.5, -2.25, None] * 40
+    return pa.RecordBatch.from_arrays([pa.array(vals, type=t), pa.array(f, type=pa.float64())], names=["d", "f"]), t
+
+
+def _in_exprs(b, batch, t):
+    d, f = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    return [b.make_expression(b.make_in_expression(d, ["1.5", "-99999999999999.9999", "42"], t), pa.field("din", pa.bool_())),
+            b.make_expression(b.make_in_expression(f, [-0.0, float("nan"), -2.25], pa.float64()), pa.field("fin", pa.bool_()))]
+
+
+def test_oracle_in_over_decimal_and_float_uses_value_equality():
+    """IN over decimal128 (16-byte values) and over float64: -0.0 and +0.0 are one value, a NaN in
+    the list or in the column matches nothing (what a hash set of doubles does)."""
+    batch, t = _in_batch()
+    b = gandiva.TreeExprBuilder()
+    got = oracle.project(_in_exprs(b, batch, t), batch)
+    import decimal as D
+    want_d = [None if v is None else v in (D.Decimal("1.5"), D.Decimal("-99999999999999.9999"), D.Decimal(42))
+              for v in batch.column(0).to_pylist()]
+    want_f = [None if v is None else (v == 0.0 or v == -2.25) for v in batch.column(1).to_pylist()]
+    assert got[0].to_pylist() == want_d
+    assert got[1].to_pylist() == want_f
+
+
+@pytest.mark.gpu
+def test_hip_in_over_decimal_and_float_matches_oracle():
+    batch, t = _in_batch()
+    b = gandiva.TreeExprBuilder()
+    exprs = _in_exprs(b, batch, t)
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        assert_bit_exact(g, w, str(e))
+    cond = b.make_condition(exprs[0].root())
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, None)
+    assert sel.to_array().equals(oracle.filter_indices(cond, batch, "int32"))
