@@ -607,7 +607,9 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     // are read, offsets = input offsets rebased, no scan.  That holds unless a NULL row carries
     // bytes (Arrow allows it, producers rarely do it); the kernel then raises NOTFLAT and the
     // batch is re-run with those outputs on the general path.
-    bool optimistic = plan_.has_flat_output && std::getenv("GDV_NO_OPTFLAT") == nullptr;
+    // (sticky: a Projector whose batches carry bytes under nulls goes straight to the general
+    // variant from then on instead of paying two launches per batch)
+    bool optimistic = plan_.has_flat_output && !prefer_general_.load() && std::getenv("GDV_NO_OPTFLAT") == nullptr;
     auto general_kernel = [&]() -> Status {
       if (kernel_general_.load() == nullptr) {
         const CompiledKernel* k = nullptr;
@@ -622,6 +624,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
       if (optimistic && (err_bits & 16u)) {
         optimistic = false;
+        prefer_general_.store(true);
         GDV_RETURN_NOT_OK(general_kernel());
         active = kernel_general_.load();
         GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));

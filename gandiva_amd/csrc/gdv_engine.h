@@ -84,6 +84,7 @@ class Projector {
   KernelPlan plan_;
   const CompiledKernel* kernel_ = nullptr;
   mutable std::atomic<const CompiledKernel*> kernel_general_{nullptr};  // without the optimistic flat path (lazy)
+  mutable std::atomic<bool> prefer_general_{false};  // a batch raised NOTFLAT: stop trying the optimistic variant
   DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
 };
 
