@@ -1115,44 +1115,43 @@ static __device__ GDV_COLD void gdv_str_copy_direct(gdv_uint8* dst, const gdv_ui
 }
 // ---- LDS staging of var-len output bytes.  Every lane writes its row's bytes into the wave's
 // private LDS window at the row's offset inside the wave tile (byte-granular, unaligned LDS
-// writes: cheap), then the wave streams the window to HBM as 16-byte pieces aligned in the
-// OUTPUT buffer (head and tail bytes singly) — one coalesced store instruction per KiB instead of
-// several scattered stores per row.
+// writes: cheap), then the wave streams the window to HBM as consecutive 16-byte pieces, the last
+// one shifted back to end exactly at the total (it overlaps its neighbour with identical bytes) —
+// one coalesced store instruction per KiB instead of several scattered stores per row.  (Pieces
+// aligned in the output with head / tail bytes stored singly measured 2 % slower.)
 #define GDV_OUT_WIN (GDV_U * 64 * 8)  // staged bytes per wave tile and output: 8 per row on average
 #ifndef GDV_HOST_BUILD
 GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gdv_int32 cnt, int lane) {
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: ordering only
-  gdv_int32 head = (gdv_int32)((16 - ((gdv_uint64)dst & 15)) & 15);
-  head = head < cnt ? head : cnt;
-  if (lane < head) dst[lane] = win[lane];
-  const gdv_int32 body = (cnt - head) & ~15;
-  for (gdv_int32 i = lane * 16; i < body; i += 1024) {
-    gdv_uint64 w[2];
-    __builtin_memcpy(w, win + head + i, 16);
-    __builtin_memcpy(__builtin_assume_aligned(dst + head + i, 16), w, 16);
+  if (cnt >= 16) {
+    for (gdv_int32 i = lane * 16; i < cnt; i += 1024) {
+      const gdv_int32 j = i + 16 <= cnt ? i : cnt - 16;  // the last piece is shifted back to end at cnt
+      gdv_uint64 w[2];
+      __builtin_memcpy(w, win + j, 16);
+      __builtin_memcpy(dst + j, w, 16);
+    }
+  } else if (lane < cnt) {
+    dst[lane] = win[lane];
   }
-  const gdv_int32 t0 = head + body;
-  if (t0 + lane < cnt) dst[t0 + lane] = win[t0 + lane];
   __builtin_amdgcn_wave_barrier();
 }
 // The output bytes of a wave tile ARE the (mapped) bytes of a contiguous input span (an input
 // column passed through, upper(col), lower(col) with no row dropped): stream them, lanes over
-// bytes, 16 B per lane, stores aligned in the output buffer.
+// bytes, 16 B per lane.
 GDV_DEV void gdv_flat_copy(gdv_uint8* __restrict__ dst, const gdv_uint8* __restrict__ src, gdv_int32 cnt,
                            gdv_int32 map, int lane) {
-  gdv_int32 head = (gdv_int32)((16 - ((gdv_uint64)dst & 15)) & 15);
-  head = head < cnt ? head : cnt;
-  if (lane < head) dst[lane] = gdv_map_byte(src[lane], map);
-  const gdv_int32 body = (cnt - head) & ~15;
-  for (gdv_int32 i = lane * 16; i < body; i += 1024) {
-    gdv_uint64 w[2];
-    __builtin_memcpy(w, src + head + i, 16);
-    w[0] = gdv_map8(w[0], map);
-    w[1] = gdv_map8(w[1], map);
-    __builtin_memcpy(__builtin_assume_aligned(dst + head + i, 16), w, 16);
+  if (cnt >= 16) {
+    for (gdv_int32 i = lane * 16; i < cnt; i += 1024) {
+      const gdv_int32 j = i + 16 <= cnt ? i : cnt - 16;
+      gdv_uint64 w[2];
+      __builtin_memcpy(w, src + j, 16);
+      w[0] = gdv_map8(w[0], map);
+      w[1] = gdv_map8(w[1], map);
+      __builtin_memcpy(dst + j, w, 16);
+    }
+  } else if (lane < cnt) {
+    dst[lane] = gdv_map_byte(src[lane], map);
   }
-  const gdv_int32 t0 = head + body;
-  if (t0 + lane < cnt) dst[t0 + lane] = gdv_map_byte(src[t0 + lane], map);
 }
 #endif
 

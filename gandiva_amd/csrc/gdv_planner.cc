@@ -1,5 +1,7 @@
 #include "gdv_planner.h"
 
+#include "gdv_runtime.h"
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -186,6 +188,8 @@ std::string HashableSource(const std::string& text) {
   return out;
 }
 
+std::string LibraryTag();
+
 uint64_t Fnv1a(const std::string& s) {
   uint64_t h = 1469598103934665603ull;
   for (unsigned char c : s) {
@@ -193,6 +197,14 @@ uint64_t Fnv1a(const std::string& s) {
     h *= 1099511628211ull;
   }
   return h;
+}
+
+// A kernel is its generated text AND the device function library it is compiled against: the
+// library's hash is part of the kernel name, so a PMC pass or a cached code object can only be
+// attributed to the code that really ran.
+std::string LibraryTag() {
+  static const std::string tag = std::to_string(Fnv1a(std::string(gdv_device_lib_src)));
+  return tag;
 }
 
 // A value inside the generated row body: a C++ expression plus its validity, split the way
@@ -1074,7 +1086,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "}\n";
 
   std::string text = s.str();
-  uint64_t h = Fnv1a(HashableSource(text));
+  uint64_t h = Fnv1a(HashableSource(text) + LibraryTag());
   char name[64];
   snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
   plan->kernel_name = name;
@@ -1467,7 +1479,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     std::string text = tmpl;
     size_t p0 = text.find("GDV_OPTFLAT_VALUE");
     text.replace(p0, strlen("GDV_OPTFLAT_VALUE"), optflat);
-    uint64_t h = Fnv1a(HashableSource(text));
+    uint64_t h = Fnv1a(HashableSource(text) + LibraryTag());
     char name[64];
     snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
     size_t pos = text.find("GDV_KERNEL_NAME");

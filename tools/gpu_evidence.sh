@@ -26,6 +26,7 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD
 done
 cd $R
 python tools/make_latency.py > $OUT/make_latency.txt 2>&1
+[ -x tools/hbm_ceiling ] && timeout 120 tools/hbm_ceiling > $OUT/hbm_ceiling.txt 2>&1
 python tools/micro_benchmarks.py > $OUT/micro_benchmarks.txt 2>&1
 python tools/latency_sweep.py > $OUT/latency_sweep.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -size +1000k -delete   # raw traces are large; stats / counters stay

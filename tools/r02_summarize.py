@@ -53,7 +53,7 @@ if acc:
         f.write("# (one wave = 256 rows = 4 sub-tiles of 64 rows)\n")
         for k, v in sorted(acc.items()):
             f.write(f"{k:22s} total {sum(v):.4g}  launches {len(v)}  per_wave {sum(v) / waves * (len(acc.get('SQ_WAVES', [1])) / len(v)):.1f}\n")
-for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log"):
+for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, "r02_" + name))
