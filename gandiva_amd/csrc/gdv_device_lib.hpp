@@ -191,6 +191,9 @@ GDV_DEV gdv_uint32 gdv_tile_total(gdv_int32 lane_total) {  // lane_total in [0, 
 }
 GDV_DEV gdv_int32 gdv_wave_sum(gdv_int32 v) { return gdv_wave_last(gdv_wave_scan_incl(v)); }
 
+// bitmap words of a tile leave with one store per wave tile
+#define GDV_WORD_ST(p, v) (*(gdv_uint64*)(p) = (v))
+#define GDV_WORD_ST_NT(p, v) __builtin_nontemporal_store((gdv_uint64)(v), (gdv_uint64*)(p))
 GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int lane) {
   return (lane == u) ? word : acc;  // v_cndmask with a scalar source
 }

@@ -26,12 +26,14 @@ CodegenOptions CodegenOptions::FromEnv() {
   if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_SCALAR_BITMAPS")) o.scalar_bitmaps = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_BITMAPS_LAST")) o.bitmaps_last = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_WPE")) o.waves_per_eu = std::max(0, std::min(8, atoi(s)));
   return o;
 }
 
 std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
-         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "");
+         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + "e" + std::to_string(waves_per_eu);
 }
 
 // ------------------------------------------------------------------ validation
@@ -893,9 +895,10 @@ struct WordAccumulators {
   }
 };
 
-std::string WordStore(const std::string& acc, const std::string& dst) {
-  return std::string("  if (lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) ") + dst +
-         "[wbase + lane] = " + acc + ";\n";
+std::string WordStore(const std::string& acc, const std::string& dst, bool nontemporal = false) {
+  return std::string("  if (!(GDV_ABL & 2) && lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) ") +
+         (nontemporal ? "GDV_WORD_ST_NT(" : "GDV_WORD_ST(") + dst +
+         " + wbase + lane, " + acc + ");\n";
 }
 
 Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
@@ -935,6 +938,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
   std::ostringstream& s = as.src;
+  s << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n";
   if (wide)
     s << "#define GDV_OUT(e, v) res##e[u] = (v)\n";
   else
@@ -967,21 +971,27 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   // ---- phase 1: every load of the tile, no control flow in between
   s << "  // ---- phase 1: all loads of this wave's GDV_U sub-tiles, issued back to back\n";
   if (sel) s << "  gdv_int64 srow[GDV_U];\n";
+  std::ostringstream bitmap_loads;  // one vector load per column: lane u <-> word u
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
     if (t.id == kBool) {
       if (cg.needs_values_[k]) {
         if (sel) s << "  bool x" << k << "[GDV_U];\n";
-        else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+        else if (!plan->opts.scalar_bitmaps) bitmap_loads << "  const gdv_uint64 dw" << k << " = (GDV_ABL & 1) ? ~0ull : gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
       }
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
     if (cg.needs_validity_[k]) {
       if (sel) s << "  bool b" << k << "[GDV_U];\n";
-      else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+      else if (!plan->opts.scalar_bitmaps) bitmap_loads << "  const gdv_uint64 vw" << k << " = (GDV_ABL & 1) ? ~0ull : gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
   }
+  // Bitmap words BEHIND the value loads (round 2): issued first, the compiler consumed them first
+  // and waited for them before most value loads were even issued (7 of 32 in the C3 predicate
+  // kernel); a hand-written copy of that kernel with every load in flight ran 0.45 ms faster
+  // (tools/hbm_ceiling.hip, profiles/r02_k1_k2_experiments.txt).
+  if (!plan->opts.bitmaps_last) s << bitmap_loads.str();
   const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
   if (wide) {
     s << "  if (FULL) {\n#pragma unroll\n    for (int g = 0; g < GDV_U / 4; g++) {\n"
@@ -1021,6 +1031,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     s << "  }\n";
   }
 
+  if (plan->opts.bitmaps_last) s << bitmap_loads.str();
   // ---- phase 2: row body
   if (plan->opts.load_fence)
     s << "  __builtin_amdgcn_sched_barrier(0);  // keep every load of the tile ahead of the first use\n";
@@ -1067,7 +1078,10 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
   // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
   // each bitmap.
-  s << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+  s << "extern \"C\" __global__ void ";
+  if (plan->opts.waves_per_eu > 0)
+    s << "__attribute__((amdgpu_waves_per_eu(" << plan->opts.waves_per_eu << ", " << plan->opts.waves_per_eu << "))) ";
+  s << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
     << "  const gdv_int64 n = A.n;\n"
@@ -1676,7 +1690,10 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
     plan->opts.subtiles = u;
   }
   std::ostringstream after;
-  after << WordStore(acc, "A.mask");
+  // the match words are written once and read by the index-emission kernel much later: non-temporal
+  // (C3, same box: 2.74 / 2.99 ms plain vs 2.69 / 2.67 ms; validity words of projections measured
+  // the other way round — C2 4.90 vs 5.0-5.1 ms — and stay plain)
+  after << WordStore(acc, "A.mask", true);
   // one selected-row count per wave tile feeds the offsets scan (gdv_kernels.hip)
   after << "  if (lane == 0) A.counts[wbase / GDV_U] = fcount;\n";
   bool string_plan = false;

@@ -34,6 +34,8 @@ struct CodegenOptions {
   // validity / bool words through the scalar data path instead of one vector load per column +
   // readlane: measured no gain on C2/C3 and a loss on C1/C4 (SGPR spills), profiles/r02_k1_k2_experiments.txt
   bool scalar_bitmaps = false;
+  bool bitmaps_last = false;   // issue the bitmap-word loads behind the value loads (GDV_BITMAPS_LAST)
+  int waves_per_eu = 0;        // > 0: amdgpu_waves_per_eu(n, n) on fixed-width kernels (GDV_WPE): lets the compiler keep every load in flight
   bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
   static CodegenOptions FromEnv();
   std::string Key() const;

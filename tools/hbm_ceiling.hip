@@ -51,6 +51,46 @@ __global__ void __launch_bounds__(256) k_read8x2(const u64* __restrict__ p, cons
   }
   if (acc == 0x1234567) out[0] = acc;
 }
+// the filter's predicate kernel, rebuilt step by step on top of the bare access shape:
+//   STEP 1: compare + ballot + match-word store + per-tile count     STEP 2: + validity-word loads
+template <int U, int STEP>
+__global__ void __launch_bounds__(256) k_pred(const long long* __restrict__ p, const long long* __restrict__ q, size_t n,
+                                              const u64* __restrict__ ones, u64* __restrict__ mask, unsigned* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const size_t nwt = n / (64 * U);
+  for (size_t wt = (size_t)blockIdx.x * 4 + wave; wt < nwt; wt += (size_t)gridDim.x * 4) {
+    const size_t rbase = wt * 64 * U;
+    long long a[U], b[U];
+    u64 vw0 = ~0ull, vw1 = ~0ull;
+    if (STEP >= 2) {  // one vector load per column: lane u <-> word u (clamped to the one all-ones word)
+      const u64 lo0 = ones[0], hi0 = ones[0], lo1 = ones[0], hi1 = ones[0];
+      vw0 = (lo0 >> 0) | ((hi0 << 1) << 63);
+      vw1 = (lo1 >> 0) | ((hi1 << 1) << 63);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      a[u] = __builtin_nontemporal_load(p + rbase + 64 * u + lane);
+      b[u] = __builtin_nontemporal_load(q + rbase + 64 * u + lane);
+    }
+    u64 acc = 0;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      bool ok = a[u] > 499 && b[u] < 250;
+      if (STEP >= 2) {
+        const u64 v0 = ((u64)(unsigned)__builtin_amdgcn_readlane((unsigned)(vw0 >> 32), u) << 32) | (unsigned)__builtin_amdgcn_readlane((unsigned)vw0, u);
+        const u64 v1 = ((u64)(unsigned)__builtin_amdgcn_readlane((unsigned)(vw1 >> 32), u) << 32) | (unsigned)__builtin_amdgcn_readlane((unsigned)vw1, u);
+        ok = ok && ((v0 >> lane) & 1) && ((v1 >> lane) & 1);
+      }
+      const u64 fm = __ballot(ok);
+      cnt += __popcll(fm);
+      acc = lane == u ? fm : acc;
+    }
+    if (lane < U) mask[wt * U + lane] = acc;
+    if (lane == 0) counts[wt] = cnt;
+  }
+}
 template <int U>
 __global__ void __launch_bounds__(256) k_write(u64x2* __restrict__ p, size_t n, u64 val) {
   size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
@@ -89,6 +129,16 @@ int main() {
   u64x2 *a, *b; u64* out;
   CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&out, 8));
   CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+  u64 *ones, *mask; unsigned* counts;
+  CK(hipMalloc(&ones, 256)); CK(hipMemset(ones, 0xff, 256));
+  CK(hipMalloc(&mask, bytes / 64 + 1024)); CK(hipMalloc(&counts, bytes / 8 / 1024 * 4 + 1024));
+  for (int g : {2048}) {
+    const size_t rows = (size_t)1000000000;
+    double s1 = timeit([&] { hipLaunchKernelGGL((k_pred<16, 1>), dim3(g), dim3(256), 0, 0, (const long long*)a, (const long long*)b, rows, ones, mask, counts); });
+    double s2 = timeit([&] { hipLaunchKernelGGL((k_pred<16, 2>), dim3(g), dim3(256), 0, 0, (const long long*)a, (const long long*)b, rows, ones, mask, counts); });
+    printf("predicate kernel rebuilt by hand, 10^9 rows x 2 int64 columns (16 GB): compare+ballot+stores %.3f ms = %.2f TB/s | + validity-word loads %.3f ms = %.2f TB/s\n",
+           s1, 16e9 / s1 / 1e9 * 1e-3 * 1e3, s2, 16e9 / s2 / 1e9 * 1e-3 * 1e3);
+  }
   for (int g : {2048, 4096, 8192}) {
     double r = timeit([&] { hipLaunchKernelGGL((k_read<8>), dim3(g), dim3(256), 0, 0, a, n, out); });
     double w = timeit([&] { hipLaunchKernelGGL((k_write<8>), dim3(g), dim3(256), 0, 0, b, n, 7ull); });

@@ -1,7 +1,5 @@
 export GDV_NO_DISK_CACHE=1
-run() { echo "--- $1"; env $2 GDV_TRACE=1 python bench.py --workload c5 --no-cpu-baseline --steps 8 --warmup 2 2>&1 | grep -E "^\[gdv\]|rror" | tail -1 | cut -c1-100; }
-for i in 1 2 3; do
-run "aligned copies (head/tail bytes)" "X=1"
-run "unaligned copies" "GDV_RTC_OPT=-DGDV_COPY_UNALIGNED=1"
-done
-GDV_RTC_OPT=-DGDV_COPY_UNALIGNED=1 timeout 300 python -m pytest tests/test_golden.py "tests/test_strings.py::test_hip_strings_match_oracle" -m gpu -x -q 2>&1 | tail -1
+one() { env $2 python bench.py --workload $1 --no-cpu-baseline --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])"; }
+for w in c3 c2; do for i in 1 2; do
+  echo "$w plain word stores $(one $w X=1) | non-temporal $(one $w GDV_RTC_OPT=-DGDV_WORD_NT=1)"
+done; done
