@@ -1400,6 +1400,11 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
 
   // ---- var-len outputs
   if (nv > 0) {
+    // every var-len output is a flat candidate: the optimistic variant needs no totals, no scanner
+    // and no barrier at all — offsets and bytes are already out
+    bool all_flat = true;
+    for (auto& vo : cg.varlen_outs_) all_flat = all_flat && vo.flat_slot >= 0;
+    if (all_flat) s << "  if (!optflat) {  // (all outputs flat: this whole block exists in the general variant only)\n";
     s << "  // ---- var-len outputs: workgroup totals -> one granule to the scanner\n"
       << "  if (lane == 0) {\n";
     for (int v = 0; v < nv; v++)
@@ -1448,7 +1453,9 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       s << "        dir" << E << " = true;\n        dbase" << E << " = base;\n        need_direct = true;\n"
         << "      }\n    }\n  }\n";
     }
-    s << "  if ((gdv_int64)gridDim.x - 1 < ntiles) __syncthreads();  // serial-safe launches only: the LDS hand-off words are reused by the next tile\n"
+    s << "  if ((gdv_int64)gridDim.x - 1 < ntiles) __syncthreads();  // serial-safe launches only: the LDS hand-off words are reused by the next tile\n";
+    if (all_flat) s << "  }\n";
+    s
       << "  }  // pass\n";
   }
   s << "}\n\n";
@@ -1468,7 +1475,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       << "  if (blockIdx.x == 0) {\n"
       << "    if (wave == 0) {\n"
       << "      gdv_uint64* const totals = (gdv_uint64*)A.counts;\n"
-      << "      gdv_scanner<GDV_NG>(A.mask, A.mask + (gdv_int64)GDV_NG * ntiles, ntiles, totals, A.err, lane);\n"
+      << "      " << (plan->has_flat_output && [&] { for (auto& vo : cg.varlen_outs_) if (vo.flat_slot < 0) return false; return true; }() ? "if (!GDV_OPTFLAT) " : "")
+      << "gdv_scanner<GDV_NG>(A.mask, A.mask + (gdv_int64)GDV_NG * ntiles, ntiles, totals, A.err, lane);\n"
       << "      if (lane == 0) {\n";
     for (int v = 0; v < nv; v++) {
       const VarlenOut& vo = cg.varlen_outs_[v];
