@@ -663,6 +663,34 @@ GDV_TSADD(timestamp)
   }
 GDV_TSDIFF(date64)
 GDV_TSDIFF(timestamp)
+// timestampdiffMonth / Quarter / Year(start, end): whole calendar months from start to end,
+// counted on (start, end) swapped into ascending order and negated afterwards.  The last month
+// counts when the end's day of month has reached the start's — or the end IS the last day of its
+// month (Jan 31 -> Feb 28 is one month) — and, on the same day of month, when the end's time of
+// day (whole seconds) has reached the start's.
+GDV_DEV gdv_int32 gdv_months_between(gdv_int64 s, gdv_int64 e) {
+  const bool fwd = e > s;
+  if (!fwd) { const gdv_int64 t = s; s = e; e = t; }
+  const gdv_int64 sday = gdv_floor_div(s, GDV_MILLIS_IN_DAY), eday = gdv_floor_div(e, GDV_MILLIS_IN_DAY);
+  const gdv_ymd a = gdv_civil_from_days(sday), b = gdv_civil_from_days(eday);
+  gdv_int32 m = (gdv_int32)(12 * (b.y - a.y) + (b.m - a.m));
+  if (b.d < a.d) {
+    m -= b.d == gdv_last_day_of_month(b.y, b.m) ? 0 : 1;
+  } else if (b.d == a.d) {
+    m -= (e - eday * GDV_MILLIS_IN_DAY) / 1000 >= (s - sday * GDV_MILLIS_IN_DAY) / 1000 ? 0 : 1;
+  }
+  return fwd ? m : -m;
+}
+#define GDV_TSDIFF_MONTHS(T)                                                                      \
+  GDV_DEV gdv_int32 timestampdiffMonth_##T##_##T(gdv_##T s, gdv_##T e) { return gdv_months_between(s, e); } \
+  GDV_DEV gdv_int32 timestampdiffQuarter_##T##_##T(gdv_##T s, gdv_##T e) {                        \
+    return gdv_months_between(s, e) / 3;                                                          \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffYear_##T##_##T(gdv_##T s, gdv_##T e) {                           \
+    return gdv_months_between(s, e) / 12;                                                         \
+  }
+GDV_TSDIFF_MONTHS(date64)
+GDV_TSDIFF_MONTHS(timestamp)
 GDV_DEV gdv_int32 datediff_date32_date32(gdv_date32 e, gdv_date32 s) {
   return (gdv_int32)((gdv_uint32)e - (gdv_uint32)s);
 }
@@ -987,6 +1015,13 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 // contiguous byte span of a wave tile with lanes over BYTES (16 B/lane, coalesced): that pass
 // answers the tile-wide questions byte-parallel (is every byte ASCII?  where does '%needle%'
 // match?) and leaves the lines in L2 / L1 for the per-row functions below.
+// Two kinds of value are not plain views (round 2, registry tail): `map & GDV_MAP_REVERSE` — the
+// characters of the view in reverse order — and `map & GDV_MAP_DIGITS` — the decimal digits of the
+// integer stored in `p`, cut to `len` bytes.  Only the copy stage of a var-len output can read
+// them (the planner rejects every other consumer), so the readers below never see these bits.
+#define GDV_MAP_CASE 3
+#define GDV_MAP_REVERSE 4
+#define GDV_MAP_DIGITS 8
 #define GDV_STR_ASCII 1  // flags: every byte of the buffer range this view came from is < 0x80
 #define GDV_STR_INBUF 2  // flags: 8-byte loads starting anywhere inside the view stay inside its buffer
 // (out-of-line device functions fault on this stack — measured, profiles/r02_c5_codesize.txt —
@@ -1063,10 +1098,79 @@ GDV_DEV gdv_uint64 gdv_raw_word_at(const gdv_str& s, gdv_int32 i) {
 GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
   return gdv_map8(gdv_raw_word_at(s, i), s.map);
 }
+// ---- copies of the two non-view kinds (P: pointer into HBM or into the LDS staging window)
+GDV_DEV gdv_int32 gdv_utf8_declared_len(gdv_uint8 c) {  // bytes the lead byte announces; 0: not a lead byte
+  if (c < 0x80) return 1;
+  if ((c & 0xE0) == 0xC0) return 2;
+  if ((c & 0xF0) == 0xE0) return 3;
+  if ((c & 0xF8) == 0xF0) return 4;
+  return 0;
+}
+template <typename P>
+GDV_DEV void gdv_store_low_bytes(P dst, gdv_uint64 w, gdv_int32 r) {  // the low r (0..7) bytes of w
+  gdv_int32 i = 0;
+  if (r & 4) { const gdv_uint32 v = (gdv_uint32)w; __builtin_memcpy(dst, &v, 4); i = 4; w >>= 32; }
+  if (r & 2) { const gdv_uint16 v = (gdv_uint16)w; __builtin_memcpy(dst + i, &v, 2); i += 2; w >>= 16; }
+  if (r & 1) dst[i] = (gdv_uint8)w;
+}
+template <typename P>
+GDV_DEV void gdv_copy_reversed(P dst, const gdv_str& s) {
+  const gdv_int32 len = s.len, cm = s.map & GDV_MAP_CASE;
+  if (s.flags & GDV_STR_ASCII) {
+    // output byte i is source byte len-1-i: 8 at a time from the end, byte-swapped
+    gdv_int32 i = 0;
+    for (; i + 8 <= len; i += 8) {
+      const gdv_uint64 w = __builtin_bswap64(gdv_map8(gdv_load8_raw(s.p + (len - i - 8)), cm));
+      __builtin_memcpy(dst + i, &w, 8);
+    }
+    const gdv_int32 r = len - i;  // source bytes [0, r) are left
+    if (r > 0) {
+      gdv_str head = s;
+      head.map = 0;
+      gdv_store_low_bytes(dst + i, __builtin_bswap64(gdv_map8(gdv_raw_word_at(head, 0), cm) << (8 * (8 - r))), r);
+    }
+    return;
+  }
+  // characters keep their byte order; a character is what its lead byte announces
+  for (gdv_int32 i = 0; i < len;) {
+    gdv_int32 cl = gdv_utf8_declared_len(s.p[i]);
+    if (cl == 0) cl = 1;
+    if (cl > len - i) cl = len - i;
+    for (gdv_int32 j = 0; j < cl; j++) dst[len - i - cl + j] = gdv_map_byte(s.p[i + j], cm);
+    i += cl;
+  }
+}
+GDV_DEV gdv_int32 gdv_count_digits(gdv_uint64 v) {
+  gdv_int32 n = 1;
+  for (gdv_uint64 p = 10; n < 20 && v >= p; p *= 10) n++;
+  return n;
+}
+template <typename P>
+GDV_DEV void gdv_copy_digits(P dst, const gdv_str& s) {
+  const gdv_int64 v = (gdv_int64)(gdv_uint64)s.p;
+  const gdv_int32 neg = v < 0 ? 1 : 0;
+  gdv_uint64 mag = neg ? 0ull - (gdv_uint64)v : (gdv_uint64)v;
+  const gdv_int32 total = gdv_count_digits(mag) + neg;
+  gdv_uint64 w0 = neg ? (gdv_uint64)'-' : 0ull, w1 = 0, w2 = 0;  // the text, left-aligned in 24 bytes
+  for (gdv_int32 k = total - 1; k >= neg; k--) {
+    const gdv_uint64 b = (gdv_uint64)('0' + (gdv_int32)(mag % 10)) << (8 * (k & 7));
+    mag /= 10;
+    if (k < 8) w0 |= b; else if (k < 16) w1 |= b; else w2 |= b;
+  }
+  const gdv_int32 len = s.len;  // <= total
+  if (len >= 8) __builtin_memcpy(dst, &w0, 8); else gdv_store_low_bytes(dst, w0, len);
+  if (len >= 16) __builtin_memcpy(dst + 8, &w1, 8); else if (len > 8) gdv_store_low_bytes(dst + 8, w1, len - 8);
+  if (len > 16) gdv_store_low_bytes(dst + 16, w2, len - 16 > 7 ? 7 : len - 16);
+}
+template <typename P>
+GDV_DEV void gdv_copy_special(P dst, const gdv_str& s) {
+  if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s); else gdv_copy_reversed(dst, s);
+}
 // Copy with as few (scattered) store instructions as possible: whole words, then ONE
 // overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
 // 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
+  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS)) { gdv_copy_special(dst, s); return; }
   if (s.len >= 8) {
     gdv_int32 i = 0;
     for (; i + 8 <= s.len; i += 8) {
@@ -1093,6 +1197,7 @@ GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
 // One row's bytes into the wave's LDS staging window: whole words, then a 4/2/1 ladder.
 typedef __attribute__((address_space(3))) gdv_uint8 gdv_lds_u8;
 GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
+  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS)) { gdv_copy_special(dst, s); return; }
   const gdv_int32 len = s.len;
   gdv_int32 i = 0;
   for (; i + 8 <= len; i += 8) {
@@ -1384,6 +1489,52 @@ GDV_DEV gdv_str castVARCHAR_utf8_int64(gdv_ctx ctx, gdv_str s, gdv_int64 n) {
   if (n < 0) { gdv_raise(ctx, GDV_ERR_BAD_ARG); r.len = 0; return r; }
   if (n >= s.len) return r;  // bytes >= characters
   r.len = gdv_utf8_byte_pos(s, (gdv_int32)n);
+  return r;
+}
+// castVARCHAR(integer, n): the decimal text of the value, cut to n bytes; n < 0 is an execution error
+GDV_DEV gdv_str castVARCHAR_int64_int64(gdv_ctx ctx, gdv_int64 v, gdv_int64 n) {
+  gdv_str r = gdv_empty_str();
+  if (n < 0) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return r; }
+  const gdv_int32 total = gdv_count_digits(v < 0 ? 0ull - (gdv_uint64)v : (gdv_uint64)v) + (v < 0 ? 1 : 0);
+  r.p = (const gdv_uint8*)(gdv_uint64)v;
+  r.len = n < total ? (gdv_int32)n : total;
+  r.map = GDV_MAP_DIGITS;
+  return r;
+}
+GDV_DEV gdv_str castVARCHAR_int32_int64(gdv_ctx ctx, gdv_int32 v, gdv_int64 n) {
+  return castVARCHAR_int64_int64(ctx, (gdv_int64)v, n);
+}
+// reverse(s): the characters of s in reverse order.  A character is what its lead byte announces
+// (1-4 bytes); a byte that cannot lead a character, or a character cut by the end of the string,
+// is an execution error.
+GDV_DEV gdv_str reverse_utf8(gdv_ctx ctx, gdv_str s) {
+  if (!gdv_str_is_ascii(s)) {
+    for (gdv_int32 i = 0; i < s.len;) {
+      const gdv_int32 cl = gdv_utf8_declared_len(s.p[i]);
+      if (cl == 0 || i + cl > s.len) { gdv_raise(ctx, GDV_ERR_BAD_ARG); s.len = 0; break; }
+      i += cl;
+    }
+  }
+  s.map |= GDV_MAP_REVERSE;
+  return s;
+}
+// lpad / rpad(text, n, fill): the result is two pieces, written back to back by the output copy —
+// the text cut to n characters, and the first n - chars(text) characters of `tab` = fill repeated
+// to n characters (n and fill are literals: the planner lays the table out in the constant
+// block).  An empty text or n <= 0 gives "", an empty fill leaves the text as it is.
+GDV_DEV gdv_str gdv_pad_text(gdv_str s, gdv_int32 n) {
+  if (s.len <= 0 || n <= 0) { s.len = 0; return s; }
+  if (n < s.len) s.len = gdv_utf8_byte_pos(s, n);  // (n >= bytes >= characters: nothing to cut)
+  return s;
+}
+GDV_DEV gdv_str gdv_pad_fill(const gdv_str& s, gdv_int32 n, const gdv_uint8* tab, gdv_int32 tab_len,
+                             bool tab_ascii) {
+  gdv_str r = gdv_make_str(tab, 0, 0, tab + tab_len + 8, GDV_STR_INBUF | (tab_ascii ? GDV_STR_ASCII : 0));
+  if (s.len <= 0 || n <= 0 || tab_len == 0) return r;
+  const gdv_int32 pad = n - gdv_utf8_count(s);
+  if (pad <= 0) return r;
+  r.len = tab_len;
+  r.len = gdv_utf8_byte_pos(r, pad);
   return r;
 }
 // locate(sub, str[, start]): 1-based character position of the first occurrence of sub in

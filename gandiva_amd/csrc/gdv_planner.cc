@@ -227,6 +227,9 @@ struct Val {
   // paths (sweep-answered '%needle%', flat output copy).  -1: anything else.
   int col_slot = -1;
   int col_map = 0;
+  // reverse() and castVARCHAR(integer) results are not readable views (GDV_MAP_REVERSE /
+  // GDV_MAP_DIGITS): like concat results, only the output copy or a concat can take them
+  bool opaque = false;
   bool never_null() const { return vcols.empty() && vlane.empty(); }
 };
 
@@ -481,7 +484,8 @@ class CodeGen {
 // functions whose fast path is "the string is pure ASCII" (character index == byte index)
 bool WantsAsciiHint(const std::string& name) {
   static const std::set<std::string> k = {"substr", "substring", "left", "right", "char_length", "length",
-                                          "lengthUtf8", "castVARCHAR", "locate", "strpos", "like"};
+                                          "lengthUtf8", "castVARCHAR", "locate", "strpos", "like",
+                                          "reverse", "lpad", "rpad"};
   return k.count(name) != 0;
 }
 
@@ -551,6 +555,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->pieces.clear();
       out->col_slot = -1;
       out->col_map = 0;
+      out->opaque = fn.name() == "reverse" || (fn.name() == "castVARCHAR" && !args[0].type.is_varlen());
       if ((fn.name() == "upper" || fn.name() == "lower") && args.size() == 1 && args[0].col_slot >= 0) {
         out->col_slot = args[0].col_slot;
         out->col_map = fn.name() == "upper" ? 1 : 2;
@@ -562,10 +567,53 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       const std::string ctype = out->type.CType();
       const bool is_concat = fn.name() == "concat" || fn.name() == "concatOperator";
       for (auto& a : args)
-        if (!a.pieces.empty() && !is_concat)
+        if ((!a.pieces.empty() || a.opaque) && !is_concat)
           return Status::CodeGenError("Function " + fn.ToString() +
-                                      " not supported yet: a concat result can only be an output "
-                                      "expression or an argument of concat in the HIP backend. ");
+                                      " not supported yet: a concat / lpad / rpad / reverse / castVARCHAR(number) "
+                                      "result can only be an output expression or an argument of concat in the "
+                                      "HIP backend. ");
+      if (fn.name() == "lpad" || fn.name() == "rpad") {
+        // lpad / rpad(text, n[, fill]) with LITERAL n and fill: two pieces (device library), the
+        // fill repeated to n characters laid out once in the constant block
+        const Node& nn = *fn.children()[1];
+        const Node* fl = fn.children().size() == 3 ? fn.children()[2].get() : nullptr;
+        if (nn.kind() != NodeKind::kLiteral || (fl != nullptr && fl->kind() != NodeKind::kLiteral))
+          return Status::CodeGenError("Function " + fn.ToString() +
+                                      " not supported yet: the HIP backend takes lpad / rpad with a literal "
+                                      "length and a literal fill only. ");
+        auto& nl = static_cast<const LiteralNode&>(nn);
+        const bool null_lit = nl.is_null() || (fl != nullptr && static_cast<const LiteralNode*>(fl)->is_null());
+        const int32_t n = null_lit ? 0 : static_cast<int32_t>(nl.value().lo);
+        if (n > (1 << 16))
+          return Status::CodeGenError("Function " + fn.ToString() +
+                                      " not supported yet: pad lengths above 65536 characters. ");
+        const std::string fill = fl != nullptr ? static_cast<const LiteralNode*>(fl)->value().bytes : " ";
+        // characters of the fill = runs starting at a non-continuation byte
+        std::vector<std::string> chars;
+        for (unsigned char c : fill) {
+          if (chars.empty() || (c & 0xC0) != 0x80) chars.emplace_back();
+          chars.back().push_back(static_cast<char>(c));
+        }
+        std::string tab;
+        bool ascii = true;
+        for (int32_t k = 0; k < n && !chars.empty(); k++) tab += chars[k % chars.size()];
+        for (unsigned char c : tab) ascii = ascii && c < 0x80;
+        const std::string N = std::to_string(n);
+        const std::string text = Tmp("gdv_str", "gdv_pad_text(" + args[0].v + ", " + N + ")");
+        const std::string pad = Tmp("gdv_str", "gdv_pad_fill(" + args[0].v + ", " + N + ", " + ByteTable(tab) + ", " +
+                                                   std::to_string(tab.size()) + ", " + (ascii ? "true" : "false") + ")");
+        if (fn.name() == "lpad") {
+          out->pieces.emplace_back(pad, "");
+          out->pieces.emplace_back(text, "");
+        } else {
+          out->pieces.emplace_back(text, "");
+          out->pieces.emplace_back(pad, "");
+        }
+        out->vcols = args[0].vcols;
+        out->vlane = null_lit ? "false" : args[0].vlane;
+        out->v = "gdv_empty_str()";  // never read: consumers use the pieces
+        return Status::OK();
+      }
       if (is_concat) {
         // concat: a null argument is the empty string, the result is never null;
         // concatOperator (||): null if any argument is null
@@ -710,12 +758,15 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       std::string take = Tmp("bool", AndFull(LaneValid(c), c.v));
       GDV_RETURN_NOT_OK(Gen(*n.then_node(), AndExpr(active, take), &t));
       GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
-      if (!t.pieces.empty() || !e.pieces.empty())
-        return Status::CodeGenError("if/else over a concat result is not supported by the HIP backend yet");
+      if (!t.pieces.empty() || !e.pieces.empty() || t.opaque || e.opaque)
+        return Status::CodeGenError(
+            "if/else over a concat / lpad / rpad / reverse / castVARCHAR(number) result is not supported by the HIP "
+            "backend yet");
       out->type = n.return_type();
       const std::string ctype = out->type.CType();
       out->pieces.clear();
       out->col_slot = -1;
+      out->opaque = false;
       out->v = Tmp(ctype, take + " ? " + t.v + " : " + e.v);
       out->vcols.clear();
       if (t.never_null() && e.never_null()) {
@@ -762,8 +813,9 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       auto& n = static_cast<const InNode&>(node);
       Val x;
       GDV_RETURN_NOT_OK(Gen(*n.eval(), active, &x));
-      if (!x.pieces.empty())
-        return Status::CodeGenError("IN over a concat result is not supported by the HIP backend yet");
+      if (!x.pieces.empty() || x.opaque)
+        return Status::CodeGenError(
+            "IN over a concat / lpad / rpad / reverse / castVARCHAR(number) result is not supported by the HIP backend yet");
       out->pieces.clear();
       out->col_slot = -1;
       out->type = boolean();

@@ -206,7 +206,8 @@ FunctionRegistry::FunctionRegistry() {
     add("date_add", {t, int32()}, t);
     add("date_sub", {t, int32()}, t);
     for (const char* f : {"timestampdiffSecond", "timestampdiffMinute", "timestampdiffHour",
-                          "timestampdiffDay", "timestampdiffWeek"}) {
+                          "timestampdiffDay", "timestampdiffWeek", "timestampdiffMonth",
+                          "timestampdiffQuarter", "timestampdiffYear"}) {
       add(f, {t, t}, int32());
     }
     add("datediff", {t, t}, int32());
@@ -267,6 +268,14 @@ FunctionRegistry::FunctionRegistry() {
   add("left", {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("right", {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("castVARCHAR", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("castVARCHAR", {int32(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("castVARCHAR", {int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("reverse", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  // lpad / rpad: planned as two pieces (gdv_planner.cc), literal length and fill only
+  for (const char* f : {"lpad", "rpad"}) {
+    add(f, {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_pad");
+    add(f, {utf8(), int32(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_pad");
+  }
   add("locate", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
   add("locate", {utf8(), utf8(), int32()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
   add("strpos", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);

@@ -45,7 +45,14 @@
  *       newline; float -> integer casts saturate and send NaN to 0; divide / mod by zero raise
  *       "divide by zero error"; integer mod by zero returns the dividend; the decimal
  *       result-type rule (precision > 38 -> scale cut to max(s - delta, min(s, 6))); castINT /
- *       castBIGINT from text accept only [blank]* '-'? digit+ [blank]*; hash of null = seed.
+ *       castBIGINT from text accept only [blank]* '-'? digit+ [blank]*; hash of null = seed;
+ *       timestampdiffMonth / Quarter / Year (the "last month counts when the end's day of month
+ *       has reached the start's, or the end is the last day of its month; equal days compare the
+ *       time of day in whole seconds" rule — where it coincides with "largest k with start + k
+ *       months <= end" it is checked against dateutil, tests/test_registry_tail.py); lpad / rpad
+ *       giving "" for an empty text and leaving the text alone for an empty fill; reverse and
+ *       castVARCHAR(integer, n) raising on broken UTF-8 / n < 0 (their regular results are
+ *       checked against Python str and pyarrow.compute).
  *
  * Program format (whitespace separated, prefix order):
  *   F <col>                               field: column index
@@ -828,12 +835,69 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
         out->v[i].i = (int64_t)acc;
       } else if (!strcmp(f, "ascii")) {
         out->v[i].i = xl > 0 ? (int8_t)map_byte(x[0], xm) : 0;
+      } else if (!strcmp(f, "reverse")) {
+        /* characters in reverse order; a character is as long as its lead byte announces; a byte
+         * that cannot start a character, or a character cut off by the end, is an error
+         * [recalled: string_ops.cc reverse_utf8] */
+        int live = out->valid[i] && (!active || active[i]);
+        uint8_t* dst = arena_alloc(c, xl > 0 ? (size_t)xl : 1);
+        int bad = 0;
+        for (int k = 0; k < xl && !bad;) {
+          uint8_t b = x[k];
+          int cl = b < 0x80 ? 1 : (b & 0xE0) == 0xC0 ? 2 : (b & 0xF0) == 0xE0 ? 3 : (b & 0xF8) == 0xF0 ? 4 : 0;
+          if (cl == 0 || k + cl > xl) { bad = 1; break; }
+          for (int j = 0; j < cl; j++) dst[xl - k - cl + j] = map_byte(x[k + j], xm);
+          k += cl;
+        }
+        out->sp[i] = dst; out->sl[i] = bad ? 0 : xl; out->sm[i] = 0;
+        if (bad && live) c->err |= 4;
+      } else if (!strcmp(f, "lpad") || !strcmp(f, "rpad")) {
+        /* lpad / rpad(text, n[, fill = " "]) [recalled: string_ops.cc lpad_utf8_int32_utf8]:
+         * "" when the text is empty or n <= 0; the text cut to n characters when it has n or more;
+         * the text unchanged when the fill is empty; else the fill, repeated from its first
+         * character, fills the missing characters on the left / right */
+        int64_t want = a[1].v[i].i;
+        const uint8_t* fb = n->nargs == 3 ? a[2].sp[i] : (const uint8_t*)" ";
+        int fbl = n->nargs == 3 ? a[2].sl[i] : 1, fbm = n->nargs == 3 ? a[2].sm[i] : 0;
+        int chars = utf8_chars(x, xl);
+        out->sm[i] = 0;
+        if (!out->valid[i] || xl <= 0 || want <= 0) { out->sp[i] = x; out->sl[i] = 0; continue; }
+        if (want <= chars || fbl <= 0) {
+          int keep = want < chars ? utf8_byte_pos(x, xl, want) : xl;
+          out->sp[i] = x; out->sl[i] = keep; out->sm[i] = (uint8_t)xm;
+          continue;
+        }
+        int64_t pad = want - chars;
+        uint8_t* dst = arena_alloc(c, (size_t)xl + (size_t)pad * 4 + 1);
+        size_t at = 0;
+        if (f[0] == 'r') for (int k = 0; k < xl; k++) dst[at++] = map_byte(x[k], xm);
+        for (int64_t done = 0, k = 0; done < pad;) { /* one character of the fill at a time, cyclically */
+          if (k >= fbl) k = 0;
+          do { dst[at++] = map_byte(fb[k], fbm); k++; } while (k < fbl && !is_lead(fb[k]));
+          done++;
+        }
+        if (f[0] == 'l') for (int k = 0; k < xl; k++) dst[at++] = map_byte(x[k], xm);
+        out->sp[i] = dst; out->sl[i] = (int32_t)at;
       } else if (!strcmp(f, "ltrim") || !strcmp(f, "rtrim") || !strcmp(f, "btrim") || !strcmp(f, "trim")) {
         int lo = 0, hi = xl;
         if (f[0] != 'r') while (lo < hi && x[lo] == ' ') lo++;
         if (f[0] != 'l') while (hi > lo && x[hi - 1] == ' ') hi--;
         out->sp[i] = x + lo; out->sl[i] = hi - lo; out->sm[i] = (uint8_t)xm;
       } else { c->err |= 0x100; }
+    }
+  } else if (!strcmp(f, "castVARCHAR") && (t0 == T_I32 || t0 == T_I64)) {
+    /* decimal text of the value cut to n bytes; n < 0 is an error [recalled:
+     * gdv_function_stubs.cc CAST_VARCHAR_FROM_INT] */
+    for (int i = 0; i < cnt; i++) {
+      int live = out->valid[i] && (!active || active[i]);
+      int64_t k = a[1].v[i].i;
+      char buf[32];
+      int len = snprintf(buf, sizeof buf, "%lld", (long long)a[0].v[i].i);
+      uint8_t* dst = arena_alloc(c, 24);
+      memcpy(dst, buf, (size_t)len);
+      out->sp[i] = dst; out->sm[i] = 0;
+      if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
+      else out->sl[i] = k < len ? (int32_t)k : len;
     }
   } else if (t0 == T_DEC || n->type == T_DEC) {
     const int two = n->nargs == 2;
@@ -1047,6 +1111,30 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
   } else if (!strcmp(f, "date_add") || !strcmp(f, "date_sub")) {
     int sign = f[5] == 'a' ? 1 : -1;
     for (int i = 0; i < cnt; i++) out->v[i].i = a[0].v[i].i + sign * a[1].v[i].i * MS_DAY;
+  } else if (!strcmp(f, "timestampdiffMonth") || !strcmp(f, "timestampdiffQuarter") ||
+             !strcmp(f, "timestampdiffYear")) {
+    /* whole months from start to end [recalled: time.cc TIMESTAMP_DIFF_MONTH_UNITS]: the pair is
+     * put in ascending order, months = 12 * dy + dm, minus one when the last month is not
+     * complete — end day-of-month < start's unless the end is the last day of its month, or equal
+     * days and an earlier time of day (whole seconds) — then / 1, 3, 12 and the sign restored */
+    const int per = f[13] == 'M' ? 1 : f[13] == 'Q' ? 3 : 12;
+    for (int i = 0; i < cnt; i++) {
+      int64_t s0 = a[0].v[i].i, e0 = a[1].v[i].i;
+      int pos = e0 > s0;
+      if (!pos) { int64_t t = s0; s0 = e0; e0 = t; }
+      int64_t sd = floor_div(s0, MS_DAY), ed = floor_div(e0, MS_DAY), sy, ey;
+      int sm_, sdd, em_, edd;
+      civil_from_days(sd, &sy, &sm_, &sdd);
+      civil_from_days(ed, &ey, &em_, &edd);
+      int64_t months = 12 * (ey - sy) + (em_ - sm_);
+      if (edd < sdd) { if (edd != last_dom(ey, em_)) months--; }
+      else if (edd == sdd) {
+        int64_t es = (e0 - ed * MS_DAY) / 1000, ss = (s0 - sd * MS_DAY) / 1000;
+        if (es < ss) months--;
+      }
+      int64_t r = months / per;
+      out->v[i].i = (int32_t)(pos ? r : -r);
+    }
   } else if (!strncmp(f, "timestampdiff", 13)) {
     const char* unit = f + 13;
     int64_t div = !strcmp(unit, "Second") ? 1000 : !strcmp(unit, "Minute") ? 60000

@@ -187,4 +187,66 @@ void host_str_in(const int* off, const unsigned char* data, long size, long n, c
   for (long i = 0; i < n; i++) out[i] = gdv_in_strings(host_row(c, i), bytes, loffs, nlits);
 }
 
+// ---- registry tail (round 2): values that only the output copy can read, and the two-piece pads
+// reverse(s) materialised by gdv_str_copy; `ascii` sets the tile-wide ASCII flag the byte sweep
+// would have set (only ever pass 1 for all-ASCII buffers).  Returns the error bits.
+unsigned host_str_reverse(const int* off, const unsigned char* data, long size, long n, int map, int ascii,
+                          int* out_off, unsigned char* out_data) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    if (ascii) s.flags |= GDV_STR_ASCII;
+    if (map == 1) s = upper_utf8(s);
+    if (map == 2) s = lower_utf8(s);
+    const gdv_str r = reverse_utf8(ctx, s);
+    gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  return err;
+}
+// lpad (right = 0) / rpad (right = 1): `tab` is the fill repeated to `want` characters, readable
+// 8 bytes past its end (what the planner lays out in the constant block)
+long host_str_pad(int right, const int* off, const unsigned char* data, long size, long n, int want,
+                  const unsigned char* tab, int tab_len, int tab_ascii, int* out_off, unsigned char* out_data) {
+  HostCol c{off, data, size};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    const gdv_str s = host_row(c, i);
+    const gdv_str text = gdv_pad_text(s, want), pad = gdv_pad_fill(s, want, tab, tab_len, tab_ascii != 0);
+    const gdv_str& first = right ? text : pad;
+    const gdv_str& second = right ? pad : text;
+    if (first.len > 0) gdv_str_copy(out_data + at, first);
+    at += first.len;
+    if (second.len > 0) gdv_str_copy(out_data + at, second);
+    at += second.len;
+    out_off[i + 1] = (int)at;
+  }
+  return at;
+}
+unsigned host_cast_varchar_int64(const long long* v, long n, long long len, int* out_off, unsigned char* out_data) {
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    const gdv_str r = castVARCHAR_int64_int64(ctx, v[i], len);
+    gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  return err;
+}
+void host_months_between(const long long* s, const long long* e, long n, int unit, int* out) {
+  for (long i = 0; i < n; i++)
+    out[i] = unit == 0 ? timestampdiffMonth_timestamp_timestamp(s[i], e[i])
+           : unit == 1 ? timestampdiffQuarter_timestamp_timestamp(s[i], e[i])
+                       : timestampdiffYear_timestamp_timestamp(s[i], e[i]);
+}
+
 }  // extern "C"
