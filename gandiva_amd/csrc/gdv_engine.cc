@@ -434,6 +434,74 @@ LruCache<Filter>& FilterCache() {
 
 }  // namespace
 
+// ------------------------------------------------------------------ two-stage plans
+
+Status StageColumns::Run(const Projector& pre, int64_t num_rows, const ColumnBuffers* in, int num_cols,
+                         MemKind mem, hipStream_t stream) {
+  const int np = pre.num_outputs();
+  cols.assign(in, in + num_cols);
+  auto alloc = [&](int64_t bytes, void** p) -> Status {
+    bytes = std::max<int64_t>(bytes, 8);
+    if (mem == MemKind::kHost) {
+      host.emplace_back(new std::vector<uint8_t>(static_cast<size_t>(bytes)));
+      *p = host.back()->data();
+      return Status::OK();
+    }
+    dev.emplace_back(new DeviceBuffer());
+    GDV_RETURN_NOT_OK(dev.back()->Allocate(static_cast<size_t>(bytes)));
+    *p = dev.back()->get();
+    return Status::OK();
+  };
+  // first guess for the byte buffers: as many bytes as the var-len inputs hold plus 32 per row
+  // (device memory; the host path starts from nothing, it sizes its buffers by a length pass
+  // anyway).  The evaluation reports what it needs, so a short buffer costs one retry.
+  int64_t guess = 0;
+  if (mem == MemKind::kDevice) {
+    guess = 32 * num_rows;
+    for (int k = 0; k < num_cols; k++)
+      if (in[k].offsets != nullptr) guess += in[k].data_size;
+    guess = std::min<int64_t>(guess, (int64_t{1} << 31) - 64);
+  }
+  std::vector<OutputBuffers> po(np);
+  std::vector<int64_t> cap(np, guess);
+  const int64_t vbytes = mem == MemKind::kHost ? BytesForBits(num_rows) : Projector::ValidityBytes(num_rows);
+  for (int e = 0; e < np; e++) {
+    if (!pre.output_type(e).is_varlen()) return Status::Invalid("two-stage plan: first stage must produce utf8 / binary");
+    GDV_RETURN_NOT_OK(alloc(vbytes, &po[e].validity));
+    po[e].validity_size = std::max<int64_t>(vbytes, 8);
+    GDV_RETURN_NOT_OK(alloc((num_rows + 1) * 4, &po[e].offsets));
+    po[e].offsets_size = (num_rows + 1) * 4;
+    GDV_RETURN_NOT_OK(alloc(cap[e], &po[e].data));
+    po[e].data_size = cap[e];
+  }
+  Status s = pre.Evaluate(num_rows, in, num_cols, nullptr, po.data(), np, mem, stream, 0);
+  if (!s.ok()) {
+    bool grew = false;
+    for (int e = 0; e < np; e++) {
+      if (po[e].data_size > cap[e]) {
+        cap[e] = po[e].data_size;
+        GDV_RETURN_NOT_OK(alloc(cap[e], &po[e].data));
+        grew = true;
+      }
+      po[e].data_size = cap[e];
+    }
+    if (!grew) return s;
+    GDV_RETURN_NOT_OK(pre.Evaluate(num_rows, in, num_cols, nullptr, po.data(), np, mem, stream, 0));
+  }
+  for (int e = 0; e < np; e++) {
+    ColumnBuffers c;
+    c.validity = po[e].validity;
+    c.validity_size = po[e].validity_size;
+    c.offsets = po[e].offsets;
+    c.offsets_size = po[e].offsets_size;
+    c.data = po[e].data;
+    // (the allocation is never shorter than 8 bytes: what a device input needs to be readable)
+    c.data_size = mem == MemKind::kDevice ? std::max<int64_t>(po[e].data_size, 8) : po[e].data_size;
+    cols.push_back(c);
+  }
+  return Status::OK();
+}
+
 // ------------------------------------------------------------------ Projector
 
 Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
@@ -455,7 +523,21 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
   }
   auto p = std::make_shared<Projector>();
   p->schema_ = schema;
-  GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, opts, &p->plan_));
+  p->plan_schema_ = schema;
+  const std::vector<ExpressionPtr>* planned = &exprs;
+  StagedExpressions staged;
+  if (mode == SelectionMode::kNone) {
+    // (with a selection vector the first stage would have to run — and could raise — on rows the
+    // selection leaves out: such plans stay single-stage and the planner rejects them as before)
+    StageMaterialisedValues(schema, exprs, &staged);
+    if (!staged.pre.empty()) {
+      for (auto& e : exprs) GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));  // errors name the caller's trees
+      GDV_RETURN_NOT_OK(Projector::Make(schema, staged.pre, SelectionMode::kNone, config, &p->pre_));
+      p->plan_schema_ = staged.schema;
+      planned = &staged.main;
+    }
+  }
+  GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_));
   GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.source, p->plan_.kernel_name, &p->kernel_));
   GDV_RETURN_NOT_OK(UploadConstBlock(p->plan_, &p->consts_));
   ProjectorCache().Put(key, p);
@@ -492,10 +574,19 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   DeviceBuffer err;
   // var-len outputs: grand totals / per-tile granules of the in-kernel offsets scan
   DeviceBuffer tile_counts, tile_starts;
+  StageColumns stage;  // two-stage plans: the first stage's temporary columns (outlive the drain below)
   // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
-  StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
+  StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output || pre_ != nullptr};
+  if (pre_) {
+    if (num_cols != static_cast<int>(schema_.size()))
+      return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
+                             ") does not match the schema (" + std::to_string(schema_.size()) + ")");
+    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream));
+    cols = stage.cols.data();
+    num_cols = static_cast<int>(stage.cols.size());
+  }
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
-  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   BindLiterals(plan_, consts_, &args);
   // pooled staging blocks (e.g. the zero-padded copy of a tiny var-len buffer) go back to the
   // pool when this call returns: an asynchronous evaluation must not outlive them
@@ -684,7 +775,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
         GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
                                              hipMemcpyDeviceToHost, stream));
   }
-  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync);
+  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync) || pre_ != nullptr;
   if (must_sync) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
   if (mem == MemKind::kHost) st.Deliver();
@@ -706,7 +797,17 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   }
   auto f = std::make_shared<Filter>();
   f->schema_ = schema;
-  GDV_RETURN_NOT_OK(PlanFilter(schema, condition, opts, &f->plan_));
+  f->plan_schema_ = schema;
+  ExpressionPtr planned = condition;
+  StagedExpressions staged;
+  StageMaterialisedValues(schema, {condition}, &staged);
+  if (!staged.pre.empty()) {
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
+    GDV_RETURN_NOT_OK(Projector::Make(schema, staged.pre, SelectionMode::kNone, config, &f->pre_));
+    f->plan_schema_ = staged.schema;
+    planned = staged.main[0];
+  }
+  GDV_RETURN_NOT_OK(PlanFilter(f->plan_schema_, planned, opts, &f->plan_));
   GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(f->plan_.source, f->plan_.kernel_name, &f->kernel_));
   GDV_RETURN_NOT_OK(UploadConstBlock(f->plan_, &f->consts_));
   FilterCache().Put(key, f);
@@ -735,9 +836,18 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   ArgBlock args(plan_.layout);
   Staging st;
   DeviceBuffer mask, counts, offsets, chunk_sums, total, err, staged_out;
+  StageColumns stage;  // two-stage plans: the first stage's temporary columns
   StreamDrain drain{stream, true};  // declared last: drains before any pooled block is freed
+  if (pre_) {
+    if (num_cols != static_cast<int>(schema_.size()))
+      return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
+                             ") does not match the schema (" + std::to_string(schema_.size()) + ")");
+    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream));
+    cols = stage.cols.data();
+    num_cols = static_cast<int>(stage.cols.size());
+  }
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
-  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   BindLiterals(plan_, consts_, &args);
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
@@ -790,7 +900,15 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
 Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
                            SelectionMode mode) {
   KernelPlan plan;
-  GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));
+  StagedExpressions staged;
+  if (mode == SelectionMode::kNone) StageMaterialisedValues(schema, exprs, &staged);
+  if (!staged.pre.empty()) {
+    for (auto& e : exprs) GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+    GDV_RETURN_NOT_OK(PrecompileProjector(schema, staged.pre, SelectionMode::kNone));
+    GDV_RETURN_NOT_OK(PlanProjector(staged.schema, staged.main, mode, CodegenOptions::FromEnv(), &plan));
+  } else {
+    GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));
+  }
   std::vector<char> code;
   GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code));
   // the variant without the optimistic flat path is otherwise compiled only when a batch needs it
@@ -801,7 +919,15 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
 
 Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition) {
   KernelPlan plan;
-  GDV_RETURN_NOT_OK(PlanFilter(schema, condition, CodegenOptions::FromEnv(), &plan));
+  StagedExpressions staged;
+  StageMaterialisedValues(schema, {condition}, &staged);
+  if (!staged.pre.empty()) {
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
+    GDV_RETURN_NOT_OK(PrecompileProjector(schema, staged.pre, SelectionMode::kNone));
+    GDV_RETURN_NOT_OK(PlanFilter(staged.schema, staged.main[0], CodegenOptions::FromEnv(), &plan));
+  } else {
+    GDV_RETURN_NOT_OK(PlanFilter(schema, condition, CodegenOptions::FromEnv(), &plan));
+  }
   std::vector<char> code;
   return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
 }

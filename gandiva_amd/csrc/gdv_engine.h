@@ -70,9 +70,10 @@ class Projector {
 
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }
+  const std::shared_ptr<Projector>& first_stage() const { return pre_; }
   int num_outputs() const { return static_cast<int>(plan_.output_types.size()); }
   const DataType& output_type(int i) const { return plan_.output_types[i]; }
-  std::string DumpIR() const { return plan_.ir; }
+  std::string DumpIR() const { return pre_ ? pre_->DumpIR() + plan_.ir : plan_.ir; }
 
   static int64_t ValidityBytes(int64_t rows) { return ((rows + 63) / 64) * 8; }
   static int64_t DataBytes(const DataType& t, int64_t rows) {
@@ -86,6 +87,20 @@ class Projector {
   mutable std::atomic<const CompiledKernel*> kernel_general_{nullptr};  // without the optimistic flat path (lazy)
   mutable std::atomic<bool> prefer_general_{false};  // a batch raised NOTFLAT: stop trying the optimistic variant
   DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
+  // two-stage plans (StageMaterialisedValues): pre_ materialises the hoisted sub-trees as
+  // temporary columns, plan_ is built over plan_schema_ = schema_ + those columns
+  std::shared_ptr<Projector> pre_;
+  Schema plan_schema_;
+};
+
+// Temporary columns of a two-stage plan: the first-stage Projector's outputs, kept in the
+// memory kind of the call, appended to the caller's columns for the second stage.
+struct StageColumns {
+  std::vector<std::unique_ptr<DeviceBuffer>> dev;
+  std::vector<std::unique_ptr<std::vector<uint8_t>>> host;
+  std::vector<ColumnBuffers> cols;  // caller's columns + the temporaries
+  Status Run(const Projector& pre, int64_t num_rows, const ColumnBuffers* in, int num_cols, MemKind mem,
+             hipStream_t stream);
 };
 
 class Filter {
@@ -101,13 +116,16 @@ class Filter {
 
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }
-  std::string DumpIR() const { return plan_.ir; }
+  const std::shared_ptr<Projector>& first_stage() const { return pre_; }
+  std::string DumpIR() const { return pre_ ? pre_->DumpIR() + plan_.ir : plan_.ir; }
 
  private:
   Schema schema_;
   KernelPlan plan_;
   const CompiledKernel* kernel_ = nullptr;
   DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
+  std::shared_ptr<Projector> pre_;  // two-stage plans, as in Projector
+  Schema plan_schema_;
 };
 
 // Builds the plan and compiles it to a gfx950 code object without touching a device

@@ -1769,4 +1769,96 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
                   after.str());
 }
 
+// ------------------------------------------------------------------ two-stage plans
+
+namespace {
+
+bool MaterialisesBytes(const Node& n) {
+  if (n.kind() != NodeKind::kFunction) return false;
+  auto& fn = static_cast<const FunctionNode&>(n);
+  const std::string& f = fn.name();
+  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse") return true;
+  return f == "castVARCHAR" && !fn.children().empty() && !fn.children()[0]->return_type().is_varlen();
+}
+
+struct Stager {
+  const Schema& schema;
+  StagedExpressions* out;
+  std::map<std::string, NodePtr> field_of;  // hoisted sub-tree (cache key) -> its temporary field
+
+  NodePtr Hoist(const NodePtr& n) {
+    std::string key;
+    n->AppendKey(&key);
+    auto it = field_of.find(key);
+    if (it != field_of.end()) return it->second;
+    Field f;
+    f.name = "__gdv_stage" + std::to_string(out->pre.size());
+    f.type = n->return_type();
+    f.nullable = true;
+    out->pre.push_back(std::make_shared<Expression>(n, f));
+    out->schema.push_back(f);
+    NodePtr field = std::make_shared<FieldNode>(f);
+    field_of[key] = field;
+    return field;
+  }
+  // `takes_bytes`: the parent is an output root or a concat — it can take a materialising child as it is
+  NodePtr Rewrite(const NodePtr& n, bool takes_bytes) {
+    if (MaterialisesBytes(*n) && !takes_bytes) return Hoist(n);  // (its own sub-tree is the first stage's business)
+    switch (n->kind()) {
+      case NodeKind::kFunction: {
+        auto& fn = static_cast<const FunctionNode&>(*n);
+        const bool is_concat = fn.name() == "concat" || fn.name() == "concatOperator";
+        NodeVector kids;
+        bool changed = false;
+        for (auto& c : fn.children()) {
+          kids.push_back(Rewrite(c, is_concat));
+          changed |= kids.back() != c;
+        }
+        return changed ? std::make_shared<FunctionNode>(fn.name(), kids, fn.return_type()) : n;
+      }
+      case NodeKind::kIf: {
+        auto& i = static_cast<const IfNode&>(*n);
+        NodePtr c = Rewrite(i.condition(), false), t = Rewrite(i.then_node(), false), e = Rewrite(i.else_node(), false);
+        if (c == i.condition() && t == i.then_node() && e == i.else_node()) return n;
+        return std::make_shared<IfNode>(c, t, e, i.return_type());
+      }
+      case NodeKind::kBoolean: {
+        auto& b = static_cast<const BooleanNode&>(*n);
+        NodeVector kids;
+        bool changed = false;
+        for (auto& c : b.children()) {
+          kids.push_back(Rewrite(c, false));
+          changed |= kids.back() != c;
+        }
+        return changed ? std::make_shared<BooleanNode>(b.op(), kids) : n;
+      }
+      case NodeKind::kIn: {
+        auto& in = static_cast<const InNode&>(*n);
+        NodePtr e = Rewrite(in.eval(), false);
+        return e == in.eval() ? n : std::make_shared<InNode>(e, in.value_type(), in.values());
+      }
+      default:
+        return n;
+    }
+  }
+};
+
+}  // namespace
+
+void StageMaterialisedValues(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                             StagedExpressions* out) {
+  out->pre.clear();
+  out->main.clear();
+  out->schema = schema;
+  Stager st{schema, out, {}};
+  for (auto& e : exprs) {
+    if (!e || !e->root()) {
+      out->main.push_back(e);
+      continue;
+    }
+    NodePtr root = st.Rewrite(e->root(), true);
+    out->main.push_back(root == e->root() ? e : std::make_shared<Expression>(root, e->result()));
+  }
+}
+
 }  // namespace gdv

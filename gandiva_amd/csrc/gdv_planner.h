@@ -95,4 +95,18 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
 
 Status ValidateExpression(const Schema& schema, const Expression& expr);
 
+// Values that only exist once their bytes are written — concat / || results, lpad / rpad,
+// reverse, castVARCHAR(number) — can be a kernel's OUTPUT (or a concat argument) but not the
+// argument of another function inside the same kernel.  Where an expression consumes one, the
+// sub-tree is hoisted: it becomes an expression of a first-stage Projector that materialises it
+// as a temporary utf8 column ("__gdv_stage<k>", appended to the schema), and the consumer reads
+// that column.  `pre` stays empty when nothing needs a first stage.
+struct StagedExpressions {
+  std::vector<ExpressionPtr> pre;   // first stage, over the caller's schema
+  Schema schema;                    // caller's schema + one field per first-stage expression
+  std::vector<ExpressionPtr> main;  // the caller's expressions, rewritten over `schema`
+};
+void StageMaterialisedValues(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                             StagedExpressions* out);
+
 }  // namespace gdv

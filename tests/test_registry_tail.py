@@ -358,3 +358,84 @@ def test_gpu_errors_and_rejections():
                  b.make_function("lpad", [s, b.make_function("castINT", [x], I32), b.make_literal("*", STR)], STR)):
         with pytest.raises(gandiva.GandivaError, match="not supported yet"):
             gandiva.make_projector(batch.schema, [b.make_expression(node, pa.field("o", STR))], None)
+
+
+# ------------------------------------------------------------------ two-stage plans (a materialised value feeds a function)
+
+def _staged_exprs(b, s, t, x):
+    lit = lambda v, ty=STR: b.make_literal(v, ty)
+    BOOL = pa.bool_()
+    cat = b.make_function("concat", [s, lit("-"), t], STR)
+    out = [
+        b.make_expression(b.make_function("upper", [cat], STR), pa.field("up_cat", STR)),
+        b.make_expression(b.make_function("char_length", [cat], I32), pa.field("len_cat", I32)),
+        b.make_expression(b.make_function("like", [cat, lit("%k-s%")], BOOL), pa.field("like_cat", BOOL)),
+        b.make_expression(b.make_function("substr", [b.make_function("reverse", [s], STR), lit(2, I64), lit(4, I64)], STR),
+                          pa.field("sub_rev", STR)),
+        b.make_expression(b.make_function("reverse", [b.make_function("lpad", [s, lit(6, I32), lit("ab", STR)], STR)], STR),
+                          pa.field("rev_lpad", STR)),
+        b.make_expression(b.make_function("castBIGINT", [b.make_function("castVARCHAR", [x, lit(30, I64)], STR)], I64),
+                          pa.field("round_trip", I64)),
+        b.make_expression(b.make_if(b.make_function("starts_with", [cat, lit("s")], BOOL), cat, s, STR), pa.field("if_cat", STR)),
+        b.make_expression(b.make_function("hash64", [b.make_function("concatOperator", [s, t], STR)], I64), pa.field("h", I64)),
+        b.make_expression(b.make_in_expression(b.make_function("rpad", [t, lit(3, I32), lit("!", STR)], STR), ["a!!", "rk!", "é!!"], STR),
+                          pa.field("in_rpad", BOOL)),
+        # two levels: upper(reverse(concat(...))) needs a first stage of the first stage
+        b.make_expression(b.make_function("upper", [b.make_function("reverse", [b.make_function("upper", [cat], STR)], STR)], STR),
+                          pa.field("deep", STR)),
+        b.make_expression(b.make_function("lower", [s], STR), pa.field("plain", STR)),
+    ]
+    return out
+
+
+def _staged_batch(rng, n):
+    s = S._strings(rng, n)
+    t = pa.array([["a", "spark", "rk", "é", "", "Sp", None][int(k)] for k in rng.integers(0, 7, n)], STR)
+    x = pa.array(_ints(rng, n), I64)
+    return pa.RecordBatch.from_arrays([s, t, x], names=["s", "t", "x"])
+
+
+def test_two_stage_plans_compile_for_gfx950_without_a_device(monkeypatch, tmp_path):
+    """A function over a concat / reverse / pad / castVARCHAR(number) result: the sub-tree is hoisted
+    into a first-stage kernel that writes a temporary column, the consumer's kernel reads it."""
+    import os
+    from gandiva_amd import _capi, gandiva as gg
+    monkeypatch.setenv("GDV_NO_DISK_CACHE", "1")
+    monkeypatch.setenv("GDV_DUMP_SOURCE", "1")
+    monkeypatch.setenv("GANDIVA_AMD_CACHE_DIR", str(tmp_path))
+    batch = _staged_batch(np.random.default_rng(1), 8)
+    b = gandiva.TreeExprBuilder()
+    s, t, x = (b.make_field(batch.schema.field(i)) for i in range(3))
+    exprs = _staged_exprs(b, s, t, x)
+    lib = _capi.lib()
+    sh = gg._make_schema(batch.schema)
+    arr = (C.c_void_p * len(exprs))(*[e._h for e in exprs])
+    assert lib.gdv_precompile_projector(sh, arr, len(exprs), 0) == 0, _capi.last_error()
+    cond = b.make_condition(b.make_function("like", [b.make_function("concat", [s, t], STR), b.make_literal("%kspark%", STR)], pa.bool_()))
+    assert lib.gdv_precompile_filter(sh, cond._h) == 0, _capi.last_error()
+    lib.gdv_schema_free(sh)
+    sources = [open(os.path.join(tmp_path, f)).read() for f in os.listdir(tmp_path) if f.endswith(".hip")]
+    assert len(sources) >= 5   # projector: stage 0 of stage 0, stage 0, main (+ flat variants); filter: stage + main
+    assert any("__gdv_stage0" in src for src in sources)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 1000, 40_000])
+def test_gpu_two_stage_projector_and_filter(n):
+    rng = np.random.default_rng(n + 11)
+    batch = _staged_batch(rng, n)
+    b = gandiva.TreeExprBuilder()
+    s, t, x = (b.make_field(batch.schema.field(i)) for i in range(3))
+    exprs = _staged_exprs(b, s, t, x)
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    want = oracle.project(exprs, batch)
+    for g, w, ex in zip(proj.evaluate(batch), want, exprs):                       # host buffers
+        assert_bit_exact(g, w, str(ex))
+    db = gandiva.DeviceBatch.from_arrow(batch) if hasattr(gandiva, "DeviceBatch") else None
+    if db is not None:                                                             # HBM-resident buffers
+        outs = proj.evaluate_device(db)
+        for g, w, ex in zip(outs, want, exprs):
+            assert_bit_exact(g.to_arrow(), w, "device " + str(ex))
+    cond = b.make_condition(b.make_function("like", [b.make_function("concat", [s, t], STR), b.make_literal("%kspark%", STR)], pa.bool_()))
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, pa.default_memory_pool(), "int32")
+    assert sel.to_array().equals(oracle.filter_indices(cond, batch, "int32"))
