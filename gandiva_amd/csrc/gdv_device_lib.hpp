@@ -1022,6 +1022,7 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 #define GDV_MAP_CASE 3
 #define GDV_MAP_REVERSE 4
 #define GDV_MAP_DIGITS 8
+#define GDV_MAP_REPLACE 16  // `lim` points at a replace table (constant block), flags >> 2 = source length
 #define GDV_STR_ASCII 1  // flags: every byte of the buffer range this view came from is < 0x80
 #define GDV_STR_INBUF 2  // flags: 8-byte loads starting anywhere inside the view stay inside its buffer
 // (out-of-line device functions fault on this stack — measured, profiles/r02_c5_codesize.txt —
@@ -1162,15 +1163,42 @@ GDV_DEV void gdv_copy_digits(P dst, const gdv_str& s) {
   if (len >= 16) __builtin_memcpy(dst + 8, &w1, 8); else if (len > 8) gdv_store_low_bytes(dst + 8, w1, len - 8);
   if (len > 16) gdv_store_low_bytes(dst + 16, w2, len - 16 > 7 ? 7 : len - 16);
 }
+// replace table: int32 from_len, int32 to_len, 8 bytes unused, `from` bytes, (16-byte aligned) `to` bytes
+GDV_DEV bool gdv_replace_match(const gdv_uint8* p, gdv_int32 i, gdv_int32 len, gdv_int32 cm, const gdv_uint8* from,
+                               gdv_int32 fl) {
+  bool m = i + fl <= len;
+  for (gdv_int32 j = 0; m && j < fl; j++) m = gdv_map_byte(p[i + j], cm) == from[j];
+  return m;
+}
+template <typename P>
+GDV_DEV void gdv_copy_replaced(P dst, const gdv_str& s) {
+  const gdv_uint8* desc = s.lim;
+  const gdv_int32 fl = ((const gdv_int32*)desc)[0], tl = ((const gdv_int32*)desc)[1];
+  const gdv_uint8* from = desc + 16;
+  const gdv_uint8* to = from + ((fl + 15) & ~15);
+  const gdv_int32 len = s.flags >> 2, cm = s.map & GDV_MAP_CASE;
+  gdv_int32 o = 0;
+  for (gdv_int32 i = 0; i < len;) {
+    if (gdv_replace_match(s.p, i, len, cm, from, fl)) {
+      for (gdv_int32 j = 0; j < tl; j++) dst[o++] = to[j];
+      i += fl;
+    } else {
+      dst[o++] = gdv_map_byte(s.p[i], cm);
+      i++;
+    }
+  }
+}
 template <typename P>
 GDV_DEV void gdv_copy_special(P dst, const gdv_str& s) {
-  if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s); else gdv_copy_reversed(dst, s);
+  if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s);
+  else if (s.map & GDV_MAP_REPLACE) gdv_copy_replaced(dst, s);
+  else gdv_copy_reversed(dst, s);
 }
 // Copy with as few (scattered) store instructions as possible: whole words, then ONE
 // overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
 // 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
-  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS)) { gdv_copy_special(dst, s); return; }
+  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE)) { gdv_copy_special(dst, s); return; }
   if (s.len >= 8) {
     gdv_int32 i = 0;
     for (; i + 8 <= s.len; i += 8) {
@@ -1197,7 +1225,7 @@ GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
 // One row's bytes into the wave's LDS staging window: whole words, then a 4/2/1 ladder.
 typedef __attribute__((address_space(3))) gdv_uint8 gdv_lds_u8;
 GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
-  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS)) { gdv_copy_special(dst, s); return; }
+  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE)) { gdv_copy_special(dst, s); return; }
   const gdv_int32 len = s.len;
   gdv_int32 i = 0;
   for (; i + 8 <= len; i += 8) {
@@ -1516,6 +1544,26 @@ GDV_DEV gdv_str reverse_utf8(gdv_ctx ctx, gdv_str s) {
     }
   }
   s.map |= GDV_MAP_REVERSE;
+  return s;
+}
+// replace(s, from, to) with literal from / to (table in the constant block): every occurrence of
+// `from`, found left to right without overlap, becomes `to`.  An empty s or from leaves s as it
+// is; a result longer than 65535 bytes is an execution error.
+GDV_DEV gdv_str gdv_replace(gdv_ctx ctx, gdv_str s, const gdv_uint8* desc) {
+  const gdv_int32 fl = ((const gdv_int32*)desc)[0], tl = ((const gdv_int32*)desc)[1];
+  if (s.len <= 0 || fl <= 0) return s;
+  const gdv_int32 cm = s.map & GDV_MAP_CASE;
+  gdv_int32 hits = 0;
+  for (gdv_int32 i = 0; i + fl <= s.len;) {
+    if (gdv_replace_match(s.p, i, s.len, cm, desc + 16, fl)) { hits++; i += fl; } else { i++; }
+  }
+  if (hits == 0) return s;
+  const gdv_int64 out = (gdv_int64)s.len + (gdv_int64)hits * (tl - fl);
+  if (out > 65535) { gdv_raise(ctx, GDV_ERR_BAD_ARG); s.len = 0; return s; }
+  s.flags = (s.flags & 3) | (s.len << 2);
+  s.lim = desc;
+  s.len = (gdv_int32)out;
+  s.map |= GDV_MAP_REPLACE;
   return s;
 }
 // lpad / rpad(text, n, fill): the result is two pieces, written back to back by the output copy —

@@ -555,7 +555,8 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->pieces.clear();
       out->col_slot = -1;
       out->col_map = 0;
-      out->opaque = fn.name() == "reverse" || (fn.name() == "castVARCHAR" && !args[0].type.is_varlen());
+      out->opaque = fn.name() == "reverse" || fn.name() == "replace" ||
+                    (fn.name() == "castVARCHAR" && !args[0].type.is_varlen());
       if ((fn.name() == "upper" || fn.name() == "lower") && args.size() == 1 && args[0].col_slot >= 0) {
         out->col_slot = args[0].col_slot;
         out->col_map = fn.name() == "upper" ? 1 : 2;
@@ -569,9 +570,41 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       for (auto& a : args)
         if ((!a.pieces.empty() || a.opaque) && !is_concat)
           return Status::CodeGenError("Function " + fn.ToString() +
-                                      " not supported yet: a concat / lpad / rpad / reverse / castVARCHAR(number) "
+                                      " not supported yet: a concat / lpad / rpad / reverse / replace / castVARCHAR(number) "
                                       "result can only be an output expression or an argument of concat in the "
                                       "HIP backend. ");
+      if (fn.name() == "replace") {
+        // replace(text, from, to) with LITERAL from / to: a table in the constant block; the result
+        // is materialised by the output copy (GDV_MAP_REPLACE)
+        for (int k = 1; k <= 2; k++)
+          if (fn.children()[k]->kind() != NodeKind::kLiteral)
+            return Status::CodeGenError("Function " + fn.ToString() +
+                                        " not supported yet: the HIP backend takes replace with literal "
+                                        "'from' and 'to' strings only. ");
+        auto& lf = static_cast<const LiteralNode&>(*fn.children()[1]);
+        auto& lt = static_cast<const LiteralNode&>(*fn.children()[2]);
+        out->vcols = args[0].vcols;
+        if (lf.is_null() || lt.is_null()) {
+          out->opaque = false;
+          out->vlane = "false";
+          out->v = "gdv_empty_str()";
+          return Status::OK();
+        }
+        const std::string& from = lf.value().bytes;
+        const std::string& to = lt.value().bytes;
+        std::string tab(16, '\0');
+        const int32_t fl = static_cast<int32_t>(from.size()), tl = static_cast<int32_t>(to.size());
+        std::memcpy(&tab[0], &fl, 4);
+        std::memcpy(&tab[4], &tl, 4);
+        tab += from;
+        tab.append((16 - from.size() % 16) % 16, '\0');
+        tab += to;
+        out->vlane = args[0].vlane;
+        can_raise_ = true;
+        const std::string guard = AndExpr(AndExpr("live", active), LaneValid(*out));
+        out->v = Tmp("gdv_str", guard + " ? gdv_replace(ctx, " + args[0].v + ", " + ByteTable(tab) + ") : gdv_empty_str()");
+        return Status::OK();
+      }
       if (fn.name() == "lpad" || fn.name() == "rpad") {
         // lpad / rpad(text, n[, fill]) with LITERAL n and fill: two pieces (device library), the
         // fill repeated to n characters laid out once in the constant block
@@ -760,7 +793,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
       if (!t.pieces.empty() || !e.pieces.empty() || t.opaque || e.opaque)
         return Status::CodeGenError(
-            "if/else over a concat / lpad / rpad / reverse / castVARCHAR(number) result is not supported by the HIP "
+            "if/else over a concat / lpad / rpad / reverse / replace / castVARCHAR(number) result is not supported by the HIP "
             "backend yet");
       out->type = n.return_type();
       const std::string ctype = out->type.CType();
@@ -815,7 +848,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       GDV_RETURN_NOT_OK(Gen(*n.eval(), active, &x));
       if (!x.pieces.empty() || x.opaque)
         return Status::CodeGenError(
-            "IN over a concat / lpad / rpad / reverse / castVARCHAR(number) result is not supported by the HIP backend yet");
+            "IN over a concat / lpad / rpad / reverse / replace / castVARCHAR(number) result is not supported by the HIP backend yet");
       out->pieces.clear();
       out->col_slot = -1;
       out->type = boolean();
@@ -1777,7 +1810,8 @@ bool MaterialisesBytes(const Node& n) {
   if (n.kind() != NodeKind::kFunction) return false;
   auto& fn = static_cast<const FunctionNode&>(n);
   const std::string& f = fn.name();
-  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse") return true;
+  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse" || f == "replace")
+    return true;
   return f == "castVARCHAR" && !fn.children().empty() && !fn.children()[0]->return_type().is_varlen();
 }
 

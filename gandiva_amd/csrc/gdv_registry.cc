@@ -271,6 +271,8 @@ FunctionRegistry::FunctionRegistry() {
   add("castVARCHAR", {int32(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("castVARCHAR", {int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("reverse", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("replace", {utf8(), utf8(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext,
+      "gdv_replace");  // planned by gdv_planner.cc (literal from / to)
   // lpad / rpad: planned as two pieces (gdv_planner.cc), literal length and fill only
   for (const char* f : {"lpad", "rpad"}) {
     add(f, {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_pad");

@@ -51,7 +51,8 @@
  *       time of day in whole seconds" rule — where it coincides with "largest k with start + k
  *       months <= end" it is checked against dateutil, tests/test_registry_tail.py); lpad / rpad
  *       giving "" for an empty text and leaving the text alone for an empty fill; reverse and
- *       castVARCHAR(integer, n) raising on broken UTF-8 / n < 0 (their regular results are
+ *       castVARCHAR(integer, n) raising on broken UTF-8 / n < 0, replace raising above 65535
+ *       result bytes and returning the text for an empty `from` (their regular results are
  *       checked against Python str and pyarrow.compute).
  *
  * Program format (whitespace separated, prefix order):
@@ -851,6 +852,32 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
         }
         out->sp[i] = dst; out->sl[i] = bad ? 0 : xl; out->sm[i] = 0;
         if (bad && live) c->err |= 4;
+      } else if (!strcmp(f, "replace")) {
+        /* every occurrence of `from`, left to right, not overlapping, becomes `to`; an empty text
+         * or `from` returns the text; more than 65535 result bytes is an error
+         * [recalled: string_ops.cc replace_with_max_len_utf8_utf8_utf8, max_length 65535] */
+        int live = out->valid[i] && (!active || active[i]);
+        const uint8_t* z = a[2].sp[i]; int zl = a[2].sl[i], zm = a[2].sm[i];
+        out->sp[i] = x; out->sl[i] = xl; out->sm[i] = (uint8_t)xm;
+        if (!out->valid[i] || xl <= 0 || yl <= 0) continue;
+        int hits = 0;
+        for (int k = 0; k + yl <= xl;) {
+          int eq = 1;
+          for (int j = 0; j < yl && eq; j++) eq = map_byte(x[k + j], xm) == map_byte(y[j], ym);
+          if (eq) { hits++; k += yl; } else k++;
+        }
+        if (hits == 0) continue;
+        int64_t total = (int64_t)xl + (int64_t)hits * (zl - yl);
+        if (total > 65535) { if (live) c->err |= 4; out->sl[i] = 0; continue; }
+        uint8_t* dst = arena_alloc(c, total > 0 ? (size_t)total : 1);
+        size_t at = 0;
+        for (int k = 0; k < xl;) {
+          int eq = k + yl <= xl;
+          for (int j = 0; j < yl && eq; j++) eq = map_byte(x[k + j], xm) == map_byte(y[j], ym);
+          if (eq) { for (int j = 0; j < zl; j++) dst[at++] = map_byte(z[j], zm); k += yl; }
+          else dst[at++] = map_byte(x[k++], xm);
+        }
+        out->sp[i] = dst; out->sl[i] = (int32_t)at; out->sm[i] = 0;
       } else if (!strcmp(f, "lpad") || !strcmp(f, "rpad")) {
         /* lpad / rpad(text, n[, fill = " "]) [recalled: string_ops.cc lpad_utf8_int32_utf8]:
          * "" when the text is empty or n <= 0; the text cut to n characters when it has n or more;

@@ -229,6 +229,26 @@ long host_str_pad(int right, const int* off, const unsigned char* data, long siz
   }
   return at;
 }
+// replace with a table laid out as the planner lays it out: int32 from_len, int32 to_len, 8 unused
+// bytes, from, (16-byte aligned) to
+unsigned host_str_replace(const int* off, const unsigned char* data, long size, long n, int map,
+                          const unsigned char* table, int* out_off, unsigned char* out_data) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    if (map == 1) s = upper_utf8(s);
+    if (map == 2) s = lower_utf8(s);
+    const gdv_str r = gdv_replace(ctx, s, table);
+    if (r.len > 0) gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  return err;
+}
 unsigned host_cast_varchar_int64(const long long* v, long n, long long len, int* out_off, unsigned char* out_data) {
   unsigned err = 0;
   gdv_ctx ctx{&err};

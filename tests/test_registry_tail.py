@@ -1,5 +1,5 @@
 """Registry tail (round-1 verdict item 9): timestampdiffMonth / Quarter / Year, castVARCHAR(integer),
-reverse, lpad / rpad.
+reverse, replace, lpad / rpad, and two-stage plans (a function over a materialised value).
 
 PARITY STATUS: unpinned — no reference source, binary or vector for these functions exists in the
 container.  The oracle restates them from memory of the reference lineage (precompiled/time.cc,
@@ -118,10 +118,17 @@ def _string_exprs(b, s, x):
     add("lpad_trim", b.make_function("lpad", [b.make_function("btrim", [s], STR), lit(6, I32), lit("0")], STR))
     for k, n in enumerate([0, 1, 5, 19, 20, 25]):
         add(f"cast{k}", b.make_function("castVARCHAR", [x, lit(n, I64)], STR))
+    for k, (frm, to) in enumerate(REPLACE_CASES):
+        add(f"repl{k}", b.make_function("replace", [s, lit(frm), lit(to)], STR))
+    add("repl_up", b.make_function("replace", [b.make_function("upper", [s], STR), lit("SPARK"), lit("flink")], STR))
     add("cat", b.make_function("concat", [b.make_function("castVARCHAR", [x, lit(25, I64)], STR), lit(":"),
                                           b.make_function("reverse", [s], STR),
                                           b.make_function("lpad", [s, lit(4, I32), lit("#")], STR)], STR))
     return out
+
+
+REPLACE_CASES = [("spark", "flink"), ("a", ""), ("", "zz"), ("é", "e"), ("ar", "ARRR"), ("日本語テキスト", "x"), ("  ", " "),
+                 ("aa", "a"), ("xx", "yyy")]
 
 
 def _string_batch(rng, n, null_fraction=0.15):
@@ -189,6 +196,11 @@ def test_oracle_reverse_pad_and_integer_text_match_python():
     assert got["lpad_trim"] == [None if v is None else _python_pad(v.strip(" "), 6, "0", False) for v in sv]
     for k, n in enumerate([0, 1, 5, 19, 20, 25]):
         assert got[f"cast{k}"] == [None if v is None else str(v)[:n] for v in xv]
+    for k, (frm, to) in enumerate(REPLACE_CASES):
+        assert got[f"repl{k}"] == [None if v is None else (v.replace(frm, to) if frm else v) for v in sv], (frm, to)
+        if frm:
+            assert pa.array(got[f"repl{k}"], STR).equals(pc.replace_substring(batch.column(0), frm, to))
+    assert got["repl_up"] == [None if v is None else ascii_upper(v).replace("SPARK", "flink") for v in sv]
     assert got["cat"] == [("" if xx is None else str(xx)) + ":" + ("" if v is None else v[::-1] + _python_pad(v, 4, "#", False))
                           for v, xx in zip(sv, xv)]
     # where Arrow's own kernels mean the same thing (non-empty text, single-codepoint fill, no cut)
@@ -213,6 +225,13 @@ def test_oracle_raises_on_negative_length_and_on_broken_utf8():
     s = b.make_field(sb.schema.field(0))
     with pytest.raises(oracle.OracleError):
         oracle.project([b.make_expression(b.make_function("reverse", [s], STR), pa.field("r", STR))], sb)
+    lb = pa.RecordBatch.from_arrays([pa.array(["a" * 40000, "b"], STR)], names=["s"])
+    s = b.make_field(lb.schema.field(0))
+    grow = b.make_expression(b.make_function("replace", [s, b.make_literal("a", STR), b.make_literal("bb", STR)], STR), pa.field("r", STR))
+    with pytest.raises(oracle.OracleError):                         # 80000 result bytes > 65535
+        oracle.project([grow], lb)
+    same = b.make_expression(b.make_function("replace", [s, b.make_literal("a", STR), b.make_literal("c", STR)], STR), pa.field("r", STR))
+    assert oracle.project([same], lb)[0].to_pylist() == ["c" * 40000, "b"]
 
 
 # ------------------------------------------------------------------ CPU: the device functions, host build
@@ -255,6 +274,15 @@ def test_device_reverse_pad_and_integer_text_on_host(hostlib, seed):
                                  int(tab.isascii()), _p(out_off), _p(out_data))
             node = b.make_function("rpad" if right else "lpad", [s, b.make_literal(want_n, I32), b.make_literal(fill, STR)], STR)
             assert strings(out_off, out_data) == want_of(node), (right, want_n, fill)
+    for frm, to in REPLACE_CASES:
+        fb, tb = frm.encode(), to.encode()
+        table = (np.array([len(fb), len(tb), 0, 0], np.int32).tobytes() + fb + b"\0" * ((16 - len(fb) % 16) % 16) + tb + b"\0" * 8)
+        tbuf = np.frombuffer(table, np.uint8).copy()
+        for mp, wrap in ((0, lambda v: v), (1, lambda v: b.make_function("upper", [v], STR))):
+            out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(4 * size + 64 * n + 64, np.uint8)
+            err = hostlib.host_str_replace(_p(off), _p(data), C.c_long(size), C.c_long(n), mp, _p(tbuf), _p(out_off), _p(out_data))
+            node = b.make_function("replace", [wrap(s), b.make_literal(frm, STR), b.make_literal(to, STR)], STR)
+            assert err == 0 and strings(out_off, out_data) == want_of(node), (frm, to, mp)
     xv = np.array(batch.column(1).to_pylist(), dtype=np.int64)
     for k in (0, 1, 5, 19, 20, 25):
         out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(24 * n + 64, np.uint8)
@@ -354,10 +382,24 @@ def test_gpu_errors_and_rejections():
     rev = gandiva.make_projector(batch.schema, [b.make_expression(b.make_function("reverse", [s], STR), pa.field("r", STR))], None)
     with pytest.raises(gandiva.GandivaError):
         rev.evaluate(bad)
-    for node in (b.make_function("upper", [b.make_function("reverse", [s], STR)], STR),
-                 b.make_function("lpad", [s, b.make_function("castINT", [x], I32), b.make_literal("*", STR)], STR)):
+    lb = pa.RecordBatch.from_arrays([pa.array([1, 2], I64), pa.array(["a" * 40000, "b"], STR)], names=["x", "s"])
+    grow = gandiva.make_projector(batch.schema, [b.make_expression(
+        b.make_function("replace", [s, b.make_literal("a", STR), b.make_literal("bb", STR)], STR), pa.field("r", STR))], None)
+    with pytest.raises(gandiva.GandivaError):
+        grow.evaluate(lb)
+    same = gandiva.make_projector(batch.schema, [b.make_expression(
+        b.make_function("replace", [s, b.make_literal("a", STR), b.make_literal("c", STR)], STR), pa.field("r", STR))], None)
+    assert same.evaluate(lb)[0].to_pylist() == ["c" * 40000, "b"]
+    # what stays outside the HIP backend: non-literal pad lengths / replace strings, and a
+    # materialised value under a selection vector (the first stage would run on unselected rows)
+    for node in (b.make_function("lpad", [s, b.make_function("castINT", [x], I32), b.make_literal("*", STR)], STR),
+                 b.make_function("replace", [s, s, b.make_literal("*", STR)], STR)):
         with pytest.raises(gandiva.GandivaError, match="not supported yet"):
             gandiva.make_projector(batch.schema, [b.make_expression(node, pa.field("o", STR))], None)
+    with pytest.raises(gandiva.GandivaError, match="not supported yet"):
+        gandiva.make_projector(batch.schema, [b.make_expression(
+            b.make_function("upper", [b.make_function("reverse", [s], STR)], STR), pa.field("o", STR))],
+            pa.default_memory_pool(), "UINT32")
 
 
 # ------------------------------------------------------------------ two-stage plans (a materialised value feeds a function)
@@ -384,6 +426,10 @@ def _staged_exprs(b, s, t, x):
         b.make_expression(b.make_function("upper", [b.make_function("reverse", [b.make_function("upper", [cat], STR)], STR)], STR),
                           pa.field("deep", STR)),
         b.make_expression(b.make_function("lower", [s], STR), pa.field("plain", STR)),
+        b.make_expression(b.make_function("like", [b.make_function("replace", [s, lit("spark"), lit("flink")], STR), lit("%flink%")], BOOL),
+                          pa.field("like_repl", BOOL)),
+        b.make_expression(b.make_function("replace", [b.make_function("replace", [s, lit("a"), lit("bb")], STR), lit("bbb"), lit("c")], STR),
+                          pa.field("repl_repl", STR)),
     ]
     return out
 
