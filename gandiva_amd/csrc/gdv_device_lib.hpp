@@ -1432,22 +1432,34 @@ GDV_DEV bool ends_with_utf8_utf8(gdv_str s, gdv_str suffix) {
   return suffix.len <= s.len && gdv_str_equal_words(s, s.len - suffix.len, suffix, suffix.len);
 }
 
-// the general (non-ASCII) substr: walks UTF-8 lead bytes; out of line, tiles of pure ASCII never call it
+// byte offset of the character with 0-based index `ci` in a string that is not pure ASCII
+// (s.len when the string has fewer characters): 8 bytes per step — the lead bytes of a word are
+// counted with one popcount, and only the word holding the wanted character is looked into
+static __device__ GDV_COLD gdv_int32 gdv_utf8_byte_pos_general(const gdv_str& s, gdv_int32 ci) {
+  gdv_int32 seen = 0;
+  for (gdv_int32 i = 0; i < s.len; i += 8) {
+    const gdv_uint64 w = gdv_raw_word_at(s, i);
+    // bit 7 of every byte that STARTS a character (not 10xxxxxx), bytes past the end excluded
+    gdv_uint64 lead = ~(w & ~(w << 1)) & GDV_B80 & gdv_low_bytes_mask(s.len - i);
+    const gdv_int32 c = __popcll(lead);
+    if (seen + c > ci) {
+      for (gdv_int32 k = ci - seen; k > 0; k--) lead &= lead - 1;  // drop the characters before it
+      return i + (__builtin_ctzll(lead) >> 3);
+    }
+    seen += c;
+  }
+  return s.len;
+}
+// the general (non-ASCII) substr; tiles of pure ASCII never call it
 static __device__ GDV_COLD gdv_str gdv_substr_utf8_general(gdv_str s, gdv_int64 from, gdv_int64 count) {
   gdv_str r = s;
   r.len = 0;
   const gdv_int64 glyphs = gdv_utf8_count(s);
   gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? glyphs + from : 0);
   if (start < 0 || start >= glyphs) return r;
-  gdv_int64 stop = start + count < glyphs ? start + count : glyphs;
-  gdv_int32 g = 0, b0 = s.len, b1 = s.len;
-  for (gdv_int32 i = 0; i < s.len; i++) {
-    if (gdv_is_utf8_lead(s.p[i])) {
-      if (g == start) b0 = i;
-      if (g == stop) { b1 = i; break; }
-      g++;
-    }
-  }
+  const gdv_int64 stop = start + count < glyphs ? start + count : glyphs;
+  const gdv_int32 b0 = gdv_utf8_byte_pos_general(s, (gdv_int32)start);
+  const gdv_int32 b1 = stop >= glyphs ? s.len : gdv_utf8_byte_pos_general(s, (gdv_int32)stop);
   r.p = s.p + b0;
   r.len = b1 - b0;
   return r;
@@ -1473,20 +1485,10 @@ GDV_DEV gdv_str substr_utf8_int64(gdv_str s, gdv_int64 from) {
   return substr_utf8_int64_int64(s, from, 0x7fffffff);
 }
 // byte offset of the character with 0-based index `ci` (s.len when the string is shorter)
-static __device__ GDV_COLD gdv_int32 gdv_utf8_byte_pos_general(const gdv_uint8* p, gdv_int32 len, gdv_int32 ci) {
-  gdv_int32 g = 0;
-  for (gdv_int32 i = 0; i < len; i++) {
-    if (gdv_is_utf8_lead(p[i])) {
-      if (g == ci) return i;
-      g++;
-    }
-  }
-  return len;
-}
 GDV_DEV gdv_int32 gdv_utf8_byte_pos(const gdv_str& s, gdv_int32 ci) {
   if (ci <= 0) return 0;
   if (s.flags & GDV_STR_ASCII) return ci < s.len ? ci : s.len;
-  return gdv_utf8_byte_pos_general(s.p, s.len, ci);
+  return gdv_utf8_byte_pos_general(s, ci);
 }
 GDV_DEV gdv_str gdv_empty_str() { return gdv_make_str(nullptr, 0, 0, nullptr, GDV_STR_ASCII | GDV_STR_INBUF); }
 // left(s, n): the first n characters; n < 0: all but the last |n|
@@ -1585,22 +1587,50 @@ GDV_DEV gdv_str gdv_pad_fill(const gdv_str& s, gdv_int32 n, const gdv_uint8* tab
   r.len = gdv_utf8_byte_pos(r, pad);
   return r;
 }
+// byte position of the first occurrence of `sub` (non-empty) in `s` at or after byte `from`, -1 when
+// absent: 8 candidate positions per step, filtered on the first two needle bytes with SWAR
+// zero-byte tests, verified on a 64-bit window (the scheme of gdv_like_contains below, with the
+// needle read through its own view)
+static __device__ GDV_COLD gdv_int32 gdv_find(const gdv_str& s, gdv_int32 from, const gdv_str& sub) {
+  const gdv_int32 m = sub.len, last = s.len - m;
+  if (from > last) return -1;
+  const gdv_uint64 mask = gdv_low_bytes_mask(m);
+  const gdv_uint64 first = gdv_word_at(sub, 0) & mask;
+  const gdv_uint64 splat = (first & 0xffull) * 0x0101010101010101ull;
+  const gdv_uint64 splat2 = ((first >> 8) & 0xffull) * 0x0101010101010101ull;
+  gdv_uint64 cur = gdv_word_at(s, from);
+  for (gdv_int32 base = from; base <= last; base += 8) {
+    const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
+    const gdv_uint64 x = cur ^ splat;
+    gdv_uint64 cand = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+    if (m >= 2) {
+      const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat2;
+      cand &= (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
+    }
+    while (cand) {
+      const int k = __builtin_ctzll(cand) >> 3;
+      cand &= cand - 1;
+      if (base + k > last) break;
+      const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
+      bool eq = (win & mask) == first;
+      for (gdv_int32 j = 8; eq && j < m; j += 8)
+        eq = ((gdv_word_at(s, base + k + j) ^ gdv_word_at(sub, j)) & gdv_low_bytes_mask(m - j)) == 0;
+      if (eq) return base + k;
+    }
+    cur = nxt;
+  }
+  return -1;
+}
 // locate(sub, str[, start]): 1-based character position of the first occurrence of sub in
 // str at or after character `start`; 0 when absent or when either string is empty
 GDV_DEV gdv_int32 locate_utf8_utf8_int32(gdv_ctx ctx, gdv_str sub, gdv_str str, gdv_int32 start) {
   if (start < 1) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return 0; }
   if (str.len <= 0 || sub.len <= 0) return 0;
-  const gdv_int32 b = gdv_utf8_byte_pos(str, start - 1);
-  for (gdv_int32 i = b; i + sub.len <= str.len; i++) {
-    bool eq = true;
-    for (gdv_int32 k = 0; k < sub.len && eq; k++) eq = gdv_str_at(str, i + k) == gdv_str_at(sub, k);
-    if (eq) {
-      gdv_str head = str;
-      head.len = i;
-      return gdv_utf8_count(head) + 1;
-    }
-  }
-  return 0;
+  const gdv_int32 at = gdv_find(str, gdv_utf8_byte_pos(str, start - 1), sub);
+  if (at < 0) return 0;
+  gdv_str head = str;
+  head.len = at;
+  return gdv_utf8_count(head) + 1;
 }
 GDV_DEV gdv_int32 locate_utf8_utf8(gdv_ctx ctx, gdv_str sub, gdv_str str) {
   return locate_utf8_utf8_int32(ctx, sub, str, 1);

@@ -249,6 +249,19 @@ unsigned host_str_replace(const int* off, const unsigned char* data, long size, 
   }
   return err;
 }
+// locate(needle, s, start) with the needle read through a view, rows through `map`
+unsigned host_str_locate(const int* off, const unsigned char* data, long size, long n, const unsigned char* lit,
+                         int litlen, int start, int map, int* out) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    s.map = map;
+    out[i] = locate_utf8_utf8_int32(ctx, host_lit(lit, litlen), s, start);
+  }
+  return err;
+}
 unsigned host_cast_varchar_int64(const long long* v, long n, long long len, int* out_off, unsigned char* out_data) {
   unsigned err = 0;
   gdv_ctx ctx{&err};

@@ -293,6 +293,39 @@ def test_device_reverse_pad_and_integer_text_on_host(hostlib, seed):
     assert hostlib.host_cast_varchar_int64(_p(xv), C.c_long(n), C.c_longlong(-1), _p(out_off), _p(out_data)) == 4
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_device_word_at_a_time_locate_and_character_positions_on_host(hostlib, seed):
+    """locate() searches 8 positions per step and substr / left / right find character positions
+    by popcount over 8-byte words (round 2): against the oracle's byte-at-a-time loops, on
+    strings with multi-byte characters, needles up to 3 words long and every start position."""
+    rng = np.random.default_rng(900 + seed)
+    n = 1200
+    alphabet = list("abks é日_") + ["ar", "spark"]
+    vals = ["".join(rng.choice(alphabet, size=int(rng.integers(0, 30)))) for _ in range(n)]
+    arr = pa.array(vals, STR)
+    batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    off, data, size = _col(arr)
+    needles = ["a", "ar", "é", "日", "spark", "k s", "ab", "arsparkar", "sparkspark", "日é日", "aaaaaaaaaaaaaaaaaaaaaaa",
+               vals[3][:11] or "x", vals[7][2:20] or "y"]
+    for needle in needles:
+        lb, ll = _lit(needle)
+        for start in (1, 2, 3, 9, 17, 40):
+            for mp, wrap in ((0, lambda v: v), (2, lambda v: b.make_function("lower", [v], STR))):
+                out = np.zeros(n, np.int32)
+                err = hostlib.host_str_locate(_p(off), _p(data), C.c_long(size), C.c_long(n), _p(lb), ll, start, mp, _p(out))
+                node = b.make_function("locate", [b.make_literal(needle, STR), wrap(s), b.make_literal(start, I32)], I32)
+                assert err == 0 and out.tolist() == oracle.project_one(node, I32, batch).to_pylist(), (needle, start, mp)
+    for frm in (1, 2, 5, 8, 9, 16, 17, 25, -1, -7, -9, -20):
+        for cnt in (1, 3, 8, 9, 30):
+            out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(size + 64, np.uint8)
+            hostlib.host_str_view(1, _p(off), _p(data), C.c_long(size), C.c_long(n), C.c_longlong(frm), C.c_longlong(cnt), 0,
+                                  _p(out_off), _p(out_data))
+            got = [bytes(out_data[out_off[i]:out_off[i + 1]]).decode() for i in range(n)]
+            assert got == [v[frm - 1:frm - 1 + cnt] if frm > 0 else (v[frm:][:cnt] if -frm <= len(v) else "") for v in vals], (frm, cnt)
+
+
 def test_device_reverse_on_host_ascii_fast_path_and_broken_utf8(hostlib):
     rng = np.random.default_rng(9)
     words = ["".join(rng.choice(list("abcXYZ 019_%"), size=int(k))) for k in rng.integers(0, 40, 800)]
