@@ -404,7 +404,7 @@ def test_oracle_concat_matches_python():
         assert g.to_pylist() == w, e.result().name
 
 
-def test_concat_results_cannot_feed_other_functions_yet():
+def test_concat_results_feed_other_functions_through_a_first_stage():
     from gandiva_amd import _capi, gandiva as gg
     import ctypes as C
     schema = pa.schema([("s", pa.string())])
@@ -414,7 +414,10 @@ def test_concat_results_cannot_feed_other_functions_yet():
     e = b.make_expression(b.make_function("like", [cc, b.make_literal("%a%", pa.string())], pa.bool_()),
                           pa.field("r", pa.bool_()))
     arr = (C.c_void_p * 1)(e._h)
-    rc = _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 0)
+    # round 2: the concat is hoisted into a first-stage kernel (tests/test_registry_tail.py) ...
+    assert _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 0) == 0, _capi.last_error()
+    # ... except under a selection vector, where the first stage would run on unselected rows
+    rc = _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 2)
     assert rc == 40 and "concat" in _capi.last_error()      # CodeGenError, said plainly
 
 
