@@ -29,6 +29,8 @@ python tools/make_latency.py > $OUT/make_latency.txt 2>&1
 [ -x tools/hbm_ceiling ] && timeout 120 tools/hbm_ceiling > $OUT/hbm_ceiling.txt 2>&1
 python tools/micro_benchmarks.py > $OUT/micro_benchmarks.txt 2>&1
 python tools/latency_sweep.py > $OUT/latency_sweep.txt 2>&1
+PYTHONPATH=$R timeout 60 python tools/flat_only_timing.py > $OUT/flat_only_plans.txt 2>&1
+PYTHONPATH=$R timeout 90 python tools/registry_tail_timing.py > $OUT/registry_tail_timing.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -size +1000k -delete   # raw traces are large; stats / counters stay
 find $OUT -name "*.csv" -size +8000k -delete
 du -sh $OUT; ls $OUT | head -50
