@@ -1,0 +1,1760 @@
+// gandiva_amd device function library (gfx950 / CDNA4, wave64).
+//
+// This header is the fixed library the fused kernels are assembled from: it replaces the
+// reference's `precompiled/*.cc` bitcode library and
+// `BitMapAccumulator` / `bitmap.cc` helpers (rows 8, 13).  It is embedded verbatim in
+// libgandiva_amd.so and handed to the runtime compiler together with the kernel body the
+// planner emits for one Projector / Filter (gdv_planner.cc).  Function names follow the
+// reference's `<name>_<type>_<type>` convention so a plan dump reads like the
+// reference's IR.  Everything is written for 64-wide wavefronts: one wavefront handles
+// 64 consecutive rows per sub-tile, i.e. exactly one 64-bit Arrow validity word
+// (LSB-first bit order: pyarrow/include/arrow/util/bit_util.h:173-175).
+//
+// Build flags that are part of the semantics: -ffp-contract=off (no FMA fusion: results
+// must be bit-identical to separate IEEE mul + add), correctly rounded f32 divide/sqrt.
+#pragma once
+
+typedef signed char gdv_int8;
+typedef short gdv_int16;
+typedef int gdv_int32;
+typedef long long gdv_int64;
+typedef unsigned char gdv_uint8;
+typedef unsigned short gdv_uint16;
+typedef unsigned int gdv_uint32;
+typedef unsigned long long gdv_uint64;
+typedef float gdv_float32;
+typedef double gdv_float64;
+typedef __int128 gdv_int128;
+typedef unsigned __int128 gdv_uint128;
+typedef bool gdv_boolean;
+typedef gdv_int32 gdv_date32;
+typedef gdv_int64 gdv_date64;
+typedef gdv_int64 gdv_timestamp;
+typedef gdv_int32 gdv_time32;
+typedef gdv_int64 gdv_time64;
+
+#define GDV_DEV static __device__ __forceinline__
+#define GDV_WAVE 64
+
+// Error bits a kernel can raise (-> Status::ExecutionError on the host).
+#define GDV_ERR_DIV_ZERO 1u
+#define GDV_ERR_OVERFLOW 2u
+#define GDV_ERR_BAD_ARG 4u
+
+struct gdv_ctx {
+  gdv_uint32* err;
+};
+GDV_DEV void gdv_raise(gdv_ctx ctx, gdv_uint32 bit) { atomicOr(ctx.err, bit); }
+
+// ------------------------------------------------------------------ memory access
+//
+// Values buffers are streamed exactly once: loads are plain coalesced loads (one row per
+// lane -> 64*sizeof(T) contiguous bytes per wave instruction), stores are non-temporal
+// so the written lines do not displace input lines in L2 / Infinity Cache.
+template <typename T>
+GDV_DEV T gdv_ld(const T* p, gdv_int64 i) { return p[i]; }
+template <typename T>
+GDV_DEV T gdv_ldnt(const T* p, gdv_int64 i) { return __builtin_nontemporal_load(p + i); }
+template <typename T>
+GDV_DEV void gdv_st(T* p, gdv_int64 i, T v) { p[i] = v; }
+template <typename T>
+GDV_DEV void gdv_stnt(T* p, gdv_int64 i, T v) { __builtin_nontemporal_store(v, p + i); }
+
+// Four consecutive rows per lane with 16-byte (or wider) instructions: the wide layout of
+// fixed-width projections (gdv_planner.cc).  Vector types carry element alignment only: Arrow
+// array offsets can leave a column's first row anywhere.
+template <typename T>
+struct gdv_quad {
+  typedef T type __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+};
+template <bool NT, typename T>
+GDV_DEV void gdv_ld4(const T* p, T* dst) {
+  typedef typename gdv_quad<T>::type V;
+  const V v = NT ? __builtin_nontemporal_load((const V*)p) : *(const V*)p;
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+template <bool NT, typename T>
+GDV_DEV void gdv_st4(T* p, const T* src) {
+  typedef typename gdv_quad<T>::type V;
+  V v;
+  v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+  if (NT) __builtin_nontemporal_store(v, (V*)p); else *(V*)p = v;
+}
+template <bool NT>
+GDV_DEV void gdv_ld4(const gdv_int128* p, gdv_int128* dst) {  // no vectors of __int128: 4 x 16 B, contiguous per lane
+#pragma unroll
+  for (int i = 0; i < 4; i++) dst[i] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+}
+template <bool NT>
+GDV_DEV void gdv_st4(gdv_int128* p, const gdv_int128* src) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) { if (NT) __builtin_nontemporal_store(src[i], p + i); else p[i] = src[i]; }
+}
+// live-row mask of the 64 rows starting at `first` (a multiple of 64) of an n-row batch
+GDV_DEV gdv_uint64 gdv_live_word(gdv_int64 first, gdv_int64 n) {
+  const gdv_int64 k = n - first;
+  return k >= 64 ? ~0ull : (k <= 0 ? 0ull : ((1ull << k) - 1));
+}
+
+// A bitmap as the kernels see it: 8-byte aligned word pointer + a bit shift < 64 (Arrow
+// array offsets and unaligned buffers are folded into these two by the host) + the
+// number of words that may be read (>= 1).  A column without a validity buffer is bound to
+// a one-word all-ones bitmap (nwords == 1): indices are clamped, never branched on, so
+// the load phase of a tile contains no control flow and all loads issue back to back.
+struct gdv_bitmap {
+  const gdv_uint64* p;
+  gdv_int32 shift;
+  gdv_int64 nwords;
+};
+
+// The GDV_U validity words of one wave tile, fetched with ONE vector load: lane u
+// (u < nsub) returns the 64 bits covering rows [64*(wbase+u), 64*(wbase+u)+64).  Words past
+// the end of the buffer are clamped to the last word: they only cover rows >= n, which
+// the caller masks with its live-row mask.
+GDV_DEV gdv_uint64 gdv_bitmap_tile(const gdv_bitmap& bm, gdv_int64 wbase, int lane, int nsub) {
+  // No exec masking: lanes >= nsub re-read word nsub-1 (same cache line, result unused),
+  // so the two loads carry no control dependence and overlap with the value loads.
+  const int l = lane < nsub ? lane : nsub - 1;
+  const gdv_int64 last = bm.nwords - 1;
+  gdv_int64 i0 = wbase + l;
+  gdv_int64 i1 = i0 + 1;
+  i0 = i0 < last ? i0 : last;
+  i1 = i1 < last ? i1 : last;
+  const gdv_uint64 lo = bm.p[i0];
+  const gdv_uint64 hi = bm.p[i1];
+  // funnel shift that is also correct for shift == 0 (no shift-by-64)
+  return (lo >> bm.shift) | ((hi << 1) << (63 - bm.shift));
+}
+
+// Word `w` (wave-uniform index) of a bitmap, through the SCALAR data path: the input bitmaps are
+// read-only for the kernel, so they are addressed as constant memory (address space 4) and the
+// two 8-byte loads become one s_load — no VGPRs, no vmcnt slot, nothing the value loads of the
+// tile have to queue behind (round 2: the vector-load + readlane form made the compiler wait for
+// the bitmap words in the middle of the value loads: 7 of 32 loads in flight in the C3 kernel).
+#ifdef GDV_HOST_BUILD
+typedef const gdv_uint64 gdv_cu64;
+#else
+typedef const __attribute__((address_space(4))) gdv_uint64 gdv_cu64;
+#endif
+GDV_DEV gdv_uint64 gdv_bitmap_word(const gdv_bitmap& bm, gdv_int64 w) {
+  const gdv_int64 last = bm.nwords - 1;
+  const gdv_int64 i0 = w < last ? w : last;
+  const gdv_int64 i1 = w + 1 < last ? w + 1 : last;
+  gdv_cu64* q = (gdv_cu64*)bm.p;
+  const gdv_uint64 lo = q[i0], hi = q[i1];
+  return (lo >> bm.shift) | ((hi << 1) << (63 - bm.shift));  // also correct for shift == 0
+}
+
+// Word `u` of a tile fetched by gdv_bitmap_tile, as a wave-uniform value (SGPR pair):
+// merging the validity of several columns is then s_and_b64, not per-lane work.
+GDV_DEV gdv_uint64 gdv_tile_word(gdv_uint64 tile, int u) {
+  gdv_uint32 lo = __builtin_amdgcn_readlane((gdv_uint32)tile, u);
+  gdv_uint32 hi = __builtin_amdgcn_readlane((gdv_uint32)(tile >> 32), u);
+  return ((gdv_uint64)hi << 32) | lo;
+}
+
+// Deposit the wave-uniform `word` into lane `u` of the accumulator: after GDV_U deposits
+// lanes 0..GDV_U-1 hold the wave's output words and store them with one coalesced store.
+// ---- wave-level prefix sum / sum of a 32-bit value (64 lanes), on the DPP data path:
+// row_shr 1,2,3 + row_shr 4/8 with bank masks, then row_bcast 15 / 31 across the four rows
+// (the classic GCN/CDNA scan; no LDS traffic, no cross-lane permute instructions).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+GDV_DEV gdv_int32 gdv_dpp_add(gdv_int32 acc, gdv_int32 src) {
+  // lanes the masks disable, and lanes whose source falls outside the row, contribute 0
+  return acc + __builtin_amdgcn_update_dpp(0, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+GDV_DEV gdv_int32 gdv_wave_scan_incl(gdv_int32 v) {
+  gdv_int32 r = v;
+  r = gdv_dpp_add<0x111, 0xf, 0xf>(r, v);  // row_shr:1
+  r = gdv_dpp_add<0x112, 0xf, 0xf>(r, v);  // row_shr:2
+  r = gdv_dpp_add<0x113, 0xf, 0xf>(r, v);  // row_shr:3
+  r = gdv_dpp_add<0x114, 0xf, 0xe>(r, r);  // row_shr:4, banks 1-3
+  r = gdv_dpp_add<0x118, 0xf, 0xc>(r, r);  // row_shr:8, banks 2-3
+  r = gdv_dpp_add<0x142, 0xa, 0xf>(r, r);  // row_bcast:15 into rows 1 and 3
+  r = gdv_dpp_add<0x143, 0xc, 0xf>(r, r);  // row_bcast:31 into rows 2 and 3
+  return r;
+}
+GDV_DEV gdv_int32 gdv_wave_last(gdv_int32 v) { return __builtin_amdgcn_readlane(v, 63); }
+// Byte totals of a wave tile must not wrap: a few very long strings (or a concat of them) can
+// exceed 2^31 bytes inside one tile.  Lanes accumulate with saturation, the wave sum is taken
+// on 16-bit halves, and a total of 2^31 or more is reported as exactly 2^31 — enough for the
+// host's "var-len output exceeds 2 GiB" check, which then never launches the byte pass.
+GDV_DEV gdv_int32 gdv_sat_add31(gdv_int32 a, gdv_int32 b) {
+  const gdv_uint32 s = (gdv_uint32)a + (gdv_uint32)b;
+  return s > 0x7fffffffu ? 0x7fffffff : (gdv_int32)s;
+}
+GDV_DEV gdv_uint32 gdv_tile_total(gdv_int32 lane_total) {  // lane_total in [0, 2^31)
+  const gdv_uint64 lo = (gdv_uint32)__builtin_amdgcn_readlane(gdv_wave_scan_incl(lane_total & 0xffff), 63);
+  const gdv_uint64 hi = (gdv_uint32)__builtin_amdgcn_readlane(gdv_wave_scan_incl(lane_total >> 16), 63);
+  const gdv_uint64 t = lo + (hi << 16);
+  return t >= 0x80000000ull ? 0x80000000u : (gdv_uint32)t;
+}
+GDV_DEV gdv_int32 gdv_wave_sum(gdv_int32 v) { return gdv_wave_last(gdv_wave_scan_incl(v)); }
+
+// bitmap words of a tile leave with one store per wave tile
+#define GDV_WORD_ST(p, v) (*(gdv_uint64*)(p) = (v))
+#define GDV_WORD_ST_NT(p, v) __builtin_nontemporal_store((gdv_uint64)(v), (gdv_uint64*)(p))
+GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int lane) {
+  return (lane == u) ? word : acc;  // v_cndmask with a scalar source
+}
+
+// Per-sub-tile register arrays inside a loop that is NOT unrolled: the current sub-tile's
+// element is always index 0 and every array rotates left by one at the end of an iteration
+// (static indices only: the arrays stay in registers; after GDV_U iterations they are back in
+// their original order, and a value written at [0] in iteration u ends up at [u]).
+#ifdef GDV_UNROLL_ROWS
+#define GDV_ROW_LOOP _Pragma("unroll")
+#else
+#define GDV_ROW_LOOP _Pragma("nounroll")
+#endif
+#ifdef GDV_U
+template <typename T>
+GDV_DEV void gdv_rot(T (&a)[GDV_U]) {
+  const T t = a[0];
+#pragma unroll
+  for (int k = 0; k + 1 < GDV_U; k++) a[k] = a[k + 1];
+  a[GDV_U - 1] = t;
+}
+#endif
+
+// Bit of an arbitrary row (selection-vector path: rows are gathered, no word structure).
+GDV_DEV bool gdv_bitmap_bit(const gdv_bitmap& bm, gdv_int64 row) {
+  gdv_int64 pos = row + bm.shift;
+  gdv_int64 i = pos >> 6;
+  i = i < bm.nwords - 1 ? i : bm.nwords - 1;
+  return (bm.p[i] >> (pos & 63)) & 1ull;
+}
+
+GDV_DEV bool gdv_lane_bit(gdv_uint64 word, int lane) { return (word >> lane) & 1ull; }
+
+// ------------------------------------------------------------------ arithmetic
+// Integer arithmetic wraps (two's complement); done in the unsigned domain so that the
+// wrap is defined behaviour.  Names: <op>_<type>_<type>, as in the reference's
+// precompiled arithmetic_ops.cc.
+
+#define GDV_INT_TYPES(X) \
+  X(int8, uint8) X(int16, uint16) X(int32, uint32) X(int64, uint64) \
+  X(uint8, uint8) X(uint16, uint16) X(uint32, uint32) X(uint64, uint64)
+#define GDV_FLOAT_TYPES(X) X(float32) X(float64)
+#define GDV_NUMERIC_TYPES(X) \
+  X(int8) X(int16) X(int32) X(int64) X(uint8) X(uint16) X(uint32) X(uint64) X(float32) X(float64)
+
+#define GDV_INT_ARITH(T, U)                                                                      \
+  GDV_DEV gdv_##T add_##T##_##T(gdv_##T a, gdv_##T b) {                                          \
+    return (gdv_##T)(gdv_##U)((gdv_##U)a + (gdv_##U)b);                                          \
+  }                                                                                              \
+  GDV_DEV gdv_##T subtract_##T##_##T(gdv_##T a, gdv_##T b) {                                     \
+    return (gdv_##T)(gdv_##U)((gdv_##U)a - (gdv_##U)b);                                          \
+  }                                                                                              \
+  GDV_DEV gdv_##T multiply_##T##_##T(gdv_##T a, gdv_##T b) {                                     \
+    return (gdv_##T)(gdv_##U)((gdv_##U)a * (gdv_##U)b);                                          \
+  }                                                                                              \
+  /* x / 0 raises "divide by zero error" and yields 0; MIN / -1 wraps to MIN. */                 \
+  GDV_DEV gdv_##T divide_##T##_##T(gdv_ctx ctx, gdv_##T a, gdv_##T b) {                          \
+    if (b == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }                                  \
+    if ((gdv_##T)(-1) < 0 && b == (gdv_##T)(-1)) return (gdv_##T)(gdv_##U)(0 - (gdv_##U)a);      \
+    return (gdv_##T)(a / b);                                                                     \
+  }
+GDV_INT_TYPES(GDV_INT_ARITH)
+
+#define GDV_FLOAT_ARITH(T)                                                                       \
+  GDV_DEV gdv_##T add_##T##_##T(gdv_##T a, gdv_##T b) { return a + b; }                          \
+  GDV_DEV gdv_##T subtract_##T##_##T(gdv_##T a, gdv_##T b) { return a - b; }                     \
+  GDV_DEV gdv_##T multiply_##T##_##T(gdv_##T a, gdv_##T b) { return a * b; }                     \
+  GDV_DEV gdv_##T divide_##T##_##T(gdv_ctx ctx, gdv_##T a, gdv_##T b) {                          \
+    if (b == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }                                  \
+    return a / b;                                                                                \
+  }
+GDV_FLOAT_TYPES(GDV_FLOAT_ARITH)
+
+// mod: a zero divisor returns the dividend unchanged (integer) / raises (float64).
+GDV_DEV gdv_int32 mod_int64_int32(gdv_int64 a, gdv_int32 b) {
+  if (b == 0) return (gdv_int32)a;
+  if (b == -1) return 0;
+  return (gdv_int32)(a % b);
+}
+GDV_DEV gdv_int64 mod_int64_int64(gdv_int64 a, gdv_int64 b) {
+  if (b == 0) return a;
+  if (b == -1) return 0;
+  return a % b;
+}
+GDV_DEV gdv_int32 mod_int32_int32(gdv_int32 a, gdv_int32 b) {
+  if (b == 0) return a;
+  if (b == -1) return 0;
+  return a % b;
+}
+GDV_DEV gdv_float64 mod_float64_float64(gdv_ctx ctx, gdv_float64 a, gdv_float64 b) {
+  if (b == 0.0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0.0; }
+  return fmod(a, b);
+}
+
+GDV_DEV gdv_int32 negative_int32(gdv_int32 a) { return (gdv_int32)(0u - (gdv_uint32)a); }
+GDV_DEV gdv_int64 negative_int64(gdv_int64 a) { return (gdv_int64)(0ull - (gdv_uint64)a); }
+GDV_DEV gdv_float32 negative_float32(gdv_float32 a) { return -a; }
+GDV_DEV gdv_float64 negative_float64(gdv_float64 a) { return -a; }
+GDV_DEV gdv_int32 abs_int32(gdv_int32 a) { return a < 0 ? negative_int32(a) : a; }
+GDV_DEV gdv_int64 abs_int64(gdv_int64 a) { return a < 0 ? negative_int64(a) : a; }
+GDV_DEV gdv_float32 abs_float32(gdv_float32 a) { return fabsf(a); }
+GDV_DEV gdv_float64 abs_float64(gdv_float64 a) { return fabs(a); }
+
+// ------------------------------------------------------------------ relational
+
+#define GDV_RELOPS(T)                                                                         \
+  GDV_DEV bool equal_##T##_##T(gdv_##T a, gdv_##T b) { return a == b; }                       \
+  GDV_DEV bool not_equal_##T##_##T(gdv_##T a, gdv_##T b) { return a != b; }                   \
+  GDV_DEV bool less_than_##T##_##T(gdv_##T a, gdv_##T b) { return a < b; }                    \
+  GDV_DEV bool less_than_or_equal_to_##T##_##T(gdv_##T a, gdv_##T b) { return a <= b; }       \
+  GDV_DEV bool greater_than_##T##_##T(gdv_##T a, gdv_##T b) { return a > b; }                 \
+  GDV_DEV bool greater_than_or_equal_to_##T##_##T(gdv_##T a, gdv_##T b) { return a >= b; }
+GDV_NUMERIC_TYPES(GDV_RELOPS)
+GDV_RELOPS(boolean)
+GDV_RELOPS(date32)
+GDV_RELOPS(date64)
+GDV_RELOPS(timestamp)
+GDV_RELOPS(time32)
+GDV_RELOPS(time64)
+
+GDV_DEV bool not_boolean(bool a) { return !a; }
+
+// null-aware predicates: the value function sees (value, validity) pairs
+template <typename T>
+GDV_DEV bool gdv_isnull(T, bool valid) { return !valid; }
+template <typename T>
+GDV_DEV bool gdv_isnotnull(T, bool valid) { return valid; }
+template <typename T>
+GDV_DEV bool gdv_is_distinct_from(T a, bool av, T b, bool bv) {
+  if (av != bv) return true;
+  if (!av) return false;
+  return a != b;
+}
+template <typename T>
+GDV_DEV bool gdv_is_not_distinct_from(T a, bool av, T b, bool bv) {
+  return !gdv_is_distinct_from(a, av, b, bv);
+}
+
+// IN-lists compare zero-extended bit images, so one sorted uint64 table serves every
+// fixed-width type.
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int8 v) { return (gdv_uint8)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint8 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int16 v) { return (gdv_uint16)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint16 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int32 v) { return (gdv_uint32)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint32 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_int64 v) { return (gdv_uint64)v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_uint64 v) { return v; }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_float32 v) { return __float_as_uint(v); }
+GDV_DEV gdv_uint64 gdv_bits64(gdv_float64 v) { return (gdv_uint64)__double_as_longlong(v); }
+GDV_DEV bool gdv_in_sorted(gdv_uint64 x, const gdv_uint64* tab, int n) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (tab[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo < n && tab[lo] == x;
+}
+GDV_DEV gdv_int128 gdv_make_int128(gdv_uint64 hi, gdv_uint64 lo) {
+  return (gdv_int128)(((gdv_uint128)hi << 64) | lo);
+}
+
+// min/max style helpers of later reference versions
+#define GDV_MINMAX(T)                                                                 \
+  GDV_DEV gdv_##T greatest_##T##_##T(gdv_##T a, gdv_##T b) { return a > b ? a : b; }  \
+  GDV_DEV gdv_##T least_##T##_##T(gdv_##T a, gdv_##T b) { return a < b ? a : b; }
+GDV_MINMAX(int32) GDV_MINMAX(int64) GDV_MINMAX(float32) GDV_MINMAX(float64)
+
+// ------------------------------------------------------------------ bitwise / boolean tests / nvl
+#define GDV_BITWISE(T)                                                                       \
+  GDV_DEV gdv_##T bitwise_and_##T##_##T(gdv_##T a, gdv_##T b) { return (gdv_##T)(a & b); }   \
+  GDV_DEV gdv_##T bitwise_or_##T##_##T(gdv_##T a, gdv_##T b) { return (gdv_##T)(a | b); }    \
+  GDV_DEV gdv_##T bitwise_xor_##T##_##T(gdv_##T a, gdv_##T b) { return (gdv_##T)(a ^ b); }   \
+  GDV_DEV gdv_##T bitwise_not_##T(gdv_##T a) { return (gdv_##T)(~a); }
+GDV_BITWISE(int32) GDV_BITWISE(int64) GDV_BITWISE(uint32) GDV_BITWISE(uint64)
+// null-aware boolean tests: never null themselves
+GDV_DEV bool istrue_boolean(bool v, bool valid) { return valid && v; }
+GDV_DEV bool isfalse_boolean(bool v, bool valid) { return valid && !v; }
+GDV_DEV bool isnottrue_boolean(bool v, bool valid) { return !(valid && v); }
+GDV_DEV bool isnotfalse_boolean(bool v, bool valid) { return !(valid && !v); }
+// nvl(a, b): a when a is valid, else b; null only when both are null
+template <typename T>
+GDV_DEV T gdv_nvl(T a, bool av, T b, bool bv, bool* out_valid) {
+  *out_valid = av || bv;
+  return av ? a : b;
+}
+
+// ------------------------------------------------------------------ casts
+GDV_DEV gdv_int64 castBIGINT_int32(gdv_int32 a) { return (gdv_int64)a; }
+GDV_DEV gdv_int32 castINT_int64(gdv_int64 a) { return (gdv_int32)(gdv_uint32)(gdv_uint64)a; }
+GDV_DEV gdv_float32 castFLOAT4_int32(gdv_int32 a) { return (gdv_float32)a; }
+GDV_DEV gdv_float32 castFLOAT4_int64(gdv_int64 a) { return (gdv_float32)a; }
+GDV_DEV gdv_float32 castFLOAT4_float64(gdv_float64 a) { return (gdv_float32)a; }
+GDV_DEV gdv_float64 castFLOAT8_int32(gdv_int32 a) { return (gdv_float64)a; }
+GDV_DEV gdv_float64 castFLOAT8_int64(gdv_int64 a) { return (gdv_float64)a; }
+GDV_DEV gdv_float64 castFLOAT8_float32(gdv_float32 a) { return (gdv_float64)a; }
+// float -> integer casts round half away from zero and saturate (out-of-range and NaN
+// inputs are undefined on the reference's CPU path; saturation / 0 keeps them defined).
+GDV_DEV gdv_int64 gdv_sat_i64(gdv_float64 r) {
+  if (r != r) return 0;
+  if (r >= 9223372036854775808.0) return 0x7fffffffffffffffLL;
+  if (r <= -9223372036854775808.0) return (gdv_int64)0x8000000000000000ULL;
+  return (gdv_int64)r;
+}
+GDV_DEV gdv_int32 gdv_sat_i32(gdv_float64 r) {
+  if (r != r) return 0;
+  if (r >= 2147483647.0) return 2147483647;
+  if (r <= -2147483648.0) return (gdv_int32)0x80000000u;
+  return (gdv_int32)r;
+}
+GDV_DEV gdv_int64 castBIGINT_float32(gdv_float32 a) { return gdv_sat_i64(round((gdv_float64)a)); }
+GDV_DEV gdv_int64 castBIGINT_float64(gdv_float64 a) { return gdv_sat_i64(round(a)); }
+GDV_DEV gdv_int32 castINT_float32(gdv_float32 a) { return gdv_sat_i32(round((gdv_float64)a)); }
+GDV_DEV gdv_int32 castINT_float64(gdv_float64 a) { return gdv_sat_i32(round(a)); }
+
+GDV_DEV gdv_date64 castDATE_int64(gdv_int64 a) { return a; }
+GDV_DEV gdv_timestamp castTIMESTAMP_int64(gdv_int64 a) { return a; }
+GDV_DEV gdv_timestamp castTIMESTAMP_date64(gdv_date64 a) { return a; }
+GDV_DEV gdv_int64 castBIGINT_date64(gdv_date64 a) { return a; }
+GDV_DEV gdv_int64 castBIGINT_timestamp(gdv_timestamp a) { return a; }
+
+// ------------------------------------------------------------------ extended math
+GDV_DEV gdv_float64 cbrt_float64(gdv_float64 a) { return cbrt(a); }
+GDV_DEV gdv_float64 exp_float64(gdv_float64 a) { return exp(a); }
+GDV_DEV gdv_float64 log_float64(gdv_float64 a) { return log(a); }
+GDV_DEV gdv_float64 log10_float64(gdv_float64 a) { return log10(a); }
+GDV_DEV gdv_float64 sqrt_float64(gdv_float64 a) { return sqrt(a); }
+GDV_DEV gdv_float64 power_float64_float64(gdv_float64 a, gdv_float64 b) { return pow(a, b); }
+GDV_DEV gdv_float64 log_float64_float64(gdv_ctx ctx, gdv_float64 base, gdv_float64 v) {
+  gdv_float64 lb = log(base);
+  if (lb == 0.0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0.0; }
+  return log(v) / lb;
+}
+GDV_DEV gdv_float64 floor_float64(gdv_float64 a) { return floor(a); }
+GDV_DEV gdv_float64 ceil_float64(gdv_float64 a) { return ceil(a); }
+GDV_DEV gdv_float64 round_float64(gdv_float64 a) { return round(a); }
+GDV_DEV gdv_float64 truncate_float64(gdv_float64 a) { return trunc(a); }
+
+// ------------------------------------------------------------------ hash
+// Murmur3-derived hashes over the 8-byte image of the value as a double (every numeric
+// type is first converted to double).  A null input hashes to the seed (0 without seed).
+GDV_DEV gdv_uint64 gdv_rotl64(gdv_uint64 v, int d) { return (v << d) | (v >> (64 - d)); }
+GDV_DEV gdv_uint64 gdv_fmix64(gdv_uint64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+GDV_DEV gdv_int64 gdv_murmur3_64(gdv_uint64 val, gdv_int32 seed) {
+  gdv_uint64 h1 = (gdv_uint64)(gdv_int64)seed;
+  gdv_uint64 h2 = (gdv_uint64)(gdv_int64)seed;
+  const gdv_uint64 c1 = 0x87c37b91114253d5ULL;
+  const gdv_uint64 c2 = 0x4cf5ad432745937fULL;
+  const gdv_uint64 length = 8;
+  gdv_uint64 k1 = val;
+  k1 *= c1;
+  k1 = gdv_rotl64(k1, 31);
+  k1 *= c2;
+  h1 ^= k1;
+  h1 ^= length;
+  h2 ^= length;
+  h1 += h2;
+  h2 += h1;
+  h1 = gdv_fmix64(h1);
+  h2 = gdv_fmix64(h2);
+  h1 += h2;
+  return (gdv_int64)h1;
+}
+GDV_DEV gdv_int32 gdv_murmur3_32(gdv_uint64 val, gdv_int32 seed) {
+  const gdv_uint32 c1 = 0xcc9e2d51u;
+  const gdv_uint32 c2 = 0x1b873593u;
+  gdv_uint32 h = (gdv_uint32)seed;
+  for (int i = 0; i < 2; i++) {
+    gdv_uint32 k = (gdv_uint32)(val >> (i * 32));
+    k *= c1;
+    k = (k << 15) | (k >> 17);
+    k *= c2;
+    h ^= k;
+    h = (h << 13) | (h >> 19);
+    h = h * 5u + 0xe6546b64u;
+  }
+  h ^= 8u;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return (gdv_int32)h;
+}
+GDV_DEV gdv_uint64 gdv_double_bits(gdv_float64 v) { return (gdv_uint64)__double_as_longlong(v); }
+
+#define GDV_HASH(T)                                                                              \
+  GDV_DEV gdv_int32 hash32_##T(gdv_##T v, bool valid) {                                          \
+    return valid ? gdv_murmur3_32(gdv_double_bits((gdv_float64)v), 0) : 0;                       \
+  }                                                                                              \
+  GDV_DEV gdv_int32 hash32_##T##_int32(gdv_##T v, bool valid, gdv_int32 seed, bool sv) {         \
+    gdv_int32 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_32(gdv_double_bits((gdv_float64)v), s) : s;                       \
+  }                                                                                              \
+  GDV_DEV gdv_int64 hash64_##T(gdv_##T v, bool valid) {                                          \
+    return valid ? gdv_murmur3_64(gdv_double_bits((gdv_float64)v), 0) : 0;                       \
+  }                                                                                              \
+  GDV_DEV gdv_int64 hash64_##T##_int64(gdv_##T v, bool valid, gdv_int64 seed, bool sv) {         \
+    gdv_int64 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_64(gdv_double_bits((gdv_float64)v), (gdv_int32)s) : s;            \
+  }
+GDV_NUMERIC_TYPES(GDV_HASH)
+GDV_HASH(boolean)
+GDV_HASH(date32)
+GDV_HASH(date64)
+GDV_HASH(timestamp)
+GDV_HASH(time32)
+
+// ------------------------------------------------------------------ date / time
+// Civil-calendar arithmetic on day counts since 1970-01-01 (proleptic Gregorian), the
+// public-domain algorithms of H. Hinnant's date library that the reference vendors
+// (present here as pyarrow/include/arrow/vendored/datetime/date.h).
+#define GDV_MILLIS_IN_DAY 86400000LL
+
+GDV_DEV gdv_int64 gdv_floor_div(gdv_int64 a, gdv_int64 b) {
+  gdv_int64 q = a / b;
+  return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+GDV_DEV gdv_int64 gdv_floor_mod(gdv_int64 a, gdv_int64 b) { return a - gdv_floor_div(a, b) * b; }
+
+struct gdv_ymd {
+  gdv_int64 y;
+  gdv_int32 m;  // 1..12
+  gdv_int32 d;  // 1..31
+};
+GDV_DEV gdv_ymd gdv_civil_from_days(gdv_int64 z) {
+  z += 719468;
+  const gdv_int64 era = (z >= 0 ? z : z - 146096) / 146097;
+  const gdv_uint32 doe = (gdv_uint32)(z - era * 146097);
+  const gdv_uint32 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const gdv_int64 y = (gdv_int64)yoe + era * 400;
+  const gdv_uint32 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const gdv_uint32 mp = (5 * doy + 2) / 153;
+  const gdv_uint32 d = doy - (153 * mp + 2) / 5 + 1;
+  const gdv_uint32 m = mp < 10 ? mp + 3 : mp - 9;
+  gdv_ymd r;
+  r.y = y + (m <= 2);
+  r.m = (gdv_int32)m;
+  r.d = (gdv_int32)d;
+  return r;
+}
+GDV_DEV gdv_int64 gdv_days_from_civil(gdv_int64 y, gdv_int32 m, gdv_int32 d) {
+  y -= m <= 2;
+  const gdv_int64 era = (y >= 0 ? y : y - 399) / 400;
+  const gdv_uint32 yoe = (gdv_uint32)(y - era * 400);
+  const gdv_uint32 doy = (153 * (m > 2 ? m - 3 : m + 9) + 2) / 5 + d - 1;
+  const gdv_uint32 doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + (gdv_int64)doe - 719468;
+}
+GDV_DEV bool gdv_is_leap(gdv_int64 y) { return (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0); }
+GDV_DEV gdv_int32 gdv_last_day_of_month(gdv_int64 y, gdv_int32 m) {
+  const gdv_int32 t[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  return (m == 2 && gdv_is_leap(y)) ? 29 : t[m - 1];
+}
+
+#define GDV_EXTRACT(T, TO_MILLIS)                                                                 \
+  GDV_DEV gdv_int64 extractYear_##T(gdv_##T v) {                                                  \
+    return gdv_civil_from_days(gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY)).y;                 \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractMonth_##T(gdv_##T v) {                                                 \
+    return gdv_civil_from_days(gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY)).m;                 \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractDay_##T(gdv_##T v) {                                                   \
+    return gdv_civil_from_days(gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY)).d;                 \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractQuarter_##T(gdv_##T v) { return (extractMonth_##T(v) - 1) / 3 + 1; }   \
+  GDV_DEV gdv_int64 extractDoy_##T(gdv_##T v) {                                                   \
+    gdv_int64 days = gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY);                              \
+    return days - gdv_days_from_civil(gdv_civil_from_days(days).y, 1, 1) + 1;                     \
+  }                                                                                               \
+  /* 1 = Sunday … 7 = Saturday */                                                                 \
+  GDV_DEV gdv_int64 extractDow_##T(gdv_##T v) {                                                   \
+    gdv_int64 days = gdv_floor_div(TO_MILLIS(v), GDV_MILLIS_IN_DAY);                              \
+    return gdv_floor_mod(days + 4, 7) + 1;                                                        \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractHour_##T(gdv_##T v) {                                                  \
+    return gdv_floor_mod(TO_MILLIS(v), GDV_MILLIS_IN_DAY) / 3600000LL;                            \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractMinute_##T(gdv_##T v) {                                                \
+    return (gdv_floor_mod(TO_MILLIS(v), GDV_MILLIS_IN_DAY) / 60000LL) % 60;                       \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractSecond_##T(gdv_##T v) {                                                \
+    return (gdv_floor_mod(TO_MILLIS(v), GDV_MILLIS_IN_DAY) / 1000LL) % 60;                        \
+  }                                                                                               \
+  GDV_DEV gdv_int64 extractEpoch_##T(gdv_##T v) { return gdv_floor_div(TO_MILLIS(v), 1000LL); }   \
+  GDV_DEV gdv_int64 extractDecade_##T(gdv_##T v) { return extractYear_##T(v) / 10; }              \
+  GDV_DEV gdv_int64 extractCentury_##T(gdv_##T v) { return (extractYear_##T(v) - 1) / 100 + 1; }  \
+  GDV_DEV gdv_int64 extractMillennium_##T(gdv_##T v) {                                            \
+    return (extractYear_##T(v) - 1) / 1000 + 1;                                                   \
+  }
+#define GDV_MS_IDENT(v) ((gdv_int64)(v))
+#define GDV_MS_FROM_DAYS(v) ((gdv_int64)(v) * GDV_MILLIS_IN_DAY)
+GDV_EXTRACT(date64, GDV_MS_IDENT)
+GDV_EXTRACT(timestamp, GDV_MS_IDENT)
+GDV_EXTRACT(date32, GDV_MS_FROM_DAYS)
+
+GDV_DEV gdv_int64 extractHour_time32(gdv_time32 v) { return (gdv_int64)v / 3600000; }
+GDV_DEV gdv_int64 extractMinute_time32(gdv_time32 v) { return ((gdv_int64)v / 60000) % 60; }
+GDV_DEV gdv_int64 extractSecond_time32(gdv_time32 v) { return ((gdv_int64)v / 1000) % 60; }
+
+// Month arithmetic clamps the day to the last day of the target month.
+GDV_DEV gdv_int64 gdv_add_months_ms(gdv_int64 millis, gdv_int64 months) {
+  gdv_int64 days = gdv_floor_div(millis, GDV_MILLIS_IN_DAY);
+  gdv_int64 tod = millis - days * GDV_MILLIS_IN_DAY;
+  gdv_ymd c = gdv_civil_from_days(days);
+  gdv_int64 total = c.y * 12 + (c.m - 1) + months;
+  gdv_int64 ny = gdv_floor_div(total, 12);
+  gdv_int32 nm = (gdv_int32)(total - ny * 12) + 1;
+  gdv_int32 last = gdv_last_day_of_month(ny, nm);
+  gdv_int32 nd = c.d > last ? last : c.d;
+  return gdv_days_from_civil(ny, nm, nd) * GDV_MILLIS_IN_DAY + tod;
+}
+
+#define GDV_TSADD(T)                                                                              \
+  GDV_DEV gdv_##T timestampaddSecond_int64_##T(gdv_int64 c, gdv_##T v) { return v + c * 1000LL; } \
+  GDV_DEV gdv_##T timestampaddMinute_int64_##T(gdv_int64 c, gdv_##T v) { return v + c * 60000LL; }\
+  GDV_DEV gdv_##T timestampaddHour_int64_##T(gdv_int64 c, gdv_##T v) { return v + c * 3600000LL; }\
+  GDV_DEV gdv_##T timestampaddDay_int64_##T(gdv_int64 c, gdv_##T v) {                             \
+    return v + c * GDV_MILLIS_IN_DAY;                                                             \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddWeek_int64_##T(gdv_int64 c, gdv_##T v) {                            \
+    return v + c * 7 * GDV_MILLIS_IN_DAY;                                                         \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddMonth_int64_##T(gdv_int64 c, gdv_##T v) {                           \
+    return gdv_add_months_ms(v, c);                                                               \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddQuarter_int64_##T(gdv_int64 c, gdv_##T v) {                         \
+    return gdv_add_months_ms(v, c * 3);                                                           \
+  }                                                                                               \
+  GDV_DEV gdv_##T timestampaddYear_int64_##T(gdv_int64 c, gdv_##T v) {                            \
+    return gdv_add_months_ms(v, c * 12);                                                          \
+  }                                                                                               \
+  GDV_DEV gdv_##T date_add_##T##_int64(gdv_##T v, gdv_int64 c) { return v + c * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_sub_##T##_int64(gdv_##T v, gdv_int64 c) { return v - c * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_add_##T##_int32(gdv_##T v, gdv_int32 c) { return v + c * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_sub_##T##_int32(gdv_##T v, gdv_int32 c) { return v - c * GDV_MILLIS_IN_DAY; }
+GDV_TSADD(date64)
+GDV_TSADD(timestamp)
+
+// Differences.  timestampdiff<Unit>(start, end) = whole units from start to end, truncated
+// toward zero; datediff(end, start) = calendar days (Hive semantics).
+#define GDV_TSDIFF(T)                                                                             \
+  GDV_DEV gdv_int32 timestampdiffSecond_##T##_##T(gdv_##T s, gdv_##T e) {                         \
+    return (gdv_int32)((e - s) / 1000LL);                                                         \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffMinute_##T##_##T(gdv_##T s, gdv_##T e) {                         \
+    return (gdv_int32)((e - s) / 60000LL);                                                        \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffHour_##T##_##T(gdv_##T s, gdv_##T e) {                           \
+    return (gdv_int32)((e - s) / 3600000LL);                                                      \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffDay_##T##_##T(gdv_##T s, gdv_##T e) {                            \
+    return (gdv_int32)((e - s) / GDV_MILLIS_IN_DAY);                                              \
+  }                                                                                               \
+  GDV_DEV gdv_int32 timestampdiffWeek_##T##_##T(gdv_##T s, gdv_##T e) {                           \
+    return (gdv_int32)((e - s) / (7 * GDV_MILLIS_IN_DAY));                                        \
+  }                                                                                               \
+  GDV_DEV gdv_int32 datediff_##T##_##T(gdv_##T e, gdv_##T s) {                                    \
+    return (gdv_int32)(gdv_floor_div(e, GDV_MILLIS_IN_DAY) - gdv_floor_div(s, GDV_MILLIS_IN_DAY)); \
+  }
+GDV_TSDIFF(date64)
+GDV_TSDIFF(timestamp)
+GDV_DEV gdv_int32 datediff_date32_date32(gdv_date32 e, gdv_date32 s) {
+  return (gdv_int32)((gdv_uint32)e - (gdv_uint32)s);
+}
+GDV_DEV gdv_date64 castDATE_date32(gdv_date32 d) { return (gdv_int64)d * GDV_MILLIS_IN_DAY; }
+GDV_DEV gdv_date32 castDATE32_date64(gdv_date64 d) {
+  return (gdv_date32)gdv_floor_div(d, GDV_MILLIS_IN_DAY);
+}
+GDV_DEV gdv_date64 castDATE_timestamp(gdv_timestamp t) {
+  return gdv_floor_div(t, GDV_MILLIS_IN_DAY) * GDV_MILLIS_IN_DAY;
+}
+
+// ------------------------------------------------------------------ decimal128
+// Arrow decimal128 = 128-bit two's complement integer + (precision, scale) in the type.
+// Precision and scale of the operands and of the result are PLAN constants: the planner passes
+// them as literals, every call is inlined, and the branches below fold away, leaving for the
+// common case (no down-scaling, e.g. dec(15,2) * dec(15,2) -> dec(31,4)) a bare 128-bit
+// multiply or add.  Result-type rules: DecimalResultType in gdv_registry.cc.  When the rules
+// had to cut the scale (precision capped at 38) the exact result is divided by 10^delta and
+// rounded half away from zero.  A result that does not fit 38 digits yields 0.
+GDV_DEV gdv_int128 gdv_pow10_128(int e) {
+  gdv_int128 r = 1;
+  for (int i = 0; i < e; i++) r *= 10;
+  return r;
+}
+GDV_DEV gdv_int128 gdv_dec_max38() { return gdv_pow10_128(38) - 1; }
+GDV_DEV gdv_int128 gdv_dec_clip38(gdv_int128 v) {
+  const gdv_int128 m = gdv_dec_max38();
+  return (v > m || v < -m) ? (gdv_int128)0 : v;
+}
+// v / 10^e rounded half away from zero
+GDV_DEV gdv_int128 gdv_dec_reduce(gdv_int128 v, int e) {
+  if (e <= 0) return v;
+  const gdv_int128 d = gdv_pow10_128(e);
+  gdv_int128 q = v / d, r = v % d;
+  if (r < 0) r = -r;
+  if (r >= d - r) q += (v < 0) ? -1 : 1;  // 2r >= d without forming 2r (d can be 10^38)
+  return q;
+}
+
+struct gdv_u256 { gdv_uint64 w[4]; };  // little-endian limbs
+GDV_DEV gdv_u256 gdv_mul_128x128(gdv_uint128 a, gdv_uint128 b) {
+  const gdv_uint64 a0 = (gdv_uint64)a, a1 = (gdv_uint64)(a >> 64);
+  const gdv_uint64 b0 = (gdv_uint64)b, b1 = (gdv_uint64)(b >> 64);
+  const gdv_uint128 p00 = (gdv_uint128)a0 * b0, p01 = (gdv_uint128)a0 * b1;
+  const gdv_uint128 p10 = (gdv_uint128)a1 * b0, p11 = (gdv_uint128)a1 * b1;
+  gdv_u256 r;
+  r.w[0] = (gdv_uint64)p00;
+  gdv_uint128 mid = (p00 >> 64) + (gdv_uint64)p01 + (gdv_uint64)p10;
+  r.w[1] = (gdv_uint64)mid;
+  gdv_uint128 hi = (mid >> 64) + (p01 >> 64) + (p10 >> 64) + (gdv_uint64)p11;
+  r.w[2] = (gdv_uint64)hi;
+  r.w[3] = (gdv_uint64)((hi >> 64) + (p11 >> 64));
+  return r;
+}
+GDV_DEV gdv_u256 gdv_mul_128x64(gdv_uint128 a, gdv_uint64 b) {
+  const gdv_uint128 p0 = (gdv_uint128)(gdv_uint64)a * b, p1 = (gdv_uint128)(gdv_uint64)(a >> 64) * b;
+  gdv_u256 r;
+  r.w[0] = (gdv_uint64)p0;
+  const gdv_uint128 mid = (p0 >> 64) + (gdv_uint64)p1;
+  r.w[1] = (gdv_uint64)mid;
+  r.w[2] = (gdv_uint64)((mid >> 64) + (p1 >> 64));
+  r.w[3] = 0;
+  return r;
+}
+// in-place divide by a 64-bit divisor, returns the remainder
+GDV_DEV gdv_uint64 gdv_divmod_u256_u64(gdv_u256& v, gdv_uint64 d) {
+  gdv_uint128 rem = 0;
+  for (int i = 3; i >= 0; i--) {
+    gdv_uint128 cur = (rem << 64) | v.w[i];
+    v.w[i] = (gdv_uint64)(cur / d);
+    rem = cur % d;
+  }
+  return (gdv_uint64)rem;
+}
+
+// p /= 10^delta, rounded half away from zero, in chunks of <= 10^18 (least significant digits
+// first).  The last chunk removed holds the most significant removed digits and alone decides
+// the rounding: 2*R >= 10^delta  <=>  2*last_rem >= last_div  (last_div is even, so lower
+// chunks can neither create nor break the tie).
+GDV_DEV void gdv_u256_div_pow10_round(gdv_u256& p, int delta) {
+  gdv_uint64 last_rem = 0, last_div = 1;
+  int left = delta;
+  while (left > 0) {
+    const int step = left > 18 ? 18 : left;
+    gdv_uint64 d = 1;
+    for (int i = 0; i < step; i++) d *= 10;
+    last_rem = gdv_divmod_u256_u64(p, d);
+    last_div = d;
+    left -= step;
+  }
+  if (delta > 0 && 2 * (gdv_uint128)last_rem >= (gdv_uint128)last_div) {
+    for (int i = 0; i < 4; i++) { if (++p.w[i] != 0) break; }
+  }
+}
+
+GDV_DEV gdv_int128 gdv_dec_rescale_up(gdv_int128 v, int by) { return by > 0 ? v * gdv_pow10_128(by) : v; }
+
+GDV_DEV gdv_int128 gdv_dec_add_large(gdv_int128 x, int xs, gdv_int128 y, int ys, int os);
+GDV_DEV gdv_int128 add_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp, int ys,
+                                             int op, int os) {
+  const int hs = xs > ys ? xs : ys;  // exact result scale
+  // Digits the operands can have once aligned to that scale — a compile-time fact.  Up to 37
+  // the aligned values and their sum fit 128 bits; beyond, the sum is formed in 256 bits.
+  const int xd = xp + hs - xs, yd = yp + hs - ys;
+  if ((xd > yd ? xd : yd) > 37) return gdv_dec_add_large(x, xs, y, ys, os);
+  gdv_int128 sum = gdv_dec_rescale_up(x, hs - xs) + gdv_dec_rescale_up(y, hs - ys);
+  return gdv_dec_clip38(gdv_dec_reduce(sum, hs - os));
+}
+GDV_DEV gdv_int128 subtract_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,
+                                                  int ys, int op, int os) {
+  return add_decimal128_decimal128(x, xp, xs, -y, yp, ys, op, os);
+}
+GDV_DEV gdv_int128 multiply_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,
+                                                  int ys, int op, int os) {
+  const int delta = xs + ys - os;  // digits the result-type rule cut from the scale
+  // Everything below is decided from the operand PRECISIONS, i.e. at compile time (they are
+  // literals in the generated kernel): no per-row branch is added.
+  if (xp + yp <= 38 && delta == 0) {  // cannot overflow 38 digits
+    // <= 18 digits fits int64 by type: one signed 64x64->128 multiply instead of 128x128
+    if (xp <= 18 && yp <= 18) return (gdv_int128)(gdv_int64)x * (gdv_int128)(gdv_int64)y;
+    return x * y;
+  }
+  const bool neg = (x < 0) != (y < 0);
+  const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  // a factor of <= 18 digits has a zero high word: half of the partial products vanish
+  gdv_u256 p = yp <= 18   ? gdv_mul_128x64(ax, (gdv_uint64)ay)
+               : xp <= 18 ? gdv_mul_128x64(ay, (gdv_uint64)ax)
+                          : gdv_mul_128x128(ax, ay);
+  gdv_u256_div_pow10_round(p, delta);
+  if (p.w[3] != 0 || p.w[2] != 0) return 0;  // overflow
+  gdv_uint128 mag = ((gdv_uint128)p.w[1] << 64) | p.w[0];
+  if (mag > (gdv_uint128)gdv_dec_max38()) return 0;
+  return neg ? -(gdv_int128)mag : (gdv_int128)mag;
+}
+
+// ---- 256-bit helpers for divide / mod: binary long division (256 shift-subtract steps).
+// Decimal division is expected to be slow; it is exact.
+GDV_DEV int gdv_u256_cmp(const gdv_u256& a, const gdv_u256& b) {
+  for (int i = 3; i >= 0; i--)
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+  return 0;
+}
+GDV_DEV void gdv_u256_sub(gdv_u256& a, const gdv_u256& b) {  // a -= b (a >= b)
+  gdv_uint64 borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    const gdv_uint128 d = (gdv_uint128)a.w[i] - b.w[i] - borrow;
+    a.w[i] = (gdv_uint64)d;
+    borrow = (gdv_uint64)(d >> 64) & 1;
+  }
+}
+GDV_DEV void gdv_u256_shl1(gdv_u256& a, gdv_uint64 in_bit) {
+  for (int i = 3; i > 0; i--) a.w[i] = (a.w[i] << 1) | (a.w[i - 1] >> 63);
+  a.w[0] = (a.w[0] << 1) | in_bit;
+}
+GDV_DEV bool gdv_u256_is_zero(const gdv_u256& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+GDV_DEV void gdv_u256_divmod(const gdv_u256& num, const gdv_u256& den, gdv_u256* q, gdv_u256* r) {
+  gdv_u256 quo = {{0, 0, 0, 0}}, rem = {{0, 0, 0, 0}};
+  for (int bit = 255; bit >= 0; bit--) {
+    gdv_u256_shl1(rem, (num.w[bit >> 6] >> (bit & 63)) & 1ull);
+    gdv_u256_shl1(quo, 0);
+    if (gdv_u256_cmp(rem, den) >= 0) {
+      gdv_u256_sub(rem, den);
+      quo.w[0] |= 1ull;
+    }
+  }
+  *q = quo;
+  *r = rem;
+}
+GDV_DEV gdv_u256 gdv_u256_from_u128(gdv_uint128 v) {
+  gdv_u256 r = {{(gdv_uint64)v, (gdv_uint64)(v >> 64), 0, 0}};
+  return r;
+}
+GDV_DEV gdv_int128 gdv_dec_from_mag(const gdv_u256& mag, bool neg) {  // 0 when it needs > 38 digits
+  if (mag.w[3] != 0 || mag.w[2] != 0) return 0;
+  const gdv_uint128 m = ((gdv_uint128)mag.w[1] << 64) | mag.w[0];
+  if (m > (gdv_uint128)gdv_dec_max38()) return 0;
+  return neg ? -(gdv_int128)m : (gdv_int128)m;
+}
+// x + y when the aligned operands can exceed 37 digits: signed-magnitude sum in 256 bits,
+// then the scale reduction (round half away from zero) and the 38-digit check
+GDV_DEV void gdv_u256_add(gdv_u256& a, const gdv_u256& b) {
+  gdv_uint64 carry = 0;
+  for (int i = 0; i < 4; i++) {
+    const gdv_uint128 t = (gdv_uint128)a.w[i] + b.w[i] + carry;
+    a.w[i] = (gdv_uint64)t;
+    carry = (gdv_uint64)(t >> 64);
+  }
+}
+GDV_DEV gdv_int128 gdv_dec_add_large(gdv_int128 x, int xs, gdv_int128 y, int ys, int os) {
+  const int hs = xs > ys ? xs : ys;
+  const bool xneg = x < 0, yneg = y < 0;
+  const gdv_u256 X = gdv_mul_128x128(xneg ? (gdv_uint128)(-x) : (gdv_uint128)x, (gdv_uint128)gdv_pow10_128(hs - xs));
+  const gdv_u256 Y = gdv_mul_128x128(yneg ? (gdv_uint128)(-y) : (gdv_uint128)y, (gdv_uint128)gdv_pow10_128(hs - ys));
+  gdv_u256 sum;
+  bool neg;
+  if (xneg == yneg) { sum = X; gdv_u256_add(sum, Y); neg = xneg; }
+  else if (gdv_u256_cmp(X, Y) >= 0) { sum = X; gdv_u256_sub(sum, Y); neg = xneg; }
+  else { sum = Y; gdv_u256_sub(sum, X); neg = yneg; }
+  gdv_u256_div_pow10_round(sum, hs - os);
+  return gdv_dec_from_mag(sum, neg);
+}
+// x / y at the result scale `os`: round_half_away(x * 10^(os - xs + ys) / y).  y == 0 raises.
+GDV_DEV gdv_int128 divide_decimal128_decimal128(gdv_ctx ctx, gdv_int128 x, int xp, int xs, gdv_int128 y,
+                                                int yp, int ys, int op, int os) {
+  if (y == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }
+  const int delta = os - xs + ys;  // >= 0 for every result type the rules produce
+  const bool neg = (x < 0) != (y < 0);
+  const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  // numerator = |x| * 10^delta; delta can exceed 38 (e.g. dec(38,0) / dec(38,37)), so the
+  // power of ten is applied in two steps and a numerator that leaves 256 bits means a
+  // quotient of more than 38 digits: overflow -> 0
+  const int d1 = delta > 38 ? 38 : (delta > 0 ? delta : 0);
+  gdv_u256 num = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(d1));
+  for (int left = delta - d1; left > 0; left -= 18) {
+    gdv_uint64 m = 1;
+    for (int i = 0; i < (left > 18 ? 18 : left); i++) m *= 10;
+    gdv_uint64 carry = 0;
+    for (int i = 0; i < 4; i++) {
+      const gdv_uint128 t = (gdv_uint128)num.w[i] * m + carry;
+      num.w[i] = (gdv_uint64)t;
+      carry = (gdv_uint64)(t >> 64);
+    }
+    if (carry != 0) return 0;
+  }
+  gdv_u256 den = gdv_u256_from_u128(ay), q, r;
+  gdv_u256_divmod(num, den, &q, &r);
+  gdv_u256_shl1(r, 0);                       // 2 * remainder (den < 2^127, no overflow)
+  if (gdv_u256_cmp(r, den) >= 0) { for (int i = 0; i < 4; i++) if (++q.w[i] != 0) break; }
+  return gdv_dec_from_mag(q, neg);
+}
+// x mod y at scale max(xs, ys), sign of the dividend.  y == 0 raises.
+GDV_DEV gdv_int128 mod_decimal128_decimal128(gdv_ctx ctx, gdv_int128 x, int xp, int xs, gdv_int128 y,
+                                             int yp, int ys, int op, int os) {
+  if (y == 0) { gdv_raise(ctx, GDV_ERR_DIV_ZERO); return 0; }
+  const gdv_uint128 ax = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = y < 0 ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  gdv_u256 a = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(ys > xs ? ys - xs : 0));
+  gdv_u256 b = gdv_mul_128x128(ay, (gdv_uint128)gdv_pow10_128(xs > ys ? xs - ys : 0));
+  gdv_u256 q, r;
+  gdv_u256_divmod(a, b, &q, &r);
+  return gdv_dec_from_mag(r, x < 0);
+}
+
+// comparisons bring both sides to the larger scale (exact: |v| < 10^38 and the scale
+// difference keeps 10^38 * 10^diff inside 256 bits only for small diffs, so compare via
+// 256-bit products when the rescale could overflow 128 bits)
+GDV_DEV int gdv_dec_compare(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp, int ys) {
+  if (xs == ys) return x < y ? -1 : (x > y ? 1 : 0);
+  const bool xneg = x < 0, yneg = y < 0;
+  if (xneg != yneg) return xneg ? -1 : 1;
+  const gdv_uint128 ax = xneg ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_uint128 ay = yneg ? (gdv_uint128)(-y) : (gdv_uint128)y;
+  gdv_u256 a = gdv_mul_128x128(ax, (gdv_uint128)gdv_pow10_128(ys > xs ? ys - xs : 0));
+  gdv_u256 b = gdv_mul_128x128(ay, (gdv_uint128)gdv_pow10_128(xs > ys ? xs - ys : 0));
+  int c = 0;
+  for (int i = 3; i >= 0 && c == 0; i--) c = a.w[i] < b.w[i] ? -1 : (a.w[i] > b.w[i] ? 1 : 0);
+  return xneg ? -c : c;
+}
+#define GDV_DEC_REL(name, expr)                                                                    \
+  GDV_DEV bool name##_decimal128_decimal128(gdv_int128 x, int xp, int xs, gdv_int128 y, int yp,   \
+                                            int ys, int op, int os) {                              \
+    const int c = gdv_dec_compare(x, xp, xs, y, yp, ys);                                           \
+    return expr;                                                                                   \
+  }
+GDV_DEC_REL(equal, c == 0)
+GDV_DEC_REL(not_equal, c != 0)
+GDV_DEC_REL(less_than, c < 0)
+GDV_DEC_REL(less_than_or_equal_to, c <= 0)
+GDV_DEC_REL(greater_than, c > 0)
+GDV_DEC_REL(greater_than_or_equal_to, c >= 0)
+
+GDV_DEV gdv_int128 negative_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return -x; }
+GDV_DEV gdv_int128 abs_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return x < 0 ? -x : x; }
+// int64 -> decimal(op, os): value * 10^os (0 on overflow of the declared precision)
+GDV_DEV gdv_int128 castDECIMAL_int64(gdv_int64 v, int op, int os) {
+  // |v| must stay below 10^(op - os); checked BEFORE scaling so the product cannot wrap
+  if (v == 0) return 0;
+  if (op - os <= 0) return 0;
+  const gdv_int128 lim = gdv_pow10_128(op - os);
+  if ((gdv_int128)v >= lim || (gdv_int128)v <= -lim) return 0;
+  return (gdv_int128)v * gdv_pow10_128(os);
+}
+GDV_DEV gdv_int128 castDECIMAL_int32(gdv_int32 v, int op, int os) { return castDECIMAL_int64(v, op, os); }
+// decimal -> decimal with another (precision, scale): rescale, round half away from zero
+GDV_DEV gdv_int128 castDECIMAL_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
+  if (os >= xs) {  // scale up: |x| must stay below 10^(op - (os - xs)), checked before scaling
+    const int by = os - xs;
+    if (x == 0) return 0;
+    if (op - by <= 0) return 0;
+    const gdv_int128 lim_in = gdv_pow10_128(op - by);
+    if (x >= lim_in || x <= -lim_in) return 0;
+    return x * gdv_pow10_128(by);
+  }
+  const gdv_int128 r = gdv_dec_reduce(x, xs - os);
+  const gdv_int128 lim = gdv_pow10_128(op);
+  return (r >= lim || r <= -lim) ? (gdv_int128)0 : r;
+}
+GDV_DEV gdv_float64 castFLOAT8_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
+  // two correctly rounded steps: int128 -> double, then divide by the exact power of ten
+  // (10^k is exact in binary64 for k <= 22; larger scales lose at most 1 ulp more)
+  gdv_float64 p = 1.0;
+  for (int i = 0; i < xs; i++) p *= 10.0;
+  const gdv_uint128 mag = x < 0 ? (gdv_uint128)(-x) : (gdv_uint128)x;
+  const gdv_float64 m = (gdv_float64)(gdv_uint64)(mag >> 64) * 18446744073709551616.0 +
+                        (gdv_float64)(gdv_uint64)mag;
+  return (x < 0 ? -m : m) / p;
+}
+GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
+  return (gdv_int64)gdv_dec_reduce(x, xs);
+}
+
+// ------------------------------------------------------------------ utf8 / binary
+// A string value inside a kernel is a VIEW: pointer + byte length into an input data buffer
+// (or a literal in the plan's constant block) plus a byte map applied on read (0 none, 1 ASCII
+// upper, 2 ASCII lower).  substr / trim produce narrower views, upper / lower set the map, so no
+// per-row scratch is ever needed; the bytes are materialised exactly once, by the copy stage of
+// a var-len output, or consumed in place by predicates (like, equal ...).
+//
+// Round 2: views carry no register cache any more.  Kernels over var-len columns first SWEEP the
+// contiguous byte span of a wave tile with lanes over BYTES (16 B/lane, coalesced): that pass
+// answers the tile-wide questions byte-parallel (is every byte ASCII?  where does '%needle%'
+// match?) and leaves the lines in L2 / L1 for the per-row functions below.
+#define GDV_STR_ASCII 1  // flags: every byte of the buffer range this view came from is < 0x80
+#define GDV_STR_INBUF 2  // flags: 8-byte loads starting anywhere inside the view stay inside its buffer
+// (out-of-line device functions fault on this stack — measured, profiles/r02_c5_codesize.txt —
+// so cold paths stay inline and the row loop of string kernels is simply not unrolled)
+#define GDV_COLD __forceinline__
+struct gdv_str {
+  const gdv_uint8* p;
+  gdv_int32 len;
+  gdv_int32 map;
+  const gdv_uint8* lim;  // end of the readable buffer p points into (8-byte loads stop here)
+  gdv_int32 flags;
+};
+GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
+                             const gdv_uint8* lim, gdv_int32 flags = 0) {
+  gdv_str s;
+  s.p = base + begin;
+  s.len = end - begin;
+  s.map = 0;
+  s.lim = lim;
+  s.flags = flags;
+  return s;
+}
+GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
+  if (map == 1) return (c >= 'a' && c <= 'z') ? (gdv_uint8)(c - 32) : c;
+  if (map == 2) return (c >= 'A' && c <= 'Z') ? (gdv_uint8)(c + 32) : c;
+  return c;
+}
+GDV_DEV gdv_uint8 gdv_str_at(const gdv_str& s, gdv_int32 i) { return gdv_map_byte(s.p[i], s.map); }
+
+// ---- word-at-a-time (SWAR) primitives: strings are processed 8 bytes per step with one
+// unaligned 8-byte load instead of 8 dependent byte loads; ASCII case mapping, UTF-8
+// continuation-byte counting and substring search all work on the 64-bit word.
+#define GDV_B80 0x8080808080808080ull
+#define GDV_B7F 0x7f7f7f7f7f7f7f7full
+// 8 bytes at p; bytes at or past `lim` read as 0.  In the last 8 bytes of the buffer the load
+// is moved back to end exactly at `lim` and shifted (one load, no byte loop).  Precondition
+// (the engine and the literal tables guarantee it): at least 8 readable bytes end at `lim`.
+GDV_DEV gdv_uint64 gdv_load8(const gdv_uint8* p, const gdv_uint8* lim) {
+  gdv_uint64 w;
+  if (p + 8 <= lim) {
+    __builtin_memcpy(&w, p, 8);
+    return w;
+  }
+  const gdv_int64 over = (gdv_int64)(p - lim) + 8;  // 1.. bytes of [p, p+8) past lim
+  __builtin_memcpy(&w, lim - 8, 8);
+  return over >= 8 ? 0ull : w >> (8 * over);
+}
+// the same without the limit check, for loads a wave-uniform test proved in range
+GDV_DEV gdv_uint64 gdv_load8_raw(const gdv_uint8* p) {
+  gdv_uint64 w;
+  __builtin_memcpy(&w, p, 8);
+  return w;
+}
+GDV_DEV gdv_uint64 gdv_low_bytes_mask(gdv_int32 nbytes) {  // nbytes in [0, 8]
+  return nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1ull);
+}
+GDV_DEV gdv_uint64 gdv_map8(gdv_uint64 w, gdv_int32 map) {
+  if (map == 0) return w;
+  const gdv_uint64 h = w & GDV_B7F;
+  const gdv_uint64 ascii = ~w & GDV_B80;
+  // top bit of each byte: h >= lo  and  h > hi, computed without cross-byte carries
+  const gdv_uint64 lo = map == 1 ? 0x1f1f1f1f1f1f1f1full : 0x3f3f3f3f3f3f3f3full;  // 0x80 - 'a' | 0x80 - 'A'
+  const gdv_uint64 hi = map == 1 ? 0x0505050505050505ull : 0x2525252525252525ull;  // 0x7f - 'z' | 0x7f - 'Z'
+  const gdv_uint64 in_range = (h + lo) & ~(h + hi) & ascii;
+  return w ^ (in_range >> 2);  // toggle bit 5 (0x20) of the letters in range
+}
+// raw bytes [i, i+8) of the string (bytes past the buffer limit read as 0)
+GDV_DEV gdv_uint64 gdv_raw_word_at(const gdv_str& s, gdv_int32 i) {
+  // INBUF is wave-uniform (one range test per tile / literal tables are padded): a scalar branch
+  if (s.flags & GDV_STR_INBUF) return gdv_load8_raw(s.p + i);
+  return gdv_load8(s.p + i, s.lim);
+}
+// mapped bytes [i, i+8) of the string (bytes past the buffer limit read as 0)
+GDV_DEV gdv_uint64 gdv_word_at(const gdv_str& s, gdv_int32 i) {
+  return gdv_map8(gdv_raw_word_at(s, i), s.map);
+}
+// Copy with as few (scattered) store instructions as possible: whole words, then ONE
+// overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
+// 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
+GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
+  if (s.len >= 8) {
+    gdv_int32 i = 0;
+    for (; i + 8 <= s.len; i += 8) {
+      const gdv_uint64 w = gdv_word_at(s, i);
+      __builtin_memcpy(dst + i, &w, 8);
+    }
+    if (i < s.len) {
+      const gdv_uint64 w = gdv_word_at(s, s.len - 8);
+      __builtin_memcpy(dst + s.len - 8, &w, 8);
+    }
+  } else if (s.len >= 4) {
+    const gdv_uint64 w = gdv_word_at(s, 0);
+    const gdv_uint32 lo = (gdv_uint32)w, hi = (gdv_uint32)(w >> (8 * (s.len - 4)));
+    __builtin_memcpy(dst, &lo, 4);
+    __builtin_memcpy(dst + s.len - 4, &hi, 4);
+  } else if (s.len > 0) {
+    const gdv_uint64 w = gdv_word_at(s, 0);
+    dst[0] = (gdv_uint8)w;
+    if (s.len > 1) dst[1] = (gdv_uint8)(w >> 8);
+    if (s.len > 2) dst[2] = (gdv_uint8)(w >> 16);
+  }
+}
+#ifndef GDV_HOST_BUILD
+// One row's bytes into the wave's LDS staging window: whole words, then a 4/2/1 ladder.
+typedef __attribute__((address_space(3))) gdv_uint8 gdv_lds_u8;
+GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
+  const gdv_int32 len = s.len;
+  gdv_int32 i = 0;
+  for (; i + 8 <= len; i += 8) {
+    const gdv_uint64 w = gdv_word_at(s, i);
+    __builtin_memcpy(dst + i, &w, 8);
+  }
+  const gdv_int32 r = len - i;
+  if (r > 0) {
+    gdv_uint64 w = gdv_word_at(s, i);  // bytes past the view are never stored
+    if (r & 4) { const gdv_uint32 v = (gdv_uint32)w; __builtin_memcpy(dst + i, &v, 4); i += 4; w >>= 32; }
+    if (r & 2) { const gdv_uint16 v = (gdv_uint16)w; __builtin_memcpy(dst + i, &v, 2); i += 2; w >>= 16; }
+    if (r & 1) dst[i] = (gdv_uint8)w;
+  }
+}
+#endif
+// the same out of line: rows that bypass the LDS staging window (wave tiles whose bytes do not
+// fit it) — rare, and inlining it at every sub-tile of every output doubles the kernel
+static __device__ GDV_COLD void gdv_str_copy_direct(gdv_uint8* dst, const gdv_uint8* p, gdv_int32 len, gdv_int32 map,
+                                                   const gdv_uint8* lim) {
+  gdv_str s;
+  s.p = p; s.len = len; s.map = map; s.lim = lim; s.flags = 0;
+  gdv_str_copy(dst, s);
+}
+// ---- LDS staging of var-len output bytes.  Every lane writes its row's bytes into the wave's
+// private LDS window at the row's offset inside the wave tile (byte-granular, unaligned LDS
+// writes: cheap), then the wave streams the window to HBM as consecutive 16-byte pieces, the last
+// one shifted back to end exactly at the total (it overlaps its neighbour with identical bytes) —
+// one coalesced store instruction per KiB instead of several scattered stores per row.  (Pieces
+// aligned in the output with head / tail bytes stored singly measured 2 % slower.)
+#define GDV_OUT_WIN (GDV_U * 64 * 8)  // staged bytes per wave tile and output: 8 per row on average
+#ifndef GDV_HOST_BUILD
+GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gdv_int32 cnt, int lane) {
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: ordering only
+  if (cnt >= 16) {
+    for (gdv_int32 i = lane * 16; i < cnt; i += 1024) {
+      const gdv_int32 j = i + 16 <= cnt ? i : cnt - 16;  // the last piece is shifted back to end at cnt
+      gdv_uint64 w[2];
+      __builtin_memcpy(w, win + j, 16);
+      __builtin_memcpy(dst + j, w, 16);
+    }
+  } else if (lane < cnt) {
+    dst[lane] = win[lane];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+// The output bytes of a wave tile ARE the (mapped) bytes of a contiguous input span (an input
+// column passed through, upper(col), lower(col) with no row dropped): stream them, lanes over
+// bytes, 16 B per lane.
+GDV_DEV void gdv_flat_copy(gdv_uint8* __restrict__ dst, const gdv_uint8* __restrict__ src, gdv_int32 cnt,
+                           gdv_int32 map, int lane) {
+  if (cnt >= 16) {
+    for (gdv_int32 i = lane * 16; i < cnt; i += 1024) {
+      const gdv_int32 j = i + 16 <= cnt ? i : cnt - 16;
+      gdv_uint64 w[2];
+      __builtin_memcpy(w, src + j, 16);
+      w[0] = gdv_map8(w[0], map);
+      w[1] = gdv_map8(w[1], map);
+      __builtin_memcpy(dst + j, w, 16);
+    }
+  } else if (lane < cnt) {
+    dst[lane] = gdv_map_byte(src[lane], map);
+  }
+}
+#endif
+
+GDV_DEV bool gdv_is_utf8_lead(gdv_uint8 c) { return (c & 0xC0) != 0x80; }
+// number of UTF-8 characters = bytes that are not continuation bytes (10xxxxxx)
+GDV_DEV gdv_uint64 gdv_mask_upto(gdv_int32 nbytes) {  // any nbytes: <= 0 -> 0, >= 8 -> all ones
+  return nbytes <= 0 ? 0ull : gdv_low_bytes_mask(nbytes);
+}
+GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
+  if (s.flags & GDV_STR_ASCII) return s.len;
+  gdv_int32 cont = 0;
+  for (gdv_int32 i = 0; i < s.len; i += 8) {
+    gdv_uint64 w = gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
+    cont += __popcll(w & GDV_B80 & ~((w << 1) & GDV_B80));
+  }
+  return s.len - cont;
+}
+static __device__ GDV_COLD bool gdv_bytes_are_ascii(const gdv_uint8* p, gdv_int32 len, const gdv_uint8* lim) {
+  gdv_uint64 acc = 0;
+  for (gdv_int32 i = 0; i < len; i += 8) acc |= gdv_load8(p + i, lim) & gdv_low_bytes_mask(len - i);
+  return (acc & GDV_B80) == 0;
+}
+GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
+  if (s.flags & GDV_STR_ASCII) return true;  // answered for the whole tile by the byte sweep
+  return gdv_bytes_are_ascii(s.p, s.len, s.lim);
+}
+// bytes [i, i+n) of s equal the n bytes at q (n >= 0; q readable up to qlim)
+GDV_DEV bool gdv_bytes_equal(const gdv_str& s, gdv_int32 i, const gdv_uint8* q, const gdv_uint8* qlim,
+                             gdv_int32 n) {
+  for (gdv_int32 k = 0; k < n; k += 8) {
+    const gdv_uint64 m = gdv_low_bytes_mask(n - k);
+    if (((gdv_word_at(s, i + k) ^ gdv_load8(q + k, qlim)) & m) != 0) return false;
+  }
+  return true;
+}
+
+// ---- hash of var-len values: MurmurHash3 over the (mapped) bytes, 8 bytes per load.
+// x64_128 variant, first 64 bits of the digest (hash64) and x86_32 variant (hash32); both
+// seeds start h1 (= h2) as the numeric variants above do.  Null hashes to the seed.
+GDV_DEV gdv_int64 gdv_murmur3_64_buf(const gdv_str& s, gdv_int32 seed) {
+  const gdv_uint64 c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  gdv_uint64 h1 = (gdv_uint64)(gdv_int64)seed, h2 = h1;
+  gdv_int32 i = 0;
+  for (; i + 16 <= s.len; i += 16) {
+    gdv_uint64 k1 = gdv_word_at(s, i), k2 = gdv_word_at(s, i + 8);
+    k1 *= c1; k1 = gdv_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = gdv_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = gdv_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = gdv_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const gdv_int32 rem = s.len - i;  // 0..15 tail bytes, zero-extended into (k1, k2)
+  if (rem > 8) {
+    gdv_uint64 k2 = gdv_word_at(s, i + 8) & gdv_low_bytes_mask(rem - 8);
+    k2 *= c2; k2 = gdv_rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+  }
+  if (rem > 0) {
+    gdv_uint64 k1 = gdv_word_at(s, i) & gdv_low_bytes_mask(rem);
+    k1 *= c1; k1 = gdv_rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  }
+  h1 ^= (gdv_uint64)s.len; h2 ^= (gdv_uint64)s.len;
+  h1 += h2; h2 += h1;
+  h1 = gdv_fmix64(h1); h2 = gdv_fmix64(h2);
+  h1 += h2;
+  return (gdv_int64)h1;
+}
+GDV_DEV gdv_uint32 gdv_mm32_block(gdv_uint32 h, gdv_uint32 k) {
+  k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u;
+  h ^= k; h = (h << 13) | (h >> 19);
+  return h * 5u + 0xe6546b64u;
+}
+GDV_DEV gdv_uint32 gdv_mm32_tail(gdv_uint32 h, gdv_uint32 k) {
+  k *= 0xcc9e2d51u; k = (k << 15) | (k >> 17); k *= 0x1b873593u;
+  return h ^ k;
+}
+GDV_DEV gdv_int32 gdv_murmur3_32_buf(const gdv_str& s, gdv_int32 seed) {
+  gdv_uint32 h = (gdv_uint32)seed;
+  for (gdv_int32 i = 0; i < s.len; i += 8) {
+    const gdv_int32 rem = s.len - i;
+    const gdv_uint64 w = gdv_word_at(s, i) & gdv_low_bytes_mask(rem);
+    const gdv_uint32 lo = (gdv_uint32)w, hi = (gdv_uint32)(w >> 32);
+    h = rem >= 4 ? gdv_mm32_block(h, lo) : gdv_mm32_tail(h, lo);
+    if (rem >= 8) h = gdv_mm32_block(h, hi);
+    else if (rem > 4) h = gdv_mm32_tail(h, hi);
+  }
+  h ^= (gdv_uint32)s.len;
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return (gdv_int32)h;
+}
+#define GDV_HASH_BUF(T)                                                                          \
+  GDV_DEV gdv_int32 hash32_##T(gdv_str v, bool valid) { return valid ? gdv_murmur3_32_buf(v, 0) : 0; } \
+  GDV_DEV gdv_int32 hash32_##T##_int32(gdv_str v, bool valid, gdv_int32 seed, bool sv) {         \
+    gdv_int32 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_32_buf(v, s) : s;                                                 \
+  }                                                                                              \
+  GDV_DEV gdv_int64 hash64_##T(gdv_str v, bool valid) { return valid ? gdv_murmur3_64_buf(v, 0) : 0; } \
+  GDV_DEV gdv_int64 hash64_##T##_int64(gdv_str v, bool valid, gdv_int64 seed, bool sv) {         \
+    gdv_int64 s = sv ? seed : 0;                                                                 \
+    return valid ? gdv_murmur3_64_buf(v, (gdv_int32)s) : s;                                      \
+  }
+GDV_HASH_BUF(utf8)
+GDV_HASH_BUF(binary)
+
+GDV_DEV gdv_int32 octet_length_utf8(gdv_str s) { return s.len; }
+GDV_DEV gdv_int32 bit_length_utf8(gdv_str s) { return s.len * 8; }
+GDV_DEV gdv_int32 char_length_utf8(gdv_str s) { return gdv_utf8_count(s); }
+GDV_DEV gdv_str upper_utf8(gdv_str s) { s.map = 1; return s; }
+GDV_DEV gdv_str lower_utf8(gdv_str s) { s.map = 2; return s; }
+
+// Comparisons work on 8-byte words (from the register cache where the view has one), not on
+// single bytes.  Bytes are compared as unsigned values in memory order, which is the little-end
+// byte of the first differing word.
+GDV_DEV int gdv_str_compare(const gdv_str& a, const gdv_str& b) {
+  const gdv_int32 n = a.len < b.len ? a.len : b.len;
+  for (gdv_int32 i = 0; i < n; i += 8) {
+    const gdv_uint64 m = gdv_low_bytes_mask(n - i);
+    const gdv_uint64 wa = gdv_word_at(a, i) & m, wb = gdv_word_at(b, i) & m;
+    const gdv_uint64 x = wa ^ wb;
+    if (x != 0) {
+      const int sh = __builtin_ctzll(x) & ~7;
+      return ((wa >> sh) & 0xffull) < ((wb >> sh) & 0xffull) ? -1 : 1;
+    }
+  }
+  return a.len < b.len ? -1 : (a.len > b.len ? 1 : 0);
+}
+GDV_DEV bool gdv_str_equal_words(const gdv_str& a, gdv_int32 at, const gdv_str& b, gdv_int32 n) {
+  for (gdv_int32 i = 0; i < n; i += 8) {  // bytes [at, at+n) of a against bytes [0, n) of b
+    const gdv_uint64 m = gdv_low_bytes_mask(n - i);
+    if (((gdv_word_at(a, at + i) ^ gdv_word_at(b, i)) & m) != 0) return false;
+  }
+  return true;
+}
+GDV_DEV bool equal_utf8_utf8(gdv_str a, gdv_str b) { return a.len == b.len && gdv_str_equal_words(a, 0, b, a.len); }
+GDV_DEV bool not_equal_utf8_utf8(gdv_str a, gdv_str b) { return !equal_utf8_utf8(a, b); }
+GDV_DEV bool less_than_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) < 0; }
+GDV_DEV bool less_than_or_equal_to_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) <= 0; }
+GDV_DEV bool greater_than_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) > 0; }
+GDV_DEV bool greater_than_or_equal_to_utf8_utf8(gdv_str a, gdv_str b) { return gdv_str_compare(a, b) >= 0; }
+GDV_DEV bool starts_with_utf8_utf8(gdv_str s, gdv_str prefix) {
+  return prefix.len <= s.len && gdv_str_equal_words(s, 0, prefix, prefix.len);
+}
+GDV_DEV bool ends_with_utf8_utf8(gdv_str s, gdv_str suffix) {
+  return suffix.len <= s.len && gdv_str_equal_words(s, s.len - suffix.len, suffix, suffix.len);
+}
+
+// the general (non-ASCII) substr: walks UTF-8 lead bytes; out of line, tiles of pure ASCII never call it
+static __device__ GDV_COLD gdv_str gdv_substr_utf8_general(gdv_str s, gdv_int64 from, gdv_int64 count) {
+  gdv_str r = s;
+  r.len = 0;
+  const gdv_int64 glyphs = gdv_utf8_count(s);
+  gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? glyphs + from : 0);
+  if (start < 0 || start >= glyphs) return r;
+  gdv_int64 stop = start + count < glyphs ? start + count : glyphs;
+  gdv_int32 g = 0, b0 = s.len, b1 = s.len;
+  for (gdv_int32 i = 0; i < s.len; i++) {
+    if (gdv_is_utf8_lead(s.p[i])) {
+      if (g == start) b0 = i;
+      if (g == stop) { b1 = i; break; }
+      g++;
+    }
+  }
+  r.p = s.p + b0;
+  r.len = b1 - b0;
+  return r;
+}
+
+// substr(s, from, len): 1-based character positions (UTF-8 aware); from < 0 counts from the
+// end; from == 0 behaves like 1; len <= 0 or a start outside the string give "".
+GDV_DEV gdv_str substr_utf8_int64_int64(gdv_str s, gdv_int64 from, gdv_int64 count) {
+  gdv_str r = s;
+  r.len = 0;
+  if (count <= 0 || s.len <= 0) return r;
+  if (gdv_str_is_ascii(s)) {  // character index == byte index
+    gdv_int64 start = from > 0 ? from - 1 : (from < 0 ? (gdv_int64)s.len + from : 0);
+    if (start < 0 || start >= s.len) return r;
+    gdv_int64 stop = start + count < s.len ? start + count : s.len;
+    r.p = s.p + start;
+    r.len = (gdv_int32)(stop - start);
+    return r;
+  }
+  return gdv_substr_utf8_general(s, from, count);
+}
+GDV_DEV gdv_str substr_utf8_int64(gdv_str s, gdv_int64 from) {
+  return substr_utf8_int64_int64(s, from, 0x7fffffff);
+}
+// byte offset of the character with 0-based index `ci` (s.len when the string is shorter)
+static __device__ GDV_COLD gdv_int32 gdv_utf8_byte_pos_general(const gdv_uint8* p, gdv_int32 len, gdv_int32 ci) {
+  gdv_int32 g = 0;
+  for (gdv_int32 i = 0; i < len; i++) {
+    if (gdv_is_utf8_lead(p[i])) {
+      if (g == ci) return i;
+      g++;
+    }
+  }
+  return len;
+}
+GDV_DEV gdv_int32 gdv_utf8_byte_pos(const gdv_str& s, gdv_int32 ci) {
+  if (ci <= 0) return 0;
+  if (s.flags & GDV_STR_ASCII) return ci < s.len ? ci : s.len;
+  return gdv_utf8_byte_pos_general(s.p, s.len, ci);
+}
+GDV_DEV gdv_str gdv_empty_str() { return gdv_make_str(nullptr, 0, 0, nullptr, GDV_STR_ASCII | GDV_STR_INBUF); }
+// left(s, n): the first n characters; n < 0: all but the last |n|
+GDV_DEV gdv_str left_utf8_int32(gdv_str s, gdv_int32 n) {
+  gdv_str r = s;
+  r.len = 0;
+  if (n == 0 || s.len <= 0) return r;
+  const gdv_int32 chars = gdv_utf8_count(s);
+  const gdv_int32 end = n > 0 ? (n < chars ? n : chars) : (chars + n > 0 ? chars + n : 0);
+  r.len = gdv_utf8_byte_pos(s, end);
+  return r;
+}
+// right(s, n): the last n characters; n < 0: all but the first |n|
+GDV_DEV gdv_str right_utf8_int32(gdv_str s, gdv_int32 n) {
+  gdv_str r = s;
+  r.len = 0;
+  if (n == 0 || s.len <= 0) return r;
+  const gdv_int32 chars = gdv_utf8_count(s);
+  const gdv_int32 start = n > 0 ? chars - (n < chars ? n : chars) : (-(gdv_int64)n < chars ? -n : chars);
+  const gdv_int32 b = gdv_utf8_byte_pos(s, start);
+  r.p = s.p + b;
+  r.len = s.len - b;
+  return r;
+}
+// castVARCHAR(s, n): s cut to at most n characters; n < 0 is an execution error
+GDV_DEV gdv_str castVARCHAR_utf8_int64(gdv_ctx ctx, gdv_str s, gdv_int64 n) {
+  gdv_str r = s;
+  if (n < 0) { gdv_raise(ctx, GDV_ERR_BAD_ARG); r.len = 0; return r; }
+  if (n >= s.len) return r;  // bytes >= characters
+  r.len = gdv_utf8_byte_pos(s, (gdv_int32)n);
+  return r;
+}
+// locate(sub, str[, start]): 1-based character position of the first occurrence of sub in
+// str at or after character `start`; 0 when absent or when either string is empty
+GDV_DEV gdv_int32 locate_utf8_utf8_int32(gdv_ctx ctx, gdv_str sub, gdv_str str, gdv_int32 start) {
+  if (start < 1) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return 0; }
+  if (str.len <= 0 || sub.len <= 0) return 0;
+  const gdv_int32 b = gdv_utf8_byte_pos(str, start - 1);
+  for (gdv_int32 i = b; i + sub.len <= str.len; i++) {
+    bool eq = true;
+    for (gdv_int32 k = 0; k < sub.len && eq; k++) eq = gdv_str_at(str, i + k) == gdv_str_at(sub, k);
+    if (eq) {
+      gdv_str head = str;
+      head.len = i;
+      return gdv_utf8_count(head) + 1;
+    }
+  }
+  return 0;
+}
+GDV_DEV gdv_int32 locate_utf8_utf8(gdv_ctx ctx, gdv_str sub, gdv_str str) {
+  return locate_utf8_utf8_int32(ctx, sub, str, 1);
+}
+GDV_DEV gdv_int32 strpos_utf8_utf8(gdv_ctx ctx, gdv_str str, gdv_str sub) {
+  return locate_utf8_utf8_int32(ctx, sub, str, 1);
+}
+// castINT / castBIGINT from text: blanks trimmed on both sides, an optional '-', one or more
+// decimal digits, nothing else; anything that is not such a number or does not fit the type is
+// an execution error (the reference: "Failed to cast the string ... to int32").
+GDV_DEV bool gdv_parse_int64(const gdv_str& s, gdv_int64 min_value, gdv_int64 max_value, gdv_int64* out) {
+  gdv_int32 lo = 0, hi = s.len;
+  while (lo < hi && gdv_str_at(s, lo) == ' ') lo++;
+  while (hi > lo && gdv_str_at(s, hi - 1) == ' ') hi--;
+  bool neg = false;
+  if (lo < hi && gdv_str_at(s, lo) == '-') { neg = true; lo++; }
+  if (lo >= hi) return false;
+  // accumulate as a NEGATIVE number so that the most negative value parses without overflow
+  gdv_int64 acc = 0;
+  const gdv_int64 floor_value = neg ? min_value : -max_value;
+  for (gdv_int32 i = lo; i < hi; i++) {
+    const gdv_int32 d = (gdv_int32)gdv_str_at(s, i) - '0';
+    if (d < 0 || d > 9) return false;
+    if (acc < (floor_value + d) / 10) return false;  // acc * 10 - d would pass the floor
+    acc = acc * 10 - d;
+  }
+  *out = neg ? acc : -acc;
+  return true;
+}
+GDV_DEV gdv_int64 castBIGINT_utf8(gdv_ctx ctx, gdv_str s) {
+  gdv_int64 v = 0;
+  if (!gdv_parse_int64(s, (gdv_int64)(-9223372036854775807LL - 1), 9223372036854775807LL, &v)) {
+    gdv_raise(ctx, GDV_ERR_BAD_ARG);
+    return 0;
+  }
+  return v;
+}
+GDV_DEV gdv_int32 castINT_utf8(gdv_ctx ctx, gdv_str s) {
+  gdv_int64 v = 0;
+  if (!gdv_parse_int64(s, -2147483648LL, 2147483647LL, &v)) {
+    gdv_raise(ctx, GDV_ERR_BAD_ARG);
+    return 0;
+  }
+  return (gdv_int32)v;
+}
+// ascii(s): the first byte as a signed char (0 for the empty string)
+GDV_DEV gdv_int32 ascii_utf8(gdv_str s) { return s.len > 0 ? (gdv_int32)(gdv_int8)gdv_str_at(s, 0) : 0; }
+
+GDV_DEV bool gdv_is_space(gdv_uint8 c) { return c == ' '; }
+GDV_DEV gdv_str ltrim_utf8(gdv_str s) {
+  while (s.len > 0 && gdv_is_space(s.p[0])) { s.p++; s.len--; }
+  return s;
+}
+GDV_DEV gdv_str rtrim_utf8(gdv_str s) {
+  while (s.len > 0 && gdv_is_space(s.p[s.len - 1])) s.len--;
+  return s;
+}
+GDV_DEV gdv_str btrim_utf8(gdv_str s) { return rtrim_utf8(ltrim_utf8(s)); }
+
+// SQL LIKE.  The pattern is compiled at Make time (gdv_planner.cc) into parallel arrays in
+// constant memory: kind[i] = 0 literal byte, 1 '_' (exactly one UTF-8 character),
+// 2 '%' (any run, possibly empty); byte[i] = the literal.  Matching is the classic
+// two-cursor wildcard walk with a single backtrack point (the last '%'): O(len * plen) worst
+// case, O(len) for the usual '%needle%' / 'prefix%' shapes.  The whole string must match.
+static __device__ GDV_COLD bool gdv_like(const gdv_str& s, const gdv_uint8* pbyte, const gdv_uint8* pkind, gdv_int32 plen) {
+  gdv_int32 i = 0, j = 0, star_j = -1, star_i = 0;
+  while (i < s.len) {
+    if (j < plen && pkind[j] == 2) {
+      star_j = j++;
+      star_i = i;
+    } else if (j < plen && pkind[j] == 1) {
+      i++;
+      while (i < s.len && !gdv_is_utf8_lead(s.p[i])) i++;  // swallow continuation bytes
+      j++;
+    } else if (j < plen && pkind[j] == 0 && gdv_str_at(s, i) == pbyte[j]) {
+      i++;
+      j++;
+    } else if (star_j >= 0) {
+      j = star_j + 1;
+      star_i++;
+      while (star_i < s.len && !gdv_is_utf8_lead(s.p[star_i])) star_i++;
+      i = star_i;
+    } else {
+      return false;
+    }
+  }
+  while (j < plen && pkind[j] == 2) j++;
+  return j == plen;
+}
+
+// LIKE shapes the planner recognises at Make time and routes around the general matcher:
+//   'literal'      -> gdv_like_equal       'literal%'  -> gdv_like_prefix
+//   '%literal'     -> gdv_like_suffix      '%literal%' -> gdv_like_contains
+// `nb` holds the literal (m bytes, readable 8 bytes past its end).
+GDV_DEV bool gdv_like_prefix(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  return m <= s.len && gdv_bytes_equal(s, 0, nb, nb + m + 8, m);
+}
+GDV_DEV bool gdv_like_suffix(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  return m <= s.len && gdv_bytes_equal(s, s.len - m, nb, nb + m + 8, m);
+}
+GDV_DEV bool gdv_like_equal(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  return m == s.len && gdv_bytes_equal(s, 0, nb, nb + m + 8, m);
+}
+// substring search, 8 candidate positions per step: a SWAR zero-byte test on
+// (word ^ first-needle-byte) yields the positions whose byte equals the needle's first byte;
+// only those are verified, on a 64-bit window assembled from the current and next word.
+// (The zero-byte test can flag a byte above a true match — harmless, it is verified too.)
+static __device__ GDV_COLD bool gdv_like_contains(const gdv_str& s, const gdv_uint8* nb, gdv_int32 m) {
+  if (m == 0) return true;
+  if (m > s.len) return false;
+  const gdv_uint64 mask = gdv_low_bytes_mask(m);
+  const gdv_uint64 first = gdv_load8(nb, nb + m + 8) & mask;
+  const gdv_uint64 splat = (first & 0xffull) * 0x0101010101010101ull;
+  const gdv_uint64 splat2 = ((first >> 8) & 0xffull) * 0x0101010101010101ull;
+  const gdv_int32 last = s.len - m;  // last candidate start
+  gdv_uint64 cur = gdv_word_at(s, 0);
+  for (gdv_int32 base = 0; base <= last; base += 8) {
+    const gdv_uint64 nxt = (base + 8 < s.len) ? gdv_word_at(s, base + 8) : 0ull;
+    const gdv_uint64 x = cur ^ splat;
+    gdv_uint64 cand = (x - 0x0101010101010101ull) & ~x & GDV_B80;
+    if (m >= 2) {
+      // second needle byte at the next position as well: with 64 lanes x 8 positions a
+      // one-byte filter lets some lane into the verification loop on nearly every word
+      const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat2;
+      cand &= (y - 0x0101010101010101ull) & ~y & GDV_B80;
+    }
+    while (cand) {
+      const int k = __builtin_ctzll(cand) >> 3;
+      cand &= cand - 1;
+      if (base + k > last) break;
+      const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
+      if ((win & mask) == first &&
+          (m <= 8 || gdv_bytes_equal(s, base + k + 8, nb + 8, nb + m + 8, m - 8)))
+        return true;
+    }
+    cur = nxt;
+  }
+  return false;
+}
+
+// IN over strings: linear probe of the literal list (lists are short in practice)
+GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_int32* offs, gdv_int32 n) {
+  for (gdv_int32 k = 0; k < n; k++) {
+    const gdv_int32 len = offs[k + 1] - offs[k];
+    if (len != s.len) continue;
+    bool eq = true;  // word-wise; the literal table is readable 8 bytes past its last byte
+    for (gdv_int32 i = 0; i < len && eq; i += 8)
+      eq = ((gdv_word_at(s, i) ^ gdv_load8_raw(bytes + offs[k] + i)) & gdv_low_bytes_mask(len - i)) == 0;
+    if (eq) return true;
+  }
+  return false;
+}
+
+
+// ------------------------------------------------------------------ var-len kernels: byte sweep
+// The rows of a wave tile occupy ONE contiguous span of the column's data buffer.  The sweep
+// walks that span with lanes over bytes (16 B per lane and step, coalesced) and answers
+// tile-wide questions once per byte instead of once per row and word:
+//   * is any byte >= 0x80?  (ASCII tiles skip every UTF-8 walk: substr, left, length ...)
+//   * where does a '%needle%' pattern match?  One bit per span byte in an LDS bitmap; a row then
+//     tests its own byte range with two word reads (gdv_range_any) — no per-row search loop.
+#define GDV_B01 0x0101010101010101ull
+#define GDV_SPAN_MAX (GDV_U * 64 * 32)  // bytes of span the LDS match bitmaps cover (32 per row)
+// bit k of the result: the m-byte needle (`first` = its bytes, `mask` = low m bytes set;
+// 2 <= m <= 8) starts at byte k of `cur` (its bytes continue in `nxt`).  Two-byte SWAR filter
+// (zero-byte tests on word ^ splat), exact verification of the few candidates.
+GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, gdv_uint64 mask,
+                              gdv_uint64 splat0, gdv_uint64 splat1) {
+  const gdv_uint64 x = cur ^ splat0;
+  gdv_uint64 cand = (x - GDV_B01) & ~x & GDV_B80;
+  const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat1;
+  cand &= (y - GDV_B01) & ~y & GDV_B80;
+  gdv_uint32 m = 0;
+  while (cand) {
+    const int k = __builtin_ctzll(cand) >> 3;
+    cand &= cand - 1;
+    const gdv_uint64 win = k == 0 ? cur : ((cur >> (8 * k)) | (nxt << (64 - 8 * k)));
+    if ((win & mask) == first) m |= 1u << k;
+  }
+  return m;
+}
+// One 16-byte piece of the byte sweep, written to a FLAT output as it is read (optimistic flat
+// mode: the output's bytes are the input's, so its offsets are the input's minus the first one
+// and need no scan).  Bytes [lo, hi) of the piece lie inside this wave's span; only those are
+// stored (neighbouring tiles write their own), and nothing at or past `cap`.
+GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
+                             gdv_int32 lo, gdv_int32 hi, gdv_int64 cap) {
+  const gdv_uint64 m0 = gdv_map8(w[0], map), m1 = gdv_map8(w[1], map);
+  if (lo <= 0 && hi >= 16 && doff + 16 <= cap) {
+    gdv_uint64 q[2] = {m0, m1};
+    __builtin_memcpy(dst + doff, q, 16);
+  } else {
+    const gdv_int32 k0 = lo > 0 ? lo : 0, k1 = hi < 16 ? hi : 16;
+    for (gdv_int32 k = k0; k < k1; k++)
+      if (doff + k < cap) dst[doff + k] = (gdv_uint8)((k < 8 ? m0 : m1) >> (8 * (k & 7)));
+  }
+}
+// any bit set in [lo, hi) of the bitmap (hi <= lo: empty range).  Branch-free for ranges of up
+// to 64 positions (rows up to 64 + needle bytes long): two adjacent words, one funnel shift, one
+// mask — the round-2 ablation (tools/c5_ablation.sh) priced the branchy word walk at 142 VALU
+// per 64 rows, a third of the kernel.  The bitmap is readable one word past any position.
+GDV_DEV bool gdv_range_any(const gdv_uint64* bm, gdv_int32 lo, gdv_int32 hi) {
+  const gdv_int32 nbits = hi - lo;
+  const gdv_int32 w = lo >> 6, s = lo & 63;
+  const gdv_uint64 x = (bm[w] >> s) | ((bm[w + 1] << 1) << (63 - s));  // positions lo .. lo+63
+  const gdv_uint64 m = nbits >= 64 ? ~0ull : ((1ull << (nbits > 0 ? nbits : 0)) - 1ull);
+  bool any = nbits > 0 && (x & m) != 0;
+  if (nbits > 64 && !any) {  // long rows: walk the remaining words
+    gdv_int32 p = lo + 64;
+    for (; p + 64 <= hi && !any; p += 64) {
+      const gdv_int32 pw = p >> 6, ps = p & 63;
+      any = ((bm[pw] >> ps) | ((bm[pw + 1] << 1) << (63 - ps))) != 0;
+    }
+    if (!any && p < hi) {
+      const gdv_int32 pw = p >> 6, ps = p & 63;
+      const gdv_uint64 y = (bm[pw] >> ps) | ((bm[pw + 1] << 1) << (63 - ps));
+      any = (y & ((1ull << (hi - p)) - 1ull)) != 0;
+    }
+  }
+  return any;
+}
+
+#ifndef GDV_HOST_BUILD
+// the value the NEXT lane holds (lane 63 gets 0): DPP wave_shl:1, no LDS traffic
+GDV_DEV gdv_uint64 gdv_next_lane(gdv_uint64 v) {
+  const gdv_uint32 lo = (gdv_uint32)__builtin_amdgcn_update_dpp(0, (int)(gdv_uint32)v, 0x130, 0xf, 0xf, false);
+  const gdv_uint32 hi = (gdv_uint32)__builtin_amdgcn_update_dpp(0, (int)(gdv_uint32)(v >> 32), 0x130, 0xf, 0xf, false);
+  return ((gdv_uint64)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------ var-len kernels: output offsets
+// ONE launch produces offsets and bytes: a workgroup tile (GDV_WAVES x GDV_U x 64 rows) needs the
+// byte total of every tile before it.  Workers post their tile's totals as an 8-byte granule and
+// poll ONE granule for the answer; a single scanner wave (workgroup 0) is the only reader of the
+// posted totals: it resolves the longest posted run in bulk and writes every tile's exclusive
+// prefix.  (Measured on MI355X, profiles/r02_k4_singlepass_proto.txt: agent-scope granule
+// accesses are priced per lane-access at the fabric, so classic decoupled look-back — every
+// tile polling up to 64 predecessors — costs more than the second pass it replaces.)
+// Granule: bits 63..62 status (0 nothing, 1 posted), bits 61..31 and 30..0 two 31-bit values
+// (two var-len outputs share a granule; Arrow offsets are int32, sums saturate at 2^31-1 and
+// the host rejects such a total).  Relaxed agent-scope atomics: the granule is its own flag.
+typedef __attribute__((address_space(1))) unsigned long long gdv_gu64;
+#define GDV_LB_POSTED (1ull << 62)
+#define GDV_LB_M31 0x7fffffffull
+#ifndef GDV_LB_WSLEEP
+#define GDV_LB_WSLEEP 4  // worker poll pace, in units of 64 clocks (sweep: profiles/r02_c5_poll_pace.txt)
+#endif
+#define GDV_ERR_STALL 8u
+#define GDV_ERR_NOTFLAT 16u  // an optimistic flat output met a null row that carries bytes: host re-runs
+GDV_DEV void gdv_lb_store(gdv_uint64* p, gdv_uint64 v) {
+  __hip_atomic_store((gdv_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+GDV_DEV gdv_uint64 gdv_lb_load(const gdv_uint64* p) {
+  return __hip_atomic_load((gdv_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+GDV_DEV gdv_uint64 gdv_sat31(gdv_uint64 v) { return v > GDV_LB_M31 ? GDV_LB_M31 : v; }
+GDV_DEV gdv_uint64 gdv_wave_excl_scan_u64(gdv_uint64 v, int lane, gdv_uint64* total) {
+  gdv_uint64 incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const gdv_uint64 o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  *total = __shfl(incl, 63, 64);
+  return incl - v;
+}
+// Scanner wave.  agg/pre: NG granule arrays of `ntiles` entries each (array g at g * ntiles).
+// totals[2 * g], totals[2 * g + 1]: grand totals of the two values of granule g.
+// Bounded: if nothing is posted for a very long time the scanner raises GDV_ERR_STALL and
+// leaves (the host then re-runs the batch in the serial-safe configuration).
+template <int NG>
+GDV_DEV void gdv_scanner(const gdv_uint64* agg, gdv_uint64* pre, gdv_int64 ntiles, gdv_uint64* totals,
+                         gdv_uint32* err, int lane) {
+  constexpr int K = 8;
+  gdv_int64 pos[NG];
+  gdv_uint64 c0[NG], c1[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) { pos[g] = 0; c0[g] = 0; c1[g] = 0; }
+  gdv_uint32 idle = 0;
+  for (;;) {
+    bool all_done = true, progressed = false;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      if (pos[g] >= ntiles) continue;
+      all_done = false;
+      const gdv_uint64* a = agg + (gdv_int64)g * ntiles;
+      gdv_uint64 s[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const gdv_int64 idx = pos[g] + (gdv_int64)lane * K + k;
+        s[k] = idx < ntiles ? gdv_lb_load(a + idx) : 0ull;
+      }
+      int lead = 0;
+      bool run = true;
+      gdv_uint64 a0 = 0, a1 = 0;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        run = run && (s[k] >> 62) == 1;
+        if (run) { lead++; a0 += s[k] & GDV_LB_M31; a1 += (s[k] >> 31) & GDV_LB_M31; }
+      }
+      const gdv_uint64 fullmask = __ballot(lead == K);
+      const int nf = fullmask == ~0ull ? 64 : __builtin_ctzll(~fullmask);
+      const int part = nf < 64 ? __builtin_amdgcn_readlane(lead, nf) : 0;
+      const int total_run = nf * K + part;
+      if (total_run == 0) continue;
+      progressed = true;
+      const int consumed = lane < nf ? K : (lane == nf ? part : 0);
+      gdv_uint64 t0, t1;
+      gdv_uint64 e0 = gdv_wave_excl_scan_u64(lane <= nf ? a0 : 0ull, lane, &t0) + c0[g];
+      gdv_uint64 e1 = gdv_wave_excl_scan_u64(lane <= nf ? a1 : 0ull, lane, &t1) + c1[g];
+      gdv_uint64* p = pre + (gdv_int64)g * ntiles + pos[g] + (gdv_int64)lane * K;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if (k < consumed) {
+          gdv_lb_store(p + k, GDV_LB_POSTED | (gdv_sat31(e1) << 31) | gdv_sat31(e0));
+          e0 += s[k] & GDV_LB_M31;
+          e1 += (s[k] >> 31) & GDV_LB_M31;
+        }
+      }
+      c0[g] += t0;
+      c1[g] += t1;
+      pos[g] += total_run;
+    }
+    if (all_done) break;
+    if (progressed) {
+      idle = 0;
+    } else {
+      __builtin_amdgcn_s_sleep(2);
+      if (++idle > (1u << 24)) {
+        if (lane == 0) atomicOr(err, GDV_ERR_STALL);
+        return;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < NG; g++) { totals[2 * g] = c0[g]; totals[2 * g + 1] = c1[g]; }
+  }
+}
+// Worker side, ONE thread: post the tile's granule g, later wait for its exclusive prefix.
+GDV_DEV void gdv_lb_post(gdv_uint64* agg, gdv_int64 ntiles, gdv_int64 tile, int g, gdv_uint64 v0, gdv_uint64 v1) {
+  gdv_lb_store(agg + (gdv_int64)g * ntiles + tile, GDV_LB_POSTED | (gdv_sat31(v1) << 31) | gdv_sat31(v0));
+}
+GDV_DEV gdv_uint64 gdv_lb_wait(const gdv_uint64* pre, gdv_int64 ntiles, gdv_int64 tile, int g, gdv_uint32* err) {
+  const gdv_uint64* p = pre + (gdv_int64)g * ntiles + tile;
+  for (gdv_uint32 spins = 0;; spins++) {
+    const gdv_uint64 v = gdv_lb_load(p);
+    if ((v >> 62) == 1) return v;
+    __builtin_amdgcn_s_sleep(GDV_LB_WSLEEP);
+    if (spins > (1u << 24)) {
+      atomicOr(err, GDV_ERR_STALL);
+      return 0;
+    }
+  }
+}
+#endif  // GDV_HOST_BUILD

@@ -1,0 +1,809 @@
+#include "gdv_engine.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <list>
+#include <unordered_map>
+
+#include "gdv_kernels.h"
+
+namespace gdv {
+
+namespace {
+
+// ------------------------------------------------------------------ LRU cache of built modules
+// (the reference keeps a process-wide, mutex-guarded LRU of compiled modules keyed on
+// schema + expressions + configuration: SURVEY.md §2 row 12)
+template <typename T>
+class LruCache {
+ public:
+  explicit LruCache(size_t cap) : cap_(cap) {}
+  std::shared_ptr<T> Get(const std::string& key) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = map_.find(key);
+    if (it == map_.end()) return nullptr;
+    order_.splice(order_.begin(), order_, it->second.second);
+    return it->second.first;
+  }
+  void Put(const std::string& key, std::shared_ptr<T> v) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (map_.count(key)) return;
+    order_.push_front(key);
+    map_[key] = {std::move(v), order_.begin()};
+    if (map_.size() > cap_) {
+      map_.erase(order_.back());
+      order_.pop_back();
+    }
+  }
+
+ private:
+  size_t cap_;
+  std::mutex mu_;
+  std::list<std::string> order_;
+  std::unordered_map<std::string,
+                     std::pair<std::shared_ptr<T>, std::list<std::string>::iterator>>
+      map_;
+};
+
+std::string SchemaKey(const Schema& s) {
+  std::string k;
+  for (auto& f : s) k += std::to_string(f.name.size()) + ":" + f.name + ":" + f.type.ToString() + ";";
+  return k;
+}
+
+// ------------------------------------------------------------------ argument block
+
+struct HostBitmap {
+  const uint64_t* p = nullptr;
+  int32_t shift = 0;
+  int32_t pad = 0;
+  int64_t nwords = 0;
+};
+static_assert(sizeof(HostBitmap) == 24, "must match struct gdv_bitmap in gdv_device_lib.hpp");
+
+class ArgBlock {
+ public:
+  explicit ArgBlock(const ArgLayout& l) : layout_(l), buf_(l.total(), 0) {}
+  void Set64(int off, uint64_t v) { std::memcpy(&buf_[off], &v, 8); }
+  void SetPtr(int off, const void* p) { Set64(off, reinterpret_cast<uint64_t>(p)); }
+  void SetInData(int k, const void* p) { SetPtr(layout_.in_base() + k * ArgLayout::kInStride, p); }
+  void SetInValid(int k, const HostBitmap& b) {
+    std::memcpy(&buf_[layout_.in_base() + k * ArgLayout::kInStride + 8], &b, 24);
+  }
+  void SetInBits(int k, const HostBitmap& b) {
+    std::memcpy(&buf_[layout_.in_base() + k * ArgLayout::kInStride + 32], &b, 24);
+  }
+  void SetInOffsets(int k, const void* p) {
+    SetPtr(layout_.in_base() + k * ArgLayout::kInStride + 56, p);
+  }
+  void SetOutData(int e, void* p) { SetPtr(layout_.out_base() + e * ArgLayout::kOutStride, p); }
+  void SetOutValid(int e, void* p) {
+    SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 8, p);
+  }
+  void SetOutOffsets(int e, void* p) {
+    SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 16, p);
+  }
+  void SetLit(int i, uint64_t v) { Set64(layout_.lit_base() + i * 8, v); }
+  void SetOutCap(int e, int64_t bytes) {
+    Set64(layout_.out_base() + e * ArgLayout::kOutStride + 24, static_cast<uint64_t>(bytes));
+  }
+  const void* data() const { return buf_.data(); }
+  size_t size() const { return buf_.size(); }
+
+ private:
+  ArgLayout layout_;
+  std::vector<char> buf_;
+};
+
+// Folds buffer misalignment and the Arrow array offset into (8-byte aligned word pointer,
+// shift < 64, readable words).  The buffer must be readable up to the next 8-byte boundary
+// (Arrow pads buffers to 64 bytes: pyarrow/include/arrow/type_fwd.h:759).
+HostBitmap FoldBitmap(const void* ptr, int64_t size, int64_t bit_offset) {
+  HostBitmap b;
+  if (ptr == nullptr) return b;
+  uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  uintptr_t aligned = a & ~uintptr_t(7);
+  int64_t lead = static_cast<int64_t>(a & 7) * 8 + bit_offset;
+  uintptr_t p = aligned + static_cast<uintptr_t>(lead >> 6) * 8;
+  b.p = reinterpret_cast<const uint64_t*>(p);
+  b.shift = static_cast<int32_t>(lead & 63);
+  int64_t bytes = static_cast<int64_t>(a + size - p);
+  b.nwords = bytes > 0 ? (bytes + 7) / 8 : 0;
+  return b;
+}
+
+int64_t BytesForBits(int64_t bits) { return (bits + 7) / 8; }
+
+// Error paths must not hand staging blocks back to the pool while copies or kernels that
+// use them are still queued: declared AFTER the Staging object, this drains the stream first.
+struct StreamDrain {
+  hipStream_t stream;
+  bool armed;
+  ~StreamDrain() {
+    if (armed) (void)hipStreamSynchronize(stream);
+  }
+};
+
+// GDV_TRACE=1: one line per Evaluate on stderr (kind, kernel, rows, device time between two
+// HIP events on the launch stream, rows/s).  The reference has no tracing of its own
+// (SURVEY.md §5); this is the hook its micro-benchmarks' std::chrono timers stood in for.
+// Tracing synchronises the stream, so it also serialises asynchronous evaluations.
+class EvalTrace {
+ public:
+  EvalTrace(const char* kind, const std::string& kernel, int64_t rows, hipStream_t stream)
+      : kind_(kind), kernel_(kernel), rows_(rows), stream_(stream) {
+    static const bool on = std::getenv("GDV_TRACE") != nullptr;
+    on_ = on;
+    if (on_ && hipEventCreate(&t0_) == hipSuccess && hipEventCreate(&t1_) == hipSuccess) {
+      (void)hipEventRecord(t0_, stream_);
+    } else {
+      on_ = false;
+    }
+  }
+  ~EvalTrace() {
+    if (!on_) return;
+    (void)hipEventRecord(t1_, stream_);
+    (void)hipEventSynchronize(t1_);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, t0_, t1_);
+    fprintf(stderr, "[gdv] %s %s rows=%lld device_ms=%.4f Mrows/s=%.1f\n", kind_, kernel_.c_str(),
+            static_cast<long long>(rows_), ms, ms > 0 ? rows_ / (ms * 1e3) : 0.0);
+    (void)hipEventDestroy(t0_);
+    (void)hipEventDestroy(t1_);
+  }
+
+ private:
+  const char* kind_;
+  std::string kernel_;
+  int64_t rows_;
+  hipStream_t stream_;
+  bool on_ = false;
+  hipEvent_t t0_ = nullptr, t1_ = nullptr;
+};
+
+// Host-buffer path.  Large batches: one device buffer and one copy per Arrow buffer (the
+// copies are PCIe-bound anyway).  Small batches (<= kPackRows rows, while they fit the
+// block): every staged input and every fixed-size output shares ONE device block mirrored by
+// ONE pinned host block — one H2D before the launches, one D2H after them — because a
+// pageable hipMemcpyAsync costs 10-25 us however small it is and a ten-expression projection
+// would issue ~30 of them (C2 at 1024 rows: 397 -> 74 us per Evaluate).
+struct Staging {
+  static constexpr int64_t kPackRows = 131072;
+  std::deque<DeviceBuffer> buffers;  // deque: references stay valid across Add()
+  DeviceBuffer& Add() {
+    buffers.emplace_back();
+    return buffers.back();
+  }
+  ~Staging() {
+    if (pin_ != nullptr) Runtime::Get().ReleasePinned(pin_);
+  }
+
+  Status EnablePacked() {
+    GDV_RETURN_NOT_OK(Runtime::Get().AcquirePinned(&pin_));
+    GDV_RETURN_NOT_OK(block_.Allocate(Runtime::kPinnedBlock));
+    packed_ = true;
+    return Status::OK();
+  }
+
+  // device copy of n host bytes, readable (zero-filled) up to `alloc` bytes
+  Status In(const void* src, size_t n, size_t alloc, hipStream_t stream, void** dev) {
+    if (alloc < n) alloc = n;
+    size_t off = 0;
+    if (packed_ && !flushed_ && Reserve(alloc, &off)) {
+      if (n > 0) std::memcpy(pin_ + off, src, n);
+      if (alloc > n) std::memset(pin_ + off + n, 0, alloc - n);
+      *dev = block_.as<char>() + off;
+      in_end_ = used_;
+      return Status::OK();
+    }
+    DeviceBuffer& d = Add();
+    GDV_RETURN_NOT_OK(d.Allocate(std::max<size_t>(alloc, 8)));
+    if (alloc > n) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(d.get(), 0, alloc, stream));
+    if (n > 0) GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(d.get(), src, n, hipMemcpyHostToDevice, stream));
+    *dev = d.get();
+    return Status::OK();
+  }
+  // all In() regions -> device with one copy; call once, before the first launch
+  Status FlushIn(hipStream_t stream) {
+    flushed_ = true;
+    if (packed_ && in_end_ > 0)
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(block_.get(), pin_, in_end_, hipMemcpyHostToDevice, stream));
+    return Status::OK();
+  }
+  // device region of `alloc` bytes whose first `copy` bytes FetchOut/Deliver bring to `user`
+  Status Out(size_t alloc, size_t copy, void* user, void** dev) {
+    size_t off = 0;
+    OutCopy oc{user, nullptr, 0, copy, false};
+    if (packed_ && Reserve(alloc, &off)) {
+      oc.off = off;
+      oc.packed = true;
+      *dev = block_.as<char>() + off;
+    } else {
+      DeviceBuffer& d = Add();
+      GDV_RETURN_NOT_OK(d.Allocate(std::max<size_t>(alloc, 8)));
+      oc.dev = d.get();
+      *dev = d.get();
+    }
+    outs_.push_back(oc);
+    return Status::OK();
+  }
+  Status FetchOut(hipStream_t stream) {
+    size_t lo = used_, hi = 0;
+    for (auto& o : outs_) {
+      if (o.n == 0) continue;
+      if (o.packed) {
+        lo = std::min(lo, o.off);
+        hi = std::max(hi, o.off + o.n);
+      } else {
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(o.user, o.dev, o.n, hipMemcpyDeviceToHost, stream));
+      }
+    }
+    if (hi > lo)
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(pin_ + lo, block_.as<char>() + lo, hi - lo,
+                                           hipMemcpyDeviceToHost, stream));
+    return Status::OK();
+  }
+  void Deliver() {  // after the stream is drained
+    for (auto& o : outs_)
+      if (o.packed && o.n > 0) std::memcpy(o.user, pin_ + o.off, o.n);
+  }
+
+ private:
+  struct OutCopy {
+    void* user;
+    void* dev;
+    size_t off, n;
+    bool packed;
+  };
+  bool Reserve(size_t bytes, size_t* off) {
+    const size_t at = (used_ + 255) & ~size_t{255};
+    if (at + bytes > Runtime::kPinnedBlock) return false;
+    *off = at;
+    used_ = at + bytes;
+    return true;
+  }
+  bool packed_ = false, flushed_ = false;
+  DeviceBuffer block_;
+  char* pin_ = nullptr;
+  size_t used_ = 0, in_end_ = 0;
+  std::vector<OutCopy> outs_;
+};
+
+// host bitmap bytes covering bits [off, off+rows) -> zero-padded device words
+Status StageBitmap(const void* host, int64_t off, int64_t rows, hipStream_t stream,
+                   Staging* st, HostBitmap* out) {
+  const int64_t first = off / 8;
+  const int64_t len = BytesForBits(off + rows) - first;
+  const int64_t words = (len + 7) / 8 + 1;
+  void* dev = nullptr;
+  GDV_RETURN_NOT_OK(st->In(static_cast<const char*>(host) + first, len, words * 8, stream, &dev));
+  out->p = static_cast<const uint64_t*>(dev);
+  out->shift = static_cast<int32_t>(off % 8);
+  out->nwords = words;
+  return Status::OK();
+}
+
+Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuffers* cols,
+                  int num_cols, int64_t num_rows, MemKind mem, hipStream_t stream,
+                  ArgBlock* args, Staging* st) {
+  if (num_cols != static_cast<int>(schema.size()))
+    return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
+                           ") does not match the schema (" + std::to_string(schema.size()) + ")");
+  for (size_t k = 0; k < plan.input_fields.size(); k++) {
+    const int idx = plan.input_fields[k];
+    const ColumnBuffers& c = cols[idx];
+    const DataType& t = schema[idx].type;
+    const std::string& name = schema[idx].name;
+    if (plan.input_needs_values[k]) {
+      if (c.data == nullptr && num_rows > 0 && !t.is_varlen())
+        return Status::Invalid("column '" + name + "' has no data buffer");
+      if (t.is_varlen()) {
+        // int32 offsets (rows + 1 of them, from the array offset) + the whole byte buffer
+        const int64_t need = (c.offset + num_rows + 1) * 4;
+        if (c.offsets == nullptr || c.offsets_size < need)
+          return Status::Invalid("column '" + name + "': offsets buffer too small");
+        const char* osrc = static_cast<const char*>(c.offsets) + c.offset * 4;
+        if (mem == MemKind::kHost) {
+          void *dof = nullptr, *dd = nullptr;
+          GDV_RETURN_NOT_OK(st->In(osrc, (num_rows + 1) * 4, (num_rows + 1) * 4, stream, &dof));
+          GDV_RETURN_NOT_OK(st->In(c.data, c.data_size, std::max<int64_t>(c.data_size, 8), stream, &dd));
+          args->SetInOffsets(static_cast<int>(k), dof);
+          args->SetInData(static_cast<int>(k), dd);
+        } else if (c.data_size < 8) {
+          // the kernels' 8-byte loads need 8 readable bytes ending at the limit: a tiny
+          // buffer is copied into a zero-padded one
+          DeviceBuffer& dd = st->Add();
+          GDV_RETURN_NOT_OK(dd.Allocate(8));
+          GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dd.get(), 0, 8, stream));
+          if (c.data_size > 0)
+            GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(dd.get(), c.data, c.data_size,
+                                                 hipMemcpyDeviceToDevice, stream));
+          args->SetInOffsets(static_cast<int>(k), osrc);
+          args->SetInData(static_cast<int>(k), dd.get());
+        } else {
+          args->SetInOffsets(static_cast<int>(k), osrc);
+          args->SetInData(static_cast<int>(k), c.data);
+        }
+        // readable extent of the byte buffer (the kernels' 8-byte loads stop at this limit)
+        HostBitmap extent;
+        extent.nwords = std::max<int64_t>(c.data_size, 8);
+        args->SetInBits(static_cast<int>(k), extent);
+      } else if (t.id == kBool) {
+        if (c.data_size < BytesForBits(c.offset + num_rows))
+          return Status::Invalid("column '" + name + "': data buffer too small");
+        HostBitmap b;
+        if (mem == MemKind::kHost) {
+          GDV_RETURN_NOT_OK(StageBitmap(c.data, c.offset, num_rows, stream, st, &b));
+        } else {
+          b = FoldBitmap(c.data, c.data_size, c.offset);
+        }
+        args->SetInBits(static_cast<int>(k), b);
+      } else {
+        const int w = t.byte_width();
+        if (c.data_size < (c.offset + num_rows) * w)
+          return Status::Invalid("column '" + name + "': data buffer too small (" +
+                                 std::to_string(c.data_size) + " bytes for " +
+                                 std::to_string(c.offset + num_rows) + " rows)");
+        const char* src = static_cast<const char*>(c.data) + c.offset * w;
+        if (mem == MemKind::kHost) {
+          void* d = nullptr;
+          GDV_RETURN_NOT_OK(st->In(src, num_rows * w, num_rows * w, stream, &d));
+          args->SetInData(static_cast<int>(k), d);
+        } else {
+          args->SetInData(static_cast<int>(k), src);
+        }
+      }
+    }
+    if (plan.input_needs_validity[k]) {
+      HostBitmap b;
+      if (c.validity == nullptr) {
+        // no validity buffer = no nulls: bind the one-word all-ones bitmap (index clamped)
+        GDV_RETURN_NOT_OK(Runtime::Get().AllOnesWord(&b.p));
+        b.shift = 0;
+        b.nwords = 1;
+      } else {
+        if (c.validity_size < BytesForBits(c.offset + num_rows))
+          return Status::Invalid("column '" + name + "': validity buffer too small");
+        if (mem == MemKind::kHost) {
+          GDV_RETURN_NOT_OK(StageBitmap(c.validity, c.offset, num_rows, stream, st, &b));
+        } else {
+          b = FoldBitmap(c.validity, c.validity_size, c.offset);
+        }
+      }
+      args->SetInValid(static_cast<int>(k), b);
+    }
+  }
+  return Status::OK();
+}
+
+int64_t GridFor(const KernelPlan& plan, int64_t rows) {
+  if (plan.string_skeleton) {
+    // one workgroup per tile (+ the scanner workgroup when there are var-len outputs)
+    const int64_t ntiles = (rows + plan.rows_per_tile() - 1) / plan.rows_per_tile();
+    return std::max<int64_t>(1, ntiles) + (plan.num_varlen_outputs > 0 ? 1 : 0);
+  }
+  const int64_t nwords = (rows + 63) / 64;
+  const int64_t per_tile = static_cast<int64_t>(plan.opts.subtiles) * plan.opts.waves;
+  int64_t ntiles = (nwords + per_tile - 1) / per_tile;
+  int blocks_per_cu = std::max(1, 32 / plan.opts.waves);
+  // String work per tile varies with the data (lengths, divergent per-row loops): four times
+  // as many, smaller shares of the grid-stride loop even out the tail (C5: 2.26 -> 2.01 ms;
+  // fixed-width plans measured best at the base value)
+  if (plan.has_varlen_input || plan.has_varlen_output) blocks_per_cu *= 4;
+  if (const char* s = std::getenv("GDV_GRID_MULT")) blocks_per_cu = std::max(1, atoi(s));
+  int64_t cap = static_cast<int64_t>(Runtime::Get().num_cus()) * blocks_per_cu;
+  return std::max<int64_t>(1, std::min(ntiles, cap));
+}
+
+std::string ErrorMessage(uint32_t bits) {
+  std::string m;
+  if (bits & 1u) m += "divide by zero error";
+  if (bits & 2u) m += (m.empty() ? "" : "; ") + std::string("overflow");
+  if (bits & 4u) m += (m.empty() ? "" : "; ") + std::string("invalid argument");
+  if (bits & 8u) m += (m.empty() ? "" : "; ") + std::string("device scan stalled");
+  return m.empty() ? "execution error" : m;
+}
+
+// String literals, LIKE patterns and IN tables of a plan live in one small device block that the
+// kernel reaches through gdv_args::aux0 (uploaded once, at Make).
+Status UploadConstBlock(const KernelPlan& plan, DeviceBuffer* out) {
+  if (plan.const_block.empty()) return Status::OK();
+  GDV_RETURN_NOT_OK(out->Allocate(plan.const_block.size() + 16));
+  GDV_HIP_RETURN_NOT_OK(hipMemcpy(out->get(), plan.const_block.data(), plan.const_block.size(), hipMemcpyHostToDevice));
+  return Status::OK();
+}
+
+void BindLiterals(const KernelPlan& plan, const DeviceBuffer& consts, ArgBlock* args) {
+  for (size_t i = 0; i < plan.literals.size(); i++) args->SetLit(static_cast<int>(i), plan.literals[i]);
+  args->SetPtr(ArgLayout::kOffAux0, consts.get());
+}
+
+LruCache<Projector>& ProjectorCache() {
+  static LruCache<Projector> c(500);
+  return c;
+}
+LruCache<Filter>& FilterCache() {
+  static LruCache<Filter> c(500);
+  return c;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ Projector
+
+Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                       SelectionMode mode, const Configuration& config,
+                       std::shared_ptr<Projector>* out) {
+  if (out == nullptr) return Status::Invalid("Projector::Make: null output pointer");
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  CodegenOptions opts = CodegenOptions::FromEnv();
+  std::string key = "P|" + SchemaKey(schema) + "|";
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    key += e->CacheKey() + ";";
+  }
+  key += "|m" + std::to_string(static_cast<int>(mode)) + "|" + opts.Key() +
+         (config.optimize ? "|O" : "|o");
+  if (auto hit = ProjectorCache().Get(key)) {
+    *out = hit;
+    return Status::OK();
+  }
+  auto p = std::make_shared<Projector>();
+  p->schema_ = schema;
+  GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, opts, &p->plan_));
+  GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.source, p->plan_.kernel_name, &p->kernel_));
+  GDV_RETURN_NOT_OK(UploadConstBlock(p->plan_, &p->consts_));
+  ProjectorCache().Put(key, p);
+  *out = p;
+  return Status::OK();
+}
+
+Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
+                           const SelectionView* sel, OutputBuffers* outs, int num_outs,
+                           MemKind mem, hipStream_t stream, uint32_t flags) const {
+  if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (outs == nullptr) return Status::Invalid("Output array vector cannot be null");
+  if (num_outs != num_outputs())
+    return Status::Invalid("number of output buffers (" + std::to_string(num_outs) +
+                           ") does not match the number of expressions (" +
+                           std::to_string(num_outputs()) + ")");
+  const bool has_sel = sel != nullptr && sel->mode != SelectionMode::kNone;
+  if (has_sel != (plan_.mode != SelectionMode::kNone) || (has_sel && sel->mode != plan_.mode))
+    return Status::Invalid("selection vector type does not match the mode the projector was built for");
+  const int64_t out_rows = has_sel ? sel->num_slots : num_rows;
+  if (has_sel) {
+    // what the selection vector's index type can address bounds its slot count
+    const int64_t cap = sel->mode == SelectionMode::kUInt16 ? 65536
+                        : sel->mode == SelectionMode::kUInt32 ? (int64_t{1} << 32)
+                                                              : INT64_MAX;
+    if (sel->num_slots < 0 || sel->num_slots > cap)
+      return Status::Invalid("selection vector: invalid slot count " + std::to_string(sel->num_slots));
+  }
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+
+  ArgBlock args(plan_.layout);
+  Staging st;
+  DeviceBuffer err;
+  // var-len outputs: grand totals / per-tile granules of the in-kernel offsets scan
+  DeviceBuffer tile_counts, tile_starts;
+  // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
+  StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output};
+  if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
+  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  BindLiterals(plan_, consts_, &args);
+  // pooled staging blocks (e.g. the zero-padded copy of a tiny var-len buffer) go back to the
+  // pool when this call returns: an asynchronous evaluation must not outlive them
+  drain.armed = drain.armed || !st.buffers.empty();
+  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
+
+  if (has_sel) {
+    const int w = plan_.mode == SelectionMode::kUInt16 ? 2 : plan_.mode == SelectionMode::kUInt32 ? 4 : 8;
+    if (out_rows > 0 && sel->indices == nullptr) return Status::Invalid("selection vector has no buffer");
+    if (mem == MemKind::kHost) {
+      void* d = nullptr;
+      GDV_RETURN_NOT_OK(st.In(sel->indices, out_rows * w, std::max<int64_t>(out_rows, 1) * w, stream, &d));
+      args.SetPtr(ArgLayout::kOffSel, d);
+    } else {
+      args.SetPtr(ArgLayout::kOffSel, sel->indices);
+    }
+  }
+
+  // outputs
+  std::vector<void*> dev_data(num_outs, nullptr), dev_valid(num_outs), dev_offs(num_outs, nullptr);
+  for (int e = 0; e < num_outs; e++) {
+    const DataType& t = plan_.output_types[e];
+    const int64_t need_valid_dev = ValidityBytes(out_rows);
+    const int64_t need_data_dev = t.is_varlen() ? 0 : DataBytes(t, out_rows);
+    const int64_t need_offs = t.is_varlen() ? (out_rows + 1) * 4 : 0;
+    if (t.is_varlen() && (outs[e].offsets == nullptr || outs[e].offsets_size < need_offs))
+      return Status::Invalid("output buffer " + std::to_string(e) + ": offsets buffer too small (" +
+                             std::to_string(need_offs) + " bytes needed)");
+    if (mem == MemKind::kHost) {
+      const int64_t need_data_host = t.id == kBool ? BytesForBits(out_rows) : need_data_dev;
+      if (outs[e].validity_size < BytesForBits(out_rows) || outs[e].data_size < need_data_host ||
+          (out_rows > 0 && (outs[e].validity == nullptr || (outs[e].data == nullptr && !t.is_varlen()))))
+        return Status::Invalid("output buffer " + std::to_string(e) + " too small");
+      const int64_t vbytes = out_rows > 0 ? BytesForBits(out_rows) : 0;
+      GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_valid_dev, 8), vbytes, outs[e].validity, &dev_valid[e]));
+      if (t.is_varlen()) {
+        GDV_RETURN_NOT_OK(st.Out(need_offs, out_rows > 0 ? need_offs : 0, outs[e].offsets, &dev_offs[e]));
+      } else {
+        const int64_t dbytes = out_rows == 0 ? 0 : (t.id == kBool ? vbytes : need_data_dev);
+        GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_data_dev, 8), dbytes, outs[e].data, &dev_data[e]));
+      }
+    } else {
+      if (outs[e].validity_size < need_valid_dev || outs[e].data_size < need_data_dev)
+        return Status::Invalid("output buffer " + std::to_string(e) +
+                               " too small (device buffers need 8-byte word granularity: " +
+                               std::to_string(need_valid_dev) + " validity bytes, " +
+                               std::to_string(need_data_dev) + " data bytes)");
+      dev_valid[e] = outs[e].validity;
+      dev_data[e] = outs[e].data;
+      dev_offs[e] = outs[e].offsets;
+    }
+    args.SetOutData(e, dev_data[e]);
+    args.SetOutValid(e, dev_valid[e]);
+    args.SetOutOffsets(e, dev_offs[e]);
+    // offsets[0] = 0 is written by the byte pass with every other offset; an empty selection
+    // launches nothing (the closing offset comes from the scan launcher)
+    if (t.is_varlen() && out_rows == 0) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_offs[e], 0, 4, stream));
+  }
+
+  const int nv = plan_.num_varlen_outputs;
+  const bool has_err = plan_.can_raise && nv == 0;  // var-len plans keep the error word in their scan-state block
+  if (has_err) {
+    GDV_RETURN_NOT_OK(err.Allocate(8));
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+    args.SetPtr(ArgLayout::kOffErr, err.get());
+  }
+
+  GDV_RETURN_NOT_OK(st.FlushIn(stream));
+  EvalTrace trace("project", plan_.kernel_name, out_rows, stream);
+  std::vector<uint64_t> totals(num_outs, 0);
+  uint32_t err_bits = 0;
+  if (nv == 0) {
+    if (out_rows > 0)
+      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
+                                  args.size(), stream));
+  } else if (out_rows > 0) {
+    // Single launch: workgroup 0 scans the tile totals (granules: tile_starts; grand totals:
+    // tile_counts), workers post one granule and poll one.  Device buffers: the caller's
+    // capacities are honoured inside the kernel (tiles that do not fit skip their bytes) and
+    // the totals say what was needed.  Host buffers: a first launch with capacity 0 sizes the
+    // device byte buffers, a second one fills them (the path is PCIe-bound anyway).
+    const int ng = (nv + 1) / 2;
+    const int64_t ntiles = (out_rows + plan_.rows_per_tile() - 1) / plan_.rows_per_tile();
+    // one block, one memset and one read-back per launch: [error word | grand totals | granules]
+    const size_t totals_bytes = static_cast<size_t>(2 * ng) * 8;
+    const size_t state_bytes = 8 + totals_bytes + static_cast<size_t>(2 * ng * ntiles) * 8;
+    GDV_RETURN_NOT_OK(tile_starts.Allocate(state_bytes));
+    char* const state = tile_starts.as<char>();
+    args.SetPtr(ArgLayout::kOffErr, state);
+    args.SetPtr(ArgLayout::kOffCounts, state + 8);
+    args.SetPtr(ArgLayout::kOffMask, state + 8 + totals_bytes);
+    std::vector<uint64_t> back(1 + 2 * ng, 0);
+    std::vector<int> vl;
+    for (int e = 0; e < num_outs; e++)
+      if (plan_.output_types[e].is_varlen()) vl.push_back(e);
+    std::vector<uint64_t> seg(2 * ng, 0);
+    const CompiledKernel* active = kernel_;
+    auto run = [&](int64_t grid) -> Status {
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(state, 0, state_bytes, stream));
+      GDV_RETURN_NOT_OK(rt.Launch(*active, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), state, 8 + totals_bytes, hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+      err_bits = static_cast<uint32_t>(back[0]);
+      for (int i = 0; i < 2 * ng; i++) seg[i] = back[1 + i];
+      return Status::OK();
+    };
+    // Outputs that are an input column's (mapped) bytes — a column passed through, upper(col),
+    // lower(col) — are first evaluated OPTIMISTICALLY: bytes copied by the byte sweep as they
+    // are read, offsets = input offsets rebased, no scan.  That holds unless a NULL row carries
+    // bytes (Arrow allows it, producers rarely do it); the kernel then raises NOTFLAT and the
+    // batch is re-run with those outputs on the general path.
+    // (sticky: a Projector whose batches carry bytes under nulls goes straight to the general
+    // variant from then on instead of paying two launches per batch)
+    bool optimistic = plan_.has_flat_output && !prefer_general_.load() && std::getenv("GDV_NO_OPTFLAT") == nullptr;
+    auto general_kernel = [&]() -> Status {
+      if (kernel_general_.load() == nullptr) {
+        const CompiledKernel* k = nullptr;
+        GDV_RETURN_NOT_OK(rt.GetKernel(plan_.source_general, plan_.kernel_name_general, &k));
+        kernel_general_.store(k);
+      }
+      return Status::OK();
+    };
+    auto launch = [&]() -> Status {
+      if (plan_.has_flat_output && !optimistic) GDV_RETURN_NOT_OK(general_kernel());
+      active = (plan_.has_flat_output && !optimistic) ? kernel_general_.load() : kernel_;
+      GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
+      if (optimistic && (err_bits & 16u)) {
+        optimistic = false;
+        prefer_general_.store(true);
+        GDV_RETURN_NOT_OK(general_kernel());
+        active = kernel_general_.load();
+        GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
+      }
+      err_bits &= ~16u;
+      if (err_bits & 8u) {
+        // The scan made no progress for a very long time: some workgroup of the grid was not
+        // scheduled while later ones waited for it.  Never observed (workgroups start in index
+        // order); the serial-safe configuration — scanner + ONE worker workgroup walking all
+        // tiles in order — cannot wait on anything unscheduled.
+        GDV_RETURN_NOT_OK(run(2));
+        if (err_bits & 8u) return Status::ExecutionError("var-len projection: device scan stalled");
+      }
+      return Status::OK();
+    };
+    for (int v = 0; v < nv; v++) args.SetOutCap(vl[v], mem == MemKind::kHost ? 0 : outs[vl[v]].data_size);
+    GDV_RETURN_NOT_OK(launch());
+    Status capacity = Status::OK();
+    for (int v = 0; v < nv; v++) {
+      const int e = vl[v];
+      totals[e] = seg[v];
+      if (totals[e] >= 0x7fffffffull)
+        return Status::Invalid("var-len output " + std::to_string(e) + " exceeds 2 GiB");
+      const int64_t have = outs[e].data_size;
+      outs[e].data_size = static_cast<int64_t>(totals[e]);  // bytes needed / produced
+      if (have < static_cast<int64_t>(totals[e]) || (totals[e] > 0 && outs[e].data == nullptr))
+        capacity = Status::Invalid("output buffer " + std::to_string(e) + ": data capacity " +
+                                   std::to_string(have) + " < " + std::to_string(totals[e]) +
+                                   " bytes needed (data_size updated; retry with a larger buffer)");
+    }
+    if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+    GDV_RETURN_NOT_OK(capacity);
+    if (mem == MemKind::kHost) {
+      bool any = false;
+      for (int v = 0; v < nv; v++) {
+        const int e = vl[v];
+        DeviceBuffer& dd = st.Add();
+        GDV_RETURN_NOT_OK(dd.Allocate(std::max<uint64_t>(totals[e], 8)));
+        dev_data[e] = dd.get();
+        args.SetOutData(e, dev_data[e]);
+        args.SetOutCap(e, static_cast<int64_t>(totals[e]));
+        any |= totals[e] > 0;
+      }
+      if (any) GDV_RETURN_NOT_OK(launch());
+    }
+  } else {
+    for (int e = 0; e < num_outs; e++)
+      if (plan_.output_types[e].is_varlen()) outs[e].data_size = 0;
+  }
+
+  if (plan_.can_raise && nv == 0)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+  if (mem == MemKind::kHost) {
+    GDV_RETURN_NOT_OK(st.FetchOut(stream));  // validity, fixed-width values, offsets
+    for (int e = 0; e < num_outs; e++)       // var-len bytes: sized after the length pass
+      if (plan_.output_types[e].is_varlen() && out_rows > 0 && totals[e] > 0)
+        GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
+                                             hipMemcpyDeviceToHost, stream));
+  }
+  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync);
+  if (must_sync) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  if (mem == MemKind::kHost) st.Deliver();
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ Filter
+
+Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
+                    const Configuration& config, std::shared_ptr<Filter>* out) {
+  if (out == nullptr) return Status::Invalid("Filter::Make: null output pointer");
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  CodegenOptions opts = CodegenOptions::FromEnv();
+  std::string key = "F|" + SchemaKey(schema) + "|" + condition->CacheKey() + "|" + opts.Key() +
+                    (config.optimize ? "|O" : "|o");
+  if (auto hit = FilterCache().Get(key)) {
+    *out = hit;
+    return Status::OK();
+  }
+  auto f = std::make_shared<Filter>();
+  f->schema_ = schema;
+  GDV_RETURN_NOT_OK(PlanFilter(schema, condition, opts, &f->plan_));
+  GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(f->plan_.source, f->plan_.kernel_name, &f->kernel_));
+  GDV_RETURN_NOT_OK(UploadConstBlock(f->plan_, &f->consts_));
+  FilterCache().Put(key, f);
+  *out = f;
+  return Status::OK();
+}
+
+Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
+                        SelectionMode mode, void* out_indices, int64_t max_slots,
+                        int64_t* num_selected, MemKind mem, hipStream_t stream) const {
+  if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (out_indices == nullptr || num_selected == nullptr)
+    return Status::Invalid("Selection vector cannot be null");
+  if (mode == SelectionMode::kNone) return Status::Invalid("Selection vector type cannot be NONE");
+  if (max_slots < num_rows)
+    return Status::Invalid("Selection vector too small: max slots " + std::to_string(max_slots) +
+                           " < rows " + std::to_string(num_rows));
+  const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
+  if (w == 2 && num_rows > 65536)
+    return Status::Invalid("uint16 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  if (w == 4 && num_rows > (int64_t(1) << 32))
+    return Status::Invalid("uint32 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+
+  ArgBlock args(plan_.layout);
+  Staging st;
+  DeviceBuffer mask, counts, offsets, chunk_sums, total, err, staged_out;
+  StreamDrain drain{stream, true};  // declared last: drains before any pooled block is freed
+  if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
+  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  BindLiterals(plan_, consts_, &args);
+  GDV_RETURN_NOT_OK(st.FlushIn(stream));
+  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
+
+  const int64_t nwords = (num_rows + 63) / 64;
+  const int64_t m = (nwords + plan_.opts.subtiles - 1) / plan_.opts.subtiles;  // wave tiles
+  GDV_RETURN_NOT_OK(mask.Allocate(nwords * 8));
+  GDV_RETURN_NOT_OK(counts.Allocate(m * 4 + 64));
+  GDV_RETURN_NOT_OK(offsets.Allocate(m * 8));
+  GDV_RETURN_NOT_OK(chunk_sums.Allocate(ScanChunks(m) * 8));
+  GDV_RETURN_NOT_OK(total.Allocate(8));
+  args.SetPtr(ArgLayout::kOffMask, mask.get());
+  args.SetPtr(ArgLayout::kOffCounts, counts.get());
+  if (plan_.can_raise) {
+    GDV_RETURN_NOT_OK(err.Allocate(8));
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+    args.SetPtr(ArgLayout::kOffErr, err.get());
+  }
+
+  EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
+  GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, num_rows), plan_.opts.waves * 64,
+                              args.data(), args.size(), stream));
+  GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>(), m, chunk_sums.as<uint64_t>(),
+                                          offsets.as<uint64_t>(), total.as<uint64_t>(), stream));
+  void* dev_out = out_indices;
+  if (mem == MemKind::kHost) {
+    GDV_RETURN_NOT_OK(staged_out.Allocate(num_rows * w));
+    dev_out = staged_out.get();
+  }
+  GDV_HIP_RETURN_NOT_OK(LaunchEmitIndices(mask.as<uint64_t>(), offsets.as<uint64_t>(), nwords,
+                                          plan_.opts.subtiles, 0, w, dev_out, rt.num_cus(),
+                                          stream));
+  uint64_t count = 0;
+  uint32_t err_bits = 0;
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&count, total.get(), 8, hipMemcpyDeviceToHost, stream));
+  if (plan_.can_raise)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+  GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  if (mem == MemKind::kHost && count > 0) {
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(out_indices, dev_out, count * w, hipMemcpyDeviceToHost, stream));
+    GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  }
+  *num_selected = static_cast<int64_t>(count);
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ precompile (no device)
+
+Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                           SelectionMode mode) {
+  KernelPlan plan;
+  GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));
+  std::vector<char> code;
+  GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code));
+  // the variant without the optimistic flat path is otherwise compiled only when a batch needs it
+  if (!plan.source_general.empty() && std::getenv("GDV_PRECOMPILE_SKIP_GENERAL") == nullptr)
+    GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source_general, plan.kernel_name_general, &code));
+  return Status::OK();
+}
+
+Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition) {
+  KernelPlan plan;
+  GDV_RETURN_NOT_OK(PlanFilter(schema, condition, CodegenOptions::FromEnv(), &plan));
+  std::vector<char> code;
+  return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
+}
+
+}  // namespace gdv

@@ -1,0 +1,119 @@
+// Projector / Filter: the objects behind gandiva::Projector::{Make,Evaluate} and
+// gandiva::Filter::{Make,Evaluate} (libgandiva.pxd:214-256), expressed over raw Arrow
+// buffers so that the same code serves the C-ABI (include/gandiva_amd.h), the gandiva::
+// C++ layer and the Python mirror.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gdv_node.h"
+#include "gdv_planner.h"
+#include "gdv_runtime.h"
+
+namespace gdv {
+
+enum class MemKind : int32_t {
+  kHost = 0,    // buffers are host memory: staged to HBM, results copied back (correctness path)
+  kDevice = 1,  // buffers are HBM-resident on the current device: zero-copy (the fast path)
+};
+
+// One Arrow array as raw buffers (pyarrow/include/arrow/array/data.h:85-95).
+struct ColumnBuffers {
+  const void* validity = nullptr;  // may be null: no nulls
+  int64_t validity_size = 0;
+  const void* data = nullptr;      // fixed-width values | bool bits | var-len bytes
+  int64_t data_size = 0;
+  const void* offsets = nullptr;   // var-len only (int32 offsets)
+  int64_t offsets_size = 0;
+  int64_t offset = 0;              // Arrow array offset, in rows
+};
+
+struct OutputBuffers {
+  void* validity = nullptr;  // >= 8 * ceil(rows / 64) bytes
+  int64_t validity_size = 0;
+  void* data = nullptr;      // >= rows * width bytes (bool: 8 * ceil(rows / 64)); var-len: bytes
+  int64_t data_size = 0;     // var-len: capacity in; bytes needed out (also on failure)
+  void* offsets = nullptr;   // var-len outputs only: (rows + 1) int32 offsets
+  int64_t offsets_size = 0;
+};
+
+struct SelectionView {
+  SelectionMode mode = SelectionMode::kNone;
+  const void* indices = nullptr;
+  int64_t num_slots = 0;
+};
+
+struct Configuration {
+  bool optimize = true;
+  bool dump_ir = false;
+};
+
+enum EvalFlags : uint32_t {
+  kEvalAsync = 1u,  // device buffers only: return after enqueueing on `stream`
+};
+
+class Projector {
+ public:
+  static Status Make(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                     SelectionMode mode, const Configuration& config,
+                     std::shared_ptr<Projector>* out);
+
+  // `cols` has one entry per schema field (unused fields may be empty).  With a selection
+  // view, outputs have sel->num_slots rows, else num_rows rows.
+  Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
+                  const SelectionView* sel, OutputBuffers* outs, int num_outs, MemKind mem,
+                  hipStream_t stream, uint32_t flags) const;
+
+  const Schema& schema() const { return schema_; }
+  const KernelPlan& plan() const { return plan_; }
+  int num_outputs() const { return static_cast<int>(plan_.output_types.size()); }
+  const DataType& output_type(int i) const { return plan_.output_types[i]; }
+  std::string DumpIR() const { return plan_.ir; }
+
+  static int64_t ValidityBytes(int64_t rows) { return ((rows + 63) / 64) * 8; }
+  static int64_t DataBytes(const DataType& t, int64_t rows) {
+    return t.id == kBool ? ValidityBytes(rows) : rows * t.byte_width();
+  }
+
+ private:
+  Schema schema_;
+  KernelPlan plan_;
+  const CompiledKernel* kernel_ = nullptr;
+  mutable std::atomic<const CompiledKernel*> kernel_general_{nullptr};  // without the optimistic flat path (lazy)
+  mutable std::atomic<bool> prefer_general_{false};  // a batch raised NOTFLAT: stop trying the optimistic variant
+  DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
+};
+
+class Filter {
+ public:
+  static Status Make(const Schema& schema, const ExpressionPtr& condition,
+                     const Configuration& config, std::shared_ptr<Filter>* out);
+
+  // Fills out_indices (capacity `max_slots`, element type by `mode`) with the ascending
+  // positions of rows where the condition is true and valid; *num_selected = count.
+  Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, SelectionMode mode,
+                  void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
+                  hipStream_t stream) const;
+
+  const Schema& schema() const { return schema_; }
+  const KernelPlan& plan() const { return plan_; }
+  std::string DumpIR() const { return plan_.ir; }
+
+ private:
+  Schema schema_;
+  KernelPlan plan_;
+  const CompiledKernel* kernel_ = nullptr;
+  DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
+};
+
+// Builds the plan and compiles it to a gfx950 code object without touching a device
+// (used by the build check and to pre-populate the on-disk kernel cache).
+Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                           SelectionMode mode);
+Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition);
+
+}  // namespace gdv

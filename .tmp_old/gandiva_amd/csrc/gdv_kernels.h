@@ -1,0 +1,31 @@
+// Launchers of the ahead-of-time kernels in gdv_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gdv {
+
+// Number of scan workgroups (= entries of `chunk_sums`) for m counts.
+int64_t ScanChunks(int64_t m);
+
+// offsets[i] = sum(counts[0..i)) for i < m; *total = sum of all counts.
+hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
+                             uint64_t* offsets, uint64_t* total, hipStream_t stream);
+
+// The same for `nseg` (<= 16) independent segments in one set of launches: segment s reads
+// counts[s*stride .. s*stride+m), writes offsets[s*stride ..), totals[s], and — when
+// closing[s] is not null — *closing[s] = (int32) totals[s] (the closing entry of an Arrow
+// var-len offsets buffer).  chunk_sums needs nseg * ScanChunks(m) entries.
+constexpr int kMaxScanSegments = 16;
+hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t stride, int nseg,
+                                      uint64_t* chunk_sums, uint64_t* offsets, uint64_t* totals,
+                                      int32_t* const* closing, hipStream_t stream);
+
+// Writes row_base + (position of every set bit of mask[0..nwords)) in ascending order to
+// out[]; offsets[] holds, per group of `subtiles` words, the number of set bits before it.
+hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int64_t nwords,
+                             int subtiles, int64_t row_base, int index_bytes, void* out,
+                             int num_cus, hipStream_t stream);
+
+}  // namespace gdv

@@ -1,0 +1,296 @@
+// Ahead-of-time kernels that do not depend on the expression: the SelectionVector
+// construction behind Filter::Evaluate.  Replaces the reference's
+// SelectionVector::PopulateFromBitMap (§3.3 hot loop #3: a serial
+// ctz / clear-lowest-bit walk over the result bitmap) with a wave-level stream compaction:
+//
+//   predicate kernel (generated)  : 64-bit match word per 64 rows via __ballot, one
+//                                   selected-row count per wave tile
+//   gdv_scan_* (here)             : exclusive prefix sum of the per-tile counts
+//   gdv_emit_indices (here)       : lane i of a set bit writes row id at
+//                                   tile_offset + popcount(word & lanemask_lt(i))
+//
+// Indices come out ascending by construction, exactly as the reference produces them.
+#include <hip/hip_runtime.h>
+
+#include "gdv_kernels.h"
+
+namespace gdv {
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanPerThread = 16;
+constexpr int kScanChunk = kScanThreads * kScanPerThread;  // counts per workgroup
+
+__device__ __forceinline__ uint64_t WaveInclusiveScan(uint64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread workgroup; returns the
+// exclusive prefix and leaves the workgroup total in *total.
+__device__ __forceinline__ uint64_t BlockExclusiveScan(uint64_t v, uint64_t* total) {
+  __shared__ uint64_t wave_sums[kScanThreads / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint64_t incl = WaveInclusiveScan(v, lane);
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; w++) {
+    uint64_t s = wave_sums[w];
+    if (w < wave) base += s;
+    sum += s;
+  }
+  __syncthreads();
+  *total = sum;
+  return base + incl - v;
+}
+
+struct ClosingOffsets { int32_t* p[kMaxScanSegments]; };
+
+__global__ void __launch_bounds__(kScanThreads)
+ScanReduce(const uint32_t* __restrict__ counts, int64_t m, uint64_t* __restrict__ sums,
+           int64_t stride) {
+  counts += (int64_t)blockIdx.y * stride;  // segment (one per var-len output; 0 for filters)
+  sums += (int64_t)blockIdx.y * gridDim.x;
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanPerThread;
+  uint64_t local = 0;
+  if (base + kScanPerThread <= m) {
+    const uint4* p = reinterpret_cast<const uint4*>(counts + base);
+#pragma unroll
+    for (int i = 0; i < kScanPerThread / 4; i++) {
+      uint4 q = p[i];
+      local += (uint64_t)q.x + q.y + q.z + q.w;
+    }
+  } else {
+    for (int i = 0; i < kScanPerThread; i++)
+      if (base + i < m) local += counts[base + i];
+  }
+  uint64_t total;
+  (void)BlockExclusiveScan(local, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// Single workgroup: exclusive scan of the chunk sums in place; grand total -> *total.
+__global__ void __launch_bounds__(kScanThreads)
+ScanSpine(uint64_t* __restrict__ sums, int64_t nb, uint64_t* __restrict__ total_out,
+          ClosingOffsets closing) {
+  sums += (int64_t)blockIdx.x * nb;  // one workgroup per segment
+  total_out += blockIdx.x;
+  const int64_t per = (nb + kScanThreads - 1) / kScanThreads;
+  const int64_t lo = (int64_t)threadIdx.x * per;
+  const int64_t hi = lo + per < nb ? lo + per : nb;
+  uint64_t local = 0;
+  for (int64_t i = lo; i < hi; i++) local += sums[i];
+  uint64_t total;
+  uint64_t prefix = BlockExclusiveScan(local, &total);
+  for (int64_t i = lo; i < hi; i++) {
+    uint64_t c = sums[i];
+    sums[i] = prefix;
+    prefix += c;
+  }
+  if (threadIdx.x == 0) {
+    *total_out = total;
+    // var-len outputs: the closing entry of the Arrow offsets buffer is the byte total
+    if (closing.p[blockIdx.x] != nullptr) *closing.p[blockIdx.x] = static_cast<int32_t>(total);
+  }
+}
+
+__global__ void __launch_bounds__(kScanThreads)
+ScanApply(const uint32_t* __restrict__ counts, int64_t m, const uint64_t* __restrict__ sums,
+          uint64_t* __restrict__ offsets, int64_t stride) {
+  counts += (int64_t)blockIdx.y * stride;
+  offsets += (int64_t)blockIdx.y * stride;
+  sums += (int64_t)blockIdx.y * gridDim.x;
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t c[kScanPerThread];
+  uint64_t local = 0;
+  if (base + kScanPerThread <= m) {
+    const uint4* p = reinterpret_cast<const uint4*>(counts + base);
+#pragma unroll
+    for (int i = 0; i < kScanPerThread / 4; i++) {
+      uint4 q = p[i];
+      c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; i++) c[i] = (base + i < m) ? counts[base + i] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) local += c[i];
+  uint64_t total;
+  uint64_t prefix = BlockExclusiveScan(local, &total) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    if (base + i < m) offsets[base + i] = prefix;
+    prefix += c[i];
+  }
+}
+
+// The whole scan in one launch when a segment fits one workgroup's chunk (m <= 4096 counts,
+// i.e. batches up to ~10^6 rows): small batches are launch-bound, two launches fewer matter.
+__global__ void __launch_bounds__(kScanThreads)
+ScanSmall(const uint32_t* __restrict__ counts, int64_t m, int64_t stride,
+          uint64_t* __restrict__ offsets, uint64_t* __restrict__ total_out, ClosingOffsets closing) {
+  counts += (int64_t)blockIdx.x * stride;
+  offsets += (int64_t)blockIdx.x * stride;
+  const int64_t base = (int64_t)threadIdx.x * kScanPerThread;
+  uint32_t c[kScanPerThread];
+  uint64_t local = 0;
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    c[i] = (base + i < m) ? counts[base + i] : 0u;
+    local += c[i];
+  }
+  uint64_t total;
+  uint64_t prefix = BlockExclusiveScan(local, &total);
+#pragma unroll
+  for (int i = 0; i < kScanPerThread; i++) {
+    if (base + i < m) offsets[base + i] = prefix;
+    prefix += c[i];
+  }
+  if (threadIdx.x == 0) {
+    total_out[blockIdx.x] = total;
+    if (closing.p[blockIdx.x] != nullptr) *closing.p[blockIdx.x] = static_cast<int32_t>(total);
+  }
+}
+
+// Index emission, LDS-staged.  One wavefront owns 64 consecutive match words (4096 rows):
+// lane i takes word i, a wave-level exclusive scan of the popcounts gives every lane its
+// slot range, the lane walks its word's set bits (ctz / clear-lowest) into the wave's
+// private LDS window, and the wave then streams the window to HBM with fully coalesced
+// stores.  (Writing straight from the bit walk would emit ~8 indices = 32 B per 64-lane
+// store instruction at C3's selectivity: measured 0.82 ms for 10^9 rows vs the ~0.15 ms
+// the 0.66 GB of traffic costs.)  `offsets` holds the selected-row count before every group
+// of `subtiles` words (subtiles divides 64), so the wave's base is offsets[first group].
+constexpr int kEmitWords = 64;
+
+template <typename IndexT>
+__global__ void __launch_bounds__(256)
+EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offsets,
+            int64_t nwords, int subtiles, int64_t row_base, IndexT* __restrict__ out) {
+  // positions inside the wave's 4096-row tile fit 12 bits: staging them as uint16 keeps the
+  // window at 8 KiB per wave (32 KiB per workgroup, 5 workgroups per CU) whatever IndexT is
+  __shared__ uint16_t stage[4][kEmitWords * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint16_t* buf = stage[wave];
+  const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  // the next tile's mask word and base are loaded while the current tile is walked
+  uint64_t m_next = 0, base_next = 0;
+  if (t < ntiles) {
+    const int64_t w = t * kEmitWords + lane;
+    m_next = (w < nwords) ? mask[w] : 0ull;
+    base_next = offsets[(t * kEmitWords) / subtiles];
+  }
+  for (; t < ntiles; t += stride) {
+    uint64_t m = m_next;
+    const uint64_t base = base_next;
+    if (t + stride < ntiles) {
+      const int64_t w = (t + stride) * kEmitWords + lane;
+      m_next = (w < nwords) ? mask[w] : 0ull;
+      base_next = offsets[((t + stride) * kEmitWords) / subtiles];
+    }
+    const uint32_t c = (uint32_t)__popcll(m);
+    const uint32_t incl = (uint32_t)WaveInclusiveScan(c, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t slot = incl - c;
+    const int64_t tile_row0 = row_base + t * (int64_t)(kEmitWords * 64);
+    while (m) {
+      buf[slot++] = static_cast<uint16_t>((lane << 6) + __builtin_ctzll(m));
+      m &= m - 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // four indices per lane per step: one 8-byte LDS read, one 4*sizeof(IndexT) store
+    IndexT* dst = out + base;
+    for (uint32_t j = (uint32_t)lane * 4; j < total; j += 256) {
+      if (j + 4 <= total) {
+        uint16_t q[4];
+        __builtin_memcpy(q, buf + j, 8);
+        IndexT v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = static_cast<IndexT>(tile_row0 + q[k]);
+        __builtin_memcpy(dst + j, v, sizeof(v));
+      } else {
+        for (uint32_t k = j; k < total; k++) dst[k] = static_cast<IndexT>(tile_row0 + buf[k]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Serial-semantics reference check helper is NOT provided here on purpose: the CPU
+// restatement lives in oracle/ only.
+
+}  // namespace
+
+int64_t ScanChunks(int64_t m) { return (m + kScanChunk - 1) / kScanChunk; }
+
+hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t stride, int nseg,
+                                      uint64_t* chunk_sums, uint64_t* offsets, uint64_t* totals,
+                                      int32_t* const* closing, hipStream_t stream) {
+  if (nseg <= 0) return hipSuccess;
+  if (nseg > kMaxScanSegments) return hipErrorInvalidValue;
+  ClosingOffsets c;
+  for (int i = 0; i < kMaxScanSegments; i++) c.p[i] = (closing != nullptr && i < nseg) ? closing[i] : nullptr;
+  if (m <= 0) {
+    hipError_t e = hipMemsetAsync(totals, 0, sizeof(uint64_t) * nseg, stream);
+    for (int i = 0; e == hipSuccess && i < nseg; i++)
+      if (c.p[i] != nullptr) e = hipMemsetAsync(c.p[i], 0, sizeof(int32_t), stream);
+    return e;
+  }
+  const int64_t nb = ScanChunks(m);
+  if (nb == 1) {
+    hipLaunchKernelGGL(ScanSmall, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, counts, m, stride,
+                       offsets, totals, c);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
+                     counts, m, chunk_sums, stride);
+  hipLaunchKernelGGL(ScanSpine, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, chunk_sums, nb,
+                     totals, c);
+  hipLaunchKernelGGL(ScanApply, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
+                     counts, m, chunk_sums, offsets, stride);
+  return hipGetLastError();
+}
+
+hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
+                             uint64_t* offsets, uint64_t* total, hipStream_t stream) {
+  return LaunchSegmentedOffsetsScan(counts, m, m, 1, chunk_sums, offsets, total, nullptr, stream);
+}
+
+hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int64_t nwords,
+                             int subtiles, int64_t row_base, int index_bytes, void* out,
+                             int num_cus, hipStream_t stream) {
+  if (nwords <= 0) return hipSuccess;
+  if (subtiles <= 0 || kEmitWords % subtiles != 0) return hipErrorInvalidValue;
+  const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
+  int64_t grid = (ntiles + 3) / 4;
+  const int64_t cap = (int64_t)num_cus * 5;  // LDS allows 5 workgroups per CU
+  if (grid > cap) grid = cap;
+  switch (index_bytes) {
+    case 2:
+      hipLaunchKernelGGL(EmitIndices<uint16_t>, dim3((unsigned)grid), dim3(256), 0, stream, mask,
+                         offsets, nwords, subtiles, row_base, static_cast<uint16_t*>(out));
+      break;
+    case 4:
+      hipLaunchKernelGGL(EmitIndices<uint32_t>, dim3((unsigned)grid), dim3(256), 0, stream, mask,
+                         offsets, nwords, subtiles, row_base, static_cast<uint32_t*>(out));
+      break;
+    default:
+      hipLaunchKernelGGL(EmitIndices<uint64_t>, dim3((unsigned)grid), dim3(256), 0, stream, mask,
+                         offsets, nwords, subtiles, row_base, static_cast<uint64_t*>(out));
+      break;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gdv

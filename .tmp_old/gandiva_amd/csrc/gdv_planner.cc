@@ -1,0 +1,1712 @@
+#include "gdv_planner.h"
+
+#include "gdv_runtime.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <regex>
+#include <sstream>
+
+namespace gdv {
+
+// ------------------------------------------------------------------ options
+
+CodegenOptions CodegenOptions::FromEnv() {
+  CodegenOptions o;
+  if (const char* s = std::getenv("GDV_U")) {
+    // powers of two only: the index-emission kernel walks 64-word groups (gdv_kernels.hip)
+    int u = std::max(1, std::min(16, atoi(s)));
+    while (u & (u - 1)) u &= u - 1;
+    o.subtiles = u;
+  }
+  if (const char* s = std::getenv("GDV_WAVES")) o.waves = std::max(1, std::min(16, atoi(s)));
+  if (const char* s = std::getenv("GDV_NT")) o.nontemporal = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_SCALAR_BITMAPS")) o.scalar_bitmaps = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_BITMAPS_LAST")) o.bitmaps_last = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_WPE")) o.waves_per_eu = std::max(0, std::min(8, atoi(s)));
+  return o;
+}
+
+std::string CodegenOptions::Key() const {
+  return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
+         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + "e" + std::to_string(waves_per_eu);
+}
+
+// ------------------------------------------------------------------ validation
+
+namespace {
+
+Status ValidateNode(const Schema& schema, const Node& node);
+
+Status ValidateField(const Schema& schema, const FieldNode& n) {
+  for (auto& f : schema) {
+    if (f.name == n.field().name) {
+      if (f.type != n.field().type) {
+        return Status::ValidationError("Field definition in schema " + f.name + ": " +
+                                       f.type.ToString() + " different from field in expression " +
+                                       n.field().name + ": " + n.field().type.ToString());
+      }
+      return Status::OK();
+    }
+  }
+  return Status::ValidationError("Field " + n.field().name + " not in schema.");
+}
+
+bool ResolveFunction(const FunctionNode& n, const FunctionDef** def, DataType* ret) {
+  std::vector<DataType> params;
+  for (auto& c : n.children()) params.push_back(c->return_type());
+  const FunctionDef* d = FunctionRegistry::Get().Lookup(n.name(), params);
+  if (d == nullptr) return false;
+  *def = d;
+  *ret = d->ret;
+  if (d->flags & kDecimalResult) {
+    DecimalOp op = DecimalOp::kAdd;
+    if (n.name() == "subtract") op = DecimalOp::kSubtract;
+    else if (n.name() == "multiply") op = DecimalOp::kMultiply;
+    else if (n.name() == "divide") op = DecimalOp::kDivide;
+    else if (n.name() == "mod") op = DecimalOp::kMod;
+    *ret = DecimalResultType(op, params[0], params[1]);
+  }
+  return true;
+}
+
+Status ValidateFunction(const Schema& schema, const FunctionNode& n) {
+  for (auto& c : n.children()) GDV_RETURN_NOT_OK(ValidateNode(schema, *c));
+  const FunctionDef* def = nullptr;
+  DataType ret;
+  if (!ResolveFunction(n, &def, &ret)) {
+    return Status::ValidationError("Function " + n.ToString() + " not supported yet. ");
+  }
+  if (ret != n.return_type()) {
+    // decimal results declared by the caller win when only precision/scale differ
+    if (!(ret.id == kDecimal128 && n.return_type().id == kDecimal128 &&
+          !(def->flags & kDecimalResult))) {
+      return Status::ValidationError("Function " + n.name() + " returns " + ret.ToString() +
+                                     " but the expression declares " +
+                                     n.return_type().ToString());
+    }
+  }
+  if (def->flags & kPatternArg) {
+    if (n.children().size() < 2 || n.children()[1]->kind() != NodeKind::kLiteral) {
+      return Status::ValidationError("'" + n.name() + "' function requires a literal as the last parameter");
+    }
+  }
+  return Status::OK();
+}
+
+Status ValidateNode(const Schema& schema, const Node& node) {
+  switch (node.kind()) {
+    case NodeKind::kField:
+      return ValidateField(schema, static_cast<const FieldNode&>(node));
+    case NodeKind::kLiteral:
+      return Status::OK();
+    case NodeKind::kFunction:
+      return ValidateFunction(schema, static_cast<const FunctionNode&>(node));
+    case NodeKind::kIf: {
+      auto& n = static_cast<const IfNode&>(node);
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.condition()));
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.then_node()));
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.else_node()));
+      if (n.condition()->return_type().id != kBool)
+        return Status::ValidationError("condition must be of boolean type, found type " +
+                                       n.condition()->return_type().ToString());
+      if (n.then_node()->return_type() != n.return_type())
+        return Status::ValidationError("return type of if " + n.return_type().ToString() +
+                                       " and then " + n.then_node()->return_type().ToString() +
+                                       " not matching.");
+      if (n.else_node()->return_type() != n.return_type())
+        return Status::ValidationError("return type of if " + n.return_type().ToString() +
+                                       " and else " + n.else_node()->return_type().ToString() +
+                                       " not matching.");
+      return Status::OK();
+    }
+    case NodeKind::kBoolean: {
+      auto& n = static_cast<const BooleanNode&>(node);
+      if (n.children().size() < 2)
+        return Status::ValidationError("Boolean expression has " +
+                                       std::to_string(n.children().size()) +
+                                       " children, expected atleast two");
+      for (auto& c : n.children()) {
+        GDV_RETURN_NOT_OK(ValidateNode(schema, *c));
+        if (c->return_type().id != kBool)
+          return Status::ValidationError("Boolean expression has a child with return type " +
+                                         c->return_type().ToString() + ", expected return type boolean");
+      }
+      return Status::OK();
+    }
+    case NodeKind::kIn: {
+      auto& n = static_cast<const InNode&>(node);
+      GDV_RETURN_NOT_OK(ValidateNode(schema, *n.eval()));
+      if (n.eval()->return_type() != n.value_type())
+        // message fragment pinned by test_gandiva.py:160-161
+        return Status::ValidationError("Evaluation expression for IN clause returns " +
+                                       n.eval()->return_type().ToString() +
+                                       " values are of type" + n.value_type().ToString());
+      return Status::OK();
+    }
+  }
+  return Status::OK();
+}
+
+}  // namespace
+
+Status ValidateExpression(const Schema& schema, const Expression& expr) {
+  if (!expr.root()) return Status::ValidationError("Root node cannot be null");
+  GDV_RETURN_NOT_OK(ValidateNode(schema, *expr.root()));
+  if (expr.root()->return_type() != expr.result().type) {
+    return Status::ValidationError("Return type of root node " +
+                                   expr.root()->return_type().ToString() +
+                                   " does not match that of expression " +
+                                   expr.result().type.ToString());
+  }
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ code generation
+
+namespace {
+
+std::string Hex64(uint64_t v) {
+  char buf[32];
+  snprintf(buf, sizeof(buf), "0x%llxull", static_cast<unsigned long long>(v));
+  return buf;
+}
+
+// The kernel's identity is its code: the "// @expr_N = ..." header lines render the expressions
+// WITH their literal values (DumpIR shows them), the code below them does not depend on the values.
+std::string HashableSource(const std::string& text) {
+  std::string out;
+  size_t pos = 0;
+  while (pos < text.size()) {
+    size_t eol = text.find('\n', pos);
+    if (eol == std::string::npos) eol = text.size();
+    if (text.compare(pos, 9, "// @expr_") != 0) out.append(text, pos, eol - pos + 1);
+    pos = eol + 1;
+  }
+  return out;
+}
+
+std::string LibraryTag();
+
+uint64_t Fnv1a(const std::string& s) {
+  uint64_t h = 1469598103934665603ull;
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+// A kernel is its generated text AND the device function library it is compiled against: the
+// library's hash is part of the kernel name, so a PMC pass or a cached code object can only be
+// attributed to the code that really ran.
+std::string LibraryTag() {
+  static const std::string tag = std::to_string(Fnv1a(std::string(gdv_device_lib_src)));
+  return tag;
+}
+
+// A value inside the generated row body: a C++ expression plus its validity, split the way
+// the reference's ValueValidityPair splits it — the set of input columns whose validity
+// words intersect, and an optional per-lane predicate for value-dependent validity
+// (if/else, SQL three-valued AND/OR, functions that produce nulls themselves).
+struct Val {
+  std::string v;
+  DataType type;
+  std::set<int> vcols;
+  std::string vlane;
+  // concat results are not a view: they are the list of their argument views, written one
+  // after the other by the output copy (piece expression, per-lane "piece present"
+  // predicate or "" for always).  Only an output expression or another concat can take one.
+  std::vector<std::pair<std::string, std::string>> pieces;
+  // A string value that IS the row of input slot `col_slot` (whole, unsliced), read through the
+  // static byte map `col_map` (0 none, 1 upper, 2 lower): candidates for the byte-parallel
+  // paths (sweep-answered '%needle%', flat output copy).  -1: anything else.
+  int col_slot = -1;
+  int col_map = 0;
+  bool never_null() const { return vcols.empty() && vlane.empty(); }
+};
+
+// '%needle%' predicate answered by the byte sweep of input slot `slot` (bytes read through `map`)
+struct ContainsHook {
+  int slot;
+  int map;
+  std::string needle;
+};
+
+// One var-len output of a projector: its row value as 1+ pieces (views written back to back),
+// each with the name of the per-sub-tile register array holding it.
+struct VarlenOut {
+  int e = 0;                      // output index
+  int flat_slot = -1;             // >= 0: the row is input slot flat_slot's whole row ...
+  int flat_map = 0;               // ... read through this byte map
+  int window = -1;                // >= 0: LDS staging window of this output (non-flat outputs)
+};
+
+class CodeGen {
+ public:
+  CodeGen(const Schema& schema, SelectionMode mode, const CodegenOptions& opts)
+      : schema_(schema), sel_mode_(mode), opts_(opts) {}
+
+  bool selection() const { return sel_mode_ != SelectionMode::kNone; }
+
+  Status Gen(const Node& node, const std::string& active, Val* out);
+
+  // ---- emission helpers
+  std::string Tmp(const std::string& ctype, const std::string& rhs) {
+    std::string key = ctype + "|" + rhs;
+    auto it = cse_.find(key);
+    if (it != cse_.end()) return it->second;
+    std::string name = "t" + std::to_string(next_tmp_++);
+    body_ << "      const " << ctype << " " << name << " = " << rhs << ";\n";
+    cse_[key] = name;
+    return name;
+  }
+  void Stmt(const std::string& s) { body_ << "      " << s << "\n"; }
+
+  // conjunction of per-lane predicates; "" stands for "always true"
+  static std::string AndExpr(const std::string& a, const std::string& b) {
+    if (a.empty() || a == "true") return (b == "true") ? "" : b;
+    if (b.empty() || b == "true") return a;
+    return "(" + a + " && " + b + ")";
+  }
+
+  // same, spelled out: never the empty string (for use as a full expression)
+  static std::string AndFull(const std::string& a, const std::string& b) {
+    std::string r = AndExpr(a, b);
+    return r.empty() ? "true" : r;
+  }
+
+  // per-lane validity of a value ("true" when it can never be null)
+  std::string LaneValid(const Val& val) {
+    std::string cols;
+    if (!val.vcols.empty()) {
+      if (selection()) {
+        for (int k : val.vcols) cols = AndExpr(cols, "b" + std::to_string(k) + "[u]");
+      } else {
+        cols = Tmp("bool", "gdv_lane_bit(" + WordExpr(val.vcols) + ", lane)");
+      }
+    }
+    std::string r = AndExpr(cols, val.vlane);
+    return r.empty() ? "true" : r;
+  }
+
+  // wave-uniform AND of the validity words of a set of input columns (row mode only)
+  std::string WordExpr(const std::set<int>& cols) {
+    if (cols.empty()) return "~0ull";
+    std::string s;
+    for (int k : cols) {
+      if (!s.empty()) s += " & ";
+      s += "v" + std::to_string(k);
+    }
+    if (cols.size() > 1) s = Tmp("gdv_uint64", s);
+    return s;
+  }
+
+  // ---- literals are kernel ARGUMENTS, not source text (round 2): `a > 499` and `a > 500`, or
+  // like '%spark%' and like '%flink%', share one compiled kernel; only the shape (types, list
+  // sizes, pattern form and needle length) is compiled in.
+  // Fixed-width literal -> 8-byte slot of gdv_args::lit (decimal128: two slots, low word first)
+  // (slots are never shared by VALUE — the code must not depend on which constants happen to be
+  // equal — only by node identity: a literal node used in several places is one slot, so common
+  // sub-expressions built from shared nodes still merge)
+  int LitSlot(uint64_t v) {
+    lits_.push_back(v);
+    return static_cast<int>(lits_.size()) - 1;
+  }
+  std::string LiteralExpr(const DataType& t, const Literal& v, const void* node) {
+    auto it = lit_of_node_.find(node);
+    if (it != lit_of_node_.end()) return it->second;
+    std::string e = LiteralExprNew(t, v);
+    lit_of_node_[node] = e;
+    return e;
+  }
+  static std::string InlineLiteral(const DataType& t, const Literal& v) {
+    switch (t.id) {
+      case kBool: return v.lo ? "true" : "false";
+      case kFloat: return "__uint_as_float(" + Hex64(v.lo & 0xffffffffull) + ")";
+      case kDouble: return "__longlong_as_double((long long)" + Hex64(v.lo) + ")";
+      case kDecimal128: return "gdv_make_int128(" + Hex64(v.hi) + ", " + Hex64(v.lo) + ")";
+      default: {
+        uint64_t mask = t.byte_width() >= 8 ? ~0ull : ((1ull << (8 * t.byte_width())) - 1);
+        return "((" + t.CType() + ")" + Hex64(v.lo & mask) + ")";
+      }
+    }
+  }
+  std::string LiteralExprNew(const DataType& t, const Literal& v) {
+    auto slot = [&](uint64_t x) { return "A.lit[" + std::to_string(LitSlot(x)) + "]"; };
+    switch (t.id) {
+      case kBool: return v.lo ? "true" : "false";
+      case kFloat: return "__uint_as_float((gdv_uint32)" + slot(v.lo & 0xffffffffull) + ")";
+      case kDouble: return "__longlong_as_double((long long)" + slot(v.lo) + ")";
+      case kDecimal128: {
+        // two consecutive slots that are never shared with single-word literals
+        lits_.push_back(v.lo);
+        lits_.push_back(v.hi);
+        const std::string i = std::to_string(lits_.size() - 2), j = std::to_string(lits_.size() - 1);
+        return "gdv_make_int128(A.lit[" + j + "], A.lit[" + i + "])";
+      }
+      default: {
+        uint64_t mask = t.byte_width() >= 8 ? ~0ull : ((1ull << (8 * t.byte_width())) - 1);
+        return "((" + t.CType() + ")" + slot(v.lo & mask) + ")";
+      }
+    }
+  }
+  // bytes -> the plan's constant block (device memory, bound through gdv_args::aux0); returns a
+  // pointer expression.  Every table starts 16-byte aligned and is readable 8 bytes past its end.
+  std::string ByteTable(const std::string& bytes, const char* ctype = "gdv_uint8") {
+    while (blob_.size() % 16 != 0) blob_.push_back('\0');
+    const size_t off = blob_.size();
+    blob_ += bytes;
+    blob_.append(8, '\0');  // 8-byte loads may run past the table's end
+    return "((const " + std::string(ctype) + "*)(gdv_cst + " + std::to_string(off) + "))";
+  }
+  std::string StringConstant(const std::string& bytes) {
+    std::string t = ByteTable(bytes);
+    bool ascii = true;
+    for (unsigned char c : bytes) ascii = ascii && c < 0x80;
+    return "gdv_make_str(" + t + ", 0, " + std::to_string(bytes.size()) + ", " + t + " + " +
+           std::to_string(bytes.size() + 8) + (ascii ? ", GDV_STR_ASCII | GDV_STR_INBUF)" : ", GDV_STR_INBUF)");
+  }
+  // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
+  static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
+                            std::string* kinds) {
+    for (size_t i = 0; i < pat.size(); i++) {
+      unsigned char c = static_cast<unsigned char>(pat[i]);
+      if (escape >= 0 && c == static_cast<unsigned char>(escape)) {
+        if (i + 1 >= pat.size())
+          return Status::Invalid("like pattern must not end with the escape character");
+        unsigned char nx = static_cast<unsigned char>(pat[i + 1]);
+        if (nx != '%' && nx != '_' && nx != static_cast<unsigned char>(escape))
+          return Status::Invalid("invalid escape sequence in like pattern");
+        bytes->push_back(static_cast<char>(nx));
+        kinds->push_back(0);
+        i++;
+      } else if (c == '%') {
+        if (kinds->empty() || kinds->back() != 2) {  // collapse runs of %
+          bytes->push_back(0);
+          kinds->push_back(2);
+        }
+      } else if (c == '_') {
+        bytes->push_back(0);
+        kinds->push_back(1);
+      } else {
+        bytes->push_back(static_cast<char>(c));
+        kinds->push_back(0);
+      }
+    }
+    return Status::OK();
+  }
+
+  // input slots of every var-len field below `node`
+  std::set<int> StringSlotsOf(const Node& node) {
+    std::set<int> r;
+    std::function<void(const Node&)> walk = [&](const Node& n) {
+      switch (n.kind()) {
+        case NodeKind::kField: {
+          auto& f = static_cast<const FieldNode&>(n);
+          if (f.return_type().is_varlen()) r.insert(SlotFor(f, true, true));
+          break;
+        }
+        case NodeKind::kFunction:
+          for (auto& c : static_cast<const FunctionNode&>(n).children()) walk(*c);
+          break;
+        case NodeKind::kIf: {
+          auto& i = static_cast<const IfNode&>(n);
+          walk(*i.condition()); walk(*i.then_node()); walk(*i.else_node());
+          break;
+        }
+        case NodeKind::kBoolean:
+          for (auto& c : static_cast<const BooleanNode&>(n).children()) walk(*c);
+          break;
+        case NodeKind::kIn: walk(*static_cast<const InNode&>(n).eval()); break;
+        default: break;
+      }
+    };
+    walk(node);
+    return r;
+  }
+
+  int SlotFor(const FieldNode& f, bool values, bool validity) {
+    int idx = -1;
+    for (size_t i = 0; i < schema_.size(); i++)
+      if (schema_[i].name == f.field().name) idx = static_cast<int>(i);
+    int slot;
+    auto it = slot_of_field_.find(idx);
+    if (it == slot_of_field_.end()) {
+      slot = static_cast<int>(input_fields_.size());
+      slot_of_field_[idx] = slot;
+      input_fields_.push_back(idx);
+      needs_values_.push_back(false);
+      needs_validity_.push_back(false);
+    } else {
+      slot = it->second;
+    }
+    if (values) needs_values_[slot] = true;
+    if (validity) needs_validity_[slot] = true;
+    return slot;
+  }
+
+  const Schema& schema_;
+  SelectionMode sel_mode_;
+  CodegenOptions opts_;
+  std::ostringstream body_;
+  std::map<std::string, std::string> cse_;
+  int next_tmp_ = 0;
+  std::map<int, int> slot_of_field_;
+  std::vector<int> input_fields_;
+  std::vector<bool> needs_values_, needs_validity_;
+  bool can_raise_ = false;
+  std::vector<uint64_t> lits_;        // gdv_args::lit
+  std::map<const void*, std::string> lit_of_node_;
+  std::string blob_;                  // constant block: string literals, patterns, IN tables
+  // string plans
+  std::vector<ContainsHook> contains_hooks_;
+  std::vector<std::string> hook_tables_;  // needle bytes in the constant block
+  std::set<int> ascii_slots_;     // input slots whose tile-wide ASCII flag some function consults
+  std::vector<VarlenOut> varlen_outs_;
+  int HookFor(int slot, int map, const std::string& needle) {
+    for (size_t h = 0; h < contains_hooks_.size(); h++)
+      if (contains_hooks_[h].slot == slot && contains_hooks_[h].map == map && contains_hooks_[h].needle == needle)
+        return static_cast<int>(h);
+    contains_hooks_.push_back({slot, map, needle});
+    hook_tables_.push_back(ByteTable(needle));
+    return static_cast<int>(contains_hooks_.size()) - 1;
+  }
+};
+
+// functions whose fast path is "the string is pure ASCII" (character index == byte index)
+bool WantsAsciiHint(const std::string& name) {
+  static const std::set<std::string> k = {"substr", "substring", "left", "right", "char_length", "length",
+                                          "lengthUtf8", "castVARCHAR", "locate", "strpos", "like"};
+  return k.count(name) != 0;
+}
+
+Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
+  switch (node.kind()) {
+    case NodeKind::kField: {
+      auto& f = static_cast<const FieldNode&>(node);
+      int slot = SlotFor(f, true, true);
+      out->type = f.return_type();
+      std::string k = std::to_string(slot);
+      if (f.return_type().is_varlen()) {
+        out->v = "s" + k;  // per-iteration view built from the two offsets (row phase prologue)
+        out->col_slot = slot;
+        out->col_map = 0;
+      } else if (f.return_type().id == kBool) {
+        out->v = selection() ? "x" + k + "[u]" : Tmp("bool", "gdv_lane_bit(d" + k + ", lane)");
+      } else {
+        out->v = "c" + k + "[u]";
+      }
+      out->vcols = {slot};
+      out->vlane.clear();
+      return Status::OK();
+    }
+    case NodeKind::kLiteral: {
+      auto& l = static_cast<const LiteralNode&>(node);
+      out->type = l.return_type();
+      out->col_slot = -1;
+      if (l.return_type().is_varlen()) {
+        out->v = StringConstant(l.value().bytes);
+        out->vcols.clear();
+        out->vlane = l.is_null() ? "false" : "";
+        return Status::OK();
+      }
+      out->v = LiteralExpr(l.return_type(), l.value(), &node);
+      out->vcols.clear();
+      out->vlane = l.is_null() ? "false" : "";
+      return Status::OK();
+    }
+    case NodeKind::kFunction: {
+      auto& fn = static_cast<const FunctionNode&>(node);
+      const FunctionDef* def = nullptr;
+      DataType ret;
+      if (!ResolveFunction(fn, &def, &ret))
+        return Status::CodeGenError("Function " + fn.ToString() + " not supported yet. ");
+      // Integer literals handed to a function over strings (substr positions, left / right
+      // counts, castVARCHAR lengths ...) are part of the query's SHAPE: compiled in, so the
+      // position arithmetic folds (C5: +0.2 ms when they were kernel arguments).  Everything
+      // else — comparison constants, arithmetic operands, IN lists, LIKE needles — is an argument.
+      bool over_strings = false;
+      for (auto& c : fn.children()) over_strings |= c->return_type().is_varlen();
+      std::vector<Val> args(fn.children().size());
+      for (size_t i = 0; i < args.size(); i++) {
+        const Node& child = *fn.children()[i];
+        if (over_strings && child.kind() == NodeKind::kLiteral && !child.return_type().is_varlen() &&
+            std::getenv("GDV_NO_INLINE_STRING_ARGS") == nullptr) {
+          auto& l = static_cast<const LiteralNode&>(child);
+          args[i].type = l.return_type();
+          args[i].v = InlineLiteral(l.return_type(), l.value());
+          args[i].vlane = l.is_null() ? "false" : "";
+          continue;
+        }
+        GDV_RETURN_NOT_OK(Gen(child, active, &args[i]));
+      }
+      out->type = fn.return_type();
+      out->vcols.clear();
+      out->vlane.clear();
+      out->pieces.clear();
+      out->col_slot = -1;
+      out->col_map = 0;
+      if ((fn.name() == "upper" || fn.name() == "lower") && args.size() == 1 && args[0].col_slot >= 0) {
+        out->col_slot = args[0].col_slot;
+        out->col_map = fn.name() == "upper" ? 1 : 2;
+      }
+      if (WantsAsciiHint(fn.name()))
+        for (size_t i = 0; i < args.size(); i++)
+          if (args[i].type.is_varlen())
+            for (int k : StringSlotsOf(*fn.children()[i])) ascii_slots_.insert(k);
+      const std::string ctype = out->type.CType();
+      const bool is_concat = fn.name() == "concat" || fn.name() == "concatOperator";
+      for (auto& a : args)
+        if (!a.pieces.empty() && !is_concat)
+          return Status::CodeGenError("Function " + fn.ToString() +
+                                      " not supported yet: a concat result can only be an output "
+                                      "expression or an argument of concat in the HIP backend. ");
+      if (is_concat) {
+        // concat: a null argument is the empty string, the result is never null;
+        // concatOperator (||): null if any argument is null
+        const bool never_null = fn.name() == "concat";
+        std::string lanes;
+        for (auto& a : args) {
+          const std::string present = never_null ? LaneValid(a) : "";
+          if (a.pieces.empty()) {
+            out->pieces.emplace_back(a.v, present == "true" ? "" : present);
+          } else {
+            for (auto& pc : a.pieces) {
+              std::string pv = AndExpr(pc.second, present);
+              out->pieces.emplace_back(pc.first, pv);
+            }
+          }
+          if (!never_null) {
+            out->vcols.insert(a.vcols.begin(), a.vcols.end());
+            lanes = AndExpr(lanes, a.vlane);
+          }
+        }
+        out->vlane = lanes;
+        out->v = "gdv_empty_str()";  // never read: consumers use the pieces
+        return Status::OK();
+      }
+      if (def->flags & kPatternArg) {
+        // like(s, 'pattern'[, 'escape']): the pattern is compiled here, at Make time, the way
+        // the reference's LikeHolder compiles it to a regex once per expression
+        auto& pat = static_cast<const LiteralNode&>(*fn.children()[1]);
+        int escape = -1;
+        if (fn.children().size() == 3) {
+          if (fn.children()[2]->kind() != NodeKind::kLiteral)
+            return Status::ValidationError("'like' function requires a literal as the escape character");
+          auto& esc = static_cast<const LiteralNode&>(*fn.children()[2]);
+          if (esc.value().bytes.size() != 1)
+            return Status::Invalid("The length of escape char in like function must be 1");
+          escape = static_cast<unsigned char>(esc.value().bytes[0]);
+        }
+        if (pat.is_null()) {
+          out->v = "false";
+          out->vlane = "false";
+          return Status::OK();
+        }
+        std::string bytes, kinds;
+        GDV_RETURN_NOT_OK(CompileLike(pat.value().bytes, escape, &bytes, &kinds));
+        out->vcols = args[0].vcols;
+        out->vlane = args[0].vlane;
+        // common shapes skip the general matcher: literal | literal% | %literal | %literal%
+        const size_t nk = kinds.size();
+        const bool lead = nk > 0 && kinds.front() == 2, trail = nk > 0 && kinds.back() == 2;
+        const size_t lo = lead ? 1 : 0, hi = nk - ((trail && nk > lo) ? 1 : 0);
+        bool plain = true;
+        for (size_t i = lo; i < hi; i++) plain = plain && kinds[i] == 0;
+        if (plain && !(nk == 1 && lead)) {
+          const std::string lit = bytes.substr(lo, hi - lo);
+          const char* fnname = lead && trail ? "gdv_like_contains" : lead ? "gdv_like_suffix"
+                               : trail ? "gdv_like_prefix" : "gdv_like_equal";
+          const std::string per_row = std::string(fnname) + "(" + args[0].v + ", " + ByteTable(lit) + ", " +
+                                      std::to_string(lit.size()) + ")";
+          if (lead && trail && lit.size() >= 2 && lit.size() <= 8 && args[0].col_slot >= 0 && !selection()) {
+            // '%needle%' over a whole input row: the byte sweep has marked every match position
+            // of the tile's span in an LDS bitmap; the row tests its own byte range.  Spans too
+            // long for the bitmap (wave-uniform) take the per-row search.
+            const int h = HookFor(args[0].col_slot, args[0].col_map, lit);
+            const std::string k = std::to_string(args[0].col_slot);
+            out->v = Tmp("bool", "((GDV_ABL & 2) ? (ob" + k + "[u] - oa" + k + "[u] > 19) : hm_ok" + k + " ? gdv_range_any(hit" + std::to_string(h) + ", oa" + k +
+                                     "[u] - sb" + k + ", ob" + k + "[u] - sb" + k + " - " +
+                                     std::to_string(lit.size() - 1) + ") : " + per_row + ")");
+            return Status::OK();
+          }
+          out->v = Tmp("bool", per_row);
+          return Status::OK();
+        }
+        std::string pb = ByteTable(bytes), pk = ByteTable(kinds);
+        out->v = Tmp("bool", "gdv_like(" + args[0].v + ", " + pb + ", " + pk + ", " +
+                                 std::to_string(kinds.size()) + ")");
+        return Status::OK();
+      }
+      std::string call = def->symbol + "(";
+      bool first = true;
+      auto push = [&](const std::string& a) {
+        if (!first) call += ", ";
+        call += a;
+        first = false;
+      };
+      if (def->flags & kNeedsContext) {
+        push("ctx");
+        can_raise_ = true;
+      }
+      if (def->policy == NullPolicy::kNullIfNull) {
+        std::string lanes;
+        for (auto& a : args) {
+          push(a.v);
+          if ((def->flags & kDecimalArgs) && a.type.is_decimal()) {
+            push(std::to_string(a.type.precision));
+            push(std::to_string(a.type.scale));
+          }
+          out->vcols.insert(a.vcols.begin(), a.vcols.end());
+          lanes = AndExpr(lanes, a.vlane);
+        }
+        if (def->flags & kDecimalArgs) {
+          push(std::to_string(out->type.precision));
+          push(std::to_string(out->type.scale));
+        }
+        out->vlane = lanes;
+        call += ")";
+        if (def->flags & kNeedsContext) {
+          // Functions that can raise run only on rows where every argument is valid and
+          // the enclosing if/else / short-circuit path is live — otherwise a guarded
+          // `if (b != 0) a / b` would raise on the rows it guards against.
+          std::string guard = AndExpr(AndExpr("live", active), LaneValid(*out));
+          const std::string idle = out->type.is_varlen() ? "gdv_empty_str()" : "(" + ctype + ")0";
+          out->v = Tmp(ctype, guard + " ? " + call + " : " + idle);
+        } else {
+          out->v = Tmp(ctype, call);
+        }
+      } else if (def->policy == NullPolicy::kNullNever) {
+        for (auto& a : args) {
+          push(a.v);
+          push(LaneValid(a));
+        }
+        call += ")";
+        out->v = Tmp(ctype, call);
+      } else {
+        for (auto& a : args) {
+          push(a.v);
+          push(LaneValid(a));
+        }
+        std::string ov = "ov" + std::to_string(next_tmp_++);
+        Stmt("bool " + ov + " = false;");
+        push("&" + ov);
+        call += ")";
+        out->v = Tmp(ctype, call);
+        out->vlane = ov;
+      }
+      return Status::OK();
+    }
+    case NodeKind::kIf: {
+      auto& n = static_cast<const IfNode&>(node);
+      Val c, t, e;
+      GDV_RETURN_NOT_OK(Gen(*n.condition(), active, &c));
+      // a null condition selects the else branch
+      std::string take = Tmp("bool", AndFull(LaneValid(c), c.v));
+      GDV_RETURN_NOT_OK(Gen(*n.then_node(), AndExpr(active, take), &t));
+      GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
+      if (!t.pieces.empty() || !e.pieces.empty())
+        return Status::CodeGenError("if/else over a concat result is not supported by the HIP backend yet");
+      out->type = n.return_type();
+      const std::string ctype = out->type.CType();
+      out->pieces.clear();
+      out->col_slot = -1;
+      out->v = Tmp(ctype, take + " ? " + t.v + " : " + e.v);
+      out->vcols.clear();
+      if (t.never_null() && e.never_null()) {
+        out->vlane.clear();
+      } else {
+        out->vlane = Tmp("bool", take + " ? " + LaneValid(t) + " : " + LaneValid(e));
+      }
+      return Status::OK();
+    }
+    case NodeKind::kBoolean: {
+      // SQL three-valued logic with left-to-right short circuit:
+      //   AND: false if any child is (valid, false); else null if any child is null; else true
+      //   OR : true  if any child is (valid, true);  else null if any child is null; else false
+      auto& n = static_cast<const BooleanNode&>(node);
+      const bool is_and = n.op() == BooleanNode::kAnd;
+      std::string decided;    // some earlier child already fixed the result
+      std::string all_valid;  // every child so far valid
+      std::string live_path = active;
+      for (auto& child : n.children()) {
+        Val c;
+        GDV_RETURN_NOT_OK(Gen(*child, live_path, &c));
+        std::string cvalid = LaneValid(c);
+        std::string hit = AndFull(cvalid, is_and ? "!" + c.v : c.v);
+        hit = Tmp("bool", hit);
+        decided = decided.empty() ? hit : Tmp("bool", "(" + decided + " || " + hit + ")");
+        all_valid = AndExpr(all_valid, cvalid);
+        live_path = AndExpr(active, "!" + decided);
+      }
+      out->type = boolean();
+      out->vcols.clear();
+      out->col_slot = -1;
+      if (all_valid.empty() || all_valid == "true") {
+        out->vlane.clear();
+        out->v = Tmp("bool", is_and ? "!" + decided : decided);
+      } else {
+        std::string av = Tmp("bool", all_valid);
+        out->vlane = Tmp("bool", "(" + decided + " || " + av + ")");
+        // value bit under a null result is defined as false
+        out->v = Tmp("bool", is_and ? "(!" + decided + " && " + av + ")" : decided);
+      }
+      return Status::OK();
+    }
+    case NodeKind::kIn: {
+      auto& n = static_cast<const InNode&>(node);
+      Val x;
+      GDV_RETURN_NOT_OK(Gen(*n.eval(), active, &x));
+      if (!x.pieces.empty())
+        return Status::CodeGenError("IN over a concat result is not supported by the HIP backend yet");
+      out->pieces.clear();
+      out->col_slot = -1;
+      out->type = boolean();
+      out->vcols = x.vcols;
+      out->vlane = x.vlane;
+      if (n.value_type().is_varlen()) {
+        std::string bytes, offs;
+        auto put32 = [&](uint32_t v) { offs.append(reinterpret_cast<const char*>(&v), 4); };
+        put32(0);
+        for (auto& l : n.values()) {
+          bytes += l.bytes;
+          put32(static_cast<uint32_t>(bytes.size()));
+        }
+        const std::string tab = ByteTable(offs, "gdv_int32");
+        out->v = Tmp("bool", "gdv_in_strings(" + x.v + ", " + ByteTable(bytes) + ", " + tab + ", " +
+                                 std::to_string(n.values().size()) + ")");
+        return Status::OK();
+      }
+      const DataType& vt = n.value_type();
+      if (vt.is_decimal()) {
+        // 16-byte values: equality against two argument slots each (lists are short in practice)
+        if (n.values().size() > 64)
+          return Status::CodeGenError("IN over decimal128 with more than 64 values is not supported by the HIP backend yet");
+        std::string e;
+        for (auto& l : n.values()) {
+          lits_.push_back(l.lo);
+          lits_.push_back(l.hi);
+          const std::string i = std::to_string(lits_.size() - 2), j = std::to_string(lits_.size() - 1);
+          if (!e.empty()) e += " || ";
+          e += "(" + x.v + " == gdv_make_int128(A.lit[" + j + "], A.lit[" + i + "]))";
+        }
+        out->v = e.empty() ? std::string("false") : Tmp("bool", e);
+        return Status::OK();
+      }
+      std::vector<uint64_t> vals;
+      uint64_t mask = vt.byte_width() >= 8 ? ~0ull : ((1ull << (8 * vt.byte_width())) - 1);
+      const bool is_fp = vt.id == kFloat || vt.id == kDouble;
+      for (auto& l : n.values()) {
+        uint64_t bits = l.lo & mask;
+        if (is_fp) {
+          // value equality, as a hash set of floats gives it: -0.0 and +0.0 are one value,
+          // a NaN equals nothing (the probe adds +0.0, which maps -0.0 to +0.0 and keeps NaNs NaN)
+          const bool nan = vt.id == kFloat ? ((bits & 0x7f800000u) == 0x7f800000u && (bits & 0x7fffffu) != 0)
+                                           : ((bits & 0x7ff0000000000000ull) == 0x7ff0000000000000ull &&
+                                              (bits & 0xfffffffffffffull) != 0);
+          if (nan) continue;
+          if (bits == (vt.id == kFloat ? 0x80000000ull : 0x8000000000000000ull)) bits = 0;
+        }
+        vals.push_back(bits);
+      }
+      std::sort(vals.begin(), vals.end());
+      vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+      const std::string probe = is_fp ? "gdv_bits64(" + x.v + " + (" + vt.CType() + ")0)" : "gdv_bits64(" + x.v + ")";
+      if (vals.empty()) {
+        out->v = "false";
+      } else if (vals.size() <= 8) {
+        const std::string xb = Tmp("gdv_uint64", probe);
+        std::string e;
+        for (auto v : vals) {
+          if (!e.empty()) e += " || ";
+          e += "(" + xb + " == A.lit[" + std::to_string(LitSlot(v)) + "])";
+        }
+        out->v = Tmp("bool", e);
+      } else {
+        // sorted table in the constant block + branch-free binary search on the value's bit image
+        std::string tab(reinterpret_cast<const char*>(vals.data()), vals.size() * 8);
+        out->v = Tmp("bool", "gdv_in_sorted(" + probe + ", " + ByteTable(tab, "gdv_uint64") + ", " +
+                                 std::to_string(vals.size()) + ")");
+      }
+      return Status::OK();
+    }
+  }
+  return Status::CodeGenError("unknown node kind");
+}
+
+// Assembles the translation unit around the generated row body.
+struct Assembler {
+  CodeGen& cg;
+  KernelPlan* plan;
+  std::ostringstream src;
+
+  void Header(const std::vector<std::string>& expr_strings) {
+    src << "// generated by gandiva_amd (gdv_planner.cc) — fused "
+        << (plan->kind == KernelKind::kFilter ? "filter" : "projection") << " kernel for gfx950\n";
+    for (size_t i = 0; i < expr_strings.size(); i++)
+      src << "// @expr_" << i << " = " << expr_strings[i] << "\n";
+    src << "#define GDV_U " << plan->opts.subtiles << "\n";
+    src << "#define GDV_WAVES " << plan->opts.waves << "\n";
+    src << "#include \"gdv_device_lib.hpp\"\n";
+    const int nin = std::max<int>(1, plan->input_fields.size());
+    const int nout = std::max<int>(1, plan->output_types.size());
+    src << "struct gdv_in_slot { const void* data; gdv_bitmap valid; gdv_bitmap bits; const gdv_int32* offsets; };\n";
+    src << "struct gdv_out_slot { void* data; gdv_uint64* valid; gdv_int32* offsets; gdv_int64 cap; };\n";
+    src << "struct gdv_args {\n"
+        << "  gdv_int64 n; gdv_uint32* err; const void* sel; gdv_uint64* mask; gdv_uint32* counts;\n"
+        << "  gdv_int64 aux0, aux1, aux2;\n"
+        << "  gdv_in_slot in[" << nin << "];\n"
+        << "  gdv_out_slot out[" << nout << "];\n"
+        << "  gdv_uint64 lit[" << std::max<size_t>(1, cg.lits_.size()) << "];  // fixed-width literals of the plan\n"
+        << "};\n";
+    plan->literals = cg.lits_;
+    plan->const_block = cg.blob_;
+    plan->layout.n_lit = static_cast<int>(cg.lits_.size());
+  }
+};
+
+std::string SelCType(SelectionMode m) {
+  switch (m) {
+    case SelectionMode::kUInt16: return "gdv_uint16";
+    case SelectionMode::kUInt32: return "gdv_uint32";
+    default: return "gdv_uint64";
+  }
+}
+
+// Output bitmap words are accumulated per wave tile: word u is deposited into lane u of an
+// accumulator register, so the tile's GDV_U words leave with one coalesced store.  Outputs
+// whose word expressions are textually identical share one accumulator.
+struct WordAccumulators {
+  std::map<std::string, std::string> by_expr;  // word expression -> accumulator name
+  std::vector<std::string> names;
+  std::string Get(CodeGen& cg, const std::string& word_expr) {
+    auto it = by_expr.find(word_expr);
+    if (it != by_expr.end()) return it->second;
+    std::string name = "acc" + std::to_string(names.size());
+    names.push_back(name);
+    by_expr[word_expr] = name;
+    cg.Stmt(name + " = gdv_deposit_word(" + name + ", u, " + word_expr + ", lane);");
+    return name;
+  }
+};
+
+std::string WordStore(const std::string& acc, const std::string& dst, bool nontemporal = false) {
+  return std::string("  if (!(GDV_ABL & 2) && lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) ") +
+         (nontemporal ? "GDV_WORD_ST_NT(" : "GDV_WORD_ST(") + dst +
+         " + wbase + lane, " + acc + ");\n";
+}
+
+Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
+                const WordAccumulators& accs, const std::string& decls_before_loop,
+                const std::string& epilogue_after_loop) {
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = cg.can_raise_;
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
+  const std::string body = cg.body_.str();
+
+  // WIDE layout (round 2): a lane owns 4 CONSECUTIVE rows of a 256-row group instead of one
+  // row of each 64-row sub-tile, so every column moves with 16-byte-per-lane instructions
+  // whatever its width (int32: one dwordx4 per 4 rows instead of four dword loads of 256 B per
+  // wave).  Element u of a lane is row  rbase + (u / 4) * 256 + 4 * lane + (u % 4).  Validity
+  // stays word-wise (word u = rows 64u .. 64u+63), which is independent of the lane mapping —
+  // so the layout applies to plans whose validity is a pure intersection of input words and
+  // whose values never look at a lane's validity bit: no bool columns, no if/else or 3-valued
+  // logic, nothing that can raise.  Those keep the one-row-per-lane layout.
+  // MEASURED (profiles/r02_wide_layout.txt): no gain for int32 (C1-shape 0.73 either way) and a
+  // large loss for 8- and 16-byte types, whose per-lane runs of 32 / 64 bytes make every wave
+  // instruction touch only half / a quarter of each line.  Off by default; GDV_WIDE=1 enables it
+  // for plans whose columns are all <= 4 bytes wide.
+  bool wide = !sel && plan->kind == KernelKind::kProject && !cg.can_raise_ && plan->opts.subtiles % 4 == 0 &&
+              std::getenv("GDV_WIDE") != nullptr && body.find("gdv_lane_bit") == std::string::npos &&
+              body.find("__ballot") == std::string::npos;
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    wide = wide && t.id != kBool && t.byte_width() <= 4;
+  }
+  for (auto& t : plan->output_types) wide = wide && t.id != kBool && t.byte_width() <= 4;
+
+  Assembler as{cg, plan, {}};
+  as.Header(expr_strings);
+  std::ostringstream& s = as.src;
+  s << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n";
+  if (wide)
+    s << "#define GDV_OUT(e, v) res##e[u] = (v)\n";
+  else
+    s << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+
+  s << "template <bool FULL>\n"
+    << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane) {\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id != kBool && cg.needs_values_[k])
+      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType() << "*)A.in[" << k
+        << "].data;\n";
+  }
+  for (size_t e = 0; e < plan->output_types.size(); e++) {
+    const DataType& t = plan->output_types[e];
+    if (t.id != kBool)
+      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
+    if (wide) s << "  " << t.CType() << " res" << e << "[GDV_U];\n";
+  }
+  if (sel)
+    s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const " << SelCType(cg.sel_mode_)
+      << "*)A.sel;\n";
+
+  // ---- phase 1: every load of the tile, no control flow in between
+  s << "  // ---- phase 1: all loads of this wave's GDV_U sub-tiles, issued back to back\n";
+  if (sel) s << "  gdv_int64 srow[GDV_U];\n";
+  std::ostringstream bitmap_loads;  // one vector load per column: lane u <-> word u
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k]) {
+        if (sel) s << "  bool x" << k << "[GDV_U];\n";
+        else if (!plan->opts.scalar_bitmaps) bitmap_loads << "  const gdv_uint64 dw" << k << " = (GDV_ABL & 1) ? ~0ull : gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      }
+    } else if (cg.needs_values_[k]) {
+      s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
+    }
+    if (cg.needs_validity_[k]) {
+      if (sel) s << "  bool b" << k << "[GDV_U];\n";
+      else if (!plan->opts.scalar_bitmaps) bitmap_loads << "  const gdv_uint64 vw" << k << " = (GDV_ABL & 1) ? ~0ull : gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+    }
+  }
+  // Bitmap words BEHIND the value loads (round 2): issued first, the compiler consumed them first
+  // and waited for them before most value loads were even issued (7 of 32 in the C3 predicate
+  // kernel); a hand-written copy of that kernel with every load in flight ran 0.45 ms faster
+  // (tools/hbm_ceiling.hip, profiles/r02_k1_k2_experiments.txt).
+  if (!plan->opts.bitmaps_last) s << bitmap_loads.str();
+  const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
+  if (wide) {
+    s << "  if (FULL) {\n#pragma unroll\n    for (int g = 0; g < GDV_U / 4; g++) {\n"
+      << "      const gdv_int64 row0 = rbase + g * 256 + 4 * lane;\n";
+    for (int k = 0; k < nin; k++)
+      if (cg.needs_values_[k]) s << "      gdv_ld4<" << (plan->opts.nt_loads ? "true" : "false") << ">(in" << k << " + row0, &c" << k << "[4 * g]);\n";
+    s << "    }\n  } else {\n#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
+      << "      const gdv_int64 row = rbase + (u >> 2) * 256 + 4 * lane + (u & 3);\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (cg.needs_values_[k]) s << "      c" << k << "[u] = row < n ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0;\n";
+    }
+    s << "    }\n  }\n";
+  } else {
+    s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+      << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "    const bool live = FULL || row < n;\n"
+      << "    (void)live;\n";
+    if (sel) {
+      s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
+      for (int k = 0; k < nin; k++) {
+        const DataType& t = cg.schema_[plan->input_fields[k]].type;
+        if (t.id == kBool) {
+          if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+        } else if (cg.needs_values_[k]) {
+          s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+        }
+        if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+      }
+    } else {
+      for (int k = 0; k < nin; k++) {
+        const DataType& t = cg.schema_[plan->input_fields[k]].type;
+        if (t.id != kBool && cg.needs_values_[k])
+          s << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
+      }
+    }
+    s << "  }\n";
+  }
+
+  if (plan->opts.bitmaps_last) s << bitmap_loads.str();
+  // ---- phase 2: row body
+  if (plan->opts.load_fence)
+    s << "  __builtin_amdgcn_sched_barrier(0);  // keep every load of the tile ahead of the first use\n";
+  s << "  // ---- phase 2: fused expression bodies (value for every row, validity per word)\n";
+  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
+  s << decls_before_loop;
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    {\n";
+  if (wide) {
+    s << "      const gdv_int64 row = rbase + (u >> 2) * 256 + 4 * lane + (u & 3);   // this lane's element u\n"
+      << "      const bool live = FULL || row < n;\n"
+      << "      const gdv_uint64 livemask = FULL ? ~0ull : gdv_live_word(rbase + 64 * u, n);  // validity WORD u\n";
+  } else {
+    s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "      const bool live = FULL || row < n;\n"
+      << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n";
+  }
+  s << "      (void)livemask; (void)row; (void)live;\n";
+  if (!sel) {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k])
+        s << "      const gdv_uint64 d" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].bits, wbase + u)" : "gdv_tile_word(dw" + std::to_string(k) + ", u)") << ";\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].valid, wbase + u)" : "gdv_tile_word(vw" + std::to_string(k) + ", u)") << ";\n";
+    }
+  }
+  s << body;
+  s << "    }\n  }\n";
+  if (wide) {
+    s << "  // ---- stores: 4 consecutive rows per lane and instruction\n"
+      << "#pragma unroll\n  for (int g = 0; g < GDV_U / 4; g++) {\n"
+      << "    const gdv_int64 row0 = rbase + g * 256 + 4 * lane;\n";
+    for (size_t e = 0; e < plan->output_types.size(); e++) {
+      s << "    if (FULL || row0 + 4 <= n) gdv_st4<" << (plan->opts.nontemporal ? "true" : "false") << ">(out" << e
+        << " + row0, &res" << e << "[4 * g]);\n"
+        << "    else {\n#pragma unroll\n      for (int i = 0; i < 4; i++) if (row0 + i < n) out" << e << "[row0 + i] = res" << e
+        << "[4 * g + i];\n    }\n";
+    }
+    s << "  }\n";
+  }
+  s << epilogue_after_loop;
+  s << "}\n\n";
+  // ---- kernel: grid-stride over workgroup tiles; wave w of a workgroup owns GDV_U
+  // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
+  // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
+  // each bitmap.
+  s << "extern \"C\" __global__ void ";
+  if (plan->opts.waves_per_eu > 0)
+    s << "__attribute__((amdgpu_waves_per_eu(" << plan->opts.waves_per_eu << ", " << plan->opts.waves_per_eu << "))) ";
+  s << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
+    << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
+    << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
+    << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nfull;\n"
+    << "       wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
+    << "    gdv_tile<true>(A, wt * GDV_U, lane);\n"
+    // The single partial wave tile is handled after the loop, not in an if/else next to
+    // the full-tile body: side by side, the compiler hoists the two bodies' common bitmap
+    // loads above the branch and serialises them in front of the value loads.
+    << "  if (nwt > nfull && wave == (int)(nfull % GDV_WAVES) &&\n"
+    << "      blockIdx.x == (unsigned)((nfull / GDV_WAVES) % gridDim.x))\n"
+    << "    gdv_tile<false>(A, nfull * GDV_U, lane);\n"
+    << "}\n";
+
+  std::string text = s.str();
+  uint64_t h = Fnv1a(HashableSource(text) + LibraryTag());
+  char name[64];
+  snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+  plan->kernel_name = name;
+  size_t pos = text.find("GDV_KERNEL_NAME");
+  text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
+  plan->source = text;
+  plan->ir = text;
+  return Status::OK();
+}
+
+
+// ------------------------------------------------------------------ string plans
+// Kernels that read or write var-len columns use their own skeleton (round 2):
+//   tile     one workgroup = GDV_WAVES waves x GDV_U sub-tiles x 64 rows; a wave's rows occupy ONE
+//            contiguous span of each var-len input's data buffer
+//   sweep    lanes over the BYTES of that span: tile-wide ASCII flag, '%needle%' match bitmaps
+//   rows     lane = row: the fused expression bodies; var-len results are kept as views
+//   offsets  per-wave DPP scan of the lengths -> workgroup totals -> ONE granule posted to the
+//            scanner wave (workgroup 0), ONE granule polled for the tile's exclusive prefix
+//   bytes    staged in LDS while waiting, flushed coalesced; or streamed flat when the output
+//            IS the (mapped) input span
+// Single launch, inputs read once (round 1: two passes, 1.43 x the algorithmic traffic).
+Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
+                       const WordAccumulators& accs, const std::string& decls_before_loop,
+                       const std::string& epilogue_after_loop) {
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = cg.can_raise_;
+  plan->string_skeleton = true;
+  for (size_t k = 0; k < plan->input_fields.size(); k++)
+    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const int nv = static_cast<int>(cg.varlen_outs_.size());
+  const int ng = (nv + 1) / 2;
+  int nstage = 0;                              // LDS staging windows per wave
+  for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());
+  plan->num_varlen_outputs = nv;
+  for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
+
+  Assembler as{cg, plan, {}};
+  as.Header(expr_strings);
+  std::ostringstream& s = as.src;
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
+  s << "#define GDV_NV " << nv << "\n#define GDV_NG " << ng << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
+    << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
+    << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
+    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
+    << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
+    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
+    << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+
+  s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
+    << "                      const int wave, gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint32 (*lds_tot)[GDV_NV > 0 ? GDV_NV : 1],\n"
+    << "                      gdv_uint64* lds_base) {\n"
+    << "  (void)lds_out; (void)lds_hit; (void)lds_tot; (void)lds_base; (void)ntiles;\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n"
+    << "  constexpr bool optflat = GDV_OPTFLAT != 0;  // flat outputs: offsets = input offsets, bytes copied after the sweep\n"
+    << "  (void)optflat;\n";
+  if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.is_varlen() && cg.needs_values_[k]) {
+      s << "  const gdv_uint8* __restrict__ sd" << k << " = (const gdv_uint8*)A.in[" << k << "].data;\n"
+        << "  const gdv_int32* __restrict__ so" << k << " = A.in[" << k << "].offsets;\n"
+        << "  const gdv_uint8* slim" << k << " = sd" << k << " + A.in[" << k << "].bits.nwords;\n";
+    } else if (t.id != kBool && cg.needs_values_[k]) {
+      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType() << "*)A.in[" << k
+        << "].data;\n";
+    }
+  }
+  for (size_t e = 0; e < plan->output_types.size(); e++) {
+    const DataType& t = plan->output_types[e];
+    if (t.is_varlen()) {
+      s << "  gdv_uint8* __restrict__ outd" << e << " = (gdv_uint8*)A.out[" << e << "].data;\n"
+        << "  gdv_int32* __restrict__ outo" << e << " = A.out[" << e << "].offsets;\n";
+    } else if (t.id != kBool) {
+      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
+    }
+  }
+  if (sel)
+    s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const " << SelCType(cg.sel_mode_)
+      << "*)A.sel;\n";
+
+  // ---- loads: offsets, fixed-width values, validity / bool words
+  s << "  // ---- loads of this wave's GDV_U sub-tiles, issued back to back\n";
+  if (sel) s << "  gdv_int64 srow[GDV_U];\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k]) {
+        if (sel) s << "  bool x" << k << "[GDV_U];\n";
+        else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      }
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k]) s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
+    } else if (cg.needs_values_[k]) {
+      s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
+    }
+    if (cg.needs_validity_[k]) {
+      if (sel) s << "  bool b" << k << "[GDV_U];\n";
+      else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+    }
+  }
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "    const bool live = row < n;\n"
+    << "    (void)live;\n";
+  if (sel) {
+    s << "    srow[u] = live ? (gdv_int64)selv[row] : 0;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool) {
+        if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+      } else if (t.is_varlen()) {
+        if (cg.needs_values_[k])
+          s << "    oa" << k << "[u] = so" << k << "[srow[u]]; ob" << k << "[u] = so" << k << "[srow[u] + 1];\n";
+      } else if (cg.needs_values_[k]) {
+        s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+      }
+      if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+    }
+  } else {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.is_varlen()) {
+        // rows past the end take the closing offset: length 0, and the span stays contiguous
+        if (cg.needs_values_[k])
+          s << "    oa" << k << "[u] = so" << k << "[live ? row : n]; ob" << k << "[u] = so" << k
+            << "[row + 1 < n ? row + 1 : n];\n";
+      } else if (t.id != kBool && cg.needs_values_[k]) {
+        s << "    c" << k << "[u] = live ? " << (plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld") << "(in" << k
+          << ", row) : (" << t.CType() << ")0;\n";
+      }
+    }
+  }
+  s << "  }\n";
+
+  // ---- sweep: lanes over the bytes of each var-len input's span
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+    std::vector<int> hooks;
+    for (int h = 0; h < nhook; h++)
+      if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
+    const bool want_ascii = cg.ascii_slots_.count(k) != 0;
+    std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
+    for (auto& vo : cg.varlen_outs_)
+      if (vo.flat_slot == k) flats.push_back(&vo);
+    const std::string K = std::to_string(k);
+    if (sel) {
+      s << "  const gdv_int32 sfl" << K << " = 0;\n";
+      continue;
+    }
+    // one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
+    s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
+      << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    if (!flats.empty())
+      s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
+    if (hooks.empty() && !want_ascii && flats.empty()) {
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+      continue;
+    }
+    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n"
+      << "  const gdv_int32 sp0" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+      << "  const gdv_int32 sp1" << K << " = __builtin_amdgcn_readlane(ob" << K << "[GDV_U - 1], 63);\n"
+      << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
+      << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
+      << "  (void)hm_ok" << K << ";\n"
+      << "  gdv_uint64 sacc" << K << " = 0;\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
+        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
+        << ";  // the needle: a runtime constant\n"
+        << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
+        << " >> 8) & 0xffull) * GDV_B01;\n";
+    }
+    s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
+      << "    const gdv_int32 a = c + 16 * lane;\n"
+      << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
+      << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+      << "    sacc" << K << " |= w[0] | w[1];\n";
+    if (!hooks.empty()) {
+      s << "    gdv_uint64 tail = 0;  // lane 63's halo: the first 8 bytes of the next step\n"
+        << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
+      for (int h : hooks) {
+        const ContainsHook& hk = cg.contains_hooks_[h];
+        const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+        const std::string H = std::to_string(h), M = std::to_string(hk.map);
+        s << "    {\n"
+          << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
+          << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
+          << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
+          << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+          << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
+          << ") << 8);\n"
+          << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
+          << ") >> 4] = (gdv_uint16)m;\n"
+          << "    }\n";
+      }
+    }
+    s << "  }\n";
+    // optimistic flat outputs: their place in the output is known from the input offsets alone, so
+    // the span is copied right here, while the sweep's lines are still in L2 / L1.  (Moving the copy
+    // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
+    // slower: 1.90 vs 1.78 ms, same box, profiles/r02_c5_tuning.txt.)
+    for (auto* vo : flats)
+      s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
+        << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
+        << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
+    if (want_ascii)
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | (__ballot((sacc" << K
+        << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
+    else
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+    if (!hooks.empty()) s << "  __builtin_amdgcn_wave_barrier();\n";
+  }
+
+  // ---- row phase
+  s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
+  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
+  s << decls_before_loop;
+  if (nv > 0)
+    s << "  bool need_direct = false;\n"
+      << "  // pass 0: lengths, offsets, staged / flat bytes.  pass 1 (rare): rows of outputs whose bytes\n"
+      << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
+      << "  for (int pass = 0; pass < 2; pass++) {\n"
+      << "  if (pass == 1 && !need_direct) break;\n";
+  else
+    s << "  constexpr int pass = 0;\n  (void)pass;\n";
+  // The row loop is NOT unrolled: the per-sub-tile registers are read and written through
+  // gdv_pick / gdv_put (selects on the wave-uniform u), so the fused body exists once — a
+  // quarter of the code, the compile time and the VGPRs of the unrolled form.
+  s << "GDV_ROW_LOOP\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    {\n"
+    << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "      const bool live = row < n;\n"
+    << "      const gdv_uint64 livemask = __ballot(live);\n"
+    << "      (void)livemask; (void)row;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k] && sel) s << "      const bool x" << k << "_u = x" << k << "[0];\n";
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k])
+        s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0], ob" << k << "_u = ob" << k << "[0];\n"
+          << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
+          << ", sfl" << k << ");\n";
+    } else if (cg.needs_values_[k]) {
+      s << "      const " << t.CType() << " c" << k << "_u = c" << k << "[0];\n";
+    }
+    if (cg.needs_validity_[k] && sel) s << "      const bool b" << k << "_u = b" << k << "[0];\n";
+  }
+  if (!sel) {
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k])
+        s << "      const gdv_uint64 d" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].bits, wbase + u)" : "gdv_tile_word(dw" + std::to_string(k) + ", u)") << ";\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].valid, wbase + u)" : "gdv_tile_word(vw" + std::to_string(k) + ", u)") << ";\n";
+    }
+  }
+  {
+    // the body addresses per-sub-tile inputs as NAME[u]: here they are the NAME_u picked above
+    static const std::regex per_u("\\b(oa|ob|c|x|b)([0-9]+)\\[u\\]");
+    s << std::regex_replace(cg.body_.str(), per_u, "$1$2_u");
+  }
+  s << "    }\n    // next sub-tile to the front\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k] && sel) s << "    gdv_rot(x" << k << ");\n";
+    } else if (t.is_varlen()) {
+      if (cg.needs_values_[k]) s << "    gdv_rot(oa" << k << "); gdv_rot(ob" << k << ");\n";
+    } else if (cg.needs_values_[k]) {
+      s << "    gdv_rot(c" << k << ");\n";
+    }
+    if (cg.needs_validity_[k] && sel) s << "    gdv_rot(b" << k << ");\n";
+  }
+  for (auto& vo : cg.varlen_outs_) s << "    gdv_rot(lc" << vo.e << ");\n";
+  s << "  }\n";
+  if (nv > 0) s << "  if (pass == 1) break;\n";
+  for (auto& vo : cg.varlen_outs_)
+    if (vo.flat_slot >= 0)
+      s << "  if (optflat && fb" << vo.e << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n";
+  s << epilogue_after_loop;
+
+  // ---- var-len outputs
+  if (nv > 0) {
+    s << "  // ---- var-len outputs: workgroup totals -> one granule to the scanner\n"
+      << "  if (lane == 0) {\n";
+    for (int v = 0; v < nv; v++)
+      s << "    lds_tot[wave][" << v << "] = (gdv_uint32)run" << cg.varlen_outs_[v].e << ";\n";
+    s << "  }\n  __syncthreads();\n"
+      << "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n"
+      << "#pragma unroll\n  for (int v = 0; v < GDV_NV; v++) { before[v] = 0; all[v] = 0; }\n"
+      << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
+      << "#pragma unroll\n    for (int v = 0; v < GDV_NV; v++) {\n"
+      << "      const gdv_uint32 t = lds_tot[w][v];\n      all[v] += t;\n      before[v] += w < wave ? t : 0u;\n    }\n  }\n"
+      << "  gdv_uint64* const lb_agg = A.mask;\n"
+      << "  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n"
+      << "  if (threadIdx.x == 0) {\n";
+    for (int g = 0; g < ng; g++)
+      s << "    gdv_lb_post(lb_agg, ntiles, tile, " << g << ", all[" << 2 * g << "], "
+        << (2 * g + 1 < nv ? "all[" + std::to_string(2 * g + 1) + "]" : std::string("0ull")) << ");\n";
+    s << "  }\n";
+    s << "  if (threadIdx.x == 0) {\n"
+      << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = (GDV_ABL & 32) ? (gdv_uint64)tile * 4000 : gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
+      << "  }\n  __syncthreads();\n";
+    for (int v = 0; v < nv; v++) {
+      const VarlenOut& vo = cg.varlen_outs_[v];
+      const std::string E = std::to_string(vo.e);
+      s << (vo.flat_slot >= 0 ? "  if (!optflat) {\n" : "  {\n")
+        << "    const gdv_int64 base = (gdv_int64)((lds_base[" << v / 2 << "] >> " << 31 * (v % 2)
+        << ") & GDV_LB_M31) + (gdv_int64)before[" << v << "];\n"
+        << "    const bool fits = run" << E << " < 0x7fffffff && base + run" << E << " <= A.out[" << E << "].cap;\n"
+        << "#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
+        << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+        << "      if (row < n) outo" << E << "[row] = (gdv_int32)(base + lc" << E << "[u]);\n"
+        << "    }\n"
+        << "    if (fits) {\n";
+      if (vo.flat_slot >= 0) {
+        const std::string K = std::to_string(vo.flat_slot);
+        s << "      if (fb" << E << " == 0) {  // no row dropped: the output IS the mapped input span\n"
+          << "        gdv_flat_copy(outd" << E << " + base, sd" << K << " + __builtin_amdgcn_readfirstlane(oa" << K
+          << "[0]), run" << E << ", " << vo.flat_map << ", lane);\n"
+          << "      } else {\n";
+      } else if (vo.window >= 0) {
+        s << "      if (run" << E << " <= GDV_OUT_WIN) {\n"
+          << "        if (!(GDV_ABL & 16)) gdv_flush_out(outd" << E << " + base, win" << E << ", run" << E << ", lane);\n"
+          << "      } else {\n";
+      } else {
+        s << "      {\n";
+      }
+      s << "        dir" << E << " = true;\n        dbase" << E << " = base;\n        need_direct = true;\n"
+        << "      }\n    }\n  }\n";
+    }
+    s << "  if ((gdv_int64)gridDim.x - 1 < ntiles) __syncthreads();  // serial-safe launches only: the LDS hand-off words are reused by the next tile\n"
+      << "  }  // pass\n";
+  }
+  s << "}\n\n";
+
+  // ---- kernel
+  s << "#ifndef GDV_STRING_KERNEL_ATTR\n#define GDV_STRING_KERNEL_ATTR\n#endif\n"
+    << "extern \"C\" __global__ void GDV_STRING_KERNEL_ATTR __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+    << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
+    << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
+    << "  __shared__ gdv_uint32 gdv_lds_tot[GDV_WAVES][GDV_NV > 0 ? GDV_NV : 1];\n"
+    << "  __shared__ gdv_uint64 gdv_lds_base[GDV_NG > 0 ? GDV_NG : 1];\n"
+    << "  const gdv_int64 ntiles = (A.n + 64 * GDV_U * GDV_WAVES - 1) / (64 * GDV_U * GDV_WAVES);\n";
+  if (nv > 0) {
+    s << "  // workgroup 0 is the scanner of the tile totals; workers are workgroups 1..\n"
+      << "  if (blockIdx.x == 0) {\n"
+      << "    if (wave == 0) {\n"
+      << "      gdv_uint64* const totals = (gdv_uint64*)A.counts;\n"
+      << "      gdv_scanner<GDV_NG>(A.mask, A.mask + (gdv_int64)GDV_NG * ntiles, ntiles, totals, A.err, lane);\n"
+      << "      if (lane == 0) {\n";
+    for (int v = 0; v < nv; v++) {
+      const VarlenOut& vo = cg.varlen_outs_[v];
+      if (vo.flat_slot >= 0)
+        s << "        if (GDV_OPTFLAT) { const gdv_int32* so = A.in[" << vo.flat_slot << "].offsets; totals[" << v
+          << "] = (gdv_uint64)(so[A.n] - so[0]); }\n";
+      s << "        A.out[" << vo.e << "].offsets[A.n] = (gdv_int32)(totals[" << v
+        << "] > GDV_LB_M31 ? GDV_LB_M31 : totals[" << v << "]);\n";
+    }
+    s << "      }\n    }\n    return;\n  }\n"
+      << "  for (gdv_int64 tile = (gdv_int64)blockIdx.x - 1; tile < ntiles; tile += (gdv_int64)gridDim.x - 1)\n";
+  } else {
+    s << "  for (gdv_int64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x)\n";
+  }
+  s << "    gdv_tile(A, tile, ntiles, lane, wave, gdv_lds_out[wave], gdv_lds_hit[wave], gdv_lds_tot, gdv_lds_base);\n"
+    << "}\n";
+
+  // Two variants of the same text: GDV_OPTFLAT = 1 (flat outputs taken optimistically; the one
+  // that runs) and, for plans that have flat outputs, GDV_OPTFLAT = 0 (every output through the
+  // scan; compiled only if a batch ever raises NOTFLAT).
+  auto finish = [&](const std::string& tmpl, const char* optflat, std::string* name_out, std::string* src_out) {
+    std::string text = tmpl;
+    size_t p0 = text.find("GDV_OPTFLAT_VALUE");
+    text.replace(p0, strlen("GDV_OPTFLAT_VALUE"), optflat);
+    uint64_t h = Fnv1a(HashableSource(text) + LibraryTag());
+    char name[64];
+    snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+    size_t pos = text.find("GDV_KERNEL_NAME");
+    text.replace(pos, strlen("GDV_KERNEL_NAME"), name);
+    *name_out = name;
+    *src_out = text;
+  };
+  const std::string tmpl = s.str();
+  finish(tmpl, plan->has_flat_output ? "1" : "0", &plan->kernel_name, &plan->source);
+  if (plan->has_flat_output) finish(tmpl, "0", &plan->kernel_name_general, &plan->source_general);
+  plan->ir = plan->source;
+  return Status::OK();
+}
+
+}  // namespace
+
+Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan) {
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+  }
+  plan->kind = KernelKind::kProject;
+  plan->mode = mode;
+  plan->opts = opts;
+  CodeGen cg(schema, mode, opts);
+  WordAccumulators accs;
+  std::ostringstream after_loop, before_loop;
+  std::vector<std::string> strings;
+  int num_staged = 0;
+  const std::string st = opts.nontemporal ? "gdv_stnt" : "gdv_st";
+  for (auto& e : exprs) plan->has_varlen_output |= e->result().type.is_varlen();
+  for (size_t e = 0; e < exprs.size(); e++) {
+    Val v;
+    cg.Stmt("// @expr_" + std::to_string(e));
+    GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "", &v));
+    const DataType& t = exprs[e]->result().type;
+    plan->output_types.push_back(t);
+    strings.push_back(exprs[e]->ToString());
+    const std::string E = std::to_string(e);
+    if (t.is_varlen()) {
+      // The row's bytes are one view, or the pieces of a concat written back to back.  Views
+      // are kept per sub-tile (registers) until the tile's base offset is known; lengths are
+      // prefix-summed inside the wave on the DPP data path.
+      const std::string ok = cg.Tmp("bool", CodeGen::AndFull("live", cg.LaneValid(v)));
+      VarlenOut vo;
+      vo.e = static_cast<int>(e);
+      const int vidx = static_cast<int>(cg.varlen_outs_.size());
+      const bool flat_cand = v.pieces.empty() && v.col_slot >= 0 && !cg.selection();
+      const bool has_window = !flat_cand && num_staged < 3;  // LDS staging windows per wave
+      std::vector<std::pair<std::string, std::string>> pieces = v.pieces;
+      if (pieces.empty()) pieces.emplace_back(v.v, "");
+      std::string total;
+      std::vector<std::string> pv;
+      for (size_t q = 0; q < pieces.size(); q++) {
+        const std::string name = "pv" + E + "_" + std::to_string(q);
+        pv.push_back(name);
+        cg.Stmt("gdv_str " + name + " = " + pieces[q].first + ";");
+        cg.Stmt("if (!(" + CodeGen::AndFull(ok, pieces[q].second) + ")) " + name + ".len = 0;");
+        total += (q ? " + " : "") + name + ".len";
+      }
+      before_loop << "  gdv_int32 lc" << E << "[GDV_U] = {};  // where each row's bytes start inside the wave tile\n"
+                  << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n"
+                  << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM at dbase" << E << "\n"
+                  << "  gdv_int64 dbase" << E << " = 0;\n";
+      if (flat_cand) {
+        vo.flat_slot = v.col_slot;
+        vo.flat_map = v.col_map;
+        const std::string K = std::to_string(v.col_slot);
+        before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
+        // optimistic flat variant of the kernel (compile-time): the bytes are copied after the
+        // sweep and the offsets are the input's, rebased: nothing of this output is scanned
+        cg.Stmt("if (optflat) {");
+        cg.Stmt("  if (pass == 0) {");
+        cg.Stmt("    if (live) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
+        cg.Stmt("    fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+        cg.Stmt("  }");
+        cg.Stmt("} else {");
+      }
+      cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+      cg.Stmt("if (pass == 0) {");
+      cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
+      cg.Stmt("  lc" + E + "[0] = run" + E + " + inc - ln" + E + "_u;");
+      // 64 lengths below 2^25 cannot wrap the 32-bit scan; otherwise the total is taken on
+      // 16-bit halves and saturates (the host rejects outputs of 2 GiB or more)
+      cg.Stmt("  const gdv_uint32 t = __builtin_expect(__ballot(ln" + E + "_u >= (1 << 25)) != 0, 0) ? gdv_tile_total(ln" + E +
+              "_u) : (gdv_uint32)gdv_wave_last(inc);");
+      cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t));");
+      if (flat_cand) {
+        const std::string K = std::to_string(v.col_slot);
+        cg.Stmt("  fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+      }
+      if (has_window) {
+        vo.window = num_staged++;
+        before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
+        // stage while the view is at hand (rows that fall outside the window are skipped: the
+        // tile then takes the second, direct pass)
+        cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
+        for (auto& name : pv) {
+          cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
+                  " + at), " + name + ");");
+          cg.Stmt("  at += " + name + ".len;");
+        }
+      }
+      cg.Stmt("} else if (dir" + E + ") {");
+      cg.Stmt("  gdv_uint8* at = outd" + E + " + dbase" + E + " + lc" + E + "[0];");
+      for (auto& name : pv) {
+        cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");
+        cg.Stmt("  at += " + name + ".len;");
+      }
+      cg.Stmt("}");
+      if (flat_cand) cg.Stmt("}");
+      (void)vidx;
+      cg.varlen_outs_.push_back(vo);
+    } else if (t.id == kBool) {
+      std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
+      after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)");
+    } else {
+      cg.Stmt("GDV_OUT(" + E + ", (" + t.CType() + ")" + v.v + ");");
+    }
+    // validity word of the 64 rows of this sub-tile
+    std::string word;
+    if (cg.selection()) {
+      word = "__ballot(" + CodeGen::AndExpr("live", cg.LaneValid(v)) + ")";
+    } else {
+      word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
+      if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
+    }
+    after_loop << WordStore(accs.Get(cg, word), "A.out[" + E + "].valid");
+  }
+  // Loads in flight: aim for >= 8 KiB of input values per wave tile (64 lanes x GDV_U rows x
+  // input bytes/row), within a budget of 512 input bytes per lane.  Wide plans (C2: 32 B/row,
+  // ten outputs) stay at 4 — measured optimum, more sub-tiles cost occupancy — narrow plans
+  // (C1: 12 B/row) go to 16 (+3 % measured).
+  bool string_plan = plan->has_varlen_output;
+  for (size_t k = 0; k < cg.input_fields_.size(); k++)
+    string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
+  if (string_plan) {
+    // workgroup tile = 4 waves x 4 sub-tiles x 64 rows.  Sub-tiles cost registers, not code (the
+    // row loop is rolled): 8 were better while the kernel carried 130 VGPRs either way; with the
+    // branch-free range test and the compile-time flat variant 4 sub-tiles fit 95 VGPRs (5 waves
+    // per SIMD) and win: 1.70 vs 1.83 ms (profiles/r02_c5_tuning.txt)
+    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = 4;
+    if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
+  }
+  if (std::getenv("GDV_U") == nullptr) {
+    int in_bytes = 0;
+    bool any_varlen = false;
+    for (size_t k = 0; k < cg.input_fields_.size(); k++) {
+      const DataType& t = schema[cg.input_fields_[k]].type;
+      any_varlen |= t.is_varlen();
+      if (cg.needs_values_[k]) in_bytes += std::max(1, t.byte_width());
+    }
+    if (!any_varlen && in_bytes > 0) {
+      int u = 4;
+      while (u < 16 && 64 * u * in_bytes < 8192 && 2 * u * in_bytes <= 512) u <<= 1;
+      plan->opts.subtiles = u;
+    }
+  }
+  return Assemble(cg, plan, strings, accs, before_loop.str(), after_loop.str());
+}
+
+Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
+                  const CodegenOptions& opts, KernelPlan* plan) {
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
+  if (condition->root()->return_type().id != kBool)
+    return Status::ValidationError("Filter condition must be of type boolean");
+  plan->kind = KernelKind::kFilter;
+  plan->mode = SelectionMode::kNone;
+  plan->opts = opts;
+  CodeGen cg(schema, SelectionMode::kNone, opts);
+  WordAccumulators accs;
+  Val v;
+  cg.Stmt("// @expr_0 (filter condition)");
+  GDV_RETURN_NOT_OK(cg.Gen(*condition->root(), "", &v));
+  // a null predicate does not select the row
+  std::string pass = CodeGen::AndExpr(cg.LaneValid(v), v.v);
+  cg.Stmt("const gdv_uint64 fm = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
+  cg.Stmt("fcount += (gdv_uint32)__popcll(fm);");
+  std::string acc = accs.Get(cg, "fm");
+  // A predicate kernel keeps nothing but its input values live, so it can afford many more
+  // loads in flight per wave than a projection: measured on C3 (2 x int64, 10^9 rows) the
+  // predicate pass goes from 5.2 TB/s at GDV_U = 4 to 5.9 TB/s at 16 (profiles/r01_c3_sweep).
+  // Budget: <= 512 bytes of input values per lane, i.e. <= 128 VGPRs of loads.
+  if (std::getenv("GDV_U") == nullptr) {
+    int in_bytes = 0;
+    for (size_t k = 0; k < cg.input_fields_.size(); k++)
+      if (cg.needs_values_[k]) in_bytes += std::max(4, schema[cg.input_fields_[k]].type.byte_width());
+    int u = 16;
+    while (u > 4 && u * std::max(in_bytes, 1) > 512) u >>= 1;
+    plan->opts.subtiles = u;
+  }
+  std::ostringstream after;
+  // the match words are written once and read by the index-emission kernel much later: non-temporal
+  // (C3, same box: 2.74 / 2.99 ms plain vs 2.69 / 2.67 ms; validity words of projections measured
+  // the other way round — C2 4.90 vs 5.0-5.1 ms — and stay plain)
+  after << WordStore(acc, "A.mask", true);
+  // one selected-row count per wave tile feeds the offsets scan (gdv_kernels.hip)
+  after << "  if (lane == 0) A.counts[wbase / GDV_U] = fcount;\n";
+  bool string_plan = false;
+  for (size_t k = 0; k < cg.input_fields_.size(); k++)
+    string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
+  if (string_plan) {
+    // the index-emission kernel walks groups of 64 match words: sub-tiles stay a power of two
+    plan->opts.subtiles = 4;
+    if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    return AssembleStrings(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n", after.str());
+  }
+  return Assemble(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n",
+                  after.str());
+}
+
+}  // namespace gdv

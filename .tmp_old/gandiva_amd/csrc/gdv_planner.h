@@ -1,0 +1,98 @@
+// Planner: expression trees -> one fused HIP kernel per Projector / Filter.
+//
+// Replaces the reference's ExprValidator + ExprDecomposer + Annotator + LLVMGenerator
+// (SURVEY.md §2 rows 3, 4, 6).  The reference's central idea is kept: every expression is
+// split into a VALUE computation, evaluated for every row, and a VALIDITY computation that
+// for null-if-null functions is just the intersection of the input validity bitmaps.  What
+// changes is the execution shape: instead of one scalar row loop per expression, ALL
+// expressions of a Projector are fused into one kernel that reads every referenced column
+// once, and validity is merged per 64-row word in scalar registers.
+#pragma once
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "gdv_node.h"
+#include "gdv_registry.h"
+
+namespace gdv {
+
+enum class SelectionMode : int32_t { kNone = 0, kUInt16 = 1, kUInt32 = 2, kUInt64 = 3 };
+
+enum class KernelKind { kProject, kFilter };
+
+// Code-generation knobs (part of the cache key).  Defaults come from measurements on
+// MI355X; environment variables GDV_U / GDV_NT / GDV_WAVES override
+// them for sweeps.
+struct CodegenOptions {
+  int subtiles = 4;        // 64-row sub-tiles each wavefront handles per tile (loads in flight)
+  int waves = 4;           // wavefronts per workgroup
+  bool nontemporal = true; // non-temporal stores for output value buffers
+  bool nt_loads = true;    // non-temporal loads of input value buffers: every value is read
+                           // exactly once (+3 % on C2, +7 % on C1, neutral on C3; GDV_NTLOAD=0)
+  // validity / bool words through the scalar data path instead of one vector load per column +
+  // readlane: measured no gain on C2/C3 and a loss on C1/C4 (SGPR spills), profiles/r02_k1_k2_experiments.txt
+  bool scalar_bitmaps = false;
+  bool bitmaps_last = false;   // issue the bitmap-word loads behind the value loads (GDV_BITMAPS_LAST)
+  int waves_per_eu = 0;        // > 0: amdgpu_waves_per_eu(n, n) on fixed-width kernels (GDV_WPE): lets the compiler keep every load in flight
+  bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
+  static CodegenOptions FromEnv();
+  std::string Key() const;
+};
+
+// Byte layout of the single by-value kernel argument (struct gdv_args in the generated
+// source).  Host (gdv_engine.cc) and device agree on this through these offsets only.
+struct ArgLayout {
+  static constexpr int kHeaderBytes = 64;  // n, err, sel, mask, counts, aux0..2
+  static constexpr int kOffN = 0, kOffErr = 8, kOffSel = 16, kOffMask = 24, kOffCounts = 32,
+                       kOffAux0 = 40, kOffAux1 = 48, kOffAux2 = 56;
+  int n_in = 0, n_out = 0, n_lit = 0;
+  // per input slot: data ptr (8) | validity gdv_bitmap (24) | value-bits gdv_bitmap (24) | offsets ptr (8)
+  static constexpr int kInStride = 64;
+  // per output slot: data ptr (8) | validity ptr (8) | offsets ptr (8) | capacity (8)
+  static constexpr int kOutStride = 32;  // ... | byte capacity of a var-len data buffer (8)
+  int in_base() const { return kHeaderBytes; }
+  int out_base() const { return kHeaderBytes + std::max(n_in, 1) * kInStride; }
+  int lit_base() const { return out_base() + std::max(n_out, 1) * kOutStride; }
+  int total() const { return lit_base() + std::max(n_lit, 1) * 8; }
+};
+
+struct KernelPlan {
+  KernelKind kind = KernelKind::kProject;
+  SelectionMode mode = SelectionMode::kNone;
+  CodegenOptions opts;
+  std::string kernel_name;
+  std::string source;              // complete HIP translation unit (minus the library header)
+  std::string ir;                  // human-readable plan dump (DumpIR)
+  // plans with flat var-len outputs: the variant without the optimistic flat path (compiled on demand)
+  std::string kernel_name_general, source_general;
+  std::vector<int> input_fields;   // input slot -> index into the schema
+  std::vector<bool> input_needs_values;
+  std::vector<bool> input_needs_validity;
+  std::vector<DataType> output_types;  // one per expression (filter: none)
+  ArgLayout layout;
+  std::vector<uint64_t> literals;  // fixed-width literal values -> gdv_args::lit (kernel arguments)
+  std::string const_block;         // string literals, LIKE patterns, IN tables -> device memory (aux0)
+  bool can_raise = false;          // kernel may set error bits
+  // Some output is utf8/binary: single launch, workgroup 0 scans the tile totals (granules in
+  // `mask`, grand totals in `counts`); workers are workgroups 1.. (gdv_planner.cc, string plans)
+  bool has_varlen_output = false;
+  bool has_varlen_input = false;   // some expression reads utf8/binary bytes
+  bool string_skeleton = false;    // tile = workgroup (waves x subtiles x 64 rows), no grid-stride
+  int num_varlen_outputs = 0;
+  bool has_flat_output = false;    // some var-len output is an input column's (mapped) bytes
+  int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
+};
+
+// Validates every expression against the schema and the function registry, then emits the
+// fused kernel.  Errors: ExpressionValidationError for type / signature problems,
+// CodeGenError for constructs the HIP backend does not cover yet.
+Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* out);
+Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
+                  const CodegenOptions& opts, KernelPlan* out);
+
+Status ValidateExpression(const Schema& schema, const Expression& expr);
+
+}  // namespace gdv

@@ -1,0 +1,367 @@
+#include "gdv_runtime.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+
+namespace gdv {
+
+Runtime& Runtime::Get() {
+  // never destroyed: cached Projectors / Filters (process-wide LRUs) own pooled device blocks and
+  // hand them back during static destruction, in an order this singleton must outlive
+  static Runtime* rt = new Runtime;
+  return *rt;
+}
+
+void Runtime::Probe() {
+  if (probed_) return;
+  probed_ = true;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    has_device_ = false;
+    if (const char* a = std::getenv("GDV_ARCH")) arch_ = a;
+    return;
+  }
+  has_device_ = true;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  device_ = dev;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    num_cus_ = prop.multiProcessorCount;
+    std::string a = prop.gcnArchName;  // e.g. "gfx950:sramecc+:xnack-"
+    size_t colon = a.find(':');
+    arch_ = colon == std::string::npos ? a : a.substr(0, colon);
+  }
+}
+
+bool Runtime::has_device() {
+  std::lock_guard<std::mutex> g(mu_);
+  Probe();
+  return has_device_;
+}
+
+Status Runtime::EnsureDevice() {
+  if (!has_device())
+    return Status::ExecutionError(
+        "no HIP device available: gandiva_amd evaluates on the GPU only (there is no CPU "
+        "fallback)");
+  // One device per process (the deployment model: one process per GPU).  Code objects, the
+  // buffer pool and the all-ones word belong to the device that was current at first use.
+  // A thread that never chose a device starts on device 0: switch it to ours rather than run
+  // on the wrong GPU.
+  int dev = -1;
+  if (hipGetDevice(&dev) == hipSuccess && dev != device_) {
+    hipError_t e = hipSetDevice(device_);
+    if (e != hipSuccess)
+      return Status::ExecutionError("gandiva_amd is bound to HIP device " + std::to_string(device_) +
+                                    " (current at first use) and could not switch the calling thread to it: " +
+                                    hipGetErrorString(e));
+  }
+  return Status::OK();
+}
+
+int Runtime::num_cus() {
+  std::lock_guard<std::mutex> g(mu_);
+  Probe();
+  return num_cus_;
+}
+
+const std::string& Runtime::arch() {
+  std::lock_guard<std::mutex> g(mu_);
+  Probe();
+  return arch_;
+}
+
+static bool DirWritable(const std::string& d) {
+  mkdir(d.c_str(), 0755);
+  return access(d.c_str(), W_OK) == 0;
+}
+
+// A cache directory outside the installation is trusted only if it is ours and nobody else
+// can write to it: code objects found there are loaded and run against the caller's HBM.
+static bool PrivateDir(const std::string& d) {
+  mkdir(d.c_str(), 0700);
+  struct stat st;
+  if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) return false;
+  return access(d.c_str(), W_OK) == 0;
+}
+
+std::string Runtime::cache_dir() {
+  if (const char* e = std::getenv("GANDIVA_AMD_CACHE_DIR")) {
+    std::string d = e;
+    if (DirWritable(d)) return d;
+  }
+  // in-tree cache next to the shared library: travels with the repo snapshot
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&gdv_device_lib_src), &info) && info.dli_fname) {
+    std::string so = info.dli_fname;
+    size_t slash = so.rfind('/');
+    std::string d = (slash == std::string::npos ? std::string(".") : so.substr(0, slash)) +
+                    "/_kcache";
+    if (DirWritable(d)) return d;
+  }
+  // per-user cache: $XDG_CACHE_HOME or ~/.cache, created 0700 and verified; as a last
+  // resort a per-uid directory under /tmp with the same checks.  "" = no disk cache.
+  std::string base;
+  if (const char* x = std::getenv("XDG_CACHE_HOME")) base = x;
+  else if (const char* h = std::getenv("HOME")) base = std::string(h) + "/.cache";
+  if (!base.empty()) {
+    mkdir(base.c_str(), 0700);
+    std::string d = base + "/gandiva_amd_kcache";
+    if (PrivateDir(d)) return d;
+  }
+  std::string d = "/tmp/gandiva_amd_kcache_" + std::to_string(static_cast<long>(geteuid()));
+  if (PrivateDir(d)) return d;
+  return "";
+}
+
+static uint64_t Fnv(const char* s, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; i++) {
+    h ^= static_cast<unsigned char>(s[i]);
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+Status Runtime::CompileToCodeObject(const std::string& source, const std::string& kernel_name,
+                                    std::vector<char>* code, bool* from_cache,
+                                    bool ignore_cached) {
+  const std::string a = arch();
+  static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
+  char tag[40];
+  snprintf(tag, sizeof(tag), "%016llx", static_cast<unsigned long long>(lib_hash));
+  const std::string dir = cache_dir();
+  const std::string path = dir + "/" + kernel_name + "." + tag + "." + a + ".hsaco";
+  const bool use_disk = !dir.empty() && std::getenv("GDV_NO_DISK_CACHE") == nullptr;
+  if (use_disk && ignore_cached) unlink(path.c_str());  // stale or corrupt: recompiled below
+  if (use_disk && !ignore_cached) {
+    std::ifstream f(path, std::ios::binary);
+    if (f) {
+      code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+      if (!code->empty()) {
+        if (from_cache) *from_cache = true;
+        return Status::OK();
+      }
+    }
+  }
+  if (from_cache) *from_cache = false;
+  if (std::getenv("GDV_DUMP_SOURCE")) {
+    std::ofstream f((dir.empty() ? std::string("/tmp") : dir) + "/" + kernel_name + ".hip");
+    f << source;
+  }
+
+  // one compilation at a time: they are rare (cached in memory and on disk) and comgr's
+  // temporary-file handling has no need to be exercised concurrently
+  static std::mutex compile_mu;
+  std::lock_guard<std::mutex> compile_guard(compile_mu);
+  hiprtcProgram prog;
+  const char* hdr_src[] = {gdv_device_lib_src};
+  const char* hdr_name[] = {"gdv_device_lib.hpp"};
+  if (hiprtcCreateProgram(&prog, source.c_str(), (kernel_name + ".hip").c_str(), 1, hdr_src,
+                          hdr_name) != HIPRTC_SUCCESS)
+    return Status::CodeGenError("hiprtcCreateProgram failed");
+  std::string arch_opt = "--offload-arch=" + a;
+  // -ffp-contract=off is part of the semantics (bit-exact vs separate mul/add)
+  std::vector<const char*> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off",
+                                   "-fhip-fp32-correctly-rounded-divide-sqrt"};
+  // GDV_RTC_OPT: one extra compiler option for experiments (e.g. -DGDV_COLD= inlines the cold
+  // paths); not part of the cache key, so combine it with GDV_NO_DISK_CACHE=1
+  if (const char* extra = std::getenv("GDV_RTC_OPT")) opts.push_back(extra);
+  hiprtcResult r = hiprtcCompileProgram(prog, static_cast<int>(opts.size()), opts.data());
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    return Status::CodeGenError("kernel compilation failed:\n" + log);
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code->resize(n);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  if (use_disk) {
+    std::string tmp = path + ".tmp." + std::to_string(getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) {
+      f.write(code->data(), static_cast<std::streamsize>(code->size()));
+      f.close();
+      rename(tmp.c_str(), path.c_str());
+    }
+  }
+  return Status::OK();
+}
+
+Status Runtime::GetKernel(const std::string& source, const std::string& kernel_name,
+                          const CompiledKernel** out) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = kernels_.find(kernel_name);
+    if (it != kernels_.end()) {
+      *out = it->second.get();
+      return Status::OK();
+    }
+  }
+  std::vector<char> code;
+  bool from_cache = false;
+  GDV_RETURN_NOT_OK(CompileToCodeObject(source, kernel_name, &code, &from_cache));
+  auto k = std::make_unique<CompiledKernel>();
+  k->name = kernel_name;
+  hipError_t le = hipModuleLoadData(&k->module, code.data());
+  if (le == hipSuccess) le = hipModuleGetFunction(&k->function, k->module, kernel_name.c_str());
+  if (le != hipSuccess && from_cache) {
+    // a cached code object that does not load (truncated, built by another toolchain): drop
+    // the file and compile afresh instead of failing every Make from now on
+    (void)hipGetLastError();
+    if (k->module != nullptr) (void)hipModuleUnload(k->module);
+    k->module = nullptr;
+    GDV_RETURN_NOT_OK(CompileToCodeObject(source, kernel_name, &code, nullptr, true));
+    le = hipModuleLoadData(&k->module, code.data());
+    if (le == hipSuccess) le = hipModuleGetFunction(&k->function, k->module, kernel_name.c_str());
+  }
+  if (le != hipSuccess)
+    return Status::ExecutionError(std::string("loading the compiled kernel failed: ") + hipGetErrorString(le));
+  std::lock_guard<std::mutex> g(mu_);
+  auto& slot = kernels_[kernel_name];
+  if (!slot) slot = std::move(k);
+  *out = slot.get();
+  return Status::OK();
+}
+
+static size_t RoundSize(size_t b) {
+  if (b < 256) return 256;
+  if (b < (1u << 20)) {
+    size_t p = 256;
+    while (p < b) p <<= 1;
+    return p;
+  }
+  const size_t g = 2u << 20;
+  return (b + g - 1) / g * g;
+}
+
+Status Runtime::Alloc(size_t bytes, void** ptr) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  size_t sz = RoundSize(bytes);
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = free_blocks_.find(sz);
+    if (it != free_blocks_.end()) {
+      *ptr = it->second;
+      free_blocks_.erase(it);
+      cached_bytes_ -= sz;
+      live_blocks_[*ptr] = sz;
+      return Status::OK();
+    }
+  }
+  hipError_t e = hipMalloc(ptr, sz);
+  if (e != hipSuccess) {
+    TrimPool();
+    e = hipMalloc(ptr, sz);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::OutOfMemory("hipMalloc of " + std::to_string(sz) + " bytes failed");
+  }
+  std::lock_guard<std::mutex> g(mu_);
+  live_blocks_[*ptr] = sz;
+  return Status::OK();
+}
+
+Status Runtime::AcquirePinned(char** p) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!pinned_free_.empty()) {
+      *p = pinned_free_.back();
+      pinned_free_.pop_back();
+      return Status::OK();
+    }
+  }
+  void* q = nullptr;
+  if (hipHostMalloc(&q, kPinnedBlock, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::OutOfMemory("hipHostMalloc of the pinned staging block failed");
+  }
+  *p = static_cast<char*>(q);
+  return Status::OK();
+}
+
+void Runtime::ReleasePinned(char* p) {
+  if (p == nullptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (pinned_free_.size() < 8) {
+    pinned_free_.push_back(p);
+  } else {
+    (void)hipHostFree(p);
+  }
+}
+
+void Runtime::Free(void* ptr) {
+  if (!ptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  auto it = live_blocks_.find(ptr);
+  if (it == live_blocks_.end()) return;
+  size_t sz = it->second;
+  live_blocks_.erase(it);
+  // keep at most kPoolCapBytes of idle blocks (staging buffers of the host path can be tens
+  // of GB); beyond that, blocks go straight back to the driver
+  static const size_t cap = [] {
+    const char* e = std::getenv("GDV_POOL_CAP_MB");
+    return (e ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(16384)) << 20;
+  }();
+  if (cached_bytes_ + sz > cap) {
+    (void)hipFree(ptr);
+    return;
+  }
+  free_blocks_.emplace(sz, ptr);
+  cached_bytes_ += sz;
+}
+
+void Runtime::TrimPool() {
+  std::multimap<size_t, void*> blocks;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    blocks.swap(free_blocks_);
+    cached_bytes_ = 0;
+  }
+  for (auto& b : blocks) (void)hipFree(b.second);
+}
+
+Status Runtime::AllOnesWord(const uint64_t** ptr) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  std::lock_guard<std::mutex> g(mu_);
+  if (all_ones_ == nullptr) {
+    void* p = nullptr;
+    GDV_HIP_RETURN_NOT_OK(hipMalloc(&p, 256));
+    GDV_HIP_RETURN_NOT_OK(hipMemset(p, 0xff, 256));
+    all_ones_ = static_cast<uint64_t*>(p);
+  }
+  *ptr = all_ones_;
+  return Status::OK();
+}
+
+Status Runtime::Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
+                       size_t arg_bytes, hipStream_t stream) {
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
+                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END};
+  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(k.function, static_cast<unsigned>(grid), 1, 1,
+                                              static_cast<unsigned>(block), 1, 1, 0, stream,
+                                              nullptr, config));
+  return Status::OK();
+}
+
+}  // namespace gdv

@@ -1,0 +1,356 @@
+/*
+ * gandiva_amd — C ABI of the MI355X-native Projector / Filter evaluator.
+ *
+ * This is the drop-in boundary for the one hot path this library replaces:
+ * gandiva::Projector::Evaluate / gandiva::Filter::Evaluate over Arrow record batches
+ * (SURVEY.md §8).  Everything is plain C: opaque handles, pointers, sizes.  No Arrow C++,
+ * torch or HIP types appear in a signature (a stream is passed as `void*`).
+ *
+ * What each group replaces in the reference (the mounted reference holds no source —
+ * SURVEY.md §0 — so citations are to the reference lineage's binding spec that IS present:
+ * PA = pyarrow/includes/libgandiva.pxd, and to the JNI boundary recalled in SURVEY.md §2
+ * row 18):
+ *
+ *   gdv_node_* / gdv_expression_*   gandiva::TreeExprBuilder::Make*           PA:110-212
+ *                                   (over JNI these trees arrive as protobuf bytes; a C
+ *                                   caller builds them with these constructors instead)
+ *   gdv_projector_make              gandiva::Projector::Make                  PA:230-240
+ *                                   JNI buildProjector(schema, exprs, selMode, configId)
+ *   gdv_projector_evaluate          gandiva::Projector::Evaluate              PA:218-226
+ *                                   JNI evaluateProjector(moduleId, numRows, bufAddrs[],
+ *                                   bufSizes[], selVecType, selVecRows, selVecAddr, …,
+ *                                   outAddrs[], outSizes[]) — same raw-address convention
+ *   gdv_projector_dump_ir           gandiva::Projector::DumpIR                PA:228
+ *   gdv_filter_make                 gandiva::Filter::Make                     PA:252-256
+ *   gdv_filter_evaluate             gandiva::Filter::Evaluate +
+ *                                   SelectionVector::MakeInt16/32/64          PA:246-248, 58-71
+ *                                   JNI evaluateFilter(moduleId, numRows, bufAddrs[],
+ *                                   bufSizes[], selVecType, outAddr, outSize) -> count
+ *   gdv_registry_*                  gandiva::GetRegisteredFunctionSignatures  PA:274-277
+ *   gdv_config_t                    gandiva::Configuration                    PA:279-298
+ *   status codes                    arrow::StatusCode 40/41/42  pyarrow/include/arrow/status.h:97-100
+ *
+ * Memory domains.  Buffers follow the Arrow columnar layout (validity bitmap LSB-first,
+ * values, int32 offsets for var-len).  `GDV_MEM_DEVICE` buffers are resident in the HBM of
+ * the current HIP device and are used in place (zero-copy; this is the measured path);
+ * `GDV_MEM_HOST` buffers are staged through HBM by the library (correctness path).
+ * There is no CPU evaluation path: without a HIP device every evaluate call fails with
+ * GDV_EXECUTION_ERROR.  The library binds to the HIP device that is current at its first
+ * use (one device per process, the one-process-per-GPU deployment model); threads calling
+ * in with another current device are switched to it.
+ *
+ * Threading: all functions may be called concurrently; evaluate is re-entrant on one
+ * handle (per-call state only), as the reference's `nogil` bindings require (PA:27-279).
+ *
+ * Errors: functions returning `int` return a gdv_status_code; the message of the last
+ * failure on the calling thread is available from gdv_last_error().  Constructors return
+ * NULL on failure.
+ */
+#ifndef GANDIVA_AMD_H_
+#define GANDIVA_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Numerically identical to arrow::StatusCode. */
+typedef enum {
+  GDV_OK = 0,
+  GDV_OUT_OF_MEMORY = 1,
+  GDV_INVALID = 4,
+  GDV_NOT_IMPLEMENTED = 10,
+  GDV_CODE_GEN_ERROR = 40,
+  GDV_EXPRESSION_VALIDATION_ERROR = 41,
+  GDV_EXECUTION_ERROR = 42
+} gdv_status_code;
+
+/* Numerically identical to arrow::Type::type (pyarrow/include/arrow/type_fwd.h:330-402). */
+typedef enum {
+  GDV_TYPE_BOOL = 1,
+  GDV_TYPE_UINT8 = 2,
+  GDV_TYPE_INT8 = 3,
+  GDV_TYPE_UINT16 = 4,
+  GDV_TYPE_INT16 = 5,
+  GDV_TYPE_UINT32 = 6,
+  GDV_TYPE_INT32 = 7,
+  GDV_TYPE_UINT64 = 8,
+  GDV_TYPE_INT64 = 9,
+  GDV_TYPE_FLOAT = 11,
+  GDV_TYPE_DOUBLE = 12,
+  GDV_TYPE_STRING = 13,
+  GDV_TYPE_BINARY = 14,
+  GDV_TYPE_DATE32 = 16,
+  GDV_TYPE_DATE64 = 17,
+  GDV_TYPE_TIMESTAMP = 18,
+  GDV_TYPE_TIME32 = 19,
+  GDV_TYPE_TIME64 = 20,
+  GDV_TYPE_DECIMAL128 = 23
+} gdv_type_id;
+
+/* precision: decimal precision, or arrow::TimeUnit (0 s, 1 ms, 2 us, 3 ns) for
+ * time32/time64/timestamp; scale: decimal scale. */
+typedef struct {
+  int32_t id;
+  int32_t precision;
+  int32_t scale;
+} gdv_type_t;
+
+/* gandiva::SelectionVector::Mode (PA:48-56). */
+typedef enum {
+  GDV_SEL_NONE = 0,
+  GDV_SEL_UINT16 = 1,
+  GDV_SEL_UINT32 = 2,
+  GDV_SEL_UINT64 = 3
+} gdv_selection_mode;
+
+typedef enum { GDV_MEM_HOST = 0, GDV_MEM_DEVICE = 1 } gdv_mem_kind;
+
+/* gdv_projector_evaluate flags */
+#define GDV_EVAL_ASYNC 1u /* device buffers: enqueue on `stream` and return without waiting
+                           * (plans that can raise, or that produce utf8/binary, wait anyway:
+                           * the error word / byte totals are read back) */
+
+typedef struct gdv_schema gdv_schema_t;
+typedef struct gdv_node gdv_node_t;
+typedef struct gdv_expression gdv_expression_t; /* also used for conditions */
+typedef struct gdv_projector gdv_projector_t;
+typedef struct gdv_filter gdv_filter_t;
+
+/* gandiva::Configuration (PA:279-298). */
+typedef struct {
+  int32_t optimize;
+  int32_t dump_ir;
+} gdv_config_t;
+
+/* One input column = one Arrow array as raw buffers. */
+typedef struct {
+  const void* validity; /* NULL: no nulls */
+  int64_t validity_size;
+  const void* data; /* fixed-width values | bool bits | var-len bytes */
+  int64_t data_size;
+  const void* offsets; /* var-len only: int32 offsets */
+  int64_t offsets_size;
+  int64_t offset; /* Arrow array offset in rows (pyarrow/include/arrow/array/data.h:88-90) */
+} gdv_column_t;
+
+/* One output column, allocated by the caller (as the JNI caller allocates outAddrs[]).
+ * Required sizes for `rows` output rows: gdv_projector_output_sizes(). */
+typedef struct {
+  void* validity;
+  int64_t validity_size;
+  void* data;        /* fixed-width values | bool bits | var-len bytes */
+  int64_t data_size; /* var-len: capacity in; bytes produced (or needed, on GDV_INVALID) out */
+  void* offsets;     /* var-len outputs only: (rows + 1) int32 offsets; NULL otherwise */
+  int64_t offsets_size;
+} gdv_out_column_t;
+
+typedef struct {
+  int32_t mode;        /* gdv_selection_mode */
+  const void* indices; /* uint16/uint32/uint64 row positions */
+  int64_t num_slots;
+} gdv_selection_t;
+
+/* ---- errors, version ------------------------------------------------------------- */
+const char* gdv_last_error(void);
+const char* gdv_version(void);
+void gdv_free_string(char* s);
+
+/* ---- schema ---------------------------------------------------------------------- */
+gdv_schema_t* gdv_schema_new(void);
+int gdv_schema_add_field(gdv_schema_t* schema, const char* name, gdv_type_t type, int nullable);
+int gdv_schema_num_fields(const gdv_schema_t* schema);
+void gdv_schema_free(gdv_schema_t* schema);
+
+/* ---- expression trees: TreeExprBuilder (PA:110-212) ------------------------------ */
+/* MakeField */
+gdv_node_t* gdv_node_field(const char* name, gdv_type_t type);
+/* MakeLiteral for fixed-width types: `value` points at the little-endian image of the
+ * value (1/2/4/8/16 bytes by type; bool: one byte); MakeNull when is_null != 0. */
+gdv_node_t* gdv_node_literal(gdv_type_t type, const void* value, int is_null);
+/* MakeStringLiteral / MakeBinaryLiteral */
+gdv_node_t* gdv_node_literal_bytes(gdv_type_t type, const char* data, int64_t len, int is_null);
+/* MakeFunction(name, children, return_type) */
+gdv_node_t* gdv_node_function(const char* name, gdv_node_t* const* children, int num_children,
+                              gdv_type_t return_type);
+/* MakeIf(condition, then, else, return_type) */
+gdv_node_t* gdv_node_if(gdv_node_t* condition, gdv_node_t* then_node, gdv_node_t* else_node,
+                        gdv_type_t return_type);
+/* MakeAnd / MakeOr */
+gdv_node_t* gdv_node_and(gdv_node_t* const* children, int num_children);
+gdv_node_t* gdv_node_or(gdv_node_t* const* children, int num_children);
+/* MakeInExpression{Int32,Int64,Date32,Date64,Time32,Time64,TimeStamp}: `values` holds
+ * num_values elements of the type's width. */
+gdv_node_t* gdv_node_in(gdv_node_t* node, gdv_type_t value_type, const void* values,
+                        int num_values);
+/* MakeInExpression{String,Binary} */
+gdv_node_t* gdv_node_in_bytes(gdv_node_t* node, gdv_type_t value_type, const char* const* values,
+                              const int64_t* lengths, int num_values);
+/* Node::ToString / Node::return_type (PA:29-31) */
+char* gdv_node_to_string(const gdv_node_t* node);
+gdv_type_t gdv_node_return_type(const gdv_node_t* node);
+/* Handles are reference-counted views of immutable shared trees: freeing a child handle
+ * after it was used to build a parent is fine. */
+void gdv_node_free(gdv_node_t* node);
+
+/* MakeExpression(root, result_field) / MakeCondition(root) */
+gdv_expression_t* gdv_expression_new(gdv_node_t* root, const char* result_name,
+                                     gdv_type_t result_type);
+gdv_expression_t* gdv_condition_new(gdv_node_t* root);
+char* gdv_expression_to_string(const gdv_expression_t* expr);
+gdv_type_t gdv_expression_result_type(const gdv_expression_t* expr);
+void gdv_expression_free(gdv_expression_t* expr);
+
+/* ---- Projector -------------------------------------------------------------------- */
+int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs,
+                       int selection_mode, const gdv_config_t* config /* NULL = default */,
+                       gdv_projector_t** out);
+int gdv_projector_num_outputs(const gdv_projector_t* p);
+gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i);
+/* Bytes the caller must provide for output i with `rows` output rows.  Device buffers
+ * are written in whole 64-bit bitmap words: validity (and bool data) = 8 * ceil(rows/64). */
+int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, int mem_kind,
+                               int64_t* validity_bytes, int64_t* data_bytes);
+/* var-len (utf8/binary) outputs: offsets need (rows + 1) * 4 bytes; *data_bytes above is
+ * reported as 0 — the byte total is only known once the rows have been evaluated: call evaluate
+ * with any capacity; the kernel never writes past it, and when it is too small the call fails with
+ * GDV_INVALID and data_size is updated to the bytes needed (the reference's JNI path grows its buffer through an expander callback
+ * for the same reason). */
+/* cols: one entry per schema field, in schema order.  sel: NULL, or the selection vector
+ * (mode must equal the mode given to make).  Output row count = sel ? sel->num_slots
+ * : num_rows.  stream: hipStream_t as void* (NULL = default stream). */
+int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
+                           int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
+                           int num_outs, int mem_kind, void* stream, uint32_t flags);
+char* gdv_projector_dump_ir(const gdv_projector_t* p);
+void gdv_projector_free(gdv_projector_t* p);
+
+/* ---- Filter ----------------------------------------------------------------------- */
+int gdv_filter_make(const gdv_schema_t* schema, gdv_expression_t* condition,
+                    const gdv_config_t* config, gdv_filter_t** out);
+/* out_indices: caller-allocated selection vector of `max_slots` (>= num_rows) elements of
+ * the width `selection_mode` implies; *num_selected receives the slot count.  Indices are
+ * ascending.  Rows whose predicate is null are not selected. */
+int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols,
+                        int num_cols, int selection_mode, void* out_indices, int64_t max_slots,
+                        int64_t* num_selected, int mem_kind, void* stream);
+char* gdv_filter_dump_ir(const gdv_filter_t* f);
+void gdv_filter_free(gdv_filter_t* f);
+
+/* ---- function registry ------------------------------------------------------------ */
+int gdv_registry_size(void);
+/* name: borrowed pointer valid for the process lifetime; params: up to max_params entries
+ * are written, *num_params receives the real count. */
+int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_type_t* params,
+                     int max_params, int* num_params);
+
+/* ---- device helpers (for hosts without their own HIP binding, e.g. a JNI caller) --- */
+int gdv_device_count(void);
+int gdv_device_num_cus(void);
+const char* gdv_device_arch(void);
+int gdv_device_alloc(int64_t bytes, void** ptr);
+int gdv_device_free(void* ptr);
+int gdv_memcpy_h2d(void* dst_device, const void* src_host, int64_t bytes);
+int gdv_memcpy_d2h(void* dst_host, const void* src_device, int64_t bytes);
+int gdv_device_synchronize(void);
+
+/* ---- JNI-shaped flat entry points --------------------------------- */
+/* What the reference's JNI layer receives from Java (JniWrapper.evaluateProjector /
+ * evaluateFilter: long[] bufAddrs, long[] bufSizes, long[] outAddrs, long[] outSizes) and
+ * would forward unchanged: every field's buffers flattened in schema order — validity,
+ * then offsets (utf8/binary only), then data — as raw addresses and byte sizes; outputs the
+ * same way, one group per expression.  Array offsets are 0 (Java's vectors have none).
+ * sel_mode/sel_addr/sel_slots describe an optional selection vector (GDV_SEL_NONE: none).
+ * A var-len output whose data capacity is too small fails with GDV_INVALID and
+ * out_sizes[data slot] is updated to the bytes needed (the JNI expander callback's role). */
+int gdv_projector_evaluate_flat(const gdv_projector_t* p, int64_t num_rows, const int64_t* buf_addrs,
+                                const int64_t* buf_sizes, int num_bufs, int sel_mode,
+                                int64_t sel_addr, int64_t sel_slots, const int64_t* out_addrs,
+                                int64_t* out_sizes, int num_out_bufs, int mem_kind);
+int gdv_filter_evaluate_flat(const gdv_filter_t* f, int64_t num_rows, const int64_t* buf_addrs,
+                             const int64_t* buf_sizes, int num_bufs, int sel_mode, int64_t out_addr,
+                             int64_t out_size_bytes, int64_t* num_selected, int mem_kind);
+
+/* ---- Arrow C Device Data Interface (the step BEFORE the path: other ROCm producers) --- */
+/* The ABI-stable structs of the Arrow C data / C device data interfaces
+ * (pyarrow/include/arrow/c/abi.h).  Declared here under the spec's own include guards so
+ * this header can be used with or without Arrow's. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+#ifndef ARROW_C_DEVICE_DATA_INTERFACE
+#define ARROW_C_DEVICE_DATA_INTERFACE
+typedef int32_t ArrowDeviceType;
+#define ARROW_DEVICE_CPU 1
+#define ARROW_DEVICE_ROCM 10
+#define ARROW_DEVICE_ROCM_HOST 11
+struct ArrowDeviceArray {
+  struct ArrowArray array;
+  int64_t device_id;
+  ArrowDeviceType device_type;
+  void* sync_event; /* hipEvent_t* for ROCM arrays, or NULL */
+  int64_t reserved[3];
+};
+#endif
+/* Evaluate over a record batch handed over as an ArrowDeviceArray: a struct array with one
+ * child per schema field (what arrow::ExportDeviceRecordBatch / pyarrow's
+ * RecordBatch._export_to_c_device produce).  device_type ARROW_DEVICE_ROCM is used in
+ * place (zero-copy; outputs must be HBM buffers); ARROW_DEVICE_CPU / ROCM_HOST take the
+ * staged host path.  A non-NULL sync_event is waited for on `stream` before the kernel.
+ * The batch is borrowed: it is NOT released by these calls. */
+int gdv_projector_evaluate_device_array(const gdv_projector_t* p,
+                                        const struct ArrowDeviceArray* batch,
+                                        const gdv_selection_t* sel, gdv_out_column_t* outs,
+                                        int num_outs, void* stream, uint32_t flags);
+int gdv_filter_evaluate_device_array(const gdv_filter_t* f, const struct ArrowDeviceArray* batch,
+                                     int selection_mode, void* out_indices, int64_t max_slots,
+                                     int64_t* num_selected, void* stream);
+
+/* The step AFTER the path: evaluate and hand the results on as an ArrowDeviceArray (a struct
+ * array, one child per expression; what arrow::ImportDeviceRecordBatch /
+ * pyarrow.RecordBatch._import_from_c_device consume).  The library allocates the result
+ * buffers: in HBM when `batch` is ARROW_DEVICE_ROCM (out->device_type ARROW_DEVICE_ROCM,
+ * out->sync_event = hipEvent_t* recorded on `stream` after the last kernel), in 64-byte
+ * aligned host memory (ARROW_DEVICE_CPU) otherwise.  `out_schema` (may be NULL) receives the
+ * matching ArrowSchema (field names = the expressions' result fields).  Both are owned by
+ * the consumer and freed through their release callbacks; children may be moved out and
+ * released independently (buffers are reference-counted). */
+int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDeviceArray* batch,
+                                  const gdv_selection_t* sel, void* stream,
+                                  struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
+/* ---- build support ----------------------------------------------------------------- */
+/* Plan + compile to a gfx950 code object without a device; fills the on-disk kernel cache. */
+int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
+                             int num_exprs, int selection_mode);
+int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* condition);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANDIVA_AMD_H_ */
