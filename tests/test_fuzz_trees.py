@@ -271,3 +271,64 @@ def test_fuzzed_string_trees_match_oracle(seed):
         got_sel = gandiva.make_projector(batch.schema, exprs, None, "UINT32").evaluate(batch, sv)
         for g, w, e in zip(got_sel, want, exprs):
             assert_bit_exact(g, oracle.take_rows(w, sel), f"seed {seed} (selection): {e}")
+
+
+# ---------------------------------------------------------------- trees with materialised values
+# (round 2) reverse / replace / lpad / rpad / castVARCHAR(integer) / concat at ANY depth: inside a
+# kernel they are values only the output copy can read, so a function over one makes the plan
+# two-stage (a first kernel writes a temporary column) — nested ones several stages deep.
+
+class TailTreeGen(StringTreeGen):
+    def string(self, depth):
+        b, r = self.b, self.rng
+        if depth > 0 and r.random() < 0.45:
+            roll = r.random()
+            if roll < 0.2:
+                return b.make_function("reverse", [self.string(depth - 1)], STR)
+            if roll < 0.4:
+                frm, to = self.pick([("spark", "flink"), ("a", ""), ("ar", "ARRR"), ("é", "e"), (" ", "__"), ("", "z")])
+                return b.make_function("replace", [self.string(depth - 1), b.make_literal(frm, STR), b.make_literal(to, STR)], STR)
+            if roll < 0.6:
+                args = [self.string(depth - 1), b.make_literal(int(r.integers(-2, 14)), I32)]
+                if r.random() < 0.7:
+                    args.append(b.make_literal(self.pick(["*", "xy", "é-", ""]), STR))
+                return b.make_function(self.pick(["lpad", "rpad"]), args, STR)
+            if roll < 0.8:
+                return b.make_function("castVARCHAR", [self.f["k"], b.make_literal(int(r.integers(0, 4)), I64)], STR)
+            return b.make_function(self.pick(["concat", "concatOperator"]), [self.string(depth - 1), self.string(depth - 1)], STR)
+        return super().string(depth)
+
+
+def _tail_expressions(seed):
+    g = TailTreeGen(_string_batch(0, 1).schema, 900 + seed)
+    exprs = [g.b.make_expression(g.string(3), pa.field("s0", STR)),
+             g.b.make_expression(g.boolean(3), pa.field("b0", BOOL)),
+             g.b.make_expression(g.string(3), pa.field("s1", STR)),
+             g.b.make_expression(g.integer(3), pa.field("i0", I32)),
+             g.b.make_expression(g.b.make_function("upper", [g.string(2)], STR), pa.field("u0", STR))]
+    return exprs, g.b.make_condition(g.boolean(3))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_generated_trees_with_materialised_values_compile(seed):
+    from gandiva_amd import _capi, gandiva as gg
+    exprs, cond = _tail_expressions(seed)
+    lib = _capi.lib()
+    sh = gg._make_schema(_string_batch(0, 1).schema)
+    arr = (C.c_void_p * len(exprs))(*[e._h for e in exprs])
+    assert lib.gdv_precompile_projector(sh, arr, len(exprs), 0) == 0, _capi.last_error()
+    assert lib.gdv_precompile_filter(sh, cond._h) == 0, _capi.last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzzed_trees_with_materialised_values_match_oracle(seed):
+    exprs, cond = _tail_expressions(seed)
+    n = [1, 64, 257, 1000, 4097, 12011][seed % 6]
+    batch = _string_batch(seed, n)
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
+        g.validate(full=True)
+        assert_bit_exact(g, w, f"seed {seed}: {e}")
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, pa.default_memory_pool(), "int32").to_array()
+    assert sel.equals(oracle.filter_indices(cond, batch, "int32")), f"seed {seed}: {cond}"

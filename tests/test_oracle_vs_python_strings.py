@@ -113,6 +113,20 @@ def py_eval(node, row):
         return a[0].startswith(a[1])
     if f == "ends_with":
         return a[0].endswith(a[1])
+    if f == "reverse":
+        return a[0][::-1]
+    if f == "replace":
+        return a[0].replace(a[1], a[2]) if a[1] else a[0]
+    if f in ("lpad", "rpad"):
+        v, n, fill = a[0], a[1], (a[2] if len(a) == 3 else " ")
+        if v == "" or n <= 0:
+            return ""
+        if len(v) >= n or fill == "":
+            return v[:n] if len(v) > n else v
+        pad = (fill * n)[:n - len(v)]
+        return v + pad if f == "rpad" else pad + v
+    if f == "castVARCHAR":
+        return str(a[0])[:a[1]]
     if f == "octet_length":
         return len(a[0].encode())
     if f == "char_length":
@@ -125,6 +139,20 @@ def py_eval(node, row):
 @pytest.mark.parametrize("seed", range(40))
 def test_oracle_string_trees_match_plain_python(seed):
     exprs, cond = F._string_expressions(100 + seed)
+    batch = F._string_batch(seed, 300)
+    rows = [dict(zip(batch.schema.names, vals)) for vals in zip(*[c.to_pylist() for c in batch.columns])]
+    got = oracle.project(exprs, batch)
+    for g, e in zip(got, exprs):
+        want = [py_eval(e.root(), r) for r in rows]
+        assert g.to_pylist() == want, f"seed {seed}: {e}"
+    sel = oracle.filter_indices(cond, batch, "int32").to_pylist()
+    assert sel == [i for i, r in enumerate(rows) if py_eval(cond.root(), r) is True], f"seed {seed}: {cond}"
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_oracle_trees_with_materialised_values_match_plain_python(seed):
+    """reverse / replace / lpad / rpad / castVARCHAR(integer) / concat nested at any depth."""
+    exprs, cond = F._tail_expressions(100 + seed)
     batch = F._string_batch(seed, 300)
     rows = [dict(zip(batch.schema.names, vals)) for vals in zip(*[c.to_pylist() for c in batch.columns])]
     got = oracle.project(exprs, batch)
