@@ -309,7 +309,7 @@ def _tail_expressions(seed):
     return exprs, g.b.make_condition(g.boolean(3))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_generated_trees_with_materialised_values_compile(seed):
     from gandiva_amd import _capi, gandiva as gg
     exprs, cond = _tail_expressions(seed)
@@ -321,7 +321,7 @@ def test_generated_trees_with_materialised_values_compile(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_fuzzed_trees_with_materialised_values_match_oracle(seed):
     exprs, cond = _tail_expressions(seed)
     n = [1, 64, 257, 1000, 4097, 12011][seed % 6]
