@@ -26,6 +26,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_SCALAR_BITMAPS")) o.scalar_bitmaps = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_EARLY_POST")) o.early_post = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_BITMAPS_LAST")) o.bitmaps_last = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_WPE")) o.waves_per_eu = std::max(0, std::min(8, atoi(s)));
   return o;
@@ -33,7 +34,7 @@ CodegenOptions CodegenOptions::FromEnv() {
 
 std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
-         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + "e" + std::to_string(waves_per_eu);
+         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + (early_post ? "ep" : "") + "e" + std::to_string(waves_per_eu);
 }
 
 // ------------------------------------------------------------------ validation
@@ -1236,10 +1237,12 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   s << "#define GDV_NV " << nv << "\n#define GDV_NG " << ng << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
     << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
+    << (plan->opts.early_post && nv > 0 ? "#define GDV_NSTAGE_USED " + std::to_string(nstage) + "\n" : std::string())
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
     << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
-    << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+    << "#define GDV_OUT(e, v) if (live" << (plan->opts.early_post && nv > 0 ? " && pass == 0" : "") << ") "
+    << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
 
   s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
     << "                      const int wave, gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint32 (*lds_tot)[GDV_NV > 0 ? GDV_NV : 1],\n"
@@ -1419,7 +1422,20 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
   for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
   s << decls_before_loop;
-  if (nv > 0)
+  const bool early = plan->opts.early_post && nv > 0;
+  if (early)
+    s << "  bool need_direct = false;\n"
+      << "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n"
+      << "  gdv_uint64* const lb_agg = A.mask;\n"
+      << "  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n"
+      << "  (void)lb_agg; (void)lb_pre;\n"
+      << "  // pass 0: lengths -> tile totals posted.  pass 1: output bytes staged in LDS while the scanner\n"
+      << "  // resolves the tile's prefix, then offsets + flush.  pass 2 (rare): rows of outputs whose bytes\n"
+      << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
+      << "  for (int pass = 0; pass < 3; pass++) {\n"
+      << "  if (pass == 2 && !need_direct) break;\n"
+      << "  if (pass != 1 || GDV_NSTAGE_USED > 0) {\n";
+  else if (nv > 0)
     s << "  bool need_direct = false;\n"
       << "  // pass 0: lengths, offsets, staged / flat bytes.  pass 1 (rare): rows of outputs whose bytes\n"
       << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
@@ -1477,7 +1493,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   }
   for (auto& vo : cg.varlen_outs_) s << "    gdv_rot(lc" << vo.e << ");\n";
   s << "  }\n";
-  if (nv > 0) s << "  if (pass == 1) break;\n";
+  if (early) s << "  }\n  if (pass == 2) break;\n  if (pass == 0) {\n";
+  else if (nv > 0) s << "  if (pass == 1) break;\n";
   for (auto& vo : cg.varlen_outs_)
     if (vo.flat_slot >= 0)
       s << "  if (optflat && fb" << vo.e << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n";
@@ -1495,18 +1512,19 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     for (int v = 0; v < nv; v++)
       s << "    lds_tot[wave][" << v << "] = (gdv_uint32)run" << cg.varlen_outs_[v].e << ";\n";
     s << "  }\n  __syncthreads();\n"
-      << "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n"
+      << (early ? "" : "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n")
       << "#pragma unroll\n  for (int v = 0; v < GDV_NV; v++) { before[v] = 0; all[v] = 0; }\n"
       << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
       << "#pragma unroll\n    for (int v = 0; v < GDV_NV; v++) {\n"
       << "      const gdv_uint32 t = lds_tot[w][v];\n      all[v] += t;\n      before[v] += w < wave ? t : 0u;\n    }\n  }\n"
-      << "  gdv_uint64* const lb_agg = A.mask;\n"
-      << "  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n"
+      << (early ? "" : "  gdv_uint64* const lb_agg = A.mask;\n  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n")
       << "  if (threadIdx.x == 0) {\n";
     for (int g = 0; g < ng; g++)
       s << "    gdv_lb_post(lb_agg, ntiles, tile, " << g << ", all[" << 2 * g << "], "
         << (2 * g + 1 < nv ? "all[" + std::to_string(2 * g + 1) + "]" : std::string("0ull")) << ");\n";
     s << "  }\n";
+    // early post: the totals are out; the row loop runs again (staging) before anybody waits
+    if (early) s << (all_flat ? "  }\n  if (optflat) break;\n" : "") << "  continue;\n  }\n" << (all_flat ? "  if (!optflat) {\n" : "");
     s << "  if (threadIdx.x == 0) {\n"
       << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = (GDV_ABL & 32) ? (gdv_uint64)tile * 4000 : gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
       << "  }\n  __syncthreads();\n";
@@ -1685,6 +1703,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
         before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
         // stage while the view is at hand (rows that fall outside the window are skipped: the
         // tile then takes the second, direct pass)
+        if (opts.early_post) cg.Stmt("} else if (pass == 1) {");  // ... or in a row pass of its own, after the post
         cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
         for (auto& name : pv) {
           cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
@@ -1692,7 +1711,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
           cg.Stmt("  at += " + name + ".len;");
         }
       }
-      cg.Stmt("} else if (dir" + E + ") {");
+      cg.Stmt(std::string("} else if (") + (opts.early_post ? "pass == 2 && " : "") + "dir" + E + ") {");
       cg.Stmt("  gdv_uint8* at = outd" + E + " + dbase" + E + " + lc" + E + "[0];");
       for (auto& name : pv) {
         cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");

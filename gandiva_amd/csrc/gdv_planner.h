@@ -37,6 +37,11 @@ struct CodegenOptions {
   bool bitmaps_last = false;   // issue the bitmap-word loads behind the value loads (GDV_BITMAPS_LAST)
   int waves_per_eu = 0;        // > 0: amdgpu_waves_per_eu(n, n) on fixed-width kernels (GDV_WPE): lets the compiler keep every load in flight
   bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
+  // String plans (GDV_EARLY_POST=1; NOT measured yet, off): the row loop runs once for the lengths,
+  // the tile totals are posted, and the LDS staging of the output bytes happens in a second run of
+  // the row loop — in the shadow of the scanner hand-off, as the hand-written prototype does
+  // (profiles/r02_k4_singlepass_proto.txt: its look-back costs 0.06 ms, the product's 0.35 ms)
+  bool early_post = false;
   static CodegenOptions FromEnv();
   std::string Key() const;
 };

@@ -70,3 +70,45 @@ def test_fixed_width_plans_have_one_variant_and_a_literal_free_body(monkeypatch,
     assert len(files) == 1
     text = open(tmp_path / files[0]).read()
     assert "A.lit[" in text and "gdv_make_int128(A.lit[" in text
+
+
+def test_committed_pmc_files_belong_to_the_kernels_this_tree_generates(monkeypatch, tmp_path):
+    """profiles/pmc_c2..c5.json carry the name of the kernel they were measured on; a kernel's name
+    is a hash of its generated text AND of the device library.  If this fails, the tree has moved
+    on since the counters were taken: re-run tools/gpu_evidence.sh (bench.py would print
+    traffic = null for the same reason)."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    plans = {"c2": (W.c2_schema(), W.c2_expressions(), None), "c3": (W.c3_schema(), None, W.c3_condition()),
+             "c4": (W.c4_schema(), W.c4_expressions(), None), "c5": (W.c5_schema(), W.c5_expressions(), None)}
+    for w, (schema, exprs, cond) in plans.items():
+        d = tmp_path / w
+        d.mkdir()
+        dumped = _precompile(monkeypatch, d, schema, exprs, cond)
+        want = json.load(open(os.path.join(here, "..", "profiles", f"pmc_{w}.json")))["kernel"]
+        assert want + ".hip" in dumped, (w, want, dumped)
+
+
+def test_early_post_variant_of_string_plans_compiles(monkeypatch, tmp_path):
+    """GDV_EARLY_POST=1 (off by default, to be measured): lengths pass -> post -> staging pass ->
+    wait.  It must compile for gfx950 in both flat variants and must not be what runs by default."""
+    b = gandiva.TreeExprBuilder()
+    sch = W.c5_schema()
+    f = b.make_field(sch.field(0))
+    STR = pa.string()
+    multi = [b.make_expression(b.make_function("concat", [f, b.make_literal("-", STR),
+                                                          b.make_function("substr", [f, b.make_literal(2, pa.int64())], STR)], STR),
+                               pa.field("c", STR)),
+             b.make_expression(b.make_function("reverse", [f], STR), pa.field("r", STR)),
+             b.make_expression(b.make_function("char_length", [f], pa.int32()), pa.field("n", pa.int32())),
+             b.make_expression(b.make_function("btrim", [f], STR), pa.field("t", STR)),
+             b.make_expression(b.make_function("lower", [b.make_function("ltrim", [f], STR)], STR), pa.field("l", STR)),
+             b.make_expression(b.make_function("upper", [f], STR), pa.field("u", STR))]
+    default = set(_precompile(monkeypatch, tmp_path, sch, W.c5_expressions()))
+    monkeypatch.setenv("GDV_EARLY_POST", "1")
+    early = set(_precompile(monkeypatch, tmp_path, sch, W.c5_expressions())) - default
+    assert len(early) == 2                                   # optimistic + general variant, both new text
+    src = open(os.path.join(tmp_path, sorted(early)[0])).read()
+    assert "pass < 3" in src and "else if (pass == 1)" in src
+    _precompile(monkeypatch, tmp_path, sch, multi)           # >3 var-len outputs: staged, direct and flat ones
+    _precompile(monkeypatch, tmp_path, sch, [multi[5]])      # all outputs flat
