@@ -1846,6 +1846,11 @@ struct Stager {
     if (it != field_of.end()) return it->second;
     Field f;
     f.name = "__gdv_stage" + std::to_string(out->pre.size());
+    for (bool clash = true; clash;) {  // fields are bound by name: stay clear of the caller's
+      clash = false;
+      for (auto& g : out->schema) clash = clash || g.name == f.name;
+      if (clash) f.name += "_";
+    }
     f.type = n->return_type();
     f.nullable = true;
     out->pre.push_back(std::make_shared<Expression>(n, f));
