@@ -228,8 +228,9 @@ struct Val {
   // paths (sweep-answered '%needle%', flat output copy).  -1: anything else.
   int col_slot = -1;
   int col_map = 0;
-  // reverse() and castVARCHAR(integer) results are not readable views (GDV_MAP_REVERSE /
-  // GDV_MAP_DIGITS): like concat results, only the output copy or a concat can take them
+  // reverse(), replace() and castVARCHAR(integer) results are not readable views (GDV_MAP_REVERSE /
+  // GDV_MAP_REPLACE / GDV_MAP_DIGITS): like concat results, only the output copy or a concat can
+  // take them (anything else gets them through a first stage, StageMaterialisedValues)
   bool opaque = false;
   bool never_null() const { return vcols.empty() && vlane.empty(); }
 };
