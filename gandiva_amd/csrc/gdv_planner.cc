@@ -486,7 +486,7 @@ class CodeGen {
 // functions whose fast path is "the string is pure ASCII" (character index == byte index)
 bool WantsAsciiHint(const std::string& name) {
   static const std::set<std::string> k = {"substr", "substring", "left", "right", "char_length", "length",
-                                          "lengthUtf8", "castVARCHAR", "locate", "strpos", "like",
+                                          "lengthUtf8", "castVARCHAR", "locate", "position", "strpos", "like",
                                           "reverse", "lpad", "rpad"};
   return k.count(name) != 0;
 }

@@ -86,6 +86,12 @@ FunctionRegistry::FunctionRegistry() {
   add("mod", {int64(), int64()}, int64());
   add("mod", {int32(), int32()}, int32());
   add("mod", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, kNeedsContext);
+  // aliases of the reference registry (recollection: mod = modulo, power = pow, locate = position)
+  add("modulo", {int64(), int32()}, int32(), NullPolicy::kNullIfNull, 0, Sym("mod", {int64(), int32()}));
+  add("modulo", {int64(), int64()}, int64(), NullPolicy::kNullIfNull, 0, Sym("mod", {int64(), int64()}));
+  add("modulo", {int32(), int32()}, int32(), NullPolicy::kNullIfNull, 0, Sym("mod", {int32(), int32()}));
+  add("modulo", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, kNeedsContext,
+      Sym("mod", {float64(), float64()}));
   for (auto& t : {int32(), int64(), float32(), float64()}) {
     add("negative", {t}, t);
     add("abs", {t}, t);
@@ -160,6 +166,7 @@ FunctionRegistry::FunctionRegistry() {
     add(f, {float64()}, float64());
   }
   add("power", {float64(), float64()}, float64());
+  add("pow", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, 0, Sym("power", {float64(), float64()}));
   add("pow", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, 0,
       "power_float64_float64");
   add("log", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, kNeedsContext);
@@ -280,6 +287,9 @@ FunctionRegistry::FunctionRegistry() {
   }
   add("locate", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
   add("locate", {utf8(), utf8(), int32()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
+  add("position", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext, Sym("locate", {utf8(), utf8()}));
+  add("position", {utf8(), utf8(), int32()}, int32(), NullPolicy::kNullIfNull, kNeedsContext,
+      Sym("locate", {utf8(), utf8(), int32()}));
   add("strpos", {utf8(), utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);
   add("ascii", {utf8()}, int32());
   add("castINT", {utf8()}, int32(), NullPolicy::kNullIfNull, kNeedsContext);

@@ -716,6 +716,9 @@ static i128 dec_rescale(i128 x, int xs, int op, int os) {
 static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active,
                           vec* out) {
   const char* f = n->name;
+  /* aliases of the registry (recollection) */
+  if (!strcmp(f, "modulo")) f = "mod";
+  else if (!strcmp(f, "position")) f = "locate";
   vec* a = (vec*)malloc(sizeof(vec) * (n->nargs ? n->nargs : 1));
   for (int k = 0; k < n->nargs; k++) eval(n->args[k], c, row0, cnt, active, &a[k]);
   out->type = n->type;

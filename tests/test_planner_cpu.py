@@ -118,3 +118,24 @@ def test_early_post_variant_of_string_plans_compiles(monkeypatch, tmp_path):
     assert "pass < 3" in src and "else if (pass == 1)" in src
     _precompile(monkeypatch, tmp_path, sch, multi)           # >3 var-len outputs: staged, direct and flat ones
     _precompile(monkeypatch, tmp_path, sch, [multi[5]])      # all outputs flat
+
+
+def test_registry_aliases_share_their_kernels(monkeypatch, tmp_path):
+    """modulo = mod, pow = power, position = locate: an alias resolves to the same device function, so
+    the generated kernel (its name is a hash of the text without the `// @expr_` header) is the same
+    one — and the oracle gives the same answers under both names."""
+    from oracle import oracle
+    b = gandiva.TreeExprBuilder()
+    sch = pa.schema([pa.field("a", pa.int64()), pa.field("k", pa.int32()), pa.field("x", pa.float64()), pa.field("s", pa.string())])
+    a, k, x, s = (b.make_field(sch.field(i)) for i in range(4))
+    pairs = [("mod", "modulo", [a, k], pa.int32()), ("power", "pow", [x, x], pa.float64()),
+             ("locate", "position", [b.make_literal("ar", pa.string()), s], pa.int32())]
+    batch = pa.RecordBatch.from_arrays([pa.array([7, -7, 100, None], pa.int64()), pa.array([3, 3, 0, 5], pa.int32()),
+                                        pa.array([2.0, 0.5, None, 3.0]), pa.array(["spark", "art", None, "bar ar"])], schema=sch)
+    for name, alias, args, t in pairs:
+        d1, d2 = tmp_path / name, tmp_path / alias
+        d1.mkdir(); d2.mkdir()
+        e1 = b.make_expression(b.make_function(name, args, t), pa.field("r", t))
+        e2 = b.make_expression(b.make_function(alias, args, t), pa.field("r", t))
+        assert _precompile(monkeypatch, d1, sch, [e1]) == _precompile(monkeypatch, d2, sch, [e2]), (name, alias)
+        assert oracle.project([e1], batch)[0].equals(oracle.project([e2], batch)[0])
