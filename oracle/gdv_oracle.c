@@ -45,7 +45,10 @@
  *       newline; float -> integer casts saturate and send NaN to 0; divide / mod by zero raise
  *       "divide by zero error"; integer mod by zero returns the dividend; the decimal
  *       result-type rule (precision > 38 -> scale cut to max(s - delta, min(s, 6))); castINT /
- *       castBIGINT from text accept only [blank]* '-'? digit+ [blank]*; hash of null = seed;
+ *       castBIGINT from text accept only [blank]* '-'? digit+ [blank]* (agrees with
+ *       arrow::internal::ParseValue of the libarrow in this image on every tested text EXCEPT
+ *       hexadecimal: that parser reads "0x10" as 16, this file and the device code reject it —
+ *       tests/test_arrow_pins.py keeps the difference visible); hash of null = seed;
  *       timestampdiffMonth / Quarter / Year (the "last month counts when the end's day of month
  *       has reached the start's, or the end is the last day of its month; equal days compare the
  *       time of day in whole seconds" rule — where it coincides with "largest k with start + k

@@ -8,6 +8,9 @@
 #include <arrow/util/basic_decimal.h>
 #include <arrow/util/decimal.h>
 #include <arrow/vendored/datetime/date.h>
+#include <arrow/type.h>
+#include <arrow/util/formatting.h>
+#include <arrow/util/value_parsing.h>
 
 #include <cstdint>
 #include <cstring>
@@ -101,6 +104,38 @@ void pin_add_months(const int64_t* ms, long n, int32_t months, int64_t* out) {
     if (!t.ok()) t = t.year() / t.month() / date::last;
     out[i] = static_cast<int64_t>(date::sys_days{t}.time_since_epoch().count()) * day_ms + tod;
   }
+}
+
+// ---- round 2: integer <-> text through the Arrow primitives the reference lineage is believed to
+// call (gdv_function_stubs.cc: arrow::internal::StringFormatter for castVARCHAR(integer, n),
+// arrow::internal::ParseValue on the blank-trimmed text for castINT / castBIGINT).
+// out: 24 bytes per value, lens[i] = number of characters
+void pin_format_int64(const long long* v, long n, char* out, int* lens) {
+  arrow::internal::StringFormatter<arrow::Int64Type> fmt;
+  for (long i = 0; i < n; i++) {
+    char* dst = out + 24 * i;
+    int* len = lens + i;
+    (void)fmt(static_cast<int64_t>(v[i]), [&](std::string_view sv) {
+      std::memcpy(dst, sv.data(), sv.size());
+      *len = static_cast<int>(sv.size());
+      return arrow::Status::OK();
+    });
+  }
+}
+// returns 1 and *out on success, 0 when the text is not an integer of that width
+int pin_parse_int(const char* text, int len, int bits, long long* out) {
+  while (len > 0 && *text == ' ') { text++; len--; }
+  while (len > 0 && text[len - 1] == ' ') len--;
+  if (bits == 32) {
+    int32_t v = 0;
+    if (!arrow::internal::ParseValue<arrow::Int32Type>(text, static_cast<size_t>(len), &v)) return 0;
+    *out = v;
+    return 1;
+  }
+  int64_t v = 0;
+  if (!arrow::internal::ParseValue<arrow::Int64Type>(text, static_cast<size_t>(len), &v)) return 0;
+  *out = v;
+  return 1;
 }
 
 }  // extern "C"

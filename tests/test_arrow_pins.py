@@ -84,3 +84,45 @@ def test_oracle_calendar_functions_match_vendored_date_h(pins):
         want = np.zeros(n, dtype=np.int64)
         pins.pin_add_months(ms.ctypes.data_as(C.c_void_p), C.c_long(n), C.c_int(months), want.ctypes.data_as(C.c_void_p))
         assert np.array_equal(got.cast(pa.int64()).to_numpy(), want), f"timestampaddMonth {months}"
+
+
+def test_oracle_integer_text_matches_arrow_formatter_and_parser(pins):
+    """castVARCHAR(integer, n) against arrow::internal::StringFormatter<Int64Type>, castINT /
+    castBIGINT(text) against arrow::internal::ParseValue on the blank-trimmed text — the Arrow
+    primitives the reference lineage is believed to call (recollection), compiled from the headers
+    and libarrow that ship with pyarrow."""
+    import test_strings as S
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([np.array([0, 1, -1, 9, 10, -10, 2**31 - 1, -2**31, 2**63 - 1, -2**63, 10**18, -10**18], np.int64),
+                           rng.integers(-2**63, 2**63 - 1, 3000, dtype=np.int64) >> rng.integers(0, 63, 3000)])
+    out = np.zeros(24 * len(vals), np.uint8)
+    lens = np.zeros(len(vals), np.int32)
+    pins.pin_format_int64(vals.ctypes.data_as(C.c_void_p), C.c_long(len(vals)), out.ctypes.data_as(C.c_void_p),
+                          lens.ctypes.data_as(C.c_void_p))
+    arrow_text = [bytes(out[24 * i:24 * i + lens[i]]).decode() for i in range(len(vals))]
+    b = gandiva.TreeExprBuilder()
+    batch = pa.RecordBatch.from_arrays([pa.array(vals, pa.int64())], names=["x"])
+    x = b.make_field(batch.schema.field(0))
+    for n in (30, 7, 1, 0):
+        node = b.make_function("castVARCHAR", [x, b.make_literal(n, pa.int64())], pa.string())
+        assert oracle.project_one(node, pa.string(), batch).to_pylist() == [t[:n] for t in arrow_text], n
+    # text -> integer: same accept / reject decision and same value as Arrow's parser
+    texts = S.NUMBER_TEXTS + [str(int(v)) for v in vals[:200]] + ["+0", "-00", "0x10", "1e3", "١", " -12 ", "--1", "9" * 19, "-" + "9" * 19]
+    for name, typ, bits in (("castINT", pa.int32(), 32), ("castBIGINT", pa.int64(), 64)):
+        for text in texts:
+            raw = text.encode()
+            got = C.c_longlong(0)
+            ok = pins.pin_parse_int(raw, len(raw), bits, C.byref(got))
+            tb = pa.RecordBatch.from_arrays([pa.array([text], pa.string())], names=["s"])
+            node = b.make_function(name, [b.make_field(tb.schema.field(0))], typ)
+            if text.strip(" ").lower().startswith("0x"):
+                # KNOWN DIVERGENCE, kept visible: today's Arrow parser reads hexadecimal ("0x10" -> 16);
+                # the oracle and the device code follow the decimal-only rule of the older lineage
+                assert ok and got.value == int(text, 16)
+                with pytest.raises(Exception, match="invalid argument"):
+                    oracle.project_one(node, typ, tb)
+            elif ok:
+                assert oracle.project_one(node, typ, tb).to_pylist() == [got.value], (name, text)
+            else:
+                with pytest.raises(Exception, match="invalid argument"):
+                    oracle.project_one(node, typ, tb)
