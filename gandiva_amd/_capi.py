@@ -98,6 +98,9 @@ PROTOTYPES = [
     ("gdv_projector_evaluate_export", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), _P, _P, _P]),
     ("gdv_precompile_projector", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_precompile_filter", C.c_int, [_P, _P]),
+    ("gdv_kernel_library_tag", _P, [C.c_char_p, C.c_char_p]),
+    ("gdv_kernel_library_items", _P, [C.c_char_p, C.c_char_p]),
+    ("gdv_device_library_source", C.c_char_p, []),
 ]
 
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "gdv_engine.h"
+#include "gdv_libtag.h"
 
 using namespace gdv;
 
@@ -900,5 +901,28 @@ int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* conditio
   return Check(PrecompileFilter(schema->fields, condition->expr));
   });
 }
+
+// The part of a kernel's name that comes from the device function library: the hash of the library
+// items `kernel_text` reaches (gdv_libtag.h).  library_source NULL = the embedded library.
+char* gdv_kernel_library_tag(const char* library_source, const char* kernel_text) {
+  if (kernel_text == nullptr) return nullptr;
+  std::string tag;
+  if (library_source == nullptr) {
+    tag = LibraryIndex::Embedded().TagFor(kernel_text);
+  } else {
+    tag = LibraryIndex(library_source).TagFor(kernel_text);
+  }
+  return DupString(tag);
+}
+char* gdv_kernel_library_items(const char* library_source, const char* kernel_text) {
+  if (kernel_text == nullptr) return nullptr;
+  std::vector<std::string> names = library_source == nullptr
+                                       ? LibraryIndex::Embedded().ReachedFrom(kernel_text)
+                                       : LibraryIndex(library_source).ReachedFrom(kernel_text);
+  std::string out;
+  for (auto& n : names) out += n + "\n";
+  return DupString(out);
+}
+const char* gdv_device_library_source(void) { return gdv_device_lib_src; }
 
 }  // extern "C"

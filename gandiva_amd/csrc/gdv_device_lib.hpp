@@ -404,10 +404,15 @@ GDV_DEV gdv_int32 gdv_sat_i32(gdv_float64 r) {
   if (r <= -2147483648.0) return (gdv_int32)0x80000000u;
   return (gdv_int32)r;
 }
-GDV_DEV gdv_int64 castBIGINT_float32(gdv_float32 a) { return gdv_sat_i64(round((gdv_float64)a)); }
-GDV_DEV gdv_int64 castBIGINT_float64(gdv_float64 a) { return gdv_sat_i64(round(a)); }
-GDV_DEV gdv_int32 castINT_float32(gdv_float32 a) { return gdv_sat_i32(round((gdv_float64)a)); }
-GDV_DEV gdv_int32 castINT_float64(gdv_float64 a) { return gdv_sat_i32(round(a)); }
+// round half away from zero the way the reference writes it (precompiled extended_math_ops:
+// `trunc(x + (x >= 0 ? 0.5 : -0.5))`), NOT C round(): the sum is itself rounded to nearest even,
+// so 0.49999999999999994 -> 1 and odd integers in [2^52, 2^53) move to the next even one.
+// float32 arguments are widened first (the reference's 0.5 is a double literal): exact.
+GDV_DEV gdv_float64 gdv_round_half_away(gdv_float64 a) { return trunc(a + (a >= 0 ? 0.5 : -0.5)); }
+GDV_DEV gdv_int64 castBIGINT_float32(gdv_float32 a) { return gdv_sat_i64(gdv_round_half_away((gdv_float64)a)); }
+GDV_DEV gdv_int64 castBIGINT_float64(gdv_float64 a) { return gdv_sat_i64(gdv_round_half_away(a)); }
+GDV_DEV gdv_int32 castINT_float32(gdv_float32 a) { return gdv_sat_i32(gdv_round_half_away((gdv_float64)a)); }
+GDV_DEV gdv_int32 castINT_float64(gdv_float64 a) { return gdv_sat_i32(gdv_round_half_away(a)); }
 
 GDV_DEV gdv_date64 castDATE_int64(gdv_int64 a) { return a; }
 GDV_DEV gdv_timestamp castTIMESTAMP_int64(gdv_int64 a) { return a; }
@@ -429,7 +434,7 @@ GDV_DEV gdv_float64 log_float64_float64(gdv_ctx ctx, gdv_float64 base, gdv_float
 }
 GDV_DEV gdv_float64 floor_float64(gdv_float64 a) { return floor(a); }
 GDV_DEV gdv_float64 ceil_float64(gdv_float64 a) { return ceil(a); }
-GDV_DEV gdv_float64 round_float64(gdv_float64 a) { return round(a); }
+GDV_DEV gdv_float64 round_float64(gdv_float64 a) { return gdv_round_half_away(a); }
 GDV_DEV gdv_float64 truncate_float64(gdv_float64 a) { return trunc(a); }
 
 // ------------------------------------------------------------------ hash
@@ -1561,7 +1566,9 @@ GDV_DEV gdv_str gdv_replace(gdv_ctx ctx, gdv_str s, const gdv_uint8* desc) {
   }
   if (hits == 0) return s;
   const gdv_int64 out = (gdv_int64)s.len + (gdv_int64)hits * (tl - fl);
-  if (out > 65535) { gdv_raise(ctx, GDV_ERR_BAD_ARG); s.len = 0; return s; }
+  // (the view packs the source length into 30 bits of `flags`: a row of 512 MiB or more cannot be
+  // described even when the replacements shrink it below the 65535-byte result limit)
+  if (out > 65535 || s.len >= (1 << 29)) { gdv_raise(ctx, GDV_ERR_BAD_ARG); s.len = 0; return s; }
   s.flags = (s.flags & 3) | (s.len << 2);
   s.lim = desc;
   s.len = (gdv_int32)out;
@@ -1638,13 +1645,34 @@ GDV_DEV gdv_int32 locate_utf8_utf8(gdv_ctx ctx, gdv_str sub, gdv_str str) {
 GDV_DEV gdv_int32 strpos_utf8_utf8(gdv_ctx ctx, gdv_str str, gdv_str sub) {
   return locate_utf8_utf8_int32(ctx, sub, str, 1);
 }
-// castINT / castBIGINT from text: blanks trimmed on both sides, an optional '-', one or more
-// decimal digits, nothing else; anything that is not such a number or does not fit the type is
-// an execution error (the reference: "Failed to cast the string ... to int32").
-GDV_DEV bool gdv_parse_int64(const gdv_str& s, gdv_int64 min_value, gdv_int64 max_value, gdv_int64* out) {
+// castINT / castBIGINT from text: blanks trimmed on both sides, then what Arrow's integer parser
+// takes (arrow::internal::ParseValue, the primitive the reference's gdv_fn_cast*_utf8 stubs call;
+// pyarrow/include/arrow/util/value_parsing.h:380-440): "0x" / "0X" + 1 .. 2*sizeof(T) hexadecimal
+// digits, read as the type's bit pattern ("0xFFFFFFFF" is -1 as int32) — or an optional '-' and
+// one or more decimal digits that fit the type.  Anything else is an execution error (the
+// reference: "Failed to cast the string ... to int32").  `hex_digits` = 2 * sizeof(T).
+GDV_DEV bool gdv_parse_int64(const gdv_str& s, gdv_int64 min_value, gdv_int64 max_value, gdv_int32 hex_digits,
+                             gdv_int64* out) {
   gdv_int32 lo = 0, hi = s.len;
   while (lo < hi && gdv_str_at(s, lo) == ' ') lo++;
   while (hi > lo && gdv_str_at(s, hi - 1) == ' ') hi--;
+  if (hi - lo > 2 && gdv_str_at(s, lo) == '0' && (gdv_str_at(s, lo + 1) | 0x20) == 'x') {
+    lo += 2;
+    if (hi - lo > hex_digits) return false;
+    gdv_uint64 acc = 0;
+    for (gdv_int32 i = lo; i < hi; i++) {
+      const gdv_int32 c = gdv_str_at(s, i);
+      gdv_int32 d;
+      if (c >= '0' && c <= '9') d = c - '0';
+      else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+      else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+      else return false;
+      acc = (acc << 4) | (gdv_uint64)d;
+    }
+    // the unsigned image of the type's width, reinterpreted
+    *out = hex_digits == 8 ? (gdv_int64)(gdv_int32)(gdv_uint32)acc : (gdv_int64)acc;
+    return true;
+  }
   bool neg = false;
   if (lo < hi && gdv_str_at(s, lo) == '-') { neg = true; lo++; }
   if (lo >= hi) return false;
@@ -1662,7 +1690,7 @@ GDV_DEV bool gdv_parse_int64(const gdv_str& s, gdv_int64 min_value, gdv_int64 ma
 }
 GDV_DEV gdv_int64 castBIGINT_utf8(gdv_ctx ctx, gdv_str s) {
   gdv_int64 v = 0;
-  if (!gdv_parse_int64(s, (gdv_int64)(-9223372036854775807LL - 1), 9223372036854775807LL, &v)) {
+  if (!gdv_parse_int64(s, (gdv_int64)(-9223372036854775807LL - 1), 9223372036854775807LL, 16, &v)) {
     gdv_raise(ctx, GDV_ERR_BAD_ARG);
     return 0;
   }
@@ -1670,7 +1698,7 @@ GDV_DEV gdv_int64 castBIGINT_utf8(gdv_ctx ctx, gdv_str s) {
 }
 GDV_DEV gdv_int32 castINT_utf8(gdv_ctx ctx, gdv_str s) {
   gdv_int64 v = 0;
-  if (!gdv_parse_int64(s, -2147483648LL, 2147483647LL, &v)) {
+  if (!gdv_parse_int64(s, -2147483648LL, 2147483647LL, 8, &v)) {
     gdv_raise(ctx, GDV_ERR_BAD_ARG);
     return 0;
   }

@@ -1,5 +1,6 @@
 #include "gdv_planner.h"
 
+#include "gdv_libtag.h"
 #include "gdv_runtime.h"
 
 #include <algorithm>
@@ -191,24 +192,13 @@ std::string HashableSource(const std::string& text) {
   return out;
 }
 
-std::string LibraryTag();
+uint64_t Fnv1a(const std::string& s) { return Fnv1a64(s); }
 
-uint64_t Fnv1a(const std::string& s) {
-  uint64_t h = 1469598103934665603ull;
-  for (unsigned char c : s) {
-    h ^= c;
-    h *= 1099511628211ull;
-  }
-  return h;
-}
-
-// A kernel is its generated text AND the device function library it is compiled against: the
-// library's hash is part of the kernel name, so a PMC pass or a cached code object can only be
-// attributed to the code that really ran.
-std::string LibraryTag() {
-  static const std::string tag = std::to_string(Fnv1a(std::string(gdv_device_lib_src)));
-  return tag;
-}
+// A kernel is its generated text AND the device functions that text reaches in the library
+// (gdv_libtag.h): their hash is part of the kernel name, so a PMC pass or a cached code object can
+// only be attributed to the code that really ran — and an edit of a function the kernel never
+// calls leaves its name alone (rounds 1-2 hashed the whole header: any edit renamed every kernel).
+std::string LibraryTag(const std::string& kernel_text) { return LibraryIndex::Embedded().TagFor(kernel_text); }
 
 // A value inside the generated row body: a C++ expression plus its validity, split the way
 // the reference's ValueValidityPair splits it — the set of input columns whose validity
@@ -1187,7 +1177,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "}\n";
 
   std::string text = s.str();
-  uint64_t h = Fnv1a(HashableSource(text) + LibraryTag());
+  uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
   char name[64];
   snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
   plan->kernel_name = name;
@@ -1605,7 +1595,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     std::string text = tmpl;
     size_t p0 = text.find("GDV_OPTFLAT_VALUE");
     text.replace(p0, strlen("GDV_OPTFLAT_VALUE"), optflat);
-    uint64_t h = Fnv1a(HashableSource(text) + LibraryTag());
+    uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
     char name[64];
     snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
     size_t pos = text.find("GDV_KERNEL_NAME");

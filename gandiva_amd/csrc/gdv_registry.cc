@@ -1,5 +1,8 @@
 #include "gdv_registry.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace gdv {
@@ -14,6 +17,15 @@ std::string FunctionDef::SignatureString() const {
 }
 
 void FunctionRegistry::Add(FunctionDef def) {
+  // one definition per (name, parameter types): a second one would be listed twice by
+  // GetRegisteredFunctionSignatures and silently shadowed in Lookup
+  auto range = by_name_.equal_range(def.name);
+  for (auto it = range.first; it != range.second; ++it) {
+    if (defs_[it->second].params == def.params) {
+      fprintf(stderr, "gandiva_amd: function %s registered twice with the same parameter types\n", def.name.c_str());
+      std::abort();
+    }
+  }
   by_name_.emplace(def.name, defs_.size());
   defs_.push_back(std::move(def));
 }
@@ -167,8 +179,6 @@ FunctionRegistry::FunctionRegistry() {
   }
   add("power", {float64(), float64()}, float64());
   add("pow", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, 0, Sym("power", {float64(), float64()}));
-  add("pow", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, 0,
-      "power_float64_float64");
   add("log", {float64(), float64()}, float64(), NullPolicy::kNullIfNull, kNeedsContext);
 
   // hash family: never null, null input hashes to the seed

@@ -349,6 +349,16 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDe
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
                              int num_exprs, int selection_mode);
 int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* condition);
+/* Kernel identity (diagnostics, tests).  A fused kernel is named after a hash of its generated text
+ * and of the device-library functions that text reaches — not of the whole library, so an edit of a
+ * function a kernel never calls leaves its name (and every profile taken on it) alone.
+ * gdv_kernel_library_tag: that library hash for `kernel_text` (what gdv_projector_dump_ir returns);
+ * gdv_kernel_library_items: the names of the hashed items, one per line; library_source NULL = the
+ * library embedded in this build, which gdv_device_library_source returns.  Strings are freed with
+ * gdv_free_string (the library source is a static string: do not free it). */
+char* gdv_kernel_library_tag(const char* library_source, const char* kernel_text);
+char* gdv_kernel_library_items(const char* library_source, const char* kernel_text);
+const char* gdv_device_library_source(void);
 
 #ifdef __cplusplus
 }

@@ -40,15 +40,16 @@
  *     arithmetic, compares, Kleene AND/OR, casts between numeric types, temporal extraction:
  *       pyarrow.compute over random trees; strings: Python str / bytes / re; MurmurHash3:
  *       sklearn + a pure-Python implementation.
- *   PURE RECOLLECTION (one opinion, mine): round(float64) = C round() (the reference may round
- *       via trunc(x +- 0.5), which differs at 0.49999999999999994); LIKE '_' and '%' match a
+ *   PURE RECOLLECTION (one opinion, mine): round(float64) and the float -> integer casts round as
+ *       trunc(x + (x >= 0 ? 0.5 : -0.5)) (round 3: was C round(); the two differ at
+ *       0.49999999999999994 and on odd integers >= 2^52); LIKE '_' and '%' match a
  *       newline; float -> integer casts saturate and send NaN to 0; divide / mod by zero raise
  *       "divide by zero error"; integer mod by zero returns the dividend; the decimal
  *       result-type rule (precision > 38 -> scale cut to max(s - delta, min(s, 6))); castINT /
- *       castBIGINT from text accept only [blank]* '-'? digit+ [blank]* (agrees with
- *       arrow::internal::ParseValue of the libarrow in this image on every tested text EXCEPT
- *       hexadecimal: that parser reads "0x10" as 16, this file and the device code reject it —
- *       tests/test_arrow_pins.py keeps the difference visible); hash of null = seed;
+ *       castBIGINT from text = blanks trimmed + arrow::internal::ParseValue (round 3: hexadecimal
+ *       "0x.." included; held to the ParseValue of the libarrow in this image on every tested
+ *       text, tests/test_arrow_pins.py — the rule "the stub trims blanks and calls ParseValue"
+ *       is the recollection, the parser itself is pinned); hash of null = seed;
  *       timestampdiffMonth / Quarter / Year (the "last month counts when the end's day of month
  *       has reached the start's, or the end is the last day of its month; equal days compare the
  *       time of day in whole seconds" rule — where it coincides with "largest k with start + k
@@ -464,7 +465,11 @@ static uint64_t dbits(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 /* ---------------------------------------------------------------- evaluation */
 static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active, vec* out);
 
-static double rnd(double x) { return round(x); }
+/* round half away from zero as the reference spells it: trunc(x + (x >= 0 ? 0.5 : -0.5))
+ * [recalled: precompiled/extended_math_ops.cc ROUND_DECIMAL; castINT/castBIGINT(float) go through
+ * the same function].  NOT C round(): the addition rounds to nearest even first, so
+ * 0.49999999999999994 gives 1 and 2^52 + 1 gives 2^52 + 2. */
+static double rnd(double x) { return trunc(x + (x >= 0 ? 0.5 : -0.5)); }
 static int64_t sat_i64(double r) {
   if (r != r) return 0;
   if (r >= 9223372036854775808.0) return INT64_MAX;
@@ -820,17 +825,35 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
           if (eq) { out->v[i].i = utf8_chars(str, p0) + 1; break; }
         }
       } else if (!strcmp(f, "castINT") || !strcmp(f, "castBIGINT")) {
-        /* text -> integer: blanks trimmed, optional '-', digits only, must fit the type */
+        /* text -> integer: blanks trimmed, then arrow::internal::ParseValue<Int32/Int64Type>
+         * (pyarrow/include/arrow/util/value_parsing.h:380-440 StringToSignedIntConverterMixin, the
+         * primitive the reference's gdv_fn_castINT_utf8 / castBIGINT_utf8 stubs hand the trimmed text
+         * to): "0x"/"0X" + at most 2*sizeof(T) hex digits = the type's bit image; else optional '-',
+         * decimal digits, value must fit the type */
         int live = out->valid[i] && (!active || active[i]);
         int lo = 0, hi = xl, neg = 0, ok = 1;
+        const int width_digits = f[4] == 'I' ? 8 : 16;
         out->v[i].i = 0;
         if (!live) continue;
         while (lo < hi && map_byte(x[lo], xm) == ' ') lo++;
         while (hi > lo && map_byte(x[hi - 1], xm) == ' ') hi--;
+        i128 acc = 0;
+        if (hi - lo > 2 && map_byte(x[lo], xm) == '0' && (map_byte(x[lo + 1], xm) == 'x' || map_byte(x[lo + 1], xm) == 'X')) {
+          uint64_t bits = 0;
+          if (hi - (lo + 2) > width_digits) ok = 0;
+          for (int k = lo + 2; k < hi && ok; k++) {
+            int ch = map_byte(x[k], xm);
+            int d = (ch >= '0' && ch <= '9') ? ch - '0' : (ch >= 'a' && ch <= 'f') ? ch - 'a' + 10
+                    : (ch >= 'A' && ch <= 'F') ? ch - 'A' + 10 : -1;
+            if (d < 0) ok = 0; else bits = bits * 16 + (uint64_t)d;
+          }
+          if (!ok) { c->err |= 4; continue; }
+          out->v[i].i = f[4] == 'I' ? (int64_t)(int32_t)(uint32_t)bits : (int64_t)bits;
+          continue;
+        }
         if (lo < hi && map_byte(x[lo], xm) == '-') { neg = 1; lo++; }
         if (lo >= hi) ok = 0;
         while (ok && lo < hi - 1 && map_byte(x[lo], xm) == '0') lo++; /* leading zeros */
-        i128 acc = 0;
         for (int k = lo; k < hi && ok; k++) {
           int d = map_byte(x[k], xm) - '0';
           if (d < 0 || d > 9 || hi - lo > 30) ok = 0; else acc = acc * 10 + d;
@@ -1083,7 +1106,7 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       double x = a[0].v[i].d;
       out->v[i].d = !strcmp(f, "cbrt") ? cbrt(x) : !strcmp(f, "exp") ? exp(x) : !strcmp(f, "log10") ? log10(x)
                   : !strcmp(f, "sqrt") ? sqrt(x) : !strcmp(f, "floor") ? floor(x) : !strcmp(f, "ceil") ? ceil(x)
-                  : !strcmp(f, "round") ? round(x) : !strcmp(f, "truncate") ? trunc(x) : log(x);
+                  : !strcmp(f, "round") ? rnd(x) : !strcmp(f, "truncate") ? trunc(x) : log(x);
     }
   } else if (!strcmp(f, "power") || !strcmp(f, "pow")) {
     for (int i = 0; i < cnt; i++) out->v[i].d = pow(a[0].v[i].d, a[1].v[i].d);

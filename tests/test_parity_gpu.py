@@ -165,6 +165,24 @@ def test_casts_hash_and_dates():
     _check_project(exprs, batch)
 
 
+def test_round_and_float_casts_on_the_edges_of_the_rule():
+    """trunc(x +- 0.5) vs C round(): the values where the two differ, on the device."""
+    from test_oracle_crosscheck import ROUND_EDGES
+    rng = np.random.default_rng(3)
+    vals = ROUND_EDGES + list(rng.integers(-10**6, 10**6, 3000) + 0.5) + list(rng.normal(0, 1e6, 3000))
+    f64 = pa.array(vals, pa.float64())
+    f32 = pa.array(np.array(vals, dtype=np.float64).astype(np.float32), pa.float32())
+    batch = pa.RecordBatch.from_arrays([f64, f32], names=["d", "f"])
+    b = gandiva.TreeExprBuilder()
+    d, f = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = [b.make_expression(b.make_function("round", [d], pa.float64()), pa.field("r", pa.float64())),
+             b.make_expression(b.make_function("castBIGINT", [d], pa.int64()), pa.field("b", pa.int64())),
+             b.make_expression(b.make_function("castINT", [d], pa.int32()), pa.field("i", pa.int32())),
+             b.make_expression(b.make_function("castBIGINT", [f], pa.int64()), pa.field("bf", pa.int64())),
+             b.make_expression(b.make_function("castINT", [f], pa.int32()), pa.field("if", pa.int32()))]
+    _check_project(exprs, batch)
+
+
 def test_math_functions_within_one_ulp():
     """exp/log/pow/cbrt come from math libraries on both sides (ROCm device libs / host
     libm), so they are not bit-comparable with each other.  north_star's tolerance is 1 ulp:
