@@ -89,6 +89,11 @@ class ArgBlock {
     SetPtr(layout_.out_base() + e * ArgLayout::kOutStride + 16, p);
   }
   void SetLit(int i, uint64_t v) { Set64(layout_.lit_base() + i * 8, v); }
+  // input slot k := slot `src_k` of another block (same column, already bound / staged there)
+  void CopyInSlot(int k, const ArgBlock& src, int src_k) {
+    std::memcpy(&buf_[layout_.in_base() + k * ArgLayout::kInStride],
+                &src.buf_[src.layout_.in_base() + src_k * ArgLayout::kInStride], ArgLayout::kInStride);
+  }
   void SetOutCap(int e, int64_t bytes) {
     Set64(layout_.out_base() + e * ArgLayout::kOutStride + 24, static_cast<uint64_t>(bytes));
   }
@@ -382,6 +387,11 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
 }
 
 int64_t GridFor(const KernelPlan& plan, int64_t rows) {
+  if (plan.wave_tiles) {
+    // wave shape: one WAVE per tile, no scanner workgroup
+    const int64_t nwt = (rows + plan.rows_per_tile() - 1) / plan.rows_per_tile();
+    return std::max<int64_t>(1, (nwt + plan.opts.waves - 1) / plan.opts.waves);
+  }
   if (plan.string_skeleton) {
     // one workgroup per tile (+ the scanner workgroup when there are var-len outputs)
     const int64_t ntiles = (rows + plan.rows_per_tile() - 1) / plan.rows_per_tile();
@@ -406,6 +416,7 @@ std::string ErrorMessage(uint32_t bits) {
   if (bits & 2u) m += (m.empty() ? "" : "; ") + std::string("overflow");
   if (bits & 4u) m += (m.empty() ? "" : "; ") + std::string("invalid argument");
   if (bits & 8u) m += (m.empty() ? "" : "; ") + std::string("device scan stalled");
+  if (bits & 48u) m += (m.empty() ? "" : "; ") + std::string("internal: optimistic var-len kernel was not re-run");
   return m.empty() ? "execution error" : m;
 }
 
@@ -540,6 +551,10 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
   GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_));
   GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.source, p->plan_.kernel_name, &p->kernel_));
   GDV_RETURN_NOT_OK(UploadConstBlock(p->plan_, &p->consts_));
+  if (p->plan_.prepass) {
+    GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.prepass->source, p->plan_.prepass->kernel_name, &p->kernel_pre_));
+    GDV_RETURN_NOT_OK(UploadConstBlock(*p->plan_.prepass, &p->consts_pre_));
+  }
   ProjectorCache().Put(key, p);
   *out = p;
   return Status::OK();
@@ -573,7 +588,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   Staging st;
   DeviceBuffer err;
   // var-len outputs: grand totals / per-tile granules of the in-kernel offsets scan
-  DeviceBuffer tile_counts, tile_starts;
+  DeviceBuffer tile_counts, tile_starts, wave_head, wave_counts, wave_bases, wave_chunks;
   StageColumns stage;  // two-stage plans: the first stage's temporary columns (outlive the drain below)
   // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
   StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output || pre_ != nullptr};
@@ -663,28 +678,40 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
                                   args.size(), stream));
   } else if (out_rows > 0) {
-    // Single launch: workgroup 0 scans the tile totals (granules: tile_starts; grand totals:
-    // tile_counts), workers post one granule and poll one.  Device buffers: the caller's
-    // capacities are honoured inside the kernel (tiles that do not fit skip their bytes) and
-    // the totals say what was needed.  Host buffers: a first launch with capacity 0 sizes the
-    // device byte buffers, a second one fills them (the path is PCIe-bound anyway).
+    // Scanner shape — single launch: workgroup 0 scans the tile totals (granules: tile_starts;
+    // grand totals: tile_counts), workers post one granule and poll one.  Wave shape (plans whose
+    // output lengths follow from the offsets, gdv_planner.cc): pre-pass -> offsets scan -> main
+    // kernel of independent wave tiles; a batch that breaks its ASCII / flat assumption is re-run
+    // on the scanner-shaped general kernel.  Device buffers: the caller's capacities are honoured
+    // inside the kernels (tiles that do not fit skip their bytes) and the totals say what was
+    // needed.  Host buffers: a first launch with capacity 0 sizes the device byte buffers, a
+    // second one fills them (the path is PCIe-bound anyway).
     const int ng = (nv + 1) / 2;
-    const int64_t ntiles = (out_rows + plan_.rows_per_tile() - 1) / plan_.rows_per_tile();
-    // one block, one memset and one read-back per launch: [error word | grand totals | granules]
+    const int64_t rows_wg = 64 * static_cast<int64_t>(plan_.opts.subtiles) * plan_.opts.waves;
+    const int64_t ntiles = (out_rows + rows_wg - 1) / rows_wg;
+    // head of the state block, one memset and one read-back per launch:
+    // [error word | grand totals (2 * ng) | wave shape: totals of the scanned segments]
+    int nseg = 0;
+    for (int sgm : plan_.wave_segments) nseg = std::max(nseg, sgm + 1);
     const size_t totals_bytes = static_cast<size_t>(2 * ng) * 8;
-    const size_t state_bytes = 8 + totals_bytes + static_cast<size_t>(2 * ng * ntiles) * 8;
-    GDV_RETURN_NOT_OK(tile_starts.Allocate(state_bytes));
-    char* const state = tile_starts.as<char>();
-    args.SetPtr(ArgLayout::kOffErr, state);
-    args.SetPtr(ArgLayout::kOffCounts, state + 8);
-    args.SetPtr(ArgLayout::kOffMask, state + 8 + totals_bytes);
-    std::vector<uint64_t> back(1 + 2 * ng, 0);
+    const size_t head_bytes = 8 + totals_bytes + static_cast<size_t>(nseg) * 8;
+    std::vector<uint64_t> back(head_bytes / 8, 0);
     std::vector<int> vl;
     for (int e = 0; e < num_outs; e++)
       if (plan_.output_types[e].is_varlen()) vl.push_back(e);
     std::vector<uint64_t> seg(2 * ng, 0);
     const CompiledKernel* active = kernel_;
-    auto run = [&](int64_t grid) -> Status {
+    char* state = nullptr;
+    size_t state_bytes = 0;
+    auto run = [&](int64_t grid) -> Status {  // scanner shape
+      if (state == nullptr) {
+        state_bytes = 8 + totals_bytes + static_cast<size_t>(2 * ng * ntiles) * 8;
+        GDV_RETURN_NOT_OK(tile_starts.Allocate(state_bytes));
+        state = tile_starts.as<char>();
+      }
+      args.SetPtr(ArgLayout::kOffErr, state);
+      args.SetPtr(ArgLayout::kOffCounts, state + 8);
+      args.SetPtr(ArgLayout::kOffMask, state + 8 + totals_bytes);
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(state, 0, state_bytes, stream));
       GDV_RETURN_NOT_OK(rt.Launch(*active, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), state, 8 + totals_bytes, hipMemcpyDeviceToHost, stream));
@@ -693,14 +720,72 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       for (int i = 0; i < 2 * ng; i++) seg[i] = back[1 + i];
       return Status::OK();
     };
+    // wave shape
+    const int64_t rows_wt = 64 * static_cast<int64_t>(plan_.opts.subtiles);
+    const int64_t nwt = (out_rows + rows_wt - 1) / rows_wt;
+    const int64_t seg_stride = (nwt + 3) & ~int64_t{3};  // the scan kernels read the totals 16 bytes at a time
+    std::unique_ptr<ArgBlock> pargs;
+    auto run_wave = [&]() -> Status {
+      if (wave_head.get() == nullptr) {
+        GDV_RETURN_NOT_OK(wave_head.Allocate(head_bytes));
+        if (nseg > 0) {
+          GDV_RETURN_NOT_OK(wave_counts.Allocate(static_cast<size_t>(nseg * seg_stride) * 4 + 64));
+          GDV_RETURN_NOT_OK(wave_bases.Allocate(static_cast<size_t>(nseg * seg_stride) * 8));
+          GDV_RETURN_NOT_OK(wave_chunks.Allocate(static_cast<size_t>(nseg * ScanChunks(nwt)) * 8));
+          // the pre-pass reads columns the main kernel has bound (and, on the host path, staged) already
+          const KernelPlan& pp = *plan_.prepass;
+          pargs.reset(new ArgBlock(pp.layout));
+          for (size_t kp = 0; kp < pp.input_fields.size(); kp++) {
+            int k = -1;
+            for (size_t j = 0; j < plan_.input_fields.size(); j++)
+              if (plan_.input_fields[j] == pp.input_fields[kp]) k = static_cast<int>(j);
+            if (k < 0 || (pp.input_needs_values[kp] && !plan_.input_needs_values[k]) ||
+                (pp.input_needs_validity[kp] && !plan_.input_needs_validity[k]))
+              return Status::ExecutionError("internal: pre-pass input not bound by the main kernel");
+            pargs->CopyInSlot(static_cast<int>(kp), args, k);
+          }
+          BindLiterals(pp, consts_pre_, pargs.get());
+          pargs->Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
+          pargs->SetPtr(ArgLayout::kOffErr, wave_head.get());
+          pargs->SetPtr(ArgLayout::kOffCounts, wave_counts.get());
+          pargs->Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
+        }
+      }
+      char* const head = wave_head.as<char>();
+      args.SetPtr(ArgLayout::kOffErr, head);
+      args.SetPtr(ArgLayout::kOffCounts, head + 8);
+      args.SetPtr(ArgLayout::kOffMask, wave_bases.get());
+      args.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(head, 0, head_bytes, stream));
+      const int64_t grid = GridFor(plan_, out_rows);
+      if (nseg > 0) {
+        GDV_RETURN_NOT_OK(rt.Launch(*kernel_pre_, grid, plan_.opts.waves * 64, pargs->data(), pargs->size(), stream));
+        int32_t* closing[kMaxScanSegments] = {};
+        for (int v = 0; v < nv; v++)
+          if (plan_.wave_segments[v] >= 0)
+            closing[plan_.wave_segments[v]] = static_cast<int32_t*>(dev_offs[vl[v]]) + out_rows;
+        GDV_HIP_RETURN_NOT_OK(LaunchSegmentedOffsetsScan(wave_counts.as<uint32_t>(), nwt, seg_stride, nseg,
+                                                         wave_chunks.as<uint64_t>(), wave_bases.as<uint64_t>(),
+                                                         reinterpret_cast<uint64_t*>(head + 8 + totals_bytes), closing, stream));
+      }
+      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), head, head_bytes, hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+      err_bits = static_cast<uint32_t>(back[0]);
+      for (int v = 0; v < nv; v++)
+        seg[v] = plan_.wave_segments[v] >= 0 ? back[1 + 2 * ng + plan_.wave_segments[v]] : back[1 + v];
+      return Status::OK();
+    };
     // Outputs that are an input column's (mapped) bytes — a column passed through, upper(col),
     // lower(col) — are first evaluated OPTIMISTICALLY: bytes copied by the byte sweep as they
     // are read, offsets = input offsets rebased, no scan.  That holds unless a NULL row carries
     // bytes (Arrow allows it, producers rarely do it); the kernel then raises NOTFLAT and the
-    // batch is re-run with those outputs on the general path.
-    // (sticky: a Projector whose batches carry bytes under nulls goes straight to the general
+    // batch is re-run with those outputs on the general path.  The wave shape adds the ASCII
+    // assumption of its pre-pass (NOTASCII) and falls back the same way.
+    // (sticky: a Projector whose batches break an assumption goes straight to the general
     // variant from then on instead of paying two launches per batch)
-    bool optimistic = plan_.has_flat_output && !prefer_general_.load() && std::getenv("GDV_NO_OPTFLAT") == nullptr;
+    const bool has_optimistic = plan_.wave_tiles || plan_.has_flat_output;
+    bool optimistic = has_optimistic && !prefer_general_.load() && std::getenv("GDV_NO_OPTFLAT") == nullptr;
     auto general_kernel = [&]() -> Status {
       if (kernel_general_.load() == nullptr) {
         const CompiledKernel* k = nullptr;
@@ -709,18 +794,23 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       }
       return Status::OK();
     };
+    const int64_t scanner_grid = std::max<int64_t>(1, ntiles) + 1;  // one workgroup per tile + the scanner
     auto launch = [&]() -> Status {
-      if (plan_.has_flat_output && !optimistic) GDV_RETURN_NOT_OK(general_kernel());
-      active = (plan_.has_flat_output && !optimistic) ? kernel_general_.load() : kernel_;
-      GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
-      if (optimistic && (err_bits & 16u)) {
+      if (optimistic && plan_.wave_tiles) {
+        GDV_RETURN_NOT_OK(run_wave());
+      } else {
+        if (has_optimistic && !optimistic) GDV_RETURN_NOT_OK(general_kernel());
+        active = (has_optimistic && !optimistic) ? kernel_general_.load() : kernel_;
+        GDV_RETURN_NOT_OK(run(scanner_grid));
+      }
+      if (optimistic && (err_bits & 48u)) {
         optimistic = false;
         prefer_general_.store(true);
         GDV_RETURN_NOT_OK(general_kernel());
         active = kernel_general_.load();
-        GDV_RETURN_NOT_OK(run(GridFor(plan_, out_rows)));
+        GDV_RETURN_NOT_OK(run(scanner_grid));
       }
-      err_bits &= ~16u;
+      err_bits &= ~48u;
       if (err_bits & 8u) {
         // The scan made no progress for a very long time: some workgroup of the grid was not
         // scheduled while later ones waited for it.  Never observed (workgroups start in index
@@ -914,6 +1004,8 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
   // the variant without the optimistic flat path is otherwise compiled only when a batch needs it
   if (!plan.source_general.empty() && std::getenv("GDV_PRECOMPILE_SKIP_GENERAL") == nullptr)
     GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source_general, plan.kernel_name_general, &code));
+  if (plan.prepass)
+    GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.prepass->source, plan.prepass->kernel_name, &code));
   return Status::OK();
 }
 

@@ -87,6 +87,8 @@ class Projector {
   mutable std::atomic<const CompiledKernel*> kernel_general_{nullptr};  // without the optimistic flat path (lazy)
   mutable std::atomic<bool> prefer_general_{false};  // a batch raised NOTFLAT: stop trying the optimistic variant
   DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
+  const CompiledKernel* kernel_pre_ = nullptr;  // wave-shaped plans: the pre-pass kernel (byte totals per wave tile)
+  DeviceBuffer consts_pre_;
   // two-stage plans (StageMaterialisedValues): pre_ materialises the hoisted sub-trees as
   // temporary columns, plan_ is built over plan_schema_ = schema_ + those columns
   std::shared_ptr<Projector> pre_;

@@ -27,7 +27,6 @@ CodegenOptions CodegenOptions::FromEnv() {
   if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_SCALAR_BITMAPS")) o.scalar_bitmaps = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
-  if (const char* s = std::getenv("GDV_EARLY_POST")) o.early_post = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_BITMAPS_LAST")) o.bitmaps_last = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_WPE")) o.waves_per_eu = std::max(0, std::min(8, atoi(s)));
   return o;
@@ -35,7 +34,7 @@ CodegenOptions CodegenOptions::FromEnv() {
 
 std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
-         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + (early_post ? "ep" : "") + "e" + std::to_string(waves_per_eu);
+         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + "e" + std::to_string(waves_per_eu);
 }
 
 // ------------------------------------------------------------------ validation
@@ -239,6 +238,7 @@ struct VarlenOut {
   int flat_slot = -1;             // >= 0: the row is input slot flat_slot's whole row ...
   int flat_map = 0;               // ... read through this byte map
   int window = -1;                // >= 0: LDS staging window of this output (non-flat outputs)
+  int segment = -1;               // wave shape: index of this output's array of wave-tile totals / bases
 };
 
 class CodeGen {
@@ -1189,66 +1189,11 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
 }
 
 
-// ------------------------------------------------------------------ string plans
-// Kernels that read or write var-len columns use their own skeleton (round 2):
-//   tile     one workgroup = GDV_WAVES waves x GDV_U sub-tiles x 64 rows; a wave's rows occupy ONE
-//            contiguous span of each var-len input's data buffer
-//   sweep    lanes over the BYTES of that span: tile-wide ASCII flag, '%needle%' match bitmaps
-//   rows     lane = row: the fused expression bodies; var-len results are kept as views
-//   offsets  per-wave DPP scan of the lengths -> workgroup totals -> ONE granule posted to the
-//            scanner wave (workgroup 0), ONE granule polled for the tile's exclusive prefix
-//   bytes    staged in LDS while waiting, flushed coalesced; or streamed flat when the output
-//            IS the (mapped) input span
-// Single launch, inputs read once (round 1: two passes, 1.43 x the algorithmic traffic).
-Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
-                       const WordAccumulators& accs, const std::string& decls_before_loop,
-                       const std::string& epilogue_after_loop) {
-  plan->input_fields = cg.input_fields_;
-  plan->input_needs_values = cg.needs_values_;
-  plan->input_needs_validity = cg.needs_validity_;
-  plan->can_raise = cg.can_raise_;
-  plan->string_skeleton = true;
-  for (size_t k = 0; k < plan->input_fields.size(); k++)
-    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
-  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
-  plan->layout.n_out = static_cast<int>(plan->output_types.size());
-  const int nv = static_cast<int>(cg.varlen_outs_.size());
-  const int ng = (nv + 1) / 2;
-  int nstage = 0;                              // LDS staging windows per wave
-  for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
-  const int nhook = static_cast<int>(cg.contains_hooks_.size());
-  plan->num_varlen_outputs = nv;
-  for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
-
-  Assembler as{cg, plan, {}};
-  as.Header(expr_strings);
-  std::ostringstream& s = as.src;
+// ---- pieces of the string skeletons shared by the scanner shape and the wave shape
+// pointers of the tile function: var-len / fixed-width inputs, outputs, the selection vector
+void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool with_outputs) {
   const bool sel = cg.selection();
   const int nin = plan->layout.n_in;
-  s << "#define GDV_NV " << nv << "\n#define GDV_NG " << ng << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
-    << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
-    << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
-    << (plan->opts.early_post && nv > 0 ? "#define GDV_NSTAGE_USED " + std::to_string(nstage) + "\n" : std::string())
-    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
-    << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
-    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
-    << "#define GDV_OUT(e, v) if (live" << (plan->opts.early_post && nv > 0 ? " && pass == 0" : "") << ") "
-    << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
-
-  s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
-    << "                      const int wave, gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint32 (*lds_tot)[GDV_NV > 0 ? GDV_NV : 1],\n"
-    << "                      gdv_uint64* lds_base) {\n"
-    << "  (void)lds_out; (void)lds_hit; (void)lds_tot; (void)lds_base; (void)ntiles;\n"
-    << "  gdv_ctx ctx{A.err};\n"
-    << "  (void)ctx;\n"
-    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
-    << "  (void)gdv_cst;\n"
-    << "  const gdv_int64 n = A.n;\n"
-    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
-    << "  const gdv_int64 rbase = wbase * 64;\n"
-    << "  constexpr bool optflat = GDV_OPTFLAT != 0;  // flat outputs: offsets = input offsets, bytes copied after the sweep\n"
-    << "  (void)optflat;\n";
-  if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
     if (t.is_varlen() && cg.needs_values_[k]) {
@@ -1260,7 +1205,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
         << "].data;\n";
     }
   }
-  for (size_t e = 0; e < plan->output_types.size(); e++) {
+  for (size_t e = 0; with_outputs && e < plan->output_types.size(); e++) {
     const DataType& t = plan->output_types[e];
     if (t.is_varlen()) {
       s << "  gdv_uint8* __restrict__ outd" << e << " = (gdv_uint8*)A.out[" << e << "].data;\n"
@@ -1327,113 +1272,13 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   }
   s << "  }\n";
 
-  // ---- sweep: lanes over the bytes of each var-len input's span
-  for (int k = 0; k < nin; k++) {
-    const DataType& t = cg.schema_[plan->input_fields[k]].type;
-    if (!(t.is_varlen() && cg.needs_values_[k])) continue;
-    std::vector<int> hooks;
-    for (int h = 0; h < nhook; h++)
-      if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
-    const bool want_ascii = cg.ascii_slots_.count(k) != 0;
-    std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
-    for (auto& vo : cg.varlen_outs_)
-      if (vo.flat_slot == k) flats.push_back(&vo);
-    const std::string K = std::to_string(k);
-    if (sel) {
-      s << "  const gdv_int32 sfl" << K << " = 0;\n";
-      continue;
-    }
-    // one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
-    s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
-      << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
-    if (!flats.empty())
-      s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
-    if (hooks.empty() && !want_ascii && flats.empty()) {
-      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
-      continue;
-    }
-    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n"
-      << "  const gdv_int32 sp0" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
-      << "  const gdv_int32 sp1" << K << " = __builtin_amdgcn_readlane(ob" << K << "[GDV_U - 1], 63);\n"
-      << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
-      << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
-      << "  (void)hm_ok" << K << ";\n"
-      << "  gdv_uint64 sacc" << K << " = 0;\n";
-    for (int h : hooks) {
-      const ContainsHook& hk = cg.contains_hooks_[h];
-      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
-      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
-        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
-        << ";  // the needle: a runtime constant\n"
-        << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
-        << " >> 8) & 0xffull) * GDV_B01;\n";
-    }
-    s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
-      << "    const gdv_int32 a = c + 16 * lane;\n"
-      << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
-      << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
-      << "    sacc" << K << " |= w[0] | w[1];\n";
-    if (!hooks.empty()) {
-      s << "    gdv_uint64 tail = 0;  // lane 63's halo: the first 8 bytes of the next step\n"
-        << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
-      for (int h : hooks) {
-        const ContainsHook& hk = cg.contains_hooks_[h];
-        const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
-        const std::string H = std::to_string(h), M = std::to_string(hk.map);
-        s << "    {\n"
-          << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
-          << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
-          << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-          << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
-          << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
-          << ") << 8);\n"
-          << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
-          << ") >> 4] = (gdv_uint16)m;\n"
-          << "    }\n";
-      }
-    }
-    s << "  }\n";
-    // optimistic flat outputs: their place in the output is known from the input offsets alone, so
-    // the span is copied right here, while the sweep's lines are still in L2 / L1.  (Moving the copy
-    // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
-    // slower: 1.90 vs 1.78 ms, same box, profiles/r02_c5_tuning.txt.)
-    for (auto* vo : flats)
-      s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
-        << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
-        << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
-    if (want_ascii)
-      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | (__ballot((sacc" << K
-        << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
-    else
-      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
-    if (!hooks.empty()) s << "  __builtin_amdgcn_wave_barrier();\n";
-  }
+}
 
-  // ---- row phase
-  s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
-  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
-  s << decls_before_loop;
-  const bool early = plan->opts.early_post && nv > 0;
-  if (early)
-    s << "  bool need_direct = false;\n"
-      << "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n"
-      << "  gdv_uint64* const lb_agg = A.mask;\n"
-      << "  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n"
-      << "  (void)lb_agg; (void)lb_pre;\n"
-      << "  // pass 0: lengths -> tile totals posted.  pass 1: output bytes staged in LDS while the scanner\n"
-      << "  // resolves the tile's prefix, then offsets + flush.  pass 2 (rare): rows of outputs whose bytes\n"
-      << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
-      << "  for (int pass = 0; pass < 3; pass++) {\n"
-      << "  if (pass == 2 && !need_direct) break;\n"
-      << "  if (pass != 1 || GDV_NSTAGE_USED > 0) {\n";
-  else if (nv > 0)
-    s << "  bool need_direct = false;\n"
-      << "  // pass 0: lengths, offsets, staged / flat bytes.  pass 1 (rare): rows of outputs whose bytes\n"
-      << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
-      << "  for (int pass = 0; pass < 2; pass++) {\n"
-      << "  if (pass == 1 && !need_direct) break;\n";
-  else
-    s << "  constexpr int pass = 0;\n  (void)pass;\n";
+// the rolled row loop: prologue (this sub-tile's inputs picked at index 0), the fused body, rotation
+// of the per-sub-tile registers; the caller appends its own rotations and closes the loop ("  }\n")
+void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
   // The row loop is NOT unrolled: the per-sub-tile registers are read and written through
   // gdv_pick / gdv_put (selects on the wave-uniform u), so the fused body exists once — a
   // quarter of the code, the compile time and the VGPRs of the unrolled form.
@@ -1482,10 +1327,194 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     }
     if (cg.needs_validity_[k] && sel) s << "    gdv_rot(b" << k << ");\n";
   }
+}
+
+// byte sweep of every var-len input: tile-wide ASCII flag, '%needle%' match bitmaps, flat outputs
+void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool wave_shape) {
+  const bool sel = cg.selection();
+  const int nin = plan->layout.n_in;
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());
+  // ---- sweep: lanes over the bytes of each var-len input's span
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+    std::vector<int> hooks;
+    for (int h = 0; h < nhook; h++)
+      if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
+    const bool want_ascii = cg.ascii_slots_.count(k) != 0;
+    std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
+    for (auto& vo : cg.varlen_outs_)
+      if (vo.flat_slot == k) flats.push_back(&vo);
+    const std::string K = std::to_string(k);
+    if (sel) {
+      s << "  const gdv_int32 sfl" << K << " = 0;\n";
+      continue;
+    }
+    // one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
+    if (wave_shape)
+      // (the span's ends come from two scalar loads: the byte sweep does not wait for the offsets' vector loads)
+      s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n"
+        << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n"
+        << "  const gdv_int32 inb" << K << " = sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    else
+      s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
+        << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    if (!flats.empty())
+      s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
+    if (hooks.empty() && !want_ascii && flats.empty()) {
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+      continue;
+    }
+    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n";
+    if (!wave_shape)
+      s << "  const gdv_int32 sp0" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+        << "  const gdv_int32 sp1" << K << " = __builtin_amdgcn_readlane(ob" << K << "[GDV_U - 1], 63);\n";
+    s << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
+      << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
+      << "  (void)hm_ok" << K << ";\n"
+      << "  gdv_uint64 sacc" << K << " = 0;\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
+        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
+        << ";  // the needle: a runtime constant\n"
+        << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
+        << " >> 8) & 0xffull) * GDV_B01;\n";
+    }
+    s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
+      << "    const gdv_int32 a = c + 16 * lane;\n"
+      << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
+      << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+      << "    sacc" << K << " |= w[0] | w[1];\n";
+    if (!hooks.empty()) {
+      s << "    gdv_uint64 tail = 0;  // lane 63's halo: the first 8 bytes of the next step\n"
+        << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
+      for (int h : hooks) {
+        const ContainsHook& hk = cg.contains_hooks_[h];
+        const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+        const std::string H = std::to_string(h), M = std::to_string(hk.map);
+        s << "    {\n"
+          << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
+          << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
+          << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
+          << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+          << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
+          << ") << 8);\n"
+          << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
+          << ") >> 4] = (gdv_uint16)m;\n"
+          << "    }\n";
+      }
+    }
+    if (wave_shape)
+      // flat outputs leave straight from the sweep's registers (prototype: -0.08 ms on C5 against a
+      // second pass over the span, profiles/r03_k4_experiments.txt); a piece's bytes outside this
+      // wave's span [sp0, sp1) belong to the neighbouring tiles
+      for (auto* vo : flats)
+        s << "    if (!(GDV_ABL & 8) && a < sp1" << K << ") gdv_sweep_store(outd" << vo->e << ", (gdv_int64)a - so0_" << K
+          << ", w, " << vo->flat_map << ", sp0" << K << " - a, sp1" << K << " - a, A.out[" << vo->e << "].cap);\n";
+    s << "  }\n";
+    // optimistic flat outputs: their place in the output is known from the input offsets alone, so
+    // the span is copied right here, while the sweep's lines are still in L2 / L1.  (Moving the copy
+    // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
+    // slower: 1.90 vs 1.78 ms, same box, profiles/r02_c5_tuning.txt.)
+    for (auto* vo : flats)
+      if (!wave_shape)
+      s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
+        << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
+        << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
+    if (want_ascii && wave_shape)
+      // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
+      // fact for the row bodies — every general UTF-8 path folds away — and a tile that breaks it
+      // raises NOTASCII: the host re-runs the batch on the general (scanner) kernel
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n"
+        << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
+    else if (want_ascii)
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | (__ballot((sacc" << K
+        << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
+    else
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+    if (!hooks.empty()) s << "  __builtin_amdgcn_wave_barrier();\n";
+  }
+
+}
+
+// ------------------------------------------------------------------ string plans
+// Kernels that read or write var-len columns use their own skeleton (round 2):
+//   tile     one workgroup = GDV_WAVES waves x GDV_U sub-tiles x 64 rows; a wave's rows occupy ONE
+//            contiguous span of each var-len input's data buffer
+//   sweep    lanes over the BYTES of that span: tile-wide ASCII flag, '%needle%' match bitmaps
+//   rows     lane = row: the fused expression bodies; var-len results are kept as views
+//   offsets  per-wave DPP scan of the lengths -> workgroup totals -> ONE granule posted to the
+//            scanner wave (workgroup 0), ONE granule polled for the tile's exclusive prefix
+//   bytes    staged in LDS while waiting, flushed coalesced; or streamed flat when the output
+//            IS the (mapped) input span
+// Single launch, inputs read once (round 1: two passes, 1.43 x the algorithmic traffic).
+Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
+                       const WordAccumulators& accs, const std::string& decls_before_loop,
+                       const std::string& epilogue_after_loop) {
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = cg.can_raise_;
+  plan->string_skeleton = true;
+  for (size_t k = 0; k < plan->input_fields.size(); k++)
+    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const int nv = static_cast<int>(cg.varlen_outs_.size());
+  const int ng = (nv + 1) / 2;
+  int nstage = 0;                              // LDS staging windows per wave
+  for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());
+  plan->num_varlen_outputs = nv;
+  for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
+
+  Assembler as{cg, plan, {}};
+  as.Header(expr_strings);
+  std::ostringstream& s = as.src;
+  s << "#define GDV_NV " << nv << "\n#define GDV_NG " << ng << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
+    << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
+    << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
+    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
+    << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
+    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
+    << "#define GDV_OUT(e, v) if (live) "
+    << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+
+  s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 tile, const gdv_int64 ntiles, const int lane,\n"
+    << "                      const int wave, gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint32 (*lds_tot)[GDV_NV > 0 ? GDV_NV : 1],\n"
+    << "                      gdv_uint64* lds_base) {\n"
+    << "  (void)lds_out; (void)lds_hit; (void)lds_tot; (void)lds_base; (void)ntiles;\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n"
+    << "  constexpr bool optflat = GDV_OPTFLAT != 0;  // flat outputs: offsets = input offsets, bytes copied after the sweep\n"
+    << "  (void)optflat;\n";
+  if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
+  EmitStringPointersAndLoads(s, cg, plan, true);
+  EmitStringSweep(s, cg, plan, /*wave_shape=*/false);
+
+  // ---- row phase
+  s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
+  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
+  s << decls_before_loop;
+  if (nv > 0)
+    s << "  bool need_direct = false;\n"
+      << "  // pass 0: lengths, offsets, staged / flat bytes.  pass 1 (rare): rows of outputs whose bytes\n"
+      << "  // neither fit the LDS window nor are a flat span are recomputed and copied straight to HBM.\n"
+      << "  for (int pass = 0; pass < 2; pass++) {\n"
+      << "  if (pass == 1 && !need_direct) break;\n";
+  else
+    s << "  constexpr int pass = 0;\n  (void)pass;\n";
+  EmitStringRowLoop(s, cg, plan);
   for (auto& vo : cg.varlen_outs_) s << "    gdv_rot(lc" << vo.e << ");\n";
   s << "  }\n";
-  if (early) s << "  }\n  if (pass == 2) break;\n  if (pass == 0) {\n";
-  else if (nv > 0) s << "  if (pass == 1) break;\n";
+  if (nv > 0) s << "  if (pass == 1) break;\n";
   for (auto& vo : cg.varlen_outs_)
     if (vo.flat_slot >= 0)
       s << "  if (optflat && fb" << vo.e << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n";
@@ -1503,19 +1532,17 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     for (int v = 0; v < nv; v++)
       s << "    lds_tot[wave][" << v << "] = (gdv_uint32)run" << cg.varlen_outs_[v].e << ";\n";
     s << "  }\n  __syncthreads();\n"
-      << (early ? "" : "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n")
+      << "  gdv_uint64 before[GDV_NV], all[GDV_NV];\n"
       << "#pragma unroll\n  for (int v = 0; v < GDV_NV; v++) { before[v] = 0; all[v] = 0; }\n"
       << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
       << "#pragma unroll\n    for (int v = 0; v < GDV_NV; v++) {\n"
       << "      const gdv_uint32 t = lds_tot[w][v];\n      all[v] += t;\n      before[v] += w < wave ? t : 0u;\n    }\n  }\n"
-      << (early ? "" : "  gdv_uint64* const lb_agg = A.mask;\n  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n")
+      << "  gdv_uint64* const lb_agg = A.mask;\n  gdv_uint64* const lb_pre = A.mask + (gdv_int64)GDV_NG * ntiles;\n"
       << "  if (threadIdx.x == 0) {\n";
     for (int g = 0; g < ng; g++)
       s << "    gdv_lb_post(lb_agg, ntiles, tile, " << g << ", all[" << 2 * g << "], "
         << (2 * g + 1 < nv ? "all[" + std::to_string(2 * g + 1) + "]" : std::string("0ull")) << ");\n";
     s << "  }\n";
-    // early post: the totals are out; the row loop runs again (staging) before anybody waits
-    if (early) s << (all_flat ? "  }\n  if (optflat) break;\n" : "") << "  continue;\n  }\n" << (all_flat ? "  if (!optflat) {\n" : "");
     s << "  if (threadIdx.x == 0) {\n"
       << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = (GDV_ABL & 32) ? (gdv_uint64)tile * 4000 : gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
       << "  }\n  __syncthreads();\n";
@@ -1610,114 +1637,355 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   return Status::OK();
 }
 
+// ------------------------------------------------------------------ string plans, wave shape (round 3)
+// Var-len plans whose output lengths are a function of the input OFFSETS (and of fixed-width
+// inputs) once the bytes are assumed ASCII — substr / left / right / upper / lower / concat /
+// castVARCHAR over columns and literals: C5 — need no hand-off inside the kernel at all:
+//   pre-pass  (kPrepass) the same row bodies reduced to their lengths, views built from the offsets
+//             only: one byte total per wave tile and output -> `counts`
+//   scan      ScanReduce / Spine / Apply over the wave-tile totals (gdv_kernels.hip) -> `mask`
+//   main      (kMain) every WAVE is an independent tile: its output base is one scalar load; no
+//             scanner workgroup, no look-back, no workgroup barrier, no LDS shared between waves;
+//             flat outputs leave straight from the byte sweep's registers
+// Measured on the hand-written prototype (tools/proto/k4h_proto.hip, profiles/r03_k4_experiments.txt):
+// 1.82 ms (scanner shape) -> 0.90-0.97 ms on C5.  The ASCII assumption is checked by the sweep: a
+// tile that breaks it raises NOTASCII and the host re-runs the batch on the scanner-shaped kernel.
+enum class WaveKind { kMain, kPrepass };
+
+Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& expr_strings,
+                           const WordAccumulators& accs, const std::string& decls_before_loop,
+                           const std::string& decls_in_pass, const std::string& after_row_loop,
+                           const std::string& epilogue_after_loop, WaveKind kind, bool has_direct_pass) {
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = cg.can_raise_;
+  plan->string_skeleton = true;
+  plan->wave_tiles = true;
+  for (size_t k = 0; k < plan->input_fields.size(); k++)
+    plan->has_varlen_input |= cg.schema_[plan->input_fields[k]].type.is_varlen() && cg.needs_values_[k];
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const bool prepass = kind == WaveKind::kPrepass;
+  const int nv = static_cast<int>(cg.varlen_outs_.size());
+  int nstage = 0;
+  for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
+  const int nhook = prepass ? 0 : static_cast<int>(cg.contains_hooks_.size());
+  plan->num_varlen_outputs = prepass ? 0 : nv;
+  for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
+
+  Assembler as{cg, plan, {}};
+  as.Header(expr_strings);
+  std::ostringstream& s = as.src;
+  const int nin = plan->layout.n_in;
+  s << "// " << (prepass ? "pre-pass: byte totals per wave tile from the offsets alone (optimistic ASCII)"
+                         : "wave shape: independent wave tiles, output bases from the pre-pass + scan")
+    << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
+    << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
+    << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
+    << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
+    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n"
+    << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+
+  s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wt, const int lane, const int wave,\n"
+    << "                      gdv_uint8* lds_out, gdv_uint64* lds_hit) {\n"
+    << "  (void)lds_out; (void)lds_hit; (void)wave;\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
+    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 wbase = wt * GDV_U;\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n"
+    << "  if (rbase >= n) return;  // (no barrier anywhere below: waves are independent)\n"
+    << "  const bool last_tile = rbase + 64 * GDV_U >= n;  // the wave tile that holds the batch's last row\n"
+    << "  const gdv_int64 seg_stride = A.aux1;  // wave-tile totals / bases: one array of seg_stride entries per scanned output\n"
+    << "  (void)last_tile; (void)seg_stride;\n";
+  EmitStringPointersAndLoads(s, cg, plan, !prepass);
+  if (prepass) {
+    // no byte is read: views are (offset, length) pairs carrying the flags the main kernel assumes
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (t.is_varlen() && cg.needs_values_[k])
+        s << "  const gdv_int32 sfl" << k << " = GDV_STR_ASCII | GDV_STR_INBUF;\n";
+    }
+  } else {
+    EmitStringSweep(s, cg, plan, /*wave_shape=*/true);
+  }
+
+  s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
+  for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
+  s << decls_before_loop;
+  if (has_direct_pass)
+    s << "  bool need_direct = false;\n"
+      << "  // pass 0: offsets + bytes staged in LDS.  pass 1 (rare): outputs whose bytes do not fit the\n"
+      << "  // LDS window are recomputed and copied straight to HBM.\n"
+      << "  for (int pass = 0; pass < 2; pass++) {\n"
+      << "  if (pass == 1 && !need_direct) break;\n";
+  else
+    s << "  constexpr int pass = 0;\n  (void)pass;\n";
+  s << decls_in_pass;
+  EmitStringRowLoop(s, cg, plan);
+  s << "  }\n";
+  if (has_direct_pass) s << "  if (pass == 1) break;\n";
+  s << after_row_loop;
+  s << epilogue_after_loop;
+  if (has_direct_pass) s << "  }  // pass\n";
+  s << "}\n\n";
+
+  s << "#ifndef GDV_STRING_KERNEL_ATTR\n#define GDV_STRING_KERNEL_ATTR\n#endif\n"
+    << "extern \"C\" __global__ void GDV_STRING_KERNEL_ATTR __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
+  if (prepass)
+    s << "  gdv_tile(A, (gdv_int64)blockIdx.x * GDV_WAVES + wave, lane, wave, nullptr, nullptr);\n";
+  else
+    s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
+      << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
+      << "  gdv_tile(A, (gdv_int64)blockIdx.x * GDV_WAVES + wave, lane, wave, gdv_lds_out[wave], gdv_lds_hit[wave]);\n";
+  s << "}\n";
+
+  std::string text = s.str();
+  uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
+  char name[64];
+  snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+  plan->kernel_name = name;
+  size_t pos = text.find("GDV_KERNEL_NAME");
+  text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
+  plan->source = text;
+  plan->ir = text;
+  return Status::OK();
+}
+
 }  // namespace
 
-Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
-                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan) {
-  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
-  for (auto& e : exprs) {
-    if (!e) return Status::Invalid("Expression cannot be null");
-    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+namespace {
+
+enum class StringShape { kScanner, kWaveMain, kWavePrepass };
+
+// Is the value of `n` — and its validity — computable without reading a single var-len BYTE once
+// every string is assumed ASCII?  (offsets, validity bitmaps, fixed-width values and literals are
+// free.)  Outputs with that property let a plan take the wave shape: their byte totals come from a
+// pre-pass over the offsets.
+bool ByteFree(const Node& n) {
+  static const std::set<std::string> over_strings = {
+      "substr", "substring", "left", "right", "upper", "lower", "octet_length", "bit_length", "char_length",
+      "length", "lengthUtf8", "castVARCHAR", "concat", "concatOperator", "reverse", "lpad", "rpad", "isnull",
+      "isnotnull"};
+  switch (n.kind()) {
+    case NodeKind::kField:
+    case NodeKind::kLiteral:
+      return true;
+    case NodeKind::kFunction: {
+      auto& fn = static_cast<const FunctionNode&>(n);
+      bool takes_strings = false;
+      for (auto& c : fn.children()) {
+        if (!ByteFree(*c)) return false;
+        takes_strings |= c->return_type().is_varlen();
+      }
+      return !takes_strings || over_strings.count(fn.name()) != 0;
+    }
+    case NodeKind::kIf: {
+      auto& i = static_cast<const IfNode&>(n);
+      return ByteFree(*i.condition()) && ByteFree(*i.then_node()) && ByteFree(*i.else_node());
+    }
+    case NodeKind::kBoolean:
+      for (auto& c : static_cast<const BooleanNode&>(n).children())
+        if (!ByteFree(*c)) return false;
+      return true;
+    case NodeKind::kIn: {
+      auto& in = static_cast<const InNode&>(n);
+      return !in.value_type().is_varlen() && ByteFree(*in.eval());
+    }
   }
+  return false;
+}
+
+// One shape of a projector's kernel.  kWavePrepass generates only the expressions listed in
+// `only` (the scanned var-len outputs of the main kernel, in that order = segment order).
+Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>& exprs, SelectionMode mode,
+                          const CodegenOptions& opts, StringShape shape, const std::vector<int>* only,
+                          KernelPlan* plan, std::vector<VarlenOut>* varlen_outs) {
   plan->kind = KernelKind::kProject;
   plan->mode = mode;
   plan->opts = opts;
   CodeGen cg(schema, mode, opts);
   WordAccumulators accs;
-  std::ostringstream after_loop, before_loop;
+  std::ostringstream after_loop, before_loop, in_pass, after_rows;
   std::vector<std::string> strings;
-  int num_staged = 0;
-  const std::string st = opts.nontemporal ? "gdv_stnt" : "gdv_st";
-  for (auto& e : exprs) plan->has_varlen_output |= e->result().type.is_varlen();
+  int num_staged = 0, num_scanned = 0;
+  const bool wave = shape != StringShape::kScanner;
+  const bool prepass = shape == StringShape::kWavePrepass;
+  if (!prepass)
+    for (auto& e : exprs) plan->has_varlen_output |= e->result().type.is_varlen();
+  // 64 lengths below 2^25 cannot wrap the 32-bit scan; otherwise the total is taken on 16-bit
+  // halves and saturates (the host rejects outputs of 2 GiB or more)
+  auto tile_total = [](const std::string& ln, const std::string& inc) {
+    return "(__builtin_expect(__ballot(" + ln + " >= (1 << 25)) != 0, 0) ? gdv_tile_total(" + ln +
+           ") : (gdv_uint32)gdv_wave_last(" + inc + "))";
+  };
   for (size_t e = 0; e < exprs.size(); e++) {
+    if (only != nullptr && std::find(only->begin(), only->end(), static_cast<int>(e)) == only->end()) continue;
     Val v;
     cg.Stmt("// @expr_" + std::to_string(e));
     GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "", &v));
     const DataType& t = exprs[e]->result().type;
-    plan->output_types.push_back(t);
+    if (!prepass) plan->output_types.push_back(t);
     strings.push_back(exprs[e]->ToString());
     const std::string E = std::to_string(e);
     if (t.is_varlen()) {
-      // The row's bytes are one view, or the pieces of a concat written back to back.  Views
-      // are kept per sub-tile (registers) until the tile's base offset is known; lengths are
+      // The row's bytes are one view, or the pieces of a concat written back to back; lengths are
       // prefix-summed inside the wave on the DPP data path.
       const std::string ok = cg.Tmp("bool", CodeGen::AndFull("live", cg.LaneValid(v)));
       VarlenOut vo;
       vo.e = static_cast<int>(e);
-      const int vidx = static_cast<int>(cg.varlen_outs_.size());
       const bool flat_cand = v.pieces.empty() && v.col_slot >= 0 && !cg.selection();
       const bool has_window = !flat_cand && num_staged < 3;  // LDS staging windows per wave
       std::vector<std::pair<std::string, std::string>> pieces = v.pieces;
       if (pieces.empty()) pieces.emplace_back(v.v, "");
       std::string total;
       std::vector<std::string> pv;
-      for (size_t q = 0; q < pieces.size(); q++) {
-        const std::string name = "pv" + E + "_" + std::to_string(q);
-        pv.push_back(name);
-        cg.Stmt("gdv_str " + name + " = " + pieces[q].first + ";");
-        cg.Stmt("if (!(" + CodeGen::AndFull(ok, pieces[q].second) + ")) " + name + ".len = 0;");
-        total += (q ? " + " : "") + name + ".len";
+      auto emit_pieces = [&] {
+        for (size_t q = 0; q < pieces.size(); q++) {
+          const std::string name = "pv" + E + "_" + std::to_string(q);
+          pv.push_back(name);
+          cg.Stmt("gdv_str " + name + " = " + pieces[q].first + ";");
+          cg.Stmt("if (!(" + CodeGen::AndFull(ok, pieces[q].second) + ")) " + name + ".len = 0;");
+          total += (q ? " + " : "") + name + ".len";
+        }
+      };
+      if (prepass) {
+        // lengths only: one byte total per wave tile -> counts[segment][wave tile]
+        emit_pieces();
+        const std::string S = std::to_string(num_scanned++);
+        in_pass << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n";
+        cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+        cg.Stmt("{ const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
+        cg.Stmt("  const gdv_uint32 t = " + tile_total("ln" + E + "_u", "inc") + ";");
+        cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t)); }");
+        after_rows << "  if (lane == 0) A.counts[" << S << " * seg_stride + wt] = (gdv_uint32)run" << E << ";\n";
+        cg.varlen_outs_.push_back(vo);
+        continue;
       }
-      before_loop << "  gdv_int32 lc" << E << "[GDV_U] = {};  // where each row's bytes start inside the wave tile\n"
-                  << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n"
-                  << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM at dbase" << E << "\n"
-                  << "  gdv_int64 dbase" << E << " = 0;\n";
-      if (flat_cand) {
+      if (wave && flat_cand) {
+        // the output IS the (mapped) input span: offsets = the input's, rebased; bytes leave from the
+        // byte sweep.  Only wrong if a NULL row carries bytes: NOTFLAT, the host re-runs (general kernel).
         vo.flat_slot = v.col_slot;
         vo.flat_map = v.col_map;
         const std::string K = std::to_string(v.col_slot);
+        const int vidx = static_cast<int>(cg.varlen_outs_.size());
         before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
-        // optimistic flat variant of the kernel (compile-time): the bytes are copied after the
-        // sweep and the offsets are the input's, rebased: nothing of this output is scanned
-        cg.Stmt("if (optflat) {");
-        cg.Stmt("  if (pass == 0) {");
-        cg.Stmt("    if (live) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
-        cg.Stmt("    fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
-        cg.Stmt("  }");
-        cg.Stmt("} else {");
-      }
-      cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
-      cg.Stmt("if (pass == 0) {");
-      cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
-      cg.Stmt("  lc" + E + "[0] = run" + E + " + inc - ln" + E + "_u;");
-      // 64 lengths below 2^25 cannot wrap the 32-bit scan; otherwise the total is taken on
-      // 16-bit halves and saturates (the host rejects outputs of 2 GiB or more)
-      cg.Stmt("  const gdv_uint32 t = __builtin_expect(__ballot(ln" + E + "_u >= (1 << 25)) != 0, 0) ? gdv_tile_total(ln" + E +
-              "_u) : (gdv_uint32)gdv_wave_last(inc);");
-      cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t));");
-      if (flat_cand) {
-        const std::string K = std::to_string(v.col_slot);
-        cg.Stmt("  fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
-      }
-      if (has_window) {
-        vo.window = num_staged++;
-        before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
-        // stage while the view is at hand (rows that fall outside the window are skipped: the
-        // tile then takes the second, direct pass)
-        if (opts.early_post) cg.Stmt("} else if (pass == 1) {");  // ... or in a row pass of its own, after the post
-        cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
+        cg.Stmt("if (live) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
+        cg.Stmt("fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+        after_rows << "  if (fb" << E << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n"
+                   << "  if (last_tile && lane == 0) {  // closing offset + byte total of a flat output\n"
+                   << "    outo" << E << "[n] = sp1" << K << " - so0_" << K << ";\n"
+                   << "    ((gdv_uint64*)A.counts)[" << vidx << "] = (gdv_uint64)(sp1" << K << " - so0_" << K << ");\n"
+                   << "  }\n";
+        cg.varlen_outs_.push_back(vo);
+      } else if (wave) {
+        // scanned output: the wave tile's base comes from the pre-pass + scan (one scalar load)
+        emit_pieces();
+        const std::string S = std::to_string(num_scanned++);
+        vo.segment = num_scanned - 1;
+        before_loop << "  const gdv_int64 base" << E << " = (gdv_int64)A.mask[" << S << " * seg_stride + wt];\n"
+                    << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM\n";
+        in_pass << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n";
+        cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+        cg.Stmt("const gdv_int32 inc" + E + " = gdv_wave_scan_incl(ln" + E + "_u);");
+        cg.Stmt("const gdv_int32 loc" + E + " = run" + E + " + inc" + E + " - ln" + E + "_u;  // where the row's bytes start inside the wave tile");
+        cg.Stmt("{ const gdv_uint32 t = " + tile_total("ln" + E + "_u", "inc" + E) + ";");
+        cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t)); }");
+        cg.Stmt("if (pass == 0) {");
+        cg.Stmt("  if (live) outo" + E + "[row] = (gdv_int32)(base" + E + " + loc" + E + ");");
+        if (has_window) {
+          vo.window = num_staged++;
+          before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
+          cg.Stmt("  gdv_int32 at = loc" + E + ";");
+          for (auto& name : pv) {
+            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
+                    " + at), " + name + ");");
+            cg.Stmt("  at += " + name + ".len;");
+          }
+        }
+        cg.Stmt("} else if (dir" + E + ") {");
+        cg.Stmt("  gdv_uint8* at = outd" + E + " + base" + E + " + loc" + E + ";");
         for (auto& name : pv) {
-          cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
-                  " + at), " + name + ");");
+          cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");
           cg.Stmt("  at += " + name + ".len;");
         }
+        cg.Stmt("}");
+        after_rows << "  if (run" << E << " < 0x7fffffff && base" << E << " + run" << E << " <= A.out[" << E << "].cap) {\n";
+        if (has_window)
+          after_rows << "    if (run" << E << " <= GDV_OUT_WIN) {\n"
+                     << "      if (!(GDV_ABL & 16)) gdv_flush_out(outd" << E << " + base" << E << ", win" << E << ", run" << E << ", lane);\n"
+                     << "    } else {\n      dir" << E << " = true;\n      need_direct = true;\n    }\n";
+        else
+          after_rows << "    dir" << E << " = true;\n    need_direct = true;\n";
+        after_rows << "  }\n";
+        cg.varlen_outs_.push_back(vo);
+      } else {
+        emit_pieces();
+        before_loop << "  gdv_int32 lc" << E << "[GDV_U] = {};  // where each row's bytes start inside the wave tile\n"
+                    << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n"
+                    << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM at dbase" << E << "\n"
+                    << "  gdv_int64 dbase" << E << " = 0;\n";
+        if (flat_cand) {
+          vo.flat_slot = v.col_slot;
+          vo.flat_map = v.col_map;
+          const std::string K = std::to_string(v.col_slot);
+          before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
+          // optimistic flat variant of the kernel (compile-time): the bytes are copied after the
+          // sweep and the offsets are the input's, rebased: nothing of this output is scanned
+          cg.Stmt("if (optflat) {");
+          cg.Stmt("  if (pass == 0) {");
+          cg.Stmt("    if (live) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
+          cg.Stmt("    fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+          cg.Stmt("  }");
+          cg.Stmt("} else {");
+        }
+        cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
+        cg.Stmt("if (pass == 0) {");
+        cg.Stmt("  const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
+        cg.Stmt("  lc" + E + "[0] = run" + E + " + inc - ln" + E + "_u;");
+        // 64 lengths below 2^25 cannot wrap the 32-bit scan; otherwise the total is taken on
+        // 16-bit halves and saturates (the host rejects outputs of 2 GiB or more)
+        cg.Stmt("  const gdv_uint32 t = __builtin_expect(__ballot(ln" + E + "_u >= (1 << 25)) != 0, 0) ? gdv_tile_total(ln" + E +
+                "_u) : (gdv_uint32)gdv_wave_last(inc);");
+        cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t));");
+        if (flat_cand) {
+          const std::string K = std::to_string(v.col_slot);
+          cg.Stmt("  fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
+        }
+        if (has_window) {
+          vo.window = num_staged++;
+          before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
+          // stage while the view is at hand (rows that fall outside the window are skipped: the
+          // tile then takes the second, direct pass)
+          cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
+          for (auto& name : pv) {
+            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
+                    " + at), " + name + ");");
+            cg.Stmt("  at += " + name + ".len;");
+          }
+        }
+        cg.Stmt("} else if (dir" + E + ") {");
+        cg.Stmt("  gdv_uint8* at = outd" + E + " + dbase" + E + " + lc" + E + "[0];");
+        for (auto& name : pv) {
+          cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");
+          cg.Stmt("  at += " + name + ".len;");
+        }
+        cg.Stmt("}");
+        if (flat_cand) cg.Stmt("}");
+        cg.varlen_outs_.push_back(vo);
       }
-      cg.Stmt(std::string("} else if (") + (opts.early_post ? "pass == 2 && " : "") + "dir" + E + ") {");
-      cg.Stmt("  gdv_uint8* at = outd" + E + " + dbase" + E + " + lc" + E + "[0];");
-      for (auto& name : pv) {
-        cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");
-        cg.Stmt("  at += " + name + ".len;");
-      }
-      cg.Stmt("}");
-      if (flat_cand) cg.Stmt("}");
-      (void)vidx;
-      cg.varlen_outs_.push_back(vo);
     } else if (t.id == kBool) {
       std::string acc = accs.Get(cg, "__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
       after_loop << WordStore(acc, "((gdv_uint64*)A.out[" + E + "].data)");
     } else {
       cg.Stmt("GDV_OUT(" + E + ", (" + t.CType() + ")" + v.v + ");");
     }
+    if (prepass) continue;
     // validity word of the 64 rows of this sub-tile
     std::string word;
     if (cg.selection()) {
@@ -1732,7 +2000,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   // input bytes/row), within a budget of 512 input bytes per lane.  Wide plans (C2: 32 B/row,
   // ten outputs) stay at 4 — measured optimum, more sub-tiles cost occupancy — narrow plans
   // (C1: 12 B/row) go to 16 (+3 % measured).
-  bool string_plan = plan->has_varlen_output;
+  bool string_plan = plan->has_varlen_output || wave;
   for (size_t k = 0; k < cg.input_fields_.size(); k++)
     string_plan |= schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k];
   if (string_plan) {
@@ -1742,8 +2010,14 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     // per SIMD) and win: 1.70 vs 1.83 ms (profiles/r02_c5_tuning.txt)
     if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = 4;
     if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    if (varlen_outs != nullptr) *varlen_outs = cg.varlen_outs_;
+    if (wave)
+      return AssembleStringsWave(cg, plan, strings, accs, before_loop.str(), in_pass.str(), after_rows.str(),
+                                 after_loop.str(), prepass ? WaveKind::kPrepass : WaveKind::kMain,
+                                 !prepass && num_scanned > 0);
     return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
   }
+  if (wave) return Status::CodeGenError("internal: wave shape asked for a plan without var-len columns");
   if (std::getenv("GDV_U") == nullptr) {
     int in_bytes = 0;
     bool any_varlen = false;
@@ -1759,6 +2033,70 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     }
   }
   return Assemble(cg, plan, strings, accs, before_loop.str(), after_loop.str());
+}
+
+
+}  // namespace
+
+Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
+                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan) {
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+  }
+  // Wave shape (pre-pass + scan + independent wave tiles): row mode, at least one var-len output,
+  // and every var-len output's bytes-free under the ASCII assumption.  Everything else — and the
+  // re-run of a batch that breaks the assumption — takes the scanner shape.
+  bool wave_ok = mode == SelectionMode::kNone && std::getenv("GDV_NO_WAVE_SHAPE") == nullptr;
+  bool any_varlen_out = false;
+  for (auto& e : exprs) {
+    if (!e->result().type.is_varlen()) continue;
+    any_varlen_out = true;
+    wave_ok = wave_ok && ByteFree(*e->root());
+  }
+  if (!(wave_ok && any_varlen_out))
+    return PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, plan, nullptr);
+
+  KernelPlan fast, slow;
+  std::vector<VarlenOut> vouts;
+  GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, opts, StringShape::kWaveMain, nullptr, &fast, &vouts));
+  GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, &slow, nullptr));
+  // one argument block serves both kernels: the two generations must have bound the same inputs,
+  // literals and constants (they run the same tree walk; checked, not assumed)
+  if (fast.input_fields != slow.input_fields || fast.input_needs_values != slow.input_needs_values ||
+      fast.input_needs_validity != slow.input_needs_validity || fast.literals != slow.literals ||
+      fast.const_block != slow.const_block || fast.opts.subtiles != slow.opts.subtiles ||
+      fast.opts.waves != slow.opts.waves) {
+    *plan = slow;
+    return Status::OK();
+  }
+  std::vector<int> scanned;
+  for (auto& vo : vouts)
+    if (vo.flat_slot < 0) scanned.push_back(vo.e);
+  if (static_cast<int>(scanned.size()) > kMaxWaveSegments) {
+    *plan = slow;
+    return Status::OK();
+  }
+  *plan = fast;
+  plan->can_raise = fast.can_raise || slow.can_raise;
+  // the fallback: the scanner-shaped kernel with every output on the general path
+  plan->kernel_name_general = slow.has_flat_output ? slow.kernel_name_general : slow.kernel_name;
+  plan->source_general = slow.has_flat_output ? slow.source_general : slow.source;
+  plan->wave_segments.clear();
+  for (auto& vo : vouts) plan->wave_segments.push_back(vo.flat_slot < 0 ? vo.segment : -1);
+  if (!scanned.empty()) {
+    auto pre = std::make_shared<KernelPlan>();
+    CodegenOptions popts = fast.opts;  // same tile: a wave tile of the pre-pass IS a wave tile of the main kernel
+    GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, popts, StringShape::kWavePrepass, &scanned, pre.get(), nullptr));
+    if (pre->opts.subtiles != fast.opts.subtiles) {
+      *plan = slow;
+      return Status::OK();
+    }
+    plan->prepass = pre;
+    plan->ir = pre->source + fast.source;
+  }
+  return Status::OK();
 }
 
 Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,

@@ -9,6 +9,7 @@
 // once, and validity is merged per 64-row word in scalar registers.
 #pragma once
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -37,11 +38,6 @@ struct CodegenOptions {
   bool bitmaps_last = false;   // issue the bitmap-word loads behind the value loads (GDV_BITMAPS_LAST)
   int waves_per_eu = 0;        // > 0: amdgpu_waves_per_eu(n, n) on fixed-width kernels (GDV_WPE): lets the compiler keep every load in flight
   bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
-  // String plans (GDV_EARLY_POST=1; NOT measured yet, off): the row loop runs once for the lengths,
-  // the tile totals are posted, and the LDS staging of the output bytes happens in a second run of
-  // the row loop — in the shadow of the scanner hand-off, as the hand-written prototype does
-  // (profiles/r02_k4_singlepass_proto.txt: its look-back costs 0.06 ms, the product's 0.35 ms)
-  bool early_post = false;
   static CodegenOptions FromEnv();
   std::string Key() const;
 };
@@ -87,8 +83,17 @@ struct KernelPlan {
   bool string_skeleton = false;    // tile = workgroup (waves x subtiles x 64 rows), no grid-stride
   int num_varlen_outputs = 0;
   bool has_flat_output = false;    // some var-len output is an input column's (mapped) bytes
-  int rows_per_tile() const { return 64 * opts.subtiles * opts.waves; }
+  // Wave shape (round 3): tile = ONE wave (64 * subtiles rows), no scanner workgroup.  Var-len
+  // outputs that are not flat take their wave-tile bases from `prepass` (a kernel of its own: byte
+  // totals per wave tile from the offsets alone) + the offsets scan; wave_segments[v] = the
+  // segment of var-len output v, -1 for flat outputs.  source_general / kernel_name_general hold
+  // the scanner-shaped fallback (a batch that breaks the ASCII / flat assumption is re-run on it).
+  bool wave_tiles = false;
+  std::shared_ptr<KernelPlan> prepass;
+  std::vector<int> wave_segments;
+  int rows_per_tile() const { return 64 * opts.subtiles * (wave_tiles ? 1 : opts.waves); }
 };
+constexpr int kMaxWaveSegments = 8;
 
 // Validates every expression against the schema and the function registry, then emits the
 // fused kernel.  Errors: ExpressionValidationError for type / signature problems,

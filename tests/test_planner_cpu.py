@@ -52,18 +52,43 @@ def test_plans_that_differ_only_in_constants_share_one_kernel(monkeypatch, tmp_p
     assert "499" not in re.sub(r"^// @expr_.*$", "", text, flags=re.M)   # constants only in the header comment
 
 
-def test_string_projection_builds_an_optimistic_and_a_general_variant(monkeypatch, tmp_path):
-    """A plan with a flat var-len output (upper(col)) has two compile-time variants; both must
-    compile for gfx950 at build time, not on the first batch that needs the general one."""
+def test_string_projection_builds_wave_prepass_and_general_kernels(monkeypatch, tmp_path):
+    """C5 (like / substr / upper): the lengths of its var-len outputs follow from the offsets once
+    the bytes are assumed ASCII, so the plan takes the wave shape (round 3): a pre-pass kernel (byte
+    totals per wave tile, no byte read), the main kernel of independent wave tiles, and the
+    scanner-shaped general kernel a batch that breaks the assumption is re-run on.  All three must
+    compile for gfx950 at build time."""
     monkeypatch.delenv("GDV_PRECOMPILE_SKIP_GENERAL", raising=False)
     files = _precompile(monkeypatch, tmp_path, W.c5_schema(), exprs=W.c5_expressions())
-    assert len(files) == 2, files
-    defs = sorted(re.search(r"#define GDV_OPTFLAT (\d)", open(tmp_path / f).read()).group(1) for f in files)
-    assert defs == ["0", "1"]
-    for f in files:
-        text = open(tmp_path / f).read()
-        assert "@expr_2 = string upper((string) s)" in text        # DumpIR keeps the readable header
-        assert "gdv_scanner<GDV_NG>" in text and "gdv_flat_copy" in text
+    assert len(files) == 3, files
+    texts = [open(tmp_path / f).read() for f in files]
+    main = [t for t in texts if "// wave shape" in t]
+    pre = [t for t in texts if "// pre-pass" in t]
+    general = [t for t in texts if "gdv_scanner<GDV_NG>" in t]
+    assert len(main) == len(pre) == len(general) == 1
+    assert "@expr_2 = string upper((string) s)" in main[0]           # DumpIR keeps the readable header
+    assert "__syncthreads" not in main[0] and "gdv_lb_wait" not in main[0] and "gdv_sweep_store" in main[0]
+    assert "GDV_ERR_NOTASCII" in main[0] and "A.mask[0 * seg_stride + wt]" in main[0]
+    assert "A.counts[0 * seg_stride + wt]" in pre[0] and "sd0 + a" not in pre[0]   # the pre-pass reads no byte
+    assert re.search(r"#define GDV_OPTFLAT (\d)", general[0]).group(1) == "0"
+
+
+def test_plans_whose_lengths_need_bytes_keep_the_scanner_shape(monkeypatch, tmp_path):
+    """rtrim / replace / an if over like(): the output length depends on the bytes — no pre-pass is
+    possible; such plans keep the single-launch scanner shape (optimistic + general variant)."""
+    b = gandiva.TreeExprBuilder()
+    sch = W.c5_schema()
+    s = b.make_field(sch.field(0))
+    exprs = [b.make_expression(b.make_function("rtrim", [s], pa.string()), pa.field("t", pa.string())),
+             b.make_expression(b.make_function("upper", [s], pa.string()), pa.field("u", pa.string()))]
+    files = _precompile(monkeypatch, tmp_path, sch, exprs=exprs)
+    texts = [open(tmp_path / f).read() for f in files]
+    assert len(files) == 2 and all("gdv_scanner<GDV_NG>" in t for t in texts), files
+    # selection-vector projections as well (the wave shape is row mode only)
+    (tmp_path / "env").mkdir()
+    monkeypatch.setenv("GDV_NO_WAVE_SHAPE", "1")
+    files = _precompile(monkeypatch, tmp_path / "env", sch, exprs=W.c5_expressions())
+    assert len(files) == 2
 
 
 def test_fixed_width_plans_have_one_variant_and_a_literal_free_body(monkeypatch, tmp_path):
@@ -93,31 +118,6 @@ def test_committed_pmc_files_belong_to_the_kernels_this_tree_generates(monkeypat
                 pytest.fail(msg)
             import warnings
             warnings.warn(msg)   # mid-round trees may be ahead of their evidence; the bench line says so too
-
-
-def test_early_post_variant_of_string_plans_compiles(monkeypatch, tmp_path):
-    """GDV_EARLY_POST=1 (off by default, to be measured): lengths pass -> post -> staging pass ->
-    wait.  It must compile for gfx950 in both flat variants and must not be what runs by default."""
-    b = gandiva.TreeExprBuilder()
-    sch = W.c5_schema()
-    f = b.make_field(sch.field(0))
-    STR = pa.string()
-    multi = [b.make_expression(b.make_function("concat", [f, b.make_literal("-", STR),
-                                                          b.make_function("substr", [f, b.make_literal(2, pa.int64())], STR)], STR),
-                               pa.field("c", STR)),
-             b.make_expression(b.make_function("reverse", [f], STR), pa.field("r", STR)),
-             b.make_expression(b.make_function("char_length", [f], pa.int32()), pa.field("n", pa.int32())),
-             b.make_expression(b.make_function("btrim", [f], STR), pa.field("t", STR)),
-             b.make_expression(b.make_function("lower", [b.make_function("ltrim", [f], STR)], STR), pa.field("l", STR)),
-             b.make_expression(b.make_function("upper", [f], STR), pa.field("u", STR))]
-    default = set(_precompile(monkeypatch, tmp_path, sch, W.c5_expressions()))
-    monkeypatch.setenv("GDV_EARLY_POST", "1")
-    early = set(_precompile(monkeypatch, tmp_path, sch, W.c5_expressions())) - default
-    assert len(early) == 2                                   # optimistic + general variant, both new text
-    src = open(os.path.join(tmp_path, sorted(early)[0])).read()
-    assert "pass < 3" in src and "else if (pass == 1)" in src
-    _precompile(monkeypatch, tmp_path, sch, multi)           # >3 var-len outputs: staged, direct and flat ones
-    _precompile(monkeypatch, tmp_path, sch, [multi[5]])      # all outputs flat
 
 
 def test_registry_aliases_share_their_kernels(monkeypatch, tmp_path):
