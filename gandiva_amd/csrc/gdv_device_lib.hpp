@@ -1260,10 +1260,30 @@ static __device__ GDV_COLD void gdv_str_copy_direct(gdv_uint8* dst, const gdv_ui
 // one shifted back to end exactly at the total (it overlaps its neighbour with identical bytes) —
 // one coalesced store instruction per KiB instead of several scattered stores per row.  (Pieces
 // aligned in the output with head / tail bytes stored singly measured 2 % slower.)
+#ifndef GDV_OUT_WIN
 #define GDV_OUT_WIN (GDV_U * 64 * 8)  // staged bytes per wave tile and output: 8 per row on average
+#endif
 #ifndef GDV_HOST_BUILD
 GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gdv_int32 cnt, int lane) {
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order: ordering only
+#ifdef GDV_FLUSH_ALIGNED
+  // experiment: 16-byte stores aligned in the OUTPUT, ragged head and tail byte by byte
+  {
+    gdv_int32 head = (gdv_int32)((16 - ((gdv_uint64)dst & 15)) & 15);
+    head = head < cnt ? head : cnt;
+    if (lane < head) dst[lane] = win[lane];
+    const gdv_int32 body = (cnt - head) & ~15;
+    for (gdv_int32 i = lane * 16; i < body; i += 1024) {
+      gdv_uint64 w[2];
+      __builtin_memcpy(w, win + head + i, 16);
+      __builtin_memcpy(__builtin_assume_aligned(dst + head + i, 16), w, 16);
+    }
+    const gdv_int32 t0 = head + body;
+    if (t0 + lane < cnt) dst[t0 + lane] = win[t0 + lane];
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
+#endif
   if (cnt >= 16) {
     for (gdv_int32 i = lane * 16; i < cnt; i += 1024) {
       const gdv_int32 j = i + 16 <= cnt ? i : cnt - 16;  // the last piece is shifted back to end at cnt
@@ -1821,7 +1841,9 @@ GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_
 //   * where does a '%needle%' pattern match?  One bit per span byte in an LDS bitmap; a row then
 //     tests its own byte range with two word reads (gdv_range_any) — no per-row search loop.
 #define GDV_B01 0x0101010101010101ull
+#ifndef GDV_SPAN_MAX
 #define GDV_SPAN_MAX (GDV_U * 64 * 32)  // bytes of span the LDS match bitmaps cover (32 per row)
+#endif
 // bit k of the result: the m-byte needle (`first` = its bytes, `mask` = low m bytes set;
 // 2 <= m <= 8) starts at byte k of `cur` (its bytes continue in `nxt`).  Two-byte SWAR filter
 // (zero-byte tests on word ^ splat), exact verification of the few candidates.
@@ -1840,20 +1862,38 @@ GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, 
   }
   return m;
 }
-// One 16-byte piece of the byte sweep, written to a FLAT output as it is read (optimistic flat
-// mode: the output's bytes are the input's, so its offsets are the input's minus the first one
-// and need no scan).  Bytes [lo, hi) of the piece lie inside this wave's span; only those are
-// stored (neighbouring tiles write their own), and nothing at or past `cap`.
+// One 16-byte piece of the byte sweep, written to a FLAT output as it is read (the output's bytes
+// are the input's: its offsets are the input's minus the first one and need no scan).  Only
+// pieces that lie entirely inside this wave's span [sp0, sp1) are stored here; the two ragged ends
+// are written once per tile by gdv_sweep_edges as whole 16-byte pieces that OVERLAP their
+// neighbours inside the span with identical bytes (a byte-wise edge loop cost 20 VGPRs: 72 -> 52
+// on C5, i.e. 6 -> 8 waves per SIMD).  Nothing is stored at or past `cap`.
 GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
-                             gdv_int32 lo, gdv_int32 hi, gdv_int64 cap) {
-  const gdv_uint64 m0 = gdv_map8(w[0], map), m1 = gdv_map8(w[1], map);
-  if (lo <= 0 && hi >= 16 && doff + 16 <= cap) {
-    gdv_uint64 q[2] = {m0, m1};
+                             bool inside, gdv_int64 cap) {
+  if (inside && doff + 16 <= cap) {
+    gdv_uint64 q[2] = {gdv_map8(w[0], map), gdv_map8(w[1], map)};
     __builtin_memcpy(dst + doff, q, 16);
-  } else {
-    const gdv_int32 k0 = lo > 0 ? lo : 0, k1 = hi < 16 ? hi : 16;
-    for (gdv_int32 k = k0; k < k1; k++)
-      if (doff + k < cap) dst[doff + k] = (gdv_uint8)((k < 8 ? m0 : m1) >> (8 * (k & 7)));
+  }
+}
+// the ends of the span: lane 0 writes bytes [sp0, sp0 + 16), lane 1 bytes [sp1 - 16, sp1) (spans
+// shorter than 16 bytes: one byte per lane).  dst = output bytes, src = input bytes, both indexed
+// by the input offset minus `rebase`.
+GDV_DEV void gdv_sweep_edges(gdv_uint8* __restrict__ dst, const gdv_uint8* __restrict__ src, gdv_int32 sp0,
+                             gdv_int32 sp1, gdv_int32 rebase, gdv_int32 map, gdv_int64 cap, int lane) {
+  const gdv_int32 cnt = sp1 - sp0;
+  if (cnt >= 16) {
+    if (lane < 2) {
+      const gdv_int32 at = lane == 0 ? sp0 : sp1 - 16;
+      if ((gdv_int64)at - rebase + 16 <= cap) {
+        gdv_uint64 q[2];
+        __builtin_memcpy(q, src + at, 16);
+        q[0] = gdv_map8(q[0], map);
+        q[1] = gdv_map8(q[1], map);
+        __builtin_memcpy(dst + (at - rebase), q, 16);
+      }
+    }
+  } else if (lane < cnt && (gdv_int64)sp0 - rebase + lane < cap) {
+    dst[sp0 - rebase + lane] = gdv_map_byte(src[sp0 + lane], map);
   }
 }
 // any bit set in [lo, hi) of the bitmap (hi <= lo: empty range).  Branch-free for ranges of up
@@ -1887,6 +1927,13 @@ GDV_DEV gdv_uint64 gdv_next_lane(gdv_uint64 v) {
   const gdv_uint32 lo = (gdv_uint32)__builtin_amdgcn_update_dpp(0, (int)(gdv_uint32)v, 0x130, 0xf, 0xf, false);
   const gdv_uint32 hi = (gdv_uint32)__builtin_amdgcn_update_dpp(0, (int)(gdv_uint32)(v >> 32), 0x130, 0xf, 0xf, false);
   return ((gdv_uint64)hi << 32) | lo;
+}
+
+// the END offset of each lane's row when only the start offsets were loaded: the next lane's
+// start (DPP wave_shl:1), lane 63 takes `after` = the first start of the next sub-tile / the tile's end
+GDV_DEV gdv_int32 gdv_next_lane_i32(gdv_int32 v, gdv_int32 after, int lane) {
+  const gdv_int32 nx = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
+  return lane == 63 ? after : nx;
 }
 
 // ------------------------------------------------------------------ var-len kernels: output offsets

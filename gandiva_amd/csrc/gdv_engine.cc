@@ -687,7 +687,10 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     // needed.  Host buffers: a first launch with capacity 0 sizes the device byte buffers, a
     // second one fills them (the path is PCIe-bound anyway).
     const int ng = (nv + 1) / 2;
-    const int64_t rows_wg = 64 * static_cast<int64_t>(plan_.opts.subtiles) * plan_.opts.waves;
+    // (tile of the scanner-shaped kernel: a wave plan's fallback has its own)
+    const int sc_u = plan_.general_subtiles > 0 ? plan_.general_subtiles : plan_.opts.subtiles;
+    const int sc_w = plan_.general_waves > 0 ? plan_.general_waves : plan_.opts.waves;
+    const int64_t rows_wg = 64 * static_cast<int64_t>(sc_u) * sc_w;
     const int64_t ntiles = (out_rows + rows_wg - 1) / rows_wg;
     // head of the state block, one memset and one read-back per launch:
     // [error word | grand totals (2 * ng) | wave shape: totals of the scanned segments]
@@ -713,7 +716,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       args.SetPtr(ArgLayout::kOffCounts, state + 8);
       args.SetPtr(ArgLayout::kOffMask, state + 8 + totals_bytes);
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(state, 0, state_bytes, stream));
-      GDV_RETURN_NOT_OK(rt.Launch(*active, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_RETURN_NOT_OK(rt.Launch(*active, grid, sc_w * 64, args.data(), args.size(), stream));
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), state, 8 + totals_bytes, hipMemcpyDeviceToHost, stream));
       GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
       err_bits = static_cast<uint32_t>(back[0]);
@@ -759,7 +762,8 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(head, 0, head_bytes, stream));
       const int64_t grid = GridFor(plan_, out_rows);
       if (nseg > 0) {
-        GDV_RETURN_NOT_OK(rt.Launch(*kernel_pre_, grid, plan_.opts.waves * 64, pargs->data(), pargs->size(), stream));
+        GDV_RETURN_NOT_OK(rt.Launch(*kernel_pre_, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
+                                    plan_.opts.waves * 64, pargs->data(), pargs->size(), stream));
         int32_t* closing[kMaxScanSegments] = {};
         for (int v = 0; v < nv; v++)
           if (plan_.wave_segments[v] >= 0)

@@ -1191,7 +1191,8 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
 
 // ---- pieces of the string skeletons shared by the scanner shape and the wave shape
 // pointers of the tile function: var-len / fixed-width inputs, outputs, the selection vector
-void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool with_outputs) {
+void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool with_outputs,
+                                bool wave_shape = false) {
   const bool sel = cg.selection();
   const int nin = plan->layout.n_in;
   for (int k = 0; k < nin; k++) {
@@ -1229,7 +1230,11 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
         else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
       }
     } else if (t.is_varlen()) {
-      if (cg.needs_values_[k]) s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
+      if (cg.needs_values_[k]) {
+        // (wave shape: only the start offsets are loaded; a row's end is the next lane's start)
+        if (wave_shape) s << "  gdv_int32 oa" << k << "[GDV_U];\n";
+        else s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
+      }
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
@@ -1261,7 +1266,9 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.is_varlen()) {
         // rows past the end take the closing offset: length 0, and the span stays contiguous
-        if (cg.needs_values_[k])
+        if (cg.needs_values_[k] && wave_shape)
+          s << "    oa" << k << "[u] = so" << k << "[live ? row : n];\n";
+        else if (cg.needs_values_[k])
           s << "    oa" << k << "[u] = so" << k << "[live ? row : n]; ob" << k << "[u] = so" << k
             << "[row + 1 < n ? row + 1 : n];\n";
       } else if (t.id != kBool && cg.needs_values_[k]) {
@@ -1276,7 +1283,7 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
 
 // the rolled row loop: prologue (this sub-tile's inputs picked at index 0), the fused body, rotation
 // of the per-sub-tile registers; the caller appends its own rotations and closes the loop ("  }\n")
-void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
+void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool wave_shape = false) {
   const bool sel = cg.selection();
   const int nin = plan->layout.n_in;
   // The row loop is NOT unrolled: the per-sub-tile registers are read and written through
@@ -1293,9 +1300,14 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
     if (t.id == kBool) {
       if (cg.needs_values_[k] && sel) s << "      const bool x" << k << "_u = x" << k << "[0];\n";
     } else if (t.is_varlen()) {
+      if (cg.needs_values_[k] && wave_shape)
+        s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0];\n"
+          << "      const gdv_int32 ob" << k << "_u = gdv_next_lane_i32(oa" << k << "_u, u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa"
+          << k << "[GDV_U > 1 ? 1 : 0]) : sp1" << k << ", lane);\n";
+      else if (cg.needs_values_[k])
+        s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0], ob" << k << "_u = ob" << k << "[0];\n";
       if (cg.needs_values_[k])
-        s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0], ob" << k << "_u = ob" << k << "[0];\n"
-          << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
+        s << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
           << ", sfl" << k << ");\n";
     } else if (cg.needs_values_[k]) {
       s << "      const " << t.CType() << " c" << k << "_u = c" << k << "[0];\n";
@@ -1321,7 +1333,7 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
     if (t.id == kBool) {
       if (cg.needs_values_[k] && sel) s << "    gdv_rot(x" << k << ");\n";
     } else if (t.is_varlen()) {
-      if (cg.needs_values_[k]) s << "    gdv_rot(oa" << k << "); gdv_rot(ob" << k << ");\n";
+      if (cg.needs_values_[k]) s << "    gdv_rot(oa" << k << ");" << (wave_shape ? "" : " gdv_rot(ob" + std::to_string(k) + ");") << "\n";
     } else if (cg.needs_values_[k]) {
       s << "    gdv_rot(c" << k << ");\n";
     }
@@ -1382,14 +1394,31 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool 
         << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
         << " >> 8) & 0xffull) * GDV_B01;\n";
     }
+    if (wave_shape) {
+      // software-pipelined: the next step's 16 bytes are in flight while this step's are matched /
+      // stored; lane 63's halo is the next step's lane 0 (no extra load)
+      s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
+        << "  if (sb" << K << " + 16 * lane < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + sb" << K << " + 16 * lane, 16), 16);\n"
+        << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
+        << "    const gdv_int32 a = c + 16 * lane;\n"
+        << "    const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
+        << "    wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
+        << "    if (a + 1024 < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
+        << "    sacc" << K << " |= w[0] | w[1];\n";
+      if (!hooks.empty())
+        s << "    const gdv_uint64 tail = (gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)wn" << K << "[0]) |\n"
+          << "                            ((gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)(wn" << K << "[0] >> 32)) << 32);\n";
+    } else {
     s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
       << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
       << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
       << "    sacc" << K << " |= w[0] | w[1];\n";
-    if (!hooks.empty()) {
+    if (!hooks.empty())
       s << "    gdv_uint64 tail = 0;  // lane 63's halo: the first 8 bytes of the next step\n"
         << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
+    }
+    if (!hooks.empty()) {
       for (int h : hooks) {
         const ContainsHook& hk = cg.contains_hooks_[h];
         const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
@@ -1411,9 +1440,13 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool 
       // second pass over the span, profiles/r03_k4_experiments.txt); a piece's bytes outside this
       // wave's span [sp0, sp1) belong to the neighbouring tiles
       for (auto* vo : flats)
-        s << "    if (!(GDV_ABL & 8) && a < sp1" << K << ") gdv_sweep_store(outd" << vo->e << ", (gdv_int64)a - so0_" << K
-          << ", w, " << vo->flat_map << ", sp0" << K << " - a, sp1" << K << " - a, A.out[" << vo->e << "].cap);\n";
+        s << "    if (!(GDV_ABL & 8)) gdv_sweep_store(outd" << vo->e << ", (gdv_int64)a - so0_" << K
+          << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= sp1" << K << ", A.out[" << vo->e << "].cap);\n";
     s << "  }\n";
+    if (wave_shape)
+      for (auto* vo : flats)
+        s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
+          << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
     // optimistic flat outputs: their place in the output is known from the input offsets alone, so
     // the span is copied right here, while the sweep's lines are still in L2 / L1.  (Moving the copy
     // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
@@ -1701,13 +1734,14 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const bool last_tile = rbase + 64 * GDV_U >= n;  // the wave tile that holds the batch's last row\n"
     << "  const gdv_int64 seg_stride = A.aux1;  // wave-tile totals / bases: one array of seg_stride entries per scanned output\n"
     << "  (void)last_tile; (void)seg_stride;\n";
-  EmitStringPointersAndLoads(s, cg, plan, !prepass);
+  EmitStringPointersAndLoads(s, cg, plan, !prepass, /*wave_shape=*/true);
   if (prepass) {
     // no byte is read: views are (offset, length) pairs carrying the flags the main kernel assumes
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.is_varlen() && cg.needs_values_[k])
-        s << "  const gdv_int32 sfl" << k << " = GDV_STR_ASCII | GDV_STR_INBUF;\n";
+        s << "  const gdv_int32 sfl" << k << " = GDV_STR_ASCII | GDV_STR_INBUF;\n"
+          << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n";
     }
   } else {
     EmitStringSweep(s, cg, plan, /*wave_shape=*/true);
@@ -1725,7 +1759,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   else
     s << "  constexpr int pass = 0;\n  (void)pass;\n";
   s << decls_in_pass;
-  EmitStringRowLoop(s, cg, plan);
+  EmitStringRowLoop(s, cg, plan, /*wave_shape=*/true);
   s << "  }\n";
   if (has_direct_pass) s << "  if (pass == 1) break;\n";
   s << after_row_loop;
@@ -1738,7 +1772,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
   if (prepass)
-    s << "  gdv_tile(A, (gdv_int64)blockIdx.x * GDV_WAVES + wave, lane, wave, nullptr, nullptr);\n";
+    // (a pre-pass tile is a few loads and one store: waves walk several tiles, grid-stride)
+    s << "  const gdv_int64 nwt = (A.n + 64 * GDV_U - 1) / (64 * GDV_U);\n"
+      << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nwt; wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
+      << "    gdv_tile(A, wt, lane, wave, nullptr, nullptr);\n";
   else
     s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
       << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
@@ -1858,12 +1895,13 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         // lengths only: one byte total per wave tile -> counts[segment][wave tile]
         emit_pieces();
         const std::string S = std::to_string(num_scanned++);
-        in_pass << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n";
-        cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
-        cg.Stmt("{ const gdv_int32 inc = gdv_wave_scan_incl(ln" + E + "_u);");
-        cg.Stmt("  const gdv_uint32 t = " + tile_total("ln" + E + "_u", "inc") + ";");
-        cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t)); }");
-        after_rows << "  if (lane == 0) A.counts[" << S << " * seg_stride + wt] = (gdv_uint32)run" << E << ";\n";
+        // (lengths add up per lane across the sub-tiles; ONE wave reduction per tile.  Exact whenever
+        // the tile stays below 2^31 bytes — the main kernel's running total then agrees — and at
+        // least 2^31-1 otherwise, which the host rejects)
+        in_pass << "  gdv_int32 run" << E << " = 0;  // this lane's bytes over the sub-tiles (saturates at 2^31-1)\n";
+        cg.Stmt("run" + E + " = gdv_sat_add31(run" + E + ", " + total + ");");
+        after_rows << "  { const gdv_uint32 t = gdv_tile_total(run" << E << ");\n"
+                   << "    if (lane == 0) A.counts[" << S << " * seg_stride + wt] = t > 0x7fffffffu ? 0x7fffffffu : t; }\n";
         cg.varlen_outs_.push_back(vo);
         continue;
       }
@@ -2008,7 +2046,19 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
     // row loop is rolled): 8 were better while the kernel carried 130 VGPRs either way; with the
     // branch-free range test and the compile-time flat variant 4 sub-tiles fit 95 VGPRs (5 waves
     // per SIMD) and win: 1.70 vs 1.83 ms (profiles/r02_c5_tuning.txt)
-    if (std::getenv("GDV_U") == nullptr) plan->opts.subtiles = 4;
+    if (std::getenv("GDV_U") == nullptr) {
+      if (shape == StringShape::kScanner) plan->opts.subtiles = 4;
+      if (shape == StringShape::kWaveMain) {
+        // wave shape: a tile costs a fixed prologue (scalar loads, sweep set-up, ends of the span,
+        // flush), so 8 sub-tiles per wave beat 4 (C5: 1.15 vs 1.29 ms, profiles/r03_c5_tuning.txt)
+        // — as long as the wave's LDS (staging windows of 8 B per row, match bitmaps of 32 bits
+        // per row) leaves room for six workgroups per CU
+        const int windows = num_staged, hooks = static_cast<int>(cg.contains_hooks_.size());
+        const int lds_u8 = windows * (8 * 64 * 8 + 16) + hooks * ((8 * 64 * 32) / 64 + 4) * 8;
+        plan->opts.subtiles = lds_u8 <= 6656 ? 8 : 4;
+      }
+      // (kWavePrepass: the caller passes the main kernel's tile)
+    }
     if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
     if (varlen_outs != nullptr) *varlen_outs = cg.varlen_outs_;
     if (wave)
@@ -2066,8 +2116,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   // literals and constants (they run the same tree walk; checked, not assumed)
   if (fast.input_fields != slow.input_fields || fast.input_needs_values != slow.input_needs_values ||
       fast.input_needs_validity != slow.input_needs_validity || fast.literals != slow.literals ||
-      fast.const_block != slow.const_block || fast.opts.subtiles != slow.opts.subtiles ||
-      fast.opts.waves != slow.opts.waves) {
+      fast.const_block != slow.const_block) {
     *plan = slow;
     return Status::OK();
   }
@@ -2083,6 +2132,8 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   // the fallback: the scanner-shaped kernel with every output on the general path
   plan->kernel_name_general = slow.has_flat_output ? slow.kernel_name_general : slow.kernel_name;
   plan->source_general = slow.has_flat_output ? slow.source_general : slow.source;
+  plan->general_subtiles = slow.opts.subtiles;
+  plan->general_waves = slow.opts.waves;
   plan->wave_segments.clear();
   for (auto& vo : vouts) plan->wave_segments.push_back(vo.flat_slot < 0 ? vo.segment : -1);
   if (!scanned.empty()) {

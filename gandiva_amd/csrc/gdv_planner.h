@@ -91,6 +91,7 @@ struct KernelPlan {
   bool wave_tiles = false;
   std::shared_ptr<KernelPlan> prepass;
   std::vector<int> wave_segments;
+  int general_subtiles = 0, general_waves = 0;  // tile of the scanner-shaped fallback (0: opts')
   int rows_per_tile() const { return 64 * opts.subtiles * (wave_tiles ? 1 : opts.waves); }
 };
 constexpr int kMaxWaveSegments = 8;

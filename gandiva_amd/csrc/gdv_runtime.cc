@@ -176,9 +176,22 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
   // -ffp-contract=off is part of the semantics (bit-exact vs separate mul/add)
   std::vector<const char*> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-fhip-fp32-correctly-rounded-divide-sqrt"};
-  // GDV_RTC_OPT: one extra compiler option for experiments (e.g. -DGDV_COLD= inlines the cold
+  // GDV_RTC_OPT: extra compiler options for experiments (e.g. -DGDV_COLD= inlines the cold
   // paths); not part of the cache key, so combine it with GDV_NO_DISK_CACHE=1
-  if (const char* extra = std::getenv("GDV_RTC_OPT")) opts.push_back(extra);
+  std::vector<std::string> extra_opts;
+  if (const char* extra = std::getenv("GDV_RTC_OPT")) {  // blank-separated list
+    std::string cur;
+    for (const char* c = extra;; c++) {
+      if (*c == ' ' || *c == '\0') {
+        if (!cur.empty()) extra_opts.push_back(cur);
+        cur.clear();
+        if (*c == '\0') break;
+      } else {
+        cur.push_back(*c);
+      }
+    }
+    for (auto& o : extra_opts) opts.push_back(o.c_str());
+  }
   hiprtcResult r = hiprtcCompileProgram(prog, static_cast<int>(opts.size()), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;

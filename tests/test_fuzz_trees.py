@@ -238,7 +238,7 @@ def _string_expressions(seed):
     return exprs, g.b.make_condition(g.boolean(3))
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(12))
 def test_generated_string_trees_validate_and_compile(seed):
     from gandiva_amd import _capi, gandiva as gg
     exprs, cond = _string_expressions(seed)
