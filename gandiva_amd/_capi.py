@@ -81,6 +81,11 @@ PROTOTYPES = [
     ("gdv_registry_size", C.c_int, []),
     ("gdv_registry_get", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(gdv_type_t), C.POINTER(gdv_type_t), C.c_int, C.POINTER(C.c_int)]),
     ("gdv_device_count", C.c_int, []),
+    ("gdv_physical_device_count", C.c_int, []),
+    ("gdv_set_virtual_devices", C.c_int, [C.c_int]),
+    ("gdv_set_device", C.c_int, [C.c_int]),
+    ("gdv_get_device", C.c_int, []),
+    ("gdv_shard_bounds", C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("gdv_device_num_cus", C.c_int, []),
     ("gdv_device_arch", C.c_char_p, []),
     ("gdv_device_alloc", C.c_int, [C.c_int64, C.POINTER(_P)]),

@@ -521,10 +521,28 @@ int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_
 }
 
 // ---------------------------------------------------------------- device helpers
-int gdv_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return n;
+int gdv_device_count(void) { return Runtime::DeviceCount(); }
+int gdv_physical_device_count(void) { return Runtime::PhysicalDeviceCount(); }
+int gdv_set_virtual_devices(int n) {
+  if (n < 0 || n > Runtime::kMaxDevices) return Fail(Status::Invalid("bad virtual device count"));
+  Runtime::SetVirtualDevices(n);
+  return GDV_OK;
+}
+int gdv_set_device(int device) { return Check(Runtime::SelectDevice(device)); }
+int gdv_get_device(void) { return Runtime::SelectedDevice(); }
+int gdv_shard_bounds(int64_t num_rows, int num_shards, int shard, int64_t* lo, int64_t* hi) {
+  if (num_rows < 0 || num_shards < 1 || shard < 0 || shard >= num_shards || !lo || !hi)
+    return Fail(Status::Invalid("bad shard arguments"));
+  // near-equal shards on 1024-row boundaries (one workgroup tile = one 128-byte line of every
+  // validity bitmap); the last shard takes the ragged tail — gandiva_amd/shard.py: shard_bounds
+  const int64_t align = 1024;
+  const int64_t tiles = (num_rows + align - 1) / align;
+  const int64_t per = tiles / num_shards, extra = tiles % num_shards;
+  const int64_t lo_tile = shard * per + std::min<int64_t>(shard, extra);
+  const int64_t hi_tile = lo_tile + per + (shard < extra ? 1 : 0);
+  *lo = std::min(lo_tile * align, num_rows);
+  *hi = std::min(hi_tile * align, num_rows);
+  return GDV_OK;
 }
 int gdv_device_num_cus(void) { return Runtime::Get().num_cus(); }
 const char* gdv_device_arch(void) { return Runtime::Get().arch().c_str(); }

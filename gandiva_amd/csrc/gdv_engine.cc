@@ -434,6 +434,34 @@ void BindLiterals(const KernelPlan& plan, const DeviceBuffer& consts, ArgBlock* 
   args->SetPtr(ArgLayout::kOffAux0, consts.get());
 }
 
+}  // namespace
+
+Status PlanDeviceStates::Get(const KernelPlan& plan, const PlanDeviceState** out) const {
+  Runtime& rt = Runtime::Get();
+  const int id = rt.id();
+  if (PlanDeviceState* s = slots_[id].load(std::memory_order_acquire)) {
+    *out = s;
+    return Status::OK();
+  }
+  std::lock_guard<std::mutex> g(mu_);
+  if (PlanDeviceState* s = slots_[id].load(std::memory_order_acquire)) {
+    *out = s;
+    return Status::OK();
+  }
+  std::unique_ptr<PlanDeviceState> st(new PlanDeviceState);
+  GDV_RETURN_NOT_OK(rt.GetKernel(plan.source, plan.kernel_name, &st->kernel));
+  GDV_RETURN_NOT_OK(UploadConstBlock(plan, &st->consts));
+  if (plan.prepass) {
+    GDV_RETURN_NOT_OK(rt.GetKernel(plan.prepass->source, plan.prepass->kernel_name, &st->kernel_pre));
+    GDV_RETURN_NOT_OK(UploadConstBlock(*plan.prepass, &st->consts_pre));
+  }
+  *out = st.get();
+  slots_[id].store(st.release(), std::memory_order_release);
+  return Status::OK();
+}
+
+namespace {
+
 LruCache<Projector>& ProjectorCache() {
   static LruCache<Projector> c(500);
   return c;
@@ -549,12 +577,8 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
     }
   }
   GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_));
-  GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.source, p->plan_.kernel_name, &p->kernel_));
-  GDV_RETURN_NOT_OK(UploadConstBlock(p->plan_, &p->consts_));
-  if (p->plan_.prepass) {
-    GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(p->plan_.prepass->source, p->plan_.prepass->kernel_name, &p->kernel_pre_));
-    GDV_RETURN_NOT_OK(UploadConstBlock(*p->plan_.prepass, &p->consts_pre_));
-  }
+  const PlanDeviceState* st = nullptr;
+  GDV_RETURN_NOT_OK(p->states_.Get(p->plan_, &st));  // compiles + loads on the calling thread's device
   ProjectorCache().Put(key, p);
   *out = p;
   return Status::OK();
@@ -583,6 +607,8 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  const PlanDeviceState* dev = nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
 
   ArgBlock args(plan_.layout);
   Staging st;
@@ -602,7 +628,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
-  BindLiterals(plan_, consts_, &args);
+  BindLiterals(plan_, dev->consts, &args);
   // pooled staging blocks (e.g. the zero-padded copy of a tiny var-len buffer) go back to the
   // pool when this call returns: an asynchronous evaluation must not outlive them
   drain.armed = drain.armed || !st.buffers.empty();
@@ -675,7 +701,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   uint32_t err_bits = 0;
   if (nv == 0) {
     if (out_rows > 0)
-      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
+      GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
                                   args.size(), stream));
   } else if (out_rows > 0) {
     // Scanner shape — single launch: workgroup 0 scans the tile totals (granules: tile_starts;
@@ -703,7 +729,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     for (int e = 0; e < num_outs; e++)
       if (plan_.output_types[e].is_varlen()) vl.push_back(e);
     std::vector<uint64_t> seg(2 * ng, 0);
-    const CompiledKernel* active = kernel_;
+    const CompiledKernel* active = dev->kernel;
     char* state = nullptr;
     size_t state_bytes = 0;
     auto run = [&](int64_t grid) -> Status {  // scanner shape
@@ -747,7 +773,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
               return Status::ExecutionError("internal: pre-pass input not bound by the main kernel");
             pargs->CopyInSlot(static_cast<int>(kp), args, k);
           }
-          BindLiterals(pp, consts_pre_, pargs.get());
+          BindLiterals(pp, dev->consts_pre, pargs.get());
           pargs->Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
           pargs->SetPtr(ArgLayout::kOffErr, wave_head.get());
           pargs->SetPtr(ArgLayout::kOffCounts, wave_counts.get());
@@ -762,7 +788,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(head, 0, head_bytes, stream));
       const int64_t grid = GridFor(plan_, out_rows);
       if (nseg > 0) {
-        GDV_RETURN_NOT_OK(rt.Launch(*kernel_pre_, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
+        GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel_pre, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
                                     plan_.opts.waves * 64, pargs->data(), pargs->size(), stream));
         int32_t* closing[kMaxScanSegments] = {};
         for (int v = 0; v < nv; v++)
@@ -772,7 +798,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
                                                          wave_chunks.as<uint64_t>(), wave_bases.as<uint64_t>(),
                                                          reinterpret_cast<uint64_t*>(head + 8 + totals_bytes), closing, stream));
       }
-      GDV_RETURN_NOT_OK(rt.Launch(*kernel_, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), head, head_bytes, hipMemcpyDeviceToHost, stream));
       GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
       err_bits = static_cast<uint32_t>(back[0]);
@@ -791,10 +817,10 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     const bool has_optimistic = plan_.wave_tiles || plan_.has_flat_output;
     bool optimistic = has_optimistic && !prefer_general_.load() && std::getenv("GDV_NO_OPTFLAT") == nullptr;
     auto general_kernel = [&]() -> Status {
-      if (kernel_general_.load() == nullptr) {
+      if (dev->kernel_general.load() == nullptr) {
         const CompiledKernel* k = nullptr;
         GDV_RETURN_NOT_OK(rt.GetKernel(plan_.source_general, plan_.kernel_name_general, &k));
-        kernel_general_.store(k);
+        const_cast<PlanDeviceState*>(dev)->kernel_general.store(k);
       }
       return Status::OK();
     };
@@ -804,14 +830,14 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
         GDV_RETURN_NOT_OK(run_wave());
       } else {
         if (has_optimistic && !optimistic) GDV_RETURN_NOT_OK(general_kernel());
-        active = (has_optimistic && !optimistic) ? kernel_general_.load() : kernel_;
+        active = (has_optimistic && !optimistic) ? dev->kernel_general.load() : dev->kernel;
         GDV_RETURN_NOT_OK(run(scanner_grid));
       }
       if (optimistic && (err_bits & 48u)) {
         optimistic = false;
         prefer_general_.store(true);
         GDV_RETURN_NOT_OK(general_kernel());
-        active = kernel_general_.load();
+        active = dev->kernel_general.load();
         GDV_RETURN_NOT_OK(run(scanner_grid));
       }
       err_bits &= ~48u;
@@ -902,8 +928,8 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
     planned = staged.main[0];
   }
   GDV_RETURN_NOT_OK(PlanFilter(f->plan_schema_, planned, opts, &f->plan_));
-  GDV_RETURN_NOT_OK(Runtime::Get().GetKernel(f->plan_.source, f->plan_.kernel_name, &f->kernel_));
-  GDV_RETURN_NOT_OK(UploadConstBlock(f->plan_, &f->consts_));
+  const PlanDeviceState* st = nullptr;
+  GDV_RETURN_NOT_OK(f->states_.Get(f->plan_, &st));  // compiles + loads on the calling thread's device
   FilterCache().Put(key, f);
   *out = f;
   return Status::OK();
@@ -926,6 +952,8 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     return Status::Invalid("uint32 selection vector cannot address " + std::to_string(num_rows) + " rows");
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  const PlanDeviceState* dev = nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
 
   ArgBlock args(plan_.layout);
   Staging st;
@@ -942,7 +970,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   }
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
   GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
-  BindLiterals(plan_, consts_, &args);
+  BindLiterals(plan_, dev->consts, &args);
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 
@@ -962,7 +990,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   }
 
   EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
-  GDV_RETURN_NOT_OK(rt.Launch(*kernel_, GridFor(plan_, num_rows), plan_.opts.waves * 64,
+  GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, GridFor(plan_, num_rows), plan_.opts.waves * 64,
                               args.data(), args.size(), stream));
   GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>(), m, chunk_sums.as<uint64_t>(),
                                           offsets.as<uint64_t>(), total.as<uint64_t>(), stream));

@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,27 @@ enum EvalFlags : uint32_t {
   kEvalAsync = 1u,  // device buffers only: return after enqueueing on `stream`
 };
 
+// What a built plan owns on ONE device context (round 3: a Projector / Filter can be evaluated by
+// threads that have selected different devices; each context loads the code objects and holds
+// the constant block on its own GPU, lazily, the first time the plan runs there).
+struct PlanDeviceState {
+  const CompiledKernel* kernel = nullptr;
+  std::atomic<const CompiledKernel*> kernel_general{nullptr};  // fallback variant (compiled on demand)
+  const CompiledKernel* kernel_pre = nullptr;  // wave-shaped plans: the pre-pass kernel
+  DeviceBuffer consts, consts_pre;  // string literals / patterns / IN tables (gdv_args::aux0)
+};
+class PlanDeviceStates {
+ public:
+  PlanDeviceStates() { for (auto& s : slots_) s.store(nullptr); }
+  ~PlanDeviceStates() { for (auto& s : slots_) delete s.load(); }
+  // the state of `plan` on the calling thread's context, created on first use
+  Status Get(const KernelPlan& plan, const PlanDeviceState** out) const;
+
+ private:
+  mutable std::mutex mu_;
+  mutable std::atomic<PlanDeviceState*> slots_[Runtime::kMaxDevices];
+};
+
 class Projector {
  public:
   static Status Make(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
@@ -83,12 +105,8 @@ class Projector {
  private:
   Schema schema_;
   KernelPlan plan_;
-  const CompiledKernel* kernel_ = nullptr;
-  mutable std::atomic<const CompiledKernel*> kernel_general_{nullptr};  // without the optimistic flat path (lazy)
-  mutable std::atomic<bool> prefer_general_{false};  // a batch raised NOTFLAT: stop trying the optimistic variant
-  DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
-  const CompiledKernel* kernel_pre_ = nullptr;  // wave-shaped plans: the pre-pass kernel (byte totals per wave tile)
-  DeviceBuffer consts_pre_;
+  PlanDeviceStates states_;  // code objects + constant block per device context
+  mutable std::atomic<bool> prefer_general_{false};  // a batch broke an optimistic assumption: stop trying
   // two-stage plans (StageMaterialisedValues): pre_ materialises the hoisted sub-trees as
   // temporary columns, plan_ is built over plan_schema_ = schema_ + those columns
   std::shared_ptr<Projector> pre_;
@@ -124,8 +142,7 @@ class Filter {
  private:
   Schema schema_;
   KernelPlan plan_;
-  const CompiledKernel* kernel_ = nullptr;
-  DeviceBuffer consts_;  // string literals / patterns / IN tables of this plan (gdv_args::aux0)
+  PlanDeviceStates states_;  // code objects + constant block per device context
   std::shared_ptr<Projector> pre_;  // two-stage plans, as in Projector
   Schema plan_schema_;
 };

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,30 +14,88 @@
 
 namespace gdv {
 
-Runtime& Runtime::Get() {
+namespace {
+std::mutex g_contexts_mu;
+Runtime* g_contexts[Runtime::kMaxDevices] = {};
+int g_virtual_devices = 0;
+thread_local int tl_selected_device = -1;
+
+int PhysicalCountUncached() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count;
+}
+}  // namespace
+
+int Runtime::PhysicalDeviceCount() {
+  static const int count = PhysicalCountUncached();
+  return count;
+}
+
+int Runtime::DeviceCount() {
+  int v = 0;
+  {
+    std::lock_guard<std::mutex> g(g_contexts_mu);
+    v = g_virtual_devices;
+  }
+  if (v == 0)
+    if (const char* e = std::getenv("GDV_VIRTUAL_DEVICES")) v = atoi(e);
+  const int phys = PhysicalDeviceCount();
+  if (phys == 0) return 0;
+  return std::min<int>(kMaxDevices, std::max(phys, v));
+}
+
+void Runtime::SetVirtualDevices(int n) {
+  std::lock_guard<std::mutex> g(g_contexts_mu);
+  g_virtual_devices = std::max(0, std::min<int>(n, kMaxDevices));
+}
+
+Runtime& Runtime::ForDevice(int id) {
+  if (id < 0 || id >= kMaxDevices) id = 0;
+  std::lock_guard<std::mutex> g(g_contexts_mu);
   // never destroyed: cached Projectors / Filters (process-wide LRUs) own pooled device blocks and
-  // hand them back during static destruction, in an order this singleton must outlive
-  static Runtime* rt = new Runtime;
-  return *rt;
+  // hand them back during static destruction, in an order the contexts must outlive
+  if (g_contexts[id] == nullptr) g_contexts[id] = new Runtime(id);
+  return *g_contexts[id];
+}
+
+int Runtime::SelectedDevice() {
+  if (tl_selected_device >= 0) return tl_selected_device;
+  int dev = 0;
+  if (PhysicalDeviceCount() > 0 && hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = 0;
+  }
+  return dev;
+}
+
+Runtime& Runtime::Get() { return ForDevice(SelectedDevice()); }
+
+Status Runtime::SelectDevice(int id) {
+  const int n = DeviceCount();
+  if (n == 0) return Status::ExecutionError("no HIP device available");
+  if (id < 0 || id >= n)
+    return Status::Invalid("device " + std::to_string(id) + " out of range (" + std::to_string(n) + " devices)");
+  tl_selected_device = id;
+  return ForDevice(id).EnsureDevice();
 }
 
 void Runtime::Probe() {
   if (probed_) return;
   probed_ = true;
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0) {
-    (void)hipGetLastError();
+  const int count = PhysicalDeviceCount();
+  if (count <= 0) {
     has_device_ = false;
     if (const char* a = std::getenv("GDV_ARCH")) arch_ = a;
     return;
   }
   has_device_ = true;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  device_ = dev;
+  physical_ = id_ % count;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+  if (hipGetDeviceProperties(&prop, physical_) == hipSuccess) {
     num_cus_ = prop.multiProcessorCount;
     std::string a = prop.gcnArchName;  // e.g. "gfx950:sramecc+:xnack-"
     size_t colon = a.find(':');
@@ -55,17 +114,14 @@ Status Runtime::EnsureDevice() {
     return Status::ExecutionError(
         "no HIP device available: gandiva_amd evaluates on the GPU only (there is no CPU "
         "fallback)");
-  // One device per process (the deployment model: one process per GPU).  Code objects, the
-  // buffer pool and the all-ones word belong to the device that was current at first use.
-  // A thread that never chose a device starts on device 0: switch it to ours rather than run
-  // on the wrong GPU.
+  // Code objects, the buffer pool and the all-ones word of this context live on physical_:
+  // make it the calling thread's HIP device (a thread that never chose one starts on device 0).
   int dev = -1;
-  if (hipGetDevice(&dev) == hipSuccess && dev != device_) {
-    hipError_t e = hipSetDevice(device_);
+  if (hipGetDevice(&dev) != hipSuccess || dev != physical_) {
+    hipError_t e = hipSetDevice(physical_);
     if (e != hipSuccess)
-      return Status::ExecutionError("gandiva_amd is bound to HIP device " + std::to_string(device_) +
-                                    " (current at first use) and could not switch the calling thread to it: " +
-                                    hipGetErrorString(e));
+      return Status::ExecutionError("could not make HIP device " + std::to_string(physical_) +
+                                    " current on the calling thread: " + hipGetErrorString(e));
   }
   return Status::OK();
 }
@@ -142,6 +198,29 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
   static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
   char tag[40];
   snprintf(tag, sizeof(tag), "%016llx", static_cast<unsigned long long>(lib_hash));
+  if (std::getenv("GDV_DUMP_SOURCE")) {
+    const std::string d = cache_dir();
+    std::ofstream f((d.empty() ? std::string("/tmp") : d) + "/" + kernel_name + ".hip");
+    f << source;
+  }
+  // every context loads the same code object: compiled (or read from disk) once per process
+  static std::mutex code_mu;
+  static std::map<std::string, std::vector<char>> code_cache;
+  const std::string mem_key = kernel_name + "." + a;
+  if (!ignore_cached) {
+    std::lock_guard<std::mutex> g(code_mu);
+    auto it = code_cache.find(mem_key);
+    if (it != code_cache.end()) {
+      *code = it->second;
+      if (from_cache) *from_cache = true;
+      return Status::OK();
+    }
+  }
+  auto remember = [&]() {
+    std::lock_guard<std::mutex> g(code_mu);
+    if (code_cache.size() > 2000) code_cache.clear();
+    code_cache[mem_key] = *code;
+  };
   const std::string dir = cache_dir();
   const std::string path = dir + "/" + kernel_name + "." + tag + "." + a + ".hsaco";
   const bool use_disk = !dir.empty() && std::getenv("GDV_NO_DISK_CACHE") == nullptr;
@@ -152,15 +231,12 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
       code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
       if (!code->empty()) {
         if (from_cache) *from_cache = true;
+        remember();
         return Status::OK();
       }
     }
   }
   if (from_cache) *from_cache = false;
-  if (std::getenv("GDV_DUMP_SOURCE")) {
-    std::ofstream f((dir.empty() ? std::string("/tmp") : dir) + "/" + kernel_name + ".hip");
-    f << source;
-  }
 
   // one compilation at a time: they are rare (cached in memory and on disk) and comgr's
   // temporary-file handling has no need to be exercised concurrently
@@ -215,6 +291,7 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
       rename(tmp.c_str(), path.c_str());
     }
   }
+  remember();
   return Status::OK();
 }
 
@@ -365,6 +442,48 @@ Status Runtime::AllOnesWord(const uint64_t** ptr) {
   }
   *ptr = all_ones_;
   return Status::OK();
+}
+
+Status Runtime::AcquireStream(hipStream_t* out) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!streams_free_.empty()) {
+      *out = streams_free_.back();
+      streams_free_.pop_back();
+      return Status::OK();
+    }
+  }
+  GDV_HIP_RETURN_NOT_OK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return Status::OK();
+}
+
+void Runtime::ReleaseStream(hipStream_t s) {
+  if (s == nullptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (streams_free_.size() < 16) streams_free_.push_back(s);
+  else (void)hipStreamDestroy(s);
+}
+
+Status Runtime::AcquireEvent(hipEvent_t* out) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!events_free_.empty()) {
+      *out = events_free_.back();
+      events_free_.pop_back();
+      return Status::OK();
+    }
+  }
+  GDV_HIP_RETURN_NOT_OK(hipEventCreateWithFlags(out, hipEventDisableTiming));
+  return Status::OK();
+}
+
+void Runtime::ReleaseEvent(hipEvent_t e) {
+  if (e == nullptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (events_free_.size() < 64) events_free_.push_back(e);
+  else (void)hipEventDestroy(e);
 }
 
 Status Runtime::Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,

@@ -1,6 +1,6 @@
 // HIP runtime plumbing: kernel compilation (hipRTC) with an in-memory + on-disk code-object
-// cache, kernel launch with a by-value argument block, and a caching device allocator for
-// scratch and staged buffers.  Replaces the reference's Engine and the
+// cache, kernel launch with a by-value argument block, a caching device allocator for scratch and
+// staged buffers — one context per device, chosen by the calling thread.  Replaces the reference's Engine and the
 // compiled-module cache (row 12).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -30,22 +30,42 @@ struct CompiledKernel {
   std::string name;
 };
 
+// One Runtime per device CONTEXT (round 3; rounds 1-2: a process singleton bound to the device
+// current at first use).  A context owns what lives on one GPU: loaded code objects, the buffer
+// pool, the all-ones bitmap word, side streams and events.  Which context a call uses is decided
+// by the CALLING THREAD: the device it selected with SelectDevice() (gdv_set_device in the C ABI),
+// else its current HIP device — so one host thread per device drives N GPUs from one process
+// (SURVEY.md §8e), and torch / HIP callers that hipSetDevice() themselves need nothing else.
+// Virtual devices: ids beyond the physical count map onto physical devices round-robin
+// (id % physical) with a context of their own — N contexts on one GPU, which is how the in-process
+// sharding tests run on the single-GPU test box.
 class Runtime {
  public:
-  static Runtime& Get();
+  static constexpr int kMaxDevices = 64;
+  static Runtime& Get();                 // the calling thread's context
+  static Runtime& ForDevice(int id);     // created on first use
+  static int PhysicalDeviceCount();      // 0 without a HIP device
+  static int DeviceCount();              // max(physical, SetVirtualDevices / GDV_VIRTUAL_DEVICES)
+  static void SetVirtualDevices(int n);
+  static Status SelectDevice(int id);    // thread-local; also makes the physical device current
+  static int SelectedDevice();           // the id Get() resolves to on this thread
+
+  int id() const { return id_; }
+  int physical() const { return physical_; }
 
   // True when a HIP device is usable in this process.
   bool has_device();
-  Status EnsureDevice();
+  Status EnsureDevice();      // the calling thread's HIP device := this context's
   int num_cus();
   const std::string& arch();  // "gfx950" when no device is present (cross-compile)
 
   // Compiles `source` (which #includes "gdv_device_lib.hpp") for arch() and returns the
-  // code object; cached on disk by kernel name (= hash of the source) + library hash.
+  // code object; cached in the process (every context loads the same object) and on disk by
+  // kernel name (= hash of the source + reached library items) + hash of the whole library.
   Status CompileToCodeObject(const std::string& source, const std::string& kernel_name,
                              std::vector<char>* code, bool* from_cache = nullptr,
                              bool ignore_cached = false);
-  // CompileToCodeObject + hipModuleLoadData; cached per process.
+  // CompileToCodeObject + hipModuleLoadData on this context's device; cached per context.
   Status GetKernel(const std::string& source, const std::string& kernel_name,
                    const CompiledKernel** out);
 
@@ -67,40 +87,52 @@ class Runtime {
   Status Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
                 size_t arg_bytes, hipStream_t stream);
 
+  // Side streams / events for pipelines inside one Evaluate (filter: index emission of chunk k
+  // behind the predicate kernel of chunk k + 1).  Pooled: creation costs tens of microseconds.
+  Status AcquireStream(hipStream_t* s);
+  void ReleaseStream(hipStream_t s);
+  Status AcquireEvent(hipEvent_t* e);
+  void ReleaseEvent(hipEvent_t e);
+
   std::string cache_dir();
 
  private:
-  Runtime() = default;
+  explicit Runtime(int id) : id_(id) {}
   std::mutex mu_;
+  int id_ = 0;
+  int physical_ = 0;
   bool probed_ = false;
   bool has_device_ = false;
   int num_cus_ = 256;
-  int device_ = 0;  // the device that was current at first use
   std::string arch_ = "gfx950";
   std::map<std::string, std::unique_ptr<CompiledKernel>> kernels_;
   std::multimap<size_t, void*> free_blocks_;
   std::map<void*, size_t> live_blocks_;
   std::vector<char*> pinned_free_;
+  std::vector<hipStream_t> streams_free_;
+  std::vector<hipEvent_t> events_free_;
   size_t cached_bytes_ = 0;
   uint64_t* all_ones_ = nullptr;
   void Probe();
 };
 
-// RAII scratch buffer from the runtime pool.
+// RAII scratch buffer from a context's pool (freed to the context it came from, whatever device
+// the freeing thread has selected).
 class DeviceBuffer {
  public:
   DeviceBuffer() = default;
   ~DeviceBuffer() { reset(); }
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-  DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+  DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_), owner_(o.owner_) { o.p_ = nullptr; o.n_ = 0; }
   Status Allocate(size_t bytes) {
     reset();
     n_ = bytes;
-    return Runtime::Get().Alloc(bytes ? bytes : 1, &p_);
+    owner_ = &Runtime::Get();
+    return owner_->Alloc(bytes ? bytes : 1, &p_);
   }
   void reset() {
-    if (p_) Runtime::Get().Free(p_);
+    if (p_) owner_->Free(p_);
     p_ = nullptr;
     n_ = 0;
   }
@@ -112,6 +144,7 @@ class DeviceBuffer {
  private:
   void* p_ = nullptr;
   size_t n_ = 0;
+  Runtime* owner_ = nullptr;
 };
 
 extern const char gdv_device_lib_src[];  // generated: gdv_device_lib_embed.cc

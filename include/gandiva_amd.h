@@ -35,9 +35,15 @@
  * the current HIP device and are used in place (zero-copy; this is the measured path);
  * `GDV_MEM_HOST` buffers are staged through HBM by the library (correctness path).
  * There is no CPU evaluation path: without a HIP device every evaluate call fails with
- * GDV_EXECUTION_ERROR.  The library binds to the HIP device that is current at its first
- * use (one device per process, the one-process-per-GPU deployment model); threads calling
- * in with another current device are switched to it.
+ * GDV_EXECUTION_ERROR.
+ *
+ * Devices (round 3).  Every call runs on the CALLING THREAD's device: the one it chose with
+ * gdv_set_device(), else its current HIP device (hipSetDevice / torch.cuda.set_device).  The
+ * library keeps one context per device — loaded code objects, buffer pool, streams — so one
+ * process drives all GPUs of a node with one host thread per device; a handle
+ * (Projector / Filter) may be evaluated from any of them, it is loaded onto a device the first
+ * time it runs there.  Device buffers handed to evaluate must live on (or be peer-accessible
+ * from) the calling thread's device.
  *
  * Threading: all functions may be called concurrently; evaluate is re-entrant on one
  * handle (per-call state only), as the reference's `nogil` bindings require (PA:27-279).
@@ -247,7 +253,21 @@ int gdv_registry_get(int index, const char** name, gdv_type_t* return_type, gdv_
                      int max_params, int* num_params);
 
 /* ---- device helpers (for hosts without their own HIP binding, e.g. a JNI caller) --- */
+/* Devices this library can be pointed at: the physical HIP devices, or more when virtual devices
+ * were asked for (gdv_set_virtual_devices / GDV_VIRTUAL_DEVICES): device d then runs on physical
+ * device d % gdv_physical_device_count() with a context of its own — N contexts on one GPU, for
+ * testing the N-device code path on a single-GPU box. */
 int gdv_device_count(void);
+int gdv_physical_device_count(void);
+int gdv_set_virtual_devices(int n);
+/* Select the device of the CALLING THREAD (thread-local; also makes it the thread's current HIP
+ * device).  gdv_get_device: the device calls from this thread run on. */
+int gdv_set_device(int device);
+int gdv_get_device(void);
+/* Row range [*lo, *hi) of shard `shard` of `num_shards` over `num_rows` rows: near-equal shards on
+ * 1024-row boundaries (no validity word or cache line straddles two shards), no exchange step —
+ * Projector outputs concatenate in shard order, Filter shards yield local indices + *lo. */
+int gdv_shard_bounds(int64_t num_rows, int num_shards, int shard, int64_t* lo, int64_t* hi);
 int gdv_device_num_cus(void);
 const char* gdv_device_arch(void);
 int gdv_device_alloc(int64_t bytes, void** ptr);

@@ -38,7 +38,9 @@ def _kernel_text(monkeypatch, tmp_path, which):
         schema, exprs = {"c2": (W.c2_schema, W.c2_expressions), "c4": (W.c4_schema, W.c4_expressions),
                          "c5": (W.c5_schema, W.c5_expressions)}[which]
         files = _precompile(monkeypatch, tmp_path, schema(), exprs=exprs())
-    return open(tmp_path / files[0]).read()
+    texts = [open(tmp_path / f).read() for f in files]
+    main = [t for t in texts if "// wave shape" in t]   # C5: pre-pass / main / general kernel
+    return main[0] if main else texts[0]
 
 
 def test_editing_a_string_function_renames_string_kernels_only(monkeypatch, tmp_path):
