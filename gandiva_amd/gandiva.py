@@ -751,6 +751,32 @@ class FunctionSignature:
         return f"FunctionSignature({self._ret} {self._name}({', '.join(map(str, self._params))}))"
 
 
+# ---- devices (round 3): every call runs on the calling thread's device context
+def device_count():
+    """Devices the library can be pointed at (physical HIP devices, or more with virtual devices)."""
+    return _capi.lib().gdv_device_count()
+
+
+def physical_device_count():
+    return _capi.lib().gdv_physical_device_count()
+
+
+def set_virtual_devices(n):
+    """Device ids up to n: id d runs on physical device d % physical_device_count() with a context
+    (code objects, buffer pool, streams) of its own — the N-device code path on fewer GPUs."""
+    _check(_capi.lib().gdv_set_virtual_devices(int(n)))
+
+
+def set_device(device):
+    """Select the calling THREAD's device (also makes it the thread's current HIP device, which
+    torch follows).  One host thread per device drives all GPUs of a node from one process."""
+    _check(_capi.lib().gdv_set_device(int(device)))
+
+
+def get_device():
+    return _capi.lib().gdv_get_device()
+
+
 def get_registered_function_signatures():
     lib = _capi.lib()
     out = []
