@@ -345,9 +345,10 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
                                 : Projector::DataBytes(t, rows);
   return GDV_OK;
 }
-int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
-                           int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
-                           int num_outs, int mem_kind, void* stream, uint32_t flags) {
+namespace {
+int ProjectorEvaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
+                      int num_cols, const gdv_selection_t* sel, const void* num_slots_device,
+                      gdv_out_column_t* outs, int num_outs, int mem_kind, void* stream, uint32_t flags) {
   return Guarded([&]() -> int {
   if (!p) return Fail(Status::Invalid("null projector"));
   if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
@@ -367,6 +368,7 @@ int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv
     if (!ToSelectionMode(sel->mode, &sv.mode)) return Fail(Status::Invalid("bad selection mode"));
     sv.indices = sel->indices;
     sv.num_slots = sel->num_slots;
+    sv.num_slots_device = num_slots_device;
   }
   Status st = p->p->Evaluate(num_rows, c.data(), num_cols, sel ? &sv : nullptr, o.data(), num_outs,
                              mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
@@ -374,6 +376,20 @@ int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv
   for (int i = 0; i < num_outs; i++) outs[i].data_size = o[i].data_size;  // var-len: bytes produced / needed
   return Check(st);
   });
+}
+}  // namespace
+
+int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
+                           int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
+                           int num_outs, int mem_kind, void* stream, uint32_t flags) {
+  return ProjectorEvaluate(p, num_rows, cols, num_cols, sel, nullptr, outs, num_outs, mem_kind, stream, flags);
+}
+int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
+                                    int num_cols, const gdv_selection_t* sel, const void* num_slots_device,
+                                    gdv_out_column_t* outs, int num_outs, void* stream, uint32_t flags) {
+  if (!sel || !num_slots_device) return Fail(Status::Invalid("selection vector and device slot count are required"));
+  return ProjectorEvaluate(p, num_rows, cols, num_cols, sel, num_slots_device, outs, num_outs, GDV_MEM_DEVICE, stream,
+                           flags);
 }
 char* gdv_projector_dump_ir(const gdv_projector_t* p) { return p ? DupString(p->p->DumpIR()) : nullptr; }
 void gdv_projector_free(gdv_projector_t* p) { delete p; }
@@ -405,6 +421,21 @@ int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_colum
   return Check(f->f->Evaluate(num_rows, c.data(), num_cols, mode, out_indices, max_slots,
                               num_selected, mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
                               static_cast<hipStream_t>(stream)));
+  });
+}
+int gdv_filter_evaluate_async(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                              int selection_mode, void* out_indices, int64_t max_slots, void* num_selected_device,
+                              void* stream) {
+  return Guarded([&]() -> int {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
+  if (!num_selected_device) return Fail(Status::Invalid("null count pointer"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+  int64_t unused = 0;
+  return Check(f->f->Evaluate(num_rows, c.data(), num_cols, mode, out_indices, max_slots, &unused, MemKind::kDevice,
+                              static_cast<hipStream_t>(stream), kEvalAsync, num_selected_device));
   });
 }
 char* gdv_filter_dump_ir(const gdv_filter_t* f) { return f ? DupString(f->f->DumpIR()) : nullptr; }

@@ -97,6 +97,30 @@ class ArgBlock {
   void SetOutCap(int e, int64_t bytes) {
     Set64(layout_.out_base() + e * ArgLayout::kOutStride + 24, static_cast<uint64_t>(bytes));
   }
+  // input slot k moved forward by `rows` rows (a multiple of 64).  width > 0: fixed-width values;
+  // 0: bool values (a bitmap); -1: var-len (offsets move, the byte buffer stays)
+  void AdvanceInSlot(int k, int64_t rows, int width) {
+    const int base = layout_.in_base() + k * ArgLayout::kInStride;
+    auto bump_ptr = [&](int off, int64_t bytes) {
+      uint64_t p;
+      std::memcpy(&p, &buf_[off], 8);
+      if (p != 0) p += static_cast<uint64_t>(bytes);
+      std::memcpy(&buf_[off], &p, 8);
+    };
+    auto bump_bitmap = [&](int off) {
+      HostBitmap b;
+      std::memcpy(&b, &buf_[off], 24);
+      if (b.p != nullptr && b.nwords > 1) {  // (nwords == 1: the all-ones word, index clamped)
+        b.p += rows / 64;
+        b.nwords = std::max<int64_t>(b.nwords - rows / 64, 1);
+      }
+      std::memcpy(&buf_[off], &b, 24);
+    };
+    if (width > 0) bump_ptr(base, rows * width);
+    bump_bitmap(base + 8);
+    if (width == 0) bump_bitmap(base + 32);
+    if (width < 0) bump_ptr(base + 56, rows * 4);
+  }
   const void* data() const { return buf_.data(); }
   size_t size() const { return buf_.size(); }
 
@@ -605,6 +629,10 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (sel->num_slots < 0 || sel->num_slots > cap)
       return Status::Invalid("selection vector: invalid slot count " + std::to_string(sel->num_slots));
   }
+  if (has_sel && sel->num_slots_device != nullptr &&
+      (mem != MemKind::kDevice || plan_.num_varlen_outputs > 0 || pre_ != nullptr))
+    return Status::Invalid("a device-resident slot count needs device buffers and fixed-width outputs "
+                           "(read the count back and pass it as num_slots instead)");
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
   const PlanDeviceState* dev = nullptr;
@@ -643,6 +671,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       args.SetPtr(ArgLayout::kOffSel, d);
     } else {
       args.SetPtr(ArgLayout::kOffSel, sel->indices);
+      args.SetPtr(ArgLayout::kOffAux2, sel->num_slots_device);  // null: the count is kOffN
     }
   }
 
@@ -935,11 +964,24 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   return Status::OK();
 }
 
+// Input slots of an argument block advanced by `lo` rows (lo a multiple of 64): what a chunk of a
+// pipelined filter binds.  Value pointers move by lo * width, bitmap word pointers by lo / 64 words
+// (their bit shift is unchanged), var-len offsets by lo entries (the byte buffer stays whole).
+static void AdvanceInputs(const KernelPlan& plan, const Schema& schema, const ArgBlock& base, int64_t lo,
+                          ArgBlock* out) {
+  *out = base;
+  for (size_t k = 0; k < plan.input_fields.size(); k++) {
+    const DataType& t = schema[plan.input_fields[k]].type;
+    out->AdvanceInSlot(static_cast<int>(k), lo, t.is_varlen() ? -1 : (t.id == kBool ? 0 : t.byte_width()));
+  }
+}
+
 Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                         SelectionMode mode, void* out_indices, int64_t max_slots,
-                        int64_t* num_selected, MemKind mem, hipStream_t stream) const {
+                        int64_t* num_selected, MemKind mem, hipStream_t stream, uint32_t flags,
+                        void* count_out) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
-  if (out_indices == nullptr || num_selected == nullptr)
+  if (out_indices == nullptr || (num_selected == nullptr && count_out == nullptr))
     return Status::Invalid("Selection vector cannot be null");
   if (mode == SelectionMode::kNone) return Status::Invalid("Selection vector type cannot be NONE");
   if (max_slots < num_rows)
@@ -954,12 +996,18 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
   const PlanDeviceState* dev = nullptr;
   GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+  // Asynchronous evaluation (device buffers; plans that cannot raise, no first stage): everything is
+  // enqueued on `stream`, nothing waits, the selected-row count lands in *count_out (8 bytes of
+  // device or pinned memory) in stream order — a selection-mode Projector can take it from there
+  // (SelectionView::num_slots_device) without a host round trip.
+  bool async = (flags & kEvalAsync) != 0 && mem == MemKind::kDevice && !plan_.can_raise && pre_ == nullptr &&
+               count_out != nullptr;
 
   ArgBlock args(plan_.layout);
   Staging st;
-  DeviceBuffer mask, counts, offsets, chunk_sums, total, err, staged_out;
+  DeviceBuffer mask, counts, offsets, chunk_sums, totals, err, staged_out;
   StageColumns stage;  // two-stage plans: the first stage's temporary columns
-  StreamDrain drain{stream, true};  // declared last: drains before any pooled block is freed
+  StreamDrain drain{stream, !async};  // declared last: drains before any pooled block is freed
   if (pre_) {
     if (num_cols != static_cast<int>(schema_.size()))
       return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
@@ -972,39 +1020,103 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
   BindLiterals(plan_, dev->consts, &args);
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
-  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
+  if (async && !st.buffers.empty()) {  // a pooled staging block is in use (tiny var-len buffer): wait after all
+    async = false;
+    drain.armed = true;
+  }
+
+  // Chunked pipeline (GDV_FILTER_CHUNKS=n, fixed-width plans over HBM-resident batches; OFF by
+  // default): the batch is cut into chunks; the predicate kernel of chunk k + 1 runs on `stream`
+  // while the offsets scan and the index emission of chunk k run on a side stream.  The scan of
+  // chunk k carries the running total of the chunks before it (device memory), so indices land at
+  // their global places.  The round-2 verdict asked for it to hide the emission (0.23 ms at 10^9
+  // rows) behind the predicate kernels; MEASURED (profiles/r03_c3_pipeline.txt, C3, one box): 1
+  // chunk 2.855 ms, 4 chunks 2.925, 8 chunks 2.956, 16 chunks 2.988 — the emission competes with
+  // the predicate kernel for the same HBM bandwidth and every extra launch adds a tail, so the
+  // pipeline loses what the overlap wins.  Kept for re-measurement, and because the carried scan
+  // is what lets the count stay on the device for the asynchronous API.
+  const int64_t tile_rows = 64 * static_cast<int64_t>(plan_.opts.subtiles);   // one count per wave tile
+  int chunks = 1;
+  if (const char* e = std::getenv("GDV_FILTER_CHUNKS")) chunks = std::max(1, std::min(64, atoi(e)));
+  if (plan_.string_skeleton || mem != MemKind::kDevice) chunks = 1;
+  // chunk boundaries: whole index-emission tiles (64 match words) and whole workgroup tiles
+  const int64_t gran = 4096 * static_cast<int64_t>(std::max(1, plan_.opts.subtiles * plan_.opts.waves / 64 + 1));
+  int64_t chunk_rows = (num_rows + chunks - 1) / chunks;
+  chunk_rows = (chunk_rows + gran - 1) / gran * gran;
+  chunks = static_cast<int>((num_rows + chunk_rows - 1) / chunk_rows);
 
   const int64_t nwords = (num_rows + 63) / 64;
-  const int64_t m = (nwords + plan_.opts.subtiles - 1) / plan_.opts.subtiles;  // wave tiles
+  const int64_t m = (num_rows + tile_rows - 1) / tile_rows;  // wave tiles
   GDV_RETURN_NOT_OK(mask.Allocate(nwords * 8));
   GDV_RETURN_NOT_OK(counts.Allocate(m * 4 + 64));
   GDV_RETURN_NOT_OK(offsets.Allocate(m * 8));
-  GDV_RETURN_NOT_OK(chunk_sums.Allocate(ScanChunks(m) * 8));
-  GDV_RETURN_NOT_OK(total.Allocate(8));
-  args.SetPtr(ArgLayout::kOffMask, mask.get());
-  args.SetPtr(ArgLayout::kOffCounts, counts.get());
+  GDV_RETURN_NOT_OK(chunk_sums.Allocate((ScanChunks((chunk_rows + tile_rows - 1) / tile_rows) + 1) * 8 * chunks));
+  GDV_RETURN_NOT_OK(totals.Allocate(8 * (chunks + 1)));
   if (plan_.can_raise) {
     GDV_RETURN_NOT_OK(err.Allocate(8));
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
     args.SetPtr(ArgLayout::kOffErr, err.get());
   }
-
-  EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
-  GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, GridFor(plan_, num_rows), plan_.opts.waves * 64,
-                              args.data(), args.size(), stream));
-  GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>(), m, chunk_sums.as<uint64_t>(),
-                                          offsets.as<uint64_t>(), total.as<uint64_t>(), stream));
   void* dev_out = out_indices;
   if (mem == MemKind::kHost) {
     GDV_RETURN_NOT_OK(staged_out.Allocate(num_rows * w));
     dev_out = staged_out.get();
   }
-  GDV_HIP_RETURN_NOT_OK(LaunchEmitIndices(mask.as<uint64_t>(), offsets.as<uint64_t>(), nwords,
-                                          plan_.opts.subtiles, 0, w, dev_out, rt.num_cus(),
-                                          stream));
+
+  EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
+  struct SideGuard {  // hands the side stream and the events back whatever path leaves the function
+    Runtime& rt; hipStream_t& side; std::vector<hipEvent_t>& events;
+    ~SideGuard() { for (auto e : events) rt.ReleaseEvent(e); rt.ReleaseStream(side); }
+  } side_guard{rt, side, events};
+  if (chunks > 1) GDV_RETURN_NOT_OK(rt.AcquireStream(&side));
+  const int64_t sums_per_chunk = ScanChunks((chunk_rows + tile_rows - 1) / tile_rows) + 1;
+  for (int c = 0; c < chunks; c++) {
+    const int64_t lo = c * chunk_rows, n = std::min(chunk_rows, num_rows - lo);
+    const int64_t words = (n + 63) / 64, tiles = (n + tile_rows - 1) / tile_rows;
+    ArgBlock cargs(plan_.layout);
+    AdvanceInputs(plan_, plan_schema_, args, lo, &cargs);
+    cargs.Set64(ArgLayout::kOffN, static_cast<uint64_t>(n));
+    cargs.SetPtr(ArgLayout::kOffMask, mask.as<uint64_t>() + lo / 64);
+    cargs.SetPtr(ArgLayout::kOffCounts, counts.as<uint32_t>() + lo / tile_rows);
+    GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, GridFor(plan_, n), plan_.opts.waves * 64, cargs.data(), cargs.size(), stream));
+    hipStream_t s2 = stream;
+    if (chunks > 1) {
+      hipEvent_t e = nullptr;
+      GDV_RETURN_NOT_OK(rt.AcquireEvent(&e));
+      events.push_back(e);
+      GDV_HIP_RETURN_NOT_OK(hipEventRecord(e, stream));
+      GDV_HIP_RETURN_NOT_OK(hipStreamWaitEvent(side, e, 0));
+      s2 = side;
+    }
+    GDV_HIP_RETURN_NOT_OK(LaunchOffsetsScan(counts.as<uint32_t>() + lo / tile_rows, tiles,
+                                            chunk_sums.as<uint64_t>() + c * sums_per_chunk,
+                                            offsets.as<uint64_t>() + lo / tile_rows, totals.as<uint64_t>() + c + 1, s2,
+                                            c == 0 ? nullptr : totals.as<uint64_t>() + c));
+    GDV_HIP_RETURN_NOT_OK(LaunchEmitIndices(mask.as<uint64_t>() + lo / 64, offsets.as<uint64_t>() + lo / tile_rows,
+                                            words, plan_.opts.subtiles, lo, w, dev_out, rt.num_cus(), s2));
+  }
+  if (chunks > 1) {  // `stream` continues only after the side stream's last emission
+    hipEvent_t e = nullptr;
+    GDV_RETURN_NOT_OK(rt.AcquireEvent(&e));
+    events.push_back(e);
+    GDV_HIP_RETURN_NOT_OK(hipEventRecord(e, side));
+    GDV_HIP_RETURN_NOT_OK(hipStreamWaitEvent(stream, e, 0));
+  }
+  const uint64_t* total_dev = totals.as<uint64_t>() + chunks;
+  if (async) {
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(count_out, total_dev, 8, hipMemcpyDefault, stream));
+    if (num_selected != nullptr) *num_selected = -1;
+    // scratch goes back to the pool when the stream has passed this point
+    mask.release_after(stream); counts.release_after(stream); offsets.release_after(stream);
+    chunk_sums.release_after(stream); totals.release_after(stream);
+    return Status::OK();
+  }
   uint64_t count = 0;
   uint32_t err_bits = 0;
-  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&count, total.get(), 8, hipMemcpyDeviceToHost, stream));
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&count, total_dev, 8, hipMemcpyDeviceToHost, stream));
+  if (count_out != nullptr) GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(count_out, total_dev, 8, hipMemcpyDefault, stream));
   if (plan_.can_raise)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
   GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
@@ -1013,7 +1125,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(out_indices, dev_out, count * w, hipMemcpyDeviceToHost, stream));
     GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
   }
-  *num_selected = static_cast<int64_t>(count);
+  if (num_selected != nullptr) *num_selected = static_cast<int64_t>(count);
   return Status::OK();
 }
 

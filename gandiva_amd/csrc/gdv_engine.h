@@ -46,6 +46,11 @@ struct SelectionView {
   SelectionMode mode = SelectionMode::kNone;
   const void* indices = nullptr;
   int64_t num_slots = 0;
+  // Device-resident slot count (round 3): when not null, the kernel reads the number of slots from
+  // this int64 in device (or pinned) memory — where an asynchronous Filter::Evaluate left it — and
+  // `num_slots` is only the capacity the outputs and the launch are sized for.  Device buffers,
+  // fixed-width outputs only.
+  const void* num_slots_device = nullptr;
 };
 
 struct Configuration {
@@ -130,9 +135,12 @@ class Filter {
 
   // Fills out_indices (capacity `max_slots`, element type by `mode`) with the ascending
   // positions of rows where the condition is true and valid; *num_selected = count.
+  // flags & kEvalAsync (device buffers, plans that cannot raise): enqueue on `stream` and return;
+  // the count then arrives in *count_out (8 bytes of device or pinned memory, int64) in stream
+  // order and *num_selected is set to -1.  count_out may also be given to a synchronous call.
   Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, SelectionMode mode,
                   void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
-                  hipStream_t stream) const;
+                  hipStream_t stream, uint32_t flags = 0, void* count_out = nullptr) const;
 
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }

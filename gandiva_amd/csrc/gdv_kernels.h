@@ -10,8 +10,11 @@ namespace gdv {
 int64_t ScanChunks(int64_t m);
 
 // offsets[i] = sum(counts[0..i)) for i < m; *total = sum of all counts.
+// carry (device pointer, may be null): added to every offset and to *total — a pipelined filter
+// scans chunk k with carry = the running total after chunk k - 1, so the offsets come out global.
 hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
-                             uint64_t* offsets, uint64_t* total, hipStream_t stream);
+                             uint64_t* offsets, uint64_t* total, hipStream_t stream,
+                             const uint64_t* carry = nullptr);
 
 // The same for `nseg` (<= 16) independent segments in one set of launches: segment s reads
 // counts[s*stride .. s*stride+m), writes offsets[s*stride ..), totals[s], and — when

@@ -80,7 +80,7 @@ ScanReduce(const uint32_t* __restrict__ counts, int64_t m, uint64_t* __restrict_
 // Single workgroup: exclusive scan of the chunk sums in place; grand total -> *total.
 __global__ void __launch_bounds__(kScanThreads)
 ScanSpine(uint64_t* __restrict__ sums, int64_t nb, uint64_t* __restrict__ total_out,
-          ClosingOffsets closing) {
+          ClosingOffsets closing, const uint64_t* __restrict__ carry) {
   sums += (int64_t)blockIdx.x * nb;  // one workgroup per segment
   total_out += blockIdx.x;
   const int64_t per = (nb + kScanThreads - 1) / kScanThreads;
@@ -88,8 +88,11 @@ ScanSpine(uint64_t* __restrict__ sums, int64_t nb, uint64_t* __restrict__ total_
   const int64_t hi = lo + per < nb ? lo + per : nb;
   uint64_t local = 0;
   for (int64_t i = lo; i < hi; i++) local += sums[i];
+  // (carry: what earlier chunks of a pipelined filter selected — the offsets come out global)
+  const uint64_t carried = carry != nullptr ? carry[blockIdx.x] : 0ull;
   uint64_t total;
-  uint64_t prefix = BlockExclusiveScan(local, &total);
+  uint64_t prefix = BlockExclusiveScan(local, &total) + carried;
+  total += carried;
   for (int64_t i = lo; i < hi; i++) {
     uint64_t c = sums[i];
     sums[i] = prefix;
@@ -137,7 +140,8 @@ ScanApply(const uint32_t* __restrict__ counts, int64_t m, const uint64_t* __rest
 // i.e. batches up to ~10^6 rows): small batches are launch-bound, two launches fewer matter.
 __global__ void __launch_bounds__(kScanThreads)
 ScanSmall(const uint32_t* __restrict__ counts, int64_t m, int64_t stride,
-          uint64_t* __restrict__ offsets, uint64_t* __restrict__ total_out, ClosingOffsets closing) {
+          uint64_t* __restrict__ offsets, uint64_t* __restrict__ total_out, ClosingOffsets closing,
+          const uint64_t* __restrict__ carry) {
   counts += (int64_t)blockIdx.x * stride;
   offsets += (int64_t)blockIdx.x * stride;
   const int64_t base = (int64_t)threadIdx.x * kScanPerThread;
@@ -148,8 +152,10 @@ ScanSmall(const uint32_t* __restrict__ counts, int64_t m, int64_t stride,
     c[i] = (base + i < m) ? counts[base + i] : 0u;
     local += c[i];
   }
+  const uint64_t carried = carry != nullptr ? carry[blockIdx.x] : 0ull;
   uint64_t total;
-  uint64_t prefix = BlockExclusiveScan(local, &total);
+  uint64_t prefix = BlockExclusiveScan(local, &total) + carried;
+  total += carried;
 #pragma unroll
   for (int i = 0; i < kScanPerThread; i++) {
     if (base + i < m) offsets[base + i] = prefix;
@@ -234,15 +240,18 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
 
 int64_t ScanChunks(int64_t m) { return (m + kScanChunk - 1) / kScanChunk; }
 
-hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t stride, int nseg,
-                                      uint64_t* chunk_sums, uint64_t* offsets, uint64_t* totals,
-                                      int32_t* const* closing, hipStream_t stream) {
+namespace {
+hipError_t ScanImpl(const uint32_t* counts, int64_t m, int64_t stride, int nseg, uint64_t* chunk_sums,
+                    uint64_t* offsets, uint64_t* totals, int32_t* const* closing, const uint64_t* carry,
+                    hipStream_t stream) {
   if (nseg <= 0) return hipSuccess;
   if (nseg > kMaxScanSegments) return hipErrorInvalidValue;
   ClosingOffsets c;
   for (int i = 0; i < kMaxScanSegments; i++) c.p[i] = (closing != nullptr && i < nseg) ? closing[i] : nullptr;
   if (m <= 0) {
-    hipError_t e = hipMemsetAsync(totals, 0, sizeof(uint64_t) * nseg, stream);
+    hipError_t e = carry != nullptr
+                       ? hipMemcpyAsync(totals, carry, sizeof(uint64_t) * nseg, hipMemcpyDeviceToDevice, stream)
+                       : hipMemsetAsync(totals, 0, sizeof(uint64_t) * nseg, stream);
     for (int i = 0; e == hipSuccess && i < nseg; i++)
       if (c.p[i] != nullptr) e = hipMemsetAsync(c.p[i], 0, sizeof(int32_t), stream);
     return e;
@@ -250,21 +259,29 @@ hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t
   const int64_t nb = ScanChunks(m);
   if (nb == 1) {
     hipLaunchKernelGGL(ScanSmall, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, counts, m, stride,
-                       offsets, totals, c);
+                       offsets, totals, c, carry);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(ScanReduce, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
                      counts, m, chunk_sums, stride);
   hipLaunchKernelGGL(ScanSpine, dim3((unsigned)nseg), dim3(kScanThreads), 0, stream, chunk_sums, nb,
-                     totals, c);
+                     totals, c, carry);
   hipLaunchKernelGGL(ScanApply, dim3((unsigned)nb, (unsigned)nseg), dim3(kScanThreads), 0, stream,
                      counts, m, chunk_sums, offsets, stride);
   return hipGetLastError();
 }
 
+}  // namespace
+
+hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t stride, int nseg,
+                                      uint64_t* chunk_sums, uint64_t* offsets, uint64_t* totals,
+                                      int32_t* const* closing, hipStream_t stream) {
+  return ScanImpl(counts, m, stride, nseg, chunk_sums, offsets, totals, closing, nullptr, stream);
+}
+
 hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
-                             uint64_t* offsets, uint64_t* total, hipStream_t stream) {
-  return LaunchSegmentedOffsetsScan(counts, m, m, 1, chunk_sums, offsets, total, nullptr, stream);
+                             uint64_t* offsets, uint64_t* total, hipStream_t stream, const uint64_t* carry) {
+  return ScanImpl(counts, m, m, 1, chunk_sums, offsets, total, nullptr, carry, stream);
 }
 
 hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int64_t nwords,

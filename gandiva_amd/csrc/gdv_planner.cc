@@ -927,6 +927,12 @@ struct Assembler {
         << (plan->kind == KernelKind::kFilter ? "filter" : "projection") << " kernel for gfx950\n";
     for (size_t i = 0; i < expr_strings.size(); i++)
       src << "// @expr_" << i << " = " << expr_strings[i] << "\n";
+    // rows of the batch: selection-mode plans may take the slot count from device memory (aux2: an
+    // asynchronous Filter left it there), so a filter -> project chain needs no host round trip
+    if (plan->mode != SelectionMode::kNone)
+      src << "#define GDV_ROWS(A) ((A).aux2 != 0 ? *(const gdv_int64*)(A).aux2 : (A).n)\n";
+    else
+      src << "#define GDV_ROWS(A) ((A).n)\n";
     src << "#define GDV_U " << plan->opts.subtiles << "\n";
     src << "#define GDV_WAVES " << plan->opts.waves << "\n";
     src << "#include \"gdv_device_lib.hpp\"\n";
@@ -1027,7 +1033,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
     << "  (void)gdv_cst;\n"
-    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 n = GDV_ROWS(A);\n"
     << "  const gdv_int64 rbase = wbase * 64;\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = cg.schema_[plan->input_fields[k]].type;
@@ -1161,7 +1167,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   s << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
-    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 n = GDV_ROWS(A);\n"
     << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
     << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
     << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
@@ -1523,7 +1529,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
     << "  (void)gdv_cst;\n"
-    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 n = GDV_ROWS(A);\n"
     << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;\n"
     << "  const gdv_int64 rbase = wbase * 64;\n"
     << "  constexpr bool optflat = GDV_OPTFLAT != 0;  // flat outputs: offsets = input offsets, bytes copied after the sweep\n"
@@ -1623,7 +1629,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
     << "  __shared__ gdv_uint32 gdv_lds_tot[GDV_WAVES][GDV_NV > 0 ? GDV_NV : 1];\n"
     << "  __shared__ gdv_uint64 gdv_lds_base[GDV_NG > 0 ? GDV_NG : 1];\n"
-    << "  const gdv_int64 ntiles = (A.n + 64 * GDV_U * GDV_WAVES - 1) / (64 * GDV_U * GDV_WAVES);\n";
+    << "  const gdv_int64 ntiles = (GDV_ROWS(A) + 64 * GDV_U * GDV_WAVES - 1) / (64 * GDV_U * GDV_WAVES);\n";
   if (nv > 0) {
     s << "  // workgroup 0 is the scanner of the tile totals; workers are workgroups 1..\n"
       << "  if (blockIdx.x == 0) {\n"
@@ -1636,8 +1642,8 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
       const VarlenOut& vo = cg.varlen_outs_[v];
       if (vo.flat_slot >= 0)
         s << "        if (GDV_OPTFLAT) { const gdv_int32* so = A.in[" << vo.flat_slot << "].offsets; totals[" << v
-          << "] = (gdv_uint64)(so[A.n] - so[0]); }\n";
-      s << "        A.out[" << vo.e << "].offsets[A.n] = (gdv_int32)(totals[" << v
+          << "] = (gdv_uint64)(so[GDV_ROWS(A)] - so[0]); }\n";
+      s << "        A.out[" << vo.e << "].offsets[GDV_ROWS(A)] = (gdv_int32)(totals[" << v
         << "] > GDV_LB_M31 ? GDV_LB_M31 : totals[" << v << "]);\n";
     }
     s << "      }\n    }\n    return;\n  }\n"
@@ -1727,7 +1733,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
     << "  (void)gdv_cst;\n"
-    << "  const gdv_int64 n = A.n;\n"
+    << "  const gdv_int64 n = GDV_ROWS(A);\n"
     << "  const gdv_int64 wbase = wt * GDV_U;\n"
     << "  const gdv_int64 rbase = wbase * 64;\n"
     << "  if (rbase >= n) return;  // (no barrier anywhere below: waves are independent)\n"
@@ -1773,7 +1779,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
   if (prepass)
     // (a pre-pass tile is a few loads and one store: waves walk several tiles, grid-stride)
-    s << "  const gdv_int64 nwt = (A.n + 64 * GDV_U - 1) / (64 * GDV_U);\n"
+    s << "  const gdv_int64 nwt = (GDV_ROWS(A) + 64 * GDV_U - 1) / (64 * GDV_U);\n"
       << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nwt; wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
       << "    gdv_tile(A, wt, lane, wave, nullptr, nullptr);\n";
   else

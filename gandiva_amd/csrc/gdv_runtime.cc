@@ -343,8 +343,47 @@ static size_t RoundSize(size_t b) {
   return (b + g - 1) / g * g;
 }
 
+void Runtime::FreeAfter(void* ptr, hipStream_t stream) {
+  if (!ptr) return;
+  hipEvent_t e = nullptr;
+  if (!AcquireEvent(&e).ok() || hipEventRecord(e, stream) != hipSuccess) {
+    // no event to wait on: fall back to waiting for the stream itself
+    (void)hipGetLastError();
+    ReleaseEvent(e);
+    (void)hipStreamSynchronize(stream);
+    Free(ptr);
+    return;
+  }
+  std::lock_guard<std::mutex> g(mu_);
+  deferred_.emplace_back(e, ptr);
+}
+
+void Runtime::Reap(bool wait) {
+  std::vector<std::pair<hipEvent_t, void*>> done;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    if (deferred_.empty()) return;
+    size_t keep = 0;
+    for (size_t i = 0; i < deferred_.size(); i++) {
+      hipError_t q = wait ? hipEventSynchronize(deferred_[i].first) : hipEventQuery(deferred_[i].first);
+      if (q == hipSuccess) {
+        done.push_back(deferred_[i]);
+      } else {
+        if (q != hipErrorNotReady) (void)hipGetLastError();
+        deferred_[keep++] = deferred_[i];
+      }
+    }
+    deferred_.resize(keep);
+  }
+  for (auto& d : done) {
+    ReleaseEvent(d.first);
+    Free(d.second);
+  }
+}
+
 Status Runtime::Alloc(size_t bytes, void** ptr) {
   GDV_RETURN_NOT_OK(EnsureDevice());
+  Reap(false);
   size_t sz = RoundSize(bytes);
   {
     std::lock_guard<std::mutex> g(mu_);
@@ -359,6 +398,8 @@ Status Runtime::Alloc(size_t bytes, void** ptr) {
   }
   hipError_t e = hipMalloc(ptr, sz);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
+    Reap(true);
     TrimPool();
     e = hipMalloc(ptr, sz);
   }

@@ -72,6 +72,9 @@ class Runtime {
   // 256-byte aligned device memory from a size-bucketed free list.
   Status Alloc(size_t bytes, void** ptr);
   void Free(void* ptr);
+  // Free once everything enqueued on `stream` so far has run: asynchronous evaluations return
+  // before their scratch is idle.  An event guards the block; Alloc recycles completed ones.
+  void FreeAfter(void* ptr, hipStream_t stream);
   void TrimPool();
 
   // Page-locked host blocks of kPinnedBlock bytes (small-batch host path: one H2D and one
@@ -111,6 +114,8 @@ class Runtime {
   std::vector<char*> pinned_free_;
   std::vector<hipStream_t> streams_free_;
   std::vector<hipEvent_t> events_free_;
+  std::vector<std::pair<hipEvent_t, void*>> deferred_;  // FreeAfter: blocks waiting for their event
+  void Reap(bool wait);
   size_t cached_bytes_ = 0;
   uint64_t* all_ones_ = nullptr;
   void Probe();
@@ -133,6 +138,12 @@ class DeviceBuffer {
   }
   void reset() {
     if (p_) owner_->Free(p_);
+    p_ = nullptr;
+    n_ = 0;
+  }
+  // give the block back once the work enqueued on `stream` so far has run
+  void release_after(hipStream_t stream) {
+    if (p_) owner_->FreeAfter(p_, stream);
     p_ = nullptr;
     n_ = 0;
   }

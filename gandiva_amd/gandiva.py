@@ -425,8 +425,23 @@ class SelectionVector:
     """gandiva::SelectionVector (libgandiva.pxd:43-71): host numpy indices or, on the
     device path, a torch tensor of indices plus the slot count."""
 
-    def __init__(self, mode, indices, num_slots, device=False):
-        self.mode, self.indices, self.num_slots, self.device = mode, indices, num_slots, device
+    def __init__(self, mode, indices, num_slots, device=False, count_tensor=None):
+        self.mode, self.indices, self.device = mode, indices, device
+        self._num_slots = num_slots
+        # asynchronous device filter: the slot count is still in HBM (torch int64 tensor of one element)
+        self.count_tensor = count_tensor
+
+    @property
+    def num_slots(self):
+        """The slot count (reads it back from the device — and waits — if the filter was asynchronous)."""
+        if self._num_slots is None:
+            self._num_slots = int(self.count_tensor.item())
+        return self._num_slots
+
+    @property
+    def pending(self):
+        """True while the slot count has not been brought to the host."""
+        return self._num_slots is None
 
     def to_array(self):
         atype, ntype = _SEL_DTYPE[self.mode]
@@ -561,7 +576,12 @@ class Projector:
         import torch
         lib = _capi.lib()
         cols = (gdv_column_t * max(len(dbatch.columns), 1))(*[c._c() for c in dbatch.columns])
-        out_rows = selection.num_slots if selection is not None else dbatch.num_rows
+        # a selection whose count is still on the device: outputs and launch are sized for its capacity
+        pending = selection is not None and selection.device and selection.pending
+        if pending:
+            out_rows = selection.indices.numel()
+        else:
+            out_rows = selection.num_slots if selection is not None else dbatch.num_rows
         n_out = len(self._out_types)
         varlen = [pa.types.is_string(t) or pa.types.is_binary(t) for t in self._out_types]
         if outputs is None:
@@ -585,15 +605,23 @@ class Projector:
                 outs[i].offsets, outs[i].offsets_size = o.offsets.data_ptr(), o.offsets.numel()
         sel_c = None
         if selection is not None:
-            s = selection._c()
+            s = gdv_selection_t()
+            s.mode = selection.mode
+            s.num_slots = out_rows
+            s.indices = selection.indices.data_ptr() if selection.device else selection.indices.ctypes.data
             sel_c = C.byref(s)
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
         for attempt in range(2):
             caps = [outs[i].data_size for i in range(n_out)]
-            rc = lib.gdv_projector_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c,
-                                            outs, n_out, GDV_MEM_DEVICE, C.c_void_p(stream),
-                                            0 if sync else GDV_EVAL_ASYNC)
+            if pending:
+                rc = lib.gdv_projector_evaluate_selected(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c,
+                                                         C.c_void_p(selection.count_tensor.data_ptr()), outs, n_out,
+                                                         C.c_void_p(stream), 0 if sync else GDV_EVAL_ASYNC)
+            else:
+                rc = lib.gdv_projector_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c,
+                                                outs, n_out, GDV_MEM_DEVICE, C.c_void_p(stream),
+                                                0 if sync else GDV_EVAL_ASYNC)
             grown = False
             if rc == 4 and attempt == 0:
                 for i in range(n_out):
@@ -701,7 +729,10 @@ class Filter:
                                        GDV_MEM_HOST, None))
         return SelectionVector(mode, idx, count.value, device=False)
 
-    def evaluate_device(self, dbatch, dtype="int32", out=None, stream=None):
+    def evaluate_device(self, dbatch, dtype="int32", out=None, stream=None, sync=True):
+        """HBM-resident filter.  sync=False: everything is enqueued and the call returns at once; the
+        SelectionVector's slot count stays on the device (``count_tensor``) until someone asks for
+        ``num_slots`` — a selection-mode Projector.evaluate_device takes it from there directly."""
         import torch
         mode = self._mode_of(dtype)
         lib = _capi.lib()
@@ -712,6 +743,12 @@ class Filter:
         count = C.c_int64(0)
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
+        if not sync:
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            _check(lib.gdv_filter_evaluate_async(self._h, dbatch.num_rows, cols, len(dbatch.columns), mode,
+                                                 C.c_void_p(out.data_ptr()), out.numel(),
+                                                 C.c_void_p(cnt.data_ptr()), C.c_void_p(stream)))
+            return SelectionVector(mode, out, None, device=True, count_tensor=cnt)
         _check(lib.gdv_filter_evaluate(self._h, dbatch.num_rows, cols, len(dbatch.columns), mode,
                                        C.c_void_p(out.data_ptr()), out.numel(), C.byref(count),
                                        GDV_MEM_DEVICE, C.c_void_p(stream)))

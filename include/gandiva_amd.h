@@ -230,6 +230,14 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
 int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
                            int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
                            int num_outs, int mem_kind, void* stream, uint32_t flags);
+/* The same under a selection vector whose slot COUNT is still on the device: the kernel reads the
+ * number of slots from *num_slots_device (int64 in device or pinned memory — where
+ * gdv_filter_evaluate_async left it); sel->num_slots is only the capacity the outputs and the launch
+ * are sized for.  Filter -> project then needs no host round trip between the two calls.  Device
+ * buffers, fixed-width outputs; rows of the outputs beyond the real count are not written. */
+int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
+                                    int num_cols, const gdv_selection_t* sel, const void* num_slots_device,
+                                    gdv_out_column_t* outs, int num_outs, void* stream, uint32_t flags);
 char* gdv_projector_dump_ir(const gdv_projector_t* p);
 void gdv_projector_free(gdv_projector_t* p);
 
@@ -242,6 +250,13 @@ int gdv_filter_make(const gdv_schema_t* schema, gdv_expression_t* condition,
 int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols,
                         int num_cols, int selection_mode, void* out_indices, int64_t max_slots,
                         int64_t* num_selected, int mem_kind, void* stream);
+/* Asynchronous variant for HBM-resident batches: everything is enqueued on `stream` and the call
+ * returns without waiting; the selected-row count (int64) lands in *num_selected_device — 8 bytes of
+ * device or pinned host memory — in stream order.  Plans that can raise (divide, mod ...) and plans
+ * with a materialising first stage wait like gdv_filter_evaluate does (the count is written either way). */
+int gdv_filter_evaluate_async(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                              int selection_mode, void* out_indices, int64_t max_slots, void* num_selected_device,
+                              void* stream);
 char* gdv_filter_dump_ir(const gdv_filter_t* f);
 void gdv_filter_free(gdv_filter_t* f);
 
