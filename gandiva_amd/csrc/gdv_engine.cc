@@ -318,13 +318,15 @@ Status StageBitmap(const void* host, int64_t off, int64_t rows, hipStream_t stre
 }
 
 Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuffers* cols,
-                  int num_cols, int64_t num_rows, MemKind mem, hipStream_t stream,
-                  ArgBlock* args, Staging* st) {
+                  int num_cols, int64_t batch_rows, MemKind mem, hipStream_t stream,
+                  ArgBlock* args, Staging* st, int64_t compact_rows = -1) {
   if (num_cols != static_cast<int>(schema.size()))
     return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
                            ") does not match the schema (" + std::to_string(schema.size()) + ")");
   for (size_t k = 0; k < plan.input_fields.size(); k++) {
     const int idx = plan.input_fields[k];
+    // (temporaries of a selection-mode first stage hold one row per slot, not per batch row)
+    const int64_t num_rows = (idx >= plan.compact_from && compact_rows >= 0) ? compact_rows : batch_rows;
     const ColumnBuffers& c = cols[idx];
     const DataType& t = schema[idx].type;
     const std::string& name = schema[idx].name;
@@ -499,9 +501,12 @@ LruCache<Filter>& FilterCache() {
 
 // ------------------------------------------------------------------ two-stage plans
 
-Status StageColumns::Run(const Projector& pre, int64_t num_rows, const ColumnBuffers* in, int num_cols,
-                         MemKind mem, hipStream_t stream) {
+Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnBuffers* in, int num_cols,
+                         MemKind mem, hipStream_t stream, const SelectionView* sel) {
   const int np = pre.num_outputs();
+  // under a selection vector the first stage evaluates the SELECTED rows only (it may raise only
+  // where the caller's projector may) and its temporaries hold one row per slot
+  const int64_t num_rows = sel != nullptr ? sel->num_slots : batch_rows;
   cols.assign(in, in + num_cols);
   auto alloc = [&](int64_t bytes, void** p) -> Status {
     bytes = std::max<int64_t>(bytes, 8);
@@ -537,7 +542,7 @@ Status StageColumns::Run(const Projector& pre, int64_t num_rows, const ColumnBuf
     GDV_RETURN_NOT_OK(alloc(cap[e], &po[e].data));
     po[e].data_size = cap[e];
   }
-  Status s = pre.Evaluate(num_rows, in, num_cols, nullptr, po.data(), np, mem, stream, 0);
+  Status s = pre.Evaluate(batch_rows, in, num_cols, sel, po.data(), np, mem, stream, 0);
   if (!s.ok()) {
     bool grew = false;
     for (int e = 0; e < np; e++) {
@@ -549,7 +554,7 @@ Status StageColumns::Run(const Projector& pre, int64_t num_rows, const ColumnBuf
       po[e].data_size = cap[e];
     }
     if (!grew) return s;
-    GDV_RETURN_NOT_OK(pre.Evaluate(num_rows, in, num_cols, nullptr, po.data(), np, mem, stream, 0));
+    GDV_RETURN_NOT_OK(pre.Evaluate(batch_rows, in, num_cols, sel, po.data(), np, mem, stream, 0));
   }
   for (int e = 0; e < np; e++) {
     ColumnBuffers c;
@@ -589,18 +594,17 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
   p->plan_schema_ = schema;
   const std::vector<ExpressionPtr>* planned = &exprs;
   StagedExpressions staged;
-  if (mode == SelectionMode::kNone) {
-    // (with a selection vector the first stage would have to run — and could raise — on rows the
-    // selection leaves out: such plans stay single-stage and the planner rejects them as before)
-    StageMaterialisedValues(schema, exprs, &staged);
-    if (!staged.pre.empty()) {
-      for (auto& e : exprs) GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));  // errors name the caller's trees
-      GDV_RETURN_NOT_OK(Projector::Make(schema, staged.pre, SelectionMode::kNone, config, &p->pre_));
-      p->plan_schema_ = staged.schema;
-      planned = &staged.main;
-    }
+  // (round 3: in every selection mode — the first stage is built in the SAME mode, so it evaluates,
+  // and can raise, only on the selected rows, and writes one temporary row per slot)
+  StageMaterialisedValues(schema, exprs, &staged);
+  if (!staged.pre.empty()) {
+    for (auto& e : exprs) GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));  // errors name the caller's trees
+    GDV_RETURN_NOT_OK(Projector::Make(schema, staged.pre, mode, config, &p->pre_));
+    p->plan_schema_ = staged.schema;
+    planned = &staged.main;
   }
-  GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_));
+  GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_,
+                                  mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
   const PlanDeviceState* st = nullptr;
   GDV_RETURN_NOT_OK(p->states_.Get(p->plan_, &st));  // compiles + loads on the calling thread's device
   ProjectorCache().Put(key, p);
@@ -650,12 +654,13 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (num_cols != static_cast<int>(schema_.size()))
       return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
                              ") does not match the schema (" + std::to_string(schema_.size()) + ")");
-    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream));
+    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream, has_sel ? sel : nullptr));
     cols = stage.cols.data();
     num_cols = static_cast<int>(stage.cols.size());
   }
   if (mem == MemKind::kHost && num_rows <= Staging::kPackRows) GDV_RETURN_NOT_OK(st.EnablePacked());
-  GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, mem, stream, &args, &st,
+                               has_sel ? out_rows : -1));
   BindLiterals(plan_, dev->consts, &args);
   // pooled staging blocks (e.g. the zero-padded copy of a tiny var-len buffer) go back to the
   // pool when this call returns: an asynchronous evaluation must not outlive them
@@ -1135,11 +1140,12 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
                            SelectionMode mode) {
   KernelPlan plan;
   StagedExpressions staged;
-  if (mode == SelectionMode::kNone) StageMaterialisedValues(schema, exprs, &staged);
+  StageMaterialisedValues(schema, exprs, &staged);
   if (!staged.pre.empty()) {
     for (auto& e : exprs) GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
-    GDV_RETURN_NOT_OK(PrecompileProjector(schema, staged.pre, SelectionMode::kNone));
-    GDV_RETURN_NOT_OK(PlanProjector(staged.schema, staged.main, mode, CodegenOptions::FromEnv(), &plan));
+    GDV_RETURN_NOT_OK(PrecompileProjector(schema, staged.pre, mode));
+    GDV_RETURN_NOT_OK(PlanProjector(staged.schema, staged.main, mode, CodegenOptions::FromEnv(), &plan,
+                                    mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
   } else {
     GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));
   }

@@ -125,7 +125,7 @@ struct StageColumns {
   std::vector<std::unique_ptr<std::vector<uint8_t>>> host;
   std::vector<ColumnBuffers> cols;  // caller's columns + the temporaries
   Status Run(const Projector& pre, int64_t num_rows, const ColumnBuffers* in, int num_cols, MemKind mem,
-             hipStream_t stream);
+             hipStream_t stream, const SelectionView* sel = nullptr);
 };
 
 class Filter {

@@ -448,6 +448,7 @@ class CodeGen {
   const Schema& schema_;
   SelectionMode sel_mode_;
   CodegenOptions opts_;
+  int compact_from_ = 0x7fffffff;  // schema fields from this index on are compact temporaries (selection mode)
   std::ostringstream body_;
   std::map<std::string, std::string> cse_;
   int next_tmp_ = 0;
@@ -783,6 +784,30 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       std::string take = Tmp("bool", AndFull(LaneValid(c), c.v));
       GDV_RETURN_NOT_OK(Gen(*n.then_node(), AndExpr(active, take), &t));
       GDV_RETURN_NOT_OK(Gen(*n.else_node(), AndExpr(active, "!" + take), &e));
+      // `if (c) <materialised value> else NULL` (and its mirror): the value is the branch's, valid only
+      // where the branch is taken — what a guarded first-stage expression of a two-stage plan looks
+      // like (StageMaterialisedValues), and fine wherever a materialised value is (output, concat)
+      {
+        const bool t_mat = !t.pieces.empty() || t.opaque, e_mat = !e.pieces.empty() || e.opaque;
+        auto null_literal = [](const Node& x) {
+          return x.kind() == NodeKind::kLiteral && static_cast<const LiteralNode&>(x).is_null();
+        };
+        if (t_mat != e_mat && null_literal(t_mat ? *n.else_node() : *n.then_node())) {
+          const Val& m = t_mat ? t : e;
+          const std::string taken = t_mat ? take : "!" + take;
+          *out = m;
+          out->type = n.return_type();
+          if (!m.vcols.empty()) {  // fold the column validity into the lane predicate next to the guard
+            out->vlane = AndExpr(LaneValid(m), taken);
+            out->vcols.clear();
+          } else {
+            out->vlane = AndExpr(m.vlane, taken);
+          }
+          for (auto& pc : out->pieces) pc.second = AndExpr(pc.second, taken);
+          out->col_slot = -1;
+          return Status::OK();
+        }
+      }
       if (!t.pieces.empty() || !e.pieces.empty() || t.opaque || e.opaque)
         return Status::CodeGenError(
             "if/else over a concat / lpad / rpad / reverse / replace / castVARCHAR(number) result is not supported by the HIP "
@@ -914,6 +939,13 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
     }
   }
   return Status::CodeGenError("unknown node kind");
+}
+
+// Selection mode: the row of input slot k that output slot `row` reads.  Columns of the caller's
+// batch are gathered through the selection vector; the temporaries of a two-stage plan (schema
+// index >= compact_from_) were produced BY a selection-mode first stage and are compact already.
+std::string RowOf(const CodeGen& cg, int k) {
+  return cg.input_fields_[k] >= cg.compact_from_ ? "(live ? row : 0)" : "srow[u]";
 }
 
 // Assembles the translation unit around the generated row body.
@@ -1098,11 +1130,11 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
       for (int k = 0; k < nin; k++) {
         const DataType& t = cg.schema_[plan->input_fields[k]].type;
         if (t.id == kBool) {
-          if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+          if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, " << RowOf(cg, k) << ");\n";
         } else if (cg.needs_values_[k]) {
-          s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+          s << "    c" << k << "[u] = gdv_ld(in" << k << ", " << RowOf(cg, k) << ");\n";
         }
-        if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+        if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, " << RowOf(cg, k) << ");\n";
       }
     } else {
       for (int k = 0; k < nin; k++) {
@@ -1258,14 +1290,14 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.id == kBool) {
-        if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, srow[u]);\n";
+        if (cg.needs_values_[k]) s << "    x" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].bits, " << RowOf(cg, k) << ");\n";
       } else if (t.is_varlen()) {
         if (cg.needs_values_[k])
-          s << "    oa" << k << "[u] = so" << k << "[srow[u]]; ob" << k << "[u] = so" << k << "[srow[u] + 1];\n";
+          s << "    oa" << k << "[u] = so" << k << "[" << RowOf(cg, k) << "]; ob" << k << "[u] = so" << k << "[" << RowOf(cg, k) << " + 1];\n";
       } else if (cg.needs_values_[k]) {
-        s << "    c" << k << "[u] = gdv_ld(in" << k << ", srow[u]);\n";
+        s << "    c" << k << "[u] = gdv_ld(in" << k << ", " << RowOf(cg, k) << ");\n";
       }
-      if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, srow[u]);\n";
+      if (cg.needs_validity_[k]) s << "    b" << k << "[u] = gdv_bitmap_bit(A.in[" << k << "].valid, " << RowOf(cg, k) << ");\n";
     }
   } else {
     for (int k = 0; k < nin; k++) {
@@ -1848,11 +1880,13 @@ bool ByteFree(const Node& n) {
 // `only` (the scanned var-len outputs of the main kernel, in that order = segment order).
 Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>& exprs, SelectionMode mode,
                           const CodegenOptions& opts, StringShape shape, const std::vector<int>* only,
-                          KernelPlan* plan, std::vector<VarlenOut>* varlen_outs) {
+                          KernelPlan* plan, std::vector<VarlenOut>* varlen_outs, int compact_from) {
   plan->kind = KernelKind::kProject;
   plan->mode = mode;
   plan->opts = opts;
+  plan->compact_from = compact_from;
   CodeGen cg(schema, mode, opts);
+  cg.compact_from_ = compact_from;
   WordAccumulators accs;
   std::ostringstream after_loop, before_loop, in_pass, after_rows;
   std::vector<std::string> strings;
@@ -2095,7 +2129,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
 }  // namespace
 
 Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
-                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan) {
+                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan, int compact_from) {
   if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
   for (auto& e : exprs) {
     if (!e) return Status::Invalid("Expression cannot be null");
@@ -2112,12 +2146,12 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     wave_ok = wave_ok && ByteFree(*e->root());
   }
   if (!(wave_ok && any_varlen_out))
-    return PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, plan, nullptr);
+    return PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, plan, nullptr, compact_from);
 
   KernelPlan fast, slow;
   std::vector<VarlenOut> vouts;
-  GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, opts, StringShape::kWaveMain, nullptr, &fast, &vouts));
-  GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, &slow, nullptr));
+  GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, opts, StringShape::kWaveMain, nullptr, &fast, &vouts, compact_from));
+  GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, &slow, nullptr, compact_from));
   // one argument block serves both kernels: the two generations must have bound the same inputs,
   // literals and constants (they run the same tree walk; checked, not assumed)
   if (fast.input_fields != slow.input_fields || fast.input_needs_values != slow.input_needs_values ||
@@ -2145,7 +2179,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   if (!scanned.empty()) {
     auto pre = std::make_shared<KernelPlan>();
     CodegenOptions popts = fast.opts;  // same tile: a wave tile of the pre-pass IS a wave tile of the main kernel
-    GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, popts, StringShape::kWavePrepass, &scanned, pre.get(), nullptr));
+    GDV_RETURN_NOT_OK(PlanProjectorShape(schema, exprs, mode, popts, StringShape::kWavePrepass, &scanned, pre.get(), nullptr, compact_from));
     if (pre->opts.subtiles != fast.opts.subtiles) {
       *plan = slow;
       return Status::OK();
@@ -2225,7 +2259,19 @@ struct Stager {
   StagedExpressions* out;
   std::map<std::string, NodePtr> field_of;  // hoisted sub-tree (cache key) -> its temporary field
 
-  NodePtr Hoist(const NodePtr& n) {
+  // `guard` (may be null): the condition under which the caller's tree evaluates `n` at all — the
+  // enclosing if/else branches and short-circuit AND / OR children.  The first stage evaluates
+  // every row, so a guarded sub-tree is hoisted as `if (guard) n else NULL`: functions that can
+  // raise (castVARCHAR(a / b, n), replace ...) then run only where the caller's tree would have
+  // run them (round-2 advisor: `if (b != 0) upper(castVARCHAR(a / b, 10)) else 'x'` raised).
+  NodePtr Hoist(const NodePtr& sub, const NodePtr& guard) {
+    NodePtr n = sub;
+    if (guard) {
+      Literal null_value;
+      null_value.is_null = true;
+      n = std::make_shared<IfNode>(guard, sub, std::make_shared<LiteralNode>(sub->return_type(), null_value),
+                                   sub->return_type());
+    }
     std::string key;
     n->AppendKey(&key);
     auto it = field_of.find(key);
@@ -2245,9 +2291,17 @@ struct Stager {
     field_of[key] = field;
     return field;
   }
+  static NodePtr AndGuard(const NodePtr& a, const NodePtr& b) {
+    if (!a) return b;
+    if (!b) return a;
+    return std::make_shared<BooleanNode>(BooleanNode::kAnd, NodeVector{a, b});
+  }
+  static NodePtr Test(const char* fn, const NodePtr& x) {  // istrue / isnottrue / isnotfalse: never null
+    return std::make_shared<FunctionNode>(fn, NodeVector{x}, boolean());
+  }
   // `takes_bytes`: the parent is an output root or a concat — it can take a materialising child as it is
-  NodePtr Rewrite(const NodePtr& n, bool takes_bytes) {
-    if (MaterialisesBytes(*n) && !takes_bytes) return Hoist(n);  // (its own sub-tree is the first stage's business)
+  NodePtr Rewrite(const NodePtr& n, bool takes_bytes, const NodePtr& guard) {
+    if (MaterialisesBytes(*n) && !takes_bytes) return Hoist(n, guard);  // (its own sub-tree is the first stage's business)
     switch (n->kind()) {
       case NodeKind::kFunction: {
         auto& fn = static_cast<const FunctionNode&>(*n);
@@ -2255,30 +2309,47 @@ struct Stager {
         NodeVector kids;
         bool changed = false;
         for (auto& c : fn.children()) {
-          kids.push_back(Rewrite(c, is_concat));
+          kids.push_back(Rewrite(c, is_concat, guard));
           changed |= kids.back() != c;
         }
         return changed ? std::make_shared<FunctionNode>(fn.name(), kids, fn.return_type()) : n;
       }
       case NodeKind::kIf: {
+        // guards are built from the caller's ORIGINAL condition: it must be evaluable by the first
+        // stage, which knows nothing of the temporaries of this one
         auto& i = static_cast<const IfNode&>(*n);
-        NodePtr c = Rewrite(i.condition(), false), t = Rewrite(i.then_node(), false), e = Rewrite(i.else_node(), false);
+        // (`if (c) <materialised> else NULL` is something the kernel takes as it is wherever it takes
+        // a materialised value — CodeGen::Gen, kIf — which is also what a guarded hoist looks like:
+        // its branch inherits `takes_bytes`, or the first stage would hoist it again, for ever)
+        auto null_literal = [](const NodePtr& x) {
+          return x->kind() == NodeKind::kLiteral && static_cast<const LiteralNode&>(*x).is_null();
+        };
+        NodePtr c = Rewrite(i.condition(), false, guard);
+        NodePtr t = Rewrite(i.then_node(), takes_bytes && null_literal(i.else_node()),
+                            AndGuard(guard, Test("istrue", i.condition())));
+        NodePtr e = Rewrite(i.else_node(), takes_bytes && null_literal(i.then_node()),
+                            AndGuard(guard, Test("isnottrue", i.condition())));
         if (c == i.condition() && t == i.then_node() && e == i.else_node()) return n;
         return std::make_shared<IfNode>(c, t, e, i.return_type());
       }
       case NodeKind::kBoolean: {
+        // left-to-right short circuit: child k of an AND runs while no earlier child was (valid,
+        // false); of an OR, while none was (valid, true)
         auto& b = static_cast<const BooleanNode&>(*n);
+        const char* still = b.op() == BooleanNode::kAnd ? "isnotfalse" : "isnottrue";
         NodeVector kids;
         bool changed = false;
+        NodePtr g = guard;
         for (auto& c : b.children()) {
-          kids.push_back(Rewrite(c, false));
+          kids.push_back(Rewrite(c, false, g));
           changed |= kids.back() != c;
+          g = AndGuard(g, Test(still, c));
         }
         return changed ? std::make_shared<BooleanNode>(b.op(), kids) : n;
       }
       case NodeKind::kIn: {
         auto& in = static_cast<const InNode&>(*n);
-        NodePtr e = Rewrite(in.eval(), false);
+        NodePtr e = Rewrite(in.eval(), false, guard);
         return e == in.eval() ? n : std::make_shared<InNode>(e, in.value_type(), in.values());
       }
       default:
@@ -2300,7 +2371,7 @@ void StageMaterialisedValues(const Schema& schema, const std::vector<ExpressionP
       out->main.push_back(e);
       continue;
     }
-    NodePtr root = st.Rewrite(e->root(), true);
+    NodePtr root = st.Rewrite(e->root(), true, nullptr);
     out->main.push_back(root == e->root() ? e : std::make_shared<Expression>(root, e->result()));
   }
 }

@@ -88,6 +88,7 @@ struct KernelPlan {
   // totals per wave tile from the offsets alone) + the offsets scan; wave_segments[v] = the
   // segment of var-len output v, -1 for flat outputs.  source_general / kernel_name_general hold
   // the scanner-shaped fallback (a batch that breaks the ASCII / flat assumption is re-run on it).
+  int compact_from = 0x7fffffff;  // selection mode: schema fields from here on are compact temporaries
   bool wave_tiles = false;
   std::shared_ptr<KernelPlan> prepass;
   std::vector<int> wave_segments;
@@ -99,8 +100,12 @@ constexpr int kMaxWaveSegments = 8;
 // Validates every expression against the schema and the function registry, then emits the
 // fused kernel.  Errors: ExpressionValidationError for type / signature problems,
 // CodeGenError for constructs the HIP backend does not cover yet.
+// compact_from (selection mode, two-stage plans): schema fields from this index on are the
+// temporaries a selection-mode first stage produced — one row per SLOT, read at the slot's own
+// position; the caller's columns are gathered through the selection vector.
 Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
-                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* out);
+                     SelectionMode mode, const CodegenOptions& opts, KernelPlan* out,
+                     int compact_from = 0x7fffffff);
 Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
                   const CodegenOptions& opts, KernelPlan* out);
 

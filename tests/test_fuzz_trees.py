@@ -330,5 +330,17 @@ def test_fuzzed_trees_with_materialised_values_match_oracle(seed):
     for g, w, e in zip(got, oracle.project(exprs, batch), exprs):
         g.validate(full=True)
         assert_bit_exact(g, w, f"seed {seed}: {e}")
-    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, pa.default_memory_pool(), "int32").to_array()
+    sv = gandiva.make_filter(batch.schema, cond).evaluate(batch, pa.default_memory_pool(), "int32")
+    sel = sv.to_array()
     assert sel.equals(oracle.filter_indices(cond, batch, "int32")), f"seed {seed}: {cond}"
+    # (round 3) materialised values under a selection vector: the first stage runs in the same
+    # SelectionVector::Mode, on the selected rows only
+    if len(sel):
+        want = oracle.project(exprs, batch)
+        for mode, dt in (("UINT32", "int32"), ("UINT64", "int64"), ("UINT16", "int16")):
+            if mode == "UINT16" and n > 65536:
+                continue
+            svm = gandiva.make_filter(batch.schema, cond).evaluate(batch, pa.default_memory_pool(), dt)
+            got_sel = gandiva.make_projector(batch.schema, exprs, None, mode).evaluate(batch, svm)
+            for g, w, e in zip(got_sel, want, exprs):
+                assert_bit_exact(g, oracle.take_rows(w, sel), f"seed {seed} ({mode}): {e}")

@@ -416,9 +416,9 @@ def test_concat_results_feed_other_functions_through_a_first_stage():
     arr = (C.c_void_p * 1)(e._h)
     # round 2: the concat is hoisted into a first-stage kernel (tests/test_registry_tail.py) ...
     assert _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 0) == 0, _capi.last_error()
-    # ... except under a selection vector, where the first stage would run on unselected rows
-    rc = _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 2)
-    assert rc == 40 and "concat" in _capi.last_error()      # CodeGenError, said plainly
+    # ... round 3: also under a selection vector — the first stage is built in the same mode and
+    # evaluates the selected rows only (tests/test_registry_tail.py)
+    assert _capi.lib().gdv_precompile_projector(gg._make_schema(schema), arr, 1, 2) == 0, _capi.last_error()
 
 
 @pytest.mark.gpu
