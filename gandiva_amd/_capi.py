@@ -78,6 +78,9 @@ PROTOTYPES = [
     ("gdv_filter_make", C.c_int, [_P, _P, C.POINTER(gdv_config_t), C.POINTER(_P)]),
     ("gdv_filter_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), C.c_int, _P]),
     ("gdv_filter_evaluate_async", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.c_int, _P, C.c_int64, _P, _P]),
+    ("gdv_projector_make_from_proto", C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.POINTER(gdv_config_t), C.POINTER(_P)]),
+    ("gdv_filter_make_from_proto", C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(gdv_config_t), C.POINTER(_P)]),
+    ("gdv_proto_describe", _P, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int]),
     ("gdv_filter_dump_ir", _P, [_P]),
     ("gdv_filter_free", None, [_P]),
     ("gdv_registry_size", C.c_int, []),

@@ -12,6 +12,7 @@
 
 #include "gdv_engine.h"
 #include "gdv_libtag.h"
+#include "gdv_proto.h"
 
 using namespace gdv;
 
@@ -436,6 +437,72 @@ int gdv_filter_evaluate_async(const gdv_filter_t* f, int64_t num_rows, const gdv
   int64_t unused = 0;
   return Check(f->f->Evaluate(num_rows, c.data(), num_cols, mode, out_indices, max_slots, &unused, MemKind::kDevice,
                               static_cast<hipStream_t>(stream), kEvalAsync, num_selected_device));
+  });
+}
+// ---------------------------------------------------------------- build from protobuf bytes (JNI)
+int gdv_projector_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes,
+                                  int64_t exprs_len, int selection_mode, const gdv_config_t* config,
+                                  gdv_projector_t** out) {
+  return Guarded([&]() -> int {
+  if (!out || schema_len < 0 || exprs_len < 0) return Fail(Status::Invalid("bad argument"));
+  Schema schema;
+  std::vector<ExpressionPtr> ex;
+  Status s = DecodeSchema(static_cast<const uint8_t*>(schema_bytes), static_cast<size_t>(schema_len), &schema);
+  if (s.ok()) s = DecodeExpressionList(static_cast<const uint8_t*>(exprs_bytes), static_cast<size_t>(exprs_len), &ex);
+  if (!s.ok()) return Fail(s);
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  Configuration cfg;
+  if (config) { cfg.optimize = config->optimize != 0; cfg.dump_ir = config->dump_ir != 0; }
+  std::shared_ptr<Projector> p;
+  s = Projector::Make(schema, ex, mode, cfg, &p);
+  if (!s.ok()) return Fail(s);
+  std::vector<std::string> names;
+  for (auto& e : ex) names.push_back(e->result().name);
+  *out = new gdv_projector{p, std::move(names)};
+  return GDV_OK;
+  });
+}
+int gdv_filter_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* condition_bytes,
+                               int64_t condition_len, const gdv_config_t* config, gdv_filter_t** out) {
+  return Guarded([&]() -> int {
+  if (!out || schema_len < 0 || condition_len < 0) return Fail(Status::Invalid("bad argument"));
+  Schema schema;
+  ExpressionPtr cond;
+  Status s = DecodeSchema(static_cast<const uint8_t*>(schema_bytes), static_cast<size_t>(schema_len), &schema);
+  if (s.ok()) s = DecodeCondition(static_cast<const uint8_t*>(condition_bytes), static_cast<size_t>(condition_len), &cond);
+  if (!s.ok()) return Fail(s);
+  Configuration cfg;
+  if (config) { cfg.optimize = config->optimize != 0; cfg.dump_ir = config->dump_ir != 0; }
+  std::shared_ptr<Filter> f;
+  s = Filter::Make(schema, cond, cfg, &f);
+  if (!s.ok()) return Fail(s);
+  *out = new gdv_filter{f};
+  return GDV_OK;
+  });
+}
+// the decoded trees, rendered (what a test — or a maintainer diffing against the Java side — reads)
+char* gdv_proto_describe(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes, int64_t exprs_len,
+                         int is_condition) {
+  return GuardedPtr([&]() -> char* {
+  Schema schema;
+  Status s = DecodeSchema(static_cast<const uint8_t*>(schema_bytes), static_cast<size_t>(schema_len), &schema);
+  std::string text;
+  if (s.ok()) {
+    for (auto& f : schema) text += "field " + f.name + ": " + f.type.ToString() + (f.nullable ? "" : " not null") + "\n";
+    if (is_condition) {
+      ExpressionPtr cond;
+      s = DecodeCondition(static_cast<const uint8_t*>(exprs_bytes), static_cast<size_t>(exprs_len), &cond);
+      if (s.ok()) text += "condition " + cond->ToString() + "\n";
+    } else {
+      std::vector<ExpressionPtr> ex;
+      s = DecodeExpressionList(static_cast<const uint8_t*>(exprs_bytes), static_cast<size_t>(exprs_len), &ex);
+      if (s.ok())
+        for (auto& e : ex) text += "expr " + e->result().name + ": " + e->result().type.ToString() + " = " + e->ToString() + "\n";
+    }
+  }
+  if (!s.ok()) { Fail(s); return nullptr; }
+  return DupString(text);
   });
 }
 char* gdv_filter_dump_ir(const gdv_filter_t* f) { return f ? DupString(f->f->DumpIR()) : nullptr; }

@@ -308,6 +308,23 @@ int gdv_filter_evaluate_flat(const gdv_filter_t* f, int64_t num_rows, const int6
                              const int64_t* buf_sizes, int num_bufs, int sel_mode, int64_t out_addr,
                              int64_t out_size_bytes, int64_t* num_selected, int mem_kind);
 
+/* ---- build from protobuf bytes: the other half of the JNI boundary ---- */
+/* What the reference's JNI buildProjector / buildFilter receive from Java: the Schema, and the
+ * ExpressionList / Condition, serialised with protobuf (java: GandivaTypes from proto/Types.proto).
+ * The message layout assumed is restated in gandiva_amd/csrc/gdv_proto.cc (from memory: the
+ * reference mount holds no source — diff it against the real Types.proto); the wire format is
+ * decoded by hand (no protoc / libprotobuf in this image).  selection_mode: gdv_selection_mode —
+ * the proto's SelectionVectorType values SV_NONE / SV_INT16 / SV_INT32 are numerically the same.
+ * The handles are the ordinary ones: evaluate with gdv_*_evaluate_flat, as the JNI layer would. */
+int gdv_projector_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes,
+                                  int64_t exprs_len, int selection_mode, const gdv_config_t* config,
+                                  gdv_projector_t** out);
+int gdv_filter_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* condition_bytes,
+                               int64_t condition_len, const gdv_config_t* config, gdv_filter_t** out);
+/* The decoded schema and trees rendered as text (NULL + gdv_last_error on malformed bytes). */
+char* gdv_proto_describe(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes, int64_t exprs_len,
+                         int is_condition);
+
 /* ---- Arrow C Device Data Interface (the step BEFORE the path: other ROCm producers) --- */
 /* The ABI-stable structs of the Arrow C data / C device data interfaces
  * (pyarrow/include/arrow/c/abi.h).  Declared here under the spec's own include guards so
