@@ -36,6 +36,11 @@ class gdv_out_column_t(C.Structure):
     ]
 
 
+class gdv_batch_t(C.Structure):
+    _fields_ = [("num_rows", C.c_int64), ("cols", C.POINTER(gdv_column_t)), ("num_cols", C.c_int),
+                ("outs", C.POINTER(gdv_out_column_t)), ("num_outs", C.c_int)]
+
+
 class gdv_selection_t(C.Structure):
     _fields_ = [("mode", C.c_int32), ("indices", C.c_void_p), ("num_slots", C.c_int64)]
 
@@ -73,6 +78,7 @@ PROTOTYPES = [
     ("gdv_projector_output_sizes", C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("gdv_projector_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_selection_t), C.POINTER(gdv_out_column_t), C.c_int, C.c_int, _P, C.c_uint32]),
     ("gdv_projector_evaluate_selected", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_selection_t), _P, C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_uint32]),
+    ("gdv_projector_evaluate_many", C.c_int, [_P, C.POINTER(gdv_batch_t), C.c_int, _P, C.c_uint32]),
     ("gdv_projector_dump_ir", _P, [_P]),
     ("gdv_projector_free", None, [_P]),
     ("gdv_filter_make", C.c_int, [_P, _P, C.POINTER(gdv_config_t), C.POINTER(_P)]),

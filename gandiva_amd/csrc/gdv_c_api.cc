@@ -392,6 +392,39 @@ int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, 
   return ProjectorEvaluate(p, num_rows, cols, num_cols, sel, num_slots_device, outs, num_outs, GDV_MEM_DEVICE, stream,
                            flags);
 }
+int gdv_projector_evaluate_many(const gdv_projector_t* p, const gdv_batch_t* batches, int num_batches, void* stream,
+                                uint32_t flags) {
+  return Guarded([&]() -> int {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (num_batches < 0 || (num_batches > 0 && !batches)) return Fail(Status::Invalid("null batch list"));
+  std::vector<std::vector<ColumnBuffers>> cols(num_batches);
+  std::vector<std::vector<OutputBuffers>> outs(num_batches);
+  std::vector<Projector::BatchView> views(num_batches);
+  for (int b = 0; b < num_batches; b++) {
+    const gdv_batch_t& g = batches[b];
+    if ((g.num_cols > 0 && !g.cols) || (g.num_outs > 0 && !g.outs)) return Fail(Status::Invalid("null column array"));
+    cols[b] = ToColumns(g.cols, g.num_cols);
+    outs[b].resize(g.num_outs > 0 ? g.num_outs : 0);
+    for (int i = 0; i < g.num_outs; i++) {
+      outs[b][i].validity = g.outs[i].validity;
+      outs[b][i].validity_size = g.outs[i].validity_size;
+      outs[b][i].data = g.outs[i].data;
+      outs[b][i].data_size = g.outs[i].data_size;
+      outs[b][i].offsets = g.outs[i].offsets;
+      outs[b][i].offsets_size = g.outs[i].offsets_size;
+    }
+    views[b].num_rows = g.num_rows;
+    views[b].cols = cols[b].data();
+    views[b].num_cols = g.num_cols;
+    views[b].outs = outs[b].data();
+    views[b].num_outs = g.num_outs;
+  }
+  Status st = p->p->EvaluateMany(views.data(), num_batches, static_cast<hipStream_t>(stream), flags);
+  for (int b = 0; b < num_batches; b++)
+    for (int i = 0; i < batches[b].num_outs; i++) batches[b].outs[i].data_size = outs[b][i].data_size;
+  return Check(st);
+  });
+}
 char* gdv_projector_dump_ir(const gdv_projector_t* p) { return p ? DupString(p->p->DumpIR()) : nullptr; }
 void gdv_projector_free(gdv_projector_t* p) { delete p; }
 

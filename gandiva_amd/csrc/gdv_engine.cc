@@ -936,6 +936,82 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   return Status::OK();
 }
 
+Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t stream, uint32_t flags) const {
+  if (nb <= 0) return Status::OK();
+  if (batches == nullptr) return Status::Invalid("null batch list");
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  const PlanDeviceState* dev = nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+  const size_t stride = static_cast<size_t>(plan_.layout.total());
+  const bool one_launch = plan_.has_many_entry && dev->kernel->function_many != nullptr && pre_ == nullptr &&
+                          plan_.num_varlen_outputs == 0 && !plan_.string_skeleton &&
+                          stride * static_cast<size_t>(nb) <= Runtime::kPinnedBlock && nb <= 65535 &&
+                          std::getenv("GDV_NO_EVALUATE_MANY") == nullptr;
+  if (!one_launch) {
+    // batch by batch, all enqueued on `stream`; one wait at the end unless the caller asked for none
+    for (int b = 0; b < nb; b++)
+      GDV_RETURN_NOT_OK(Evaluate(batches[b].num_rows, batches[b].cols, batches[b].num_cols, nullptr, batches[b].outs,
+                                 batches[b].num_outs, MemKind::kDevice, stream, kEvalAsync));
+    if (!(flags & kEvalAsync)) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+    return Status::OK();
+  }
+  char* pin = nullptr;
+  GDV_RETURN_NOT_OK(rt.AcquirePinned(&pin));
+  struct PinGuard {
+    Runtime& rt; char*& pin;
+    ~PinGuard() { if (pin != nullptr) rt.ReleasePinned(pin); }
+  } pin_guard{rt, pin};
+  DeviceBuffer table, err;
+  GDV_RETURN_NOT_OK(table.Allocate(stride * nb));
+  if (plan_.can_raise) {
+    GDV_RETURN_NOT_OK(err.Allocate(8));
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
+  }
+  Staging st;  // (device buffers bind in place: nothing is staged)
+  int64_t grid = 1;
+  for (int b = 0; b < nb; b++) {
+    const BatchView& v = batches[b];
+    if (v.num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+    if (v.outs == nullptr || v.num_outs != num_outputs())
+      return Status::Invalid("batch " + std::to_string(b) + ": number of output buffers does not match the number of expressions");
+    ArgBlock args(plan_.layout);
+    GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, v.cols, v.num_cols, v.num_rows, MemKind::kDevice, stream, &args, &st));
+    if (!st.buffers.empty()) return Status::Invalid("internal: staged input in a multi-batch evaluation");
+    BindLiterals(plan_, dev->consts, &args);
+    args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(v.num_rows));
+    if (plan_.can_raise) args.SetPtr(ArgLayout::kOffErr, err.get());
+    for (int e = 0; e < v.num_outs; e++) {
+      const DataType& t = plan_.output_types[e];
+      if (v.outs[e].validity == nullptr || v.outs[e].data == nullptr || v.outs[e].validity_size < ValidityBytes(v.num_rows) ||
+          v.outs[e].data_size < DataBytes(t, v.num_rows))
+        return Status::Invalid("batch " + std::to_string(b) + ", output buffer " + std::to_string(e) + " too small");
+      args.SetOutData(e, v.outs[e].data);
+      args.SetOutValid(e, v.outs[e].validity);
+    }
+    std::memcpy(pin + stride * b, args.data(), stride);
+    grid = std::max(grid, GridFor(plan_, v.num_rows));
+  }
+  EvalTrace trace("project-many", plan_.kernel_name, nb, stream);
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(table.get(), pin, stride * nb, hipMemcpyHostToDevice, stream));
+  GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel, grid, nb, plan_.opts.waves * 64, table.get(), stream));
+  uint32_t err_bits = 0;
+  if (plan_.can_raise)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
+  if ((flags & kEvalAsync) && !plan_.can_raise) {
+    // the table and the pinned block go back once the stream has passed this point
+    table.release_after(stream);
+    char* p = pin;
+    pin = nullptr;
+    Runtime* owner = &rt;
+    rt.Defer(stream, [owner, p] { owner->ReleasePinned(p); });
+    return Status::OK();
+  }
+  GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  return Status::OK();
+}
+
 // ------------------------------------------------------------------ Filter
 
 Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,

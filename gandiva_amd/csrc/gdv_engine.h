@@ -95,6 +95,19 @@ class Projector {
                   const SelectionView* sel, OutputBuffers* outs, int num_outs, MemKind mem,
                   hipStream_t stream, uint32_t flags) const;
 
+  // Many (small) HBM-resident batches in ONE launch (round 3): the reference is fed 4K-64K-row
+  // batches, where a launch + argument marshalling per batch is all overhead.  The argument blocks
+  // of all batches travel as one table (one H2D copy), blockIdx.y picks the batch.  Row-mode plans
+  // with fixed-width outputs; anything else is evaluated batch by batch on the same stream.
+  struct BatchView {
+    int64_t num_rows = 0;
+    const ColumnBuffers* cols = nullptr;
+    int num_cols = 0;
+    OutputBuffers* outs = nullptr;
+    int num_outs = 0;
+  };
+  Status EvaluateMany(const BatchView* batches, int num_batches, hipStream_t stream, uint32_t flags) const;
+
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }
   const std::shared_ptr<Projector>& first_stage() const { return pre_; }

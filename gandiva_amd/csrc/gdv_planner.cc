@@ -1193,36 +1193,47 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
   // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
   // each bitmap.
-  s << "extern \"C\" __global__ void ";
+  std::string attrs;
   if (plan->opts.waves_per_eu > 0)
-    s << "__attribute__((amdgpu_waves_per_eu(" << plan->opts.waves_per_eu << ", " << plan->opts.waves_per_eu << "))) ";
-  s << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    attrs = "__attribute__((amdgpu_waves_per_eu(" + std::to_string(plan->opts.waves_per_eu) + ", " +
+            std::to_string(plan->opts.waves_per_eu) + "))) ";
+  s << "GDV_DEV void gdv_kernel_body(const gdv_args& A, const gdv_int64 first_group, const gdv_int64 num_groups) {\n"
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
     << "  const gdv_int64 n = GDV_ROWS(A);\n"
     << "  const gdv_int64 nwords = (n + 63) >> 6;\n"
     << "  const gdv_int64 nfull = n / (64 * GDV_U);                // full wave tiles\n"
     << "  const gdv_int64 nwt = (nwords + GDV_U - 1) / GDV_U;      // all wave tiles\n"
-    << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nfull;\n"
-    << "       wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
+    << "  for (gdv_int64 wt = first_group * GDV_WAVES + wave; wt < nfull; wt += num_groups * GDV_WAVES)\n"
     << "    gdv_tile<true>(A, wt * GDV_U, lane);\n"
     // The single partial wave tile is handled after the loop, not in an if/else next to
     // the full-tile body: side by side, the compiler hoists the two bodies' common bitmap
     // loads above the branch and serialises them in front of the value loads.
     << "  if (nwt > nfull && wave == (int)(nfull % GDV_WAVES) &&\n"
-    << "      blockIdx.x == (unsigned)((nfull / GDV_WAVES) % gridDim.x))\n"
+    << "      first_group == (gdv_int64)((nfull / GDV_WAVES) % num_groups))\n"
     << "    gdv_tile<false>(A, nfull * GDV_U, lane);\n"
+    << "}\n"
+    << "extern \"C\" __global__ void " << attrs << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  gdv_kernel_body(A, (gdv_int64)blockIdx.x, (gdv_int64)gridDim.x);\n"
     << "}\n";
+  // Many small batches in ONE launch (round 3: the reference is fed 4K-64K-row batches, where a
+  // launch per batch is all overhead): blockIdx.y picks the batch, its argument block comes from a
+  // table in device memory instead of the kernel-argument segment.  Row mode projections only.
+  if (!sel && plan->kind == KernelKind::kProject)
+    s << "extern \"C\" __global__ void " << attrs << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME_many(const gdv_args* __restrict__ table) {\n"
+      << "  gdv_kernel_body(table[blockIdx.y], (gdv_int64)blockIdx.x, (gdv_int64)gridDim.x);\n"
+      << "}\n";
 
   std::string text = s.str();
   uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
   char name[64];
   snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
   plan->kernel_name = name;
-  size_t pos = text.find("GDV_KERNEL_NAME");
-  text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
+  for (size_t pos = text.find("GDV_KERNEL_NAME"); pos != std::string::npos; pos = text.find("GDV_KERNEL_NAME", pos))
+    text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
   plan->source = text;
   plan->ir = text;
+  plan->has_many_entry = !sel && plan->kind == KernelKind::kProject;
   return Status::OK();
 }
 

@@ -325,6 +325,11 @@ Status Runtime::GetKernel(const std::string& source, const std::string& kernel_n
   }
   if (le != hipSuccess)
     return Status::ExecutionError(std::string("loading the compiled kernel failed: ") + hipGetErrorString(le));
+  if (source.find(kernel_name + "_many(") != std::string::npos &&
+      hipModuleGetFunction(&k->function_many, k->module, (kernel_name + "_many").c_str()) != hipSuccess) {
+    (void)hipGetLastError();
+    k->function_many = nullptr;
+  }
   std::lock_guard<std::mutex> g(mu_);
   auto& slot = kernels_[kernel_name];
   if (!slot) slot = std::move(k);
@@ -362,7 +367,7 @@ void Runtime::Reap(bool wait) {
   std::vector<std::pair<hipEvent_t, void*>> done;
   {
     std::lock_guard<std::mutex> g(mu_);
-    if (deferred_.empty()) return;
+    if (deferred_.empty() && deferred_fns_.empty()) return;
     size_t keep = 0;
     for (size_t i = 0; i < deferred_.size(); i++) {
       hipError_t q = wait ? hipEventSynchronize(deferred_[i].first) : hipEventQuery(deferred_[i].first);
@@ -378,6 +383,26 @@ void Runtime::Reap(bool wait) {
   for (auto& d : done) {
     ReleaseEvent(d.first);
     Free(d.second);
+  }
+  std::vector<std::pair<hipEvent_t, std::function<void()>>> fns;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    size_t keep = 0;
+    for (size_t i = 0; i < deferred_fns_.size(); i++) {
+      hipError_t q = wait ? hipEventSynchronize(deferred_fns_[i].first) : hipEventQuery(deferred_fns_[i].first);
+      if (q == hipSuccess) {
+        fns.push_back(std::move(deferred_fns_[i]));
+      } else {
+        if (q != hipErrorNotReady) (void)hipGetLastError();
+        if (keep != i) deferred_fns_[keep] = std::move(deferred_fns_[i]);
+        keep++;
+      }
+    }
+    deferred_fns_.resize(keep);
+  }
+  for (auto& f : fns) {
+    ReleaseEvent(f.first);
+    f.second();
   }
 }
 
@@ -414,6 +439,7 @@ Status Runtime::Alloc(size_t bytes, void** ptr) {
 
 Status Runtime::AcquirePinned(char** p) {
   GDV_RETURN_NOT_OK(EnsureDevice());
+  Reap(false);
   {
     std::lock_guard<std::mutex> g(mu_);
     if (!pinned_free_.empty()) {
@@ -483,6 +509,29 @@ Status Runtime::AllOnesWord(const uint64_t** ptr) {
   }
   *ptr = all_ones_;
   return Status::OK();
+}
+
+Status Runtime::LaunchMany(const CompiledKernel& k, int64_t grid_x, int64_t batches, int block,
+                           const void* table_device, hipStream_t stream) {
+  if (k.function_many == nullptr) return Status::ExecutionError("kernel has no multi-batch entry point");
+  void* params[] = {&table_device};
+  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(k.function_many, static_cast<unsigned>(grid_x),
+                                              static_cast<unsigned>(batches), 1, static_cast<unsigned>(block), 1, 1,
+                                              0, stream, params, nullptr));
+  return Status::OK();
+}
+
+void Runtime::Defer(hipStream_t stream, std::function<void()> fn) {
+  hipEvent_t e = nullptr;
+  if (!AcquireEvent(&e).ok() || hipEventRecord(e, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    ReleaseEvent(e);
+    (void)hipStreamSynchronize(stream);
+    fn();
+    return;
+  }
+  std::lock_guard<std::mutex> g(mu_);
+  deferred_fns_.emplace_back(e, std::move(fn));
 }
 
 Status Runtime::AcquireStream(hipStream_t* out) {

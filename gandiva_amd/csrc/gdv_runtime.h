@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -27,6 +28,7 @@ namespace gdv {
 struct CompiledKernel {
   hipModule_t module = nullptr;
   hipFunction_t function = nullptr;
+  hipFunction_t function_many = nullptr;  // <name>_many(const gdv_args* table), when the plan has one
   std::string name;
 };
 
@@ -89,6 +91,12 @@ class Runtime {
 
   Status Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
                 size_t arg_bytes, hipStream_t stream);
+  // the multi-batch entry point: grid (grid_x, batches), argument blocks in a device table
+  Status LaunchMany(const CompiledKernel& k, int64_t grid_x, int64_t batches, int block, const void* table_device,
+                    hipStream_t stream);
+  // run `fn` once everything enqueued on `stream` so far has completed (polled from Alloc /
+  // AcquirePinned: no callback thread) — how asynchronous calls give pinned blocks back
+  void Defer(hipStream_t stream, std::function<void()> fn);
 
   // Side streams / events for pipelines inside one Evaluate (filter: index emission of chunk k
   // behind the predicate kernel of chunk k + 1).  Pooled: creation costs tens of microseconds.
@@ -115,6 +123,7 @@ class Runtime {
   std::vector<hipStream_t> streams_free_;
   std::vector<hipEvent_t> events_free_;
   std::vector<std::pair<hipEvent_t, void*>> deferred_;  // FreeAfter: blocks waiting for their event
+  std::vector<std::pair<hipEvent_t, std::function<void()>>> deferred_fns_;
   void Reap(bool wait);
   size_t cached_bytes_ = 0;
   uint64_t* all_ones_ = nullptr;

@@ -641,6 +641,48 @@ class Projector:
         return outputs
 
 
+def _evaluate_device_many(self, dbatches, outputs=None, stream=None, sync=True):
+    """Many HBM-resident batches in one call (gdv_projector_evaluate_many): row-mode plans with
+    fixed-width outputs run them all in ONE launch.  Returns a list (one per batch) of lists of
+    DeviceColumns; pass it back as ``outputs`` to reuse the buffers."""
+    import torch
+    lib = _capi.lib()
+    n_out = len(self._out_types)
+    if any(pa.types.is_string(t) or pa.types.is_binary(t) for t in self._out_types):
+        raise NotImplementedError("evaluate_device_many: fixed-width outputs only")
+    if outputs is None:
+        outputs = []
+        for db in dbatches:
+            cols = []
+            for i, t in enumerate(self._out_types):
+                vb, dbytes = C.c_int64(), C.c_int64()
+                _check(lib.gdv_projector_output_sizes(self._h, i, db.num_rows, GDV_MEM_DEVICE, vb, dbytes))
+                cols.append(DeviceColumn(t, db.num_rows,
+                                         torch.empty(_pad64(max(vb.value, 1)), dtype=torch.uint8, device="cuda"),
+                                         torch.empty(_pad64(max(dbytes.value, 1)), dtype=torch.uint8, device="cuda"), None))
+            outputs.append(cols)
+    nb = len(dbatches)
+    batches = (_capi.gdv_batch_t * max(nb, 1))()
+    keep = []
+    for b, db in enumerate(dbatches):
+        cols = (gdv_column_t * max(len(db.columns), 1))(*[c._c() for c in db.columns])
+        outs = (gdv_out_column_t * n_out)()
+        for i, o in enumerate(outputs[b]):
+            outs[i].validity, outs[i].validity_size = o.validity.data_ptr(), o.validity.numel()
+            outs[i].data, outs[i].data_size = o.data.data_ptr(), o.data.numel()
+        keep.append((cols, outs))
+        batches[b].num_rows = db.num_rows
+        batches[b].cols, batches[b].num_cols = cols, len(db.columns)
+        batches[b].outs, batches[b].num_outs = outs, n_out
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    _check(lib.gdv_projector_evaluate_many(self._h, batches, nb, C.c_void_p(stream), 0 if sync else GDV_EVAL_ASYNC))
+    return outputs
+
+
+Projector.evaluate_device_many = _evaluate_device_many
+
+
 def _evaluate_device_array(projector, array_address, num_rows, on_device):
     """Shared body of Projector.evaluate_device_array: fixed-width outputs only."""
     lib = _capi.lib()

@@ -230,6 +230,21 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
 int gdv_projector_evaluate(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
                            int num_cols, const gdv_selection_t* sel, gdv_out_column_t* outs,
                            int num_outs, int mem_kind, void* stream, uint32_t flags);
+/* Many HBM-resident batches in ONE call (round 3).  The reference is fed 4K-64K-row batches by its
+ * query engine; at that size a kernel launch and the marshalling of one argument block per batch
+ * cost more than the evaluation.  Row-mode plans with fixed-width outputs run ALL batches in one
+ * launch (the argument blocks travel as one table, the grid's second dimension picks the batch);
+ * other plans are evaluated batch by batch on `stream`.  Device buffers only.  With
+ * GDV_EVAL_ASYNC nothing waits (plans that can raise wait anyway). */
+typedef struct {
+  int64_t num_rows;
+  const gdv_column_t* cols; /* one per schema field */
+  int num_cols;
+  gdv_out_column_t* outs;   /* one per expression */
+  int num_outs;
+} gdv_batch_t;
+int gdv_projector_evaluate_many(const gdv_projector_t* p, const gdv_batch_t* batches, int num_batches, void* stream,
+                                uint32_t flags);
 /* The same under a selection vector whose slot COUNT is still on the device: the kernel reads the
  * number of slots from *num_slots_device (int64 in device or pinned memory — where
  * gdv_filter_evaluate_async left it); sel->num_slots is only the capacity the outputs and the launch
