@@ -41,6 +41,11 @@ class gdv_batch_t(C.Structure):
                 ("outs", C.POINTER(gdv_out_column_t)), ("num_outs", C.c_int)]
 
 
+class gdv_filter_batch_t(C.Structure):
+    _fields_ = [("num_rows", C.c_int64), ("cols", C.POINTER(gdv_column_t)), ("num_cols", C.c_int),
+                ("out_indices", C.c_void_p), ("max_slots", C.c_int64)]
+
+
 class gdv_selection_t(C.Structure):
     _fields_ = [("mode", C.c_int32), ("indices", C.c_void_p), ("num_slots", C.c_int64)]
 
@@ -87,6 +92,7 @@ PROTOTYPES = [
     ("gdv_projector_make_from_proto", C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.POINTER(gdv_config_t), C.POINTER(_P)]),
     ("gdv_filter_make_from_proto", C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(gdv_config_t), C.POINTER(_P)]),
     ("gdv_proto_describe", _P, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int]),
+    ("gdv_filter_evaluate_many", C.c_int, [_P, C.POINTER(gdv_filter_batch_t), C.c_int, C.c_int, C.POINTER(C.c_int64), _P, _P, C.c_uint32]),
     ("gdv_filter_dump_ir", _P, [_P]),
     ("gdv_filter_free", None, [_P]),
     ("gdv_registry_size", C.c_int, []),

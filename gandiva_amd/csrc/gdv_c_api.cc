@@ -472,6 +472,30 @@ int gdv_filter_evaluate_async(const gdv_filter_t* f, int64_t num_rows, const gdv
                               static_cast<hipStream_t>(stream), kEvalAsync, num_selected_device));
   });
 }
+int gdv_filter_evaluate_many(const gdv_filter_t* f, const gdv_filter_batch_t* batches, int num_batches,
+                             int selection_mode, int64_t* num_selected, void* num_selected_device, void* stream,
+                             uint32_t flags) {
+  return Guarded([&]() -> int {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  if (num_batches < 0 || (num_batches > 0 && !batches)) return Fail(Status::Invalid("null batch list"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<std::vector<ColumnBuffers>> cols(num_batches);
+  std::vector<Filter::BatchView> views(num_batches);
+  for (int b = 0; b < num_batches; b++) {
+    if (batches[b].num_cols > 0 && !batches[b].cols) return Fail(Status::Invalid("null column array"));
+    cols[b] = ToColumns(batches[b].cols, batches[b].num_cols);
+    views[b].num_rows = batches[b].num_rows;
+    views[b].cols = cols[b].data();
+    views[b].num_cols = batches[b].num_cols;
+    views[b].out_indices = batches[b].out_indices;
+    views[b].max_slots = batches[b].max_slots;
+  }
+  return Check(f->f->EvaluateMany(views.data(), num_batches, mode, num_selected, num_selected_device,
+                                  static_cast<hipStream_t>(stream), flags));
+  });
+}
+
 // ---------------------------------------------------------------- build from protobuf bytes (JNI)
 int gdv_projector_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes,
                                   int64_t exprs_len, int selection_mode, const gdv_config_t* config,

@@ -1936,6 +1936,59 @@ GDV_DEV gdv_int32 gdv_next_lane_i32(gdv_int32 v, gdv_int32 after, int lane) {
   return lane == 63 ? after : nx;
 }
 
+// ------------------------------------------------------------------ small-batch filter: scan + emission in the predicate's own workgroup
+// A batch of up to GDV_SMALL_MAX_TILES wave tiles (the reference's 4K-64K-row batches) is filtered
+// by ONE workgroup in ONE launch: after its waves have run the predicate over every wave tile
+// (match words -> `mask`, one count per wave tile -> `counts`), wave 0 prefix-sums the counts into
+// LDS, then every wave turns 64 match words at a time into ascending row indices — the algorithm
+// of the ahead-of-time scan / index-emission kernels (gdv_kernels.hip), which large batches keep
+// using.  Several batches: one workgroup each (the grid's second dimension), still one launch.
+#define GDV_SMALL_MAX_TILES 1024
+typedef __attribute__((address_space(3))) gdv_uint32 gdv_lds_u32;
+GDV_DEV void gdv_small_filter_finish(const gdv_uint64* __restrict__ mask, const gdv_uint32* __restrict__ counts,
+                                     gdv_int64 n, void* __restrict__ out, gdv_int32 index_bytes,
+                                     gdv_int64* __restrict__ count_out, gdv_uint32* lds_offsets,
+                                     gdv_uint16* lds_stage, int lane, int wave, int nwaves, int subtiles) {
+  const gdv_int64 nwords = (n + 63) >> 6;
+  const gdv_int32 m = (gdv_int32)((nwords + subtiles - 1) / subtiles);  // wave tiles = counts
+  if (wave == 0) {
+    gdv_uint32 base = 0;
+    for (gdv_int32 i0 = 0; i0 < m; i0 += 64) {
+      const gdv_int32 i = i0 + lane;
+      const gdv_int32 c = i < m ? (gdv_int32)counts[i] : 0;
+      const gdv_int32 incl = gdv_wave_scan_incl(c);
+      if (i < m) lds_offsets[i] = base + (gdv_uint32)(incl - c);
+      base += (gdv_uint32)gdv_wave_last(incl);
+    }
+    if (lane == 0 && count_out != nullptr) *count_out = (gdv_int64)base;
+  }
+  __syncthreads();
+  gdv_uint16* const buf = lds_stage + (gdv_int64)wave * (64 * 64);
+  const gdv_int64 ntiles = (nwords + 63) / 64;  // emission tiles: 64 match words = 4096 rows
+  for (gdv_int64 t = wave; t < ntiles; t += nwaves) {
+    const gdv_int64 w = t * 64 + lane;
+    gdv_uint64 bits = w < nwords ? mask[w] : 0ull;
+    const gdv_uint32 base = lds_offsets[(t * 64) / subtiles];
+    const gdv_int32 c = (gdv_int32)__popcll(bits);
+    const gdv_int32 incl = gdv_wave_scan_incl(c);
+    const gdv_uint32 total = (gdv_uint32)gdv_wave_last(incl);
+    gdv_uint32 slot = (gdv_uint32)(incl - c);
+    while (bits) {
+      buf[slot++] = (gdv_uint16)((lane << 6) + __builtin_ctzll(bits));
+      bits &= bits - 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const gdv_int64 row0 = t * 4096;
+    for (gdv_uint32 j = (gdv_uint32)lane; j < total; j += 64) {
+      const gdv_int64 v = row0 + buf[j];
+      if (index_bytes == 4) ((gdv_uint32*)out)[base + j] = (gdv_uint32)v;
+      else if (index_bytes == 2) ((gdv_uint16*)out)[base + j] = (gdv_uint16)v;
+      else ((gdv_uint64*)out)[base + j] = (gdv_uint64)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------ var-len kernels: output offsets
 // ONE launch produces offsets and bytes: a workgroup tile (GDV_WAVES x GDV_U x 64 rows) needs the
 // byte total of every tile before it.  Workers post their tile's totals as an 8-byte granule and

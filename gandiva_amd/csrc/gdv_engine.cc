@@ -956,12 +956,13 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
     if (!(flags & kEvalAsync)) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
     return Status::OK();
   }
+  const bool small_pin = stride * static_cast<size_t>(nb) <= Runtime::kPinnedSmall;
   char* pin = nullptr;
-  GDV_RETURN_NOT_OK(rt.AcquirePinned(&pin));
+  GDV_RETURN_NOT_OK(small_pin ? rt.AcquirePinnedSmall(&pin) : rt.AcquirePinned(&pin));
   struct PinGuard {
-    Runtime& rt; char*& pin;
-    ~PinGuard() { if (pin != nullptr) rt.ReleasePinned(pin); }
-  } pin_guard{rt, pin};
+    Runtime& rt; char*& pin; bool small;
+    ~PinGuard() { if (pin != nullptr) { if (small) rt.ReleasePinnedSmall(pin); else rt.ReleasePinned(pin); } }
+  } pin_guard{rt, pin, small_pin};
   DeviceBuffer table, err;
   GDV_RETURN_NOT_OK(table.Allocate(stride * nb));
   if (plan_.can_raise) {
@@ -1004,7 +1005,8 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
     char* p = pin;
     pin = nullptr;
     Runtime* owner = &rt;
-    rt.Defer(stream, [owner, p] { owner->ReleasePinned(p); });
+    const bool small = small_pin;
+    rt.Defer(stream, [owner, p, small] { if (small) owner->ReleasePinnedSmall(p); else owner->ReleasePinned(p); });
     return Status::OK();
   }
   GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
@@ -1045,6 +1047,137 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   return Status::OK();
 }
 
+namespace {
+struct ScratchPart {  // a piece of a scratch block, spelled like a DeviceBuffer
+  char* p;
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+}  // namespace
+
+int64_t Filter::SmallBatchRows() const {
+  if (!plan_.has_small_entry || plan_.string_skeleton || pre_ != nullptr) return 0;
+  // one workgroup: at most 1024 wave tiles (LDS offsets), and no more rows than a workgroup gets
+  // through in about the time the three-launch pipeline needs to start (~20 us)
+  return std::min<int64_t>(64 * static_cast<int64_t>(plan_.opts.subtiles) * 1024, int64_t{1} << 17);
+}
+
+Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode, int64_t* counts_host,
+                            void* counts_device, hipStream_t stream, uint32_t flags) const {
+  if (nb <= 0) return Status::OK();
+  if (batches == nullptr) return Status::Invalid("null batch list");
+  if (mode == SelectionMode::kNone) return Status::Invalid("Selection vector type cannot be NONE");
+  if (counts_host == nullptr && counts_device == nullptr) return Status::Invalid("Selection vector cannot be null");
+  const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  const PlanDeviceState* dev = nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+  const int64_t cap_rows = SmallBatchRows();
+  const size_t stride = static_cast<size_t>(plan_.layout.total());
+  bool fused = cap_rows > 0 && dev->kernel->function_small != nullptr && nb <= 65535 &&
+               stride * static_cast<size_t>(nb) <= Runtime::kPinnedBlock / 2 &&
+               std::getenv("GDV_NO_SMALL_FILTER") == nullptr;
+  for (int b = 0; fused && b < nb; b++) fused = batches[b].num_rows <= cap_rows;
+  if (!fused) {
+    for (int b = 0; b < nb; b++) {
+      int64_t count = 0;
+      GDV_RETURN_NOT_OK(Evaluate(batches[b].num_rows, batches[b].cols, batches[b].num_cols, mode, batches[b].out_indices,
+                                 batches[b].max_slots, &count, MemKind::kDevice, stream, flags | kEvalNoSmall,
+                                 counts_device != nullptr ? static_cast<char*>(counts_device) + 8 * b : nullptr));
+      if (counts_host != nullptr) counts_host[b] = count;
+    }
+    return Status::OK();
+  }
+  const int64_t tile_rows = 64 * static_cast<int64_t>(plan_.opts.subtiles);
+  // scratch: [argument table | error word | counts (int64 per batch) | per batch: match words, wave-tile counts]
+  size_t scratch = stride * nb;
+  scratch = (scratch + 255) & ~size_t{255};
+  const size_t err_off = scratch;
+  scratch += 256;
+  const size_t cnt_off = scratch;
+  scratch += (static_cast<size_t>(nb) * 8 + 255) & ~size_t{255};
+  std::vector<size_t> mask_off(nb), tiles_off(nb);
+  for (int b = 0; b < nb; b++) {
+    const BatchView& v = batches[b];
+    if (v.num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+    if (v.out_indices == nullptr) return Status::Invalid("Selection vector cannot be null");
+    if (v.max_slots < v.num_rows)
+      return Status::Invalid("Selection vector too small: max slots " + std::to_string(v.max_slots) + " < rows " +
+                             std::to_string(v.num_rows));
+    if (w == 2 && v.num_rows > 65536)
+      return Status::Invalid("uint16 selection vector cannot address " + std::to_string(v.num_rows) + " rows");
+    const int64_t nwords = (v.num_rows + 63) / 64, m = (v.num_rows + tile_rows - 1) / tile_rows;
+    mask_off[b] = scratch;
+    scratch += (static_cast<size_t>(nwords) * 8 + 255) & ~size_t{255};
+    tiles_off[b] = scratch;
+    scratch += (static_cast<size_t>(m) * 4 + 64 + 255) & ~size_t{255};
+  }
+  DeviceBuffer block;
+  GDV_RETURN_NOT_OK(block.Allocate(scratch));
+  char* const base = block.as<char>();
+  // one batch: its argument block goes by value; several: a table, staged through a pinned block
+  const bool by_value = nb == 1 && dev->kernel->function_small1 != nullptr;
+  const bool small_pin = stride * static_cast<size_t>(nb) <= Runtime::kPinnedSmall;
+  char* pin = nullptr;
+  std::vector<char> one(by_value ? stride : 0);
+  if (by_value) pin = one.data();
+  else GDV_RETURN_NOT_OK(small_pin ? rt.AcquirePinnedSmall(&pin) : rt.AcquirePinned(&pin));
+  struct PinGuard {
+    Runtime& rt; char*& pin; bool small, owned;
+    ~PinGuard() { if (pin != nullptr && owned) { if (small) rt.ReleasePinnedSmall(pin); else rt.ReleasePinned(pin); } }
+  } pin_guard{rt, pin, small_pin, !by_value};
+  Staging st;
+  for (int b = 0; b < nb; b++) {
+    const BatchView& v = batches[b];
+    ArgBlock args(plan_.layout);
+    GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, v.cols, v.num_cols, v.num_rows, MemKind::kDevice, stream, &args, &st));
+    if (!st.buffers.empty()) return Status::Invalid("internal: staged input in a multi-batch evaluation");
+    BindLiterals(plan_, dev->consts, &args);
+    args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(v.num_rows));
+    args.SetPtr(ArgLayout::kOffErr, base + err_off);
+    args.SetPtr(ArgLayout::kOffMask, base + mask_off[b]);
+    args.SetPtr(ArgLayout::kOffCounts, base + tiles_off[b]);
+    args.SetPtr(ArgLayout::kOffAux1, v.out_indices);
+    args.Set64(ArgLayout::kOffSel, static_cast<uint64_t>(w));
+    args.SetPtr(ArgLayout::kOffAux2, base + cnt_off + 8 * b);
+    std::memcpy(pin + stride * b, args.data(), stride);
+  }
+  EvalTrace trace("filter-small", plan_.kernel_name, nb, stream);
+  if (plan_.can_raise) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(base + err_off, 0, 8, stream));
+  if (by_value) {
+    GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, 1, plan_.opts.waves * 64, pin, stride, stream, dev->kernel->function_small1));
+  } else {
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(base, pin, stride * nb, hipMemcpyHostToDevice, stream));
+    GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel, 1, nb, plan_.opts.waves * 64, base, stream, /*small=*/true));
+  }
+  if (counts_device != nullptr)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(counts_device, base + cnt_off, 8 * static_cast<size_t>(nb), hipMemcpyDefault, stream));
+  const bool async = (flags & kEvalAsync) != 0 && !plan_.can_raise && counts_device != nullptr;
+  if (async) {
+    if (counts_host != nullptr)
+      for (int b = 0; b < nb; b++) counts_host[b] = -1;
+    block.release_after(stream);
+    if (!by_value) {
+      char* p = pin;
+      pin = nullptr;
+      Runtime* owner = &rt;
+      const bool small = small_pin;
+      rt.Defer(stream, [owner, p, small] { if (small) owner->ReleasePinnedSmall(p); else owner->ReleasePinned(p); });
+    }
+    return Status::OK();
+  }
+  std::vector<int64_t> counts(nb, 0);
+  uint32_t err_bits = 0;
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(counts.data(), base + cnt_off, 8 * static_cast<size_t>(nb), hipMemcpyDeviceToHost, stream));
+  if (plan_.can_raise)
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, base + err_off, 4, hipMemcpyDeviceToHost, stream));
+  GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  if (counts_host != nullptr)
+    for (int b = 0; b < nb; b++) counts_host[b] = counts[b];
+  return Status::OK();
+}
+
 // Input slots of an argument block advanced by `lo` rows (lo a multiple of 64): what a chunk of a
 // pipelined filter binds.  Value pointers move by lo * width, bitmap word pointers by lo / 64 words
 // (their bit shift is unchanged), var-len offsets by lo entries (the byte buffer stays whole).
@@ -1073,6 +1206,19 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     return Status::Invalid("uint16 selection vector cannot address " + std::to_string(num_rows) + " rows");
   if (w == 4 && num_rows > (int64_t(1) << 32))
     return Status::Invalid("uint32 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  // small HBM-resident batches: predicate + scan + emission by one workgroup in one launch
+  // (one workgroup is the right tool up to a few thousand rows; beyond that the three-launch path,
+  // which spreads the predicate over the chip, is faster for a single batch —
+  // profiles/r03_small_batches.txt)
+  if (mem == MemKind::kDevice && !(flags & kEvalNoSmall) && num_rows <= std::min<int64_t>(SmallBatchRows(), 8192) &&
+      std::getenv("GDV_NO_SMALL_FILTER") == nullptr) {
+    BatchView v;
+    v.num_rows = num_rows; v.cols = cols; v.num_cols = num_cols; v.out_indices = out_indices; v.max_slots = max_slots;
+    int64_t count = -1;
+    GDV_RETURN_NOT_OK(EvaluateMany(&v, 1, mode, &count, count_out, stream, flags));
+    if (num_selected != nullptr) *num_selected = count;
+    return Status::OK();
+  }
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
   const PlanDeviceState* dev = nullptr;
@@ -1086,7 +1232,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
 
   ArgBlock args(plan_.layout);
   Staging st;
-  DeviceBuffer mask, counts, offsets, chunk_sums, totals, err, staged_out;
+  DeviceBuffer scratch, err, staged_out;
   StageColumns stage;  // two-stage plans: the first stage's temporary columns
   StreamDrain drain{stream, !async};  // declared last: drains before any pooled block is freed
   if (pre_) {
@@ -1128,11 +1274,16 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
 
   const int64_t nwords = (num_rows + 63) / 64;
   const int64_t m = (num_rows + tile_rows - 1) / tile_rows;  // wave tiles
-  GDV_RETURN_NOT_OK(mask.Allocate(nwords * 8));
-  GDV_RETURN_NOT_OK(counts.Allocate(m * 4 + 64));
-  GDV_RETURN_NOT_OK(offsets.Allocate(m * 8));
-  GDV_RETURN_NOT_OK(chunk_sums.Allocate((ScanChunks((chunk_rows + tile_rows - 1) / tile_rows) + 1) * 8 * chunks));
-  GDV_RETURN_NOT_OK(totals.Allocate(8 * (chunks + 1)));
+  // one scratch block (one pool round trip, one deferred release): match words | wave-tile counts |
+  // offsets | scan chunk sums | running totals
+  auto up = [](size_t v) { return (v + 255) & ~size_t{255}; };
+  const size_t mask_b = up(static_cast<size_t>(nwords) * 8), counts_b = up(static_cast<size_t>(m) * 4 + 64),
+               offsets_b = up(static_cast<size_t>(m) * 8),
+               sums_b = up(static_cast<size_t>(ScanChunks((chunk_rows + tile_rows - 1) / tile_rows) + 1) * 8 * chunks),
+               totals_b = up(8 * static_cast<size_t>(chunks + 1));
+  GDV_RETURN_NOT_OK(scratch.Allocate(mask_b + counts_b + offsets_b + sums_b + totals_b));
+  const ScratchPart mask{scratch.as<char>()}, counts{mask.p + mask_b}, offsets{counts.p + counts_b},
+      chunk_sums{offsets.p + offsets_b}, totals{chunk_sums.p + sums_b};
   if (plan_.can_raise) {
     GDV_RETURN_NOT_OK(err.Allocate(8));
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
@@ -1190,8 +1341,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(count_out, total_dev, 8, hipMemcpyDefault, stream));
     if (num_selected != nullptr) *num_selected = -1;
     // scratch goes back to the pool when the stream has passed this point
-    mask.release_after(stream); counts.release_after(stream); offsets.release_after(stream);
-    chunk_sums.release_after(stream); totals.release_after(stream);
+    scratch.release_after(stream);
     return Status::OK();
   }
   uint64_t count = 0;

@@ -59,7 +59,8 @@ struct Configuration {
 };
 
 enum EvalFlags : uint32_t {
-  kEvalAsync = 1u,  // device buffers only: return after enqueueing on `stream`
+  kEvalAsync = 1u,    // device buffers only: return after enqueueing on `stream`
+  kEvalNoSmall = 2u,  // internal: a batch-by-batch fallback must not re-enter the fused small-batch path
 };
 
 // What a built plan owns on ONE device context (round 3: a Projector / Filter can be evaluated by
@@ -154,6 +155,23 @@ class Filter {
   Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, SelectionMode mode,
                   void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
                   hipStream_t stream, uint32_t flags = 0, void* count_out = nullptr) const;
+
+  // Many small HBM-resident batches in ONE launch (round 3): every batch is filtered by one
+  // workgroup that runs predicate, offsets scan and index emission back to back
+  // (gdv_small_filter_finish).  counts_host (may be null with kEvalAsync) / counts_device (may be
+  // null; int64[num_batches] in device or pinned memory) receive the selected-row counts.
+  // Batches too big for one workgroup, string plans and two-stage plans go batch by batch.
+  struct BatchView {
+    int64_t num_rows = 0;
+    const ColumnBuffers* cols = nullptr;
+    int num_cols = 0;
+    void* out_indices = nullptr;
+    int64_t max_slots = 0;
+  };
+  Status EvaluateMany(const BatchView* batches, int num_batches, SelectionMode mode, int64_t* counts_host,
+                      void* counts_device, hipStream_t stream, uint32_t flags) const;
+  // rows one workgroup takes (0: the plan has no small-batch entry point)
+  int64_t SmallBatchRows() const;
 
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }

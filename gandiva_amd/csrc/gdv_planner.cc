@@ -1223,6 +1223,26 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     s << "extern \"C\" __global__ void " << attrs << "__launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME_many(const gdv_args* __restrict__ table) {\n"
       << "  gdv_kernel_body(table[blockIdx.y], (gdv_int64)blockIdx.x, (gdv_int64)gridDim.x);\n"
       << "}\n";
+  // Small batches of a filter: predicate, offsets scan and index emission by ONE workgroup in ONE
+  // launch (gdv_small_filter_finish); blockIdx.y picks the batch.  The batch's argument block gives
+  // the index buffer in aux1, the index width in `sel`, where the count goes in aux2.
+  if (plan->kind == KernelKind::kFilter)
+    s << "GDV_DEV void gdv_small_filter(const gdv_args& A) {\n"
+      << "  __shared__ gdv_uint32 lds_offsets[GDV_SMALL_MAX_TILES];\n"
+      << "  __shared__ gdv_uint16 lds_stage[GDV_WAVES * 64 * 64];\n"
+      << "  gdv_kernel_body(A, 0, 1);  // this workgroup runs the predicate over every wave tile of its batch\n"
+      << "  __syncthreads();           // match words and counts are this workgroup's own: visible after the barrier\n"
+      << "  gdv_small_filter_finish(A.mask, A.counts, A.n, (void*)A.aux1, (gdv_int32)(gdv_int64)A.sel, (gdv_int64*)A.aux2,\n"
+      << "                          lds_offsets, lds_stage, threadIdx.x & 63, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)),\n"
+      << "                          GDV_WAVES, GDV_U);\n"
+      << "}\n"
+      << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME_small(const gdv_args* __restrict__ table) {\n"
+      << "  gdv_small_filter(table[blockIdx.y]);\n"
+      << "}\n"
+      // (one batch: its argument block travels in the kernel-argument segment — no table to upload)
+      << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME_small1(const gdv_args A) {\n"
+      << "  gdv_small_filter(A);\n"
+      << "}\n";
 
   std::string text = s.str();
   uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
@@ -1234,6 +1254,7 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   plan->source = text;
   plan->ir = text;
   plan->has_many_entry = !sel && plan->kind == KernelKind::kProject;
+  plan->has_small_entry = plan->kind == KernelKind::kFilter;
   return Status::OK();
 }
 

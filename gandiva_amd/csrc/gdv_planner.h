@@ -88,6 +88,7 @@ struct KernelPlan {
   // totals per wave tile from the offsets alone) + the offsets scan; wave_segments[v] = the
   // segment of var-len output v, -1 for flat outputs.  source_general / kernel_name_general hold
   // the scanner-shaped fallback (a batch that breaks the ASCII / flat assumption is re-run on it).
+  bool has_small_entry = false;  // filters: <kernel_name>_small(table): predicate + scan + emission, one workgroup per batch
   bool has_many_entry = false;  // the code object also holds <kernel_name>_many(const gdv_args* table): one launch, many batches
   int compact_from = 0x7fffffff;  // selection mode: schema fields from here on are compact temporaries
   bool wave_tiles = false;

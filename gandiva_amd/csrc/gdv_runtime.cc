@@ -330,6 +330,16 @@ Status Runtime::GetKernel(const std::string& source, const std::string& kernel_n
     (void)hipGetLastError();
     k->function_many = nullptr;
   }
+  if (source.find(kernel_name + "_small(") != std::string::npos &&
+      hipModuleGetFunction(&k->function_small, k->module, (kernel_name + "_small").c_str()) != hipSuccess) {
+    (void)hipGetLastError();
+    k->function_small = nullptr;
+  }
+  if (k->function_small != nullptr &&
+      hipModuleGetFunction(&k->function_small1, k->module, (kernel_name + "_small1").c_str()) != hipSuccess) {
+    (void)hipGetLastError();
+    k->function_small1 = nullptr;
+  }
   std::lock_guard<std::mutex> g(mu_);
   auto& slot = kernels_[kernel_name];
   if (!slot) slot = std::move(k);
@@ -512,10 +522,11 @@ Status Runtime::AllOnesWord(const uint64_t** ptr) {
 }
 
 Status Runtime::LaunchMany(const CompiledKernel& k, int64_t grid_x, int64_t batches, int block,
-                           const void* table_device, hipStream_t stream) {
-  if (k.function_many == nullptr) return Status::ExecutionError("kernel has no multi-batch entry point");
+                           const void* table_device, hipStream_t stream, bool small) {
+  hipFunction_t fn = small ? k.function_small : k.function_many;
+  if (fn == nullptr) return Status::ExecutionError("kernel has no multi-batch entry point");
   void* params[] = {&table_device};
-  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(k.function_many, static_cast<unsigned>(grid_x),
+  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(fn, static_cast<unsigned>(grid_x),
                                               static_cast<unsigned>(batches), 1, static_cast<unsigned>(block), 1, 1,
                                               0, stream, params, nullptr));
   return Status::OK();
@@ -576,11 +587,38 @@ void Runtime::ReleaseEvent(hipEvent_t e) {
   else (void)hipEventDestroy(e);
 }
 
+Status Runtime::AcquirePinnedSmall(char** p) {
+  GDV_RETURN_NOT_OK(EnsureDevice());
+  Reap(false);
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!pinned_small_free_.empty()) {
+      *p = pinned_small_free_.back();
+      pinned_small_free_.pop_back();
+      return Status::OK();
+    }
+  }
+  void* q = nullptr;
+  if (hipHostMalloc(&q, kPinnedSmall, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::OutOfMemory("hipHostMalloc of a pinned argument-table block failed");
+  }
+  *p = static_cast<char*>(q);
+  return Status::OK();
+}
+
+void Runtime::ReleasePinnedSmall(char* p) {
+  if (p == nullptr) return;
+  std::lock_guard<std::mutex> g(mu_);
+  if (pinned_small_free_.size() < 256) pinned_small_free_.push_back(p);
+  else (void)hipHostFree(p);
+}
+
 Status Runtime::Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
-                       size_t arg_bytes, hipStream_t stream) {
+                       size_t arg_bytes, hipStream_t stream, hipFunction_t entry) {
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args),
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_bytes, HIP_LAUNCH_PARAM_END};
-  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(k.function, static_cast<unsigned>(grid), 1, 1,
+  GDV_HIP_RETURN_NOT_OK(hipModuleLaunchKernel(entry != nullptr ? entry : k.function, static_cast<unsigned>(grid), 1, 1,
                                               static_cast<unsigned>(block), 1, 1, 0, stream,
                                               nullptr, config));
   return Status::OK();

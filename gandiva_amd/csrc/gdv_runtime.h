@@ -29,6 +29,8 @@ struct CompiledKernel {
   hipModule_t module = nullptr;
   hipFunction_t function = nullptr;
   hipFunction_t function_many = nullptr;  // <name>_many(const gdv_args* table), when the plan has one
+  hipFunction_t function_small = nullptr; // <name>_small(const gdv_args* table): fused small-batch filter
+  hipFunction_t function_small1 = nullptr;  // <name>_small1(const gdv_args A): the same for one batch, by value
   std::string name;
 };
 
@@ -84,16 +86,21 @@ class Runtime {
   static constexpr size_t kPinnedBlock = 16u << 20;
   Status AcquirePinned(char** p);
   void ReleasePinned(char* p);
+  // ... and small ones (argument tables of multi-batch launches: asynchronous calls hold theirs
+  // until the stream has passed, so several are in flight at a time)
+  static constexpr size_t kPinnedSmall = 64u << 10;
+  Status AcquirePinnedSmall(char** p);
+  void ReleasePinnedSmall(char* p);
 
   // Device-resident bitmap word with all 64 bits set: what a column WITHOUT a validity
   // (or with an elided all-valid) buffer is bound to, so kernels never branch on "has nulls".
   Status AllOnesWord(const uint64_t** ptr);
 
   Status Launch(const CompiledKernel& k, int64_t grid, int block, const void* args,
-                size_t arg_bytes, hipStream_t stream);
+                size_t arg_bytes, hipStream_t stream, hipFunction_t entry = nullptr);
   // the multi-batch entry point: grid (grid_x, batches), argument blocks in a device table
   Status LaunchMany(const CompiledKernel& k, int64_t grid_x, int64_t batches, int block, const void* table_device,
-                    hipStream_t stream);
+                    hipStream_t stream, bool small = false);
   // run `fn` once everything enqueued on `stream` so far has completed (polled from Alloc /
   // AcquirePinned: no callback thread) — how asynchronous calls give pinned blocks back
   void Defer(hipStream_t stream, std::function<void()> fn);
@@ -119,7 +126,7 @@ class Runtime {
   std::map<std::string, std::unique_ptr<CompiledKernel>> kernels_;
   std::multimap<size_t, void*> free_blocks_;
   std::map<void*, size_t> live_blocks_;
-  std::vector<char*> pinned_free_;
+  std::vector<char*> pinned_free_, pinned_small_free_;
   std::vector<hipStream_t> streams_free_;
   std::vector<hipEvent_t> events_free_;
   std::vector<std::pair<hipEvent_t, void*>> deferred_;  // FreeAfter: blocks waiting for their event

@@ -797,6 +797,33 @@ class Filter:
         return SelectionVector(mode, out, count.value, device=True)
 
 
+def _filter_evaluate_device_many(self, dbatches, dtype="int32", stream=None):
+    """Many small HBM-resident batches in one launch (gdv_filter_evaluate_many): returns one device
+    SelectionVector per batch."""
+    import torch
+    mode = self._mode_of(dtype)
+    lib = _capi.lib()
+    tdt = {1: torch.int16, 2: torch.int32, 3: torch.int64}[mode]
+    nb = len(dbatches)
+    batches = (_capi.gdv_filter_batch_t * max(nb, 1))()
+    keep, outs = [], []
+    for b, db in enumerate(dbatches):
+        cols = (gdv_column_t * max(len(db.columns), 1))(*[c._c() for c in db.columns])
+        out = torch.empty(max(db.num_rows, 1), dtype=tdt, device="cuda")
+        keep.append(cols)
+        outs.append(out)
+        batches[b].num_rows, batches[b].cols, batches[b].num_cols = db.num_rows, cols, len(db.columns)
+        batches[b].out_indices, batches[b].max_slots = out.data_ptr(), out.numel()
+    counts = (C.c_int64 * max(nb, 1))()
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    _check(lib.gdv_filter_evaluate_many(self._h, batches, nb, mode, counts, None, C.c_void_p(stream), 0))
+    return [SelectionVector(mode, outs[b], counts[b], device=True) for b in range(nb)]
+
+
+Filter.evaluate_device_many = _filter_evaluate_device_many
+
+
 def make_filter(schema, condition, configuration=None):
     if not isinstance(condition, Condition):
         raise TypeError("make_filter expects a gandiva Condition")

@@ -272,6 +272,22 @@ int gdv_filter_evaluate(const gdv_filter_t* f, int64_t num_rows, const gdv_colum
 int gdv_filter_evaluate_async(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols, int num_cols,
                               int selection_mode, void* out_indices, int64_t max_slots, void* num_selected_device,
                               void* stream);
+/* Many small HBM-resident batches in ONE launch: each batch is filtered by one workgroup that runs
+ * the predicate, the offsets scan and the index emission back to back (batches of up to 2^17 rows;
+ * bigger ones, string plans and two-stage plans are evaluated one by one on `stream`).  A single
+ * small batch handed to gdv_filter_evaluate takes the same kernel.  num_selected (host array, may
+ * be NULL with GDV_EVAL_ASYNC) / num_selected_device (int64[num_batches] in device or pinned
+ * memory, may be NULL) receive the counts; with GDV_EVAL_ASYNC and a device array nothing waits. */
+typedef struct {
+  int64_t num_rows;
+  const gdv_column_t* cols; /* one per schema field */
+  int num_cols;
+  void* out_indices;        /* max_slots elements of the selection mode's width */
+  int64_t max_slots;        /* >= num_rows */
+} gdv_filter_batch_t;
+int gdv_filter_evaluate_many(const gdv_filter_t* f, const gdv_filter_batch_t* batches, int num_batches,
+                             int selection_mode, int64_t* num_selected, void* num_selected_device, void* stream,
+                             uint32_t flags);
 char* gdv_filter_dump_ir(const gdv_filter_t* f);
 void gdv_filter_free(gdv_filter_t* f);
 

@@ -684,3 +684,42 @@ def test_many_small_batches_in_one_launch_match_the_oracle():
     assert got[2][0].to_arrow().to_pylist() == [5, 4]
     with pytest.raises(pa.lib.ArrowException, match="divide by zero"):
         div.evaluate_device_many([gandiva.DeviceBatch.from_arrow(x) for x in (ok, bad, ok)])
+
+
+@pytest.mark.parametrize("dtype", ["int16", "int32", "int64"])
+def test_small_batch_filter_one_workgroup_per_batch(dtype):
+    """Round 3: an HBM-resident batch of up to 2^17 rows is filtered by ONE workgroup in ONE launch
+    (predicate, offsets scan, index emission back to back); many such batches still take one launch.
+    Every index against the oracle, batch sizes around every tile boundary, nulls, all index widths;
+    and the same batches through the three-launch path (GDV_NO_SMALL_FILTER) agree."""
+    import torch
+    rng = np.random.default_rng(5)
+    sizes = [1, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 16384, 50_001, 65536]
+    if dtype != "int16":
+        sizes += [65537, 100_000, 131072]
+    b = gandiva.TreeExprBuilder()
+    batches = [_batch(rng, [pa.int64(), pa.int64(), pa.float64()], n, 0.2) for n in sizes]
+    a, c, d = (b.make_field(batches[0].schema.field(i)) for i in range(3))
+    cond = b.make_condition(b.make_or([b.make_function("greater_than", [a, c], pa.bool_()),
+                                       b.make_function("isnull", [d], pa.bool_())]))
+    flt = gandiva.make_filter(batches[0].schema, cond)
+    dbs = [gandiva.DeviceBatch.from_arrow(x) for x in batches]
+    sels = flt.evaluate_device_many(dbs, dtype)
+    for x, db, sv in zip(batches, dbs, sels):
+        want = oracle.filter_indices(cond, x, dtype)
+        assert sv.to_array().equals(want), x.num_rows
+        assert flt.evaluate_device(db, dtype).to_array().equals(want)            # single batch: same kernel
+        sva = flt.evaluate_device(db, dtype, sync=False)                          # ... asynchronously
+        torch.cuda.synchronize()
+        assert sva.to_array().equals(want)
+    os.environ["GDV_NO_SMALL_FILTER"] = "1"
+    try:
+        assert flt.evaluate_device(dbs[-1], dtype).to_array().equals(oracle.filter_indices(cond, batches[-1], dtype))
+    finally:
+        del os.environ["GDV_NO_SMALL_FILTER"]
+    # an all-false and an all-true predicate
+    t = b.make_condition(b.make_function("isnotnull", [b.make_literal(1, pa.int64())], pa.bool_()))
+    full = gandiva.make_filter(batches[0].schema, t).evaluate_device(dbs[9], dtype)
+    assert full.num_slots == sizes[9] and full.to_array().to_pylist() == list(range(sizes[9]))
+    f = b.make_condition(b.make_function("isnull", [b.make_literal(1, pa.int64())], pa.bool_()))
+    assert gandiva.make_filter(batches[0].schema, f).evaluate_device(dbs[9], dtype).num_slots == 0

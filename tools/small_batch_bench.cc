@@ -61,8 +61,8 @@ int main() {
   CHECK(gdv_filter_make(fschema, gdv_condition_new(gdv_node_and(conj, 2)), nullptr, &flt) == GDV_OK);
 
   const int NB = 64;
-  printf("%8s %10s %10s %10s   %12s %12s   (microseconds per batch, %d batches per round)\n", "rows", "proj sync",
-         "proj async", "proj many", "filter sync", "filter async", NB);
+  printf("%8s %10s %10s %10s   %12s %12s %12s   %10s   (microseconds per batch, %d batches per round)\n", "rows", "proj sync",
+         "proj async", "proj many", "filter sync", "filter async", "filter many", "proj host", NB);
   for (int64_t rows : {1024, 4096, 16384, 65536, 262144}) {
     const int64_t vbytes = ((rows + 63) / 64) * 8;
     // NB independent batches: inputs + outputs in HBM
@@ -128,7 +128,37 @@ int main() {
       for (int bch = 0; bch < NB; bch++)
         CHECK(gdv_filter_evaluate_async(flt, rows, cols[bch].data(), 2, GDV_SEL_UINT32, idx, rows, cnt, nullptr) == GDV_OK);
     });
-    printf("%8lld %10.1f %10.1f %10.1f   %12.1f %12.1f\n", (long long)rows, p_sync, p_async, p_many, f_sync, f_async);
+    // host buffers in and out (what pyarrow / JNI callers pass): staged through HBM by the library
+    std::vector<std::vector<double>> hout(10, std::vector<double>(rows));
+    std::vector<std::vector<uint8_t>> hval(10, std::vector<uint8_t>((rows + 7) / 8 + 8));
+    gdv_column_t hc[4];
+    gdv_out_column_t ho[10];
+    for (int k = 0; k < 4; k++) {
+      memset(&hc[k], 0, sizeof(hc[k]));
+      hc[k].validity = bits.data(); hc[k].validity_size = (rows + 7) / 8;
+      hc[k].data = host.data(); hc[k].data_size = rows * 8;
+    }
+    for (int e = 0; e < 10; e++) {
+      memset(&ho[e], 0, sizeof(ho[e]));
+      ho[e].validity = hval[e].data(); ho[e].validity_size = (rows + 7) / 8;
+      ho[e].data = hout[e].data(); ho[e].data_size = rows * 8;
+    }
+    const double p_host = time_rounds([&] {
+      for (int bch = 0; bch < NB; bch++)
+        CHECK(gdv_projector_evaluate(proj, rows, hc, 4, nullptr, ho, 10, GDV_MEM_HOST, nullptr, 0) == GDV_OK);
+    });
+    std::vector<void*> idxs(NB);
+    std::vector<gdv_filter_batch_t> fb(NB);
+    for (int bch = 0; bch < NB; bch++) {
+      CHECK(gdv_device_alloc(rows * 4 + 64, &idxs[bch]) == GDV_OK);
+      fb[bch] = gdv_filter_batch_t{rows, cols[bch].data(), 2, idxs[bch], rows};
+    }
+    std::vector<int64_t> counts(NB);
+    const double f_many = time_rounds([&] {
+      CHECK(gdv_filter_evaluate_many(flt, fb.data(), NB, GDV_SEL_UINT32, counts.data(), nullptr, nullptr, 0) == GDV_OK);
+    });
+    for (int bch = 0; bch < NB; bch++) gdv_device_free(idxs[bch]);
+    printf("%8lld %10.1f %10.1f %10.1f   %12.1f %12.1f %12.1f   %10.1f\n", (long long)rows, p_sync, p_async, p_many, f_sync, f_async, f_many, p_host);
     fflush(stdout);
     for (int bch = 0; bch < NB; bch++) {
       for (int k = 0; k < 4; k++) { gdv_device_free((void*)cols[bch][k].validity); gdv_device_free((void*)cols[bch][k].data); }
