@@ -203,6 +203,110 @@ def load_traffic(tag, running_kernel):
     return d.get("hbm_bytes_per_launch"), f"profiles/pmc_{tag}.json@{d.get('kernel')}"
 
 
+class BoxSampler:
+    """Clocks, power and temperature of the GPU while the timed loop runs (round 3: the same binary
+    measured 4.84 .. 6.20 ms on C2 across boxes of the pool — a reader must be able to tell a slow
+    box from a slow kernel).  Reads the amdgpu sysfs / hwmon files every few milliseconds from a
+    thread (microseconds per read; rocm-smi is a Python program that takes longer than the whole
+    timed region).  Everything is best effort: a missing file is a missing key."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.dev = None
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if open(os.path.join(card, "vendor")).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                continue
+            real = os.path.realpath(card)
+            if pci_bus_id and pci_bus_id.lower() not in real.lower():
+                continue
+            self.dev = card
+            break
+        self.hwmon = None
+        if self.dev:
+            hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")))
+            self.hwmon = hw[0] if hw else None
+        self.samples = []
+        self._stop = False
+        self._thread = None
+
+    @staticmethod
+    def _read(path, scale):
+        try:
+            return float(open(path).read().split()[0]) * scale
+        except (OSError, ValueError, IndexError):
+            return None
+
+    @staticmethod
+    def _active_mhz(path):
+        """pp_dpm_sclk / pp_dpm_mclk: the line marked '*' is the current level."""
+        try:
+            for line in open(path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def sample(self):
+        s = {}
+        if self.hwmon:
+            s["sclk_mhz"] = self._read(os.path.join(self.hwmon, "freq1_input"), 1e-6)
+            s["mclk_mhz"] = self._read(os.path.join(self.hwmon, "freq2_input"), 1e-6)
+            p = self._read(os.path.join(self.hwmon, "power1_average"), 1e-6)
+            s["power_w"] = p if p is not None else self._read(os.path.join(self.hwmon, "power1_input"), 1e-6)
+            s["temp_edge_c"] = self._read(os.path.join(self.hwmon, "temp1_input"), 1e-3)
+            s["temp_junction_c"] = self._read(os.path.join(self.hwmon, "temp2_input"), 1e-3)
+            s["temp_mem_c"] = self._read(os.path.join(self.hwmon, "temp3_input"), 1e-3)
+        if self.dev:
+            if s.get("sclk_mhz") is None:
+                s["sclk_mhz"] = self._active_mhz(os.path.join(self.dev, "pp_dpm_sclk"))
+            if s.get("mclk_mhz") is None:
+                s["mclk_mhz"] = self._active_mhz(os.path.join(self.dev, "pp_dpm_mclk"))
+            s["gpu_busy_pct"] = self._read(os.path.join(self.dev, "gpu_busy_percent"), 1.0)
+        return {k: v for k, v in s.items() if v is not None}
+
+    def start(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                x = self.sample()
+                if x:
+                    self.samples.append(x)
+                time.sleep(0.004)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        out = {"samples": len(self.samples), "source": "amdgpu sysfs (hwmon)" if self.hwmon else
+               ("amdgpu sysfs" if self.dev else "unavailable")}
+        keys = sorted({k for s in self.samples for k in s})
+        for k in keys:
+            vals = [s[k] for s in self.samples if k in s]
+            out[k] = {"min": round(min(vals), 1), "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
+        return out
+
+
+def hbm_ceilings(bytes_per_buffer=4 << 30):
+    """Read-only / write-only / copy rate of plain streaming kernels on THIS box, in THIS process
+    (gdv_device_hbm_ceilings: ~0.1 s)."""
+    import ctypes as C
+    from gandiva_amd import _capi
+    r, w, c = C.c_double(), C.c_double(), C.c_double()
+    if _capi.lib().gdv_device_hbm_ceilings(bytes_per_buffer, C.byref(r), C.byref(w), C.byref(c)) != 0:
+        return None
+    return {"read": round(r.value, 1), "write": round(w.value, 1), "copy": round(c.value, 1), "unit": "GB/s",
+            "bytes_per_buffer": bytes_per_buffer}
+
+
 def kernel_name_of(obj):
     import re
     m = re.search(r"gdv_k_[0-9a-f]{16}", obj.llvm_ir)
@@ -301,8 +405,8 @@ def main():
 
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
-        kernel_desc = ("single-pass var-len kernel, 1 launch: byte sweep, scanner-wave offsets, "
-                       "flat / LDS-staged copies")
+        kernel_desc = ("wave-shaped var-len plan: offsets-only pre-pass + offsets scan + main kernel of "
+                       "independent wave tiles (byte sweep, flat output from the sweep's registers, LDS-staged substr)")
     else:
         rows = args.rows or 1_000_000_000
         dbatch = W.c3_device_batch(rows)
@@ -320,7 +424,17 @@ def main():
         step()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    try:
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+        bus_id = f"{int(bus):02x}:" if isinstance(bus, int) else str(bus)
+    except Exception:
+        bus_id = None
+    sampler = BoxSampler(bus_id if rank == 0 else None) if rank == 0 else None
+    if sampler is not None and sampler.dev is None:
+        sampler = BoxSampler(None)   # bus id did not match a sysfs path: take the first amdgpu card
     barrier()
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         starts[i].record()
@@ -328,6 +442,8 @@ def main():
         ends[i].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    if sampler:
+        sampler.stop()
     dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     mean_dev_ms = sum(dev_ms) / len(dev_ms)
 
@@ -396,6 +512,22 @@ def main():
                 "kernel_ms_max": round(max(dev_ms), 4),
             },
         }
+        # the box this number was taken on: telemetry during the timed loop + what plain streaming
+        # kernels reach here, now, in this process
+        box = sampler.summary() if sampler else {}
+        ceil = None
+        try:
+            torch.cuda.synchronize()
+            ceil = hbm_ceilings()
+        except Exception as e:  # never take the bench line down
+            box["ceiling_error"] = str(e)
+        if ceil:
+            box["ceiling"] = ceil
+            rshare = read_per_row / bytes_per_row
+            mixed = 1.0 / (rshare / ceil["read"] + (1.0 - rshare) / ceil["write"])
+            box["ceiling_for_this_read_write_mix"] = round(mixed, 1)
+            line["roofline"]["frac_of_measured_ceiling"] = round(achieved / mixed, 4)
+        line["roofline"]["box"] = box
         if world == 1 and not args.no_cpu_baseline:
             try:
                 fn = {"c1": lambda r: {"value": None, "unit": "million rows/s", "cores": 0, "kind": "port",

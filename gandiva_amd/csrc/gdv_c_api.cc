@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "gdv_engine.h"
+#include "gdv_kernels.h"
 #include "gdv_libtag.h"
 #include "gdv_proto.h"
 
@@ -713,6 +714,25 @@ int gdv_memcpy_h2d(void* dst, const void* src, int64_t bytes) {
 int gdv_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
   hipError_t e = hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost);
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+}
+int gdv_device_hbm_ceilings(int64_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs) {
+  return Guarded([&]() -> int {
+  if (bytes < (1 << 20) || !read_gbs || !write_gbs || !copy_gbs) return Fail(Status::Invalid("bad argument"));
+  bytes &= ~int64_t{4095};
+  Runtime& rt = Runtime::Get();
+  Status st = rt.EnsureDevice();
+  if (!st.ok()) return Fail(st);
+  DeviceBuffer a, b;
+  st = a.Allocate(static_cast<size_t>(bytes));
+  if (st.ok()) st = b.Allocate(static_cast<size_t>(bytes));
+  if (!st.ok()) return Fail(st);
+  hipError_t e = hipMemset(a.get(), 1, static_cast<size_t>(bytes));
+  if (e == hipSuccess) e = hipMemset(b.get(), 2, static_cast<size_t>(bytes));
+  if (e == hipSuccess)
+    e = MeasureHbmCeilings(a.get(), b.get(), static_cast<size_t>(bytes), rt.num_cus() * 16, read_gbs, write_gbs, copy_gbs);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+  });
 }
 int gdv_device_synchronize(void) {
   hipError_t e = hipDeviceSynchronize();

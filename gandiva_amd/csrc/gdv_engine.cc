@@ -502,7 +502,8 @@ LruCache<Filter>& FilterCache() {
 // ------------------------------------------------------------------ two-stage plans
 
 Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnBuffers* in, int num_cols,
-                         MemKind mem, hipStream_t stream, const SelectionView* sel) {
+                         MemKind mem, hipStream_t stream, const SelectionView* sel,
+                         std::vector<std::atomic<int64_t>>* hints) {
   const int np = pre.num_outputs();
   // under a selection vector the first stage evaluates the SELECTED rows only (it may raise only
   // where the caller's projector may) and its temporaries hold one row per slot
@@ -532,6 +533,15 @@ Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnB
   }
   std::vector<OutputBuffers> po(np);
   std::vector<int64_t> cap(np, guess);
+  // (round-2 advisor: the blanket guess grabbed gigabytes of HBM scratch per call however small the
+  // temporaries were) — what the previous batch of this plan produced, per row, + 25 % is a far
+  // better first guess; a short buffer still costs one retry
+  if (hints != nullptr && mem == MemKind::kDevice)
+    for (int e = 0; e < np && e < static_cast<int>(hints->size()); e++) {
+      const int64_t per_row_x16 = (*hints)[e].load(std::memory_order_relaxed);
+      if (per_row_x16 > 0)
+        cap[e] = std::min<int64_t>(guess, (per_row_x16 * num_rows / 16) * 5 / 4 + 4096);
+    }
   const int64_t vbytes = mem == MemKind::kHost ? BytesForBits(num_rows) : Projector::ValidityBytes(num_rows);
   for (int e = 0; e < np; e++) {
     if (!pre.output_type(e).is_varlen()) return Status::Invalid("two-stage plan: first stage must produce utf8 / binary");
@@ -556,6 +566,10 @@ Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnB
     if (!grew) return s;
     GDV_RETURN_NOT_OK(pre.Evaluate(batch_rows, in, num_cols, sel, po.data(), np, mem, stream, 0));
   }
+  if (hints != nullptr)
+    for (int e = 0; e < np && e < static_cast<int>(hints->size()); e++)
+      (*hints)[e].store(std::max<int64_t>(1, po[e].data_size * 16 / std::max<int64_t>(num_rows, 1) + 1),
+                        std::memory_order_relaxed);
   for (int e = 0; e < np; e++) {
     ColumnBuffers c;
     c.validity = po[e].validity;
@@ -602,6 +616,7 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
     GDV_RETURN_NOT_OK(Projector::Make(schema, staged.pre, mode, config, &p->pre_));
     p->plan_schema_ = staged.schema;
     planned = &staged.main;
+    p->stage_hints_ = std::vector<std::atomic<int64_t>>(staged.pre.size());
   }
   GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_,
                                   mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
@@ -654,7 +669,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     if (num_cols != static_cast<int>(schema_.size()))
       return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
                              ") does not match the schema (" + std::to_string(schema_.size()) + ")");
-    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream, has_sel ? sel : nullptr));
+    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream, has_sel ? sel : nullptr, &stage_hints_));
     cols = stage.cols.data();
     num_cols = static_cast<int>(stage.cols.size());
   }
@@ -891,6 +906,8 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     for (int v = 0; v < nv; v++) {
       const int e = vl[v];
       totals[e] = seg[v];
+      // (totals saturate at 2^31 - 1, so a total of exactly that many bytes cannot be told from an
+      // overflow: rejected too — one byte short of what int32 offsets could address)
       if (totals[e] >= 0x7fffffffull)
         return Status::Invalid("var-len output " + std::to_string(e) + " exceeds 2 GiB");
       const int64_t have = outs[e].data_size;
@@ -1038,6 +1055,7 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
     GDV_RETURN_NOT_OK(Projector::Make(schema, staged.pre, SelectionMode::kNone, config, &f->pre_));
     f->plan_schema_ = staged.schema;
     planned = staged.main[0];
+    f->stage_hints_ = std::vector<std::atomic<int64_t>>(staged.pre.size());
   }
   GDV_RETURN_NOT_OK(PlanFilter(f->plan_schema_, planned, opts, &f->plan_));
   const PlanDeviceState* st = nullptr;
@@ -1239,7 +1257,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     if (num_cols != static_cast<int>(schema_.size()))
       return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
                              ") does not match the schema (" + std::to_string(schema_.size()) + ")");
-    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream));
+    GDV_RETURN_NOT_OK(stage.Run(*pre_, num_rows, cols, num_cols, mem, stream, nullptr, &stage_hints_));
     cols = stage.cols.data();
     num_cols = static_cast<int>(stage.cols.size());
   }

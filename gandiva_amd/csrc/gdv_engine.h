@@ -130,6 +130,7 @@ class Projector {
   // temporary columns, plan_ is built over plan_schema_ = schema_ + those columns
   std::shared_ptr<Projector> pre_;
   Schema plan_schema_;
+  mutable std::vector<std::atomic<int64_t>> stage_hints_;  // sizes of the first stage's temporaries, learnt from the last batch
 };
 
 // Temporary columns of a two-stage plan: the first-stage Projector's outputs, kept in the
@@ -138,8 +139,11 @@ struct StageColumns {
   std::vector<std::unique_ptr<DeviceBuffer>> dev;
   std::vector<std::unique_ptr<std::vector<uint8_t>>> host;
   std::vector<ColumnBuffers> cols;  // caller's columns + the temporaries
+  // hints (may be null): per first-stage output, bytes per row x 16 the previous batch produced —
+  // read to size the temporaries, updated with what this batch produced
   Status Run(const Projector& pre, int64_t num_rows, const ColumnBuffers* in, int num_cols, MemKind mem,
-             hipStream_t stream, const SelectionView* sel = nullptr);
+             hipStream_t stream, const SelectionView* sel = nullptr,
+             std::vector<std::atomic<int64_t>>* hints = nullptr);
 };
 
 class Filter {
@@ -184,6 +188,7 @@ class Filter {
   PlanDeviceStates states_;  // code objects + constant block per device context
   std::shared_ptr<Projector> pre_;  // two-stage plans, as in Projector
   Schema plan_schema_;
+  mutable std::vector<std::atomic<int64_t>> stage_hints_;
 };
 
 // Builds the plan and compiles it to a gfx950 code object without touching a device

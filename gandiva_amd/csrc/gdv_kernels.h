@@ -31,4 +31,9 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
                              int subtiles, int64_t row_base, int index_bytes, void* out,
                              int num_cus, hipStream_t stream);
 
+// Read-only / write-only / copy rate (GB/s, best of 4) of plain streaming kernels over two device
+// buffers of `bytes` bytes each (bytes a multiple of 16; use >= 1 GiB: the Infinity Cache holds 256 MiB).
+hipError_t MeasureHbmCeilings(void* a, void* b, size_t bytes, int grid, double* read_gbs, double* write_gbs,
+                              double* copy_gbs);
+
 }  // namespace gdv

@@ -236,6 +236,48 @@ EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offs
 // Serial-semantics reference check helper is NOT provided here on purpose: the CPU
 // restatement lives in oracle/ only.
 
+// ---- what plain streaming kernels reach on THIS box, right now (round 3: the same binary measured
+// 4.84 .. 6.20 ms on C2 across boxes of the pool; a bench line that also carries the box's own
+// read / write / copy ceilings can be compared across boxes).  16 B per lane, 8 in flight,
+// non-temporal, grid-stride: the shape of tools/hbm_ceiling.hip.
+typedef unsigned long long CeilU64x2 __attribute__((ext_vector_type(2)));
+constexpr int kCeilU = 8;
+__global__ void __launch_bounds__(256) CeilRead(const CeilU64x2* __restrict__ p, size_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  size_t i = (size_t)blockIdx.x * 256 * kCeilU + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * kCeilU;
+  for (; i + 256 * (kCeilU - 1) < n; i += stride) {
+    CeilU64x2 v[kCeilU];
+#pragma unroll
+    for (int u = 0; u < kCeilU; u++) v[u] = __builtin_nontemporal_load(p + i + 256 * u);
+#pragma unroll
+    for (int u = 0; u < kCeilU; u++) acc += v[u].x ^ v[u].y;
+  }
+  if (acc == 0x1234567) out[0] = acc;
+}
+__global__ void __launch_bounds__(256) CeilWrite(CeilU64x2* __restrict__ p, size_t n, unsigned long long val) {
+  size_t i = (size_t)blockIdx.x * 256 * kCeilU + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * kCeilU;
+  CeilU64x2 v;
+  v.x = val;
+  v.y = val + 1;
+  for (; i + 256 * (kCeilU - 1) < n; i += stride) {
+#pragma unroll
+    for (int u = 0; u < kCeilU; u++) __builtin_nontemporal_store(v, p + i + 256 * u);
+  }
+}
+__global__ void __launch_bounds__(256) CeilCopy(const CeilU64x2* __restrict__ a, CeilU64x2* __restrict__ b, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 * kCeilU + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * kCeilU;
+  for (; i + 256 * (kCeilU - 1) < n; i += stride) {
+    CeilU64x2 v[kCeilU];
+#pragma unroll
+    for (int u = 0; u < kCeilU; u++) v[u] = __builtin_nontemporal_load(a + i + 256 * u);
+#pragma unroll
+    for (int u = 0; u < kCeilU; u++) __builtin_nontemporal_store(v[u], b + i + 256 * u);
+  }
+}
+
 }  // namespace
 
 int64_t ScanChunks(int64_t m) { return (m + kScanChunk - 1) / kScanChunk; }
@@ -282,6 +324,38 @@ hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t
 hipError_t LaunchOffsetsScan(const uint32_t* counts, int64_t m, uint64_t* chunk_sums,
                              uint64_t* offsets, uint64_t* total, hipStream_t stream, const uint64_t* carry) {
   return ScanImpl(counts, m, m, 1, chunk_sums, offsets, total, nullptr, carry, stream);
+}
+
+hipError_t MeasureHbmCeilings(void* a, void* b, size_t bytes, int grid, double* read_gbs, double* write_gbs,
+                              double* copy_gbs) {
+  const size_t n = bytes / 16;
+  hipEvent_t e0, e1;
+  hipError_t err = hipEventCreate(&e0);
+  if (err != hipSuccess) return err;
+  err = hipEventCreate(&e1);
+  if (err != hipSuccess) { (void)hipEventDestroy(e0); return err; }
+  auto best_of = [&](auto&& launch, double moved, double* out) {
+    float best = 1e30f;
+    for (int it = 0; it < 5 && err == hipSuccess; it++) {
+      err = hipEventRecord(e0, nullptr);
+      launch();
+      if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+      if (err == hipSuccess) err = hipEventSynchronize(e1);
+      float ms = 0;
+      if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+      if (it >= 1 && ms < best) best = ms;
+    }
+    *out = moved / (best * 1e-3) / 1e9;
+  };
+  best_of([&] { hipLaunchKernelGGL(CeilRead, dim3(grid), dim3(256), 0, nullptr, static_cast<const CeilU64x2*>(a), n,
+                                   static_cast<unsigned long long*>(b)); }, (double)bytes, read_gbs);
+  best_of([&] { hipLaunchKernelGGL(CeilWrite, dim3(grid), dim3(256), 0, nullptr, static_cast<CeilU64x2*>(b), n, 7ull); },
+          (double)bytes, write_gbs);
+  best_of([&] { hipLaunchKernelGGL(CeilCopy, dim3(grid), dim3(256), 0, nullptr, static_cast<const CeilU64x2*>(a),
+                                   static_cast<CeilU64x2*>(b), n); }, 2.0 * bytes, copy_gbs);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return err != hipSuccess ? err : hipGetLastError();
 }
 
 hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int64_t nwords,

@@ -321,6 +321,11 @@ int gdv_device_free(void* ptr);
 int gdv_memcpy_h2d(void* dst_device, const void* src_host, int64_t bytes);
 int gdv_memcpy_d2h(void* dst_host, const void* src_device, int64_t bytes);
 int gdv_device_synchronize(void);
+/* What plain streaming kernels reach on the calling thread's device right now: read-only, write-only
+ * and copy rates in GB/s over two scratch buffers of `bytes` bytes (>= 1 GiB: the Infinity Cache holds
+ * 256 MiB).  Boxes of one pool differ by 10-25 % on the same binary; a benchmark line that carries
+ * these can be compared across boxes (bench.py: roofline.box). */
+int gdv_device_hbm_ceilings(int64_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs);
 
 /* ---- JNI-shaped flat entry points --------------------------------- */
 /* What the reference's JNI layer receives from Java (JniWrapper.evaluateProjector /

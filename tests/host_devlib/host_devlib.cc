@@ -231,8 +231,10 @@ long host_str_pad(int right, const int* off, const unsigned char* data, long siz
 }
 // replace with a table laid out as the planner lays it out: int32 from_len, int32 to_len, 8 unused
 // bytes, from, (16-byte aligned) to
+// inbuf != 0: the data buffer is readable 8 bytes past `size` — rows carry GDV_STR_INBUF and take
+// the word-at-a-time search (gdv_find_raw), as every tile but a batch's last few does on the device
 unsigned host_str_replace(const int* off, const unsigned char* data, long size, long n, int map,
-                          const unsigned char* table, int* out_off, unsigned char* out_data) {
+                          const unsigned char* table, int* out_off, unsigned char* out_data, int inbuf) {
   HostCol c{off, data, size};
   unsigned err = 0;
   gdv_ctx ctx{&err};
@@ -240,6 +242,7 @@ unsigned host_str_replace(const int* off, const unsigned char* data, long size, 
   out_off[0] = 0;
   for (long i = 0; i < n; i++) {
     gdv_str s = host_row(c, i);
+    if (inbuf) s.flags |= GDV_STR_INBUF;
     if (map == 1) s = upper_utf8(s);
     if (map == 2) s = lower_utf8(s);
     const gdv_str r = gdv_replace(ctx, s, table);

@@ -278,11 +278,14 @@ def test_device_reverse_pad_and_integer_text_on_host(hostlib, seed):
         fb, tb = frm.encode(), to.encode()
         table = (np.array([len(fb), len(tb), 0, 0], np.int32).tobytes() + fb + b"\0" * ((16 - len(fb) % 16) % 16) + tb + b"\0" * 8)
         tbuf = np.frombuffer(table, np.uint8).copy()
+        padded = np.concatenate([data[:size], np.full(16, 0x61, np.uint8)])   # 'a's behind the buffer: must never match
         for mp, wrap in ((0, lambda v: v), (1, lambda v: b.make_function("upper", [v], STR))):
-            out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(4 * size + 64 * n + 64, np.uint8)
-            err = hostlib.host_str_replace(_p(off), _p(data), C.c_long(size), C.c_long(n), mp, _p(tbuf), _p(out_off), _p(out_data))
             node = b.make_function("replace", [wrap(s), b.make_literal(frm, STR), b.make_literal(to, STR)], STR)
-            assert err == 0 and strings(out_off, out_data) == want_of(node), (frm, to, mp)
+            for inbuf, buf in ((0, data), (1, padded)):   # byte-wise path | word-at-a-time search (round 3)
+                out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(4 * size + 64 * n + 64, np.uint8)
+                err = hostlib.host_str_replace(_p(off), _p(buf), C.c_long(size), C.c_long(n), mp, _p(tbuf), _p(out_off),
+                                               _p(out_data), inbuf)
+                assert err == 0 and strings(out_off, out_data) == want_of(node), (frm, to, mp, inbuf)
     xv = np.array(batch.column(1).to_pylist(), dtype=np.int64)
     for k in (0, 1, 5, 19, 20, 25):
         out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(24 * n + 64, np.uint8)
