@@ -1994,45 +1994,62 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
                    << "  }\n";
         cg.varlen_outs_.push_back(vo);
       } else if (wave) {
-        // scanned output: the wave tile's base comes from the pre-pass + scan (one scalar load)
+        // scanned output: the wave tile's base comes from the pre-pass + scan (one scalar load), so
+        // bytes can leave as soon as they are staged.  The LDS window STREAMS: when the next
+        // sub-tile's rows would not fit behind what is staged, the staged bytes are flushed
+        // (coalesced, to their final place) and the window starts over at that sub-tile — outputs
+        // of up to GDV_OUT_WIN / 64 bytes per row on average (32 at 4 sub-tiles, 64 at 8) never
+        // touch the per-row direct copy, whatever the tile's total is (rounds 1-2 and the scanner
+        // shape: a tile above 8 bytes per row takes a second row pass with scattered stores — what
+        // made upper(concat(s, '-', s)) cost 4.1 ms at 5 * 10^7 rows).  A single sub-tile wider than
+        // the whole window is copied row by row, in place.
         emit_pieces();
         const std::string S = std::to_string(num_scanned++);
         vo.segment = num_scanned - 1;
         before_loop << "  const gdv_int64 base" << E << " = (gdv_int64)A.mask[" << S << " * seg_stride + wt];\n"
-                    << "  bool dir" << E << " = false;  // second row pass: copy straight to HBM\n";
-        in_pass << "  gdv_int32 run" << E << " = 0;  // bytes this wave tile produces (saturates at 2^31-1)\n";
+                    << "  gdv_int32 run" << E << " = 0;   // bytes this wave tile has produced so far (saturates at 2^31-1)\n"
+                    << "  gdv_int32 wb" << E << " = 0;    // tile-relative position of the window's first byte\n";
         cg.Stmt("const gdv_int32 ln" + E + "_u = " + total + ";");
         cg.Stmt("const gdv_int32 inc" + E + " = gdv_wave_scan_incl(ln" + E + "_u);");
         cg.Stmt("const gdv_int32 loc" + E + " = run" + E + " + inc" + E + " - ln" + E + "_u;  // where the row's bytes start inside the wave tile");
+        cg.Stmt("const gdv_int32 sub0_" + E + " = run" + E + ";");
         cg.Stmt("{ const gdv_uint32 t = " + tile_total("ln" + E + "_u", "inc" + E) + ";");
         cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t)); }");
-        cg.Stmt("if (pass == 0) {");
-        cg.Stmt("  if (live) outo" + E + "[row] = (gdv_int32)(base" + E + " + loc" + E + ");");
+        cg.Stmt("if (live) outo" + E + "[row] = (gdv_int32)(base" + E + " + loc" + E + ");");
+        // nothing at or past the caller's capacity is written (the grand total says what was needed)
+        cg.Stmt("const bool fit" + E + " = run" + E + " < 0x7fffffff && base" + E + " + run" + E + " <= A.out[" + E + "].cap;");
         if (has_window) {
           vo.window = num_staged++;
           before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
-          cg.Stmt("  gdv_int32 at = loc" + E + ";");
+          cg.Stmt("if (run" + E + " - wb" + E + " > GDV_OUT_WIN) {  // wave-uniform: the window is full");
+          cg.Stmt("  if (fit" + E + " && sub0_" + E + " > wb" + E + ") gdv_flush_out(outd" + E + " + base" + E + " + wb" + E + ", win" + E + ", sub0_" + E +
+                  " - wb" + E + ", lane);");
+          cg.Stmt("  wb" + E + " = sub0_" + E + ";");
+          cg.Stmt("}");
+          cg.Stmt("if (run" + E + " - wb" + E + " <= GDV_OUT_WIN) {");
+          cg.Stmt("  gdv_int32 at = loc" + E + " - wb" + E + ";");
           for (auto& name : pv) {
-            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
-                    " + at), " + name + ");");
+            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0) gdv_stage_copy((gdv_lds_u8*)(win" + E + " + at), " + name + ");");
             cg.Stmt("  at += " + name + ".len;");
           }
+          cg.Stmt("} else if (fit" + E + ") {  // this sub-tile alone is wider than the window: row by row, in place");
+        } else {
+          cg.Stmt("if (fit" + E + ") {  // (no LDS window left for this output: row by row, in place)");
         }
-        cg.Stmt("} else if (dir" + E + ") {");
         cg.Stmt("  gdv_uint8* at = outd" + E + " + base" + E + " + loc" + E + ";");
         for (auto& name : pv) {
           cg.Stmt("  if (" + name + ".len > 0) gdv_str_copy(at, " + name + ");");
           cg.Stmt("  at += " + name + ".len;");
         }
-        cg.Stmt("}");
-        after_rows << "  if (run" << E << " < 0x7fffffff && base" << E << " + run" << E << " <= A.out[" << E << "].cap) {\n";
-        if (has_window)
-          after_rows << "    if (run" << E << " <= GDV_OUT_WIN) {\n"
-                     << "      if (!(GDV_ABL & 16)) gdv_flush_out(outd" << E << " + base" << E << ", win" << E << ", run" << E << ", lane);\n"
-                     << "    } else {\n      dir" << E << " = true;\n      need_direct = true;\n    }\n";
-        else
-          after_rows << "    dir" << E << " = true;\n    need_direct = true;\n";
-        after_rows << "  }\n";
+        if (has_window) {
+          cg.Stmt("  wb" + E + " = run" + E + ";  // nothing of it is staged");
+          cg.Stmt("}");
+          after_rows << "  if (run" << E << " > wb" << E << " && run" << E << " < 0x7fffffff && base" << E << " + run" << E << " <= A.out[" << E
+                     << "].cap && !(GDV_ABL & 16))\n"
+                     << "    gdv_flush_out(outd" << E << " + base" << E << " + wb" << E << ", win" << E << ", run" << E << " - wb" << E << ", lane);\n";
+        } else {
+          cg.Stmt("}");
+        }
         cg.varlen_outs_.push_back(vo);
       } else {
         emit_pieces();
@@ -2136,7 +2153,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
     if (wave)
       return AssembleStringsWave(cg, plan, strings, accs, before_loop.str(), in_pass.str(), after_rows.str(),
                                  after_loop.str(), prepass ? WaveKind::kPrepass : WaveKind::kMain,
-                                 !prepass && num_scanned > 0);
+                                 /*has_direct_pass=*/false);
     return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
   }
   if (wave) return Status::CodeGenError("internal: wave shape asked for a plan without var-len columns");
