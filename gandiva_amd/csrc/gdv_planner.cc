@@ -449,6 +449,7 @@ class CodeGen {
   SelectionMode sel_mode_;
   CodegenOptions opts_;
   int compact_from_ = 0x7fffffff;  // schema fields from this index on are compact temporaries (selection mode)
+  bool no_hooks_ = false;          // pre-pass kernels have no byte sweep: '%needle%' takes the per-row search
   std::ostringstream body_;
   std::map<std::string, std::string> cse_;
   int next_tmp_ = 0;
@@ -698,7 +699,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
                                : trail ? "gdv_like_prefix" : "gdv_like_equal";
           const std::string per_row = std::string(fnname) + "(" + args[0].v + ", " + ByteTable(lit) + ", " +
                                       std::to_string(lit.size()) + ")";
-          if (lead && trail && lit.size() >= 2 && lit.size() <= 8 && args[0].col_slot >= 0 && !selection()) {
+          if (lead && trail && lit.size() >= 2 && lit.size() <= 8 && args[0].col_slot >= 0 && !selection() && !no_hooks_) {
             // '%needle%' over a whole input row: the byte sweep has marked every match position
             // of the tile's span in an LDS bitmap; the row tests its own byte range.  Spans too
             // long for the bitmap (wave-uniform) take the per-row search.
@@ -1806,12 +1807,16 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  (void)last_tile; (void)seg_stride;\n";
   EmitStringPointersAndLoads(s, cg, plan, !prepass, /*wave_shape=*/true);
   if (prepass) {
-    // no byte is read: views are (offset, length) pairs carrying the flags the main kernel assumes
+    // views carry the flags the main kernel will give them — the optimistic ASCII flag where a
+    // function consults it — so both kernels compute the same lengths.  Outputs whose length is a
+    // function of the offsets (substr, left, concat ...) read no byte here; others (replace, rtrim,
+    // an if over like ...) read the rows' bytes a first time.
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.is_varlen() && cg.needs_values_[k])
-        s << "  const gdv_int32 sfl" << k << " = GDV_STR_ASCII | GDV_STR_INBUF;\n"
-          << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n";
+        s << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n"
+          << "  const gdv_int32 sfl" << k << " = (sd" << k << " + sp1" << k << " + 8 <= slim" << k << " ? GDV_STR_INBUF : 0)"
+          << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
   } else {
     EmitStringSweep(s, cg, plan, /*wave_shape=*/true);
@@ -1919,6 +1924,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
   plan->compact_from = compact_from;
   CodeGen cg(schema, mode, opts);
   cg.compact_from_ = compact_from;
+  cg.no_hooks_ = shape == StringShape::kWavePrepass;
   WordAccumulators accs;
   std::ostringstream after_loop, before_loop, in_pass, after_rows;
   std::vector<std::string> strings;
@@ -2184,15 +2190,19 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     if (!e) return Status::Invalid("Expression cannot be null");
     GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
   }
-  // Wave shape (pre-pass + scan + independent wave tiles): row mode, at least one var-len output,
-  // and every var-len output's bytes-free under the ASCII assumption.  Everything else — and the
-  // re-run of a batch that breaks the assumption — takes the scanner shape.
+  // Wave shape (pre-pass + scan + independent wave tiles): row mode and at least one var-len
+  // output.  Outputs whose length follows from the offsets under the ASCII assumption (ByteFree)
+  // cost a pre-pass over the offsets only; the others make the pre-pass read the bytes a first
+  // time — still faster than the scanner shape, whose hand-off, occupancy and second row pass for
+  // outputs above 8 bytes per row cost more (replace at 5 * 10^7 rows: 3.3 ms there).  Selection-
+  // mode plans — and the re-run of a batch that breaks an assumption — take the scanner shape.
   bool wave_ok = mode == SelectionMode::kNone && std::getenv("GDV_NO_WAVE_SHAPE") == nullptr;
   bool any_varlen_out = false;
+  const bool bytefree_only = std::getenv("GDV_WAVE_BYTEFREE_ONLY") != nullptr;
   for (auto& e : exprs) {
     if (!e->result().type.is_varlen()) continue;
     any_varlen_out = true;
-    wave_ok = wave_ok && ByteFree(*e->root());
+    if (bytefree_only) wave_ok = wave_ok && ByteFree(*e->root());
   }
   if (!(wave_ok && any_varlen_out))
     return PlanProjectorShape(schema, exprs, mode, opts, StringShape::kScanner, nullptr, plan, nullptr, compact_from);

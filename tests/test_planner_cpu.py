@@ -73,22 +73,30 @@ def test_string_projection_builds_wave_prepass_and_general_kernels(monkeypatch, 
     assert re.search(r"#define GDV_OPTFLAT (\d)", general[0]).group(1) == "0"
 
 
-def test_plans_whose_lengths_need_bytes_keep_the_scanner_shape(monkeypatch, tmp_path):
-    """rtrim / replace / an if over like(): the output length depends on the bytes — no pre-pass is
-    possible; such plans keep the single-launch scanner shape (optimistic + general variant)."""
+def test_plans_whose_lengths_need_bytes_get_a_byte_reading_prepass(monkeypatch, tmp_path):
+    """rtrim / replace / an if over like(): the output length depends on the bytes.  Such plans take
+    the wave shape too — their pre-pass reads the rows' bytes a first time (no sweep there: a
+    '%needle%' inside it is the per-row search); GDV_WAVE_BYTEFREE_ONLY=1 and GDV_NO_WAVE_SHAPE=1
+    restore the scanner shape, which selection-mode plans always take."""
     b = gandiva.TreeExprBuilder()
     sch = W.c5_schema()
     s = b.make_field(sch.field(0))
     exprs = [b.make_expression(b.make_function("rtrim", [s], pa.string()), pa.field("t", pa.string())),
-             b.make_expression(b.make_function("upper", [s], pa.string()), pa.field("u", pa.string()))]
+             b.make_expression(b.make_if(b.make_function("like", [s, b.make_literal("%spark%", pa.string())], pa.bool_()),
+                                         b.make_function("upper", [s], pa.string()), b.make_literal("-", pa.string()),
+                                         pa.string()), pa.field("u", pa.string()))]
     files = _precompile(monkeypatch, tmp_path, sch, exprs=exprs)
     texts = [open(tmp_path / f).read() for f in files]
-    assert len(files) == 2 and all("gdv_scanner<GDV_NG>" in t for t in texts), files
-    # selection-vector projections as well (the wave shape is row mode only)
-    (tmp_path / "env").mkdir()
-    monkeypatch.setenv("GDV_NO_WAVE_SHAPE", "1")
-    files = _precompile(monkeypatch, tmp_path / "env", sch, exprs=W.c5_expressions())
-    assert len(files) == 2
+    pre = [t for t in texts if "// pre-pass" in t]
+    assert len(files) == 3 and len(pre) == 1, files
+    assert "rtrim_utf8" in pre[0] and "gdv_like_contains" in pre[0] and "gdv_range_any" not in pre[0]
+    for env in ("GDV_WAVE_BYTEFREE_ONLY", "GDV_NO_WAVE_SHAPE"):
+        d = tmp_path / env
+        d.mkdir()
+        monkeypatch.setenv(env, "1")
+        files = _precompile(monkeypatch, d, sch, exprs=exprs)
+        assert all("gdv_scanner<GDV_NG>" in open(d / f).read() for f in files), (env, files)
+        monkeypatch.delenv(env)
 
 
 def test_fixed_width_plans_have_one_variant_and_a_literal_free_body(monkeypatch, tmp_path):
