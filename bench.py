@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
     p.add_argument("--cpu-rows", type=int, default=1 << 26, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--inproc", action="store_true",
+                   help="ONE process, --gpus host threads, each on its own device context (round 3: "
+                        "in-process multi-device; virtual contexts when the box has fewer GPUs). c2 only")
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                    help="weak: --rows per GPU (default); strong: ONE logical batch of --rows rows "
                         "row-sharded across the ranks by gandiva_amd.shard (c2 only)")
@@ -313,8 +316,79 @@ def kernel_name_of(obj):
     return m.group(0) if m else None
 
 
+def main_inproc(args):
+    """One process drives N device contexts with one host thread each: every thread
+    selects its device (gandiva.set_device), generates its own 2^28-row shard there and evaluates the
+    SAME Projector handle — the handle is loaded onto a context the first time it runs there.  Same
+    barrier / max-over-threads timing as the multi-process launch; no collective, weak scaling.  With
+    fewer physical GPUs than threads the contexts are virtual and share the GPUs (the value is then
+    a correctness / plumbing figure, not a scaling one)."""
+    import threading
+    import torch
+    import gandiva_amd as gandiva
+    from gandiva_amd import workloads as W
+    n = args.gpus
+    rows = args.rows or (1 << 28)
+    physical = gandiva.physical_device_count()
+    if physical < 1:
+        raise SystemExit("bench.py needs a HIP device")
+    if n > physical:
+        gandiva.set_virtual_devices(n)
+        if not args.rows:
+            rows = max((1 << 28) // n, 1 << 20)   # the shards share one GPU's HBM
+    proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
+    bar = threading.Barrier(n)
+    elapsed = [0.0] * n
+    errors = []
+
+    def work(r):
+        try:
+            gandiva.set_device(r)
+            dev = f"cuda:{r % physical}"
+            with torch.cuda.device(r % physical):
+                dbatch = W.c2_device_batch(rows, device=dev, seed_offset=1000 * r)
+                outs = proj.evaluate_device(dbatch)
+                for _ in range(args.warmup):
+                    proj.evaluate_device(dbatch, outputs=outs, sync=False)
+                torch.cuda.synchronize()
+                bar.wait()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    proj.evaluate_device(dbatch, outputs=outs, sync=False)
+                torch.cuda.synchronize()
+                bar.wait()
+                elapsed[r] = time.perf_counter() - t0
+        except Exception as e:
+            errors.append((r, repr(e)))
+            try:
+                bar.abort()
+            except Exception:
+                pass
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit(f"in-process bench failed: {errors}")
+    el = max(elapsed)
+    total_rows = rows * n
+    print(json.dumps({
+        "metric": "million rows/sec, 10-expr float64 Projector (10% nulls)", "value": round(total_rows * args.steps / el / 1e6, 1),
+        "unit": "million rows/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column",
+                   "rows_per_gpu": rows, "total_rows": total_rows,
+                   "sharding": f"row-range x{n}, ONE process, one host thread + device context per shard, no collective",
+                   "physical_gpus": physical, "virtual_contexts": n > physical,
+                   "residency": "inputs and outputs in HBM (zero-copy C-ABI path)"}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.inproc:
+        return main_inproc(args)
     import torch
     import torch.distributed as dist
     import gandiva_amd as gandiva

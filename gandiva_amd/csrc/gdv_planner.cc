@@ -2244,7 +2244,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
       return Status::OK();
     }
     plan->prepass = pre;
-    plan->ir = pre->source + fast.source;
+    plan->ir = fast.source + pre->source;  // (the main kernel first: its name is the plan's)
   }
   return Status::OK();
 }

@@ -29,9 +29,11 @@ def pmc(fetch_csv, write_csv, dst, algorithmic, launches_per_step=1):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("gdv_k_"):
                 vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-        # dominant kernel = the one with the largest mean counter value
+        # one Evaluate may be several generated kernels (C5: pre-pass + main): the step's traffic is the
+        # sum of their per-launch means; the kernel named is the dominant one
         name, v = max(vals.items(), key=lambda kv: sum(kv[1]) / len(kv[1]))
-        return name, sum(v) / len(v), len(v)
+        total = sum(sum(x) / len(x) for x in vals.values())
+        return name, total, len(v)
     kname, fetch_kb, nf = per_launch(fetch_csv, "FETCH_SIZE")
     _, write_kb, nw = per_launch(write_csv, "WRITE_SIZE")
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction
@@ -43,6 +45,8 @@ def pmc(fetch_csv, write_csv, dst, algorithmic, launches_per_step=1):
     write_bytes = write_kb * 1024 * launches_per_step
     out = {
         "kernel": kname,
+        "note": "per Evaluate: summed over the generated kernels of one step (a wave-shaped var-len plan runs a "
+                "pre-pass and a main kernel); the ahead-of-time scan kernels (a few MB) are not included",
         "launches_sampled": {"fetch_pass": nf, "write_pass": nw},
         "launches_per_step": launches_per_step,
         "FETCH_SIZE_KiB_raw": fetch_kb,

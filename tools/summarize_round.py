@@ -1,4 +1,7 @@
-"""gpurun_out/r02 (tools/gpu_evidence.sh) -> the small files committed under profiles/."""
+"""gpurun_out/<round> (tools/gpu_evidence.sh) -> the small files committed under profiles/.
+
+  python tools/summarize_round.py r03
+"""
 import csv
 import glob
 import json
@@ -10,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import summarize_prof as SP  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -22,24 +26,24 @@ def first(pattern):
 for w in ("c1", "c2", "c3", "c4", "c5"):
     b = os.path.join(SRC, f"bench_{w}.json")
     if os.path.exists(b) and os.path.getsize(b) > 0:
-        shutil.copy(b, os.path.join(DST, f"r02_{w}_bench.json"))
+        shutil.copy(b, os.path.join(DST, f"{ROUND}_{w}_bench.json"))
     b = os.path.join(SRC, f"bench_{w}_cpu.json")
     if os.path.exists(b) and os.path.getsize(b) > 0:
-        shutil.copy(b, os.path.join(DST, f"r02_{w}_bench_with_cpu_baseline.json"))
+        shutil.copy(b, os.path.join(DST, f"{ROUND}_{w}_bench_with_cpu_baseline.json"))
 for w in ("c2", "c3", "c4", "c5"):
     st = first(f"prof_{w}/**/{w}_kernel_stats.csv")
     if st:
-        SP.stats(st, os.path.join(DST, f"r02_{w}_kernel_stats.csv"))
+        SP.stats(st, os.path.join(DST, f"{ROUND}_{w}_kernel_stats.csv"))
     pb = os.path.join(SRC, f"prof_{w}_bench.json")
     if os.path.exists(pb) and os.path.getsize(pb) > 0:
-        shutil.copy(pb, os.path.join(DST, f"r02_{w}_bench_under_rocprof.json"))
+        shutil.copy(pb, os.path.join(DST, f"{ROUND}_{w}_bench_under_rocprof.json"))
     f, wr = first(f"pmc_fetch_{w}/**/{w}_counter_collection.csv"), first(f"pmc_write_{w}/**/{w}_counter_collection.csv")
     bench = os.path.join(SRC, f"bench_{w}.json")
     if f and wr and os.path.exists(bench):
         d = json.load(open(bench))
         alg = d["roofline"]["algorithmic_bytes_per_row"] * d["config"]["rows_per_gpu"]
         SP.pmc(f, wr, os.path.join(DST, f"pmc_{w}.json"), alg, 1)
-        shutil.copy(os.path.join(DST, f"pmc_{w}.json"), os.path.join(DST, f"r02_pmc_{w}.json"))
+        shutil.copy(os.path.join(DST, f"pmc_{w}.json"), os.path.join(DST, f"{ROUND}_pmc_{w}.json"))
 # SQ counters of the C5 kernel, per wave
 acc = {}
 for path in glob.glob(os.path.join(SRC, "sq_c5_*", "**", "c5_counter_collection.csv"), recursive=True):
@@ -47,18 +51,20 @@ for path in glob.glob(os.path.join(SRC, "sq_c5_*", "**", "c5_counter_collection.
         if r["Kernel_Name"].startswith("gdv_k_"):
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if acc:
-    with open(os.path.join(DST, "r02_c5_sq_counters.txt"), "w") as f:
+    with open(os.path.join(DST, ROUND + "_c5_sq_counters.txt"), "w") as f:
         waves = sum(acc.get("SQ_WAVES", [0])) or 1
-        f.write("# C5 single-pass kernel, SQ counters summed over the profiled launches; per wave = / SQ_WAVES\n")
+        f.write("# C5 kernels (pre-pass + main), SQ counters summed over the profiled launches; per wave = / SQ_WAVES\n")
         f.write("# (one wave = 256 rows = 4 sub-tiles of 64 rows)\n")
         for k, v in sorted(acc.items()):
             f.write(f"{k:22s} total {sum(v):.4g}  launches {len(v)}  per_wave {sum(v) / waves * (len(acc.get('SQ_WAVES', [1])) / len(v)):.1f}\n")
-for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt"):
+for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt",
+             "small_batches.txt", "registry_tail_timing.txt", "flat_only_plans.txt", "inproc_bench.txt", "multi_device.txt",
+             "c5_variants.txt", "filter_project_chain.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
-        shutil.copy(p, os.path.join(DST, "r02_" + name))
+        shutil.copy(p, os.path.join(DST, ROUND + "_" + name))
 p = os.path.join(SRC, "pytest_gpu_full.log")
 if os.path.exists(p):
     lines = [l for l in open(p) if "passed" in l or "failed" in l or l.startswith(("FAILED", "ERROR"))]
-    open(os.path.join(DST, "r02_pytest_gpu_summary.txt"), "w").writelines(lines[-10:])
+    open(os.path.join(DST, ROUND + "_pytest_gpu_summary.txt"), "w").writelines(lines[-10:])
 print(sorted(os.listdir(DST)))
