@@ -204,9 +204,25 @@ GDV_DEV gdv_uint64 gdv_deposit_word(gdv_uint64 acc, int u, gdv_uint64 word, int 
 // their original order, and a value written at [0] in iteration u ends up at [u]).
 #ifdef GDV_UNROLL_ROWS
 #define GDV_ROW_LOOP _Pragma("unroll")
+#elif defined(GDV_ROW_UNROLL2)
+#define GDV_ROW_LOOP _Pragma("unroll 2")
 #else
 #define GDV_ROW_LOOP _Pragma("nounroll")
 #endif
+// 16 bytes to HBM (unaligned): plain, or non-temporal (experiment: -DGDV_NT_STRING_STORES)
+typedef gdv_uint64 gdv_u64x2_t __attribute__((ext_vector_type(2)));
+GDV_DEV void gdv_store16(gdv_uint8* dst, gdv_uint64 lo, gdv_uint64 hi) {
+#ifdef GDV_NT_STRING_STORES
+  typedef gdv_u64x2_t __attribute__((aligned(1))) unaligned_t;
+  gdv_u64x2_t v;
+  v.x = lo;
+  v.y = hi;
+  __builtin_nontemporal_store(v, (unaligned_t*)dst);
+#else
+  gdv_uint64 q[2] = {lo, hi};
+  __builtin_memcpy(dst, q, 16);
+#endif
+}
 #ifdef GDV_U
 template <typename T>
 GDV_DEV void gdv_rot(T (&a)[GDV_U]) {
@@ -1354,7 +1370,7 @@ GDV_DEV void gdv_flush_out(gdv_uint8* __restrict__ dst, const gdv_uint8* win, gd
       const gdv_int32 j = i + 16 <= cnt ? i : cnt - 16;  // the last piece is shifted back to end at cnt
       gdv_uint64 w[2];
       __builtin_memcpy(w, win + j, 16);
-      __builtin_memcpy(dst + j, w, 16);
+      gdv_store16(dst + j, w[0], w[1]);
     }
   } else if (lane < cnt) {
     dst[lane] = win[lane];
@@ -1941,10 +1957,7 @@ GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, 
 // on C5, i.e. 6 -> 8 waves per SIMD).  Nothing is stored at or past `cap`.
 GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
                              bool inside, gdv_int64 cap) {
-  if (inside && doff + 16 <= cap) {
-    gdv_uint64 q[2] = {gdv_map8(w[0], map), gdv_map8(w[1], map)};
-    __builtin_memcpy(dst + doff, q, 16);
-  }
+  if (inside && doff + 16 <= cap) gdv_store16(dst + doff, gdv_map8(w[0], map), gdv_map8(w[1], map));
 }
 // the ends of the span: lane 0 writes bytes [sp0, sp0 + 16), lane 1 bytes [sp1 - 16, sp1) (spans
 // shorter than 16 bytes: one byte per lane).  dst = output bytes, src = input bytes, both indexed

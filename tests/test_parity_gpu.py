@@ -723,3 +723,34 @@ def test_small_batch_filter_one_workgroup_per_batch(dtype):
     assert full.num_slots == sizes[9] and full.to_array().to_pylist() == list(range(sizes[9]))
     f = b.make_condition(b.make_function("isnull", [b.make_literal(1, pa.int64())], pa.bool_()))
     assert gandiva.make_filter(batches[0].schema, f).evaluate_device(dbs[9], dtype).num_slots == 0
+
+
+def test_filters_that_can_raise_report_the_error_on_every_path():
+    """divide inside a predicate: the fused small-batch kernel, the multi-batch launch and the
+    three-launch path all hand the device error word back as an ExecutionError; guarded divides do
+    not raise on any of them."""
+    b = gandiva.TreeExprBuilder()
+    sch = pa.schema([pa.field("a", pa.int64()), pa.field("z", pa.int64())])
+    fa, fz = b.make_field(sch.field(0)), b.make_field(sch.field(1))
+    div = b.make_function("divide", [fa, fz], pa.int64())
+    raw = b.make_condition(b.make_function("greater_than", [div, b.make_literal(1, pa.int64())], pa.bool_()))
+    guarded = b.make_condition(b.make_and([b.make_function("not_equal", [fz, b.make_literal(0, pa.int64())], pa.bool_()),
+                                           b.make_function("greater_than", [div, b.make_literal(1, pa.int64())], pa.bool_())]))
+    rng = np.random.default_rng(4)
+    for n in (100, 5000, 300_000):           # fused kernel | fused kernel | three launches
+        a = pa.array(rng.integers(-50, 50, n), pa.int64())
+        z = pa.array(rng.integers(0, 4, n), pa.int64())
+        batch = pa.RecordBatch.from_arrays([a, z], schema=sch)
+        db = gandiva.DeviceBatch.from_arrow(batch)
+        with pytest.raises(pa.lib.ArrowException, match="divide by zero"):
+            gandiva.make_filter(sch, raw).evaluate_device(db, "int32")
+        with pytest.raises(pa.lib.ArrowException, match="divide by zero"):
+            gandiva.make_filter(sch, raw).evaluate(batch, None)
+        g = gandiva.make_filter(sch, guarded)
+        want = oracle.filter_indices(guarded, batch, "int32")
+        assert g.evaluate_device(db, "int32").to_array().equals(want)
+        assert g.evaluate_device(db, "int32", sync=False).to_array().equals(want)   # (plans that can raise wait anyway)
+        if n <= 5000:
+            assert g.evaluate_device_many([db, db], "int32")[1].to_array().equals(want)
+            with pytest.raises(pa.lib.ArrowException, match="divide by zero"):
+                gandiva.make_filter(sch, raw).evaluate_device_many([db, db], "int32")
