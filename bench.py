@@ -234,6 +234,8 @@ class BoxSampler:
         self.samples = []
         self._stop = False
         self._thread = None
+        # hwmon reads go to the SMU: keep them rare (GDV_BENCH_TELEMETRY_MS, default 25 ms)
+        self.interval = max(0.002, float(os.environ.get("GDV_BENCH_TELEMETRY_MS", "25")) / 1e3)
 
     @staticmethod
     def _read(path, scale):
@@ -279,7 +281,7 @@ class BoxSampler:
                 x = self.sample()
                 if x:
                     self.samples.append(x)
-                time.sleep(0.004)
+                time.sleep(self.interval)
         self._thread = threading.Thread(target=loop, daemon=True)
         self._thread.start()
 
@@ -503,7 +505,7 @@ def main():
         bus_id = f"{int(bus):02x}:" if isinstance(bus, int) else str(bus)
     except Exception:
         bus_id = None
-    sampler = BoxSampler(bus_id if rank == 0 else None) if rank == 0 else None
+    sampler = BoxSampler(bus_id if rank == 0 else None) if rank == 0 and os.environ.get("GDV_BENCH_NO_TELEMETRY") is None else None
     if sampler is not None and sampler.dev is None:
         sampler = BoxSampler(None)   # bus id did not match a sysfs path: take the first amdgpu card
     barrier()
