@@ -1326,6 +1326,44 @@ GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
     if (r & 1) dst[i] = (gdv_uint8)w;
   }
 }
+// Wave-shaped kernels sweep one sub-tile (64 rows) at a time and keep its span in LDS: GDV_SUB_SPAN =
+// bytes of span the match bitmaps and the mirror cover (32 per row on average; longer spans —
+// wave-uniform — take the per-row search and read HBM).
+#define GDV_SUB_SPAN 2048
+typedef __attribute__((address_space(3))) gdv_uint64 gdv_lds_u64;
+// 8 bytes at byte offset d of the LDS mirror (base 16-byte aligned, readable 16 bytes past any
+// valid offset): two ALIGNED words and a funnel shift — no unaligned LDS read
+GDV_DEV gdv_uint64 gdv_mirror_word(const gdv_lds_u8* mir, gdv_int32 d) {
+  const gdv_lds_u64* q = (const gdv_lds_u64*)(mir + (d & ~7));
+  const gdv_uint64 lo = q[0], hi = q[1];
+  const gdv_int32 sh = (d & 7) * 8;
+  return (lo >> sh) | ((hi << 1) << (63 - sh));
+}
+// gdv_stage_copy for a view that lies inside the mirrored span [mbase, mbase + mlen) of its column:
+// the bytes come from LDS (the sweep put them there) instead of a second trip to L2 / the fabric.
+// Any other view — literals, other columns, spans too long for the mirror (mlen = 0) — and the
+// non-view kinds take the ordinary copy.  The test is per lane.
+GDV_DEV void gdv_stage_copy_mir(gdv_lds_u8* dst, const gdv_str& s, const gdv_lds_u8* mir, const gdv_uint8* mbase,
+                                gdv_int32 mlen) {
+  const gdv_int64 d64 = s.p - mbase;
+  if ((s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE)) || d64 < 0 || d64 + s.len > (gdv_int64)mlen) {
+    gdv_stage_copy(dst, s);
+    return;
+  }
+  const gdv_int32 d = (gdv_int32)d64, len = s.len;
+  gdv_int32 i = 0;
+  for (; i + 8 <= len; i += 8) {
+    const gdv_uint64 w = gdv_map8(gdv_mirror_word(mir, d + i), s.map);
+    __builtin_memcpy(dst + i, &w, 8);
+  }
+  const gdv_int32 r = len - i;
+  if (r > 0) {
+    gdv_uint64 w = gdv_map8(gdv_mirror_word(mir, d + i), s.map);  // bytes past the view are never stored
+    if (r & 4) { const gdv_uint32 v = (gdv_uint32)w; __builtin_memcpy(dst + i, &v, 4); i += 4; w >>= 32; }
+    if (r & 2) { const gdv_uint16 v = (gdv_uint16)w; __builtin_memcpy(dst + i, &v, 2); i += 2; w >>= 16; }
+    if (r & 1) dst[i] = (gdv_uint8)w;
+  }
+}
 #endif
 // the same out of line: rows that bypass the LDS staging window (wave tiles whose bytes do not
 // fit it) — rare, and inlining it at every sub-tile of every output doubles the kernel
@@ -1935,7 +1973,9 @@ GDV_DEV bool gdv_in_strings(const gdv_str& s, const gdv_uint8* bytes, const gdv_
 // 2 <= m <= 8) starts at byte k of `cur` (its bytes continue in `nxt`).  Two-byte SWAR filter
 // (zero-byte tests on word ^ splat), exact verification of the few candidates.
 GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, gdv_uint64 mask,
-                              gdv_uint64 splat0, gdv_uint64 splat1) {
+                              gdv_uint32 splat0_4, gdv_uint32 splat1_4) {
+  // (the splats of the needle's first two bytes travel as 32-bit words: half the scalar registers)
+  const gdv_uint64 splat0 = ((gdv_uint64)splat0_4 << 32) | splat0_4, splat1 = ((gdv_uint64)splat1_4 << 32) | splat1_4;
   const gdv_uint64 x = cur ^ splat0;
   gdv_uint64 cand = (x - GDV_B01) & ~x & GDV_B80;
   const gdv_uint64 y = ((cur >> 8) | (nxt << 56)) ^ splat1;

@@ -29,12 +29,13 @@ CodegenOptions CodegenOptions::FromEnv() {
   if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_BITMAPS_LAST")) o.bitmaps_last = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_WPE")) o.waves_per_eu = std::max(0, std::min(8, atoi(s)));
+  if (const char* s = std::getenv("GDV_NO_LDS_MIRROR")) o.lds_mirror = atoi(s) == 0;
   return o;
 }
 
 std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
-         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + "e" + std::to_string(waves_per_eu);
+         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + (lds_mirror ? "" : "nm") + "e" + std::to_string(waves_per_eu);
 }
 
 // ------------------------------------------------------------------ validation
@@ -1354,13 +1355,15 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
 
 // the rolled row loop: prologue (this sub-tile's inputs picked at index 0), the fused body, rotation
 // of the per-sub-tile registers; the caller appends its own rotations and closes the loop ("  }\n")
-void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool wave_shape = false) {
+void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool wave_shape = false,
+                       const std::string& at_top = std::string()) {
   const bool sel = cg.selection();
   const int nin = plan->layout.n_in;
   // The row loop is NOT unrolled: the per-sub-tile registers are read and written through
   // gdv_pick / gdv_put (selects on the wave-uniform u), so the fused body exists once — a
   // quarter of the code, the compile time and the VGPRs of the unrolled form.
   s << "GDV_ROW_LOOP\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << at_top
     << "    {\n"
     << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
     << "      const bool live = row < n;\n"
@@ -1412,8 +1415,9 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
   }
 }
 
-// byte sweep of every var-len input: tile-wide ASCII flag, '%needle%' match bitmaps, flat outputs
-void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool wave_shape) {
+// byte sweep of every var-len input (scanner shape): tile-wide ASCII flag, '%needle%' match
+// bitmaps, flat outputs.  (Wave-shaped kernels sweep one sub-tile at a time: EmitWaveSweep.)
+void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
   const bool sel = cg.selection();
   const int nin = plan->layout.n_in;
   const int nhook = static_cast<int>(cg.contains_hooks_.size());
@@ -1434,25 +1438,18 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool 
       continue;
     }
     // one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
-    if (wave_shape)
-      // (the span's ends come from two scalar loads: the byte sweep does not wait for the offsets' vector loads)
-      s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n"
-        << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n"
-        << "  const gdv_int32 inb" << K << " = sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
-    else
-      s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
-        << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    s << "  const gdv_int32 inb" << K << " = sd" << K << " + __builtin_amdgcn_readlane(ob" << K
+      << "[GDV_U - 1], 63) + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
     if (!flats.empty())
       s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
     if (hooks.empty() && !want_ascii && flats.empty()) {
       s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
       continue;
     }
-    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n";
-    if (!wave_shape)
-      s << "  const gdv_int32 sp0" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
-        << "  const gdv_int32 sp1" << K << " = __builtin_amdgcn_readlane(ob" << K << "[GDV_U - 1], 63);\n";
-    s << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
+    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n"
+      << "  const gdv_int32 sp0" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+      << "  const gdv_int32 sp1" << K << " = __builtin_amdgcn_readlane(ob" << K << "[GDV_U - 1], 63);\n"
+      << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
       << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
       << "  (void)hm_ok" << K << ";\n"
       << "  gdv_uint64 sacc" << K << " = 0;\n";
@@ -1462,24 +1459,9 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool 
       s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
         << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
         << ";  // the needle: a runtime constant\n"
-        << "  const gdv_uint64 ns0_" << h << " = (nd" << h << " & 0xffull) * GDV_B01, ns1_" << h << " = ((nd" << h
-        << " >> 8) & 0xffull) * GDV_B01;\n";
+        << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
+        << " >> 8) & 0xffull) * 0x01010101u;\n";
     }
-    if (wave_shape) {
-      // software-pipelined: the next step's 16 bytes are in flight while this step's are matched /
-      // stored; lane 63's halo is the next step's lane 0 (no extra load)
-      s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
-        << "  if (sb" << K << " + 16 * lane < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + sb" << K << " + 16 * lane, 16), 16);\n"
-        << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
-        << "    const gdv_int32 a = c + 16 * lane;\n"
-        << "    const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
-        << "    wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
-        << "    if (a + 1024 < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
-        << "    sacc" << K << " |= w[0] | w[1];\n";
-      if (!hooks.empty())
-        s << "    const gdv_uint64 tail = (gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)wn" << K << "[0]) |\n"
-          << "                            ((gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)(wn" << K << "[0] >> 32)) << 32);\n";
-    } else {
     s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
       << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
@@ -1488,59 +1470,172 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, bool 
     if (!hooks.empty())
       s << "    gdv_uint64 tail = 0;  // lane 63's halo: the first 8 bytes of the next step\n"
         << "    if (lane == 63 && a + 16 < sp1" << K << ") tail = gdv_load8_raw(sd" << K << " + a + 16);\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      const std::string H = std::to_string(h), M = std::to_string(hk.map);
+      s << "    {\n"
+        << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
+        << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
+        << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
+        << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+        << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
+        << ") << 8);\n"
+        << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
+        << ") >> 4] = (gdv_uint16)m;\n"
+        << "    }\n";
     }
-    if (!hooks.empty()) {
-      for (int h : hooks) {
-        const ContainsHook& hk = cg.contains_hooks_[h];
-        const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
-        const std::string H = std::to_string(h), M = std::to_string(hk.map);
-        s << "    {\n"
-          << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
-          << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
-          << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-          << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
-          << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
-          << ") << 8);\n"
-          << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
-          << ") >> 4] = (gdv_uint16)m;\n"
-          << "    }\n";
-      }
-    }
-    if (wave_shape)
-      // flat outputs leave straight from the sweep's registers (prototype: -0.08 ms on C5 against a
-      // second pass over the span, profiles/r03_k4_experiments.txt); a piece's bytes outside this
-      // wave's span [sp0, sp1) belong to the neighbouring tiles
-      for (auto* vo : flats)
-        s << "    if (!(GDV_ABL & 8)) gdv_sweep_store(outd" << vo->e << ", (gdv_int64)a - so0_" << K
-          << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= sp1" << K << ", A.out[" << vo->e << "].cap);\n";
     s << "  }\n";
-    if (wave_shape)
-      for (auto* vo : flats)
-        s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
-          << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
     // optimistic flat outputs: their place in the output is known from the input offsets alone, so
     // the span is copied right here, while the sweep's lines are still in L2 / L1.  (Moving the copy
     // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
     // slower: 1.90 vs 1.78 ms, same box, profiles/r02_c5_tuning.txt.)
     for (auto* vo : flats)
-      if (!wave_shape)
       s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
         << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
         << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
-    if (want_ascii && wave_shape)
-      // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
-      // fact for the row bodies — every general UTF-8 path folds away — and a tile that breaks it
-      // raises NOTASCII: the host re-runs the batch on the general (scanner) kernel
-      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n"
-        << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
-    else if (want_ascii)
+    if (want_ascii)
       s << "  const gdv_int32 sfl" << K << " = inb" << K << " | (__ballot((sacc" << K
         << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
     else
       s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
     if (!hooks.empty()) s << "  __builtin_amdgcn_wave_barrier();\n";
   }
+}
 
+// The byte sweep of wave-shaped kernels, one SUB-TILE (64 rows) at a time, at the top of the row
+// loop: lanes over the bytes of the sub-tile's span — 16 B per lane and step, coalesced, the first
+// step of the NEXT sub-tile already in flight while this one's rows are evaluated.  Per piece:
+//   * tile-wide ASCII check (optimistic: the row bodies were compiled for ASCII; a byte >= 0x80
+//     raises NOTASCII after the loop and the host re-runs the batch on the general kernel),
+//   * '%needle%' match bits -> LDS bitmap of the sub-tile's span,
+//   * flat outputs leave straight from the registers (a piece is stored by the sub-tile that holds
+//     its last byte's predecessor: pieces that straddle two sub-tiles are stored exactly once),
+//   * the bytes themselves -> the LDS MIRROR of the span, which the rows' staged copies read.
+// Why per sub-tile and not per wave tile as in the first wave-shaped kernels: by the time the rows
+// of a 512-row tile re-read their bytes (8-byte loads at the row's offset) the lines had left the
+// XCD's L2 — 0.6 GB of extra fabric reads on C5, 1.40 x the algorithmic traffic
+// (profiles/r03_c5_traffic.txt).  A sub-tile's span is small enough to keep in LDS (GDV_SUB_SPAN =
+// 32 bytes per row; longer spans — wave-uniform — read HBM as before), so nothing is read twice.
+struct WaveSweepText {
+  std::string prologue;   // before the row loop
+  std::string per_sub;    // top of the row loop's body (u = the sub-tile)
+  std::string epilogue;   // after the row loop
+};
+void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText* out) {
+  std::ostringstream s, b, e;
+  const int nin = plan->layout.n_in;
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+    std::vector<int> hooks;
+    for (int h = 0; h < nhook; h++)
+      if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
+    const bool want_ascii = cg.ascii_slots_.count(k) != 0;
+    std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
+    for (auto& vo : cg.varlen_outs_)
+      if (vo.flat_slot == k) flats.push_back(&vo);
+    const bool mirror = mirror_slot == k;
+    const std::string K = std::to_string(k);
+    // the tile's span: its ends come from two scalar loads; one wave-uniform range test per tile
+    // makes every 8-byte read of these rows unchecked
+    s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n"
+      << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n"
+      << "  const gdv_int32 inb" << K << " = sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    if (!flats.empty())
+      s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
+    if (hooks.empty() && !want_ascii && flats.empty()) {
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+      continue;
+    }
+    s << "  // ---- byte sweep of input " << k << ", one sub-tile at a time (inside the row loop)\n"
+      << "  gdv_uint64 sacc" << K << " = 0;\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
+        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
+        << ";  // the needle: a runtime constant\n"
+        << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
+        << " >> 8) & 0xffull) * 0x01010101u;\n";
+    }
+    if (mirror)
+      s << "  gdv_lds_u8* const mir" << K << " = (gdv_lds_u8*)lds_in;  // LDS mirror of the current sub-tile's span\n";
+    // the first piece of sub-tile 0 (every later sub-tile's first piece is loaded one iteration ahead)
+    s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
+      << "  {\n"
+      << "    const gdv_int32 e0 = GDV_U > 1 ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+      << "    const gdv_int32 b0 = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
+      << "    if (!(GDV_ABL & 64) && b0 + 16 * lane < e0) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
+      << " + b0 + 16 * lane, 16), 16);\n"
+      << "  }\n";
+    // the two ragged ends of the tile's span (whole 16-byte pieces that overlap their neighbours)
+    for (auto* vo : flats)
+      s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
+        << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
+    if (want_ascii)
+      // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
+      // fact for the row bodies — every general UTF-8 path folds away
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n";
+    else
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+
+    // ---- per sub-tile
+    b << "    // byte sweep of this sub-tile's span of input " << k << "\n"
+      << "    const gdv_int32 ss" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+      << "    const gdv_int32 se" << K << " = u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+      << "    const gdv_int32 sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
+      << "    const bool hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap / mirror\n"
+      << "    (void)hm_ok" << K << ";\n"
+      << "    for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : se" << K << "); c += 1024) {\n"
+      << "      const gdv_int32 a = c + 16 * lane;\n"
+      << "      const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
+      << "      wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
+      << "      if (a + 1024 < se" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
+      << "      sacc" << K << " |= w[0] | w[1];\n";
+    if (!hooks.empty())
+      // lane 63's halo is the next step's lane 0 (no extra load)
+      b << "      const gdv_uint64 tail = (gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)wn" << K << "[0]) |\n"
+        << "                              ((gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)(wn" << K << "[0] >> 32)) << 32);\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      const std::string H = std::to_string(h), M = std::to_string(hk.map);
+      b << "      {\n"
+        << "        const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
+        << "        gdv_uint64 nx = gdv_next_lane(lo);\n"
+        << "        if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
+        << "        const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+        << "                             (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
+        << ") << 8);\n"
+        << "        if (hm_ok" << K << " && a < se" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
+        << ") >> 4] = (gdv_uint16)m;\n"
+        << "      }\n";
+    }
+    if (mirror)
+      b << "      if (hm_ok" << K << " && a < se" << K << ") __builtin_memcpy(mir" << K << " + (a - sb" << K << "), w, 16);\n";
+    // a piece is stored by the sub-tile in whose span it ENDS (a + 16 <= se): the piece that
+    // straddles two sub-tiles is the next one's first piece; the tile's own ends: gdv_sweep_edges
+    for (auto* vo : flats)
+      b << "      if (!(GDV_ABL & 8)) gdv_sweep_store(outd" << vo->e << ", (gdv_int64)a - so0_" << K
+        << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= se" << K << ", A.out[" << vo->e << "].cap);\n";
+    b << "    }\n"
+      << "    if (u + 1 < GDV_U) {  // the first piece of the next sub-tile's span\n"
+      << "      const gdv_int32 e2 = u + 2 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 2 ? 2 : 0]) : sp1" << K << ";\n"
+      << "      const gdv_int32 nb = se" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + se" << K << ") & 15);\n"
+      << "      if (!(GDV_ABL & 64) && nb + 16 * lane < e2) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
+      << " + nb + 16 * lane, 16), 16);\n"
+      << "    }\n";
+    if (!hooks.empty() || mirror) b << "    __builtin_amdgcn_wave_barrier();\n";
+
+    // ---- after the loop
+    if (want_ascii)
+      e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
+  }
+  out->prologue = s.str();
+  out->per_sub = b.str();
+  out->epilogue = e.str();
 }
 
 // ------------------------------------------------------------------ string plans
@@ -1582,6 +1677,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
+    << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy(dst, v)\n"
     << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
     << "#define GDV_OUT(e, v) if (live) "
     << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
@@ -1601,7 +1697,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "  (void)optflat;\n";
   if (nv == 0) s << "  if (rbase >= n) return;  // nothing but dead rows (no workgroup barrier below)\n";
   EmitStringPointersAndLoads(s, cg, plan, true);
-  EmitStringSweep(s, cg, plan, /*wave_shape=*/false);
+  EmitStringSweep(s, cg, plan);
 
   // ---- row phase
   s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
@@ -1777,23 +1873,44 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   const int nhook = prepass ? 0 : static_cast<int>(cg.contains_hooks_.size());
   plan->num_varlen_outputs = prepass ? 0 : nv;
   for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
+  const int nin = plan->layout.n_in;
+  // LDS mirror: the first swept var-len input, when some output stages bytes (its copies are the readers)
+  int mirror_slot = -1;
+  if (!prepass && plan->opts.lds_mirror) {
+    bool any_window = false;
+    for (auto& vo : cg.varlen_outs_) any_window |= vo.window >= 0;
+    for (int k = 0; any_window && k < nin && mirror_slot < 0; k++) {
+      const DataType& t = cg.schema_[plan->input_fields[k]].type;
+      if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+      bool swept = cg.ascii_slots_.count(k) != 0;
+      for (auto& h : cg.contains_hooks_) swept |= h.slot == k;
+      for (auto& vo : cg.varlen_outs_) swept |= vo.flat_slot == k;
+      if (swept) mirror_slot = k;
+    }
+  }
 
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
   std::ostringstream& s = as.src;
-  const int nin = plan->layout.n_in;
   s << "// " << (prepass ? "pre-pass: byte totals per wave tile from the offsets alone (optimistic ASCII)"
                          : "wave shape: independent wave tiles, output bases from the pre-pass + scan")
     << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
-    << "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n"
+    << "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n"
     << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+  if (mirror_slot >= 0)
+    // staged copies read the row's bytes from the LDS mirror of the sub-tile's span when the view
+    // lies inside it (any view of that column does; literals, other columns: HBM as before)
+    s << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy_mir(dst, v, mir" << mirror_slot << ", sd" << mirror_slot << " + sb" << mirror_slot
+      << ", hm_ok" << mirror_slot << " ? se" << mirror_slot << " - sb" << mirror_slot << " : 0)\n";
+  else
+    s << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy(dst, v)\n";
 
   s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wt, const int lane, const int wave,\n"
-    << "                      gdv_uint8* lds_out, gdv_uint64* lds_hit) {\n"
-    << "  (void)lds_out; (void)lds_hit; (void)wave;\n"
+    << "                      gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint8* lds_in) {\n"
+    << "  (void)lds_out; (void)lds_hit; (void)lds_in; (void)wave;\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
@@ -1806,6 +1923,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const gdv_int64 seg_stride = A.aux1;  // wave-tile totals / bases: one array of seg_stride entries per scanned output\n"
     << "  (void)last_tile; (void)seg_stride;\n";
   EmitStringPointersAndLoads(s, cg, plan, !prepass, /*wave_shape=*/true);
+  WaveSweepText sweep;
   if (prepass) {
     // views carry the flags the main kernel will give them — the optimistic ASCII flag where a
     // function consults it — so both kernels compute the same lengths.  Outputs whose length is a
@@ -1819,7 +1937,8 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
           << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
   } else {
-    EmitStringSweep(s, cg, plan, /*wave_shape=*/true);
+    EmitWaveSweep(cg, plan, mirror_slot, &sweep);
+    s << sweep.prologue;
   }
 
   s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
@@ -1834,11 +1953,21 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   else
     s << "  constexpr int pass = 0;\n  (void)pass;\n";
   s << decls_in_pass;
-  EmitStringRowLoop(s, cg, plan, /*wave_shape=*/true);
+  EmitStringRowLoop(s, cg, plan, /*wave_shape=*/true, sweep.per_sub);
   s << "  }\n";
   if (has_direct_pass) s << "  if (pass == 1) break;\n";
+  s << sweep.epilogue;
   s << after_row_loop;
-  s << epilogue_after_loop;
+  if (!prepass && !has_direct_pass)
+    // the epilogue's pointers (validity words, closing offsets, totals) are read from the argument
+    // block HERE, not hoisted above the row loop where they would sit in — or be spilled from —
+    // scalar registers for the whole tile: the block's address goes through an opaque zero
+    s << "  {\n  gdv_int64 gdv_z = 0;\n  asm volatile(\"\" : \"+s\"(gdv_z));\n"
+      << "  const gdv_args& A_late = *(const gdv_args*)((const gdv_uint8*)&A + gdv_z);\n"
+      << "  {\n  const gdv_args& A = A_late;\n"
+      << epilogue_after_loop << "  }\n  }\n";
+  else
+    s << epilogue_after_loop;
   if (has_direct_pass) s << "  }  // pass\n";
   s << "}\n\n";
 
@@ -1850,11 +1979,13 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     // (a pre-pass tile is a few loads and one store: waves walk several tiles, grid-stride)
     s << "  const gdv_int64 nwt = (GDV_ROWS(A) + 64 * GDV_U - 1) / (64 * GDV_U);\n"
       << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nwt; wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
-      << "    gdv_tile(A, wt, lane, wave, nullptr, nullptr);\n";
+      << "    gdv_tile(A, wt, lane, wave, nullptr, nullptr, nullptr);\n";
   else
     s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
       << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
-      << "  gdv_tile(A, (gdv_int64)blockIdx.x * GDV_WAVES + wave, lane, wave, gdv_lds_out[wave], gdv_lds_hit[wave]);\n";
+      << (mirror_slot >= 0 ? "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_in[GDV_WAVES][GDV_SUB_SPAN + 32];\n" : "")
+      << "  gdv_tile(A, (gdv_int64)blockIdx.x * GDV_WAVES + wave, lane, wave, gdv_lds_out[wave], gdv_lds_hit[wave], "
+      << (mirror_slot >= 0 ? "gdv_lds_in[wave]" : "nullptr") << ");\n";
   s << "}\n";
 
   std::string text = s.str();
@@ -2035,7 +2166,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
           cg.Stmt("if (run" + E + " - wb" + E + " <= GDV_OUT_WIN) {");
           cg.Stmt("  gdv_int32 at = loc" + E + " - wb" + E + ";");
           for (auto& name : pv) {
-            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0) gdv_stage_copy((gdv_lds_u8*)(win" + E + " + at), " + name + ");");
+            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0) GDV_STAGE_COPY((gdv_lds_u8*)(win" + E + " + at), " + name + ");");
             cg.Stmt("  at += " + name + ".len;");
           }
           cg.Stmt("} else if (fit" + E + ") {  // this sub-tile alone is wider than the window: row by row, in place");
@@ -2097,7 +2228,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
           // tile then takes the second, direct pass)
           cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
           for (auto& name : pv) {
-            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) gdv_stage_copy((gdv_lds_u8*)(win" + E +
+            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) GDV_STAGE_COPY((gdv_lds_u8*)(win" + E +
                     " + at), " + name + ");");
             cg.Stmt("  at += " + name + ".len;");
           }
@@ -2146,10 +2277,10 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
       if (shape == StringShape::kWaveMain) {
         // wave shape: a tile costs a fixed prologue (scalar loads, sweep set-up, ends of the span,
         // flush), so 8 sub-tiles per wave beat 4 (C5: 1.15 vs 1.29 ms, profiles/r03_c5_tuning.txt)
-        // — as long as the wave's LDS (staging windows of 8 B per row, match bitmaps of 32 bits
-        // per row) leaves room for six workgroups per CU
+        // — as long as the wave's LDS (staging windows of 8 B per row, the match bitmaps and the
+        // mirror of ONE sub-tile's span) leaves room for six workgroups per CU
         const int windows = num_staged, hooks = static_cast<int>(cg.contains_hooks_.size());
-        const int lds_u8 = windows * (8 * 64 * 8 + 16) + hooks * ((8 * 64 * 32) / 64 + 4) * 8;
+        const int lds_u8 = windows * (8 * 64 * 8 + 16) + hooks * (2048 / 64 + 4) * 8 + (opts.lds_mirror && windows > 0 ? 2048 + 32 : 0);
         plan->opts.subtiles = lds_u8 <= 6656 ? 8 : 4;
       }
       // (kWavePrepass: the caller passes the main kernel's tile)

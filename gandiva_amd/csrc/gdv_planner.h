@@ -37,6 +37,10 @@ struct CodegenOptions {
   bool scalar_bitmaps = false;
   bool bitmaps_last = false;   // issue the bitmap-word loads behind the value loads (GDV_BITMAPS_LAST)
   int waves_per_eu = 0;        // > 0: amdgpu_waves_per_eu(n, n) on fixed-width kernels (GDV_WPE): lets the compiler keep every load in flight
+  // Wave-shaped string kernels: the byte sweep of a sub-tile also drops the bytes into an LDS mirror
+  // and the staged copy of the rows reads them from there instead of going back to L2, which the
+  // lines have left by then (profiles/r03_c5_traffic.txt).  GDV_NO_LDS_MIRROR=1 switches it off.
+  bool lds_mirror = true;
   bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
   static CodegenOptions FromEnv();
   std::string Key() const;
