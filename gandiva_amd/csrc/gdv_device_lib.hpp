@@ -1999,6 +1999,12 @@ GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const 
                              bool inside, gdv_int64 cap) {
   if (inside && doff + 16 <= cap) gdv_store16(dst + doff, gdv_map8(w[0], map), gdv_map8(w[1], map));
 }
+// the same with the output position and the capacity as 32-bit values (a flat output is below
+// 2 GiB: its offsets are int32) — a scalar base + 32-bit lane offset instead of 64-bit lane arithmetic
+GDV_DEV void gdv_sweep_store32(gdv_uint8* __restrict__ dst, gdv_int32 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
+                               bool inside, gdv_int32 cap31) {
+  if (inside && doff <= cap31 - 16) gdv_store16(dst + (gdv_uint32)doff, gdv_map8(w[0], map), gdv_map8(w[1], map));
+}
 // the ends of the span: lane 0 writes bytes [sp0, sp0 + 16), lane 1 bytes [sp1 - 16, sp1) (spans
 // shorter than 16 bytes: one byte per lane).  dst = output bytes, src = input bytes, both indexed
 // by the input offset minus `rebase`.

@@ -240,6 +240,7 @@ struct VarlenOut {
   int flat_map = 0;               // ... read through this byte map
   int window = -1;                // >= 0: LDS staging window of this output (non-flat outputs)
   int segment = -1;               // wave shape: index of this output's array of wave-tile totals / bases
+  bool reads_views = false;       // staged output whose copies read readable views (candidates for the LDS mirror)
 };
 
 class CodeGen {
@@ -451,6 +452,7 @@ class CodeGen {
   CodegenOptions opts_;
   int compact_from_ = 0x7fffffff;  // schema fields from this index on are compact temporaries (selection mode)
   bool no_hooks_ = false;          // pre-pass kernels have no byte sweep: '%needle%' takes the per-row search
+  int mirror_slot_ = -1;           // wave main kernel: the var-len input whose sub-tile spans are mirrored in LDS
   std::ostringstream body_;
   std::map<std::string, std::string> cse_;
   int next_tmp_ = 0;
@@ -1564,13 +1566,18 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText
       s << "  gdv_lds_u8* const mir" << K << " = (gdv_lds_u8*)lds_in;  // LDS mirror of the current sub-tile's span\n";
     // the first piece of sub-tile 0 (every later sub-tile's first piece is loaded one iteration ahead)
     s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
+      << (hooks.empty() ? "" : "  gdv_uint64 tn" + K + " = 0;  // lane 63's halo (the 8 bytes behind its piece), loaded WITH the piece\n")
       << "  {\n"
       << "    const gdv_int32 e0 = GDV_U > 1 ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
       << "    const gdv_int32 b0 = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
       << "    if (!(GDV_ABL & 64) && b0 + 16 * lane < e0) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
       << " + b0 + 16 * lane, 16), 16);\n"
+      << (hooks.empty() ? "" : "    if (!(GDV_ABL & 64) && lane == 63 && b0 + 1024 < e0) tn" + K + " = gdv_load8_raw(sd" + K + " + b0 + 1024);\n")
       << "  }\n";
     // the two ragged ends of the tile's span (whole 16-byte pieces that overlap their neighbours)
+    for (auto* vo : flats)
+      s << "  const gdv_int32 fcap" << vo->e << " = (gdv_int32)(A.out[" << vo->e << "].cap > 0x7fffffff ? 0x7fffffff : A.out[" << vo->e
+        << "].cap);\n";
     for (auto* vo : flats)
       s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
         << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
@@ -1592,12 +1599,11 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText
       << "      const gdv_int32 a = c + 16 * lane;\n"
       << "      const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
       << "      wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
+      << (hooks.empty() ? "" : "      const gdv_uint64 tail = tn" + K + ";  // (lane 63 only) — loaded one step ahead like the piece: nothing here waits for a load it has just issued\n"
+                               "      tn" + K + " = 0ull;\n")
       << "      if (a + 1024 < se" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
+      << (hooks.empty() ? "" : "      if (lane == 63 && a + 1024 + 16 < se" + K + ") tn" + K + " = gdv_load8_raw(sd" + K + " + a + 1024 + 16);\n")
       << "      sacc" << K << " |= w[0] | w[1];\n";
-    if (!hooks.empty())
-      // lane 63's halo is the next step's lane 0 (no extra load)
-      b << "      const gdv_uint64 tail = (gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)wn" << K << "[0]) |\n"
-        << "                              ((gdv_uint64)(gdv_uint32)__builtin_amdgcn_readfirstlane((gdv_int32)(gdv_uint32)(wn" << K << "[0] >> 32)) << 32);\n";
     for (int h : hooks) {
       const ContainsHook& hk = cg.contains_hooks_[h];
       const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
@@ -1618,14 +1624,15 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText
     // a piece is stored by the sub-tile in whose span it ENDS (a + 16 <= se): the piece that
     // straddles two sub-tiles is the next one's first piece; the tile's own ends: gdv_sweep_edges
     for (auto* vo : flats)
-      b << "      if (!(GDV_ABL & 8)) gdv_sweep_store(outd" << vo->e << ", (gdv_int64)a - so0_" << K
-        << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= se" << K << ", A.out[" << vo->e << "].cap);\n";
+      b << "      if (!(GDV_ABL & 8)) gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
+        << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= se" << K << ", fcap" << vo->e << ");\n";
     b << "    }\n"
       << "    if (u + 1 < GDV_U) {  // the first piece of the next sub-tile's span\n"
       << "      const gdv_int32 e2 = u + 2 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 2 ? 2 : 0]) : sp1" << K << ";\n"
       << "      const gdv_int32 nb = se" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + se" << K << ") & 15);\n"
       << "      if (!(GDV_ABL & 64) && nb + 16 * lane < e2) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
       << " + nb + 16 * lane, 16), 16);\n"
+      << (hooks.empty() ? "" : "      if (!(GDV_ABL & 64) && lane == 63 && nb + 1024 < e2) tn" + K + " = gdv_load8_raw(sd" + K + " + nb + 1024);\n")
       << "    }\n";
     if (!hooks.empty() || mirror) b << "    __builtin_amdgcn_wave_barrier();\n";
 
@@ -1636,6 +1643,105 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText
   out->prologue = s.str();
   out->per_sub = b.str();
   out->epilogue = e.str();
+}
+
+// The byte sweep of wave-shaped kernels WITHOUT an LDS mirror: the whole wave tile's span in one
+// go, before the row loop (full 1024-byte steps: cheaper per byte than the per-sub-tile sweep,
+// whose steps are three quarters full on average).  Taken when no staged copy would read the
+// mirror — flat-only plans, outputs that are not readable views (reverse, replace, digits).
+void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std::string* epilogue) {
+  std::ostringstream e;
+  const int nin = plan->layout.n_in;
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = cg.schema_[plan->input_fields[k]].type;
+    if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+    std::vector<int> hooks;
+    for (int h = 0; h < nhook; h++)
+      if (cg.contains_hooks_[h].slot == k) hooks.push_back(h);
+    const bool want_ascii = cg.ascii_slots_.count(k) != 0;
+    std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
+    for (auto& vo : cg.varlen_outs_)
+      if (vo.flat_slot == k) flats.push_back(&vo);
+    const std::string K = std::to_string(k);
+    // the span's ends come from two scalar loads (the sweep does not wait for the offsets' vector
+    // loads); one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
+    s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n"
+      << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n"
+      << "  const gdv_int32 inb" << K << " = sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n";
+    if (!flats.empty())
+      s << "  const gdv_int32 so0_" << K << " = so" << K << "[0];  // the batch's first offset (flat outputs rebase by it)\n";
+    if (hooks.empty() && !want_ascii && flats.empty()) {
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+      continue;
+    }
+    s << "  // ---- byte sweep of input " << k << ": the wave tile's rows are one contiguous span\n"
+      << "  const gdv_int32 sb" << K << " = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
+      << "  const bool hm_ok" << K << " = sp1" << K << " - sb" << K << " <= GDV_SPAN_MAX;\n"
+      << "  (void)hm_ok" << K << ";\n"
+      << "  gdv_uint64 sacc" << K << " = 0;\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
+        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
+        << ";  // the needle: a runtime constant\n"
+        << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
+        << " >> 8) & 0xffull) * 0x01010101u;\n";
+    }
+    for (auto* vo : flats)
+      s << "  const gdv_int32 fcap" << vo->e << " = (gdv_int32)(A.out[" << vo->e << "].cap > 0x7fffffff ? 0x7fffffff : A.out[" << vo->e
+        << "].cap);\n";
+    // software-pipelined: the next step's 16 bytes — and lane 63's halo, the 8 bytes behind its
+    // piece — are in flight while this step's are matched / stored
+    s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
+      << (hooks.empty() ? "" : "  gdv_uint64 tn" + K + " = 0;\n")
+      << "  if (sb" << K << " + 16 * lane < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + sb" << K << " + 16 * lane, 16), 16);\n"
+      << (hooks.empty() ? "" : "  if (lane == 63 && sb" + K + " + 1024 < sp1" + K + ") tn" + K + " = gdv_load8_raw(sd" + K + " + sb" + K + " + 1024);\n")
+      << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
+      << "    const gdv_int32 a = c + 16 * lane;\n"
+      << "    const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
+      << "    wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
+      << (hooks.empty() ? "" : "    const gdv_uint64 tail = tn" + K + ";  // (lane 63 only)\n    tn" + K + " = 0ull;\n")
+      << "    if (a + 1024 < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
+      << (hooks.empty() ? "" : "    if (lane == 63 && a + 1024 + 16 < sp1" + K + ") tn" + K + " = gdv_load8_raw(sd" + K + " + a + 1024 + 16);\n")
+      << "    sacc" << K << " |= w[0] | w[1];\n";
+    for (int h : hooks) {
+      const ContainsHook& hk = cg.contains_hooks_[h];
+      const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
+      const std::string H = std::to_string(h), M = std::to_string(hk.map);
+      s << "    {\n"
+        << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
+        << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
+        << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
+        << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+        << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
+        << ") << 8);\n"
+        << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
+        << ") >> 4] = (gdv_uint16)m;\n"
+        << "    }\n";
+    }
+    // flat outputs leave straight from the sweep's registers; a piece's bytes outside this wave's
+    // span [sp0, sp1) belong to the neighbouring tiles
+    for (auto* vo : flats)
+      s << "    if (!(GDV_ABL & 8)) gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
+        << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= sp1" << K << ", fcap" << vo->e << ");\n";
+    s << "  }\n";
+    for (auto* vo : flats)
+      s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
+        << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
+    if (want_ascii) {
+      // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
+      // fact for the row bodies — every general UTF-8 path folds away — and a tile that breaks it
+      // raises NOTASCII: the host re-runs the batch on the general (scanner) kernel
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n";
+      e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
+    } else {
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+    }
+    if (!hooks.empty()) s << "  __builtin_amdgcn_wave_barrier();\n";
+  }
+  *epilogue = e.str();
 }
 
 // ------------------------------------------------------------------ string plans
@@ -1874,20 +1980,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   plan->num_varlen_outputs = prepass ? 0 : nv;
   for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
   const int nin = plan->layout.n_in;
-  // LDS mirror: the first swept var-len input, when some output stages bytes (its copies are the readers)
-  int mirror_slot = -1;
-  if (!prepass && plan->opts.lds_mirror) {
-    bool any_window = false;
-    for (auto& vo : cg.varlen_outs_) any_window |= vo.window >= 0;
-    for (int k = 0; any_window && k < nin && mirror_slot < 0; k++) {
-      const DataType& t = cg.schema_[plan->input_fields[k]].type;
-      if (!(t.is_varlen() && cg.needs_values_[k])) continue;
-      bool swept = cg.ascii_slots_.count(k) != 0;
-      for (auto& h : cg.contains_hooks_) swept |= h.slot == k;
-      for (auto& vo : cg.varlen_outs_) swept |= vo.flat_slot == k;
-      if (swept) mirror_slot = k;
-    }
-  }
+  const int mirror_slot = prepass ? -1 : cg.mirror_slot_;  // (decided with the tile shape, PlanProjectorShape)
 
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
@@ -1896,7 +1989,8 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
                          : "wave shape: independent wave tiles, output bases from the pre-pass + scan")
     << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
-    << "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
+    << (mirror_slot >= 0 ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
+                         : "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n")
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n"
     << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
@@ -1936,9 +2030,11 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
           << "  const gdv_int32 sfl" << k << " = (sd" << k << " + sp1" << k << " + 8 <= slim" << k << " ? GDV_STR_INBUF : 0)"
           << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
-  } else {
+  } else if (mirror_slot >= 0) {
     EmitWaveSweep(cg, plan, mirror_slot, &sweep);
     s << sweep.prologue;
+  } else {
+    EmitWaveTileSweep(s, cg, plan, &sweep.epilogue);
   }
 
   s << "  // ---- rows: fused expression bodies (value for every row, validity per word)\n";
@@ -1953,6 +2049,12 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   else
     s << "  constexpr int pass = 0;\n  (void)pass;\n";
   s << decls_in_pass;
+  if (!prepass)
+    // every load issued so far (offsets, validity words, the tile's base, the first piece) is waited
+    // for HERE, once: left to the compiler, the wait lands at the value's first use inside the loop
+    // as a vmcnt(0) that every later iteration pays again — stalling on the previous sub-tile's
+    // stores and on the piece it has just prefetched
+    s << "  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)\n";
   EmitStringRowLoop(s, cg, plan, /*wave_shape=*/true, sweep.per_sub);
   s << "  }\n";
   if (has_direct_pass) s << "  if (pass == 1) break;\n";
@@ -2157,6 +2259,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         cg.Stmt("const bool fit" + E + " = run" + E + " < 0x7fffffff && base" + E + " + run" + E + " <= A.out[" + E + "].cap;");
         if (has_window) {
           vo.window = num_staged++;
+          vo.reads_views = !v.opaque;  // (concat results: their pieces are mostly views of columns)
           before_loop << "  gdv_uint8* const win" << E << " = lds_out + " << vo.window << " * (GDV_OUT_WIN + 16);\n";
           cg.Stmt("if (run" + E + " - wb" + E + " > GDV_OUT_WIN) {  // wave-uniform: the window is full");
           cg.Stmt("  if (fit" + E + " && sub0_" + E + " > wb" + E + ") gdv_flush_out(outd" + E + " + base" + E + " + wb" + E + ", win" + E + ", sub0_" + E +
@@ -2280,7 +2383,20 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         // — as long as the wave's LDS (staging windows of 8 B per row, the match bitmaps and the
         // mirror of ONE sub-tile's span) leaves room for six workgroups per CU
         const int windows = num_staged, hooks = static_cast<int>(cg.contains_hooks_.size());
-        const int lds_u8 = windows * (8 * 64 * 8 + 16) + hooks * (2048 / 64 + 4) * 8 + (opts.lds_mirror && windows > 0 ? 2048 + 32 : 0);
+        // LDS mirror (and with it the per-sub-tile sweep): the first swept var-len input, when some
+        // staged output's copies would read it
+        cg.mirror_slot_ = -1;
+        bool readers = false;
+        for (auto& vo : cg.varlen_outs_) readers |= vo.window >= 0 && vo.reads_views;
+        for (size_t k = 0; opts.lds_mirror && readers && k < cg.input_fields_.size() && cg.mirror_slot_ < 0; k++) {
+          if (!(schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k])) continue;
+          bool swept = cg.ascii_slots_.count(static_cast<int>(k)) != 0;
+          for (auto& h : cg.contains_hooks_) swept |= h.slot == static_cast<int>(k);
+          for (auto& vo : cg.varlen_outs_) swept |= vo.flat_slot == static_cast<int>(k);
+          if (swept) cg.mirror_slot_ = static_cast<int>(k);
+        }
+        const int lds_u8 = windows * (8 * 64 * 8 + 16) +
+                           (cg.mirror_slot_ >= 0 ? hooks * (2048 / 64 + 4) * 8 + 2048 + 32 : hooks * ((8 * 64 * 32) / 64 + 4) * 8);
         plan->opts.subtiles = lds_u8 <= 6656 ? 8 : 4;
       }
       // (kWavePrepass: the caller passes the main kernel's tile)

@@ -27,7 +27,8 @@ print(sys.argv[2], "| device ms", sys.argv[3], "| FETCH raw GB", sorted(round(su
 PY
 }
 run "sub-tile sweep + LDS mirror" A=1
-run "sub-tile sweep, no mirror" GDV_NO_LDS_MIRROR=1
 run "mirror + NT stores" "GDV_RTC_OPT=-DGDV_NT_STRING_STORES"
+(cd $R && PYTHONPATH=$R timeout 150 python tools/registry_tail_timing.py 2>&1 | tail -8 | tee $OUT/registry_tail_timing.txt)
+(cd $R && PYTHONPATH=$R timeout 60 python tools/flat_only_timing.py 2>&1 | tail -4 | tee $OUT/flat_only.txt)
 timeout 100 python $R/bench.py --workload c5 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_c5.json
 cat $OUT/bench_c5.json | cut -c1-400
