@@ -482,7 +482,8 @@ def main():
         def step():
             proj.evaluate_device(dbatch, outputs=outs, sync=False)
         kernel_desc = ("wave-shaped var-len plan: offsets-only pre-pass + offsets scan + main kernel of "
-                       "independent wave tiles (byte sweep, flat output from the sweep's registers, LDS-staged substr)")
+                       "independent wave tiles (byte sweep per 64-row sub-tile: match bits + LDS mirror of the span, "
+                       "flat output from the sweep's registers, substr staged LDS -> LDS)")
     else:
         rows = args.rows or 1_000_000_000
         dbatch = W.c3_device_batch(rows)
