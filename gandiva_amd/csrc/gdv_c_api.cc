@@ -339,7 +339,7 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
   const bool dev = mem_kind == GDV_MEM_DEVICE;
   if (validity_bytes) *validity_bytes = dev ? Projector::ValidityBytes(rows) : (rows + 7) / 8;
   if (data_bytes && t.is_varlen()) {
-    *data_bytes = 0;
+    *data_bytes = p->p->VarlenBytesHint(i, rows);  // 0 until a batch has been evaluated
     return GDV_OK;
   }
   if (data_bytes)
@@ -986,7 +986,8 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const ArrowDeviceArr
     o[e].validity_size = dev ? Projector::ValidityBytes(out_rows) : (out_rows + 7) / 8;
     if (t.is_varlen()) {
       o[e].offsets_size = (out_rows + 1) * 4;
-      o[e].data_size = varlen_guess;
+      const int64_t hint = p->p->VarlenBytesHint(e, out_rows);  // what earlier batches produced per row
+      o[e].data_size = hint > 0 ? hint : varlen_guess;
       st = block->Allocate(o[e].offsets_size, &o[e].offsets);
       if (!st.ok()) return Fail(st);
     } else {

@@ -586,6 +586,15 @@ Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnB
 
 // ------------------------------------------------------------------ Projector
 
+int64_t Projector::VarlenBytesHint(int i, int64_t rows) const {
+  if (i < 0 || static_cast<size_t>(i) >= out_bytes_x16_.size() || rows <= 0) return 0;
+  const int64_t x16 = out_bytes_x16_[i].load(std::memory_order_relaxed);
+  if (x16 <= 0) return 0;
+  // (an eighth of head room: batches of one column rarely differ by more)
+  const __int128 bytes = static_cast<__int128>(x16) * rows / 16 * 9 / 8 + 256;
+  return static_cast<int64_t>(std::min<__int128>(bytes, (int64_t{1} << 31) - 64));
+}
+
 Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
                        SelectionMode mode, const Configuration& config,
                        std::shared_ptr<Projector>* out) {
@@ -620,6 +629,7 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
   }
   GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_,
                                   mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
+  p->out_bytes_x16_ = std::vector<std::atomic<int64_t>>(exprs.size());
   const PlanDeviceState* st = nullptr;
   GDV_RETURN_NOT_OK(p->states_.Get(p->plan_, &st));  // compiles + loads on the calling thread's device
   ProjectorCache().Put(key, p);
@@ -912,6 +922,12 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
         return Status::Invalid("var-len output " + std::to_string(e) + " exceeds 2 GiB");
       const int64_t have = outs[e].data_size;
       outs[e].data_size = static_cast<int64_t>(totals[e]);  // bytes needed / produced
+      if (static_cast<size_t>(e) < out_bytes_x16_.size() && out_rows > 0) {
+        const int64_t seen = static_cast<int64_t>(totals[e]) * 16 / out_rows + 1;
+        int64_t cur = out_bytes_x16_[e].load(std::memory_order_relaxed);
+        while (seen > cur && !out_bytes_x16_[e].compare_exchange_weak(cur, seen, std::memory_order_relaxed)) {
+        }
+      }
       if (have < static_cast<int64_t>(totals[e]) || (totals[e] > 0 && outs[e].data == nullptr))
         capacity = Status::Invalid("output buffer " + std::to_string(e) + ": data capacity " +
                                    std::to_string(have) + " < " + std::to_string(totals[e]) +

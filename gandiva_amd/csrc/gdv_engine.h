@@ -131,6 +131,14 @@ class Projector {
   std::shared_ptr<Projector> pre_;
   Schema plan_schema_;
   mutable std::vector<std::atomic<int64_t>> stage_hints_;  // sizes of the first stage's temporaries, learnt from the last batch
+  // var-len outputs: the most bytes per row (x 16) a batch has produced so far; 0 = no batch yet
+  mutable std::vector<std::atomic<int64_t>> out_bytes_x16_;
+
+ public:
+  // A capacity HINT for var-len output i over `rows` rows, from what earlier batches produced
+  // (0 before the first one).  Callers that size their byte buffer by it avoid the
+  // "too small -> bytes needed -> retry" round trip on every batch after the first.
+  int64_t VarlenBytesHint(int i, int64_t rows) const;
 };
 
 // Temporary columns of a two-stage plan: the first-stage Projector's outputs, kept in the

@@ -467,7 +467,7 @@ Status Projector::Evaluate(const arrow::RecordBatch& batch, const SelectionVecto
     const bool varlen = IsVarlen(*output_fields_[e]->type());
     int64_t vbytes = 0, dbytes = 0;
     GDV_CXX_RETURN_NOT_OK(gdv_projector_output_sizes(handle_, e, out_rows, mem, &vbytes, &dbytes));
-    if (varlen) dbytes = varlen_guess;
+    if (varlen && dbytes == 0) dbytes = varlen_guess;  // (non-zero: what earlier batches produced per row)
     ARROW_ASSIGN_OR_RAISE(vbuf[e], AllocOut(vbytes, device, pool, mm));
     ARROW_ASSIGN_OR_RAISE(dbuf[e], AllocOut(dbytes, device, pool, mm));
     std::memset(&outs[e], 0, sizeof(outs[e]));

@@ -507,7 +507,7 @@ class Projector:
             vb, db = C.c_int64(), C.c_int64()
             _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_HOST, vb, db))
             v = pa.allocate_buffer(_pad64(max(vb.value, 1)))
-            d = pa.allocate_buffer(_pad64(guess if varlen[i] else max(db.value, 1)))
+            d = pa.allocate_buffer(_pad64((db.value or guess) if varlen[i] else max(db.value, 1)))
             o = pa.allocate_buffer(_pad64((out_rows + 1) * 4)) if varlen[i] else None
             holders[i] = [v, d, o]
             outs[i].validity, outs[i].validity_size = v.address, v.size
@@ -593,7 +593,8 @@ class Projector:
                 outputs.append(DeviceColumn(
                     t, out_rows,
                     torch.empty(_pad64(max(vb.value, 1)), dtype=torch.uint8, device="cuda"),
-                    torch.empty(_pad64(guess if varlen[i] else max(db.value, 1)), dtype=torch.uint8,
+                    # (var-len: db = what earlier batches of this projector produced per row, 0 before the first)
+                    torch.empty(_pad64((db.value or guess) if varlen[i] else max(db.value, 1)), dtype=torch.uint8,
                                 device="cuda"),
                     torch.empty(_pad64((out_rows + 1) * 4), dtype=torch.uint8, device="cuda")
                     if varlen[i] else None))

@@ -220,7 +220,10 @@ gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i);
 int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, int mem_kind,
                                int64_t* validity_bytes, int64_t* data_bytes);
 /* var-len (utf8/binary) outputs: offsets need (rows + 1) * 4 bytes; *data_bytes above is
- * reported as 0 — the byte total is only known once the rows have been evaluated: call evaluate
+ * reported as 0 before this projector has evaluated a batch and afterwards as a capacity HINT
+ * (the most bytes per row a batch has produced so far, with an eighth of head room — sizing the
+ * buffer by it saves the retry below on every batch after the first).  It is not a bound:
+ * the byte total is only known once the rows have been evaluated: call evaluate
  * with any capacity; the kernel never writes past it, and when it is too small the call fails with
  * GDV_INVALID and data_size is updated to the bytes needed (the reference's JNI path grows its buffer through an expander callback
  * for the same reason). */

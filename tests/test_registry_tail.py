@@ -597,3 +597,37 @@ def test_gpu_hoisted_values_keep_the_guards_of_the_tree_they_came_from():
         oracle.project(bare, batch)
     with pytest.raises(pa.lib.ArrowException, match="divide by zero"):
         gandiva.make_projector(batch.schema, bare, None).evaluate(batch)
+
+
+@pytest.mark.gpu
+def test_gpu_varlen_capacity_hint_is_learnt_from_the_first_batch():
+    """gdv_projector_output_sizes reports 0 data bytes for a var-len output until the projector has
+    evaluated a batch, then what that batch produced per row (with head room): an output LONGER than
+    its inputs (lpad to 16) no longer costs 'too small -> bytes needed -> retry' on every batch."""
+    from gandiva_amd import _capi, DeviceBatch
+    lib = _capi.lib()
+    rng = np.random.default_rng(7)
+    words = ["".join(rng.choice(list("abcdefgh"), size=int(k))) for k in rng.integers(0, 9, 30_000)]
+    batch = pa.RecordBatch.from_arrays([pa.array(words, STR)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    expr = b.make_expression(b.make_function("lpad", [s, b.make_literal(16, pa.int32()), b.make_literal("*", STR)], STR),
+                             pa.field("l", STR))
+    proj = gandiva.make_projector(batch.schema, [expr], pa.default_memory_pool())
+
+    def hint(rows):
+        vb, db = C.c_int64(), C.c_int64()
+        assert lib.gdv_projector_output_sizes(proj._h, 0, rows, 1, C.byref(vb), C.byref(db)) == 0
+        return db.value
+
+    assert hint(batch.num_rows) == 0
+    want = oracle.project([expr], batch)[0]
+    produced = want.buffers()[2].size if want.buffers()[2] is not None else 0
+    for attempt in range(2):      # the second call sizes its buffer by the hint
+        got = proj.evaluate_device(DeviceBatch.from_arrow(batch))[0]
+        assert_bit_exact(got.to_arrow(), want, f"lpad, call {attempt}")
+        h = hint(batch.num_rows)
+        assert 16 * batch.num_rows <= h <= 2 * 16 * batch.num_rows + 4096, h
+        if attempt == 1:
+            assert got.data.numel() >= produced and got.data.numel() < 2 * produced + 8192
+    assert_bit_exact(proj.evaluate(batch)[0], want, "host path, sized by the hint")
