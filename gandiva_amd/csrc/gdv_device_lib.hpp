@@ -1720,6 +1720,92 @@ GDV_DEV gdv_str gdv_replace(gdv_ctx ctx, gdv_str s, const gdv_uint8* desc) {
   s.map |= GDV_MAP_REPLACE;
   return s;
 }
+// ---- replace() answered by the byte sweep (round 3).  Kernels whose replace() takes a whole
+// column row and a 'from' of 2..8 bytes that cannot overlap itself let the sweep mark every
+// match position of the sub-tile's span in the LDS bitmap the '%needle%' predicate uses; a row
+// then COUNTS its matches with a popcount over its own bit range (no search loop: the per-row
+// SWAR search made replace the most instruction-hungry function of the library, ~1000 VALU per
+// 64 rows), and the copy walks the set bits.  Matches cannot overlap, so every marked position
+// is a replacement, left to right.
+#define GDV_MAP_HITS 32  // a GDV_MAP_REPLACE value whose matches are marked in the sweep's bitmap
+// set bits in [lo, hi) of the bitmap (readable one word past any position)
+GDV_DEV gdv_int32 gdv_range_count(const gdv_uint64* bm, gdv_int32 lo, gdv_int32 hi) {
+  gdv_int32 cnt = 0;
+  for (gdv_int32 p = lo; p < hi; p += 64) {
+    const gdv_int32 w = p >> 6, sh = p & 63;
+    gdv_uint64 x = (bm[w] >> sh) | ((bm[w + 1] << 1) << (63 - sh));  // positions p .. p+63
+    const gdv_int32 left = hi - p;
+    if (left < 64) x &= (1ull << left) - 1ull;
+    cnt += (gdv_int32)__builtin_popcountll(x);
+  }
+  return cnt;
+}
+// the first set bit in [p, hi), or -1
+GDV_DEV gdv_int32 gdv_range_next(const gdv_uint64* bm, gdv_int32 p, gdv_int32 hi) {
+  for (; p < hi; p += 64) {
+    const gdv_int32 w = p >> 6, sh = p & 63;
+    gdv_uint64 x = (bm[w] >> sh) | ((bm[w + 1] << 1) << (63 - sh));
+    const gdv_int32 left = hi - p;
+    if (left < 64) x &= (1ull << left) - 1ull;
+    if (x != 0) return p + (gdv_int32)__builtin_ctzll(x);
+  }
+  return -1;
+}
+// gdv_replace with the matches counted in the bitmap: bit `lo` = the row's first byte
+GDV_DEV gdv_str gdv_replace_hits(gdv_ctx ctx, gdv_str s, const gdv_uint8* desc, const gdv_uint64* bm, gdv_int32 lo) {
+  const gdv_int32 fl = ((const gdv_int32*)desc)[0], tl = ((const gdv_int32*)desc)[1];
+  if (s.len <= 0 || fl <= 0) return s;
+  const gdv_int32 hits = gdv_range_count(bm, lo, lo + s.len - fl + 1);
+  if (hits == 0) return s;
+  const gdv_int64 out = (gdv_int64)s.len + (gdv_int64)hits * (tl - fl);
+  if (out > 65535 || s.len >= (1 << 29)) { gdv_raise(ctx, GDV_ERR_BAD_ARG); s.len = 0; return s; }
+  s.flags = (s.flags & 3) | (s.len << 2);
+  s.lim = desc;
+  s.len = (gdv_int32)out;
+  s.map |= GDV_MAP_REPLACE | GDV_MAP_HITS;
+  return s;
+}
+// 8 raw bytes at offset k of a row in HBM (the LDS reader lives with the LDS mirror below)
+struct gdv_rd_hbm {
+  const gdv_uint8* p;
+  __device__ __forceinline__ gdv_uint64 operator()(gdv_int32 k) const { return gdv_load8_raw(p + k); }
+};
+// the copy of such a value: the stretches between the marked positions, `to` at each of them.
+// rd(k) = 8 raw bytes at offset k of the SOURCE row (up to 7 bytes past the row may be read,
+// never used); bit `lo` of the bitmap = the row's first byte.
+template <typename P, typename R>
+GDV_DEV void gdv_copy_replaced_hits(P dst, const gdv_str& s, R rd, const gdv_uint64* bm, gdv_int32 lo) {
+  const gdv_uint8* desc = s.lim;
+  const gdv_int32 fl = ((const gdv_int32*)desc)[0], tl = ((const gdv_int32*)desc)[1];
+  const gdv_uint8* to = desc + 16 + ((fl + 15) & ~15);
+  const gdv_int32 len = s.flags >> 2, cm = s.map & GDV_MAP_CASE;
+  const gdv_int32 hi = lo + len - fl + 1;
+  gdv_int32 o = 0;
+  for (gdv_int32 pos = 0;;) {
+    const gdv_int32 j = gdv_range_next(bm, lo + pos, hi);
+    const gdv_int32 stop = j < 0 ? len : j - lo;
+    gdv_int32 k = pos;
+    for (; k + 8 <= stop; k += 8, o += 8) {
+      const gdv_uint64 w = gdv_map8(rd(k), cm);
+      __builtin_memcpy(dst + o, &w, 8);
+    }
+    if (k < stop) {
+      gdv_store_low_bytes(dst + o, gdv_map8(rd(k), cm), stop - k);
+      o += stop - k;
+    }
+    if (j < 0) break;
+    gdv_int32 t = 0;
+    for (; t + 8 <= tl; t += 8, o += 8) {
+      const gdv_uint64 w = gdv_load8_raw(to + t);
+      __builtin_memcpy(dst + o, &w, 8);
+    }
+    if (t < tl) {
+      gdv_store_low_bytes(dst + o, gdv_load8_raw(to + t), tl - t);
+      o += tl - t;
+    }
+    pos = stop + fl;
+  }
+}
 // lpad / rpad(text, n, fill): the result is two pieces, written back to back by the output copy —
 // the text cut to n characters, and the first n - chars(text) characters of `tab` = fill repeated
 // to n characters (n and fill are literals: the planner lays the table out in the constant
@@ -2064,6 +2150,28 @@ GDV_DEV gdv_uint64 gdv_next_lane(gdv_uint64 v) {
 GDV_DEV gdv_int32 gdv_next_lane_i32(gdv_int32 v, gdv_int32 after, int lane) {
   const gdv_int32 nx = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);
   return lane == 63 ? after : nx;
+}
+
+// ---- staged copies of kernels whose replace() is answered by the sweep: the SOURCE row of a
+// replace() value inside the mirrored span is copied from LDS along the marked positions;
+// everything else as gdv_stage_copy_mir
+struct gdv_rd_lds {
+  const gdv_lds_u8* mir;
+  gdv_int32 d;  // offset of the row's first byte inside the mirror
+  __device__ __forceinline__ gdv_uint64 operator()(gdv_int32 k) const { return gdv_mirror_word(mir, d + k); }
+};
+GDV_DEV void gdv_stage_copy_mirh(gdv_lds_u8* dst, const gdv_str& s, const gdv_lds_u8* mir, const gdv_uint8* mbase,
+                                 gdv_int32 mlen, const gdv_uint64* bm) {
+  if (s.map & GDV_MAP_REPLACE) {
+    const gdv_int64 d64 = s.p - mbase;
+    const gdv_int32 src = s.flags >> 2;
+    if ((s.map & GDV_MAP_HITS) && d64 >= 0 && d64 + src <= (gdv_int64)mlen)
+      gdv_copy_replaced_hits(dst, s, gdv_rd_lds{mir, (gdv_int32)d64}, bm, (gdv_int32)d64);
+    else
+      gdv_copy_special(dst, s);
+    return;
+  }
+  gdv_stage_copy_mir(dst, s, mir, mbase, mlen);
 }
 
 // ------------------------------------------------------------------ small-batch filter: scan + emission in the predicate's own workgroup

@@ -452,7 +452,10 @@ class CodeGen {
   CodegenOptions opts_;
   int compact_from_ = 0x7fffffff;  // schema fields from this index on are compact temporaries (selection mode)
   bool no_hooks_ = false;          // pre-pass kernels have no byte sweep: '%needle%' takes the per-row search
-  int mirror_slot_ = -1;           // wave main kernel: the var-len input whose sub-tile spans are mirrored in LDS
+  int mirror_slot_ = -1;           // wave kernels: the var-len input whose sub-tile spans are swept one at a time
+                                   // (main kernel: and mirrored in LDS)
+  bool replace_hits_ = false;      // wave kernels: replace() over a whole column row may be answered by the sweep
+  int replace_hook_ = -1;          // ... the hook (match bitmap) that does
   std::ostringstream body_;
   std::map<std::string, std::string> cse_;
   int next_tmp_ = 0;
@@ -599,6 +602,33 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         out->vlane = args[0].vlane;
         can_raise_ = true;
         const std::string guard = AndExpr(AndExpr("live", active), LaneValid(*out));
+        // A 'from' that cannot overlap itself (no proper prefix is a suffix), over a whole column
+        // row: the byte sweep marks the match positions of the sub-tile's span (the '%needle%'
+        // machinery); the row counts its own bits, the copy walks them.  One such needle per
+        // kernel; spans too long for the bitmap (wave-uniform) search per row as before.
+        bool self_overlap = false;
+        for (size_t k = 1; k < from.size(); k++) self_overlap |= from.compare(0, from.size() - k, from, k, from.size() - k) == 0;
+        if (replace_hits_ && !selection() && args[0].col_slot >= 0 && from.size() >= 2 && from.size() <= 8 && !self_overlap) {
+          int h = -1;
+          for (size_t i = 0; i < contains_hooks_.size(); i++)
+            if (contains_hooks_[i].slot == args[0].col_slot && contains_hooks_[i].map == args[0].col_map && contains_hooks_[i].needle == from)
+              h = static_cast<int>(i);
+          if (replace_hook_ < 0 || replace_hook_ == h) {
+            const std::string K = std::to_string(args[0].col_slot), table = ByteTable(tab);
+            if (h < 0) {
+              // (the needle's bytes are in the replace table itself, 16 bytes in: no table of its own,
+              // so the scanner-shaped fallback — which has no such hook — lays out the same constants)
+              contains_hooks_.push_back({args[0].col_slot, args[0].col_map, from});
+              hook_tables_.push_back("(" + table + " + 16)");
+              h = static_cast<int>(contains_hooks_.size()) - 1;
+            }
+            replace_hook_ = h;
+            out->v = Tmp("gdv_str", guard + " ? (hm_ok" + K + " ? gdv_replace_hits(ctx, " + args[0].v + ", " + table + ", hit" +
+                                        std::to_string(h) + ", oa" + K + "[u] - sb" + K + ") : gdv_replace(ctx, " + args[0].v + ", " +
+                                        table + ")) : gdv_empty_str()");
+            return Status::OK();
+          }
+        }
         out->v = Tmp("gdv_str", guard + " ? gdv_replace(ctx, " + args[0].v + ", " + ByteTable(tab) + ") : gdv_empty_str()");
         return Status::OK();
       }
@@ -1524,7 +1554,7 @@ struct WaveSweepText {
   std::string per_sub;    // top of the row loop's body (u = the sub-tile)
   std::string epilogue;   // after the row loop
 };
-void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText* out) {
+void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass, WaveSweepText* out) {
   std::ostringstream s, b, e;
   const int nin = plan->layout.n_in;
   const int nhook = static_cast<int>(cg.contains_hooks_.size());
@@ -1538,8 +1568,16 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText
     std::vector<const VarlenOut*> flats;  // outputs that are this column's (mapped) bytes
     for (auto& vo : cg.varlen_outs_)
       if (vo.flat_slot == k) flats.push_back(&vo);
-    const bool mirror = mirror_slot == k;
+    const bool mirror = mirror_slot == k && !prepass;  // (a pre-pass needs the match bits only)
     const std::string K = std::to_string(k);
+    if (prepass && mirror_slot != k) {
+      // a pre-pass sweeps nothing but the column whose replace() counts matches in the bitmap; views
+      // carry the flags the main kernel will give them (the optimistic ASCII flag where consulted)
+      s << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n"
+        << "  const gdv_int32 sfl" << K << " = (sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0)"
+        << (want_ascii ? " | GDV_STR_ASCII" : "") << ";\n";
+      continue;
+    }
     // the tile's span: its ends come from two scalar loads; one wave-uniform range test per tile
     // makes every 8-byte read of these rows unchecked
     s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n"
@@ -1637,7 +1675,7 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, WaveSweepText
     if (!hooks.empty() || mirror) b << "    __builtin_amdgcn_wave_barrier();\n";
 
     // ---- after the loop
-    if (want_ascii)
+    if (want_ascii && !prepass)  // (the main kernel raises it)
       e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
   }
   out->prologue = s.str();
@@ -1976,11 +2014,11 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   const int nv = static_cast<int>(cg.varlen_outs_.size());
   int nstage = 0;
   for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
-  const int nhook = prepass ? 0 : static_cast<int>(cg.contains_hooks_.size());
+  const int nhook = static_cast<int>(cg.contains_hooks_.size());  // (a pre-pass has hooks only for a swept replace())
   plan->num_varlen_outputs = prepass ? 0 : nv;
   for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
   const int nin = plan->layout.n_in;
-  const int mirror_slot = prepass ? -1 : cg.mirror_slot_;  // (decided with the tile shape, PlanProjectorShape)
+  const int mirror_slot = cg.mirror_slot_;  // (decided with the tile shape, PlanProjectorShape)
 
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
@@ -1994,13 +2032,21 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n"
     << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
-  if (mirror_slot >= 0)
+  if (prepass) {
+    // (no staged copies in a pre-pass)
+  } else if (mirror_slot >= 0) {
     // staged copies read the row's bytes from the LDS mirror of the sub-tile's span when the view
-    // lies inside it (any view of that column does; literals, other columns: HBM as before)
-    s << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy_mir(dst, v, mir" << mirror_slot << ", sd" << mirror_slot << " + sb" << mirror_slot
-      << ", hm_ok" << mirror_slot << " ? se" << mirror_slot << " - sb" << mirror_slot << " : 0)\n";
-  else
+    // lies inside it (any view of that column does; literals, other columns: HBM as before); a
+    // replace() value answered by the sweep is copied from there along its marked positions
+    const std::string M = std::to_string(mirror_slot);
+    const std::string where = "mir" + M + ", sd" + M + " + sb" + M + ", hm_ok" + M + " ? se" + M + " - sb" + M + " : 0";
+    if (cg.replace_hook_ >= 0)
+      s << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy_mirh(dst, v, " << where << ", hit" << cg.replace_hook_ << ")\n";
+    else
+      s << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy_mir(dst, v, " << where << ")\n";
+  } else {
     s << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy(dst, v)\n";
+  }
 
   s << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wt, const int lane, const int wave,\n"
     << "                      gdv_uint8* lds_out, gdv_uint64* lds_hit, gdv_uint8* lds_in) {\n"
@@ -2018,7 +2064,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  (void)last_tile; (void)seg_stride;\n";
   EmitStringPointersAndLoads(s, cg, plan, !prepass, /*wave_shape=*/true);
   WaveSweepText sweep;
-  if (prepass) {
+  if (prepass && mirror_slot < 0) {
     // views carry the flags the main kernel will give them — the optimistic ASCII flag where a
     // function consults it — so both kernels compute the same lengths.  Outputs whose length is a
     // function of the offsets (substr, left, concat ...) read no byte here; others (replace, rtrim,
@@ -2031,7 +2077,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
           << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
   } else if (mirror_slot >= 0) {
-    EmitWaveSweep(cg, plan, mirror_slot, &sweep);
+    EmitWaveSweep(cg, plan, mirror_slot, prepass, &sweep);
     s << sweep.prologue;
   } else {
     EmitWaveTileSweep(s, cg, plan, &sweep.epilogue);
@@ -2079,9 +2125,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
   if (prepass)
     // (a pre-pass tile is a few loads and one store: waves walk several tiles, grid-stride)
-    s << "  const gdv_int64 nwt = (GDV_ROWS(A) + 64 * GDV_U - 1) / (64 * GDV_U);\n"
+    s << (mirror_slot >= 0 ? "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n" : "")
+      << "  const gdv_int64 nwt = (GDV_ROWS(A) + 64 * GDV_U - 1) / (64 * GDV_U);\n"
       << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nwt; wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
-      << "    gdv_tile(A, wt, lane, wave, nullptr, nullptr, nullptr);\n";
+      << "    gdv_tile(A, wt, lane, wave, nullptr, " << (mirror_slot >= 0 ? "gdv_lds_hit[wave]" : "nullptr") << ", nullptr);\n";
   else
     s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
       << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
@@ -2158,6 +2205,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
   CodeGen cg(schema, mode, opts);
   cg.compact_from_ = compact_from;
   cg.no_hooks_ = shape == StringShape::kWavePrepass;
+  cg.replace_hits_ = shape != StringShape::kScanner && opts.lds_mirror && mode == SelectionMode::kNone;
   WordAccumulators accs;
   std::ostringstream after_loop, before_loop, in_pass, after_rows;
   std::vector<std::string> strings;
@@ -2386,7 +2434,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         // LDS mirror (and with it the per-sub-tile sweep): the first swept var-len input, when some
         // staged output's copies would read it
         cg.mirror_slot_ = -1;
-        bool readers = false;
+        bool readers = cg.replace_hook_ >= 0;  // (rows of a swept replace() are copied from the mirror)
         for (auto& vo : cg.varlen_outs_) readers |= vo.window >= 0 && vo.reads_views;
         for (size_t k = 0; opts.lds_mirror && readers && k < cg.input_fields_.size() && cg.mirror_slot_ < 0; k++) {
           if (!(schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k])) continue;
@@ -2395,11 +2443,15 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
           for (auto& vo : cg.varlen_outs_) swept |= vo.flat_slot == static_cast<int>(k);
           if (swept) cg.mirror_slot_ = static_cast<int>(k);
         }
+        // (the mirror must hold the column whose matches the bitmap marks)
+        if (opts.lds_mirror && cg.replace_hook_ >= 0) cg.mirror_slot_ = cg.contains_hooks_[cg.replace_hook_].slot;
         const int lds_u8 = windows * (8 * 64 * 8 + 16) +
                            (cg.mirror_slot_ >= 0 ? hooks * (2048 / 64 + 4) * 8 + 2048 + 32 : hooks * ((8 * 64 * 32) / 64 + 4) * 8);
         plan->opts.subtiles = lds_u8 <= 6656 ? 8 : 4;
       }
       // (kWavePrepass: the caller passes the main kernel's tile)
+      if (shape == StringShape::kWavePrepass)  // a pre-pass sweeps only for a replace() that counts its matches in the bitmap
+        cg.mirror_slot_ = cg.replace_hook_ >= 0 ? cg.contains_hooks_[cg.replace_hook_].slot : -1;
     }
     if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
     if (varlen_outs != nullptr) *varlen_outs = cg.varlen_outs_;

@@ -252,6 +252,48 @@ unsigned host_str_replace(const int* off, const unsigned char* data, long size, 
   }
   return err;
 }
+// replace answered by the byte sweep (round 3): the match bitmap of the whole column is built the way
+// the generated kernels build it — 16-byte pieces, two gdv_match8 per piece, the next piece's first
+// word as halo — then every row counts its bits (gdv_replace_hits) and is copied along them
+// (gdv_copy_replaced_hits).  The data buffer must be readable 16 bytes past `size`.
+unsigned host_str_replace_hits(const int* off, const unsigned char* data, long size, long n, int map,
+                               const unsigned char* table, int* out_off, unsigned char* out_data) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  const gdv_int32 fl = ((const gdv_int32*)table)[0];
+  const gdv_uint64 mask = gdv_low_bytes_mask(fl);
+  const gdv_uint64 nd = gdv_load8_raw(table + 16) & mask;
+  const gdv_uint32 s0 = (gdv_uint32)(nd & 0xffull) * 0x01010101u, s1 = (gdv_uint32)((nd >> 8) & 0xffull) * 0x01010101u;
+  const long pieces = (size + 15) / 16;
+  gdv_uint64* bm = new gdv_uint64[pieces / 4 + 4]();
+  for (long q = 0; q < pieces; q++) {
+    const long a = q * 16;
+    gdv_uint64 w[2] = {0, 0}, nxw = 0;
+    std::memcpy(w, data + a, 16);                     // (readable: 16 bytes of padding behind the column)
+    if (a + 16 < size) std::memcpy(&nxw, data + a + 16, 8);
+    const gdv_uint64 lo = gdv_map8(w[0], map), hi = gdv_map8(w[1], map), nx = gdv_map8(nxw, map);
+    const gdv_uint32 m = gdv_match8(lo, hi, nd, mask, s0, s1) | (gdv_match8(hi, nx, nd, mask, s0, s1) << 8);
+    ((gdv_uint16*)bm)[q] = (gdv_uint16)m;
+  }
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    s.flags |= GDV_STR_INBUF;
+    if (map == 1) s = upper_utf8(s);
+    if (map == 2) s = lower_utf8(s);
+    const gdv_str r = gdv_replace_hits(ctx, s, table, bm, off[i]);
+    if (r.len > 0) {
+      if (r.map & GDV_MAP_HITS) gdv_copy_replaced_hits(out_data + at, r, gdv_rd_hbm{r.p}, bm, off[i]);
+      else gdv_str_copy(out_data + at, r);
+    }
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  delete[] bm;
+  return err;
+}
 // locate(needle, s, start) with the needle read through a view, rows through `map`
 unsigned host_str_locate(const int* off, const unsigned char* data, long size, long n, const unsigned char* lit,
                          int litlen, int start, int map, int* out) {

@@ -286,6 +286,24 @@ def test_device_reverse_pad_and_integer_text_on_host(hostlib, seed):
                 err = hostlib.host_str_replace(_p(off), _p(buf), C.c_long(size), C.c_long(n), mp, _p(tbuf), _p(out_off),
                                                _p(out_data), inbuf)
                 assert err == 0 and strings(out_off, out_data) == want_of(node), (frm, to, mp, inbuf)
+    # round 3: a 'from' of 2..8 bytes that cannot overlap itself is answered by the byte sweep's match
+    # bitmap — rows count their bits, the copy walks them (gdv_replace_hits / gdv_copy_replaced_hits)
+    def overlaps_itself(t):
+        return any(t[:len(t) - k] == t[k:] for k in range(1, len(t)))
+    for frm, to in REPLACE_CASES + [("ab", "X"), ("k ", "_"), ("é日", "!!"), ("rk s", ""), ("ks", "a much longer replacement text"),
+                                    ("sp", "sp"), ("ark", "é"), ("SPARK", "flink"), ("AR", "x")]:
+        fb, tb = frm.encode(), to.encode()
+        if not (2 <= len(fb) <= 8) or overlaps_itself(fb):
+            continue
+        table = (np.array([len(fb), len(tb), 0, 0], np.int32).tobytes() + fb + b"\0" * ((16 - len(fb) % 16) % 16) + tb + b"\0" * 8)
+        tbuf = np.frombuffer(table, np.uint8).copy()
+        padded = np.concatenate([data[:size], np.frombuffer((fb * 16)[:32], np.uint8)])   # the needle itself behind the buffer
+        for mp, wrap in ((0, lambda v: v), (1, lambda v: b.make_function("upper", [v], STR))):
+            node = b.make_function("replace", [wrap(s), b.make_literal(frm, STR), b.make_literal(to, STR)], STR)
+            out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(40 * size + 64 * n + 64, np.uint8)
+            err = hostlib.host_str_replace_hits(_p(off), _p(padded), C.c_long(size), C.c_long(n), mp, _p(tbuf), _p(out_off),
+                                                _p(out_data))
+            assert err == 0 and strings(out_off, out_data) == want_of(node), (frm, to, mp, "hits")
     xv = np.array(batch.column(1).to_pylist(), dtype=np.int64)
     for k in (0, 1, 5, 19, 20, 25):
         out_off, out_data = np.zeros(n + 1, np.int32), np.zeros(24 * n + 64, np.uint8)
@@ -631,3 +649,41 @@ def test_gpu_varlen_capacity_hint_is_learnt_from_the_first_batch():
         if attempt == 1:
             assert got.data.numel() >= produced and got.data.numel() < 2 * produced + 8192
     assert_bit_exact(proj.evaluate(batch)[0], want, "host path, sized by the hint")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_gpu_replace_answered_by_the_sweep_across_tile_shapes(seed):
+    """replace() with a 'from' of 2..8 bytes that cannot overlap itself is counted and copied from the
+    byte sweep's match bitmap (round 3).  Batches that mix sub-tiles whose span fits the LDS bitmap
+    (short rows) with sub-tiles whose span does not (long rows: per-row search), matches at the very
+    start / end of rows, across 16-byte pieces, 1024-byte steps and sub-tile boundaries, nulls, empty
+    rows, replacements longer and shorter than the needle — against the oracle."""
+    from gandiva_amd import DeviceBatch
+    rng = np.random.default_rng(4100 + seed)
+    words = ["spark", "ar", "k", " ", "é", "日", "sparkspark", "spar", "park", "x" * 37, "-" * 300, "ab" * 90, ""]
+    rows = []
+    for blk in range(40):
+        long_rows = blk % 3 == 2               # 64 rows x ~200 bytes: the sub-tile's span exceeds the bitmap
+        for _ in range(64 if blk % 5 else 61):  # (ragged blocks: rows drift against the 64-row sub-tiles)
+            k = int(rng.integers(0, 40 if long_rows else 6))
+            pick = words if long_rows or rng.random() < 0.02 else words[:9]   # short blocks: ~10 bytes per row
+            rows.append(None if rng.random() < 0.07 else "".join(rng.choice(pick, size=k)))
+    batch = pa.RecordBatch.from_arrays([pa.array(rows, STR)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    lit = lambda v: b.make_literal(v, STR)
+    exprs = [b.make_expression(b.make_function("replace", [s, lit(f), lit(t)], STR), pa.field(f"r{i}", STR))
+             for i, (f, t) in enumerate([("spark", "flink"), ("ar", "ARRR"), ("é", ""), ("k ", "<a much longer replacement>"),
+                                         ("ab", "b")])]
+    exprs.append(b.make_expression(b.make_function("replace", [b.make_function("upper", [s], STR), lit("SPARK"), lit("x")], STR),
+                                   pa.field("ru", STR)))
+    for e in exprs:      # one kernel each (one swept needle per kernel), then two in one kernel (the second searches per row)
+        proj = gandiva.make_projector(batch.schema, [e], pa.default_memory_pool())
+        want = oracle.project([e], batch)[0]
+        assert_bit_exact(proj.evaluate_device(DeviceBatch.from_arrow(batch))[0].to_arrow(), want, str(e))
+        assert_bit_exact(proj.evaluate(batch)[0], want, "host path " + str(e))
+    both = [exprs[0], exprs[1]]
+    proj = gandiva.make_projector(batch.schema, both, pa.default_memory_pool())
+    for g, w in zip(proj.evaluate(batch), oracle.project(both, batch)):
+        assert_bit_exact(g, w, "two replace() in one kernel")
