@@ -147,3 +147,35 @@ def test_registry_aliases_share_their_kernels(monkeypatch, tmp_path):
         e2 = b.make_expression(b.make_function(alias, args, t), pa.field("r", t))
         assert _precompile(monkeypatch, d1, sch, [e1]) == _precompile(monkeypatch, d2, sch, [e2]), (name, alias)
         assert oracle.project([e1], batch)[0].equals(oracle.project([e2], batch)[0])
+
+
+def test_replace_is_answered_by_the_sweep_only_where_matches_cannot_overlap(monkeypatch, tmp_path):
+    """replace(col, from, to): a 'from' of 2..8 bytes that cannot overlap itself is counted in the byte
+    sweep's match bitmap in BOTH wave-shaped kernels (pre-pass and main) and copied along it; a needle
+    with a border ('aa'), of one byte or of more than eight keeps the per-row search.  Either way the
+    plan stays wave-shaped: the scanner-shaped fallback lays out the same constant block (the hook reads
+    the needle out of the replace table, it has no table of its own)."""
+    b = gandiva.TreeExprBuilder()
+    sch = pa.schema([pa.field("s", pa.string())])
+    s = b.make_field(sch.field(0))
+
+    def kernels(frm, sub):
+        d = tmp_path / sub
+        d.mkdir()
+        e = b.make_expression(b.make_function("replace", [s, b.make_literal(frm, pa.string()), b.make_literal("flink", pa.string())],
+                                              pa.string()), pa.field("r", pa.string()))
+        files = _precompile(monkeypatch, d, sch, exprs=[e])
+        texts = [open(d / f).read() for f in files]
+        assert len(texts) == 3, files                                   # pre-pass + main + scanner-shaped fallback
+        return ([t for t in texts if "// pre-pass:" in t][0], [t for t in texts if "// wave shape:" in t][0],
+                [t for t in texts if "// pre-pass:" not in t and "// wave shape:" not in t][0])
+
+    pre, main, general = kernels("spark", "a")
+    for t in (pre, main):
+        assert "gdv_replace_hits(" in t and "gdv_match8(" in t and "GDV_SUB_SPAN" in t
+    assert "gdv_stage_copy_mirh(" in main and "gdv_lds_in" in main and "gdv_lds_in" not in pre
+    assert "gdv_replace_hits(" not in general and "gdv_replace(" in general
+    for k, frm in enumerate(["aa", "abab", "x", "a much longer needle"]):
+        pre, main, general = kernels(frm, f"b{k}")
+        for t in (pre, main, general):
+            assert "gdv_replace_hits(" not in t and "gdv_replace(" in t, frm
