@@ -2080,13 +2080,9 @@ GDV_DEV gdv_uint32 gdv_match8(gdv_uint64 cur, gdv_uint64 nxt, gdv_uint64 first, 
 // pieces that lie entirely inside this wave's span [sp0, sp1) are stored here; the two ragged ends
 // are written once per tile by gdv_sweep_edges as whole 16-byte pieces that OVERLAP their
 // neighbours inside the span with identical bytes (a byte-wise edge loop cost 20 VGPRs: 72 -> 52
-// on C5, i.e. 6 -> 8 waves per SIMD).  Nothing is stored at or past `cap`.
-GDV_DEV void gdv_sweep_store(gdv_uint8* __restrict__ dst, gdv_int64 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
-                             bool inside, gdv_int64 cap) {
-  if (inside && doff + 16 <= cap) gdv_store16(dst + doff, gdv_map8(w[0], map), gdv_map8(w[1], map));
-}
-// the same with the output position and the capacity as 32-bit values (a flat output is below
-// 2 GiB: its offsets are int32) — a scalar base + 32-bit lane offset instead of 64-bit lane arithmetic
+// on C5, i.e. 6 -> 8 waves per SIMD).  Nothing is stored at or past the capacity.  The output
+// position and the capacity are 32-bit values (a flat output is below 2 GiB: its offsets are
+// int32): a scalar base + 32-bit lane offset instead of 64-bit lane arithmetic.
 GDV_DEV void gdv_sweep_store32(gdv_uint8* __restrict__ dst, gdv_int32 doff, const gdv_uint64 (&w)[2], gdv_int32 map,
                                bool inside, gdv_int32 cap31) {
   if (inside && doff <= cap31 - 16) gdv_store16(dst + (gdv_uint32)doff, gdv_map8(w[0], map), gdv_map8(w[1], map));
