@@ -320,6 +320,70 @@ unsigned host_cast_varchar_int64(const long long* v, long n, long long len, int*
   }
   return err;
 }
+// ---------------------------------------------------------------- numeric / date / hash scalars (round 3)
+// op: 0 round_float64 (-> double), 1 truncate_float64 (-> double), 2 castBIGINT_float64 (-> int64),
+//     3 castINT_float64 (-> int32 widened to int64)
+void host_f64_op(int op, const double* x, long n, double* outd, long long* outi) {
+  for (long i = 0; i < n; i++) {
+    switch (op) {
+      case 0: outd[i] = round_float64(x[i]); break;
+      case 1: outd[i] = truncate_float64(x[i]); break;
+      case 2: outi[i] = castBIGINT_float64(x[i]); break;
+      default: outi[i] = castINT_float64(x[i]); break;
+    }
+  }
+}
+// op: 0 Year 1 Month 2 Day 3 Hour 4 Minute 5 Second 6 Doy 7 Dow 8 Quarter 9 Epoch 10 Decade 11 Century 12 Millennium
+void host_extract_timestamp(int op, const long long* t, long n, long long* out) {
+  for (long i = 0; i < n; i++) {
+    switch (op) {
+      case 0: out[i] = extractYear_timestamp(t[i]); break;
+      case 1: out[i] = extractMonth_timestamp(t[i]); break;
+      case 2: out[i] = extractDay_timestamp(t[i]); break;
+      case 3: out[i] = extractHour_timestamp(t[i]); break;
+      case 4: out[i] = extractMinute_timestamp(t[i]); break;
+      case 5: out[i] = extractSecond_timestamp(t[i]); break;
+      case 6: out[i] = extractDoy_timestamp(t[i]); break;
+      case 7: out[i] = extractDow_timestamp(t[i]); break;
+      case 8: out[i] = extractQuarter_timestamp(t[i]); break;
+      case 9: out[i] = extractEpoch_timestamp(t[i]); break;
+      case 10: out[i] = extractDecade_timestamp(t[i]); break;
+      case 11: out[i] = extractCentury_timestamp(t[i]); break;
+      default: out[i] = extractMillennium_timestamp(t[i]); break;
+    }
+  }
+}
+// hash32 / hash64 of int64, float64 and utf8 values (valid rows; seed 0)
+void host_hash_fixed(int is_f64, const void* v, long n, int* h32, long long* h64) {
+  for (long i = 0; i < n; i++) {
+    if (is_f64) {
+      h32[i] = hash32_float64(((const double*)v)[i], true);
+      h64[i] = hash64_float64(((const double*)v)[i], true);
+    } else {
+      h32[i] = hash32_int64(((const long long*)v)[i], true);
+      h64[i] = hash64_int64(((const long long*)v)[i], true);
+    }
+  }
+}
+void host_hash_utf8(const int* off, const unsigned char* data, long size, long n, int* h32, long long* h64) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) {
+    const gdv_str s = host_row(c, i);
+    h32[i] = hash32_utf8(s, true);
+    h64[i] = hash64_utf8(s, true);
+  }
+}
+// castBIGINT / castINT of text (blanks trimmed, decimal or 0x.. hexadecimal); bad[i] != 0: the row raised
+void host_parse_int(int wide, const int* off, const unsigned char* data, long size, long n, long long* out, unsigned char* bad) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) {
+    unsigned err = 0;
+    gdv_ctx ctx{&err};
+    const gdv_str s = host_row(c, i);
+    out[i] = wide ? castBIGINT_utf8(ctx, s) : (long long)castINT_utf8(ctx, s);
+    bad[i] = err != 0;
+  }
+}
 void host_months_between(const long long* s, const long long* e, long n, int unit, int* out) {
   for (long i = 0; i < n; i++)
     out[i] = unit == 0 ? timestampdiffMonth_timestamp_timestamp(s[i], e[i])

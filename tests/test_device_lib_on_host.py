@@ -313,3 +313,109 @@ def test_device_decimal_functions_reproduce_the_c4_golden_fixture(hostlib):
     for raw, want in ((disc_price, outs[0]), (charge, outs[1])):
         valid = [v is not None for v in want.to_pylist()]
         assert _from_raw128(raw, want.type, valid) == want.to_pylist()
+
+
+# ---------------------------------------------------------------- numeric / date / hash scalars (round 3)
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _project_one(name, args_arrays, args_types, out_type, lits=()):
+    """The oracle's answer for fn(col0, col1, ..., *lits) over the given arrays."""
+    import gandiva_amd as gandiva
+    from oracle import oracle
+    fields = [pa.field(f"c{i}", t) for i, t in enumerate(args_types)]
+    batch = pa.RecordBatch.from_arrays(args_arrays, schema=pa.schema(fields))
+    b = gandiva.TreeExprBuilder()
+    node = b.make_function(name, [b.make_field(f) for f in fields] + [b.make_literal(v, t) for v, t in lits], out_type)
+    return oracle.project_one(node, out_type, batch)
+
+
+EDGE_F64 = [0.0, -0.0, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 0.49999999999999994, -0.49999999999999994, 4503599627370495.5,
+            4503599627370497.0, -4503599627370497.0, 9007199254740993.0, 1e18, -1e18, 9.3e18, -9.3e18, 1e300, -1e300,
+            2147483647.5, -2147483648.5, 2147483646.5, float("inf"), float("-inf"), float("nan"), 5e-324, 123456.5, -7.5]
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_device_round_and_float_casts_on_host(hostlib, seed):
+    """round() and the float -> integer casts follow trunc(x +- 0.5) with saturation (round 3): the
+    device functions on the CPU against the oracle, dense random values plus the edges of the rule."""
+    rng = np.random.default_rng(5100 + seed)
+    x = np.concatenate([np.array(EDGE_F64), rng.normal(0, 1e3, 2000), rng.uniform(-3, 3, 2000).round(1),
+                        (rng.integers(-10**6, 10**6, 2000) + 0.5), rng.uniform(-1e19, 1e19, 500)]).astype(np.float64)
+    n = len(x)
+    arr = pa.array(x, pa.float64())
+    outd, outi = np.zeros(n, np.float64), np.zeros(n, np.int64)
+    for op, name, t in ((0, "round", pa.float64()), (1, "truncate", pa.float64()), (2, "castBIGINT", pa.int64()),
+                        (3, "castINT", pa.int32())):
+        hostlib.host_f64_op(op, _p(x), C.c_long(n), _p(outd), _p(outi))
+        want = _project_one(name, [arr], [pa.float64()], t)
+        if op < 2:
+            got = pa.array(outd, pa.float64())
+            w, g = np.array(want.to_pylist(), np.float64), np.array(got.to_pylist(), np.float64)
+            assert np.array_equal(w.view(np.uint64)[~np.isnan(w)], g.view(np.uint64)[~np.isnan(w)]) and \
+                np.array_equal(np.isnan(w), np.isnan(g)), name
+        else:
+            finite = np.isfinite(x)          # (NaN / inf -> integer: not defined by the rule; not compared)
+            assert np.array(want.to_pylist(), np.int64)[finite].tolist() == outi[finite].tolist(), name
+
+
+def test_device_timestamp_extraction_on_host(hostlib):
+    rng = np.random.default_rng(77)
+    ts = np.concatenate([np.array([0, -1, 1, 86399999, 86400000, -86400000, -86400001, 951782400000, 951868800000,
+                                   -62135596800000, 253402300799999, 4102444800000, -2208988800000]),
+                         rng.integers(-62135596800000, 253402300799999, 5000)]).astype(np.int64)
+    n = len(ts)
+    arr = pa.array(ts, pa.timestamp("ms"))
+    out = np.zeros(n, np.int64)
+    for op, name in enumerate(["extractYear", "extractMonth", "extractDay", "extractHour", "extractMinute", "extractSecond",
+                               "extractDoy", "extractDow", "extractQuarter", "extractEpoch", "extractDecade", "extractCentury",
+                               "extractMillennium"]):
+        hostlib.host_extract_timestamp(op, _p(ts), C.c_long(n), _p(out))
+        want = _project_one(name, [arr], [pa.timestamp("ms")], pa.int64())
+        assert want.to_pylist() == out.tolist(), name
+
+
+def test_device_hashes_on_host(hostlib):
+    rng = np.random.default_rng(78)
+    n = 3000
+    iv = np.concatenate([np.array([0, 1, -1, 2**63 - 1, -2**63]), rng.integers(-2**62, 2**62, n - 5)]).astype(np.int64)
+    fv = np.concatenate([np.array([0.0, -0.0, 1.0, float("inf"), 1e-300]), rng.normal(0, 1e6, n - 5)]).astype(np.float64)
+    h32, h64 = np.zeros(n, np.int32), np.zeros(n, np.int64)
+    for is_f, vals, t in ((0, iv, pa.int64()), (1, fv, pa.float64())):
+        hostlib.host_hash_fixed(is_f, _p(vals), C.c_long(n), _p(h32), _p(h64))
+        arr = pa.array(vals, t)
+        assert _project_one("hash32", [arr], [t], pa.int32()).to_pylist() == h32.tolist()
+        assert _project_one("hash64", [arr], [t], pa.int64()).to_pylist() == h64.tolist()
+    words = ["".join(rng.choice(list("abcdefgh é日0123456789"), size=int(k))) for k in rng.integers(0, 70, n)]
+    sarr = pa.array(words, pa.string())
+    off = np.frombuffer(sarr.buffers()[1], np.int32)[: n + 1].copy()
+    raw = sarr.buffers()[2]
+    size = int(off[-1])
+    data = np.concatenate([np.frombuffer(raw, np.uint8)[:size], np.zeros(16, np.uint8)])
+    hostlib.host_hash_utf8(_p(off), _p(data), C.c_long(size), C.c_long(n), _p(h32), _p(h64))
+    assert _project_one("hash32", [sarr], [pa.string()], pa.int32()).to_pylist() == h32.tolist()
+    assert _project_one("hash64", [sarr], [pa.string()], pa.int64()).to_pylist() == h64.tolist()
+
+
+def test_device_text_to_integer_casts_on_host(hostlib):
+    """castBIGINT / castINT(text): blanks trimmed, then arrow::internal::ParseValue's rules incl.
+    hexadecimal (round 3) — device functions on the CPU against the oracle, and rejected texts raise."""
+    good64 = ["0", "-0", "  42 ", "9223372036854775807", "-9223372036854775808", "0x10", "0XfF", "0x7fffffffffffffff",
+              "0xffffffffffffffff", "000123", "-000", " 0x0 ", "1", "-1"]
+    good32 = ["0", "2147483647", "-2147483648", "0x7fffffff", "0xffffffff", "  -12  ", "0X1a"]
+    bad = ["", " ", "abc", "+7", "+0", "1.5", "9223372036854775808", "-9223372036854775809", "0x", "0x1g", "1 2", "--1", "0x10000000000000000",
+           "١٢", "1e3"]
+    for wide, good, t, name in ((1, good64, pa.int64(), "castBIGINT"), (0, good32, pa.int32(), "castINT")):
+        texts = good + (bad if wide else bad + ["2147483648", "-2147483649", "0x100000000"])
+        n = len(texts)
+        sarr = pa.array(texts, pa.string())
+        off = np.frombuffer(sarr.buffers()[1], np.int32)[: n + 1].copy()
+        size = int(off[-1])
+        data = np.concatenate([np.frombuffer(sarr.buffers()[2], np.uint8)[:size], np.zeros(16, np.uint8)])
+        out, flag = np.zeros(n, np.int64), np.zeros(n, np.uint8)
+        hostlib.host_parse_int(wide, _p(off), _p(data), C.c_long(size), C.c_long(n), _p(out), _p(flag))
+        assert flag[: len(good)].tolist() == [0] * len(good), [g for g, f in zip(good, flag) if f]
+        assert flag[len(good):].tolist() == [1] * (n - len(good)), [b_ for b_, f in zip(texts[len(good):], flag[len(good):]) if not f]
+        want = _project_one(name, [pa.array(good, pa.string())], [pa.string()], t).to_pylist()
+        assert want == out[: len(good)].tolist(), name
