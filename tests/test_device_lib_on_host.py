@@ -398,7 +398,7 @@ def test_device_hashes_on_host(hostlib):
     assert _project_one("hash64", [sarr], [pa.string()], pa.int64()).to_pylist() == h64.tolist()
 
 
-def test_device_text_to_integer_casts_on_host(hostlib):
+def test_device_text_to_integer_casts_raise_and_hexadecimal_on_host(hostlib):
     """castBIGINT / castINT(text): blanks trimmed, then arrow::internal::ParseValue's rules incl.
     hexadecimal (round 3) — device functions on the CPU against the oracle, and rejected texts raise."""
     good64 = ["0", "-0", "  42 ", "9223372036854775807", "-9223372036854775808", "0x10", "0XfF", "0x7fffffffffffffff",
