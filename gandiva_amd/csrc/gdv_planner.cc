@@ -21,26 +21,51 @@ CodegenOptions CodegenOptions::FromEnv() {
     int u = std::max(1, std::min(16, atoi(s)));
     while (u & (u - 1)) u &= u - 1;
     o.subtiles = u;
+    o.subtiles_forced = true;
   }
-  if (const char* s = std::getenv("GDV_WAVES")) o.waves = std::max(1, std::min(16, atoi(s)));
+  if (const char* s = std::getenv("GDV_WAVES")) {
+    o.waves = std::max(1, std::min(16, atoi(s)));
+    o.waves_forced = true;
+  }
   if (const char* s = std::getenv("GDV_NT")) o.nontemporal = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_NTLOAD")) o.nt_loads = atoi(s) != 0;
-  if (const char* s = std::getenv("GDV_SCALAR_BITMAPS")) o.scalar_bitmaps = atoi(s) != 0;
-  if (const char* s = std::getenv("GDV_LOAD_FENCE")) o.load_fence = atoi(s) != 0;
-  if (const char* s = std::getenv("GDV_BITMAPS_LAST")) o.bitmaps_last = atoi(s) != 0;
-  if (const char* s = std::getenv("GDV_WPE")) o.waves_per_eu = std::max(0, std::min(8, atoi(s)));
   if (const char* s = std::getenv("GDV_NO_LDS_MIRROR")) o.lds_mirror = atoi(s) == 0;
+  o.no_inline_string_args = std::getenv("GDV_NO_INLINE_STRING_ARGS") != nullptr;
+  o.no_wave_shape = std::getenv("GDV_NO_WAVE_SHAPE") != nullptr;
+  o.wave_bytefree_only = std::getenv("GDV_WAVE_BYTEFREE_ONLY") != nullptr;
+  o.ablation = std::getenv("GDV_ABLATION") != nullptr;
   return o;
 }
 
 std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
-         (nt_loads ? "ntl" : "") + (scalar_bitmaps ? "sb" : "") + (load_fence ? "lf" : "") + (bitmaps_last ? "bl" : "") + (lds_mirror ? "" : "nm") + "e" + std::to_string(waves_per_eu);
+         (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
+         (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
+         (ablation ? "abl" : "");
 }
 
 // ------------------------------------------------------------------ validation
 
 namespace {
+
+// Ablation branches (GDV_ABL masks, set through GDV_RTC_OPT=-DGDV_ABL=<mask>) are experiment
+// scaffolding: they are emitted only into kernels planned with GDV_ABLATION=1 in the environment of
+// Make.  A product kernel's text does not contain them (round-3 verdict: 27 sites in every kernel).
+thread_local bool tl_ablation = false;
+struct AblationScope {
+  bool prev;
+  explicit AblationScope(bool on) : prev(tl_ablation) { tl_ablation = on; }
+  ~AblationScope() { tl_ablation = prev; }
+};
+std::string AblNot(int bit) { return tl_ablation ? "!(GDV_ABL & " + std::to_string(bit) + ") && " : ""; }
+std::string AblAnd(int bit) { return tl_ablation ? " && !(GDV_ABL & " + std::to_string(bit) + ")" : ""; }
+std::string AblIf(int bit) { return tl_ablation ? "if (!(GDV_ABL & " + std::to_string(bit) + ")) " : ""; }
+std::string AblSel(int bit, const std::string& on, const std::string& off) {
+  return tl_ablation ? "((GDV_ABL & " + std::to_string(bit) + ") ? " + on + " : " + off + ")" : off;
+}
+std::string AblDefine() {
+  return tl_ablation ? "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n" : "";
+}
 
 Status ValidateNode(const Schema& schema, const Node& node);
 
@@ -540,7 +565,7 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       for (size_t i = 0; i < args.size(); i++) {
         const Node& child = *fn.children()[i];
         if (over_strings && child.kind() == NodeKind::kLiteral && !child.return_type().is_varlen() &&
-            std::getenv("GDV_NO_INLINE_STRING_ARGS") == nullptr) {
+            !opts_.no_inline_string_args) {
           auto& l = static_cast<const LiteralNode&>(child);
           args[i].type = l.return_type();
           args[i].v = InlineLiteral(l.return_type(), l.value());
@@ -738,9 +763,10 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
             // long for the bitmap (wave-uniform) take the per-row search.
             const int h = HookFor(args[0].col_slot, args[0].col_map, lit);
             const std::string k = std::to_string(args[0].col_slot);
-            out->v = Tmp("bool", "((GDV_ABL & 2) ? (ob" + k + "[u] - oa" + k + "[u] > 19) : hm_ok" + k + " ? gdv_range_any(hit" + std::to_string(h) + ", oa" + k +
-                                     "[u] - sb" + k + ", ob" + k + "[u] - sb" + k + " - " +
-                                     std::to_string(lit.size() - 1) + ") : " + per_row + ")");
+            out->v = Tmp("bool", AblSel(2, "(ob" + k + "[u] - oa" + k + "[u] > 19)",
+                                            "(hm_ok" + k + " ? gdv_range_any(hit" + std::to_string(h) + ", oa" + k + "[u] - sb" + k +
+                                                ", ob" + k + "[u] - sb" + k + " - " + std::to_string(lit.size() - 1) + ") : " +
+                                                per_row + ")"));
             return Status::OK();
           }
           out->v = Tmp("bool", per_row);
@@ -1045,7 +1071,7 @@ struct WordAccumulators {
 };
 
 std::string WordStore(const std::string& acc, const std::string& dst, bool nontemporal = false) {
-  return std::string("  if (!(GDV_ABL & 2) && lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) ") +
+  return std::string("  if (") + AblNot(2) + std::string("lane < GDV_U && (FULL || wbase + lane < ((n + 63) >> 6))) ") +
          (nontemporal ? "GDV_WORD_ST_NT(" : "GDV_WORD_ST(") + dst +
          " + wbase + lane, " + acc + ");\n";
 }
@@ -1063,35 +1089,11 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
   const int nin = plan->layout.n_in;
   const std::string body = cg.body_.str();
 
-  // WIDE layout (round 2): a lane owns 4 CONSECUTIVE rows of a 256-row group instead of one
-  // row of each 64-row sub-tile, so every column moves with 16-byte-per-lane instructions
-  // whatever its width (int32: one dwordx4 per 4 rows instead of four dword loads of 256 B per
-  // wave).  Element u of a lane is row  rbase + (u / 4) * 256 + 4 * lane + (u % 4).  Validity
-  // stays word-wise (word u = rows 64u .. 64u+63), which is independent of the lane mapping —
-  // so the layout applies to plans whose validity is a pure intersection of input words and
-  // whose values never look at a lane's validity bit: no bool columns, no if/else or 3-valued
-  // logic, nothing that can raise.  Those keep the one-row-per-lane layout.
-  // MEASURED (profiles/r02_wide_layout.txt): no gain for int32 (C1-shape 0.73 either way) and a
-  // large loss for 8- and 16-byte types, whose per-lane runs of 32 / 64 bytes make every wave
-  // instruction touch only half / a quarter of each line.  Off by default; GDV_WIDE=1 enables it
-  // for plans whose columns are all <= 4 bytes wide.
-  bool wide = !sel && plan->kind == KernelKind::kProject && !cg.can_raise_ && plan->opts.subtiles % 4 == 0 &&
-              std::getenv("GDV_WIDE") != nullptr && body.find("gdv_lane_bit") == std::string::npos &&
-              body.find("__ballot") == std::string::npos;
-  for (int k = 0; k < nin; k++) {
-    const DataType& t = cg.schema_[plan->input_fields[k]].type;
-    wide = wide && t.id != kBool && t.byte_width() <= 4;
-  }
-  for (auto& t : plan->output_types) wide = wide && t.id != kBool && t.byte_width() <= 4;
-
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
   std::ostringstream& s = as.src;
-  s << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n";
-  if (wide)
-    s << "#define GDV_OUT(e, v) res##e[u] = (v)\n";
-  else
-    s << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
+  s << AblDefine();
+  s << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
 
   s << "template <bool FULL>\n"
     << "GDV_DEV void gdv_tile(const gdv_args& A, const gdv_int64 wbase, const int lane) {\n"
@@ -1111,7 +1113,6 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     const DataType& t = plan->output_types[e];
     if (t.id != kBool)
       s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
-    if (wide) s << "  " << t.CType() << " res" << e << "[GDV_U];\n";
   }
   if (sel)
     s << "  const " << SelCType(cg.sel_mode_) << "* __restrict__ selv = (const " << SelCType(cg.sel_mode_)
@@ -1126,35 +1127,23 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     if (t.id == kBool) {
       if (cg.needs_values_[k]) {
         if (sel) s << "  bool x" << k << "[GDV_U];\n";
-        else if (!plan->opts.scalar_bitmaps) bitmap_loads << "  const gdv_uint64 dw" << k << " = (GDV_ABL & 1) ? ~0ull : gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+        else bitmap_loads << "  const gdv_uint64 dw" << k << " = " << AblSel(1, "~0ull", "gdv_bitmap_tile(A.in[" + std::to_string(k) + "].bits, wbase, lane, GDV_U)") << ";\n";
       }
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
     if (cg.needs_validity_[k]) {
       if (sel) s << "  bool b" << k << "[GDV_U];\n";
-      else if (!plan->opts.scalar_bitmaps) bitmap_loads << "  const gdv_uint64 vw" << k << " = (GDV_ABL & 1) ? ~0ull : gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+      else bitmap_loads << "  const gdv_uint64 vw" << k << " = " << AblSel(1, "~0ull", "gdv_bitmap_tile(A.in[" + std::to_string(k) + "].valid, wbase, lane, GDV_U)") << ";\n";
     }
   }
   // Bitmap words BEHIND the value loads (round 2): issued first, the compiler consumed them first
   // and waited for them before most value loads were even issued (7 of 32 in the C3 predicate
   // kernel); a hand-written copy of that kernel with every load in flight ran 0.45 ms faster
   // (tools/hbm_ceiling.hip, profiles/r02_k1_k2_experiments.txt).
-  if (!plan->opts.bitmaps_last) s << bitmap_loads.str();
+  s << bitmap_loads.str();
   const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
-  if (wide) {
-    s << "  if (FULL) {\n#pragma unroll\n    for (int g = 0; g < GDV_U / 4; g++) {\n"
-      << "      const gdv_int64 row0 = rbase + g * 256 + 4 * lane;\n";
-    for (int k = 0; k < nin; k++)
-      if (cg.needs_values_[k]) s << "      gdv_ld4<" << (plan->opts.nt_loads ? "true" : "false") << ">(in" << k << " + row0, &c" << k << "[4 * g]);\n";
-    s << "    }\n  } else {\n#pragma unroll\n    for (int u = 0; u < GDV_U; u++) {\n"
-      << "      const gdv_int64 row = rbase + (u >> 2) * 256 + 4 * lane + (u & 3);\n";
-    for (int k = 0; k < nin; k++) {
-      const DataType& t = cg.schema_[plan->input_fields[k]].type;
-      if (cg.needs_values_[k]) s << "      c" << k << "[u] = row < n ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0;\n";
-    }
-    s << "    }\n  }\n";
-  } else {
+  {
     s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
       << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
       << "    const bool live = FULL || row < n;\n"
@@ -1180,57 +1169,33 @@ Status Assemble(CodeGen& cg, KernelPlan* plan, const std::vector<std::string>& e
     s << "  }\n";
   }
 
-  if (plan->opts.bitmaps_last) s << bitmap_loads.str();
   // ---- phase 2: row body
-  if (plan->opts.load_fence)
-    s << "  __builtin_amdgcn_sched_barrier(0);  // keep every load of the tile ahead of the first use\n";
   s << "  // ---- phase 2: fused expression bodies (value for every row, validity per word)\n";
   for (auto& a : accs.names) s << "  gdv_uint64 " << a << " = 0;\n";
   s << decls_before_loop;
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
     << "    {\n";
-  if (wide) {
-    s << "      const gdv_int64 row = rbase + (u >> 2) * 256 + 4 * lane + (u & 3);   // this lane's element u\n"
-      << "      const bool live = FULL || row < n;\n"
-      << "      const gdv_uint64 livemask = FULL ? ~0ull : gdv_live_word(rbase + 64 * u, n);  // validity WORD u\n";
-  } else {
-    s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
-      << "      const bool live = FULL || row < n;\n"
-      << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n";
-  }
+  s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "      const bool live = FULL || row < n;\n"
+    << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n";
   s << "      (void)livemask; (void)row; (void)live;\n";
   if (!sel) {
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.id == kBool && cg.needs_values_[k])
-        s << "      const gdv_uint64 d" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].bits, wbase + u)" : "gdv_tile_word(dw" + std::to_string(k) + ", u)") << ";\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].valid, wbase + u)" : "gdv_tile_word(vw" + std::to_string(k) + ", u)") << ";\n";
+        s << "      const gdv_uint64 d" << k << " = " << "gdv_tile_word(dw" + std::to_string(k) + ", u)" << ";\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << "gdv_tile_word(vw" + std::to_string(k) + ", u)" << ";\n";
     }
   }
   s << body;
   s << "    }\n  }\n";
-  if (wide) {
-    s << "  // ---- stores: 4 consecutive rows per lane and instruction\n"
-      << "#pragma unroll\n  for (int g = 0; g < GDV_U / 4; g++) {\n"
-      << "    const gdv_int64 row0 = rbase + g * 256 + 4 * lane;\n";
-    for (size_t e = 0; e < plan->output_types.size(); e++) {
-      s << "    if (FULL || row0 + 4 <= n) gdv_st4<" << (plan->opts.nontemporal ? "true" : "false") << ">(out" << e
-        << " + row0, &res" << e << "[4 * g]);\n"
-        << "    else {\n#pragma unroll\n      for (int i = 0; i < 4; i++) if (row0 + i < n) out" << e << "[row0 + i] = res" << e
-        << "[4 * g + i];\n    }\n";
-    }
-    s << "  }\n";
-  }
   s << epilogue_after_loop;
   s << "}\n\n";
   // ---- kernel: grid-stride over workgroup tiles; wave w of a workgroup owns GDV_U
   // consecutive 64-row sub-tiles, so a workgroup tile is a contiguous run of
   // 64*GDV_U*GDV_WAVES rows and (for GDV_U*GDV_WAVES = 16) exactly one 128-byte line of
   // each bitmap.
-  std::string attrs;
-  if (plan->opts.waves_per_eu > 0)
-    attrs = "__attribute__((amdgpu_waves_per_eu(" + std::to_string(plan->opts.waves_per_eu) + ", " +
-            std::to_string(plan->opts.waves_per_eu) + "))) ";
+  const std::string attrs;
   s << "GDV_DEV void gdv_kernel_body(const gdv_args& A, const gdv_int64 first_group, const gdv_int64 num_groups) {\n"
     << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
@@ -1331,7 +1296,7 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
     if (t.id == kBool) {
       if (cg.needs_values_[k]) {
         if (sel) s << "  bool x" << k << "[GDV_U];\n";
-        else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+        else s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
       }
     } else if (t.is_varlen()) {
       if (cg.needs_values_[k]) {
@@ -1344,7 +1309,7 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
     }
     if (cg.needs_validity_[k]) {
       if (sel) s << "  bool b" << k << "[GDV_U];\n";
-      else if (!plan->opts.scalar_bitmaps) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+      else s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
   }
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
@@ -1424,8 +1389,8 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (t.id == kBool && cg.needs_values_[k])
-        s << "      const gdv_uint64 d" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].bits, wbase + u)" : "gdv_tile_word(dw" + std::to_string(k) + ", u)") << ";\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << (plan->opts.scalar_bitmaps ? "gdv_bitmap_word(A.in[" + std::to_string(k) + "].valid, wbase + u)" : "gdv_tile_word(vw" + std::to_string(k) + ", u)") << ";\n";
+        s << "      const gdv_uint64 d" << k << " = " << "gdv_tile_word(dw" + std::to_string(k) + ", u)" << ";\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = " << "gdv_tile_word(vw" + std::to_string(k) + ", u)" << ";\n";
     }
   }
   {
@@ -1494,7 +1459,7 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
         << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
         << " >> 8) & 0xffull) * 0x01010101u;\n";
     }
-    s << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
+    s << "  for (gdv_int32 c = sb" << K << "; c < " << AblSel(64, "sb" + K, "sp1" + K) << "; c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
       << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
       << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
@@ -1510,7 +1475,7 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
         << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
         << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
         << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-        << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+        << "      const gdv_uint32 m = " << (tl_ablation ? "(GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : " : "") << "gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
         << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
         << ") << 8);\n"
         << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
@@ -1523,7 +1488,7 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
     // behind the post of the tile totals, "into the shadow" of the scanner hand-off, measured
     // slower: 1.90 vs 1.78 ms, same box, profiles/r02_c5_tuning.txt.)
     for (auto* vo : flats)
-      s << "  if (!(GDV_ABL & 8) && optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
+      s << "  if (" << AblNot(8) << "optflat && (gdv_int64)sp1" << K << " - so0_" << K << " <= A.out[" << vo->e << "].cap)\n"
         << "    gdv_flat_copy(outd" << vo->e << " + (sp0" << K << " - so0_" << K << "), sd" << K << " + sp0" << K << ", sp1" << K
         << " - sp0" << K << ", " << vo->flat_map << ", lane);\n";
     if (want_ascii)
@@ -1608,16 +1573,16 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
       << "  {\n"
       << "    const gdv_int32 e0 = GDV_U > 1 ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
       << "    const gdv_int32 b0 = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
-      << "    if (!(GDV_ABL & 64) && b0 + 16 * lane < e0) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
+      << "    if (" << AblNot(64) << "b0 + 16 * lane < e0) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
       << " + b0 + 16 * lane, 16), 16);\n"
-      << (hooks.empty() ? "" : "    if (!(GDV_ABL & 64) && lane == 63 && b0 + 1024 < e0) tn" + K + " = gdv_load8_raw(sd" + K + " + b0 + 1024);\n")
+      << (hooks.empty() ? "" : "    if (" + AblNot(64) + "lane == 63 && b0 + 1024 < e0) tn" + K + " = gdv_load8_raw(sd" + K + " + b0 + 1024);\n")
       << "  }\n";
     // the two ragged ends of the tile's span (whole 16-byte pieces that overlap their neighbours)
     for (auto* vo : flats)
       s << "  const gdv_int32 fcap" << vo->e << " = (gdv_int32)(A.out[" << vo->e << "].cap > 0x7fffffff ? 0x7fffffff : A.out[" << vo->e
         << "].cap);\n";
     for (auto* vo : flats)
-      s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
+      s << "  " << AblIf(8) << "gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
         << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
     if (want_ascii)
       // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
@@ -1633,7 +1598,7 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
       << "    const gdv_int32 sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
       << "    const bool hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap / mirror\n"
       << "    (void)hm_ok" << K << ";\n"
-      << "    for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : se" << K << "); c += 1024) {\n"
+      << "    for (gdv_int32 c = sb" << K << "; c < " << AblSel(64, "sb" + K, "se" + K) << "; c += 1024) {\n"
       << "      const gdv_int32 a = c + 16 * lane;\n"
       << "      const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
       << "      wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
@@ -1650,7 +1615,7 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
         << "        const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
         << "        gdv_uint64 nx = gdv_next_lane(lo);\n"
         << "        if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-        << "        const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+        << "        const gdv_uint32 m = " << (tl_ablation ? "(GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : " : "") << "gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
         << "                             (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
         << ") << 8);\n"
         << "        if (hm_ok" << K << " && a < se" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
@@ -1662,15 +1627,15 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
     // a piece is stored by the sub-tile in whose span it ENDS (a + 16 <= se): the piece that
     // straddles two sub-tiles is the next one's first piece; the tile's own ends: gdv_sweep_edges
     for (auto* vo : flats)
-      b << "      if (!(GDV_ABL & 8)) gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
+      b << "      " << AblIf(8) << "gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
         << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= se" << K << ", fcap" << vo->e << ");\n";
     b << "    }\n"
       << "    if (u + 1 < GDV_U) {  // the first piece of the next sub-tile's span\n"
       << "      const gdv_int32 e2 = u + 2 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 2 ? 2 : 0]) : sp1" << K << ";\n"
       << "      const gdv_int32 nb = se" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + se" << K << ") & 15);\n"
-      << "      if (!(GDV_ABL & 64) && nb + 16 * lane < e2) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
+      << "      if (" << AblNot(64) << "nb + 16 * lane < e2) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
       << " + nb + 16 * lane, 16), 16);\n"
-      << (hooks.empty() ? "" : "      if (!(GDV_ABL & 64) && lane == 63 && nb + 1024 < e2) tn" + K + " = gdv_load8_raw(sd" + K + " + nb + 1024);\n")
+      << (hooks.empty() ? "" : "      if (" + AblNot(64) + "lane == 63 && nb + 1024 < e2) tn" + K + " = gdv_load8_raw(sd" + K + " + nb + 1024);\n")
       << "    }\n";
     if (!hooks.empty() || mirror) b << "    __builtin_amdgcn_wave_barrier();\n";
 
@@ -1736,7 +1701,7 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
       << (hooks.empty() ? "" : "  gdv_uint64 tn" + K + " = 0;\n")
       << "  if (sb" << K << " + 16 * lane < sp1" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + sb" << K << " + 16 * lane, 16), 16);\n"
       << (hooks.empty() ? "" : "  if (lane == 63 && sb" + K + " + 1024 < sp1" + K + ") tn" + K + " = gdv_load8_raw(sd" + K + " + sb" + K + " + 1024);\n")
-      << "  for (gdv_int32 c = sb" << K << "; c < ((GDV_ABL & 64) ? sb" << K << " : sp1" << K << "); c += 1024) {\n"
+      << "  for (gdv_int32 c = sb" << K << "; c < " << AblSel(64, "sb" + K, "sp1" + K) << "; c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
       << "    const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
       << "    wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
@@ -1752,7 +1717,7 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
         << "      const gdv_uint64 lo = gdv_map8(w[0], " << M << "), hi = gdv_map8(w[1], " << M << ");\n"
         << "      gdv_uint64 nx = gdv_next_lane(lo);\n"
         << "      if (lane == 63) nx = gdv_map8(tail, " << M << ");\n"
-        << "      const gdv_uint32 m = (GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
+        << "      const gdv_uint32 m = " << (tl_ablation ? "(GDV_ABL & 1) ? (gdv_uint32)(lo >> 60) : " : "") << "gdv_match8(lo, hi, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H << ") |\n"
         << "                           (gdv_match8(hi, nx, nd" << H << ", " << Hex64(mask) << ", ns0_" << H << ", ns1_" << H
         << ") << 8);\n"
         << "      if (hm_ok" << K << " && a < sp1" << K << ") ((gdv_uint16*)hit" << H << ")[(a - sb" << K
@@ -1762,11 +1727,11 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
     // flat outputs leave straight from the sweep's registers; a piece's bytes outside this wave's
     // span [sp0, sp1) belong to the neighbouring tiles
     for (auto* vo : flats)
-      s << "    if (!(GDV_ABL & 8)) gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
+      s << "    " << AblIf(8) << "gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
         << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= sp1" << K << ", fcap" << vo->e << ");\n";
     s << "  }\n";
     for (auto* vo : flats)
-      s << "  if (!(GDV_ABL & 8)) gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
+      s << "  " << AblIf(8) << "gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
         << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
     if (want_ascii) {
       // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
@@ -1822,7 +1787,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << "#define GDV_OPTFLAT GDV_OPTFLAT_VALUE\n"
     << "#define GDV_STAGE_COPY(dst, v) gdv_stage_copy(dst, v)\n"
-    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments (tools/c5_ablation.sh); 0 = the product\n#endif\n"
+    << AblDefine()
     << "#define GDV_OUT(e, v) if (live) "
     << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
 
@@ -1888,7 +1853,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
         << (2 * g + 1 < nv ? "all[" + std::to_string(2 * g + 1) + "]" : std::string("0ull")) << ");\n";
     s << "  }\n";
     s << "  if (threadIdx.x == 0) {\n"
-      << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = (GDV_ABL & 32) ? (gdv_uint64)tile * 4000 : gdv_lb_wait(lb_pre, ntiles, tile, g, A.err);\n"
+      << "#pragma unroll\n    for (int g = 0; g < GDV_NG; g++) lds_base[g] = " << AblSel(32, "(gdv_uint64)tile * 4000", "gdv_lb_wait(lb_pre, ntiles, tile, g, A.err)") << ";\n"
       << "  }\n  __syncthreads();\n";
     for (int v = 0; v < nv; v++) {
       const VarlenOut& vo = cg.varlen_outs_[v];
@@ -1910,7 +1875,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
           << "      } else {\n";
       } else if (vo.window >= 0) {
         s << "      if (run" << E << " <= GDV_OUT_WIN) {\n"
-          << "        if (!(GDV_ABL & 16)) gdv_flush_out(outd" << E << " + base, win" << E << ", run" << E << ", lane);\n"
+          << "        " << AblIf(16) << "gdv_flush_out(outd" << E << " + base, win" << E << ", run" << E << ", lane);\n"
           << "      } else {\n";
       } else {
         s << "      {\n";
@@ -2030,7 +1995,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << (mirror_slot >= 0 ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
                          : "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n")
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
-    << "#ifndef GDV_ABL\n#define GDV_ABL 0  // ablation mask for experiments; 0 = the product\n#endif\n"
+    << AblDefine()
     << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
   if (prepass) {
     // (no staged copies in a pre-pass)
@@ -2317,7 +2282,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
           cg.Stmt("if (run" + E + " - wb" + E + " <= GDV_OUT_WIN) {");
           cg.Stmt("  gdv_int32 at = loc" + E + " - wb" + E + ";");
           for (auto& name : pv) {
-            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0) GDV_STAGE_COPY((gdv_lds_u8*)(win" + E + " + at), " + name + ");");
+            cg.Stmt("  if (" + AblNot(4) + name + ".len > 0) GDV_STAGE_COPY((gdv_lds_u8*)(win" + E + " + at), " + name + ");");
             cg.Stmt("  at += " + name + ".len;");
           }
           cg.Stmt("} else if (fit" + E + ") {  // this sub-tile alone is wider than the window: row by row, in place");
@@ -2333,7 +2298,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
           cg.Stmt("  wb" + E + " = run" + E + ";  // nothing of it is staged");
           cg.Stmt("}");
           after_rows << "  if (run" << E << " > wb" << E << " && run" << E << " < 0x7fffffff && base" << E << " + run" << E << " <= A.out[" << E
-                     << "].cap && !(GDV_ABL & 16))\n"
+                     << "].cap" << AblAnd(16) << ")\n"
                      << "    gdv_flush_out(outd" << E << " + base" << E << " + wb" << E << ", win" << E << ", run" << E << " - wb" << E << ", lane);\n";
         } else {
           cg.Stmt("}");
@@ -2379,7 +2344,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
           // tile then takes the second, direct pass)
           cg.Stmt("  gdv_int32 at = lc" + E + "[0];");
           for (auto& name : pv) {
-            cg.Stmt("  if (!(GDV_ABL & 4) && " + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) GDV_STAGE_COPY((gdv_lds_u8*)(win" + E +
+            cg.Stmt("  if (" + AblNot(4) + name + ".len > 0 && at + " + name + ".len <= GDV_OUT_WIN) GDV_STAGE_COPY((gdv_lds_u8*)(win" + E +
                     " + at), " + name + ");");
             cg.Stmt("  at += " + name + ".len;");
           }
@@ -2423,7 +2388,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
     // row loop is rolled): 8 were better while the kernel carried 130 VGPRs either way; with the
     // branch-free range test and the compile-time flat variant 4 sub-tiles fit 95 VGPRs (5 waves
     // per SIMD) and win: 1.70 vs 1.83 ms (profiles/r02_c5_tuning.txt)
-    if (std::getenv("GDV_U") == nullptr) {
+    if (!plan->opts.subtiles_forced) {
       if (shape == StringShape::kScanner) plan->opts.subtiles = 4;
       if (shape == StringShape::kWaveMain) {
         // wave shape: a tile costs a fixed prologue (scalar loads, sweep set-up, ends of the span,
@@ -2453,7 +2418,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
       if (shape == StringShape::kWavePrepass)  // a pre-pass sweeps only for a replace() that counts its matches in the bitmap
         cg.mirror_slot_ = cg.replace_hook_ >= 0 ? cg.contains_hooks_[cg.replace_hook_].slot : -1;
     }
-    if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    if (!plan->opts.waves_forced) plan->opts.waves = 4;
     if (varlen_outs != nullptr) *varlen_outs = cg.varlen_outs_;
     if (wave)
       return AssembleStringsWave(cg, plan, strings, accs, before_loop.str(), in_pass.str(), after_rows.str(),
@@ -2462,7 +2427,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
     return AssembleStrings(cg, plan, strings, accs, before_loop.str(), after_loop.str());
   }
   if (wave) return Status::CodeGenError("internal: wave shape asked for a plan without var-len columns");
-  if (std::getenv("GDV_U") == nullptr) {
+  if (!plan->opts.subtiles_forced) {
     int in_bytes = 0;
     bool any_varlen = false;
     for (size_t k = 0; k < cg.input_fields_.size(); k++) {
@@ -2484,6 +2449,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
 
 Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
                      SelectionMode mode, const CodegenOptions& opts, KernelPlan* plan, int compact_from) {
+  AblationScope ablation_scope(opts.ablation);
   if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
   for (auto& e : exprs) {
     if (!e) return Status::Invalid("Expression cannot be null");
@@ -2495,9 +2461,9 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   // time — still faster than the scanner shape, whose hand-off, occupancy and second row pass for
   // outputs above 8 bytes per row cost more (replace at 5 * 10^7 rows: 3.3 ms there).  Selection-
   // mode plans — and the re-run of a batch that breaks an assumption — take the scanner shape.
-  bool wave_ok = mode == SelectionMode::kNone && std::getenv("GDV_NO_WAVE_SHAPE") == nullptr;
+  bool wave_ok = mode == SelectionMode::kNone && !opts.no_wave_shape;
   bool any_varlen_out = false;
-  const bool bytefree_only = std::getenv("GDV_WAVE_BYTEFREE_ONLY") != nullptr;
+  const bool bytefree_only = opts.wave_bytefree_only;
   for (auto& e : exprs) {
     if (!e->result().type.is_varlen()) continue;
     any_varlen_out = true;
@@ -2550,6 +2516,7 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
 
 Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
                   const CodegenOptions& opts, KernelPlan* plan) {
+  AblationScope ablation_scope(opts.ablation);
   if (!condition) return Status::Invalid("Condition cannot be null");
   GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
   if (condition->root()->return_type().id != kBool)
@@ -2571,7 +2538,7 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
   // loads in flight per wave than a projection: measured on C3 (2 x int64, 10^9 rows) the
   // predicate pass goes from 5.2 TB/s at GDV_U = 4 to 5.9 TB/s at 16 (profiles/r01_c3_sweep).
   // Budget: <= 512 bytes of input values per lane, i.e. <= 128 VGPRs of loads.
-  if (std::getenv("GDV_U") == nullptr) {
+  if (!plan->opts.subtiles_forced) {
     int in_bytes = 0;
     for (size_t k = 0; k < cg.input_fields_.size(); k++)
       if (cg.needs_values_[k]) in_bytes += std::max(4, schema[cg.input_fields_[k]].type.byte_width());
@@ -2592,7 +2559,7 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
   if (string_plan) {
     // the index-emission kernel walks groups of 64 match words: sub-tiles stay a power of two
     plan->opts.subtiles = 4;
-    if (std::getenv("GDV_WAVES") == nullptr) plan->opts.waves = 4;
+    if (!plan->opts.waves_forced) plan->opts.waves = 4;
     return AssembleStrings(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n", after.str());
   }
   return Assemble(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n",

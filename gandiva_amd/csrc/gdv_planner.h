@@ -32,16 +32,16 @@ struct CodegenOptions {
   bool nontemporal = true; // non-temporal stores for output value buffers
   bool nt_loads = true;    // non-temporal loads of input value buffers: every value is read
                            // exactly once (+3 % on C2, +7 % on C1, neutral on C3; GDV_NTLOAD=0)
-  // validity / bool words through the scalar data path instead of one vector load per column +
-  // readlane: measured no gain on C2/C3 and a loss on C1/C4 (SGPR spills), profiles/r02_k1_k2_experiments.txt
-  bool scalar_bitmaps = false;
-  bool bitmaps_last = false;   // issue the bitmap-word loads behind the value loads (GDV_BITMAPS_LAST)
-  int waves_per_eu = 0;        // > 0: amdgpu_waves_per_eu(n, n) on fixed-width kernels (GDV_WPE): lets the compiler keep every load in flight
   // Wave-shaped string kernels: the byte sweep of a sub-tile also drops the bytes into an LDS mirror
   // and the staged copy of the rows reads them from there instead of going back to L2, which the
   // lines have left by then (profiles/r03_c5_traffic.txt).  GDV_NO_LDS_MIRROR=1 switches it off.
   bool lds_mirror = true;
-  bool load_fence = false;     // scheduling barrier between the load phase and the row bodies (GDV_LOAD_FENCE=1)
+  // Read from the environment ONCE, at Make (FromEnv); nothing below is looked up during Evaluate.
+  bool subtiles_forced = false, waves_forced = false;  // GDV_U / GDV_WAVES were given: the planner keeps them
+  bool no_inline_string_args = false;  // GDV_NO_INLINE_STRING_ARGS
+  bool no_wave_shape = false;          // GDV_NO_WAVE_SHAPE: var-len plans take the scanner shape
+  bool wave_bytefree_only = false;     // GDV_WAVE_BYTEFREE_ONLY
+  bool ablation = false;               // GDV_ABLATION=1: emit the GDV_ABL experiment branches into the kernels
   static CodegenOptions FromEnv();
   std::string Key() const;
 };

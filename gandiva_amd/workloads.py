@@ -103,6 +103,67 @@ def c2_device_batch(n, device="cuda", chunk=1 << 24, seed_offset=0):
     return gdv.DeviceBatch(c2_schema(), cols, n)
 
 
+def c2_device_batch_pcg64(n, device="cuda", chunk=1 << 22, seed_offset=0):
+    """C2 inputs in HBM from BASELINE.md §4's frozen streams: the SAME rows c2_batch(n) holds
+    (numpy PCG64, value seeds 42..45, mask seeds 142..145 — consecutive calls on one Generator
+    continue its stream, so chunked generation equals one call), produced chunk by chunk on
+    the host — one thread per stream, numpy releases the GIL inside the generators — and
+    uploaded as they come.  ~10-20 s for 2^28 rows; nothing of it is inside a timed region."""
+    import threading
+    import torch
+    nbytes_valid = (n + 63) // 64 * 8
+    datas = [torch.empty(n, dtype=torch.float64, device=device) for _ in range(4)]
+    valids = [torch.zeros(nbytes_valid, dtype=torch.uint8, device=device) for _ in range(4)]
+    errors = []
+
+    def values(k):
+        try:
+            rng = np.random.Generator(np.random.PCG64(42 + k + seed_offset))
+            for lo in range(0, n, chunk):
+                m = min(chunk, n - lo)
+                datas[k][lo:lo + m].copy_(torch.from_numpy(rng.standard_normal(m)))
+        except Exception as e:  # surfaced by the caller
+            errors.append(e)
+
+    def masks(k):
+        try:
+            rng = np.random.Generator(np.random.PCG64(142 + k + seed_offset))
+            for lo in range(0, n, chunk):          # chunk is a multiple of 8: whole bitmap bytes
+                m = min(chunk, n - lo)
+                w = np.packbits(rng.random(m) >= 0.10, bitorder="little")
+                valids[k][lo // 8: lo // 8 + w.size].copy_(torch.from_numpy(w))
+        except Exception as e:
+            errors.append(e)
+    threads = [threading.Thread(target=f, args=(k,)) for k in range(4) for f in (values, masks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+    cols = [gdv.DeviceColumn(pa.float64(), n, valids[k], datas[k].view(torch.uint8)) for k in range(4)]
+    return gdv.DeviceBatch(c2_schema(), cols, n)
+
+
+def c2_expected_window(dbatch, lo, m):
+    """What C2's ten outputs must hold for rows [lo, lo+m) (lo a multiple of 8), recomputed by an
+    independent engine on the device: torch float64 elementwise arithmetic (IEEE add / subtract /
+    multiply, one rounding per operator, no fused multiply-add: torch evaluates every operator as
+    its own kernel) and the bitwise AND of the input validity bytes.  Returns
+    ([10 float64 tensors], [10 uint8 tensors of ceil(m/8) validity bytes])."""
+    import torch
+    a, b, c, d = (col.data.view(torch.float64)[lo:lo + m] for col in dbatch.columns)
+    nb = (m + 7) // 8
+    va, vb, vc, vd = (col.validity[lo // 8: lo // 8 + nb] for col in dbatch.columns)
+    ab, cd, abcd = va & vb, vc & vd, va & vb & vc & vd
+    s, df, p, q = a + b, a - b, a * b, c * d
+    vals = [s, df, p, c + d, q, s * c, df * d, p + q, s * (c - d), (p * c) * d]
+    valid = [ab, ab, ab, cd, cd, ab & vc, ab & vd, abcd, abcd, abcd]
+    return vals, valid
+
+
 # ------------------------------------------------------------------------------- C3
 
 C3_K1, C3_K2 = 499, 250

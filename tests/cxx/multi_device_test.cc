@@ -8,7 +8,11 @@
 // With fewer physical GPUs than N the contexts are virtual (gdv_set_virtual_devices): N contexts
 // share the GPUs round-robin — the same code path, which is how this runs on a one-GPU box; on a
 // multi-GPU node the same binary uses real devices.
-//   multi_device_test [N=2] [rows=300000]
+// Round 4: "equal to its own unsharded run" says nothing about the VALUES.  With a third argument the
+// inputs and the unsharded results are written to that directory as raw Arrow buffers; the Python
+// wrapper (tests/test_multi_device.py) rebuilds the batch and compares the results with the oracle —
+// sharded == unsharded (checked here) and unsharded == oracle (checked there).
+//   multi_device_test [N=2] [rows=300000] [dump_dir]
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +93,13 @@ struct Output {  // one output column, host side
 };
 
 bool BitAt(const std::vector<uint8_t>& bm, int64_t i) { return (bm[i >> 3] >> (i & 7)) & 1; }
+
+void DumpBytes(const std::string& dir, const std::string& name, const void* p, size_t n) {
+  FILE* f = fopen((dir + "/" + name).c_str(), "wb");
+  CHECK(f != nullptr);
+  if (n > 0) CHECK(fwrite(p, 1, n, f) == n);
+  CHECK(fclose(f) == 0);
+}
 
 }  // namespace
 
@@ -306,6 +317,24 @@ int main(int argc, char** argv) {
   CHECK(his[N - 1] == rows && checked == rows);
   CHECK(cat_sel == wsel);
   for (size_t i = 1; i < cat_sel.size(); i++) CHECK(cat_sel[i - 1] < cat_sel[i]);
+  if (argc > 3) {
+    const std::string dir = argv[3];
+    const HostColumn* in[5] = {&a, &b, &k1, &k2, &s};
+    const char* names[5] = {"a", "b", "k1", "k2", "s"};
+    for (int k = 0; k < 5; k++) {
+      DumpBytes(dir, std::string(names[k]) + ".data", in[k]->data.data(), in[k]->data.size());
+      DumpBytes(dir, std::string(names[k]) + ".validity", in[k]->validity.data(), in[k]->validity.size());
+      DumpBytes(dir, std::string(names[k]) + ".offsets", in[k]->offsets.data(), in[k]->offsets.size() * 4);
+    }
+    for (int e = 0; e < 3; e++) {
+      DumpBytes(dir, "c2_" + std::to_string(e) + ".data", w2[e].data.data(), w2[e].data.size());
+      DumpBytes(dir, "c2_" + std::to_string(e) + ".validity", w2[e].validity.data(), w2[e].validity.size());
+      DumpBytes(dir, "c5_" + std::to_string(e) + ".data", w5[e].data.data(), w5[e].data.size());
+      DumpBytes(dir, "c5_" + std::to_string(e) + ".validity", w5[e].validity.data(), w5[e].validity.size());
+      DumpBytes(dir, "c5_" + std::to_string(e) + ".offsets", w5[e].offsets.data(), w5[e].offsets.size() * 4);
+    }
+    DumpBytes(dir, "c3.indices", wsel.data(), wsel.size() * 4);
+  }
   printf("multi-device ok: %d contexts (%d physical), %lld rows: C2 / C3 (%zu selected) / C5 shards == unsharded\n", N,
          gdv_physical_device_count(), (long long)rows, wsel.size());
   return 0;

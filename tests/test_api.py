@@ -7,6 +7,7 @@ node kind compile to gfx950 code objects offline, and evaluation fails loudly (n
 fallback) when there is no HIP device.
 """
 import ctypes as C
+import numpy as np
 import os
 import re
 
@@ -243,3 +244,28 @@ def test_c_program_evaluates_the_reference_kat(tmp_path):
     r = subprocess.run([_build_c_kat(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "10 15 15 17" in r.stdout
+
+
+def test_the_bench_generator_reproduces_the_frozen_pcg64_streams_chunk_by_chunk():
+    """bench.py's C2 batch (workloads.c2_device_batch_pcg64: chunked, one host thread per stream) holds the
+    very rows workloads.c2_batch holds — BASELINE.md §4's PCG64 value seeds 42-45 / mask seeds 142-145."""
+    import torch
+    from gandiva_amd import workloads as W
+    n = 100_003
+    want = W.c2_batch(n)
+    got = W.c2_device_batch_pcg64(n, device="cpu", chunk=4096)
+    for k in range(4):
+        vals, mask = W.c2_columns_numpy(n)[0][k], W.c2_columns_numpy(n)[1][k]
+        assert np.array_equal(got.columns[k].data.view(torch.float64).numpy().view(np.int64), vals.view(np.int64))
+        bits = np.unpackbits(got.columns[k].validity.numpy(), bitorder="little")[:n].astype(bool)
+        assert np.array_equal(bits, mask)
+        assert want.column(k).null_count == n - int(mask.sum())
+    # the independent restatement bench.py verifies its outputs with agrees with the oracle on this batch
+    from oracle import oracle
+    vals, valid = W.c2_expected_window(got, 0, n)
+    for e, w in enumerate(oracle.project(W.c2_expressions(), want)):
+        wv = np.frombuffer(w.buffers()[1], dtype=np.int64)[:n]
+        assert np.array_equal(vals[e].numpy().view(np.int64), wv), f"e{e}"
+        wb = np.unpackbits(np.frombuffer(w.buffers()[0], dtype=np.uint8), bitorder="little")[:n]
+        gb = np.unpackbits(valid[e].numpy(), bitorder="little")[:n]
+        assert np.array_equal(gb, wb), f"validity of e{e}"

@@ -6,7 +6,7 @@ The oracle cannot hold these batches, so each config is pinned three ways:
   * a 10^5-row prefix and a 10^5-row window from the middle of the batch copied to the host
     and compared bit for bit with the oracle;
   * structural invariants of the Arrow result (ascending indices, closing offset = byte total).
-(C2 at 2^26 rows is in test_parity_gpu.py::test_full_size_properties_c2.)
+Round 4: C2 — the headline configuration — at its own 2^28 rows, every output and every validity buffer.
 """
 import os
 
@@ -39,6 +39,43 @@ def _host_out_fixed(col, lo, m, t):
     raw = col.data[lo * w:(lo + m) * w].cpu().numpy()
     valid = col.validity[lo // 8:lo // 8 + (m + 7) // 8].cpu().numpy()
     return pa.Array.from_buffers(t, m, [pa.py_buffer(valid), pa.py_buffer(raw)])
+
+
+def test_c2_headline_projection_at_2_to_the_28_rows():
+    """The configuration BASELINE.json's metric is quoted on, at the size it is quoted at, on the data
+    bench.py times (BASELINE.md §4's PCG64 streams): ALL ten outputs bit for bit against torch float64
+    arithmetic and ALL ten validity buffers against the bitwise AND of their inputs' bitmaps, over every
+    row in slabs; the head of the batch and a window from its middle bit-exact against the oracle."""
+    import torch
+    n = (1 << 28) if FULL else (1 << 22)
+    db = W.c2_device_batch_pcg64(n)
+    exprs = W.c2_expressions()
+    proj = gandiva.make_projector(W.c2_schema(), exprs, None)
+    outs = proj.evaluate_device(db)
+    torch.cuda.synchronize()
+    slab = 1 << 24
+    for lo in range(0, n, slab):
+        m = min(slab, n - lo)
+        vals, valid = W.c2_expected_window(db, lo, m)
+        for e, (o, v, vb) in enumerate(zip(outs, vals, valid)):
+            assert torch.equal(o.data.view(torch.int64)[lo:lo + m], v.view(torch.int64)), f"e{e}, rows [{lo}, {lo + m})"
+            assert torch.equal(o.validity[lo // 8:(lo + m) // 8], vb[:m // 8]), f"validity of e{e}, rows [{lo}, {lo + m})"
+        del vals, valid
+    # about one row in ten is NULL in each input: the merged bitmaps are neither all-ones nor all-zeros
+    pop = int(torch.count_nonzero(outs[9].validity[:n // 8] == 0xff))
+    assert 0.030 * (n // 8) < pop < 0.039 * (n // 8)   # P(all 8 rows of a byte valid in all 4 inputs) = 0.9^32 = 0.0343
+    for lo in (0, (n // 2) & ~63):
+        m = min(WIN, n - lo)
+        cols = []
+        for c in db.columns:
+            raw = c.data[lo * 8:(lo + m) * 8].cpu().numpy()
+            vb = c.validity[lo // 8:lo // 8 + (m + 7) // 8].cpu().numpy()
+            cols.append(pa.Array.from_buffers(pa.float64(), m, [pa.py_buffer(vb), pa.py_buffer(raw)]))
+        hb = pa.RecordBatch.from_arrays(cols, schema=W.c2_schema())
+        if lo == 0:   # the device batch IS the frozen stream: its head equals the host generator's
+            assert hb.equals(W.c2_batch(m))
+        for o, w, e in zip(outs, oracle.project(exprs, hb), exprs):
+            assert_bit_exact(_host_out_fixed(o, lo, m, w.type), w, f"{e} rows [{lo}, {lo + m})")
 
 
 def test_c3_filter_at_one_billion_rows():
