@@ -95,6 +95,7 @@ PROTOTYPES = [
     ("gdv_filter_evaluate_many", C.c_int, [_P, C.POINTER(gdv_filter_batch_t), C.c_int, C.c_int, C.POINTER(C.c_int64), _P, _P, C.c_uint32]),
     ("gdv_filter_dump_ir", _P, [_P]),
     ("gdv_filter_free", None, [_P]),
+    ("gdv_filter_set_tuning", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("gdv_registry_size", C.c_int, []),
     ("gdv_registry_get", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(gdv_type_t), C.POINTER(gdv_type_t), C.c_int, C.POINTER(C.c_int)]),
     ("gdv_device_count", C.c_int, []),

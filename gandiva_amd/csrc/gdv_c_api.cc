@@ -543,6 +543,11 @@ int gdv_filter_make_from_proto(const void* schema_bytes, int64_t schema_len, con
 char* gdv_proto_describe(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes, int64_t exprs_len,
                          int is_condition) {
   return GuardedPtr([&]() -> char* {
+  if (schema_len < 0 || exprs_len < 0 || (schema_len > 0 && schema_bytes == nullptr) ||
+      (exprs_len > 0 && exprs_bytes == nullptr)) {
+    Fail(Status::Invalid("gdv_proto_describe: negative length or null message"));
+    return nullptr;
+  }
   Schema schema;
   Status s = DecodeSchema(static_cast<const uint8_t*>(schema_bytes), static_cast<size_t>(schema_len), &schema);
   std::string text;
@@ -565,6 +570,13 @@ char* gdv_proto_describe(const void* schema_bytes, int64_t schema_len, const voi
 }
 char* gdv_filter_dump_ir(const gdv_filter_t* f) { return f ? DupString(f->f->DumpIR()) : nullptr; }
 void gdv_filter_free(gdv_filter_t* f) { delete f; }
+int gdv_filter_set_tuning(gdv_filter_t* f, const char* key, int64_t value) {
+  return Guarded([&]() -> int {
+    if (f == nullptr || key == nullptr) return Fail(Status::Invalid("gdv_filter_set_tuning: null argument"));
+    Status st = f->f->SetTuning(key, value);
+    return st.ok() ? GDV_OK : Fail(st);
+  });
+}
 
 // ---------------------------------------------------------------- JNI-shaped flat entry points
 namespace {

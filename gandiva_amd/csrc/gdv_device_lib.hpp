@@ -60,42 +60,9 @@ GDV_DEV void gdv_st(T* p, gdv_int64 i, T v) { p[i] = v; }
 template <typename T>
 GDV_DEV void gdv_stnt(T* p, gdv_int64 i, T v) { __builtin_nontemporal_store(v, p + i); }
 
-// Four consecutive rows per lane with 16-byte (or wider) instructions: the wide layout of
-// fixed-width projections (gdv_planner.cc).  Vector types carry element alignment only: Arrow
-// array offsets can leave a column's first row anywhere.
-template <typename T>
-struct gdv_quad {
-  typedef T type __attribute__((ext_vector_type(4), aligned(sizeof(T))));
-};
-template <bool NT, typename T>
-GDV_DEV void gdv_ld4(const T* p, T* dst) {
-  typedef typename gdv_quad<T>::type V;
-  const V v = NT ? __builtin_nontemporal_load((const V*)p) : *(const V*)p;
-  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-}
-template <bool NT, typename T>
-GDV_DEV void gdv_st4(T* p, const T* src) {
-  typedef typename gdv_quad<T>::type V;
-  V v;
-  v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-  if (NT) __builtin_nontemporal_store(v, (V*)p); else *(V*)p = v;
-}
-template <bool NT>
-GDV_DEV void gdv_ld4(const gdv_int128* p, gdv_int128* dst) {  // no vectors of __int128: 4 x 16 B, contiguous per lane
-#pragma unroll
-  for (int i = 0; i < 4; i++) dst[i] = NT ? __builtin_nontemporal_load(p + i) : p[i];
-}
-template <bool NT>
-GDV_DEV void gdv_st4(gdv_int128* p, const gdv_int128* src) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) { if (NT) __builtin_nontemporal_store(src[i], p + i); else p[i] = src[i]; }
-}
-// live-row mask of the 64 rows starting at `first` (a multiple of 64) of an n-row batch
-GDV_DEV gdv_uint64 gdv_live_word(gdv_int64 first, gdv_int64 n) {
-  const gdv_int64 k = n - first;
-  return k >= 64 ? ~0ull : (k <= 0 ? 0ull : ((1ull << k) - 1));
-}
-
+// rows of a selection-mode launch whose slot count sits in device memory: never more than the
+// capacity n the outputs and the grid were sized for, never negative
+GDV_DEV gdv_int64 gdv_clamp_rows(gdv_int64 count, gdv_int64 n) { return count < 0 ? 0 : (count > n ? n : count); }
 // A bitmap as the kernels see it: 8-byte aligned word pointer + a bit shift < 64 (Arrow
 // array offsets and unaligned buffers are folded into these two by the host) + the
 // number of words that may be read (>= 1).  A column without a validity buffer is bound to

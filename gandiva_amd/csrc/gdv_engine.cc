@@ -158,6 +158,32 @@ struct StreamDrain {
   }
 };
 
+// Debug switches of the evaluation path, read from the environment ONCE per process (first use): no
+// getenv is reachable from Evaluate (round-3 verdict: a getenv per call on a path that takes 0.6-7 us
+// per batch, and not safe against a concurrent setenv).  Code-generation switches are read at Make
+// (CodegenOptions::FromEnv).
+struct EngineKnobs {
+  bool trace = false;              // GDV_TRACE: one line per Evaluate on stderr
+  bool no_optflat = false;         // GDV_NO_OPTFLAT: var-len plans go straight to the general kernel
+  bool no_evaluate_many = false;   // GDV_NO_EVALUATE_MANY: multi-batch calls run batch by batch
+  bool no_small_filter = false;    // GDV_NO_SMALL_FILTER: default of Filter "small_filter" tuning (read at Make)
+  int filter_chunks = 1;           // GDV_FILTER_CHUNKS: default of Filter "chunks" tuning (read at Make)
+  int grid_mult = 0;               // GDV_GRID_MULT: workgroups per CU of the grid-stride launch (0: default)
+  static const EngineKnobs& Get() {
+    static const EngineKnobs k = [] {
+      EngineKnobs x;
+      x.trace = std::getenv("GDV_TRACE") != nullptr;
+      x.no_optflat = std::getenv("GDV_NO_OPTFLAT") != nullptr;
+      x.no_evaluate_many = std::getenv("GDV_NO_EVALUATE_MANY") != nullptr;
+      x.no_small_filter = std::getenv("GDV_NO_SMALL_FILTER") != nullptr;
+      if (const char* s = std::getenv("GDV_GRID_MULT")) x.grid_mult = std::max(1, atoi(s));
+      if (const char* s = std::getenv("GDV_FILTER_CHUNKS")) x.filter_chunks = std::max(1, std::min(64, atoi(s)));
+      return x;
+    }();
+    return k;
+  }
+};
+
 // GDV_TRACE=1: one line per Evaluate on stderr (kind, kernel, rows, device time between two
 // HIP events on the launch stream, rows/s).  The reference has no tracing of its own
 // (SURVEY.md §5); this is the hook its micro-benchmarks' std::chrono timers stood in for.
@@ -166,8 +192,7 @@ class EvalTrace {
  public:
   EvalTrace(const char* kind, const std::string& kernel, int64_t rows, hipStream_t stream)
       : kind_(kind), kernel_(kernel), rows_(rows), stream_(stream) {
-    static const bool on = std::getenv("GDV_TRACE") != nullptr;
-    on_ = on;
+    on_ = EngineKnobs::Get().trace;
     if (on_ && hipEventCreate(&t0_) == hipSuccess && hipEventCreate(&t1_) == hipSuccess) {
       (void)hipEventRecord(t0_, stream_);
     } else {
@@ -431,7 +456,7 @@ int64_t GridFor(const KernelPlan& plan, int64_t rows) {
   // as many, smaller shares of the grid-stride loop even out the tail (C5: 2.26 -> 2.01 ms;
   // fixed-width plans measured best at the base value)
   if (plan.has_varlen_input || plan.has_varlen_output) blocks_per_cu *= 4;
-  if (const char* s = std::getenv("GDV_GRID_MULT")) blocks_per_cu = std::max(1, atoi(s));
+  if (EngineKnobs::Get().grid_mult > 0) blocks_per_cu = EngineKnobs::Get().grid_mult;
   int64_t cap = static_cast<int64_t>(Runtime::Get().num_cus()) * blocks_per_cu;
   return std::max<int64_t>(1, std::min(ntiles, cap));
 }
@@ -874,7 +899,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     // (sticky: a Projector whose batches break an assumption goes straight to the general
     // variant from then on instead of paying two launches per batch)
     const bool has_optimistic = plan_.wave_tiles || plan_.has_flat_output;
-    bool optimistic = has_optimistic && !prefer_general_.load() && std::getenv("GDV_NO_OPTFLAT") == nullptr;
+    bool optimistic = has_optimistic && !prefer_general_.load() && !EngineKnobs::Get().no_optflat;
     auto general_kernel = [&]() -> Status {
       if (dev->kernel_general.load() == nullptr) {
         const CompiledKernel* k = nullptr;
@@ -924,8 +949,13 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       outs[e].data_size = static_cast<int64_t>(totals[e]);  // bytes needed / produced
       if (static_cast<size_t>(e) < out_bytes_x16_.size() && out_rows > 0) {
         const int64_t seen = static_cast<int64_t>(totals[e]) * 16 / out_rows + 1;
+        // a DECAYING maximum: a batch that produces more raises the hint at once, one that produces
+        // less lets it sink by an eighth towards what it produced — one outlier batch no longer makes
+        // every later call allocate for its ratio for good (round-3 advisor)
         int64_t cur = out_bytes_x16_[e].load(std::memory_order_relaxed);
-        while (seen > cur && !out_bytes_x16_[e].compare_exchange_weak(cur, seen, std::memory_order_relaxed)) {
+        for (;;) {
+          const int64_t next = seen >= cur ? seen : std::max(seen, cur - (cur >> 3) - 1);
+          if (next == cur || out_bytes_x16_[e].compare_exchange_weak(cur, next, std::memory_order_relaxed)) break;
         }
       }
       if (have < static_cast<int64_t>(totals[e]) || (totals[e] > 0 && outs[e].data == nullptr))
@@ -980,7 +1010,7 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
   const bool one_launch = plan_.has_many_entry && dev->kernel->function_many != nullptr && pre_ == nullptr &&
                           plan_.num_varlen_outputs == 0 && !plan_.string_skeleton &&
                           stride * static_cast<size_t>(nb) <= Runtime::kPinnedBlock && nb <= 65535 &&
-                          std::getenv("GDV_NO_EVALUATE_MANY") == nullptr;
+                          !EngineKnobs::Get().no_evaluate_many;
   if (!one_launch) {
     // batch by batch, all enqueued on `stream`; one wait at the end unless the caller asked for none
     for (int b = 0; b < nb; b++)
@@ -997,13 +1027,13 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
     ~PinGuard() { if (pin != nullptr) { if (small) rt.ReleasePinnedSmall(pin); else rt.ReleasePinned(pin); } }
   } pin_guard{rt, pin, small_pin};
   DeviceBuffer table, err;
+  StreamDrain drain{stream, false};  // declared after the pooled blocks: an error return waits for what was enqueued
   GDV_RETURN_NOT_OK(table.Allocate(stride * nb));
-  if (plan_.can_raise) {
-    GDV_RETURN_NOT_OK(err.Allocate(8));
-    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
-  }
+  if (plan_.can_raise) GDV_RETURN_NOT_OK(err.Allocate(8));
   Staging st;  // (device buffers bind in place: nothing is staged)
   int64_t grid = 1;
+  // every batch is validated and its argument block written (host memory only) BEFORE anything is
+  // enqueued: an Invalid return frees `table` / `err` with nothing pending on them
   for (int b = 0; b < nb; b++) {
     const BatchView& v = batches[b];
     if (v.num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
@@ -1027,6 +1057,8 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
     grid = std::max(grid, GridFor(plan_, v.num_rows));
   }
   EvalTrace trace("project-many", plan_.kernel_name, nb, stream);
+  drain.armed = true;
+  if (plan_.can_raise) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
   GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(table.get(), pin, stride * nb, hipMemcpyHostToDevice, stream));
   GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel, grid, nb, plan_.opts.waves * 64, table.get(), stream));
   uint32_t err_bits = 0;
@@ -1040,9 +1072,11 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
     Runtime* owner = &rt;
     const bool small = small_pin;
     rt.Defer(stream, [owner, p, small] { if (small) owner->ReleasePinnedSmall(p); else owner->ReleasePinned(p); });
+    drain.armed = false;
     return Status::OK();
   }
   GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  drain.armed = false;
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
   return Status::OK();
 }
@@ -1063,6 +1097,8 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   auto f = std::make_shared<Filter>();
   f->schema_ = schema;
   f->plan_schema_ = schema;
+  f->chunks_.store(EngineKnobs::Get().filter_chunks);
+  f->small_filter_.store(!EngineKnobs::Get().no_small_filter);
   ExpressionPtr planned = condition;
   StagedExpressions staged;
   StageMaterialisedValues(schema, {condition}, &staged);
@@ -1088,6 +1124,18 @@ struct ScratchPart {  // a piece of a scratch block, spelled like a DeviceBuffer
 };
 }  // namespace
 
+Status Filter::SetTuning(const std::string& key, int64_t value) {
+  if (key == "chunks") {
+    if (value < 1 || value > 64) return Status::Invalid("filter tuning 'chunks': 1..64");
+    chunks_.store(static_cast<int>(value));
+  } else if (key == "small_filter") {
+    small_filter_.store(value != 0);
+  } else {
+    return Status::Invalid("unknown filter tuning key '" + key + "'");
+  }
+  return Status::OK();
+}
+
 int64_t Filter::SmallBatchRows() const {
   if (!plan_.has_small_entry || plan_.string_skeleton || pre_ != nullptr) return 0;
   // one workgroup: at most 1024 wave tiles (LDS offsets), and no more rows than a workgroup gets
@@ -1110,7 +1158,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
   const size_t stride = static_cast<size_t>(plan_.layout.total());
   bool fused = cap_rows > 0 && dev->kernel->function_small != nullptr && nb <= 65535 &&
                stride * static_cast<size_t>(nb) <= Runtime::kPinnedBlock / 2 &&
-               std::getenv("GDV_NO_SMALL_FILTER") == nullptr;
+               small_filter_.load(std::memory_order_relaxed);
   for (int b = 0; fused && b < nb; b++) fused = batches[b].num_rows <= cap_rows;
   if (!fused) {
     for (int b = 0; b < nb; b++) {
@@ -1160,6 +1208,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
     Runtime& rt; char*& pin; bool small, owned;
     ~PinGuard() { if (pin != nullptr && owned) { if (small) rt.ReleasePinnedSmall(pin); else rt.ReleasePinned(pin); } }
   } pin_guard{rt, pin, small_pin, !by_value};
+  StreamDrain drain{stream, false};  // armed once something is enqueued: error returns wait before the blocks go back
   Staging st;
   for (int b = 0; b < nb; b++) {
     const BatchView& v = batches[b];
@@ -1177,6 +1226,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
     std::memcpy(pin + stride * b, args.data(), stride);
   }
   EvalTrace trace("filter-small", plan_.kernel_name, nb, stream);
+  drain.armed = true;
   if (plan_.can_raise) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(base + err_off, 0, 8, stream));
   if (by_value) {
     GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, 1, plan_.opts.waves * 64, pin, stride, stream, dev->kernel->function_small1));
@@ -1198,6 +1248,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
       const bool small = small_pin;
       rt.Defer(stream, [owner, p, small] { if (small) owner->ReleasePinnedSmall(p); else owner->ReleasePinned(p); });
     }
+    drain.armed = false;
     return Status::OK();
   }
   std::vector<int64_t> counts(nb, 0);
@@ -1206,6 +1257,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
   if (plan_.can_raise)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, base + err_off, 4, hipMemcpyDeviceToHost, stream));
   GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  drain.armed = false;
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
   if (counts_host != nullptr)
     for (int b = 0; b < nb; b++) counts_host[b] = counts[b];
@@ -1245,7 +1297,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   // which spreads the predicate over the chip, is faster for a single batch —
   // profiles/r03_small_batches.txt)
   if (mem == MemKind::kDevice && !(flags & kEvalNoSmall) && num_rows <= std::min<int64_t>(SmallBatchRows(), 8192) &&
-      std::getenv("GDV_NO_SMALL_FILTER") == nullptr) {
+      small_filter_.load(std::memory_order_relaxed)) {
     BatchView v;
     v.num_rows = num_rows; v.cols = cols; v.num_cols = num_cols; v.out_indices = out_indices; v.max_slots = max_slots;
     int64_t count = -1;
@@ -1297,8 +1349,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   // pipeline loses what the overlap wins.  Kept for re-measurement, and because the carried scan
   // is what lets the count stay on the device for the asynchronous API.
   const int64_t tile_rows = 64 * static_cast<int64_t>(plan_.opts.subtiles);   // one count per wave tile
-  int chunks = 1;
-  if (const char* e = std::getenv("GDV_FILTER_CHUNKS")) chunks = std::max(1, std::min(64, atoi(e)));
+  int chunks = chunks_.load(std::memory_order_relaxed);
   if (plan_.string_skeleton || mem != MemKind::kDevice) chunks = 1;
   // chunk boundaries: whole index-emission tiles (64 match words) and whole workgroup tiles
   const int64_t gran = 4096 * static_cast<int64_t>(std::max(1, plan_.opts.subtiles * plan_.opts.waves / 64 + 1));
@@ -1330,12 +1381,22 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   }
 
   EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
+  // From here on kernels that write `scratch` are in flight: an error return must not hand the block
+  // back to the pool (another thread could be given it) before the streams have passed them.  The
+  // drain is armed for every exit; the one successful asynchronous exit disarms it again and releases
+  // the scratch behind an event instead.
+  drain.armed = true;
+  bool enqueued_all = false;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> events;
   struct SideGuard {  // hands the side stream and the events back whatever path leaves the function
-    Runtime& rt; hipStream_t& side; std::vector<hipEvent_t>& events;
-    ~SideGuard() { for (auto e : events) rt.ReleaseEvent(e); rt.ReleaseStream(side); }
-  } side_guard{rt, side, events};
+    Runtime& rt; hipStream_t& side; std::vector<hipEvent_t>& events; const bool& done;
+    ~SideGuard() {
+      if (!done && side != nullptr) (void)hipStreamSynchronize(side);  // error path: work of the side stream may still use the scratch
+      for (auto e : events) rt.ReleaseEvent(e);
+      rt.ReleaseStream(side);
+    }
+  } side_guard{rt, side, events, enqueued_all};
   if (chunks > 1) GDV_RETURN_NOT_OK(rt.AcquireStream(&side));
   const int64_t sums_per_chunk = ScanChunks((chunk_rows + tile_rows - 1) / tile_rows) + 1;
   for (int c = 0; c < chunks; c++) {
@@ -1371,11 +1432,13 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     GDV_HIP_RETURN_NOT_OK(hipStreamWaitEvent(stream, e, 0));
   }
   const uint64_t* total_dev = totals.as<uint64_t>() + chunks;
+  enqueued_all = true;  // (`stream` now waits for the side stream's last kernel)
   if (async) {
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(count_out, total_dev, 8, hipMemcpyDefault, stream));
     if (num_selected != nullptr) *num_selected = -1;
     // scratch goes back to the pool when the stream has passed this point
     scratch.release_after(stream);
+    drain.armed = false;
     return Status::OK();
   }
   uint64_t count = 0;
@@ -1412,6 +1475,7 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
   std::vector<char> code;
   GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code));
   // the variant without the optimistic flat path is otherwise compiled only when a batch needs it
+  // (offline tool path, not reachable from Evaluate)
   if (!plan.source_general.empty() && std::getenv("GDV_PRECOMPILE_SKIP_GENERAL") == nullptr)
     GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source_general, plan.kernel_name_general, &code));
   if (plan.prepass)

@@ -131,12 +131,13 @@ class Projector {
   std::shared_ptr<Projector> pre_;
   Schema plan_schema_;
   mutable std::vector<std::atomic<int64_t>> stage_hints_;  // sizes of the first stage's temporaries, learnt from the last batch
-  // var-len outputs: the most bytes per row (x 16) a batch has produced so far; 0 = no batch yet
+  // var-len outputs: bytes per row (x 16) recent batches produced — a decaying maximum (rises at once,
+  // sinks by an eighth per batch towards what that batch produced); 0 = no batch yet
   mutable std::vector<std::atomic<int64_t>> out_bytes_x16_;
 
  public:
-  // A capacity HINT for var-len output i over `rows` rows, from what earlier batches produced
-  // (0 before the first one).  Callers that size their byte buffer by it avoid the
+  // A capacity HINT for var-len output i over `rows` rows, from what recent batches produced per row
+  // (a decaying maximum + an eighth of head room; 0 before the first batch).  Callers that size their byte buffer by it avoid the
   // "too small -> bytes needed -> retry" round trip on every batch after the first.
   int64_t VarlenBytesHint(int i, int64_t rows) const;
 };
@@ -190,7 +191,15 @@ class Filter {
   const std::shared_ptr<Projector>& first_stage() const { return pre_; }
   std::string DumpIR() const { return pre_ ? pre_->DumpIR() + plan_.ir : plan_.ir; }
 
+  // Per-object tuning, for tests and measurements (gdv_filter_set_tuning); never read from the
+  // environment during Evaluate.  "chunks": cut big HBM-resident batches into n pipelined chunks
+  // (1 = off, the default: measured slower); "small_filter": 0 keeps small batches on the
+  // three-launch path.  Defaults come from GDV_FILTER_CHUNKS / GDV_NO_SMALL_FILTER once, at Make.
+  Status SetTuning(const std::string& key, int64_t value);
+
  private:
+  std::atomic<int> chunks_{1};
+  std::atomic<bool> small_filter_{true};
   Schema schema_;
   KernelPlan plan_;
   PlanDeviceStates states_;  // code objects + constant block per device context

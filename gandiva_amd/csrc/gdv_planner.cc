@@ -1022,7 +1022,9 @@ struct Assembler {
     // rows of the batch: selection-mode plans may take the slot count from device memory (aux2: an
     // asynchronous Filter left it there), so a filter -> project chain needs no host round trip
     if (plan->mode != SelectionMode::kNone)
-      src << "#define GDV_ROWS(A) ((A).aux2 != 0 ? *(const gdv_int64*)(A).aux2 : (A).n)\n";
+      // (clamped to [0, n]: n is the capacity the outputs and the grid were sized for — a stale or
+      // foreign count word must not make the kernel write past them)
+      src << "#define GDV_ROWS(A) ((A).aux2 != 0 ? gdv_clamp_rows(*(const gdv_int64*)(A).aux2, (A).n) : (A).n)\n";
     else
       src << "#define GDV_ROWS(A) ((A).n)\n";
     src << "#define GDV_U " << plan->opts.subtiles << "\n";

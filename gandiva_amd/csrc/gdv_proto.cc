@@ -120,6 +120,18 @@ Status DecodeType(Reader r, DataType* out) {
     else r.Skip(w);
   }
   if (!r.ok) return Malformed("ExtGandivaType");
+  // type parameters are checked here, as the JNI side rejects what it cannot map: a time unit is
+  // SEC / MILLISEC / MICROSEC / NANOSEC (0..3), time32 counts seconds or milliseconds, time64
+  // microseconds or nanoseconds, a decimal128 has 1 <= precision <= 38 and 0 <= scale <= precision
+  if ((gtype == 18 || gtype == 19 || gtype == 20) && time_unit != -1 && (time_unit < 0 || time_unit > 3))
+    return Status::Invalid("malformed protobuf message: time unit " + std::to_string(time_unit) + " is not one of 0..3");
+  if (gtype == 19 && time_unit != -1 && time_unit != kSecond && time_unit != kMilli)
+    return Status::Invalid("malformed protobuf message: time32 counts seconds or milliseconds");
+  if (gtype == 20 && time_unit != -1 && time_unit != kMicro && time_unit != kNano)
+    return Status::Invalid("malformed protobuf message: time64 counts microseconds or nanoseconds");
+  if (gtype == 22 && (precision < 1 || precision > 38 || scale < 0 || scale > precision))
+    return Status::Invalid("malformed protobuf message: decimal128(" + std::to_string(precision) + ", " +
+                           std::to_string(scale) + ") is outside 1 <= precision <= 38, 0 <= scale <= precision");
   switch (gtype) {
     case 1: *out = boolean(); break;
     case 2: *out = uint8(); break;
@@ -194,8 +206,11 @@ bool ParseDecimalDigits(const std::string& text, Literal* out) {
   if (i < text.size() && (text[i] == '-' || text[i] == '+')) neg = text[i++] == '-';
   if (i >= text.size()) return false;
   unsigned __int128 v = 0;
+  int digits = 0;
   for (; i < text.size(); i++) {
     if (text[i] < '0' || text[i] > '9') return false;
+    if (v != 0 || text[i] != '0') digits++;
+    if (digits > 38) return false;  // beyond decimal128: the accumulator would wrap silently
     v = v * 10 + static_cast<unsigned>(text[i] - '0');
   }
   if (neg) v = ~v + 1;
@@ -351,6 +366,15 @@ Status DecodeNode(Reader r, int depth, NodePtr* out) {
       }
       Literal l;
       if (!body.ok || !ParseDecimalDigits(digits, &l)) return Malformed("DecimalNode");
+      if (precision < 1 || precision > 38 || scale < 0 || scale > precision)
+        return Status::Invalid("malformed protobuf message: DecimalNode precision / scale out of range");
+      {  // the value must fit the declared precision
+        unsigned __int128 mag = (static_cast<unsigned __int128>(l.hi) << 64) | l.lo;
+        if (static_cast<__int128>(mag) < 0) mag = ~mag + 1;
+        unsigned __int128 lim = 1;
+        for (int k = 0; k < precision; k++) lim *= 10;
+        if (mag >= lim) return Status::Invalid("malformed protobuf message: DecimalNode value exceeds its precision");
+      }
       *out = std::make_shared<LiteralNode>(decimal128(precision, scale), l);
       return Status::OK();
     }

@@ -41,8 +41,10 @@ int Runtime::DeviceCount() {
     std::lock_guard<std::mutex> g(g_contexts_mu);
     v = g_virtual_devices;
   }
-  if (v == 0)
-    if (const char* e = std::getenv("GDV_VIRTUAL_DEVICES")) v = atoi(e);
+  if (v == 0) {  // GDV_VIRTUAL_DEVICES: read once per process
+    static const int from_env = [] { const char* e = std::getenv("GDV_VIRTUAL_DEVICES"); return e ? atoi(e) : 0; }();
+    v = from_env;
+  }
   const int phys = PhysicalDeviceCount();
   if (phys == 0) return 0;
   return std::min<int>(kMaxDevices, std::max(phys, v));

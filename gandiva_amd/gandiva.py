@@ -364,6 +364,18 @@ class DeviceColumn:
     def __init__(self, type, length, validity, data, offsets=None, offset=0):
         self.type, self.length = type, length
         self.validity, self.data, self.offsets, self.offset = validity, data, offsets, offset
+        # Outputs of a selection-mode evaluation whose slot count was still on the device: `length` is
+        # the CAPACITY the buffers were sized for, rows past the real count were never written.  The
+        # count tensor travels with the column; `num_rows` / `to_arrow` read it (and wait) when asked.
+        self.count_tensor = None
+
+    @property
+    def num_rows(self):
+        """Rows that hold results (reads the device-resident count — and waits — if there is one)."""
+        if self.count_tensor is not None:
+            self.length = min(self.length, int(self.count_tensor.item()))
+            self.count_tensor = None
+        return self.length
 
     def _c(self):
         col = gdv_column_t()
@@ -384,7 +396,7 @@ class DeviceColumn:
         used = getattr(self, "data_used", None)
         data = self.data if used is None else self.data[:used]
         bufs.append(pa.py_buffer(data.cpu().numpy()))
-        return pa.Array.from_buffers(self.type, self.length, bufs, offset=self.offset)
+        return pa.Array.from_buffers(self.type, self.num_rows, bufs, offset=self.offset)
 
 
 def _pad64(n):
@@ -639,6 +651,10 @@ class Projector:
         for i in range(n_out):
             if varlen[i]:
                 outputs[i].data_used = outs[i].data_size
+            # (pending selection: the columns were sized for its capacity; they trim themselves to the
+            # real count when it is first asked for)
+            outputs[i].count_tensor = selection.count_tensor if pending else None
+            outputs[i].length = out_rows
         return outputs
 
 
@@ -771,6 +787,10 @@ class Filter:
                                        idx.ctypes.data, batch.num_rows, C.byref(count),
                                        GDV_MEM_HOST, None))
         return SelectionVector(mode, idx, count.value, device=False)
+
+    def set_tuning(self, key, value):
+        """gdv_filter_set_tuning: "chunks" (1..64) / "small_filter" (0 / 1) — tests and measurements."""
+        _check(_capi.lib().gdv_filter_set_tuning(self._h, key.encode(), int(value)))
 
     def evaluate_device(self, dbatch, dtype="int32", out=None, stream=None, sync=True):
         """HBM-resident filter.  sync=False: everything is enqueued and the call returns at once; the

@@ -221,8 +221,10 @@ int gdv_projector_output_sizes(const gdv_projector_t* p, int i, int64_t rows, in
                                int64_t* validity_bytes, int64_t* data_bytes);
 /* var-len (utf8/binary) outputs: offsets need (rows + 1) * 4 bytes; *data_bytes above is
  * reported as 0 before this projector has evaluated a batch and afterwards as a capacity HINT
- * (the most bytes per row a batch has produced so far, with an eighth of head room — sizing the
- * buffer by it saves the retry below on every batch after the first).  It is not a bound:
+ * (bytes per row recent batches produced, with an eighth of head room: a maximum that rises at
+ * once and decays by an eighth per batch towards what that batch produced, so one outlier batch
+ * does not size every later buffer — sizing the buffer by it saves the retry below on every batch
+ * after the first).  It is not a bound:
  * the byte total is only known once the rows have been evaluated: call evaluate
  * with any capacity; the kernel never writes past it, and when it is too small the call fails with
  * GDV_INVALID and data_size is updated to the bytes needed (the reference's JNI path grows its buffer through an expander callback
@@ -293,6 +295,12 @@ int gdv_filter_evaluate_many(const gdv_filter_t* f, const gdv_filter_batch_t* ba
                              uint32_t flags);
 char* gdv_filter_dump_ir(const gdv_filter_t* f);
 void gdv_filter_free(gdv_filter_t* f);
+/* Per-object tuning for tests and measurements (nothing on the Evaluate path reads the environment):
+ *   "chunks"        1..64  cut big HBM-resident batches into n pipelined chunks (default 1 = off)
+ *   "small_filter"  0 / 1  small batches filtered by one workgroup in one launch (default 1)
+ * Defaults are taken once, at Make, from GDV_FILTER_CHUNKS / GDV_NO_SMALL_FILTER.  Filters are
+ * cached per (schema, condition): the setting applies to every holder of the same plan. */
+int gdv_filter_set_tuning(gdv_filter_t* f, const char* key, int64_t value);
 
 /* ---- function registry ------------------------------------------------------------ */
 int gdv_registry_size(void);

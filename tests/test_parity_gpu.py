@@ -595,7 +595,6 @@ def test_pipelined_filter_chunks_match_the_oracle(monkeypatch, chunks, dtype):
     side stream.  Forced here at a size the oracle handles: ragged last chunk, nulls, every chunk
     boundary inside the batch; indices ascending and identical to the unchunked result."""
     import torch
-    monkeypatch.setenv("GDV_FILTER_CHUNKS", str(chunks))
     n = 100_003
     rng = np.random.default_rng(chunks)
     batch = _batch(rng, [pa.int64(), pa.int64(), pa.float64()], n, 0.15)
@@ -604,6 +603,7 @@ def test_pipelined_filter_chunks_match_the_oracle(monkeypatch, chunks, dtype):
     cond = b.make_condition(b.make_or([b.make_function("greater_than", [a, c], pa.bool_()),
                                        b.make_function("isnull", [d], pa.bool_())]))
     flt = gandiva.make_filter(batch.schema, cond)
+    flt.set_tuning("chunks", chunks)
     want = oracle.filter_indices(cond, batch, dtype)
     db = gandiva.DeviceBatch.from_arrow(batch)
     sel = flt.evaluate_device(db, dtype)
@@ -613,7 +613,7 @@ def test_pipelined_filter_chunks_match_the_oracle(monkeypatch, chunks, dtype):
     sl = batch.slice(37, n - 100)
     sel2 = flt.evaluate_device(gandiva.DeviceBatch.from_arrow(sl), dtype)
     assert sel2.to_array().equals(oracle.filter_indices(cond, sl, dtype))
-    monkeypatch.setenv("GDV_FILTER_CHUNKS", "1")
+    flt.set_tuning("chunks", 1)
     assert flt.evaluate_device(db, dtype).to_array().equals(want)
 
 
@@ -634,8 +634,8 @@ def test_asynchronous_filter_feeds_a_projector_without_a_host_round_trip():
     flt = gandiva.make_filter(batch.schema, cond)
     proj = gandiva.make_projector(batch.schema, exprs, None, "UINT32")
     db = gandiva.DeviceBatch.from_arrow(batch)
-    for chunks in ("1", "3"):
-        os.environ["GDV_FILTER_CHUNKS"] = chunks
+    for chunks in (1, 3):
+        flt.set_tuning("chunks", chunks)
         try:
             sel = flt.evaluate_device(db, "int32", sync=False)
             assert sel.pending                                   # the count has not left the device
@@ -643,12 +643,14 @@ def test_asynchronous_filter_feeds_a_projector_without_a_host_round_trip():
             assert sel.pending
             torch.cuda.synchronize()
         finally:
-            del os.environ["GDV_FILTER_CHUNKS"]
+            flt.set_tuning("chunks", 1)
         want_sel = oracle.filter_indices(cond, batch, "int32")
         assert sel.num_slots == len(want_sel) and sel.to_array().equals(want_sel)
         want = oracle.project(exprs, oracle.take_rows(batch, want_sel.to_numpy()))
         for o, w in zip(outs, want):
-            got = o.to_arrow().slice(0, sel.num_slots)           # outputs were sized for the capacity
+            assert o.length == n                                 # sized for the capacity ...
+            got = o.to_arrow()                                   # ... and trimmed to the count when read
+            assert o.num_rows == sel.num_slots == len(got)
             assert_bit_exact(got, w)
 
 
@@ -712,11 +714,11 @@ def test_small_batch_filter_one_workgroup_per_batch(dtype):
         sva = flt.evaluate_device(db, dtype, sync=False)                          # ... asynchronously
         torch.cuda.synchronize()
         assert sva.to_array().equals(want)
-    os.environ["GDV_NO_SMALL_FILTER"] = "1"
+    flt.set_tuning("small_filter", 0)
     try:
         assert flt.evaluate_device(dbs[-1], dtype).to_array().equals(oracle.filter_indices(cond, batches[-1], dtype))
     finally:
-        del os.environ["GDV_NO_SMALL_FILTER"]
+        flt.set_tuning("small_filter", 1)
     # an all-false and an all-true predicate
     t = b.make_condition(b.make_function("isnotnull", [b.make_literal(1, pa.int64())], pa.bool_()))
     full = gandiva.make_filter(batches[0].schema, t).evaluate_device(dbs[9], dtype)

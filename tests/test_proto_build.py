@@ -162,3 +162,44 @@ def test_nine_reference_kats_through_build_from_proto_and_evaluate_flat(kat):
     lib.gdv_projector_free(ph)
     for g, w in zip(got, expected):
         assert g.equals(w), (g, w)
+
+
+def test_type_parameters_in_the_bytes_are_validated():
+    """Round-3 advisor: any integer used to pass as a time unit or as a decimal precision / scale, a
+    decimal literal of more than 38 digits wrapped silently, and gdv_proto_describe took a negative
+    length for a huge one.  All refused with a Status now."""
+    lib = _capi.lib()
+
+    def schema_of(type_bytes):
+        return P.ld(1, P.ld(1, b"x") + P.ld(2, type_bytes) + P.vi(3, 1))
+
+    def describe(sb, body=b""):
+        p = lib.gdv_proto_describe(sb, len(sb), body, len(body), 0)
+        if p:
+            return _capi.take_string(p)
+        return None
+    ok = [P.vi(1, 18) + P.vi(6, 1), P.vi(1, 18) + P.vi(6, 3), P.vi(1, 19) + P.vi(6, 0), P.vi(1, 20) + P.vi(6, 3),
+          P.vi(1, 22) + P.vi(3, 38) + P.vi(4, 38), P.vi(1, 22) + P.vi(3, 1) + P.vi(4, 0)]
+    for t in ok:
+        assert describe(schema_of(t)) is not None, _capi.last_error()
+    bad = [P.vi(1, 18) + P.vi(6, 4), P.vi(1, 18) + P.vi(6, 77), P.vi(1, 19) + P.vi(6, 2), P.vi(1, 20) + P.vi(6, 1),
+           P.vi(1, 22) + P.vi(3, 0) + P.vi(4, 0), P.vi(1, 22) + P.vi(3, 39) + P.vi(4, 2),
+           P.vi(1, 22) + P.vi(3, 10) + P.vi(4, 11), P.vi(1, 22) + P.vi(3, 10) + P.vi(4, -1)]
+    for t in bad:
+        assert describe(schema_of(t)) is None, t
+        assert "malformed" in _capi.last_error()
+    # decimal literals: DecimalNode { value = 1 (digits), precision = 2, scale = 3 } is TreeNode field 19
+    sb = schema_of(P.vi(1, 22) + P.vi(3, 38) + P.vi(4, 2))
+
+    def expr_with_decimal(digits, precision, scale):
+        node = P.ld(19, P.ld(1, digits.encode()) + P.vi(2, precision) + P.vi(3, scale))
+        rt = P.ld(2, P.vi(1, 22) + P.vi(3, 38) + P.vi(4, 2))
+        return P.ld(2, P.ld(1, node) + P.ld(2, P.ld(1, b"r") + rt + P.vi(3, 1)))   # ExpressionList.exprs = 2
+    assert describe(sb, expr_with_decimal("9" * 38, 38, 2)) is not None, _capi.last_error()
+    assert describe(sb, expr_with_decimal("-" + "9" * 38, 38, 2)) is not None, _capi.last_error()
+    assert describe(sb, expr_with_decimal("000" + "9" * 38, 38, 2)) is not None      # leading zeros are not digits
+    for digits, p, s in (("1" + "0" * 38, 38, 2), ("9" * 60, 38, 2), ("12345", 4, 2), ("1", 0, 0), ("1", 39, 0), ("1", 5, 6)):
+        assert describe(sb, expr_with_decimal(digits, p, s)) is None, (digits, p, s)
+    # negative lengths
+    assert not lib.gdv_proto_describe(sb, -1, b"", 0, 0)
+    assert not lib.gdv_proto_describe(sb, len(sb), b"", -5, 0)
