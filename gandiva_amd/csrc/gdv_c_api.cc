@@ -25,6 +25,7 @@ struct gdv_projector {
   std::vector<std::string> output_names;  // result field names, for the C data export
 };
 struct gdv_filter { std::shared_ptr<Filter> f; };
+struct gdv_filter_project { std::shared_ptr<FilterProject> fp; };
 
 namespace {
 
@@ -578,6 +579,55 @@ int gdv_filter_set_tuning(gdv_filter_t* f, const char* key, int64_t value) {
   });
 }
 
+// ---------------------------------------------------------------- fused filter -> project
+int gdv_filter_project_make(const gdv_schema_t* schema, gdv_expression_t* condition, gdv_expression_t* const* exprs,
+                            int num_exprs, int index_mode, const gdv_config_t* config, gdv_filter_project_t** out) {
+  return Guarded([&]() -> int {
+  if (!schema || !out) return Fail(Status::Invalid("null schema or output pointer"));
+  if (!condition || !condition->expr) return Fail(Status::Invalid("Condition cannot be null"));
+  if (num_exprs <= 0 || !exprs) return Fail(Status::Invalid("Expressions cannot be empty"));
+  SelectionMode mode;
+  if (!ToSelectionMode(index_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<ExpressionPtr> ex;
+  for (int i = 0; i < num_exprs; i++) {
+    if (!exprs[i] || !exprs[i]->expr) return Fail(Status::Invalid("Expression cannot be null"));
+    ex.push_back(exprs[i]->expr);
+  }
+  Configuration cfg;
+  if (config) { cfg.optimize = config->optimize != 0; cfg.dump_ir = config->dump_ir != 0; }
+  std::shared_ptr<FilterProject> fp;
+  Status s = FilterProject::Make(schema->fields, condition->expr, ex, mode, cfg, &fp);
+  if (!s.ok()) return Fail(s);
+  *out = new gdv_filter_project{fp};
+  return GDV_OK;
+  });
+}
+int gdv_filter_project_num_outputs(const gdv_filter_project_t* fp) { return fp ? fp->fp->num_outputs() : 0; }
+gdv_type_t gdv_filter_project_output_type(const gdv_filter_project_t* fp, int i) {
+  if (!fp || i < 0 || i >= fp->fp->num_outputs()) return gdv_type_t{0, 0, 0};
+  return FromType(fp->fp->output_type(i));
+}
+int gdv_filter_project_evaluate(const gdv_filter_project_t* fp, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                gdv_out_column_t* outs, int num_outs, void* out_indices, int64_t max_slots,
+                                int64_t* num_selected, void* num_selected_device, int mem_kind, void* stream,
+                                uint32_t flags) {
+  return Guarded([&]() -> int {
+  if (!fp) return Fail(Status::Invalid("null filter-project"));
+  if ((num_cols > 0 && !cols) || (num_outs > 0 && !outs)) return Fail(Status::Invalid("null column array"));
+  std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+  std::vector<OutputBuffers> o(num_outs > 0 ? num_outs : 0);
+  for (int i = 0; i < num_outs; i++) {
+    o[i].validity = outs[i].validity; o[i].validity_size = outs[i].validity_size;
+    o[i].data = outs[i].data; o[i].data_size = outs[i].data_size;
+  }
+  return Check(fp->fp->Evaluate(num_rows, c.data(), num_cols, o.data(), num_outs, out_indices, max_slots, num_selected,
+                                mem_kind == GDV_MEM_DEVICE ? MemKind::kDevice : MemKind::kHost,
+                                static_cast<hipStream_t>(stream), flags, num_selected_device));
+  });
+}
+char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp) { return fp ? DupString(fp->fp->DumpIR()) : nullptr; }
+void gdv_filter_project_free(gdv_filter_project_t* fp) { delete fp; }
+
 // ---------------------------------------------------------------- JNI-shaped flat entry points
 namespace {
 // validity, [offsets,] data per field, in schema order
@@ -1099,6 +1149,20 @@ int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const
   SelectionMode mode;
   if (!ToSelectionMode(selection_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
   return Check(PrecompileProjector(schema->fields, ex, mode));
+  });
+}
+int gdv_precompile_filter_project(const gdv_schema_t* schema, gdv_expression_t* condition, gdv_expression_t* const* exprs,
+                                  int num_exprs, int index_mode) {
+  return Guarded([&]() -> int {
+  if (!schema || !condition || !condition->expr || !exprs || num_exprs <= 0) return Fail(Status::Invalid("null argument"));
+  SelectionMode mode;
+  if (!ToSelectionMode(index_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<ExpressionPtr> ex;
+  for (int i = 0; i < num_exprs; i++) {
+    if (!exprs[i] || !exprs[i]->expr) return Fail(Status::Invalid("Expression cannot be null"));
+    ex.push_back(exprs[i]->expr);
+  }
+  return Check(PrecompileFilterProject(schema->fields, condition->expr, ex, mode));
   });
 }
 int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* condition) {

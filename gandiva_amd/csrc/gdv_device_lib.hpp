@@ -2329,4 +2329,97 @@ GDV_DEV gdv_uint64 gdv_lb_wait(const gdv_uint64* pre, gdv_int64 ntiles, gdv_int6
     }
   }
 }
+// ------------------------------------------------------------------ fused filter -> project (K2F, round 4)
+// ONE pass: predicate, the output base of every workgroup tile by a decoupled look-back over the
+// workgroup tiles' selected-row counts, projections of the selected rows stored compacted (and the
+// selection vector itself, if asked for).  A workgroup tile's granule: bits 63..62 = status (0
+// nothing, 1 the tile's own count, 2 the inclusive prefix through the tile), bits 61..0 = value;
+// relaxed agent-scope atomics, the granule is its own flag.  ONE wave per workgroup looks back (the
+// waves' counts meet in LDS first): tools/proto/k2_proto.hip measured the per-wave window at 4.3 ms
+// and this workgroup-level form at 3.56 ms on the 10^9-row filter (profiles/r02_k2_singlepass_proto.txt).
+// Workgroups are dispatched in index order and wait only for lower indices: no deadlock.
+#define GDV_FP_AGG (1ull << 62)
+#define GDV_FP_PFX (2ull << 62)
+#define GDV_FP_VAL ((1ull << 62) - 1)
+// Exclusive prefix of `agg` over tiles [0, tile); wave-uniform; all 64 lanes call it.  Aggregates are
+// workgroup-tile counts (< 2^25): 64 of them sum in 32 bits; the prefix value is taken apart.
+GDV_DEV gdv_uint64 gdv_fp_lookback(gdv_uint64* state, gdv_int64 tile, gdv_uint32 agg, int lane, gdv_uint32* err) {
+  if (tile == 0) {
+    if (lane == 0) gdv_lb_store(state, GDV_FP_PFX | agg);
+    return 0;
+  }
+  if (lane == 0) gdv_lb_store(state + tile, GDV_FP_AGG | agg);
+  gdv_uint64 excl = 0;
+  gdv_int64 pos = tile - 1;
+  gdv_uint64 since = 0;
+  for (gdv_uint32 spins = 0;; spins++) {
+    const gdv_int64 idx = pos - lane;
+    const gdv_uint64 s = idx >= 0 ? gdv_lb_load(state + idx) : GDV_FP_PFX;  // a virtual prefix 0 before tile 0
+    const gdv_uint32 st = (gdv_uint32)(s >> 62);
+    const gdv_uint64 missing = __ballot(st == 0);
+    const gdv_uint64 pmask = __ballot(st == 2);
+    // window = lanes up to and including the nearest prefix (all 64 when there is none)
+    const int fp = pmask ? __builtin_ctzll(pmask) : 63;
+    const gdv_uint64 need = fp == 63 ? ~0ull : ((2ull << fp) - 1);
+    if (missing & need) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 4095u) == 4095u) {  // bounded by wall clock, like the scanner shape's hand-off
+        const gdv_uint64 now = __builtin_amdgcn_s_memrealtime();
+        if (since == 0) since = now;
+        else if (now - since > GDV_LB_STALL_TICKS) {
+          if (lane == 0) atomicOr(err, GDV_ERR_STALL);
+          return 0;
+        }
+      }
+      continue;
+    }
+    const gdv_uint64 v = lane <= fp ? (s & GDV_FP_VAL) : 0;
+    const gdv_uint64 pv = pmask ? (((gdv_uint64)(gdv_uint32)__builtin_amdgcn_readlane((gdv_uint32)(v >> 32), fp) << 32) |
+                                   (gdv_uint32)__builtin_amdgcn_readlane((gdv_uint32)v, fp)) : 0;
+    excl += pv + (gdv_uint32)gdv_wave_sum((pmask && lane == fp) ? 0 : (gdv_int32)(gdv_uint32)v);
+    if (pmask) break;
+    pos -= 64;
+  }
+  if (lane == 0) gdv_lb_store(state + tile, GDV_FP_PFX | (excl + agg));
+  return excl;
+}
+// rank of this lane among the set bits of a wave-uniform mask (bits below its own)
+GDV_DEV int gdv_rank_below(gdv_uint64 m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((gdv_uint32)(m >> 32), __builtin_amdgcn_mbcnt_lo((gdv_uint32)m, 0));
+}
+// The bits of `word` at the set positions of `fm`, packed into the low cnt = popcount(fm) bits
+// (wave-uniform result): the compacted validity / bool word of the selected rows of one sub-tile.
+// Selected lanes send their bit to lane `rank`, the others to the lanes behind (a full permutation:
+// every lane is written exactly once), one ds_permute through the LDS crossbar, no LDS memory.
+GDV_DEV gdv_uint64 gdv_compact_word(gdv_uint64 word, gdv_uint64 fm, int below, int cnt, int lane) {
+  const gdv_uint64 ones = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
+  if ((fm & ~word) == 0) return ones;  // wave-uniform: every selected row's bit is set
+  const bool sel = (fm >> lane) & 1;
+  const int dest = sel ? below : cnt + (lane - below);
+  const int got = __builtin_amdgcn_ds_permute(dest << 2, (int)((word >> lane) & 1));
+  return __ballot(got != 0) & ones;
+}
+// Output bitmap words of a wave tile, one per lane: lane j holds word (first >> 6) + j, `first` = the
+// tile's first output position.  Appends the low `cnt` bits of the wave-uniform `bits` at output
+// position `at` (>= first; everything a wave appends is contiguous).
+GDV_DEV gdv_uint64 gdv_bits_append(gdv_uint64 acc, gdv_int64 first, gdv_int64 at, gdv_uint64 bits, int cnt, int lane) {
+  if (cnt == 0) return acc;
+  const gdv_int64 q = at - (first & ~63ll);   // bit position relative to the tile's first word
+  const int w = (int)(q >> 6), s = (int)(q & 63);
+  if (lane == w) acc |= bits << s;
+  if (lane == w + 1 && s != 0) acc |= bits >> (64 - s);
+  return acc;
+}
+// ... and stores them: a word that lies entirely inside [first, first + total) belongs to this wave
+// alone (plain store); the first and the last word may be shared with the neighbouring tiles and are
+// OR-ed into the pre-zeroed buffer.
+GDV_DEV void gdv_bits_flush(gdv_uint64* bm, gdv_uint64 acc, gdv_int64 first, gdv_int64 total, int lane) {
+  if (total <= 0) return;
+  const gdv_int64 w0 = first >> 6, w1 = (first + total - 1) >> 6;
+  const gdv_int64 w = w0 + lane;
+  if (w > w1) return;
+  const bool whole = w * 64 >= first && (w + 1) * 64 <= first + total;
+  if (whole) bm[w] = acc;
+  else if (acc != 0) atomicOr((unsigned long long*)(bm + w), (unsigned long long)acc);
+}
 #endif  // GDV_HOST_BUILD

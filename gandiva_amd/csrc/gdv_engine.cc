@@ -1457,6 +1457,145 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   return Status::OK();
 }
 
+// ------------------------------------------------------------------ fused filter -> project
+
+Status FilterProject::Make(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
+                           SelectionMode index_mode, const Configuration& config, std::shared_ptr<FilterProject>* out) {
+  (void)config;
+  if (out == nullptr) return Status::Invalid("FilterProject::Make: null output pointer");
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  // materialised values (concat / castVARCHAR ...) need a first stage: the chain handles them
+  StagedExpressions staged;
+  std::vector<ExpressionPtr> all = exprs;
+  all.push_back(condition);
+  StageMaterialisedValues(schema, all, &staged);
+  if (!staged.pre.empty()) return Status::CodeGenError("fused filter-project: two-stage plans take the filter + projector chain");
+  auto fp = std::make_shared<FilterProject>();
+  fp->schema_ = schema;
+  GDV_RETURN_NOT_OK(PlanFilterProject(schema, condition, exprs, index_mode, CodegenOptions::FromEnv(), &fp->plan_));
+  fp->raises_ = fp->plan_.exprs_raise;
+  const PlanDeviceState* st = nullptr;
+  GDV_RETURN_NOT_OK(fp->states_.Get(fp->plan_, &st));
+  *out = fp;
+  return Status::OK();
+}
+
+Status FilterProject::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs,
+                               int num_outs, void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
+                               hipStream_t stream, uint32_t flags, void* count_out) const {
+  if (num_rows < 0) return Status::Invalid("negative row count");
+  if (num_outs != num_outputs() || (num_outs > 0 && outs == nullptr))
+    return Status::Invalid("number of output buffers does not match the number of expressions");
+  const SelectionMode mode = plan_.mode;
+  const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : mode == SelectionMode::kUInt64 ? 8 : 0;
+  if (w != 0) {
+    if (out_indices == nullptr && num_rows > 0) return Status::Invalid("Selection vector cannot be null");
+    if (max_slots < num_rows)
+      return Status::Invalid("Selection vector too small: max slots " + std::to_string(max_slots) + " < rows " +
+                             std::to_string(num_rows));
+    if (w == 2 && num_rows > 65536) return Status::Invalid("uint16 selection vector cannot address " + std::to_string(num_rows) + " rows");
+    if (w == 4 && num_rows > (int64_t(1) << 32)) return Status::Invalid("uint32 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  }
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  const PlanDeviceState* dev = nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+  bool async = (flags & kEvalAsync) != 0 && mem == MemKind::kDevice && !raises_ && count_out != nullptr;
+
+  ArgBlock args(plan_.layout);
+  Staging st;
+  DeviceBuffer scratch;                      // look-back granules | count | error word
+  std::vector<DeviceBuffer> staged(mem == MemKind::kHost ? 2 * num_outs + 1 : 0);  // host path: results are produced in HBM first
+  StreamDrain drain{stream, !async};         // declared last: drains before any pooled block is freed
+  if (num_rows == 0) {
+    if (num_selected != nullptr) *num_selected = 0;
+    if (count_out != nullptr) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(count_out, 0, 8, stream));
+    return Status::OK();
+  }
+  GDV_RETURN_NOT_OK(BindInputs(plan_, schema_, cols, num_cols, num_rows, mem, stream, &args, &st));
+  BindLiterals(plan_, dev->consts, &args);
+  if (!st.buffers.empty()) { async = false; drain.armed = true; }
+  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
+
+  const int64_t rows_per_wg = 64 * static_cast<int64_t>(plan_.opts.subtiles) * plan_.opts.waves;
+  const int64_t grid = (num_rows + rows_per_wg - 1) / rows_per_wg;
+  if (grid > 0x7fffffff) return Status::Invalid("batch too large for the fused filter-project launch");
+  auto up = [](size_t v) { return (v + 255) & ~size_t{255}; };
+  const size_t state_b = up(static_cast<size_t>(grid) * 8);
+  GDV_RETURN_NOT_OK(scratch.Allocate(state_b + 256));
+  char* const base = scratch.as<char>();
+  // granules, count and error word start at zero (one memset)
+  GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(base, 0, state_b + 256, stream));
+  drain.armed = true;  // from here on an error return must wait for what was enqueued (re-disarmed on the async exit)
+  args.SetPtr(ArgLayout::kOffMask, base);
+  args.SetPtr(ArgLayout::kOffCounts, base + state_b);
+  args.SetPtr(ArgLayout::kOffErr, base + state_b + 64);
+
+  // outputs: the validity (and bool value) bitmaps are OR-ed into at tile boundaries -> pre-zeroed
+  std::vector<void*> dev_data(num_outs), dev_valid(num_outs);
+  for (int e = 0; e < num_outs; e++) {
+    const DataType& t = plan_.output_types[e];
+    const int64_t vbytes = Projector::ValidityBytes(num_rows), dbytes = Projector::DataBytes(t, num_rows);
+    if (mem == MemKind::kHost) {
+      const int64_t host_v = BytesForBits(num_rows), host_d = t.id == kBool ? BytesForBits(num_rows) : dbytes;
+      if (outs[e].validity == nullptr || outs[e].data == nullptr || outs[e].validity_size < host_v || outs[e].data_size < host_d)
+        return Status::Invalid("output buffer " + std::to_string(e) + " too small");
+      GDV_RETURN_NOT_OK(staged[2 * e].Allocate(std::max<int64_t>(vbytes, 8)));
+      GDV_RETURN_NOT_OK(staged[2 * e + 1].Allocate(std::max<int64_t>(dbytes, 8)));
+      dev_valid[e] = staged[2 * e].get();
+      dev_data[e] = staged[2 * e + 1].get();
+    } else {
+      if (outs[e].validity == nullptr || outs[e].data == nullptr || outs[e].validity_size < vbytes || outs[e].data_size < dbytes)
+        return Status::Invalid("output buffer " + std::to_string(e) + " too small (device buffers need 8-byte word granularity: " +
+                               std::to_string(vbytes) + " validity bytes, " + std::to_string(dbytes) + " data bytes)");
+      dev_valid[e] = outs[e].validity;
+      dev_data[e] = outs[e].data;
+    }
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_valid[e], 0, vbytes, stream));
+    if (t.id == kBool) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(dev_data[e], 0, dbytes, stream));
+    args.SetOutData(e, dev_data[e]);
+    args.SetOutValid(e, dev_valid[e]);
+  }
+  void* dev_idx = out_indices;
+  if (w != 0 && mem == MemKind::kHost) {
+    GDV_RETURN_NOT_OK(staged[2 * num_outs].Allocate(num_rows * w));
+    dev_idx = staged[2 * num_outs].get();
+  }
+  args.SetPtr(ArgLayout::kOffSel, dev_idx);
+  GDV_RETURN_NOT_OK(st.FlushIn(stream));
+
+  EvalTrace trace("filter-project", plan_.kernel_name, num_rows, stream);
+  GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+  const char* count_dev = base + state_b;
+  if (count_out != nullptr) GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(count_out, count_dev, 8, hipMemcpyDefault, stream));
+  if (async) {
+    if (num_selected != nullptr) *num_selected = -1;
+    scratch.release_after(stream);
+    drain.armed = false;
+    return Status::OK();
+  }
+  int64_t count = 0;
+  uint32_t err_bits = 0;
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&count, count_dev, 8, hipMemcpyDeviceToHost, stream));
+  GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, base + state_b + 64, 4, hipMemcpyDeviceToHost, stream));
+  GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  if (mem == MemKind::kHost && count > 0) {
+    for (int e = 0; e < num_outs; e++) {
+      const DataType& t = plan_.output_types[e];
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].validity, dev_valid[e], BytesForBits(count), hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], t.id == kBool ? BytesForBits(count) : count * t.byte_width(),
+                                           hipMemcpyDeviceToHost, stream));
+    }
+    if (w != 0) GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(out_indices, dev_idx, count * w, hipMemcpyDeviceToHost, stream));
+    GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  }
+  drain.armed = false;
+  if (num_selected != nullptr) *num_selected = count;
+  return Status::OK();
+}
+
 // ------------------------------------------------------------------ precompile (no device)
 
 Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
@@ -1494,6 +1633,14 @@ Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition) {
   } else {
     GDV_RETURN_NOT_OK(PlanFilter(schema, condition, CodegenOptions::FromEnv(), &plan));
   }
+  std::vector<char> code;
+  return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
+}
+
+Status PrecompileFilterProject(const Schema& schema, const ExpressionPtr& condition,
+                               const std::vector<ExpressionPtr>& exprs, SelectionMode index_mode) {
+  KernelPlan plan;
+  GDV_RETURN_NOT_OK(PlanFilterProject(schema, condition, exprs, index_mode, CodegenOptions::FromEnv(), &plan));
   std::vector<char> code;
   return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
 }

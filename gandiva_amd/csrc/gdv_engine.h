@@ -208,10 +208,47 @@ class Filter {
   mutable std::vector<std::atomic<int64_t>> stage_hints_;
 };
 
+// Filter -> SelectionVector -> Projector(selection) in ONE kernel (round 4): the condition, the
+// output base of every workgroup tile (decoupled look-back) and the projections of the selected
+// rows, stored compacted — the batch is read once (gdv_planner.cc, PlanFilterProject).  Results are
+// bit-identical to Filter::Evaluate followed by a selection-mode Projector::Evaluate.  Fixed-width /
+// bool outputs over fixed-width columns; Make returns CodeGenError for anything else and callers
+// chain the two operators (gandiva::FilterProject and gandiva_amd.make_filter_project do).
+class FilterProject {
+ public:
+  // index_mode: element type of the selection vector the evaluation ALSO emits; kNone = none.
+  static Status Make(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
+                     SelectionMode index_mode, const Configuration& config, std::shared_ptr<FilterProject>* out);
+
+  // outs[e]: buffers for up to num_rows rows (the count is only known afterwards).  out_indices
+  // (max_slots >= num_rows elements of the index mode) may be null when index_mode is kNone.
+  // *num_selected = rows produced.  flags & kEvalAsync (device buffers): everything is enqueued, the
+  // count lands in *count_out (8 bytes of device or pinned memory) in stream order, *num_selected = -1
+  // and device-side errors (divide by zero ...) are NOT reported — plans that can raise wait anyway.
+  Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs, int num_outs,
+                  void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem, hipStream_t stream,
+                  uint32_t flags = 0, void* count_out = nullptr) const;
+
+  const Schema& schema() const { return schema_; }
+  const KernelPlan& plan() const { return plan_; }
+  int num_outputs() const { return static_cast<int>(plan_.output_types.size()); }
+  const DataType& output_type(int i) const { return plan_.output_types[i]; }
+  SelectionMode index_mode() const { return plan_.mode; }
+  std::string DumpIR() const { return plan_.ir; }
+
+ private:
+  Schema schema_;
+  KernelPlan plan_;
+  bool raises_ = false;  // some expression can raise: asynchronous calls wait for the error word
+  PlanDeviceStates states_;
+};
+
 // Builds the plan and compiles it to a gfx950 code object without touching a device
 // (used by the build check and to pre-populate the on-disk kernel cache).
 Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
                            SelectionMode mode);
 Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition);
+Status PrecompileFilterProject(const Schema& schema, const ExpressionPtr& condition,
+                               const std::vector<ExpressionPtr>& exprs, SelectionMode index_mode);
 
 }  // namespace gdv

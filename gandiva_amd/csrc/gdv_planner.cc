@@ -1021,7 +1021,7 @@ struct Assembler {
       src << "// @expr_" << i << " = " << expr_strings[i] << "\n";
     // rows of the batch: selection-mode plans may take the slot count from device memory (aux2: an
     // asynchronous Filter left it there), so a filter -> project chain needs no host round trip
-    if (plan->mode != SelectionMode::kNone)
+    if (plan->mode != SelectionMode::kNone && plan->kind != KernelKind::kFilterProject)
       // (clamped to [0, n]: n is the capacity the outputs and the grid were sized for — a stale or
       // foreign count word must not make the kernel write past them)
       src << "#define GDV_ROWS(A) ((A).aux2 != 0 ? gdv_clamp_rows(*(const gdv_int64*)(A).aux2, (A).n) : (A).n)\n";
@@ -2566,6 +2566,233 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
   }
   return Assemble(cg, plan, {condition->ToString()}, accs, "  gdv_uint32 fcount = 0;\n",
                   after.str());
+}
+
+// ------------------------------------------------------------------ fused filter -> project (K2F)
+//
+// Filter::Evaluate followed by a selection-mode Projector::Evaluate reads most lines of the
+// predicate's columns twice (at a selectivity of 1/8 nearly every 128-byte line holds a selected
+// row: 2.86 + 2.94 ms at 10^9 rows, profiles/r03_filter_project_chain.txt).  This plan does both in
+// ONE pass over the batch:
+//   1  all loads of the wave tile (predicate AND projection columns), no control flow in between
+//   2  the predicate: one 64-bit match word per sub-tile, the tile's selected-row count
+//   3  output base of the workgroup tile: the waves' counts meet in LDS, ONE wave looks back over
+//      the earlier workgroup tiles (gdv_fp_lookback)
+//   4  the projections, evaluated from the registers phase 1 filled; functions that can raise run on
+//      selected rows only; the values of selected rows are stored at  base + rank  (compacted in
+//      the output: a wave's stores cover one contiguous run of elements), their validity / bool
+//      bits are compacted per sub-tile (gdv_compact_word) and leave as whole bitmap words; the
+//      row indices (the SelectionVector) are written the same way when the plan asks for them.
+// The result equals Filter::Evaluate + Projector::Evaluate(batch, selection_vector) bit for bit.
+// Fixed-width (and bool) outputs over fixed-width columns; anything else -> CodeGenError and the
+// callers chain the two operators as before.
+Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
+                         SelectionMode index_mode, const CodegenOptions& opts, KernelPlan* plan) {
+  AblationScope ablation_scope(opts.ablation);
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
+  if (condition->root()->return_type().id != kBool)
+    return Status::ValidationError("Filter condition must be of type boolean");
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+    if (e->result().type.is_varlen())
+      return Status::CodeGenError("fused filter-project: var-len outputs take the filter + projector chain");
+  }
+  plan->kind = KernelKind::kFilterProject;
+  plan->mode = index_mode;  // width of the emitted row indices; kNone: no SelectionVector output
+  plan->opts = opts;
+  CodeGen cg(schema, SelectionMode::kNone, opts);
+  // ---- phase 2: the predicate (row mode; a null predicate does not select the row)
+  Val c;
+  cg.Stmt("// @expr_0 (filter condition)");
+  GDV_RETURN_NOT_OK(cg.Gen(*condition->root(), "", &c));
+  const std::string pass = CodeGen::AndExpr(cg.LaneValid(c), c.v);
+  cg.Stmt("fm[u] = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
+  cg.Stmt("fcount += (gdv_uint32)__popcll(fm[u]);");
+  const std::string cond_body = cg.body_.str();
+  // ---- phase 4: the projections.  Temporaries of the predicate loop are out of scope: common
+  // sub-expressions are shared among the projections only.
+  cg.body_.str("");
+  cg.cse_.clear();
+  std::vector<std::string> strings{condition->ToString()};
+  std::map<std::string, int> bitmap_of;   // compacted-word expression -> accumulator index
+  std::vector<std::string> flushes;       // after the row loop: one per output bitmap
+  auto bits_acc = [&](const std::string& word_expr) {
+    auto it = bitmap_of.find(word_expr);
+    if (it != bitmap_of.end()) return it->second;
+    const int k = static_cast<int>(bitmap_of.size());
+    bitmap_of[word_expr] = k;
+    cg.Stmt("bacc" + std::to_string(k) + " = gdv_bits_append(bacc" + std::to_string(k) + ", pos0, pos0 + run, gdv_compact_word(" +
+            word_expr + ", fmu, below, cnt, lane), cnt, lane);");
+    return k;
+  };
+  for (size_t e = 0; e < exprs.size(); e++) {
+    Val v;
+    cg.Stmt("// @expr_" + std::to_string(e + 1));
+    GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "fsel", &v));
+    if (!v.pieces.empty() || v.opaque) return Status::CodeGenError("fused filter-project: materialised values take the chain");
+    const DataType& t = exprs[e]->result().type;
+    plan->output_types.push_back(t);
+    strings.push_back(exprs[e]->ToString());
+    const std::string E = std::to_string(e);
+    if (t.id == kBool) {
+      const int k = bits_acc("__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
+      flushes.push_back("  gdv_bits_flush((gdv_uint64*)A.out[" + E + "].data, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
+    } else {
+      cg.Stmt("if (fsel) out" + E + "[opos] = (" + t.CType() + ")" + v.v + ";");
+    }
+    std::string word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
+    if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
+    const int k = bits_acc(word);
+    flushes.push_back("  gdv_bits_flush(A.out[" + E + "].valid, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
+  }
+  const std::string proj_body = cg.body_.str();
+  for (size_t k = 0; k < cg.input_fields_.size(); k++)
+    if (schema[cg.input_fields_[k]].type.is_varlen())
+      return Status::CodeGenError("fused filter-project: var-len columns take the filter + projector chain");
+
+  plan->input_fields = cg.input_fields_;
+  plan->input_needs_values = cg.needs_values_;
+  plan->input_needs_validity = cg.needs_validity_;
+  plan->can_raise = true;  // (the look-back's stall bit travels in the error word)
+  plan->exprs_raise = cg.can_raise_;
+  plan->layout.n_in = static_cast<int>(plan->input_fields.size());
+  plan->layout.n_out = static_cast<int>(plan->output_types.size());
+  const int nin = plan->layout.n_in;
+  // loads in flight: as a predicate kernel, within 512 bytes of input values per lane; the match
+  // words of the tile live in scalar registers (2 per sub-tile)
+  if (!plan->opts.subtiles_forced) {
+    int in_bytes = 0;
+    for (int k = 0; k < nin; k++)
+      if (cg.needs_values_[k]) in_bytes += std::max(4, schema[cg.input_fields_[k]].type.byte_width());
+    int u = 16;
+    while (u > 2 && u * std::max(in_bytes, 1) > 384) u >>= 1;
+    plan->opts.subtiles = u;
+  }
+  if (!plan->opts.waves_forced) plan->opts.waves = 4;
+
+  Assembler as{cg, plan, {}};
+  as.Header(strings);
+  std::ostringstream& s = as.src;
+  s << "template <bool FULL>\n"
+    << "GDV_DEV void gdv_fused_tile(const gdv_args& A, const gdv_int64 tile, const int lane, const int wave,\n"
+    << "                            gdv_uint32* wg_cnt, gdv_uint64* wg_excl) {\n"
+    << "  gdv_ctx ctx{A.err};\n"
+    << "  (void)ctx;\n"
+    << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
+    << "  (void)gdv_cst;\n"
+    << "  const gdv_int64 n = GDV_ROWS(A);\n"
+    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;  // this wave's first 64-row word\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = schema[plan->input_fields[k]].type;
+    if (t.id != kBool && cg.needs_values_[k])
+      s << "  const " << t.CType() << "* __restrict__ in" << k << " = (const " << t.CType() << "*)A.in[" << k << "].data;\n";
+  }
+  for (size_t e = 0; e < plan->output_types.size(); e++) {
+    const DataType& t = plan->output_types[e];
+    if (t.id != kBool)
+      s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
+  }
+  if (index_mode != SelectionMode::kNone)
+    s << "  " << SelCType(index_mode) << "* __restrict__ selv = (" << SelCType(index_mode) << "*)A.sel;\n";
+  s << "  // ---- phase 1: all loads of this wave's GDV_U sub-tiles, issued back to back\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = schema[plan->input_fields[k]].type;
+    if (t.id == kBool) {
+      if (cg.needs_values_[k]) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+    } else if (cg.needs_values_[k]) {
+      s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
+    }
+    if (cg.needs_validity_[k]) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+  }
+  const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+    << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+    << "    const bool live = FULL || row < n;\n"
+    << "    (void)live;\n";
+  for (int k = 0; k < nin; k++) {
+    const DataType& t = schema[plan->input_fields[k]].type;
+    if (t.id != kBool && cg.needs_values_[k])
+      s << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
+  }
+  s << "  }\n";
+  auto row_prologue = [&] {
+    s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "      const bool live = FULL || row < n;\n"
+      << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
+      << "      (void)livemask; (void)row; (void)live;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = schema[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+    }
+  };
+  s << "  // ---- phase 2: the predicate -> one match word per sub-tile (scalar registers)\n"
+    << "  gdv_uint64 fm[GDV_U];\n"
+    << "  gdv_uint32 fcount = 0;\n"
+    << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
+  row_prologue();
+  s << "      const bool fsel = true;  // (the predicate itself runs on every live row)\n      (void)fsel;\n"
+    << cond_body << "    }\n  }\n"
+    << "  // ---- phase 3: output base of this wave: the workgroup's waves meet in LDS, wave 0 looks back\n"
+    << "  if (lane == 0) wg_cnt[wave] = fcount;\n"
+    << "  __syncthreads();\n"
+    << "  gdv_uint32 before = 0, wg_total = 0;\n"
+    << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
+    << "    const gdv_uint32 cw = wg_cnt[w];\n"
+    << "    wg_total += cw;\n"
+    << "    if (w < wave) before += cw;\n"
+    << "  }\n"
+    << "  if (wave == 0) {\n"
+    << "    const gdv_uint64 e = gdv_fp_lookback(A.mask, tile, wg_total, lane, A.err);\n"
+    << "    if (lane == 0) {\n"
+    << "      *wg_excl = e;\n"
+    << "      if (tile == (gdv_int64)gridDim.x - 1) *(gdv_int64*)A.counts = (gdv_int64)(e + wg_total);  // the batch's selected-row count\n"
+    << "    }\n"
+    << "  }\n"
+    << "  __syncthreads();\n"
+    << "  const gdv_int64 pos0 = (gdv_int64)*wg_excl + before;  // output position of this wave's first selected row\n"
+    << "  // ---- phase 4: the projections of the selected rows, stored compacted\n"
+    << "  gdv_int64 run = 0;\n";
+  for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;\n";
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
+  row_prologue();
+  s << "      const gdv_uint64 fmu = fm[u];\n"
+    << "      const int cnt = (int)__popcll(fmu);\n"
+    << "      const bool fsel = (fmu >> lane) & 1;\n"
+    << "      const int below = gdv_rank_below(fmu);\n"
+    << "      const gdv_int64 opos = pos0 + run + below;  // where this lane's row lands if it is selected\n"
+    << "      (void)opos; (void)cnt; (void)below;\n";
+  if (index_mode != SelectionMode::kNone)
+    s << "      if (fsel) selv[opos] = (" << SelCType(index_mode) << ")row;\n";
+  s << proj_body
+    << "      run += cnt;\n"
+    << "    }\n  }\n";
+  for (auto& f : flushes) s << f;
+  s << "}\n\n"
+    << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
+    << "  __shared__ gdv_uint32 wg_cnt[GDV_WAVES];\n"
+    << "  __shared__ gdv_uint64 wg_excl;\n"
+    << "  const int lane = threadIdx.x & 63;\n"
+    << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+    << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_U x 64 rows; index order = row order\n"
+    << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
+    << "  if ((tile + 1) * (GDV_WAVES * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true>(A, tile, lane, wave, wg_cnt, &wg_excl);\n"
+    << "  else gdv_fused_tile<false>(A, tile, lane, wave, wg_cnt, &wg_excl);\n"
+    << "}\n";
+  std::string text = s.str();
+  uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
+  char name[64];
+  snprintf(name, sizeof(name), "gdv_k_%016llx", static_cast<unsigned long long>(h));
+  plan->kernel_name = name;
+  for (size_t pos = text.find("GDV_KERNEL_NAME"); pos != std::string::npos; pos = text.find("GDV_KERNEL_NAME", pos))
+    text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
+  plan->source = text;
+  plan->ir = text;
+  return Status::OK();
 }
 
 // ------------------------------------------------------------------ two-stage plans

@@ -21,7 +21,7 @@ namespace gdv {
 
 enum class SelectionMode : int32_t { kNone = 0, kUInt16 = 1, kUInt32 = 2, kUInt64 = 3 };
 
-enum class KernelKind { kProject, kFilter };
+enum class KernelKind { kProject, kFilter, kFilterProject };
 
 // Code-generation knobs (part of the cache key).  Defaults come from measurements on
 // MI355X; environment variables GDV_U / GDV_NT / GDV_WAVES override
@@ -80,6 +80,7 @@ struct KernelPlan {
   std::vector<uint64_t> literals;  // fixed-width literal values -> gdv_args::lit (kernel arguments)
   std::string const_block;         // string literals, LIKE patterns, IN tables -> device memory (aux0)
   bool can_raise = false;          // kernel may set error bits
+  bool exprs_raise = false;        // fused filter-project: some EXPRESSION can raise (can_raise is always set there: the look-back's stall bit)
   // Some output is utf8/binary: single launch, workgroup 0 scans the tile totals (granules in
   // `mask`, grand totals in `counts`); workers are workgroups 1.. (gdv_planner.cc, string plans)
   bool has_varlen_output = false;
@@ -114,6 +115,13 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
                      int compact_from = 0x7fffffff);
 Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
                   const CodegenOptions& opts, KernelPlan* out);
+
+// Fused filter -> project (round 4): ONE kernel evaluates the condition, finds every workgroup tile's
+// output base by a decoupled look-back and stores the projections of the selected rows compacted
+// (+ the selection vector when index_mode != kNone).  plan->mode = index_mode.  CodeGenError for
+// plans the fused shape does not take (var-len columns or outputs): callers chain Filter + Projector.
+Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
+                         SelectionMode index_mode, const CodegenOptions& opts, KernelPlan* out);
 
 Status ValidateExpression(const Schema& schema, const Expression& expr);
 

@@ -859,6 +859,141 @@ def make_filter(schema, condition, configuration=None):
     return Filter(out, schema, condition)
 
 
+# ---------------------------------------------------------------------------- Filter -> Projector, fused
+
+class FilterProject:
+    """Filter.evaluate -> SelectionVector -> Projector.evaluate(batch, selection) as ONE operator
+    (gdv_filter_project_*): a single kernel reads the batch once and writes the projections of the
+    selected rows, compacted, plus the selection vector itself when ``index_dtype`` is given.  Plans
+    the fused kernel does not take (var-len columns / outputs) are evaluated as the chain of a Filter
+    and a selection-mode Projector — same results, same interface (``fused`` tells which)."""
+
+    def __init__(self, handle, schema, condition, exprs, mode, chain=None):
+        self._h, self._schema, self._condition, self._exprs, self._mode = handle, schema, condition, exprs, mode
+        self._chain = chain  # (Filter, Projector) when the plan is not fused
+        if handle is not None:
+            lib = _capi.lib()
+            self._out_types = [from_gdv_type(lib.gdv_filter_project_output_type(handle, i))
+                               for i in range(lib.gdv_filter_project_num_outputs(handle))]
+        else:
+            self._out_types = chain[1]._out_types
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _capi.lib().gdv_filter_project_free(self._h)
+        except Exception:
+            pass
+
+    @property
+    def fused(self):
+        return self._h is not None
+
+    @property
+    def llvm_ir(self):
+        if self._h is None:
+            return self._chain[0].llvm_ir + self._chain[1].llvm_ir
+        return _capi.take_string(_capi.lib().gdv_filter_project_dump_ir(self._h))
+
+    def evaluate(self, batch):
+        """Host buffers in, host pyarrow arrays out: ``(arrays, selection_vector or None)``."""
+        _check_batch(batch, self._schema)
+        if self._h is None:
+            flt, proj = self._chain
+            sel = flt.evaluate(batch, None, {1: "int16", 2: "int32", 3: "int64"}[self._mode or 2])
+            return proj.evaluate(batch, sel), (sel if self._mode else None)
+        lib = _capi.lib()
+        n = batch.num_rows
+        cols = (gdv_column_t * max(batch.num_columns, 1))(*[_column_of_array(a) for a in batch.columns])
+        n_out = len(self._out_types)
+        outs = (gdv_out_column_t * n_out)()
+        holders = []
+        for i, t in enumerate(self._out_types):
+            v = pa.allocate_buffer(_pad64(max((n + 7) // 8, 1)))
+            d = pa.allocate_buffer(_pad64(max((n + 7) // 8 if pa.types.is_boolean(t) else n * t.bit_width // 8, 1)))
+            holders.append((v, d))
+            outs[i].validity, outs[i].validity_size = v.address, v.size
+            outs[i].data, outs[i].data_size = d.address, d.size
+        idx = None
+        if self._mode:
+            idx = np.empty(max(n, 1), dtype=_SEL_DTYPE[self._mode][1])
+        count = C.c_int64(0)
+        _check(lib.gdv_filter_project_evaluate(self._h, n, cols, batch.num_columns, outs, n_out,
+                                               C.c_void_p(idx.ctypes.data if idx is not None else 0), n, C.byref(count),
+                                               None, GDV_MEM_HOST, None, 0))
+        k = count.value
+        arrays = [pa.Array.from_buffers(t, k, [v, d]) for t, (v, d) in zip(self._out_types, holders)]
+        return arrays, (SelectionVector(self._mode, idx, k) if self._mode else None)
+
+    def evaluate_device(self, dbatch, outputs=None, indices=None, stream=None, sync=True):
+        """HBM-resident: returns ``(DeviceColumns, SelectionVector or None)``.  The columns are sized for
+        ``dbatch.num_rows`` rows (the count is known only afterwards) and carry the count: ``num_rows`` /
+        ``to_arrow`` trim to it.  sync=False (plans that cannot raise): nothing waits, the count stays on the
+        device until someone asks."""
+        import torch
+        if self._h is None:
+            flt, proj = self._chain
+            sel = flt.evaluate_device(dbatch, {1: "int16", 2: "int32", 3: "int64"}[self._mode or 2], out=indices,
+                                      stream=stream, sync=sync)
+            return proj.evaluate_device(dbatch, selection=sel, outputs=outputs, stream=stream, sync=sync), (sel if self._mode else None)
+        lib = _capi.lib()
+        n = dbatch.num_rows
+        cols = (gdv_column_t * max(len(dbatch.columns), 1))(*[c._c() for c in dbatch.columns])
+        n_out = len(self._out_types)
+        vbytes = (n + 63) // 64 * 8
+        if outputs is None:
+            outputs = [DeviceColumn(t, n, torch.empty(_pad64(max(vbytes, 1)), dtype=torch.uint8, device="cuda"),
+                                    torch.empty(_pad64(max(vbytes if pa.types.is_boolean(t) else n * t.bit_width // 8, 1)),
+                                                dtype=torch.uint8, device="cuda")) for t in self._out_types]
+        outs = (gdv_out_column_t * n_out)()
+        for i, o in enumerate(outputs):
+            outs[i].validity, outs[i].validity_size = o.validity.data_ptr(), o.validity.numel()
+            outs[i].data, outs[i].data_size = o.data.data_ptr(), o.data.numel()
+        if self._mode and indices is None:
+            indices = torch.empty(max(n, 1), dtype={1: torch.int16, 2: torch.int32, 3: torch.int64}[self._mode], device="cuda")
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        count = C.c_int64(0)
+        _check(lib.gdv_filter_project_evaluate(self._h, n, cols, len(dbatch.columns), outs, n_out,
+                                               C.c_void_p(indices.data_ptr() if self._mode else 0),
+                                               indices.numel() if self._mode else 0, C.byref(count),
+                                               C.c_void_p(cnt.data_ptr()), GDV_MEM_DEVICE, C.c_void_p(stream),
+                                               0 if sync else GDV_EVAL_ASYNC))
+        pending = count.value < 0
+        for o in outputs:
+            o.length = n if pending else count.value
+            o.count_tensor = cnt if pending else None
+        sel = None
+        if self._mode:
+            sel = SelectionVector(self._mode, indices, None if pending else count.value, device=True, count_tensor=cnt)
+        self.last_count_tensor = cnt
+        return outputs, sel
+
+
+def make_filter_project(schema, condition, children, index_dtype=None, configuration=None):
+    """One operator for filter -> project.  ``index_dtype`` ("int16" / "int32" / "int64"): also emit the
+    selection vector.  Fused where the plan allows it, the Filter + Projector chain otherwise."""
+    if not isinstance(condition, Condition):
+        raise TypeError("make_filter_project expects a gandiva Condition")
+    mode = 0 if index_dtype is None else Filter._mode_of(index_dtype)
+    lib = _capi.lib()
+    sh = _make_schema(schema)
+    try:
+        out = C.c_void_p()
+        cfg = (configuration or Configuration())._c()
+        arr = (C.c_void_p * len(children))(*[e._h for e in children])
+        rc = lib.gdv_filter_project_make(sh, condition._h, arr, len(children), mode, C.byref(cfg), C.byref(out))
+    finally:
+        lib.gdv_schema_free(sh)
+    if rc == 40:  # CodeGenError: not a fused shape -> the chain
+        flt = make_filter(schema, condition, configuration)
+        proj = make_projector(schema, children, None, {0: "UINT32", 1: "UINT16", 2: "UINT32", 3: "UINT64"}[mode], configuration)
+        return FilterProject(None, schema, condition, children, mode, chain=(flt, proj))
+    _check(rc)
+    return FilterProject(out, schema, condition, children, mode)
+
+
 # ---------------------------------------------------------------------------- registry
 
 class FunctionSignature:

@@ -124,6 +124,7 @@ typedef struct gdv_node gdv_node_t;
 typedef struct gdv_expression gdv_expression_t; /* also used for conditions */
 typedef struct gdv_projector gdv_projector_t;
 typedef struct gdv_filter gdv_filter_t;
+typedef struct gdv_filter_project gdv_filter_project_t;
 
 /* gandiva::Configuration (PA:279-298). */
 typedef struct {
@@ -302,6 +303,32 @@ void gdv_filter_free(gdv_filter_t* f);
  * cached per (schema, condition): the setting applies to every holder of the same plan. */
 int gdv_filter_set_tuning(gdv_filter_t* f, const char* key, int64_t value);
 
+/* ---- Filter -> Projector in one pass (round 4) ---------------------------------------
+ * Replaces the caller-side chain of the reference (pyarrow/tests/test_gandiva.py:329-373:
+ * Filter::Evaluate -> SelectionVector -> Projector::Evaluate(batch, selection_vector)) by ONE kernel
+ * that reads the batch once: the condition, the output position of every selected row (decoupled
+ * look-back across workgroup tiles) and the projections of the selected rows, stored compacted.
+ * Results are bit-identical to the chain.  index_mode = GDV_SEL_UINT16/32/64: the selection vector is
+ * ALSO written to out_indices; GDV_SEL_NONE: only the projected columns are produced.
+ * make fails with GDV_CODE_GEN_ERROR for plans the fused shape does not take (var-len columns or
+ * outputs, materialised values): chain gdv_filter_* and gdv_projector_* as before.
+ * evaluate: outs[e] must hold num_rows rows (the count is known only afterwards; sizes as
+ * gdv_projector_output_sizes reports for num_rows rows); *num_selected receives the row count.
+ * GDV_EVAL_ASYNC (device buffers, num_selected_device given, plans that cannot raise): everything
+ * is enqueued on `stream`, the count lands in *num_selected_device (int64, device or pinned memory)
+ * in stream order and *num_selected is set to -1. */
+int gdv_filter_project_make(const gdv_schema_t* schema, gdv_expression_t* condition, gdv_expression_t* const* exprs,
+                            int num_exprs, int index_mode, const gdv_config_t* config /* NULL = default */,
+                            gdv_filter_project_t** out);
+int gdv_filter_project_num_outputs(const gdv_filter_project_t* fp);
+gdv_type_t gdv_filter_project_output_type(const gdv_filter_project_t* fp, int i);
+int gdv_filter_project_evaluate(const gdv_filter_project_t* fp, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                gdv_out_column_t* outs, int num_outs, void* out_indices /* NULL with GDV_SEL_NONE */,
+                                int64_t max_slots, int64_t* num_selected, void* num_selected_device /* may be NULL */,
+                                int mem_kind, void* stream, uint32_t flags);
+char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp);
+void gdv_filter_project_free(gdv_filter_project_t* fp);
+
 /* ---- function registry ------------------------------------------------------------ */
 int gdv_registry_size(void);
 /* name: borrowed pointer valid for the process lifetime; params: up to max_params entries
@@ -448,6 +475,8 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDe
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
                              int num_exprs, int selection_mode);
 int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* condition);
+int gdv_precompile_filter_project(const gdv_schema_t* schema, gdv_expression_t* condition, gdv_expression_t* const* exprs,
+                                  int num_exprs, int index_mode);
 /* Kernel identity (diagnostics, tests).  A fused kernel is named after a hash of its generated text
  * and of the device-library functions that text reaches — not of the whole library, so an edit of a
  * function a kernel never calls leaves its name (and every profile taken on it) alone.

@@ -32,6 +32,8 @@ def assert_bit_exact(got, want, what=""):
     (values under nulls are unspecified in Arrow and not compared)."""
     assert got.type == want.type, f"{what}: type {got.type} != {want.type}"
     assert len(got) == len(want), f"{what}: length {len(got)} != {len(want)}"
+    if len(got) == 0:
+        return
     gv, wv = validity_np(got), validity_np(want)
     if not np.array_equal(gv, wv):
         bad = np.flatnonzero(gv != wv)

@@ -61,3 +61,27 @@ print(f"filter -> project chain: {ms_sync:7.3f} ms with the count read back betw
 assert s.num_slots == k
 assert torch.equal(outs_cap[0].data[:8 * k].view(torch.int64), want)
 print("asynchronous chain verified against torch")
+
+# round 4: the same result from ONE kernel (gdv_filter_project_*: predicate + look-back + compacted projection)
+fp = gandiva.make_filter_project(W.c3_schema(), W.c3_condition(), [expr], "int32")
+assert fp.fused
+fo, fsel = fp.evaluate_device(db, indices=out)
+torch.cuda.synchronize()
+assert fsel.num_slots == k
+assert torch.equal(fo[0].data[:8 * k].view(torch.int64), want)
+for label, sync in (("synchronous", True), ("asynchronous", False)):
+    t = time.perf_counter()
+    for _ in range(5):
+        fo, fsel = fp.evaluate_device(db, outputs=fo, indices=out, sync=sync)
+    torch.cuda.synchronize()
+    print(f"fused filter-project ({label}): {(time.perf_counter() - t) / 5 * 1e3:7.3f} ms   (chain above: {ms_sync:.3f} / {ms_async:.3f} ms)")
+fp0 = gandiva.make_filter_project(W.c3_schema(), W.c3_condition(), [expr], None)
+fo0, _ = fp0.evaluate_device(db)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(5):
+    fo0, _ = fp0.evaluate_device(db, outputs=fo0, sync=False)
+torch.cuda.synchronize()
+print(f"fused filter-project without the selection vector: {(time.perf_counter() - t) / 5 * 1e3:7.3f} ms")
+assert torch.equal(fo0[0].data[:8 * k].view(torch.int64), want)
+print("fused results verified against torch")
