@@ -2609,8 +2609,9 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
   cg.Stmt("// @expr_0 (filter condition)");
   GDV_RETURN_NOT_OK(cg.Gen(*condition->root(), "", &c));
   const std::string pass = CodeGen::AndExpr(cg.LaneValid(c), c.v);
-  cg.Stmt("fm[u] = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
-  cg.Stmt("fcount += (gdv_uint32)__popcll(fm[u]);");
+  cg.Stmt("const gdv_uint64 fmw = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
+  cg.Stmt("fcount += (gdv_uint32)__popcll(fmw);");
+  cg.Stmt("fm = gdv_deposit_word(fm, u, fmw, lane);  // lane u keeps sub-tile u's match word (2 VGPRs, not 2 x GDV_U SGPRs)");
   const std::string cond_body = cg.body_.str();
   // ---- phase 4: the projections.  Temporaries of the predicate loop are out of scope: common
   // sub-expressions are shared among the projections only.
@@ -2671,7 +2672,10 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
     while (u > 2 && u * std::max(in_bytes, 1) > 384) u >>= 1;
     plan->opts.subtiles = u;
   }
-  if (!plan->opts.waves_forced) plan->opts.waves = 4;
+  // 8 waves per workgroup: half as many look-back participants as 4 (measured at 10^9 rows, C3 shape:
+  // 16 x 4: 4.45 / 4.10 ms with / without the selection vector, 16 x 8: 4.26 / 4.05, 16 x 16: 4.89 / 4.19,
+  // 8 x 8: 4.58 / 4.40 — profiles/r04_filter_project.txt)
+  if (!plan->opts.waves_forced) plan->opts.waves = 8;
 
   Assembler as{cg, plan, {}};
   as.Header(strings);
@@ -2730,8 +2734,8 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
       if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
     }
   };
-  s << "  // ---- phase 2: the predicate -> one match word per sub-tile (scalar registers)\n"
-    << "  gdv_uint64 fm[GDV_U];\n"
+  s << "  // ---- phase 2: the predicate -> one match word per sub-tile\n"
+    << "  gdv_uint64 fm = 0;\n"
     << "  gdv_uint32 fcount = 0;\n"
     << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
   row_prologue();
@@ -2760,7 +2764,7 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
   for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;\n";
   s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
   row_prologue();
-  s << "      const gdv_uint64 fmu = fm[u];\n"
+  s << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
     << "      const int cnt = (int)__popcll(fmu);\n"
     << "      const bool fsel = (fmu >> lane) & 1;\n"
     << "      const int below = gdv_rank_below(fmu);\n"

@@ -16,4 +16,6 @@ using FieldPtr = std::shared_ptr<arrow::Field>;
 using FieldVector = std::vector<FieldPtr>;
 using SchemaPtr = std::shared_ptr<arrow::Schema>;
 using ArrayVector = std::vector<ArrayPtr>;
+using ArrayDataPtr = std::shared_ptr<arrow::ArrayData>;
+using ArrayDataVector = std::vector<ArrayDataPtr>;
 }  // namespace gandiva

@@ -28,6 +28,17 @@ class Projector {
                   ArrayVector* output) const;
   Status Evaluate(const arrow::RecordBatch& batch, const SelectionVector* selection_vector,
                   arrow::MemoryPool* pool, ArrayVector* output) const;
+  // Caller-allocated outputs — what the JNI layer and any caller that keeps its result buffers
+  // (HBM-resident ones included) use.  [M]: restated from the lineage's projector.h as recalled; the
+  // .pxd does not bind these overloads.  output[i] is the ArrayData of expression i: type = the
+  // expression's result type, length = the number of output rows, buffers = {validity, data} for
+  // fixed-width types (validity >= ceil(rows / 8) bytes — 8 * ceil(rows / 64) for device buffers —,
+  // data >= rows * width) and {validity, offsets, data} for utf8 / binary (offsets >= (rows + 1) * 4
+  // bytes; the data buffer's size is the capacity: too small -> Invalid naming the bytes needed).
+  // All buffers must be mutable and live in the same memory domain as the batch.
+  Status Evaluate(const arrow::RecordBatch& batch, const ArrayDataVector& output) const;
+  Status Evaluate(const arrow::RecordBatch& batch, const SelectionVector* selection_vector,
+                  const ArrayDataVector& output) const;
   std::string DumpIR();
 
  private:

@@ -3,6 +3,7 @@
 #include <unordered_set>
 
 #include "gandiva/condition.h"
+#include "gandiva/decimal_scalar.h"
 #include "gandiva/node.h"
 
 namespace gandiva {
@@ -24,6 +25,8 @@ class TreeExprBuilder {
   static NodePtr MakeBinaryLiteral(const std::string& value);
   // unscaled 128-bit value as (high, low) words
   static NodePtr MakeDecimalLiteral(int64_t high, uint64_t low, int32_t precision, int32_t scale);
+  // [M] the lineage's decimal literal (tree_expr_builder.h as recalled; not bound by the .pxd)
+  static NodePtr MakeLiteral(const DecimalScalar128& value);
   static NodePtr MakeNull(DataTypePtr data_type);
 
   static NodePtr MakeField(FieldPtr field);
@@ -49,6 +52,12 @@ class TreeExprBuilder {
   static NodePtr MakeInExpressionTime32(NodePtr node, const std::unordered_set<int32_t>& constants);
   static NodePtr MakeInExpressionTime64(NodePtr node, const std::unordered_set<int64_t>& constants);
   static NodePtr MakeInExpressionTimeStamp(NodePtr node, const std::unordered_set<int64_t>& constants);
+  // [M] the lineage's remaining IN builders (as recalled; not bound by the .pxd).  Floating-point
+  // values compare by VALUE, as a hash set of floats does: -0.0 and +0.0 are one value, NaN equals nothing.
+  static NodePtr MakeInExpressionFloat(NodePtr node, const std::unordered_set<float>& constants);
+  static NodePtr MakeInExpressionDouble(NodePtr node, const std::unordered_set<double>& constants);
+  static NodePtr MakeInExpressionDecimal(NodePtr node, std::unordered_set<DecimalScalar128>& constants,
+                                         int32_t precision, int32_t scale);
 };
 
 }  // namespace gandiva

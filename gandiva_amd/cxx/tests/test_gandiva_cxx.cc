@@ -5,12 +5,15 @@
 //   less_than(a, 1000.0) filter   (:93-114)
 //   filter -> UINT32 selection -> project with a null (:329-373)
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <iostream>
+#include <unordered_set>
 
 #include "arrow/api.h"
 #include "gandiva/expression_registry.h"
 #include "gandiva/filter.h"
+#include "gandiva/filter_project.h"
 #include "gandiva/projector.h"
 #include "gandiva/tree_expr_builder.h"
 
@@ -62,6 +65,36 @@ int main(int argc, char** argv) {
     arrow::Status s = Projector::Make(schema, {bad}, &p);
     CHECK(!s.ok());
     CHECK(host_only || s.code() == arrow::StatusCode::ExpressionValidationError);
+  }
+  {  // round 4: the builder / registry members the .pxd does not bind ([M], see the headers)
+    DecimalScalar128 d1("12345", 10, 2), d2(0, 12345, 10, 2), d3("-7", 10, 2);
+    CHECK(d1 == d2 && d1 != d3 && d1.ToString() == "12345,10,2");
+    CHECK(std::hash<DecimalScalar128>()(d1) == std::hash<DecimalScalar128>()(d2));
+    auto lit = TreeExprBuilder::MakeLiteral(d3);
+    CHECK(lit && lit->return_type()->Equals(arrow::decimal128(10, 2)));
+    CHECK(lit->ToString().find("decimal") != std::string::npos || lit->ToString().find("-7") != std::string::npos);
+    auto fx = TreeExprBuilder::MakeField(arrow::field("x", arrow::float64()));
+    auto ff = TreeExprBuilder::MakeField(arrow::field("f", arrow::float32()));
+    auto fd = TreeExprBuilder::MakeField(arrow::field("d", arrow::decimal128(10, 2)));
+    CHECK(TreeExprBuilder::MakeInExpressionDouble(fx, {1.5, -0.0, 3.0}) != nullptr);
+    CHECK(TreeExprBuilder::MakeInExpressionFloat(ff, {1.5f, 2.5f}) != nullptr);
+    std::unordered_set<DecimalScalar128> ds{d1, d3};
+    auto in_d = TreeExprBuilder::MakeInExpressionDecimal(fd, ds, 10, 2);
+    CHECK(in_d != nullptr && in_d->return_type()->Equals(arrow::boolean()));
+    CHECK(TreeExprBuilder::MakeInExpressionDouble(nullptr, {1.0}) == nullptr);
+    ExpressionRegistry registry;
+    size_t n_sigs = 0;
+    bool saw_add = false;
+    for (auto it = registry.function_signature_begin(); it != registry.function_signature_end(); it++) {
+      n_sigs++;
+      const FunctionSignature sig = *it;
+      saw_add = saw_add || (sig.base_name() == "add" && sig.ret_type()->Equals(arrow::float64()));
+    }
+    CHECK(n_sigs == GetRegisteredFunctionSignatures().size() && saw_add);
+    auto types = ExpressionRegistry::supported_types();
+    bool has_dec = false, has_utf8 = false;
+    for (auto& t : types) { has_dec = has_dec || t->id() == arrow::Type::DECIMAL128; has_utf8 = has_utf8 || t->Equals(arrow::utf8()); }
+    CHECK(types.size() >= 18 && has_dec && has_utf8);
   }
   if (host_only) {
     std::shared_ptr<Projector> p;
@@ -146,6 +179,99 @@ int main(int argc, char** argv) {
     CHECK_OK(p->Evaluate(*batch, pool, &out));
     CHECK(out.size() == 2 && out[0]->Equals(MakeArr<arrow::BooleanBuilder, bool>({false, true, true, true})));
     CHECK(out[1]->Equals(MakeArr<arrow::StringBuilder, std::string>({"PARK", "SPARKLE", "BRIGHT SPARK AND FIRE", "SPARK"})));
+  }
+  {  // round 4: caller-allocated outputs (Projector::Evaluate(batch, ArrayDataVector))
+    std::shared_ptr<Projector> p;
+    CHECK_OK(Projector::Make(schema, {expr}, &p));
+    auto batch = arrow::RecordBatch::Make(schema, 4, {MakeArr<arrow::Int32Builder, int32_t>({10, 12, -20, 5}, {true, true, false, true}),
+                                                      MakeArr<arrow::Int32Builder, int32_t>({5, 15, 15, 17}),
+                                                      MakeArr<arrow::Int32Builder, int32_t>({0, 0, 0, 0})});
+    std::shared_ptr<arrow::Buffer> vb = arrow::AllocateBuffer(64, pool).ValueOrDie(), db = arrow::AllocateBuffer(64, pool).ValueOrDie();
+    std::memset(vb->mutable_data(), 0xAB, 64);
+    auto data = arrow::ArrayData::Make(arrow::int32(), 4, {vb, db});
+    CHECK_OK(p->Evaluate(*batch, ArrayDataVector{data}));
+    // (a NULL condition operand selects the else branch: row 2 -> b = 15)
+    CHECK(arrow::MakeArray(data)->Equals(MakeArr<arrow::Int32Builder, int32_t>({10, 15, 15, 17})));
+    // contract violations are Invalid, nothing is written
+    CHECK(p->Evaluate(*batch, ArrayDataVector{}).IsInvalid());
+    CHECK(p->Evaluate(*batch, ArrayDataVector{arrow::ArrayData::Make(arrow::int64(), 4, {vb, db})}).IsInvalid());
+    std::shared_ptr<arrow::Buffer> tiny = arrow::AllocateBuffer(8, pool).ValueOrDie();
+    CHECK(p->Evaluate(*batch, ArrayDataVector{arrow::ArrayData::Make(arrow::int32(), 4, {vb, tiny})}).IsInvalid());
+    CHECK(p->Evaluate(*batch, ArrayDataVector{arrow::ArrayData::Make(arrow::int32(), 2, {vb, db})}).IsInvalid());
+    // a var-len output into caller-allocated buffers; too small a byte buffer names the bytes needed
+    auto fs = arrow::field("s", arrow::utf8());
+    auto s3 = arrow::schema({fs});
+    auto up = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeFunction("upper", {TreeExprBuilder::MakeField(fs)}, arrow::utf8()),
+                                              arrow::field("u", arrow::utf8()));
+    std::shared_ptr<Projector> ps;
+    CHECK_OK(Projector::Make(s3, {up}, &ps));
+    auto sbatch = arrow::RecordBatch::Make(s3, 3, {MakeArr<arrow::StringBuilder, std::string>({"abc", "", "spark plug"})});
+    std::shared_ptr<arrow::Buffer> ob = arrow::AllocateBuffer(64, pool).ValueOrDie(), sb = arrow::AllocateBuffer(64, pool).ValueOrDie();
+    auto sdata = arrow::ArrayData::Make(arrow::utf8(), 3, {vb, ob, sb});
+    CHECK_OK(ps->Evaluate(*sbatch, ArrayDataVector{sdata}));
+    CHECK(arrow::MakeArray(sdata)->Equals(MakeArr<arrow::StringBuilder, std::string>({"ABC", "", "SPARK PLUG"})));
+    auto short_data = arrow::ArrayData::Make(arrow::utf8(), 3, {vb, ob, tiny});
+    arrow::Status st = ps->Evaluate(*sbatch, ArrayDataVector{short_data});
+    CHECK(st.IsInvalid() && st.ToString().find("13 needed") != std::string::npos);
+  }
+  {  // round 4: IN over float64 / decimal128 and a decimal literal, evaluated
+    auto fx = arrow::field("x", arrow::float64());
+    auto fd = arrow::field("d", arrow::decimal128(10, 2));
+    auto s4 = arrow::schema({fx, fd});
+    auto nx = TreeExprBuilder::MakeField(fx), nd = TreeExprBuilder::MakeField(fd);
+    std::unordered_set<DecimalScalar128> ds{DecimalScalar128("12345", 10, 2), DecimalScalar128("-7", 10, 2)};
+    auto e1 = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeInExpressionDouble(nx, {1.5, 0.0}), arrow::field("i", arrow::boolean()));
+    auto e2 = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeInExpressionDecimal(nd, ds, 10, 2), arrow::field("j", arrow::boolean()));
+    auto e3 = TreeExprBuilder::MakeExpression(
+        TreeExprBuilder::MakeFunction("equal", {nd, TreeExprBuilder::MakeLiteral(DecimalScalar128("-7", 10, 2))}, arrow::boolean()),
+        arrow::field("k", arrow::boolean()));
+    std::shared_ptr<Projector> p;
+    CHECK_OK(Projector::Make(s4, {e1, e2, e3}, &p));
+    arrow::Decimal128Builder db(arrow::decimal128(10, 2));
+    for (int64_t v : {12345, -7, 8, 0}) (void)db.Append(arrow::Decimal128(v));
+    auto batch = arrow::RecordBatch::Make(s4, 4, {MakeArr<arrow::DoubleBuilder, double>({1.5, -0.0, 2.0, std::nan("")}), db.Finish().ValueOrDie()});
+    ArrayVector out;
+    CHECK_OK(p->Evaluate(*batch, pool, &out));
+    CHECK(out.size() == 3 && out[0]->Equals(MakeArr<arrow::BooleanBuilder, bool>({true, true, false, false})));
+    CHECK(out[1]->Equals(MakeArr<arrow::BooleanBuilder, bool>({true, true, false, false})));
+    CHECK(out[2]->Equals(MakeArr<arrow::BooleanBuilder, bool>({false, true, false, false})));
+  }
+  {  // round 4: FilterProject = the test_filter_project KAT above as ONE operator (fused kernel)
+    auto batch = arrow::RecordBatch::Make(
+        schema, 6,
+        {MakeArr<arrow::Int32Builder, int32_t>({10, 12, -20, 5, 21, 29}),
+         MakeArr<arrow::Int32Builder, int32_t>({5, 15, 15, 17, 12, 3}),
+         MakeArr<arrow::Int32Builder, int32_t>({1, 25, 11, 30, -21, 0}, {true, true, true, true, true, false})});
+    auto fcond = TreeExprBuilder::MakeCondition(gt);
+    auto pcond = TreeExprBuilder::MakeFunction("less_than", {nb, nc}, arrow::boolean());
+    auto e = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeIf(pcond, nb, nc, arrow::int32()),
+                                             arrow::field("res", arrow::int32()));
+    std::shared_ptr<FilterProject> fp;
+    CHECK_OK(FilterProject::Make(schema, fcond, {e}, SelectionVector::MODE_UINT32, ConfigurationBuilder::DefaultConfiguration(), &fp));
+    CHECK(fp->fused() && fp->DumpIR().find("gdv_fp_lookback") != std::string::npos);
+    std::shared_ptr<SelectionVector> sel;
+    CHECK_OK(SelectionVector::MakeInt32(6, pool, &sel));
+    ArrayVector out;
+    CHECK_OK(fp->Evaluate(*batch, pool, &out, sel));
+    CHECK(sel->GetNumSlots() == 3);
+    CHECK(sel->ToArray()->Equals(MakeArr<arrow::UInt32Builder, uint32_t>({0, 4, 5})));
+    CHECK(out.size() == 1 && out[0]->Equals(MakeArr<arrow::Int32Builder, int32_t>({1, -21, 0}, {true, true, false})));
+    // without a selection vector; and a var-len projection, which takes the chain behind the same interface
+    std::shared_ptr<FilterProject> fp0;
+    CHECK_OK(FilterProject::Make(schema, fcond, {e}, SelectionVector::MODE_NONE, ConfigurationBuilder::DefaultConfiguration(), &fp0));
+    ArrayVector out0;
+    CHECK_OK(fp0->Evaluate(*batch, pool, &out0));
+    CHECK(out0.size() == 1 && out0[0]->Equals(out[0]));
+    auto cs = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeFunction("castVARCHAR", {na, TreeExprBuilder::MakeLiteral(int64_t(10))}, arrow::utf8()),
+                                              arrow::field("t", arrow::utf8()));
+    std::shared_ptr<FilterProject> fpc;
+    CHECK_OK(FilterProject::Make(schema, fcond, {cs}, SelectionVector::MODE_UINT32, ConfigurationBuilder::DefaultConfiguration(), &fpc));
+    CHECK(!fpc->fused());
+    ArrayVector outc;
+    std::shared_ptr<SelectionVector> selc;
+    CHECK_OK(SelectionVector::MakeInt32(6, pool, &selc));
+    CHECK_OK(fpc->Evaluate(*batch, pool, &outc, selc));
+    CHECK(outc.size() == 1 && outc[0]->Equals(MakeArr<arrow::StringBuilder, std::string>({"10", "21", "29"})));
   }
   std::printf(failures ? "FAILED\n" : "OK\n");
   return failures ? 1 : 0;
