@@ -329,6 +329,7 @@ int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* expr
   });
 }
 int gdv_projector_num_outputs(const gdv_projector_t* p) { return p ? p->p->num_outputs() : 0; }
+int gdv_projector_path_hint(const gdv_projector_t* p) { return p ? p->p->path_hint() : -1; }
 gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i) {
   if (!p || i < 0 || i >= p->p->num_outputs()) return gdv_type_t{0, 0, 0};
   return FromType(p->p->output_type(i));

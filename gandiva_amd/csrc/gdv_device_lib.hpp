@@ -2213,6 +2213,7 @@ typedef __attribute__((address_space(1))) unsigned long long gdv_gu64;
 #endif
 #define GDV_ERR_NOTFLAT 16u  // an optimistic flat output met a null row that carries bytes: host re-runs
 #define GDV_ERR_NOTASCII 32u  // pre-scanned plan (lengths from offsets under the ASCII assumption) met a byte >= 0x80: host re-runs
+#define GDV_ERR_SAWUTF8 64u   // exact variant of a wave plan: this batch did hold a byte >= 0x80 (not an error: the host keeps the exact kernels for the next batch)
 GDV_DEV void gdv_lb_store(gdv_uint64* p, gdv_uint64 v) {
   __hip_atomic_store((gdv_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -838,7 +838,29 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     const int64_t nwt = (out_rows + rows_wt - 1) / rows_wt;
     const int64_t seg_stride = (nwt + 3) & ~int64_t{3};  // the scan kernels read the totals 16 bytes at a time
     std::unique_ptr<ArgBlock> pargs;
-    auto run_wave = [&]() -> Status {
+    const bool has_exact = plan_.wave_tiles && plan_.exact != nullptr;
+    auto exact_kernels = [&]() -> Status {  // compiled the first time a batch needs them
+      PlanDeviceState* d = const_cast<PlanDeviceState*>(dev);
+      if (d->kernel_exact.load() == nullptr) {
+        const CompiledKernel* k = nullptr;
+        GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->source, plan_.exact->kernel_name, &k));
+        if (plan_.exact->prepass) {
+          const CompiledKernel* kp = nullptr;
+          GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->prepass->source, plan_.exact->prepass->kernel_name, &kp));
+          d->kernel_pre_exact.store(kp);
+        }
+        d->kernel_exact.store(k);
+      }
+      return Status::OK();
+    };
+    auto run_wave = [&](bool exact) -> Status {
+      const CompiledKernel* k_main = dev->kernel;
+      const CompiledKernel* k_pre = dev->kernel_pre;
+      if (exact) {
+        GDV_RETURN_NOT_OK(exact_kernels());
+        k_main = dev->kernel_exact.load();
+        k_pre = dev->kernel_pre_exact.load();
+      }
       if (wave_head.get() == nullptr) {
         GDV_RETURN_NOT_OK(wave_head.Allocate(head_bytes));
         if (nseg > 0) {
@@ -872,7 +894,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(head, 0, head_bytes, stream));
       const int64_t grid = GridFor(plan_, out_rows);
       if (nseg > 0) {
-        GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel_pre, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
+        GDV_RETURN_NOT_OK(rt.Launch(*k_pre, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
                                     plan_.opts.waves * 64, pargs->data(), pargs->size(), stream));
         int32_t* closing[kMaxScanSegments] = {};
         for (int v = 0; v < nv; v++)
@@ -882,7 +904,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
                                                          wave_chunks.as<uint64_t>(), wave_bases.as<uint64_t>(),
                                                          reinterpret_cast<uint64_t*>(head + 8 + totals_bytes), closing, stream));
       }
-      GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+      GDV_RETURN_NOT_OK(rt.Launch(*k_main, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), head, head_bytes, hipMemcpyDeviceToHost, stream));
       GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
       err_bits = static_cast<uint32_t>(back[0]);
@@ -895,11 +917,15 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     // are read, offsets = input offsets rebased, no scan.  That holds unless a NULL row carries
     // bytes (Arrow allows it, producers rarely do it); the kernel then raises NOTFLAT and the
     // batch is re-run with those outputs on the general path.  The wave shape adds the ASCII
-    // assumption of its pre-pass (NOTASCII) and falls back the same way.
-    // (sticky: a Projector whose batches break an assumption goes straight to the general
-    // variant from then on instead of paying two launches per batch)
+    // assumption of its pre-pass (NOTASCII).
+    // Round 4 — which kernels a batch runs on is decided PER BATCH (it used to be sticky for good:
+    // one byte >= 0x80 sent every later batch of the Projector to the scanner kernel, 0.27 of the
+    // roofline):  NOTASCII -> the wave shape's EXACT variant (flags from the sweep: same structure,
+    // the pre-pass reads the bytes once more), which also tells whether the batch really held such
+    // bytes — if not, the next batch starts on the optimistic kernels again;  NOTFLAT -> the
+    // scanner-shaped general kernel, and the optimistic kernels get another try every 16th batch.
     const bool has_optimistic = plan_.wave_tiles || plan_.has_flat_output;
-    bool optimistic = has_optimistic && !prefer_general_.load() && !EngineKnobs::Get().no_optflat;
+    constexpr uint32_t kNotFlat = 16u, kNotAscii = 32u, kSawUtf8 = 64u;
     auto general_kernel = [&]() -> Status {
       if (dev->kernel_general.load() == nullptr) {
         const CompiledKernel* k = nullptr;
@@ -910,21 +936,39 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     };
     const int64_t scanner_grid = std::max<int64_t>(1, ntiles) + 1;  // one workgroup per tile + the scanner
     auto launch = [&]() -> Status {
-      if (optimistic && plan_.wave_tiles) {
-        GDV_RETURN_NOT_OK(run_wave());
+      if (!has_optimistic) {
+        active = dev->kernel;
+        GDV_RETURN_NOT_OK(run(scanner_grid));
       } else {
-        if (has_optimistic && !optimistic) GDV_RETURN_NOT_OK(general_kernel());
-        active = (has_optimistic && !optimistic) ? dev->kernel_general.load() : dev->kernel;
-        GDV_RETURN_NOT_OK(run(scanner_grid));
+        int path = EngineKnobs::Get().no_optflat ? 2 : path_hint_.load(std::memory_order_relaxed);
+        if (path == 1 && !has_exact) path = 2;
+        if (path == 2 && !EngineKnobs::Get().no_optflat &&
+            (general_batches_.fetch_add(1, std::memory_order_relaxed) & 15u) == 15u)
+          path = 0;
+        if (path == 0) {
+          if (plan_.wave_tiles) {
+            GDV_RETURN_NOT_OK(run_wave(false));
+          } else {
+            active = dev->kernel;
+            GDV_RETURN_NOT_OK(run(scanner_grid));
+          }
+          if ((err_bits & kNotAscii) && !(err_bits & kNotFlat) && has_exact) path = 1;
+          else if (err_bits & (kNotAscii | kNotFlat)) path = 2;
+          else path_hint_.store(0, std::memory_order_relaxed);
+        }
+        if (path == 1) {
+          GDV_RETURN_NOT_OK(run_wave(true));
+          if (err_bits & kNotFlat) path = 2;
+          else path_hint_.store((err_bits & kSawUtf8) ? 1 : 0, std::memory_order_relaxed);
+        }
+        if (path == 2) {
+          GDV_RETURN_NOT_OK(general_kernel());
+          active = dev->kernel_general.load();
+          GDV_RETURN_NOT_OK(run(scanner_grid));
+          path_hint_.store(2, std::memory_order_relaxed);
+        }
       }
-      if (optimistic && (err_bits & 48u)) {
-        optimistic = false;
-        prefer_general_.store(true);
-        GDV_RETURN_NOT_OK(general_kernel());
-        active = dev->kernel_general.load();
-        GDV_RETURN_NOT_OK(run(scanner_grid));
-      }
-      err_bits &= ~48u;
+      err_bits &= ~(kNotFlat | kNotAscii | kSawUtf8);
       if (err_bits & 8u) {
         // The scan made no progress for a very long time: some workgroup of the grid was not
         // scheduled while later ones waited for it.  Never observed (workgroups start in index
@@ -1619,6 +1663,11 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
     GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source_general, plan.kernel_name_general, &code));
   if (plan.prepass)
     GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.prepass->source, plan.prepass->kernel_name, &code));
+  if (plan.exact && std::getenv("GDV_PRECOMPILE_SKIP_GENERAL") == nullptr) {  // (as the general variant: on demand at run time)
+    GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.exact->source, plan.exact->kernel_name, &code));
+    if (plan.exact->prepass)
+      GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.exact->prepass->source, plan.exact->prepass->kernel_name, &code));
+  }
   return Status::OK();
 }
 

@@ -70,6 +70,8 @@ struct PlanDeviceState {
   const CompiledKernel* kernel = nullptr;
   std::atomic<const CompiledKernel*> kernel_general{nullptr};  // fallback variant (compiled on demand)
   const CompiledKernel* kernel_pre = nullptr;  // wave-shaped plans: the pre-pass kernel
+  // the exact variant of a wave-shaped plan (main + pre-pass), compiled when a batch first needs it
+  std::atomic<const CompiledKernel*> kernel_exact{nullptr}, kernel_pre_exact{nullptr};
   DeviceBuffer consts, consts_pre;  // string literals / patterns / IN tables (gdv_args::aux0)
 };
 class PlanDeviceStates {
@@ -125,7 +127,17 @@ class Projector {
   Schema schema_;
   KernelPlan plan_;
   PlanDeviceStates states_;  // code objects + constant block per device context
-  mutable std::atomic<bool> prefer_general_{false};  // a batch broke an optimistic assumption: stop trying
+  // Which kernels the NEXT var-len batch starts on (round 4: per batch, no longer sticky for good):
+  // 0 = optimistic (ASCII + flat assumed), 1 = the wave shape's exact variant (the last batch held
+  // bytes >= 0x80), 2 = the scanner-shaped general kernel (a NULL row carried bytes under a flat
+  // output; the optimistic kernels are tried again every 16th batch).
+  mutable std::atomic<int> path_hint_{0};
+  mutable std::atomic<uint32_t> general_batches_{0};
+
+ public:
+  int path_hint() const { return path_hint_.load(std::memory_order_relaxed); }
+
+ private:
   // two-stage plans (StageMaterialisedValues): pre_ materialises the hoisted sub-trees as
   // temporary columns, plan_ is built over plan_schema_ = schema_ + those columns
   std::shared_ptr<Projector> pre_;

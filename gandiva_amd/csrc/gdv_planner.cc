@@ -477,6 +477,12 @@ class CodeGen {
   CodegenOptions opts_;
   int compact_from_ = 0x7fffffff;  // schema fields from this index on are compact temporaries (selection mode)
   bool no_hooks_ = false;          // pre-pass kernels have no byte sweep: '%needle%' takes the per-row search
+  // Wave kernels, round 4: false = the OPTIMISTIC variant (views of swept columns carry GDV_STR_ASCII as
+  // a compile-time fact; a byte >= 0x80 raises NOTASCII); true = the EXACT variant the host re-runs such
+  // a batch on: the flag is what the byte sweep of the (sub-)tile found, in the pre-pass and in the main
+  // kernel alike, and a tile that did hold a byte >= 0x80 reports GDV_ERR_SAWUTF8 (so the host knows
+  // when a later batch may go back to the optimistic kernels).
+  bool exact_ascii_ = false;
   int mirror_slot_ = -1;           // wave kernels: the var-len input whose sub-tile spans are swept one at a time
                                    // (main kernel: and mirrored in LDS)
   bool replace_hits_ = false;      // wave kernels: replace() over a whole column row may be answered by the sweep
@@ -1516,6 +1522,23 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
 // XCD's L2 — 0.6 GB of extra fabric reads on C5, 1.40 x the algorithmic traffic
 // (profiles/r03_c5_traffic.txt).  A sub-tile's span is small enough to keep in LDS (GDV_SUB_SPAN =
 // 32 bytes per row; longer spans — wave-uniform — read HBM as before), so nothing is read twice.
+// Exact variant, kernels that have no other reason to read column K's bytes (a ByteFree pre-pass):
+// a bare sweep of the wave tile's span — 16 B per lane and step, OR-reduced — gives the tile's ASCII flag.
+// Needs sp0K / sp1K (the span) and sdK / slimK in scope; defines inbK? no: sflK only.
+std::string ExactAsciiTileFlag(const std::string& K) {
+  std::ostringstream s;
+  s << "  gdv_uint64 sacc" << K << " = 0;\n"
+    << "  for (gdv_int32 c = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15); c < sp1" << K << "; c += 1024) {\n"
+    << "    const gdv_int32 a = c + 16 * lane;\n"
+    << "    gdv_uint64 w[2] = {0ull, 0ull};\n"
+    << "    if (a < sp1" << K << ") __builtin_memcpy(w, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+    << "    sacc" << K << " |= w[0] | w[1];\n"
+    << "  }\n"
+    << "  const gdv_int32 sfl" << K << " = (sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0) |\n"
+    << "                       (__ballot((sacc" << K << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n";
+  return s.str();
+}
+
 struct WaveSweepText {
   std::string prologue;   // before the row loop
   std::string per_sub;    // top of the row loop's body (u = the sub-tile)
@@ -1540,9 +1563,13 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
     if (prepass && mirror_slot != k) {
       // a pre-pass sweeps nothing but the column whose replace() counts matches in the bitmap; views
       // carry the flags the main kernel will give them (the optimistic ASCII flag where consulted)
-      s << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n"
-        << "  const gdv_int32 sfl" << K << " = (sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0)"
-        << (want_ascii ? " | GDV_STR_ASCII" : "") << ";\n";
+      s << "  const gdv_int32 sp1" << K << " = so" << K << "[last_tile ? n : rbase + 64 * GDV_U];\n";
+      if (want_ascii && cg.exact_ascii_) {
+        s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n" << ExactAsciiTileFlag(K);
+      } else {
+        s << "  const gdv_int32 sfl" << K << " = (sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0)"
+          << (want_ascii ? " | GDV_STR_ASCII" : "") << ";\n";
+      }
       continue;
     }
     // the tile's span: its ends come from two scalar loads; one wave-uniform range test per tile
@@ -1586,7 +1613,11 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
     for (auto* vo : flats)
       s << "  " << AblIf(8) << "gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
         << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
-    if (want_ascii)
+    if (want_ascii && cg.exact_ascii_)
+      // exact variant: the flag of the CURRENT sub-tile, set by its sweep at the top of the row loop
+      s << "  gdv_int32 sfl" << K << " = inb" << K << ";\n"
+        << "  gdv_uint64 sawhi" << K << " = 0;  // OR of every byte swept so far (reported as SAWUTF8)\n";
+    else if (want_ascii)
       // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
       // fact for the row bodies — every general UTF-8 path folds away
       s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n";
@@ -1639,10 +1670,18 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
       << " + nb + 16 * lane, 16), 16);\n"
       << (hooks.empty() ? "" : "      if (" + AblNot(64) + "lane == 63 && nb + 1024 < e2) tn" + K + " = gdv_load8_raw(sd" + K + " + nb + 1024);\n")
       << "    }\n";
+    if (want_ascii && cg.exact_ascii_)
+      // (the sweep of a sub-tile covers whole 16-byte pieces: a few bytes of the neighbouring rows may
+      // clear the flag needlessly — the general paths are exact for ASCII rows too)
+      b << "    sfl" << K << " = inb" << K << " | (__ballot((sacc" << K << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n"
+        << "    sawhi" << K << " |= sacc" << K << ";\n"
+        << "    sacc" << K << " = 0;\n";
     if (!hooks.empty() || mirror) b << "    __builtin_amdgcn_wave_barrier();\n";
 
     // ---- after the loop
-    if (want_ascii && !prepass)  // (the main kernel raises it)
+    if (want_ascii && cg.exact_ascii_ && !prepass)
+      e << "  if (__ballot((sawhi" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_SAWUTF8);\n";
+    else if (want_ascii && !prepass)  // (the main kernel raises it)
       e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
   }
   out->prologue = s.str();
@@ -1735,10 +1774,15 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
     for (auto* vo : flats)
       s << "  " << AblIf(8) << "gdv_sweep_edges(outd" << vo->e << ", sd" << K << ", sp0" << K << ", sp1" << K << ", so0_" << K
         << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
-    if (want_ascii) {
+    if (want_ascii && cg.exact_ascii_) {
+      // exact variant: the tile's flag is what its sweep found
+      s << "  const bool hi8_" << K << " = __ballot((sacc" << K << " & GDV_B80) != 0) != 0;\n"
+        << "  const gdv_int32 sfl" << K << " = inb" << K << " | (hi8_" << K << " ? 0 : GDV_STR_ASCII);\n";
+      e << "  if (hi8_" << K << " && lane == 0) atomicOr(A.err, GDV_ERR_SAWUTF8);\n";
+    } else if (want_ascii) {
       // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
       // fact for the row bodies — every general UTF-8 path folds away — and a tile that breaks it
-      // raises NOTASCII: the host re-runs the batch on the general (scanner) kernel
+      // raises NOTASCII: the host re-runs the batch on the exact variant of these kernels
       s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n";
       e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
     } else {
@@ -1990,8 +2034,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
   std::ostringstream& s = as.src;
-  s << "// " << (prepass ? "pre-pass: byte totals per wave tile from the offsets alone (optimistic ASCII)"
-                         : "wave shape: independent wave tiles, output bases from the pre-pass + scan")
+  s << "// " << (prepass ? (cg.exact_ascii_ ? "pre-pass: byte totals per wave tile (exact variant: ASCII flags from a sweep of the bytes)"
+                                            : "pre-pass: byte totals per wave tile from the offsets alone (optimistic ASCII)")
+                         : (cg.exact_ascii_ ? "wave shape, exact variant: ASCII flags per (sub-)tile from the byte sweep"
+                                            : "wave shape: independent wave tiles, output bases from the pre-pass + scan"))
     << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
     << (mirror_slot >= 0 ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
@@ -2038,9 +2084,13 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     // an if over like ...) read the rows' bytes a first time.
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
-      if (t.is_varlen() && cg.needs_values_[k])
-        s << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n"
-          << "  const gdv_int32 sfl" << k << " = (sd" << k << " + sp1" << k << " + 8 <= slim" << k << " ? GDV_STR_INBUF : 0)"
+      if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+      s << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n";
+      if (cg.exact_ascii_ && cg.ascii_slots_.count(k))
+        // exact variant: the lengths depend on the bytes now — the pre-pass sweeps the tile's span for its flag
+        s << "  const gdv_int32 sp0" << k << " = so" << k << "[rbase];\n" << ExactAsciiTileFlag(std::to_string(k));
+      else
+        s << "  const gdv_int32 sfl" << k << " = (sd" << k << " + sp1" << k << " + 8 <= slim" << k << " ? GDV_STR_INBUF : 0)"
           << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
   } else if (mirror_slot >= 0) {
@@ -2120,7 +2170,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
 
 namespace {
 
-enum class StringShape { kScanner, kWaveMain, kWavePrepass };
+enum class StringShape { kScanner, kWaveMain, kWavePrepass, kWaveMainExact, kWavePrepassExact };
 
 // Is the value of `n` — and its validity — computable without reading a single var-len BYTE once
 // every string is assumed ASCII?  (offsets, validity bitmaps, fixed-width values and literals are
@@ -2171,6 +2221,9 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
   plan->compact_from = compact_from;
   CodeGen cg(schema, mode, opts);
   cg.compact_from_ = compact_from;
+  cg.exact_ascii_ = shape == StringShape::kWaveMainExact || shape == StringShape::kWavePrepassExact;
+  if (shape == StringShape::kWaveMainExact) shape = StringShape::kWaveMain;
+  if (shape == StringShape::kWavePrepassExact) shape = StringShape::kWavePrepass;
   cg.no_hooks_ = shape == StringShape::kWavePrepass;
   cg.replace_hits_ = shape != StringShape::kScanner && opts.lds_mirror && mode == SelectionMode::kNone;
   WordAccumulators accs;
@@ -2512,6 +2565,34 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
     }
     plan->prepass = pre;
     plan->ir = fast.source + pre->source;  // (the main kernel first: its name is the plan's)
+  }
+  // The exact variant (round 4): only where some function consults the ASCII flag — i.e. where the
+  // optimistic kernels can raise NOTASCII at all.  Same tree walk, same inputs / literals / constants
+  // (checked): the host hands it the optimistic kernels' argument blocks.
+  if (fast.source.find("GDV_ERR_NOTASCII") != std::string::npos) {
+    auto ex = std::make_shared<KernelPlan>();
+    std::vector<VarlenOut> evouts;
+    Status st = PlanProjectorShape(schema, exprs, mode, fast.opts, StringShape::kWaveMainExact, nullptr, ex.get(), &evouts, compact_from);
+    bool ok = st.ok() && ex->opts.subtiles == fast.opts.subtiles && ex->opts.waves == fast.opts.waves &&
+              ex->input_fields == fast.input_fields && ex->input_needs_values == fast.input_needs_values &&
+              ex->input_needs_validity == fast.input_needs_validity && ex->literals == fast.literals &&
+              ex->const_block == fast.const_block && evouts.size() == vouts.size();
+    for (size_t i = 0; ok && i < vouts.size(); i++)
+      ok = evouts[i].flat_slot == vouts[i].flat_slot && evouts[i].segment == vouts[i].segment;
+    if (ok && plan->prepass) {
+      auto epre = std::make_shared<KernelPlan>();
+      st = PlanProjectorShape(schema, exprs, mode, fast.opts, StringShape::kWavePrepassExact, &scanned, epre.get(), nullptr, compact_from);
+      const KernelPlan& p0 = *plan->prepass;
+      ok = st.ok() && epre->opts.subtiles == fast.opts.subtiles && epre->input_fields == p0.input_fields &&
+           epre->input_needs_values == p0.input_needs_values && epre->input_needs_validity == p0.input_needs_validity &&
+           epre->literals == p0.literals && epre->const_block == p0.const_block &&
+           epre->layout.total() == p0.layout.total();
+      ex->prepass = epre;
+    }
+    if (ok) {
+      plan->exact = ex;
+      plan->can_raise = plan->can_raise || ex->can_raise;
+    }
   }
   return Status::OK();
 }

@@ -97,6 +97,11 @@ struct KernelPlan {
   bool has_many_entry = false;  // the code object also holds <kernel_name>_many(const gdv_args* table): one launch, many batches
   int compact_from = 0x7fffffff;  // selection mode: schema fields from here on are compact temporaries
   bool wave_tiles = false;
+  // Round 4: the EXACT variant of a wave-shaped plan whose row bodies consult the ASCII flag (main
+  // kernel; its own pre-pass hangs off exact->prepass).  Same argument blocks as the optimistic pair.
+  // A batch that raises NOTASCII is re-run on it — and the next batches start there until one of
+  // them turns out to be pure ASCII again.  Null when nothing consults the flag.
+  std::shared_ptr<KernelPlan> exact;
   std::shared_ptr<KernelPlan> prepass;
   std::vector<int> wave_segments;
   int general_subtiles = 0, general_waves = 0;  // tile of the scanner-shaped fallback (0: opts')

@@ -501,6 +501,11 @@ class Projector:
         """DumpIR(): the generated HIP source of the fused kernel (contains `@expr_N`)."""
         return _capi.take_string(_capi.lib().gdv_projector_dump_ir(self._h))
 
+    @property
+    def path_hint(self):
+        """gdv_projector_path_hint: 0 optimistic kernels, 1 exact wave variant, 2 scanner-shaped general kernel."""
+        return _capi.lib().gdv_projector_path_hint(self._h)
+
     def evaluate(self, batch, selection=None):
         """Host-buffer path: stages the batch through HBM, returns host pyarrow arrays."""
         _check_batch(batch, self._schema)

@@ -306,8 +306,10 @@ def c5_expressions(builder=None):
             b.make_expression(up, pa.field("up", pa.string()))]
 
 
-def c5_numpy(n, seed=21, null_fraction=0.0):
-    """(offsets int32[n+1], bytes uint8[total], null mask or None)"""
+def c5_numpy(n, seed=21, null_fraction=0.0, non_ascii_fraction=0.0):
+    """(offsets int32[n+1], bytes uint8[total], null mask or None).  non_ascii_fraction > 0: that share
+    of the rows gets one two-byte character (e-acute, C3 A9) over two of its bytes — the variant of C5
+    that real utf8 columns look like (round 4: profiles/r04_c5_nonascii.txt)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     lens = rng.integers(4, 21, n).astype(np.int64)
     offsets = np.zeros(n + 1, dtype=np.int64)
@@ -320,19 +322,25 @@ def c5_numpy(n, seed=21, null_fraction=0.0):
     for k, ch in enumerate(b"spark"):
         data[pos + k] = ch
     mask = (rng.random(n) < null_fraction) if null_fraction > 0 else None
+    if non_ascii_fraction > 0:
+        rng2 = np.random.Generator(np.random.PCG64(seed + 1000))
+        rows = np.flatnonzero(rng2.random(n) < non_ascii_fraction)
+        at = offsets[rows] + (rng2.random(len(rows)) * (lens[rows] - 1)).astype(np.int64)   # lens >= 4: room for two bytes
+        data[at] = 0xC3
+        data[at + 1] = 0xA9
     return offsets.astype(np.int32), data, mask
 
 
-def c5_batch(n, null_fraction=0.0):
-    offsets, data, mask = c5_numpy(n, null_fraction=null_fraction)
+def c5_batch(n, null_fraction=0.0, non_ascii_fraction=0.0):
+    offsets, data, mask = c5_numpy(n, null_fraction=null_fraction, non_ascii_fraction=non_ascii_fraction)
     validity = None if mask is None else pa.py_buffer(np.packbits(~mask, bitorder="little"))
     arr = pa.Array.from_buffers(pa.string(), n, [validity, pa.py_buffer(offsets), pa.py_buffer(data)])
     return pa.RecordBatch.from_arrays([arr], schema=c5_schema())
 
 
-def c5_device_batch(n, device="cuda"):
+def c5_device_batch(n, device="cuda", non_ascii_fraction=0.0):
     import torch
-    offsets, data, _ = c5_numpy(n)
+    offsets, data, _ = c5_numpy(n, non_ascii_fraction=non_ascii_fraction)
     pad = lambda t: torch.cat([t, torch.zeros((-t.numel()) % 64 + 64, dtype=torch.uint8)])
     off_t = pad(torch.from_numpy(offsets.view(np.uint8).copy())).to(device)
     dat_t = pad(torch.from_numpy(data)).to(device)

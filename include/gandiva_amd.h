@@ -215,6 +215,11 @@ int gdv_projector_make(const gdv_schema_t* schema, gdv_expression_t* const* expr
                        int selection_mode, const gdv_config_t* config /* NULL = default */,
                        gdv_projector_t** out);
 int gdv_projector_num_outputs(const gdv_projector_t* p);
+/* Diagnostics: the kernels the NEXT var-len batch of this projector starts on — 0 the optimistic pair
+ * (ASCII + flat outputs assumed), 1 the exact variant of the wave shape (the last batch held bytes
+ * >= 0x80), 2 the scanner-shaped general kernel (a NULL row carried bytes under a flat output).
+ * Decided per batch: an all-ASCII batch brings the projector back to 0. */
+int gdv_projector_path_hint(const gdv_projector_t* p);
 gdv_type_t gdv_projector_output_type(const gdv_projector_t* p, int i);
 /* Bytes the caller must provide for output i with `rows` output rows.  Device buffers
  * are written in whole 64-bit bitmap words: validity (and bool data) = 8 * ceil(rows/64). */

@@ -590,3 +590,100 @@ def test_oracle_like_wildcards_match_newlines_as_arrows_re2_backed_match_like_do
     for pat in ["a_b", "a%b", "_", "%", "a__b", "x%y", "%spark%", "line1_spark%", "%\n%"]:
         node = b.make_function("like", [s, b.make_literal(pat, pa.string())], pa.bool_())
         assert oracle.project_one(node, pa.bool_(), batch).equals(pc.match_like(arr, pat)), pat
+
+
+# ------------------------------------------------------------------ round 4: per-batch choice of the kernels
+
+@pytest.mark.gpu
+def test_a_non_ascii_batch_takes_the_exact_wave_variant_and_an_ascii_batch_brings_the_fast_path_back():
+    """Round 3 sent a Projector to the scanner-shaped kernel FOR GOOD after one byte >= 0x80.  Now: the
+    batch that raises NOTASCII is re-run on the exact variant of the wave kernels (path 1), the next
+    batches start there, and the first all-ASCII batch returns the Projector to the optimistic pair (0)."""
+    exprs = W.c5_expressions()
+    proj = gandiva.make_projector(W.c5_schema(), exprs, pa.default_memory_pool())
+    assert proj.path_hint == 0
+    n = 60_013
+    ascii_batch = W.c5_batch(n)
+    mixed = W.c5_batch(n, non_ascii_fraction=0.01)
+    nulls_mixed = W.c5_batch(n, null_fraction=0.1, non_ascii_fraction=0.3)
+
+    def check(batch, what):
+        for g, w in zip(proj.evaluate(batch), oracle.project(exprs, batch)):
+            assert_bit_exact(g, w, what)
+    check(ascii_batch, "ASCII batch on the optimistic kernels")
+    assert proj.path_hint == 0
+    check(mixed, "1 % of the rows hold a two-byte character")
+    assert proj.path_hint == 1                      # re-run on the exact variant; the next batch starts there
+    check(nulls_mixed, "30 % non-ASCII rows, 10 % nulls, straight on the exact variant")
+    assert proj.path_hint == 1
+    check(ascii_batch, "an ASCII batch on the exact variant")
+    assert proj.path_hint == 0                      # it saw no byte >= 0x80: back to the optimistic kernels
+    check(ascii_batch, "and again on the optimistic kernels")
+    assert proj.path_hint == 0
+    # HBM-resident, buffers reused across the switch
+    import torch
+    dm, da = gandiva.DeviceBatch.from_arrow(mixed), gandiva.DeviceBatch.from_arrow(ascii_batch)
+    outs = proj.evaluate_device(dm)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, oracle.project(exprs, mixed)):
+        assert_bit_exact(o.to_arrow(), w, "device-resident, non-ASCII")
+    assert proj.path_hint == 1
+    outs = proj.evaluate_device(da)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, oracle.project(exprs, ascii_batch)):
+        assert_bit_exact(o.to_arrow(), w, "device-resident, ASCII after non-ASCII")
+    assert proj.path_hint == 0
+
+
+@pytest.mark.gpu
+def test_character_functions_on_the_exact_variant_match_the_oracle_on_multibyte_text():
+    """substr / left / right / char_length / lpad / reverse / locate over rows mixing 1-, 2-, 3- and 4-byte
+    characters, through the wave shape's exact variant (every batch here is non-ASCII)."""
+    rng = np.random.default_rng(77)
+    alphabet = list("abcXYZ 019") + ["é", "ü", "ß", "日", "本", "語", "𝄞", "€"]
+    rows = [None if rng.random() < 0.08 else "".join(rng.choice(alphabet, size=int(rng.integers(0, 30)))) for _ in range(30_011)]
+    batch = pa.RecordBatch.from_arrays([pa.array(rows, pa.string())], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    i64 = pa.int64()
+
+    def lit(v):
+        return b.make_literal(v, i64)
+    exprs = [b.make_expression(b.make_function("substr", [s, lit(2), lit(5)], pa.string()), pa.field("a", pa.string())),
+             b.make_expression(b.make_function("substr", [s, lit(-3), lit(2)], pa.string()), pa.field("b", pa.string())),
+             b.make_expression(b.make_function("left", [s, b.make_literal(4, pa.int32())], pa.string()), pa.field("c", pa.string())),
+             b.make_expression(b.make_function("right", [s, b.make_literal(3, pa.int32())], pa.string()), pa.field("d", pa.string())),
+             b.make_expression(b.make_function("char_length", [s], pa.int32()), pa.field("e", pa.int32())),
+             b.make_expression(b.make_function("upper", [s], pa.string()), pa.field("f", pa.string()))]
+    proj = gandiva.make_projector(batch.schema, exprs, pa.default_memory_pool())
+    want = oracle.project(exprs, batch)
+    for rnd in range(2):   # first call: optimistic -> NOTASCII -> exact; second: exact from the start
+        for g, w, e in zip(proj.evaluate(batch), want, exprs):
+            assert_bit_exact(g, w, f"{e} (call {rnd})")
+        assert proj.path_hint == 1
+
+
+@pytest.mark.gpu
+def test_null_rows_that_carry_bytes_take_the_general_kernel_and_the_fast_path_is_tried_again_later():
+    """A flat output (upper(col)) whose NULL rows hold bytes raises NOTFLAT: the general (scanner-shaped)
+    kernel takes the batch and the following ones (path 2); every 16th batch the optimistic kernels get
+    another try, so a Projector fed clean batches afterwards comes back to them."""
+    n = 20_011
+    offsets, data, _ = W.c5_numpy(n)
+    rng = np.random.default_rng(3)
+    mask = rng.random(n) < 0.1                      # NULL rows KEEP their bytes
+    dirty = pa.RecordBatch.from_arrays([pa.Array.from_buffers(pa.string(), n, [
+        pa.py_buffer(np.packbits(~mask, bitorder="little")), pa.py_buffer(offsets), pa.py_buffer(data)])], schema=W.c5_schema())
+    clean = W.c5_batch(n)
+    exprs = W.c5_expressions()
+    proj = gandiva.make_projector(W.c5_schema(), exprs, pa.default_memory_pool())
+    for g, w in zip(proj.evaluate(dirty), oracle.project(exprs, dirty)):
+        assert_bit_exact(g, w, "NULL rows with bytes")
+    assert proj.path_hint == 2
+    want = oracle.project(exprs, clean)
+    hints = []
+    for _ in range(20):
+        for g, w in zip(proj.evaluate(clean), want):
+            assert_bit_exact(g, w, "clean batch")
+        hints.append(proj.path_hint)
+    assert hints[0] == 2 and hints[-1] == 0 and 0 in hints[:17]
