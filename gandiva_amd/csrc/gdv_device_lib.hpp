@@ -44,7 +44,20 @@ typedef gdv_int64 gdv_time64;
 struct gdv_ctx {
   gdv_uint32* err;
 };
-GDV_DEV void gdv_raise(gdv_ctx ctx, gdv_uint32 bit) { atomicOr(ctx.err, bit); }
+// A bit is raised ONCE, not once per raiser: same-address read-modify-write atomics are served one
+// after the other (~12 ns each, profiles/r02_k2_singlepass_proto.txt) — round 4 found the C5 kernels
+// taking 2.3 ms instead of 1.0 on a batch where nearly every wave tile raised NOTASCII (195 000 atomicOr
+// on one word).  A relaxed agent-scope load first (loads of one address are not serialised); the few
+// raisers that read the word before the first atomic landed do the atomic, everyone after them does not.
+#ifdef GDV_HOST_BUILD
+GDV_DEV void gdv_raise_bits(gdv_uint32* err, gdv_uint32 bit) { *err |= bit; }
+#else
+GDV_DEV void gdv_raise_bits(gdv_uint32* err, gdv_uint32 bit) {
+  typedef __attribute__((address_space(1))) gdv_uint32 gdv_gu32;
+  if ((__hip_atomic_load((gdv_gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) != bit) atomicOr(err, bit);
+}
+#endif
+GDV_DEV void gdv_raise(gdv_ctx ctx, gdv_uint32 bit) { gdv_raise_bits(ctx.err, bit); }
 
 // ------------------------------------------------------------------ memory access
 //
@@ -1013,6 +1026,7 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 #define GDV_MAP_REPLACE 16  // `lim` points at a replace table (constant block), flags >> 2 = source length
 #define GDV_STR_ASCII 1  // flags: every byte of the buffer range this view came from is < 0x80
 #define GDV_STR_INBUF 2  // flags: 8-byte loads starting anywhere inside the view stay inside its buffer
+#define GDV_STR_LEAD 4   // flags: `lead` / `lead_p` are set (exact variant of the wave kernels, rows with bytes >= 0x80)
 // (out-of-line device functions fault on this stack — measured, profiles/r02_c5_codesize.txt —
 // so cold paths stay inline and the row loop of string kernels is simply not unrolled)
 #define GDV_COLD __forceinline__
@@ -1022,6 +1036,12 @@ struct gdv_str {
   gdv_int32 map;
   const gdv_uint8* lim;  // end of the readable buffer p points into (8-byte loads stop here)
   gdv_int32 flags;
+  // GDV_STR_LEAD (round 4): bit i of `lead` = the byte lead_p[i] STARTS a character (is not 10xxxxxx),
+  // i < 64 — the row's lead-byte mask, taken from the byte sweep's bitmap.  Character counts and
+  // positions of any view inside [lead_p, lead_p + 64) are popcount / select on it: no byte of the row is
+  // read again (gdv_lead_window).  Untouched (dead) in kernels that never set the flag.
+  gdv_uint64 lead;
+  const gdv_uint8* lead_p;
 };
 GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 end,
                              const gdv_uint8* lim, gdv_int32 flags = 0) {
@@ -1031,7 +1051,19 @@ GDV_DEV gdv_str gdv_make_str(const gdv_uint8* base, gdv_int32 begin, gdv_int32 e
   s.map = 0;
   s.lim = lim;
   s.flags = flags;
+  s.lead = 0;
+  s.lead_p = nullptr;
   return s;
+}
+// the lead-byte mask of view s (bit i: byte i of s starts a character), when the view lies inside the
+// 64 bytes its row's mask covers
+GDV_DEV bool gdv_lead_window(const gdv_str& s, gdv_uint64* m) {
+  if (!(s.flags & GDV_STR_LEAD)) return false;
+  const gdv_int64 off = s.p - s.lead_p;
+  if (off < 0 || off + s.len > 64 || s.len < 0) return false;
+  const gdv_uint64 w = off >= 64 ? 0ull : (s.lead >> off);
+  *m = s.len >= 64 ? w : (w & ((1ull << s.len) - 1ull));
+  return true;
 }
 GDV_DEV gdv_uint8 gdv_map_byte(gdv_uint8 c, gdv_int32 map) {
   if (map == 1) return (c >= 'a' && c <= 'z') ? (gdv_uint8)(c - 32) : c;
@@ -1409,6 +1441,8 @@ GDV_DEV gdv_uint64 gdv_mask_upto(gdv_int32 nbytes) {  // any nbytes: <= 0 -> 0, 
 }
 GDV_DEV gdv_int32 gdv_utf8_count(const gdv_str& s) {
   if (s.flags & GDV_STR_ASCII) return s.len;
+  gdv_uint64 lead;
+  if (gdv_lead_window(s, &lead)) return (gdv_int32)__popcll(lead);
   gdv_int32 cont = 0;
   for (gdv_int32 i = 0; i < s.len; i += 8) {
     gdv_uint64 w = gdv_raw_word_at(s, i) & gdv_low_bytes_mask(s.len - i);
@@ -1423,6 +1457,9 @@ static __device__ GDV_COLD bool gdv_bytes_are_ascii(const gdv_uint8* p, gdv_int3
 }
 GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
   if (s.flags & GDV_STR_ASCII) return true;  // answered for the whole tile by the byte sweep
+  // (a row the exact variant flagged holds a byte >= 0x80 itself or shares a 16-byte piece with one
+  // that does: the general paths are exact either way, and with the lead mask they read no byte)
+  if (s.flags & GDV_STR_LEAD) return false;
   return gdv_bytes_are_ascii(s.p, s.len, s.lim);
 }
 // bytes [i, i+n) of s equal the n bytes at q (n >= 0; q readable up to qlim)
@@ -1547,6 +1584,12 @@ GDV_DEV bool ends_with_utf8_utf8(gdv_str s, gdv_str suffix) {
 // (s.len when the string has fewer characters): 8 bytes per step — the lead bytes of a word are
 // counted with one popcount, and only the word holding the wanted character is looked into
 static __device__ GDV_COLD gdv_int32 gdv_utf8_byte_pos_general(const gdv_str& s, gdv_int32 ci) {
+  gdv_uint64 lm;
+  if (gdv_lead_window(s, &lm)) {  // select: the position of the ci-th set bit of the lead mask
+    if (ci < 0 || ci >= (gdv_int32)__popcll(lm)) return ci < 0 ? 0 : s.len;
+    for (gdv_int32 k = ci; k > 0; k--) lm &= lm - 1;
+    return (gdv_int32)__builtin_ctzll(lm);
+  }
   gdv_int32 seen = 0;
   for (gdv_int32 i = 0; i < s.len; i += 8) {
     const gdv_uint64 w = gdv_raw_word_at(s, i);
@@ -2074,6 +2117,40 @@ GDV_DEV void gdv_sweep_edges(gdv_uint8* __restrict__ dst, const gdv_uint8* __res
   } else if (lane < cnt && (gdv_int64)sp0 - rebase + lane < cap) {
     dst[sp0 - rebase + lane] = gdv_map_byte(src[sp0 + lane], map);
   }
+}
+// bit i of the result: byte i of the 16-byte piece (w0, w1) is a UTF-8 continuation byte (10xxxxxx)
+GDV_DEV gdv_uint32 gdv_cont_mask16(gdv_uint64 w0, gdv_uint64 w1) {
+  const gdv_uint64 c0 = (w0 & ~(w0 << 1) & GDV_B80) >> 7, c1 = (w1 & ~(w1 << 1) & GDV_B80) >> 7;  // bit 8j: byte j continues
+  // (bits at multiples of 8 -> 8 adjacent bits: every partial product of the multiply lands on its own position)
+  return (gdv_uint32)((c0 * 0x0102040810204080ull) >> 56) | ((gdv_uint32)((c1 * 0x0102040810204080ull) >> 56) << 8);
+}
+// Row view of the exact variant of the wave kernels.  "Character index == byte index" — what the
+// ASCII fast paths assume — holds exactly when the row contains no CONTINUATION byte (a lone byte
+// >= 0xC0 is one character either way), so that is the test, per row, on the sweep's continuation
+// bitmap `cb` (bit = position in the sub-tile's span; readable one word past any position):
+//   sub-tile without any byte >= 0x80 (wave-uniform)   -> ASCII, nothing is looked at
+//   row of <= 64 bytes inside the bitmap's reach       -> ASCII if its 64-position window holds no
+//        continuation bit; otherwise the window becomes the row's lead-byte mask (GDV_STR_LEAD):
+//        character counts and positions are popcount / select on it, no byte is read again
+//   anything else (long rows, spans beyond the bitmap) -> neither: the general paths walk the bytes
+GDV_DEV gdv_str gdv_with_lead(gdv_str s, bool subtile_has_high, bool in_bitmap, const gdv_uint64* cb, gdv_int32 lo) {
+  if (!subtile_has_high) {
+    s.flags |= GDV_STR_ASCII;
+    return s;
+  }
+  if (in_bitmap && s.len <= 64) {
+    const gdv_int32 w = lo >> 6, sh = lo & 63;
+    const gdv_uint64 x = (cb[w] >> sh) | ((cb[w + 1] << 1) << (63 - sh));
+    const gdv_uint64 cont = s.len >= 64 ? x : (x & ((1ull << (s.len > 0 ? s.len : 0)) - 1ull));
+    if (cont == 0) {
+      s.flags |= GDV_STR_ASCII;
+    } else {
+      s.lead = ~x;
+      s.lead_p = s.p;
+      s.flags |= GDV_STR_LEAD;
+    }
+  }
+  return s;
 }
 // any bit set in [lo, hi) of the bitmap (hi <= lo: empty range).  Branch-free for ranges of up
 // to 64 positions (rows up to 64 + needle bytes long): two adjacent words, one funnel shift, one

@@ -367,7 +367,10 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
         if (mem == MemKind::kHost) {
           void *dof = nullptr, *dd = nullptr;
           GDV_RETURN_NOT_OK(st->In(osrc, (num_rows + 1) * 4, (num_rows + 1) * 4, stream, &dof));
-          GDV_RETURN_NOT_OK(st->In(c.data, c.data_size, std::max<int64_t>(c.data_size, 8), stream, &dd));
+          // (16 zero bytes behind the last byte: the byte sweep reads whole 16-byte pieces, and whatever
+          // the block held before must not look like a byte >= 0x80 — it would send an ASCII batch to
+          // the exact variant of the string kernels for nothing)
+          GDV_RETURN_NOT_OK(st->In(c.data, c.data_size, c.data_size + 16, stream, &dd));
           args->SetInOffsets(static_cast<int>(k), dof);
           args->SetInData(static_cast<int>(k), dd);
         } else if (c.data_size < 8) {
@@ -956,8 +959,11 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
           else if (err_bits & (kNotAscii | kNotFlat)) path = 2;
           else path_hint_.store(0, std::memory_order_relaxed);
         }
+        if (EngineKnobs::Get().trace)
+          fprintf(stderr, "[gdv] var-len path after the optimistic attempt: %d (error bits 0x%x)\n", path, err_bits);
         if (path == 1) {
           GDV_RETURN_NOT_OK(run_wave(true));
+          if (EngineKnobs::Get().trace) fprintf(stderr, "[gdv] exact wave variant ran (error bits 0x%x)\n", err_bits);
           if (err_bits & kNotFlat) path = 2;
           else path_hint_.store((err_bits & kSawUtf8) ? 1 : 0, std::memory_order_relaxed);
         }

@@ -34,6 +34,8 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.no_wave_shape = std::getenv("GDV_NO_WAVE_SHAPE") != nullptr;
   o.wave_bytefree_only = std::getenv("GDV_WAVE_BYTEFREE_ONLY") != nullptr;
   o.ablation = std::getenv("GDV_ABLATION") != nullptr;
+  o.runtime_needles = std::getenv("GDV_RUNTIME_NEEDLES") != nullptr;
+  o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
   return o;
 }
 
@@ -41,7 +43,7 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "");
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -483,6 +485,15 @@ class CodeGen {
   // kernel alike, and a tile that did hold a byte >= 0x80 reports GDV_ERR_SAWUTF8 (so the host knows
   // when a later batch may go back to the optimistic kernels).
   bool exact_ascii_ = false;
+  std::set<int> row_ascii_slots_;  // exact variant: inputs whose views take a PER-ROW flag (gdv_with_lead)
+  bool bake_needles_ = false;      // wave kernels: '%needle%' bytes are immediates of the kernel text (NeedleConstants)
+  bool unroll_rows_ = false;       // the row loop of this kernel is unrolled (small bodies that index registers by u)
+  // ... and their lead-byte mask from the sweep's continuation bitmap: LDS bitmap index (behind the hooks' bitmaps)
+  int CbIndex(int slot) {
+    int j = 0;
+    for (int k : ascii_slots_) { if (k == slot) return static_cast<int>(contains_hooks_.size()) + j; j++; }
+    return -1;
+  }
   int mirror_slot_ = -1;           // wave kernels: the var-len input whose sub-tile spans are swept one at a time
                                    // (main kernel: and mirrored in LDS)
   bool replace_hits_ = false;      // wave kernels: replace() over a whole column row may be answered by the sweep
@@ -1033,6 +1044,7 @@ struct Assembler {
       src << "#define GDV_ROWS(A) ((A).aux2 != 0 ? gdv_clamp_rows(*(const gdv_int64*)(A).aux2, (A).n) : (A).n)\n";
     else
       src << "#define GDV_ROWS(A) ((A).n)\n";
+    if (cg.unroll_rows_) src << "#define GDV_UNROLL_ROWS 1\n";
     src << "#define GDV_U " << plan->opts.subtiles << "\n";
     src << "#define GDV_WAVES " << plan->opts.waves << "\n";
     src << "#include \"gdv_device_lib.hpp\"\n";
@@ -1385,7 +1397,11 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
           << k << "[GDV_U > 1 ? 1 : 0]) : sp1" << k << ", lane);\n";
       else if (cg.needs_values_[k])
         s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0], ob" << k << "_u = ob" << k << "[0];\n";
-      if (cg.needs_values_[k])
+      if (cg.needs_values_[k] && cg.row_ascii_slots_.count(k))
+        // exact variant: ASCII is a fact about THIS row (conservatively: about the 16-byte pieces it touches)
+        s << "      const gdv_str s" << k << " = gdv_with_lead(gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
+          << ", sfl" << k << "), hi8_" << k << ", hm_ok" << k << ", cb" << k << ", oa" << k << "_u - sb" << k << ");\n";
+      else if (cg.needs_values_[k])
         s << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
           << ", sfl" << k << ");\n";
     } else if (cg.needs_values_[k]) {
@@ -1418,6 +1434,32 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
     }
     if (cg.needs_validity_[k] && sel) s << "    gdv_rot(b" << k << ");\n";
   }
+}
+
+// The '%needle%' of a sweep hook as the matcher's three constants.  Wave-shaped kernels (round 4) carry
+// them in the kernel TEXT: the needle is a literal of the plan, and as immediates its bytes cost no
+// scalar loads, no registers across the row loop and let the compiler fold the first-byte splats (the
+// round-3 verdict priced the runtime needle among the 0.2 ms the generic emitter paid over its
+// prototype).  Plans that differ in the needle are different kernels there; the scanner shape keeps the
+// needle a run-time constant (one code object for every pattern of a given length).
+std::string NeedleConstants(CodeGen& cg, int h, uint64_t mask) {
+  const ContainsHook& hk = cg.contains_hooks_[h];
+  std::ostringstream s;
+  const std::string H = std::to_string(h);
+  if (cg.bake_needles_) {
+    uint64_t v = 0;
+    std::memcpy(&v, hk.needle.data(), std::min<size_t>(8, hk.needle.size()));
+    v &= mask;
+    s << "  const gdv_uint64 nd" << H << " = " << Hex64(v) << ";  // the needle: a literal of the plan\n"
+      << "  const gdv_uint32 ns0_" << H << " = " << Hex64((v & 0xff) * 0x01010101ull) << ", ns1_" << H << " = "
+      << Hex64(((v >> 8) & 0xff) * 0x01010101ull) << ";\n";
+  } else {
+    s << "  const gdv_uint64 nd" << H << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
+      << ";  // the needle: a runtime constant\n"
+      << "  const gdv_uint32 ns0_" << H << " = (gdv_uint32)(nd" << H << " & 0xffull) * 0x01010101u, ns1_" << H << " = (gdv_uint32)((nd" << H
+      << " >> 8) & 0xffull) * 0x01010101u;\n";
+  }
+  return s.str();
 }
 
 // byte sweep of every var-len input (scanner shape): tile-wide ASCII flag, '%needle%' match
@@ -1462,10 +1504,7 @@ void EmitStringSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan) {
       const ContainsHook& hk = cg.contains_hooks_[h];
       const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
       s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
-        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
-        << ";  // the needle: a runtime constant\n"
-        << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
-        << " >> 8) & 0xffull) * 0x01010101u;\n";
+        << NeedleConstants(cg, h, mask);
     }
     s << "  for (gdv_int32 c = sb" << K << "; c < " << AblSel(64, "sb" + K, "sp1" + K) << "; c += 1024) {\n"
       << "    const gdv_int32 a = c + 16 * lane;\n"
@@ -1589,10 +1628,7 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
       const ContainsHook& hk = cg.contains_hooks_[h];
       const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
       s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
-        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
-        << ";  // the needle: a runtime constant\n"
-        << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
-        << " >> 8) & 0xffull) * 0x01010101u;\n";
+        << NeedleConstants(cg, h, mask);
     }
     if (mirror)
       s << "  gdv_lds_u8* const mir" << K << " = (gdv_lds_u8*)lds_in;  // LDS mirror of the current sub-tile's span\n";
@@ -1615,8 +1651,10 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
         << ", " << vo->flat_map << ", A.out[" << vo->e << "].cap, lane);\n";
     if (want_ascii && cg.exact_ascii_)
       // exact variant: the flag of the CURRENT sub-tile, set by its sweep at the top of the row loop
-      s << "  gdv_int32 sfl" << K << " = inb" << K << ";\n"
-        << "  gdv_uint64 sawhi" << K << " = 0;  // OR of every byte swept so far (reported as SAWUTF8)\n";
+      s << "  const gdv_int32 sfl" << K << " = inb" << K << ";  // (the rows' views take a per-row flag: gdv_row_has_high)\n"
+        << "  gdv_uint64 sawhi" << K << " = 0;  // OR of every byte swept so far (reported as SAWUTF8)\n"
+        << "  bool hi8_" << K << " = false;  // the current sub-tile's span holds a byte >= 0x80\n"
+        << "  gdv_uint64* const cb" << K << " = lds_hit + " << cg.CbIndex(k) << " * GDV_HIT_WORDS;  // continuation-byte bitmap of the sub-tile's span\n";
     else if (want_ascii)
       // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
       // fact for the row bodies — every general UTF-8 path folds away
@@ -1640,6 +1678,12 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
       << "      if (a + 1024 < se" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
       << (hooks.empty() ? "" : "      if (lane == 63 && a + 1024 + 16 < se" + K + ") tn" + K + " = gdv_load8_raw(sd" + K + " + a + 1024 + 16);\n")
       << "      sacc" << K << " |= w[0] | w[1];\n";
+    if (want_ascii && cg.exact_ascii_) {
+      cg.row_ascii_slots_.insert(k);
+      b << "      { const gdv_uint64 hbw = __ballot(((w[0] | w[1]) & GDV_B80) != 0);\n"
+        << "        const gdv_uint32 cm = hbw != 0 ? gdv_cont_mask16(w[0], w[1]) : 0u;  // (wave-uniform branch: ASCII steps skip the packing)\n"
+        << "        if (hm_ok" << K << " && a < se" << K << ") ((gdv_uint16*)cb" << K << ")[(a - sb" << K << ") >> 4] = (gdv_uint16)cm; }\n";
+    }
     for (int h : hooks) {
       const ContainsHook& hk = cg.contains_hooks_[h];
       const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
@@ -1673,16 +1717,16 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
     if (want_ascii && cg.exact_ascii_)
       // (the sweep of a sub-tile covers whole 16-byte pieces: a few bytes of the neighbouring rows may
       // clear the flag needlessly — the general paths are exact for ASCII rows too)
-      b << "    sfl" << K << " = inb" << K << " | (__ballot((sacc" << K << " & GDV_B80) != 0) == 0 ? GDV_STR_ASCII : 0);\n"
+      b << "    hi8_" << K << " = __ballot((sacc" << K << " & GDV_B80) != 0) != 0;  // this sub-tile's span holds a byte >= 0x80\n"
         << "    sawhi" << K << " |= sacc" << K << ";\n"
         << "    sacc" << K << " = 0;\n";
-    if (!hooks.empty() || mirror) b << "    __builtin_amdgcn_wave_barrier();\n";
+    if (!hooks.empty() || mirror || (want_ascii && cg.exact_ascii_)) b << "    __builtin_amdgcn_wave_barrier();\n";
 
     // ---- after the loop
     if (want_ascii && cg.exact_ascii_ && !prepass)
-      e << "  if (__ballot((sawhi" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_SAWUTF8);\n";
+      e << "  if (__ballot((sawhi" << K << " & GDV_B80) != 0) != 0 && lane == 0) gdv_raise_bits(A.err, GDV_ERR_SAWUTF8);\n";
     else if (want_ascii && !prepass)  // (the main kernel raises it)
-      e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
+      e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) gdv_raise_bits(A.err, GDV_ERR_NOTASCII);\n";
   }
   out->prologue = s.str();
   out->per_sub = b.str();
@@ -1728,10 +1772,7 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
       const ContainsHook& hk = cg.contains_hooks_[h];
       const uint64_t mask = hk.needle.size() >= 8 ? ~0ull : ((1ull << (8 * hk.needle.size())) - 1);
       s << "  gdv_uint64* const hit" << h << " = lds_hit + " << h << " * GDV_HIT_WORDS;\n"
-        << "  const gdv_uint64 nd" << h << " = gdv_load8_raw(" << cg.hook_tables_[h] << ") & " << Hex64(mask)
-        << ";  // the needle: a runtime constant\n"
-        << "  const gdv_uint32 ns0_" << h << " = (gdv_uint32)(nd" << h << " & 0xffull) * 0x01010101u, ns1_" << h << " = (gdv_uint32)((nd" << h
-        << " >> 8) & 0xffull) * 0x01010101u;\n";
+        << NeedleConstants(cg, h, mask);
     }
     for (auto* vo : flats)
       s << "  const gdv_int32 fcap" << vo->e << " = (gdv_int32)(A.out[" << vo->e << "].cap > 0x7fffffff ? 0x7fffffff : A.out[" << vo->e
@@ -1778,13 +1819,13 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
       // exact variant: the tile's flag is what its sweep found
       s << "  const bool hi8_" << K << " = __ballot((sacc" << K << " & GDV_B80) != 0) != 0;\n"
         << "  const gdv_int32 sfl" << K << " = inb" << K << " | (hi8_" << K << " ? 0 : GDV_STR_ASCII);\n";
-      e << "  if (hi8_" << K << " && lane == 0) atomicOr(A.err, GDV_ERR_SAWUTF8);\n";
+      e << "  if (hi8_" << K << " && lane == 0) gdv_raise_bits(A.err, GDV_ERR_SAWUTF8);\n";
     } else if (want_ascii) {
       // optimistic ASCII (the pre-pass computed the lengths under it): the flag is a compile-time
       // fact for the row bodies — every general UTF-8 path folds away — and a tile that breaks it
       // raises NOTASCII: the host re-runs the batch on the exact variant of these kernels
       s << "  const gdv_int32 sfl" << K << " = inb" << K << " | GDV_STR_ASCII;\n";
-      e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTASCII);\n";
+      e << "  if (__ballot((sacc" << K << " & GDV_B80) != 0) != 0 && lane == 0) gdv_raise_bits(A.err, GDV_ERR_NOTASCII);\n";
     } else {
       s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
     }
@@ -1872,7 +1913,7 @@ Status AssembleStrings(CodeGen& cg, KernelPlan* plan, const std::vector<std::str
   if (nv > 0) s << "  if (pass == 1) break;\n";
   for (auto& vo : cg.varlen_outs_)
     if (vo.flat_slot >= 0)
-      s << "  if (optflat && fb" << vo.e << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n";
+      s << "  if (optflat && fb" << vo.e << " != 0 && lane == 0) gdv_raise_bits(A.err, GDV_ERR_NOTFLAT);\n";
   s << epilogue_after_loop;
 
   // ---- var-len outputs
@@ -2025,11 +2066,19 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   const int nv = static_cast<int>(cg.varlen_outs_.size());
   int nstage = 0;
   for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
-  const int nhook = static_cast<int>(cg.contains_hooks_.size());  // (a pre-pass has hooks only for a swept replace())
+  // (a pre-pass has hooks only for a swept replace(); the exact variant adds one continuation-byte bitmap
+  // per input whose ASCII flag is consulted)
+  const int ncb = cg.exact_ascii_ ? static_cast<int>(cg.ascii_slots_.size()) : 0;
+  const int nhook = static_cast<int>(cg.contains_hooks_.size()) + ncb;
   plan->num_varlen_outputs = prepass ? 0 : nv;
   for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
   const int nin = plan->layout.n_in;
   const int mirror_slot = cg.mirror_slot_;  // (decided with the tile shape, PlanProjectorShape)
+  if (prepass && mirror_slot < 0 && !cg.exact_ascii_ && !plan->opts.prepass_rolled)
+    // optimistic pre-pass without a sweep: the body is a few integer operations per row (every general
+    // UTF-8 path folds away under the compile-time ASCII flag) — unrolled, the eight sub-tiles' offsets
+    // are consumed from their registers without the rotation of the rolled loop
+    cg.unroll_rows_ = true;
 
   Assembler as{cg, plan, {}};
   as.Header(expr_strings);
@@ -2040,8 +2089,8 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
                                             : "wave shape: independent wave tiles, output bases from the pre-pass + scan"))
     << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
-    << (mirror_slot >= 0 ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
-                         : "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n")
+    << (mirror_slot >= 0 || (prepass && ncb > 0) ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
+                                                 : "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n")
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
     << AblDefine()
     << "#define GDV_OUT(e, v) if (live) " << (plan->opts.nontemporal ? "gdv_stnt" : "gdv_st") << "(out##e, row, (v))\n";
@@ -2086,10 +2135,51 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (!(t.is_varlen() && cg.needs_values_[k])) continue;
       s << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n";
-      if (cg.exact_ascii_ && cg.ascii_slots_.count(k))
-        // exact variant: the lengths depend on the bytes now — the pre-pass sweeps the tile's span for its flag
-        s << "  const gdv_int32 sp0" << k << " = so" << k << "[rbase];\n" << ExactAsciiTileFlag(std::to_string(k));
-      else
+      if (cg.exact_ascii_ && cg.ascii_slots_.count(k)) {
+        // exact variant: the lengths depend on the bytes now — the pre-pass sweeps every sub-tile's span
+        // (at the top of the row loop) for the pieces that hold a byte >= 0x80; rows take a per-row flag
+        const std::string K = std::to_string(k);
+        cg.row_ascii_slots_.insert(k);
+        s << "  const gdv_int32 inb" << K << " = sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n"
+          << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+        // software-pipelined like the main kernel's sweep: the first 1024-byte step of the NEXT sub-tile's
+        // span is requested before this sub-tile's rows are looked at (unrolling the loop to have all
+        // eight in flight measured slower: 0.81 vs 0.52 ms at 10^8 rows — the general UTF-8 paths are
+        // inlined into every copy of the body)
+        s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
+          << "  {\n"
+          << "    const gdv_int32 ss = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+          << "    const gdv_int32 se = GDV_U > 1 ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+          << "    const gdv_int32 a = ss - (gdv_int32)((gdv_uint64)(sd" << K << " + ss) & 15) + 16 * lane;\n"
+          << "    if (a < se) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+          << "  }\n";
+        std::ostringstream b;
+        b << "    // exact pre-pass: the continuation bytes of this sub-tile's span of input " << k << " -> LDS bitmap\n"
+          << "    const gdv_int32 ss" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+          << "    const gdv_int32 se" << K << " = u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+          << "    const gdv_int32 sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
+          << "    const bool hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap\n"
+          << "    gdv_uint64* const cb" << K << " = lds_hit + " << cg.CbIndex(k) << " * GDV_HIT_WORDS;\n"
+          << "    gdv_uint64 sacc" << K << " = 0;\n"
+          << "    for (gdv_int32 c = sb" << K << "; c < se" << K << "; c += 1024) {\n"
+          << "      const gdv_int32 a = c + 16 * lane;\n"
+          << "      const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
+          << "      wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
+          << "      if (a + 1024 < se" << K << ") __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + a + 1024, 16), 16);\n"
+          << "      sacc" << K << " |= w[0] | w[1];\n"
+          << "      const gdv_uint64 hbw = __ballot(((w[0] | w[1]) & GDV_B80) != 0);\n"
+          << "      const gdv_uint32 cm = hbw != 0 ? gdv_cont_mask16(w[0], w[1]) : 0u;\n"
+          << "      if (hm_ok" << K << " && a < se" << K << ") ((gdv_uint16*)cb" << K << ")[(a - sb" << K << ") >> 4] = (gdv_uint16)cm;\n"
+          << "    }\n"
+          << "    if (u + 1 < GDV_U) {  // the first piece of the next sub-tile's span\n"
+          << "      const gdv_int32 e2 = u + 2 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 2 ? 2 : 0]) : sp1" << K << ";\n"
+          << "      const gdv_int32 nb = se" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + se" << K << ") & 15);\n"
+          << "      if (nb + 16 * lane < e2) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K << " + nb + 16 * lane, 16), 16);\n"
+          << "    }\n"
+          << "    const bool hi8_" << K << " = __ballot((sacc" << K << " & GDV_B80) != 0) != 0;\n"
+          << "    __builtin_amdgcn_wave_barrier();\n";
+        sweep.per_sub += b.str();
+      } else
         s << "  const gdv_int32 sfl" << k << " = (sd" << k << " + sp1" << k << " + 8 <= slim" << k << " ? GDV_STR_INBUF : 0)"
           << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
@@ -2142,10 +2232,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
   if (prepass)
     // (a pre-pass tile is a few loads and one store: waves walk several tiles, grid-stride)
-    s << (mirror_slot >= 0 ? "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n" : "")
+    s << (mirror_slot >= 0 || ncb > 0 ? "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n" : "")
       << "  const gdv_int64 nwt = (GDV_ROWS(A) + 64 * GDV_U - 1) / (64 * GDV_U);\n"
       << "  for (gdv_int64 wt = (gdv_int64)blockIdx.x * GDV_WAVES + wave; wt < nwt; wt += (gdv_int64)gridDim.x * GDV_WAVES)\n"
-      << "    gdv_tile(A, wt, lane, wave, nullptr, " << (mirror_slot >= 0 ? "gdv_lds_hit[wave]" : "nullptr") << ", nullptr);\n";
+      << "    gdv_tile(A, wt, lane, wave, nullptr, " << (mirror_slot >= 0 || ncb > 0 ? "gdv_lds_hit[wave]" : "nullptr") << ", nullptr);\n";
   else
     s << "  __shared__ __attribute__((aligned(16))) gdv_uint8 gdv_lds_out[GDV_WAVES][GDV_NSTAGE * (GDV_OUT_WIN + 16)];\n"
       << "  __shared__ __attribute__((aligned(16))) gdv_uint64 gdv_lds_hit[GDV_WAVES][GDV_NHOOK * GDV_HIT_WORDS];\n"
@@ -2225,6 +2315,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
   if (shape == StringShape::kWaveMainExact) shape = StringShape::kWaveMain;
   if (shape == StringShape::kWavePrepassExact) shape = StringShape::kWavePrepass;
   cg.no_hooks_ = shape == StringShape::kWavePrepass;
+  cg.bake_needles_ = shape != StringShape::kScanner && !opts.runtime_needles;
   cg.replace_hits_ = shape != StringShape::kScanner && opts.lds_mirror && mode == SelectionMode::kNone;
   WordAccumulators accs;
   std::ostringstream after_loop, before_loop, in_pass, after_rows;
@@ -2294,7 +2385,7 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         before_loop << "  gdv_uint64 fb" << E << " = 0;  // rows that drop bytes of the input span (nulls with a length)\n";
         cg.Stmt("if (live) outo" + E + "[row] = oa" + K + "[u] - so0_" + K + ";");
         cg.Stmt("fb" + E + " |= __ballot(!" + ok + " && ob" + K + "[u] > oa" + K + "[u]);");
-        after_rows << "  if (fb" << E << " != 0 && lane == 0) atomicOr(A.err, GDV_ERR_NOTFLAT);\n"
+        after_rows << "  if (fb" << E << " != 0 && lane == 0) gdv_raise_bits(A.err, GDV_ERR_NOTFLAT);\n"
                    << "  if (last_tile && lane == 0) {  // closing offset + byte total of a flat output\n"
                    << "    outo" << E << "[n] = sp1" << K << " - so0_" << K << ";\n"
                    << "    ((gdv_uint64*)A.counts)[" << vidx << "] = (gdv_uint64)(sp1" << K << " - so0_" << K << ");\n"

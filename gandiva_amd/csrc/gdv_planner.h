@@ -42,6 +42,8 @@ struct CodegenOptions {
   bool no_wave_shape = false;          // GDV_NO_WAVE_SHAPE: var-len plans take the scanner shape
   bool wave_bytefree_only = false;     // GDV_WAVE_BYTEFREE_ONLY
   bool ablation = false;               // GDV_ABLATION=1: emit the GDV_ABL experiment branches into the kernels
+  bool prepass_rolled = false;         // GDV_PREPASS_ROLLED=1: keep the row loop of optimistic offsets-only pre-passes rolled
+  bool runtime_needles = false;        // GDV_RUNTIME_NEEDLES=1: wave kernels load their '%needle%' bytes instead of carrying them as immediates
   static CodegenOptions FromEnv();
   std::string Key() const;
 };

@@ -60,12 +60,19 @@ def test_string_projection_builds_wave_prepass_and_general_kernels(monkeypatch, 
     compile for gfx950 at build time."""
     monkeypatch.delenv("GDV_PRECOMPILE_SKIP_GENERAL", raising=False)
     files = _precompile(monkeypatch, tmp_path, W.c5_schema(), exprs=W.c5_expressions())
-    assert len(files) == 3, files
+    assert len(files) == 5, files
     texts = [open(tmp_path / f).read() for f in files]
-    main = [t for t in texts if "// wave shape" in t]
-    pre = [t for t in texts if "// pre-pass" in t]
+    main = [t for t in texts if "// wave shape:" in t]
+    pre = [t for t in texts if "// pre-pass:" in t and "exact variant" not in t]
     general = [t for t in texts if "gdv_scanner<GDV_NG>" in t]
-    assert len(main) == len(pre) == len(general) == 1
+    # round 4: the EXACT variant of the pair — what a batch with bytes >= 0x80 is re-run on: ASCII is a
+    # fact about each row there (continuation bitmap from the sweep), in the pre-pass and the main kernel
+    main_x = [t for t in texts if "// wave shape, exact variant" in t]
+    pre_x = [t for t in texts if "// pre-pass:" in t and "exact variant" in t]
+    assert len(main) == len(pre) == len(general) == len(main_x) == len(pre_x) == 1
+    for t in (main_x[0], pre_x[0]):
+        assert "gdv_with_lead(" in t and "gdv_cont_mask16(" in t and "GDV_ERR_NOTASCII" not in t
+    assert "GDV_ERR_SAWUTF8" in main_x[0] and "gdv_with_lead(" not in main[0] and "| GDV_STR_ASCII" in main[0]
     assert "@expr_2 = string upper((string) s)" in main[0]           # DumpIR keeps the readable header
     assert "__syncthreads" not in main[0] and "gdv_lb_wait" not in main[0] and "gdv_sweep_store" in main[0]
     assert "GDV_ERR_NOTASCII" in main[0] and "A.mask[0 * seg_stride + wt]" in main[0]
@@ -87,8 +94,9 @@ def test_plans_whose_lengths_need_bytes_get_a_byte_reading_prepass(monkeypatch, 
                                          pa.string()), pa.field("u", pa.string()))]
     files = _precompile(monkeypatch, tmp_path, sch, exprs=exprs)
     texts = [open(tmp_path / f).read() for f in files]
+    texts = [t for t in texts if "exact variant" not in t]   # (round 4: + the exact variant of the wave pair)
     pre = [t for t in texts if "// pre-pass" in t]
-    assert len(files) == 3 and len(pre) == 1, files
+    assert len(texts) == 3 and len(pre) == 1, files
     assert "rtrim_utf8" in pre[0] and "gdv_like_contains" in pre[0] and "gdv_range_any" not in pre[0]
     for env in ("GDV_WAVE_BYTEFREE_ONLY", "GDV_NO_WAVE_SHAPE"):
         d = tmp_path / env
