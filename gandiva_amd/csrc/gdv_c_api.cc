@@ -797,6 +797,35 @@ int gdv_device_hbm_ceilings(int64_t bytes, double* read_gbs, double* write_gbs, 
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
   });
 }
+int gdv_device_stream_ceiling(int64_t bytes_per_stream, int num_read, int num_write, double* gbs, int* workgroups_per_cu,
+                              int* nontemporal) {
+  return Guarded([&]() -> int {
+  if (bytes_per_stream < (1 << 20) || !gbs || num_read < 0 || num_write < 0 || num_read + num_write < 1 ||
+      num_read > 10 || num_write > 10)
+    return Fail(Status::Invalid("bad argument"));
+  bytes_per_stream &= ~int64_t{8191};
+  Runtime& rt = Runtime::Get();
+  Status st = rt.EnsureDevice();
+  if (!st.ok()) return Fail(st);
+  std::vector<DeviceBuffer> bufs(num_read + num_write);
+  std::vector<void*> ptrs;
+  for (auto& b : bufs) {
+    st = b.Allocate(static_cast<size_t>(bytes_per_stream));
+    if (!st.ok()) return Fail(st);
+    hipError_t e = hipMemset(b.get(), 1, static_cast<size_t>(bytes_per_stream));
+    if (e != hipSuccess) return Fail(Status::ExecutionError(hipGetErrorString(e)));
+    ptrs.push_back(b.get());
+  }
+  int wg = 0, nt = 0;
+  hipError_t e = MeasureStreamCeiling(ptrs.data(), num_read, num_write, static_cast<size_t>(bytes_per_stream / 8), rt.num_cus(),
+                                      gbs, &wg, &nt);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipErrorInvalidValue) return Fail(Status::Invalid("no ceiling kernel for this (reads, writes) shape"));
+  if (workgroups_per_cu) *workgroups_per_cu = wg;
+  if (nontemporal) *nontemporal = nt;
+  return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+  });
+}
 int gdv_device_synchronize(void) {
   hipError_t e = hipDeviceSynchronize();
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));

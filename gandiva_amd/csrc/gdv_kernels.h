@@ -33,6 +33,8 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
 
 // Read-only / write-only / copy rate (GB/s, best of 4) of plain streaming kernels over two device
 // buffers of `bytes` bytes each (bytes a multiple of 16; use >= 1 GiB: the Infinity Cache holds 256 MiB).
+hipError_t MeasureStreamCeiling(void* const* streams, int nr, int nw, size_t elems, int num_cus, double* gbs,
+                                int* workgroups_per_cu, int* nontemporal);
 hipError_t MeasureHbmCeilings(void* a, void* b, size_t bytes, int grid, double* read_gbs, double* write_gbs,
                               double* copy_gbs);
 

@@ -278,7 +278,101 @@ __global__ void __launch_bounds__(256) CeilCopy(const CeilU64x2* __restrict__ a,
   }
 }
 
+// Round 4: the ceiling for a workload's OWN traffic shape.  The three kernels above drive one (or two)
+// 16-byte streams; the round-3 driver run had the product's C2 kernel — four input streams, ten output
+// streams — moving MORE bytes per second than the mix those ceilings predicted (frac 1.057: an
+// instrument that under-drives HBM says nothing about slow box vs slow kernel).  CeilStream is the
+// projection kernel's skeleton with the arithmetic taken out: NR input streams and NW output streams
+// of 8-byte elements, one row per lane, GDV_U = 4 sub-tiles per wave, 4 waves per workgroup, every load
+// of the tile in flight before the first store, grid-stride.  MeasureStreamCeiling sweeps the grid
+// (2 .. 32 workgroups per CU) x {plain, non-temporal} and reports the best: by construction at least
+// what any kernel of that shape reaches.
+struct CeilPointers {
+  const unsigned long long* in[10];
+  unsigned long long* out[10];
+};
+template <int NR, int NW, bool NT>
+__global__ void __launch_bounds__(256) CeilStream(const CeilPointers P, size_t n) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t ntiles = n / (256 * U);
+  for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const size_t base = t * (256 * U) + (size_t)wave * (64 * U) + lane;
+    unsigned long long v[NR > 0 ? NR : 1][U];
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int r = 0; r < NR; r++)
+        v[r][u] = NT ? __builtin_nontemporal_load(P.in[r] + base + 64 * u) : P.in[r][base + 64 * u];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      unsigned long long x = t;
+#pragma unroll
+      for (int r = 0; r < NR; r++) x ^= v[r][u];
+      acc |= x;
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        if (NT) __builtin_nontemporal_store(x + w, P.out[w] + base + 64 * u);
+        else P.out[w][base + 64 * u] = x + w;
+      }
+    }
+    if (NW == 0 && acc == 0x12345678abcdefull) P.out[0][0] = acc;  // (keeps the loads of a read-only shape alive)
+  }
+}
+
 }  // namespace
+
+namespace {
+template <int NR, int NW>
+hipError_t StreamCeilingFor(const CeilPointers& P, size_t n, int num_cus, double* best_gbs, int* best_grid, int* best_nt) {
+  hipEvent_t e0, e1;
+  hipError_t err = hipEventCreate(&e0);
+  if (err != hipSuccess) return err;
+  err = hipEventCreate(&e1);
+  if (err != hipSuccess) { (void)hipEventDestroy(e0); return err; }
+  const double moved = (double)(NR + NW) * 8.0 * (double)(n / 1024 * 1024);
+  *best_gbs = 0;
+  for (int nt = 0; nt < 2 && err == hipSuccess; nt++) {
+    for (int per_cu = 2; per_cu <= 32 && err == hipSuccess; per_cu *= 2) {
+      const int grid = num_cus * per_cu;
+      float best = 1e30f;
+      for (int it = 0; it < 3 && err == hipSuccess; it++) {
+        err = hipEventRecord(e0, nullptr);
+        if (nt) hipLaunchKernelGGL((CeilStream<NR, NW, true>), dim3(grid), dim3(256), 0, nullptr, P, n);
+        else hipLaunchKernelGGL((CeilStream<NR, NW, false>), dim3(grid), dim3(256), 0, nullptr, P, n);
+        if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float ms = 0;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (it >= 1 && ms < best) best = ms;
+      }
+      const double gbs = moved / (best * 1e-3) / 1e9;
+      if (err == hipSuccess && gbs > *best_gbs) { *best_gbs = gbs; *best_grid = per_cu; *best_nt = nt; }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return err != hipSuccess ? err : hipGetLastError();
+}
+}  // namespace
+
+// streams[0 .. nr) are read, streams[nr .. nr + nw) written; every stream holds `elems` 8-byte elements.
+// Shapes: (nr, nw) in {(1,0) (2,0) (4,0) (0,1) (0,4) (0,10) (2,1) (3,1) (4,10) (7,5) (2,3)}.
+hipError_t MeasureStreamCeiling(void* const* streams, int nr, int nw, size_t elems, int num_cus, double* gbs,
+                                int* workgroups_per_cu, int* nontemporal) {
+  CeilPointers P;
+  for (int i = 0; i < 10; i++) { P.in[i] = nullptr; P.out[i] = nullptr; }
+  for (int i = 0; i < nr; i++) P.in[i] = static_cast<const unsigned long long*>(streams[i]);
+  for (int i = 0; i < nw; i++) P.out[i] = static_cast<unsigned long long*>(streams[nr + i]);
+  if (nw == 0) P.out[0] = const_cast<unsigned long long*>(P.in[0]);  // never written (see the kernel)
+#define GDV_CEIL_SHAPE(R, W) if (nr == R && nw == W) return StreamCeilingFor<R, W>(P, elems, num_cus, gbs, workgroups_per_cu, nontemporal)
+  GDV_CEIL_SHAPE(1, 0); GDV_CEIL_SHAPE(2, 0); GDV_CEIL_SHAPE(4, 0);
+  GDV_CEIL_SHAPE(0, 1); GDV_CEIL_SHAPE(0, 4); GDV_CEIL_SHAPE(0, 10);
+  GDV_CEIL_SHAPE(2, 1); GDV_CEIL_SHAPE(3, 1); GDV_CEIL_SHAPE(4, 10); GDV_CEIL_SHAPE(7, 5); GDV_CEIL_SHAPE(2, 3);
+#undef GDV_CEIL_SHAPE
+  return hipErrorInvalidValue;
+}
 
 int64_t ScanChunks(int64_t m) { return (m + kScanChunk - 1) / kScanChunk; }
 

@@ -758,8 +758,17 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
           out->vlane = "false";
           return Status::OK();
         }
+        std::string pattern = pat.value().bytes;
+        if (fn.name() == "ilike") {
+          // case-insensitive: the pattern's ASCII letters are lowered here, the string is read through the
+          // lower-case byte map (a whole-column argument stays a whole-column view: the sweep still answers '%needle%')
+          for (auto& ch : pattern)
+            if (ch >= 'A' && ch <= 'Z') ch = static_cast<char>(ch + 32);
+          args[0].v = Tmp("gdv_str", "lower_utf8(" + args[0].v + ")");
+          if (args[0].col_slot >= 0) args[0].col_map = 2;
+        }
         std::string bytes, kinds;
-        GDV_RETURN_NOT_OK(CompileLike(pat.value().bytes, escape, &bytes, &kinds));
+        GDV_RETURN_NOT_OK(CompileLike(pattern, escape, &bytes, &kinds));
         out->vcols = args[0].vcols;
         out->vlane = args[0].vlane;
         // common shapes skip the general matcher: literal | literal% | %literal | %literal%

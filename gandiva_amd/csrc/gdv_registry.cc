@@ -267,6 +267,11 @@ FunctionRegistry::FunctionRegistry() {
   add("lengthUtf8", {binary()}, int32(), NullPolicy::kNullIfNull, 0, "char_length_utf8");
   add("like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
   add("like", {utf8(), utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
+  // ilike (round 4): like without regard to the case of ASCII letters — both sides are read through the
+  // lower-case byte map, so every fast path of like (prefix / suffix / equality / '%needle%' answered by
+  // the byte sweep) serves it.  The lineage folds case through RE2 (Unicode simple folding); letters
+  // outside ASCII compare exactly here: recollection + a stated limit, "parity unpinned".
+  add("ilike", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
   add("upper", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("lower", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("substr", {utf8(), int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);

@@ -784,6 +784,13 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       } else if (!strcmp(f, "like")) {
         int esc = n->nargs == 3 ? a[2].sp[i][0] : -1;
         out->v[i].i = like_match(x, xl, xm, y, yl, esc);
+      } else if (!strcmp(f, "ilike")) {
+        /* like, ASCII letters compared without regard to case (recollection: the lineage folds through
+         * RE2; letters outside ASCII compare exactly here) */
+        uint8_t* lp = (uint8_t*)malloc(yl + 1);
+        for (int k = 0; k < yl; k++) lp[k] = map_byte(map_byte(y[k], ym), 2);
+        out->v[i].i = like_match(x, xl, 2, lp, yl, -1);
+        free(lp);
       } else if (!strcmp(f, "upper") || !strcmp(f, "lower")) {
         out->sp[i] = x; out->sl[i] = xl; out->sm[i] = f[0] == 'u' ? 1 : 2;
       } else if (!strcmp(f, "substr") || !strcmp(f, "substring")) {

@@ -205,6 +205,10 @@ class StringTreeGen:
             return self.f["z"]
         roll = r.random()
         if roll < 0.35:
+            # (round 4: ilike = like without regard to the case of ASCII letters; mixed-case patterns)
+            if self.rng.random() < 0.3:
+                pat = "".join(c.upper() if self.rng.random() < 0.5 else c for c in self.pick(PATTERNS))
+                return b.make_function("ilike", [self.string(depth - 1), b.make_literal(pat, STR)], BOOL)
             return b.make_function("like", [self.string(depth - 1), b.make_literal(self.pick(PATTERNS), STR)], BOOL)
         if roll < 0.5:
             op = self.pick(["equal", "not_equal", "less_than", "greater_than_or_equal_to"])

@@ -106,6 +106,8 @@ def py_eval(node, row):
         return _substr(*a)
     if f == "like":
         return _like(a[0], a[1])
+    if f == "ilike":
+        return _like(_lower(a[0]), _lower(a[1]))
     if f in ("equal", "not_equal", "less_than", "greater_than_or_equal_to"):
         x, y = a[0].encode(), a[1].encode()
         return {"equal": x == y, "not_equal": x != y, "less_than": x < y, "greater_than_or_equal_to": x >= y}[f]

@@ -37,6 +37,9 @@ def _exprs(b, s):
         out.append(b.make_expression(node, pa.field(name, t)))
     for i, pat in enumerate(["%spark%", "spark%", "%spark", "s_ark%", "%", "", "a_b%c", "%a%b%", "_%_"]):
         add(f"like{i}", b.make_function("like", [s, lit(pat)], pa.bool_()), pa.bool_())
+    add("ilike0", b.make_function("ilike", [s, lit("%SpArK%")], pa.bool_()), pa.bool_())
+    add("ilike1", b.make_function("ilike", [s, lit("mixed c_se%")], pa.bool_()), pa.bool_())
+    add("ilike_up", b.make_function("ilike", [b.make_function("upper", [s], pa.string()), lit("%spark%")], pa.bool_()), pa.bool_())
     add("like_esc", b.make_function("like", [s, lit("100#%"), lit("#")], pa.bool_()), pa.bool_())
     add("like_esc2", b.make_function("like", [s, lit("a\\_b\\%c"), lit("\\")], pa.bool_()), pa.bool_())
     add("starts", b.make_function("starts_with", [s, lit("spa")], pa.bool_()), pa.bool_())
