@@ -184,6 +184,15 @@ def c3_condition(builder=None):
     return b.make_condition(b.make_and([gt, lt]))
 
 
+def c3_sum_expression(builder=None):
+    """[a + b]: what the filter -> project chain of tools/filter_project_chain.py (and the fused
+    filter-project kernel) projects for the rows C3's condition selects."""
+    b = builder or gdv.TreeExprBuilder()
+    s = c3_schema()
+    a, bb = b.make_field(s.field(0)), b.make_field(s.field(1))
+    return [b.make_expression(b.make_function("add", [a, bb], pa.int64()), pa.field("s", pa.int64()))]
+
+
 def c3_batch(n, null_fraction=0.0):
     a = np.random.Generator(np.random.PCG64(7)).integers(0, 1000, n, dtype=np.int64)
     b = np.random.Generator(np.random.PCG64(8)).integers(0, 1000, n, dtype=np.int64)
