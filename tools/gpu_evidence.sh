@@ -3,29 +3,37 @@
 # default bench line, rocprofv3 kernel stats of the same command, PMC passes (FETCH_SIZE /
 # WRITE_SIZE, separate, kernel-trace only) on the FINAL kernels of C2..C5, the other workloads'
 # bench lines + kernel stats, Make latency, small-batch latency, registry-tail timing, the
-# in-process multi-device runs.  Raw output: gpurun_out/<round>/ ; condensed into profiles/ by
-# tools/summarize_round.py <round>.      ROUND=r03 bash tools/gpu_evidence.sh
+# in-process multi-device runs; round 4: the fused filter-project, C5 on non-ASCII columns, C4 run
+# three times plain and three times under rocprofv3 on this one box (the 9 % gap of round 3).
+# Raw output: gpurun_out/<round>/ ; condensed into profiles/ by tools/summarize_round.py <round>.
+#      ROUND=r04 bash tools/gpu_evidence.sh
 export TMPDIR=/tmp
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$ROUND; rm -rf $OUT; mkdir -p $OUT
 cd $R
-python -m pytest tests -m gpu -q --timeout 1800 > $OUT/pytest_gpu_full.log 2>&1
-grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu_full.log | tail -5
+if [ -z "$SKIP_TESTS" ]; then
+  python -m pytest tests -m gpu -q --timeout 1800 > $OUT/pytest_gpu_full.log 2>&1
+  grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu_full.log | tail -5
+fi
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.log
-python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-400 $OUT/bench_c2.json
+python bench.py --steps 20 --warmup 5 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-400 $OUT/bench_c2.json
 for w in c1 c3 c4 c5; do python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2>$OUT/bench_$w.err; done
 for w in c3 c4 c5; do python bench.py --workload $w --steps 3 --warmup 1 > $OUT/bench_${w}_cpu.json 2>/dev/null; done
 cd /tmp
 for w in c2 c3 c4 c5; do
-  rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o $w --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline > $OUT/prof_${w}_bench.json 2> /dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o $w --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline --no-verify > $OUT/prof_${w}_bench.json 2> /dev/null
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
 done
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_c5_$tag -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_c5_$tag -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
 done
+# C4: the same command three times plain and three times under rocprofv3, back to back on this box
+{ for i in 1 2 3; do python $R/bench.py --workload c4 --no-cpu-baseline --no-verify 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('plain   run $i: ms_per_step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'min', r['kernel_ms_min'], 'max', r['kernel_ms_max'], 'sclk', r['box'].get('sclk_mhz'))"; done
+  for i in 1 2 3; do rocprofv3 --kernel-trace --stats -d $OUT/c4rep_$i -o c4 --output-format csv -- python $R/bench.py --workload c4 --no-cpu-baseline --no-verify 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); r=d['roofline']; print('rocprof run $i: ms_per_step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'sclk', r['box'].get('sclk_mhz'))"
+    grep '^"gdv_k_' $(find $OUT/c4rep_$i -name "*kernel_stats.csv" | head -1) | awk -F, '{printf "          rocprofv3 average of %s: %.4f ms over %s calls\n", $1, $4/1e6, $2}'; done; } > $OUT/c4_repeat.txt 2>&1
 cd $R
 python tools/make_latency.py > $OUT/make_latency.txt 2>&1
 [ -x tools/hbm_ceiling ] && timeout 120 tools/hbm_ceiling > $OUT/hbm_ceiling.txt 2>&1
@@ -33,9 +41,15 @@ python tools/make_latency.py > $OUT/make_latency.txt 2>&1
 python tools/micro_benchmarks.py > $OUT/micro_benchmarks.txt 2>&1
 PYTHONPATH=$R timeout 60 python tools/flat_only_timing.py > $OUT/flat_only_plans.txt 2>&1
 PYTHONPATH=$R timeout 120 python tools/registry_tail_timing.py > $OUT/registry_tail_timing.txt 2>&1
-PYTHONPATH=$R timeout 120 python tools/filter_project_chain.py > $OUT/filter_project_chain.txt 2>&1
+PYTHONPATH=$R timeout 200 python tools/filter_project_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_project_chain.txt
+PYTHONPATH=$R timeout 200 python tools/fused_fp_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_project.txt
+PYTHONPATH=$R timeout 300 python tools/c5_nonascii.py 2>&1 | grep -v amdgpu.ids > $OUT/c5_nonascii.txt
+( cd /tmp; rocprofv3 --kernel-trace --stats -d $OUT/prof_c5na -o na --output-format csv -- python $R/tools/c5_nonascii_profile.py > /dev/null 2>&1 )
+grep '^"gdv_k_' $(find $OUT/prof_c5na -name "*kernel_stats.csv" | head -1) | awk -F, '{printf "rocprofv3, 1 %% non-ASCII rows: %s average %.4f ms over %s calls\n", $1, $4/1e6, $2}' >> $OUT/c5_nonascii.txt
 # in-process multi-device: N host threads over N device contexts (virtual on a one-GPU box)
 for n in 1 2 8; do echo "--inproc --gpus $n: $(timeout 300 python bench.py --inproc --gpus $n --steps 10 --warmup 2 2>&1 | tail -1 | cut -c1-420)"; done > $OUT/inproc_bench.txt
+# the N-rank launch path on this one-GPU box (gloo: the ranks share cuda:0 — control flow, not scaling)
+echo "GDV_BENCH_BACKEND=gloo bench.py --gpus 2 --rows 16777216: $(GDV_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --rows 16777216 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 | cut -c1-600)" > $OUT/bench_two_ranks.txt
 find $OUT -name "*kernel_trace.csv" -size +1000k -delete   # raw traces are large; stats / counters stay
 find $OUT -name "*.csv" -size +8000k -delete
-du -sh $OUT; ls $OUT | head -60
+du -sh $OUT; ls $OUT | head -70

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import summarize_prof as SP  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles")
 
@@ -59,7 +59,8 @@ if acc:
             f.write(f"{k:22s} total {sum(v):.4g}  launches {len(v)}  per_wave {sum(v) / waves * (len(acc.get('SQ_WAVES', [1])) / len(v)):.1f}\n")
 for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt",
              "small_batches.txt", "registry_tail_timing.txt", "flat_only_plans.txt", "inproc_bench.txt", "multi_device.txt",
-             "c5_variants.txt", "filter_project_chain.txt"):
+             "c5_variants.txt", "filter_project_chain.txt", "filter_project.txt", "c5_nonascii.txt", "c4_repeat.txt",
+             "bench_two_ranks.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, ROUND + "_" + name))
