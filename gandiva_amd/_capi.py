@@ -98,6 +98,7 @@ PROTOTYPES = [
     ("gdv_filter_free", None, [_P]),
     ("gdv_filter_set_tuning", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("gdv_filter_project_make", C.c_int, [_P, _P, C.POINTER(_P), C.c_int, C.c_int, C.POINTER(gdv_config_t), C.POINTER(_P)]),
+    ("gdv_filter_project_make_from_proto", C.c_int, [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.POINTER(gdv_config_t), C.POINTER(_P)]),
     ("gdv_filter_project_num_outputs", C.c_int, [_P]),
     ("gdv_filter_project_output_type", gdv_type_t, [_P, C.c_int]),
     ("gdv_filter_project_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), _P, C.c_int, _P, C.c_uint32]),

@@ -541,6 +541,29 @@ int gdv_filter_make_from_proto(const void* schema_bytes, int64_t schema_len, con
   return GDV_OK;
   });
 }
+int gdv_filter_project_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* condition_bytes,
+                                       int64_t condition_len, const void* exprs_bytes, int64_t exprs_len, int index_mode,
+                                       const gdv_config_t* config, gdv_filter_project_t** out) {
+  return Guarded([&]() -> int {
+  if (!out || schema_len < 0 || condition_len < 0 || exprs_len < 0) return Fail(Status::Invalid("bad argument"));
+  SelectionMode mode;
+  if (!ToSelectionMode(index_mode, &mode)) return Fail(Status::Invalid("bad selection mode"));
+  Schema schema;
+  ExpressionPtr cond;
+  std::vector<ExpressionPtr> exprs;
+  Status s = DecodeSchema(static_cast<const uint8_t*>(schema_bytes), static_cast<size_t>(schema_len), &schema);
+  if (s.ok()) s = DecodeCondition(static_cast<const uint8_t*>(condition_bytes), static_cast<size_t>(condition_len), &cond);
+  if (s.ok()) s = DecodeExpressionList(static_cast<const uint8_t*>(exprs_bytes), static_cast<size_t>(exprs_len), &exprs);
+  if (!s.ok()) return Fail(s);
+  Configuration cfg;
+  if (config) { cfg.optimize = config->optimize != 0; cfg.dump_ir = config->dump_ir != 0; }
+  std::shared_ptr<FilterProject> fp;
+  s = FilterProject::Make(schema, cond, exprs, mode, cfg, &fp);
+  if (!s.ok()) return Fail(s);
+  *out = new gdv_filter_project{fp};
+  return GDV_OK;
+  });
+}
 // the decoded trees, rendered (what a test — or a maintainer diffing against the Java side — reads)
 char* gdv_proto_describe(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes, int64_t exprs_len,
                          int is_condition) {

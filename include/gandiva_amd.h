@@ -407,6 +407,10 @@ int gdv_projector_make_from_proto(const void* schema_bytes, int64_t schema_len, 
                                   gdv_projector_t** out);
 int gdv_filter_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* condition_bytes,
                                int64_t condition_len, const gdv_config_t* config, gdv_filter_t** out);
+/* the fused filter -> project operator (gdv_filter_project_*) from the same three messages */
+int gdv_filter_project_make_from_proto(const void* schema_bytes, int64_t schema_len, const void* condition_bytes,
+                                       int64_t condition_len, const void* exprs_bytes, int64_t exprs_len, int index_mode,
+                                       const gdv_config_t* config, gdv_filter_project_t** out);
 /* The decoded schema and trees rendered as text (NULL + gdv_last_error on malformed bytes). */
 char* gdv_proto_describe(const void* schema_bytes, int64_t schema_len, const void* exprs_bytes, int64_t exprs_len,
                          int is_condition);

@@ -239,3 +239,25 @@ def test_fused_filter_project_at_c3_scale_against_torch():
     assert bool((outs[0].validity[:k // 8] == 0xff).all())
     if k % 8:
         assert int(outs[0].validity[k // 8]) == (1 << (k % 8)) - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzzed_trees_through_the_fused_operator_match_the_oracle_chain(seed):
+    """The random numeric trees of tests/test_fuzz_trees.py (every fixed-width type, if/else, three-valued
+    AND / OR, IN lists, casts, bool outputs) as condition + projections of ONE fused kernel, in all three
+    index widths and without a selection vector, against the oracle's filter -> take -> project."""
+    import test_fuzz_trees as F
+    exprs, cond = F._expressions(seed)
+    n = [1, 63, 64, 65, 1000, 8191, 8193, 60001][seed % 8]
+    batch = F._batch(seed, n)
+    dtype = [None, "int16", "int32", "int64"][seed % 4]
+    fp = gandiva.make_filter_project(batch.schema, cond, exprs, dtype)
+    assert fp.fused, "numeric trees are a fused shape"
+    got, sel = fp.evaluate(batch)
+    want_sel = oracle.filter_indices(cond, batch, dtype or "int32")
+    if dtype is not None:
+        assert sel.to_array().equals(want_sel), f"seed {seed}: {cond}"
+    want = oracle.project(exprs, batch)
+    for g, w, e in zip(got, want, exprs):
+        assert_bit_exact(g, oracle.take_rows(w, want_sel.to_numpy()), f"seed {seed}: {e}")

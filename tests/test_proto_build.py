@@ -203,3 +203,34 @@ def test_type_parameters_in_the_bytes_are_validated():
     # negative lengths
     assert not lib.gdv_proto_describe(sb, -1, b"", 0, 0)
     assert not lib.gdv_proto_describe(sb, len(sb), b"", -5, 0)
+
+
+@pytest.mark.gpu
+def test_the_filter_project_kat_as_one_fused_operator_built_from_proto_bytes():
+    """pyarrow/tests/test_gandiva.py:329-373 (filter -> UINT32 selection -> project, one null) through
+    gdv_filter_project_make_from_proto + gdv_filter_project_evaluate: ONE kernel, same answer."""
+    kat = [k for k in KATS if k()[0] == "filter_project"][0]
+    _, batch, (cond, exprs), expected = kat()
+    lib = _capi.lib()
+    sb, cb, eb = P.schema(batch.schema), P.condition(cond), P.expression_list(exprs)
+    fp = C.c_void_p()
+    assert lib.gdv_filter_project_make_from_proto(sb, len(sb), cb, len(cb), eb, len(eb), 2, None, C.byref(fp)) == 0, \
+        _capi.last_error()
+    n = batch.num_rows
+    cols = (_capi.gdv_column_t * batch.num_columns)(*[gandiva.gandiva._column_of_array(a) for a in batch.columns])
+    outs = (_capi.gdv_out_column_t * len(exprs))()
+    keep = []
+    for i, e in enumerate(exprs):
+        v, d = np.zeros(64, np.uint8), np.zeros(n * 8 + 64, np.uint8)
+        keep.append((v, d))
+        outs[i].validity, outs[i].validity_size = v.ctypes.data, v.nbytes
+        outs[i].data, outs[i].data_size = d.ctypes.data, d.nbytes
+    idx = np.zeros(n, np.uint32)
+    count = C.c_int64()
+    assert lib.gdv_filter_project_evaluate(fp, n, cols, batch.num_columns, outs, len(exprs), C.c_void_p(idx.ctypes.data), n,
+                                           C.byref(count), None, 0, None, 0) == 0, _capi.last_error()
+    k = count.value
+    for (v, d), e, w in zip(keep, exprs, expected):
+        got = pa.Array.from_buffers(e.result().type, k, [pa.py_buffer(v), pa.py_buffer(d)])
+        assert got.equals(w), (got, w)
+    lib.gdv_filter_project_free(fp)
