@@ -108,6 +108,7 @@ PROTOTYPES = [
     ("gdv_registry_size", C.c_int, []),
     ("gdv_registry_get", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(gdv_type_t), C.POINTER(gdv_type_t), C.c_int, C.POINTER(C.c_int)]),
     ("gdv_device_stream_ceiling", C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("gdv_device_stream_ceiling_on", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("gdv_device_count", C.c_int, []),
     ("gdv_physical_device_count", C.c_int, []),
     ("gdv_set_virtual_devices", C.c_int, [C.c_int]),

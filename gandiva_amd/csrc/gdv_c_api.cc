@@ -849,6 +849,26 @@ int gdv_device_stream_ceiling(int64_t bytes_per_stream, int num_read, int num_wr
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
   });
 }
+int gdv_device_stream_ceiling_on(void* const* streams, int num_read, int num_write, int64_t elems, double* gbs,
+                                 int* workgroups_per_cu, int* nontemporal) {
+  return Guarded([&]() -> int {
+  if (!streams || !gbs || elems < 1024 || num_read < 0 || num_write < 0 || num_read + num_write < 1 || num_read > 10 ||
+      num_write > 10)
+    return Fail(Status::Invalid("bad argument"));
+  for (int i = 0; i < num_read + num_write; i++)
+    if (streams[i] == nullptr) return Fail(Status::Invalid("null stream"));
+  Runtime& rt = Runtime::Get();
+  Status st = rt.EnsureDevice();
+  if (!st.ok()) return Fail(st);
+  int wg = 0, nt = 0;
+  hipError_t e = MeasureStreamCeiling(streams, num_read, num_write, static_cast<size_t>(elems), rt.num_cus(), gbs, &wg, &nt);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipErrorInvalidValue) return Fail(Status::Invalid("no ceiling kernel for this (reads, writes) shape"));
+  if (workgroups_per_cu) *workgroups_per_cu = wg;
+  if (nontemporal) *nontemporal = nt;
+  return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
+  });
+}
 int gdv_device_synchronize(void) {
   hipError_t e = hipDeviceSynchronize();
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));

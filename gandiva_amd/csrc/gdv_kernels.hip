@@ -332,25 +332,38 @@ hipError_t StreamCeilingFor(const CeilPointers& P, size_t n, int num_cus, double
   err = hipEventCreate(&e1);
   if (err != hipSuccess) { (void)hipEventDestroy(e0); return err; }
   const double moved = (double)(NR + NW) * 8.0 * (double)(n / 1024 * 1024);
-  *best_gbs = 0;
-  for (int nt = 0; nt < 2 && err == hipSuccess; nt++) {
-    for (int per_cu = 2; per_cu <= 32 && err == hipSuccess; per_cu *= 2) {
-      const int grid = num_cus * per_cu;
-      float best = 1e30f;
-      for (int it = 0; it < 3 && err == hipSuccess; it++) {
-        err = hipEventRecord(e0, nullptr);
-        if (nt) hipLaunchKernelGGL((CeilStream<NR, NW, true>), dim3(grid), dim3(256), 0, nullptr, P, n);
-        else hipLaunchKernelGGL((CeilStream<NR, NW, false>), dim3(grid), dim3(256), 0, nullptr, P, n);
-        if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
-        if (err == hipSuccess) err = hipEventSynchronize(e1);
-        float ms = 0;
-        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
-        if (it >= 1 && ms < best) best = ms;
-      }
-      const double gbs = moved / (best * 1e-3) / 1e9;
-      if (err == hipSuccess && gbs > *best_gbs) { *best_gbs = gbs; *best_grid = per_cu; *best_nt = nt; }
+  auto time_once = [&](int per_cu, int nt) -> float {
+    const int grid = num_cus * per_cu;
+    if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
+    if (nt) hipLaunchKernelGGL((CeilStream<NR, NW, true>), dim3(grid), dim3(256), 0, nullptr, P, n);
+    else hipLaunchKernelGGL((CeilStream<NR, NW, false>), dim3(grid), dim3(256), 0, nullptr, P, n);
+    if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 1e30f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+  };
+  // coarse pass: every (grid, nt) once after one warm-up launch; then the two best configurations
+  // are timed six more times each and the minimum taken — a single short launch on a GPU whose clocks
+  // are still moving is not a measurement (round 4: 5.3 .. 6.2 TB/s for the same configuration within
+  // one second on one box)
+  struct Cfg { int per_cu, nt; float ms; };
+  Cfg cfgs[10];
+  int nc = 0;
+  (void)time_once(8, 0);
+  for (int nt = 0; nt < 2; nt++)
+    for (int per_cu = 2; per_cu <= 32; per_cu *= 2) cfgs[nc++] = Cfg{per_cu, nt, time_once(per_cu, nt)};
+  for (int i = 0; i < nc; i++)
+    for (int j = i + 1; j < nc; j++)
+      if (cfgs[j].ms < cfgs[i].ms) { const Cfg t = cfgs[i]; cfgs[i] = cfgs[j]; cfgs[j] = t; }
+  float best = 1e30f;
+  for (int c = 0; c < 2 && err == hipSuccess; c++) {
+    for (int it = 0; it < 6; it++) {
+      const float ms = time_once(cfgs[c].per_cu, cfgs[c].nt);
+      if (ms < best) { best = ms; *best_grid = cfgs[c].per_cu; *best_nt = cfgs[c].nt; }
     }
   }
+  *best_gbs = moved / (best * 1e-3) / 1e9;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return err != hipSuccess ? err : hipGetLastError();

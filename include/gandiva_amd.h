@@ -376,6 +376,12 @@ int gdv_device_hbm_ceilings(int64_t bytes, double* read_gbs, double* write_gbs, 
  * (2,3).  A product kernel of that shape should not beat it: achieved / ceiling <= 1 on every box. */
 int gdv_device_stream_ceiling(int64_t bytes_per_stream, int num_read, int num_write, double* gbs, int* workgroups_per_cu,
                               int* nontemporal);
+/* The same sweep over the CALLER's buffers: streams[0 .. num_read) are read, the next num_write are
+ * OVERWRITTEN, `elems` 8-byte elements each.  bench.py runs it on the very buffers the timed loop used
+ * (after verifying them): same addresses, same sizes, same traffic shape — what is left between that
+ * rate and the product kernel's is the kernel, not the box or where its memory happens to sit. */
+int gdv_device_stream_ceiling_on(void* const* streams, int num_read, int num_write, int64_t elems, double* gbs,
+                                 int* workgroups_per_cu, int* nontemporal);
 
 /* ---- JNI-shaped flat entry points --------------------------------- */
 /* What the reference's JNI layer receives from Java (JniWrapper.evaluateProjector /
