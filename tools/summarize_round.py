@@ -54,7 +54,7 @@ if acc:
     with open(os.path.join(DST, ROUND + "_c5_sq_counters.txt"), "w") as f:
         waves = sum(acc.get("SQ_WAVES", [0])) or 1
         f.write("# C5 kernels (pre-pass + main), SQ counters summed over the profiled launches; per wave = / SQ_WAVES\n")
-        f.write("# (main kernel: one wave = one wave tile = 512 rows = 8 sub-tiles of 64 rows; the pre-pass walks several tiles per wave; totals are per 5 profiled Evaluates of each kernel)\n")
+        f.write("# (main kernel: one wave = one wave tile = 512 rows = 8 sub-tiles of 64 rows; the pre-pass walks several tiles per wave; launches = every Evaluate of the profiled command, pre-warm steps included)\n")
         for k, v in sorted(acc.items()):
             f.write(f"{k:22s} total {sum(v):.4g}  launches {len(v)}  per_wave {sum(v) / waves * (len(acc.get('SQ_WAVES', [1])) / len(v)):.1f}\n")
 for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt",
