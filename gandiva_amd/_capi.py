@@ -83,6 +83,7 @@ PROTOTYPES = [
     ("gdv_projector_output_sizes", C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("gdv_projector_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_selection_t), C.POINTER(gdv_out_column_t), C.c_int, C.c_int, _P, C.c_uint32]),
     ("gdv_projector_evaluate_selected", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_selection_t), _P, C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_uint32]),
+    ("gdv_projector_evaluate_async", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_selection_t), _P, C.POINTER(gdv_out_column_t), C.c_int, _P, _P]),
     ("gdv_projector_evaluate_many", C.c_int, [_P, C.POINTER(gdv_batch_t), C.c_int, _P, C.c_uint32]),
     ("gdv_projector_dump_ir", _P, [_P]),
     ("gdv_projector_path_hint", C.c_int, [_P]),

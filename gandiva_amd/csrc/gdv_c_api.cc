@@ -395,6 +395,31 @@ int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, 
   return ProjectorEvaluate(p, num_rows, cols, num_cols, sel, num_slots_device, outs, num_outs, GDV_MEM_DEVICE, stream,
                            flags);
 }
+int gdv_projector_evaluate_async(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                 const gdv_selection_t* sel, const void* num_slots_device, gdv_out_column_t* outs,
+                                 int num_outs, void* stream, void* result) {
+  return Guarded([&]() -> int {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
+  if (!outs || !result) return Fail(Status::Invalid("Output array vector and result block cannot be null"));
+  std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+  std::vector<OutputBuffers> o(num_outs > 0 ? num_outs : 0);
+  for (int i = 0; i < num_outs; i++) {
+    o[i].validity = outs[i].validity; o[i].validity_size = outs[i].validity_size;
+    o[i].data = outs[i].data; o[i].data_size = outs[i].data_size;
+    o[i].offsets = outs[i].offsets; o[i].offsets_size = outs[i].offsets_size;
+  }
+  SelectionView sv;
+  if (sel) {
+    if (!ToSelectionMode(sel->mode, &sv.mode)) return Fail(Status::Invalid("bad selection mode"));
+    sv.indices = sel->indices;
+    sv.num_slots = sel->num_slots;
+    sv.num_slots_device = num_slots_device;
+  }
+  return Check(p->p->EvaluateAsync(num_rows, c.data(), num_cols, sel ? &sv : nullptr, o.data(), num_outs,
+                                   static_cast<hipStream_t>(stream), result));
+  });
+}
 int gdv_projector_evaluate_many(const gdv_projector_t* p, const gdv_batch_t* batches, int num_batches, void* stream,
                                 uint32_t flags) {
   return Guarded([&]() -> int {

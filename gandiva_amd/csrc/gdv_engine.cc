@@ -1131,6 +1131,185 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
   return Status::OK();
 }
 
+// ------------------------------------------------------------------ var-len plans, asynchronously
+
+Status Projector::EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
+                                OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const {
+  if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (outs == nullptr || result == nullptr) return Status::Invalid("Output array vector and result block cannot be null");
+  if (num_outs != num_outputs()) return Status::Invalid("number of output buffers does not match the number of expressions");
+  if (pre_ != nullptr) return Status::Invalid("two-stage plans are evaluated synchronously (their first stage sizes the temporaries)");
+  const bool has_sel = sel != nullptr && sel->mode != SelectionMode::kNone;
+  if (has_sel != (plan_.mode != SelectionMode::kNone) || (has_sel && sel->mode != plan_.mode))
+    return Status::Invalid("selection vector type does not match the mode the projector was built for");
+  const int64_t out_rows = has_sel ? sel->num_slots : num_rows;   // (with a device-resident count: the capacity)
+  if (has_sel && (sel->num_slots < 0 || (out_rows > 0 && sel->indices == nullptr)))
+    return Status::Invalid("selection vector: invalid slot count or no buffer");
+  const int nv = plan_.num_varlen_outputs;
+  uint64_t* const res = static_cast<uint64_t*>(result);
+  if (nv == 0) {  // fixed-width plans: the ordinary asynchronous launch; no byte totals, errors only if the plan cannot raise
+    if (plan_.can_raise) return Status::Invalid("a fixed-width plan that can raise is evaluated synchronously");
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));
+    return Evaluate(num_rows, cols, num_cols, sel, outs, num_outs, MemKind::kDevice, stream, kEvalAsync);
+  }
+  if (out_rows == 0) {
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));
+    for (int e = 0; e < num_outs; e++)
+      if (plan_.output_types[e].is_varlen() && outs[e].offsets != nullptr)
+        GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(outs[e].offsets, 0, 4, stream));
+    return Status::OK();
+  }
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  const PlanDeviceState* dev = nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+
+  ArgBlock args(plan_.layout);
+  Staging st;
+  DeviceBuffer state, wave_head, wave_counts, wave_bases, wave_chunks;
+  StreamDrain drain{stream, false};  // declared last: an error return after the first enqueue waits before the blocks go back
+  GDV_RETURN_NOT_OK(BindInputs(plan_, plan_schema_, cols, num_cols, num_rows, MemKind::kDevice, stream, &args, &st,
+                               has_sel ? out_rows : -1));
+  BindLiterals(plan_, dev->consts, &args);
+  drain.armed = !st.buffers.empty();   // (a tiny var-len buffer was copied into a padded pool block)
+  args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
+  if (has_sel) {
+    args.SetPtr(ArgLayout::kOffSel, sel->indices);
+    args.SetPtr(ArgLayout::kOffAux2, sel->num_slots_device);  // null: the count is kOffN
+  }
+  std::vector<int> vl;
+  for (int e = 0; e < num_outs; e++) {
+    const DataType& t = plan_.output_types[e];
+    const int64_t need_valid = ValidityBytes(out_rows), need_data = t.is_varlen() ? 0 : DataBytes(t, out_rows);
+    if (outs[e].validity == nullptr || outs[e].validity_size < need_valid || outs[e].data_size < need_data ||
+        (outs[e].data == nullptr && (need_data > 0 || outs[e].data_size > 0)))
+      return Status::Invalid("output buffer " + std::to_string(e) + " too small");
+    if (t.is_varlen()) {
+      if (outs[e].offsets == nullptr || outs[e].offsets_size < (out_rows + 1) * 4)
+        return Status::Invalid("output buffer " + std::to_string(e) + ": offsets buffer too small");
+      vl.push_back(e);
+    }
+    args.SetOutData(e, outs[e].data);
+    args.SetOutValid(e, outs[e].validity);
+    args.SetOutOffsets(e, outs[e].offsets);
+    if (t.is_varlen()) args.SetOutCap(e, outs[e].data_size);
+  }
+  GDV_RETURN_NOT_OK(st.FlushIn(stream));
+  GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));
+  drain.armed = true;
+
+  const int ng = (nv + 1) / 2;
+  const size_t totals_bytes = static_cast<size_t>(2 * ng) * 8;
+  const bool has_optimistic = plan_.wave_tiles || plan_.has_flat_output;
+  int path = !has_optimistic ? 2 : (EngineKnobs::Get().no_optflat ? 2 : path_hint_.load(std::memory_order_relaxed));
+  if (path == 1 && !(plan_.wave_tiles && plan_.exact != nullptr)) path = 2;
+  EvalTrace trace("project-async", plan_.kernel_name, out_rows, stream);
+  if (path != 2 && plan_.wave_tiles) {
+    // ---- wave shape: pre-pass -> offsets scan -> main kernel (the optimistic pair or its exact variant)
+    const CompiledKernel* k_main = dev->kernel;
+    const CompiledKernel* k_pre = dev->kernel_pre;
+    const KernelPlan* pp = plan_.prepass.get();
+    if (path == 1) {
+      PlanDeviceState* d = const_cast<PlanDeviceState*>(dev);
+      if (d->kernel_exact.load() == nullptr) {
+        const CompiledKernel* k = nullptr;
+        GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->source, plan_.exact->kernel_name, &k));
+        if (plan_.exact->prepass) {
+          const CompiledKernel* kp = nullptr;
+          GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->prepass->source, plan_.exact->prepass->kernel_name, &kp));
+          d->kernel_pre_exact.store(kp);
+        }
+        d->kernel_exact.store(k);
+      }
+      k_main = dev->kernel_exact.load();
+      k_pre = dev->kernel_pre_exact.load();
+    }
+    int nseg = 0;
+    for (int sgm : plan_.wave_segments) nseg = std::max(nseg, sgm + 1);
+    const size_t head_bytes = 8 + totals_bytes + static_cast<size_t>(nseg) * 8;
+    const int64_t rows_wt = 64 * static_cast<int64_t>(plan_.opts.subtiles);
+    const int64_t nwt = (out_rows + rows_wt - 1) / rows_wt;
+    const int64_t seg_stride = (nwt + 3) & ~int64_t{3};
+    GDV_RETURN_NOT_OK(wave_head.Allocate(head_bytes));
+    char* const head = wave_head.as<char>();
+    args.SetPtr(ArgLayout::kOffErr, head);
+    args.SetPtr(ArgLayout::kOffCounts, head + 8);
+    args.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(head, 0, head_bytes, stream));
+    const int64_t grid = GridFor(plan_, out_rows);
+    if (nseg > 0) {
+      if (pp == nullptr || k_pre == nullptr) return Status::ExecutionError("internal: wave plan without a pre-pass");
+      GDV_RETURN_NOT_OK(wave_counts.Allocate(static_cast<size_t>(nseg * seg_stride) * 4 + 64));
+      GDV_RETURN_NOT_OK(wave_bases.Allocate(static_cast<size_t>(nseg * seg_stride) * 8));
+      GDV_RETURN_NOT_OK(wave_chunks.Allocate(static_cast<size_t>(nseg * ScanChunks(nwt)) * 8));
+      args.SetPtr(ArgLayout::kOffMask, wave_bases.get());
+      ArgBlock pargs(pp->layout);
+      for (size_t kp = 0; kp < pp->input_fields.size(); kp++) {
+        int k = -1;
+        for (size_t j = 0; j < plan_.input_fields.size(); j++)
+          if (plan_.input_fields[j] == pp->input_fields[kp]) k = static_cast<int>(j);
+        if (k < 0) return Status::ExecutionError("internal: pre-pass input not bound by the main kernel");
+        pargs.CopyInSlot(static_cast<int>(kp), args, k);
+      }
+      BindLiterals(*pp, dev->consts_pre, &pargs);
+      pargs.Set64(ArgLayout::kOffN, static_cast<uint64_t>(out_rows));
+      pargs.SetPtr(ArgLayout::kOffErr, head);
+      pargs.SetPtr(ArgLayout::kOffCounts, wave_counts.get());
+      pargs.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
+      GDV_RETURN_NOT_OK(rt.Launch(*k_pre, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
+                                  plan_.opts.waves * 64, pargs.data(), pargs.size(), stream));
+      int32_t* closing[kMaxScanSegments] = {};
+      for (int v = 0; v < nv; v++)
+        if (plan_.wave_segments[v] >= 0) closing[plan_.wave_segments[v]] = static_cast<int32_t*>(outs[vl[v]].offsets) + out_rows;
+      GDV_HIP_RETURN_NOT_OK(LaunchSegmentedOffsetsScan(wave_counts.as<uint32_t>(), nwt, seg_stride, nseg,
+                                                       wave_chunks.as<uint64_t>(), wave_bases.as<uint64_t>(),
+                                                       reinterpret_cast<uint64_t*>(head + 8 + totals_bytes), closing, stream));
+    }
+    GDV_RETURN_NOT_OK(rt.Launch(*k_main, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(res, head, 4, hipMemcpyDefault, stream));   // the error word (upper half stays 0)
+    for (int v = 0; v < nv; v++) {
+      const char* src = plan_.wave_segments[v] >= 0 ? head + 8 + totals_bytes + 8 * plan_.wave_segments[v] : head + 8 + 8 * v;
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(res + 1 + vl[v], src, 8, hipMemcpyDefault, stream));
+    }
+  } else {
+    // ---- scanner shape: one launch (selection-mode plans; plans without a wave shape; path 2: the general kernel)
+    const CompiledKernel* active = dev->kernel;
+    if (has_optimistic && path == 2) {
+      if (dev->kernel_general.load() == nullptr) {
+        const CompiledKernel* k = nullptr;
+        GDV_RETURN_NOT_OK(rt.GetKernel(plan_.source_general, plan_.kernel_name_general, &k));
+        const_cast<PlanDeviceState*>(dev)->kernel_general.store(k);
+      }
+      active = dev->kernel_general.load();
+    }
+    const bool general = has_optimistic && path == 2 && plan_.wave_tiles;
+    const int sc_u = general && plan_.general_subtiles > 0 ? plan_.general_subtiles : plan_.opts.subtiles;
+    const int sc_w = general && plan_.general_waves > 0 ? plan_.general_waves : plan_.opts.waves;
+    const int64_t rows_wg = 64 * static_cast<int64_t>(sc_u) * sc_w;
+    const int64_t ntiles = (out_rows + rows_wg - 1) / rows_wg;
+    const size_t state_bytes = 8 + totals_bytes + static_cast<size_t>(2 * ng * ntiles) * 8;
+    GDV_RETURN_NOT_OK(state.Allocate(state_bytes));
+    char* const sp = state.as<char>();
+    args.SetPtr(ArgLayout::kOffErr, sp);
+    args.SetPtr(ArgLayout::kOffCounts, sp + 8);
+    args.SetPtr(ArgLayout::kOffMask, sp + 8 + totals_bytes);
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(sp, 0, state_bytes, stream));
+    GDV_RETURN_NOT_OK(rt.Launch(*active, std::max<int64_t>(1, ntiles) + 1, sc_w * 64, args.data(), args.size(), stream));
+    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(res, sp, 4, hipMemcpyDefault, stream));
+    for (int v = 0; v < nv; v++)
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(res + 1 + vl[v], sp + 8 + 8 * v, 8, hipMemcpyDefault, stream));
+  }
+  // scratch goes back to the pool when the stream has passed this point
+  state.release_after(stream);
+  wave_head.release_after(stream);
+  wave_counts.release_after(stream);
+  wave_bases.release_after(stream);
+  wave_chunks.release_after(stream);
+  for (auto& b : st.buffers) b.release_after(stream);
+  drain.armed = false;
+  return Status::OK();
+}
+
 // ------------------------------------------------------------------ Filter
 
 Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,

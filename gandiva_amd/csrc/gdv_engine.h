@@ -111,6 +111,21 @@ class Projector {
   };
   Status EvaluateMany(const BatchView* batches, int num_batches, hipStream_t stream, uint32_t flags) const;
 
+  // Var-len plans WITHOUT a host synchronisation (round 4; device buffers, single-stage plans).
+  // Everything is enqueued on `stream`: the kernels of the path this Projector is currently on (the
+  // optimistic wave pair, its exact variant or the scanner-shaped kernel; selection-mode plans: the
+  // scanner shape, which may take its slot count from sel->num_slots_device), then `result`
+  // ((1 + num_outs) x uint64 in device or pinned memory) receives, in stream order,
+  //   [0]      the device error word: 0 = the outputs are complete; any bit = discard them and evaluate
+  //            the batch with the synchronous call (a raised error, or an optimistic assumption —
+  //            ASCII, flat — that did not hold; the synchronous call then also moves the Projector to
+  //            the kernels that take such batches)
+  //   [1 + e]  the bytes output e produced (fixed-width outputs: 0).  More than the capacity
+  //            outs[e].data_size means the buffer was too small: nothing was written past it.
+  // Scratch goes back to the pool behind the stream.  outs[e].data_size is left as it was.
+  Status EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
+                       OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const;
+
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }
   const std::shared_ptr<Projector>& first_stage() const { return pre_; }

@@ -394,6 +394,15 @@ class DeviceColumn:
         if self.offsets is not None:
             bufs.append(pa.py_buffer(self.offsets.cpu().numpy()))
         used = getattr(self, "data_used", None)
+        pending = getattr(self, "result", None)
+        if pending is not None and self.offsets is not None:
+            # an asynchronous evaluation left the byte total on the device (gdv_projector_evaluate_async)
+            if int(pending[0]) != 0:
+                raise GandivaError("the asynchronous evaluation did not complete these outputs (status "
+                                   f"{int(pending[0])}): evaluate the batch with evaluate_device")
+            used = int(pending[1 + self.result_index])
+            if used > self.data.numel():
+                raise GandivaError(f"var-len output needs {used} bytes, the buffer holds {self.data.numel()}")
         data = self.data if used is None else self.data[:used]
         bufs.append(pa.py_buffer(data.cpu().numpy()))
         return pa.Array.from_buffers(self.type, self.num_rows, bufs, offset=self.offset)
@@ -661,6 +670,61 @@ class Projector:
             outputs[i].count_tensor = selection.count_tensor if pending else None
             outputs[i].length = out_rows
         return outputs
+
+
+def _evaluate_device_async(self, dbatch, selection=None, outputs=None, capacity_bytes=None, stream=None):
+    """Var-len plans without a host synchronisation (gdv_projector_evaluate_async): everything is enqueued and
+    the call returns ``(outputs, result)`` — ``result`` is a torch int64 tensor of 1 + num_outputs elements that
+    will hold, once the stream has passed: [0] the device status (0 = outputs complete; anything else: discard
+    them and call evaluate_device), [1 + e] the bytes output e produced (above its capacity: buffer too small).
+    ``selection`` may be a pending device SelectionVector (filter.evaluate_device(sync=False)): its count is
+    read on the device.  ``capacity_bytes``: byte capacity of every var-len output (default: the capacity
+    hint of earlier batches, else the bytes of the var-len inputs)."""
+    import torch
+    lib = _capi.lib()
+    cols = (gdv_column_t * max(len(dbatch.columns), 1))(*[c._c() for c in dbatch.columns])
+    pending = selection is not None and selection.device and selection.pending
+    if selection is not None and not selection.device:
+        raise TypeError("evaluate_device_async takes a device selection vector")
+    out_rows = dbatch.num_rows if selection is None else (selection.indices.numel() if pending else selection.num_slots)
+    n_out = len(self._out_types)
+    varlen = [pa.types.is_string(t) or pa.types.is_binary(t) for t in self._out_types]
+    if outputs is None:
+        outputs = []
+        guess = 64 + sum(c.data.numel() for c in dbatch.columns if c.offsets is not None)
+        for i, t in enumerate(self._out_types):
+            vb, db = C.c_int64(), C.c_int64()
+            _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_DEVICE, vb, db))
+            dbytes = (capacity_bytes or db.value or guess) if varlen[i] else max(db.value, 1)
+            outputs.append(DeviceColumn(t, out_rows, torch.empty(_pad64(max(vb.value, 1)), dtype=torch.uint8, device="cuda"),
+                                        torch.empty(_pad64(dbytes), dtype=torch.uint8, device="cuda"),
+                                        torch.empty(_pad64((out_rows + 1) * 4), dtype=torch.uint8, device="cuda") if varlen[i] else None))
+    outs = (gdv_out_column_t * n_out)()
+    for i, o in enumerate(outputs):
+        outs[i].validity, outs[i].validity_size = o.validity.data_ptr(), o.validity.numel()
+        outs[i].data, outs[i].data_size = o.data.data_ptr(), o.data.numel()
+        if o.offsets is not None:
+            outs[i].offsets, outs[i].offsets_size = o.offsets.data_ptr(), o.offsets.numel()
+    sel_c, cnt_ptr = None, None
+    if selection is not None:
+        s = gdv_selection_t()
+        s.mode, s.num_slots, s.indices = selection.mode, out_rows, selection.indices.data_ptr()
+        sel_c = C.byref(s)
+        if pending:
+            cnt_ptr = C.c_void_p(selection.count_tensor.data_ptr())
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    result = torch.zeros(1 + n_out, dtype=torch.int64, device="cuda")
+    _check(lib.gdv_projector_evaluate_async(self._h, dbatch.num_rows, cols, len(dbatch.columns), sel_c, cnt_ptr, outs, n_out,
+                                            C.c_void_p(stream), C.c_void_p(result.data_ptr())))
+    for i, o in enumerate(outputs):
+        o.length = out_rows
+        o.count_tensor = selection.count_tensor if pending else None
+        o.result, o.result_index = result, i   # (the byte total is result[1 + i] once the stream has passed)
+    return outputs, result
+
+
+Projector.evaluate_device_async = _evaluate_device_async
 
 
 def _evaluate_device_many(self, dbatches, outputs=None, stream=None, sync=True):

@@ -264,6 +264,24 @@ int gdv_projector_evaluate_many(const gdv_projector_t* p, const gdv_batch_t* bat
 int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols,
                                     int num_cols, const gdv_selection_t* sel, const void* num_slots_device,
                                     gdv_out_column_t* outs, int num_outs, void* stream, uint32_t flags);
+/* Var-len (utf8 / binary) plans WITHOUT a host synchronisation (round 4).  gdv_projector_evaluate reads a
+ * var-len plan's byte totals — and whether its optimistic kernels' assumptions held — back before it
+ * returns.  This entry point enqueues the kernels of the path the projector is currently on
+ * (gdv_projector_path_hint) and returns; `result` — (1 + num_outs) x uint64 in device or pinned host memory —
+ * receives, in stream order:
+ *   result[0]      the device error word.  0: the outputs are complete.  Anything else (a raised error,
+ *                  or an assumption — ASCII, flat — that did not hold for this batch): discard them and
+ *                  evaluate the batch with gdv_projector_evaluate, which also moves the projector to the
+ *                  kernels that take such batches.
+ *   result[1 + e]  the bytes output e produced (0 for fixed-width outputs).  A value above the capacity
+ *                  outs[e].data_size means the buffer was too small: nothing was written past it.
+ * outs[e].data_size is not updated.  sel may be NULL (row mode) or a selection vector of the projector's
+ * mode; with num_slots_device != NULL the slot count is read from that int64 on the device
+ * (gdv_filter_evaluate_async left it there) and sel->num_slots is the capacity: filter -> upper(s) without
+ * a host round trip.  Device buffers; single-stage plans (two-stage plans: GDV_INVALID). */
+int gdv_projector_evaluate_async(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                 const gdv_selection_t* sel, const void* num_slots_device, gdv_out_column_t* outs,
+                                 int num_outs, void* stream, void* result);
 char* gdv_projector_dump_ir(const gdv_projector_t* p);
 void gdv_projector_free(gdv_projector_t* p);
 
