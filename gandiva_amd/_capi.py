@@ -123,6 +123,11 @@ PROTOTYPES = [
     ("gdv_memcpy_h2d", C.c_int, [_P, _P, C.c_int64]),
     ("gdv_memcpy_d2h", C.c_int, [_P, _P, C.c_int64]),
     ("gdv_device_synchronize", C.c_int, []),
+    ("gdv_host_register", C.c_int, [_P, C.c_int64]),
+    ("gdv_host_unregister", C.c_int, [_P]),
+    ("gdv_host_alloc", C.c_int, [C.c_int64, C.POINTER(_P)]),
+    ("gdv_host_free", C.c_int, [_P]),
+    ("gdv_host_staged_bytes", C.c_int64, []),
     ("gdv_device_hbm_ceilings", C.c_int, [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("gdv_projector_evaluate_device_array", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_uint32]),
     ("gdv_filter_evaluate_device_array", C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), _P]),

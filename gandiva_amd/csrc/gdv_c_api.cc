@@ -826,6 +826,25 @@ int gdv_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
   hipError_t e = hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyDeviceToHost);
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));
 }
+int gdv_host_register(void* ptr, int64_t bytes) {
+  return Guarded([&]() -> int {
+  if (bytes < 0) return Fail(Status::Invalid("bad argument"));
+  return Check(HostRegistry::Get().Register(ptr, static_cast<size_t>(bytes)));
+  });
+}
+int gdv_host_unregister(void* ptr) {
+  return Guarded([&]() -> int { return Check(HostRegistry::Get().Unregister(ptr)); });
+}
+int gdv_host_alloc(int64_t bytes, void** ptr) {
+  return Guarded([&]() -> int {
+  if (bytes < 0) return Fail(Status::Invalid("bad argument"));
+  return Check(HostRegistry::Get().Alloc(static_cast<size_t>(bytes), ptr));
+  });
+}
+int gdv_host_free(void* ptr) {
+  return Guarded([&]() -> int { return Check(HostRegistry::Get().Free(ptr)); });
+}
+int64_t gdv_host_staged_bytes(void) { return HostRegistry::StagedBytes().load(std::memory_order_relaxed); }
 int gdv_device_hbm_ceilings(int64_t bytes, double* read_gbs, double* write_gbs, double* copy_gbs) {
   return Guarded([&]() -> int {
   if (bytes < (1 << 20) || !read_gbs || !write_gbs || !copy_gbs) return Fail(Status::Invalid("bad argument"));

@@ -247,6 +247,7 @@ struct Staging {
   // device copy of n host bytes, readable (zero-filled) up to `alloc` bytes
   Status In(const void* src, size_t n, size_t alloc, hipStream_t stream, void** dev) {
     if (alloc < n) alloc = n;
+    HostRegistry::StagedBytes().fetch_add(static_cast<int64_t>(n), std::memory_order_relaxed);
     size_t off = 0;
     if (packed_ && !flushed_ && Reserve(alloc, &off)) {
       if (n > 0) std::memcpy(pin_ + off, src, n);
@@ -273,6 +274,7 @@ struct Staging {
   Status Out(size_t alloc, size_t copy, void* user, void** dev) {
     size_t off = 0;
     OutCopy oc{user, nullptr, 0, copy, false};
+    HostRegistry::StagedBytes().fetch_add(static_cast<int64_t>(copy), std::memory_order_relaxed);
     if (packed_ && Reserve(alloc, &off)) {
       oc.off = off;
       oc.packed = true;
@@ -397,7 +399,9 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
           return Status::Invalid("column '" + name + "': data buffer too small");
         HostBitmap b;
         if (mem == MemKind::kHost) {
-          GDV_RETURN_NOT_OK(StageBitmap(c.data, c.offset, num_rows, stream, st, &b));
+          // (a buffer inside a registered host range is read in place: gdv_host_register)
+          if (const void* v = HostRegistry::Get().View(c.data, c.data_size)) b = FoldBitmap(v, c.data_size, c.offset);
+          else GDV_RETURN_NOT_OK(StageBitmap(c.data, c.offset, num_rows, stream, st, &b));
         } else {
           b = FoldBitmap(c.data, c.data_size, c.offset);
         }
@@ -410,8 +414,8 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
                                  std::to_string(c.offset + num_rows) + " rows)");
         const char* src = static_cast<const char*>(c.data) + c.offset * w;
         if (mem == MemKind::kHost) {
-          void* d = nullptr;
-          GDV_RETURN_NOT_OK(st->In(src, num_rows * w, num_rows * w, stream, &d));
+          void* d = HostRegistry::Get().View(src, num_rows * w);
+          if (d == nullptr) GDV_RETURN_NOT_OK(st->In(src, num_rows * w, num_rows * w, stream, &d));
           args->SetInData(static_cast<int>(k), d);
         } else {
           args->SetInData(static_cast<int>(k), src);
@@ -429,7 +433,8 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
         if (c.validity_size < BytesForBits(c.offset + num_rows))
           return Status::Invalid("column '" + name + "': validity buffer too small");
         if (mem == MemKind::kHost) {
-          GDV_RETURN_NOT_OK(StageBitmap(c.validity, c.offset, num_rows, stream, st, &b));
+          if (const void* v = HostRegistry::Get().View(c.validity, c.validity_size)) b = FoldBitmap(v, c.validity_size, c.offset);
+          else GDV_RETURN_NOT_OK(StageBitmap(c.validity, c.offset, num_rows, stream, st, &b));
         } else {
           b = FoldBitmap(c.validity, c.validity_size, c.offset);
         }
@@ -749,12 +754,21 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
           (out_rows > 0 && (outs[e].validity == nullptr || (outs[e].data == nullptr && !t.is_varlen()))))
         return Status::Invalid("output buffer " + std::to_string(e) + " too small");
       const int64_t vbytes = out_rows > 0 ? BytesForBits(out_rows) : 0;
-      GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_valid_dev, 8), vbytes, outs[e].validity, &dev_valid[e]));
+      // Buffers inside a registered host range (gdv_host_register / gdv_host_alloc) that hold whole
+      // 8-byte words are written in place by the kernel; the others come back through the staging block.
+      const bool fixed = !t.is_varlen();
+      dev_valid[e] = fixed && outs[e].validity_size >= need_valid_dev && (reinterpret_cast<uintptr_t>(outs[e].validity) & 7) == 0
+                         ? HostRegistry::Get().View(outs[e].validity, need_valid_dev) : nullptr;
+      if (dev_valid[e] == nullptr)
+        GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_valid_dev, 8), vbytes, outs[e].validity, &dev_valid[e]));
       if (t.is_varlen()) {
         GDV_RETURN_NOT_OK(st.Out(need_offs, out_rows > 0 ? need_offs : 0, outs[e].offsets, &dev_offs[e]));
       } else {
         const int64_t dbytes = out_rows == 0 ? 0 : (t.id == kBool ? vbytes : need_data_dev);
-        GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_data_dev, 8), dbytes, outs[e].data, &dev_data[e]));
+        dev_data[e] = fixed && outs[e].data_size >= need_data_dev && (reinterpret_cast<uintptr_t>(outs[e].data) & 15) == 0
+                          ? HostRegistry::Get().View(outs[e].data, need_data_dev) : nullptr;
+        if (dev_data[e] == nullptr)
+          GDV_RETURN_NOT_OK(st.Out(std::max<int64_t>(need_data_dev, 8), dbytes, outs[e].data, &dev_data[e]));
       }
     } else {
       if (outs[e].validity_size < need_valid_dev || outs[e].data_size < need_data_dev)

@@ -626,4 +626,97 @@ Status Runtime::Launch(const CompiledKernel& k, int64_t grid, int block, const v
   return Status::OK();
 }
 
+// ------------------------------------------------------------------ registered host memory
+
+HostRegistry& HostRegistry::Get() {
+  static HostRegistry r;
+  return r;
+}
+
+Status HostRegistry::Insert(void* p, size_t bytes, bool owned) {
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess || dev == nullptr) {
+    (void)hipGetLastError();
+    return Status::ExecutionError("hipHostGetDevicePointer failed for a page-locked range");
+  }
+  std::unique_lock<std::shared_mutex> g(mu_);
+  ranges_[reinterpret_cast<uintptr_t>(p)] = Range{bytes, static_cast<char*>(dev), owned};
+  count_.store(static_cast<int>(ranges_.size()), std::memory_order_relaxed);
+  return Status::OK();
+}
+
+Status HostRegistry::Register(void* p, size_t bytes) {
+  if (p == nullptr || bytes == 0) return Status::Invalid("gdv_host_register: empty range");
+  GDV_RETURN_NOT_OK(Runtime::Get().EnsureDevice());
+  {
+    std::shared_lock<std::shared_mutex> g(mu_);
+    if (ranges_.count(reinterpret_cast<uintptr_t>(p))) return Status::Invalid("gdv_host_register: range already registered");
+  }
+  if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::ExecutionError("hipHostRegister failed (" + std::to_string(bytes) + " bytes)");
+  }
+  Status s = Insert(p, bytes, false);
+  if (!s.ok()) (void)hipHostUnregister(p);
+  return s;
+}
+
+Status HostRegistry::Unregister(void* p) {
+  {
+    std::unique_lock<std::shared_mutex> g(mu_);
+    auto it = ranges_.find(reinterpret_cast<uintptr_t>(p));
+    if (it == ranges_.end() || it->second.owned) return Status::Invalid("gdv_host_unregister: not a registered range");
+    ranges_.erase(it);
+    count_.store(static_cast<int>(ranges_.size()), std::memory_order_relaxed);
+  }
+  if (hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::ExecutionError("hipHostUnregister failed");
+  }
+  return Status::OK();
+}
+
+Status HostRegistry::Alloc(size_t bytes, void** p) {
+  if (p == nullptr) return Status::Invalid("gdv_host_alloc: null output pointer");
+  GDV_RETURN_NOT_OK(Runtime::Get().EnsureDevice());
+  void* q = nullptr;
+  if (hipHostMalloc(&q, std::max<size_t>(bytes, 8), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return Status::OutOfMemory("hipHostMalloc failed (" + std::to_string(bytes) + " bytes)");
+  }
+  Status s = Insert(q, std::max<size_t>(bytes, 8), true);
+  if (!s.ok()) {
+    (void)hipHostFree(q);
+    return s;
+  }
+  *p = q;
+  return Status::OK();
+}
+
+Status HostRegistry::Free(void* p) {
+  if (p == nullptr) return Status::OK();
+  {
+    std::unique_lock<std::shared_mutex> g(mu_);
+    auto it = ranges_.find(reinterpret_cast<uintptr_t>(p));
+    if (it == ranges_.end() || !it->second.owned) return Status::Invalid("gdv_host_free: not a gdv_host_alloc block");
+    ranges_.erase(it);
+    count_.store(static_cast<int>(ranges_.size()), std::memory_order_relaxed);
+  }
+  (void)hipHostFree(p);
+  return Status::OK();
+}
+
+void* HostRegistry::View(const void* p, size_t bytes) const {
+  if (p == nullptr || empty()) return nullptr;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uintptr_t lo = a & ~uintptr_t{7}, hi = (a + bytes + 7) & ~uintptr_t{7};
+  std::shared_lock<std::shared_mutex> g(mu_);
+  auto it = ranges_.upper_bound(a);
+  if (it == ranges_.begin()) return nullptr;
+  --it;
+  const uintptr_t base = it->first, end = (base + it->second.size + 7) & ~uintptr_t{7};
+  if (lo < (base & ~uintptr_t{7}) || hi > end) return nullptr;
+  return it->second.dev + (a - base);
+}
+
 }  // namespace gdv

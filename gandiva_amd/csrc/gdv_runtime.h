@@ -9,7 +9,9 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -175,5 +177,43 @@ class DeviceBuffer {
 };
 
 extern const char gdv_device_lib_src[];  // generated: gdv_device_lib_embed.cc
+
+// Host memory the GPUs can address directly (round 4; process-wide, every device): ranges the caller
+// page-locked through gdv_host_register (hipHostRegister: its own arenas — an Arrow MemoryPool's,
+// JNI direct buffers) or obtained from gdv_host_alloc (hipHostMalloc).  The host-buffer path of
+// Evaluate binds fixed-width columns, bitmaps and outputs that lie inside such a range straight into
+// the kernel's argument block — the kernel reads and writes them over the fabric, no staging memcpy,
+// no H2D / D2H copy — and stages everything else as before.  Nothing is registered behind the
+// caller's back: a registration outliving a free() would leave the device a window onto pages that
+// now belong to someone else.
+class HostRegistry {
+ public:
+  static HostRegistry& Get();
+  Status Register(void* p, size_t bytes);
+  Status Unregister(void* p);
+  Status Alloc(size_t bytes, void** p);
+  Status Free(void* p);
+  // Device-visible address of [p, p + bytes) — widened to 8-byte boundaries, the granularity the
+  // kernels read bitmaps at — when all of it lies inside ONE registered range; nullptr otherwise.
+  void* View(const void* p, size_t bytes) const;
+  bool empty() const { return count_.load(std::memory_order_relaxed) == 0; }
+  // bytes GDV_MEM_HOST evaluations have copied through staging blocks so far (process-wide): what a
+  // caller watches to see whether its registrations take effect
+  static std::atomic<int64_t>& StagedBytes() {
+    static std::atomic<int64_t> n{0};
+    return n;
+  }
+
+ private:
+  struct Range {
+    size_t size;
+    char* dev;
+    bool owned;  // gdv_host_alloc
+  };
+  Status Insert(void* p, size_t bytes, bool owned);
+  mutable std::shared_mutex mu_;
+  std::map<uintptr_t, Range> ranges_;
+  std::atomic<int> count_{0};
+};
 
 }  // namespace gdv

@@ -412,6 +412,72 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+class HostArena:
+    """Page-locked host memory the GPUs address directly (``gdv_host_alloc``), handed out as pyarrow
+    buffers by a bump allocator.  A host ``evaluate`` whose batch was placed with ``place`` and whose outputs
+    come from the arena (``evaluate(batch, arena=...)``) copies nothing: the kernel reads and writes the
+    arrays where they are.  ``HostArena.over(ndarray)`` registers memory the caller owns instead
+    (``gdv_host_register``).  Buffers keep the arena alive; ``reset()`` recycles the space once they are gone."""
+
+    def __init__(self, nbytes, _foreign=None):
+        lib = _capi.lib()
+        self._foreign = _foreign
+        self._size, self._used, self._base = int(nbytes), 0, None
+        if _foreign is None:
+            p = C.c_void_p()
+            _check(lib.gdv_host_alloc(self._size, C.byref(p)))
+            self._base = p.value
+        else:
+            _check(lib.gdv_host_register(C.c_void_p(_foreign.ctypes.data), self._size))
+            self._base = _foreign.ctypes.data
+
+    @staticmethod
+    def over(array):
+        """Register a writable, contiguous numpy array the caller owns; unregistered when the arena goes."""
+        return HostArena(array.nbytes, _foreign=array)
+
+    def __del__(self):
+        if getattr(self, "_base", None) is not None:
+            lib = _capi.lib()
+            if self._foreign is None:
+                lib.gdv_host_free(C.c_void_p(self._base))
+            else:
+                lib.gdv_host_unregister(C.c_void_p(self._base))
+            self._base = None
+
+    def reset(self):
+        self._used = 0
+
+    def allocate(self, nbytes):
+        """A 64-byte aligned, 64-byte padded pyarrow buffer of ``nbytes`` bytes inside the arena."""
+        at = (self._base + self._used + 63) // 64 * 64 - self._base
+        room = _pad64(max(int(nbytes), 1))
+        if at + room > self._size:
+            raise MemoryError(f"HostArena: {nbytes} bytes do not fit ({self._size - at} left)")
+        self._used = at + room
+        return pa.foreign_buffer(self._base + at, int(nbytes), base=self)
+
+    def place(self, batch):
+        """A copy of the record batch (flat columns) whose buffers live in the arena."""
+        cols = []
+        for arr in batch.columns:
+            bufs = []
+            for b in arr.buffers():
+                if b is None:
+                    bufs.append(None)
+                    continue
+                nb = self.allocate(_pad64(b.size))
+                C.memmove(nb.address, b.address, b.size)
+                bufs.append(nb.slice(0, b.size))
+            cols.append(pa.Array.from_buffers(arr.type, len(arr), bufs, arr.null_count, arr.offset))
+        return pa.RecordBatch.from_arrays(cols, schema=batch.schema)
+
+
+def host_staged_bytes():
+    """``gdv_host_staged_bytes``: bytes host evaluations have copied through staging blocks so far."""
+    return int(_capi.lib().gdv_host_staged_bytes())
+
+
 class DeviceBatch:
     """A record batch resident in the HBM of the current device (Arrow layout, buffers
     padded to 64 bytes).  Build with ``DeviceBatch.from_arrow`` (uploads) or directly from
@@ -515,8 +581,10 @@ class Projector:
         """gdv_projector_path_hint: 0 optimistic kernels, 1 exact wave variant, 2 scanner-shaped general kernel."""
         return _capi.lib().gdv_projector_path_hint(self._h)
 
-    def evaluate(self, batch, selection=None):
-        """Host-buffer path: stages the batch through HBM, returns host pyarrow arrays."""
+    def evaluate(self, batch, selection=None, arena=None):
+        """Host-buffer path: stages the batch through HBM, returns host pyarrow arrays.  ``arena`` (a
+        ``HostArena``): the outputs are allocated there and written by the kernel in place."""
+        alloc = pa.allocate_buffer if arena is None else arena.allocate
         _check_batch(batch, self._schema)
         lib = _capi.lib()
         cols = (gdv_column_t * max(batch.num_columns, 1))(*[_column_of_array(a) for a in batch.columns])
@@ -532,9 +600,9 @@ class Projector:
         for i, t in enumerate(self._out_types):
             vb, db = C.c_int64(), C.c_int64()
             _check(lib.gdv_projector_output_sizes(self._h, i, out_rows, GDV_MEM_HOST, vb, db))
-            v = pa.allocate_buffer(_pad64(max(vb.value, 1)))
-            d = pa.allocate_buffer(_pad64((db.value or guess) if varlen[i] else max(db.value, 1)))
-            o = pa.allocate_buffer(_pad64((out_rows + 1) * 4)) if varlen[i] else None
+            v = alloc(_pad64(max(vb.value, 1)))
+            d = alloc(_pad64((db.value or guess) if varlen[i] else max(db.value, 1)))
+            o = alloc(_pad64((out_rows + 1) * 4)) if varlen[i] else None
             holders[i] = [v, d, o]
             outs[i].validity, outs[i].validity_size = v.address, v.size
             outs[i].data, outs[i].data_size = d.address, d.size
@@ -555,7 +623,7 @@ class Projector:
                 # a var-len byte buffer was too small: data_size now holds the bytes needed
                 for i in range(n_out):
                     if varlen[i] and outs[i].data_size > caps[i]:
-                        d = pa.allocate_buffer(_pad64(outs[i].data_size))
+                        d = alloc(_pad64(outs[i].data_size))
                         holders[i][1] = d
                         outs[i].data, outs[i].data_size = d.address, d.size
                         grown = True

@@ -382,6 +382,25 @@ int gdv_device_free(void* ptr);
 int gdv_memcpy_h2d(void* dst_device, const void* src_host, int64_t bytes);
 int gdv_memcpy_d2h(void* dst_host, const void* src_device, int64_t bytes);
 int gdv_device_synchronize(void);
+/* Round 4 — host memory the GPUs address directly.  GDV_MEM_HOST evaluations stage the caller's buffers
+ * through a page-locked block (two memcpys + two DMA copies per call: 133 us for 16 K rows of the C2
+ * shape).  Fixed-width columns, bitmaps and outputs that lie INSIDE a range registered here are instead
+ * bound straight into the kernel — it reads and writes them over the fabric, nothing is copied — and
+ * everything else is staged as before (per buffer; output bitmaps / values also need whole 8-byte
+ * words of room, i.e. Arrow's own 64-byte padding).
+ *   gdv_host_register(p, bytes): page-lock and map a range the CALLER owns (hipHostRegister) — the arena
+ *     of an Arrow MemoryPool, JNI direct buffers.  Costs ~0.1 ms per MiB, once.  The caller unregisters
+ *     before it frees the memory; the library never registers anything on its own (a registration that
+ *     outlives a free() would leave the device a window onto somebody else's pages).
+ *   gdv_host_alloc / gdv_host_free: page-locked memory from the library (hipHostMalloc), registered.
+ * Process-wide, visible to every device.  The reference has no counterpart: its buffers are the CPU's. */
+int gdv_host_register(void* ptr, int64_t bytes);
+int gdv_host_unregister(void* ptr);
+int gdv_host_alloc(int64_t bytes, void** ptr);
+int gdv_host_free(void* ptr);
+/* Bytes GDV_MEM_HOST evaluations have moved through staging blocks so far (process-wide, cumulative):
+ * unchanged across a call = every buffer of that call was addressed in place. */
+int64_t gdv_host_staged_bytes(void);
 /* What plain streaming kernels reach on the calling thread's device right now: read-only, write-only
  * and copy rates in GB/s over two scratch buffers of `bytes` bytes (>= 1 GiB: the Infinity Cache holds
  * 256 MiB).  Boxes of one pool differ by 10-25 % on the same binary; a benchmark line that carries
