@@ -1024,6 +1024,9 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 #define GDV_MAP_REVERSE 4
 #define GDV_MAP_DIGITS 8
 #define GDV_MAP_REPLACE 16  // `lim` points at a replace table (constant block), flags >> 2 = source length
+// GDV_MAP_DIGITS with GDV_STR_DECIMAL in `flags` (round 4): the text of the decimal128 whose low / high
+// words sit in `p` / `lim`, scale = flags >> 8, cut to `len` bytes (castVARCHAR(decimal, n))
+#define GDV_STR_DECIMAL 128
 #define GDV_STR_ASCII 1  // flags: every byte of the buffer range this view came from is < 0x80
 #define GDV_STR_INBUF 2  // flags: 8-byte loads starting anywhere inside the view stay inside its buffer
 #define GDV_STR_LEAD 4   // flags: `lead` / `lead_p` are set (exact variant of the wave kernels, rows with bytes >= 0x80)
@@ -1166,8 +1169,77 @@ GDV_DEV gdv_int32 gdv_count_digits(gdv_uint64 v) {
   for (gdv_uint64 p = 10; n < 20 && v >= p; p *= 10) n++;
   return n;
 }
+// ---- decimal128 -> text, Arrow's Decimal128::ToString(scale) [arrow/util/decimal.cc
+// AdjustIntegerStringWithScale, as recalled; pinned against pyarrow's decimal -> string cast in
+// tests/test_registry_tail.py]: digits D (no leading zeros, "0" for zero), nd of them,
+// adjusted exponent adj = nd - 1 - scale;
+//   scale == 0              ->  [-]D
+//   adj < -6                ->  [-]d[.ddd]E-x      (x = -adj: the only scientific case for scale >= 0)
+//   nd > scale              ->  [-]ddd.ddd         (point scale digits from the right)
+//   otherwise               ->  [-]0.000ddd        (scale - nd zeros)
+struct gdv_dec_text {
+  gdv_uint64 hi, lo;  // |value| = hi * 10^19 + lo
+  gdv_int32 nd, scale, neg, len;
+};
+GDV_DEV gdv_dec_text gdv_dec_text_of(gdv_int128 v, gdv_int32 scale) {
+  gdv_dec_text t;
+  t.neg = v < 0 ? 1 : 0;
+  const gdv_uint128 mag = t.neg ? (gdv_uint128)0 - (gdv_uint128)v : (gdv_uint128)v;
+  const gdv_uint64 p19 = 10000000000000000000ull;
+  t.hi = (gdv_uint64)(mag / p19);
+  t.lo = (gdv_uint64)(mag % p19);
+  t.nd = t.hi != 0 ? 19 + gdv_count_digits(t.hi) : gdv_count_digits(t.lo);
+  t.scale = scale;
+  const gdv_int32 adj = t.nd - 1 - scale;
+  if (scale <= 0) t.len = t.neg + t.nd;
+  else if (adj < -6) t.len = t.neg + t.nd + (t.nd > 1 ? 1 : 0) + 2 + (-adj >= 10 ? 2 : 1);
+  else if (t.nd > scale) t.len = t.neg + t.nd + 1;
+  else t.len = t.neg + 2 + scale;
+  return t;
+}
+// the first `len` bytes of the text (len <= t.len), one byte store each (registry tail: not a hot path)
+template <typename P>
+GDV_DEV void gdv_copy_dec_text(P dst, const gdv_dec_text& t, gdv_int32 len) {
+  const gdv_int32 adj = t.nd - 1 - t.scale;
+  const bool sci = t.scale > 0 && adj < -6, lead0 = t.scale > 0 && !sci && t.nd <= t.scale;
+  const gdv_int32 point = t.scale <= 0 ? -1 : sci ? (t.nd > 1 ? t.neg + 1 : -1) : lead0 ? t.neg + 1 : t.neg + t.nd - t.scale;
+  if (t.neg && len > 0) dst[0] = (gdv_uint8)'-';
+  if (point >= 0 && point < len) dst[point] = (gdv_uint8)'.';
+  gdv_int32 first = t.neg;  // text position of the most significant digit
+  if (lead0) {
+    if (t.neg < len) dst[t.neg] = (gdv_uint8)'0';
+    first = t.neg + 2 + (t.scale - t.nd);
+    for (gdv_int32 k = t.neg + 2; k < first && k < len; k++) dst[k] = (gdv_uint8)'0';
+  }
+  gdv_uint64 chunk = t.lo;
+  for (gdv_int32 i = t.nd - 1; i >= 0; i--) {  // least significant digit first
+    if (i == t.nd - 20) chunk = t.hi;         // the 19 digits of `lo` are out
+    const gdv_uint8 d = (gdv_uint8)('0' + (gdv_int32)(chunk % 10));
+    chunk /= 10;
+    gdv_int32 pos = first + i;
+    if (point >= 0 && !lead0 && pos >= point) pos++;
+    if (pos < len) dst[pos] = d;
+  }
+  if (sci) {
+    gdv_int32 at = t.neg + t.nd + (t.nd > 1 ? 1 : 0);
+    const gdv_int32 x = -adj;
+    if (at < len) dst[at] = (gdv_uint8)'E';
+    if (at + 1 < len) dst[at + 1] = (gdv_uint8)'-';
+    if (x >= 10) {
+      if (at + 2 < len) dst[at + 2] = (gdv_uint8)('0' + x / 10);
+      if (at + 3 < len) dst[at + 3] = (gdv_uint8)('0' + x % 10);
+    } else if (at + 2 < len) {
+      dst[at + 2] = (gdv_uint8)('0' + x);
+    }
+  }
+}
 template <typename P>
 GDV_DEV void gdv_copy_digits(P dst, const gdv_str& s) {
+  if (s.flags & GDV_STR_DECIMAL) {
+    const gdv_int128 v = (gdv_int128)(((gdv_uint128)(gdv_uint64)s.lim << 64) | (gdv_uint64)s.p);
+    gdv_copy_dec_text(dst, gdv_dec_text_of(v, s.flags >> 8), s.len);
+    return;
+  }
   const gdv_int64 v = (gdv_int64)(gdv_uint64)s.p;
   const gdv_int32 neg = v < 0 ? 1 : 0;
   gdv_uint64 mag = neg ? 0ull - (gdv_uint64)v : (gdv_uint64)v;
@@ -1687,6 +1759,20 @@ GDV_DEV gdv_str castVARCHAR_int64_int64(gdv_ctx ctx, gdv_int64 v, gdv_int64 n) {
 }
 GDV_DEV gdv_str castVARCHAR_int32_int64(gdv_ctx ctx, gdv_int32 v, gdv_int64 n) {
   return castVARCHAR_int64_int64(ctx, (gdv_int64)v, n);
+}
+// castVARCHAR(decimal128, n): Arrow's text of the value at the type's scale, cut to n bytes
+// [gdv_fn_dec_to_string + the length cut of castVARCHAR_decimal128_int64, as recalled]
+GDV_DEV gdv_str castVARCHAR_decimal128_int64(gdv_ctx ctx, gdv_int128 v, int xp, int xs, gdv_int64 n, int op, int os) {
+  (void)xp; (void)op; (void)os;
+  gdv_str r = gdv_empty_str();
+  if (n < 0) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return r; }
+  const gdv_int32 total = gdv_dec_text_of(v, xs).len;
+  r.p = (const gdv_uint8*)(gdv_uint64)(gdv_uint128)v;
+  r.lim = (const gdv_uint8*)(gdv_uint64)((gdv_uint128)v >> 64);
+  r.len = n < total ? (gdv_int32)n : total;
+  r.map = GDV_MAP_DIGITS;
+  r.flags = GDV_STR_DECIMAL | (xs << 8);
+  return r;
 }
 // reverse(s): the characters of s in reverse order.  A character is what its lead byte announces
 // (1-4 bytes); a byte that cannot lead a character, or a character cut by the end of the string,

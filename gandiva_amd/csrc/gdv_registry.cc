@@ -247,6 +247,7 @@ FunctionRegistry::FunctionRegistry() {
     add("castDECIMAL", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
     add("castFLOAT8", {dec}, float64(), NullPolicy::kNullIfNull, kDecimalArgs);
     add("castBIGINT", {dec}, int64(), NullPolicy::kNullIfNull, kDecimalArgs);
+    add("castVARCHAR", {dec, int64()}, utf8(), NullPolicy::kNullIfNull, kDecimalArgs | kVarlenResult | kNeedsContext);
     add("isnull", {dec}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnull");
     add("isnotnull", {dec}, boolean(), NullPolicy::kNullNever, 0, "gdv_isnotnull");
   }

@@ -13,6 +13,7 @@
 #include "gandiva/filter.h"
 #include "gandiva/filter_project.h"
 #include "gandiva/function_signature.h"
+#include "gandiva/host_memory.h"
 #include "gandiva/node.h"
 #include "gandiva/projector.h"
 #include "gandiva/selection_vector.h"
@@ -171,6 +172,16 @@ arrow::Result<std::shared_ptr<arrow::Buffer>> AllocOut(int64_t bytes, bool devic
 }  // namespace
 
 // ------------------------------------------------------------------ Node / Expression
+
+Status RegisterHostMemory(void* ptr, int64_t bytes) {
+  GDV_CXX_RETURN_NOT_OK(gdv_host_register(ptr, bytes));
+  return Status::OK();
+}
+Status UnregisterHostMemory(void* ptr) {
+  GDV_CXX_RETURN_NOT_OK(gdv_host_unregister(ptr));
+  return Status::OK();
+}
+int64_t HostStagedBytes() { return gdv_host_staged_bytes(); }
 
 Node::~Node() { gdv_node_free(handle_); }
 std::string Node::ToString() const {

@@ -14,6 +14,7 @@
 #include "gandiva/expression_registry.h"
 #include "gandiva/filter.h"
 #include "gandiva/filter_project.h"
+#include "gandiva/host_memory.h"
 #include "gandiva/projector.h"
 #include "gandiva/tree_expr_builder.h"
 
@@ -213,6 +214,30 @@ int main(int argc, char** argv) {
     auto short_data = arrow::ArrayData::Make(arrow::utf8(), 3, {vb, ob, tiny});
     arrow::Status st = ps->Evaluate(*sbatch, ArrayDataVector{short_data});
     CHECK(st.IsInvalid() && st.ToString().find("13 needed") != std::string::npos);
+  }
+  {  // round 4: a batch and its caller-allocated outputs inside REGISTERED host memory are evaluated in place
+    std::shared_ptr<Projector> p;
+    CHECK_OK(Projector::Make(schema, {expr}, &p));
+    std::shared_ptr<arrow::Buffer> block = arrow::AllocateBuffer(1 << 20, pool).ValueOrDie();
+    std::memset(block->mutable_data(), 0, block->size());
+    CHECK_OK(RegisterHostMemory(block->mutable_data(), block->size()));
+    CHECK(RegisterHostMemory(block->mutable_data(), block->size()).IsInvalid());  // once
+    const int32_t a[4] = {10, 12, -20, 5}, b[4] = {5, 15, 15, 17}, c[4] = {0, 0, 0, 0};
+    auto col = [&](int64_t at, const int32_t* v) {
+      std::memcpy(block->mutable_data() + at, v, 16);
+      return arrow::MakeArray(arrow::ArrayData::Make(arrow::int32(), 4, {nullptr, arrow::SliceBuffer(block, at, 64)}));
+    };
+    auto batch = arrow::RecordBatch::Make(schema, 4, {col(0, a), col(64, b), col(128, c)});
+    auto data = arrow::ArrayData::Make(arrow::int32(), 4, {arrow::SliceMutableBuffer(block, 4096, 64), arrow::SliceMutableBuffer(block, 8192, 64)});
+    const int64_t before = HostStagedBytes();
+    CHECK_OK(p->Evaluate(*batch, ArrayDataVector{data}));
+    CHECK(HostStagedBytes() == before);  // nothing went through the staging block
+    CHECK(arrow::MakeArray(data)->Equals(MakeArr<arrow::Int32Builder, int32_t>({10, 15, 15, 17})));
+    CHECK_OK(UnregisterHostMemory(block->mutable_data()));
+    CHECK(UnregisterHostMemory(block->mutable_data()).IsInvalid());
+    CHECK_OK(p->Evaluate(*batch, ArrayDataVector{data}));  // staged again, same result
+    CHECK(HostStagedBytes() > before);
+    CHECK(arrow::MakeArray(data)->Equals(MakeArr<arrow::Int32Builder, int32_t>({10, 15, 15, 17})));
   }
   {  // round 4: IN over float64 / decimal128 and a decimal literal, evaluated
     auto fx = arrow::field("x", arrow::float64());

@@ -962,6 +962,41 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
       else out->sl[i] = k < len ? (int32_t)k : len;
     }
+  } else if (!strcmp(f, "castVARCHAR") && t0 == T_DEC) {
+    /* Arrow's Decimal128::ToString(scale) cut to n bytes; n < 0 is an error [recalled:
+     * gdv_function_stubs.cc castVARCHAR_decimal128_int64 over gdv_fn_dec_to_string; the text rules:
+     * arrow/util/decimal.cc AdjustIntegerStringWithScale — pinned against pyarrow's decimal -> string
+     * cast in tests/test_registry_tail.py] */
+    for (int i = 0; i < cnt; i++) {
+      int live = out->valid[i] && (!active || active[i]);
+      int64_t k = a[1].v[i].i;
+      i128 v = a[0].v[i].q;
+      const int scale = a[0].scale, neg = v < 0;
+      unsigned __int128 mag = neg ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
+      char dig[48]; int nd = 0;
+      do { dig[nd++] = (char)('0' + (int)(mag % 10)); mag /= 10; } while (mag != 0);   /* least significant first */
+      char buf[64]; int len = 0;
+      const int adj = nd - 1 - scale;
+      if (neg) buf[len++] = '-';
+      if (scale <= 0) {
+        for (int j = nd - 1; j >= 0; j--) buf[len++] = dig[j];
+      } else if (adj < -6) {
+        buf[len++] = dig[nd - 1];
+        if (nd > 1) { buf[len++] = '.'; for (int j = nd - 2; j >= 0; j--) buf[len++] = dig[j]; }
+        len += snprintf(buf + len, sizeof buf - (size_t)len, "E%d", adj);
+      } else if (nd > scale) {
+        for (int j = nd - 1; j >= 0; j--) { if (j == scale - 1) buf[len++] = '.'; buf[len++] = dig[j]; }
+      } else {
+        buf[len++] = '0'; buf[len++] = '.';
+        for (int j = 0; j < scale - nd; j++) buf[len++] = '0';
+        for (int j = nd - 1; j >= 0; j--) buf[len++] = dig[j];
+      }
+      uint8_t* dst = arena_alloc(c, 64);
+      memcpy(dst, buf, (size_t)len);
+      out->sp[i] = dst; out->sm[i] = 0;
+      if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
+      else out->sl[i] = k < len ? (int32_t)k : len;
+    }
   } else if (t0 == T_DEC || n->type == T_DEC) {
     const int two = n->nargs == 2;
     for (int i = 0; i < cnt; i++) {

@@ -320,6 +320,21 @@ unsigned host_cast_varchar_int64(const long long* v, long n, long long len, int*
   }
   return err;
 }
+// castVARCHAR(decimal128(p, s), len): values are 16-byte little-endian
+unsigned host_cast_varchar_decimal(const void* xv, int xp, int xs, long n, long long len, int* out_off, unsigned char* out_data) {
+  const gdv_int128* x = static_cast<const gdv_int128*>(xv);
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    const gdv_str r = castVARCHAR_decimal128_int64(ctx, x[i], xp, xs, len, 0, 0);
+    gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  return err;
+}
 // ---------------------------------------------------------------- numeric / date / hash scalars (round 3)
 // op: 0 round_float64 (-> double), 1 truncate_float64 (-> double), 2 castBIGINT_float64 (-> int64),
 //     3 castINT_float64 (-> int32 widened to int64)
