@@ -598,6 +598,50 @@ GDV_EXTRACT(date64, GDV_MS_IDENT)
 GDV_EXTRACT(timestamp, GDV_MS_IDENT)
 GDV_EXTRACT(date32, GDV_MS_FROM_DAYS)
 
+// date_trunc_<Unit>(date64 | timestamp) [recalled: precompiled/time.cc DATE_TRUNC_FUNCTIONS over EpochTimePoint]:
+// the start of the unit the instant lies in (floor: instants before 1970 go DOWN); weeks start on Monday;
+// decade = year / 10 * 10, century / millennium start in year ...01 (the conventions of extractCentury /
+// extractMillennium above).  extractWeek / weekofyear: the ISO-8601 week (week 1 holds January 4th).
+// last_day: midnight of the last day of the instant's month.
+GDV_DEV gdv_int64 gdv_trunc_to_ymd(gdv_int64 y, gdv_int32 m) { return gdv_days_from_civil(y, m, 1) * GDV_MILLIS_IN_DAY; }
+GDV_DEV gdv_int64 gdv_iso_week(gdv_int64 days) {
+  // the Thursday of this date's ISO week decides the ISO year; the week number is that Thursday's ordinal week
+  const gdv_int64 thu = days - gdv_floor_mod(days + 3, 7) + 3;
+  return (thu - gdv_days_from_civil(gdv_civil_from_days(thu).y, 1, 1)) / 7 + 1;
+}
+#define GDV_DATE_TRUNC(T)                                                                                   \
+  GDV_DEV gdv_##T date_trunc_Second_##T(gdv_##T v) { return gdv_floor_div(v, 1000LL) * 1000LL; }            \
+  GDV_DEV gdv_##T date_trunc_Minute_##T(gdv_##T v) { return gdv_floor_div(v, 60000LL) * 60000LL; }          \
+  GDV_DEV gdv_##T date_trunc_Hour_##T(gdv_##T v) { return gdv_floor_div(v, 3600000LL) * 3600000LL; }        \
+  GDV_DEV gdv_##T date_trunc_Day_##T(gdv_##T v) { return gdv_floor_div(v, GDV_MILLIS_IN_DAY) * GDV_MILLIS_IN_DAY; } \
+  GDV_DEV gdv_##T date_trunc_Week_##T(gdv_##T v) {                                                          \
+    const gdv_int64 days = gdv_floor_div(v, GDV_MILLIS_IN_DAY);                                             \
+    return (days - gdv_floor_mod(days + 3, 7)) * GDV_MILLIS_IN_DAY; /* day 0 was a Thursday */              \
+  }                                                                                                         \
+  GDV_DEV gdv_##T date_trunc_Month_##T(gdv_##T v) {                                                         \
+    const gdv_ymd c = gdv_civil_from_days(gdv_floor_div(v, GDV_MILLIS_IN_DAY));                             \
+    return gdv_trunc_to_ymd(c.y, c.m);                                                                      \
+  }                                                                                                         \
+  GDV_DEV gdv_##T date_trunc_Quarter_##T(gdv_##T v) {                                                       \
+    const gdv_ymd c = gdv_civil_from_days(gdv_floor_div(v, GDV_MILLIS_IN_DAY));                             \
+    return gdv_trunc_to_ymd(c.y, (c.m - 1) / 3 * 3 + 1);                                                    \
+  }                                                                                                         \
+  GDV_DEV gdv_##T date_trunc_Year_##T(gdv_##T v) { return gdv_trunc_to_ymd(extractYear_##T(v), 1); }        \
+  GDV_DEV gdv_##T date_trunc_Decade_##T(gdv_##T v) { return gdv_trunc_to_ymd(extractYear_##T(v) / 10 * 10, 1); } \
+  GDV_DEV gdv_##T date_trunc_Century_##T(gdv_##T v) {                                                       \
+    return gdv_trunc_to_ymd((extractYear_##T(v) - 1) / 100 * 100 + 1, 1);                                   \
+  }                                                                                                         \
+  GDV_DEV gdv_##T date_trunc_Millennium_##T(gdv_##T v) {                                                    \
+    return gdv_trunc_to_ymd((extractYear_##T(v) - 1) / 1000 * 1000 + 1, 1);                                 \
+  }                                                                                                         \
+  GDV_DEV gdv_int64 extractWeek_##T(gdv_##T v) { return gdv_iso_week(gdv_floor_div(v, GDV_MILLIS_IN_DAY)); } \
+  GDV_DEV gdv_date64 last_day_##T(gdv_##T v) {                                                              \
+    const gdv_ymd c = gdv_civil_from_days(gdv_floor_div(v, GDV_MILLIS_IN_DAY));                             \
+    return gdv_days_from_civil(c.y, c.m, gdv_last_day_of_month(c.y, c.m)) * GDV_MILLIS_IN_DAY;              \
+  }
+GDV_DATE_TRUNC(date64)
+GDV_DATE_TRUNC(timestamp)
+
 GDV_DEV gdv_int64 extractHour_time32(gdv_time32 v) { return (gdv_int64)v / 3600000; }
 GDV_DEV gdv_int64 extractMinute_time32(gdv_time32 v) { return ((gdv_int64)v / 60000) % 60; }
 GDV_DEV gdv_int64 extractSecond_time32(gdv_time32 v) { return ((gdv_int64)v / 1000) % 60; }

@@ -213,6 +213,14 @@ FunctionRegistry::FunctionRegistry() {
     add(f, {time32()}, int64());
   }
   for (auto& t : {date64(), timestamp()}) {
+    // round 4 (registry tail): unit starts, ISO week, end of month
+    for (const char* f : {"date_trunc_Second", "date_trunc_Minute", "date_trunc_Hour", "date_trunc_Day", "date_trunc_Week",
+                          "date_trunc_Month", "date_trunc_Quarter", "date_trunc_Year", "date_trunc_Decade",
+                          "date_trunc_Century", "date_trunc_Millennium"})
+      add(f, {t}, t);
+    add("extractWeek", {t}, int64());
+    add("weekofyear", {t}, int64(), NullPolicy::kNullIfNull, 0, Sym("extractWeek", {t}));
+    add("last_day", {t}, date64());
     for (const char* f : {"timestampaddSecond", "timestampaddMinute", "timestampaddHour",
                           "timestampaddDay", "timestampaddWeek", "timestampaddMonth",
                           "timestampaddQuarter", "timestampaddYear"}) {

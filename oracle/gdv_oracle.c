@@ -1169,6 +1169,42 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       else out->v[i].i = a[0].valid[i] ? murmur3_32(bits, (int32_t)seed) : (int32_t)seed;
       out->valid[i] = 1;
     }
+  } else if (!strncmp(f, "date_trunc_", 11) || !strcmp(f, "last_day")) {
+    /* start of the unit the instant lies in (floor; weeks start on Monday; decade = y / 10 * 10, century and
+     * millennium start in year ...01) [recalled: precompiled/time.cc DATE_TRUNC_FUNCTIONS]; last_day: midnight
+     * of the last day of the month.  Pinned against pyarrow.compute floor_temporal / datetime in
+     * tests/test_registry_tail.py. */
+    const char* unit = f[0] == 'l' ? "Last" : f + 11;
+    for (int i = 0; i < cnt; i++) {
+      int64_t ms = a[0].v[i].i, days = floor_div(ms, MS_DAY), y, r;
+      int m, d;
+      civil_from_days(days, &y, &m, &d);
+      if (!strcmp(unit, "Second")) r = floor_div(ms, 1000) * 1000;
+      else if (!strcmp(unit, "Minute")) r = floor_div(ms, 60000) * 60000;
+      else if (!strcmp(unit, "Hour")) r = floor_div(ms, 3600000) * 3600000;
+      else if (!strcmp(unit, "Day")) r = days * MS_DAY;
+      else if (!strcmp(unit, "Week")) r = (days - floor_mod(days + 3, 7)) * MS_DAY;
+      else if (!strcmp(unit, "Month")) r = days_from_civil(y, m, 1) * MS_DAY;
+      else if (!strcmp(unit, "Quarter")) r = days_from_civil(y, (m - 1) / 3 * 3 + 1, 1) * MS_DAY;
+      else if (!strcmp(unit, "Year")) r = days_from_civil(y, 1, 1) * MS_DAY;
+      else if (!strcmp(unit, "Decade")) r = days_from_civil(y / 10 * 10, 1, 1) * MS_DAY;
+      else if (!strcmp(unit, "Century")) r = days_from_civil((y - 1) / 100 * 100 + 1, 1, 1) * MS_DAY;
+      else if (!strcmp(unit, "Millennium")) r = days_from_civil((y - 1) / 1000 * 1000 + 1, 1, 1) * MS_DAY;
+      else {
+        static const int mdays[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+        int last = (m == 2 && (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0)) ? 29 : mdays[m - 1];
+        r = days_from_civil(y, m, last) * MS_DAY;
+      }
+      out->v[i].i = r;
+    }
+  } else if (!strcmp(f, "extractWeek") || !strcmp(f, "weekofyear")) {
+    /* ISO-8601 week number: the week's Thursday names the ISO year [recalled: time.cc weekofyear] */
+    for (int i = 0; i < cnt; i++) {
+      int64_t days = floor_div(a[0].v[i].i, MS_DAY), thu = days - floor_mod(days + 3, 7) + 3, y;
+      int m, d;
+      civil_from_days(thu, &y, &m, &d);
+      out->v[i].i = (thu - days_from_civil(y, 1, 1)) / 7 + 1;
+    }
   } else if (!strncmp(f, "extract", 7)) {
     const char* part = f + 7;
     for (int i = 0; i < cnt; i++) {

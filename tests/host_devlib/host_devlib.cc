@@ -368,6 +368,27 @@ void host_extract_timestamp(int op, const long long* t, long n, long long* out) 
     }
   }
 }
+// op: 0..10 date_trunc_{Second, Minute, Hour, Day, Week, Month, Quarter, Year, Decade, Century, Millennium},
+//     11 extractWeek, 12 last_day — over timestamps (ms)
+void host_date_trunc_timestamp(int op, const long long* t, long n, long long* out) {
+  for (long i = 0; i < n; i++) {
+    switch (op) {
+      case 0: out[i] = date_trunc_Second_timestamp(t[i]); break;
+      case 1: out[i] = date_trunc_Minute_timestamp(t[i]); break;
+      case 2: out[i] = date_trunc_Hour_timestamp(t[i]); break;
+      case 3: out[i] = date_trunc_Day_timestamp(t[i]); break;
+      case 4: out[i] = date_trunc_Week_timestamp(t[i]); break;
+      case 5: out[i] = date_trunc_Month_timestamp(t[i]); break;
+      case 6: out[i] = date_trunc_Quarter_timestamp(t[i]); break;
+      case 7: out[i] = date_trunc_Year_timestamp(t[i]); break;
+      case 8: out[i] = date_trunc_Decade_timestamp(t[i]); break;
+      case 9: out[i] = date_trunc_Century_timestamp(t[i]); break;
+      case 10: out[i] = date_trunc_Millennium_timestamp(t[i]); break;
+      case 11: out[i] = extractWeek_timestamp(t[i]); break;
+      default: out[i] = last_day_timestamp(t[i]); break;
+    }
+  }
+}
 // hash32 / hash64 of int64, float64 and utf8 values (valid rows; seed 0)
 void host_hash_fixed(int is_f64, const void* v, long n, int* h32, long long* h64) {
   for (long i = 0; i < n; i++) {

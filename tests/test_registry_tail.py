@@ -115,3 +115,80 @@ def test_text_of_a_decimal_feeds_other_string_functions_and_selection_mode():
         assert_bit_exact(g, w, "selection mode")
     with pytest.raises(Exception):
         gandiva.make_projector(batch.schema, [cast_expr(batch.schema.field(0), -2)], None).evaluate(batch)
+
+
+# ------------------------------------------------------------------ date_trunc_*, extractWeek / weekofyear, last_day
+
+UNITS = ["Second", "Minute", "Hour", "Day", "Week", "Month", "Quarter", "Year", "Decade", "Century", "Millennium"]
+
+
+def instants(seed, n=4000):
+    rng = np.random.default_rng(seed)
+    fixed = [0, -1, 1, 86399999, 86400000, -86400000, -86400001, 951782400000, 951868800000, 4102444800000, -2208988800000,
+             1609459199999, 1609459200000, 1230768000000, 1262217600000, 1293753600000, 978307200000 - 1, 978307200000,
+             -62135596800000, 253402300799999]
+    return np.concatenate([np.array(fixed), rng.integers(-62135596800000, 253402300799999, n),
+                           rng.integers(-3 * 10 ** 12, 5 * 10 ** 12, n)]).astype(np.int64)
+
+
+def independent_answer(unit, ms):
+    """pyarrow.compute where it has the operation, the calendar by hand elsewhere."""
+    arr = pa.array(ms, pa.timestamp("ms"))
+    if unit in ("Second", "Minute", "Hour", "Day", "Month", "Quarter", "Year"):
+        return pc.floor_temporal(arr, unit=unit.lower()).cast(pa.int64()).to_numpy()
+    if unit == "Week":
+        return pc.floor_temporal(arr, unit="week", week_starts_monday=True).cast(pa.int64()).to_numpy()
+    if unit == "IsoWeek":
+        return pc.iso_week(arr).to_numpy()
+    years = pc.year(arr).to_numpy()
+    if unit == "Last":
+        months = pc.month(arr).to_numpy()
+        nxt = np.array([np.datetime64(f"{y + (m == 12):04d}-{m % 12 + 1:02d}-01", "D") for y, m in zip(years, months)])
+        return (nxt - np.timedelta64(1, "D")).astype("datetime64[ms]").astype(np.int64)
+    start = {"Decade": years // 10 * 10, "Century": (years - 1) // 100 * 100 + 1, "Millennium": (years - 1) // 1000 * 1000 + 1}[unit]
+    return np.array([np.datetime64(f"{y:04d}-01-01", "ms") for y in start]).astype(np.int64)
+
+
+def date_expr(name, field, out_type):
+    b = gandiva.TreeExprBuilder()
+    return b.make_expression(b.make_function(name, [b.make_field(field)], out_type), pa.field("r", out_type))
+
+
+def date_cases():
+    return ([(f"date_trunc_{u}", u, None) for u in UNITS] + [("extractWeek", "IsoWeek", pa.int64()), ("weekofyear", "IsoWeek", pa.int64()),
+                                                             ("last_day", "Last", pa.date64())])
+
+
+@pytest.mark.parametrize("t", [pa.timestamp("ms"), pa.date64()])
+def test_oracle_unit_starts_iso_weeks_and_month_ends_agree_with_pyarrow_and_the_calendar(t):
+    ms = instants(5)
+    if pa.types.is_date64(t):
+        ms = ms // 86400000 * 86400000
+    ms = ms[ms >= -62135596800000 + 86400000 * 400]          # (year 1 onwards: numpy / pyarrow calendars agree there)
+    batch = pa.RecordBatch.from_arrays([pa.array(ms, pa.int64()).cast(t)], names=["t"])
+    for name, unit, rt in date_cases():
+        got = oracle.project([date_expr(name, batch.schema.field(0), rt or t)], batch)[0]
+        assert got.cast(pa.int64()).to_numpy().tolist() == independent_answer(unit, ms).tolist(), (name, str(t))
+
+
+def test_device_date_functions_on_the_host(hostlib):  # noqa: F811
+    ms = instants(6)
+    ms = ms[ms >= -62135596800000 + 86400000 * 400]
+    out = np.zeros(len(ms), np.int64)
+    for op, unit in enumerate(UNITS + ["IsoWeek", "Last"]):
+        hostlib.host_date_trunc_timestamp(op, ms.ctypes.data_as(C.c_void_p), C.c_long(len(ms)), out.ctypes.data_as(C.c_void_p))
+        assert out.tolist() == independent_answer(unit, ms).tolist(), unit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [pa.timestamp("ms"), pa.date64()])
+def test_date_trunc_week_and_last_day_on_the_gpu(t):
+    ms = instants(7, n=30_000)
+    if pa.types.is_date64(t):
+        ms = ms // 86400000 * 86400000
+    mask = np.arange(len(ms)) % 13 == 5
+    batch = pa.RecordBatch.from_arrays([pa.array(ms, pa.int64(), mask=mask).cast(t)], names=["t"])
+    exprs = [date_expr(name, batch.schema.field(0), rt or t) for name, _, rt in date_cases()]
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    for g, w, (name, _, _) in zip(proj.evaluate(batch), oracle.project(exprs, batch), date_cases()):
+        assert_bit_exact(g, w, name)
