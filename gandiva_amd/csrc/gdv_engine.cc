@@ -476,6 +476,7 @@ std::string ErrorMessage(uint32_t bits) {
   if (bits & 4u) m += (m.empty() ? "" : "; ") + std::string("invalid argument");
   if (bits & 8u) m += (m.empty() ? "" : "; ") + std::string("device scan stalled");
   if (bits & 48u) m += (m.empty() ? "" : "; ") + std::string("internal: optimistic var-len kernel was not re-run");
+  if (bits & 128u) m += (m.empty() ? "" : "; ") + std::string("asynchronous two-stage evaluation: a temporary was too small");
   return m.empty() ? "execution error" : m;
 }
 
@@ -582,7 +583,7 @@ Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnB
     po[e].validity_size = std::max<int64_t>(vbytes, 8);
     GDV_RETURN_NOT_OK(alloc((num_rows + 1) * 4, &po[e].offsets));
     po[e].offsets_size = (num_rows + 1) * 4;
-    GDV_RETURN_NOT_OK(alloc(cap[e], &po[e].data));
+    GDV_RETURN_NOT_OK(alloc(cap[e] + 16, &po[e].data));  // (+16: zeroed behind the bytes produced, below)
     po[e].data_size = cap[e];
   }
   Status s = pre.Evaluate(batch_rows, in, num_cols, sel, po.data(), np, mem, stream, 0);
@@ -591,7 +592,7 @@ Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnB
     for (int e = 0; e < np; e++) {
       if (po[e].data_size > cap[e]) {
         cap[e] = po[e].data_size;
-        GDV_RETURN_NOT_OK(alloc(cap[e], &po[e].data));
+        GDV_RETURN_NOT_OK(alloc(cap[e] + 16, &po[e].data));
         grew = true;
       }
       po[e].data_size = cap[e];
@@ -610,8 +611,15 @@ Status StageColumns::Run(const Projector& pre, int64_t batch_rows, const ColumnB
     c.offsets = po[e].offsets;
     c.offsets_size = po[e].offsets_size;
     c.data = po[e].data;
-    // (the allocation is never shorter than 8 bytes: what a device input needs to be readable)
-    c.data_size = mem == MemKind::kDevice ? std::max<int64_t>(po[e].data_size, 8) : po[e].data_size;
+    // The second stage's byte sweep reads whole 16-byte pieces: the 16 bytes behind the text are zeroed and
+    // readable, so that pool garbage is never taken for bytes >= 0x80 (round 4: every synchronous two-stage
+    // batch went optimistic kernel -> NOTASCII -> exact variant because of it).
+    if (mem == MemKind::kDevice) {
+      GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(static_cast<char*>(po[e].data) + po[e].data_size, 0, 16, stream));
+      c.data_size = po[e].data_size + 16;
+    } else {
+      c.data_size = po[e].data_size;
+    }
     cols.push_back(c);
   }
   return Status::OK();
@@ -660,6 +668,7 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
     planned = &staged.main;
     p->stage_hints_ = std::vector<std::atomic<int64_t>>(staged.pre.size());
   }
+  if (p->pre_) opts.rows_word = true;  // (second stage: GDV_ROWS reads the gate's word of an asynchronous evaluation)
   GDV_RETURN_NOT_OK(PlanProjector(p->plan_schema_, *planned, mode, opts, &p->plan_,
                                   mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
   p->out_bytes_x16_ = std::vector<std::atomic<int64_t>>(exprs.size());
@@ -1149,10 +1158,89 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
 
 Status Projector::EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
                                 OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const {
+  if (pre_ != nullptr) return EvaluateAsyncTwoStage(num_rows, cols, num_cols, sel, outs, num_outs, stream, result);
+  return EvaluateAsyncStage(num_rows, cols, num_cols, sel, outs, num_outs, stream, result, nullptr);
+}
+
+// Both stages of a two-stage plan on the stream, a gate kernel between them (gdv_kernels.h: StageGate).
+Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
+                                        OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const {
+  if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (outs == nullptr || result == nullptr) return Status::Invalid("Output array vector and result block cannot be null");
+  if (plan_.num_varlen_outputs == 0)
+    return Status::Invalid("two-stage plans with fixed-width outputs only are evaluated synchronously");
+  if (pre_->pre_ != nullptr) return Status::Invalid("plans with more than two stages are evaluated synchronously");
+  if (num_cols != static_cast<int>(schema_.size()))
+    return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
+                           ") does not match the schema (" + std::to_string(schema_.size()) + ")");
+  const int np = pre_->num_outputs();
+  if (np > kMaxStageOutputs) return Status::Invalid("too many temporaries for an asynchronous two-stage evaluation");
+  const bool has_sel = sel != nullptr && sel->mode != SelectionMode::kNone;
+  const int64_t stage_rows = has_sel ? sel->num_slots : num_rows;   // (with a device-resident count: the capacity)
+  if (stage_rows <= 0) return EvaluateAsyncStage(num_rows, cols, num_cols, sel, outs, num_outs, stream, result, nullptr);
+  Runtime& rt = Runtime::Get();
+  GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  // temporaries: validity | offsets | bytes per first-stage output, sized like StageColumns::Run sizes them
+  int64_t guess = 32 * stage_rows;
+  for (int k = 0; k < num_cols; k++)
+    if (cols[k].offsets != nullptr) guess += cols[k].data_size;
+  guess = std::min<int64_t>(guess, (int64_t{1} << 31) - 64);
+  StageCaps caps{};
+  std::vector<DeviceBuffer> blocks(3 * static_cast<size_t>(np) + 1);
+  std::vector<OutputBuffers> po(np);
+  std::vector<ColumnBuffers> all(cols, cols + num_cols);
+  StreamDrain drain{stream, false};  // declared after the blocks: an error return after the first enqueue waits
+  const int64_t vbytes = ValidityBytes(stage_rows);
+  for (int e = 0; e < np; e++) {
+    if (!pre_->output_type(e).is_varlen()) return Status::Invalid("two-stage plan: first stage must produce utf8 / binary");
+    int64_t cap = guess;
+    const int64_t per_row_x16 = e < static_cast<int>(stage_hints_.size()) ? stage_hints_[e].load(std::memory_order_relaxed) : 0;
+    if (per_row_x16 > 0) cap = std::min<int64_t>(guess, (per_row_x16 * stage_rows / 16) * 5 / 4 + 4096);
+    cap = std::max<int64_t>(cap, 8);
+    GDV_RETURN_NOT_OK(blocks[3 * e].Allocate(static_cast<size_t>(std::max<int64_t>(vbytes, 8))));
+    GDV_RETURN_NOT_OK(blocks[3 * e + 1].Allocate(static_cast<size_t>((stage_rows + 1) * 4)));
+    GDV_RETURN_NOT_OK(blocks[3 * e + 2].Allocate(static_cast<size_t>(cap) + 16));  // (+16: zeroed by the gate)
+    po[e].validity = blocks[3 * e].get();
+    po[e].validity_size = std::max<int64_t>(vbytes, 8);
+    po[e].offsets = blocks[3 * e + 1].get();
+    po[e].offsets_size = (stage_rows + 1) * 4;
+    po[e].data = blocks[3 * e + 2].get();
+    po[e].data_size = cap;
+    caps.cap[e] = cap;
+    caps.data[e] = po[e].data;
+    ColumnBuffers c;
+    c.validity = po[e].validity;
+    c.validity_size = po[e].validity_size;
+    c.offsets = po[e].offsets;
+    c.offsets_size = po[e].offsets_size;
+    c.data = po[e].data;
+    c.data_size = cap + 16;
+    all.push_back(c);
+  }
+  // gate block: first stage's result (1 + np words) | rows word | status word
+  DeviceBuffer& gate = blocks[3 * static_cast<size_t>(np)];
+  GDV_RETURN_NOT_OK(gate.Allocate(256));
+  uint64_t* const stage_result = gate.as<uint64_t>();
+  int64_t* const rows_word = reinterpret_cast<int64_t*>(gate.as<char>() + 128);
+  uint64_t* const status_word = reinterpret_cast<uint64_t*>(gate.as<char>() + 136);
+  drain.armed = true;
+  GDV_RETURN_NOT_OK(pre_->EvaluateAsyncStage(num_rows, cols, num_cols, sel, po.data(), np, stream, stage_result, nullptr));
+  GDV_HIP_RETURN_NOT_OK(LaunchStageGate(stage_result, np, caps, has_sel ? static_cast<const int64_t*>(sel->num_slots_device) : nullptr,
+                                        stage_rows, rows_word, status_word, stream));
+  GDV_RETURN_NOT_OK(EvaluateAsyncStage(num_rows, all.data(), static_cast<int>(all.size()), sel, outs, num_outs, stream, result,
+                                       rows_word));
+  GDV_HIP_RETURN_NOT_OK(LaunchOrStatus(static_cast<uint64_t*>(result), status_word, stream));
+  for (auto& b : blocks) b.release_after(stream);
+  drain.armed = false;
+  return Status::OK();
+}
+
+Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
+                                     OutputBuffers* outs, int num_outs, hipStream_t stream, void* result,
+                                     const void* rows_word) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
   if (outs == nullptr || result == nullptr) return Status::Invalid("Output array vector and result block cannot be null");
   if (num_outs != num_outputs()) return Status::Invalid("number of output buffers does not match the number of expressions");
-  if (pre_ != nullptr) return Status::Invalid("two-stage plans are evaluated synchronously (their first stage sizes the temporaries)");
   const bool has_sel = sel != nullptr && sel->mode != SelectionMode::kNone;
   if (has_sel != (plan_.mode != SelectionMode::kNone) || (has_sel && sel->mode != plan_.mode))
     return Status::Invalid("selection vector type does not match the mode the projector was built for");
@@ -1191,6 +1279,7 @@ Status Projector::EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int
     args.SetPtr(ArgLayout::kOffSel, sel->indices);
     args.SetPtr(ArgLayout::kOffAux2, sel->num_slots_device);  // null: the count is kOffN
   }
+  if (rows_word != nullptr) args.SetPtr(ArgLayout::kOffAux2, rows_word);  // second stage: the gate's word (it folds the slot count in)
   std::vector<int> vl;
   for (int e = 0; e < num_outs; e++) {
     const DataType& t = plan_.output_types[e];
@@ -1270,6 +1359,7 @@ Status Projector::EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int
       pargs.SetPtr(ArgLayout::kOffErr, head);
       pargs.SetPtr(ArgLayout::kOffCounts, wave_counts.get());
       pargs.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
+      if (rows_word != nullptr) pargs.SetPtr(ArgLayout::kOffAux2, rows_word);  // (the pre-pass walks the same rows as the main kernel)
       GDV_RETURN_NOT_OK(rt.Launch(*k_pre, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
                                   plan_.opts.waves * 64, pargs.data(), pargs.size(), stream));
       int32_t* closing[kMaxScanSegments] = {};
@@ -1849,7 +1939,9 @@ Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr
   if (!staged.pre.empty()) {
     for (auto& e : exprs) GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
     GDV_RETURN_NOT_OK(PrecompileProjector(schema, staged.pre, mode));
-    GDV_RETURN_NOT_OK(PlanProjector(staged.schema, staged.main, mode, CodegenOptions::FromEnv(), &plan,
+    CodegenOptions second = CodegenOptions::FromEnv();
+    second.rows_word = true;
+    GDV_RETURN_NOT_OK(PlanProjector(staged.schema, staged.main, mode, second, &plan,
                                     mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
   } else {
     GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, mode, CodegenOptions::FromEnv(), &plan));

@@ -123,8 +123,22 @@ class Projector {
   //   [1 + e]  the bytes output e produced (fixed-width outputs: 0).  More than the capacity
   //            outs[e].data_size means the buffer was too small: nothing was written past it.
   // Scratch goes back to the pool behind the stream.  outs[e].data_size is left as it was.
+  // Two-stage plans (var-len outputs; round 4): both stages are enqueued; the temporaries are sized from
+  // what recent batches produced (the first guess before any).  A device-side gate between the stages
+  // gives the second stage 0 rows when the first did not complete (status bits, or a temporary too
+  // small: bit 128 in result[0]) — it then touches nothing, and the caller re-runs synchronously.
   Status EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
                        OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const;
+
+ private:
+  // rows_word (may be null): device word the kernels take their row count from (GDV_ROWS; plans of a
+  // second stage and selection-mode plans read it)
+  Status EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
+                            OutputBuffers* outs, int num_outs, hipStream_t stream, void* result, const void* rows_word) const;
+  Status EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
+                               OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const;
+
+ public:
 
   const Schema& schema() const { return schema_; }
   const KernelPlan& plan() const { return plan_; }

@@ -27,6 +27,22 @@ hipError_t LaunchSegmentedOffsetsScan(const uint32_t* counts, int64_t m, int64_t
 
 // Writes row_base + (position of every set bit of mask[0..nwords)) in ascending order to
 // out[]; offsets[] holds, per group of `subtiles` words, the number of set bits before it.
+// Asynchronous two-stage plans (round 4): the gate between the stages.  stage_result = the first stage's
+// { status, bytes of output 0, ... } block (gdv_projector_evaluate_async); caps = the capacities of the
+// temporaries.  *rows_out = the rows the second stage may process: rows_in (device word, may be null: then
+// `rows`) when the first stage completed and every temporary fits, 0 otherwise; *status_out = the first
+// stage's error bits (its SAWUTF8 note dropped) | kStageOverflow when a temporary was too small.
+constexpr uint64_t kStageOverflow = 128;
+constexpr int kMaxStageOutputs = 8;
+// (data[e]: the temporary's byte buffer, cap[e] + 16 bytes long — the gate zeroes the 16 bytes behind what the
+// first stage wrote: the second stage's byte sweep reads whole 16-byte pieces and must not take pool garbage
+// for bytes >= 0x80)
+struct StageCaps { int64_t cap[kMaxStageOutputs]; void* data[kMaxStageOutputs]; };
+hipError_t LaunchStageGate(const uint64_t* stage_result, int num_outputs, const StageCaps& caps, const int64_t* rows_in,
+                           int64_t rows, int64_t* rows_out, uint64_t* status_out, hipStream_t stream);
+// result[0] |= *status
+hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream);
+
 hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int64_t nwords,
                              int subtiles, int64_t row_base, int index_bytes, void* out,
                              int num_cus, hipStream_t stream);

@@ -491,4 +491,39 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
   return hipGetLastError();
 }
 
+// ---- the gate between the two stages of an asynchronous two-stage plan (gdv_kernels.h)
+__global__ void StageGate(const uint64_t* __restrict__ stage_result, int num_outputs, StageCaps caps,
+                          const int64_t* __restrict__ rows_in, int64_t rows, int64_t* __restrict__ rows_out,
+                          uint64_t* __restrict__ status_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t bad = stage_result[0] & ~uint64_t{64};   // (64: the exact string kernels' "saw UTF-8" note)
+  for (int e = 0; e < num_outputs; e++) {
+    const int64_t total = static_cast<int64_t>(stage_result[1 + e]);
+    if (total > caps.cap[e]) {
+      bad |= kStageOverflow;
+    } else if (caps.data[e] != nullptr) {
+      char* end = static_cast<char*>(caps.data[e]) + total;
+      for (int i = 0; i < 16; i++) end[i] = 0;
+    }
+  }
+  int64_t n = rows_in != nullptr ? *rows_in : rows;
+  if (n < 0) n = 0;
+  if (n > rows) n = rows;
+  *rows_out = bad != 0 ? 0 : n;
+  *status_out = bad;
+}
+__global__ void OrStatus(uint64_t* __restrict__ result, const uint64_t* __restrict__ status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) result[0] |= status[0];
+}
+hipError_t LaunchStageGate(const uint64_t* stage_result, int num_outputs, const StageCaps& caps, const int64_t* rows_in,
+                           int64_t rows, int64_t* rows_out, uint64_t* status_out, hipStream_t stream) {
+  if (num_outputs < 0 || num_outputs > kMaxStageOutputs) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(StageGate, dim3(1), dim3(64), 0, stream, stage_result, num_outputs, caps, rows_in, rows, rows_out, status_out);
+  return hipGetLastError();
+}
+hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream) {
+  hipLaunchKernelGGL(OrStatus, dim3(1), dim3(64), 0, stream, result, status);
+  return hipGetLastError();
+}
+
 }  // namespace gdv

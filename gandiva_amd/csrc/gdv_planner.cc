@@ -43,7 +43,7 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "");
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -1047,7 +1047,7 @@ struct Assembler {
       src << "// @expr_" << i << " = " << expr_strings[i] << "\n";
     // rows of the batch: selection-mode plans may take the slot count from device memory (aux2: an
     // asynchronous Filter left it there), so a filter -> project chain needs no host round trip
-    if (plan->mode != SelectionMode::kNone && plan->kind != KernelKind::kFilterProject)
+    if ((plan->mode != SelectionMode::kNone || plan->opts.rows_word) && plan->kind != KernelKind::kFilterProject)
       // (clamped to [0, n]: n is the capacity the outputs and the grid were sized for — a stale or
       // foreign count word must not make the kernel write past them)
       src << "#define GDV_ROWS(A) ((A).aux2 != 0 ? gdv_clamp_rows(*(const gdv_int64*)(A).aux2, (A).n) : (A).n)\n";

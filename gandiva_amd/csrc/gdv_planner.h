@@ -43,6 +43,10 @@ struct CodegenOptions {
   bool wave_bytefree_only = false;     // GDV_WAVE_BYTEFREE_ONLY
   bool ablation = false;               // GDV_ABLATION=1: emit the GDV_ABL experiment branches into the kernels
   bool prepass_rolled = false;         // GDV_PREPASS_ROLLED=1: keep the row loop of optimistic offsets-only pre-passes rolled
+  // Second stage of a two-stage plan (set by the engine, not from the environment): the kernel takes its row
+  // count from the device word aux2 points at when there is one — an asynchronous evaluation's gate writes 0
+  // there when the first stage did not complete, and the second stage then touches nothing.
+  bool rows_word = false;
   bool runtime_needles = false;        // GDV_RUNTIME_NEEDLES=1: wave kernels load their '%needle%' bytes instead of carrying them as immediates
   static CodegenOptions FromEnv();
   std::string Key() const;

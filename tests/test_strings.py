@@ -781,3 +781,80 @@ def test_filter_then_upper_without_a_host_round_trip():
     want = oracle.project(exprs, oracle.take_rows(batch, want_sel.to_numpy()))
     for i, (o, w) in enumerate(zip(outs, want)):
         assert_bit_exact(o.to_arrow(), w, f"output {i}")
+
+
+@pytest.mark.gpu
+def test_two_stage_plans_evaluate_without_a_host_synchronisation():
+    """upper(concat(s, '-', s)) needs the concat materialised first (a two-stage plan).  Asynchronously both stages
+    are enqueued with a device-side gate between them: the second stage runs over the rows the gate lets through —
+    all of them when the first stage completed and its temporaries were large enough, none otherwise (bit 128)."""
+    import torch
+    n = 60_013
+    batch = W.c5_batch(n, 0.1)
+    b = gandiva.TreeExprBuilder()
+    fs = b.make_field(batch.schema.field(0))
+    dash = b.make_literal("-", pa.string())
+    cat = b.make_function("concat", [fs, dash, fs], pa.string())
+    exprs = [b.make_expression(b.make_function("upper", [cat], pa.string()), pa.field("u", pa.string())),
+             b.make_expression(b.make_function("substr", [b.make_function("reverse", [fs], pa.string()),
+                                                          b.make_literal(2, pa.int64()), b.make_literal(4, pa.int64())], pa.string()),
+                               pa.field("r", pa.string())),
+             b.make_expression(b.make_function("like", [cat, b.make_literal("%k-s%", pa.string())], pa.bool_()), pa.field("l", pa.bool_()))]
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    db = gandiva.DeviceBatch.from_arrow(batch)
+    want = oracle.project(exprs, batch)
+    # before any synchronous batch: the temporaries are sized by the first guess
+    outs, result = proj.evaluate_device_async(db, capacity_bytes=4 << 20)
+    torch.cuda.synchronize()
+    assert int(result[0]) == 0
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert_bit_exact(o.to_arrow(), w, f"asynchronous two-stage, first guess, output {i}")
+    # after one: sized from what that batch produced
+    for g, w in zip(proj.evaluate_device(db), want):
+        assert_bit_exact(g.to_arrow(), w, "synchronous")
+    outs, result = proj.evaluate_device_async(db)
+    torch.cuda.synchronize()
+    assert int(result[0]) == 0
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert_bit_exact(o.to_arrow(), w, f"asynchronous two-stage, learnt sizes, output {i}")
+    # a batch whose rows are far longer than anything seen so far: the temporaries are too small, the gate
+    # closes, the status says so, and the synchronous call completes it
+    long_rows = pa.array(["spark-" * 40 + str(i) for i in range(n)], pa.string())
+    big = pa.RecordBatch.from_arrays([long_rows], schema=batch.schema)
+    dbig = gandiva.DeviceBatch.from_arrow(big)
+    short = pa.RecordBatch.from_arrays([pa.array(["ab"] * n, pa.string())], schema=batch.schema)
+    for _ in range(12):                       # (the size hint decays towards the short rows)
+        proj.evaluate_device(gandiva.DeviceBatch.from_arrow(short))
+    outs, result = proj.evaluate_device_async(dbig, capacity_bytes=64 << 20)
+    torch.cuda.synchronize()
+    assert int(result[0]) & 128, f"status {int(result[0])}"
+    with pytest.raises(gandiva.GandivaError):
+        outs[0].to_arrow()
+    for g, w in zip(proj.evaluate_device(dbig), oracle.project(exprs, big)):
+        assert_bit_exact(g.to_arrow(), w, "synchronous, long rows")
+
+
+@pytest.mark.gpu
+def test_filter_then_a_two_stage_projection_without_a_host_round_trip():
+    import torch
+    n = 90_001
+    rng = np.random.default_rng(12)
+    s = W.c5_batch(n).column(0)
+    k = pa.array(rng.integers(0, 100, n), pa.int64())
+    batch = pa.RecordBatch.from_arrays([s, k], names=["s", "k"])
+    b = gandiva.TreeExprBuilder()
+    fs, fk = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    cond = b.make_condition(b.make_function("less_than", [fk, b.make_literal(25, pa.int64())], pa.bool_()))
+    exprs = [b.make_expression(b.make_function("upper", [b.make_function("concat", [fs, b.make_function("castVARCHAR", [fk, b.make_literal(10, pa.int64())], pa.string())],
+                                                                          pa.string())], pa.string()), pa.field("u", pa.string()))]
+    flt = gandiva.make_filter(batch.schema, cond)
+    proj = gandiva.make_projector(batch.schema, exprs, None, "UINT32")
+    db = gandiva.DeviceBatch.from_arrow(batch)
+    sel = flt.evaluate_device(db, "int32", sync=False)
+    outs, result = proj.evaluate_device_async(db, selection=sel)
+    assert sel.pending
+    torch.cuda.synchronize()
+    want_sel = oracle.filter_indices(cond, batch, "int32")
+    assert sel.to_array().equals(want_sel) and int(result[0]) == 0
+    for o, w in zip(outs, oracle.project(exprs, oracle.take_rows(batch, want_sel.to_numpy()))):
+        assert_bit_exact(o.to_arrow(), w, "filter -> two-stage projection, asynchronous")
