@@ -31,3 +31,30 @@ for name, e in plans.items():
         torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     ts.sort()
     print(f"{name}: n={n} median {ts[3]:.3f} ms ({n / ts[3] / 1e6:.1f} G rows/s)")
+
+# the two-stage plan again, asynchronously (gdv_projector_evaluate_async: both stages + the gate on the stream,
+# nothing read back): 8 evaluations back to back between two events
+name = "upper(concat(s, '-', s))  [two stages]"
+p = gandiva.make_projector(sch, plans[name], None)
+outs = p.evaluate_device(db)
+cap = int(outs[0].data.numel())
+outs, res = p.evaluate_device_async(db, capacity_bytes=cap)
+torch.cuda.synchronize()
+assert int(res[0]) == 0, int(res[0])
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(8):          # (8 evaluations in flight hold 8 sets of temporaries: the first round allocates them)
+    outs, res = p.evaluate_device_async(db, outputs=outs)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(8):
+    outs, res = p.evaluate_device_async(db, outputs=outs)
+e1.record()
+torch.cuda.synchronize()
+assert int(res[0]) == 0
+print(f"{name}, asynchronous: n={n} {e0.elapsed_time(e1) / 8:.3f} ms per Evaluate, 8 back to back")
+e0.record()
+for _ in range(8):
+    p.evaluate_device(db, outputs=None)
+e1.record()
+torch.cuda.synchronize()
+print(f"{name}, synchronous:  n={n} {e0.elapsed_time(e1) / 8:.3f} ms per Evaluate, 8 back to back")
