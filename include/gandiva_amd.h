@@ -36,6 +36,11 @@
  * `GDV_MEM_HOST` buffers are staged through HBM by the library (correctness path).
  * There is no CPU evaluation path: without a HIP device every evaluate call fails with
  * GDV_EXECUTION_ERROR.
+ * Device buffers are read in aligned words: a validity / bool bitmap up to the next 8-byte boundary, the
+ * bytes of a utf8 / binary column up to the next 16-byte boundary (never across it, so never into another
+ * page).  Arrow's builders zero the padding of their buffers; a byte buffer that is followed by other
+ * (non-zero) bytes inside that last 16-byte block is still evaluated correctly, but a byte >= 0x80 there
+ * makes the string kernels take their exact (UTF-8 aware, slower) variant for the batch.
  *
  * Devices (round 3).  Every call runs on the CALLING THREAD's device: the one it chose with
  * gdv_set_device(), else its current HIP device (hipSetDevice / torch.cuda.set_device).  The
