@@ -438,11 +438,14 @@ class HostArena:
 
     def __del__(self):
         if getattr(self, "_base", None) is not None:
-            lib = _capi.lib()
-            if self._foreign is None:
-                lib.gdv_host_free(C.c_void_p(self._base))
-            else:
-                lib.gdv_host_unregister(C.c_void_p(self._base))
+            try:
+                lib = _capi.lib()
+                if self._foreign is None:
+                    lib.gdv_host_free(C.c_void_p(self._base))
+                else:
+                    lib.gdv_host_unregister(C.c_void_p(self._base))
+            except Exception:   # (interpreter shutdown: the library may be gone already)
+                pass
             self._base = None
 
     def reset(self):
