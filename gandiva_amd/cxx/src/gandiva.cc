@@ -3,7 +3,11 @@
 // C ABI of libgandiva_amd.so (include/gandiva_amd.h).  Nothing is evaluated here: trees are
 // forwarded to gdv_node_*, Evaluate hands raw Arrow buffer addresses to
 // gdv_projector_evaluate / gdv_filter_evaluate, which launch the HIP kernels.
+#include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "arrow/api.h"
 #include "arrow/device.h"
@@ -155,6 +159,10 @@ Status MarshalBatch(const arrow::RecordBatch& batch, const SchemaPtr& schema,
   return Status::OK();
 }
 
+// bytes the kernels may write behind `address()`: Arrow pads its own allocations to 64 bytes (capacity),
+// which is what lets a validity bitmap in registered host memory be written in whole 8-byte words
+int64_t Room(const arrow::Buffer& b) { return std::max(b.size(), b.capacity()); }
+
 arrow::Result<std::shared_ptr<arrow::Buffer>> AllocOut(int64_t bytes, bool device,
                                                        arrow::MemoryPool* pool,
                                                        const std::shared_ptr<arrow::MemoryManager>& mm) {
@@ -182,6 +190,92 @@ Status UnregisterHostMemory(void* ptr) {
   return Status::OK();
 }
 int64_t HostStagedBytes() { return gdv_host_staged_bytes(); }
+
+// ---- HostMemoryPool: power-of-two blocks carved from page-locked chunks
+struct HostMemoryPool::Impl {
+  struct Chunk { uint8_t* base; int64_t size, used; };
+  std::mutex mu;
+  int64_t chunk_bytes;
+  std::vector<Chunk> chunks;
+  std::map<int64_t, std::vector<uint8_t*>> free_blocks;  // block size -> blocks
+  std::map<uint8_t*, int64_t> large;                      // blocks with a page-locked allocation of their own
+  int64_t allocated = 0, peak = 0, total = 0, count = 0;
+  static int64_t BlockSize(int64_t size, int64_t alignment) {
+    int64_t b = 64;
+    while (b < size || b < alignment) b <<= 1;
+    return b;
+  }
+};
+namespace {
+alignas(64) uint8_t g_zero_size_area[64];
+}
+HostMemoryPool::HostMemoryPool(int64_t chunk_bytes) : impl_(new Impl) {
+  impl_->chunk_bytes = std::max<int64_t>(chunk_bytes, int64_t{1} << 20);
+}
+HostMemoryPool::~HostMemoryPool() {
+  for (auto& c : impl_->chunks) gdv_host_free(c.base);
+  for (auto& l : impl_->large) gdv_host_free(l.first);
+}
+Status HostMemoryPool::Allocate(int64_t size, int64_t alignment, uint8_t** out) {
+  if (size < 0) return Status::Invalid("negative malloc size");
+  if (size == 0) { *out = g_zero_size_area; return Status::OK(); }
+  const int64_t block = Impl::BlockSize(size, alignment);
+  std::lock_guard<std::mutex> g(impl_->mu);
+  uint8_t* p = nullptr;
+  auto fl = impl_->free_blocks.find(block);
+  if (fl != impl_->free_blocks.end() && !fl->second.empty()) {
+    p = fl->second.back();
+    fl->second.pop_back();
+  } else if (block > impl_->chunk_bytes / 2) {
+    void* q = nullptr;
+    GDV_CXX_RETURN_NOT_OK(gdv_host_alloc(block, &q));
+    p = static_cast<uint8_t*>(q);
+    impl_->large[p] = block;
+  } else {
+    for (auto& c : impl_->chunks) {
+      const int64_t at = (c.used + block - 1) / block * block;  // (chunks are page aligned, blocks powers of two)
+      if (at + block <= c.size) { p = c.base + at; c.used = at + block; break; }
+    }
+    if (p == nullptr) {
+      void* q = nullptr;
+      GDV_CXX_RETURN_NOT_OK(gdv_host_alloc(impl_->chunk_bytes, &q));
+      impl_->chunks.push_back(Impl::Chunk{static_cast<uint8_t*>(q), impl_->chunk_bytes, block});
+      p = static_cast<uint8_t*>(q);
+    }
+  }
+  impl_->allocated += size;
+  impl_->peak = std::max(impl_->peak, impl_->allocated);
+  impl_->total += size;
+  impl_->count++;
+  *out = p;
+  return Status::OK();
+}
+void HostMemoryPool::Free(uint8_t* buffer, int64_t size, int64_t alignment) {
+  if (buffer == nullptr || size == 0 || buffer == g_zero_size_area) return;
+  const int64_t block = Impl::BlockSize(size, alignment);
+  std::lock_guard<std::mutex> g(impl_->mu);
+  impl_->allocated -= size;
+  impl_->free_blocks[block].push_back(buffer);   // (blocks with an allocation of their own are recycled too)
+}
+Status HostMemoryPool::Reallocate(int64_t old_size, int64_t new_size, int64_t alignment, uint8_t** ptr) {
+  if (new_size < 0) return Status::Invalid("negative realloc size");
+  if (old_size > 0 && new_size > 0 && Impl::BlockSize(old_size, alignment) == Impl::BlockSize(new_size, alignment)) {
+    std::lock_guard<std::mutex> g(impl_->mu);
+    impl_->allocated += new_size - old_size;
+    impl_->peak = std::max(impl_->peak, impl_->allocated);
+    return Status::OK();  // same block
+  }
+  uint8_t* fresh = nullptr;
+  ARROW_RETURN_NOT_OK(Allocate(new_size, alignment, &fresh));
+  if (old_size > 0 && new_size > 0) std::memcpy(fresh, *ptr, static_cast<size_t>(std::min(old_size, new_size)));
+  Free(*ptr, old_size, alignment);
+  *ptr = fresh;
+  return Status::OK();
+}
+int64_t HostMemoryPool::bytes_allocated() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->allocated; }
+int64_t HostMemoryPool::max_memory() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->peak; }
+int64_t HostMemoryPool::total_bytes_allocated() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->total; }
+int64_t HostMemoryPool::num_allocations() const { std::lock_guard<std::mutex> g(impl_->mu); return impl_->count; }
 
 Node::~Node() { gdv_node_free(handle_); }
 std::string Node::ToString() const {
@@ -501,9 +595,9 @@ Status Projector::Evaluate(const arrow::RecordBatch& batch, const SelectionVecto
     ARROW_ASSIGN_OR_RAISE(dbuf[e], AllocOut(dbytes, device, pool, mm));
     std::memset(&outs[e], 0, sizeof(outs[e]));
     outs[e].validity = reinterpret_cast<void*>(vbuf[e]->address());
-    outs[e].validity_size = vbuf[e]->size();
+    outs[e].validity_size = Room(*vbuf[e]);
     outs[e].data = reinterpret_cast<void*>(dbuf[e]->address());
-    outs[e].data_size = dbuf[e]->size();
+    outs[e].data_size = varlen ? dbuf[e]->size() : Room(*dbuf[e]);
     if (varlen) {
       ARROW_ASSIGN_OR_RAISE(obuf[e], AllocOut((out_rows + 1) * 4, device, pool, mm));
       outs[e].offsets = reinterpret_cast<void*>(obuf[e]->address());
@@ -591,7 +685,7 @@ Status Projector::Evaluate(const arrow::RecordBatch& batch, const SelectionVecto
     GDV_CXX_RETURN_NOT_OK(gdv_projector_output_sizes(handle_, e, out_rows, mem, &vbytes, &dbytes));
     std::memset(&outs[e], 0, sizeof(outs[e]));
     outs[e].validity = reinterpret_cast<void*>(d->buffers[0]->address());
-    outs[e].validity_size = d->buffers[0]->size();
+    outs[e].validity_size = Room(*d->buffers[0]);
     if (outs[e].validity_size < vbytes)
       return Status::Invalid("output array data ", e, ": validity buffer of ", outs[e].validity_size, " bytes, ", vbytes, " needed");
     if (varlen) {
@@ -760,9 +854,9 @@ Status FilterProject::Evaluate(const arrow::RecordBatch& batch, arrow::MemoryPoo
     ARROW_ASSIGN_OR_RAISE(dbuf[e], AllocOut(dbytes, device, pool, mm));
     std::memset(&outs[e], 0, sizeof(outs[e]));
     outs[e].validity = reinterpret_cast<void*>(vbuf[e]->address());
-    outs[e].validity_size = vbuf[e]->size();
+    outs[e].validity_size = Room(*vbuf[e]);
     outs[e].data = reinterpret_cast<void*>(dbuf[e]->address());
-    outs[e].data_size = dbuf[e]->size();
+    outs[e].data_size = Room(*dbuf[e]);
   }
   int64_t count = 0;
   GDV_CXX_RETURN_NOT_OK(gdv_filter_project_evaluate(

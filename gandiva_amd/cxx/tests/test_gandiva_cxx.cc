@@ -239,6 +239,47 @@ int main(int argc, char** argv) {
     CHECK(HostStagedBytes() > before);
     CHECK(arrow::MakeArray(data)->Equals(MakeArr<arrow::Int32Builder, int32_t>({10, 15, 15, 17})));
   }
+  {  // round 4: HostMemoryPool — arrays built in it and outputs allocated from it are evaluated in place
+    HostMemoryPool hpool(int64_t{4} << 20);
+    std::shared_ptr<Projector> p;
+    CHECK_OK(Projector::Make(schema, {expr}, &p));
+    const int n = 50000;
+    arrow::Int32Builder ba(&hpool), bb(&hpool), bc(&hpool);
+    std::vector<int32_t> want(n);
+    for (int i = 0; i < n; i++) {
+      const int32_t x = static_cast<int32_t>((int64_t{i} * 7919) % 1000 - 500), y = static_cast<int32_t>((int64_t{i} * 104729) % 1000 - 500);
+      (void)ba.Append(x); (void)bb.Append(y); (void)bc.Append(0);
+      want[i] = x > y ? x : y;
+    }
+    auto batch = arrow::RecordBatch::Make(schema, n, {ba.Finish().ValueOrDie(), bb.Finish().ValueOrDie(), bc.Finish().ValueOrDie()});
+    const int64_t before = HostStagedBytes();
+    ArrayVector out;
+    CHECK_OK(p->Evaluate(*batch, &hpool, &out));
+    CHECK(HostStagedBytes() == before);
+    auto got = std::static_pointer_cast<arrow::Int32Array>(out[0]);
+    bool same = got->length() == n && got->null_count() == 0;
+    for (int i = 0; same && i < n; i++) same = got->Value(i) == want[i];
+    CHECK(same);
+    CHECK(hpool.bytes_allocated() > 0 && hpool.backend_name() == "gandiva_amd-host");
+    // blocks come back and are handed out again; a request above half a chunk gets a block of its own
+    uint8_t *q1 = nullptr, *q2 = nullptr, *big = nullptr;
+    CHECK_OK(hpool.Allocate(1000, &q1));
+    hpool.Free(q1, 1000);
+    CHECK_OK(hpool.Allocate(900, &q2));
+    CHECK(q1 == q2);
+    CHECK_OK(hpool.Reallocate(900, 1020, &q2));
+    CHECK(q1 == q2);
+    CHECK_OK(hpool.Reallocate(1020, 5000, &q2));
+    CHECK(q1 != q2);
+    hpool.Free(q2, 5000);
+    CHECK_OK(hpool.Allocate(int64_t{3} << 20, &big));
+    std::memset(big, 1, size_t{3} << 20);
+    hpool.Free(big, int64_t{3} << 20);
+    out.clear();
+    got.reset();
+    batch.reset();
+    CHECK(hpool.bytes_allocated() == 0);
+  }
   {  // round 4: IN over float64 / decimal128 and a decimal literal, evaluated
     auto fx = arrow::field("x", arrow::float64());
     auto fd = arrow::field("d", arrow::decimal128(10, 2));
