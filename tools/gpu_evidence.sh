@@ -43,6 +43,9 @@ PYTHONPATH=$R timeout 60 python tools/flat_only_timing.py > $OUT/flat_only_plans
 PYTHONPATH=$R timeout 120 python tools/registry_tail_timing.py > $OUT/registry_tail_timing.txt 2>&1
 PYTHONPATH=$R timeout 200 python tools/filter_project_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_project_chain.txt
 PYTHONPATH=$R timeout 200 python tools/fused_fp_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_project.txt
+# the fused kernel's HBM traffic against the chain's (two --pmc passes) and its rocprofv3 kernel stats
+timeout 300 bash tools/fused_fp_traffic.sh $OUT/fp_traffic > /dev/null 2>&1; cp $OUT/fp_traffic/fp_traffic.txt $OUT/filter_project_traffic.txt 2>/dev/null
+( cd /tmp; rocprofv3 --kernel-trace --stats -d $OUT/prof_fp -o fp --output-format csv -- python $R/tools/fused_fp_timing.py > /dev/null 2>&1 )
 PYTHONPATH=$R timeout 300 python tools/c5_nonascii.py 2>&1 | grep -v amdgpu.ids > $OUT/c5_nonascii.txt
 ( cd /tmp; rocprofv3 --kernel-trace --stats -d $OUT/prof_c5na -o na --output-format csv -- python $R/tools/c5_nonascii_profile.py > /dev/null 2>&1 )
 grep '^"gdv_k_' $(find $OUT/prof_c5na -name "*kernel_stats.csv" | head -1) | awk -F, '{printf "rocprofv3, 1 %% non-ASCII rows: %s average %.4f ms over %s calls\n", $1, $4/1e6, $2}' >> $OUT/c5_nonascii.txt

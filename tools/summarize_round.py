@@ -60,10 +60,13 @@ if acc:
 for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt",
              "small_batches.txt", "registry_tail_timing.txt", "flat_only_plans.txt", "inproc_bench.txt", "multi_device.txt",
              "c5_variants.txt", "filter_project_chain.txt", "filter_project.txt", "c5_nonascii.txt", "c4_repeat.txt",
-             "bench_two_ranks.txt"):
+             "bench_two_ranks.txt", "filter_project_traffic.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, ROUND + "_" + name))
+st = first("prof_fp/**/fp_kernel_stats.csv")
+if st:
+    SP.stats(st, os.path.join(DST, f"{ROUND}_filter_project_kernel_stats.csv"))
 p = os.path.join(SRC, "pytest_gpu_full.log")
 if os.path.exists(p):
     lines = [l for l in open(p) if "passed" in l or "failed" in l or l.startswith(("FAILED", "ERROR"))]
