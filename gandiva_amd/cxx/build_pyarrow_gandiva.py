@@ -18,16 +18,24 @@ OUT_DIR = os.path.join(PKG, "_pyarrow")
 
 
 def build(force=False):
+    """pyarrow's gandiva.pyx -> _pyarrow/gandiva.<abi>.so (returned), and this directory's host_pool.pyx (a
+    pyarrow.MemoryPool over gandiva::HostMemoryPool) -> _pyarrow/host_pool.<abi>.so."""
+    pa_dir = os.path.dirname(pa.__file__)
+    out = _build_one(os.path.join(pa_dir, "gandiva.pyx"), "gandiva", force)
+    _build_one(os.path.join(HERE, "host_pool.pyx"), "host_pool", force)
+    return out
+
+
+def _build_one(pyx, name, force):
     pa_dir = os.path.dirname(pa.__file__)
     site = os.path.dirname(pa_dir)
-    pyx = os.path.join(pa_dir, "gandiva.pyx")
     ext = sysconfig.get_config_var("EXT_SUFFIX")
-    out = os.path.join(OUT_DIR, "gandiva" + ext)
+    out = os.path.join(OUT_DIR, name + ext)
     lib = os.path.join(PKG, "libgandiva.so")
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(lib):
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(lib), os.path.getmtime(pyx)):
         return out
     os.makedirs(OUT_DIR, exist_ok=True)
-    cpp = os.path.join(OUT_DIR, "gandiva.cpp")
+    cpp = os.path.join(OUT_DIR, name + ".cpp")
     subprocess.check_call([sys.executable, "-m", "cython", "--cplus", "-3", "-I", site, pyx, "-o", cpp])
     arrow_so = sorted(f for f in os.listdir(pa_dir) if f.startswith("libarrow.so."))[0]
     cmd = ["g++", "-std=c++20", "-O1", "-g0", "-fPIC", "-shared", "-w", cpp, "-o", out,

@@ -39,3 +39,33 @@ def load(build=True):
     import pyarrow as pa
     pa.gandiva = mod
     return mod
+
+
+def host_memory_pool(chunk_bytes=64 << 20):
+    """A `pyarrow.MemoryPool` over page-locked host memory the GPUs address directly (gandiva::HostMemoryPool).
+    `pa.array(x, memory_pool=pool)` puts a column there, `pyarrow.gandiva.make_projector(schema, exprs, pool)`
+    the outputs: such batches are evaluated in place, nothing is staged."""
+    return _host_pool_module().host_memory_pool(chunk_bytes)
+
+
+def host_staged_bytes():
+    return _host_pool_module().host_staged_bytes()
+
+
+def _host_pool_module():
+    name = "gandiva_amd._pyarrow_host_pool"
+    if name in sys.modules:
+        return sys.modules[name]
+    load()
+    sys.path.insert(0, os.path.join(_HERE, "cxx"))
+    try:
+        import build_pyarrow_gandiva as b
+    finally:
+        sys.path.pop(0)
+    path = os.path.join(b.OUT_DIR, "host_pool" + __import__("sysconfig").get_config_var("EXT_SUFFIX"))
+    loader = importlib.machinery.ExtensionFileLoader("host_pool", path)
+    spec = importlib.util.spec_from_file_location("host_pool", path, loader=loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    sys.modules[name] = mod
+    return mod
