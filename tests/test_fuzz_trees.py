@@ -31,7 +31,11 @@ EXACT = {"add", "subtract", "multiply", "negative", "abs", "nvl", "least", "grea
          "greater_than_or_equal_to", "is_distinct_from", "is_not_distinct_from", "isnull",
          "isnotnull", "not", "istrue", "isfalse", "isnottrue", "isnotfalse", "hash32", "hash64",
          "castBIGINT", "castFLOAT4", "castFLOAT8", "bitwise_and", "bitwise_or", "bitwise_xor",
-         "bitwise_not", "extractYear", "extractMonth", "extractDay"}
+         "bitwise_not", "extractYear", "extractMonth", "extractDay",
+         # round 4 (registry tail): unit starts, ISO weeks, month ends — date64 -> date64 / int64, any depth
+         "date_trunc_Day", "date_trunc_Week", "date_trunc_Month", "date_trunc_Quarter", "date_trunc_Year",
+         "date_trunc_Decade", "date_trunc_Century", "extractWeek", "weekofyear", "last_day", "extractDoy", "extractDow",
+         "extractQuarter"}
 
 
 def _signatures():
