@@ -681,8 +681,9 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
 
 Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                            const SelectionView* sel, OutputBuffers* outs, int num_outs,
-                           MemKind mem, hipStream_t stream, uint32_t flags) const {
+                           MemKind mem, hipStream_t stream, uint32_t flags, const void* rows_word) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  const bool two_stage = pre_ != nullptr && !(flags & kEvalStaged);  // (kEvalStaged: the caller ran the first stage)
   if (outs == nullptr) return Status::Invalid("Output array vector cannot be null");
   if (num_outs != num_outputs())
     return Status::Invalid("number of output buffers (" + std::to_string(num_outs) +
@@ -701,7 +702,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       return Status::Invalid("selection vector: invalid slot count " + std::to_string(sel->num_slots));
   }
   if (has_sel && sel->num_slots_device != nullptr &&
-      (mem != MemKind::kDevice || plan_.num_varlen_outputs > 0 || pre_ != nullptr))
+      (mem != MemKind::kDevice || plan_.num_varlen_outputs > 0 || two_stage))
     return Status::Invalid("a device-resident slot count needs device buffers and fixed-width outputs "
                            "(read the count back and pass it as num_slots instead)");
   Runtime& rt = Runtime::Get();
@@ -716,8 +717,8 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   DeviceBuffer tile_counts, tile_starts, wave_head, wave_counts, wave_bases, wave_chunks;
   StageColumns stage;  // two-stage plans: the first stage's temporary columns (outlive the drain below)
   // declared last: drains first (the byte pass of a var-len plan reads pooled scratch)
-  StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output || pre_ != nullptr};
-  if (pre_) {
+  StreamDrain drain{stream, mem == MemKind::kHost || plan_.has_varlen_output || two_stage};
+  if (two_stage) {
     if (num_cols != static_cast<int>(schema_.size()))
       return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
                              ") does not match the schema (" + std::to_string(schema_.size()) + ")");
@@ -746,6 +747,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       args.SetPtr(ArgLayout::kOffAux2, sel->num_slots_device);  // null: the count is kOffN
     }
   }
+  if (rows_word != nullptr) args.SetPtr(ArgLayout::kOffAux2, rows_word);
 
   // outputs
   std::vector<void*> dev_data(num_outs, nullptr), dev_valid(num_outs), dev_offs(num_outs, nullptr);
@@ -1065,7 +1067,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
         GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
                                              hipMemcpyDeviceToHost, stream));
   }
-  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync) || pre_ != nullptr;
+  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync) || two_stage;
   if (must_sync) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
   if (mem == MemKind::kHost) st.Deliver();
@@ -1167,8 +1169,9 @@ Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* c
                                         OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
   if (outs == nullptr || result == nullptr) return Status::Invalid("Output array vector and result block cannot be null");
-  if (plan_.num_varlen_outputs == 0)
-    return Status::Invalid("two-stage plans with fixed-width outputs only are evaluated synchronously");
+  if (plan_.num_varlen_outputs == 0 && plan_.can_raise)
+    return Status::Invalid("a two-stage plan whose second stage can raise is evaluated synchronously");
+  if (num_outs != num_outputs()) return Status::Invalid("number of output buffers does not match the number of expressions");
   if (pre_->pre_ != nullptr) return Status::Invalid("plans with more than two stages are evaluated synchronously");
   if (num_cols != static_cast<int>(schema_.size()))
     return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
@@ -1227,8 +1230,14 @@ Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* c
   GDV_RETURN_NOT_OK(pre_->EvaluateAsyncStage(num_rows, cols, num_cols, sel, po.data(), np, stream, stage_result, nullptr));
   GDV_HIP_RETURN_NOT_OK(LaunchStageGate(stage_result, np, caps, has_sel ? static_cast<const int64_t*>(sel->num_slots_device) : nullptr,
                                         stage_rows, rows_word, status_word, stream));
-  GDV_RETURN_NOT_OK(EvaluateAsyncStage(num_rows, all.data(), static_cast<int>(all.size()), sel, outs, num_outs, stream, result,
-                                       rows_word));
+  if (plan_.num_varlen_outputs > 0) {
+    GDV_RETURN_NOT_OK(EvaluateAsyncStage(num_rows, all.data(), static_cast<int>(all.size()), sel, outs, num_outs, stream, result,
+                                         rows_word));
+  } else {  // fixed-width outputs only: the ordinary asynchronous launch over the staged columns, rows from the gate
+    GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));
+    GDV_RETURN_NOT_OK(Evaluate(num_rows, all.data(), static_cast<int>(all.size()), sel, outs, num_outs, MemKind::kDevice, stream,
+                               kEvalAsync | kEvalStaged, rows_word));
+  }
   GDV_HIP_RETURN_NOT_OK(LaunchOrStatus(static_cast<uint64_t*>(result), status_word, stream));
   for (auto& b : blocks) b.release_after(stream);
   drain.armed = false;

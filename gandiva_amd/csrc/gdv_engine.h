@@ -61,6 +61,7 @@ struct Configuration {
 enum EvalFlags : uint32_t {
   kEvalAsync = 1u,    // device buffers only: return after enqueueing on `stream`
   kEvalNoSmall = 2u,  // internal: a batch-by-batch fallback must not re-enter the fused small-batch path
+  kEvalStaged = 4u,   // internal: the columns already hold the first stage's temporaries (asynchronous two-stage plans)
 };
 
 // What a built plan owns on ONE device context (round 3: a Projector / Filter can be evaluated by
@@ -94,9 +95,11 @@ class Projector {
 
   // `cols` has one entry per schema field (unused fields may be empty).  With a selection
   // view, outputs have sel->num_slots rows, else num_rows rows.
+  // (rows_word, internal: device word second-stage kernels take their row count from — the gate of an
+  // asynchronous two-stage evaluation)
   Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                   const SelectionView* sel, OutputBuffers* outs, int num_outs, MemKind mem,
-                  hipStream_t stream, uint32_t flags) const;
+                  hipStream_t stream, uint32_t flags, const void* rows_word = nullptr) const;
 
   // Many (small) HBM-resident batches in ONE launch (round 3): the reference is fed 4K-64K-row
   // batches, where a launch + argument marshalling per batch is all overhead.  The argument blocks
@@ -127,6 +130,7 @@ class Projector {
   // what recent batches produced (the first guess before any).  A device-side gate between the stages
   // gives the second stage 0 rows when the first did not complete (status bits, or a temporary too
   // small: bit 128 in result[0]) — it then touches nothing, and the caller re-runs synchronously.
+  // (second stages with fixed-width outputs only: plans that cannot raise)
   Status EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
                        OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const;
 

@@ -287,8 +287,9 @@ int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, 
  * Two-stage plans (a function over a value that is materialised first: upper(concat(a, b)) ...): both stages
  * are enqueued, the temporaries sized from what earlier batches produced; a one-thread gate kernel between the
  * stages hands the second stage its row count — 0 when the first stage did not complete or a temporary was too
- * small (bit 128 of result[0]), so that it touches nothing.  Two-stage plans whose outputs are all fixed-width,
- * and plans with more than two stages: GDV_INVALID (evaluate them synchronously). */
+ * small (bit 128 of result[0]), so that it touches nothing.  A second stage with fixed-width outputs only is
+ * launched the same way unless it can raise; that, and plans with more than two stages: GDV_INVALID (evaluate
+ * them synchronously). */
 int gdv_projector_evaluate_async(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols, int num_cols,
                                  const gdv_selection_t* sel, const void* num_slots_device, gdv_out_column_t* outs,
                                  int num_outs, void* stream, void* result);

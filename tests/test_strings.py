@@ -858,3 +858,44 @@ def test_filter_then_a_two_stage_projection_without_a_host_round_trip():
     assert sel.to_array().equals(want_sel) and int(result[0]) == 0
     for o, w in zip(outs, oracle.project(exprs, oracle.take_rows(batch, want_sel.to_numpy()))):
         assert_bit_exact(o.to_arrow(), w, "filter -> two-stage projection, asynchronous")
+
+
+@pytest.mark.gpu
+def test_two_stage_plans_with_fixed_width_outputs_evaluate_without_a_host_synchronisation():
+    """like(concat(s, '-', s), ...) and length(concat(...)): the second stage has fixed-width outputs only — the
+    ordinary asynchronous launch over the staged columns, its row count from the gate."""
+    import torch
+    n = 40_009
+    batch = W.c5_batch(n, 0.1)
+    b = gandiva.TreeExprBuilder()
+    fs = b.make_field(batch.schema.field(0))
+    cat = b.make_function("concat", [fs, b.make_literal("-", pa.string()), fs], pa.string())
+    exprs = [b.make_expression(b.make_function("like", [cat, b.make_literal("%k-s%", pa.string())], pa.bool_()), pa.field("l", pa.bool_())),
+             b.make_expression(b.make_function("length", [b.make_function("reverse", [fs], pa.string())], pa.int32()), pa.field("n", pa.int32())),
+             b.make_expression(b.make_function("starts_with", [cat, b.make_literal("sp", pa.string())], pa.bool_()), pa.field("p", pa.bool_()))]
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    db = gandiva.DeviceBatch.from_arrow(batch)
+    # (a second stage that can raise — locate checks its start position — has to report errors: synchronous only)
+    raising = gandiva.make_projector(batch.schema, [b.make_expression(b.make_function("locate", [b.make_literal("k-", pa.string()), cat], pa.int32()),
+                                                                       pa.field("q", pa.int32()))], None)
+    with pytest.raises(pa.ArrowInvalid):
+        raising.evaluate_device_async(db)
+    want = oracle.project(exprs, batch)
+    for attempt in ("first guess", "learnt sizes"):
+        outs, result = proj.evaluate_device_async(db)
+        torch.cuda.synchronize()
+        assert int(result[0]) == 0, (attempt, int(result[0]))
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert_bit_exact(o.to_arrow(), w, f"{attempt}, output {i}")
+        for g, w in zip(proj.evaluate_device(db), want):
+            assert_bit_exact(g.to_arrow(), w, "synchronous")
+    short = pa.RecordBatch.from_arrays([pa.array(["ab"] * n, pa.string())], schema=batch.schema)
+    for _ in range(12):
+        proj.evaluate_device(gandiva.DeviceBatch.from_arrow(short))
+    big = pa.RecordBatch.from_arrays([pa.array(["spark-" * 40 + str(i) for i in range(n)], pa.string())], schema=batch.schema)
+    dbig = gandiva.DeviceBatch.from_arrow(big)
+    outs, result = proj.evaluate_device_async(dbig)
+    torch.cuda.synchronize()
+    assert int(result[0]) & 128
+    for g, w in zip(proj.evaluate_device(dbig), oracle.project(exprs, big)):
+        assert_bit_exact(g.to_arrow(), w, "synchronous, long rows")
