@@ -184,6 +184,201 @@ std::string DeclaredName(const std::string& code) {
   return std::string();
 }
 
+// ---- function-like macros of the header: expanding the type-family instantiations -------------
+// `GDV_NUMERIC_TYPES(GDV_RELOPS)` carries no name, but what it EXPANDS to does: ten times six
+// functions, each with a name of its own.  Rounds 3-4 hashed such lines (and, through the
+// identifiers they mention, the macros behind them) into every kernel; a new `GDV_DATE_TRUNC(T)`
+// family then renamed the float64 projection and orphaned its profiles.  The instantiations are
+// expanded here instead — parameters substituted, `##` pasted, the result rescanned at brace
+// depth 0 (X-macro lists hand macro names on as arguments) — and split into ordinary named items.
+// Nothing inside a function body is expanded: a macro used there is an identifier like any other
+// and reached by name.  The header uses neither `#param` nor variadic macros; a line that does
+// not expand cleanly stays a base item as before.
+struct FnMacro {
+  std::vector<std::string> params;
+  std::string body;
+};
+
+std::vector<std::string> SplitArgs(const std::string& s) {
+  std::vector<std::string> out;
+  std::string cur;
+  int depth = 0;
+  for (size_t i = 0; i < s.size(); i++) {
+    const char c = s[i];
+    if (c == '"' || c == '\'') {
+      cur.push_back(c);
+      for (i++; i < s.size() && s[i] != c; i++) {
+        cur.push_back(s[i]);
+        if (s[i] == '\\' && i + 1 < s.size()) cur.push_back(s[++i]);
+      }
+      if (i < s.size()) cur.push_back(c);
+      continue;
+    }
+    if (c == '(' || c == '[' || c == '{') depth++;
+    else if (c == ')' || c == ']' || c == '}') depth--;
+    if (c == ',' && depth == 0) {
+      out.push_back(Collapse(cur));
+      cur.clear();
+    } else {
+      cur.push_back(c);
+    }
+  }
+  out.push_back(Collapse(cur));
+  return out;
+}
+
+// `#define NAME(a, b) body` (already collapsed to one line) -> table entry; false for object-like macros
+bool ParseFnMacro(const std::string& code, std::string* name, FnMacro* m) {
+  size_t p = code.find("define");
+  if (p == std::string::npos) return false;
+  p += 6;
+  while (p < code.size() && code[p] == ' ') p++;
+  size_t q = p;
+  while (q < code.size() && IsIdentChar(code[q])) q++;
+  if (q == p || q >= code.size() || code[q] != '(') return false;  // a blank before '(' = object-like
+  *name = code.substr(p, q - p);
+  size_t close = code.find(')', q);
+  if (close == std::string::npos) return false;
+  const std::string plist = code.substr(q + 1, close - q - 1);
+  if (plist.find("...") != std::string::npos) return false;
+  m->params.clear();
+  if (!Collapse(plist).empty())
+    for (auto& a : SplitArgs(plist)) m->params.push_back(a);
+  m->body = code.substr(close + 1);
+  return true;
+}
+
+bool Substitute(const FnMacro& m, const std::vector<std::string>& args, std::string* out) {
+  if (args.size() != m.params.size()) return false;
+  std::string r;
+  const std::string& b = m.body;
+  for (size_t i = 0; i < b.size();) {
+    if (b[i] == '"' || b[i] == '\'') {
+      const char q = b[i];
+      r.push_back(b[i++]);
+      while (i < b.size() && b[i] != q) {
+        if (b[i] == '\\' && i + 1 < b.size()) r.push_back(b[i++]);
+        r.push_back(b[i++]);
+      }
+      if (i < b.size()) r.push_back(b[i++]);
+    } else if (IsIdentStart(b[i])) {
+      size_t j = i;
+      while (j < b.size() && IsIdentChar(b[j])) j++;
+      const std::string id = b.substr(i, j - i);
+      size_t k = 0;
+      for (; k < m.params.size(); k++)
+        if (m.params[k] == id) break;
+      r += k < m.params.size() ? args[k] : id;
+      i = j;
+    } else if (std::isdigit(static_cast<unsigned char>(b[i]))) {
+      while (i < b.size() && (IsIdentChar(b[i]) || b[i] == '.')) r.push_back(b[i++]);
+    } else if (b[i] == '#' && i + 1 < b.size() && b[i + 1] == '#') {
+      while (!r.empty() && r.back() == ' ') r.pop_back();
+      i += 2;
+      while (i < b.size() && b[i] == ' ') i++;
+    } else if (b[i] == '#') {
+      return false;  // stringification: not used by the header, not modelled
+    } else {
+      r.push_back(b[i++]);
+    }
+  }
+  *out = r;
+  return true;
+}
+
+// expands macro invocations found at brace depth 0 of `in` (recursively); false = leave the line alone
+bool ExpandTopLevel(const std::map<std::string, FnMacro>& macros, const std::string& in, std::string* out, int guard) {
+  if (guard > 16) return false;
+  int braces = 0;
+  for (size_t i = 0; i < in.size();) {
+    const char c = in[i];
+    if (c == '"' || c == '\'') {
+      out->push_back(in[i++]);
+      while (i < in.size() && in[i] != c) {
+        if (in[i] == '\\' && i + 1 < in.size()) out->push_back(in[i++]);
+        out->push_back(in[i++]);
+      }
+      if (i < in.size()) out->push_back(in[i++]);
+      continue;
+    }
+    if (c == '{') braces++;
+    if (c == '}') braces--;
+    if (braces == 0 && IsIdentStart(c) && (i == 0 || !IsIdentChar(in[i - 1]))) {
+      size_t j = i;
+      while (j < in.size() && IsIdentChar(in[j])) j++;
+      const std::string id = in.substr(i, j - i);
+      auto it = macros.find(id);
+      size_t k = j;
+      while (k < in.size() && in[k] == ' ') k++;
+      if (it != macros.end() && k < in.size() && in[k] == '(') {
+        int depth = 0;
+        size_t e = k;
+        for (; e < in.size(); e++) {
+          if (in[e] == '(') depth++;
+          else if (in[e] == ')' && --depth == 0) break;
+        }
+        if (e >= in.size()) return false;
+        const std::string inner = in.substr(k + 1, e - k - 1);
+        std::vector<std::string> args;
+        if (!(it->second.params.empty() && Collapse(inner).empty())) args = SplitArgs(inner);
+        std::string once, deep;
+        if (!Substitute(it->second, args, &once)) return false;
+        if (!ExpandTopLevel(macros, once, &deep, guard + 1)) return false;
+        *out += deep;
+        out->push_back(' ');
+        i = e + 1;
+        continue;
+      }
+      *out += id;
+      i = j;
+      continue;
+    }
+    out->push_back(in[i++]);
+  }
+  return true;
+}
+
+// top-level declarations of a text without directives (the expansion of a family)
+std::vector<std::string> SplitTopLevel(const std::string& text) {
+  std::vector<std::string> out;
+  std::string cur;
+  int braces = 0, parens = 0;
+  for (size_t i = 0; i < text.size(); i++) {
+    const char c = text[i];
+    cur.push_back(c);
+    if (c == '"' || c == '\'') {
+      for (i++; i < text.size() && text[i] != c; i++) {
+        cur.push_back(text[i]);
+        if (text[i] == '\\' && i + 1 < text.size()) cur.push_back(text[++i]);
+      }
+      if (i < text.size()) cur.push_back(c);
+      continue;
+    }
+    if (c == '(') parens++;
+    else if (c == ')') parens--;
+    else if (c == '{') braces++;
+    else if (c == '}') {
+      braces--;
+      if (braces == 0 && parens == 0) {
+        size_t k = i + 1;
+        while (k < text.size() && text[k] == ' ') k++;
+        if (k < text.size() && text[k] == ';') {
+          cur.push_back(';');
+          i = k;
+        }
+        out.push_back(Collapse(cur));
+        cur.clear();
+      }
+    } else if (c == ';' && braces == 0 && parens == 0) {
+      out.push_back(Collapse(cur));
+      cur.clear();
+    }
+  }
+  const std::string rest = Collapse(cur);
+  if (!rest.empty()) out.push_back(rest);
+  return out;
+}
+
 }  // namespace
 
 LibraryIndex::LibraryIndex(const std::string& header_source) {
@@ -196,6 +391,21 @@ LibraryIndex::LibraryIndex(const std::string& header_source) {
     it.idents = Identifiers(code);
     if (!name.empty()) by_name_.emplace(name, items_.size());
     items_.push_back(std::move(it));
+  };
+  std::map<std::string, FnMacro> fn_macros;  // the header's function-like macros, as met so far
+  // an instantiation line: its expansion as named items; a base item when it does not expand
+  auto add_instantiation = [&](const std::string& code) {
+    std::string expanded;
+    if (ExpandTopLevel(fn_macros, code, &expanded, 0)) {
+      const std::vector<std::string> decls = SplitTopLevel(Collapse(expanded));
+      bool all_named = !decls.empty();
+      for (auto& d : decls) all_named = all_named && !DeclaredName(d).empty() && d.find('{') != std::string::npos;
+      if (all_named) {
+        for (auto& d : decls) add(DeclaredName(d), d);
+        return;
+      }
+    }
+    add(std::string(), code);
   };
   std::string cur;     // text of the item being collected
   int braces = 0, parens = 0;
@@ -224,6 +434,9 @@ LibraryIndex::LibraryIndex(const std::string& header_source) {
         size_t q = p;
         while (q < code.size() && IsIdentChar(code[q])) q++;
         name = code.substr(p, q - p);
+        std::string mname;
+        FnMacro fm;
+        if (ParseFnMacro(code, &mname, &fm)) fn_macros[mname] = std::move(fm);
       }
       add(name, code);  // #if / #ifndef / #else / #endif / #pragma / #undef: base
       cur.clear();
@@ -266,7 +479,7 @@ LibraryIndex::LibraryIndex(const std::string& header_source) {
     if (braces == 0 && parens == 0) {
       const std::string code = Collapse(cur);
       if (!code.empty() && IsMacroInstantiation(code)) {
-        add(std::string(), code);
+        add_instantiation(code);
         cur.clear();
       }
     }

@@ -49,7 +49,9 @@ def test_editing_a_string_function_renames_string_kernels_only(monkeypatch, tmp_
     c5 = _kernel_text(monkeypatch, tmp_path / "c5", "c5") if (tmp_path / "c5").mkdir() is None else None
     # the float64 projection reaches no string function at all
     reached = _items(c2)
-    assert "add_float64_float64" not in reached  # macro family: hashed through the base items
+    assert "add_float64_float64" in reached      # round 5: the expansion of GDV_FLOAT_TYPES(GDV_FLOAT_ARITH), by name
+    assert "add_int32_int32" not in reached and "less_than_int64_int64" not in reached
+    assert not [r for r in reached if r.startswith("<base>") and not r.startswith("<base> #")], reached   # directives only: no instantiation line left in the base
     for name in ("substr_utf8_int64_int64", "upper_utf8", "gdv_like_contains", "gdv_scanner", "gdv_flat_copy"):
         assert name not in reached, name
     assert "substr_utf8_int64_int64" in _items(c5)
@@ -67,11 +69,46 @@ def test_editing_a_string_function_renames_string_kernels_only(monkeypatch, tmp_
     assert _tag(c5, commented) == _tag(c5)
 
 
+def test_a_new_macro_family_renames_nothing_and_an_edited_one_only_its_users(monkeypatch, tmp_path):
+    """Round 4 lost its evidence to exactly this: `GDV_DATE_TRUNC(T)` + two instantiation lines were
+    added late, the instantiations sat in the always-hashed base, and every kernel — the float64
+    projection included — got a new name.  Families are expanded now and their functions attributed
+    by name like hand-written ones."""
+    src = _lib_source()
+    texts = {}
+    for w in ("c2", "c3", "c4", "c5"):
+        (tmp_path / w).mkdir()
+        texts[w] = _kernel_text(monkeypatch, tmp_path / w, w)
+    family = ("\n#define GDV_NEW_FAMILY(T) \\\n  GDV_DEV gdv_##T brand_new_##T(gdv_##T a) { return a; } \\\n"
+              "  GDV_DEV gdv_##T brand_newer_##T##_##T(gdv_##T a, gdv_##T b) { return add_##T##_##T(a, b); }\n"
+              "GDV_NEW_FAMILY(float64)\nGDV_NUMERIC_TYPES(GDV_NEW_FAMILY)\n")
+    anchor = "GDV_FLOAT_TYPES(GDV_FLOAT_ARITH)\n"
+    assert anchor in src
+    added = src.replace(anchor, anchor + family, 1)
+    for w, t in texts.items():
+        assert _tag(t, added) == _tag(t, src) == _tag(t), w
+    assert "brand_new_float64" not in _items(texts["c2"], added)
+    assert "brand_new_float64" in _items("x = brand_new_float64(y);", added)
+    # a real edit of the float arithmetic family renames the float64 projection, and NOT the int64
+    # filter, the decimal projection or the string kernels
+    edited = src.replace("GDV_DEV gdv_##T add_##T##_##T(gdv_##T a, gdv_##T b) { return a + b; }",
+                         "GDV_DEV gdv_##T add_##T##_##T(gdv_##T a, gdv_##T b) { return b + a; }", 1)
+    assert edited != src
+    assert _tag(texts["c2"], edited) != _tag(texts["c2"], src)
+    for w in ("c3", "c4", "c5"):
+        assert _tag(texts[w], edited) == _tag(texts[w], src), w
+    # ... and an edit of the relational family renames the filter, not the projection
+    edited = src.replace("GDV_DEV bool greater_than_##T##_##T(gdv_##T a, gdv_##T b) { return a > b; }",
+                         "GDV_DEV bool greater_than_##T##_##T(gdv_##T a, gdv_##T b) { return b < a; }", 1)
+    assert edited != src
+    assert _tag(texts["c3"], edited) != _tag(texts["c3"], src)
+    assert _tag(texts["c2"], edited) == _tag(texts["c2"], src)
+
+
 def test_editing_arithmetic_or_core_items_renames_every_kernel(monkeypatch, tmp_path):
     src = _lib_source()
     (tmp_path / "c2").mkdir()
     c2 = _kernel_text(monkeypatch, tmp_path / "c2", "c2")
-    # the type-family macros cannot be attributed to a name (token pasting): always hashed
     edited = src.replace("#define GDV_FLOAT_ARITH(T)", "#define GDV_FLOAT_ARITH(T) /* */ ", 1)
     assert edited != src
     assert _tag(c2, edited) == _tag(c2, src)  # a comment is still not code

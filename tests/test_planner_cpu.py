@@ -123,17 +123,23 @@ def test_committed_pmc_files_belong_to_the_kernels_this_tree_generates(monkeypat
     here = os.path.dirname(os.path.abspath(__file__))
     plans = {"c2": (W.c2_schema(), W.c2_expressions(), None), "c3": (W.c3_schema(), None, W.c3_condition()),
              "c4": (W.c4_schema(), W.c4_expressions(), None), "c5": (W.c5_schema(), W.c5_expressions(), None)}
+    stale = []
     for w, (schema, exprs, cond) in plans.items():
         d = tmp_path / w
         d.mkdir()
         dumped = _precompile(monkeypatch, d, schema, exprs, cond)
         want = json.load(open(os.path.join(here, "..", "profiles", f"pmc_{w}.json")))["kernel"]
         if want + ".hip" not in dumped:
-            msg = f"profiles/pmc_{w}.json was measured on {want}; this tree generates {dumped}: re-run tools/gpu_evidence.sh"
-            if os.environ.get("GDV_STRICT_EVIDENCE") == "1":
-                pytest.fail(msg)
+            stale.append(f"profiles/pmc_{w}.json was measured on {want}; this tree generates {dumped}")
+    if stale:
+        msg = "; ".join(stale) + ": re-run tools/gpu_evidence.sh"
+        # round 5: stale evidence FAILS.  Round 4 only warned here and shipped four orphaned counter files.
+        # Work in progress opts out explicitly (GDV_EVIDENCE_PENDING=1) — the default run does not.
+        if os.environ.get("GDV_EVIDENCE_PENDING") == "1":
             import warnings
-            warnings.warn(msg)   # mid-round trees may be ahead of their evidence; the bench line says so too
+            warnings.warn(msg)
+        else:
+            pytest.fail(msg)
 
 
 def test_registry_aliases_share_their_kernels(monkeypatch, tmp_path):
