@@ -104,6 +104,7 @@ PROTOTYPES = [
     ("gdv_filter_project_output_type", gdv_type_t, [_P, C.c_int]),
     ("gdv_filter_project_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), _P, C.c_int, _P, C.c_uint32]),
     ("gdv_filter_project_dump_ir", _P, [_P]),
+    ("gdv_filter_project_kernel_shape", C.c_int, [_P]),
     ("gdv_filter_project_free", None, [_P]),
     ("gdv_precompile_filter_project", C.c_int, [_P, _P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_registry_size", C.c_int, []),

@@ -675,6 +675,7 @@ int gdv_filter_project_evaluate(const gdv_filter_project_t* fp, int64_t num_rows
   });
 }
 char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp) { return fp ? DupString(fp->fp->DumpIR()) : nullptr; }
+int gdv_filter_project_kernel_shape(const gdv_filter_project_t* fp) { return fp ? fp->fp->which_kernel() : -1; }
 void gdv_filter_project_free(gdv_filter_project_t* fp) { delete fp; }
 
 // ---------------------------------------------------------------- JNI-shaped flat entry points

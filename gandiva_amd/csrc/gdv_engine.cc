@@ -169,6 +169,8 @@ struct EngineKnobs {
   bool no_small_filter = false;    // GDV_NO_SMALL_FILTER: default of Filter "small_filter" tuning (read at Make)
   int filter_chunks = 1;           // GDV_FILTER_CHUNKS: default of Filter "chunks" tuning (read at Make)
   int grid_mult = 0;               // GDV_GRID_MULT: workgroups per CU of the grid-stride launch (0: default)
+  bool fp_window_only = false;     // GDV_FP_WINDOW_ONLY: fused filter-project never moves to its direct kernel (tests, sweeps)
+  bool fp_force_stall = false;     // GDV_FP_FORCE_STALL: treat every fused launch as stalled (exercises the chain re-run)
   static const EngineKnobs& Get() {
     static const EngineKnobs k = [] {
       EngineKnobs x;
@@ -176,6 +178,8 @@ struct EngineKnobs {
       x.no_optflat = std::getenv("GDV_NO_OPTFLAT") != nullptr;
       x.no_evaluate_many = std::getenv("GDV_NO_EVALUATE_MANY") != nullptr;
       x.no_small_filter = std::getenv("GDV_NO_SMALL_FILTER") != nullptr;
+      x.fp_window_only = std::getenv("GDV_FP_WINDOW_ONLY") != nullptr;
+      x.fp_force_stall = std::getenv("GDV_FP_FORCE_STALL") != nullptr;
       if (const char* s = std::getenv("GDV_GRID_MULT")) x.grid_mult = std::max(1, atoi(s));
       if (const char* s = std::getenv("GDV_FILTER_CHUNKS")) x.filter_chunks = std::max(1, std::min(64, atoi(s)));
       return x;
@@ -468,6 +472,8 @@ int64_t GridFor(const KernelPlan& plan, int64_t rows) {
   int64_t cap = static_cast<int64_t>(Runtime::Get().num_cus()) * blocks_per_cu;
   return std::max<int64_t>(1, std::min(ntiles, cap));
 }
+
+constexpr uint32_t kErrStall = 8u;  // GDV_ERR_STALL (gdv_device_lib.hpp): a look-back / scanner hand-off gave up
 
 std::string ErrorMessage(uint32_t bits) {
   std::string m;
@@ -1354,6 +1360,9 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
       GDV_RETURN_NOT_OK(wave_counts.Allocate(static_cast<size_t>(nseg * seg_stride) * 4 + 64));
       GDV_RETURN_NOT_OK(wave_bases.Allocate(static_cast<size_t>(nseg * seg_stride) * 8));
       GDV_RETURN_NOT_OK(wave_chunks.Allocate(static_cast<size_t>(nseg * ScanChunks(nwt)) * 8));
+      // a second stage whose gate is closed walks 0 rows: its pre-pass writes no count, the scan must still see zeros
+      if (rows_word != nullptr)
+        GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(wave_counts.get(), 0, static_cast<size_t>(nseg * seg_stride) * 4 + 64, stream));
       args.SetPtr(ArgLayout::kOffMask, wave_bases.get());
       ArgBlock pargs(pp->layout);
       for (size_t kp = 0; kp < pp->input_fields.size(); kp++) {
@@ -1379,7 +1388,9 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
                                                        reinterpret_cast<uint64_t*>(head + 8 + totals_bytes), closing, stream));
     }
     GDV_RETURN_NOT_OK(rt.Launch(*k_main, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
-    GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(res, head, 4, hipMemcpyDefault, stream));   // the error word (upper half stays 0)
+    // the error word, minus the exact kernels' note that the batch did hold bytes >= 0x80 (64: not an error —
+    // round 4 published it, and every asynchronous call on non-ASCII text looked failed to its caller)
+    GDV_HIP_RETURN_NOT_OK(LaunchPublishStatus(res, reinterpret_cast<const uint32_t*>(head), 64u, stream));
     for (int v = 0; v < nv; v++) {
       const char* src = plan_.wave_segments[v] >= 0 ? head + 8 + totals_bytes + 8 * plan_.wave_segments[v] : head + 8 + 8 * v;
       GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(res + 1 + vl[v], src, 8, hipMemcpyDefault, stream));
@@ -1815,6 +1826,8 @@ Status FilterProject::Make(const Schema& schema, const ExpressionPtr& condition,
   if (!staged.pre.empty()) return Status::CodeGenError("fused filter-project: two-stage plans take the filter + projector chain");
   auto fp = std::make_shared<FilterProject>();
   fp->schema_ = schema;
+  fp->condition_ = condition;
+  fp->exprs_ = exprs;
   GDV_RETURN_NOT_OK(PlanFilterProject(schema, condition, exprs, index_mode, CodegenOptions::FromEnv(), &fp->plan_));
   fp->raises_ = fp->plan_.exprs_raise;
   const PlanDeviceState* st = nullptr;
@@ -1823,9 +1836,71 @@ Status FilterProject::Make(const Schema& schema, const ExpressionPtr& condition,
   return Status::OK();
 }
 
+int FilterProject::which_kernel() const {
+  if (plan_.fp_window_rows <= 0 || plan_.exact == nullptr) return -1;
+  // the window holds fp_window_rows of a wave tile's 64 x subtiles rows; beyond ~85 % of that on average, wave
+  // tiles start to overflow into the re-read path and the direct kernel is the better one
+  const int limit = plan_.fp_window_rows * 1024 / (64 * plan_.opts.subtiles) * 85 / 100;
+  return selected_per_1024_.load(std::memory_order_relaxed) > limit ? 1 : 0;
+}
+
 Status FilterProject::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs,
                                int num_outs, void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
                                hipStream_t stream, uint32_t flags, void* count_out) const {
+  bool stalled = false;
+  GDV_RETURN_NOT_OK(EvaluateFused(num_rows, cols, num_cols, outs, num_outs, out_indices, max_slots, num_selected, mem, stream,
+                                  flags, count_out, &stalled));
+  if (!stalled) return Status::OK();
+  // The look-back waited 5 s for an earlier workgroup tile (a device time-sliced away, or workgroups not dispatched
+  // in index order): the launch is over, its outputs are not complete.  Round 4 returned ExecutionError here; the
+  // reference's own chain gives the same results without any cross-workgroup wait.
+  return EvaluateChain(num_rows, cols, num_cols, outs, num_outs, out_indices, max_slots, num_selected, mem, stream, count_out);
+}
+
+Status FilterProject::EvaluateChain(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs, int num_outs,
+                                    void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
+                                    hipStream_t stream, void* count_out) const {
+  // index width of the chain: the plan's own, or the narrowest that addresses the batch when it emits none
+  const SelectionMode mode = plan_.mode != SelectionMode::kNone ? plan_.mode
+                             : (num_rows <= (int64_t{1} << 32) ? SelectionMode::kUInt32 : SelectionMode::kUInt64);
+  const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
+  {
+    std::lock_guard<std::mutex> lock(chain_mu_);
+    if (chain_filter_ == nullptr) GDV_RETURN_NOT_OK(Filter::Make(schema_, condition_, Configuration{}, &chain_filter_));
+    if (chain_projector_ == nullptr || chain_projector_->plan().mode != mode)
+      GDV_RETURN_NOT_OK(Projector::Make(schema_, exprs_, mode, Configuration{}, &chain_projector_));
+  }
+  std::vector<char> host_idx;
+  DeviceBuffer dev_idx;
+  void* idx = out_indices;
+  if (plan_.mode == SelectionMode::kNone) {
+    if (mem == MemKind::kHost) {
+      host_idx.resize(static_cast<size_t>(num_rows) * w);
+      idx = host_idx.data();
+    } else {
+      GDV_RETURN_NOT_OK(dev_idx.Allocate(static_cast<size_t>(num_rows) * w));
+      idx = dev_idx.get();
+    }
+    max_slots = num_rows;
+  }
+  int64_t count = 0;
+  GDV_RETURN_NOT_OK(chain_filter_->Evaluate(num_rows, cols, num_cols, mode, idx, max_slots, &count, mem, stream, 0, count_out));
+  if (count > 0) {
+    SelectionView sel;
+    sel.mode = mode;
+    sel.indices = idx;
+    sel.num_slots = count;
+    // the projector sizes its checks for `count` rows; the caller's buffers hold num_rows
+    GDV_RETURN_NOT_OK(chain_projector_->Evaluate(num_rows, cols, num_cols, &sel, outs, num_outs, mem, stream, 0));
+  }
+  if (num_selected != nullptr) *num_selected = count;
+  return Status::OK();
+}
+
+Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs,
+                                    int num_outs, void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
+                                    hipStream_t stream, uint32_t flags, void* count_out, bool* stalled) const {
+  *stalled = false;
   if (num_rows < 0) return Status::Invalid("negative row count");
   if (num_outs != num_outputs() || (num_outs > 0 && outs == nullptr))
     return Status::Invalid("number of output buffers does not match the number of expressions");
@@ -1907,10 +1982,29 @@ Status FilterProject::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int 
   args.SetPtr(ArgLayout::kOffSel, dev_idx);
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
 
-  EvalTrace trace("filter-project", plan_.kernel_name, num_rows, stream);
-  GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+  // which shape: the windowed kernel unless recent batches selected more rows than its LDS window holds (the
+  // direct kernel takes the same argument block: PlanFilterProject checks that its literals and constants are a
+  // prefix of the windowed plan's)
+  const CompiledKernel* kernel = dev->kernel;
+  const KernelPlan* running = &plan_;
+  if (which_kernel() == 1 && !EngineKnobs::Get().fp_window_only) {
+    PlanDeviceState* d = const_cast<PlanDeviceState*>(dev);
+    if (d->kernel_exact.load() == nullptr) {
+      const CompiledKernel* k = nullptr;
+      GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->source, plan_.exact->kernel_name, &k));
+      d->kernel_exact.store(k);
+    }
+    kernel = dev->kernel_exact.load();
+    running = plan_.exact.get();
+  }
+  EvalTrace trace("filter-project", running->kernel_name, num_rows, stream);
+  GDV_RETURN_NOT_OK(rt.Launch(*kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
   const char* count_dev = base + state_b;
-  if (count_out != nullptr) GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(count_out, count_dev, 8, hipMemcpyDefault, stream));
+  // the count leaves through a one-thread kernel: -1 when the look-back gave up (GDV_ERR_STALL in the error word) —
+  // round 4 copied the word as it was and an asynchronous caller never learnt that the outputs were not complete
+  if (count_out != nullptr)
+    GDV_HIP_RETURN_NOT_OK(LaunchPublishCount(static_cast<int64_t*>(count_out), reinterpret_cast<const int64_t*>(count_dev),
+                                             reinterpret_cast<const uint32_t*>(base + state_b + 64), kErrStall, stream));
   if (async) {
     if (num_selected != nullptr) *num_selected = -1;
     scratch.release_after(stream);
@@ -1922,7 +2016,13 @@ Status FilterProject::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int 
   GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&count, count_dev, 8, hipMemcpyDeviceToHost, stream));
   GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, base + state_b + 64, 4, hipMemcpyDeviceToHost, stream));
   GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+  if ((err_bits & kErrStall) != 0 || EngineKnobs::Get().fp_force_stall) {
+    drain.armed = false;
+    *stalled = true;
+    return Status::OK();
+  }
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
+  selected_per_1024_.store(static_cast<int>(count * 1024 / num_rows), std::memory_order_relaxed);
   if (mem == MemKind::kHost && count > 0) {
     for (int e = 0; e < num_outs; e++) {
       const DataType& t = plan_.output_types[e];
@@ -1991,7 +2091,10 @@ Status PrecompileFilterProject(const Schema& schema, const ExpressionPtr& condit
   KernelPlan plan;
   GDV_RETURN_NOT_OK(PlanFilterProject(schema, condition, exprs, index_mode, CodegenOptions::FromEnv(), &plan));
   std::vector<char> code;
-  return Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code);
+  GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.source, plan.kernel_name, &code));
+  if (plan.exact)  // round 5: the direct kernel behind the windowed one
+    GDV_RETURN_NOT_OK(Runtime::Get().CompileToCodeObject(plan.exact->source, plan.exact->kernel_name, &code));
+  return Status::OK();
 }
 
 }  // namespace gdv

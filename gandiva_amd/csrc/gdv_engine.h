@@ -270,6 +270,9 @@ class FilterProject {
   // *num_selected = rows produced.  flags & kEvalAsync (device buffers): everything is enqueued, the
   // count lands in *count_out (8 bytes of device or pinned memory) in stream order, *num_selected = -1
   // and device-side errors (divide by zero ...) are NOT reported — plans that can raise wait anyway.
+  // Round 5: a launch whose look-back gave up leaves -1 in *count_out (the outputs are not complete: evaluate
+  // the batch with the synchronous call, which re-runs such a launch on the filter + projector chain).
+  // which_kernel(): 0 = the windowed kernel runs next, 1 = the direct one, -1 = the plan has one shape only.
   Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs, int num_outs,
                   void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem, hipStream_t stream,
                   uint32_t flags = 0, void* count_out = nullptr) const;
@@ -280,12 +283,31 @@ class FilterProject {
   const DataType& output_type(int i) const { return plan_.output_types[i]; }
   SelectionMode index_mode() const { return plan_.mode; }
   std::string DumpIR() const { return plan_.ir; }
+  int which_kernel() const;
 
  private:
+  // the kernel launch of one evaluation; *stalled = the look-back gave up (the outputs are not complete)
+  Status EvaluateFused(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs, int num_outs,
+                       void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem, hipStream_t stream,
+                       uint32_t flags, void* count_out, bool* stalled) const;
+  // Filter::Evaluate + selection-mode Projector::Evaluate over the same buffers: what a stalled fused launch is
+  // re-run on (round 5; both operators are built on first need)
+  Status EvaluateChain(int64_t num_rows, const ColumnBuffers* cols, int num_cols, OutputBuffers* outs, int num_outs,
+                       void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem, hipStream_t stream,
+                       void* count_out) const;
   Schema schema_;
+  ExpressionPtr condition_;
+  std::vector<ExpressionPtr> exprs_;
   KernelPlan plan_;
   bool raises_ = false;  // some expression can raise: asynchronous calls wait for the error word
   PlanDeviceStates states_;
+  // Round 5: plan_ is the WINDOWED kernel (selected rows staged in LDS, GDV_FP_CAP per wave tile) where that
+  // shape exists, plan_.exact the direct round-4 kernel.  Synchronous evaluations record the share of rows they
+  // selected (x 1024); once it is beyond what the window holds, the next batches run on the direct kernel.
+  mutable std::atomic<int> selected_per_1024_{-1};
+  mutable std::mutex chain_mu_;
+  mutable std::shared_ptr<Filter> chain_filter_;
+  mutable std::shared_ptr<Projector> chain_projector_;
 };
 
 // Builds the plan and compiles it to a gfx950 code object without touching a device

@@ -40,6 +40,12 @@ constexpr int kMaxStageOutputs = 8;
 struct StageCaps { int64_t cap[kMaxStageOutputs]; void* data[kMaxStageOutputs]; };
 hipError_t LaunchStageGate(const uint64_t* stage_result, int num_outputs, const StageCaps& caps, const int64_t* rows_in,
                            int64_t rows, int64_t* rows_out, uint64_t* status_out, hipStream_t stream);
+// result[0] = *err & ~clear: an asynchronous evaluation publishes its launch's error word WITHOUT the bits that are
+// notes to the host, not errors (the exact string kernels' "saw UTF-8", bit 64) — `0 = complete` is the contract
+hipError_t LaunchPublishStatus(uint64_t* result, const uint32_t* err, uint32_t clear, hipStream_t stream);
+// *dst = (*err & fatal) ? -1 : *count — the selected-row count of a fused filter-project launch as an asynchronous
+// caller sees it: negative when the launch did not complete (its look-back gave up)
+hipError_t LaunchPublishCount(int64_t* dst, const int64_t* count, const uint32_t* err, uint32_t fatal, hipStream_t stream);
 // result[0] |= *status
 hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream);
 

@@ -521,6 +521,21 @@ hipError_t LaunchStageGate(const uint64_t* stage_result, int num_outputs, const 
   hipLaunchKernelGGL(StageGate, dim3(1), dim3(64), 0, stream, stage_result, num_outputs, caps, rows_in, rows, rows_out, status_out);
   return hipGetLastError();
 }
+__global__ void PublishStatus(uint64_t* __restrict__ result, const uint32_t* __restrict__ err, uint32_t clear) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) result[0] = err[0] & ~clear;
+}
+hipError_t LaunchPublishStatus(uint64_t* result, const uint32_t* err, uint32_t clear, hipStream_t stream) {
+  hipLaunchKernelGGL(PublishStatus, dim3(1), dim3(64), 0, stream, result, err, clear);
+  return hipGetLastError();
+}
+__global__ void PublishCount(int64_t* __restrict__ dst, const int64_t* __restrict__ count, const uint32_t* __restrict__ err,
+                             uint32_t fatal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = (err[0] & fatal) != 0 ? int64_t{-1} : count[0];
+}
+hipError_t LaunchPublishCount(int64_t* dst, const int64_t* count, const uint32_t* err, uint32_t fatal, hipStream_t stream) {
+  hipLaunchKernelGGL(PublishCount, dim3(1), dim3(64), 0, stream, dst, count, err, fatal);
+  return hipGetLastError();
+}
 hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream) {
   hipLaunchKernelGGL(OrStatus, dim3(1), dim3(64), 0, stream, result, status);
   return hipGetLastError();

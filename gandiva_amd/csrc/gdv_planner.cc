@@ -36,6 +36,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.ablation = std::getenv("GDV_ABLATION") != nullptr;
   o.runtime_needles = std::getenv("GDV_RUNTIME_NEEDLES") != nullptr;
   o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
+  if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
   return o;
 }
 
@@ -43,7 +44,8 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "");
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") +
+         (fp_window_bytes != 6144 ? "fw" + std::to_string(fp_window_bytes) : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -2767,70 +2769,102 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
 // The result equals Filter::Evaluate + Projector::Evaluate(batch, selection_vector) bit for bit.
 // Fixed-width (and bool) outputs over fixed-width columns; anything else -> CodeGenError and the
 // callers chain the two operators as before.
-Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
-                         SelectionMode index_mode, const CodegenOptions& opts, KernelPlan* plan) {
+//
+// Round 5 — the WINDOWED shape (the default; the round-4 shape above stays as its `exact` variant for
+// batches that select most of their rows).  Round 4 held every loaded value in registers across the
+// look-back (111 VGPRs: two 8-wave workgroups per CU) and stored the selected rows from there — 8 of 64
+// lanes per store instruction at a selectivity of 1/8.  Now predicate and projections run in ONE loop
+// BEFORE the look-back and the selected rows' values (and row indices) are written, at their rank inside
+// the wave tile, to a wave-private LDS window of GDV_FP_CAP rows; validity / bool bits are accumulated at
+// wave-local bit positions.  Nothing wide is live across the barrier + look-back; afterwards the window
+// leaves with full-width stores at pos0 + i and the local bitmap words are shifted into place
+// (gdv_bits_flush_local).  A wave tile that selects more than GDV_FP_CAP rows re-reads the sub-tiles that
+// did not fit (rolled loop, from L2 / Infinity Cache) and stores those rows directly; the engine moves a
+// FilterProject whose batches select more than that to the direct kernel.
+namespace {
+enum class FpShape { kDirect, kWindow };
+
+Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
+                              SelectionMode index_mode, const CodegenOptions& opts, FpShape shape, KernelPlan* plan) {
   AblationScope ablation_scope(opts.ablation);
-  if (!condition) return Status::Invalid("Condition cannot be null");
-  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
-  GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
-  if (condition->root()->return_type().id != kBool)
-    return Status::ValidationError("Filter condition must be of type boolean");
-  for (auto& e : exprs) {
-    if (!e) return Status::Invalid("Expression cannot be null");
-    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
-    if (e->result().type.is_varlen())
-      return Status::CodeGenError("fused filter-project: var-len outputs take the filter + projector chain");
-  }
+  const bool win = shape == FpShape::kWindow;
   plan->kind = KernelKind::kFilterProject;
   plan->mode = index_mode;  // width of the emitted row indices; kNone: no SelectionVector output
   plan->opts = opts;
   CodeGen cg(schema, SelectionMode::kNone, opts);
-  // ---- phase 2: the predicate (row mode; a null predicate does not select the row)
+  // ---- the predicate (row mode; a null predicate does not select the row)
   Val c;
   cg.Stmt("// @expr_0 (filter condition)");
   GDV_RETURN_NOT_OK(cg.Gen(*condition->root(), "", &c));
   const std::string pass = CodeGen::AndExpr(cg.LaneValid(c), c.v);
   cg.Stmt("const gdv_uint64 fmw = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
+  if (win) cg.Stmt("const gdv_uint32 run = fcount;  // selected rows of this wave tile before this sub-tile");
   cg.Stmt("fcount += (gdv_uint32)__popcll(fmw);");
   cg.Stmt("fm = gdv_deposit_word(fm, u, fmw, lane);  // lane u keeps sub-tile u's match word (2 VGPRs, not 2 x GDV_U SGPRs)");
   const std::string cond_body = cg.body_.str();
-  // ---- phase 4: the projections.  Temporaries of the predicate loop are out of scope: common
-  // sub-expressions are shared among the projections only.
+  // ---- the projections.  Direct shape: a loop of its own after the look-back — the predicate's temporaries
+  // are out of scope, common sub-expressions are shared among the projections only.  Windowed shape: the same
+  // loop iteration as the predicate, and once more (values only) for the rows that did not fit the window.
   cg.body_.str("");
-  cg.cse_.clear();
+  if (!win) cg.cse_.clear();
   std::vector<std::string> strings{condition->ToString()};
   std::map<std::string, int> bitmap_of;   // compacted-word expression -> accumulator index
   std::vector<std::string> flushes;       // after the row loop: one per output bitmap
+  const std::string first_bit = win ? "0" : "pos0";
+  const std::string at_bit = win ? "(gdv_int64)run" : "pos0 + run";
+  const std::string flush_fn = win ? "gdv_bits_flush_local" : "gdv_bits_flush";
   auto bits_acc = [&](const std::string& word_expr) {
     auto it = bitmap_of.find(word_expr);
     if (it != bitmap_of.end()) return it->second;
     const int k = static_cast<int>(bitmap_of.size());
     bitmap_of[word_expr] = k;
-    cg.Stmt("bacc" + std::to_string(k) + " = gdv_bits_append(bacc" + std::to_string(k) + ", pos0, pos0 + run, gdv_compact_word(" +
-            word_expr + ", fmu, below, cnt, lane), cnt, lane);");
+    cg.Stmt("bacc" + std::to_string(k) + " = gdv_bits_append(bacc" + std::to_string(k) + ", " + first_bit + ", " + at_bit +
+            ", gdv_compact_word(" + word_expr + ", fmu, below, cnt, lane), cnt, lane);");
     return k;
   };
-  for (size_t e = 0; e < exprs.size(); e++) {
-    Val v;
-    cg.Stmt("// @expr_" + std::to_string(e + 1));
-    GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), "fsel", &v));
-    if (!v.pieces.empty() || v.opaque) return Status::CodeGenError("fused filter-project: materialised values take the chain");
-    const DataType& t = exprs[e]->result().type;
-    plan->output_types.push_back(t);
-    strings.push_back(exprs[e]->ToString());
-    const std::string E = std::to_string(e);
-    if (t.id == kBool) {
-      const int k = bits_acc("__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
-      flushes.push_back("  gdv_bits_flush((gdv_uint64*)A.out[" + E + "].data, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
-    } else {
-      cg.Stmt("if (fsel) out" + E + "[opos] = (" + t.CType() + ")" + v.v + ";");
+  // pass 0: the main projection body; pass 1 (windowed shape only): the values again, stored directly, for
+  // the rows beyond the window
+  std::string proj_body, tail_body;
+  int window_bytes_per_row = index_mode == SelectionMode::kUInt16 ? 2 : index_mode == SelectionMode::kUInt32 ? 4
+                             : index_mode == SelectionMode::kUInt64 ? 8 : 0;
+  for (int pass_no = 0; pass_no < (win ? 2 : 1); pass_no++) {
+    const bool tail = pass_no == 1;
+    if (tail) {
+      cg.body_.str("");
+      cg.cse_.clear();
     }
-    std::string word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
-    if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
-    const int k = bits_acc(word);
-    flushes.push_back("  gdv_bits_flush(A.out[" + E + "].valid, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
+    for (size_t e = 0; e < exprs.size(); e++) {
+      Val v;
+      cg.Stmt("// @expr_" + std::to_string(e + 1));
+      GDV_RETURN_NOT_OK(cg.Gen(*exprs[e]->root(), tail ? "ftail" : "fsel", &v));
+      if (!v.pieces.empty() || v.opaque) return Status::CodeGenError("fused filter-project: materialised values take the chain");
+      const DataType& t = exprs[e]->result().type;
+      const std::string E = std::to_string(e);
+      if (!tail) {
+        plan->output_types.push_back(t);
+        strings.push_back(exprs[e]->ToString());
+      }
+      if (t.id == kBool) {
+        if (!tail) {
+          const int k = bits_acc("__ballot(" + CodeGen::AndExpr("live", v.v) + ")");
+          flushes.push_back("  " + flush_fn + "((gdv_uint64*)A.out[" + E + "].data, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
+        }
+      } else if (tail) {
+        cg.Stmt("if (ftail) out" + E + "[opos] = (" + t.CType() + ")" + v.v + ";");
+      } else if (win) {
+        cg.Stmt("if (fwin) win" + E + "[slot] = (" + t.CType() + ")" + v.v + ";");
+        window_bytes_per_row += t.byte_width();
+      } else {
+        cg.Stmt("if (fsel) out" + E + "[opos] = (" + t.CType() + ")" + v.v + ";");
+      }
+      if (tail) continue;
+      std::string word = "(" + cg.WordExpr(v.vcols) + " & livemask)";
+      if (!v.vlane.empty()) word = "(" + word + " & __ballot(live && " + v.vlane + "))";
+      const int k = bits_acc(word);
+      flushes.push_back("  " + flush_fn + "(A.out[" + E + "].valid, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
+    }
+    (tail ? tail_body : proj_body) = cg.body_.str();
   }
-  const std::string proj_body = cg.body_.str();
   for (size_t k = 0; k < cg.input_fields_.size(); k++)
     if (schema[cg.input_fields_[k]].type.is_varlen())
       return Status::CodeGenError("fused filter-project: var-len columns take the filter + projector chain");
@@ -2857,13 +2891,29 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
   // 16 x 4: 4.45 / 4.10 ms with / without the selection vector, 16 x 8: 4.26 / 4.05, 16 x 16: 4.89 / 4.19,
   // 8 x 8: 4.58 / 4.40 — profiles/r04_filter_project.txt)
   if (!plan->opts.waves_forced) plan->opts.waves = 8;
+  // the window: GDV_FP_CAP rows per wave tile, every windowed output + the index at its own width; 6 KB per
+  // wave (48 KB per 8-wave workgroup: three workgroups per CU), at most half the wave tile's rows
+  int cap = 0;
+  if (win) {
+    if (window_bytes_per_row == 0) return Status::CodeGenError("fused filter-project: nothing to window (bitmap outputs only)");
+    const int rows_wave = 64 * plan->opts.subtiles;
+    cap = std::min(rows_wave / 2, opts.fp_window_bytes / window_bytes_per_row) / 64 * 64;
+    if (cap < 128) return Status::CodeGenError("fused filter-project: rows too wide for the LDS window");
+  }
 
   Assembler as{cg, plan, {}};
   as.Header(strings);
   std::ostringstream& s = as.src;
+  if (win) s << "#define GDV_FP_CAP " << cap << "  // rows of a wave tile's LDS window\n";
   s << "template <bool FULL>\n"
     << "GDV_DEV void gdv_fused_tile(const gdv_args& A, const gdv_int64 tile, const int lane, const int wave,\n"
-    << "                            gdv_uint32* wg_cnt, gdv_uint64* wg_excl) {\n"
+    << "                            gdv_uint32* wg_cnt, gdv_uint64* wg_excl";
+  if (win) {
+    for (size_t e = 0; e < plan->output_types.size(); e++)
+      if (plan->output_types[e].id != kBool) s << ", " << plan->output_types[e].CType() << "* win" << e;
+    if (index_mode != SelectionMode::kNone) s << ", " << SelCType(index_mode) << "* widx";
+  }
+  s << ") {\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
@@ -2915,13 +2965,28 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
       if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
     }
   };
-  s << "  // ---- phase 2: the predicate -> one match word per sub-tile\n"
+  s << "  // ---- phase 2: the predicate -> one match word per sub-tile"
+    << (win ? "; the projections of the selected rows -> the wave's LDS window, at their rank in the wave tile\n" : "\n")
     << "  gdv_uint64 fm = 0;\n"
-    << "  gdv_uint32 fcount = 0;\n"
-    << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
+    << "  gdv_uint32 fcount = 0;\n";
+  if (win)
+    for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;  // output bitmap words at wave-local bit positions\n";
+  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
   row_prologue();
-  s << "      const bool fsel = true;  // (the predicate itself runs on every live row)\n      (void)fsel;\n"
-    << cond_body << "    }\n  }\n"
+  if (!win) s << "      const bool fsel = true;  // (the predicate itself runs on every live row)\n      (void)fsel;\n";
+  s << cond_body;
+  if (win) {
+    s << "      const gdv_uint64 fmu = fmw;\n"
+      << "      const int cnt = (int)__popcll(fmu);\n"
+      << "      const bool fsel = (fmu >> lane) & 1;\n"
+      << "      const int below = gdv_rank_below(fmu);\n"
+      << "      const int slot = (int)run + below;  // this lane's rank among the wave tile's selected rows\n"
+      << "      const bool fwin = fsel && slot < GDV_FP_CAP;\n"
+      << "      (void)cnt; (void)below; (void)slot; (void)fwin;\n";
+    if (index_mode != SelectionMode::kNone) s << "      if (fwin) widx[slot] = (" << SelCType(index_mode) << ")row;\n";
+    s << proj_body;
+  }
+  s << "    }\n  }\n"
     << "  // ---- phase 3: output base of this wave: the workgroup's waves meet in LDS, wave 0 looks back\n"
     << "  if (lane == 0) wg_cnt[wave] = fcount;\n"
     << "  __syncthreads();\n"
@@ -2939,34 +3004,88 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
     << "    }\n"
     << "  }\n"
     << "  __syncthreads();\n"
-    << "  const gdv_int64 pos0 = (gdv_int64)*wg_excl + before;  // output position of this wave's first selected row\n"
-    << "  // ---- phase 4: the projections of the selected rows, stored compacted\n"
-    << "  gdv_int64 run = 0;\n";
-  for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;\n";
-  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
-  row_prologue();
-  s << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
-    << "      const int cnt = (int)__popcll(fmu);\n"
-    << "      const bool fsel = (fmu >> lane) & 1;\n"
-    << "      const int below = gdv_rank_below(fmu);\n"
-    << "      const gdv_int64 opos = pos0 + run + below;  // where this lane's row lands if it is selected\n"
-    << "      (void)opos; (void)cnt; (void)below;\n";
-  if (index_mode != SelectionMode::kNone)
-    s << "      if (fsel) selv[opos] = (" << SelCType(index_mode) << ")row;\n";
-  s << proj_body
-    << "      run += cnt;\n"
-    << "    }\n  }\n";
+    << "  const gdv_int64 pos0 = (gdv_int64)*wg_excl + before;  // output position of this wave's first selected row\n";
+  if (win) {
+    const std::string st = plan->opts.nontemporal ? "gdv_stnt" : "gdv_st";
+    s << "  // ---- phase 4: the window leaves with full-width stores (lane i -> output position pos0 + i)\n"
+      << "  const int in_window = (int)(fcount < (gdv_uint32)GDV_FP_CAP ? fcount : (gdv_uint32)GDV_FP_CAP);\n"
+      << "  for (int i = lane; i < in_window; i += 64) {\n";
+    for (size_t e = 0; e < plan->output_types.size(); e++)
+      if (plan->output_types[e].id != kBool) s << "    " << st << "(out" << e << ", pos0 + i, win" << e << "[i]);\n";
+    if (index_mode != SelectionMode::kNone) s << "    " << st << "(selv, pos0 + i, widx[i]);\n";
+    s << "  }\n"
+      << "  // ---- rows beyond the window (a wave tile that selected more than GDV_FP_CAP rows): their sub-tiles are read\n"
+      << "  //      again, one at a time, and the values stored directly\n"
+      << "  if (fcount > (gdv_uint32)GDV_FP_CAP) {\n"
+      << "    gdv_uint32 run = 0;\n"
+      << "#pragma unroll 1\n    for (int u = 0; u < GDV_U; u++) {\n"
+      << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
+      << "      const int cnt = (int)__popcll(fmu);\n"
+      << "      if (run + (gdv_uint32)cnt > (gdv_uint32)GDV_FP_CAP) {\n";
+    // (indentation of the generated body is that of the unrolled loops; harmless)
+    s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "      const bool live = FULL || row < n;\n"
+      << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
+      << "      (void)livemask; (void)row; (void)live;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = schema[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+      if (t.id != kBool && cg.needs_values_[k])
+        s << "      const gdv_one<" << t.CType() << "> c" << k << "{live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0};  // (shadows the tile's registers)\n";
+    }
+    s << "      const bool fsel = (fmu >> lane) & 1;\n"
+      << "      const int below = gdv_rank_below(fmu);\n"
+      << "      const int slot = (int)run + below;\n"
+      << "      const bool ftail = fsel && slot >= GDV_FP_CAP;\n"
+      << "      const gdv_int64 opos = pos0 + slot;\n"
+      << "      (void)opos; (void)below; (void)ftail;\n";
+    if (index_mode != SelectionMode::kNone) s << "      if (ftail) selv[opos] = (" << SelCType(index_mode) << ")row;\n";
+    s << tail_body
+      << "      }\n"
+      << "      run += (gdv_uint32)cnt;\n"
+      << "    }\n  }\n";
+  } else {
+    s << "  // ---- phase 4: the projections of the selected rows, stored compacted\n"
+      << "  gdv_int64 run = 0;\n";
+    for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;\n";
+    s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
+    row_prologue();
+    s << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
+      << "      const int cnt = (int)__popcll(fmu);\n"
+      << "      const bool fsel = (fmu >> lane) & 1;\n"
+      << "      const int below = gdv_rank_below(fmu);\n"
+      << "      const gdv_int64 opos = pos0 + run + below;  // where this lane's row lands if it is selected\n"
+      << "      (void)opos; (void)cnt; (void)below;\n";
+    if (index_mode != SelectionMode::kNone)
+      s << "      if (fsel) selv[opos] = (" << SelCType(index_mode) << ")row;\n";
+    s << proj_body
+      << "      run += cnt;\n"
+      << "    }\n  }\n";
+  }
   for (auto& f : flushes) s << f;
   s << "}\n\n"
     << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
     << "  __shared__ gdv_uint32 wg_cnt[GDV_WAVES];\n"
-    << "  __shared__ gdv_uint64 wg_excl;\n"
-    << "  const int lane = threadIdx.x & 63;\n"
+    << "  __shared__ gdv_uint64 wg_excl;\n";
+  std::string win_args;
+  if (win) {
+    for (size_t e = 0; e < plan->output_types.size(); e++)
+      if (plan->output_types[e].id != kBool) {
+        s << "  __shared__ " << plan->output_types[e].CType() << " win" << e << "[GDV_WAVES * GDV_FP_CAP];\n";
+        win_args += ", win" + std::to_string(e) + " + wave * GDV_FP_CAP";
+      }
+    if (index_mode != SelectionMode::kNone) {
+      s << "  __shared__ " << SelCType(index_mode) << " widx[GDV_WAVES * GDV_FP_CAP];\n";
+      win_args += ", widx + wave * GDV_FP_CAP";
+    }
+  }
+  s << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
     << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_U x 64 rows; index order = row order\n"
     << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
-    << "  if ((tile + 1) * (GDV_WAVES * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true>(A, tile, lane, wave, wg_cnt, &wg_excl);\n"
-    << "  else gdv_fused_tile<false>(A, tile, lane, wave, wg_cnt, &wg_excl);\n"
+    << "  if ((tile + 1) * (GDV_WAVES * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+    << "  else gdv_fused_tile<false>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
     << "}\n";
   std::string text = s.str();
   uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
@@ -2977,6 +3096,46 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
     text.replace(pos, strlen("GDV_KERNEL_NAME"), plan->kernel_name);
   plan->source = text;
   plan->ir = text;
+  plan->fp_window_rows = cap;
+  return Status::OK();
+}
+}  // namespace
+
+Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
+                         SelectionMode index_mode, const CodegenOptions& opts, KernelPlan* plan) {
+  if (!condition) return Status::Invalid("Condition cannot be null");
+  if (exprs.empty()) return Status::Invalid("Expressions cannot be empty");
+  GDV_RETURN_NOT_OK(ValidateExpression(schema, *condition));
+  if (condition->root()->return_type().id != kBool)
+    return Status::ValidationError("Filter condition must be of type boolean");
+  for (auto& e : exprs) {
+    if (!e) return Status::Invalid("Expression cannot be null");
+    GDV_RETURN_NOT_OK(ValidateExpression(schema, *e));
+    if (e->result().type.is_varlen())
+      return Status::CodeGenError("fused filter-project: var-len outputs take the filter + projector chain");
+  }
+  // the direct shape always exists; the windowed one is the main kernel wherever its window fits
+  auto direct = std::make_shared<KernelPlan>();
+  GDV_RETURN_NOT_OK(PlanFilterProjectShape(schema, condition, exprs, index_mode, opts, FpShape::kDirect, direct.get()));
+  if (opts.fp_window_bytes > 0) {
+    KernelPlan windowed;
+    Status st = PlanFilterProjectShape(schema, condition, exprs, index_mode, opts, FpShape::kWindow, &windowed);
+    // the engine launches either kernel with the windowed plan's argument block: the direct plan's literals and
+    // constant block must be a prefix of it (they are: the windowed body generates the same trees first, then the
+    // tail's copies) — if that ever stops holding, the plan keeps the direct shape alone
+    const bool prefix = st.ok() && direct->literals.size() <= windowed.literals.size() &&
+                        std::equal(direct->literals.begin(), direct->literals.end(), windowed.literals.begin()) &&
+                        windowed.const_block.compare(0, direct->const_block.size(), direct->const_block) == 0 &&
+                        direct->input_fields == windowed.input_fields && direct->opts.subtiles == windowed.opts.subtiles &&
+                        direct->opts.waves == windowed.opts.waves;
+    if (st.ok() && prefix) {
+      *plan = std::move(windowed);
+      plan->exact = direct;
+      return Status::OK();
+    }
+    if (!st.ok() && st.code != kCodeGenError) return st;
+  }
+  *plan = std::move(*direct);
   return Status::OK();
 }
 

@@ -47,6 +47,9 @@ struct CodegenOptions {
   // count from the device word aux2 points at when there is one — an asynchronous evaluation's gate writes 0
   // there when the first stage did not complete, and the second stage then touches nothing.
   bool rows_word = false;
+  // Fused filter-project, windowed shape (round 5): bytes of LDS window per wave tile (every windowed output + the
+  // row index, GDV_FP_CAP rows of them); 0 = the direct round-4 shape only.  GDV_FP_WINDOW=<bytes>.
+  int fp_window_bytes = 6144;
   bool runtime_needles = false;        // GDV_RUNTIME_NEEDLES=1: wave kernels load their '%needle%' bytes instead of carrying them as immediates
   static CodegenOptions FromEnv();
   std::string Key() const;
@@ -110,6 +113,7 @@ struct KernelPlan {
   std::shared_ptr<KernelPlan> exact;
   std::shared_ptr<KernelPlan> prepass;
   std::vector<int> wave_segments;
+  int fp_window_rows = 0;  // fused filter-project, windowed shape: GDV_FP_CAP (0: the direct shape); `exact` = the direct shape
   int general_subtiles = 0, general_waves = 0;  // tile of the scanner-shaped fallback (0: opts')
   int rows_per_tile() const { return 64 * opts.subtiles * (wave_tiles ? 1 : opts.waves); }
 };

@@ -828,10 +828,26 @@ Status FilterProject::Evaluate(const arrow::RecordBatch& batch, arrow::MemoryPoo
     if (out_selection->GetMaxSlots() < batch.num_rows())
       return Status::Invalid("Selection vector too small: max slots ", out_selection->GetMaxSlots(), " < number of rows ",
                              batch.num_rows());
+  } else if (out_selection) {
+    // MODE_NONE promises no selection vector: the fused kernel writes no index, and round 4 still set the
+    // vector's slot count (uninitialised indices) while the chain below filled it — refused, both ways
+    return Status::Invalid("FilterProject was made with MODE_NONE: it fills no selection vector");
   }
   if (handle_ == nullptr) {  // the chain
     std::shared_ptr<SelectionVector> sv = out_selection;
-    if (!sv) ARROW_RETURN_NOT_OK(SelectionVector::MakeInt32(batch.num_rows(), pool, &sv));
+    if (!sv) {
+      // the temporary lives where the batch does (a CPU vector under HBM-resident columns is refused by Filter)
+      std::vector<gdv_column_t> probe;
+      bool on_device = false;
+      std::shared_ptr<arrow::MemoryManager> bmm;
+      ARROW_RETURN_NOT_OK(MarshalBatch(batch, schema_, &probe, &on_device, &bmm));
+      if (on_device) {
+        ARROW_ASSIGN_OR_RAISE(auto ibuf, AllocOut(batch.num_rows() * 4, true, pool, bmm));
+        ARROW_RETURN_NOT_OK(SelectionVector::Make(SelectionVector::MODE_UINT32, batch.num_rows(), ibuf, &sv));
+      } else {
+        ARROW_RETURN_NOT_OK(SelectionVector::MakeInt32(batch.num_rows(), pool, &sv));
+      }
+    }
     ARROW_RETURN_NOT_OK(filter_->Evaluate(batch, sv));
     return projector_->Evaluate(batch, sv.get(), pool, output);
   }

@@ -328,6 +328,10 @@ int main(int argc, char** argv) {
     ArrayVector out0;
     CHECK_OK(fp0->Evaluate(*batch, pool, &out0));
     CHECK(out0.size() == 1 && out0[0]->Equals(out[0]));
+    {  // MODE_NONE fills no selection vector: handing one in is refused (round 4 set its slot count over garbage)
+      ArrayVector outx;
+      CHECK(!fp0->Evaluate(*batch, pool, &outx, sel).ok());
+    }
     auto cs = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeFunction("castVARCHAR", {na, TreeExprBuilder::MakeLiteral(int64_t(10))}, arrow::utf8()),
                                               arrow::field("t", arrow::utf8()));
     std::shared_ptr<FilterProject> fpc;

@@ -1035,6 +1035,12 @@ class FilterProject:
             return self._chain[0].llvm_ir + self._chain[1].llvm_ir
         return _capi.take_string(_capi.lib().gdv_filter_project_dump_ir(self._h))
 
+    @property
+    def kernel_shape(self):
+        """0: the windowed kernel runs next (selected rows staged in LDS); 1: the direct one (recent batches selected
+        more rows than the window holds); -1: the plan has one shape only, or is a chain."""
+        return -1 if self._h is None else _capi.lib().gdv_filter_project_kernel_shape(self._h)
+
     def evaluate(self, batch):
         """Host buffers in, host pyarrow arrays out: ``(arrays, selection_vector or None)``."""
         _check_batch(batch, self._schema)

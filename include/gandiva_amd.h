@@ -361,6 +361,16 @@ int gdv_filter_project_evaluate(const gdv_filter_project_t* fp, int64_t num_rows
                                 int64_t max_slots, int64_t* num_selected, void* num_selected_device /* may be NULL */,
                                 int mem_kind, void* stream, uint32_t flags);
 char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp);
+/* Round 5.  The fused plan has two kernels: the WINDOWED one (selected rows are staged, at their rank, in a
+ * wave-private LDS window and leave with full-width stores once the look-back has returned the output base) and
+ * the DIRECT one of round 4 (values held in registers across the look-back, stored from there).  Synchronous
+ * evaluations record the share of rows they selected; beyond what the window holds the next batches run on the
+ * direct kernel, and come back when the share drops.  Returns 0 = windowed next, 1 = direct next, -1 = the plan has
+ * one shape only (rows too wide for the window).
+ * A launch whose look-back gives up (GDV_ERR_STALL: 5 s without progress) is re-run inside evaluate on the
+ * filter + selection-mode projector chain (round 4: ExecutionError); under GDV_EVAL_ASYNC *num_selected_device
+ * then receives -1 — evaluate the batch with the synchronous call. */
+int gdv_filter_project_kernel_shape(const gdv_filter_project_t* fp);
 void gdv_filter_project_free(gdv_filter_project_t* fp);
 
 /* ---- function registry ------------------------------------------------------------ */

@@ -261,3 +261,93 @@ def test_fuzzed_trees_through_the_fused_operator_match_the_oracle_chain(seed):
     want = oracle.project(exprs, batch)
     for g, w, e in zip(got, want, exprs):
         assert_bit_exact(g, oracle.take_rows(w, want_sel.to_numpy()), f"seed {seed}: {e}")
+
+
+# ------------------------------------------------------------------------------------------ round 5: the windowed shape
+
+def test_the_plan_carries_both_shapes_and_the_direct_one_takes_the_windowed_argument_block(monkeypatch, tmp_path):
+    """PlanFilterProject: the windowed kernel (GDV_FP_CAP rows of LDS window per wave tile) is the plan, the direct
+    round-4 kernel its `exact` variant; rows too wide for the window, or a plan without any windowed output, keep
+    the direct shape alone.  (CPU: both are planned and compiled for gfx950.)"""
+    from test_planner_cpu import _precompile_fp
+    batch = _batch(np.random.default_rng(0), 100, 0.1)
+    cond, exprs = _plan(batch.schema, 500)
+    files = _precompile_fp(monkeypatch, tmp_path / "a", batch.schema, cond, exprs, 2)
+    texts = [open(tmp_path / "a" / f).read() for f in files]
+    win = [t for t in texts if "GDV_FP_CAP" in t]
+    assert len(win) == 1 and len(texts) == 2, files
+    assert "#define GDV_FP_CAP 192" in win[0]            # 6144 bytes / (8 + 8 + 8 + 4 + 4 bytes per row) -> 192 rows
+    assert "gdv_bits_flush_local(" in win[0] and "gdv_one<" in win[0] and "win0[slot]" in win[0]
+    direct = [t for t in texts if "GDV_FP_CAP" not in t][0]
+    assert "gdv_bits_flush(" in direct and "out0[opos]" in direct
+    # bool outputs only + no selection vector: nothing to window
+    files = _precompile_fp(monkeypatch, tmp_path / "b", batch.schema, cond, exprs[2:3], 0)
+    assert len(files) == 1 and "GDV_FP_CAP" not in open(tmp_path / "b" / files[0]).read()
+    # GDV_FP_WINDOW=0: the direct shape alone
+    monkeypatch.setenv("GDV_FP_WINDOW", "0")
+    files = _precompile_fp(monkeypatch, tmp_path / "c", batch.schema, cond, exprs, 2)
+    assert len(files) == 1 and "GDV_FP_CAP" not in open(tmp_path / "c" / files[0]).read()
+
+
+@pytest.mark.gpu
+def test_the_kernel_follows_the_selectivity_of_recent_batches():
+    """First batch: the windowed kernel whatever it selects (rows beyond the window take its re-read path — still
+    bit-exact).  A synchronous evaluation that selected more than the window holds moves the next batches to the
+    direct kernel; a sparse batch brings them back."""
+    n = 90_001
+    rng = np.random.default_rng(77)
+    batch = _batch(rng, n, 0.1)
+    bld = gandiva.TreeExprBuilder()
+    results = {}
+    for thr in (-1, 930):            # every valid row / ~7 %
+        cond, exprs = _plan(batch.schema, thr)
+        results[thr] = (cond, exprs, *_chain(cond, exprs, batch, "int32"))
+    # one FilterProject per threshold would never change shape: build ONE whose threshold is a column
+    thr_col = pa.array(np.full(n, 0, np.int64))
+    sch = batch.schema.append(pa.field("t", I64))
+    fa, ft = bld.make_field(sch.field(0)), bld.make_field(sch.field(5))
+    cond = bld.make_condition(bld.make_function("greater_than", [fa, ft], BOOL))
+    _, exprs = _plan(sch, 0)
+    fp = gandiva.make_filter_project(sch, cond, exprs, "int32")
+    assert fp.fused and fp.kernel_shape == 0
+    shapes = []
+    for thr in (-1, -1, 930, 930, -1):
+        b2 = pa.RecordBatch.from_arrays(batch.columns + [pa.array(np.full(n, thr, np.int64))], schema=sch)
+        shapes.append(fp.kernel_shape)
+        got, sel = fp.evaluate(b2)
+        want_sel, want = _chain(cond, exprs, b2, "int32")
+        assert sel.to_array().equals(want_sel), thr
+        for e, (g, w) in enumerate(zip(got, want)):
+            assert_bit_exact(g, w, f"threshold {thr}, expression {e}, kernel shape {shapes[-1]}")
+    assert shapes == [0, 1, 1, 0, 0], shapes
+
+
+@pytest.mark.gpu
+def test_a_stalled_launch_is_re_run_on_the_chain():
+    """GDV_FP_FORCE_STALL=1 (read once per process: a subprocess) makes the engine treat every fused launch as one
+    whose look-back gave up; evaluate then answers through Filter + selection-mode Projector — same results, no
+    ExecutionError (round 4 returned "device scan stalled")."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, pyarrow as pa
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import gandiva_amd as gandiva
+        from oracle import oracle
+        import test_filter_project as T
+        from helpers import assert_bit_exact
+        batch = T._batch(np.random.default_rng(5), 33_333, 0.1)
+        cond, exprs = T._plan(batch.schema, 700)
+        for dtype in ("int32", None):
+            fp = gandiva.make_filter_project(batch.schema, cond, exprs[:3] + exprs[4:], dtype)
+            assert fp.fused
+            got, sel = fp.evaluate(batch)
+            want_sel, want = T._chain(cond, exprs[:3] + exprs[4:], batch, dtype)
+            if dtype: assert sel.to_array().equals(want_sel)
+            for g, w in zip(got, want): assert_bit_exact(g, w)
+            dgot, dsel = fp.evaluate_device(gandiva.DeviceBatch.from_arrow(batch))
+            for g, w in zip(dgot, want): assert_bit_exact(g.to_arrow(), w)
+        print("chain ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GDV_FP_FORCE_STALL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "chain ok" in r.stdout, r.stdout + r.stderr

@@ -29,6 +29,23 @@ def _precompile(monkeypatch, tmp_path, schema, exprs=None, cond=None):
     return sorted(f for f in os.listdir(tmp_path) if f.endswith(".hip"))
 
 
+def _precompile_fp(monkeypatch, tmp_path, schema, cond, exprs, mode):
+    """the fused filter-project plan: every kernel it holds is compiled (the windowed shape AND its direct variant)"""
+    tmp_path.mkdir(parents=True, exist_ok=True)
+    monkeypatch.setenv("GDV_NO_DISK_CACHE", "1")
+    monkeypatch.setenv("GDV_DUMP_SOURCE", "1")
+    monkeypatch.setenv("GANDIVA_AMD_CACHE_DIR", str(tmp_path))
+    lib = _capi.lib()
+    sh = gg._make_schema(schema)
+    try:
+        arr = (C.c_void_p * len(exprs))(*[e._h for e in exprs])
+        rc = lib.gdv_precompile_filter_project(sh, cond._h, arr, len(exprs), mode)
+        assert rc == 0, _capi.last_error()
+    finally:
+        lib.gdv_schema_free(sh)
+    return sorted(f for f in os.listdir(tmp_path) if f.endswith(".hip"))
+
+
 def test_plans_that_differ_only_in_constants_share_one_kernel(monkeypatch, tmp_path):
     """Fixed-width literals, IN values and LIKE needles are kernel arguments / constant-block
     bytes: two filters with different constants must generate the SAME source (same kernel name);

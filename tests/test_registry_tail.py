@@ -134,7 +134,13 @@ def instants(seed, n=4000):
 def independent_answer(unit, ms):
     """pyarrow.compute where it has the operation, the calendar by hand elsewhere."""
     arr = pa.array(ms, pa.timestamp("ms"))
-    if unit in ("Second", "Minute", "Hour", "Day", "Month", "Quarter", "Year"):
+    if unit in ("Second", "Minute", "Hour", "Day"):
+        # upstream's DATE_TRUNC_FIXED_UNIT is (millis / N) * N with C++ division: towards ZERO, so instants before
+        # 1970 go up.  pyarrow floors; mirrored around zero it is the same rule.
+        up = -pc.floor_temporal(pa.array(-ms, pa.timestamp("ms")), unit=unit.lower()).cast(pa.int64()).to_numpy()
+        down = pc.floor_temporal(arr, unit=unit.lower()).cast(pa.int64()).to_numpy()
+        return np.where(ms < 0, up, down)
+    if unit in ("Month", "Quarter", "Year"):
         return pc.floor_temporal(arr, unit=unit.lower()).cast(pa.int64()).to_numpy()
     if unit == "Week":
         return pc.floor_temporal(arr, unit="week", week_starts_monday=True).cast(pa.int64()).to_numpy()
@@ -145,7 +151,7 @@ def independent_answer(unit, ms):
         months = pc.month(arr).to_numpy()
         nxt = np.array([np.datetime64(f"{y + (m == 12):04d}-{m % 12 + 1:02d}-01", "D") for y, m in zip(years, months)])
         return (nxt - np.timedelta64(1, "D")).astype("datetime64[ms]").astype(np.int64)
-    start = {"Decade": years // 10 * 10, "Century": (years - 1) // 100 * 100 + 1, "Millennium": (years - 1) // 1000 * 1000 + 1}[unit]
+    start = {"Decade": (years - 1) // 10 * 10 + 1, "Century": (years - 1) // 100 * 100 + 1, "Millennium": (years - 1) // 1000 * 1000 + 1}[unit]
     return np.array([np.datetime64(f"{y:04d}-01-01", "ms") for y in start]).astype(np.int64)
 
 

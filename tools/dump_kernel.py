@@ -21,7 +21,12 @@ def plan_source(which):
     lib = _capi.lib()
     d = tempfile.mkdtemp()
     os.environ["GANDIVA_AMD_CACHE_DIR"] = d
-    if which == "c3":
+    if which == "fp":   # the fused filter -> project kernel (C3's condition, a + b, uint32 selection vector)
+        sh = gg._make_schema(W.c3_schema())
+        cond, ex = W.c3_condition(), W.c3_sum_expression()
+        arr = (C.c_void_p * len(ex))(*[e._h for e in ex])
+        rc = lib.gdv_precompile_filter_project(sh, cond._h, arr, len(ex), int(os.environ.get("FP_MODE", "2")))
+    elif which == "c3":
         sh = gg._make_schema(W.c3_schema())
         cond = W.c3_condition()
         rc = lib.gdv_precompile_filter(sh, cond._h)
