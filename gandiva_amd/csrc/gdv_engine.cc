@@ -70,6 +70,7 @@ class ArgBlock {
  public:
   explicit ArgBlock(const ArgLayout& l) : layout_(l), buf_(l.total(), 0) {}
   void Set64(int off, uint64_t v) { std::memcpy(&buf_[off], &v, 8); }
+  uint64_t Get64(int off) const { uint64_t v; std::memcpy(&v, &buf_[off], 8); return v; }
   void SetPtr(int off, const void* p) { Set64(off, reinterpret_cast<uint64_t>(p)); }
   void SetInData(int k, const void* p) { SetPtr(layout_.in_base() + k * ArgLayout::kInStride, p); }
   void SetInValid(int k, const HostBitmap& b) {
@@ -918,6 +919,9 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
           pargs->SetPtr(ArgLayout::kOffErr, wave_head.get());
           pargs->SetPtr(ArgLayout::kOffCounts, wave_counts.get());
           pargs->Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
+          // selection mode (round 5): the pre-pass walks the same slots — the (staged) selection vector, the rows word
+          pargs->Set64(ArgLayout::kOffSel, args.Get64(ArgLayout::kOffSel));
+          pargs->Set64(ArgLayout::kOffAux2, args.Get64(ArgLayout::kOffAux2));
         }
       }
       char* const head = wave_head.as<char>();
@@ -1361,7 +1365,8 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
       GDV_RETURN_NOT_OK(wave_bases.Allocate(static_cast<size_t>(nseg * seg_stride) * 8));
       GDV_RETURN_NOT_OK(wave_chunks.Allocate(static_cast<size_t>(nseg * ScanChunks(nwt)) * 8));
       // a second stage whose gate is closed walks 0 rows: its pre-pass writes no count, the scan must still see zeros
-      if (rows_word != nullptr)
+      // (the same for a selection whose slot count sits in device memory: wave tiles past it write no count)
+      if (rows_word != nullptr || (has_sel && sel->num_slots_device != nullptr))
         GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(wave_counts.get(), 0, static_cast<size_t>(nseg * seg_stride) * 4 + 64, stream));
       args.SetPtr(ArgLayout::kOffMask, wave_bases.get());
       ArgBlock pargs(pp->layout);
@@ -1377,7 +1382,8 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
       pargs.SetPtr(ArgLayout::kOffErr, head);
       pargs.SetPtr(ArgLayout::kOffCounts, wave_counts.get());
       pargs.Set64(ArgLayout::kOffAux1, static_cast<uint64_t>(seg_stride));
-      if (rows_word != nullptr) pargs.SetPtr(ArgLayout::kOffAux2, rows_word);  // (the pre-pass walks the same rows as the main kernel)
+      pargs.Set64(ArgLayout::kOffSel, args.Get64(ArgLayout::kOffSel));    // (the pre-pass walks the same rows / slots as the main kernel)
+      pargs.Set64(ArgLayout::kOffAux2, args.Get64(ArgLayout::kOffAux2));
       GDV_RETURN_NOT_OK(rt.Launch(*k_pre, std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * 16),
                                   plan_.opts.waves * 64, pargs.data(), pargs.size(), stream));
       int32_t* closing[kMaxScanSegments] = {};

@@ -36,6 +36,8 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.ablation = std::getenv("GDV_ABLATION") != nullptr;
   o.runtime_needles = std::getenv("GDV_RUNTIME_NEEDLES") != nullptr;
   o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
+  o.no_sel_wave = std::getenv("GDV_NO_SEL_WAVE") != nullptr;
+  if (const char* s = std::getenv("GDV_FP_EXPERIMENT")) o.fp_experiment = atoi(s);
   if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
   return o;
 }
@@ -44,7 +46,7 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") +
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") +
          (fp_window_bytes != 6144 ? "fw" + std::to_string(fp_window_bytes) : "");
 }
 
@@ -1332,7 +1334,8 @@ void EmitStringPointersAndLoads(std::ostringstream& s, CodeGen& cg, KernelPlan* 
     } else if (t.is_varlen()) {
       if (cg.needs_values_[k]) {
         // (wave shape: only the start offsets are loaded; a row's end is the next lane's start)
-        if (wave_shape) s << "  gdv_int32 oa" << k << "[GDV_U];\n";
+        // (... of a CONTIGUOUS run of rows: under a selection vector both ends are gathered)
+        if (wave_shape && !sel) s << "  gdv_int32 oa" << k << "[GDV_U];\n";
         else s << "  gdv_int32 oa" << k << "[GDV_U], ob" << k << "[GDV_U];\n";
       }
     } else if (cg.needs_values_[k]) {
@@ -1402,7 +1405,7 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
     if (t.id == kBool) {
       if (cg.needs_values_[k] && sel) s << "      const bool x" << k << "_u = x" << k << "[0];\n";
     } else if (t.is_varlen()) {
-      if (cg.needs_values_[k] && wave_shape)
+      if (cg.needs_values_[k] && wave_shape && !sel)
         s << "      const gdv_int32 oa" << k << "_u = oa" << k << "[0];\n"
           << "      const gdv_int32 ob" << k << "_u = gdv_next_lane_i32(oa" << k << "_u, u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa"
           << k << "[GDV_U > 1 ? 1 : 0]) : sp1" << k << ", lane);\n";
@@ -1439,7 +1442,7 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
     if (t.id == kBool) {
       if (cg.needs_values_[k] && sel) s << "    gdv_rot(x" << k << ");\n";
     } else if (t.is_varlen()) {
-      if (cg.needs_values_[k]) s << "    gdv_rot(oa" << k << ");" << (wave_shape ? "" : " gdv_rot(ob" + std::to_string(k) + ");") << "\n";
+      if (cg.needs_values_[k]) s << "    gdv_rot(oa" << k << ");" << (wave_shape && !sel ? "" : " gdv_rot(ob" + std::to_string(k) + ");") << "\n";
     } else if (cg.needs_values_[k]) {
       s << "    gdv_rot(c" << k << ");\n";
     }
@@ -1763,6 +1766,12 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
     for (auto& vo : cg.varlen_outs_)
       if (vo.flat_slot == k) flats.push_back(&vo);
     const std::string K = std::to_string(k);
+    if (cg.selection()) {
+      // selected rows are not one span of bytes: nothing to sweep, no tile-wide fact about them — every row
+      // function takes its general (UTF-8-exact, range-checked) path, as in the scanner-shaped kernel
+      s << "  const gdv_int32 sfl" << K << " = 0;\n";
+      continue;
+    }
     // the span's ends come from two scalar loads (the sweep does not wait for the offsets' vector
     // loads); one wave-uniform range test per tile makes every 8-byte read of these rows unchecked
     s << "  const gdv_int32 sp0" << K << " = so" << K << "[rbase];\n"
@@ -2085,7 +2094,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   for (auto& vo : cg.varlen_outs_) plan->has_flat_output |= vo.flat_slot >= 0;
   const int nin = plan->layout.n_in;
   const int mirror_slot = cg.mirror_slot_;  // (decided with the tile shape, PlanProjectorShape)
-  if (prepass && mirror_slot < 0 && !cg.exact_ascii_ && !plan->opts.prepass_rolled)
+  if (prepass && mirror_slot < 0 && !cg.exact_ascii_ && !plan->opts.prepass_rolled && !cg.selection())
     // optimistic pre-pass without a sweep: the body is a few integer operations per row (every general
     // UTF-8 path folds away under the compile-time ASCII flag) — unrolled, the eight sub-tiles' offsets
     // are consumed from their registers without the rotation of the rolled loop
@@ -2098,6 +2107,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
                                             : "pre-pass: byte totals per wave tile from the offsets alone (optimistic ASCII)")
                          : (cg.exact_ascii_ ? "wave shape, exact variant: ASCII flags per (sub-)tile from the byte sweep"
                                             : "wave shape: independent wave tiles, output bases from the pre-pass + scan"))
+    << (cg.selection() ? " (rows = the slots of a selection vector: gathered, no byte sweep)" : "")
     << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
     << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
     << (mirror_slot >= 0 || (prepass && ncb > 0) ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
@@ -2131,6 +2141,14 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     << "  const gdv_int64 n = GDV_ROWS(A);\n"
     << "  const gdv_int64 wbase = wt * GDV_U;\n"
     << "  const gdv_int64 rbase = wbase * 64;\n"
+    << (cg.selection() && !prepass ? [&] {
+         // an EMPTY selection whose count sits in device memory still launches: offsets[0] = 0 is then nobody's row
+         std::string z;
+         for (size_t e = 0; e < plan->output_types.size(); e++)
+           if (plan->output_types[e].is_varlen())
+             z += "  if (n <= 0 && wt == 0 && lane == 0) A.out[" + std::to_string(e) + "].offsets[0] = 0;\n";
+         return z;
+       }() : std::string())
     << "  if (rbase >= n) return;  // (no barrier anywhere below: waves are independent)\n"
     << "  const bool last_tile = rbase + 64 * GDV_U >= n;  // the wave tile that holds the batch's last row\n"
     << "  const gdv_int64 seg_stride = A.aux1;  // wave-tile totals / bases: one array of seg_stride entries per scanned output\n"
@@ -2145,6 +2163,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (!(t.is_varlen() && cg.needs_values_[k])) continue;
+      if (cg.selection()) {  // (gathered rows: general row functions, the lengths are exact by construction)
+        s << "  const gdv_int32 sfl" << k << " = 0;\n";
+        continue;
+      }
       s << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n";
       if (cg.exact_ascii_ && cg.ascii_slots_.count(k)) {
         // exact variant: the lengths depend on the bytes now — the pre-pass sweeps every sub-tile's span
@@ -2425,6 +2447,10 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         cg.Stmt("{ const gdv_uint32 t = " + tile_total("ln" + E + "_u", "inc" + E) + ";");
         cg.Stmt("  run" + E + " = gdv_sat_add31(run" + E + ", (gdv_int32)(t > 0x7fffffffu ? 0x7fffffffu : t)); }");
         cg.Stmt("if (live) outo" + E + "[row] = (gdv_int32)(base" + E + " + loc" + E + ");");
+        if (cg.selection())
+          // the slot count may live in device memory (GDV_ROWS reads it): the host cannot know where the closing
+          // offset belongs, so the wave tile that holds the last slot writes it
+          after_rows << "  if (last_tile && lane == 0) outo" << E << "[n] = (gdv_int32)(base" << E << " + run" << E << ");\n";
         // nothing at or past the caller's capacity is written (the grand total says what was needed)
         cg.Stmt("const bool fit" + E + " = run" + E + " < 0x7fffffff && base" + E + " + run" + E + " <= A.out[" + E + "].cap;");
         if (has_window) {
@@ -2556,9 +2582,9 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
         // LDS mirror (and with it the per-sub-tile sweep): the first swept var-len input, when some
         // staged output's copies would read it
         cg.mirror_slot_ = -1;
-        bool readers = cg.replace_hook_ >= 0;  // (rows of a swept replace() are copied from the mirror)
+        bool readers = cg.replace_hook_ >= 0 && !cg.selection();  // (rows of a swept replace() are copied from the mirror)
         for (auto& vo : cg.varlen_outs_) readers |= vo.window >= 0 && vo.reads_views;
-        for (size_t k = 0; opts.lds_mirror && readers && k < cg.input_fields_.size() && cg.mirror_slot_ < 0; k++) {
+        for (size_t k = 0; opts.lds_mirror && readers && !cg.selection() && k < cg.input_fields_.size() && cg.mirror_slot_ < 0; k++) {
           if (!(schema[cg.input_fields_[k]].type.is_varlen() && cg.needs_values_[k])) continue;
           bool swept = cg.ascii_slots_.count(static_cast<int>(k)) != 0;
           for (auto& h : cg.contains_hooks_) swept |= h.slot == static_cast<int>(k);
@@ -2618,7 +2644,10 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   // time — still faster than the scanner shape, whose hand-off, occupancy and second row pass for
   // outputs above 8 bytes per row cost more (replace at 5 * 10^7 rows: 3.3 ms there).  Selection-
   // mode plans — and the re-run of a batch that breaks an assumption — take the scanner shape.
-  bool wave_ok = mode == SelectionMode::kNone && !opts.no_wave_shape;
+  // Round 5: selection-mode plans take the wave shape too (rows = slots, gathered through the selection vector;
+  // no byte sweep, no optimistic assumption: the row functions run their general paths in the pre-pass and in the
+  // main kernel alike) — rounds 2-4 sent them to the scanner shape.  GDV_NO_SEL_WAVE=1: as before.
+  bool wave_ok = (mode == SelectionMode::kNone || !opts.no_sel_wave) && !opts.no_wave_shape;
   bool any_varlen_out = false;
   const bool bytefree_only = opts.wave_bytefree_only;
   for (auto& e : exprs) {
@@ -2997,7 +3026,11 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
     << "    if (w < wave) before += cw;\n"
     << "  }\n"
     << "  if (wave == 0) {\n"
-    << "    const gdv_uint64 e = gdv_fp_lookback(A.mask, tile, wg_total, lane, A.err);\n"
+    << (opts.fp_experiment == 1
+            // EXPERIMENT (GDV_FP_EXPERIMENT=1, never the product: the outputs land at the tile's own first row): what the
+            // kernel costs WITHOUT the look-back — every workgroup tile takes tile x rows-per-tile as its base
+            ? "    const gdv_uint64 e = (gdv_uint64)tile * (GDV_WAVES * GDV_U * 64); (void)wg_total;\n"
+            : "    const gdv_uint64 e = gdv_fp_lookback(A.mask, tile, wg_total, lane, A.err);\n")
     << "    if (lane == 0) {\n"
     << "      *wg_excl = e;\n"
     << "      if (tile == (gdv_int64)gridDim.x - 1) *(gdv_int64*)A.counts = (gdv_int64)(e + wg_total);  // the batch's selected-row count\n"

@@ -50,6 +50,8 @@ struct CodegenOptions {
   // Fused filter-project, windowed shape (round 5): bytes of LDS window per wave tile (every windowed output + the
   // row index, GDV_FP_CAP rows of them); 0 = the direct round-4 shape only.  GDV_FP_WINDOW=<bytes>.
   int fp_window_bytes = 6144;
+  int fp_experiment = 0;               // GDV_FP_EXPERIMENT=<n>: timing experiments on the fused kernel (wrong results; tools only)
+  bool no_sel_wave = false;            // GDV_NO_SEL_WAVE=1: selection-mode var-len plans take the scanner shape (rounds 2-4)
   bool runtime_needles = false;        // GDV_RUNTIME_NEEDLES=1: wave kernels load their '%needle%' bytes instead of carrying them as immediates
   static CodegenOptions FromEnv();
   std::string Key() const;

@@ -903,3 +903,102 @@ def test_two_stage_plans_with_fixed_width_outputs_evaluate_without_a_host_synchr
     assert int(result[0]) & 128
     for g, w in zip(proj.evaluate_device(dbig), oracle.project(exprs, big)):
         assert_bit_exact(g.to_arrow(), w, "synchronous, long rows")
+
+
+# ------------------------------------------------------------------ round 5: selection-mode plans on the wave shape
+
+def test_selection_mode_string_plans_take_the_wave_shape(monkeypatch, tmp_path):
+    """Rounds 2-4: every var-len plan under a selection vector ran the scanner-shaped kernel (0.27 of the roofline,
+    5x the per-row cost of row mode: profiles/r05_filter_string_chain_before.txt).  Now: pre-pass + offsets scan +
+    independent wave tiles, rows = slots (gathered), no byte sweep, no optimistic assumption — and no exact
+    variant, there is nothing to be optimistic about."""
+    import ctypes as C
+    from gandiva_amd import _capi, gandiva as gg
+    monkeypatch.setenv("GDV_NO_DISK_CACHE", "1")
+    monkeypatch.setenv("GDV_DUMP_SOURCE", "1")
+    lib = _capi.lib()
+    ex = W.c5_expressions()
+    for sub, env, want_wave in (("wave", None, True), ("scanner", "GDV_NO_SEL_WAVE", False)):
+        d = tmp_path / sub
+        d.mkdir()
+        monkeypatch.setenv("GANDIVA_AMD_CACHE_DIR", str(d))
+        if env:
+            monkeypatch.setenv(env, "1")
+        sh = gg._make_schema(W.c5_schema())
+        try:
+            arr = (C.c_void_p * len(ex))(*[e._h for e in ex])
+            assert lib.gdv_precompile_projector(sh, arr, len(ex), 2) == 0, _capi.last_error()
+        finally:
+            lib.gdv_schema_free(sh)
+        texts = [open(d / f).read() for f in os.listdir(d) if f.endswith(".hip")]
+        wave = [t for t in texts if "// wave shape:" in t]
+        pre = [t for t in texts if "// pre-pass:" in t]
+        if want_wave:
+            assert len(wave) == 1 and len(pre) == 1 and len(texts) == 3          # + the scanner-shaped fallback
+            assert "rows = the slots of a selection vector" in wave[0] and "selv[row]" in wave[0] and "selv[row]" in pre[0]
+            assert "GDV_ERR_NOTASCII" not in wave[0] and "GDV_STR_ASCII" not in wave[0].split("gdv_tile(")[1]
+            assert "outo1[n] =" in wave[0]            # the closing offset is the kernel's own business (device-resident counts)
+        else:
+            assert not wave and not pre and len(texts) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,dtype", [("UINT16", "int16"), ("UINT32", "int32"), ("UINT64", "int64")])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 511, 512, 513, 4097, 40_003])
+def test_selection_mode_wave_shape_matches_the_oracle(mode, dtype, n):
+    """C5's three expressions + multi-byte text under a selection vector (every wave-tile boundary: 512 slots),
+    sparse and dense selections, nulls, host and HBM-resident paths."""
+    import torch
+    if dtype == "int16":
+        n = min(n, 30_000)
+    rng = np.random.default_rng(n * 3 + len(mode))
+    base = W.c5_batch(n, 0.1, non_ascii_fraction=0.05 if n % 2 else 0.0)
+    key = pa.array(rng.integers(0, 100, n), pa.int64())
+    batch = pa.RecordBatch.from_arrays([base.column(0), key], names=["s", "k"])
+    b = gandiva.TreeExprBuilder()
+    fs, fk = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = [b.make_expression(b.make_function("upper", [fs], pa.string()), pa.field("u", pa.string())),
+             b.make_expression(b.make_function("substr", [fs, b.make_literal(2, pa.int64()), b.make_literal(5, pa.int64())], pa.string()),
+                               pa.field("t", pa.string())),
+             b.make_expression(b.make_function("like", [fs, b.make_literal("%spark%", pa.string())], pa.bool_()), pa.field("m", pa.bool_())),
+             b.make_expression(b.make_function("concat", [fs, b.make_literal("-", pa.string()), fs], pa.string()), pa.field("c", pa.string())),
+             b.make_expression(b.make_function("add", [fk, fk], pa.int64()), pa.field("kk", pa.int64()))]
+    proj = gandiva.make_projector(batch.schema, exprs, None, mode)
+    for thr in (10, 60, 98):
+        cond = b.make_condition(b.make_function("greater_than", [fk, b.make_literal(thr, pa.int64())], pa.bool_()))
+        sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, None, dtype)
+        want = oracle.project(exprs, oracle.take_rows(batch, sel.to_array().to_numpy()))
+        for i, (g, w) in enumerate(zip(proj.evaluate(batch, sel), want)):
+            assert_bit_exact(g, w, f"host buffers, threshold {thr}, output {i}")
+        db = gandiva.DeviceBatch.from_arrow(batch)
+        dsel = gandiva.make_filter(batch.schema, cond).evaluate_device(db, dtype)
+        outs = proj.evaluate_device(db, selection=dsel)
+        torch.cuda.synchronize()
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert_bit_exact(o.to_arrow(), w, f"HBM-resident, threshold {thr}, output {i}")
+    assert proj.path_hint == 0
+
+
+@pytest.mark.gpu
+def test_an_empty_selection_whose_count_sits_in_device_memory():
+    """filter (asynchronous) selects nothing -> the selection-mode wave kernels launch for the capacity, walk 0 slots
+    and still leave a valid empty column: offsets[0] = 0, byte totals 0, status 0."""
+    import torch
+    n = 10_000
+    batch = pa.RecordBatch.from_arrays([W.c5_batch(n).column(0), pa.array(np.arange(n) % 50, pa.int64())], names=["s", "k"])
+    b = gandiva.TreeExprBuilder()
+    fs, fk = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    cond = b.make_condition(b.make_function("greater_than", [fk, b.make_literal(1000, pa.int64())], pa.bool_()))
+    exprs = [b.make_expression(b.make_function("upper", [fs], pa.string()), pa.field("u", pa.string()))]
+    db = gandiva.DeviceBatch.from_arrow(batch)
+    sel = gandiva.make_filter(batch.schema, cond).evaluate_device(db, "int32", sync=False)
+    proj = gandiva.make_projector(batch.schema, exprs, None, "UINT32")
+    outs, result = proj.evaluate_device_async(db, selection=sel)
+    outs[0].offsets.fill_(0x55)         # whatever was there must not survive as offsets[0]
+    outs, result = proj.evaluate_device_async(db, selection=sel, outputs=outs)
+    torch.cuda.synchronize()
+    assert sel.num_slots == 0 and int(result[0]) == 0 and int(result[1]) == 0
+    got = outs[0].to_arrow()
+    assert len(got) == 0
+    got.validate(full=True)
+    assert int(outs[0].offsets[:4].view(torch.int32)[0]) == 0

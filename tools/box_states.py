@@ -17,6 +17,7 @@ from gandiva_amd import workloads as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 28
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+carve_rounds = 0 if "--no-carve" in sys.argv else 2
 proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), pa.default_memory_pool())
 
 
@@ -66,7 +67,7 @@ def carve(total_views):
     return block, views
 
 
-for r in range(2):
+for r in range(carve_rounds):
     src = make_inputs_torch()
     need = []
     for c in src.columns:

@@ -45,7 +45,10 @@ VARIANTS = [("direct (round 4)   U16 W8", {"GDV_FP_WINDOW": "0"}),
             ("window 6144        U8  W8", {"GDV_U": "8"}),
             ("window 6144        U8  W16", {"GDV_U": "8", "GDV_WAVES": "16"}),
             ("window 12288       U16 W8", {"GDV_FP_WINDOW": "12288"}),
-            ("direct (round 4)   U16 W4", {"GDV_FP_WINDOW": "0", "GDV_WAVES": "4"})]
+            ("direct (round 4)   U16 W4", {"GDV_FP_WINDOW": "0", "GDV_WAVES": "4"}),
+            ("window, NO look-back U16 W8", {"GDV_FP_EXPERIMENT": "1"}),
+            ("direct, NO look-back U16 W8", {"GDV_FP_EXPERIMENT": "1", "GDV_FP_WINDOW": "0"}),
+            ("window, NO look-back U16 W4", {"GDV_FP_EXPERIMENT": "1", "GDV_WAVES": "4"})]
 only = os.environ.get("FP_VARIANTS")
 for k2 in k2s:
     flt = gandiva.make_filter(W.c3_schema(), condition(k2))
@@ -54,7 +57,7 @@ for k2 in k2s:
     for vi, (label, env) in enumerate(VARIANTS):
         if only and str(vi) not in only.split(","):
             continue
-        for k in ("GDV_FP_WINDOW", "GDV_U", "GDV_WAVES"):
+        for k in ("GDV_FP_WINDOW", "GDV_U", "GDV_WAVES", "GDV_FP_EXPERIMENT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         row = []
