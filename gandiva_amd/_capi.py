@@ -105,6 +105,7 @@ PROTOTYPES = [
     ("gdv_filter_project_evaluate", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.POINTER(gdv_out_column_t), C.c_int, _P, C.c_int64, C.POINTER(C.c_int64), _P, C.c_int, _P, C.c_uint32]),
     ("gdv_filter_project_dump_ir", _P, [_P]),
     ("gdv_filter_project_kernel_shape", C.c_int, [_P]),
+    ("gdv_filter_project_set_tuning", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("gdv_filter_project_free", None, [_P]),
     ("gdv_precompile_filter_project", C.c_int, [_P, _P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_registry_size", C.c_int, []),

@@ -676,6 +676,13 @@ int gdv_filter_project_evaluate(const gdv_filter_project_t* fp, int64_t num_rows
 }
 char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp) { return fp ? DupString(fp->fp->DumpIR()) : nullptr; }
 int gdv_filter_project_kernel_shape(const gdv_filter_project_t* fp) { return fp ? fp->fp->which_kernel() : -1; }
+int gdv_filter_project_set_tuning(gdv_filter_project_t* fp, const char* key, int64_t value) {
+  return Guarded([&]() -> int {
+    if (fp == nullptr || key == nullptr) return Fail(Status::Invalid("gdv_filter_project_set_tuning: null argument"));
+    Status st = fp->fp->SetTuning(key, value);
+    return st.ok() ? GDV_OK : Fail(st);
+  });
+}
 void gdv_filter_project_free(gdv_filter_project_t* fp) { delete fp; }
 
 // ---------------------------------------------------------------- JNI-shaped flat entry points

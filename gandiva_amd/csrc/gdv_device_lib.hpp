@@ -1576,6 +1576,12 @@ static __device__ GDV_COLD bool gdv_bytes_are_ascii(const gdv_uint8* p, gdv_int3
   for (gdv_int32 i = 0; i < len; i += 8) acc |= gdv_load8(p + i, lim) & gdv_low_bytes_mask(len - i);
   return (acc & GDV_B80) == 0;
 }
+// the same test inlined: selection-mode wave kernels run it on every row they copy (round 5)
+GDV_DEV bool gdv_row_is_ascii(const gdv_str& s) {
+  gdv_uint64 acc = 0;
+  for (gdv_int32 i = 0; i < s.len; i += 8) acc |= gdv_load8(s.p + i, s.lim) & gdv_low_bytes_mask(s.len - i);
+  return (acc & GDV_B80) == 0;
+}
 GDV_DEV bool gdv_str_is_ascii(const gdv_str& s) {
   if (s.flags & GDV_STR_ASCII) return true;  // answered for the whole tile by the byte sweep
   // (a row the exact variant flagged holds a byte >= 0x80 itself or shares a 16-byte piece with one

@@ -1842,8 +1842,16 @@ Status FilterProject::Make(const Schema& schema, const ExpressionPtr& condition,
   return Status::OK();
 }
 
+Status FilterProject::SetTuning(const std::string& key, int64_t value) {
+  if (key == "max_workgroups" && value >= 0) max_workgroups_.store(value);
+  else if (key == "kernel" && value >= -1 && value <= 1) pinned_kernel_.store(static_cast<int>(value));
+  else return Status::Invalid("FilterProject tuning: unknown key or value out of range: " + key);
+  return Status::OK();
+}
+
 int FilterProject::which_kernel() const {
   if (plan_.fp_window_rows <= 0 || plan_.exact == nullptr) return -1;
+  if (pinned_kernel_.load(std::memory_order_relaxed) >= 0) return pinned_kernel_.load(std::memory_order_relaxed);
   // the window holds fp_window_rows of a wave tile's 64 x subtiles rows; beyond ~85 % of that on average, wave
   // tiles start to overflow into the re-read path and the direct kernel is the better one
   const int limit = plan_.fp_window_rows * 1024 / (64 * plan_.opts.subtiles) * 85 / 100;
@@ -2003,8 +2011,27 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
     kernel = dev->kernel_exact.load();
     running = plan_.exact.get();
   }
+  // the pipelined shape runs PERSISTENT workgroups: as many as the device holds at once (every workgroup of the
+  // launch must be resident — a tile's look-back waits for lower tiles, which other workgroups of the same launch
+  // own), each walking tiles b, b + launch, ...
+  int64_t launch = grid;
+  if (running->fp_persistent) {
+    int per_cu = resident_per_cu_.load(std::memory_order_relaxed);
+    if (per_cu <= 0) {
+      int nb = 0;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel->function, plan_.opts.waves * 64, 0) != hipSuccess || nb <= 0) {
+        (void)hipGetLastError();
+        nb = 1;
+      }
+      per_cu = nb;
+      resident_per_cu_.store(per_cu, std::memory_order_relaxed);
+    }
+    launch = std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * per_cu);
+    const int64_t cap = max_workgroups_.load(std::memory_order_relaxed);
+    if (cap > 0) launch = std::min(launch, cap);
+  }
   EvalTrace trace("filter-project", running->kernel_name, num_rows, stream);
-  GDV_RETURN_NOT_OK(rt.Launch(*kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
+  GDV_RETURN_NOT_OK(rt.Launch(*kernel, launch, plan_.opts.waves * 64, args.data(), args.size(), stream));
   const char* count_dev = base + state_b;
   // the count leaves through a one-thread kernel: -1 when the look-back gave up (GDV_ERR_STALL in the error word) —
   // round 4 copied the word as it was and an asynchronous caller never learnt that the outputs were not complete

@@ -284,6 +284,10 @@ class FilterProject {
   SelectionMode index_mode() const { return plan_.mode; }
   std::string DumpIR() const { return plan_.ir; }
   int which_kernel() const;
+  // "max_workgroups" (0 = what the device holds): bound of the pipelined shape's persistent launch — tests walk
+  // many tiles per workgroup with it, deployments can leave CUs to other streams; "kernel" (-1 follow the
+  // selectivity, 0 windowed, 1 direct): pin the shape
+  Status SetTuning(const std::string& key, int64_t value);
 
  private:
   // the kernel launch of one evaluation; *stalled = the look-back gave up (the outputs are not complete)
@@ -305,6 +309,9 @@ class FilterProject {
   // shape exists, plan_.exact the direct round-4 kernel.  Synchronous evaluations record the share of rows they
   // selected (x 1024); once it is beyond what the window holds, the next batches run on the direct kernel.
   mutable std::atomic<int> selected_per_1024_{-1};
+  mutable std::atomic<int> resident_per_cu_{0};
+  std::atomic<int64_t> max_workgroups_{0};
+  std::atomic<int> pinned_kernel_{-1};  // pipelined shape: workgroups of the kernel one CU holds at once (queried once)
   mutable std::mutex chain_mu_;
   mutable std::shared_ptr<Filter> chain_filter_;
   mutable std::shared_ptr<Projector> chain_projector_;

@@ -38,6 +38,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
   o.no_sel_wave = std::getenv("GDV_NO_SEL_WAVE") != nullptr;
   if (const char* s = std::getenv("GDV_FP_EXPERIMENT")) o.fp_experiment = atoi(s);
+  if (const char* s = std::getenv("GDV_FP_PIPELINE")) o.fp_pipeline = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
   return o;
 }
@@ -46,7 +47,7 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") +
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_pipeline ? "" : "np") +
          (fp_window_bytes != 6144 ? "fw" + std::to_string(fp_window_bytes) : "");
 }
 
@@ -489,6 +490,9 @@ class CodeGen {
   // kernel alike, and a tile that did hold a byte >= 0x80 reports GDV_ERR_SAWUTF8 (so the host knows
   // when a later batch may go back to the optimistic kernels).
   bool exact_ascii_ = false;
+  // selection-mode wave main kernel (round 5): the pre-pass took its lengths from the offsets under the ASCII
+  // assumption; the rows, which read their bytes here anyway, verify it (NOTASCII -> the general kernel)
+  bool sel_ascii_check_ = false;
   std::set<int> row_ascii_slots_;  // exact variant: inputs whose views take a PER-ROW flag (gdv_with_lead)
   bool bake_needles_ = false;      // wave kernels: '%needle%' bytes are immediates of the kernel text (NeedleConstants)
   bool unroll_rows_ = false;       // the row loop of this kernel is unrolled (small bodies that index registers by u)
@@ -1418,6 +1422,8 @@ void EmitStringRowLoop(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, boo
       else if (cg.needs_values_[k])
         s << "      const gdv_str s" << k << " = gdv_make_str(sd" << k << ", oa" << k << "_u, ob" << k << "_u, slim" << k
           << ", sfl" << k << ");\n";
+      if (cg.needs_values_[k] && cg.sel_ascii_check_ && cg.ascii_slots_.count(k))
+        s << "      nasc" << k << " |= __ballot(live && !gdv_row_is_ascii(s" << k << "));\n";
     } else if (cg.needs_values_[k]) {
       s << "      const " << t.CType() << " c" << k << "_u = c" << k << "[0];\n";
     }
@@ -1769,7 +1775,15 @@ void EmitWaveTileSweep(std::ostringstream& s, CodeGen& cg, KernelPlan* plan, std
     if (cg.selection()) {
       // selected rows are not one span of bytes: nothing to sweep, no tile-wide fact about them — every row
       // function takes its general (UTF-8-exact, range-checked) path, as in the scanner-shaped kernel
-      s << "  const gdv_int32 sfl" << K << " = 0;\n";
+      // ... except the OPTIMISTIC one the pre-pass made: a function that consults the ASCII flag gets it set here too
+      // (so both kernels compute the same lengths) and every row, which reads its bytes in this kernel anyway, checks it
+      if (want_ascii) {
+        s << "  const gdv_int32 sfl" << K << " = GDV_STR_ASCII;\n"
+          << "  gdv_uint64 nasc" << K << " = 0;  // rows that turned out to hold a byte >= 0x80\n";
+        e << "  if (nasc" << K << " != 0 && lane == 0) gdv_raise_bits(A.err, GDV_ERR_NOTASCII);\n";
+      } else {
+        s << "  const gdv_int32 sfl" << K << " = 0;\n";
+      }
       continue;
     }
     // the span's ends come from two scalar loads (the sweep does not wait for the offsets' vector
@@ -2083,6 +2097,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
   plan->layout.n_in = static_cast<int>(plan->input_fields.size());
   plan->layout.n_out = static_cast<int>(plan->output_types.size());
   const bool prepass = kind == WaveKind::kPrepass;
+  cg.sel_ascii_check_ = cg.selection() && !prepass;
   const int nv = static_cast<int>(cg.varlen_outs_.size());
   int nstage = 0;
   for (auto& vo : cg.varlen_outs_) nstage = std::max(nstage, vo.window + 1);
@@ -2163,8 +2178,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     for (int k = 0; k < nin; k++) {
       const DataType& t = cg.schema_[plan->input_fields[k]].type;
       if (!(t.is_varlen() && cg.needs_values_[k])) continue;
-      if (cg.selection()) {  // (gathered rows: general row functions, the lengths are exact by construction)
-        s << "  const gdv_int32 sfl" << k << " = 0;\n";
+      if (cg.selection()) {
+        // gathered rows.  Functions that consult the ASCII flag get it OPTIMISTICALLY — their lengths then follow from
+        // the offsets and this pre-pass reads no byte; the main kernel checks every row it copies
+        s << "  const gdv_int32 sfl" << k << " = " << (cg.ascii_slots_.count(k) ? "GDV_STR_ASCII" : "0") << ";\n";
         continue;
       }
       s << "  const gdv_int32 sp1" << k << " = so" << k << "[last_tile ? n : rbase + 64 * GDV_U];\n";
@@ -2700,7 +2717,8 @@ Status PlanProjector(const Schema& schema, const std::vector<ExpressionPtr>& exp
   // The exact variant (round 4): only where some function consults the ASCII flag — i.e. where the
   // optimistic kernels can raise NOTASCII at all.  Same tree walk, same inputs / literals / constants
   // (checked): the host hands it the optimistic kernels' argument blocks.
-  if (fast.source.find("GDV_ERR_NOTASCII") != std::string::npos) {
+  // (selection-mode plans: a batch that breaks the assumption takes the scanner-shaped general kernel)
+  if (mode == SelectionMode::kNone && fast.source.find("GDV_ERR_NOTASCII") != std::string::npos) {
     auto ex = std::make_shared<KernelPlan>();
     std::vector<VarlenOut> evouts;
     Status st = PlanProjectorShape(schema, exprs, mode, fast.opts, StringShape::kWaveMainExact, nullptr, ex.get(), &evouts, compact_from);
@@ -2811,12 +2829,13 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
 // did not fit (rolled loop, from L2 / Infinity Cache) and stores those rows directly; the engine moves a
 // FilterProject whose batches select more than that to the direct kernel.
 namespace {
-enum class FpShape { kDirect, kWindow };
+enum class FpShape { kDirect, kWindow, kPipelined };
 
 Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
                               SelectionMode index_mode, const CodegenOptions& opts, FpShape shape, KernelPlan* plan) {
   AblationScope ablation_scope(opts.ablation);
-  const bool win = shape == FpShape::kWindow;
+  const bool pipe = shape == FpShape::kPipelined;  // windowed + persistent workgroups, next tile's loads in flight across the look-back
+  const bool win = shape == FpShape::kWindow || pipe;
   plan->kind = KernelKind::kFilterProject;
   plan->mode = index_mode;  // width of the emitted row indices; kNone: no SelectionVector output
   plan->opts = opts;
@@ -2934,8 +2953,12 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   as.Header(strings);
   std::ostringstream& s = as.src;
   if (win) s << "#define GDV_FP_CAP " << cap << "  // rows of a wave tile's LDS window\n";
-  s << "template <bool FULL>\n"
-    << "GDV_DEV void gdv_fused_tile(const gdv_args& A, const gdv_int64 tile, const int lane, const int wave,\n"
+  // PIPE (the pipelined shape): the function walks the tiles first, first + step, ... < end of ONE persistent
+  // workgroup; the loads of the next tile are issued right after the barrier that ends this tile's use of the
+  // registers — they are in flight while wave 0 looks back and the window is flushed.
+  s << "template <bool FULL, bool PIPE>\n"
+    << "GDV_DEV void gdv_fused_tile(const gdv_args& A, gdv_int64 tile, const gdv_int64 tile_step, const gdv_int64 tile_end,\n"
+    << "                            const gdv_int64 ntiles, const int lane, const int wave,\n"
     << "                            gdv_uint32* wg_cnt, gdv_uint64* wg_excl";
   if (win) {
     for (size_t e = 0; e < plan->output_types.size(); e++)
@@ -2943,13 +2966,12 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
     if (index_mode != SelectionMode::kNone) s << ", " << SelCType(index_mode) << "* widx";
   }
   s << ") {\n"
+    << "  (void)tile_step; (void)tile_end;\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
     << "  (void)gdv_cst;\n"
-    << "  const gdv_int64 n = GDV_ROWS(A);\n"
-    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;  // this wave's first 64-row word\n"
-    << "  const gdv_int64 rbase = wbase * 64;\n";
+    << "  const gdv_int64 n = GDV_ROWS(A);\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = schema[plan->input_fields[k]].type;
     if (t.id != kBool && cg.needs_values_[k])
@@ -2966,23 +2988,37 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   for (int k = 0; k < nin; k++) {
     const DataType& t = schema[plan->input_fields[k]].type;
     if (t.id == kBool) {
-      if (cg.needs_values_[k]) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      if (cg.needs_values_[k]) s << "  gdv_uint64 dw" << k << ";\n";
     } else if (cg.needs_values_[k]) {
       s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
     }
-    if (cg.needs_validity_[k]) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+    if (cg.needs_validity_[k]) s << "  gdv_uint64 vw" << k << ";\n";
   }
   const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
-  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
-    << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
-    << "    const bool live = FULL || row < n;\n"
-    << "    (void)live;\n";
-  for (int k = 0; k < nin; k++) {
-    const DataType& t = schema[plan->input_fields[k]].type;
-    if (t.id != kBool && cg.needs_values_[k])
-      s << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
-  }
-  s << "  }\n";
+  auto emit_loads = [&](const std::string& tile_expr, const std::string& ind) {
+    s << ind << "{\n"
+      << ind << "  const gdv_int64 lwbase = (" << tile_expr << " * GDV_WAVES + wave) * GDV_U, lrbase = lwbase * 64;\n"
+      << ind << "  (void)lrbase;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = schema[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k]) s << ind << "  dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, lwbase, lane, GDV_U);\n";
+      if (cg.needs_validity_[k]) s << ind << "  vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, lwbase, lane, GDV_U);\n";
+    }
+    s << "#pragma unroll\n" << ind << "  for (int u = 0; u < GDV_U; u++) {\n"
+      << ind << "    const gdv_int64 row = lrbase + u * 64 + lane;\n"
+      << ind << "    const bool live = FULL || row < n;\n"
+      << ind << "    (void)live; (void)row;\n";
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = schema[plan->input_fields[k]].type;
+      if (t.id != kBool && cg.needs_values_[k])
+        s << ind << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
+    }
+    s << ind << "  }\n" << ind << "}\n";
+  };
+  emit_loads("tile", "  ");
+  s << "  for (;;) {  // (one iteration unless PIPE)\n"
+    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;  // this wave's first 64-row word\n"
+    << "  const gdv_int64 rbase = wbase * 64;\n";
   auto row_prologue = [&] {
     s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
       << "      const bool live = FULL || row < n;\n"
@@ -3018,8 +3054,15 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   s << "    }\n  }\n"
     << "  // ---- phase 3: output base of this wave: the workgroup's waves meet in LDS, wave 0 looks back\n"
     << "  if (lane == 0) wg_cnt[wave] = fcount;\n"
-    << "  __syncthreads();\n"
-    << "  gdv_uint32 before = 0, wg_total = 0;\n"
+    << "  __syncthreads();\n";
+  if (pipe) {
+    s << "  const gdv_int64 tile_next = tile + tile_step;\n"
+      << "  const bool has_next = PIPE && tile_next < tile_end;  // workgroup-uniform\n"
+      << "  if (has_next) {  // the next tile's loads: in flight across the look-back and the flush below\n";
+    emit_loads("tile_next", "    ");
+    s << "  }\n";
+  }
+  s << "  gdv_uint32 before = 0, wg_total = 0;\n"
     << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
     << "    const gdv_uint32 cw = wg_cnt[w];\n"
     << "    wg_total += cw;\n"
@@ -3033,7 +3076,7 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
             : "    const gdv_uint64 e = gdv_fp_lookback(A.mask, tile, wg_total, lane, A.err);\n")
     << "    if (lane == 0) {\n"
     << "      *wg_excl = e;\n"
-    << "      if (tile == (gdv_int64)gridDim.x - 1) *(gdv_int64*)A.counts = (gdv_int64)(e + wg_total);  // the batch's selected-row count\n"
+    << "      if (tile == ntiles - 1) *(gdv_int64*)A.counts = (gdv_int64)(e + wg_total);  // the batch's selected-row count\n"
     << "    }\n"
     << "  }\n"
     << "  __syncthreads();\n"
@@ -3055,6 +3098,12 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
       << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
       << "      const int cnt = (int)__popcll(fmu);\n"
       << "      if (run + (gdv_uint32)cnt > (gdv_uint32)GDV_FP_CAP) {\n";
+    // (the tile's bitmap words are fetched again: under PIPE the registers hold the NEXT tile's by now)
+    for (int k = 0; k < nin; k++) {
+      const DataType& t = schema[plan->input_fields[k]].type;
+      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 dwt" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 vwt" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+    }
     // (indentation of the generated body is that of the unrolled loops; harmless)
     s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
       << "      const bool live = FULL || row < n;\n"
@@ -3062,8 +3111,8 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
       << "      (void)livemask; (void)row; (void)live;\n";
     for (int k = 0; k < nin; k++) {
       const DataType& t = schema[plan->input_fields[k]].type;
-      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dwt" << k << ", u);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vwt" << k << ", u);\n";
       if (t.id != kBool && cg.needs_values_[k])
         s << "      const gdv_one<" << t.CType() << "> c" << k << "{live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0};  // (shadows the tile's registers)\n";
     }
@@ -3097,7 +3146,9 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
       << "    }\n  }\n";
   }
   for (auto& f : flushes) s << f;
-  s << "}\n\n"
+  if (pipe) s << "  if (!has_next) break;\n  tile = tile_next;\n";
+  else s << "  break;\n";
+  s << "  }\n}\n\n"
     << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
     << "  __shared__ gdv_uint32 wg_cnt[GDV_WAVES];\n"
     << "  __shared__ gdv_uint64 wg_excl;\n";
@@ -3115,11 +3166,25 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   }
   s << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
-    << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_U x 64 rows; index order = row order\n"
-    << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
-    << "  if ((tile + 1) * (GDV_WAVES * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
-    << "  else gdv_fused_tile<false>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
-    << "}\n";
+    ;
+  if (pipe)
+    s << "  // persistent workgroups (the launch is sized to what the device holds at once): workgroup b takes the full tiles\n"
+      << "  // b, b + gridDim.x, ... — neighbours in time are neighbours in the batch, so a look-back never reaches far — and\n"
+      << "  // the batch's partial last tile, if there is one, goes to the workgroup whose turn it would be, unpipelined\n"
+      << "  const gdv_int64 tile_rows = GDV_WAVES * GDV_U * 64;\n"
+      << "  const gdv_int64 ntiles_full = GDV_ROWS(A) / tile_rows, ntiles = (GDV_ROWS(A) + tile_rows - 1) / tile_rows;\n"
+      << "  // (workgroup-uniform branches: the barriers inside are reached by every wave of the workgroup)\n"
+      << "  if ((gdv_int64)blockIdx.x < ntiles_full)\n"
+      << "    gdv_fused_tile<true, true>(A, (gdv_int64)blockIdx.x, (gdv_int64)gridDim.x, ntiles_full, ntiles, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+      << "  if (ntiles > ntiles_full && ntiles_full % (gdv_int64)gridDim.x == (gdv_int64)blockIdx.x)\n"
+      << "    gdv_fused_tile<false, false>(A, ntiles_full, 0, 0, ntiles, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+      << "}\n";
+  else
+    s << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_U x 64 rows; index order = row order\n"
+      << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
+      << "  if ((tile + 1) * (GDV_WAVES * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true, false>(A, tile, 0, 0, (gdv_int64)gridDim.x, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+      << "  else gdv_fused_tile<false, false>(A, tile, 0, 0, (gdv_int64)gridDim.x, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+      << "}\n";
   std::string text = s.str();
   uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
   char name[64];
@@ -3130,6 +3195,7 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   plan->source = text;
   plan->ir = text;
   plan->fp_window_rows = cap;
+  plan->fp_persistent = pipe;
   return Status::OK();
 }
 }  // namespace
@@ -3152,7 +3218,8 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
   GDV_RETURN_NOT_OK(PlanFilterProjectShape(schema, condition, exprs, index_mode, opts, FpShape::kDirect, direct.get()));
   if (opts.fp_window_bytes > 0) {
     KernelPlan windowed;
-    Status st = PlanFilterProjectShape(schema, condition, exprs, index_mode, opts, FpShape::kWindow, &windowed);
+    Status st = PlanFilterProjectShape(schema, condition, exprs, index_mode, opts,
+                                       opts.fp_pipeline ? FpShape::kPipelined : FpShape::kWindow, &windowed);
     // the engine launches either kernel with the windowed plan's argument block: the direct plan's literals and
     // constant block must be a prefix of it (they are: the windowed body generates the same trees first, then the
     // tail's copies) — if that ever stops holding, the plan keeps the direct shape alone

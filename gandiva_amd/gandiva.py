@@ -1035,6 +1035,11 @@ class FilterProject:
             return self._chain[0].llvm_ir + self._chain[1].llvm_ir
         return _capi.take_string(_capi.lib().gdv_filter_project_dump_ir(self._h))
 
+    def set_tuning(self, key, value):
+        """gdv_filter_project_set_tuning: "max_workgroups" (bound of the persistent launch), "kernel" (-1 / 0 / 1)."""
+        if self._h is not None:
+            _check(_capi.lib().gdv_filter_project_set_tuning(self._h, key.encode(), int(value)))
+
     @property
     def kernel_shape(self):
         """0: the windowed kernel runs next (selected rows staged in LDS); 1: the direct one (recent batches selected

@@ -371,6 +371,11 @@ char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp);
  * filter + selection-mode projector chain (round 4: ExecutionError); under GDV_EVAL_ASYNC *num_selected_device
  * then receives -1 — evaluate the batch with the synchronous call. */
 int gdv_filter_project_kernel_shape(const gdv_filter_project_t* fp);
+/* "max_workgroups" (0 = as many as the device holds at once): the windowed kernel runs PERSISTENT workgroups — each
+ * walks tiles b, b + launch, ... with the next tile's loads in flight across the look-back — and this bounds the
+ * launch (tests; deployments that share the device between streams).  "kernel": -1 follow the selectivity
+ * (default), 0 / 1 pin the windowed / the direct kernel. */
+int gdv_filter_project_set_tuning(gdv_filter_project_t* fp, const char* key, int64_t value);
 void gdv_filter_project_free(gdv_filter_project_t* fp);
 
 /* ---- function registry ------------------------------------------------------------ */

@@ -351,3 +351,27 @@ def test_a_stalled_launch_is_re_run_on_the_chain():
     env = dict(os.environ, GDV_FP_FORCE_STALL="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "chain ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wgs", [1, 2, 3, 7])
+@pytest.mark.parametrize("n", [8192 * 4, 8192 * 9 + 5, 8192 * 23 + 8191, 300_007])
+def test_persistent_workgroups_walk_many_tiles_each(wgs, n):
+    """The pipelined shape with its launch bounded to 1 / 2 / 3 / 7 workgroups: every workgroup walks many tiles (the
+    next tile's loads in flight across the look-back), the partial last tile goes to the workgroup whose turn it is.
+    Values, validity, bool outputs and the selection vector against the oracle's chain, sparse and dense."""
+    rng = np.random.default_rng(n + wgs)
+    batch = _batch(rng, n, 0.1)
+    for thr, dtype in ((870, "int32"), (300, None), (-1, "int64")):
+        cond, exprs = _plan(batch.schema, thr)
+        fp = gandiva.make_filter_project(batch.schema, cond, exprs, dtype)
+        fp.set_tuning("max_workgroups", wgs)
+        fp.set_tuning("kernel", 0)            # stay on the windowed / pipelined kernel whatever the batch selects
+        assert fp.kernel_shape == 0
+        for rep in range(2):
+            got, sel = fp.evaluate(batch)
+            want_sel, want = _chain(cond, exprs, batch, dtype)
+            if dtype is not None:
+                assert sel.to_array().equals(want_sel), (thr, rep)
+            for e, (g, w) in enumerate(zip(got, want)):
+                assert_bit_exact(g, w, f"threshold {thr}, expression {e}, {wgs} workgroups, run {rep}")

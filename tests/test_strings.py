@@ -936,7 +936,10 @@ def test_selection_mode_string_plans_take_the_wave_shape(monkeypatch, tmp_path):
         if want_wave:
             assert len(wave) == 1 and len(pre) == 1 and len(texts) == 3          # + the scanner-shaped fallback
             assert "rows = the slots of a selection vector" in wave[0] and "selv[row]" in wave[0] and "selv[row]" in pre[0]
-            assert "GDV_ERR_NOTASCII" not in wave[0] and "GDV_STR_ASCII" not in wave[0].split("gdv_tile(")[1]
+            # optimistic ASCII: the pre-pass reads offsets only, the main kernel checks every row it copies;
+            # no exact variant (a batch that breaks the assumption takes the scanner-shaped general kernel)
+            assert "gdv_row_is_ascii(s0)" in wave[0] and "GDV_ERR_NOTASCII" in wave[0] and "gdv_row_is_ascii" not in pre[0]
+            assert "exact variant" not in "".join(texts)
             assert "outo1[n] =" in wave[0]            # the closing offset is the kernel's own business (device-resident counts)
         else:
             assert not wave and not pre and len(texts) == 1
@@ -976,7 +979,8 @@ def test_selection_mode_wave_shape_matches_the_oracle(mode, dtype, n):
         torch.cuda.synchronize()
         for i, (o, w) in enumerate(zip(outs, want)):
             assert_bit_exact(o.to_arrow(), w, f"HBM-resident, threshold {thr}, output {i}")
-    assert proj.path_hint == 0
+    # ASCII batches stay on the wave pair; one with bytes >= 0x80 under substr / like was re-run on the general kernel
+    assert proj.path_hint == 0 if n % 2 == 0 else proj.path_hint in (0, 2)
 
 
 @pytest.mark.gpu
