@@ -1843,8 +1843,7 @@ Status FilterProject::Make(const Schema& schema, const ExpressionPtr& condition,
 }
 
 Status FilterProject::SetTuning(const std::string& key, int64_t value) {
-  if (key == "max_workgroups" && value >= 0) max_workgroups_.store(value);
-  else if (key == "kernel" && value >= -1 && value <= 1) pinned_kernel_.store(static_cast<int>(value));
+  if (key == "kernel" && value >= -1 && value <= 1) pinned_kernel_.store(static_cast<int>(value));
   else return Status::Invalid("FilterProject tuning: unknown key or value out of range: " + key);
   return Status::OK();
 }
@@ -1854,7 +1853,7 @@ int FilterProject::which_kernel() const {
   if (pinned_kernel_.load(std::memory_order_relaxed) >= 0) return pinned_kernel_.load(std::memory_order_relaxed);
   // the window holds fp_window_rows of a wave tile's 64 x subtiles rows; beyond ~85 % of that on average, wave
   // tiles start to overflow into the re-read path and the direct kernel is the better one
-  const int limit = plan_.fp_window_rows * 1024 / (64 * plan_.opts.subtiles) * 85 / 100;
+  const int limit = plan_.fp_window_rows * 1024 / (64 * plan_.opts.subtiles * std::max(1, plan_.fp_rounds)) * 85 / 100;
   return selected_per_1024_.load(std::memory_order_relaxed) > limit ? 1 : 0;
 }
 
@@ -1949,7 +1948,23 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   if (!st.buffers.empty()) { async = false; drain.armed = true; }
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 
-  const int64_t rows_per_wg = 64 * static_cast<int64_t>(plan_.opts.subtiles) * plan_.opts.waves;
+  // which shape: the windowed kernel unless recent batches selected more rows than its LDS window holds (the
+  // direct kernel takes the same argument block: PlanFilterProject checks that its literals and constants are a
+  // prefix of the windowed plan's)
+  const CompiledKernel* kernel = dev->kernel;
+  const KernelPlan* running = &plan_;
+  if (which_kernel() == 1 && !EngineKnobs::Get().fp_window_only) {
+    PlanDeviceState* d = const_cast<PlanDeviceState*>(dev);
+    if (d->kernel_exact.load() == nullptr) {
+      const CompiledKernel* k = nullptr;
+      GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->source, plan_.exact->kernel_name, &k));
+      d->kernel_exact.store(k);
+    }
+    kernel = dev->kernel_exact.load();
+    running = plan_.exact.get();
+  }
+  // one workgroup tile: waves x rounds x sub-tiles x 64 rows (the windowed kernel walks GDV_FP_K rounds per look-back)
+  const int64_t rows_per_wg = 64 * static_cast<int64_t>(plan_.opts.subtiles) * plan_.opts.waves * std::max(1, running->fp_rounds);
   const int64_t grid = (num_rows + rows_per_wg - 1) / rows_per_wg;
   if (grid > 0x7fffffff) return Status::Invalid("batch too large for the fused filter-project launch");
   auto up = [](size_t v) { return (v + 255) & ~size_t{255}; };
@@ -1996,42 +2011,8 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   args.SetPtr(ArgLayout::kOffSel, dev_idx);
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
 
-  // which shape: the windowed kernel unless recent batches selected more rows than its LDS window holds (the
-  // direct kernel takes the same argument block: PlanFilterProject checks that its literals and constants are a
-  // prefix of the windowed plan's)
-  const CompiledKernel* kernel = dev->kernel;
-  const KernelPlan* running = &plan_;
-  if (which_kernel() == 1 && !EngineKnobs::Get().fp_window_only) {
-    PlanDeviceState* d = const_cast<PlanDeviceState*>(dev);
-    if (d->kernel_exact.load() == nullptr) {
-      const CompiledKernel* k = nullptr;
-      GDV_RETURN_NOT_OK(rt.GetKernel(plan_.exact->source, plan_.exact->kernel_name, &k));
-      d->kernel_exact.store(k);
-    }
-    kernel = dev->kernel_exact.load();
-    running = plan_.exact.get();
-  }
-  // the pipelined shape runs PERSISTENT workgroups: as many as the device holds at once (every workgroup of the
-  // launch must be resident — a tile's look-back waits for lower tiles, which other workgroups of the same launch
-  // own), each walking tiles b, b + launch, ...
-  int64_t launch = grid;
-  if (running->fp_persistent) {
-    int per_cu = resident_per_cu_.load(std::memory_order_relaxed);
-    if (per_cu <= 0) {
-      int nb = 0;
-      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel->function, plan_.opts.waves * 64, 0) != hipSuccess || nb <= 0) {
-        (void)hipGetLastError();
-        nb = 1;
-      }
-      per_cu = nb;
-      resident_per_cu_.store(per_cu, std::memory_order_relaxed);
-    }
-    launch = std::min<int64_t>(grid, static_cast<int64_t>(rt.num_cus()) * per_cu);
-    const int64_t cap = max_workgroups_.load(std::memory_order_relaxed);
-    if (cap > 0) launch = std::min(launch, cap);
-  }
   EvalTrace trace("filter-project", running->kernel_name, num_rows, stream);
-  GDV_RETURN_NOT_OK(rt.Launch(*kernel, launch, plan_.opts.waves * 64, args.data(), args.size(), stream));
+  GDV_RETURN_NOT_OK(rt.Launch(*kernel, grid, plan_.opts.waves * 64, args.data(), args.size(), stream));
   const char* count_dev = base + state_b;
   // the count leaves through a one-thread kernel: -1 when the look-back gave up (GDV_ERR_STALL in the error word) —
   // round 4 copied the word as it was and an asynchronous caller never learnt that the outputs were not complete

@@ -284,9 +284,7 @@ class FilterProject {
   SelectionMode index_mode() const { return plan_.mode; }
   std::string DumpIR() const { return plan_.ir; }
   int which_kernel() const;
-  // "max_workgroups" (0 = what the device holds): bound of the pipelined shape's persistent launch — tests walk
-  // many tiles per workgroup with it, deployments can leave CUs to other streams; "kernel" (-1 follow the
-  // selectivity, 0 windowed, 1 direct): pin the shape
+  // "kernel" (-1 follow the selectivity, 0 windowed, 1 direct): pin the shape (tests, measurements)
   Status SetTuning(const std::string& key, int64_t value);
 
  private:
@@ -310,7 +308,6 @@ class FilterProject {
   // selected (x 1024); once it is beyond what the window holds, the next batches run on the direct kernel.
   mutable std::atomic<int> selected_per_1024_{-1};
   mutable std::atomic<int> resident_per_cu_{0};
-  std::atomic<int64_t> max_workgroups_{0};
   std::atomic<int> pinned_kernel_{-1};  // pipelined shape: workgroups of the kernel one CU holds at once (queried once)
   mutable std::mutex chain_mu_;
   mutable std::shared_ptr<Filter> chain_filter_;

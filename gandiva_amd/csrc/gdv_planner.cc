@@ -38,7 +38,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
   o.no_sel_wave = std::getenv("GDV_NO_SEL_WAVE") != nullptr;
   if (const char* s = std::getenv("GDV_FP_EXPERIMENT")) o.fp_experiment = atoi(s);
-  if (const char* s = std::getenv("GDV_FP_PIPELINE")) o.fp_pipeline = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_FP_K")) o.fp_rounds = std::max(1, std::min(8, atoi(s)));
   if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
   return o;
 }
@@ -47,8 +47,8 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_pipeline ? "" : "np") +
-         (fp_window_bytes != 6144 ? "fw" + std::to_string(fp_window_bytes) : "");
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_rounds != 3 ? "k" + std::to_string(fp_rounds) : "") +
+         (fp_window_bytes != 9984 ? "fw" + std::to_string(fp_window_bytes) : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -2829,17 +2829,18 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
 // did not fit (rolled loop, from L2 / Infinity Cache) and stores those rows directly; the engine moves a
 // FilterProject whose batches select more than that to the direct kernel.
 namespace {
-enum class FpShape { kDirect, kWindow, kPipelined };
+enum class FpShape { kDirect, kWindow };
 
 Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
                               SelectionMode index_mode, const CodegenOptions& opts, FpShape shape, KernelPlan* plan) {
   AblationScope ablation_scope(opts.ablation);
-  const bool pipe = shape == FpShape::kPipelined;  // windowed + persistent workgroups, next tile's loads in flight across the look-back
-  const bool win = shape == FpShape::kWindow || pipe;
+  const bool win = shape == FpShape::kWindow;
   plan->kind = KernelKind::kFilterProject;
   plan->mode = index_mode;  // width of the emitted row indices; kNone: no SelectionVector output
   plan->opts = opts;
   CodeGen cg(schema, SelectionMode::kNone, opts);
+  const std::string sel_t = SelCType(index_mode);
+  const bool with_index = index_mode != SelectionMode::kNone;
   // ---- the predicate (row mode; a null predicate does not select the row)
   Val c;
   cg.Stmt("// @expr_0 (filter condition)");
@@ -2848,11 +2849,12 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   cg.Stmt("const gdv_uint64 fmw = __ballot(" + CodeGen::AndExpr("live", pass) + ");");
   if (win) cg.Stmt("const gdv_uint32 run = fcount;  // selected rows of this wave tile before this sub-tile");
   cg.Stmt("fcount += (gdv_uint32)__popcll(fmw);");
-  cg.Stmt("fm = gdv_deposit_word(fm, u, fmw, lane);  // lane u keeps sub-tile u's match word (2 VGPRs, not 2 x GDV_U SGPRs)");
+  if (!win) cg.Stmt("fm = gdv_deposit_word(fm, u, fmw, lane);  // lane u keeps sub-tile u's match word (2 VGPRs, not 2 x GDV_U SGPRs)");
   const std::string cond_body = cg.body_.str();
   // ---- the projections.  Direct shape: a loop of its own after the look-back — the predicate's temporaries
   // are out of scope, common sub-expressions are shared among the projections only.  Windowed shape: the same
-  // loop iteration as the predicate, and once more (values only) for the rows that did not fit the window.
+  // loop iteration as the predicate; and once more, predicate included, for wave tiles whose selected rows did not
+  // all fit the window (they are read again: nothing of the tile is kept in registers across the look-back).
   cg.body_.str("");
   if (!win) cg.cse_.clear();
   std::vector<std::string> strings{condition->ToString()};
@@ -2870,8 +2872,6 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
             ", gdv_compact_word(" + word_expr + ", fmu, below, cnt, lane), cnt, lane);");
     return k;
   };
-  // pass 0: the main projection body; pass 1 (windowed shape only): the values again, stored directly, for
-  // the rows beyond the window
   std::string proj_body, tail_body;
   int window_bytes_per_row = index_mode == SelectionMode::kUInt16 ? 2 : index_mode == SelectionMode::kUInt32 ? 4
                              : index_mode == SelectionMode::kUInt64 ? 8 : 0;
@@ -2880,6 +2880,18 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
     if (tail) {
       cg.body_.str("");
       cg.cse_.clear();
+      Val c2;
+      cg.Stmt("// @expr_0 (filter condition), again");
+      GDV_RETURN_NOT_OK(cg.Gen(*condition->root(), "", &c2));
+      cg.Stmt("const gdv_uint64 fmu = __ballot(" + CodeGen::AndExpr("live", CodeGen::AndExpr(cg.LaneValid(c2), c2.v)) + ");");
+      cg.Stmt("const int cnt = (int)__popcll(fmu);");
+      cg.Stmt("if (run + (gdv_uint32)cnt > (gdv_uint32)GDV_FP_CAP) {  // wave-uniform: a selected row of this sub-tile is beyond the window");
+      cg.Stmt("const bool fsel = (fmu >> lane) & 1;");
+      cg.Stmt("const int slot = (int)run + gdv_rank_below(fmu);");
+      cg.Stmt("const bool ftail = fsel && slot >= GDV_FP_CAP;");
+      cg.Stmt("const gdv_int64 opos = pos0 + slot;");
+      cg.Stmt("(void)opos; (void)ftail;");
+      if (with_index) cg.Stmt("if (ftail) selv[opos] = (" + sel_t + ")row;");
     }
     for (size_t e = 0; e < exprs.size(); e++) {
       Val v;
@@ -2911,6 +2923,10 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
       const int k = bits_acc(word);
       flushes.push_back("  " + flush_fn + "(A.out[" + E + "].valid, bacc" + std::to_string(k) + ", pos0, (gdv_int64)fcount, lane);\n");
     }
+    if (tail) {
+      cg.Stmt("}");
+      cg.Stmt("run += (gdv_uint32)cnt;");
+    }
     (tail ? tail_body : proj_body) = cg.body_.str();
   }
   for (size_t k = 0; k < cg.input_fields_.size(); k++)
@@ -2925,8 +2941,7 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   plan->layout.n_in = static_cast<int>(plan->input_fields.size());
   plan->layout.n_out = static_cast<int>(plan->output_types.size());
   const int nin = plan->layout.n_in;
-  // loads in flight: as a predicate kernel, within 512 bytes of input values per lane; the match
-  // words of the tile live in scalar registers (2 per sub-tile)
+  // loads in flight: as a predicate kernel, within 512 bytes of input values per lane
   if (!plan->opts.subtiles_forced) {
     int in_bytes = 0;
     for (int k = 0; k < nin; k++)
@@ -2939,12 +2954,17 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   // 16 x 4: 4.45 / 4.10 ms with / without the selection vector, 16 x 8: 4.26 / 4.05, 16 x 16: 4.89 / 4.19,
   // 8 x 8: 4.58 / 4.40 — profiles/r04_filter_project.txt)
   if (!plan->opts.waves_forced) plan->opts.waves = 8;
-  // the window: GDV_FP_CAP rows per wave tile, every windowed output + the index at its own width; 6 KB per
-  // wave (48 KB per 8-wave workgroup: three workgroups per CU), at most half the wave tile's rows
-  int cap = 0;
+  // Windowed shape: a wave tile is GDV_FP_K ROUNDS of GDV_U sub-tiles (contiguous rows) — the look-back, which costs
+  // 0.8 ms of the 4.3 at 10^9 rows whatever the shape of the stores (profiles/r05_filter_project_no_lookback.txt), is paid
+  // once per K x 8192 rows.  The bitmap accumulators hold one local word per lane: K x U <= 63.
+  // The window: GDV_FP_CAP rows per wave tile, every windowed output + the index at its own width, at most half
+  // the wave tile's rows (78 KB per 8-wave workgroup at the default: two workgroups per CU, which is what the
+  // kernel's registers allow anyway).
+  int rounds = 1, cap = 0;
   if (win) {
     if (window_bytes_per_row == 0) return Status::CodeGenError("fused filter-project: nothing to window (bitmap outputs only)");
-    const int rows_wave = 64 * plan->opts.subtiles;
+    rounds = std::max(1, std::min(opts.fp_rounds, 63 / plan->opts.subtiles));
+    const int rows_wave = 64 * plan->opts.subtiles * rounds;
     cap = std::min(rows_wave / 2, opts.fp_window_bytes / window_bytes_per_row) / 64 * 64;
     if (cap < 128) return Status::CodeGenError("fused filter-project: rows too wide for the LDS window");
   }
@@ -2952,26 +2972,23 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   Assembler as{cg, plan, {}};
   as.Header(strings);
   std::ostringstream& s = as.src;
+  s << "#define GDV_FP_K " << rounds << "  // rounds of GDV_U sub-tiles per wave tile\n";
   if (win) s << "#define GDV_FP_CAP " << cap << "  // rows of a wave tile's LDS window\n";
-  // PIPE (the pipelined shape): the function walks the tiles first, first + step, ... < end of ONE persistent
-  // workgroup; the loads of the next tile are issued right after the barrier that ends this tile's use of the
-  // registers — they are in flight while wave 0 looks back and the window is flushed.
-  s << "template <bool FULL, bool PIPE>\n"
-    << "GDV_DEV void gdv_fused_tile(const gdv_args& A, gdv_int64 tile, const gdv_int64 tile_step, const gdv_int64 tile_end,\n"
-    << "                            const gdv_int64 ntiles, const int lane, const int wave,\n"
+  s << "template <bool FULL>\n"
+    << "GDV_DEV void gdv_fused_tile(const gdv_args& A, const gdv_int64 tile, const int lane, const int wave,\n"
     << "                            gdv_uint32* wg_cnt, gdv_uint64* wg_excl";
   if (win) {
     for (size_t e = 0; e < plan->output_types.size(); e++)
       if (plan->output_types[e].id != kBool) s << ", " << plan->output_types[e].CType() << "* win" << e;
-    if (index_mode != SelectionMode::kNone) s << ", " << SelCType(index_mode) << "* widx";
+    if (with_index) s << ", " << sel_t << "* widx";
   }
   s << ") {\n"
-    << "  (void)tile_step; (void)tile_end;\n"
     << "  gdv_ctx ctx{A.err};\n"
     << "  (void)ctx;\n"
     << "  const gdv_uint8* const gdv_cst = (const gdv_uint8*)A.aux0;  // the plan's constant block\n"
     << "  (void)gdv_cst;\n"
-    << "  const gdv_int64 n = GDV_ROWS(A);\n";
+    << "  const gdv_int64 n = GDV_ROWS(A);\n"
+    << "  const gdv_int64 wfirst = (tile * GDV_WAVES + wave) * (GDV_FP_K * GDV_U);  // this wave's first 64-row word\n";
   for (int k = 0; k < nin; k++) {
     const DataType& t = schema[plan->input_fields[k]].type;
     if (t.id != kBool && cg.needs_values_[k])
@@ -2982,62 +2999,59 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
     if (t.id != kBool)
       s << "  " << t.CType() << "* __restrict__ out" << e << " = (" << t.CType() << "*)A.out[" << e << "].data;\n";
   }
-  if (index_mode != SelectionMode::kNone)
-    s << "  " << SelCType(index_mode) << "* __restrict__ selv = (" << SelCType(index_mode) << "*)A.sel;\n";
-  s << "  // ---- phase 1: all loads of this wave's GDV_U sub-tiles, issued back to back\n";
-  for (int k = 0; k < nin; k++) {
-    const DataType& t = schema[plan->input_fields[k]].type;
-    if (t.id == kBool) {
-      if (cg.needs_values_[k]) s << "  gdv_uint64 dw" << k << ";\n";
-    } else if (cg.needs_values_[k]) {
-      s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
-    }
-    if (cg.needs_validity_[k]) s << "  gdv_uint64 vw" << k << ";\n";
-  }
+  if (with_index) s << "  " << sel_t << "* __restrict__ selv = (" << sel_t << "*)A.sel;\n";
   const std::string ld = plan->opts.nt_loads ? "gdv_ldnt" : "gdv_ld";
-  auto emit_loads = [&](const std::string& tile_expr, const std::string& ind) {
-    s << ind << "{\n"
-      << ind << "  const gdv_int64 lwbase = (" << tile_expr << " * GDV_WAVES + wave) * GDV_U, lrbase = lwbase * 64;\n"
-      << ind << "  (void)lrbase;\n";
+  // phase 1 of one round: all loads of GDV_U sub-tiles, issued back to back
+  auto emit_loads = [&] {
+    s << "  // ---- phase 1: all loads of this round's GDV_U sub-tiles, issued back to back\n";
     for (int k = 0; k < nin; k++) {
       const DataType& t = schema[plan->input_fields[k]].type;
-      if (t.id == kBool && cg.needs_values_[k]) s << ind << "  dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, lwbase, lane, GDV_U);\n";
-      if (cg.needs_validity_[k]) s << ind << "  vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, lwbase, lane, GDV_U);\n";
+      if (t.id == kBool) {
+        if (cg.needs_values_[k]) s << "  const gdv_uint64 dw" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      } else if (cg.needs_values_[k]) {
+        s << "  " << t.CType() << " c" << k << "[GDV_U];\n";
+      }
+      if (cg.needs_validity_[k]) s << "  const gdv_uint64 vw" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
-    s << "#pragma unroll\n" << ind << "  for (int u = 0; u < GDV_U; u++) {\n"
-      << ind << "    const gdv_int64 row = lrbase + u * 64 + lane;\n"
-      << ind << "    const bool live = FULL || row < n;\n"
-      << ind << "    (void)live; (void)row;\n";
+    s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n"
+      << "    const gdv_int64 row = rbase + u * 64 + lane;\n"
+      << "    const bool live = FULL || row < n;\n"
+      << "    (void)live;\n";
     for (int k = 0; k < nin; k++) {
       const DataType& t = schema[plan->input_fields[k]].type;
       if (t.id != kBool && cg.needs_values_[k])
-        s << ind << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
+        s << "    c" << k << "[u] = live ? " << ld << "(in" << k << ", row) : (" << t.CType() << ")0;\n";
     }
-    s << ind << "  }\n" << ind << "}\n";
+    s << "  }\n";
   };
-  emit_loads("tile", "  ");
-  s << "  for (;;) {  // (one iteration unless PIPE)\n"
-    << "  const gdv_int64 wbase = (tile * GDV_WAVES + wave) * GDV_U;  // this wave's first 64-row word\n"
-    << "  const gdv_int64 rbase = wbase * 64;\n";
-  auto row_prologue = [&] {
+  auto row_prologue = [&](const std::string& words_suffix) {
     s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
       << "      const bool live = FULL || row < n;\n"
       << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
       << "      (void)livemask; (void)row; (void)live;\n";
     for (int k = 0; k < nin; k++) {
       const DataType& t = schema[plan->input_fields[k]].type;
-      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << k << ", u);\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << k << ", u);\n";
+      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dw" << words_suffix << k << ", u);\n";
+      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vw" << words_suffix << k << ", u);\n";
     }
   };
+  s << "  gdv_uint32 fcount = 0;\n";
+  if (win) {
+    for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;  // output bitmap words at wave-local bit positions\n";
+    s << (rounds > 1 ? "#pragma unroll 1\n" : "")
+      << "  for (int kb = 0; kb < GDV_FP_K; kb++) {\n"
+      << "  const gdv_int64 wbase = wfirst + kb * GDV_U;\n"
+      << "  const gdv_int64 rbase = wbase * 64;\n";
+  } else {
+    s << "  gdv_uint64 fm = 0;\n"
+      << "  const gdv_int64 wbase = wfirst;\n"
+      << "  const gdv_int64 rbase = wbase * 64;\n";
+  }
+  emit_loads();
   s << "  // ---- phase 2: the predicate -> one match word per sub-tile"
     << (win ? "; the projections of the selected rows -> the wave's LDS window, at their rank in the wave tile\n" : "\n")
-    << "  gdv_uint64 fm = 0;\n"
-    << "  gdv_uint32 fcount = 0;\n";
-  if (win)
-    for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;  // output bitmap words at wave-local bit positions\n";
-  s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
-  row_prologue();
+    << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
+  row_prologue("");
   if (!win) s << "      const bool fsel = true;  // (the predicate itself runs on every live row)\n      (void)fsel;\n";
   s << cond_body;
   if (win) {
@@ -3048,21 +3062,15 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
       << "      const int slot = (int)run + below;  // this lane's rank among the wave tile's selected rows\n"
       << "      const bool fwin = fsel && slot < GDV_FP_CAP;\n"
       << "      (void)cnt; (void)below; (void)slot; (void)fwin;\n";
-    if (index_mode != SelectionMode::kNone) s << "      if (fwin) widx[slot] = (" << SelCType(index_mode) << ")row;\n";
+    if (with_index) s << "      if (fwin) widx[slot] = (" << sel_t << ")row;\n";
     s << proj_body;
   }
-  s << "    }\n  }\n"
-    << "  // ---- phase 3: output base of this wave: the workgroup's waves meet in LDS, wave 0 looks back\n"
+  s << "    }\n  }\n";
+  if (win) s << "  }  // round\n";
+  s << "  // ---- phase 3: output base of this wave: the workgroup's waves meet in LDS, wave 0 looks back\n"
     << "  if (lane == 0) wg_cnt[wave] = fcount;\n"
-    << "  __syncthreads();\n";
-  if (pipe) {
-    s << "  const gdv_int64 tile_next = tile + tile_step;\n"
-      << "  const bool has_next = PIPE && tile_next < tile_end;  // workgroup-uniform\n"
-      << "  if (has_next) {  // the next tile's loads: in flight across the look-back and the flush below\n";
-    emit_loads("tile_next", "    ");
-    s << "  }\n";
-  }
-  s << "  gdv_uint32 before = 0, wg_total = 0;\n"
+    << "  __syncthreads();\n"
+    << "  gdv_uint32 before = 0, wg_total = 0;\n"
     << "#pragma unroll\n  for (int w = 0; w < GDV_WAVES; w++) {\n"
     << "    const gdv_uint32 cw = wg_cnt[w];\n"
     << "    wg_total += cw;\n"
@@ -3072,11 +3080,11 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
     << (opts.fp_experiment == 1
             // EXPERIMENT (GDV_FP_EXPERIMENT=1, never the product: the outputs land at the tile's own first row): what the
             // kernel costs WITHOUT the look-back — every workgroup tile takes tile x rows-per-tile as its base
-            ? "    const gdv_uint64 e = (gdv_uint64)tile * (GDV_WAVES * GDV_U * 64); (void)wg_total;\n"
+            ? "    const gdv_uint64 e = (gdv_uint64)tile * (GDV_WAVES * GDV_FP_K * GDV_U * 64); (void)wg_total;\n"
             : "    const gdv_uint64 e = gdv_fp_lookback(A.mask, tile, wg_total, lane, A.err);\n")
     << "    if (lane == 0) {\n"
     << "      *wg_excl = e;\n"
-    << "      if (tile == ntiles - 1) *(gdv_int64*)A.counts = (gdv_int64)(e + wg_total);  // the batch's selected-row count\n"
+    << "      if (tile == (gdv_int64)gridDim.x - 1) *(gdv_int64*)A.counts = (gdv_int64)(e + wg_total);  // the batch's selected-row count\n"
     << "    }\n"
     << "  }\n"
     << "  __syncthreads();\n"
@@ -3088,67 +3096,48 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
       << "  for (int i = lane; i < in_window; i += 64) {\n";
     for (size_t e = 0; e < plan->output_types.size(); e++)
       if (plan->output_types[e].id != kBool) s << "    " << st << "(out" << e << ", pos0 + i, win" << e << "[i]);\n";
-    if (index_mode != SelectionMode::kNone) s << "    " << st << "(selv, pos0 + i, widx[i]);\n";
+    if (with_index) s << "    " << st << "(selv, pos0 + i, widx[i]);\n";
     s << "  }\n"
-      << "  // ---- rows beyond the window (a wave tile that selected more than GDV_FP_CAP rows): their sub-tiles are read\n"
-      << "  //      again, one at a time, and the values stored directly\n"
+      << "  // ---- a wave tile that selected more than GDV_FP_CAP rows: its rows are read AGAIN, one sub-tile at a time, the\n"
+      << "  //      predicate is evaluated again and the rows beyond the window are stored directly (bits were all appended above)\n"
       << "  if (fcount > (gdv_uint32)GDV_FP_CAP) {\n"
       << "    gdv_uint32 run = 0;\n"
-      << "#pragma unroll 1\n    for (int u = 0; u < GDV_U; u++) {\n"
-      << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
-      << "      const int cnt = (int)__popcll(fmu);\n"
-      << "      if (run + (gdv_uint32)cnt > (gdv_uint32)GDV_FP_CAP) {\n";
-    // (the tile's bitmap words are fetched again: under PIPE the registers hold the NEXT tile's by now)
+      << "#pragma unroll 1\n    for (int kb = 0; kb < GDV_FP_K; kb++) {\n"
+      << "    const gdv_int64 wbase = wfirst + kb * GDV_U;\n"
+      << "    const gdv_int64 rbase = wbase * 64;\n";
     for (int k = 0; k < nin; k++) {
       const DataType& t = schema[plan->input_fields[k]].type;
-      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 dwt" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 vwt" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
+      if (t.id == kBool && cg.needs_values_[k]) s << "    const gdv_uint64 dwt" << k << " = gdv_bitmap_tile(A.in[" << k << "].bits, wbase, lane, GDV_U);\n";
+      if (cg.needs_validity_[k]) s << "    const gdv_uint64 vwt" << k << " = gdv_bitmap_tile(A.in[" << k << "].valid, wbase, lane, GDV_U);\n";
     }
-    // (indentation of the generated body is that of the unrolled loops; harmless)
-    s << "      const gdv_int64 row = rbase + u * 64 + lane;\n"
-      << "      const bool live = FULL || row < n;\n"
-      << "      const gdv_uint64 livemask = FULL ? ~0ull : __ballot(live);\n"
-      << "      (void)livemask; (void)row; (void)live;\n";
+    s << "#pragma unroll 1\n    for (int u = 0; u < GDV_U; u++) {\n";
+    row_prologue("t");
     for (int k = 0; k < nin; k++) {
       const DataType& t = schema[plan->input_fields[k]].type;
-      if (t.id == kBool && cg.needs_values_[k]) s << "      const gdv_uint64 d" << k << " = gdv_tile_word(dwt" << k << ", u);\n";
-      if (cg.needs_validity_[k]) s << "      const gdv_uint64 v" << k << " = gdv_tile_word(vwt" << k << ", u);\n";
       if (t.id != kBool && cg.needs_values_[k])
-        s << "      const gdv_one<" << t.CType() << "> c" << k << "{live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0};  // (shadows the tile's registers)\n";
+        s << "      const gdv_one<" << t.CType() << "> c" << k << "{live ? gdv_ld(in" << k << ", row) : (" << t.CType() << ")0};  // (answers c" << k << "[u])\n";
     }
-    s << "      const bool fsel = (fmu >> lane) & 1;\n"
-      << "      const int below = gdv_rank_below(fmu);\n"
-      << "      const int slot = (int)run + below;\n"
-      << "      const bool ftail = fsel && slot >= GDV_FP_CAP;\n"
-      << "      const gdv_int64 opos = pos0 + slot;\n"
-      << "      (void)opos; (void)below; (void)ftail;\n";
-    if (index_mode != SelectionMode::kNone) s << "      if (ftail) selv[opos] = (" << SelCType(index_mode) << ")row;\n";
     s << tail_body
-      << "      }\n"
-      << "      run += (gdv_uint32)cnt;\n"
-      << "    }\n  }\n";
+      << "    }\n    }\n  }\n";
   } else {
     s << "  // ---- phase 4: the projections of the selected rows, stored compacted\n"
       << "  gdv_int64 run = 0;\n";
     for (size_t k = 0; k < bitmap_of.size(); k++) s << "  gdv_uint64 bacc" << k << " = 0;\n";
     s << "#pragma unroll\n  for (int u = 0; u < GDV_U; u++) {\n    {\n";
-    row_prologue();
+    row_prologue("");
     s << "      const gdv_uint64 fmu = gdv_tile_word(fm, u);\n"
       << "      const int cnt = (int)__popcll(fmu);\n"
       << "      const bool fsel = (fmu >> lane) & 1;\n"
       << "      const int below = gdv_rank_below(fmu);\n"
       << "      const gdv_int64 opos = pos0 + run + below;  // where this lane's row lands if it is selected\n"
       << "      (void)opos; (void)cnt; (void)below;\n";
-    if (index_mode != SelectionMode::kNone)
-      s << "      if (fsel) selv[opos] = (" << SelCType(index_mode) << ")row;\n";
+    if (with_index) s << "      if (fsel) selv[opos] = (" << sel_t << ")row;\n";
     s << proj_body
       << "      run += cnt;\n"
       << "    }\n  }\n";
   }
   for (auto& f : flushes) s << f;
-  if (pipe) s << "  if (!has_next) break;\n  tile = tile_next;\n";
-  else s << "  break;\n";
-  s << "  }\n}\n\n"
+  s << "}\n\n"
     << "extern \"C\" __global__ void __launch_bounds__(GDV_WAVES * 64) GDV_KERNEL_NAME(const gdv_args A) {\n"
     << "  __shared__ gdv_uint32 wg_cnt[GDV_WAVES];\n"
     << "  __shared__ gdv_uint64 wg_excl;\n";
@@ -3159,32 +3148,18 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
         s << "  __shared__ " << plan->output_types[e].CType() << " win" << e << "[GDV_WAVES * GDV_FP_CAP];\n";
         win_args += ", win" + std::to_string(e) + " + wave * GDV_FP_CAP";
       }
-    if (index_mode != SelectionMode::kNone) {
-      s << "  __shared__ " << SelCType(index_mode) << " widx[GDV_WAVES * GDV_FP_CAP];\n";
+    if (with_index) {
+      s << "  __shared__ " << sel_t << " widx[GDV_WAVES * GDV_FP_CAP];\n";
       win_args += ", widx + wave * GDV_FP_CAP";
     }
   }
   s << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
-    ;
-  if (pipe)
-    s << "  // persistent workgroups (the launch is sized to what the device holds at once): workgroup b takes the full tiles\n"
-      << "  // b, b + gridDim.x, ... — neighbours in time are neighbours in the batch, so a look-back never reaches far — and\n"
-      << "  // the batch's partial last tile, if there is one, goes to the workgroup whose turn it would be, unpipelined\n"
-      << "  const gdv_int64 tile_rows = GDV_WAVES * GDV_U * 64;\n"
-      << "  const gdv_int64 ntiles_full = GDV_ROWS(A) / tile_rows, ntiles = (GDV_ROWS(A) + tile_rows - 1) / tile_rows;\n"
-      << "  // (workgroup-uniform branches: the barriers inside are reached by every wave of the workgroup)\n"
-      << "  if ((gdv_int64)blockIdx.x < ntiles_full)\n"
-      << "    gdv_fused_tile<true, true>(A, (gdv_int64)blockIdx.x, (gdv_int64)gridDim.x, ntiles_full, ntiles, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
-      << "  if (ntiles > ntiles_full && ntiles_full % (gdv_int64)gridDim.x == (gdv_int64)blockIdx.x)\n"
-      << "    gdv_fused_tile<false, false>(A, ntiles_full, 0, 0, ntiles, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
-      << "}\n";
-  else
-    s << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_U x 64 rows; index order = row order\n"
-      << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
-      << "  if ((tile + 1) * (GDV_WAVES * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true, false>(A, tile, 0, 0, (gdv_int64)gridDim.x, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
-      << "  else gdv_fused_tile<false, false>(A, tile, 0, 0, (gdv_int64)gridDim.x, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
-      << "}\n";
+    << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_FP_K x GDV_U x 64 rows; index order = row order\n"
+    << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
+    << "  if ((tile + 1) * (GDV_WAVES * GDV_FP_K * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+    << "  else gdv_fused_tile<false>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
+    << "}\n";
   std::string text = s.str();
   uint64_t h = Fnv1a(HashableSource(text) + LibraryTag(text));
   char name[64];
@@ -3195,7 +3170,7 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   plan->source = text;
   plan->ir = text;
   plan->fp_window_rows = cap;
-  plan->fp_persistent = pipe;
+  plan->fp_rounds = rounds;
   return Status::OK();
 }
 }  // namespace
@@ -3218,8 +3193,7 @@ Status PlanFilterProject(const Schema& schema, const ExpressionPtr& condition, c
   GDV_RETURN_NOT_OK(PlanFilterProjectShape(schema, condition, exprs, index_mode, opts, FpShape::kDirect, direct.get()));
   if (opts.fp_window_bytes > 0) {
     KernelPlan windowed;
-    Status st = PlanFilterProjectShape(schema, condition, exprs, index_mode, opts,
-                                       opts.fp_pipeline ? FpShape::kPipelined : FpShape::kWindow, &windowed);
+    Status st = PlanFilterProjectShape(schema, condition, exprs, index_mode, opts, FpShape::kWindow, &windowed);
     // the engine launches either kernel with the windowed plan's argument block: the direct plan's literals and
     // constant block must be a prefix of it (they are: the windowed body generates the same trees first, then the
     // tail's copies) — if that ever stops holding, the plan keeps the direct shape alone

@@ -49,8 +49,8 @@ struct CodegenOptions {
   bool rows_word = false;
   // Fused filter-project, windowed shape (round 5): bytes of LDS window per wave tile (every windowed output + the
   // row index, GDV_FP_CAP rows of them); 0 = the direct round-4 shape only.  GDV_FP_WINDOW=<bytes>.
-  int fp_window_bytes = 6144;
-  bool fp_pipeline = true;             // GDV_FP_PIPELINE=0: the windowed shape one tile per workgroup (no persistent loop)
+  int fp_window_bytes = 9984;
+  int fp_rounds = 3;                   // GDV_FP_K: rounds of GDV_U sub-tiles per wave tile of the windowed shape (one look-back per K x 8192 rows)
   int fp_experiment = 0;               // GDV_FP_EXPERIMENT=<n>: timing experiments on the fused kernel (wrong results; tools only)
   bool no_sel_wave = false;            // GDV_NO_SEL_WAVE=1: selection-mode var-len plans take the scanner shape (rounds 2-4)
   bool runtime_needles = false;        // GDV_RUNTIME_NEEDLES=1: wave kernels load their '%needle%' bytes instead of carrying them as immediates
@@ -116,7 +116,7 @@ struct KernelPlan {
   std::shared_ptr<KernelPlan> exact;
   std::shared_ptr<KernelPlan> prepass;
   std::vector<int> wave_segments;
-  bool fp_persistent = false;  // fused filter-project, pipelined shape: the launch is sized to the workgroups resident at once
+  int fp_rounds = 1;  // fused filter-project: rounds of `subtiles` sub-tiles per wave tile (windowed shape: GDV_FP_K; direct: 1)
   int fp_window_rows = 0;  // fused filter-project, windowed shape: GDV_FP_CAP (0: the direct shape); `exact` = the direct shape
   int general_subtiles = 0, general_waves = 0;  // tile of the scanner-shaped fallback (0: opts')
   int rows_per_tile() const { return 64 * opts.subtiles * (wave_tiles ? 1 : opts.waves); }

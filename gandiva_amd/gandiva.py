@@ -1036,7 +1036,7 @@ class FilterProject:
         return _capi.take_string(_capi.lib().gdv_filter_project_dump_ir(self._h))
 
     def set_tuning(self, key, value):
-        """gdv_filter_project_set_tuning: "max_workgroups" (bound of the persistent launch), "kernel" (-1 / 0 / 1)."""
+        """gdv_filter_project_set_tuning: "kernel" (-1 follow the selectivity / 0 windowed / 1 direct)."""
         if self._h is not None:
             _check(_capi.lib().gdv_filter_project_set_tuning(self._h, key.encode(), int(value)))
 

@@ -362,7 +362,8 @@ int gdv_filter_project_evaluate(const gdv_filter_project_t* fp, int64_t num_rows
                                 int mem_kind, void* stream, uint32_t flags);
 char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp);
 /* Round 5.  The fused plan has two kernels: the WINDOWED one (selected rows are staged, at their rank, in a
- * wave-private LDS window and leave with full-width stores once the look-back has returned the output base) and
+ * wave-private LDS window and leave with full-width stores once the look-back has returned the output base; a wave
+ * tile is three rounds of loads, so the look-back is paid once per 24576 rows) and
  * the DIRECT one of round 4 (values held in registers across the look-back, stored from there).  Synchronous
  * evaluations record the share of rows they selected; beyond what the window holds the next batches run on the
  * direct kernel, and come back when the share drops.  Returns 0 = windowed next, 1 = direct next, -1 = the plan has
@@ -371,10 +372,7 @@ char* gdv_filter_project_dump_ir(const gdv_filter_project_t* fp);
  * filter + selection-mode projector chain (round 4: ExecutionError); under GDV_EVAL_ASYNC *num_selected_device
  * then receives -1 — evaluate the batch with the synchronous call. */
 int gdv_filter_project_kernel_shape(const gdv_filter_project_t* fp);
-/* "max_workgroups" (0 = as many as the device holds at once): the windowed kernel runs PERSISTENT workgroups — each
- * walks tiles b, b + launch, ... with the next tile's loads in flight across the look-back — and this bounds the
- * launch (tests; deployments that share the device between streams).  "kernel": -1 follow the selectivity
- * (default), 0 / 1 pin the windowed / the direct kernel. */
+/* "kernel": -1 follow the selectivity (default), 0 / 1 pin the windowed / the direct kernel (tests, measurements). */
 int gdv_filter_project_set_tuning(gdv_filter_project_t* fp, const char* key, int64_t value);
 void gdv_filter_project_free(gdv_filter_project_t* fp);
 

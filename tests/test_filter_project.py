@@ -276,7 +276,8 @@ def test_the_plan_carries_both_shapes_and_the_direct_one_takes_the_windowed_argu
     texts = [open(tmp_path / "a" / f).read() for f in files]
     win = [t for t in texts if "GDV_FP_CAP" in t]
     assert len(win) == 1 and len(texts) == 2, files
-    assert "#define GDV_FP_CAP 192" in win[0]            # 6144 bytes / (8 + 8 + 8 + 4 + 4 bytes per row) -> 192 rows
+    assert "#define GDV_FP_CAP 256" in win[0]            # 9984 bytes / (8 + 8 + 8 + 4 + 4 bytes per row) -> 256 rows
+    assert "#define GDV_FP_K 3" in win[0] and "for (int kb = 0; kb < GDV_FP_K; kb++)" in win[0]
     assert "gdv_bits_flush_local(" in win[0] and "gdv_one<" in win[0] and "win0[slot]" in win[0]
     direct = [t for t in texts if "GDV_FP_CAP" not in t][0]
     assert "gdv_bits_flush(" in direct and "out0[opos]" in direct
@@ -354,24 +355,25 @@ def test_a_stalled_launch_is_re_run_on_the_chain():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wgs", [1, 2, 3, 7])
-@pytest.mark.parametrize("n", [8192 * 4, 8192 * 9 + 5, 8192 * 23 + 8191, 300_007])
-def test_persistent_workgroups_walk_many_tiles_each(wgs, n):
-    """The pipelined shape with its launch bounded to 1 / 2 / 3 / 7 workgroups: every workgroup walks many tiles (the
-    next tile's loads in flight across the look-back), the partial last tile goes to the workgroup whose turn it is.
-    Values, validity, bool outputs and the selection vector against the oracle's chain, sparse and dense."""
-    rng = np.random.default_rng(n + wgs)
+@pytest.mark.parametrize("rounds", [1, 2, 3])
+@pytest.mark.parametrize("n", [1535, 1536, 1537, 12287, 12288, 12289, 12288 * 3 + 1536 * 5 + 77, 300_007])
+def test_wave_tiles_of_several_rounds(monkeypatch, rounds, n):
+    """The windowed kernel's wave tile is GDV_FP_K rounds of GDV_U sub-tiles (one look-back per K x 8192 rows at the
+    C3 shape; here U = 8: 512 x K rows per wave, 4096 x K per workgroup): every round / wave-tile / workgroup-tile
+    boundary, sparse (everything fits the window), medium and dense (every wave tile overflows into the re-read
+    path) selections; values, validity, bool outputs and the selection vector against the oracle's chain."""
+    monkeypatch.setenv("GDV_FP_K", str(rounds))
+    rng = np.random.default_rng(n + rounds)
     batch = _batch(rng, n, 0.1)
     for thr, dtype in ((870, "int32"), (300, None), (-1, "int64")):
         cond, exprs = _plan(batch.schema, thr)
         fp = gandiva.make_filter_project(batch.schema, cond, exprs, dtype)
-        fp.set_tuning("max_workgroups", wgs)
-        fp.set_tuning("kernel", 0)            # stay on the windowed / pipelined kernel whatever the batch selects
-        assert fp.kernel_shape == 0
+        fp.set_tuning("kernel", 0)            # stay on the windowed kernel whatever the batch selects
+        assert fp.kernel_shape == 0 and f"#define GDV_FP_K {rounds}" in fp.llvm_ir
         for rep in range(2):
             got, sel = fp.evaluate(batch)
             want_sel, want = _chain(cond, exprs, batch, dtype)
             if dtype is not None:
                 assert sel.to_array().equals(want_sel), (thr, rep)
             for e, (g, w) in enumerate(zip(got, want)):
-                assert_bit_exact(g, w, f"threshold {thr}, expression {e}, {wgs} workgroups, run {rep}")
+                assert_bit_exact(g, w, f"threshold {thr}, expression {e}, {rounds} rounds, run {rep}")

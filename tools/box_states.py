@@ -54,20 +54,24 @@ for r in range(rounds):
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
 
-# one big block, 2 MiB-aligned carving
-def carve(total_views):
-    sizes = [(_s + (1 << 21) - 1) & ~((1 << 21) - 1) for _s in total_views]
-    block = torch.empty(sum(sizes) + (1 << 21), dtype=torch.uint8, device="cuda")
-    base = block.data_ptr()
-    off = (-base) % (1 << 21)
+# one big block, carved by hand: buffer i starts at a 2 MiB boundary + i * stagger bytes.  stagger = 0: every stream
+# shares its low 21 address bits with every other (what torch's allocator gives for large tensors); a stagger
+# de-phases the 14 + 10 concurrently advancing streams in the bits a channel / bank hash may use.
+def carve(total_views, stagger):
+    slot = [((_s + stagger * len(total_views) + (1 << 21) - 1) & ~((1 << 21) - 1)) for _s in total_views]
+    block = torch.empty(sum(slot) + (1 << 21), dtype=torch.uint8, device="cuda")
+    off = (-block.data_ptr()) % (1 << 21)
     views = []
-    for sz, want in zip(sizes, total_views):
-        views.append(block[off:off + want])
+    for i, (sz, want) in enumerate(zip(slot, total_views)):
+        a = off + i * stagger
+        views.append(block[a:a + want])
         off += sz
     return block, views
 
 
+staggers = [int(x) for x in os.environ.get("STAGGERS", "0,256,4352,69888").split(",")] if carve_rounds else []
 for r in range(carve_rounds):
+  for stagger in staggers:
     src = make_inputs_torch()
     need = []
     for c in src.columns:
@@ -75,7 +79,7 @@ for r in range(carve_rounds):
     vb = (n + 63) // 64 * 8
     for _ in range(10):
         need += [n * 8, vb]
-    block, views = carve(need)
+    block, views = carve(need, stagger)
     cols = []
     for k, c in enumerate(src.columns):
         views[2 * k].copy_(c.data)
@@ -85,7 +89,6 @@ for r in range(carve_rounds):
     torch.cuda.empty_cache()
     db = gandiva.DeviceBatch(W.c2_schema(), cols, n)
     outs = [gandiva.DeviceColumn(pa.float64(), n, views[8 + 2 * e + 1], views[8 + 2 * e]) for e in range(10)]
-    time_round(db, outs, f"carved round {r} (one block, 2 MiB-aligned sub-buffers)")
-    time_round(db, outs, f"carved round {r} again")
+    time_round(db, outs, f"carved round {r}, stagger {stagger:6d} B")
     del db, outs, cols, views, block
     torch.cuda.empty_cache()

@@ -38,22 +38,16 @@ def condition(k2):
                                         b.make_function("less_than", [f[1], b.make_literal(k2, pa.int64())], pa.bool_())]))
 
 
-VARIANTS = [("direct (round 4)   U16 W8", {"GDV_FP_WINDOW": "0"}),
-            ("window 6144        U16 W8", {"GDV_FP_PIPELINE": "0"}),
-            ("window 6144        U16 W4", {"GDV_WAVES": "4", "GDV_FP_PIPELINE": "0"}),
-            ("window 3072        U16 W8", {"GDV_FP_WINDOW": "3072", "GDV_FP_PIPELINE": "0"}),
-            ("window 6144        U8  W8", {"GDV_U": "8", "GDV_FP_PIPELINE": "0"}),
-            ("window 6144        U8  W16", {"GDV_U": "8", "GDV_WAVES": "16", "GDV_FP_PIPELINE": "0"}),
-            ("window 12288       U16 W8", {"GDV_FP_WINDOW": "12288", "GDV_FP_PIPELINE": "0"}),
-            ("direct (round 4)   U16 W4", {"GDV_FP_WINDOW": "0", "GDV_WAVES": "4"}),
-            ("window, NO look-back U16 W8", {"GDV_FP_EXPERIMENT": "1", "GDV_FP_PIPELINE": "0"}),
-            ("direct, NO look-back U16 W8", {"GDV_FP_EXPERIMENT": "1", "GDV_FP_WINDOW": "0"}),
-            ("window, NO look-back U16 W4", {"GDV_FP_EXPERIMENT": "1", "GDV_WAVES": "4", "GDV_FP_PIPELINE": "0"}),
-            ("PIPELINED window   U16 W8", {}),
-            ("PIPELINED window   U16 W4", {"GDV_WAVES": "4"}),
-            ("PIPELINED 12288    U16 W8", {"GDV_FP_WINDOW": "12288"}),
-            ("PIPELINED, NO look-back W8", {"GDV_FP_EXPERIMENT": "1"}),
-            ("PIPELINED window   U8  W8", {"GDV_U": "8"})]
+VARIANTS = [("direct (round 4)      U16 W8", {"GDV_FP_WINDOW": "0"}),
+            ("window, K=1          U16 W8", {"GDV_FP_K": "1"}),
+            ("window, K=2          U16 W8", {"GDV_FP_K": "2"}),
+            ("window, K=3 (default)      ", {}),
+            ("window, K=3          U16 W4", {"GDV_WAVES": "4"}),
+            ("window, K=3, 6 KB window   ", {"GDV_FP_WINDOW": "6144"}),
+            ("window, K=1, NO look-back  ", {"GDV_FP_K": "1", "GDV_FP_EXPERIMENT": "1"}),
+            ("window, K=3, NO look-back  ", {"GDV_FP_EXPERIMENT": "1"}),
+            ("window, K=7          U8  W8", {"GDV_FP_K": "7", "GDV_U": "8", "GDV_FP_WINDOW": "12288"}),
+            ("window, K=3          U16 W16", {"GDV_WAVES": "16", "GDV_FP_WINDOW": "4992"})]
 only = os.environ.get("FP_VARIANTS")
 for k2 in k2s:
     flt = gandiva.make_filter(W.c3_schema(), condition(k2))
@@ -62,7 +56,7 @@ for k2 in k2s:
     for vi, (label, env) in enumerate(VARIANTS):
         if only and str(vi) not in only.split(","):
             continue
-        for k in ("GDV_FP_WINDOW", "GDV_U", "GDV_WAVES", "GDV_FP_EXPERIMENT", "GDV_FP_PIPELINE"):
+        for k in ("GDV_FP_WINDOW", "GDV_U", "GDV_WAVES", "GDV_FP_EXPERIMENT", "GDV_FP_K"):
             os.environ.pop(k, None)
         os.environ.update(env)
         row = []
