@@ -6,9 +6,12 @@
 # in-process multi-device runs; round 4: the fused filter-project, C5 on non-ASCII columns, C4 run
 # three times plain and three times under rocprofv3 on this one box (the 9 % gap of round 3).
 # Raw output: gpurun_out/<round>/ ; condensed into profiles/ by tools/summarize_round.py <round>.
-#      ROUND=r04 bash tools/gpu_evidence.sh
+#      ROUND=r05 bash tools/gpu_evidence.sh
+# Round 5: + the filter -> string-projection chain (selection-mode wave kernels), the fused filter-project's shapes side by
+# side; the C4 plain / rocprof repeats are gone (the "two box states" are diagnosed: profiles/r05_box_states.txt) and the
+# counter passes run on ONE placement (--placements 1: counters are per launch, the placement search only adds launches).
 export TMPDIR=/tmp
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$ROUND; rm -rf $OUT; mkdir -p $OUT
 cd $R
@@ -23,17 +26,13 @@ for w in c3 c4 c5; do python bench.py --workload $w --steps 3 --warmup 1 > $OUT/
 cd /tmp
 for w in c2 c3 c4 c5; do
   rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o $w --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline --no-verify > $OUT/prof_${w}_bench.json 2> /dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
 done
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_c5_$tag -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_c5_$tag -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --placements 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
 done
-# C4: the same command three times plain and three times under rocprofv3, back to back on this box
-{ for i in 1 2 3; do python $R/bench.py --workload c4 --no-cpu-baseline --no-verify 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('plain   run $i: ms_per_step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'min', r['kernel_ms_min'], 'max', r['kernel_ms_max'], 'sclk', r['box'].get('sclk_mhz'))"; done
-  for i in 1 2 3; do rocprofv3 --kernel-trace --stats -d $OUT/c4rep_$i -o c4 --output-format csv -- python $R/bench.py --workload c4 --no-cpu-baseline --no-verify 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); r=d['roofline']; print('rocprof run $i: ms_per_step', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], 'sclk', r['box'].get('sclk_mhz'))"
-    grep '^"gdv_k_' $(find $OUT/c4rep_$i -name "*kernel_stats.csv" | head -1) | awk -F, '{printf "          rocprofv3 average of %s: %.4f ms over %s calls\n", $1, $4/1e6, $2}'; done; } > $OUT/c4_repeat.txt 2>&1
 cd $R
 python tools/make_latency.py > $OUT/make_latency.txt 2>&1
 [ -x tools/hbm_ceiling ] && timeout 120 tools/hbm_ceiling > $OUT/hbm_ceiling.txt 2>&1
@@ -43,6 +42,9 @@ PYTHONPATH=$R timeout 60 python tools/flat_only_timing.py > $OUT/flat_only_plans
 PYTHONPATH=$R timeout 120 python tools/registry_tail_timing.py > $OUT/registry_tail_timing.txt 2>&1
 PYTHONPATH=$R timeout 200 python tools/filter_project_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_project_chain.txt
 PYTHONPATH=$R timeout 200 python tools/fused_fp_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_project.txt
+FP_VARIANTS=0,1,3,7 PYTHONPATH=$R timeout 300 python tools/fused_fp_sweep.py 1000000000 250 60 2>&1 | grep -v amdgpu.ids > $OUT/filter_project_shapes.txt
+PYTHONPATH=$R timeout 200 python tools/filter_string_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_string_chain.txt
+GDV_NO_SEL_WAVE=1 PYTHONPATH=$R timeout 200 python tools/filter_string_chain.py 2>&1 | grep -v amdgpu.ids | sed 's/^/[scanner shape, rounds 2-4] /' >> $OUT/filter_string_chain.txt
 # the fused kernel's HBM traffic against the chain's (two --pmc passes) and its rocprofv3 kernel stats
 timeout 300 bash tools/fused_fp_traffic.sh $OUT/fp_traffic > /dev/null 2>&1; cp $OUT/fp_traffic/fp_traffic.txt $OUT/filter_project_traffic.txt 2>/dev/null
 ( cd /tmp; rocprofv3 --kernel-trace --stats -d $OUT/prof_fp -o fp --output-format csv -- python $R/tools/fused_fp_timing.py > /dev/null 2>&1 )

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import summarize_prof as SP  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles")
 
@@ -60,7 +60,7 @@ if acc:
 for name in ("make_latency.txt", "micro_benchmarks.txt", "latency_sweep.txt", "smoke.log", "hbm_ceiling.txt",
              "small_batches.txt", "registry_tail_timing.txt", "flat_only_plans.txt", "inproc_bench.txt", "multi_device.txt",
              "c5_variants.txt", "filter_project_chain.txt", "filter_project.txt", "c5_nonascii.txt", "c4_repeat.txt",
-             "bench_two_ranks.txt", "filter_project_traffic.txt"):
+             "bench_two_ranks.txt", "filter_project_traffic.txt", "filter_project_shapes.txt", "filter_string_chain.txt"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, ROUND + "_" + name))
@@ -71,4 +71,36 @@ p = os.path.join(SRC, "pytest_gpu_full.log")
 if os.path.exists(p):
     lines = [l for l in open(p) if "passed" in l or "failed" in l or l.startswith(("FAILED", "ERROR"))]
     open(os.path.join(DST, ROUND + "_pytest_gpu_summary.txt"), "w").writelines(lines[-10:])
+
+# ---- one table for DESIGN.md §4: bench line + rocprofv3 kernel stats + PMC traffic per workload
+def kernel_rows(path):
+    out = []
+    if path and os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            if r["Name"].startswith("gdv_k_") or r["Name"].startswith("void gdv::") or "gdv::" in r["Name"]:
+                out.append((r["Name"][:24], int(r["Calls"]), float(r["AverageNs"]) / 1e6))
+    return out
+
+
+with open(os.path.join(DST, ROUND + "_summary.md"), "w") as f:
+    f.write(f"<!-- written by tools/summarize_round.py {ROUND} from gpurun_out/{ROUND} (one run of tools/gpu_evidence.sh) -->\n")
+    f.write("| workload | ms / Evaluate (bench) | kernel_ms (HIP events) | rocprofv3 averages of the same command | rows/s | achieved | frac of 8 TB/s | frac of measured ceiling | PMC traffic / algorithmic | placement trials (ms) |\n|---|---|---|---|---|---|---|---|---|---|\n")
+    for w in ("c2", "c3", "c4", "c5", "c1"):
+        b = os.path.join(DST, f"{ROUND}_{w}_bench.json")
+        if not os.path.exists(b):
+            continue
+        try:
+            d = json.loads([l for l in open(b) if l.startswith("{")][-1])
+        except Exception:
+            continue
+        r = d["roofline"]
+        ks = kernel_rows(os.path.join(DST, f"{ROUND}_{w}_kernel_stats.csv"))
+        ks = ", ".join(f"{n} {a:.3f} ms x{c}" for n, c, a in ks if a > 0.004) or "-"
+        pm = os.path.join(DST, f"{ROUND}_pmc_{w}.json")
+        tr = "-"
+        if os.path.exists(pm):
+            pj = json.load(open(pm))
+            tr = f"{pj['traffic_over_algorithmic']:.4f} x (on {pj['kernel'][:22]})"
+        f.write(f"| {w.upper()} ({d['config'].get('workload', '')[:60]}) | {d['ms_per_step']} | {r['kernel_ms']} (min {r['kernel_ms_min']}, max {r['kernel_ms_max']}) on {r['kernel_name']} | {ks} | "
+                f"{d['value'] / 1e3:.1f} G | {r['achieved'] / 1e3:.2f} TB/s | {r['frac']} | {r.get('frac_of_measured_ceiling', '-')} | {tr} | {r.get('placement_trials_ms') or '-'} |\n")
 print(sorted(os.listdir(DST)))
