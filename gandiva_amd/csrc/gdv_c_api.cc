@@ -202,7 +202,7 @@ gdv_node_t* gdv_node_function(const char* name, gdv_node_t* const* children, int
   if (!name) return FailPtr<gdv_node_t>("function name is null");
   if (!ToType(return_type, &t)) return FailPtr<gdv_node_t>("unsupported return type id");
   if (!CollectChildren(children, num_children, &kids)) return FailPtr<gdv_node_t>("null child node");
-  return new gdv_node{std::make_shared<FunctionNode>(name, std::move(kids), t)};
+  return new gdv_node{MakeFunctionNode(name, std::move(kids), t)};
   });
 }
 

@@ -1073,6 +1073,8 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 #define GDV_MAP_REVERSE 4
 #define GDV_MAP_DIGITS 8
 #define GDV_MAP_REPLACE 16  // `lim` points at a replace table (constant block), flags >> 2 = source length
+#define GDV_MAP_INITCAP 32  // round 5: the view's bytes with every word's first letter in upper case, the others in lower case
+#define GDV_MAP_SPECIAL (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE | GDV_MAP_INITCAP)  // only the output copy reads these
 // GDV_MAP_DIGITS with GDV_STR_DECIMAL in `flags` (round 4): the text of the decimal128 whose low / high
 // words sit in `p` / `lim`, scale = flags >> 8, cut to `len` bytes (castVARCHAR(decimal, n))
 #define GDV_STR_DECIMAL 128
@@ -1394,9 +1396,37 @@ GDV_DEV void gdv_copy_replaced(P dst, const gdv_str& s) {
     }
   }
 }
+// initcap [recalled: string_ops.cc initcap_utf8 — "any character is considered as space, except if it is
+// alphanumeric"]: a letter that follows a non-alphanumeric character (or starts the text) goes to upper case, every other
+// letter to lower case; digits are word characters.  ASCII only: bytes >= 0x80 are copied as they are and count as
+// word characters (upstream maps them through utf8proc — stated in the oracle's recollection list).  The length of the
+// text does not change.
+template <typename P>
+GDV_DEV void gdv_copy_initcap(P dst, const gdv_str& s) {
+  const gdv_int32 cm = s.map & GDV_MAP_CASE;
+  bool in_word = false;
+  for (gdv_int32 i = 0; i < s.len; i += 8) {
+    const gdv_int32 nb = s.len - i < 8 ? s.len - i : 8;
+    gdv_str plain = s;
+    plain.map = 0;
+    const gdv_uint64 w = gdv_map8(gdv_raw_word_at(plain, i), cm);
+    gdv_uint64 o = 0;
+    for (gdv_int32 j = 0; j < nb; j++) {
+      gdv_uint32 b = (gdv_uint32)(w >> (8 * j)) & 0xffu;
+      const bool lower = b - 0x61u < 26u, upper = b - 0x41u < 26u;
+      if (lower && !in_word) b -= 0x20u;
+      else if (upper && in_word) b += 0x20u;
+      in_word = lower || upper || b - 0x30u < 10u || b >= 0x80u;
+      o |= (gdv_uint64)b << (8 * j);
+    }
+    if (nb == 8) __builtin_memcpy(dst + i, &o, 8);
+    else gdv_store_low_bytes(dst + i, o, nb);
+  }
+}
 template <typename P>
 GDV_DEV void gdv_copy_special(P dst, const gdv_str& s) {
-  if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s);
+  if (s.map & GDV_MAP_INITCAP) gdv_copy_initcap(dst, s);
+  else if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s);
   else if (s.map & GDV_MAP_REPLACE) gdv_copy_replaced(dst, s);
   else gdv_copy_reversed(dst, s);
 }
@@ -1404,7 +1434,7 @@ GDV_DEV void gdv_copy_special(P dst, const gdv_str& s) {
 // overlapping store for the tail (the last 8 bytes again for len >= 8, two overlapping
 // 4-byte stores for 4..7) instead of a 4 + 2 + 1 byte ladder.
 GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
-  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE)) { gdv_copy_special(dst, s); return; }
+  if (s.map & GDV_MAP_SPECIAL) { gdv_copy_special(dst, s); return; }
   if (s.len >= 8) {
     gdv_int32 i = 0;
     for (; i + 8 <= s.len; i += 8) {
@@ -1431,7 +1461,7 @@ GDV_DEV void gdv_str_copy(gdv_uint8* dst, const gdv_str& s) {
 // One row's bytes into the wave's LDS staging window: whole words, then a 4/2/1 ladder.
 typedef __attribute__((address_space(3))) gdv_uint8 gdv_lds_u8;
 GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
-  if (s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE)) { gdv_copy_special(dst, s); return; }
+  if (s.map & GDV_MAP_SPECIAL) { gdv_copy_special(dst, s); return; }
   const gdv_int32 len = s.len;
   gdv_int32 i = 0;
   for (; i + 8 <= len; i += 8) {
@@ -1466,7 +1496,7 @@ GDV_DEV gdv_uint64 gdv_mirror_word(const gdv_lds_u8* mir, gdv_int32 d) {
 GDV_DEV void gdv_stage_copy_mir(gdv_lds_u8* dst, const gdv_str& s, const gdv_lds_u8* mir, const gdv_uint8* mbase,
                                 gdv_int32 mlen) {
   const gdv_int64 d64 = s.p - mbase;
-  if ((s.map & (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE)) || d64 < 0 || d64 + s.len > (gdv_int64)mlen) {
+  if ((s.map & GDV_MAP_SPECIAL) || d64 < 0 || d64 + s.len > (gdv_int64)mlen) {
     gdv_stage_copy(dst, s);
     return;
   }
@@ -1841,6 +1871,10 @@ GDV_DEV gdv_str reverse_utf8(gdv_ctx ctx, gdv_str s) {
     }
   }
   s.map |= GDV_MAP_REVERSE;
+  return s;
+}
+GDV_DEV gdv_str initcap_utf8(gdv_str s) {
+  s.map |= GDV_MAP_INITCAP;
   return s;
 }
 // replace(s, from, to) with literal from / to (table in the constant block): every occurrence of

@@ -285,4 +285,40 @@ void InNode::AppendKey(std::string* out) const {
   *out += ']';
 }
 
+
+namespace {
+bool PlainRegexLiteral(const std::string& t) {
+  if (t.empty()) return false;
+  for (unsigned char ch : t)
+    if (std::strchr("\\^$.|?*+()[]{}%_", ch) != nullptr || ch == 0) return false;
+  return true;
+}
+}  // namespace
+
+NodePtr MakeFunctionNode(std::string name, NodeVector children, DataType ret) {
+  auto literal_text = [&](size_t i, std::string* out) {
+    if (i >= children.size() || !children[i] || children[i]->kind() != NodeKind::kLiteral) return false;
+    auto& l = static_cast<const LiteralNode&>(*children[i]);
+    if (l.is_null() || !l.return_type().is_varlen()) return false;
+    *out = l.value().bytes;
+    return true;
+  };
+  std::string pat, to;
+  if ((name == "regexp_like" || name == "regexp_matches") && children.size() == 2 && literal_text(1, &pat)) {
+    const bool head = !pat.empty() && pat.front() == '^';
+    const bool tail = pat.size() > (head ? 1u : 0u) && pat.back() == '$';
+    const std::string lit = pat.substr(head ? 1 : 0, pat.size() - (head ? 1 : 0) - (tail ? 1 : 0));
+    if (PlainRegexLiteral(lit)) {
+      Literal v;
+      v.bytes = (head ? "" : "%") + lit + (tail ? "" : "%");
+      NodeVector kids{children[0], std::make_shared<LiteralNode>(children[1]->return_type(), v)};
+      return std::make_shared<FunctionNode>("like", std::move(kids), ret);
+    }
+  }
+  if (name == "regexp_replace" && children.size() == 3 && literal_text(1, &pat) && literal_text(2, &to) &&
+      PlainRegexLiteral(pat) && to.find('\\') == std::string::npos)
+    return std::make_shared<FunctionNode>("replace", std::move(children), ret);
+  return std::make_shared<FunctionNode>(std::move(name), std::move(children), ret);
+}
+
 }  // namespace gdv

@@ -80,6 +80,14 @@ class FunctionNode : public Node {
   NodeVector children_;
 };
 
+// Builds a function node; the REGULAR-EXPRESSION functions of the registry are taken in their literal subset
+// (round 5) and rewritten here, once, onto the matchers that exist:
+//   regexp_like / regexp_matches(s, 'lit' | '^lit' | 'lit$' | '^lit$')  ->  like(s, '%lit%' | 'lit%' | '%lit' | 'lit')
+//   regexp_replace(s, 'lit', 'to')                                      ->  replace(s, 'lit', 'to')
+// where lit is a non-empty literal without regular-expression or LIKE metacharacters and `to` holds no backslash
+// (RE2 rewrite syntax).  Anything else stays a regexp_* node, which the planner refuses with CodeGenError.
+NodePtr MakeFunctionNode(std::string name, NodeVector children, DataType ret);
+
 class IfNode : public Node {
  public:
   IfNode(NodePtr c, NodePtr t, NodePtr e, DataType ret)

@@ -599,13 +599,18 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         }
         GDV_RETURN_NOT_OK(Gen(child, active, &args[i]));
       }
+      if (fn.name().compare(0, 7, "regexp_") == 0)
+        return Status::CodeGenError("Function " + fn.ToString() + " not supported yet: the HIP backend takes regular "
+                                    "expressions in their literal subset only — regexp_like / regexp_matches with "
+                                    "'lit', '^lit', 'lit$' or '^lit$', regexp_replace with a literal pattern and a "
+                                    "replacement without backslashes (no metacharacters, no '%' or '_'). ");
       out->type = fn.return_type();
       out->vcols.clear();
       out->vlane.clear();
       out->pieces.clear();
       out->col_slot = -1;
       out->col_map = 0;
-      out->opaque = fn.name() == "reverse" || fn.name() == "replace" ||
+      out->opaque = fn.name() == "reverse" || fn.name() == "replace" || fn.name() == "initcap" ||
                     (fn.name() == "castVARCHAR" && !args[0].type.is_varlen());
       if ((fn.name() == "upper" || fn.name() == "lower") && args.size() == 1 && args[0].col_slot >= 0) {
         out->col_slot = args[0].col_slot;
@@ -2319,7 +2324,7 @@ enum class StringShape { kScanner, kWaveMain, kWavePrepass, kWaveMainExact, kWav
 bool ByteFree(const Node& n) {
   static const std::set<std::string> over_strings = {
       "substr", "substring", "left", "right", "upper", "lower", "octet_length", "bit_length", "char_length",
-      "length", "lengthUtf8", "castVARCHAR", "concat", "concatOperator", "reverse", "lpad", "rpad", "isnull",
+      "length", "lengthUtf8", "castVARCHAR", "concat", "concatOperator", "reverse", "initcap", "lpad", "rpad", "isnull",
       "isnotnull"};
   switch (n.kind()) {
     case NodeKind::kField:
@@ -3221,7 +3226,7 @@ bool MaterialisesBytes(const Node& n) {
   if (n.kind() != NodeKind::kFunction) return false;
   auto& fn = static_cast<const FunctionNode&>(n);
   const std::string& f = fn.name();
-  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse" || f == "replace")
+  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse" || f == "replace" || f == "initcap")
     return true;
   return f == "castVARCHAR" && !fn.children().empty() && !fn.children()[0]->return_type().is_varlen();
 }

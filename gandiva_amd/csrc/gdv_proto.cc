@@ -286,7 +286,7 @@ Status DecodeNode(Reader r, int depth, NodePtr* out) {
       DataType ret;
       std::string name;
       GDV_RETURN_NOT_OK(DecodeChildren(body, 2, depth, &kids, &ret, 3, &name));
-      *out = std::make_shared<FunctionNode>(name, std::move(kids), ret);
+      *out = MakeFunctionNode(name, std::move(kids), ret);
       return Status::OK();
     }
     case 6: {  // IfNode { cond = 1, then = 2, else = 3, returnType = 4 }

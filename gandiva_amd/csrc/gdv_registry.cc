@@ -276,6 +276,14 @@ FunctionRegistry::FunctionRegistry() {
   add("lengthUtf8", {binary()}, int32(), NullPolicy::kNullIfNull, 0, "char_length_utf8");
   add("like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
   add("like", {utf8(), utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
+  // Regular expressions (round 5), LITERAL SUBSET: gdv_node.h MakeFunctionNode rewrites regexp_like / regexp_matches
+  // with 'lit', '^lit', 'lit$', '^lit$' onto like, and regexp_replace with a literal pattern onto replace, when the
+  // tree is built; a node that is still regexp_* when it reaches the planner is refused (CodeGenError).  [recalled:
+  // the lineage evaluates these through RE2 — PartialMatch / GlobalReplace; on a metacharacter-free pattern those are
+  // contains / starts / ends / equals and left-to-right non-overlapping replace]
+  add("regexp_like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_regexp_unsupported");
+  add("regexp_matches", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_regexp_unsupported");
+  add("regexp_replace", {utf8(), utf8(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_regexp_unsupported");
   // ilike (round 4): like without regard to the case of ASCII letters — both sides are read through the
   // lower-case byte map, so every fast path of like (prefix / suffix / equality / '%needle%' answered by
   // the byte sweep) serves it.  The lineage folds case through RE2 (Unicode simple folding); letters
@@ -302,6 +310,7 @@ FunctionRegistry::FunctionRegistry() {
   add("castVARCHAR", {int32(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("castVARCHAR", {int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("reverse", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("initcap", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   add("replace", {utf8(), utf8(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext,
       "gdv_replace");  // planned by gdv_planner.cc (literal from / to)
   // lpad / rpad: planned as two pieces (gdv_planner.cc), literal length and fill only

@@ -4,6 +4,20 @@ pyarrow ships gandiva.pyx but no compiled module (the wheel is built without Gan
 `load()` builds that file against gandiva_amd's C++ API if needed
 (gandiva_amd/cxx/build_pyarrow_gandiva.py) and registers the result as `pyarrow.gandiva`, so
 existing code — `import pyarrow.gandiva as gandiva` — runs unchanged on MI355X.
+
+Quick start (host batches, the fast way).  With pyarrow's default pool every host batch is STAGED through a
+page-locked block (two memcpys + two DMA copies: 103-133 us per 16K-row batch); arrays and outputs that live in
+`host_memory_pool()` are read and written in place by the kernel (51 us):
+
+    from gandiva_amd import pyarrow_gandiva
+    gandiva = pyarrow_gandiva.load()                     # = import pyarrow.gandiva as gandiva
+    pool = pyarrow_gandiva.host_memory_pool()            # page-locked, GPU-addressable arrow MemoryPool
+    a = pa.array(values, pa.float64(), memory_pool=pool) # put the columns there (builders, IPC readers take a pool too)
+    batch = pa.RecordBatch.from_arrays([a], names=["a"])
+    proj = gandiva.make_projector(batch.schema, exprs, pool)   # outputs are allocated from `pool`
+    out, = proj.evaluate(batch)                          # nothing is staged: pyarrow_gandiva.host_staged_bytes() stays put
+
+HBM-resident batches (`gandiva_amd.DeviceBatch`, the Arrow C Device Data Interface) skip the host link altogether.
 """
 import importlib.machinery
 import importlib.util

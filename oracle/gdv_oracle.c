@@ -68,6 +68,15 @@
  *         2011-01-01): upstream's DATE_TRUNC_FIXED_UNIT / DATE_TRUNC_YEAR_UNITS macros as two independent
  *         recollections have them (rounds 3-4 floored and used year / 10 * 10).  The independent engine in
  *         tests/test_registry_tail.py checks the arithmetic of the rule, not that the rule is upstream's.
+ *       - initcap: "any character is considered as space, except if it is alphanumeric" — first letter of a word upper,
+ *         the rest lower, digits inside words; ASCII letters only: bytes >= 0x80 are copied unchanged and count as
+ *         word characters (upstream: utf8proc case mapping and categories — a DIVERGENCE for non-ASCII letters).
+ *         Checked against a regular-expression restatement in Python and, where the two rules coincide (words
+ *         without digits, ASCII), against pyarrow.compute.utf8_title.
+ *       - regexp_like / regexp_matches / regexp_replace: the lineage runs RE2 (PartialMatch / GlobalReplace); only the
+ *         LITERAL SUBSET exists here ([^]lit[$] without metacharacters; replacement without backslashes), where RE2's
+ *         semantics are contains / starts / ends / equals and left-to-right non-overlapping replace — checked against
+ *         Python's re.  regexp_replace inherits replace's 65535-byte result cap (RE2 has none).
  *
  * Program format (whitespace separated, prefix order):
  *   F <col>                               field: column index
@@ -794,6 +803,19 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       } else if (!strcmp(f, "like")) {
         int esc = n->nargs == 3 ? a[2].sp[i][0] : -1;
         out->v[i].i = like_match(x, xl, xm, y, yl, esc);
+      } else if (!strcmp(f, "regexp_like") || !strcmp(f, "regexp_matches")) {
+        /* [recalled: RE2::PartialMatch(text, pattern)] in the LITERAL SUBSET the backend takes: pattern = [^]lit[$],
+         * lit free of metacharacters -> contains / starts with / ends with / equals.  Anything else: error 4. */
+        int head = yl > 0 && y[0] == '^', tail = yl > head && y[yl - 1] == '$';
+        const uint8_t* lit = y + head; int ll = yl - head - tail, plain = ll > 0;
+        for (int k = 0; k < ll; k++) plain = plain && strchr("\\^$.|?*+()[]{}%_", lit[k]) == NULL && lit[k] != 0;
+        if (!plain) { if (out->valid[i]) c->err |= 4; out->v[i].i = 0; continue; }
+        int hit = 0;
+        if (head && tail) hit = xl == ll && str_cmp(x, xl, xm, lit, ll, ym) == 0;
+        else if (head) hit = ll <= xl && str_cmp(x, ll, xm, lit, ll, ym) == 0;
+        else if (tail) hit = ll <= xl && str_cmp(x + (xl - ll), ll, xm, lit, ll, ym) == 0;
+        else for (int k = 0; k + ll <= xl && !hit; k++) hit = str_cmp(x + k, ll, xm, lit, ll, ym) == 0;
+        out->v[i].i = hit;
       } else if (!strcmp(f, "ilike")) {
         /* like, ASCII letters compared without regard to case (recollection: the lineage folds through
          * RE2; letters outside ASCII compare exactly here) */
@@ -898,7 +920,31 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
         }
         out->sp[i] = dst; out->sl[i] = bad ? 0 : xl; out->sm[i] = 0;
         if (bad && live) c->err |= 4;
-      } else if (!strcmp(f, "replace")) {
+      } else if (!strcmp(f, "initcap")) {
+        /* [recalled: string_ops.cc initcap_utf8: "any character is considered as space, except if it is
+         * alphanumeric"] a letter after a non-alphanumeric character (or at the start) -> upper case, every
+         * other letter -> lower case; digits are word characters.  ASCII ONLY here: bytes >= 0x80 are copied as
+         * they are and count as word characters — upstream case-maps and classifies them through utf8proc. */
+        uint8_t* dst = arena_alloc(c, xl > 0 ? (size_t)xl : 1);
+        int in_word = 0;
+        for (int k = 0; k < xl; k++) {
+          uint8_t b = map_byte(x[k], xm);
+          int lower = b >= 'a' && b <= 'z', upper = b >= 'A' && b <= 'Z';
+          if (lower && !in_word) b = (uint8_t)(b - 32);
+          else if (upper && in_word) b = (uint8_t)(b + 32);
+          in_word = lower || upper || (b >= '0' && b <= '9') || b >= 0x80;
+          dst[k] = b;
+        }
+        out->sp[i] = dst; out->sl[i] = xl; out->sm[i] = 0;
+      } else if (!strcmp(f, "replace") || !strcmp(f, "regexp_replace")) {
+        /* (regexp_replace [recalled: RE2::GlobalReplace] in the literal subset: a metacharacter-free pattern and a
+         * replacement without backslashes — then it IS replace; anything else: error 4) */
+        if (f[1] == 'e' && f[2] == 'g') {
+          int plain = yl > 0;
+          for (int k = 0; k < yl; k++) plain = plain && strchr("\\^$.|?*+()[]{}%_", y[k]) == NULL && y[k] != 0;
+          for (int k = 0; k < a[2].sl[i]; k++) plain = plain && a[2].sp[i][k] != 92;
+          if (!plain) { if (out->valid[i]) c->err |= 4; out->sp[i] = x; out->sl[i] = 0; out->sm[i] = 0; continue; }
+        }
         /* every occurrence of `from`, left to right, not overlapping, becomes `to`; an empty text
          * or `from` returns the text; more than 65535 result bytes is an error
          * [recalled: string_ops.cc replace_with_max_len_utf8_utf8_utf8, max_length 65535] */

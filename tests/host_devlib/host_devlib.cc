@@ -209,6 +209,21 @@ unsigned host_str_reverse(const int* off, const unsigned char* data, long size, 
   }
   return err;
 }
+// initcap(s) (round 5), materialised by gdv_str_copy; map: 0 the column, 1 upper(column), 2 lower(column)
+void host_str_initcap(const int* off, const unsigned char* data, long size, long n, int map, int* out_off, unsigned char* out_data) {
+  HostCol c{off, data, size};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    if (map == 1) s = upper_utf8(s);
+    if (map == 2) s = lower_utf8(s);
+    const gdv_str r = initcap_utf8(s);
+    gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+}
 // lpad (right = 0) / rpad (right = 1): `tab` is the fill repeated to `want` characters, readable
 // 8 bytes past its end (what the planner lays out in the constant block)
 long host_str_pad(int right, const int* off, const unsigned char* data, long size, long n, int want,

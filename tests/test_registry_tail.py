@@ -11,6 +11,7 @@ import pyarrow.compute as pc
 import pytest
 
 import gandiva_amd as gandiva
+from gandiva_amd import workloads as W
 from helpers import assert_bit_exact
 from oracle import oracle
 from test_device_lib_on_host import hostlib, _raw128  # noqa: F401  (fixture)
@@ -198,3 +199,192 @@ def test_date_trunc_week_and_last_day_on_the_gpu(t):
     proj = gandiva.make_projector(batch.schema, exprs, None)
     for g, w, (name, _, _) in zip(proj.evaluate(batch), oracle.project(exprs, batch), date_cases()):
         assert_bit_exact(g, w, name)
+
+
+# ------------------------------------------------------------------ round 5: initcap
+# [recalled: string_ops.cc initcap_utf8 — "any character is considered as space, except if it is alphanumeric"]: the
+# first letter of a word in upper case, the other letters in lower case, digits are word characters.  ASCII letters
+# only on this backend (bytes >= 0x80: copied as they are, word characters — upstream maps them through utf8proc: a
+# stated divergence, oracle header).  Second engines: a regular-expression restatement over bytes, and
+# pyarrow.compute.utf8_title wherever the two rules coincide (ASCII text whose words hold no digit).
+
+import re  # noqa: E402
+
+STR = pa.string()
+WORDS = ["hello", "WORLD", "mIxEd", "a", "Z", "x1y2", "42", "9lives", "o'neil", "snake_case", "kebab-case", "dotted.name",
+         "tab\tsep", "two  spaces", " lead", "trail ", "", "ÉCOLE", "straße", "naïve café", "日本語 text", "aéb CÉD", "éx"]
+
+
+def _initcap_by_regex(t):
+    if t is None:
+        return None
+    def word(m):
+        w = m.group(0)
+        head = w[:1].upper() if w[0] < 0x80 else w[:1]
+        return head + w[1:].lower()          # bytes.lower() / .upper() touch ASCII letters only
+    return re.sub(rb"[A-Za-z0-9\x80-\xff]+", word, t.encode()).decode()
+
+
+def _initcap_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    seps = [" ", "  ", "-", "_", ".", ",", "'", "/", "\t", "1", ""]
+    vals = []
+    for _ in range(n):
+        k = int(rng.integers(0, 6))
+        t = "".join(str(rng.choice(WORDS)) + str(rng.choice(seps)) for _ in range(k))
+        vals.append(None if rng.random() < 0.1 else t)
+    return vals
+
+
+def _initcap_exprs(b, s):
+    f = lambda name, *a: b.make_function(name, list(a), STR)  # noqa: E731
+    lit = lambda v, t=STR: b.make_literal(v, t)  # noqa: E731
+    return [("initcap", f("initcap", s)), ("initcap(upper)", f("initcap", f("upper", s))),
+            ("initcap(substr)", f("initcap", f("substr", s, lit(3, pa.int64()), lit(12, pa.int64())))),
+            ("concat(initcap, '!')", f("concat", f("initcap", s), lit("!"))),
+            ("upper(initcap) [two-stage]", f("upper", f("initcap", s)))]
+
+
+def test_oracle_initcap_matches_the_regex_restatement_and_arrows_title_where_the_rules_coincide():
+    vals = WORDS + _initcap_cases(3, 3000)
+    batch = pa.RecordBatch.from_arrays([pa.array(vals, STR)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    e = b.make_expression(b.make_function("initcap", [s], STR), pa.field("r", STR))
+    got = oracle.project([e], batch)[0].to_pylist()
+    assert got == [_initcap_by_regex(v) for v in vals]
+    # pyarrow.compute.utf8_title starts a new word after anything that is not a LETTER (digits included) and knows
+    # Unicode: same answers on ASCII text whose words carry no digit
+    same = [v for v in vals if v is not None and v.isascii() and not re.search(r"\d", v)]
+    title = pc.utf8_title(pa.array(same, STR)).to_pylist()
+    assert [_initcap_by_regex(v) for v in same] == title
+    assert gandiva.get_registered_function_signatures and any(
+        sig.name() == "initcap" for sig in gandiva.get_registered_function_signatures())
+
+
+def test_device_initcap_on_the_host(hostlib):  # noqa: F811
+    vals = [v for v in WORDS + _initcap_cases(4, 2000) if v is not None]
+    arr = pa.array(vals, STR)
+    off = np.frombuffer(arr.buffers()[1], np.int32)[: len(vals) + 1].copy()
+    raw = np.frombuffer(arr.buffers()[2], np.uint8) if arr.buffers()[2] is not None else np.zeros(0, np.uint8)
+    size = int(off[-1])
+    data = np.concatenate([raw[:size], np.zeros(64, np.uint8)])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for mp, pre in ((0, lambda t: t), (1, lambda t: t.encode().upper().decode()), (2, lambda t: t.encode().lower().decode())):
+        out_off, out_data = np.zeros(len(vals) + 1, np.int32), np.zeros(size + 64, np.uint8)
+        hostlib.host_str_initcap(p(off), p(data), C.c_long(size), C.c_long(len(vals)), mp, p(out_off), p(out_data))
+        got = [bytes(out_data[out_off[i]:out_off[i + 1]]).decode() for i in range(len(vals))]
+        assert got == [_initcap_by_regex(pre(v)) for v in vals], mp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 40_003])
+def test_initcap_on_the_gpu(n):
+    vals = (WORDS + _initcap_cases(n, n))[:n] if n >= len(WORDS) else _initcap_cases(n, n)
+    batch = pa.RecordBatch.from_arrays([pa.array(vals, STR)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    exprs = [b.make_expression(node, pa.field(f"r{i}", STR)) for i, (_, node) in enumerate(_initcap_exprs(b, s))]
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    for g, w, (name, _) in zip(proj.evaluate(batch), oracle.project(exprs, batch), _initcap_exprs(b, s)):
+        assert_bit_exact(g, w, name)
+    # under a selection vector (the wave-shaped selection-mode kernels)
+    keep = np.arange(0, n, 3, dtype=np.uint32)
+    sel = gandiva.SelectionVector(2, keep, len(keep))
+    psel = gandiva.make_projector(batch.schema, exprs[:4], None, "UINT32")
+    for g, w in zip(psel.evaluate(batch, sel), oracle.project(exprs[:4], oracle.take_rows(batch, keep))):
+        assert_bit_exact(g, w, "selection mode")
+
+
+# ------------------------------------------------------------------ round 5: regular expressions, the literal subset
+# [recalled: regexp_like / regexp_matches = RE2::PartialMatch, regexp_replace = RE2::GlobalReplace].  The tree builder
+# rewrites the literal subset onto like / replace (gdv_node.h MakeFunctionNode); everything else is CodeGenError.
+# Second engine: Python's re (search / sub), whose semantics on metacharacter-free patterns are RE2's.
+
+REGEX_OK = ["spark", "^spark", "spark$", "^spark$", "a", "^a", "k$", "ar", "é", "^日本", "x-y", "it's"]
+REGEX_REFUSED = ["sp.rk", "spa*", "(spark)", "[sp]ark", "a|b", "^", "$", "", "50%", "a_b", "back\\slash", "x{2}", "q?"]
+REPLACEMENTS = [("spark", "flink"), ("ar", ""), ("é", "e"), ("a", "AAA"), ("x-y", "-")]
+
+
+def _regex_batch(n, seed=9):
+    rng = np.random.default_rng(seed)
+    base = W.c5_batch(n, 0.1).column(0).to_pylist()
+    extra = ["spark", "sparks fly", "a spark", "x-y", "it's", "é", "日本語", "", "park", "sparkspark", "café x-y ar"]
+    vals = [extra[int(rng.integers(0, len(extra)))] if rng.random() < 0.2 else v for v in base]
+    return pa.RecordBatch.from_arrays([pa.array(vals, STR)], names=["s"])
+
+
+def _regex_exprs(b, s):
+    out = []
+    for k, pat in enumerate(REGEX_OK):
+        for fn in ("regexp_like", "regexp_matches"):
+            out.append((f"{fn}({pat!r})", b.make_expression(b.make_function(fn, [s, b.make_literal(pat, STR)], pa.bool_()),
+                                                            pa.field(f"m{k}{fn[-1]}", pa.bool_())), ("search", pat, None)))
+    for k, (pat, to) in enumerate(REPLACEMENTS):
+        out.append((f"regexp_replace({pat!r}, {to!r})",
+                    b.make_expression(b.make_function("regexp_replace", [s, b.make_literal(pat, STR), b.make_literal(to, STR)], STR),
+                                      pa.field(f"r{k}", STR)), ("sub", pat, to)))
+    return out
+
+
+def test_oracle_regexp_subset_matches_pythons_re():
+    batch = _regex_batch(4000)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    cases = _regex_exprs(b, s)
+    got = oracle.project([e for _, e, _ in cases], batch)
+    vals = batch.column(0).to_pylist()
+    for (name, _, (kind, pat, to)), g in zip(cases, got):
+        rx = re.compile(pat)
+        want = [None if v is None else (rx.search(v) is not None if kind == "search" else rx.sub(to, v)) for v in vals]
+        assert g.to_pylist() == want, name
+
+
+def test_regexps_beyond_the_literal_subset_are_refused_not_guessed(monkeypatch, tmp_path):
+    """The rewritten forms compile for gfx950 (they ARE like / replace plans); a pattern with a metacharacter, a LIKE
+    wildcard, nothing at all, or a replacement with a backslash reaches the planner as regexp_* and is refused there
+    with CodeGenError — and the oracle refuses the same inputs."""
+    from test_planner_cpu import _precompile
+    batch = _regex_batch(64)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    ok = [e for _, e, _ in _regex_exprs(b, s)]
+    files = _precompile(monkeypatch, tmp_path, batch.schema, exprs=ok[:6] + ok[-2:])
+    text = "".join(open(tmp_path / f).read() for f in files)
+    assert "regexp_" not in text.split("#include")[1]        # nothing of the regexp names is left below the @expr header
+    assert "gdv_like" in text or "gdv_range_any" in text
+    from gandiva_amd import _capi, gandiva as gg
+    for pat in REGEX_REFUSED:
+        for fn, extra, t in (("regexp_like", [], pa.bool_()), ("regexp_replace", [b.make_literal("z", STR)], STR)):
+            e = b.make_expression(b.make_function(fn, [s, b.make_literal(pat, STR)] + extra, t), pa.field("r", t))
+            sh = gg._make_schema(batch.schema)
+            try:
+                arr = (C.c_void_p * 1)(e._h)
+                assert _capi.lib().gdv_precompile_projector(sh, arr, 1, 0) == 40, (fn, pat, _capi.last_error())
+                assert "literal subset" in _capi.last_error()
+            finally:
+                _capi.lib().gdv_schema_free(sh)
+            with pytest.raises(Exception):
+                oracle.project([e], batch)
+    e = b.make_expression(b.make_function("regexp_replace", [s, b.make_literal("a", STR), b.make_literal("\\1", STR)], STR), pa.field("r", STR))
+    with pytest.raises(Exception):
+        oracle.project([e], batch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 1000, 50_003])
+def test_regexp_subset_on_the_gpu(n):
+    batch = _regex_batch(n, seed=n)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    cases = _regex_exprs(b, s)
+    exprs = [e for _, e, _ in cases]
+    # (one projector per group: a kernel takes one swept replace() needle and a few '%needle%' hooks)
+    for lo in range(0, len(exprs), 6):
+        part = exprs[lo:lo + 6]
+        got = gandiva.make_projector(batch.schema, part, None).evaluate(batch)
+        for g, w, (name, _, _) in zip(got, oracle.project(part, batch), cases[lo:lo + 6]):
+            assert_bit_exact(g, w, name)
+    cond = b.make_condition(b.make_function("regexp_like", [s, b.make_literal("^spark", STR)], pa.bool_()))
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, None, "int32")
+    assert sel.to_array().equals(oracle.filter_indices(cond, batch, "int32"))
