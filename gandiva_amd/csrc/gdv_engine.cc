@@ -170,6 +170,7 @@ struct EngineKnobs {
   bool no_small_filter = false;    // GDV_NO_SMALL_FILTER: default of Filter "small_filter" tuning (read at Make)
   int filter_chunks = 1;           // GDV_FILTER_CHUNKS: default of Filter "chunks" tuning (read at Make)
   int grid_mult = 0;               // GDV_GRID_MULT: workgroups per CU of the grid-stride launch (0: default)
+  bool no_async_two_stage = false; // GDV_NO_ASYNC_TWO_STAGE: synchronous two-stage evaluations go stage by stage (rounds 3-4)
   bool fp_window_only = false;     // GDV_FP_WINDOW_ONLY: fused filter-project never moves to its direct kernel (tests, sweeps)
   bool fp_force_stall = false;     // GDV_FP_FORCE_STALL: treat every fused launch as stalled (exercises the chain re-run)
   static const EngineKnobs& Get() {
@@ -180,6 +181,7 @@ struct EngineKnobs {
       x.no_evaluate_many = std::getenv("GDV_NO_EVALUATE_MANY") != nullptr;
       x.no_small_filter = std::getenv("GDV_NO_SMALL_FILTER") != nullptr;
       x.fp_window_only = std::getenv("GDV_FP_WINDOW_ONLY") != nullptr;
+      x.no_async_two_stage = std::getenv("GDV_NO_ASYNC_TWO_STAGE") != nullptr;
       x.fp_force_stall = std::getenv("GDV_FP_FORCE_STALL") != nullptr;
       if (const char* s = std::getenv("GDV_GRID_MULT")) x.grid_mult = std::max(1, atoi(s));
       if (const char* s = std::getenv("GDV_FILTER_CHUNKS")) x.filter_chunks = std::max(1, std::min(64, atoi(s)));
@@ -688,7 +690,7 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
 
 Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                            const SelectionView* sel, OutputBuffers* outs, int num_outs,
-                           MemKind mem, hipStream_t stream, uint32_t flags, const void* rows_word) const {
+                           MemKind mem, hipStream_t stream, uint32_t flags, const void* rows_word, void* err_word) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
   const bool two_stage = pre_ != nullptr && !(flags & kEvalStaged);  // (kEvalStaged: the caller ran the first stage)
   if (outs == nullptr) return Status::Invalid("Output array vector cannot be null");
@@ -714,6 +716,44 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
                            "(read the count back and pass it as num_slots instead)");
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
+  // Round 5: a synchronous two-stage evaluation over HBM-resident buffers no longer waits for its first stage —
+  // both stages and the gate between them are enqueued exactly as the asynchronous call enqueues them, and the
+  // host waits ONCE, for the status word and the byte totals.  Whatever that attempt cannot finish (a temporary or
+  // an output too small, a batch that breaks an optimistic assumption, a raised error, a shape the gate does not
+  // take) falls through to the stage-by-stage path below, which also re-learns the sizes and names the error.
+  if (two_stage && mem == MemKind::kDevice && pre_->pre_ == nullptr && !(has_sel && sel->num_slots_device != nullptr) &&
+      !EngineKnobs::Get().no_async_two_stage && out_rows > 0) {
+    DeviceBuffer res;
+    GDV_RETURN_NOT_OK(res.Allocate(8 * (1 + static_cast<size_t>(num_outs))));
+    std::vector<OutputBuffers> attempt(outs, outs + num_outs);
+    Status st_async = EvaluateAsyncTwoStage(num_rows, cols, num_cols, sel, attempt.data(), num_outs, stream, res.get());
+    if (st_async.ok()) {
+      std::vector<uint64_t> back(1 + static_cast<size_t>(num_outs), 0);
+      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), res.get(), back.size() * 8, hipMemcpyDeviceToHost, stream));
+      GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
+      bool complete = back[0] == 0;
+      for (int e = 0; complete && e < num_outs; e++)
+        if (plan_.output_types[e].is_varlen())
+          complete = back[1 + e] < 0x7fffffffull && static_cast<int64_t>(back[1 + e]) <= outs[e].data_size && (back[1 + e] == 0 || outs[e].data != nullptr);
+      if (complete) {
+        for (int e = 0; e < num_outs; e++) {
+          if (!plan_.output_types[e].is_varlen()) continue;
+          outs[e].data_size = static_cast<int64_t>(back[1 + e]);
+          if (static_cast<size_t>(e) < out_bytes_x16_.size()) {
+            const int64_t seen = static_cast<int64_t>(back[1 + e]) * 16 / out_rows + 1;
+            int64_t cur = out_bytes_x16_[e].load(std::memory_order_relaxed);
+            for (;;) {
+              const int64_t next = seen >= cur ? seen : std::max(seen, cur - (cur >> 3) - 1);
+              if (next == cur || out_bytes_x16_[e].compare_exchange_weak(cur, next, std::memory_order_relaxed)) break;
+            }
+          }
+        }
+        return Status::OK();
+      }
+    } else {
+      (void)hipStreamSynchronize(stream);
+    }
+  }
   const PlanDeviceState* dev = nullptr;
   GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
 
@@ -808,10 +848,13 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
 
   const int nv = plan_.num_varlen_outputs;
   const bool has_err = plan_.can_raise && nv == 0;  // var-len plans keep the error word in their scan-state block
-  if (has_err) {
+  const bool own_err = has_err && err_word == nullptr;
+  if (own_err) {
     GDV_RETURN_NOT_OK(err.Allocate(8));
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
     args.SetPtr(ArgLayout::kOffErr, err.get());
+  } else if (has_err) {
+    args.SetPtr(ArgLayout::kOffErr, err_word);  // the caller's word: raised into, never read here
   }
 
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
@@ -1068,7 +1111,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       if (plan_.output_types[e].is_varlen()) outs[e].data_size = 0;
   }
 
-  if (plan_.can_raise && nv == 0)
+  if (own_err)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
   if (mem == MemKind::kHost) {
     GDV_RETURN_NOT_OK(st.FetchOut(stream));  // validity, fixed-width values, offsets
@@ -1077,7 +1120,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
         GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(outs[e].data, dev_data[e], totals[e],
                                              hipMemcpyDeviceToHost, stream));
   }
-  const bool must_sync = mem == MemKind::kHost || plan_.can_raise || !(flags & kEvalAsync) || two_stage;
+  const bool must_sync = mem == MemKind::kHost || (plan_.can_raise && err_word == nullptr) || !(flags & kEvalAsync) || two_stage;
   if (must_sync) GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
   if (err_bits != 0) return Status::ExecutionError(ErrorMessage(err_bits));
   if (mem == MemKind::kHost) st.Deliver();
@@ -1179,8 +1222,6 @@ Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* c
                                         OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
   if (outs == nullptr || result == nullptr) return Status::Invalid("Output array vector and result block cannot be null");
-  if (plan_.num_varlen_outputs == 0 && plan_.can_raise)
-    return Status::Invalid("a two-stage plan whose second stage can raise is evaluated synchronously");
   if (num_outs != num_outputs()) return Status::Invalid("number of output buffers does not match the number of expressions");
   if (pre_->pre_ != nullptr) return Status::Invalid("plans with more than two stages are evaluated synchronously");
   if (num_cols != static_cast<int>(schema_.size()))
@@ -1244,9 +1285,11 @@ Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* c
     GDV_RETURN_NOT_OK(EvaluateAsyncStage(num_rows, all.data(), static_cast<int>(all.size()), sel, outs, num_outs, stream, result,
                                          rows_word));
   } else {  // fixed-width outputs only: the ordinary asynchronous launch over the staged columns, rows from the gate
+    // (a second stage that can raise — divide, castINT of the staged text ... — raises into result[0] itself: round 4
+    // sent such plans to the synchronous call)
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));
     GDV_RETURN_NOT_OK(Evaluate(num_rows, all.data(), static_cast<int>(all.size()), sel, outs, num_outs, MemKind::kDevice, stream,
-                               kEvalAsync | kEvalStaged, rows_word));
+                               kEvalAsync | kEvalStaged, rows_word, plan_.can_raise ? result : nullptr));
   }
   GDV_HIP_RETURN_NOT_OK(LaunchOrStatus(static_cast<uint64_t*>(result), status_word, stream));
   for (auto& b : blocks) b.release_after(stream);
@@ -1268,10 +1311,10 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
     return Status::Invalid("selection vector: invalid slot count or no buffer");
   const int nv = plan_.num_varlen_outputs;
   uint64_t* const res = static_cast<uint64_t*>(result);
-  if (nv == 0) {  // fixed-width plans: the ordinary asynchronous launch; no byte totals, errors only if the plan cannot raise
-    if (plan_.can_raise) return Status::Invalid("a fixed-width plan that can raise is evaluated synchronously");
+  if (nv == 0) {  // fixed-width plans: the ordinary asynchronous launch; no byte totals; a plan that can raise raises into result[0]
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));
-    return Evaluate(num_rows, cols, num_cols, sel, outs, num_outs, MemKind::kDevice, stream, kEvalAsync);
+    return Evaluate(num_rows, cols, num_cols, sel, outs, num_outs, MemKind::kDevice, stream, kEvalAsync, nullptr,
+                    plan_.can_raise ? result : nullptr);
   }
   if (out_rows == 0) {
     GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(result, 0, 8 * (1 + static_cast<size_t>(num_outs)), stream));

@@ -97,9 +97,12 @@ class Projector {
   // view, outputs have sel->num_slots rows, else num_rows rows.
   // (rows_word, internal: device word second-stage kernels take their row count from — the gate of an
   // asynchronous two-stage evaluation)
+  // (err_word, internal: a pre-zeroed device word the kernel raises its error bits into INSTEAD of a word of this
+  // call's own — the caller reads it, so a plan that can raise may still be enqueued without a wait: the second
+  // stage of an asynchronous two-stage evaluation reports through result[0])
   Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                   const SelectionView* sel, OutputBuffers* outs, int num_outs, MemKind mem,
-                  hipStream_t stream, uint32_t flags, const void* rows_word = nullptr) const;
+                  hipStream_t stream, uint32_t flags, const void* rows_word = nullptr, void* err_word = nullptr) const;
 
   // Many (small) HBM-resident batches in ONE launch (round 3): the reference is fed 4K-64K-row
   // batches, where a launch + argument marshalling per batch is all overhead.  The argument blocks
@@ -130,7 +133,7 @@ class Projector {
   // what recent batches produced (the first guess before any).  A device-side gate between the stages
   // gives the second stage 0 rows when the first did not complete (status bits, or a temporary too
   // small: bit 128 in result[0]) — it then touches nothing, and the caller re-runs synchronously.
-  // (second stages with fixed-width outputs only: plans that cannot raise)
+  // (round 5: a second stage — or a single-stage fixed-width plan — that can raise raises into result[0] itself)
   Status EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
                        OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const;
 

@@ -288,8 +288,9 @@ int gdv_projector_evaluate_selected(const gdv_projector_t* p, int64_t num_rows, 
  * are enqueued, the temporaries sized from what earlier batches produced; a one-thread gate kernel between the
  * stages hands the second stage its row count — 0 when the first stage did not complete or a temporary was too
  * small (bit 128 of result[0]), so that it touches nothing.  A second stage with fixed-width outputs only is
- * launched the same way unless it can raise; that, and plans with more than two stages: GDV_INVALID (evaluate
- * them synchronously). */
+ * launched the same way; if it can raise (a division, a text -> integer cast over the staged value ...) it raises
+ * into result[0] itself (round 5 — as does a single-stage fixed-width plan that can raise).  Plans with more than two
+ * stages: GDV_INVALID (evaluate them synchronously). */
 int gdv_projector_evaluate_async(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols, int num_cols,
                                  const gdv_selection_t* sel, const void* num_slots_device, gdv_out_column_t* outs,
                                  int num_outs, void* stream, void* result);

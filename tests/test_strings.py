@@ -879,11 +879,24 @@ def test_two_stage_plans_with_fixed_width_outputs_evaluate_without_a_host_synchr
              b.make_expression(b.make_function("starts_with", [cat, b.make_literal("sp", pa.string())], pa.bool_()), pa.field("p", pa.bool_()))]
     proj = gandiva.make_projector(batch.schema, exprs, None)
     db = gandiva.DeviceBatch.from_arrow(batch)
-    # (a second stage that can raise — locate checks its start position — has to report errors: synchronous only)
-    raising = gandiva.make_projector(batch.schema, [b.make_expression(b.make_function("locate", [b.make_literal("k-", pa.string()), cat], pa.int32()),
-                                                                       pa.field("q", pa.int32()))], None)
-    with pytest.raises(pa.ArrowInvalid):
-        raising.evaluate_device_async(db)
+    # a second stage that CAN raise (locate checks its start position; an integer division) raises into result[0]
+    # itself (round 5; round 4 refused such plans: "synchronous only")
+    len_cat = b.make_function("length", [cat], pa.int32())
+    can_raise = [b.make_expression(b.make_function("locate", [b.make_literal("k-", pa.string()), cat], pa.int32()), pa.field("q", pa.int32())),
+                 b.make_expression(b.make_function("divide", [len_cat, b.make_literal(7, pa.int32())], pa.int32()), pa.field("d", pa.int32()))]
+    raising = gandiva.make_projector(batch.schema, can_raise, None)
+    outs_r, result_r = raising.evaluate_device_async(db)
+    torch.cuda.synchronize()
+    assert int(result_r[0]) == 0
+    for o, w in zip(outs_r, oracle.project(can_raise, batch)):
+        assert_bit_exact(o.to_arrow(), w, "second stage that can raise, asynchronously")
+    by_zero = gandiva.make_projector(batch.schema, [b.make_expression(b.make_function("divide", [len_cat, b.make_literal(0, pa.int32())], pa.int32()),
+                                                                       pa.field("z", pa.int32()))], None)
+    outs_z, result_z = by_zero.evaluate_device_async(db)
+    torch.cuda.synchronize()
+    assert int(result_z[0]) & 1, "divide by zero must arrive in the status word"
+    with pytest.raises(gandiva.GandivaError):
+        outs_z[0].to_arrow()
     want = oracle.project(exprs, batch)
     for attempt in ("first guess", "learnt sizes"):
         outs, result = proj.evaluate_device_async(db)
