@@ -1040,6 +1040,45 @@ GDV_DEV gdv_int128 castDECIMAL_decimal128(gdv_int128 x, int xp, int xs, int op, 
   const gdv_int128 lim = gdv_pow10_128(op);
   return (r >= lim || r <= -lim) ? (gdv_int128)0 : r;
 }
+// ---- round / truncate / ceil / floor over decimal128 (round 5) [recalled: precompiled/decimal_ops.cc Round / Truncate /
+// Ceil / Floor: the value is brought to `k` fractional digits (k < 0: to a multiple of 10^-k) — half away from zero,
+// towards zero, up, down — and then expressed in the (precision, scale) the EXPRESSION declares, which is the caller's
+// to choose as in the lineage; a result that does not fit that precision is 0, like every decimal overflow here].
+// mode: 0 half away from zero, 1 towards zero, 2 towards +inf, 3 towards -inf.
+GDV_DEV gdv_int128 gdv_dec_round_to(gdv_int128 x, int xs, gdv_int32 k, int mode, int op, int os) {
+  if (k > xs) k = xs;
+  if (k < -38) return 0;  // every representable value is nearer to 0 than to 10^39
+  const int drop = xs - (int)k;  // digits that go
+  gdv_int128 r = x;
+  if (drop > 0) {
+    if (drop > 38) {
+      r = 0;
+      if (mode == 2 && x > 0) r = 1;
+      if (mode == 3 && x < 0) r = -1;
+    } else {
+      const gdv_int128 d = gdv_pow10_128(drop);
+      gdv_int128 q = x / d, m = x % d;  // C division: towards zero
+      if (mode == 0) {
+        const gdv_int128 a = m < 0 ? -m : m;
+        if (a >= d - a) q += x < 0 ? -1 : 1;
+      } else if (mode == 2) {
+        if (m > 0) q += 1;
+      } else if (mode == 3) {
+        if (m < 0) q -= 1;
+      }
+      r = q;
+    }
+  }
+  // r counts units of 10^-k (k >= 0: at scale k; k < 0: multiples of 10^-k, i.e. scale 0 after multiplying back)
+  const int have = drop > 0 ? (int)k : xs;  // the scale r is expressed at (may be negative)
+  return castDECIMAL_decimal128(have < 0 ? r * gdv_pow10_128(-have > 38 ? 38 : -have) : r, 38, have < 0 ? 0 : have, op, os);
+}
+GDV_DEV gdv_int128 round_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return gdv_dec_round_to(x, xs, 0, 0, op, os); }
+GDV_DEV gdv_int128 round_decimal128_int32(gdv_int128 x, int xp, int xs, gdv_int32 k, int op, int os) { return gdv_dec_round_to(x, xs, k, 0, op, os); }
+GDV_DEV gdv_int128 truncate_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return gdv_dec_round_to(x, xs, 0, 1, op, os); }
+GDV_DEV gdv_int128 truncate_decimal128_int32(gdv_int128 x, int xp, int xs, gdv_int32 k, int op, int os) { return gdv_dec_round_to(x, xs, k, 1, op, os); }
+GDV_DEV gdv_int128 ceil_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return gdv_dec_round_to(x, xs, 0, 2, op, os); }
+GDV_DEV gdv_int128 floor_decimal128(gdv_int128 x, int xp, int xs, int op, int os) { return gdv_dec_round_to(x, xs, 0, 3, op, os); }
 GDV_DEV gdv_float64 castFLOAT8_decimal128(gdv_int128 x, int xp, int xs, int op, int os) {
   // two correctly rounded steps: int128 -> double, then divide by the exact power of ten
   // (10^k is exact in binary64 for k <= 22; larger scales lose at most 1 ulp more)

@@ -170,7 +170,6 @@ struct EngineKnobs {
   bool no_small_filter = false;    // GDV_NO_SMALL_FILTER: default of Filter "small_filter" tuning (read at Make)
   int filter_chunks = 1;           // GDV_FILTER_CHUNKS: default of Filter "chunks" tuning (read at Make)
   int grid_mult = 0;               // GDV_GRID_MULT: workgroups per CU of the grid-stride launch (0: default)
-  bool no_async_two_stage = false; // GDV_NO_ASYNC_TWO_STAGE: synchronous two-stage evaluations go stage by stage (rounds 3-4)
   bool fp_window_only = false;     // GDV_FP_WINDOW_ONLY: fused filter-project never moves to its direct kernel (tests, sweeps)
   bool fp_force_stall = false;     // GDV_FP_FORCE_STALL: treat every fused launch as stalled (exercises the chain re-run)
   static const EngineKnobs& Get() {
@@ -181,7 +180,6 @@ struct EngineKnobs {
       x.no_evaluate_many = std::getenv("GDV_NO_EVALUATE_MANY") != nullptr;
       x.no_small_filter = std::getenv("GDV_NO_SMALL_FILTER") != nullptr;
       x.fp_window_only = std::getenv("GDV_FP_WINDOW_ONLY") != nullptr;
-      x.no_async_two_stage = std::getenv("GDV_NO_ASYNC_TWO_STAGE") != nullptr;
       x.fp_force_stall = std::getenv("GDV_FP_FORCE_STALL") != nullptr;
       if (const char* s = std::getenv("GDV_GRID_MULT")) x.grid_mult = std::max(1, atoi(s));
       if (const char* s = std::getenv("GDV_FILTER_CHUNKS")) x.filter_chunks = std::max(1, std::min(64, atoi(s)));
@@ -716,44 +714,6 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
                            "(read the count back and pass it as num_slots instead)");
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
-  // Round 5: a synchronous two-stage evaluation over HBM-resident buffers no longer waits for its first stage —
-  // both stages and the gate between them are enqueued exactly as the asynchronous call enqueues them, and the
-  // host waits ONCE, for the status word and the byte totals.  Whatever that attempt cannot finish (a temporary or
-  // an output too small, a batch that breaks an optimistic assumption, a raised error, a shape the gate does not
-  // take) falls through to the stage-by-stage path below, which also re-learns the sizes and names the error.
-  if (two_stage && mem == MemKind::kDevice && pre_->pre_ == nullptr && !(has_sel && sel->num_slots_device != nullptr) &&
-      !EngineKnobs::Get().no_async_two_stage && out_rows > 0) {
-    DeviceBuffer res;
-    GDV_RETURN_NOT_OK(res.Allocate(8 * (1 + static_cast<size_t>(num_outs))));
-    std::vector<OutputBuffers> attempt(outs, outs + num_outs);
-    Status st_async = EvaluateAsyncTwoStage(num_rows, cols, num_cols, sel, attempt.data(), num_outs, stream, res.get());
-    if (st_async.ok()) {
-      std::vector<uint64_t> back(1 + static_cast<size_t>(num_outs), 0);
-      GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(back.data(), res.get(), back.size() * 8, hipMemcpyDeviceToHost, stream));
-      GDV_HIP_RETURN_NOT_OK(hipStreamSynchronize(stream));
-      bool complete = back[0] == 0;
-      for (int e = 0; complete && e < num_outs; e++)
-        if (plan_.output_types[e].is_varlen())
-          complete = back[1 + e] < 0x7fffffffull && static_cast<int64_t>(back[1 + e]) <= outs[e].data_size && (back[1 + e] == 0 || outs[e].data != nullptr);
-      if (complete) {
-        for (int e = 0; e < num_outs; e++) {
-          if (!plan_.output_types[e].is_varlen()) continue;
-          outs[e].data_size = static_cast<int64_t>(back[1 + e]);
-          if (static_cast<size_t>(e) < out_bytes_x16_.size()) {
-            const int64_t seen = static_cast<int64_t>(back[1 + e]) * 16 / out_rows + 1;
-            int64_t cur = out_bytes_x16_[e].load(std::memory_order_relaxed);
-            for (;;) {
-              const int64_t next = seen >= cur ? seen : std::max(seen, cur - (cur >> 3) - 1);
-              if (next == cur || out_bytes_x16_[e].compare_exchange_weak(cur, next, std::memory_order_relaxed)) break;
-            }
-          }
-        }
-        return Status::OK();
-      }
-    } else {
-      (void)hipStreamSynchronize(stream);
-    }
-  }
   const PlanDeviceState* dev = nullptr;
   GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
 

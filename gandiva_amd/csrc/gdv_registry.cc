@@ -250,6 +250,14 @@ FunctionRegistry::FunctionRegistry() {
       add(f, {dec, dec}, boolean(), NullPolicy::kNullIfNull, kDecimalArgs);
     add("negative", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
     add("abs", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    // round / truncate (trunc) / ceil / floor (round 5): the result's precision and scale are the expression's own
+    for (const char* f : {"round", "truncate", "trunc"}) {
+      const std::string base = std::string(f) == "round" ? "round" : "truncate";
+      add(f, {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs, base + "_decimal128");
+      add(f, {dec, int32()}, dec, NullPolicy::kNullIfNull, kDecimalArgs, base + "_decimal128_int32");
+    }
+    add("ceil", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
+    add("floor", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
     add("castDECIMAL", {int64()}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
     add("castDECIMAL", {int32()}, dec, NullPolicy::kNullIfNull, kDecimalArgs);
     add("castDECIMAL", {dec}, dec, NullPolicy::kNullIfNull, kDecimalArgs);

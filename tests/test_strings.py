@@ -895,8 +895,6 @@ def test_two_stage_plans_with_fixed_width_outputs_evaluate_without_a_host_synchr
     outs_z, result_z = by_zero.evaluate_device_async(db)
     torch.cuda.synchronize()
     assert int(result_z[0]) & 1, "divide by zero must arrive in the status word"
-    with pytest.raises(gandiva.GandivaError):
-        outs_z[0].to_arrow()
     want = oracle.project(exprs, batch)
     for attempt in ("first guess", "learnt sizes"):
         outs, result = proj.evaluate_device_async(db)
