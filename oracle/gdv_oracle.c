@@ -73,6 +73,11 @@
  *         word characters (upstream: utf8proc case mapping and categories — a DIVERGENCE for non-ASCII letters).
  *         Checked against a regular-expression restatement in Python and, where the two rules coincide (words
  *         without digits, ASCII), against pyarrow.compute.utf8_title.
+ *       - round / truncate (trunc) / ceil / floor over decimal128: value brought to k fractional digits (half away from
+ *         zero / towards zero / up / down), then expressed in the precision and scale the EXPRESSION declares (the
+ *         lineage leaves that type to the caller as well); overflow of that precision -> 0.  The arithmetic is pinned
+ *         against Python's decimal (ROUND_HALF_UP / ROUND_DOWN / ROUND_CEILING / ROUND_FLOOR); that these are the
+ *         lineage's rules (and its result types) is recollection.
  *       - regexp_like / regexp_matches / regexp_replace: the lineage runs RE2 (PartialMatch / GlobalReplace); only the
  *         LITERAL SUBSET exists here ([^]lit[$] without metacharacters; replacement without backslashes), where RE2's
  *         semantics are contains / starts / ends / equals and left-to-right non-overlapping replace — checked against
@@ -740,6 +745,35 @@ static i128 dec_rescale(i128 x, int xs, int op, int os) {
   return (r >= lim || r <= -lim) ? 0 : r;
 }
 
+/* round / truncate / ceil / floor over decimal128 [recalled: precompiled/decimal_ops.cc]: bring x (scale xs) to k
+ * fractional digits (k < 0: a multiple of 10^-k; k > xs: nothing to do; k < -38: 0) — mode 0 half away from zero,
+ * 1 towards zero, 2 up, 3 down — then express it in the (precision, scale) the expression declares; what does not fit: 0.
+ * Stated through FLOOR division and a non-negative remainder (the device library truncates and fixes up). */
+static i128 dec_round_to(i128 x, int xs, int k, int mode, int op, int os) {
+  if (k > xs) k = xs;
+  if (k < -38) return 0;
+  i128 q = x;
+  int at = xs;
+  if (k < xs) {
+    int drop = xs - k;
+    if (drop > 38) {
+      q = (mode == 2 && x > 0) ? 1 : (mode == 3 && x < 0) ? -1 : 0;
+    } else {
+      i128 d = pow10_128(drop);
+      i128 fl = x / d;
+      if (x % d != 0 && x < 0) fl -= 1;
+      i128 rem = x - fl * d;                       /* 0 <= rem < d */
+      if (mode == 3) q = fl;
+      else if (mode == 2) q = fl + (rem != 0);
+      else if (mode == 1) q = (x < 0 && rem != 0) ? fl + 1 : fl;
+      else q = x >= 0 ? fl + (rem >= d - rem) : fl + (rem > d - rem);
+    }
+    at = k;
+  }
+  if (at < 0) { q *= pow10_128(-at); at = 0; }
+  return dec_rescale(q, at, op, os);
+}
+
 static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active,
                           vec* out) {
   const char* f = n->name;
@@ -1053,6 +1087,10 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
       else out->sl[i] = k < len ? (int32_t)k : len;
     }
+  } else if (t0 == T_DEC && (!strcmp(f, "round") || !strcmp(f, "truncate") || !strcmp(f, "trunc") || !strcmp(f, "ceil") || !strcmp(f, "floor"))) {
+    const int mode = f[0] == 'r' ? 0 : f[0] == 't' ? 1 : f[0] == 'c' ? 2 : 3;
+    for (int i = 0; i < cnt; i++)
+      out->v[i].q = dec_round_to(a[0].v[i].q, a[0].scale, n->nargs == 2 ? (int)a[1].v[i].i : 0, mode, n->prec, n->scale);
   } else if (t0 == T_DEC || n->type == T_DEC) {
     const int two = n->nargs == 2;
     for (int i = 0; i < cnt; i++) {

@@ -54,6 +54,19 @@ int host_decimal_cast(const void* xv, int xp, int xs, int op, int os, void* out,
   for (long i = 0; i < n; i++) r[i] = castDECIMAL_decimal128(x[i], xp, xs, op, os);
   return 0;
 }
+// round / truncate / ceil / floor (round 5): mode 0 round, 1 truncate, 2 ceil, 3 floor; k = fractional digits kept
+void host_decimal_round(int mode, const void* xv, int xp, int xs, const int* k, int op, int os, void* out, long n) {
+  const gdv_int128* x = (const gdv_int128*)xv;
+  gdv_int128* r = (gdv_int128*)out;
+  for (long i = 0; i < n; i++) {
+    switch (mode) {
+      case 0: r[i] = k ? round_decimal128_int32(x[i], xp, xs, k[i], op, os) : round_decimal128(x[i], xp, xs, op, os); break;
+      case 1: r[i] = k ? truncate_decimal128_int32(x[i], xp, xs, k[i], op, os) : truncate_decimal128(x[i], xp, xs, op, os); break;
+      case 2: r[i] = ceil_decimal128(x[i], xp, xs, op, os); break;
+      default: r[i] = floor_decimal128(x[i], xp, xs, op, os); break;
+    }
+  }
+}
 int host_decimal_from_int64(const long long* v, int op, int os, void* out, long n) {
   gdv_int128* r = static_cast<gdv_int128*>(out);
   for (long i = 0; i < n; i++) r[i] = castDECIMAL_int64(v[i], op, os);

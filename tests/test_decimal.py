@@ -343,3 +343,108 @@ def test_hip_in_over_decimal_and_float_matches_oracle():
     cond = b.make_condition(exprs[0].root())
     sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, None)
     assert sel.to_array().equals(oracle.filter_indices(cond, batch, "int32"))
+
+
+# ------------------------------------------------------------------ round 5: round / truncate / ceil / floor
+# [recalled: precompiled/decimal_ops.cc Round / Truncate / Ceil / Floor; the result's (precision, scale) is the
+# expression's own, chosen by the caller as in the lineage].  Second engine: Python's decimal quantize under
+# ROUND_HALF_UP / ROUND_DOWN / ROUND_CEILING / ROUND_FLOOR, then the declared type's precision check.
+
+ROUNDINGS = {"round": decimal.ROUND_HALF_UP, "truncate": decimal.ROUND_DOWN, "trunc": decimal.ROUND_DOWN,
+             "ceil": decimal.ROUND_CEILING, "floor": decimal.ROUND_FLOOR}
+
+
+def _python_rounded(fn, vals, ks, rt):
+    out = []
+    for v, k in zip(vals, ks):
+        if v is None or k is None:
+            out.append(None)
+            continue
+        if k < -38:
+            r = decimal.Decimal(0)
+        else:
+            r = v if -v.as_tuple().exponent <= k else v.quantize(decimal.Decimal(1).scaleb(-k, CTX), rounding=ROUNDINGS[fn], context=CTX)
+        r = r.quantize(decimal.Decimal(1).scaleb(-rt.scale, CTX), rounding=decimal.ROUND_HALF_UP, context=CTX)
+        if abs(int(r.scaleb(rt.scale, CTX))) >= 10 ** rt.precision:
+            r = decimal.Decimal(0).scaleb(-rt.scale, CTX)
+        out.append(r)
+    return out
+
+
+def _rounding_cases(rng):
+    """(function, input type, k column or None, declared result type)"""
+    cases = []
+    for (p, s) in DENSE_TYPES + [(12, 4), (9, 9)]:
+        t = pa.decimal128(p, s)
+        for fn in ("round", "truncate", "ceil", "floor"):
+            cases.append((fn, t, False, pa.decimal128(min(38, p - s + 1) if p > s else 1, 0)))   # to an integer: one more digit
+        for fn in ("round", "trunc"):
+            cases.append((fn, t, True, pa.decimal128(38, s)))      # k per row, result kept at the input's scale
+            cases.append((fn, t, True, pa.decimal128(38, max(s - 2, 0))))
+    return cases
+
+
+def _rounding_batch(rng, t, n):
+    x = _dense_decimals(rng, t, n)
+    ks = rng.integers(-6, t.scale + 4, n).astype(np.int32)
+    ks[:6] = [0, t.scale, t.scale + 1, -1, -38, -39][:6]
+    kmask = rng.random(n) < 0.05
+    return pa.RecordBatch.from_arrays([x, pa.array(ks, pa.int32(), mask=kmask)], names=["x", "k"])
+
+
+def _rounding_node(b, batch, fn, with_k, rt):
+    fx, fk = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    return b.make_function(fn, [fx, fk] if with_k else [fx], rt)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_decimal_rounding_matches_python_decimal(seed):
+    rng = np.random.default_rng(4100 + seed)
+    b = gandiva.TreeExprBuilder()
+    for fn, t, with_k, rt in _rounding_cases(rng):
+        batch = _rounding_batch(rng, t, 200)
+        got = oracle.project_one(_rounding_node(b, batch, fn, with_k, rt), rt, batch)
+        ks = batch.column(1).to_pylist() if with_k else [0] * len(batch)
+        assert got.to_pylist() == _python_rounded(fn, batch.column(0).to_pylist(), ks, rt), f"{fn} {t} k={with_k} -> {rt}"
+
+
+def test_device_decimal_rounding_on_the_host():
+    import ctypes as C
+    from test_device_lib_on_host import LIB, SRC, HERE, _raw128, _from_raw128
+    import subprocess
+    hdr = os.path.join(HERE, "..", "gandiva_amd", "csrc", "gdv_device_lib.hpp")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unused-function", "-Wno-unused-variable", SRC, "-o", LIB])
+    lib = C.CDLL(LIB)
+    rng = np.random.default_rng(77)
+    for fn, t, with_k, rt in _rounding_cases(rng):
+        batch = _rounding_batch(rng, t, 150)
+        x = batch.column(0)
+        raw = _raw128(x)
+        ks = np.asarray(batch.column(1).fill_null(0), dtype=np.int32)
+        out = np.zeros(len(x) * 2, np.uint64)
+        mode = {"round": 0, "truncate": 1, "trunc": 1, "ceil": 2, "floor": 3}[fn]
+        lib.host_decimal_round(mode, raw.ctypes.data_as(C.c_void_p), t.precision, t.scale,
+                               ks.ctypes.data_as(C.c_void_p) if with_k else None, rt.precision, rt.scale,
+                               out.ctypes.data_as(C.c_void_p), C.c_long(len(x)))
+        valid = [v is not None for v in x.to_pylist()]
+        got = _from_raw128(out, rt, valid)
+        got = got.to_pylist() if hasattr(got, "to_pylist") else list(got)
+        want = _python_rounded(fn, x.to_pylist(), ks.tolist() if with_k else [0] * len(x), rt)
+        assert got == want, f"{fn} {t} k={with_k} -> {rt}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 1000, 30_011])
+def test_hip_decimal_rounding_matches_oracle(n):
+    rng = np.random.default_rng(n)
+    b = gandiva.TreeExprBuilder()
+    for t in (pa.decimal128(38, 10), pa.decimal128(12, 4), pa.decimal128(20, 5)):
+        batch = _rounding_batch(rng, t, n)
+        cases = [c for c in _rounding_cases(rng) if c[1] == t]
+        exprs = [b.make_expression(_rounding_node(b, batch, fn, with_k, rt), pa.field(f"r{i}", rt))
+                 for i, (fn, _, with_k, rt) in enumerate(cases)]
+        got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+        for g, w, c in zip(got, oracle.project(exprs, batch), cases):
+            assert g.equals(w), str(c)
