@@ -1112,8 +1112,11 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 #define GDV_MAP_REVERSE 4
 #define GDV_MAP_DIGITS 8
 #define GDV_MAP_REPLACE 16  // `lim` points at a replace table (constant block), flags >> 2 = source length
-#define GDV_MAP_INITCAP 32  // round 5: the view's bytes with every word's first letter in upper case, the others in lower case
-#define GDV_MAP_SPECIAL (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE | GDV_MAP_INITCAP)  // only the output copy reads these
+#define GDV_MAP_INITCAP 128  // (32 is GDV_MAP_HITS, further down) round 5: the view's bytes with every word's first letter in upper case, the others in lower case
+// round 5: lower-case hex text of a message digest; (map >> 8) & 3 = 0 SHA-256, 1 SHA-1, 2 MD5; bit 10 (1024): the message is
+// the 8 bytes of `lead`, else the `lead` bytes at `lead_p` (read through the low map bits)
+#define GDV_MAP_DIGEST 64
+#define GDV_MAP_SPECIAL (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE | GDV_MAP_INITCAP | GDV_MAP_DIGEST)  // only the output copy reads these
 // GDV_MAP_DIGITS with GDV_STR_DECIMAL in `flags` (round 4): the text of the decimal128 whose low / high
 // words sit in `p` / `lim`, scale = flags >> 8, cut to `len` bytes (castVARCHAR(decimal, n))
 #define GDV_STR_DECIMAL 128
@@ -1462,9 +1465,143 @@ GDV_DEV void gdv_copy_initcap(P dst, const gdv_str& s) {
     else gdv_store_low_bytes(dst + i, o, nb);
   }
 }
+
+// ---- message digests (round 5): hashSHA256 / hashSHA1 / hashMD5 [recalled: gandiva/hash_utils.cc + gdv_function_stubs:
+// the digest of a string's bytes; of a NUMBER the digest of the 8 bytes of (double)value — the numeric types all go
+// through gdv_double_to_long, as hash32 / hash64 do; of a NULL the digest of the empty message; the result is the
+// lower-case hexadecimal text, never null].  FIPS 180-4 / RFC 1321.  Every loop below has a constant trip count and
+// is fully unrolled, so the 16-word schedule and the state live in registers (nothing of these kernels may sit in
+// scratch memory).  The text is produced by the output copy, like every value that only exists once it is written.
+GDV_DEV gdv_uint32 gdv_rotl32(gdv_uint32 x, int n) { return (x << n) | (x >> (32 - n)); }
+GDV_DEV gdv_uint32 gdv_rotr32(gdv_uint32 x, int n) { return (x >> n) | (x << (32 - n)); }
+GDV_DEV gdv_int32 gdv_digest_message_len(const gdv_str& s) { return (s.map & 1024) ? 8 : (gdv_int32)s.lead; }
+// message bytes [8k, 8k + 8) with the padding's 0x80 byte in place (the 64-bit bit count is the caller's)
+GDV_DEV gdv_uint64 gdv_digest_chunk(const gdv_str& s, gdv_int32 k) {
+  const gdv_int32 mlen = gdv_digest_message_len(s);
+  const gdv_int32 at = 8 * k;
+  gdv_uint64 w = 0;
+  if (at < mlen) {
+    if (s.map & 1024) {
+      w = s.lead;
+    } else {
+      gdv_str src = s;
+      src.p = s.lead_p;
+      src.len = mlen;
+      src.map = 0;
+      src.flags = s.flags & GDV_STR_INBUF;
+      w = gdv_map8(gdv_raw_word_at(src, at), s.map & GDV_MAP_CASE) & gdv_low_bytes_mask(mlen - at);
+    }
+  }
+  if (mlen >= at && mlen < at + 8) w |= 0x80ull << (8 * (mlen - at));
+  return w;
+}
+GDV_DEV void gdv_sha256_block(gdv_uint32 (&h)[8], gdv_uint32 (&w)[16]) {
+  static constexpr gdv_uint32 K[64] = {
+      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u,
+      0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu,
+      0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u,
+      0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+      0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u,
+      0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+      0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+  gdv_uint32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+  for (int t = 0; t < 64; t++) {
+    if (t >= 16) {
+      const gdv_uint32 w1 = w[(t + 1) & 15], w14 = w[(t + 14) & 15];
+      w[t & 15] += (gdv_rotr32(w1, 7) ^ gdv_rotr32(w1, 18) ^ (w1 >> 3)) + w[(t + 9) & 15] +
+                   (gdv_rotr32(w14, 17) ^ gdv_rotr32(w14, 19) ^ (w14 >> 10));
+    }
+    const gdv_uint32 t1 = hh + (gdv_rotr32(e, 6) ^ gdv_rotr32(e, 11) ^ gdv_rotr32(e, 25)) + ((e & f) ^ (~e & g)) + K[t] + w[t & 15];
+    const gdv_uint32 t2 = (gdv_rotr32(a, 2) ^ gdv_rotr32(a, 13) ^ gdv_rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+GDV_DEV void gdv_sha1_block(gdv_uint32 (&h)[8], gdv_uint32 (&w)[16]) {
+  gdv_uint32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+#pragma unroll
+  for (int t = 0; t < 80; t++) {
+    if (t >= 16) w[t & 15] = gdv_rotl32(w[(t + 13) & 15] ^ w[(t + 8) & 15] ^ w[(t + 2) & 15] ^ w[t & 15], 1);
+    const gdv_uint32 f = t < 20 ? ((b & c) | (~b & d)) : t < 40 ? (b ^ c ^ d) : t < 60 ? ((b & c) | (b & d) | (c & d)) : (b ^ c ^ d);
+    const gdv_uint32 k = t < 20 ? 0x5a827999u : t < 40 ? 0x6ed9eba1u : t < 60 ? 0x8f1bbcdcu : 0xca62c1d6u;
+    const gdv_uint32 tmp = gdv_rotl32(a, 5) + f + e + k + w[t & 15];
+    e = d; d = c; c = gdv_rotl32(b, 30); b = a; a = tmp;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e;
+}
+GDV_DEV void gdv_md5_block(gdv_uint32 (&h)[8], gdv_uint32 (&w)[16]) {
+  static constexpr gdv_uint32 K[64] = {
+      0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u, 0x698098d8u, 0x8b44f7afu,
+      0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u, 0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau,
+      0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u, 0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u,
+      0x676f02d9u, 0x8d2a4c8au, 0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
+      0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u, 0xf4292244u, 0x432aff97u,
+      0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u, 0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u,
+      0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
+  static constexpr int R[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 5, 9,  14, 20,
+                                4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+  gdv_uint32 a = h[0], b = h[1], c = h[2], d = h[3];
+#pragma unroll
+  for (int t = 0; t < 64; t++) {
+    const gdv_uint32 f = t < 16 ? ((b & c) | (~b & d)) : t < 32 ? ((d & b) | (~d & c)) : t < 48 ? (b ^ c ^ d) : (c ^ (b | ~d));
+    const int g = t < 16 ? t : t < 32 ? (5 * t + 1) & 15 : t < 48 ? (3 * t + 5) & 15 : (7 * t) & 15;
+    const gdv_uint32 tmp = d;
+    d = c;
+    c = b;
+    b = b + gdv_rotl32(a + f + K[t] + w[g], R[t]);
+    a = tmp;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+}
+// eight hexadecimal digits of x, most significant first, as the 8 bytes of one word
+GDV_DEV gdv_uint64 gdv_hex8(gdv_uint32 x) {
+  gdv_uint64 v = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) v |= (gdv_uint64)((x >> (28 - 4 * j)) & 0xfu) << (8 * j);
+  const gdv_uint64 letter = ((v + 0x0606060606060606ull) >> 4) & 0x0101010101010101ull;  // 1 where the nibble is 10..15
+  return v + 0x3030303030303030ull + letter * 39ull;
+}
+template <typename P>
+GDV_DEV void gdv_copy_digest(P dst, const gdv_str& s) {
+  const int algo = (s.map >> 8) & 3;  // 0 SHA-256, 1 SHA-1, 2 MD5
+  gdv_uint32 h[8];
+  if (algo == 0) {
+    h[0] = 0x6a09e667u; h[1] = 0xbb67ae85u; h[2] = 0x3c6ef372u; h[3] = 0xa54ff53au;
+    h[4] = 0x510e527fu; h[5] = 0x9b05688cu; h[6] = 0x1f83d9abu; h[7] = 0x5be0cd19u;
+  } else {
+    h[0] = 0x67452301u; h[1] = 0xefcdab89u; h[2] = 0x98badcfeu; h[3] = 0x10325476u; h[4] = 0xc3d2e1f0u; h[5] = 0; h[6] = 0; h[7] = 0;
+  }
+  const gdv_int32 mlen = gdv_digest_message_len(s);
+  const gdv_int32 nblocks = (mlen + 9 + 63) / 64;
+  const gdv_uint64 bits = (gdv_uint64)mlen * 8;
+  for (gdv_int32 b = 0; b < nblocks; b++) {
+    gdv_uint32 w[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      gdv_uint64 c = gdv_digest_chunk(s, 8 * b + j);
+      if (b == nblocks - 1 && j == 7) c = algo == 2 ? bits : __builtin_bswap64(bits);  // the closing 64-bit bit count
+      // SHA reads the message as big-endian 32-bit words, MD5 as little-endian ones
+      w[2 * j] = algo == 2 ? (gdv_uint32)c : __builtin_bswap32((gdv_uint32)c);
+      w[2 * j + 1] = algo == 2 ? (gdv_uint32)(c >> 32) : __builtin_bswap32((gdv_uint32)(c >> 32));
+    }
+    if (algo == 0) gdv_sha256_block(h, w);
+    else if (algo == 1) gdv_sha1_block(h, w);
+    else gdv_md5_block(h, w);
+  }
+  const int words = algo == 0 ? 8 : algo == 1 ? 5 : 4;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if (j < words) {
+      const gdv_uint64 t = gdv_hex8(algo == 2 ? __builtin_bswap32(h[j]) : h[j]);
+      __builtin_memcpy(dst + 8 * j, &t, 8);
+    }
+  }
+}
 template <typename P>
 GDV_DEV void gdv_copy_special(P dst, const gdv_str& s) {
-  if (s.map & GDV_MAP_INITCAP) gdv_copy_initcap(dst, s);
+  if (s.map & GDV_MAP_DIGEST) gdv_copy_digest(dst, s);
+  else if (s.map & GDV_MAP_INITCAP) gdv_copy_initcap(dst, s);
   else if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s);
   else if (s.map & GDV_MAP_REPLACE) gdv_copy_replaced(dst, s);
   else gdv_copy_reversed(dst, s);
@@ -1912,6 +2049,40 @@ GDV_DEV gdv_str reverse_utf8(gdv_ctx ctx, gdv_str s) {
   s.map |= GDV_MAP_REVERSE;
   return s;
 }
+
+// hashSHA256 / hashSHA1 / hashMD5 (and their sha256 / sha1 / sha / md5 aliases): a view whose text the output copy
+// computes.  Never null: a NULL argument is the empty message.
+GDV_DEV gdv_str gdv_digest_of_str(gdv_str s, bool valid, int algo) {
+  gdv_str r = s;
+  r.lead_p = s.p;
+  r.lead = valid && s.len > 0 ? (gdv_uint64)s.len : 0ull;
+  r.p = nullptr;
+  r.len = algo == 0 ? 64 : algo == 1 ? 40 : 32;
+  r.map = GDV_MAP_DIGEST | (algo << 8) | (s.map & GDV_MAP_CASE);
+  return r;
+}
+GDV_DEV gdv_str gdv_digest_of_f64(gdv_float64 v, bool valid, int algo) {
+  gdv_str r = gdv_empty_str();
+  r.lead_p = nullptr;
+  r.lead = 0;
+  r.len = algo == 0 ? 64 : algo == 1 ? 40 : 32;
+  r.map = GDV_MAP_DIGEST | (algo << 8);
+  if (valid) {
+    __builtin_memcpy(&r.lead, &v, 8);
+    r.map |= 1024;
+  }
+  return r;
+}
+#define GDV_DIGEST_FNS(NAME, ALGO)                                                                                   \
+  GDV_DEV gdv_str NAME##_utf8(gdv_str s, bool valid) { return gdv_digest_of_str(s, valid, ALGO); }                     \
+  GDV_DEV gdv_str NAME##_binary(gdv_str s, bool valid) { return gdv_digest_of_str(s, valid, ALGO); }                   \
+  GDV_DEV gdv_str NAME##_int32(gdv_int32 v, bool valid) { return gdv_digest_of_f64((gdv_float64)v, valid, ALGO); }     \
+  GDV_DEV gdv_str NAME##_int64(gdv_int64 v, bool valid) { return gdv_digest_of_f64((gdv_float64)v, valid, ALGO); }     \
+  GDV_DEV gdv_str NAME##_float32(gdv_float32 v, bool valid) { return gdv_digest_of_f64((gdv_float64)v, valid, ALGO); } \
+  GDV_DEV gdv_str NAME##_float64(gdv_float64 v, bool valid) { return gdv_digest_of_f64(v, valid, ALGO); }
+GDV_DIGEST_FNS(hashSHA256, 0)
+GDV_DIGEST_FNS(hashSHA1, 1)
+GDV_DIGEST_FNS(hashMD5, 2)
 GDV_DEV gdv_str initcap_utf8(gdv_str s) {
   s.map |= GDV_MAP_INITCAP;
   return s;

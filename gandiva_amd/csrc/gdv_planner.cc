@@ -610,7 +610,9 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       out->pieces.clear();
       out->col_slot = -1;
       out->col_map = 0;
-      out->opaque = fn.name() == "reverse" || fn.name() == "replace" || fn.name() == "initcap" ||
+      const bool digest = fn.name().compare(0, 4, "hash") == 0 ? fn.return_type().is_varlen()
+                                                                : (fn.name() == "sha256" || fn.name() == "sha1" || fn.name() == "sha" || fn.name() == "md5");
+      out->opaque = fn.name() == "reverse" || fn.name() == "replace" || fn.name() == "initcap" || digest ||
                     (fn.name() == "castVARCHAR" && !args[0].type.is_varlen());
       if ((fn.name() == "upper" || fn.name() == "lower") && args.size() == 1 && args[0].col_slot >= 0) {
         out->col_slot = args[0].col_slot;
@@ -2324,7 +2326,8 @@ enum class StringShape { kScanner, kWaveMain, kWavePrepass, kWaveMainExact, kWav
 bool ByteFree(const Node& n) {
   static const std::set<std::string> over_strings = {
       "substr", "substring", "left", "right", "upper", "lower", "octet_length", "bit_length", "char_length",
-      "length", "lengthUtf8", "castVARCHAR", "concat", "concatOperator", "reverse", "initcap", "lpad", "rpad", "isnull",
+      "length", "lengthUtf8", "castVARCHAR", "concat", "concatOperator", "reverse", "initcap", "lpad", "rpad", "isnull", "hashSHA256", "sha256",
+      "hashSHA1", "sha1", "sha", "hashMD5", "md5",
       "isnotnull"};
   switch (n.kind()) {
     case NodeKind::kField:
@@ -3226,7 +3229,8 @@ bool MaterialisesBytes(const Node& n) {
   if (n.kind() != NodeKind::kFunction) return false;
   auto& fn = static_cast<const FunctionNode&>(n);
   const std::string& f = fn.name();
-  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse" || f == "replace" || f == "initcap")
+  if (f == "concat" || f == "concatOperator" || f == "lpad" || f == "rpad" || f == "reverse" || f == "replace" || f == "initcap" ||
+      f == "hashSHA256" || f == "sha256" || f == "hashSHA1" || f == "sha1" || f == "sha" || f == "hashMD5" || f == "md5")
     return true;
   return f == "castVARCHAR" && !fn.children().empty() && !fn.children()[0]->return_type().is_varlen();
 }

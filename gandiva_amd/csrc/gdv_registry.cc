@@ -319,6 +319,12 @@ FunctionRegistry::FunctionRegistry() {
   add("castVARCHAR", {int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("reverse", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("initcap", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
+  // message digests (round 5): lower-case hex text, never null (a NULL hashes as the empty message)
+  for (auto& t : std::vector<DataType>{utf8(), binary(), int32(), int64(), float32(), float64()}) {
+    for (const char* f : {"hashSHA256", "sha256"}) add(f, {t}, utf8(), NullPolicy::kNullNever, kVarlenResult, Sym("hashSHA256", {t}));
+    for (const char* f : {"hashSHA1", "sha1", "sha"}) add(f, {t}, utf8(), NullPolicy::kNullNever, kVarlenResult, Sym("hashSHA1", {t}));
+    for (const char* f : {"hashMD5", "md5"}) add(f, {t}, utf8(), NullPolicy::kNullNever, kVarlenResult, Sym("hashMD5", {t}));
+  }
   add("replace", {utf8(), utf8(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext,
       "gdv_replace");  // planned by gdv_planner.cc (literal from / to)
   // lpad / rpad: planned as two pieces (gdv_planner.cc), literal length and fill only

@@ -78,6 +78,9 @@
  *         lineage leaves that type to the caller as well); overflow of that precision -> 0.  The arithmetic is pinned
  *         against Python's decimal (ROUND_HALF_UP / ROUND_DOWN / ROUND_CEILING / ROUND_FLOOR); that these are the
  *         lineage's rules (and its result types) is recollection.
+ *       - hashSHA256 / hashSHA1 / hashMD5 (sha256 / sha1 / sha / md5): the digests themselves are FIPS 180-4 / RFC 1321 and
+ *         pinned against Python's hashlib; that a NUMBER is hashed as the 8 bytes of (double)value, a NULL as the empty
+ *         message, and that the text is lower-case hex, is recollection.
  *       - regexp_like / regexp_matches / regexp_replace: the lineage runs RE2 (PartialMatch / GlobalReplace); only the
  *         LITERAL SUBSET exists here ([^]lit[$] without metacharacters; replacement without backslashes), where RE2's
  *         semantics are contains / starts / ends / equals and left-to-right non-overlapping replace — checked against
@@ -774,6 +777,94 @@ static i128 dec_round_to(i128 x, int xs, int k, int mode, int op, int os) {
   return dec_rescale(q, at, op, os);
 }
 
+/* ---- message digests: hashSHA256 / hashSHA1 / hashMD5 (+ sha256 / sha1 / sha / md5) [recalled: gandiva/hash_utils.cc,
+ * gdv_function_stubs.cc: lower-case hex of the digest of a string's bytes; of a number, of the 8 bytes of (double)value;
+ * of a NULL, of the empty message; never null].  FIPS 180-4 / RFC 1321, the textbook array formulations; pinned
+ * against Python's hashlib in tests/test_registry_tail.py. */
+static uint32_t rol32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+static uint32_t ror32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static const uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+/* digest of msg[0..len): algo 0 SHA-256 (32 bytes), 1 SHA-1 (20), 2 MD5 (16); returns the digest length */
+static int digest_bytes(int algo, const uint8_t* msg, size_t len, uint8_t* out) {
+  size_t padded = ((len + 9 + 63) / 64) * 64;
+  uint8_t* m = (uint8_t*)calloc(padded, 1);
+  memcpy(m, msg, len);
+  m[len] = 0x80;
+  uint64_t bits = (uint64_t)len * 8;
+  for (int k = 0; k < 8; k++) m[padded - 1 - (algo == 2 ? 7 - k : k)] = (uint8_t)(bits >> (8 * k));
+  uint32_t h[8] = {0x67452301, 0xefcdab89, 0x98badcfe, 0x10325476, 0xc3d2e1f0, 0, 0, 0};
+  if (algo == 0) {
+    static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(h, iv, sizeof iv);
+  }
+  for (size_t off = 0; off < padded; off += 64) {
+    uint32_t w[80];
+    for (int t = 0; t < 16; t++) {
+      const uint8_t* q = m + off + 4 * t;
+      w[t] = algo == 2 ? ((uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24)
+                       : ((uint32_t)q[0] << 24 | (uint32_t)q[1] << 16 | (uint32_t)q[2] << 8 | (uint32_t)q[3]);
+    }
+    if (algo == 0) {
+      for (int t = 16; t < 64; t++) {
+        uint32_t s0 = ror32(w[t - 15], 7) ^ ror32(w[t - 15], 18) ^ (w[t - 15] >> 3);
+        uint32_t s1 = ror32(w[t - 2], 17) ^ ror32(w[t - 2], 19) ^ (w[t - 2] >> 10);
+        w[t] = w[t - 16] + s0 + w[t - 7] + s1;
+      }
+      uint32_t v[8];
+      memcpy(v, h, sizeof v);
+      for (int t = 0; t < 64; t++) {
+        uint32_t t1 = v[7] + (ror32(v[4], 6) ^ ror32(v[4], 11) ^ ror32(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + SHA256_K[t] + w[t];
+        uint32_t t2 = (ror32(v[0], 2) ^ ror32(v[0], 13) ^ ror32(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+        for (int k = 7; k > 0; k--) v[k] = v[k - 1];
+        v[4] += t1;
+        v[0] = t1 + t2;
+      }
+      for (int k = 0; k < 8; k++) h[k] += v[k];
+    } else if (algo == 1) {
+      for (int t = 16; t < 80; t++) w[t] = rol32(w[t - 3] ^ w[t - 8] ^ w[t - 14] ^ w[t - 16], 1);
+      uint32_t A = h[0], B = h[1], C2 = h[2], D = h[3], E = h[4];
+      for (int t = 0; t < 80; t++) {
+        uint32_t fn = t < 20 ? ((B & C2) | (~B & D)) : t < 40 ? (B ^ C2 ^ D) : t < 60 ? ((B & C2) | (B & D) | (C2 & D)) : (B ^ C2 ^ D);
+        uint32_t kk = t < 20 ? 0x5a827999 : t < 40 ? 0x6ed9eba1 : t < 60 ? 0x8f1bbcdc : 0xca62c1d6;
+        uint32_t tmp = rol32(A, 5) + fn + E + kk + w[t];
+        E = D; D = C2; C2 = rol32(B, 30); B = A; A = tmp;
+      }
+      h[0] += A; h[1] += B; h[2] += C2; h[3] += D; h[4] += E;
+    } else {
+      static const int R[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+      uint32_t A = h[0], B = h[1], C2 = h[2], D = h[3];
+      for (int t = 0; t < 64; t++) {
+        uint32_t fn; int g;
+        if (t < 16) { fn = (B & C2) | (~B & D); g = t; }
+        else if (t < 32) { fn = (D & B) | (~D & C2); g = (5 * t + 1) % 16; }
+        else if (t < 48) { fn = B ^ C2 ^ D; g = (3 * t + 5) % 16; }
+        else { fn = C2 ^ (B | ~D); g = (7 * t) % 16; }
+        /* K[t] = floor(2^32 * |sin(t + 1)|) */
+        uint32_t kt = (uint32_t)(int64_t)floor(fabs(sin((double)(t + 1))) * 4294967296.0);
+        uint32_t tmp = D;
+        D = C2; C2 = B; B = B + rol32(A + fn + kt + w[g], R[t / 16][t % 4]); A = tmp;
+      }
+      h[0] += A; h[1] += B; h[2] += C2; h[3] += D;
+    }
+  }
+  free(m);
+  int nb = algo == 0 ? 32 : algo == 1 ? 20 : 16;
+  for (int k = 0; k < nb; k++) out[k] = algo == 2 ? (uint8_t)(h[k / 4] >> (8 * (k % 4))) : (uint8_t)(h[k / 4] >> (24 - 8 * (k % 4)));
+  return nb;
+}
+static int digest_algo(const char* f) {
+  if (!strcmp(f, "hashSHA256") || !strcmp(f, "sha256")) return 0;
+  if (!strcmp(f, "hashSHA1") || !strcmp(f, "sha1") || !strcmp(f, "sha")) return 1;
+  if (!strcmp(f, "hashMD5") || !strcmp(f, "md5")) return 2;
+  return -1;
+}
+
 static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* active,
                           vec* out) {
   const char* f = n->name;
@@ -793,7 +884,33 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
     out->valid[i] = v;
   }
   int op;
-  if (is_str(t0) && !strncmp(f, "concat", 6)) {
+  if (digest_algo(f) >= 0) {
+    const int algo = digest_algo(f);
+    for (int i = 0; i < cnt; i++) {
+      uint8_t msg8[8], dg[32];
+      const uint8_t* msg = msg8;
+      size_t ml = 0;
+      uint8_t* tmp = NULL;
+      if (a[0].valid[i]) {
+        if (is_str(t0)) {
+          ml = (size_t)(a[0].sl[i] > 0 ? a[0].sl[i] : 0);
+          tmp = (uint8_t*)malloc(ml + 1);
+          for (size_t k = 0; k < ml; k++) tmp[k] = map_byte(a[0].sp[i][k], a[0].sm[i]);
+          msg = tmp;
+        } else {
+          uint64_t bits = dbits(as_double(t0, &a[0], i));
+          memcpy(msg8, &bits, 8);
+          ml = 8;
+        }
+      }
+      int nb = digest_bytes(algo, msg, ml, dg);
+      uint8_t* dst = arena_alloc(c, 64);
+      for (int k = 0; k < nb; k++) { dst[2 * k] = (uint8_t)"0123456789abcdef"[dg[k] >> 4]; dst[2 * k + 1] = (uint8_t)"0123456789abcdef"[dg[k] & 15]; }
+      out->sp[i] = dst; out->sl[i] = 2 * nb; out->sm[i] = 0;
+      out->valid[i] = 1;
+      free(tmp);
+    }
+  } else if (is_str(t0) && !strncmp(f, "concat", 6)) {
     /* concat: a null argument is the empty string, never null; concatOperator (||): null if
      * any argument is null.  The bytes are materialised (byte maps applied) in the chunk arena. */
     const int never_null = f[6] == '\0';

@@ -237,6 +237,24 @@ void host_str_initcap(const int* off, const unsigned char* data, long size, long
     out_off[i + 1] = (int)at;
   }
 }
+// message digests (round 5): algo 0 SHA-256, 1 SHA-1, 2 MD5 over string rows (valid[i] = 0: NULL -> the empty message) ...
+void host_str_digest(int algo, const int* off, const unsigned char* data, long size, long n, const unsigned char* valid, int map,
+                     unsigned char* out /* n x 64 bytes */) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    if (map == 1) s = upper_utf8(s);
+    const gdv_str r = algo == 0 ? hashSHA256_utf8(s, valid[i] != 0) : algo == 1 ? hashSHA1_utf8(s, valid[i] != 0) : hashMD5_utf8(s, valid[i] != 0);
+    gdv_str_copy(out + 64 * i, r);
+  }
+}
+// ... and over numbers (hashed as the 8 bytes of the double)
+void host_f64_digest(int algo, const double* v, long n, const unsigned char* valid, unsigned char* out) {
+  for (long i = 0; i < n; i++) {
+    const gdv_str r = algo == 0 ? hashSHA256_float64(v[i], valid[i] != 0) : algo == 1 ? hashSHA1_float64(v[i], valid[i] != 0) : hashMD5_float64(v[i], valid[i] != 0);
+    gdv_str_copy(out + 64 * i, r);
+  }
+}
 // lpad (right = 0) / rpad (right = 1): `tab` is the fill repeated to `want` characters, readable
 // 8 bytes past its end (what the planner lays out in the constant block)
 long host_str_pad(int right, const int* off, const unsigned char* data, long size, long n, int want,

@@ -387,7 +387,8 @@ def _rounding_cases(rng):
 def _rounding_batch(rng, t, n):
     x = _dense_decimals(rng, t, n)
     ks = rng.integers(-6, t.scale + 4, n).astype(np.int32)
-    ks[:6] = [0, t.scale, t.scale + 1, -1, -38, -39][:6]
+    edge = [0, t.scale, t.scale + 1, -1, -38, -39][:n]
+    ks[:len(edge)] = edge
     kmask = rng.random(n) < 0.05
     return pa.RecordBatch.from_arrays([x, pa.array(ks, pa.int32(), mask=kmask)], names=["x", "k"])
 

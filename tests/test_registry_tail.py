@@ -388,3 +388,108 @@ def test_regexp_subset_on_the_gpu(n):
     cond = b.make_condition(b.make_function("regexp_like", [s, b.make_literal("^spark", STR)], pa.bool_()))
     sel = gandiva.make_filter(batch.schema, cond).evaluate(batch, None, "int32")
     assert sel.to_array().equals(oracle.filter_indices(cond, batch, "int32"))
+
+
+# ------------------------------------------------------------------ round 5: hashSHA256 / hashSHA1 / hashMD5
+# The digests are public standards: pinned against Python's hashlib.  [recalled] a number is hashed as the 8 bytes of
+# (double)value, a NULL as the empty message, the result is lower-case hex and never null.
+
+import hashlib  # noqa: E402
+import struct  # noqa: E402
+
+DIGESTS = [("hashSHA256", "sha256", hashlib.sha256, 0), ("hashSHA1", "sha1", hashlib.sha1, 1), ("hashMD5", "md5", hashlib.md5, 2)]
+DIGEST_TEXTS = ["", "a", "abc", "message digest", "x" * 55, "y" * 56, "z" * 63, "w" * 64, "v" * 65, "u" * 119, "t" * 120, "s" * 1000,
+                "The quick brown fox jumps over the lazy dog", "日本語テキスト", "é" * 40]
+
+
+def _digest_batch(n, seed=5):
+    rng = np.random.default_rng(seed)
+    base = W.c5_batch(n, 0.1).column(0).to_pylist()
+    vals = [(DIGEST_TEXTS[int(rng.integers(0, len(DIGEST_TEXTS)))] if rng.random() < 0.3 else v) for v in base]
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 12, n)
+    x[:4] = [0.0, -0.0, 1.0, -1.5]
+    k = rng.integers(-2 ** 40, 2 ** 40, n)
+    m = rng.random(n) < 0.1
+    return pa.RecordBatch.from_arrays([pa.array(vals, STR), pa.array(x, pa.float64(), mask=m), pa.array(k, pa.int64(), mask=m),
+                                       pa.array((k % 1000).astype(np.int32), pa.int32())], names=["s", "x", "k", "i"])
+
+
+def _digest_exprs(b, batch):
+    s, x, k, i32 = (b.make_field(batch.schema.field(j)) for j in range(4))
+    out = []
+    for name, alias, fn, _ in DIGESTS:
+        out += [(f"{name}(s)", b.make_function(name, [s], STR), ("s", fn)), (f"{alias}(upper(s))", b.make_function(alias, [b.make_function("upper", [s], STR)], STR), ("S", fn)),
+                (f"{name}(x)", b.make_function(name, [x], STR), ("x", fn)), (f"{alias}(k)", b.make_function(alias, [k], STR), ("k", fn)),
+                (f"{name}(i)", b.make_function(name, [i32], STR), ("i", fn))]
+    return out
+
+
+def _digest_want(batch, what, fn):
+    col = {"s": 0, "S": 0, "x": 1, "k": 2, "i": 3}[what]
+    want = []
+    for v in batch.column(col).to_pylist():
+        if v is None:
+            msg = b""
+        elif what == "s":
+            msg = v.encode()
+        elif what == "S":
+            msg = v.encode().upper()
+        else:
+            msg = struct.pack("<d", float(v))
+        want.append(fn(msg).hexdigest())
+    return want
+
+
+def test_oracle_digests_match_hashlib():
+    batch = _digest_batch(1500)
+    b = gandiva.TreeExprBuilder()
+    cases = _digest_exprs(b, batch)
+    exprs = [b.make_expression(node, pa.field(f"h{j}", STR)) for j, (_, node, _) in enumerate(cases)]
+    for (name, _, (what, fn)), g in zip(cases, oracle.project(exprs, batch)):
+        assert g.null_count == 0 and g.to_pylist() == _digest_want(batch, what, fn), name
+
+
+def test_device_digests_on_the_host(hostlib):  # noqa: F811
+    batch = _digest_batch(600, seed=8)
+    arr = batch.column(0)
+    vals = arr.to_pylist()
+    filled = pa.array([v if v is not None else "" for v in vals], STR)
+    off = np.frombuffer(filled.buffers()[1], np.int32)[: len(vals) + 1].copy()
+    size = int(off[-1])
+    data = np.concatenate([np.frombuffer(filled.buffers()[2], np.uint8)[:size], np.zeros(64, np.uint8)])
+    valid = np.array([v is not None for v in vals], np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for _, _, fn, algo in DIGESTS:
+        nhex = fn(b"").digest_size * 2
+        for mp, what in ((0, "s"), (1, "S")):
+            out = np.zeros(64 * len(vals), np.uint8)
+            hostlib.host_str_digest(algo, p(off), p(data), C.c_long(size), C.c_long(len(vals)), p(valid), mp, p(out))
+            got = [bytes(out[64 * i:64 * i + nhex]).decode() for i in range(len(vals))]
+            assert got == _digest_want(batch, what, fn), (algo, mp)
+        x = np.asarray(batch.column(1).fill_null(0.0), np.float64)
+        xv = np.array([v is not None for v in batch.column(1).to_pylist()], np.uint8)
+        out = np.zeros(64 * len(x), np.uint8)
+        hostlib.host_f64_digest(algo, p(x), C.c_long(len(x)), p(xv), p(out))
+        got = [bytes(out[64 * i:64 * i + nhex]).decode() for i in range(len(x))]
+        assert got == _digest_want(batch, "x", fn), algo
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 20_011])
+def test_digests_on_the_gpu(n):
+    batch = _digest_batch(n, seed=n)
+    b = gandiva.TreeExprBuilder()
+    cases = _digest_exprs(b, batch)
+    for lo in range(0, len(cases), 5):     # one projector per algorithm (a wave's LDS staging windows are three)
+        part = cases[lo:lo + 5]
+        for j in range(0, len(part), 3):
+            exprs = [b.make_expression(node, pa.field(f"h{q}", STR)) for q, (_, node, _) in enumerate(part[j:j + 3])]
+            got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+            for g, w, (name, _, _) in zip(got, oracle.project(exprs, batch), part[j:j + 3]):
+                assert_bit_exact(g, w, name)
+    # a digest as the argument of another function: two stages
+    s = b.make_field(batch.schema.field(0))
+    e = b.make_expression(b.make_function("upper", [b.make_function("substr", [b.make_function("hashMD5", [s], STR), b.make_literal(1, pa.int64()),
+                                                                             b.make_literal(8, pa.int64())], STR)], STR), pa.field("u", STR))
+    got = gandiva.make_projector(batch.schema, [e], None).evaluate(batch)
+    assert_bit_exact(got[0], oracle.project([e], batch)[0], "upper(substr(hashMD5(s), 1, 8))")
