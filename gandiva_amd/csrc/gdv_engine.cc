@@ -372,12 +372,17 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
           return Status::Invalid("column '" + name + "': offsets buffer too small");
         const char* osrc = static_cast<const char*>(c.offsets) + c.offset * 4;
         if (mem == MemKind::kHost) {
-          void *dof = nullptr, *dd = nullptr;
-          GDV_RETURN_NOT_OK(st->In(osrc, (num_rows + 1) * 4, (num_rows + 1) * 4, stream, &dof));
+          // Round 5: offsets and bytes that lie in REGISTERED host memory (gdv_host_register / gdv_host_alloc) are
+          // read in place over the fabric, like fixed-width columns since round 4.  The bytes need their 16-byte
+          // granule behind the last byte inside the registered range as well (the sweep reads whole pieces: Arrow's
+          // zeroed 64-byte padding covers it; a buffer that ends flush with its range is staged as before).
+          void* dof = (reinterpret_cast<uintptr_t>(osrc) & 3) == 0 ? HostRegistry::Get().View(osrc, (num_rows + 1) * 4) : nullptr;
+          void* dd = c.data_size >= 8 ? HostRegistry::Get().View(c.data, c.data_size + 16) : nullptr;
+          if (dof == nullptr) GDV_RETURN_NOT_OK(st->In(osrc, (num_rows + 1) * 4, (num_rows + 1) * 4, stream, &dof));
           // (16 zero bytes behind the last byte: the byte sweep reads whole 16-byte pieces, and whatever
           // the block held before must not look like a byte >= 0x80 — it would send an ASCII batch to
           // the exact variant of the string kernels for nothing)
-          GDV_RETURN_NOT_OK(st->In(c.data, c.data_size, c.data_size + 16, stream, &dd));
+          if (dd == nullptr) GDV_RETURN_NOT_OK(st->In(c.data, c.data_size, c.data_size + 16, stream, &dd));
           args->SetInOffsets(static_cast<int>(k), dof);
           args->SetInData(static_cast<int>(k), dd);
         } else if (c.data_size < 8) {

@@ -454,10 +454,13 @@ class HostArena:
     def allocate(self, nbytes):
         """A 64-byte aligned, 64-byte padded pyarrow buffer of ``nbytes`` bytes inside the arena."""
         at = (self._base + self._used + 63) // 64 * 64 - self._base
-        room = _pad64(max(int(nbytes), 1))
+        # (16 zeroed bytes behind every buffer: the string kernels sweep var-len bytes in whole 16-byte pieces —
+        # in place, since round 5 — and what follows the last byte must not look like text)
+        room = _pad64(max(int(nbytes), 1) + 16)
         if at + room > self._size:
             raise MemoryError(f"HostArena: {nbytes} bytes do not fit ({self._size - at} left)")
         self._used = at + room
+        C.memset(self._base + at + int(nbytes), 0, room - int(nbytes))
         return pa.foreign_buffer(self._base + at, int(nbytes), base=self)
 
     def place(self, batch):

@@ -90,12 +90,31 @@ def test_registered_memory_of_the_caller_sliced_batches_bool_outputs_and_the_fil
 
 
 @pytest.mark.gpu
-def test_var_len_plans_keep_staging_their_bytes_and_still_agree():
+def test_var_len_columns_in_registered_memory_are_read_in_place():
+    """Round 5: the offsets and the bytes of a utf8 column that lies in registered host memory are bound in place
+    (round 4 staged them); var-len OUTPUTS still come back through the staging block."""
     n = 20_011
     batch = W.c5_batch(n, 0.1)
-    exprs = W.c5_expressions()
-    proj = gandiva.make_projector(batch.schema, exprs, None)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    fixed = [b.make_expression(b.make_function("like", [s, b.make_literal("%spark%", pa.string())], pa.bool_()), pa.field("m", pa.bool_())),
+             b.make_expression(b.make_function("char_length", [s], pa.int32()), pa.field("n", pa.int32())),
+             b.make_expression(b.make_function("hash64", [s], pa.int64()), pa.field("h", pa.int64()))]
     arena = gandiva.HostArena(64 << 20)
-    got = proj.evaluate(arena.place(batch), arena=arena)
-    for g, w in zip(got, oracle.project(exprs, batch)):
+    placed = arena.place(batch)
+    proj = gandiva.make_projector(batch.schema, fixed, None)
+    proj.evaluate(placed, arena=arena)                       # (first call: whatever Make-time uploads there are)
+    before = gandiva.host_staged_bytes()
+    got = proj.evaluate(placed, arena=arena)
+    assert gandiva.host_staged_bytes() == before, "a var-len column in an arena must not be staged"
+    for g, w in zip(got, oracle.project(fixed, batch)):
+        assert_bit_exact(g, w, "var-len input in place, fixed-width outputs")
+    # sliced (array offset) and multi-byte text
+    sl = arena.place(W.c5_batch(n, 0.1, non_ascii_fraction=0.05)).slice(777, 9000)
+    for g, w in zip(proj.evaluate(sl, arena=arena), oracle.project(fixed, sl)):
+        assert_bit_exact(g, w, "sliced, multi-byte")
+    # var-len outputs: inputs in place, outputs staged, same answers
+    exprs = W.c5_expressions()
+    p5 = gandiva.make_projector(batch.schema, exprs, None)
+    for g, w in zip(p5.evaluate(placed, arena=arena), oracle.project(exprs, batch)):
         assert_bit_exact(g, w, "C5 through an arena")
