@@ -148,6 +148,13 @@ def test_committed_pmc_files_belong_to_the_kernels_this_tree_generates(monkeypat
         want = json.load(open(os.path.join(here, "..", "profiles", f"pmc_{w}.json")))["kernel"]
         if want + ".hip" not in dumped:
             stale.append(f"profiles/pmc_{w}.json was measured on {want}; this tree generates {dumped}")
+        # ... and the latest round's rocprofv3 kernel stats of the same workload name a kernel this tree generates
+        import glob
+        stats = sorted(glob.glob(os.path.join(here, "..", "profiles", f"r[0-9][0-9]_{w}_kernel_stats.csv")))
+        if stats:
+            text = open(stats[-1]).read()
+            if want not in text:
+                stale.append(f"{os.path.basename(stats[-1])} was not taken on {want}, the kernel profiles/pmc_{w}.json names")
     if stale:
         msg = "; ".join(stale) + ": re-run tools/gpu_evidence.sh"
         # round 5: stale evidence FAILS.  Round 4 only warned here and shipped four orphaned counter files.

@@ -407,7 +407,7 @@ def _digest_batch(n, seed=5):
     base = W.c5_batch(n, 0.1).column(0).to_pylist()
     vals = [(DIGEST_TEXTS[int(rng.integers(0, len(DIGEST_TEXTS)))] if rng.random() < 0.3 else v) for v in base]
     x = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 12, n)
-    x[:4] = [0.0, -0.0, 1.0, -1.5]
+    x[:min(4, n)] = [0.0, -0.0, 1.0, -1.5][:n]
     k = rng.integers(-2 ** 40, 2 ** 40, n)
     m = rng.random(n) < 0.1
     return pa.RecordBatch.from_arrays([pa.array(vals, STR), pa.array(x, pa.float64(), mask=m), pa.array(k, pa.int64(), mask=m),

@@ -13,27 +13,33 @@
 export TMPDIR=/tmp
 ROUND=${ROUND:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/$ROUND; rm -rf $OUT; mkdir -p $OUT
+# WORKLOADS="c5" + NO_EXTRAS=1: re-take one workload's bench / rocprofv3 / PMC files after a change that renamed only its
+# kernels (the files merge into the round's directory; the other workloads' evidence stays valid — kernel identity).
+WL=${WORKLOADS:-"c2 c3 c4 c5"}
+OUT=$R/gpurun_out/$ROUND; [ -z "$WORKLOADS" ] && rm -rf $OUT; mkdir -p $OUT
 cd $R
 if [ -z "$SKIP_TESTS" ]; then
   python -m pytest tests -m gpu -q --timeout 1800 > $OUT/pytest_gpu_full.log 2>&1
   grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu_full.log | tail -5
 fi
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $OUT/smoke.log
-python bench.py --steps 20 --warmup 5 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-400 $OUT/bench_c2.json
-for w in c1 c3 c4 c5; do python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2>$OUT/bench_$w.err; done
-for w in c3 c4 c5; do python bench.py --workload $w --steps 3 --warmup 1 > $OUT/bench_${w}_cpu.json 2>/dev/null; done
+case " $WL " in *" c2 "*) python bench.py --steps 20 --warmup 5 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; cut -c1-400 $OUT/bench_c2.json;; esac
+[ -z "$WORKLOADS" ] && BENCH_WL="$WL c1" || BENCH_WL="$WL"
+for w in c1 c3 c4 c5; do case " $BENCH_WL " in *" $w "*) python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2>$OUT/bench_$w.err;; esac; done
+for w in c3 c4 c5; do case " $WL " in *" $w "*) python bench.py --workload $w --steps 3 --warmup 1 > $OUT/bench_${w}_cpu.json 2>/dev/null;; esac; done
 cd /tmp
-for w in c2 c3 c4 c5; do
+for w in $WL; do
   rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o $w --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline --no-verify > $OUT/prof_${w}_bench.json 2> /dev/null
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o $w --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
 done
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+case " $WL " in *" c5 "*) ;; *) SKIP_SQ=1;; esac
+[ -z "$SKIP_SQ" ] && for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace -d $OUT/sq_c5_$tag -o c5 --output-format csv -- python $R/bench.py --workload c5 --steps 3 --warmup 1 --placements 1 --no-cpu-baseline --no-verify > /dev/null 2>&1
 done
 cd $R
+if [ -z "$NO_EXTRAS" ]; then
 python tools/make_latency.py > $OUT/make_latency.txt 2>&1
 [ -x tools/hbm_ceiling ] && timeout 120 tools/hbm_ceiling > $OUT/hbm_ceiling.txt 2>&1
 [ -x tools/small_batch_bench ] && timeout 120 tools/small_batch_bench > $OUT/small_batches.txt 2>&1
@@ -55,6 +61,14 @@ grep '^"gdv_k_' $(find $OUT/prof_c5na -name "*kernel_stats.csv" | head -1) | awk
 for n in 1 2 8; do echo "--inproc --gpus $n: $(timeout 300 python bench.py --inproc --gpus $n --steps 10 --warmup 2 2>&1 | tail -1 | cut -c1-420)"; done > $OUT/inproc_bench.txt
 # the N-rank launch path on this one-GPU box (gloo: the ranks share cuda:0 — control flow, not scaling)
 echo "GDV_BENCH_BACKEND=gloo bench.py --gpus 2 --rows 16777216: $(GDV_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --rows 16777216 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 | cut -c1-600)" > $OUT/bench_two_ranks.txt
+fi
+if [ -n "$NO_EXTRAS" ]; then case " $WL " in *" c5 "*)
+  PYTHONPATH=$R timeout 300 python tools/c5_nonascii.py 2>&1 | grep -v amdgpu.ids > $OUT/c5_nonascii.txt
+  ( cd /tmp; rocprofv3 --kernel-trace --stats -d $OUT/prof_c5na -o na --output-format csv -- python $R/tools/c5_nonascii_profile.py > /dev/null 2>&1 )
+  grep '^"gdv_k_' $(find $OUT/prof_c5na -name "*kernel_stats.csv" | head -1) | awk -F, '{printf "rocprofv3, 1 %% non-ASCII rows: %s average %.4f ms over %s calls\n", $1, $4/1e6, $2}' >> $OUT/c5_nonascii.txt
+  PYTHONPATH=$R timeout 200 python tools/filter_string_chain.py 2>&1 | grep -v amdgpu.ids > $OUT/filter_string_chain.txt
+  GDV_NO_SEL_WAVE=1 PYTHONPATH=$R timeout 200 python tools/filter_string_chain.py 2>&1 | grep -v amdgpu.ids | sed 's/^/[scanner shape, rounds 2-4] /' >> $OUT/filter_string_chain.txt
+  PYTHONPATH=$R timeout 120 python tools/registry_tail_timing.py > $OUT/registry_tail_timing.txt 2>&1;; esac; fi
 find $OUT -name "*kernel_trace.csv" -size +1000k -delete   # raw traces are large; stats / counters stay
 find $OUT -name "*.csv" -size +8000k -delete
 du -sh $OUT; ls $OUT | head -70
