@@ -1856,6 +1856,10 @@ Status FilterProject::SetTuning(const std::string& key, int64_t value) {
   return Status::OK();
 }
 
+FilterProject::~FilterProject() {
+  if (int64_t* p = pinned_count_.load()) (void)hipHostFree(p);
+}
+
 int FilterProject::which_kernel() const {
   if (plan_.fp_window_rows <= 0 || plan_.exact == nullptr) return -1;
   if (pinned_kernel_.load(std::memory_order_relaxed) >= 0) return pinned_kernel_.load(std::memory_order_relaxed);
@@ -1956,6 +1960,10 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   if (!st.buffers.empty()) { async = false; drain.armed = true; }
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 
+  if (int64_t* seen = pinned_count_.load(std::memory_order_relaxed)) {  // what an earlier asynchronous call selected
+    const int64_t c = *reinterpret_cast<volatile int64_t*>(seen), r = pinned_rows_.load(std::memory_order_relaxed);
+    if (c >= 0 && r > 0 && c <= r) selected_per_1024_.store(static_cast<int>(c * 1024 / r), std::memory_order_relaxed);
+  }
   // which shape: the windowed kernel unless recent batches selected more rows than its LDS window holds (the
   // direct kernel takes the same argument block: PlanFilterProject checks that its literals and constants are a
   // prefix of the windowed plan's)
@@ -2024,9 +2032,25 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   const char* count_dev = base + state_b;
   // the count leaves through a one-thread kernel: -1 when the look-back gave up (GDV_ERR_STALL in the error word) —
   // round 4 copied the word as it was and an asynchronous caller never learnt that the outputs were not complete
-  if (count_out != nullptr)
+  int64_t* telemetry = nullptr;
+  if (async && plan_.exact != nullptr) {  // (two shapes to choose between: let the next call learn this one's count)
+    telemetry = pinned_count_.load(std::memory_order_relaxed);
+    if (telemetry == nullptr) {
+      int64_t* fresh = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&fresh), 64, hipHostMallocDefault) == hipSuccess && fresh != nullptr) {
+        fresh[0] = -1;
+        int64_t* expected = nullptr;
+        if (pinned_count_.compare_exchange_strong(expected, fresh)) telemetry = fresh;
+        else { (void)hipHostFree(fresh); telemetry = expected; }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    pinned_rows_.store(num_rows, std::memory_order_relaxed);
+  }
+  if (count_out != nullptr || telemetry != nullptr)
     GDV_HIP_RETURN_NOT_OK(LaunchPublishCount(static_cast<int64_t*>(count_out), reinterpret_cast<const int64_t*>(count_dev),
-                                             reinterpret_cast<const uint32_t*>(base + state_b + 64), kErrStall, stream));
+                                             reinterpret_cast<const uint32_t*>(base + state_b + 64), kErrStall, stream, telemetry));
   if (async) {
     if (num_selected != nullptr) *num_selected = -1;
     scratch.release_after(stream);

@@ -267,6 +267,7 @@ class FilterProject {
   // index_mode: element type of the selection vector the evaluation ALSO emits; kNone = none.
   static Status Make(const Schema& schema, const ExpressionPtr& condition, const std::vector<ExpressionPtr>& exprs,
                      SelectionMode index_mode, const Configuration& config, std::shared_ptr<FilterProject>* out);
+  ~FilterProject();
 
   // outs[e]: buffers for up to num_rows rows (the count is only known afterwards).  out_indices
   // (max_slots >= num_rows elements of the index mode) may be null when index_mode is kNone.
@@ -310,6 +311,10 @@ class FilterProject {
   // shape exists, plan_.exact the direct round-4 kernel.  Synchronous evaluations record the share of rows they
   // selected (x 1024); once it is beyond what the window holds, the next batches run on the direct kernel.
   mutable std::atomic<int> selected_per_1024_{-1};
+  // asynchronous evaluations never see their count on the host: the count also lands in this pinned word, and the NEXT
+  // call reads what the previous one left there (one batch late is early enough to pick the kernel shape)
+  mutable std::atomic<int64_t*> pinned_count_{nullptr};
+  mutable std::atomic<int64_t> pinned_rows_{0};
   mutable std::atomic<int> resident_per_cu_{0};
   std::atomic<int> pinned_kernel_{-1};  // pipelined shape: workgroups of the kernel one CU holds at once (queried once)
   mutable std::mutex chain_mu_;

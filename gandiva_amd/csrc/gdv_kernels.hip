@@ -528,12 +528,17 @@ hipError_t LaunchPublishStatus(uint64_t* result, const uint32_t* err, uint32_t c
   hipLaunchKernelGGL(PublishStatus, dim3(1), dim3(64), 0, stream, result, err, clear);
   return hipGetLastError();
 }
-__global__ void PublishCount(int64_t* __restrict__ dst, const int64_t* __restrict__ count, const uint32_t* __restrict__ err,
-                             uint32_t fatal) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = (err[0] & fatal) != 0 ? int64_t{-1} : count[0];
+__global__ void PublishCount(int64_t* __restrict__ dst, int64_t* __restrict__ also, const int64_t* __restrict__ count,
+                             const uint32_t* __restrict__ err, uint32_t fatal) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t v = (err[0] & fatal) != 0 ? int64_t{-1} : count[0];
+    if (dst != nullptr) dst[0] = v;
+    if (also != nullptr) also[0] = v;
+  }
 }
-hipError_t LaunchPublishCount(int64_t* dst, const int64_t* count, const uint32_t* err, uint32_t fatal, hipStream_t stream) {
-  hipLaunchKernelGGL(PublishCount, dim3(1), dim3(64), 0, stream, dst, count, err, fatal);
+hipError_t LaunchPublishCount(int64_t* dst, const int64_t* count, const uint32_t* err, uint32_t fatal, hipStream_t stream,
+                              int64_t* also) {
+  hipLaunchKernelGGL(PublishCount, dim3(1), dim3(64), 0, stream, dst, also, count, err, fatal);
   return hipGetLastError();
 }
 hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream) {

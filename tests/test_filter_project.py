@@ -377,3 +377,27 @@ def test_wave_tiles_of_several_rounds(monkeypatch, rounds, n):
                 assert sel.to_array().equals(want_sel), (thr, rep)
             for e, (g, w) in enumerate(zip(got, want)):
                 assert_bit_exact(g, w, f"threshold {thr}, expression {e}, {rounds} rounds, run {rep}")
+
+
+@pytest.mark.gpu
+def test_asynchronous_evaluations_move_the_kernel_shape_too():
+    """An asynchronous evaluation never sees its count on the host; the operator learns it one call late through a
+    pinned word of its own (the kernel that publishes the count writes it there as well)."""
+    import torch
+    n = 120_000
+    rng = np.random.default_rng(3)
+    batch = _batch(rng, n, 0.0)
+    cond, exprs = _plan(batch.schema, -1)          # every row selected
+    fp = gandiva.make_filter_project(batch.schema, cond, exprs[:3], "int32")   # (a plan that cannot raise: truly asynchronous)
+    db = gandiva.DeviceBatch.from_arrow(batch)
+    assert fp.kernel_shape == 0
+    outs, sel = fp.evaluate_device(db, sync=False)
+    torch.cuda.synchronize()
+    assert fp.kernel_shape == 0                    # nothing has read the pinned word yet
+    outs, sel = fp.evaluate_device(db, outputs=outs, indices=sel.indices, sync=False)   # reads what the first call left
+    torch.cuda.synchronize()
+    assert fp.kernel_shape == 1
+    want_sel, want = _chain(cond, exprs[:3], batch, "int32")
+    assert sel.num_slots == len(want_sel)
+    for o, w in zip(outs, want):
+        assert_bit_exact(o.to_arrow(), w, "asynchronous, direct kernel")
