@@ -14,6 +14,8 @@
 
 #include "gdv_kernels.h"
 
+#include <cstdlib>
+
 namespace gdv {
 
 namespace {
@@ -175,41 +177,41 @@ ScanSmall(const uint32_t* __restrict__ counts, int64_t m, int64_t stride,
 // store instruction at C3's selectivity: measured 0.82 ms for 10^9 rows vs the ~0.15 ms
 // the 0.66 GB of traffic costs.)  `offsets` holds the selected-row count before every group
 // of `subtiles` words (subtiles divides 64), so the wave's base is offsets[first group].
-constexpr int kEmitWords = 64;
+constexpr int kEmitWords = 64;  // (launcher default; the kernel is a template on it: GDV_EMIT_WORDS=32 for experiments)
 
-template <typename IndexT>
+template <typename IndexT, int kWords>
 __global__ void __launch_bounds__(256)
 EmitIndices(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ offsets,
             int64_t nwords, int subtiles, int64_t row_base, IndexT* __restrict__ out) {
   // positions inside the wave's 4096-row tile fit 12 bits: staging them as uint16 keeps the
   // window at 8 KiB per wave (32 KiB per workgroup, 5 workgroups per CU) whatever IndexT is
-  __shared__ uint16_t stage[4][kEmitWords * 64];
+  __shared__ uint16_t stage[4][kWords * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint16_t* buf = stage[wave];
-  const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
+  const int64_t ntiles = (nwords + kWords - 1) / kWords;
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t t = (int64_t)blockIdx.x * 4 + wave;
   // the next tile's mask word and base are loaded while the current tile is walked
   uint64_t m_next = 0, base_next = 0;
   if (t < ntiles) {
-    const int64_t w = t * kEmitWords + lane;
-    m_next = (w < nwords) ? mask[w] : 0ull;
-    base_next = offsets[(t * kEmitWords) / subtiles];
+    const int64_t w = t * kWords + lane;
+    m_next = (lane < kWords && w < nwords) ? mask[w] : 0ull;
+    base_next = offsets[(t * kWords) / subtiles];
   }
   for (; t < ntiles; t += stride) {
     uint64_t m = m_next;
     const uint64_t base = base_next;
     if (t + stride < ntiles) {
-      const int64_t w = (t + stride) * kEmitWords + lane;
-      m_next = (w < nwords) ? mask[w] : 0ull;
-      base_next = offsets[((t + stride) * kEmitWords) / subtiles];
+      const int64_t w = (t + stride) * kWords + lane;
+      m_next = (lane < kWords && w < nwords) ? mask[w] : 0ull;
+      base_next = offsets[((t + stride) * kWords) / subtiles];
     }
     const uint32_t c = (uint32_t)__popcll(m);
     const uint32_t incl = (uint32_t)WaveInclusiveScan(c, lane);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     uint32_t slot = incl - c;
-    const int64_t tile_row0 = row_base + t * (int64_t)(kEmitWords * 64);
+    const int64_t tile_row0 = row_base + t * (int64_t)(kWords * 64);
     while (m) {
       buf[slot++] = static_cast<uint16_t>((lane << 6) + __builtin_ctzll(m));
       m &= m - 1;
@@ -469,25 +471,22 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
                              int subtiles, int64_t row_base, int index_bytes, void* out,
                              int num_cus, hipStream_t stream) {
   if (nwords <= 0) return hipSuccess;
-  if (subtiles <= 0 || kEmitWords % subtiles != 0) return hipErrorInvalidValue;
-  const int64_t ntiles = (nwords + kEmitWords - 1) / kEmitWords;
+  // experiments (read once): words per wave tile (64, or 32: half the LDS window, twice the workgroups per CU) and the
+  // grid cap in workgroups per CU
+  static const int words = [] { const char* e = std::getenv("GDV_EMIT_WORDS"); return e != nullptr && atoi(e) == 32 ? 32 : kEmitWords; }();
+  static const int per_cu = [] { const char* e = std::getenv("GDV_EMIT_WGS_PER_CU"); return e != nullptr && atoi(e) > 0 ? atoi(e) : 0; }();
+  if (subtiles <= 0 || words % subtiles != 0) return hipErrorInvalidValue;
+  const int64_t ntiles = (nwords + words - 1) / words;
   int64_t grid = (ntiles + 3) / 4;
-  const int64_t cap = (int64_t)num_cus * 5;  // LDS allows 5 workgroups per CU
+  const int64_t cap = (int64_t)num_cus * (per_cu > 0 ? per_cu : (words == 32 ? 8 : 5));  // LDS: 5 workgroups per CU at 64 words, 8 waves per SIMD at 32
   if (grid > cap) grid = cap;
-  switch (index_bytes) {
-    case 2:
-      hipLaunchKernelGGL(EmitIndices<uint16_t>, dim3((unsigned)grid), dim3(256), 0, stream, mask,
-                         offsets, nwords, subtiles, row_base, static_cast<uint16_t*>(out));
-      break;
-    case 4:
-      hipLaunchKernelGGL(EmitIndices<uint32_t>, dim3((unsigned)grid), dim3(256), 0, stream, mask,
-                         offsets, nwords, subtiles, row_base, static_cast<uint32_t*>(out));
-      break;
-    default:
-      hipLaunchKernelGGL(EmitIndices<uint64_t>, dim3((unsigned)grid), dim3(256), 0, stream, mask,
-                         offsets, nwords, subtiles, row_base, static_cast<uint64_t*>(out));
-      break;
+#define GDV_EMIT(T, W) hipLaunchKernelGGL((EmitIndices<T, W>), dim3((unsigned)grid), dim3(256), 0, stream, mask, offsets, nwords, subtiles, row_base, static_cast<T*>(out))
+  if (words == 32) {
+    switch (index_bytes) { case 2: GDV_EMIT(uint16_t, 32); break; case 4: GDV_EMIT(uint32_t, 32); break; default: GDV_EMIT(uint64_t, 32); break; }
+  } else {
+    switch (index_bytes) { case 2: GDV_EMIT(uint16_t, 64); break; case 4: GDV_EMIT(uint32_t, 64); break; default: GDV_EMIT(uint64_t, 64); break; }
   }
+#undef GDV_EMIT
   return hipGetLastError();
 }
 
