@@ -478,7 +478,9 @@ hipError_t LaunchEmitIndices(const uint64_t* mask, const uint64_t* offsets, int6
   if (subtiles <= 0 || words % subtiles != 0) return hipErrorInvalidValue;
   const int64_t ntiles = (nwords + words - 1) / words;
   int64_t grid = (ntiles + 3) / 4;
-  const int64_t cap = (int64_t)num_cus * (per_cu > 0 ? per_cu : (words == 32 ? 8 : 5));  // LDS: 5 workgroups per CU at 64 words, 8 waves per SIMD at 32
+  // LDS would allow 5 workgroups per CU at 64 words (8 at 32); FOUR measured best at 10^9 rows, 1/8 selected, one box:
+  // 3 / 4 / 5 per CU: 0.218 / 0.189 / 0.232 ms; 32-word tiles 0.216-0.264 (profiles/r05_emit_indices_experiments.txt)
+  const int64_t cap = (int64_t)num_cus * (per_cu > 0 ? per_cu : 4);
   if (grid > cap) grid = cap;
 #define GDV_EMIT(T, W) hipLaunchKernelGGL((EmitIndices<T, W>), dim3((unsigned)grid), dim3(256), 0, stream, mask, offsets, nwords, subtiles, row_base, static_cast<T*>(out))
   if (words == 32) {
