@@ -47,7 +47,7 @@ def parse():
                    help="c2 inputs: pcg64 = BASELINE.md §4's frozen numpy PCG64 streams (value seeds 42-45, mask "
                         "seeds 142-145; generated on the host cores, uploaded before the timed region); "
                         "philox = same distributions from torch's device generator (faster to set up)")
-    p.add_argument("--placements", type=int, default=4,
+    p.add_argument("--placements", type=int, default=8,
                    help="projection workloads: allocate the batch's columns and outputs this many times, time 3 steps on "
                         "each placement and keep the fastest (profiles/r05_box_states.txt: where the driver puts the "
                         "buffers moves a C2 step between 4.9 and 7.0 ms, and stays with the buffers); 1 = first allocation")
