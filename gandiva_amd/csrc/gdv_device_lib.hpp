@@ -1326,8 +1326,88 @@ GDV_DEV void gdv_copy_dec_text(P dst, const gdv_dec_text& t, gdv_int32 len) {
     }
   }
 }
+// ---- float32 / float64 -> text (round 5).  castVARCHAR(real, n) keeps the value's SHORTEST round-trip
+// decimal digits (gdv_shortest_digits, further down) in the view: `p` = the digits as an integer D
+// (no trailing zeros, at most 17), `lim` = nd | (k + 2048) << 8 | neg << 24 | kind << 25 where
+// value = 0.D * 10^k and kind = 0 finite non-zero, 1 zero, 2 infinity, 3 NaN.  The text is the
+// Java-compatible form of gandiva/formatting_utils.h [as recalled: FloatToStringGdvMixin —
+// double-conversion ToShortest with "Infinity", "NaN", 'E', decimal_in_shortest_low -3, high 7,
+// trailing ".0"]:  x = k - 1 (the decimal exponent)
+//   -3 <= x < 7   ->  [-]ddd.ddd   (at least one digit either side of the point: 100.0, 0.001)
+//   otherwise     ->  [-]d.dddE[-]x (1.0E7, 1.234E-5)
+#define GDV_STR_REAL 64  // flags, with GDV_MAP_DIGITS
+struct gdv_real_text {
+  gdv_uint64 digits;
+  gdv_int32 nd, k, neg, kind, len;
+};
+GDV_DEV gdv_real_text gdv_real_text_of(gdv_uint64 digits, gdv_uint64 info) {
+  gdv_real_text t;
+  t.digits = digits;
+  t.nd = (gdv_int32)(info & 255);
+  t.k = (gdv_int32)((info >> 8) & 0xffff) - 2048;
+  t.neg = (gdv_int32)((info >> 24) & 1);
+  t.kind = (gdv_int32)((info >> 25) & 3);
+  const gdv_int32 x = t.k - 1, ax = x < 0 ? -x : x;
+  if (t.kind == 3) t.len = 3;                      // NaN (no sign)
+  else if (t.kind == 2) t.len = t.neg + 8;         // [-]Infinity
+  else if (t.kind == 1) t.len = t.neg + 3;         // [-]0.0
+  else if (x >= -3 && x < 7) t.len = t.neg + (t.k <= 0 ? 2 - t.k + t.nd : t.nd <= t.k ? t.k + 2 : t.nd + 1);
+  else t.len = t.neg + 2 + (t.nd > 1 ? t.nd - 1 : 1) + 1 + (x < 0 ? 1 : 0) + (ax >= 100 ? 3 : ax >= 10 ? 2 : 1);
+  return t;
+}
+// the first `len` bytes of the text (len <= t.len), one byte store each (registry tail: not a hot path)
+template <typename P>
+GDV_DEV void gdv_copy_real_text(P dst, const gdv_real_text& t, gdv_int32 len) {
+  if (t.neg && t.kind != 3 && len > 0) dst[0] = (gdv_uint8)'-';
+  if (t.kind >= 2) {
+    const gdv_uint64 w = t.kind == 3 ? 0x4e614eull : 0x7974696e69666e49ull;  // "NaN" / "Infinity", first byte lowest
+    const gdv_int32 at = t.kind == 3 ? 0 : t.neg, nb = t.kind == 3 ? 3 : 8;
+    for (gdv_int32 i = 0; i < nb && at + i < len; i++) dst[at + i] = (gdv_uint8)(w >> (8 * i));
+    return;
+  }
+  if (t.kind == 1) {
+    if (t.neg < len) dst[t.neg] = (gdv_uint8)'0';
+    if (t.neg + 1 < len) dst[t.neg + 1] = (gdv_uint8)'.';
+    if (t.neg + 2 < len) dst[t.neg + 2] = (gdv_uint8)'0';
+    return;
+  }
+  const gdv_int32 x = t.k - 1;
+  const bool fixed = x >= -3 && x < 7;
+  // text position of the most significant digit and of the point
+  gdv_int32 first = t.neg, point;
+  if (!fixed) point = t.neg + 1;
+  else if (t.k <= 0) { point = t.neg + 1; first = t.neg + 2 - t.k; }
+  else point = t.neg + t.k;
+  if (fixed && t.k <= 0)
+    for (gdv_int32 i = t.neg; i < first && i < len; i++) dst[i] = (gdv_uint8)'0';  // "0.000": the point overwrites its place below
+  if (fixed && t.k > t.nd)
+    for (gdv_int32 i = t.neg + t.nd; i < t.neg + t.k && i < len; i++) dst[i] = (gdv_uint8)'0';  // 1200000.0
+  if (point < len) dst[point] = (gdv_uint8)'.';
+  if ((fixed ? t.k >= t.nd : t.nd == 1) && point + 1 < len) dst[point + 1] = (gdv_uint8)'0';  // the lone digit behind the point
+  gdv_uint64 d = t.digits;
+  for (gdv_int32 i = t.nd - 1; i >= 0; i--) {  // least significant digit first
+    gdv_int32 pos = first + i;
+    if (pos >= point && !(fixed && t.k <= 0)) pos++;
+    if (pos < len) dst[pos] = (gdv_uint8)('0' + (gdv_int32)(d % 10));
+    d /= 10;
+  }
+  if (!fixed) {
+    gdv_int32 at = t.neg + 2 + (t.nd > 1 ? t.nd - 1 : 1);
+    gdv_int32 ax = x < 0 ? -x : x;
+    if (at < len) dst[at] = (gdv_uint8)'E';
+    at++;
+    if (x < 0) { if (at < len) dst[at] = (gdv_uint8)'-'; at++; }
+    if (ax >= 100) { if (at < len) dst[at] = (gdv_uint8)('0' + ax / 100); at++; }
+    if (ax >= 10) { if (at < len) dst[at] = (gdv_uint8)('0' + ax / 10 % 10); at++; }
+    if (at < len) dst[at] = (gdv_uint8)('0' + ax % 10);
+  }
+}
 template <typename P>
 GDV_DEV void gdv_copy_digits(P dst, const gdv_str& s) {
+  if (s.flags & GDV_STR_REAL) {
+    gdv_copy_real_text(dst, gdv_real_text_of((gdv_uint64)s.p, (gdv_uint64)s.lim), s.len);
+    return;
+  }
   if (s.flags & GDV_STR_DECIMAL) {
     const gdv_int128 v = (gdv_int128)(((gdv_uint128)(gdv_uint64)s.lim << 64) | (gdv_uint64)s.p);
     gdv_copy_dec_text(dst, gdv_dec_text_of(v, s.flags >> 8), s.len);
@@ -2035,6 +2115,276 @@ GDV_DEV gdv_str castVARCHAR_decimal128_int64(gdv_ctx ctx, gdv_int128 v, int xp, 
   r.flags = GDV_STR_DECIMAL | (xs << 8);
   return r;
 }
+// ---- shortest round-trip digits of a binary floating-point value f * 2^e (round 5): the free-format
+// algorithm of Burger & Dybvig ("Printing Floating-Point Numbers Quickly and Accurately", 1996) over
+// exact integers — r / s = the value scaled into [0.1, 1), m- / m+ = the distances to the neighbouring
+// values' midpoints; digits are generated while the remainder is further from both midpoints than the
+// digits already out could be.  Per-lane big integers of up to 36 32-bit words (a double's 2^-1074
+// scaled by 10^324 needs 1132 bits) in private memory, lengths tracked, so ordinary magnitudes touch a
+// few words.  A registry-tail function: correct first (pinned to Python's repr and numpy's float32
+// digits on the host build of this header), ~10^4 operations per value at the exponent range's ends.
+#define GDV_BIG_WORDS 36
+struct gdv_big {
+  gdv_uint32 w[GDV_BIG_WORDS];
+  gdv_int32 n;  // words in use; w[n..] are zero
+};
+GDV_DEV void gdv_big_set(gdv_big& b, gdv_uint64 v, gdv_int32 sh) {  // b = v << sh
+  for (gdv_int32 i = 0; i < GDV_BIG_WORDS; i++) b.w[i] = 0;
+  const gdv_int32 word = sh >> 5, bit = sh & 31;
+  const gdv_uint128 t = (gdv_uint128)v << bit;
+  b.w[word] = (gdv_uint32)t;
+  if (word + 1 < GDV_BIG_WORDS) b.w[word + 1] = (gdv_uint32)(t >> 32);
+  if (word + 2 < GDV_BIG_WORDS) b.w[word + 2] = (gdv_uint32)(t >> 64);
+  b.n = word + 3 < GDV_BIG_WORDS ? word + 3 : GDV_BIG_WORDS;
+  while (b.n > 0 && b.w[b.n - 1] == 0) b.n--;
+}
+GDV_DEV void gdv_big_mul(gdv_big& b, gdv_uint32 m) {
+  gdv_uint64 carry = 0;
+  for (gdv_int32 i = 0; i < b.n; i++) {
+    const gdv_uint64 t = (gdv_uint64)b.w[i] * m + carry;
+    b.w[i] = (gdv_uint32)t;
+    carry = t >> 32;
+  }
+  if (carry != 0 && b.n < GDV_BIG_WORDS) b.w[b.n++] = (gdv_uint32)carry;
+}
+GDV_DEV void gdv_big_pow10(gdv_big& b, gdv_int32 k) {  // b *= 10^k, k >= 0
+  for (; k >= 9; k -= 9) gdv_big_mul(b, 1000000000u);
+  gdv_uint32 p = 1;
+  for (; k > 0; k--) p *= 10u;
+  if (p > 1) gdv_big_mul(b, p);
+}
+GDV_DEV gdv_int32 gdv_big_cmp(const gdv_big& a, const gdv_big& b) {
+  if (a.n != b.n) return a.n < b.n ? -1 : 1;
+  for (gdv_int32 i = a.n - 1; i >= 0; i--)
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+  return 0;
+}
+GDV_DEV void gdv_big_add(gdv_big& a, const gdv_big& b) {  // a += b
+  const gdv_int32 n = a.n > b.n ? a.n : b.n;
+  gdv_uint64 carry = 0;
+  for (gdv_int32 i = 0; i < n; i++) {
+    const gdv_uint64 t = (gdv_uint64)a.w[i] + b.w[i] + carry;
+    a.w[i] = (gdv_uint32)t;
+    carry = t >> 32;
+  }
+  a.n = n;
+  if (carry != 0 && a.n < GDV_BIG_WORDS) a.w[a.n++] = (gdv_uint32)carry;
+}
+GDV_DEV void gdv_big_sub(gdv_big& a, const gdv_big& b) {  // a -= b, a >= b
+  gdv_int64 borrow = 0;
+  for (gdv_int32 i = 0; i < a.n; i++) {
+    const gdv_int64 t = (gdv_int64)a.w[i] - (i < b.n ? b.w[i] : 0u) - borrow;
+    a.w[i] = (gdv_uint32)t;
+    borrow = t < 0 ? 1 : 0;
+  }
+  while (a.n > 0 && a.w[a.n - 1] == 0) a.n--;
+}
+struct gdv_real_digits {
+  gdv_uint64 digits;  // no trailing zeros
+  gdv_int32 nd, k;    // value = 0.digits * 10^k
+};
+// f != 0; `closer_below`: the neighbour below is half as far away as the one above (f is the smallest
+// significand of its binade and not of the lowest binade)
+GDV_DEV gdv_real_digits gdv_shortest_digits(gdv_uint64 f, gdv_int32 e, bool closer_below) {
+  gdv_big r, s, m;
+  const gdv_int32 sh = closer_below ? 2 : 1;
+  gdv_big_set(r, f, sh + (e > 0 ? e : 0));
+  gdv_big_set(s, 1, sh + (e < 0 ? -e : 0));
+  gdv_big_set(m, 1, e > 0 ? e : 0);  // m- ; m+ = m- (twice m- when closer_below)
+  const bool even = (f & 1) == 0;    // round-to-even reads the midpoints themselves back as f
+  const gdv_int32 lg = e + 63 - __builtin_clzll(f);
+  gdv_int32 k = (gdv_int32)ceil((double)lg * 0.30102999566398114 - 1e-10);  // ceil(log10 v) or one less
+  if (k >= 0) gdv_big_pow10(s, k);
+  else { gdv_big_pow10(r, -k); gdv_big_pow10(m, -k); }
+  {  // the estimate was one too low when v + m+ reaches s
+    gdv_big_add(r, m);
+    if (closer_below) gdv_big_add(r, m);
+    const gdv_int32 c = gdv_big_cmp(r, s);
+    gdv_big_sub(r, m);
+    if (closer_below) gdv_big_sub(r, m);
+    if (even ? c >= 0 : c > 0) { k++; gdv_big_mul(s, 10u); }
+  }
+  gdv_real_digits out;
+  out.digits = 0;
+  out.nd = 0;
+  out.k = k;
+  for (;;) {
+    gdv_big_mul(r, 10u);
+    gdv_big_mul(m, 10u);
+    gdv_int32 d = 0;
+    while (d < 9 && gdv_big_cmp(r, s) >= 0) { gdv_big_sub(r, s); d++; }
+    const gdv_int32 c1 = gdv_big_cmp(r, m);
+    const bool tc1 = even ? c1 <= 0 : c1 < 0;  // the digits so far read back as f from below
+    gdv_big_add(r, m);
+    if (closer_below) gdv_big_add(r, m);
+    const gdv_int32 c2 = gdv_big_cmp(r, s);
+    gdv_big_sub(r, m);
+    if (closer_below) gdv_big_sub(r, m);
+    const bool tc2 = even ? c2 >= 0 : c2 > 0;  // ... with the last digit one up, from above
+    if (!tc1 && !tc2 && out.nd < 17) {
+      out.digits = out.digits * 10 + (gdv_uint64)d;
+      out.nd++;
+      continue;
+    }
+    if (tc1 && tc2) {  // both ends are in: the closer one; a tie goes to the even digit
+      gdv_big_add(r, r);
+      const gdv_int32 c = gdv_big_cmp(r, s);
+      if (c > 0 || (c == 0 && (d & 1))) d++;
+    } else if (tc2) {
+      d++;
+    }
+    out.digits = out.digits * 10 + (gdv_uint64)d;
+    out.nd++;
+    break;
+  }
+  // (a final digit of 10 cannot happen — v + m+ < 10^k is the loop's invariant — but the integer form
+  // absorbs it, and trailing zeros never survive)
+  if (gdv_count_digits(out.digits) > out.nd) { out.k++; out.nd++; }
+  while (out.digits != 0 && out.digits % 10 == 0) { out.digits /= 10; out.nd--; }
+  return out;
+}
+GDV_DEV gdv_str gdv_real_view(gdv_ctx ctx, gdv_uint64 f, gdv_int32 e, bool closer_below, gdv_int32 neg, gdv_int32 kind, gdv_int64 n) {
+  gdv_str r = gdv_empty_str();
+  if (n < 0) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return r; }
+  gdv_real_digits d;
+  d.digits = 0; d.nd = 0; d.k = 0;
+  if (kind == 0) d = gdv_shortest_digits(f, e, closer_below);
+  const gdv_uint64 info = (gdv_uint64)d.nd | ((gdv_uint64)(d.k + 2048) << 8) | ((gdv_uint64)neg << 24) | ((gdv_uint64)kind << 25);
+  const gdv_int32 total = gdv_real_text_of(d.digits, info).len;
+  r.p = (const gdv_uint8*)d.digits;
+  r.lim = (const gdv_uint8*)info;
+  r.len = n < total ? (gdv_int32)n : total;
+  r.map = GDV_MAP_DIGITS;
+  r.flags = GDV_STR_REAL;
+  return r;
+}
+// castVARCHAR(float64 / float32, n): the shortest digits that read back as the value (of ITS type), in the
+// Java-compatible layout above, cut to n bytes; n < 0 is an execution error
+// [gdv_function_stubs.cc GDV_FN_CAST_VARCHAR_REAL over gandiva/formatting_utils.h, as recalled]
+GDV_DEV gdv_str castVARCHAR_float64_int64(gdv_ctx ctx, gdv_float64 v, gdv_int64 n) {
+  const gdv_uint64 b = (gdv_uint64)__double_as_longlong(v);
+  const gdv_int32 ex = (gdv_int32)((b >> 52) & 2047);
+  const gdv_uint64 mant = b & ((1ull << 52) - 1);
+  const gdv_int32 kind = ex == 2047 ? (mant != 0 ? 3 : 2) : (ex == 0 && mant == 0 ? 1 : 0);
+  return gdv_real_view(ctx, ex == 0 ? mant : (mant | (1ull << 52)), ex == 0 ? -1074 : ex - 1075, mant == 0 && ex > 1,
+                       (gdv_int32)(b >> 63), kind, n);
+}
+GDV_DEV gdv_str castVARCHAR_float32_int64(gdv_ctx ctx, gdv_float32 v, gdv_int64 n) {
+  const gdv_uint32 b = __float_as_uint(v);
+  const gdv_int32 ex = (gdv_int32)((b >> 23) & 255);
+  const gdv_uint32 mant = b & ((1u << 23) - 1);
+  const gdv_int32 kind = ex == 255 ? (mant != 0 ? 3 : 2) : (ex == 0 && mant == 0 ? 1 : 0);
+  return gdv_real_view(ctx, ex == 0 ? mant : (mant | (1u << 23)), ex == 0 ? -149 : ex - 150, mant == 0 && ex > 1,
+                       (gdv_int32)(b >> 31), kind, n);
+}
+// ---- to_date(text, 'pattern'[, suppress_errors]) (round 5).  The lineage's ToDateHolder turns the SQL pattern into a
+// strptime format at Make time (date_utils.cc ToInternalFormat) and calls arrow::internal::ParseTimestampStrptime(...,
+// ignore_time_in_day = true, allow_trailing_chars = true): the C library's strptime, then year / month / max(day, 1)
+// through the civil-date arithmetic — the time fields are parsed, range-checked and dropped [as recalled].  Here the
+// planner compiles the pattern to one byte per directive and the row interprets it the way glibc's strptime does:
+//   ' '  any run of white space          'L' c  the byte c itself (text inside "double quotes" included)
+//   'Y' 0..9999 (<= 4 digits)  'y' 0..99 (69-99 -> 19xx, else 20xx)  'm' 1..12  'd' 1..31  'j' 1..366 (<= 3 digits)
+//   'H' 0..23  'I' 1..12  'M' 0..59  'S' 0..61          numbers: blanks skipped, at least one digit, further digits
+//   'b' month name, 'a' weekday name (English, full or 3 letters, any case)  'p' AM / PM       while value * 10 <= max
+// A text that does not match raises (suppress_errors = 0) or gives null (1).
+GDV_DEV bool gdv_c_isspace(gdv_uint8 c) { return c == ' ' || (c >= 9 && c <= 13); }
+GDV_DEV bool gdv_scan_number(const gdv_str& s, gdv_int32& i, gdv_int32 from, gdv_int32 to, gdv_int32 n, gdv_int32* val) {
+  while (i < s.len && gdv_c_isspace(gdv_str_at(s, i))) i++;
+  if (i >= s.len) return false;
+  gdv_uint8 c = gdv_str_at(s, i);
+  if (c < '0' || c > '9') return false;
+  gdv_int32 v = 0;
+  for (;;) {
+    v = v * 10 + (c - '0');
+    i++;
+    if (--n <= 0 || v * 10 > to || i >= s.len) break;
+    c = gdv_str_at(s, i);
+    if (c < '0' || c > '9') break;
+  }
+  *val = v;
+  return v >= from && v <= to;
+}
+// a name out of `count`: three letters packed low byte first in abbr[], the rest of the full name in rest[] (<= 6 letters);
+// the full name is taken when all of it is there, else the three letters (glibc tries them in that order)
+GDV_DEV gdv_int32 gdv_scan_name(const gdv_str& s, gdv_int32& i, const gdv_uint32* abbr, const gdv_uint64* rest, gdv_int32 count) {
+  if (i + 3 > s.len) return -1;
+  gdv_uint32 w = 0;
+  for (gdv_int32 j = 0; j < 3; j++) w |= (gdv_uint32)(gdv_str_at(s, i + j) | 0x20) << (8 * j);
+  for (gdv_int32 k = 0; k < count; k++) {
+    if (abbr[k] != w) continue;
+    gdv_int32 j = 0;
+    bool full = true;
+    for (gdv_uint64 r = rest[k]; r != 0; r >>= 8, j++)
+      if (i + 3 + j >= s.len || (gdv_uint8)(gdv_str_at(s, i + 3 + j) | 0x20) != (gdv_uint8)r) { full = false; break; }
+    i += 3 + (full ? j : 0);
+    return k;
+  }
+  return -1;
+}
+GDV_DEV gdv_int64 gdv_parse_date(gdv_ctx ctx, gdv_str s, const gdv_uint8* ops, gdv_int32 nops, gdv_int32 suppress, bool in_valid,
+                                 bool* out_valid) {
+  *out_valid = false;
+  if (!in_valid) return 0;
+  const gdv_uint32 mon3[12] = {0x6e616a, 0x626566, 0x72616d, 0x727061, 0x79616d, 0x6e756a, 0x6c756a, 0x677561, 0x706573, 0x74636f, 0x766f6e, 0x636564};
+  const gdv_uint64 monr[12] = {0x79726175ull, 0x7972617572ull, 0x6863ull, 0x6c69ull, 0ull, 0x65ull, 0x79ull, 0x747375ull, 0x7265626d6574ull, 0x7265626full,
+                               0x7265626d65ull, 0x7265626d65ull};
+  const gdv_uint32 day3[7] = {0x6e7573, 0x6e6f6d, 0x657574, 0x646577, 0x756874, 0x697266, 0x746173};
+  const gdv_uint64 dayr[7] = {0x796164ull, 0x796164ull, 0x79616473ull, 0x79616473656eull, 0x7961647372ull, 0x796164ull, 0x7961647275ull};
+  gdv_int32 year = 1900, mon = 1, mday = 0, yday = -1, i = 0, v = 0;
+  bool ok = true, have_mon = false, have_mday = false, have_wday = false;
+  for (gdv_int32 op = 0; ok && op < nops; op++) {
+    const gdv_uint8 c = ops[op];
+    if (c == ' ') { while (i < s.len && gdv_c_isspace(gdv_str_at(s, i))) i++; }
+    else if (c == 'L') { op++; ok = i < s.len && gdv_str_at(s, i) == ops[op]; i++; }
+    else if (c == 'Y') { ok = gdv_scan_number(s, i, 0, 9999, 4, &v); year = v; }
+    else if (c == 'y') { ok = gdv_scan_number(s, i, 0, 99, 2, &v); year = v >= 69 ? 1900 + v : 2000 + v; }
+    else if (c == 'm') { ok = gdv_scan_number(s, i, 1, 12, 2, &v); mon = v; have_mon = true; }
+    else if (c == 'd') { ok = gdv_scan_number(s, i, 1, 31, 2, &v); mday = v; have_mday = true; }
+    else if (c == 'j') { ok = gdv_scan_number(s, i, 1, 366, 3, &v); yday = v - 1; }
+    else if (c == 'H') ok = gdv_scan_number(s, i, 0, 23, 2, &v);
+    else if (c == 'I') ok = gdv_scan_number(s, i, 1, 12, 2, &v);
+    else if (c == 'M') ok = gdv_scan_number(s, i, 0, 59, 2, &v);
+    else if (c == 'S') ok = gdv_scan_number(s, i, 0, 61, 2, &v);
+    else if (c == 'b') { v = gdv_scan_name(s, i, mon3, monr, 12); ok = v >= 0; mon = v + 1; have_mon = true; }
+    else if (c == 'a') { ok = gdv_scan_name(s, i, day3, dayr, 7) >= 0; have_wday = true; }
+    else if (c == 'p') {
+      ok = i + 2 <= s.len && (gdv_str_at(s, i + 1) | 0x20) == 'm' && ((gdv_str_at(s, i) | 0x20) == 'a' || (gdv_str_at(s, i) | 0x20) == 'p');
+      i += 2;
+    } else ok = false;
+  }
+  if (!ok) {
+    if (!suppress) gdv_raise(ctx, GDV_ERR_BAD_ARG);
+    return 0;
+  }
+  *out_valid = true;
+  if (yday >= 0 && !have_wday && !(have_mon && have_mday)) {
+    // a day of the year fills in the month and / or the day of the month that the text did not give (glibc's strptime
+    // does this itself, and only when no weekday name was parsed)
+    const bool leap = (year % 4 == 0) && (year % 100 != 0 || year % 400 == 0);
+    gdv_int32 t_mon = 1, first = 0;  // month t_mon starts at day-of-year `first`
+    for (; t_mon < 12; t_mon++) {
+      const gdv_int32 len = t_mon == 2 ? (leap ? 29 : 28) : (t_mon == 4 || t_mon == 6 || t_mon == 9 || t_mon == 11) ? 30 : 31;
+      if (first + len > yday) break;
+      first += len;
+    }
+    if (!have_mon) mon = t_mon;
+    if (!have_mday) mday = yday - first + 1;
+  }
+  return gdv_days_from_civil(year, mon, mday < 1 ? 1 : mday) * GDV_MILLIS_IN_DAY;
+}
+// to_timestamp / to_time over numbers: seconds since the epoch -> milliseconds (time: of the day) [time.cc TO_TIMESTAMP /
+// TO_TIME, as recalled: static_cast<int64>(seconds * MILLIS_IN_SEC), % MILLIS_IN_DAY]
+#define GDV_TO_TIMESTAMP(T)                                                                                        \
+  GDV_DEV gdv_int64 to_timestamp_##T(gdv_##T seconds) { return gdv_seconds_to_millis(seconds); }            \
+  GDV_DEV gdv_int32 to_time_##T(gdv_##T seconds) { return (gdv_int32)(gdv_seconds_to_millis(seconds) % GDV_MILLIS_IN_DAY); }
+GDV_DEV gdv_int64 gdv_seconds_to_millis(gdv_int32 s) { return (gdv_int64)s * 1000; }
+GDV_DEV gdv_int64 gdv_seconds_to_millis(gdv_int64 s) { return (gdv_int64)((gdv_uint64)s * 1000ull); }
+GDV_DEV gdv_int64 gdv_seconds_to_millis(gdv_float32 s) { return gdv_sat_i64((gdv_float64)(s * 1000.0f)); }
+GDV_DEV gdv_int64 gdv_seconds_to_millis(gdv_float64 s) { return gdv_sat_i64(s * 1000.0); }
+GDV_TO_TIMESTAMP(int32)
+GDV_TO_TIMESTAMP(int64)
+GDV_TO_TIMESTAMP(float32)
+GDV_TO_TIMESTAMP(float64)
 // reverse(s): the characters of s in reverse order.  A character is what its lead byte announces
 // (1-4 bytes); a byte that cannot lead a character, or a character cut by the end of the string,
 // is an execution error.

@@ -129,6 +129,12 @@ Status ValidateFunction(const Schema& schema, const FunctionNode& n) {
       return Status::ValidationError("'" + n.name() + "' function requires a literal as the last parameter");
     }
   }
+  if (def->flags & kDateFormatArg) {  // [to_date_holder.cc ToDateHolder::Make's two messages, as recalled]
+    if (n.children()[1]->kind() != NodeKind::kLiteral)
+      return Status::ValidationError("'" + n.name() + "' function requires a literal as the second parameter");
+    if (n.children().size() == 3 && n.children()[2]->kind() != NodeKind::kLiteral)
+      return Status::ValidationError("'" + n.name() + "' function requires a int literal as the third parameter");
+  }
   return Status::OK();
 }
 
@@ -401,7 +407,50 @@ class CodeGen {
            std::to_string(bytes.size() + 8) + (ascii ? ", GDV_STR_ASCII | GDV_STR_INBUF)" : ", GDV_STR_INBUF)");
   }
   // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
-  static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
+  static // to_date's SQL pattern -> one byte per strptime directive (gdv_parse_date).  Tokens are matched case-insensitively,
+// longest first; any other letter sequence is an error, every other character stands for itself (white space: any
+// run of it) [date_utils.cc DateUtils::ToInternalFormat, as recalled; the time-zone tokens TZD / TZO / TZH:TZM and the
+// fractional-second / era / century / week-of-year tokens are not taken: the message says so].
+Status CompileDateFormat(const std::string& pattern, std::string* ops) {
+  static const std::pair<const char*, char> tokens[] = {
+      {"YYYY", 'Y'}, {"HH24", 'H'}, {"HH12", 'I'}, {"MONTH", 'b'}, {"MON", 'b'}, {"DDD", 'j'}, {"DAY", 'a'}, {"YY", 'y'}, {"MM", 'm'},
+      {"DD", 'd'},   {"DY", 'a'},   {"HH", 'I'},   {"MI", 'M'},    {"SS", 'S'},  {"AM", 'p'},  {"PM", 'p'}};
+  ops->clear();
+  bool quoted = false;  // inside "double quotes" every character stands for itself
+  for (size_t i = 0; i < pattern.size();) {
+    const unsigned char c = static_cast<unsigned char>(pattern[i]);
+    if (c == '"') { quoted = !quoted; i++; continue; }
+    if (quoted) { ops->push_back('L'); ops->push_back(static_cast<char>(c)); i++; continue; }
+    if (c == ' ' || (c >= 9 && c <= 13)) {
+      if (ops->empty() || ops->back() != ' ') ops->push_back(' ');
+      i++;
+      continue;
+    }
+    if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'))) {
+      ops->push_back('L');
+      ops->push_back(static_cast<char>(c));
+      i++;
+      continue;
+    }
+    bool hit = false;
+    for (auto& tk : tokens) {
+      const size_t n = std::strlen(tk.first);
+      if (i + n > pattern.size()) continue;
+      bool same = true;
+      for (size_t j = 0; same && j < n; j++) same = (pattern[i + j] & ~0x20) == tk.first[j] || pattern[i + j] == tk.first[j];
+      if (same) { ops->push_back(tk.second); i += n; hit = true; break; }
+    }
+    if (!hit) {
+      size_t j = i;
+      while (j < pattern.size() && (((pattern[j] | 0x20) >= 'a' && (pattern[j] | 0x20) <= 'z') || (pattern[j] >= '0' && pattern[j] <= '9'))) j++;
+      return Status::Invalid("Invalid date format: the HIP backend takes YYYY YY MM MON MONTH DD DDD DY DAY HH HH12 HH24 MI SS AM PM; not '" +
+                             pattern.substr(i, j - i) + "'");
+    }
+  }
+  return Status::OK();
+}
+
+Status CompileLike(const std::string& pat, int escape, std::string* bytes,
                             std::string* kinds) {
     for (size_t i = 0; i < pat.size(); i++) {
       unsigned char c = static_cast<unsigned char>(pat[i]);
@@ -753,6 +802,27 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         }
         out->vlane = lanes;
         out->v = "gdv_empty_str()";  // never read: consumers use the pieces
+        return Status::OK();
+      }
+      if (def->flags & kDateFormatArg) {
+        // to_date(s, 'pattern'[, suppress_errors]): the pattern becomes one byte per strptime directive here, at Make
+        // time, the way the reference's ToDateHolder converts it once per expression; the row interprets it
+        auto& pat = static_cast<const LiteralNode&>(*fn.children()[1]);
+        if (pat.is_null()) return Status::Invalid("Invalid date format: null");
+        int suppress = 0;
+        if (fn.children().size() == 3) {
+          auto& sl = static_cast<const LiteralNode&>(*fn.children()[2]);
+          suppress = !sl.is_null() && static_cast<int32_t>(sl.value().lo) == 1 ? 1 : 0;
+        }
+        std::string ops;
+        GDV_RETURN_NOT_OK(CompileDateFormat(pat.value().bytes, &ops));
+        can_raise_ = true;
+        const std::string ov = "ov" + std::to_string(next_tmp_++);
+        Stmt("bool " + ov + " = false;");
+        const std::string guard = AndExpr(AndExpr("live", active), LaneValid(args[0]));
+        out->v = Tmp("gdv_int64", guard + " ? gdv_parse_date(ctx, " + args[0].v + ", " + ByteTable(ops) + ", " + std::to_string(ops.size()) + ", " +
+                                      std::to_string(suppress) + ", true, &" + ov + ") : (gdv_int64)0");
+        out->vlane = ov;
         return Status::OK();
       }
       if (def->flags & kPatternArg) {

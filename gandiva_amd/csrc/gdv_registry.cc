@@ -238,6 +238,14 @@ FunctionRegistry::FunctionRegistry() {
     add("datediff", {t, t}, int32());
     add("date_diff", {t, t}, int32(), NullPolicy::kNullIfNull, 0, Sym("datediff", {t, t}));
   }
+  // round 5: to_date(text, 'pattern'[, suppress_errors]) — the holder's pattern is compiled by the planner;
+  // to_timestamp / to_time over numbers (seconds since the epoch)
+  add("to_date", {utf8(), utf8()}, date64(), NullPolicy::kNullInternal, kNeedsContext | kDateFormatArg, "gdv_parse_date");
+  add("to_date", {utf8(), utf8(), int32()}, date64(), NullPolicy::kNullInternal, kNeedsContext | kDateFormatArg, "gdv_parse_date");
+  for (auto& t : {int32(), int64(), float32(), float64()}) {
+    add("to_timestamp", {t}, timestamp());
+    add("to_time", {t}, time32());
+  }
   // decimal128: precision/scale are wildcards in the parameter match
   {
     const DataType dec = decimal128(38, 0);  // enumerated like the reference's decimal128()
@@ -317,6 +325,9 @@ FunctionRegistry::FunctionRegistry() {
   add("castVARCHAR", {utf8(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("castVARCHAR", {int32(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("castVARCHAR", {int64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  // round 5: shortest round-trip digits in the Java-compatible layout (gandiva/formatting_utils.h, as recalled)
+  add("castVARCHAR", {float32(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
+  add("castVARCHAR", {float64(), int64()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("reverse", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext);
   add("initcap", {utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult);
   // message digests (round 5): lower-case hex text, never null (a NULL hashes as the empty message)

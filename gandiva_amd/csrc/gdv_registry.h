@@ -27,6 +27,7 @@ enum FunctionFlags : uint32_t {
   kVarlenResult = 8u,    // returns utf8/binary: two-pass (length, then copy) evaluation
   kDecimalArgs = 16u,    // device function takes (precision, scale) after every decimal
                          // argument and the result's (precision, scale) last
+  kDateFormatArg = 32u,  // to_date: the pattern (and suppress_errors) must be literals; compiled at Make time
 };
 
 struct FunctionDef {

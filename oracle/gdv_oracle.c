@@ -1,3 +1,4 @@
+#define _GNU_SOURCE 1  /* strptime, strncasecmp */
 /*
  * oracle/gdv_oracle.c — CPU restatement of the reference's Projector / Filter evaluation.
  *
@@ -81,6 +82,15 @@
  *       - hashSHA256 / hashSHA1 / hashMD5 (sha256 / sha1 / sha / md5): the digests themselves are FIPS 180-4 / RFC 1321 and
  *         pinned against Python's hashlib; that a NUMBER is hashed as the 8 bytes of (double)value, a NULL as the empty
  *         message, and that the text is lower-case hex, is recollection.
+ *       - castVARCHAR(float32 / float64, n): shortest round-trip digits of the value's OWN type in the Java-compatible layout
+ *         (fixed for 10^-3 <= |v| < 10^7 with at least "d.d", else d.dddE[-]x; "NaN", "[-]Infinity", "[-]0.0") — what
+ *         gandiva/formatting_utils.h configures double-conversion to, as recalled (older upstream versions printed Arrow's
+ *         own "1e+07" style).  The digits are pinned against Python's repr / numpy's float32 shortest digits.
+ *       - to_date(text, 'pattern'[, suppress_errors]): the pattern-to-strptime token table, "time of day parsed and dropped",
+ *         "trailing characters allowed", "day defaults to 1", "an unparsable text raises unless suppress_errors = 1 (then
+ *         null)" are recollection; the parsing itself is THE C LIBRARY'S strptime (what the lineage calls), so the device
+ *         library's own interpreter is held to glibc on every tested text.  to_timestamp / to_time over numbers:
+ *         (int64)(seconds * 1000) [% 86400000] — recollection.
  *       - regexp_like / regexp_matches / regexp_replace: the lineage runs RE2 (PartialMatch / GlobalReplace); only the
  *         LITERAL SUBSET exists here ([^]lit[$] without metacharacters; replacement without backslashes), where RE2's
  *         semantics are contains / starts / ends / equals and left-to-right non-overlapping replace — checked against
@@ -103,6 +113,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
+#include <ctype.h>
+#include <time.h>
 
 #define CHUNK 1024
 
@@ -1014,6 +1027,42 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
           for (int k = 0; k < subl && eq; k++) eq = map_byte(str[p0 + k], strm) == map_byte(sub[k], subm);
           if (eq) { out->v[i].i = utf8_chars(str, p0) + 1; break; }
         }
+      } else if (!strcmp(f, "to_date")) {
+        /* [recalled: to_date_holder.cc — the SQL pattern becomes a strptime format once (date_utils.cc ToInternalFormat), the
+         * row goes through arrow::internal::ParseTimestampStrptime(ignore_time_in_day, allow_trailing_chars) = the C
+         * library's strptime on a NUL-terminated copy, then year / month / max(day, 1) -> days * 86400000; a text that does
+         * not parse raises, or gives null with suppress_errors = 1].  This restatement CALLS strptime; the device library
+         * interprets the directives itself.  Tokens: YYYY YY MM MON MONTH DD DDD DY DAY HH HH12 HH24 MI SS AM PM. */
+        int live = out->valid[i] && (!active || active[i]);
+        out->v[i].i = 0;
+        if (!live) continue;
+        const int suppress = n->nargs == 3 && a[2].valid[i] && a[2].v[i].i == 1;
+        char fmt[256]; int fl = 0, bad = 0;
+        static const struct { const char* sql; const char* c; } tok[] = {
+          {"YYYY", "%Y"}, {"HH24", "%H"}, {"HH12", "%I"}, {"MONTH", "%b"}, {"MON", "%b"}, {"DDD", "%j"}, {"DAY", "%a"}, {"YY", "%y"},
+          {"MM", "%m"}, {"DD", "%d"}, {"DY", "%a"}, {"HH", "%I"}, {"MI", "%M"}, {"SS", "%S"}, {"AM", "%p"}, {"PM", "%p"}};
+        int quoted = 0;   /* inside "double quotes" every character stands for itself */
+        for (int k = 0; k < yl && fl < 250 && !bad;) {
+          int ch = map_byte(y[k], ym);
+          if (ch == '"') { quoted = !quoted; k++; continue; }
+          if (quoted || !isalpha(ch)) { if (ch == '%') fmt[fl++] = '%'; fmt[fl++] = (char)ch; k++; continue; }
+          int hit = 0;
+          for (size_t q = 0; q < sizeof tok / sizeof tok[0] && !hit; q++) {
+            int tl = (int)strlen(tok[q].sql);
+            if (k + tl <= yl && !strncasecmp((const char*)y + k, tok[q].sql, (size_t)tl)) { fmt[fl++] = '%'; fmt[fl++] = tok[q].c[1]; k += tl; hit = 1; }
+          }
+          if (!hit) bad = 1;
+        }
+        fmt[fl] = 0;
+        if (bad) { c->err |= 4; continue; }
+        char* buf = (char*)malloc((size_t)xl + 1);
+        for (int k = 0; k < xl; k++) buf[k] = (char)map_byte(x[k], xm);
+        buf[xl] = 0;
+        struct tm tm; memset(&tm, 0, sizeof tm);
+        const char* end = strptime(buf, fmt, &tm);
+        free(buf);
+        if (!end) { if (suppress) out->valid[i] = 0; else c->err |= 4; continue; }
+        out->v[i].i = days_from_civil((int64_t)tm.tm_year + 1900, tm.tm_mon + 1, tm.tm_mday > 1 ? tm.tm_mday : 1) * MS_DAY;
       } else if (!strcmp(f, "castINT") || !strcmp(f, "castBIGINT")) {
         /* text -> integer: blanks trimmed, then arrow::internal::ParseValue<Int32/Int64Type>
          * (pyarrow/include/arrow/util/value_parsing.h:380-440 StringToSignedIntConverterMixin, the
@@ -1164,6 +1213,62 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       char buf[32];
       int len = snprintf(buf, sizeof buf, "%lld", (long long)a[0].v[i].i);
       uint8_t* dst = arena_alloc(c, 24);
+      memcpy(dst, buf, (size_t)len);
+      out->sp[i] = dst; out->sm[i] = 0;
+      if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
+      else out->sl[i] = k < len ? (int32_t)k : len;
+    }
+  } else if (!strcmp(f, "castVARCHAR") && (t0 == T_F32 || t0 == T_F64)) {
+    /* shortest digits that read back as the value OF ITS TYPE, laid out the Java way ("1.0E7", "0.001", "NaN",
+     * "Infinity"), cut to n bytes; n < 0 is an error [recalled: gdv_function_stubs.cc GDV_FN_CAST_VARCHAR_REAL over
+     * gandiva/formatting_utils.h — double-conversion ToShortest, 'E', decimal_in_shortest_low -3, high 7].
+     * Digits here: the C library's correctly rounded "%.{p}e" for p = 0.. until strtod / strtof gives the value back
+     * (an engine of its own: the device library generates them with exact big integers). */
+    for (int i = 0; i < cnt; i++) {
+      int live = out->valid[i] && (!active || active[i]);
+      int64_t k = a[1].v[i].i;
+      const double v = t0 == T_F64 ? a[0].v[i].d : (double)a[0].v[i].f;
+      char buf[48]; int len = 0;
+      if (isnan(v)) len = snprintf(buf, sizeof buf, "NaN");
+      else if (isinf(v)) len = snprintf(buf, sizeof buf, "%sInfinity", v < 0 ? "-" : "");
+      else if (v == 0) len = snprintf(buf, sizeof buf, "%s0.0", signbit(v) ? "-" : "");
+      else {
+        /* p + 1 digits: the decimal NEAREST the value ("%.{p}e" is correctly rounded); when that one does not read back, its
+         * neighbour on the value's other side may (the gap below a power of two is half the gap above it: the shortest text
+         * of 2^-77 is 6.617444900424222E-24, which is not the nearest 16-digit decimal) */
+        char e[48]; int prec = 0, x = 0; unsigned long long D = 0;
+        const double av = fabs(v);
+        for (; prec < 17; prec++) {
+          snprintf(e, sizeof e, "%.*e", prec, av);
+          D = 0;
+          const char* q = e;
+          for (; *q && *q != 'e'; q++) if (*q != '.') D = D * 10 + (unsigned long long)(*q - '0');
+          x = atoi(q + 1);
+          const double back = t0 == T_F64 ? strtod(e, NULL) : (double)strtof(e, NULL);
+          if (back == av) break;
+          unsigned long long lim = 1; for (int j = 0; j < prec; j++) lim *= 10;   /* 10^prec <= D < 10^(prec + 1) */
+          unsigned long long D2 = back < av ? D + 1 : D - 1; int x2 = x;
+          if (D2 == lim * 10) { D2 = lim; x2++; }
+          else if (D2 < lim) { D2 = lim * 10 - 1; x2--; }
+          snprintf(e, sizeof e, "%llue%d", D2, x2 - prec);
+          if ((t0 == T_F64 ? strtod(e, NULL) : (double)strtof(e, NULL)) == av) { D = D2; x = x2; break; }
+        }
+        char dig[24]; int nd = snprintf(dig, sizeof dig, "%llu", D);
+        while (nd > 1 && dig[nd - 1] == '0') nd--;
+        if (v < 0) buf[len++] = '-';
+        if (x >= -3 && x < 7) {
+          const int kk = x + 1;  /* digits before the point */
+          if (kk <= 0) { buf[len++] = '0'; buf[len++] = '.'; for (int j = 0; j < -kk; j++) buf[len++] = '0'; for (int j = 0; j < nd; j++) buf[len++] = dig[j]; }
+          else if (nd <= kk) { for (int j = 0; j < kk; j++) buf[len++] = j < nd ? dig[j] : '0'; buf[len++] = '.'; buf[len++] = '0'; }
+          else { for (int j = 0; j < nd; j++) { if (j == kk) buf[len++] = '.'; buf[len++] = dig[j]; } }
+        } else {
+          buf[len++] = dig[0]; buf[len++] = '.';
+          if (nd == 1) buf[len++] = '0';
+          for (int j = 1; j < nd; j++) buf[len++] = dig[j];
+          len += snprintf(buf + len, sizeof buf - (size_t)len, "E%d", x);
+        }
+      }
+      uint8_t* dst = arena_alloc(c, 32);
       memcpy(dst, buf, (size_t)len);
       out->sp[i] = dst; out->sm[i] = 0;
       if (k < 0) { if (live) c->err |= 4; out->sl[i] = 0; }
@@ -1331,6 +1436,15 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
       if (t0 == T_F64) out->v[i].d = ab ? fabs(a[0].v[i].d) : -a[0].v[i].d;
       else if (t0 == T_F32) out->v[i].f = ab ? fabsf(a[0].v[i].f) : -a[0].v[i].f;
       else out->v[i].i = wrap_int(t0, (ab && a[0].v[i].i >= 0) ? a[0].v[i].u : 0 - a[0].v[i].u);
+    }
+  } else if (!strcmp(f, "to_timestamp") || !strcmp(f, "to_time")) {
+    /* seconds since the epoch -> milliseconds (to_time: of the day) [recalled: time.cc TO_TIMESTAMP / TO_TIME:
+     * static_cast<int64>(seconds * MILLIS_IN_SEC) — in the argument's own arithmetic, so float32 multiplies in
+     * float32 — and millis % MILLIS_IN_DAY].  Out-of-range floats saturate like every float -> integer cast here. */
+    for (int i = 0; i < cnt; i++) {
+      int64_t ms = t0 == T_F64 ? sat_i64(a[0].v[i].d * 1000.0) : t0 == T_F32 ? sat_i64((double)(a[0].v[i].f * 1000.0f))
+                 : (int64_t)((uint64_t)a[0].v[i].i * 1000u);
+      out->v[i].i = f[7] == 0 ? (int64_t)(int32_t)(ms % MS_DAY) : ms;
     }
   } else if (!strcmp(f, "greatest") || !strcmp(f, "least")) {
     int g = f[0] == 'g';

@@ -255,6 +255,38 @@ void host_f64_digest(int algo, const double* v, long n, const unsigned char* val
     gdv_str_copy(out + 64 * i, r);
   }
 }
+// castVARCHAR(float64 / float32, n) (round 5): 32 bytes per row, out_len[i] = the length
+int host_real_text(int is32, const void* v, long n, long cut, unsigned char* out, int* out_len) {
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  for (long i = 0; i < n; i++) {
+    const gdv_str r = is32 ? castVARCHAR_float32_int64(ctx, ((const float*)v)[i], cut) : castVARCHAR_float64_int64(ctx, ((const double*)v)[i], cut);
+    out_len[i] = r.len;
+    if (r.len > 0) gdv_str_copy(out + 32 * i, r);
+  }
+  return (int)err;
+}
+// to_date(text, pattern) (round 5): ops = the planner's compiled pattern; out_valid[i] = parsed; returns the error bits
+int host_parse_date(const int* off, const unsigned char* data, long size, long n, const unsigned char* ops, int nops, int suppress,
+                    long long* out, unsigned char* out_valid) {
+  HostCol c{off, data, size};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  for (long i = 0; i < n; i++) {
+    bool ov = false;
+    out[i] = gdv_parse_date(ctx, host_row(c, i), ops, nops, suppress, true, &ov);
+    out_valid[i] = ov ? 1 : 0;
+  }
+  return (int)err;
+}
+void host_to_timestamp(int kind, const void* v, long n, long long* ts, int* tm) {
+  for (long i = 0; i < n; i++) {
+    if (kind == 0) { ts[i] = to_timestamp_int32(((const int*)v)[i]); tm[i] = to_time_int32(((const int*)v)[i]); }
+    else if (kind == 1) { ts[i] = to_timestamp_int64(((const long long*)v)[i]); tm[i] = to_time_int64(((const long long*)v)[i]); }
+    else if (kind == 2) { ts[i] = to_timestamp_float32(((const float*)v)[i]); tm[i] = to_time_float32(((const float*)v)[i]); }
+    else { ts[i] = to_timestamp_float64(((const double*)v)[i]); tm[i] = to_time_float64(((const double*)v)[i]); }
+  }
+}
 // lpad (right = 0) / rpad (right = 1): `tab` is the fill repeated to `want` characters, readable
 // 8 bytes past its end (what the planner lays out in the constant block)
 long host_str_pad(int right, const int* off, const unsigned char* data, long size, long n, int want,

@@ -493,3 +493,309 @@ def test_digests_on_the_gpu(n):
                                                                              b.make_literal(8, pa.int64())], STR)], STR), pa.field("u", STR))
     got = gandiva.make_projector(batch.schema, [e], None).evaluate(batch)
     assert_bit_exact(got[0], oracle.project([e], batch)[0], "upper(substr(hashMD5(s), 1, 8))")
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: castVARCHAR(float32 / float64, n) — shortest round-trip digits, Java-compatible layout.
+#   engine 1 (oracle): the C library's "%.{p}e" with growing p until strtod / strtof reads the value back
+#   engine 2 (device library, host build and GPU): Burger-Dybvig free-format over exact big integers
+#   engine 3 (here): numpy's Dragon4 "unique" digits / Python's repr
+import math  # noqa: E402
+
+
+def _java_layout(digits, k, neg):
+    """digits without trailing zeros, value = 0.digits * 10^k"""
+    x, nd = k - 1, len(digits)
+    if -3 <= x < 7:
+        t = "0." + "0" * (-k) + digits if k <= 0 else digits + "0" * (k - nd) + ".0" if nd <= k else digits[:k] + "." + digits[k:]
+    else:
+        t = digits[0] + "." + (digits[1:] or "0") + "E" + str(x)
+    return ("-" if neg else "") + t
+
+
+def _real_text(v, t):
+    if v is None:
+        return None
+    if math.isnan(v):
+        return "NaN"
+    if math.isinf(v):
+        return "-Infinity" if v < 0 else "Infinity"
+    neg = math.copysign(1.0, v) < 0
+    if v == 0:
+        return "-0.0" if neg else "0.0"
+    s = np.format_float_scientific(np.float32(v) if t == pa.float32() else np.float64(v), unique=True, trim="-")
+    m, e = s.lstrip("-").split("e")
+    return _java_layout(m.replace(".", "").rstrip("0") or "0", int(e) + 1, neg)
+
+
+REAL_SPECIALS = [0.0, -0.0, 1.0, 1.5, 100.0, 1e7, 9999999.0, 0.001, 0.00099999, 1e-5, 1.0e10, 123456.789, float("inf"), float("-inf"), float("nan"),
+                 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 2.0 ** 52, 2.0 ** -1022, 9007199254740993.0, 0.1, 1 / 3, 4.567, -3.4567, 1e22,
+                 1e23, 8.41e21, 1.4e-45, 1.17549435e-38, 3.4028235e38, 16777216.0, 1.2345679, 10.0, 0.00001, 1234567.0, 12345678.0]
+
+
+def _real_values(n, t, seed):
+    rng = np.random.default_rng(seed)
+    with np.errstate(all="ignore"):
+        if t == pa.float32():
+            bits = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).astype(np.float64)
+        else:
+            bits = rng.integers(0, 2 ** 64, n, dtype=np.uint64).view(np.float64)
+    mid = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 12, n)
+    pick = rng.integers(0, 4, n)
+    with np.errstate(all="ignore"):
+        x = np.where(pick == 0, bits, np.where(pick == 1, mid, np.where(pick == 2, np.round(mid, 2), 2.0 ** rng.integers(-140, 120, n))))
+        x[:min(n, len(REAL_SPECIALS))] = REAL_SPECIALS[:n]
+        return x.astype(np.float32 if t == pa.float32() else np.float64)
+
+
+def _real_batch(n, t, seed):
+    x = _real_values(n, t, seed)
+    m = np.random.default_rng(seed + 1).random(n) < 0.1
+    m[:min(n, len(REAL_SPECIALS))] = False
+    return pa.RecordBatch.from_arrays([pa.array(x, t, mask=m)], names=["x"])
+
+
+def _real_exprs(b, batch, cuts=(40, 6, 0)):
+    x = b.make_field(batch.schema.field(0))
+    return [b.make_expression(b.make_function("castVARCHAR", [x, b.make_literal(c, pa.int64())], STR), pa.field(f"t{c}", STR)) for c in cuts]
+
+
+@pytest.mark.parametrize("t", [pa.float64(), pa.float32()])
+def test_oracle_text_of_a_real_is_the_shortest_digits_in_the_java_layout(t):
+    batch = _real_batch(6000, t, seed=3)
+    b = gandiva.TreeExprBuilder()
+    want = [_real_text(v, t) for v in batch.column(0).to_pylist()]
+    for cut, g in zip((40, 6, 0), oracle.project(_real_exprs(b, batch), batch)):
+        assert g.to_pylist() == [None if w is None else w[:cut] for w in want], cut
+    # the handful the lineage's own test names [gdv_function_stubs_test.cc TestCastVarcharFromFloat / Double, as recalled]
+    for v, text in ((4.567, "4.567"), (-3.4567, "-3.4567"), (0.00001, "1.0E-5"), (0.00099999, "9.9999E-4"), (0.0, "0.0"), (10.0, "10.0"), (1.2345679, "1.2345679")):
+        assert _real_text(float(np.float32(v)), pa.float32()) == text
+
+
+@pytest.mark.parametrize("is32", [0, 1])
+def test_device_real_text_on_the_host(hostlib, is32):  # noqa: F811
+    t = pa.float32() if is32 else pa.float64()
+    x = _real_values(120_000, t, seed=11)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for cut in (40, 5):
+        out, ln = np.zeros(32 * len(x), np.uint8), np.zeros(len(x), np.int32)
+        assert hostlib.host_real_text(is32, p(x), C.c_long(len(x)), C.c_long(cut), p(out), p(ln)) == 0
+        got = [bytes(out[32 * i:32 * i + ln[i]]).decode() for i in range(len(x))]
+        assert got == [_real_text(float(v), t)[:cut] for v in x], cut
+    assert hostlib.host_real_text(is32, p(x), C.c_long(4), C.c_long(-1), p(out), p(ln)) != 0   # n < 0 raises
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [pa.float64(), pa.float32()])
+@pytest.mark.parametrize("n", [1, 64, 1000, 30_011])
+def test_cast_real_to_text_on_the_gpu(n, t):
+    batch = _real_batch(n, t, seed=n)
+    b = gandiva.TreeExprBuilder()
+    exprs = _real_exprs(b, batch)
+    got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    for g, w, c in zip(got, oracle.project(exprs, batch), (40, 6, 0)):
+        assert_bit_exact(g, w, f"castVARCHAR(x, {c})")
+    assert got[0].to_pylist() == [_real_text(v, t) for v in batch.column(0).to_pylist()]
+
+
+@pytest.mark.gpu
+def test_text_of_a_real_feeds_concat_other_functions_and_selection_mode():
+    batch = _real_batch(5000, pa.float64(), seed=2)
+    b = gandiva.TreeExprBuilder()
+    x = b.make_field(batch.schema.field(0))
+    text = b.make_function("castVARCHAR", [x, b.make_literal(40, pa.int64())], STR)
+    e = [b.make_expression(b.make_function("concat", [b.make_literal("v=", STR), text], STR), pa.field("c", STR)),
+         b.make_expression(b.make_function("upper", [b.make_function("substr", [text, b.make_literal(1, pa.int64()), b.make_literal(4, pa.int64())], STR)], STR),
+                           pa.field("u", STR))]
+    got = gandiva.make_projector(batch.schema, e, None).evaluate(batch)
+    for g, w in zip(got, oracle.project(e, batch)):
+        assert_bit_exact(g, w, "castVARCHAR(x, 40) inside concat / upper(substr())")
+    cond = b.make_condition(b.make_function("greater_than", [x, b.make_literal(0.0, pa.float64())], pa.bool_()))
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch)
+    got = gandiva.make_projector(batch.schema, e[:1], None, "UINT32").evaluate(batch, sel)
+    rows = sel.to_array().to_numpy()
+    assert got[0].to_pylist() == [oracle.project(e[:1], batch)[0][int(r)].as_py() for r in rows]
+    with pytest.raises(Exception):
+        neg = b.make_expression(b.make_function("castVARCHAR", [x, b.make_literal(-1, pa.int64())], STR), pa.field("n", STR))
+        gandiva.make_projector(batch.schema, [neg], None).evaluate(batch)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: to_date(text, 'pattern'[, suppress_errors]), to_timestamp / to_time over numbers.
+#   engine 1 (oracle): glibc's strptime itself (what the lineage calls) on the converted pattern
+#   engine 2 (device library, host build and GPU): its own interpreter of the planner's compiled pattern
+#   engine 3 (here): Python's datetime.strptime on well-formed texts
+import datetime  # noqa: E402
+
+DATE_PATTERNS = [("YYYY-MM-DD", "%Y-%m-%d"), ("YYYY-MM-DD HH24:MI:SS", "%Y-%m-%d %H:%M:%S"), ("DD/MM/YYYY", "%d/%m/%Y"), ("MON DD, YYYY", "%b %d, %Y"),
+                 ("DD MONTH YYYY", "%d %B %Y"), ("yyyymmdd", "%Y%m%d"), ("DY, DD MON YY HH12:MI:SS AM", "%a, %d %b %y %I:%M:%S %p"), ("YYYY.DDD", "%Y.%j"),
+                 ('YYYY-MM-DD"T"HH24:MI', "%Y-%m-%dT%H:%M")]
+_DATE_TOKENS = [("YYYY", "Y"), ("HH24", "H"), ("HH12", "I"), ("MONTH", "b"), ("MON", "b"), ("DDD", "j"), ("DAY", "a"), ("YY", "y"), ("MM", "m"), ("DD", "d"),
+                ("DY", "a"), ("HH", "I"), ("MI", "M"), ("SS", "S"), ("AM", "p"), ("PM", "p")]
+
+
+def _compile_date_pattern(p):
+    """the planner's CompileDateFormat, restated: one byte per directive, 'L' c for a literal, ' ' for white space"""
+    ops, i, quoted = b"", 0, False
+    while i < len(p):
+        c = p[i]
+        if c == '"':
+            quoted, i = not quoted, i + 1
+        elif quoted:
+            ops, i = ops + b"L" + c.encode(), i + 1
+        elif c.isspace():
+            ops += b" " if not ops.endswith(b" ") else b""
+            i += 1
+        elif not c.isalpha():
+            ops += b"L" + c.encode()
+            i += 1
+        else:
+            tok = next((t for t in _DATE_TOKENS if p[i:i + len(t[0])].upper() == t[0]), None)
+            assert tok is not None, p[i:]
+            ops += tok[1].encode()
+            i += len(tok[0])
+    return ops
+
+
+def _date_texts(pyfmt, n, seed, mutate):
+    rng = np.random.default_rng(seed)
+    days = rng.integers(-20000, 30000, n)
+    secs = rng.integers(0, 86400, n)
+    out, want = [], []
+    for d, s in zip(days, secs):
+        t = datetime.datetime(1970, 1, 1) + datetime.timedelta(days=int(d), seconds=int(s))
+        if "%y" in pyfmt:
+            t = t.replace(year=1969 + int(d) % 100, day=min(t.day, 28))     # the two-digit window 1969 .. 2068
+        text = t.strftime(pyfmt)
+        if "%Y" in pyfmt and t.year < 1000:
+            text = text.replace(str(t.year), f"{t.year:04d}", 1)
+        w = datetime.datetime(t.year, t.month, t.day)   # (a day of the year gives month and day as well: glibc fills them in)
+        if mutate and rng.random() < 0.5:
+            k = int(rng.integers(0, 5))
+            pos = int(rng.integers(0, len(text) + 1))
+            if k == 0:
+                text = text[:pos]
+            elif k == 1:
+                text = text[:pos] + "xX9 -:/"[int(rng.integers(0, 7))] + text[pos + 1:]
+            elif k == 2:
+                text = text[:pos] + " " * int(rng.integers(1, 3)) + text[pos:]
+            elif k == 3:
+                text = text + " trailing"
+            else:
+                text = text.upper() if rng.random() < 0.5 else text.lower()
+            w = None
+        out.append(text)
+        want.append(w)
+    return out, want
+
+
+def _to_date_exprs(b, s, pattern, suppress):
+    args = [s, b.make_literal(pattern, STR)] + ([b.make_literal(suppress, pa.int32())] if suppress is not None else [])
+    return b.make_expression(b.make_function("to_date", args, pa.date64()), pa.field("d", pa.date64()))
+
+
+@pytest.mark.parametrize("pattern,pyfmt", DATE_PATTERNS)
+def test_oracle_to_date_is_strptime_and_agrees_with_pythons_on_well_formed_texts(pattern, pyfmt):
+    texts, want = _date_texts(pyfmt, 800, seed=len(pattern), mutate=False)
+    batch = pa.RecordBatch.from_arrays([pa.array(texts + [None], STR)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    got = oracle.project([_to_date_exprs(b, s, pattern, None)], batch)[0]
+    assert got.to_pylist() == [w.date() for w in want] + [None], pattern
+    # texts that do not parse: null with suppress_errors = 1, an error without
+    bad = pa.RecordBatch.from_arrays([pa.array(["not a date", texts[0], ""], STR)], names=["s"])
+    got = oracle.project([_to_date_exprs(b, s, pattern, 1)], bad)[0].to_pylist()
+    assert got[0] is None and got[2] is None and got[1] == want[0].date()
+    for flag in (None, 0):
+        with pytest.raises(Exception):
+            oracle.project([_to_date_exprs(b, s, pattern, flag)], bad)
+
+
+@pytest.mark.parametrize("pattern,pyfmt", DATE_PATTERNS)
+def test_device_to_date_interpreter_on_the_host_agrees_with_strptime_on_mutated_texts(hostlib, pattern, pyfmt):  # noqa: F811
+    texts, _ = _date_texts(pyfmt, 4000, seed=7 + len(pattern), mutate=True)
+    texts += ["", " ", "0", "9999-12-31", "1-1-1", "  2020-1-2", "2020-02-30", "2020-13-01", "69-01-01", "Feb", "Sunday", "12:00:61 PM", "2020.366", "2019.365", "2020.60", "2019.060"]
+    arr = pa.array(texts, STR)
+    batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    want = oracle.project([_to_date_exprs(b, b.make_field(batch.schema.field(0)), pattern, 1)], batch)[0]
+    off = np.frombuffer(arr.buffers()[1], np.int32)[: len(texts) + 1].copy()
+    size = int(off[-1])
+    data = np.concatenate([np.frombuffer(arr.buffers()[2], np.uint8)[:size], np.zeros(64, np.uint8)])
+    ops = np.frombuffer(_compile_date_pattern(pattern) + b"\0" * 8, np.uint8).copy()
+    out, ov = np.zeros(len(texts), np.int64), np.zeros(len(texts), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert hostlib.host_parse_date(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(ops), len(ops) - 8, 1, p(out), p(ov)) == 0
+    got = [int(v) if ok else None for v, ok in zip(out, ov)]
+    assert got == want.cast(pa.int64()).to_pylist(), pattern
+    if any(g is None for g in got):   # without suppress_errors the same rows raise
+        assert hostlib.host_parse_date(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(ops), len(ops) - 8, 0, p(out), p(ov)) == 4
+
+
+def _seconds_batch(n, seed=1):
+    rng = np.random.default_rng(seed)
+    k = rng.integers(-2 ** 33, 2 ** 33, n)
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(0, 11, n)
+    return pa.RecordBatch.from_arrays([pa.array((k % 2 ** 31).astype(np.int32)), pa.array(k, pa.int64(), mask=rng.random(n) < 0.1), pa.array(x.astype(np.float32)),
+                                       pa.array(x, pa.float64())], names=["i", "k", "f", "x"])
+
+
+def _seconds_exprs(b, batch):
+    out = []
+    for j in range(4):
+        fld = b.make_field(batch.schema.field(j))
+        out += [b.make_expression(b.make_function("to_timestamp", [fld], pa.timestamp("ms")), pa.field(f"ts{j}", pa.timestamp("ms"))),
+                b.make_expression(b.make_function("to_time", [fld], pa.time32("ms")), pa.field(f"tm{j}", pa.time32("ms")))]
+    return out
+
+
+def test_oracle_and_device_seconds_to_millis(hostlib):  # noqa: F811
+    batch = _seconds_batch(3000)
+    b = gandiva.TreeExprBuilder()
+    got = oracle.project(_seconds_exprs(b, batch), batch)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for j, dt in enumerate((np.int32, np.int64, np.float32, np.float64)):
+        col = batch.column(j)
+        v = np.asarray(col.fill_null(0), dt)
+        ms = (v.astype(np.float32) * np.float32(1000.0)).astype(np.float64) if dt == np.float32 else v * 1000.0 if dt == np.float64 else None
+        want = (v.astype(np.int64) * 1000) if ms is None else np.trunc(ms).astype(np.int64)
+        ok = np.array([x is not None for x in col.to_pylist()])
+        ts = np.asarray(got[2 * j].cast(pa.int64()).fill_null(0))
+        tm = np.asarray(got[2 * j + 1].cast(pa.int32()).fill_null(0))
+        assert (ts[ok] == want[ok]).all() and (tm[ok] == np.fmod(want[ok], 86400000)).all(), dt
+        hts, htm = np.zeros(len(v), np.int64), np.zeros(len(v), np.int32)
+        hostlib.host_to_timestamp(j, p(v), C.c_long(len(v)), p(hts), p(htm))
+        assert (hts[ok] == ts[ok]).all() and (htm[ok] == tm[ok]).all(), dt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 5000])
+def test_to_date_and_seconds_to_millis_on_the_gpu(n):
+    b = gandiva.TreeExprBuilder()
+    for pattern, pyfmt in DATE_PATTERNS:
+        texts, _ = _date_texts(pyfmt, n, seed=n + len(pattern), mutate=True)
+        batch = pa.RecordBatch.from_arrays([pa.array(texts, STR, mask=np.random.default_rng(n).random(n) < 0.1)], names=["s"])
+        s = b.make_field(batch.schema.field(0))
+        e = [_to_date_exprs(b, s, pattern, 1), _to_date_exprs(b, b.make_function("upper", [s], STR), pattern, 1)]
+        got = gandiva.make_projector(batch.schema, e, None).evaluate(batch)
+        for g, w in zip(got, oracle.project(e, batch)):
+            assert_bit_exact(g, w, f"to_date(s, '{pattern}', 1)")
+        clean, want = _date_texts(pyfmt, n, seed=n, mutate=False)
+        cb = pa.RecordBatch.from_arrays([pa.array(clean, STR)], names=["s"])
+        got = gandiva.make_projector(cb.schema, [_to_date_exprs(b, s, pattern, None)], None).evaluate(cb)
+        assert got[0].to_pylist() == [w.date() for w in want], pattern
+        if any(v is None for v in oracle.project(e[:1], batch)[0].to_pylist()) and batch.column(0).null_count < n:
+            with pytest.raises(Exception):
+                gandiva.make_projector(batch.schema, [_to_date_exprs(b, s, pattern, 0)], None).evaluate(batch)
+    batch = _seconds_batch(n, seed=n)
+    e = _seconds_exprs(b, batch)
+    for g, w in zip(gandiva.make_projector(batch.schema, e, None).evaluate(batch), oracle.project(e, batch)):
+        assert_bit_exact(g, w, "to_timestamp / to_time")
+
+
+def test_to_date_wants_literal_arguments_and_known_tokens():
+    b = gandiva.TreeExprBuilder()
+    sch = pa.schema([pa.field("s", STR), pa.field("p", STR)])
+    s, p = b.make_field(sch.field(0)), b.make_field(sch.field(1))
+    with pytest.raises(Exception, match="literal as the second parameter"):
+        gandiva.make_projector(sch, [b.make_expression(b.make_function("to_date", [s, p], pa.date64()), pa.field("d", pa.date64()))], None)
