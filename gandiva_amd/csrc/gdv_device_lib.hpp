@@ -1116,7 +1116,12 @@ GDV_DEV gdv_int64 castBIGINT_decimal128(gdv_int128 x, int xp, int xs, int op, in
 // round 5: lower-case hex text of a message digest; (map >> 8) & 3 = 0 SHA-256, 1 SHA-1, 2 MD5; bit 10 (1024): the message is
 // the 8 bytes of `lead`, else the `lead` bytes at `lead_p` (read through the low map bits)
 #define GDV_MAP_DIGEST 64
-#define GDV_MAP_SPECIAL (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE | GDV_MAP_INITCAP | GDV_MAP_DIGEST)  // only the output copy reads these
+// round 5, arguments that are not literals: GDV_MAP_CYCLE — the `lead` bytes at `p`, repeated cyclically to `len` bytes (the
+// fill of lpad / rpad); GDV_MAP_REPLACE_ROW — replace() with per-row from / to: `lim` = from's bytes, `lead_p` = to's,
+// lead = text length | from length << 32 | to length << 48, flags >> 8 = from's case map | to's << 2
+#define GDV_MAP_CYCLE 2048
+#define GDV_MAP_REPLACE_ROW 4096
+#define GDV_MAP_SPECIAL (GDV_MAP_REVERSE | GDV_MAP_DIGITS | GDV_MAP_REPLACE | GDV_MAP_INITCAP | GDV_MAP_DIGEST | GDV_MAP_CYCLE | GDV_MAP_REPLACE_ROW)  // only the output copy reads these
 // GDV_MAP_DIGITS with GDV_STR_DECIMAL in `flags` (round 4): the text of the decimal128 whose low / high
 // words sit in `p` / `lim`, scale = flags >> 8, cut to `len` bytes (castVARCHAR(decimal, n))
 #define GDV_STR_DECIMAL 128
@@ -1678,8 +1683,39 @@ GDV_DEV void gdv_copy_digest(P dst, const gdv_str& s) {
     }
   }
 }
+// (byte loops: the per-row-argument forms are registry-tail paths; the literal forms above keep the word-at-a-time code)
+template <typename P>
+GDV_DEV void gdv_copy_cycle(P dst, const gdv_str& s) {
+  const gdv_int32 period = (gdv_int32)s.lead, cm = s.map & GDV_MAP_CASE;
+  for (gdv_int32 j = 0, k = 0; j < s.len; j++) {
+    dst[j] = gdv_map_byte(s.p[k], cm);
+    if (++k == period) k = 0;
+  }
+}
+GDV_DEV bool gdv_match_row(const gdv_uint8* p, gdv_int32 i, gdv_int32 len, gdv_int32 cm, const gdv_uint8* from, gdv_int32 fl, gdv_int32 fm) {
+  bool m = i + fl <= len;
+  for (gdv_int32 j = 0; m && j < fl; j++) m = gdv_map_byte(p[i + j], cm) == gdv_map_byte(from[j], fm);
+  return m;
+}
+template <typename P>
+GDV_DEV void gdv_copy_replaced_row(P dst, const gdv_str& s) {
+  const gdv_int32 len = (gdv_int32)(gdv_uint32)s.lead, fl = (gdv_int32)((s.lead >> 32) & 0xffff), tl = (gdv_int32)(s.lead >> 48);
+  const gdv_int32 cm = s.map & GDV_MAP_CASE, fm = (s.flags >> 8) & 3, tm = (s.flags >> 10) & 3;
+  gdv_int32 o = 0;
+  for (gdv_int32 i = 0; i < len;) {
+    if (gdv_match_row(s.p, i, len, cm, s.lim, fl, fm)) {
+      for (gdv_int32 j = 0; j < tl; j++) dst[o++] = gdv_map_byte(s.lead_p[j], tm);
+      i += fl;
+    } else {
+      dst[o++] = gdv_map_byte(s.p[i], cm);
+      i++;
+    }
+  }
+}
 template <typename P>
 GDV_DEV void gdv_copy_special(P dst, const gdv_str& s) {
+  if (s.map & GDV_MAP_CYCLE) { gdv_copy_cycle(dst, s); return; }
+  if (s.map & GDV_MAP_REPLACE_ROW) { gdv_copy_replaced_row(dst, s); return; }
   if (s.map & GDV_MAP_DIGEST) gdv_copy_digest(dst, s);
   else if (s.map & GDV_MAP_INITCAP) gdv_copy_initcap(dst, s);
   else if (s.map & GDV_MAP_DIGITS) gdv_copy_digits(dst, s);
@@ -2464,6 +2500,45 @@ GDV_DEV gdv_str gdv_replace(gdv_ctx ctx, gdv_str s, const gdv_uint8* desc) {
   s.len = (gdv_int32)out;
   s.map |= GDV_MAP_REPLACE;
   return s;
+}
+// replace(s, from, to) with from / to that are not literals (round 5): the same rule, the arguments read through their own
+// views.  A `from` of more than 65535 bytes that does occur in s cannot be described by the view: execution error.
+GDV_DEV gdv_str gdv_replace_row(gdv_ctx ctx, gdv_str s, const gdv_str& from, const gdv_str& to) {
+  if (s.len <= 0 || from.len <= 0 || from.len > s.len) return s;
+  const gdv_int32 cm = s.map & GDV_MAP_CASE, fm = from.map & GDV_MAP_CASE;
+  gdv_int32 hits = 0;
+  for (gdv_int32 i = 0; i + from.len <= s.len;) {
+    if (gdv_match_row(s.p, i, s.len, cm, from.p, from.len, fm)) { hits++; i += from.len; } else { i++; }
+  }
+  if (hits == 0) return s;
+  const gdv_int64 out = (gdv_int64)s.len + (gdv_int64)hits * (to.len - from.len);
+  if (out > 65535 || from.len > 65535) { gdv_raise(ctx, GDV_ERR_BAD_ARG); s.len = 0; return s; }
+  s.lead = (gdv_uint64)(gdv_uint32)s.len | ((gdv_uint64)from.len << 32) | ((gdv_uint64)to.len << 48);  // (out <= 65535 with at least one hit bounds to.len by 65535 as well)
+  s.lim = from.p;
+  s.lead_p = to.p;
+  s.flags = (fm << 8) | ((to.map & GDV_MAP_CASE) << 10);
+  s.len = (gdv_int32)out;
+  s.map = cm | GDV_MAP_REPLACE_ROW;
+  return s;
+}
+// lpad / rpad(text, n, fill) with n or fill not a literal (round 5): the fill's characters, cyclically, up to n - chars(text)
+// of them — whole repetitions and then a prefix, which in bytes is simply the fill's bytes read cyclically.  "" when nothing
+// is to be added (an empty text, n <= 0, an empty fill, a text of n characters or more); more than 65536 characters: error.
+GDV_DEV gdv_str gdv_pad_fill_row(gdv_ctx ctx, const gdv_str& s, gdv_int32 n, const gdv_str& fill) {
+  gdv_str r = gdv_empty_str();
+  if (s.len <= 0 || n <= 0 || fill.len <= 0) return r;
+  const gdv_int32 pad = n - gdv_utf8_count(s);
+  if (pad <= 0) return r;
+  if (n > (1 << 16)) { gdv_raise(ctx, GDV_ERR_BAD_ARG); return r; }
+  gdv_int32 fchars = gdv_utf8_count(fill);
+  if (fchars <= 0) fchars = 1;
+  const gdv_int32 reps = pad / fchars, part = pad - reps * fchars;
+  r = fill;
+  r.flags &= ~GDV_STR_LEAD;
+  r.lead = (gdv_uint64)fill.len;
+  r.len = reps * fill.len + (part > 0 ? gdv_utf8_byte_pos(fill, part) : 0);
+  r.map = (fill.map & GDV_MAP_CASE) | GDV_MAP_CYCLE;
+  return r;
 }
 // ---- replace() answered by the byte sweep (round 3).  Kernels whose replace() takes a whole
 // column row and a 'from' of 2..8 bytes that cannot overlap itself let the sweep mark every

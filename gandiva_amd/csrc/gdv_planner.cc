@@ -37,6 +37,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.runtime_needles = std::getenv("GDV_RUNTIME_NEEDLES") != nullptr;
   o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
   o.no_sel_wave = std::getenv("GDV_NO_SEL_WAVE") != nullptr;
+  if (const char* s = std::getenv("GDV_PREPASS_AHEAD")) o.prepass_ahead = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_FP_EXPERIMENT")) o.fp_experiment = atoi(s);
   if (const char* s = std::getenv("GDV_FP_K")) o.fp_rounds = std::max(1, std::min(8, atoi(s)));
   if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
@@ -47,7 +48,7 @@ std::string CodegenOptions::Key() const {
   return "u" + std::to_string(subtiles) + "w" + std::to_string(waves) + (nontemporal ? "nt" : "") +
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
-         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_rounds != 3 ? "k" + std::to_string(fp_rounds) : "") +
+         (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (prepass_ahead ? "" : "npa") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_rounds != 3 ? "k" + std::to_string(fp_rounds) : "") +
          (fp_window_bytes != 9984 ? "fw" + std::to_string(fp_window_bytes) : "");
 }
 
@@ -406,12 +407,11 @@ class CodeGen {
     return "gdv_make_str(" + t + ", 0, " + std::to_string(bytes.size()) + ", " + t + " + " +
            std::to_string(bytes.size() + 8) + (ascii ? ", GDV_STR_ASCII | GDV_STR_INBUF)" : ", GDV_STR_INBUF)");
   }
-  // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
-  static // to_date's SQL pattern -> one byte per strptime directive (gdv_parse_date).  Tokens are matched case-insensitively,
+  // to_date's SQL pattern -> one byte per strptime directive (gdv_parse_date).  Tokens are matched case-insensitively,
 // longest first; any other letter sequence is an error, every other character stands for itself (white space: any
 // run of it) [date_utils.cc DateUtils::ToInternalFormat, as recalled; the time-zone tokens TZD / TZO / TZH:TZM and the
 // fractional-second / era / century / week-of-year tokens are not taken: the message says so].
-Status CompileDateFormat(const std::string& pattern, std::string* ops) {
+static Status CompileDateFormat(const std::string& pattern, std::string* ops) {
   static const std::pair<const char*, char> tokens[] = {
       {"YYYY", 'Y'}, {"HH24", 'H'}, {"HH12", 'I'}, {"MONTH", 'b'}, {"MON", 'b'}, {"DDD", 'j'}, {"DAY", 'a'}, {"YY", 'y'}, {"MM", 'm'},
       {"DD", 'd'},   {"DY", 'a'},   {"HH", 'I'},   {"MI", 'M'},    {"SS", 'S'},  {"AM", 'p'},  {"PM", 'p'}};
@@ -450,7 +450,8 @@ Status CompileDateFormat(const std::string& pattern, std::string* ops) {
   return Status::OK();
 }
 
-Status CompileLike(const std::string& pat, int escape, std::string* bytes,
+// SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
+  static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
                             std::string* kinds) {
     for (size_t i = 0; i < pat.size(); i++) {
       unsigned char c = static_cast<unsigned char>(pat[i]);
@@ -682,11 +683,20 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
       if (fn.name() == "replace") {
         // replace(text, from, to) with LITERAL from / to: a table in the constant block; the result
         // is materialised by the output copy (GDV_MAP_REPLACE)
-        for (int k = 1; k <= 2; k++)
-          if (fn.children()[k]->kind() != NodeKind::kLiteral)
-            return Status::CodeGenError("Function " + fn.ToString() +
-                                        " not supported yet: the HIP backend takes replace with literal "
-                                        "'from' and 'to' strings only. ");
+        if (fn.children()[1]->kind() != NodeKind::kLiteral || fn.children()[2]->kind() != NodeKind::kLiteral) {
+          // round 5: from / to that are not both literals — the same rule with the arguments read through their own views,
+          // per row (byte loops: a registry-tail path; literal arguments keep the table and the sweep's match bits)
+          std::string lanes;
+          for (auto& a : args) {
+            out->vcols.insert(a.vcols.begin(), a.vcols.end());
+            lanes = AndExpr(lanes, a.vlane);
+          }
+          out->vlane = lanes;
+          can_raise_ = true;
+          const std::string guard = AndExpr(AndExpr("live", active), LaneValid(*out));
+          out->v = Tmp("gdv_str", guard + " ? gdv_replace_row(ctx, " + args[0].v + ", " + args[1].v + ", " + args[2].v + ") : gdv_empty_str()");
+          return Status::OK();
+        }
         auto& lf = static_cast<const LiteralNode&>(*fn.children()[1]);
         auto& lt = static_cast<const LiteralNode&>(*fn.children()[2]);
         out->vcols = args[0].vcols;
@@ -743,10 +753,30 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         // fill repeated to n characters laid out once in the constant block
         const Node& nn = *fn.children()[1];
         const Node* fl = fn.children().size() == 3 ? fn.children()[2].get() : nullptr;
-        if (nn.kind() != NodeKind::kLiteral || (fl != nullptr && fl->kind() != NodeKind::kLiteral))
-          return Status::CodeGenError("Function " + fn.ToString() +
-                                      " not supported yet: the HIP backend takes lpad / rpad with a literal "
-                                      "length and a literal fill only. ");
+        if (nn.kind() != NodeKind::kLiteral || (fl != nullptr && fl->kind() != NodeKind::kLiteral)) {
+          // round 5: a length or a fill that is not a literal — the fill is read cyclically through its own view, per row
+          std::string lanes;
+          for (auto& a : args) {
+            out->vcols.insert(a.vcols.begin(), a.vcols.end());
+            lanes = AndExpr(lanes, a.vlane);
+          }
+          can_raise_ = true;
+          const std::string fillv = fl != nullptr ? args[2].v : Tmp("gdv_str", StringConstant(" "));
+          const std::string guard = AndExpr(AndExpr("live", active), AndExpr(lanes, LaneValid(args[0])));
+          const std::string want = Tmp("gdv_int32", guard + " ? (gdv_int32)" + args[1].v + " : 0");
+          const std::string text = Tmp("gdv_str", "gdv_pad_text(" + args[0].v + ", " + want + ")");
+          const std::string pad = Tmp("gdv_str", "gdv_pad_fill_row(ctx, " + args[0].v + ", " + want + ", " + fillv + ")");
+          if (fn.name() == "lpad") {
+            out->pieces.emplace_back(pad, "");
+            out->pieces.emplace_back(text, "");
+          } else {
+            out->pieces.emplace_back(text, "");
+            out->pieces.emplace_back(pad, "");
+          }
+          out->vlane = lanes;
+          out->v = "gdv_empty_str()";  // never read: consumers use the pieces
+          return Status::OK();
+        }
         auto& nl = static_cast<const LiteralNode&>(nn);
         const bool null_lit = nl.is_null() || (fl != nullptr && static_cast<const LiteralNode*>(fl)->is_null());
         const int32_t n = null_lit ? 0 : static_cast<int32_t>(nl.value().lo);
@@ -2201,7 +2231,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
                                             : "wave shape: independent wave tiles, output bases from the pre-pass + scan"))
     << (cg.selection() ? " (rows = the slots of a selection vector: gathered, no byte sweep)" : "")
     << "\n#define GDV_NV " << nv << "\n#define GDV_NSTAGE " << std::max(nstage, 1)
-    << "\n#define GDV_NHOOK " << std::max(nhook, 1) << "\n"
+    << "\n#define GDV_NHOOK " << (prepass && mirror_slot < 0 && ncb > 0 && plan->opts.prepass_ahead ? "(" + std::to_string(nhook) + " * GDV_U)" : std::to_string(std::max(nhook, 1))) << "\n"
     << (mirror_slot >= 0 || (prepass && ncb > 0) ? "#define GDV_HIT_WORDS (GDV_SUB_SPAN / 64 + 4)  // match bits of ONE sub-tile's span\n"
                                                  : "#define GDV_HIT_WORDS (GDV_SPAN_MAX / 64 + 4)\n")
     << "constexpr bool FULL = false;  // string tiles test `live` at run time (one code path)\n"
@@ -2269,6 +2299,58 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
         cg.row_ascii_slots_.insert(k);
         s << "  const gdv_int32 inb" << K << " = sd" << K << " + sp1" << K << " + 8 <= slim" << K << " ? GDV_STR_INBUF : 0;\n"
           << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
+        if (plan->opts.prepass_ahead) {
+          // round 5: every sub-tile's span is swept HERE, before the row loop — the first 1024-byte piece of all GDV_U spans
+          // is requested back to back (GDV_U loads in flight per lane where the pipelined form below has one; the sweep is
+          // a dozen instructions, unrolling IT is cheap — unrolling the row body was not), each span's continuation
+          // bytes go to a bitmap of its own, bit u of hiw = sub-tile u's span holds a byte >= 0x80
+          const std::string CB = std::to_string(cg.CbIndex(k));
+          s << "  gdv_uint32 hiw" << K << " = 0;\n"
+            << "  {\n"
+            << "    gdv_int32 sx[GDV_U + 1];  // the sub-tiles' first bytes (wave-uniform); sx[GDV_U] = the tile's end\n"
+            << "#pragma unroll\n"
+            << "    for (int u = 0; u < GDV_U; u++) sx[u] = __builtin_amdgcn_readfirstlane(oa" << K << "[u]);\n"
+            << "    sx[GDV_U] = sp1" << K << ";\n"
+            << "    gdv_uint64 pw[GDV_U][2];\n"
+            << "#pragma unroll\n"
+            << "    for (int u = 0; u < GDV_U; u++) {\n"
+            << "      const gdv_int32 a = sx[u] - (gdv_int32)((gdv_uint64)(sd" << K << " + sx[u]) & 15) + 16 * lane;\n"
+            << "      pw[u][0] = 0ull; pw[u][1] = 0ull;\n"
+            << "      if (a < sx[u + 1]) __builtin_memcpy(pw[u], __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+            << "    }\n"
+            << "#pragma unroll\n"
+            << "    for (int u = 0; u < GDV_U; u++) {\n"
+            << "      const gdv_int32 sb = sx[u] - (gdv_int32)((gdv_uint64)(sd" << K << " + sx[u]) & 15), se = sx[u + 1];\n"
+            << "      const bool fits = se - sb <= GDV_SUB_SPAN;\n"
+            << "      gdv_uint64* const cb = lds_hit + (" << CB << " * GDV_U + u) * GDV_HIT_WORDS;\n"
+            << "      gdv_uint64 sacc = 0, w0 = pw[u][0], w1 = pw[u][1];\n"
+            << "      for (gdv_int32 c = sb; c < se; c += 1024) {\n"
+            << "        const gdv_int32 a = c + 16 * lane;\n"
+            << "        if (c != sb) {  // a span longer than one step (rows of more than 16 bytes on average): loaded as it comes\n"
+            << "          gdv_uint64 t[2] = {0ull, 0ull};\n"
+            << "          if (a < se) __builtin_memcpy(t, __builtin_assume_aligned(sd" << K << " + a, 16), 16);\n"
+            << "          w0 = t[0]; w1 = t[1];\n"
+            << "        }\n"
+            << "        sacc |= w0 | w1;\n"
+            << "        const gdv_uint64 hbw = __ballot(((w0 | w1) & GDV_B80) != 0);\n"
+            << "        const gdv_uint32 cm = hbw != 0 ? gdv_cont_mask16(w0, w1) : 0u;\n"
+            << "        if (fits && a < se) ((gdv_uint16*)cb)[(a - sb) >> 4] = (gdv_uint16)cm;\n"
+            << "      }\n"
+            << "      if (__ballot((sacc & GDV_B80) != 0) != 0) hiw" << K << " |= 1u << u;\n"
+            << "    }\n"
+            << "  }\n"
+            << "  __builtin_amdgcn_wave_barrier();\n";
+          std::ostringstream b;
+          b << "    // exact pre-pass: this sub-tile's continuation-byte bitmap (filled before the loop)\n"
+            << "    const gdv_int32 ss" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+            << "    const gdv_int32 se" << K << " = u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+            << "    const gdv_int32 sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
+            << "    const bool hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap\n"
+            << "    const gdv_uint64* const cb" << K << " = lds_hit + (" << CB << " * GDV_U + u) * GDV_HIT_WORDS;\n"
+            << "    const bool hi8_" << K << " = ((hiw" << K << " >> u) & 1u) != 0;\n";
+          sweep.per_sub += b.str();
+          continue;
+        }
         // software-pipelined like the main kernel's sweep: the first 1024-byte step of the NEXT sub-tile's
         // span is requested before this sub-tile's rows are looked at (unrolling the loop to have all
         // eight in flight measured slower: 0.81 vs 0.52 ms at 10^8 rows — the general UTF-8 paths are

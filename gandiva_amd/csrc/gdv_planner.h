@@ -52,6 +52,10 @@ struct CodegenOptions {
   int fp_window_bytes = 9984;
   int fp_rounds = 3;                   // GDV_FP_K: rounds of GDV_U sub-tiles per wave tile of the windowed shape (one look-back per K x 8192 rows)
   int fp_experiment = 0;               // GDV_FP_EXPERIMENT=<n>: timing experiments on the fused kernel (wrong results; tools only)
+  // exact pre-pass of the wave kernels (round 5): all GDV_U sub-tile spans of a wave tile are swept before the row loop, their
+  // first pieces requested back to back (GDV_U loads in flight per lane; one bitmap per sub-tile in LDS).  GDV_PREPASS_AHEAD=0:
+  // one span per row-loop iteration, the next one's first piece prefetched (round 4).
+  bool prepass_ahead = true;
   bool no_sel_wave = false;            // GDV_NO_SEL_WAVE=1: selection-mode var-len plans take the scanner shape (rounds 2-4)
   bool runtime_needles = false;        // GDV_RUNTIME_NEEDLES=1: wave kernels load their '%needle%' bytes instead of carrying them as immediates
   static CodegenOptions FromEnv();

@@ -337,8 +337,8 @@ FunctionRegistry::FunctionRegistry() {
     for (const char* f : {"hashMD5", "md5"}) add(f, {t}, utf8(), NullPolicy::kNullNever, kVarlenResult, Sym("hashMD5", {t}));
   }
   add("replace", {utf8(), utf8(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult | kNeedsContext,
-      "gdv_replace");  // planned by gdv_planner.cc (literal from / to)
-  // lpad / rpad: planned as two pieces (gdv_planner.cc), literal length and fill only
+      "gdv_replace");  // planned by gdv_planner.cc (literal from / to: a table + the sweep's match bits; otherwise per row)
+  // lpad / rpad: planned as two pieces (gdv_planner.cc); a length / fill that is not a literal: the fill read cyclically, per row
   for (const char* f : {"lpad", "rpad"}) {
     add(f, {utf8(), int32()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_pad");
     add(f, {utf8(), int32(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_pad");

@@ -287,6 +287,46 @@ void host_to_timestamp(int kind, const void* v, long n, long long* ts, int* tm) 
     else { ts[i] = to_timestamp_float64(((const double*)v)[i]); tm[i] = to_time_float64(((const double*)v)[i]); }
   }
 }
+// replace / lpad / rpad with per-row arguments (round 5): three string columns (text, from | fill, to) and a length column
+long host_replace_row(const int* off0, const unsigned char* d0, long s0, const int* off1, const unsigned char* d1, long s1, const int* off2,
+                      const unsigned char* d2, long s2, long n, int text_map, int* out_off, unsigned char* out_data, int* err_out) {
+  HostCol c0{off0, d0, s0}, c1{off1, d1, s1}, c2{off2, d2, s2};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c0, i);
+    if (text_map == 1) s = upper_utf8(s);
+    const gdv_str r = gdv_replace_row(ctx, s, host_row(c1, i), host_row(c2, i));
+    if (r.len > 0) gdv_str_copy(out_data + at, r);
+    at += r.len;
+    out_off[i + 1] = (int)at;
+  }
+  *err_out = (int)err;
+  return at;
+}
+long host_pad_row(int right, const int* off0, const unsigned char* d0, long s0, const int* want, const int* off1, const unsigned char* d1, long s1,
+                  long n, int* out_off, unsigned char* out_data, int* err_out) {
+  HostCol c0{off0, d0, s0}, c1{off1, d1, s1};
+  unsigned err = 0;
+  gdv_ctx ctx{&err};
+  long at = 0;
+  out_off[0] = 0;
+  for (long i = 0; i < n; i++) {
+    const gdv_str s = host_row(c0, i);
+    const gdv_str text = gdv_pad_text(s, want[i]), pad = gdv_pad_fill_row(ctx, s, want[i], host_row(c1, i));
+    const gdv_str& first = right ? text : pad;
+    const gdv_str& second = right ? pad : text;
+    if (first.len > 0) gdv_str_copy(out_data + at, first);
+    at += first.len;
+    if (second.len > 0) gdv_str_copy(out_data + at, second);
+    at += second.len;
+    out_off[i + 1] = (int)at;
+  }
+  *err_out = (int)err;
+  return at;
+}
 // lpad (right = 0) / rpad (right = 1): `tab` is the fill repeated to `want` characters, readable
 // 8 bytes past its end (what the planner lays out in the constant block)
 long host_str_pad(int right, const int* off, const unsigned char* data, long size, long n, int want,

@@ -799,3 +799,112 @@ def test_to_date_wants_literal_arguments_and_known_tokens():
     s, p = b.make_field(sch.field(0)), b.make_field(sch.field(1))
     with pytest.raises(Exception, match="literal as the second parameter"):
         gandiva.make_projector(sch, [b.make_expression(b.make_function("to_date", [s, p], pa.date64()), pa.field("d", pa.date64()))], None)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: replace / lpad / rpad with arguments that are NOT literals (columns, expressions): engine 1 the oracle (always took
+# them per row), engine 2 the device functions (host build, GPU), engine 3 Python's str.replace / ljust / rjust restated per character
+def _row_args_batch(n, seed=13):
+    rng = np.random.default_rng(seed)
+    words = ["ab", "a", "abc", "é", "日本", "x", "", "ba", "aa", "spark", "-", "0"]
+    text, frm, to, fill = [], [], [], []
+    for _ in range(n):
+        k = int(rng.integers(0, 12))
+        t = "".join(words[int(rng.integers(0, len(words)))] for _ in range(k))
+        text.append(t)
+        frm.append(words[int(rng.integers(0, len(words)))] if rng.random() < 0.8 or not t else t[int(rng.integers(0, len(t))):][:3])
+        to.append(words[int(rng.integers(0, len(words)))] * int(rng.integers(0, 3)))
+        fill.append(words[int(rng.integers(0, len(words)))] + ("é" if rng.random() < 0.2 else ""))
+    want = rng.integers(-2, 24, n).astype(np.int32)
+    m = lambda: rng.random(n) < 0.08  # noqa: E731
+    return pa.RecordBatch.from_arrays([pa.array(text, STR, mask=m()), pa.array(frm, STR, mask=m()), pa.array(to, STR, mask=m()), pa.array(fill, STR, mask=m()),
+                                       pa.array(want, pa.int32(), mask=m())], names=["t", "f", "r", "p", "n"])
+
+
+def _py_replace(t, f, r):
+    return t if not t or not f else t.replace(f, r)
+
+
+def _py_pad(t, n, p, right):
+    if not t or n <= 0:
+        return ""
+    if n <= len(t) or not p:
+        return t[:n] if n < len(t) else t
+    pad = (p * (n // len(p) + 1))[: n - len(t)]
+    return t + pad if right else pad + t
+
+
+def _row_args_exprs(b, batch):
+    t, f, r, p, n = (b.make_field(batch.schema.field(j)) for j in range(5))
+    lit = lambda s: b.make_literal(s, STR)  # noqa: E731
+    return [("replace(t, f, r)", b.make_function("replace", [t, f, r], STR), lambda v: None if None in (v[0], v[1], v[2]) else _py_replace(v[0], v[1], v[2])),
+            ("replace(t, 'a', r)", b.make_function("replace", [t, lit("a"), r], STR), lambda v: None if None in (v[0], v[2]) else _py_replace(v[0], "a", v[2])),
+            ("replace(upper(t), f, '_')", b.make_function("replace", [b.make_function("upper", [t], STR), f, lit("_")], STR),
+             lambda v: None if None in (v[0], v[1]) else _py_replace("".join(c.upper() if "a" <= c <= "z" else c for c in v[0]), v[1], "_")),
+            ("lpad(t, n, p)", b.make_function("lpad", [t, n, p], STR), lambda v: None if None in (v[0], v[3], v[4]) else _py_pad(v[0], v[4], v[3], False)),
+            ("rpad(t, n, p)", b.make_function("rpad", [t, n, p], STR), lambda v: None if None in (v[0], v[3], v[4]) else _py_pad(v[0], v[4], v[3], True)),
+            ("lpad(t, n)", b.make_function("lpad", [t, n], STR), lambda v: None if None in (v[0], v[4]) else _py_pad(v[0], v[4], " ", False)),
+            ("rpad(t, 9, p)", b.make_function("rpad", [t, b.make_literal(9, pa.int32()), p], STR), lambda v: None if None in (v[0], v[3]) else _py_pad(v[0], 9, v[3], True)),
+            ("lpad(t, n, 'é-')", b.make_function("lpad", [t, n, lit("é-")], STR), lambda v: None if None in (v[0], v[4]) else _py_pad(v[0], v[4], "é-", False))]
+
+
+def test_oracle_replace_and_pad_with_per_row_arguments_match_python():
+    batch = _row_args_batch(3000)
+    rows = list(zip(*[c.to_pylist() for c in batch.columns]))
+    b = gandiva.TreeExprBuilder()
+    cases = _row_args_exprs(b, batch)
+    exprs = [b.make_expression(node, pa.field(f"o{j}", STR)) for j, (_, node, _) in enumerate(cases)]
+    for (name, _, py), g in zip(cases, oracle.project(exprs, batch)):
+        assert g.to_pylist() == [py(v) for v in rows], name
+
+
+def test_device_replace_and_pad_with_per_row_arguments_on_the_host(hostlib):  # noqa: F811
+    batch = _row_args_batch(4000, seed=17)
+    cols = []
+    for j in range(4):
+        filled = pa.array([v if v is not None else "" for v in batch.column(j).to_pylist()], STR)
+        off = np.frombuffer(filled.buffers()[1], np.int32)[: len(filled) + 1].copy()
+        size = int(off[-1])
+        data = np.concatenate([np.frombuffer(filled.buffers()[2], np.uint8)[:size] if size else np.zeros(0, np.uint8), np.zeros(64, np.uint8)])
+        cols.append((off, data, size, filled.to_pylist()))
+    want_n = np.asarray(batch.column(4).fill_null(0), np.int32)
+    n = batch.num_rows
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    out_off, out = np.zeros(n + 1, np.int32), np.zeros(1 << 22, np.uint8)
+    err = C.c_int(0)
+    (o0, d0, s0, t), (o1, d1, s1, f), (o2, d2, s2, r), (o3, d3, s3, fill) = cols
+    for mp in (0, 1):
+        hostlib.host_replace_row.restype = C.c_long
+        hostlib.host_replace_row(p(o0), p(d0), C.c_long(s0), p(o1), p(d1), C.c_long(s1), p(o2), p(d2), C.c_long(s2), C.c_long(n), mp, p(out_off), p(out), C.byref(err))
+        got = [bytes(out[out_off[i]:out_off[i + 1]]).decode() for i in range(n)]
+        up = (lambda s: "".join(c.upper() if "a" <= c <= "z" else c for c in s)) if mp else (lambda s: s)
+        assert err.value == 0 and got == [_py_replace(up(a), b_, c) for a, b_, c in zip(t, f, r)], mp
+    for right in (0, 1):
+        hostlib.host_pad_row(right, p(o0), p(d0), C.c_long(s0), p(want_n), p(o3), p(d3), C.c_long(s3), C.c_long(n), p(out_off), p(out), C.byref(err))
+        got = [bytes(out[out_off[i]:out_off[i + 1]]).decode() for i in range(n)]
+        assert err.value == 0 and got == [_py_pad(a, int(k), q, bool(right)) for a, k, q in zip(t, want_n, fill)], right
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 20_011])
+def test_replace_and_pad_with_per_row_arguments_on_the_gpu(n):
+    batch = _row_args_batch(n, seed=n)
+    b = gandiva.TreeExprBuilder()
+    cases = _row_args_exprs(b, batch)
+    for lo in range(0, len(cases), 3):
+        exprs = [b.make_expression(node, pa.field(f"o{j}", STR)) for j, (_, node, _) in enumerate(cases[lo:lo + 3])]
+        got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+        for g, w, (name, _, _) in zip(got, oracle.project(exprs, batch), cases[lo:lo + 3]):
+            assert_bit_exact(g, w, name)
+    # under a selection vector, and a per-row replace feeding another function (two stages)
+    t, f, r = (b.make_field(batch.schema.field(j)) for j in range(3))
+    e = [b.make_expression(b.make_function("upper", [b.make_function("replace", [t, f, r], STR)], STR), pa.field("u", STR))]
+    got = gandiva.make_projector(batch.schema, e, None).evaluate(batch)
+    assert_bit_exact(got[0], oracle.project(e, batch)[0], "upper(replace(t, f, r))")
+    cond = b.make_condition(b.make_function("isnotnull", [t], pa.bool_()))
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch)
+    e2 = [b.make_expression(cases[0][1], pa.field("o", STR)), b.make_expression(cases[3][1], pa.field("q", STR))]
+    got = gandiva.make_projector(batch.schema, e2, None, "UINT32").evaluate(batch, sel)
+    rows = sel.to_array().to_numpy()
+    for g, w in zip(got, oracle.project(e2, batch)):
+        assert g.to_pylist() == [w[int(i)].as_py() for i in rows]

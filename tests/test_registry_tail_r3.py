@@ -444,11 +444,11 @@ def test_gpu_errors_and_rejections():
     same = gandiva.make_projector(batch.schema, [b.make_expression(
         b.make_function("replace", [s, b.make_literal("a", STR), b.make_literal("c", STR)], STR), pa.field("r", STR))], None)
     assert same.evaluate(lb)[0].to_pylist() == ["c" * 40000, "b"]
-    # what stays outside the HIP backend: non-literal pad lengths / replace strings
+    # (rounds 2-4 refused non-literal pad lengths / replace strings; round 5 takes them per row: tests/test_registry_tail.py)
     for node in (b.make_function("lpad", [s, b.make_function("castINT", [x], I32), b.make_literal("*", STR)], STR),
                  b.make_function("replace", [s, s, b.make_literal("*", STR)], STR)):
-        with pytest.raises(gandiva.GandivaError, match="not supported yet"):
-            gandiva.make_projector(batch.schema, [b.make_expression(node, pa.field("o", STR))], None)
+        e = [b.make_expression(node, pa.field("o", STR))]
+        assert_bit_exact(gandiva.make_projector(batch.schema, e, None).evaluate(batch)[0], oracle.project(e, batch)[0], "per-row arguments")
     # (round 3) a materialised value under a selection vector is a two-stage plan like any other: the
     # first stage runs in the same selection mode, on the selected rows only
     sel_proj = gandiva.make_projector(batch.schema, [b.make_expression(
