@@ -108,6 +108,8 @@ PROTOTYPES = [
     ("gdv_filter_project_set_tuning", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("gdv_filter_project_free", None, [_P]),
     ("gdv_precompile_filter_project", C.c_int, [_P, _P, C.POINTER(_P), C.c_int, C.c_int]),
+    ("gdv_compile_regex", C.c_int, [C.c_char_p, C.c_int64, _P]),
+    ("gdv_compile_date_format", C.c_int, [C.c_char_p, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("gdv_registry_size", C.c_int, []),
     ("gdv_registry_get", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(gdv_type_t), C.POINTER(gdv_type_t), C.c_int, C.POINTER(C.c_int)]),
     ("gdv_device_stream_ceiling", C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

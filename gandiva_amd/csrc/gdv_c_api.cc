@@ -14,6 +14,7 @@
 #include "gdv_kernels.h"
 #include "gdv_libtag.h"
 #include "gdv_proto.h"
+#include "gdv_regex.h"
 
 using namespace gdv;
 
@@ -1294,6 +1295,30 @@ int gdv_precompile_filter(const gdv_schema_t* schema, gdv_expression_t* conditio
   return Guarded([&]() -> int {
   if (!schema || !condition || !condition->expr) return Fail(Status::Invalid("null argument"));
   return Check(PrecompileFilter(schema->fields, condition->expr));
+  });
+}
+
+int gdv_compile_regex(const char* pattern, int64_t pattern_len, uint8_t* table) {
+  return Guarded([&]() -> int {
+  if (!pattern || pattern_len < 0 || !table) return Fail(Status::Invalid("null argument"));
+  std::string bytes;
+  Status st = CompileRegex(std::string(pattern, static_cast<size_t>(pattern_len)), &bytes);
+  if (!st.ok()) return Fail(st);
+  std::memcpy(table, bytes.data(), bytes.size());
+  return 0;
+  });
+}
+
+int gdv_compile_date_format(const char* pattern, int64_t pattern_len, uint8_t* ops, int64_t cap, int64_t* n) {
+  return Guarded([&]() -> int {
+  if (!pattern || pattern_len < 0 || !ops || !n) return Fail(Status::Invalid("null argument"));
+  std::string bytes;
+  Status st = CompileDateFormat(std::string(pattern, static_cast<size_t>(pattern_len)), &bytes);
+  if (!st.ok()) return Fail(st);
+  if (static_cast<int64_t>(bytes.size()) > cap) return Fail(Status::Invalid("ops buffer too small"));
+  std::memcpy(ops, bytes.data(), bytes.size());
+  *n = static_cast<int64_t>(bytes.size());
+  return 0;
   });
 }
 

@@ -2313,6 +2313,27 @@ GDV_DEV gdv_str castVARCHAR_float32_int64(gdv_ctx ctx, gdv_float32 v, gdv_int64 
   return gdv_real_view(ctx, ex == 0 ? mant : (mant | (1u << 23)), ex == 0 ? -149 : ex - 150, mant == 0 && ex > 1,
                        (gdv_int32)(b >> 31), kind, n);
 }
+// ---- regexp_like / regexp_matches (round 5, late): does the text contain a match of the pattern?  The planner compiles the
+// pattern to a position automaton of at most 63 positions (gdv_regex.h): table = first, last, flags (1 nullable, 2 anchored at
+// the start, 4 at the end), follow[64], match[256].  One 64-bit set of live positions per row: a byte b takes the set S to
+// (follow(S) | first, where a match may start) & match[b]; a position of `last` in the set = a match ends behind this byte.
+GDV_DEV bool gdv_regex_search(const gdv_str& s, const gdv_uint8* table) {
+  const gdv_uint64* t = (const gdv_uint64*)table;
+  const gdv_uint64 first = t[0], last = t[1], flags = t[2];
+  const gdv_uint64* follow = t + 3;
+  const gdv_uint64* match = t + 3 + 64;
+  const bool at_start = (flags & 2) != 0, at_end = (flags & 4) != 0;
+  if ((flags & 1) != 0 && (!(at_start && at_end) || s.len <= 0)) return true;  // the empty match
+  gdv_uint64 live = 0;
+  for (gdv_int32 i = 0; i < s.len; i++) {
+    gdv_uint64 next = (!at_start || i == 0) ? first : 0ull;
+    for (gdv_uint64 w = live; w != 0; w &= w - 1) next |= follow[__builtin_ctzll(w)];
+    live = next & match[gdv_str_at(s, i)];
+    if ((live & last) != 0 && (!at_end || i + 1 == s.len)) return true;
+    if (live == 0 && at_start) return false;  // anchored and dead: nothing can start later
+  }
+  return false;
+}
 // ---- to_date(text, 'pattern'[, suppress_errors]) (round 5).  The lineage's ToDateHolder turns the SQL pattern into a
 // strptime format at Make time (date_utils.cc ToInternalFormat) and calls arrow::internal::ParseTimestampStrptime(...,
 // ignore_time_in_day = true, allow_trailing_chars = true): the C library's strptime, then year / month / max(day, 1)

@@ -1,6 +1,7 @@
 #include "gdv_planner.h"
 
 #include "gdv_libtag.h"
+#include "gdv_regex.h"
 #include "gdv_runtime.h"
 
 #include <algorithm>
@@ -407,50 +408,7 @@ class CodeGen {
     return "gdv_make_str(" + t + ", 0, " + std::to_string(bytes.size()) + ", " + t + " + " +
            std::to_string(bytes.size() + 8) + (ascii ? ", GDV_STR_ASCII | GDV_STR_INBUF)" : ", GDV_STR_INBUF)");
   }
-  // to_date's SQL pattern -> one byte per strptime directive (gdv_parse_date).  Tokens are matched case-insensitively,
-// longest first; any other letter sequence is an error, every other character stands for itself (white space: any
-// run of it) [date_utils.cc DateUtils::ToInternalFormat, as recalled; the time-zone tokens TZD / TZO / TZH:TZM and the
-// fractional-second / era / century / week-of-year tokens are not taken: the message says so].
-static Status CompileDateFormat(const std::string& pattern, std::string* ops) {
-  static const std::pair<const char*, char> tokens[] = {
-      {"YYYY", 'Y'}, {"HH24", 'H'}, {"HH12", 'I'}, {"MONTH", 'b'}, {"MON", 'b'}, {"DDD", 'j'}, {"DAY", 'a'}, {"YY", 'y'}, {"MM", 'm'},
-      {"DD", 'd'},   {"DY", 'a'},   {"HH", 'I'},   {"MI", 'M'},    {"SS", 'S'},  {"AM", 'p'},  {"PM", 'p'}};
-  ops->clear();
-  bool quoted = false;  // inside "double quotes" every character stands for itself
-  for (size_t i = 0; i < pattern.size();) {
-    const unsigned char c = static_cast<unsigned char>(pattern[i]);
-    if (c == '"') { quoted = !quoted; i++; continue; }
-    if (quoted) { ops->push_back('L'); ops->push_back(static_cast<char>(c)); i++; continue; }
-    if (c == ' ' || (c >= 9 && c <= 13)) {
-      if (ops->empty() || ops->back() != ' ') ops->push_back(' ');
-      i++;
-      continue;
-    }
-    if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'))) {
-      ops->push_back('L');
-      ops->push_back(static_cast<char>(c));
-      i++;
-      continue;
-    }
-    bool hit = false;
-    for (auto& tk : tokens) {
-      const size_t n = std::strlen(tk.first);
-      if (i + n > pattern.size()) continue;
-      bool same = true;
-      for (size_t j = 0; same && j < n; j++) same = (pattern[i + j] & ~0x20) == tk.first[j] || pattern[i + j] == tk.first[j];
-      if (same) { ops->push_back(tk.second); i += n; hit = true; break; }
-    }
-    if (!hit) {
-      size_t j = i;
-      while (j < pattern.size() && (((pattern[j] | 0x20) >= 'a' && (pattern[j] | 0x20) <= 'z') || (pattern[j] >= '0' && pattern[j] <= '9'))) j++;
-      return Status::Invalid("Invalid date format: the HIP backend takes YYYY YY MM MON MONTH DD DDD DY DAY HH HH12 HH24 MI SS AM PM; not '" +
-                             pattern.substr(i, j - i) + "'");
-    }
-  }
-  return Status::OK();
-}
-
-// SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
+  // SQL LIKE pattern -> (literal bytes, token kinds); `escape` < 0 means no escape character
   static Status CompileLike(const std::string& pat, int escape, std::string* bytes,
                             std::string* kinds) {
     for (size_t i = 0; i < pat.size(); i++) {
@@ -649,11 +607,34 @@ Status CodeGen::Gen(const Node& node, const std::string& active, Val* out) {
         }
         GDV_RETURN_NOT_OK(Gen(child, active, &args[i]));
       }
+      if (fn.name() == "regexp_like" || fn.name() == "regexp_matches") {
+        // (patterns that are a plain literal became `like` when the tree was built: gdv_node.cc MakeFunctionNode)  Round 5, late:
+        // the pattern is compiled to a position automaton here, at Make time; the row walks it with one 64-bit state set
+        auto& pat = static_cast<const LiteralNode&>(*fn.children()[1]);
+        out->type = fn.return_type();
+        out->vcols = args[0].vcols;
+        out->vlane = args[0].vlane;
+        out->pieces.clear();
+        out->col_slot = -1;
+        out->col_map = 0;
+        out->opaque = false;
+        if (pat.is_null()) {
+          out->v = "false";
+          out->vlane = "false";
+          return Status::OK();
+        }
+        if (!args[0].pieces.empty() || args[0].opaque)
+          return Status::CodeGenError("Function " + fn.ToString() + " not supported yet: a concat / lpad / rpad / reverse / replace / "
+                                      "castVARCHAR(number) result can only be an output expression or an argument of concat in the HIP backend. ");
+        std::string table;
+        GDV_RETURN_NOT_OK(CompileRegex(pat.value().bytes, &table));
+        out->v = Tmp("bool", "gdv_regex_search(" + args[0].v + ", " + ByteTable(table) + ")");
+        return Status::OK();
+      }
       if (fn.name().compare(0, 7, "regexp_") == 0)
-        return Status::CodeGenError("Function " + fn.ToString() + " not supported yet: the HIP backend takes regular "
-                                    "expressions in their literal subset only — regexp_like / regexp_matches with "
-                                    "'lit', '^lit', 'lit$' or '^lit$', regexp_replace with a literal pattern and a "
-                                    "replacement without backslashes (no metacharacters, no '%' or '_'). ");
+        return Status::CodeGenError("Function " + fn.ToString() + " not supported yet: the HIP backend takes regexp_replace "
+                                    "with a literal pattern and a replacement without backslashes only (no metacharacters, "
+                                    "no '%' or '_'). ");
       out->type = fn.return_type();
       out->vcols.clear();
       out->vlane.clear();

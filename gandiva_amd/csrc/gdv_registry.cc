@@ -292,13 +292,13 @@ FunctionRegistry::FunctionRegistry() {
   add("lengthUtf8", {binary()}, int32(), NullPolicy::kNullIfNull, 0, "char_length_utf8");
   add("like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
   add("like", {utf8(), utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_like");
-  // Regular expressions (round 5), LITERAL SUBSET: gdv_node.h MakeFunctionNode rewrites regexp_like / regexp_matches
-  // with 'lit', '^lit', 'lit$', '^lit$' onto like, and regexp_replace with a literal pattern onto replace, when the
-  // tree is built; a node that is still regexp_* when it reaches the planner is refused (CodeGenError).  [recalled:
-  // the lineage evaluates these through RE2 — PartialMatch / GlobalReplace; on a metacharacter-free pattern those are
-  // contains / starts / ends / equals and left-to-right non-overlapping replace]
-  add("regexp_like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_regexp_unsupported");
-  add("regexp_matches", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_regexp_unsupported");
+  // Regular expressions (round 5).  regexp_like / regexp_matches: gdv_node.h MakeFunctionNode rewrites 'lit', '^lit', 'lit$',
+  // '^lit$' onto like when the tree is built (the sweep's match bits answer those); every other pattern is compiled by the
+  // planner into a position automaton of at most 63 positions (gdv_regex.h lists the syntax; what it does not take is refused
+  // with the reason).  regexp_replace: a literal pattern and a replacement without backslashes only (-> replace).  [recalled:
+  // the lineage's holders compile the pattern with RE2 once per expression]
+  add("regexp_like", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_regex_search");
+  add("regexp_matches", {utf8(), utf8()}, boolean(), NullPolicy::kNullIfNull, kPatternArg, "gdv_regex_search");
   add("regexp_replace", {utf8(), utf8(), utf8()}, utf8(), NullPolicy::kNullIfNull, kVarlenResult, "gdv_regexp_unsupported");
   // ilike (round 4): like without regard to the case of ASCII letters — both sides are read through the
   // lower-case byte map, so every fast path of like (prefix / suffix / equality / '%needle%' answered by

@@ -91,10 +91,12 @@
  *         null)" are recollection; the parsing itself is THE C LIBRARY'S strptime (what the lineage calls), so the device
  *         library's own interpreter is held to glibc on every tested text.  to_timestamp / to_time over numbers:
  *         (int64)(seconds * 1000) [% 86400000] — recollection.
- *       - regexp_like / regexp_matches / regexp_replace: the lineage runs RE2 (PartialMatch / GlobalReplace); only the
- *         LITERAL SUBSET exists here ([^]lit[$] without metacharacters; replacement without backslashes), where RE2's
- *         semantics are contains / starts / ends / equals and left-to-right non-overlapping replace — checked against
- *         Python's re.  regexp_replace inherits replace's 65535-byte result cap (RE2 has none).
+ *       - regexp_like / regexp_matches: the lineage runs RE2::PartialMatch.  Here: a Thompson program over code points run as a
+ *         thread list, for the syntax gandiva_amd/csrc/gdv_regex.h lists (no back-references, \b, look-around, flags, inner
+ *         anchors); '.' excludes the newline and '$' means the end of the text (RE2's defaults, as recalled) — checked
+ *         against Python's re on patterns and texts where Python's rules coincide.  regexp_replace: the lineage runs
+ *         RE2::GlobalReplace; only the LITERAL SUBSET exists (a metacharacter-free pattern, a replacement without
+ *         backslashes: left-to-right non-overlapping replace), with replace's 65535-byte result cap (RE2 has none).
  *
  * Program format (whitespace separated, prefix order):
  *   F <col>                               field: column index
@@ -550,6 +552,205 @@ static int str_cmp(const uint8_t* a, int al, int am, const uint8_t* b, int bl, i
   }
   return al < bl ? -1 : (al > bl ? 1 : 0);
 }
+/* ---- regular expressions for regexp_like / regexp_matches: "does the text contain a match" [recalled: RE2::PartialMatch with
+ * default options — '.' does not match a newline, '$' only the end of the text].  An engine of its own kind: the pattern is
+ * parsed into a tree over CODE POINTS (the text is decoded from UTF-8 first), compiled to a Thompson program (char / split /
+ * jump / match) and run as a thread list (Pike) — where the device library walks a byte-level position automaton.  The syntax
+ * the HIP backend takes (gandiva_amd/csrc/gdv_regex.h); anything else returns -1 (the caller raises). */
+typedef struct rx_node { int kind; /* 0 empty 1 set 2 cat 3 alt 4 star 5 plus 6 opt */ uint8_t ascii[16]; int neg; int32_t lit; struct rx_node *a, *b; } rx_node;
+typedef struct { const uint8_t* p; int n, i, bad; rx_node* pool[4096]; int npool; } rx_parser;
+static rx_node* rx_new(rx_parser* P, int kind, rx_node* a, rx_node* b) {
+  if (P->npool >= 4096) { P->bad = 1; return P->pool[0]; }
+  rx_node* x = (rx_node*)calloc(1, sizeof(rx_node)); x->kind = kind; x->a = a; x->b = b; x->lit = -1; P->pool[P->npool++] = x; return x;
+}
+static rx_node* rx_clone(rx_parser* P, const rx_node* x) {
+  if (!x) return NULL;
+  rx_node* y = rx_new(P, x->kind, rx_clone(P, x->a), rx_clone(P, x->b));
+  memcpy(y->ascii, x->ascii, 16); y->neg = x->neg; y->lit = x->lit; return y;
+}
+static void rx_add(rx_node* x, int lo, int hi) { for (int c = lo; c <= hi; c++) x->ascii[c >> 3] |= (uint8_t)(1 << (c & 7)); }
+static rx_node* rx_alt(rx_parser* P);
+static int rx_escape(rx_parser* P, rx_node* set, int* negated) { /* one escape into `set`; returns 0 when not taken */
+  if (P->i >= P->n) return 0;
+  int c = P->p[P->i++]; *negated = 0;
+  switch (c) {
+    case 'D': *negated = 1; /* fall through */ case 'd': rx_add(set, '0', '9'); return 1;
+    case 'W': *negated = 1; /* fall through */ case 'w': rx_add(set, '0', '9'); rx_add(set, 'a', 'z'); rx_add(set, 'A', 'Z'); rx_add(set, '_', '_'); return 1;
+    case 'S': *negated = 1; /* fall through */ case 's': rx_add(set, ' ', ' '); rx_add(set, 9, 13); return 1;
+    case 't': rx_add(set, 9, 9); return 1; case 'n': rx_add(set, 10, 10); return 1; case 'r': rx_add(set, 13, 13); return 1;
+    case 'f': rx_add(set, 12, 12); return 1; case 'v': rx_add(set, 11, 11); return 1;
+    case 'x': {
+      if (P->i + 2 > P->n || !isxdigit(P->p[P->i]) || !isxdigit(P->p[P->i + 1])) return 0;
+      char h[3] = {(char)P->p[P->i], (char)P->p[P->i + 1], 0}; P->i += 2;
+      int v = (int)strtol(h, NULL, 16); if (v >= 128) return 0; rx_add(set, v, v); return 1; }
+    default: if (isalnum(c) || c >= 128) return 0; rx_add(set, c, c); return 1;
+  }
+}
+static rx_node* rx_atom(rx_parser* P) {
+  int c = P->p[P->i];
+  if (c == '(') {
+    P->i++;
+    if (P->i < P->n && P->p[P->i] == '?') { if (P->i + 1 < P->n && P->p[P->i + 1] == ':') P->i += 2; else { P->bad = 1; return rx_new(P, 0, NULL, NULL); } }
+    rx_node* x = rx_alt(P);
+    if (P->i >= P->n || P->p[P->i] != ')') P->bad = 1; else P->i++;
+    return x;
+  }
+  rx_node* s = rx_new(P, 1, NULL, NULL);
+  if (c == '[') {
+    P->i++;
+    if (P->i < P->n && P->p[P->i] == '^') { s->neg = 1; P->i++; }
+    for (int first = 1;; first = 0) {
+      if (P->i >= P->n) { P->bad = 1; return s; }
+      int m = P->p[P->i];
+      if (m == ']' && !first) { P->i++; break; }
+      if (m == '[' && P->i + 1 < P->n && P->p[P->i + 1] == ':') { P->bad = 1; return s; }
+      P->i++;
+      int lo = m, single = 1;
+      if (m == '\\') {
+        rx_node tmp; memset(&tmp, 0, sizeof tmp); int ng = 0;
+        if (!rx_escape(P, &tmp, &ng) || ng) { P->bad = 1; return s; }
+        int cnt = 0; for (int k = 0; k < 128; k++) if (tmp.ascii[k >> 3] & (1 << (k & 7))) { cnt++; lo = k; }
+        single = cnt == 1;
+        if (!single) { for (int k = 0; k < 16; k++) s->ascii[k] |= tmp.ascii[k]; continue; }
+      } else if (m >= 128) { P->bad = 1; return s; }
+      if (single && P->i + 1 < P->n && P->p[P->i] == '-' && P->p[P->i + 1] != ']') {
+        P->i++;
+        int hi = P->p[P->i++];
+        if (hi == '\\') {
+          rx_node tmp; memset(&tmp, 0, sizeof tmp); int ng = 0, cnt = 0;
+          if (!rx_escape(P, &tmp, &ng)) { P->bad = 1; return s; }
+          for (int k = 0; k < 128; k++) if (tmp.ascii[k >> 3] & (1 << (k & 7))) { cnt++; hi = k; }
+          if (cnt != 1) { P->bad = 1; return s; }
+        }
+        if (hi >= 128 || hi < lo) { P->bad = 1; return s; }
+        rx_add(s, lo, hi);
+      } else rx_add(s, lo, lo);
+    }
+    return s;
+  }
+  if (c == '.') { P->i++; s->neg = 1; rx_add(s, 10, 10); return s; }
+  if (c == '\\') { P->i++; int ng = 0; if (!rx_escape(P, s, &ng)) P->bad = 1; s->neg = ng; return s; }
+  if (c == '^' || c == '$' || c == '*' || c == '+' || c == '?' || c == '{') { P->bad = 1; return s; }
+  if (c < 128) { P->i++; rx_add(s, c, c); return s; }
+  /* a non-ASCII character of the pattern: one code point */
+  int len = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : 2;
+  if (c < 0xC2 || P->i + len > P->n) { P->bad = 1; return s; }
+  int32_t cp = c & (0xFF >> (len + 1));
+  for (int k = 1; k < len; k++) cp = (cp << 6) | (P->p[P->i + k] & 0x3F);
+  P->i += len; s->lit = cp; return s;
+}
+static rx_node* rx_repeat(rx_parser* P) {
+  rx_node* x = rx_atom(P);
+  while (!P->bad && P->i < P->n) {
+    int c = P->p[P->i];
+    if (c == '*' || c == '+' || c == '?') { P->i++; x = rx_new(P, c == '*' ? 4 : c == '+' ? 5 : 6, x, NULL); }
+    else if (c == '{') {
+      int j = P->i + 1, lo = 0, hi = -1, digits = 0;
+      while (j < P->n && isdigit(P->p[j]) && lo < 1000) { lo = lo * 10 + (P->p[j++] - '0'); digits++; }
+      if (!digits) { P->bad = 1; break; }
+      if (j < P->n && P->p[j] == ',') {
+        j++;
+        if (j < P->n && P->p[j] != '}') { hi = 0; digits = 0; while (j < P->n && isdigit(P->p[j]) && hi < 1000) { hi = hi * 10 + (P->p[j++] - '0'); digits++; } if (!digits) { P->bad = 1; break; } }
+      } else hi = lo;
+      if (j >= P->n || P->p[j] != '}' || (hi >= 0 && hi < lo) || lo > 63 || hi > 63) { P->bad = 1; break; }
+      P->i = j + 1;
+      rx_node* seq = rx_new(P, 0, NULL, NULL);
+      for (int k = 0; k < lo; k++) seq = rx_new(P, 2, seq, rx_clone(P, x));
+      if (hi < 0) seq = rx_new(P, 2, seq, rx_new(P, 4, rx_clone(P, x), NULL));
+      for (int k = lo; k < hi; k++) seq = rx_new(P, 2, seq, rx_new(P, 6, rx_clone(P, x), NULL));
+      x = seq;
+    } else break;
+    if (P->i < P->n && P->p[P->i] == '?') P->i++;
+    else if (P->i < P->n && P->p[P->i] == '+') P->bad = 1;
+  }
+  return x;
+}
+static rx_node* rx_cat(rx_parser* P) {
+  rx_node* x = rx_new(P, 0, NULL, NULL);
+  while (!P->bad && P->i < P->n && P->p[P->i] != '|' && P->p[P->i] != ')') x = rx_new(P, 2, x, rx_repeat(P));
+  return x;
+}
+static rx_node* rx_alt(rx_parser* P) {
+  rx_node* x = rx_cat(P);
+  while (!P->bad && P->i < P->n && P->p[P->i] == '|') { P->i++; x = rx_new(P, 3, x, rx_cat(P)); }
+  return x;
+}
+typedef struct { int op; /* 0 char 1 split 2 jmp 3 match */ int x, y; const rx_node* set; } rx_inst;
+typedef struct { rx_inst* code; int n, cap; } rx_prog;
+static int rx_emit1(rx_prog* g, int op, int x, int y, const rx_node* set) {
+  if (g->n == g->cap) { g->cap = g->cap ? g->cap * 2 : 64; g->code = (rx_inst*)realloc(g->code, (size_t)g->cap * sizeof(rx_inst)); }
+  g->code[g->n].op = op; g->code[g->n].x = x; g->code[g->n].y = y; g->code[g->n].set = set; return g->n++;
+}
+static void rx_emit(rx_prog* g, const rx_node* x) {
+  switch (x->kind) {
+    case 0: break;
+    case 1: rx_emit1(g, 0, 0, 0, x); break;
+    case 2: rx_emit(g, x->a); rx_emit(g, x->b); break;
+    case 3: { int s = rx_emit1(g, 1, 0, 0, NULL); g->code[s].x = g->n; rx_emit(g, x->a); int j = rx_emit1(g, 2, 0, 0, NULL); g->code[s].y = g->n; rx_emit(g, x->b); g->code[j].x = g->n; break; }
+    case 4: { int s = rx_emit1(g, 1, 0, 0, NULL); g->code[s].x = g->n; rx_emit(g, x->a); rx_emit1(g, 2, s, 0, NULL); g->code[s].y = g->n; break; }
+    case 5: { int l = g->n; rx_emit(g, x->a); int s = rx_emit1(g, 1, l, 0, NULL); g->code[s].y = g->n; break; }
+    default: { int s = rx_emit1(g, 1, 0, 0, NULL); g->code[s].x = g->n; rx_emit(g, x->a); g->code[s].y = g->n; break; }
+  }
+}
+static void rx_add_thread(const rx_prog* g, int* list, int* n, uint8_t* on, int pc) {
+  if (on[pc]) return;
+  on[pc] = 1;
+  if (g->code[pc].op == 2) rx_add_thread(g, list, n, on, g->code[pc].x);
+  else if (g->code[pc].op == 1) { rx_add_thread(g, list, n, on, g->code[pc].x); rx_add_thread(g, list, n, on, g->code[pc].y); }
+  else list[(*n)++] = pc;
+}
+static int rx_set_has(const rx_node* s, int32_t cp) {
+  if (s->lit >= 0) return cp == s->lit;
+  int in = cp < 128 && (s->ascii[cp >> 3] & (1 << (cp & 7)));
+  return s->neg ? !in : in;
+}
+/* 1 / 0: the text (bytes read through case map `sm`) does / does not contain a match; -1: pattern not taken */
+static int regex_search(const uint8_t* s, int sl, int sm, const uint8_t* pat, int pl) {
+  int at_start = pl > 0 && pat[0] == '^', at_end = 0;
+  const uint8_t* body = pat + at_start; int bl = pl - at_start;
+  if (bl > 0 && body[bl - 1] == '$') { int sl2 = 0; while (sl2 + 1 < bl && body[bl - 2 - sl2] == '\\') sl2++; if (sl2 % 2 == 0) { at_end = 1; bl--; } }
+  if (at_start || at_end) { /* an anchor next to a top-level '|' binds to one branch: not taken */
+    int depth = 0, in_class = 0;
+    for (int i = 0; i < bl; i++) {
+      int c = body[i];
+      if (c == '\\') { i++; continue; }
+      if (in_class) { if (c == ']') in_class = 0; continue; }
+      if (c == '[') { in_class = 1; if (i + 1 < bl && body[i + 1] == '^') i++; if (i + 1 < bl && body[i + 1] == ']') i++; }
+      else if (c == '(') depth++; else if (c == ')') depth--; else if (c == '|' && depth == 0) return -1;
+    }
+  }
+  rx_parser P; memset(&P, 0, sizeof P); P.p = body; P.n = bl;
+  rx_node* tree = rx_alt(&P);
+  int result = -1;
+  if (!P.bad && P.i == P.n) {
+    rx_prog g; memset(&g, 0, sizeof g);
+    rx_emit(&g, tree); rx_emit1(&g, 3, 0, 0, NULL);
+    int32_t* cps = (int32_t*)malloc(((size_t)sl + 1) * sizeof(int32_t)); int nc = 0;
+    for (int i = 0; i < sl;) {
+      int c = map_byte(s[i], sm), len = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : c >= 0xC2 ? 2 : 1;
+      if (i + len > sl) len = 1;
+      int32_t cp = len == 1 ? c : (c & (0xFF >> (len + 1)));
+      for (int k = 1; k < len; k++) cp = (cp << 6) | (s[i + k] & 0x3F);
+      cps[nc++] = cp; i += len;
+    }
+    int* cur = (int*)malloc((size_t)g.n * sizeof(int)); int* nxt = (int*)malloc((size_t)g.n * sizeof(int));
+    uint8_t* on = (uint8_t*)malloc((size_t)g.n);
+    int ncur = 0; result = 0;
+    for (int i = 0; i <= nc && !result; i++) {
+      if (!at_start || i == 0) { memset(on, 0, (size_t)g.n); for (int k = 0; k < ncur; k++) on[cur[k]] = 1; rx_add_thread(&g, cur, &ncur, on, 0); }
+      int nn = 0; memset(on, 0, (size_t)g.n);
+      for (int k = 0; k < ncur; k++) {
+        const rx_inst* in = &g.code[cur[k]];
+        if (in->op == 3) { if (!at_end || i == nc) result = 1; }
+        else if (i < nc && rx_set_has(in->set, cps[i])) rx_add_thread(&g, nxt, &nn, on, cur[k] + 1);
+      }
+      int* tswap = cur; cur = nxt; nxt = tswap; ncur = nn;
+    }
+    free(cur); free(nxt); free(on); free(cps); free(g.code);
+  }
+  for (int k = 0; k < P.npool; k++) free(P.pool[k]);
+  return result;
+}
 /* SQL LIKE by dynamic programming over (pattern tokens) x (characters): independent of the
  * device library's two-cursor matcher.  '%' any run, '_' one UTF-8 character, esc optional. */
 static int like_match(const uint8_t* s, int sl, int smap, const uint8_t* pat, int pl, int esc) {
@@ -968,17 +1169,9 @@ static void eval_function(const node* n, ctx* c, int64_t row0, int cnt, const ui
         int esc = n->nargs == 3 ? a[2].sp[i][0] : -1;
         out->v[i].i = like_match(x, xl, xm, y, yl, esc);
       } else if (!strcmp(f, "regexp_like") || !strcmp(f, "regexp_matches")) {
-        /* [recalled: RE2::PartialMatch(text, pattern)] in the LITERAL SUBSET the backend takes: pattern = [^]lit[$],
-         * lit free of metacharacters -> contains / starts with / ends with / equals.  Anything else: error 4. */
-        int head = yl > 0 && y[0] == '^', tail = yl > head && y[yl - 1] == '$';
-        const uint8_t* lit = y + head; int ll = yl - head - tail, plain = ll > 0;
-        for (int k = 0; k < ll; k++) plain = plain && strchr("\\^$.|?*+()[]{}%_", lit[k]) == NULL && lit[k] != 0;
-        if (!plain) { if (out->valid[i]) c->err |= 4; out->v[i].i = 0; continue; }
-        int hit = 0;
-        if (head && tail) hit = xl == ll && str_cmp(x, xl, xm, lit, ll, ym) == 0;
-        else if (head) hit = ll <= xl && str_cmp(x, ll, xm, lit, ll, ym) == 0;
-        else if (tail) hit = ll <= xl && str_cmp(x + (xl - ll), ll, xm, lit, ll, ym) == 0;
-        else for (int k = 0; k + ll <= xl && !hit; k++) hit = str_cmp(x + k, ll, xm, lit, ll, ym) == 0;
+        /* [recalled: RE2::PartialMatch(text, pattern)]: regex_search above; a pattern outside the syntax the backend takes: error 4 */
+        int hit = regex_search(x, xl, xm, y, yl);
+        if (hit < 0) { if (out->valid[i]) c->err |= 4; out->v[i].i = 0; continue; }
         out->v[i].i = hit;
       } else if (!strcmp(f, "ilike")) {
         /* like, ASCII letters compared without regard to case (recollection: the lineage folds through

@@ -327,6 +327,15 @@ long host_pad_row(int right, const int* off0, const unsigned char* d0, long s0, 
   *err_out = (int)err;
   return at;
 }
+// regexp_like (round 5): `table` = what gdv_compile_regex lays out; map 1 = the text read through upper()
+void host_regex_search(const int* off, const unsigned char* data, long size, long n, const unsigned char* table, int map, unsigned char* out) {
+  HostCol c{off, data, size};
+  for (long i = 0; i < n; i++) {
+    gdv_str s = host_row(c, i);
+    if (map == 1) s = upper_utf8(s);
+    out[i] = gdv_regex_search(s, table) ? 1 : 0;
+  }
+}
 // lpad (right = 0) / rpad (right = 1): `tab` is the fill repeated to `want` characters, readable
 // 8 bytes past its end (what the planner lays out in the constant block)
 long host_str_pad(int right, const int* off, const unsigned char* data, long size, long n, int want,

@@ -354,18 +354,18 @@ def test_regexps_beyond_the_literal_subset_are_refused_not_guessed(monkeypatch, 
     assert "regexp_" not in text.split("#include")[1]        # nothing of the regexp names is left below the @expr header
     assert "gdv_like" in text or "gdv_range_any" in text
     from gandiva_amd import _capi, gandiva as gg
+    # (regexp_like / regexp_matches take general patterns since late round 5 — further down; regexp_replace still does not)
     for pat in REGEX_REFUSED:
-        for fn, extra, t in (("regexp_like", [], pa.bool_()), ("regexp_replace", [b.make_literal("z", STR)], STR)):
-            e = b.make_expression(b.make_function(fn, [s, b.make_literal(pat, STR)] + extra, t), pa.field("r", t))
-            sh = gg._make_schema(batch.schema)
-            try:
-                arr = (C.c_void_p * 1)(e._h)
-                assert _capi.lib().gdv_precompile_projector(sh, arr, 1, 0) == 40, (fn, pat, _capi.last_error())
-                assert "literal subset" in _capi.last_error()
-            finally:
-                _capi.lib().gdv_schema_free(sh)
-            with pytest.raises(Exception):
-                oracle.project([e], batch)
+        e = b.make_expression(b.make_function("regexp_replace", [s, b.make_literal(pat, STR), b.make_literal("z", STR)], STR), pa.field("r", STR))
+        sh = gg._make_schema(batch.schema)
+        try:
+            arr = (C.c_void_p * 1)(e._h)
+            assert _capi.lib().gdv_precompile_projector(sh, arr, 1, 0) == 40, (pat, _capi.last_error())
+            assert "regexp_replace with a literal pattern" in _capi.last_error()
+        finally:
+            _capi.lib().gdv_schema_free(sh)
+        with pytest.raises(Exception):
+            oracle.project([e], batch)
     e = b.make_expression(b.make_function("regexp_replace", [s, b.make_literal("a", STR), b.make_literal("\\1", STR)], STR), pa.field("r", STR))
     with pytest.raises(Exception):
         oracle.project([e], batch)
@@ -626,6 +626,7 @@ def test_text_of_a_real_feeds_concat_other_functions_and_selection_mode():
 #   engine 2 (device library, host build and GPU): its own interpreter of the planner's compiled pattern
 #   engine 3 (here): Python's datetime.strptime on well-formed texts
 import datetime  # noqa: E402
+from gandiva_amd import _capi as gandiva_capi  # noqa: E402
 
 DATE_PATTERNS = [("YYYY-MM-DD", "%Y-%m-%d"), ("YYYY-MM-DD HH24:MI:SS", "%Y-%m-%d %H:%M:%S"), ("DD/MM/YYYY", "%d/%m/%Y"), ("MON DD, YYYY", "%b %d, %Y"),
                  ("DD MONTH YYYY", "%d %B %Y"), ("yyyymmdd", "%Y%m%d"), ("DY, DD MON YY HH12:MI:SS AM", "%a, %d %b %y %I:%M:%S %p"), ("YYYY.DDD", "%Y.%j"),
@@ -722,7 +723,11 @@ def test_device_to_date_interpreter_on_the_host_agrees_with_strptime_on_mutated_
     off = np.frombuffer(arr.buffers()[1], np.int32)[: len(texts) + 1].copy()
     size = int(off[-1])
     data = np.concatenate([np.frombuffer(arr.buffers()[2], np.uint8)[:size], np.zeros(64, np.uint8)])
-    ops = np.frombuffer(_compile_date_pattern(pattern) + b"\0" * 8, np.uint8).copy()
+    # the planner's own compiler (gdv_compile_date_format) — and this file's restatement of it agrees
+    raw, buf, cnt = pattern.encode(), np.zeros(256, np.uint8), C.c_int64(0)
+    assert gandiva_capi.lib().gdv_compile_date_format(raw, len(raw), buf.ctypes.data_as(C.c_void_p), 248, C.byref(cnt)) == 0
+    assert bytes(buf[:cnt.value]) == _compile_date_pattern(pattern)
+    ops = buf[:cnt.value + 8].copy()
     out, ov = np.zeros(len(texts), np.int64), np.zeros(len(texts), np.uint8)
     p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     assert hostlib.host_parse_date(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(ops), len(ops) - 8, 1, p(out), p(ov)) == 0
@@ -908,3 +913,129 @@ def test_replace_and_pad_with_per_row_arguments_on_the_gpu(n):
     rows = sel.to_array().to_numpy()
     for g, w in zip(got, oracle.project(e2, batch)):
         assert g.to_pylist() == [w[int(i)].as_py() for i in rows]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5, late: regexp_like / regexp_matches beyond the literal subset.
+#   engine 1 (oracle): Thompson program over code points, thread list
+#   engine 2 (device library, host build and GPU): byte-level position automaton compiled by the planner (gdv_compile_regex)
+#   engine 3 (here): Python's re (ASCII classes; '$' written as \Z: Python's own '$' also matches before a final newline)
+REGEX_PATTERNS = [r"\d+", r"^a.*3$", r"a.b", r"^$", r"[^a-z]+", r"(foo|bar)\.ba?r", r"x(yz)+y", r"é{2}", r"^\d{4}-\d{2}-\d{2}$", r"a{2,3}", r"日.語",
+                  r"^(ab|abc)$", r"\w+\s\w+", r"[\d.]+$", r"z*", r"sp.rk\d?", r"^[A-Z][a-z]+$", r"(a|b)*c", r"\S+@\S+\.com", r"[^\d\s]{3,}", r"^.{3}$",
+                  r"colou?r", r"\W", r"^\D*$", r"(?:ab){2,}", r"a+?b", r"[a-c-]+x", r"[]x]+y", r"\x41\x2e", r"^(\d+|[a-f]+)(\.\d*)?$", r".\n.", r"é+$"]
+REGEX_WORDS = ["ab", "abc", "a", "3", "2021-03-04", "foo.bar", "bar.br", "xyzyzy", "é", "éé", "日本語", "日x語", " ", "\n", "spark", "sperk7", "Color", "colour",
+               "x@y.com", "A.", "-", "]", "c", "zz", "Hello", "0.5", "ff.", "aab", "b-a-x", "]]xy", "\t"]
+
+
+def _regex_texts(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(0, 4))
+        out.append("".join(REGEX_WORDS[int(rng.integers(0, len(REGEX_WORDS)))] for _ in range(k)))
+    return out
+
+
+def _py_regex(p):
+    body = p[:-1] + r"\Z" if p.endswith("$") and not p.endswith(r"\$") else p
+    return re.compile(body, re.ASCII)
+
+
+def _regex_expr(b, s, p, name="regexp_like"):
+    return b.make_expression(b.make_function(name, [s, b.make_literal(p, STR)], pa.bool_()), pa.field("m", pa.bool_()))
+
+
+def test_oracle_regular_expressions_match_pythons_re():
+    texts = _regex_texts(1500, seed=4) + REGEX_WORDS
+    batch = pa.RecordBatch.from_arrays([pa.array(texts + [None], STR)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    for p in REGEX_PATTERNS:
+        rx = _py_regex(p)
+        got = oracle.project([_regex_expr(b, s, p)], batch)[0].to_pylist()
+        assert got == [rx.search(t) is not None for t in texts] + [None], p
+
+
+def test_device_regular_expressions_on_the_host_match_pythons_re(hostlib):  # noqa: F811
+    texts = _regex_texts(4000, seed=6) + REGEX_WORDS
+    arr = pa.array(texts, STR)
+    off = np.frombuffer(arr.buffers()[1], np.int32)[: len(texts) + 1].copy()
+    size = int(off[-1])
+    data = np.concatenate([np.frombuffer(arr.buffers()[2], np.uint8)[:size], np.zeros(64, np.uint8)])
+    lib = gandiva._capi.lib() if hasattr(gandiva, "_capi") else __import__("gandiva_amd._capi", fromlist=["lib"]).lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for pat in REGEX_PATTERNS:
+        table = np.zeros(2584 + 8, np.uint8)
+        raw = pat.encode()
+        assert lib.gdv_compile_regex(raw, C.c_int64(len(raw)), p(table)) == 0, pat
+        for mp in (0, 1):
+            out = np.zeros(len(texts), np.uint8)
+            hostlib.host_regex_search(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(table), mp, p(out))
+            rx = _py_regex(pat)
+            up = (lambda t: "".join(c.upper() if "a" <= c <= "z" else c for c in t)) if mp else (lambda t: t)
+            assert out.astype(bool).tolist() == [rx.search(up(t)) is not None for t in texts], (pat, mp)
+
+
+def test_regular_expressions_outside_the_syntax_are_refused_with_a_reason():
+    lib = __import__("gandiva_amd._capi", fromlist=["lib", "last_error"])
+    table = np.zeros(2592, np.uint8)
+    for pat, why in ((r"(a)\1", "escape"), (r"\bword", "escape"), (r"(?i)abc", "group flags"), (r"a^b", "anchor"), (r"^a|b", "top-level"),
+                     (r"[é]", "non-ASCII"), (r"(ab", "unmatched"), (r"a{3,2}", "n < m"), (r"(abcdefgh){9}", "63"), (r"a*+", "possessive"),
+                     (r"(?=x)", "look-around"), (r"[[:alpha:]]", "POSIX")):
+        raw = pat.encode()
+        assert lib.lib().gdv_compile_regex(raw, C.c_int64(len(raw)), table.ctypes.data_as(C.c_void_p)) != 0, pat
+        assert why in lib.last_error(), (pat, lib.last_error())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 3000])
+def test_regular_expressions_on_the_gpu(n):
+    texts = (_regex_texts(n, seed=n) + REGEX_WORDS)[:max(n, 1)]
+    batch = pa.RecordBatch.from_arrays([pa.array(texts, STR, mask=np.random.default_rng(n).random(len(texts)) < 0.1)], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    for lo in range(0, len(REGEX_PATTERNS), 8):
+        e = [_regex_expr(b, s, p, "regexp_like" if j % 2 else "regexp_matches") for j, p in enumerate(REGEX_PATTERNS[lo:lo + 8])]
+        got = gandiva.make_projector(batch.schema, e, None).evaluate(batch)
+        for g, w, p in zip(got, oracle.project(e, batch), REGEX_PATTERNS[lo:lo + 8]):
+            assert_bit_exact(g, w, p)
+    # as a filter condition, and over upper(s)
+    cond = b.make_condition(b.make_function("regexp_like", [b.make_function("upper", [s], STR), b.make_literal(r"^[A-Z]+\d*$", STR)], pa.bool_()))
+    sel = gandiva.make_filter(batch.schema, cond).evaluate(batch).to_array().to_pylist()
+    rx = re.compile(r"^[A-Z]+\d*\Z", re.ASCII)
+    assert sel == [i for i, t in enumerate(batch.column(0).to_pylist()) if t is not None and rx.search(t.upper() if t.isascii() else "".join(c.upper() if "a" <= c <= "z" else c for c in t))]
+
+
+def test_random_patterns_three_engines_agree(hostlib):  # noqa: F811
+    """patterns drawn from a small grammar (atoms x quantifiers, anchors, a top-level alternation): the oracle's thread list, the
+    device library's position automaton (host build) and Python's re give the same answer on every text"""
+    lib = __import__("gandiva_amd._capi", fromlist=["lib"]).lib()
+    rng = np.random.default_rng(3)
+    atoms = ["a", "b", "c", ".", "\\d", "\\w", "\\s", "[ab]", "[^a]", "[a-c]", "é", "x", "\\.", "(ab|c)", "(a|b)", "(?:bc)"]
+    quants = ["", "", "", "*", "+", "?", "{2}", "{1,3}", "{2,}", "*?"]
+    texts = _regex_texts(500, seed=9) + REGEX_WORDS + ["abcabc", "aab", "ccc", "a.c", "bcbc", "é.é"]
+    arr = pa.array(texts, STR)
+    off = np.frombuffer(arr.buffers()[1], np.int32)[: len(texts) + 1].copy()
+    size = int(off[-1])
+    data = np.concatenate([np.frombuffer(arr.buffers()[2], np.uint8)[:size], np.zeros(64, np.uint8)])
+    batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    tried = 0
+    for _ in range(160):
+        k = int(rng.integers(1, 5))
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] + quants[int(rng.integers(0, len(quants)))] for _ in range(k))
+        pat = ("^" if rng.random() < 0.3 else "") + pat + ("$" if rng.random() < 0.3 else "")
+        if rng.random() < 0.2:
+            pat = "(" + pat.strip("^$") + ")|zz"
+        raw, table = pat.encode(), np.zeros(2592, np.uint8)
+        if lib.gdv_compile_regex(raw, C.c_int64(len(raw)), p(table)) != 0:
+            continue   # (more than 63 positions)
+        tried += 1
+        out = np.zeros(len(texts), np.uint8)
+        hostlib.host_regex_search(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(table), 0, p(out))
+        want = [_py_regex(pat).search(t) is not None for t in texts]
+        assert out.astype(bool).tolist() == want, pat
+        assert oracle.project([_regex_expr(b, s, pat)], batch)[0].to_pylist() == want, pat
+    assert tried > 100
