@@ -1182,13 +1182,12 @@ Status Projector::EvaluateAsync(int64_t num_rows, const ColumnBuffers* cols, int
   return EvaluateAsyncStage(num_rows, cols, num_cols, sel, outs, num_outs, stream, result, nullptr);
 }
 
-// Both stages of a two-stage plan on the stream, a gate kernel between them (gdv_kernels.h: StageGate).
+// The stages of a staged plan on the stream, a gate kernel between each two (gdv_kernels.h: StageGate).
 Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* cols, int num_cols, const SelectionView* sel,
                                         OutputBuffers* outs, int num_outs, hipStream_t stream, void* result) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
   if (outs == nullptr || result == nullptr) return Status::Invalid("Output array vector and result block cannot be null");
   if (num_outs != num_outputs()) return Status::Invalid("number of output buffers does not match the number of expressions");
-  if (pre_->pre_ != nullptr) return Status::Invalid("plans with more than two stages are evaluated synchronously");
   if (num_cols != static_cast<int>(schema_.size()))
     return Status::Invalid("number of columns in batch (" + std::to_string(num_cols) +
                            ") does not match the schema (" + std::to_string(schema_.size()) + ")");
@@ -1243,7 +1242,12 @@ Status Projector::EvaluateAsyncTwoStage(int64_t num_rows, const ColumnBuffers* c
   int64_t* const rows_word = reinterpret_cast<int64_t*>(gate.as<char>() + 128);
   uint64_t* const status_word = reinterpret_cast<uint64_t*>(gate.as<char>() + 136);
   drain.armed = true;
-  GDV_RETURN_NOT_OK(pre_->EvaluateAsyncStage(num_rows, cols, num_cols, sel, po.data(), np, stream, stage_result, nullptr));
+  // (a first stage that is itself staged — upper(reverse(replace(..))) — goes through this function again: its result block,
+  // status and byte totals, is what the gate reads either way; round 5: three and more stages were synchronous only)
+  if (pre_->pre_ != nullptr)
+    GDV_RETURN_NOT_OK(pre_->EvaluateAsyncTwoStage(num_rows, cols, num_cols, sel, po.data(), np, stream, stage_result));
+  else
+    GDV_RETURN_NOT_OK(pre_->EvaluateAsyncStage(num_rows, cols, num_cols, sel, po.data(), np, stream, stage_result, nullptr));
   GDV_HIP_RETURN_NOT_OK(LaunchStageGate(stage_result, np, caps, has_sel ? static_cast<const int64_t*>(sel->num_slots_device) : nullptr,
                                         stage_rows, rows_word, status_word, stream));
   if (plan_.num_varlen_outputs > 0) {

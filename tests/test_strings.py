@@ -839,6 +839,43 @@ def test_two_stage_plans_evaluate_without_a_host_synchronisation():
 
 
 @pytest.mark.gpu
+def test_plans_of_three_stages_evaluate_without_a_host_synchronisation():
+    """upper(reverse(replace(s, 'a', 'bb'))): the replace is materialised for the reverse, the reverse for the upper — three
+    stages, two gates.  Rounds 3-4 evaluated such plans synchronously only; the staged asynchronous call now nests."""
+    import torch
+    n = 30_011
+    batch = W.c5_batch(n, 0.1)
+    b = gandiva.TreeExprBuilder()
+    fs = b.make_field(batch.schema.field(0))
+    S = pa.string()
+    rep = b.make_function("replace", [fs, b.make_literal("a", S), b.make_literal("bb", S)], S)
+    rev = b.make_function("reverse", [rep], S)
+    exprs = [b.make_expression(b.make_function("upper", [rev], S), pa.field("u", S)),
+             b.make_expression(b.make_function("length", [rev], pa.int32()), pa.field("n", pa.int32())),
+             b.make_expression(b.make_function("substr", [rep, b.make_literal(2, pa.int64()), b.make_literal(3, pa.int64())], S), pa.field("p", S))]
+    proj = gandiva.make_projector(batch.schema, exprs, None)
+    db = gandiva.DeviceBatch.from_arrow(batch)
+    want = oracle.project(exprs, batch)
+    outs, result = proj.evaluate_device_async(db, capacity_bytes=4 << 20)
+    torch.cuda.synchronize()
+    assert int(result[0]) == 0
+    for i, (o, w) in enumerate(zip(outs, want)):
+        assert_bit_exact(o.to_arrow(), w, f"asynchronous, three stages, output {i}")
+    for g, w in zip(proj.evaluate_device(db), want):
+        assert_bit_exact(g.to_arrow(), w, "synchronous, three stages")
+    # behind an asynchronous filter (the count stays in device memory through both gates)
+    cond = b.make_condition(b.make_function("like", [fs, b.make_literal("%a%", S)], pa.bool_()))
+    flt = gandiva.make_filter(batch.schema, cond)
+    sproj = gandiva.make_projector(batch.schema, exprs[:1], None, "UINT32")
+    sel = flt.evaluate_device(db, "int32", sync=False)
+    outs, result = sproj.evaluate_device_async(db, selection=sel)
+    torch.cuda.synchronize()
+    want_sel = oracle.filter_indices(cond, batch, "int32")
+    assert sel.to_array().equals(want_sel) and int(result[0]) == 0
+    assert_bit_exact(outs[0].to_arrow(), oracle.project(exprs[:1], oracle.take_rows(batch, want_sel.to_numpy()))[0], "filter -> three stages, asynchronous")
+
+
+@pytest.mark.gpu
 def test_filter_then_a_two_stage_projection_without_a_host_round_trip():
     import torch
     n = 90_001
