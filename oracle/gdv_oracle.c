@@ -89,12 +89,15 @@
  *       - to_date(text, 'pattern'[, suppress_errors]): the pattern-to-strptime token table, "time of day parsed and dropped",
  *         "trailing characters allowed", "day defaults to 1", "an unparsable text raises unless suppress_errors = 1 (then
  *         null)" are recollection; the parsing itself is THE C LIBRARY'S strptime (what the lineage calls), so the device
- *         library's own interpreter is held to glibc on every tested text.  to_timestamp / to_time over numbers:
+ *         library's own interpreter is held to glibc on every tested text, and the oracle to Arrow's strptime kernel
+ *         (pyarrow.compute.strptime) on well-formed texts.  to_timestamp / to_time over numbers:
  *         (int64)(seconds * 1000) [% 86400000] — recollection.
  *       - regexp_like / regexp_matches: the lineage runs RE2::PartialMatch.  Here: a Thompson program over code points run as a
  *         thread list, for the syntax gandiva_amd/csrc/gdv_regex.h lists (no back-references, \b, look-around, flags, inner
- *         anchors); '.' excludes the newline and '$' means the end of the text (RE2's defaults, as recalled) — checked
- *         against Python's re on patterns and texts where Python's rules coincide.  regexp_replace: the lineage runs
+ *         anchors); '.' excludes the newline and '$' means the end of the text — checked against RE2 ITSELF (pyarrow.compute's
+ *         match_substring_regex: the RE2 linked into this image's libarrow, PartialMatch with default options) and against
+ *         Python's re, fixed and random patterns (tests/test_registry_tail.py).  That the lineage's holder uses default
+ *         options is the recollection.  regexp_replace: the lineage runs
  *         RE2::GlobalReplace; only the LITERAL SUBSET exists (a metacharacter-free pattern, a replacement without
  *         backslashes: left-to-right non-overlapping replace), with replace's 65535-byte result cap (RE2 has none).
  *

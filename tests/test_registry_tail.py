@@ -703,6 +703,9 @@ def test_oracle_to_date_is_strptime_and_agrees_with_pythons_on_well_formed_texts
     s = b.make_field(batch.schema.field(0))
     got = oracle.project([_to_date_exprs(b, s, pattern, None)], batch)[0]
     assert got.to_pylist() == [w.date() for w in want] + [None], pattern
+    # ... and Arrow's own strptime kernel (the primitive the lineage's holder calls; it keeps the time of day: cut to the date here)
+    arrow = pc.strptime(batch.column(0), format=pyfmt, unit="s", error_is_null=True).cast(pa.int64())
+    assert [None if v is None else (v // 86400) * 86400000 for v in arrow.to_pylist()] == got.cast(pa.int64()).to_pylist(), pattern
     # texts that do not parse: null with suppress_errors = 1, an error without
     bad = pa.RecordBatch.from_arrays([pa.array(["not a date", texts[0], ""], STR)], names=["s"])
     got = oracle.project([_to_date_exprs(b, s, pattern, 1)], bad)[0].to_pylist()
@@ -954,6 +957,8 @@ def test_oracle_regular_expressions_match_pythons_re():
         rx = _py_regex(p)
         got = oracle.project([_regex_expr(b, s, p)], batch)[0].to_pylist()
         assert got == [rx.search(t) is not None for t in texts] + [None], p
+        # ... and RE2 itself — the lineage's engine, as linked into the libarrow of this image (PartialMatch, default options)
+        assert got == pc.match_substring_regex(batch.column(0), p).to_pylist(), p
 
 
 def test_device_regular_expressions_on_the_host_match_pythons_re(hostlib):  # noqa: F811
@@ -1036,6 +1041,7 @@ def test_random_patterns_three_engines_agree(hostlib):  # noqa: F811
         out = np.zeros(len(texts), np.uint8)
         hostlib.host_regex_search(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(table), 0, p(out))
         want = [_py_regex(pat).search(t) is not None for t in texts]
+        assert want == pc.match_substring_regex(arr, pat).to_pylist(), pat      # RE2 (libarrow) agrees with Python's re here
         assert out.astype(bool).tolist() == want, pat
         assert oracle.project([_regex_expr(b, s, pat)], batch)[0].to_pylist() == want, pat
     assert tried > 100
