@@ -48,6 +48,43 @@ def round5_expressions(seed):
     return exprs, g.b.make_condition(g.boolean(3))
 
 
+class LateGen(Round5Gen):
+    """late round 5: general regular expressions, to_date, castVARCHAR(float), replace / lpad / rpad with per-row arguments"""
+    REGEX = [r"sp.rk", r"\d+", r"^[a-z]+$", r"(ab|sp)+", r"[^a-z ]", r"a.*k$", r"é+", r"\w+\s\w+", r"^.{0,3}$", r"(?:ar|XY){1,2}", r"_%?"]
+
+    def string(self, depth):
+        b, r = self.b, self.rng
+        if depth > 0 and r.random() < 0.35:
+            roll = r.random()
+            if roll < 0.25:
+                return b.make_function("replace", [self.string(depth - 1), super().string(0), self.pick([b.make_literal("-", STR), super().string(0)])], STR)
+            if roll < 0.5:
+                return b.make_function(self.pick(["lpad", "rpad"]), [super().string(depth - 1), b.make_function("castINT", [self.f["k"]], I32), super().string(0)], STR)
+            if roll < 0.75:
+                x = b.make_function("divide", [b.make_function("castFLOAT8", [self.f["k"]], pa.float64()), b.make_literal(self.pick([3.0, 7.0, 1e-9, 1e9]), pa.float64())], pa.float64())
+                return b.make_function("castVARCHAR", [x, b.make_literal(int(r.integers(0, 26)), I64)], STR)
+            return b.make_function("castVARCHAR", [b.make_function("castFLOAT4", [self.f["k"]], pa.float32()), b.make_literal(30, I64)], STR)
+        return super().string(depth)
+
+    def boolean(self, depth):
+        b, r = self.b, self.rng
+        if depth > 0 and r.random() < 0.3:
+            roll = r.random()
+            if roll < 0.7:
+                return b.make_function(self.pick(["regexp_like", "regexp_matches"]), [Round5Gen.string(self, depth - 1) if r.random() < 0.5 else self.f["s"],
+                                                                                    b.make_literal(self.pick(self.REGEX), STR)], BOOL)
+            d = b.make_function("to_date", [self.f["t"], b.make_literal(self.pick(["YYYY-MM-DD", "DD MON YY", "YYYY/MM/DD HH24"]), STR), b.make_literal(1, I32)], pa.date64())
+            return b.make_function("isnull", [d], BOOL)
+        return super().boolean(depth)
+
+
+def late_expressions(seed):
+    g = LateGen(F._string_batch(0, 1).schema, 9000 + seed)
+    exprs = [g.b.make_expression(g.string(3), pa.field("s0", STR)), g.b.make_expression(g.boolean(3), pa.field("b0", BOOL)),
+             g.b.make_expression(g.string(2), pa.field("s1", STR)), g.b.make_expression(g.boolean(2), pa.field("b1", BOOL))]
+    return exprs, g.b.make_condition(g.boolean(3))
+
+
 def check(tag, exprs, cond, batch):
     want = oracle.project(exprs, batch)
     got = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
@@ -71,7 +108,8 @@ plans = failures = 0
 for seed in range(first, first + count):
     n = sizes[seed % len(sizes)]
     batch = F._string_batch(seed, n)
-    for name, maker in (("string", F._string_expressions), ("tail", F._tail_expressions), ("round5", round5_expressions)):
+    makers = (("string", F._string_expressions), ("tail", F._tail_expressions), ("round5", round5_expressions), ("late", late_expressions))
+    for name, maker in [m for m in makers if not os.environ.get("FUZZ_ONLY") or m[0] == os.environ["FUZZ_ONLY"]]:
         try:
             exprs, cond = maker(seed)
             check(f"{name} seed {seed} n {n}", exprs, cond, batch)
