@@ -66,9 +66,16 @@ ByteSet Spaces() {
   return s;
 }
 
+// (?i): a set that holds an ASCII letter holds it in both cases
+ByteSet FoldCase(ByteSet s) {
+  for (int c = 'a'; c <= 'z'; c++)
+    if (s.test(static_cast<size_t>(c)) || s.test(static_cast<size_t>(c - 32))) { s.set(static_cast<size_t>(c)); s.set(static_cast<size_t>(c - 32)); }
+  return s;
+}
+
 class Parser {
  public:
-  explicit Parser(const std::string& p) : p_(p) {}
+  Parser(const std::string& p, bool fold) : p_(p), fold_(fold) {}
   Status Parse(ReP* out) {
     GDV_RETURN_NOT_OK(Alt(out));
     if (i_ < p_.size()) return Bad(p_[i_] == ')' ? "unmatched ')'" : "unexpected character");
@@ -192,11 +199,21 @@ class Parser {
     bool negate = false;
     if (More() && p_[i_] == '^') { negate = true; i_++; }
     ByteSet set;
+    std::vector<std::string> extras;  // non-ASCII members: whole characters, as alternatives next to the byte set
     bool first = true;
     for (;; first = false) {
       if (!More()) return Bad("unterminated character class");
       unsigned char c = static_cast<unsigned char>(p_[i_]);
       if (c == ']' && !first) { i_++; break; }
+      if (c >= 0xC2) {  // a non-ASCII character: a member of its own (not an end of a range)
+        size_t j = i_ + 1;
+        while (j < p_.size() && (static_cast<unsigned char>(p_[j]) & 0xC0) == 0x80) j++;
+        if (j < p_.size() && p_[j] == '-' && j + 1 < p_.size() && p_[j + 1] != ']') return Bad("character range with a non-ASCII end");
+        if (fold_) return Bad("(?i) with a non-ASCII character");
+        extras.push_back(p_.substr(i_, j - i_));
+        i_ = j;
+        continue;
+      }
       if (c == '[' && i_ + 1 < p_.size() && p_[i_ + 1] == ':') return Bad("POSIX character class");
       ByteSet one;
       bool single = true;
@@ -229,8 +246,19 @@ class Parser {
       }
       set |= one;
     }
-    if (negate) *out = WholeCharacter(AnyLead() & ~set);
-    else *out = MkSet(set);
+    if (fold_) set = FoldCase(set);
+    if (negate) {
+      if (!extras.empty()) return Bad("negated character class with non-ASCII members");
+      *out = WholeCharacter(AnyLead() & ~set);
+      return Status::OK();
+    }
+    ReP all = set.any() || extras.empty() ? MkSet(set) : nullptr;
+    for (const std::string& x : extras) {
+      ReP seq;
+      for (unsigned char k : x) seq = seq ? Mk(Re::kCat, std::move(seq), MkSet(Range(k, k))) : MkSet(Range(k, k));
+      all = all ? Mk(Re::kAlt, std::move(all), std::move(seq)) : std::move(seq);
+    }
+    *out = std::move(all);
     return Status::OK();
   }
   Status Atom(ReP* out) {
@@ -262,6 +290,7 @@ class Parser {
         ByteSet set;
         negated_escape_ = false;
         GDV_RETURN_NOT_OK(Escape(&set));
+        if (fold_) set = negated_escape_ ? ~FoldCase(~set) : FoldCase(set);
         *out = negated_escape_ ? WholeCharacter(AnyLead() & set) : MkSet(set);
         return Status::OK();
       }
@@ -275,7 +304,8 @@ class Parser {
         return Bad("quantifier with nothing to repeat");
       default: {
         i_++;
-        ReP atom = MkSet(Range(c, c));
+        if (fold_ && c >= 0x80) return Bad("(?i) with a non-ASCII character");
+        ReP atom = MkSet(fold_ ? FoldCase(Range(c, c)) : Range(c, c));
         // a non-ASCII character of the pattern is ONE atom (a quantifier behind it repeats the character): its lead byte
         // and the continuation bytes that follow, one position each
         if (c >= 0xC2)
@@ -292,6 +322,7 @@ class Parser {
   const std::string& p_;
   size_t i_ = 0;
   bool negated_escape_ = false;
+  bool fold_ = false;  // (?i): ASCII letters match in either case
 };
 
 struct Glushkov {
@@ -346,6 +377,11 @@ Status CompileRegex(const std::string& pattern, std::string* table) {
   // the two anchors the backend takes: '^' first, '$' last (not escaped)
   std::string body = pattern;
   uint64_t flags = 0;
+  bool fold = false;
+  if (body.compare(0, 4, "(?i)") == 0) {  // the one flag taken, and only in front: ASCII letters in either case
+    fold = true;
+    body.erase(0, 4);
+  }
   if (!body.empty() && body.front() == '^') {
     flags |= 2;
     body.erase(0, 1);
@@ -375,7 +411,7 @@ Status CompileRegex(const std::string& pattern, std::string* table) {
     }
   }
   ReP tree;
-  Parser parser(body);
+  Parser parser(body, fold);
   Status st = parser.Parse(&tree);
   if (!st.ok()) {  // (messages quote the pattern as the caller wrote it)
     const std::string quoted = "'" + body + "'";

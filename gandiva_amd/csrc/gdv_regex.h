@@ -9,9 +9,11 @@
 //
 // Syntax taken: literals, '.', classes [a-z0-9_] and [^...] (ASCII members), \d \D \w \W \s \S, \t \n \r \f \v \xHH and
 // escaped punctuation, groups ( ) and (?: ), alternation |, quantifiers * + ? {m} {m,} {m,n} (and their lazy forms), '^'
-// as the pattern's first and '$' as its last character.  '.' and negated classes consume a whole UTF-8 character (a lead
+// as the pattern's first and '$' as its last character, '(?i)' in front of everything (ASCII letters in either case), non-ASCII
+// characters as members of a positive class.  '.' and negated classes consume a whole UTF-8 character (a lead
 // byte and its continuation bytes); '.' does not match a newline (RE2's default).  Anything else — back-references, \b,
-// look-around, flags such as (?i), anchors inside the pattern, classes with non-ASCII members, more than 63 positions — is
+// look-around, other flags, anchors inside the pattern, non-ASCII range ends or negated classes with non-ASCII members, (?i) next to
+// non-ASCII characters, more than 63 positions — is
 // refused with a message, not guessed.
 #pragma once
 #include <string>

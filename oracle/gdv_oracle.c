@@ -560,8 +560,8 @@ static int str_cmp(const uint8_t* a, int al, int am, const uint8_t* b, int bl, i
  * parsed into a tree over CODE POINTS (the text is decoded from UTF-8 first), compiled to a Thompson program (char / split /
  * jump / match) and run as a thread list (Pike) — where the device library walks a byte-level position automaton.  The syntax
  * the HIP backend takes (gandiva_amd/csrc/gdv_regex.h); anything else returns -1 (the caller raises). */
-typedef struct rx_node { int kind; /* 0 empty 1 set 2 cat 3 alt 4 star 5 plus 6 opt */ uint8_t ascii[16]; int neg; int32_t lit; struct rx_node *a, *b; } rx_node;
-typedef struct { const uint8_t* p; int n, i, bad; rx_node* pool[4096]; int npool; } rx_parser;
+typedef struct rx_node { int kind; /* 0 empty 1 set 2 cat 3 alt 4 star 5 plus 6 opt */ uint8_t ascii[16]; int neg; int32_t lit; int32_t extra[8]; int nextra; struct rx_node *a, *b; } rx_node;
+typedef struct { const uint8_t* p; int n, i, bad, fold; rx_node* pool[4096]; int npool; } rx_parser;
 static rx_node* rx_new(rx_parser* P, int kind, rx_node* a, rx_node* b) {
   if (P->npool >= 4096) { P->bad = 1; return P->pool[0]; }
   rx_node* x = (rx_node*)calloc(1, sizeof(rx_node)); x->kind = kind; x->a = a; x->b = b; x->lit = -1; P->pool[P->npool++] = x; return x;
@@ -569,7 +569,7 @@ static rx_node* rx_new(rx_parser* P, int kind, rx_node* a, rx_node* b) {
 static rx_node* rx_clone(rx_parser* P, const rx_node* x) {
   if (!x) return NULL;
   rx_node* y = rx_new(P, x->kind, rx_clone(P, x->a), rx_clone(P, x->b));
-  memcpy(y->ascii, x->ascii, 16); y->neg = x->neg; y->lit = x->lit; return y;
+  memcpy(y->ascii, x->ascii, 16); y->neg = x->neg; y->lit = x->lit; memcpy(y->extra, x->extra, sizeof x->extra); y->nextra = x->nextra; return y;
 }
 static void rx_add(rx_node* x, int lo, int hi) { for (int c = lo; c <= hi; c++) x->ascii[c >> 3] |= (uint8_t)(1 << (c & 7)); }
 static rx_node* rx_alt(rx_parser* P);
@@ -607,6 +607,16 @@ static rx_node* rx_atom(rx_parser* P) {
       int m = P->p[P->i];
       if (m == ']' && !first) { P->i++; break; }
       if (m == '[' && P->i + 1 < P->n && P->p[P->i + 1] == ':') { P->bad = 1; return s; }
+      if (m >= 0xC2) { /* a non-ASCII member: one code point (not an end of a range, not under (?i), not in a negated class) */
+        int len = m >= 0xF0 ? 4 : m >= 0xE0 ? 3 : 2;
+        if (P->i + len > P->n || s->nextra >= 8 || P->fold) { P->bad = 1; return s; }
+        int32_t cp = m & (0xFF >> (len + 1));
+        for (int k = 1; k < len; k++) cp = (cp << 6) | (P->p[P->i + k] & 0x3F);
+        P->i += len;
+        if (P->i + 1 < P->n && P->p[P->i] == '-' && P->p[P->i + 1] != ']') { P->bad = 1; return s; }
+        s->extra[s->nextra++] = cp;
+        continue;
+      }
       P->i++;
       int lo = m, single = 1;
       if (m == '\\') {
@@ -629,6 +639,7 @@ static rx_node* rx_atom(rx_parser* P) {
         rx_add(s, lo, hi);
       } else rx_add(s, lo, lo);
     }
+    if (s->neg && s->nextra) P->bad = 1;
     return s;
   }
   if (c == '.') { P->i++; s->neg = 1; rx_add(s, 10, 10); return s; }
@@ -640,6 +651,7 @@ static rx_node* rx_atom(rx_parser* P) {
   if (c < 0xC2 || P->i + len > P->n) { P->bad = 1; return s; }
   int32_t cp = c & (0xFF >> (len + 1));
   for (int k = 1; k < len; k++) cp = (cp << 6) | (P->p[P->i + k] & 0x3F);
+  if (P->fold) P->bad = 1;
   P->i += len; s->lit = cp; return s;
 }
 static rx_node* rx_repeat(rx_parser* P) {
@@ -702,13 +714,17 @@ static void rx_add_thread(const rx_prog* g, int* list, int* n, uint8_t* on, int 
   else if (g->code[pc].op == 1) { rx_add_thread(g, list, n, on, g->code[pc].x); rx_add_thread(g, list, n, on, g->code[pc].y); }
   else list[(*n)++] = pc;
 }
-static int rx_set_has(const rx_node* s, int32_t cp) {
+static int rx_set_has(const rx_node* s, int32_t cp, int fold) {
   if (s->lit >= 0) return cp == s->lit;
   int in = cp < 128 && (s->ascii[cp >> 3] & (1 << (cp & 7)));
+  if (!in && fold && cp < 128 && isalpha(cp)) { int o = cp ^ 32; in = (s->ascii[o >> 3] & (1 << (o & 7))) != 0; }  /* (?i) */
+  for (int k = 0; k < s->nextra && !in; k++) in = cp == s->extra[k];
   return s->neg ? !in : in;
 }
 /* 1 / 0: the text (bytes read through case map `sm`) does / does not contain a match; -1: pattern not taken */
 static int regex_search(const uint8_t* s, int sl, int sm, const uint8_t* pat, int pl) {
+  int fold = pl >= 4 && !memcmp(pat, "(?i)", 4);   /* the one flag taken, in front only: ASCII letters in either case */
+  if (fold) { pat += 4; pl -= 4; }
   int at_start = pl > 0 && pat[0] == '^', at_end = 0;
   const uint8_t* body = pat + at_start; int bl = pl - at_start;
   if (bl > 0 && body[bl - 1] == '$') { int sl2 = 0; while (sl2 + 1 < bl && body[bl - 2 - sl2] == '\\') sl2++; if (sl2 % 2 == 0) { at_end = 1; bl--; } }
@@ -722,7 +738,7 @@ static int regex_search(const uint8_t* s, int sl, int sm, const uint8_t* pat, in
       else if (c == '(') depth++; else if (c == ')') depth--; else if (c == '|' && depth == 0) return -1;
     }
   }
-  rx_parser P; memset(&P, 0, sizeof P); P.p = body; P.n = bl;
+  rx_parser P; memset(&P, 0, sizeof P); P.p = body; P.n = bl; P.fold = fold;
   rx_node* tree = rx_alt(&P);
   int result = -1;
   if (!P.bad && P.i == P.n) {
@@ -745,7 +761,7 @@ static int regex_search(const uint8_t* s, int sl, int sm, const uint8_t* pat, in
       for (int k = 0; k < ncur; k++) {
         const rx_inst* in = &g.code[cur[k]];
         if (in->op == 3) { if (!at_end || i == nc) result = 1; }
-        else if (i < nc && rx_set_has(in->set, cps[i])) rx_add_thread(&g, nxt, &nn, on, cur[k] + 1);
+        else if (i < nc && rx_set_has(in->set, cps[i], fold)) rx_add_thread(&g, nxt, &nn, on, cur[k] + 1);
       }
       int* tswap = cur; cur = nxt; nxt = tswap; ncur = nn;
     }

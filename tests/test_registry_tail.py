@@ -925,7 +925,8 @@ def test_replace_and_pad_with_per_row_arguments_on_the_gpu(n):
 #   engine 3 (here): Python's re (ASCII classes; '$' written as \Z: Python's own '$' also matches before a final newline)
 REGEX_PATTERNS = [r"\d+", r"^a.*3$", r"a.b", r"^$", r"[^a-z]+", r"(foo|bar)\.ba?r", r"x(yz)+y", r"é{2}", r"^\d{4}-\d{2}-\d{2}$", r"a{2,3}", r"日.語",
                   r"^(ab|abc)$", r"\w+\s\w+", r"[\d.]+$", r"z*", r"sp.rk\d?", r"^[A-Z][a-z]+$", r"(a|b)*c", r"\S+@\S+\.com", r"[^\d\s]{3,}", r"^.{3}$",
-                  r"colou?r", r"\W", r"^\D*$", r"(?:ab){2,}", r"a+?b", r"[a-c-]+x", r"[]x]+y", r"\x41\x2e", r"^(\d+|[a-f]+)(\.\d*)?$", r".\n.", r"é+$"]
+                  r"colou?r", r"\W", r"^\D*$", r"(?:ab){2,}", r"a+?b", r"[a-c-]+x", r"[]x]+y", r"\x41\x2e", r"^(\d+|[a-f]+)(\.\d*)?$", r".\n.", r"é+$",
+                  r"(?i)spark", r"(?i)^[a-c]+\d?$", r"(?i)colou?r|HELLO", r"(?i)[^a]b", r"[é語x]+", r"^[日é][本é]", r"(?i)\W[A-Z]"]
 REGEX_WORDS = ["ab", "abc", "a", "3", "2021-03-04", "foo.bar", "bar.br", "xyzyzy", "é", "éé", "日本語", "日x語", " ", "\n", "spark", "sperk7", "Color", "colour",
                "x@y.com", "A.", "-", "]", "c", "zz", "Hello", "0.5", "ff.", "aab", "b-a-x", "]]xy", "\t"]
 
@@ -984,8 +985,8 @@ def test_device_regular_expressions_on_the_host_match_pythons_re(hostlib):  # no
 def test_regular_expressions_outside_the_syntax_are_refused_with_a_reason():
     lib = __import__("gandiva_amd._capi", fromlist=["lib", "last_error"])
     table = np.zeros(2592, np.uint8)
-    for pat, why in ((r"(a)\1", "escape"), (r"\bword", "escape"), (r"(?i)abc", "group flags"), (r"a^b", "anchor"), (r"^a|b", "top-level"),
-                     (r"[é]", "non-ASCII"), (r"(ab", "unmatched"), (r"a{3,2}", "n < m"), (r"(abcdefgh){9}", "63"), (r"a*+", "possessive"),
+    for pat, why in ((r"(a)\1", "escape"), (r"\bword", "escape"), (r"a^b", "anchor"), (r"^a|b", "top-level"),
+                     (r"[^é]", "non-ASCII"), (r"[à-ÿ]", "non-ASCII"), (r"(?i)é", "non-ASCII"), (r"(?s)a.b", "group flags"), (r"(ab", "unmatched"), (r"a{3,2}", "n < m"), (r"(abcdefgh){9}", "63"), (r"a*+", "possessive"),
                      (r"(?=x)", "look-around"), (r"[[:alpha:]]", "POSIX")):
         raw = pat.encode()
         assert lib.lib().gdv_compile_regex(raw, C.c_int64(len(raw)), table.ctypes.data_as(C.c_void_p)) != 0, pat
@@ -1034,6 +1035,8 @@ def test_random_patterns_three_engines_agree(hostlib):  # noqa: F811
         pat = ("^" if rng.random() < 0.3 else "") + pat + ("$" if rng.random() < 0.3 else "")
         if rng.random() < 0.2:
             pat = "(" + pat.strip("^$") + ")|zz"
+        if "é" not in pat and rng.random() < 0.25:
+            pat = "(?i)" + pat
         raw, table = pat.encode(), np.zeros(2592, np.uint8)
         if lib.gdv_compile_regex(raw, C.c_int64(len(raw)), p(table)) != 0:
             continue   # (more than 63 positions)
