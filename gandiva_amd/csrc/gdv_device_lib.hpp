@@ -2314,23 +2314,54 @@ GDV_DEV gdv_str castVARCHAR_float32_int64(gdv_ctx ctx, gdv_float32 v, gdv_int64 
                        (gdv_int32)(b >> 31), kind, n);
 }
 // ---- regexp_like / regexp_matches (round 5, late): does the text contain a match of the pattern?  The planner compiles the
-// pattern to a position automaton of at most 63 positions (gdv_regex.h): table = first, last, flags (1 nullable, 2 anchored at
-// the start, 4 at the end), follow[64], match[256].  One 64-bit set of live positions per row: a byte b takes the set S to
-// (follow(S) | first, where a match may start) & match[b]; a position of `last` in the set = a match ends behind this byte.
+// pattern to a position automaton of at most 63 positions whose edges carry GAP CONDITIONS (gdv_regex.h): what ^ $ \A \z \b \B
+// ask of the gap between two bytes — conjunctions of 1 word boundary, 2 not a word boundary, 4 start of the text, 8 end of the
+// text, at most 8 distinct ones per pattern (id 0 = none).  table (64-bit words) = flags | nullable | predicates[8] | first[8] |
+// last[8] | follow[64][8] | match[256].  One 64-bit set of live positions per row: over the gap in front of byte b (the
+// conditions it satisfies: `sat`) the set S becomes (first[c] | follow[p][c] for p in S, c in sat) & match[b]; a position of
+// last[c], c satisfied by the gap behind the byte, ends a match.
+GDV_DEV bool gdv_regex_word_byte(gdv_uint8 c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
 GDV_DEV bool gdv_regex_search(const gdv_str& s, const gdv_uint8* table) {
   const gdv_uint64* t = (const gdv_uint64*)table;
-  const gdv_uint64 first = t[0], last = t[1], flags = t[2];
-  const gdv_uint64* follow = t + 3;
-  const gdv_uint64* match = t + 3 + 64;
-  const bool at_start = (flags & 2) != 0, at_end = (flags & 4) != 0;
-  if ((flags & 1) != 0 && (!(at_start && at_end) || s.len <= 0)) return true;  // the empty match
+  const gdv_uint32 used = (gdv_uint32)(t[0] >> 8) & 255u, nullable = (gdv_uint32)t[1];
+  const bool start_only = (t[0] & 1) != 0;
+  const gdv_uint64* preds = t + 2;
+  const gdv_uint64* first = t + 10;
+  const gdv_uint64* last = t + 18;
+  const gdv_uint64* follow = t + 26;
+  const gdv_uint64* match = t + 26 + 64 * 8;
+  const gdv_int32 len = s.len > 0 ? s.len : 0;
   gdv_uint64 live = 0;
-  for (gdv_int32 i = 0; i < s.len; i++) {
-    gdv_uint64 next = (!at_start || i == 0) ? first : 0ull;
-    for (gdv_uint64 w = live; w != 0; w &= w - 1) next |= follow[__builtin_ctzll(w)];
-    live = next & match[gdv_str_at(s, i)];
-    if ((live & last) != 0 && (!at_end || i + 1 == s.len)) return true;
-    if (live == 0 && at_start) return false;  // anchored and dead: nothing can start later
+  bool prev_word = false;
+  for (gdv_int32 i = 0; i <= len; i++) {
+    // the gap in front of byte i (behind byte i - 1): its predicates, and the conditions of the pattern they satisfy.  RE2 looks
+    // at BYTES here, and its search may begin at any byte: inside a multi-byte character (in front of a continuation byte) the
+    // gap is "not a word boundary" for a match that BEGINS there, while a match under way — every atom consumes whole
+    // characters — can neither end nor pass an assertion there
+    const gdv_uint8 b = i < len ? gdv_str_at(s, i) : (gdv_uint8)0;
+    const bool next_word = i < len && gdv_regex_word_byte(b);
+    const bool inside = i < len && (b & 0xC0) == 0x80;
+    const gdv_uint32 gap = (prev_word != next_word ? 1u : 2u) | (i == 0 ? 4u : 0u) | (i == len ? 8u : 0u);
+    gdv_uint32 sat_new = 1u;
+    for (gdv_uint32 w = used & ~1u; w != 0; w &= w - 1) {
+      const int c = __builtin_ctz(w);
+      if (((gdv_uint32)preds[c] & ~gap) == 0) sat_new |= 1u << c;
+    }
+    const gdv_uint32 sat_run = inside ? 1u : sat_new;
+    // a match that ends here: the empty one, or a live position that may be left over this gap
+    if ((nullable & sat_new) != 0) return true;
+    gdv_uint64 ends = 0, next = 0;
+    for (gdv_uint32 w = sat_run; w != 0; w &= w - 1) ends |= last[__builtin_ctz(w)];
+    for (gdv_uint32 w = sat_new; w != 0; w &= w - 1) next |= first[__builtin_ctz(w)];
+    if ((live & ends) != 0) return true;
+    if (i == len) break;
+    for (gdv_uint64 w = live; w != 0; w &= w - 1) {
+      const gdv_uint64* f = follow + 8 * __builtin_ctzll(w);
+      for (gdv_uint32 v = sat_run; v != 0; v &= v - 1) next |= f[__builtin_ctz(v)];
+    }
+    live = next & match[b];
+    if (live == 0 && start_only) return false;  // nothing can begin behind the first byte
+    prev_word = next_word;
   }
   return false;
 }

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <array>
 #include <bitset>
+#include <cctype>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -14,7 +15,8 @@ using ByteSet = std::bitset<256>;
 
 // syntax tree: leaves are byte sets (one automaton position each)
 struct Re {
-  enum Kind { kEmpty, kSet, kCat, kAlt, kStar, kPlus, kOpt } kind = kEmpty;
+  enum Kind { kEmpty, kSet, kCat, kAlt, kStar, kPlus, kOpt, kAssert } kind = kEmpty;
+  int cond = 0;  // kAssert: 1 word boundary, 2 not a word boundary, 3 start of the text, 4 end of the text
   ByteSet set;
   std::unique_ptr<Re> a, b;
   int pos = -1;
@@ -34,10 +36,17 @@ ReP MkSet(const ByteSet& s) {
   r->set = s;
   return r;
 }
+ReP MkAssert(int cond) {
+  ReP r(new Re);
+  r->kind = Re::kAssert;
+  r->cond = cond;
+  return r;
+}
 ReP Clone(const Re& x) {
   ReP r(new Re);
   r->kind = x.kind;
   r->set = x.set;
+  r->cond = x.cond;
   if (x.a) r->a = Clone(*x.a);
   if (x.b) r->b = Clone(*x.b);
   return r;
@@ -75,7 +84,7 @@ ByteSet FoldCase(ByteSet s) {
 
 class Parser {
  public:
-  Parser(const std::string& p, bool fold) : p_(p), fold_(fold) {}
+  Parser(const std::string& p, bool fold, bool dot_nl) : p_(p), fold_(fold), dot_nl_(dot_nl) {}
   Status Parse(ReP* out) {
     GDV_RETURN_NOT_OK(Alt(out));
     if (i_ < p_.size()) return Bad(p_[i_] == ')' ? "unmatched ')'" : "unexpected character");
@@ -214,7 +223,29 @@ class Parser {
         i_ = j;
         continue;
       }
-      if (c == '[' && i_ + 1 < p_.size() && p_[i_ + 1] == ':') return Bad("POSIX character class");
+      if (c == '[' && i_ + 1 < p_.size() && p_[i_ + 1] == ':') {
+        const size_t close = p_.find(":]", i_ + 2);
+        if (close == std::string::npos) return Bad("unterminated POSIX character class");
+        const std::string name = p_.substr(i_ + 2, close - i_ - 2);
+        ByteSet cls;
+        if (name == "alpha") cls = Range('a', 'z') | Range('A', 'Z');
+        else if (name == "digit") cls = Digits();
+        else if (name == "alnum") cls = Digits() | Range('a', 'z') | Range('A', 'Z');
+        else if (name == "upper") cls = Range('A', 'Z');
+        else if (name == "lower") cls = Range('a', 'z');
+        else if (name == "space") cls = Spaces();
+        else if (name == "blank") cls = Range(' ', ' ') | Range('\t', '\t');
+        else if (name == "punct") cls = Range('!', '/') | Range(':', '@') | Range('[', '`') | Range('{', '~');
+        else if (name == "xdigit") cls = Digits() | Range('a', 'f') | Range('A', 'F');
+        else if (name == "word") cls = WordChars();
+        else if (name == "cntrl") cls = Range(0, 31) | Range(127, 127);
+        else if (name == "graph") cls = Range('!', '~');
+        else if (name == "print") cls = Range(' ', '~');
+        else return Bad("POSIX character class [:" + name + ":]");
+        set |= cls;
+        i_ = close + 2;
+        continue;
+      }
       ByteSet one;
       bool single = true;
       i_++;
@@ -267,8 +298,16 @@ class Parser {
       case '(': {
         i_++;
         if (More() && p_[i_] == '?') {
-          if (i_ + 1 < p_.size() && p_[i_ + 1] == ':') i_ += 2;
-          else return Bad("group flags / look-around / named groups");
+          if (i_ + 1 < p_.size() && p_[i_ + 1] == ':') {
+            i_ += 2;
+          } else if (i_ + 2 < p_.size() && p_[i_ + 1] == 'P' && p_[i_ + 2] == '<') {  // (?P<name>...): a group like any other
+            size_t j = i_ + 3;
+            while (j < p_.size() && (std::isalnum(static_cast<unsigned char>(p_[j])) || p_[j] == '_')) j++;
+            if (j == i_ + 3 || j >= p_.size() || p_[j] != '>') return Bad("malformed group name");
+            i_ = j + 1;
+          } else {
+            return Bad("group flags inside the pattern / look-around");
+          }
         }
         GDV_RETURN_NOT_OK(Alt(out));
         if (!More() || p_[i_] != ')') return Bad("unmatched '('");
@@ -281,12 +320,17 @@ class Parser {
       case '.': {
         i_++;
         ByteSet lead = AnyLead();
-        lead.reset('\n');
+        if (!dot_nl_) lead.reset('\n');
         *out = WholeCharacter(lead);
         return Status::OK();
       }
       case '\\': {
         i_++;
+        if (More() && (p_[i_] == 'b' || p_[i_] == 'B' || p_[i_] == 'A' || p_[i_] == 'z')) {
+          const char k = p_[i_++];
+          *out = MkAssert(k == 'b' ? 1 : k == 'B' ? 2 : k == 'A' ? 3 : 4);
+          return Status::OK();
+        }
         ByteSet set;
         negated_escape_ = false;
         GDV_RETURN_NOT_OK(Escape(&set));
@@ -295,8 +339,13 @@ class Parser {
         return Status::OK();
       }
       case '^':
+        i_++;
+        *out = MkAssert(3);
+        return Status::OK();
       case '$':
-        return Bad("an anchor that is not the pattern's first ('^') or last ('$') character");
+        i_++;
+        *out = MkAssert(4);
+        return Status::OK();
       case '*':
       case '+':
       case '?':
@@ -322,96 +371,112 @@ class Parser {
   const std::string& p_;
   size_t i_ = 0;
   bool negated_escape_ = false;
-  bool fold_ = false;  // (?i): ASCII letters match in either case
+  bool fold_ = false;    // (?i): ASCII letters match in either case
+  bool dot_nl_ = false;  // (?s): '.' matches a newline too
 };
 
+// Position automaton with GAP CONDITIONS.  An assertion (^ $ \\A \\z \\b \\B) consumes nothing: it constrains the gap between two
+// consecutive bytes (or the text's edges).  Every relation of the construction therefore carries a condition: nullable under a
+// condition, first / last positions under a condition, follow[p][c] = the positions that may come behind p when the gap between
+// them satisfies c.  A condition is a CONJUNCTION of the four predicates — 1 word boundary, 2 not a word boundary, 4 start of
+// the text, 8 end of the text — and gets a small id (0 = no predicate); a pattern may use kConds distinct conjunctions
+// ("^$" uses three: start, end, start-and-end).
+constexpr int kConds = 8;
+constexpr int kRegexTableWords = 2 + 3 * kConds + 64 * kConds + 256;  // = GDV_REGEX_TABLE_BYTES / 8
 struct Glushkov {
-  uint64_t follow[64] = {};
+  uint64_t follow[64][kConds] = {};
   ByteSet sets[64];
   int npos = 0;
   struct Info {
-    bool nullable;
-    uint64_t first, last;
+    uint32_t nullable = 0;          // bit c: the empty string, where the gap satisfies c
+    uint64_t first[kConds] = {};    // first[c]: positions a match may begin with, entered over a gap satisfying c
+    uint64_t last[kConds] = {};     // last[c]: positions a match may end with, left over a gap satisfying c
   };
-  bool overflow = false;
+  bool overflow = false, clash = false;
+  uint32_t masks[kConds] = {};  // condition id -> its predicates
+  int nconds = 1;               // (id 0: no predicate)
+  int CondFor(uint32_t mask) {
+    for (int c = 0; c < nconds; c++)
+      if (masks[c] == mask) return c;
+    if (nconds == kConds) { clash = true; return -1; }
+    masks[nconds] = mask;
+    return nconds++;
+  }
+  int Both(int a, int b) { return CondFor(masks[a] | masks[b]); }  // the condition "a and b" on one gap
+  void Link(const Info& a, const Info& b) {
+    for (int ca = 0; ca < kConds; ca++)
+      for (int cb = 0; cb < kConds; cb++) {
+        if (a.last[ca] == 0 || b.first[cb] == 0) continue;
+        const int c = Both(ca, cb);
+        if (c < 0) continue;
+        for (int p = 0; p < 64; p++)
+          if ((a.last[ca] >> p) & 1) follow[p][c] |= b.first[cb];
+      }
+  }
   Info Build(Re& x) {
+    Info r;
     switch (x.kind) {
-      case Re::kEmpty: return {true, 0, 0};
-      case Re::kSet: {
-        if (npos >= 63) { overflow = true; return {false, 0, 0}; }
+      case Re::kEmpty:
+        r.nullable = 1;
+        return r;
+      case Re::kAssert: {
+        const int c = CondFor(1u << (x.cond - 1));
+        if (c >= 0) r.nullable = 1u << c;
+        return r;
+      }
+      case Re::kSet:
+        if (npos >= 63) { overflow = true; return r; }
         x.pos = npos++;
         sets[x.pos] = x.set;
-        return {false, 1ull << x.pos, 1ull << x.pos};
-      }
+        r.first[0] = r.last[0] = 1ull << x.pos;
+        return r;
       case Re::kCat: {
         const Info a = Build(*x.a), b = Build(*x.b);
-        Link(a.last, b.first);
-        return {a.nullable && b.nullable, a.first | (a.nullable ? b.first : 0), b.last | (b.nullable ? a.last : 0)};
+        Link(a, b);
+        for (int c = 0; c < kConds; c++) { r.first[c] |= a.first[c]; r.last[c] |= b.last[c]; }
+        for (int ca = 0; ca < kConds; ca++)
+          for (int cb = 0; cb < kConds; cb++) {
+            if (((a.nullable >> ca) & 1) && ((b.nullable >> cb) & 1)) { const int c = Both(ca, cb); if (c >= 0) r.nullable |= 1u << c; }
+            if (((a.nullable >> ca) & 1) && b.first[cb] != 0) { const int c = Both(ca, cb); if (c >= 0) r.first[c] |= b.first[cb]; }
+            if (((b.nullable >> cb) & 1) && a.last[ca] != 0) { const int c = Both(ca, cb); if (c >= 0) r.last[c] |= a.last[ca]; }
+          }
+        return r;
       }
       case Re::kAlt: {
         const Info a = Build(*x.a), b = Build(*x.b);
-        return {a.nullable || b.nullable, a.first | b.first, a.last | b.last};
+        r.nullable = a.nullable | b.nullable;
+        for (int c = 0; c < kConds; c++) { r.first[c] = a.first[c] | b.first[c]; r.last[c] = a.last[c] | b.last[c]; }
+        return r;
       }
       case Re::kStar:
-      case Re::kPlus: {
-        const Info a = Build(*x.a);
-        Link(a.last, a.first);
-        return {x.kind == Re::kStar || a.nullable, a.first, a.last};
-      }
+      case Re::kPlus:
       case Re::kOpt: {
-        const Info a = Build(*x.a);
-        return {true, a.first, a.last};
+        r = Build(*x.a);
+        if (x.kind != Re::kOpt) Link(r, r);
+        if (x.kind != Re::kPlus) r.nullable |= 1;
+        return r;
       }
     }
-    return {true, 0, 0};
-  }
-  void Link(uint64_t from, uint64_t to) {
-    for (int p = 0; p < 64; p++)
-      if ((from >> p) & 1) follow[p] |= to;
+    return r;
   }
 };
 
 }  // namespace
 
 Status CompileRegex(const std::string& pattern, std::string* table) {
-  // the two anchors the backend takes: '^' first, '$' last (not escaped)
+  // flags, in front of everything only: (?i) ASCII letters in either case, (?s) '.' matches a newline
   std::string body = pattern;
-  uint64_t flags = 0;
-  bool fold = false;
-  if (body.compare(0, 4, "(?i)") == 0) {  // the one flag taken, and only in front: ASCII letters in either case
-    fold = true;
-    body.erase(0, 4);
-  }
-  if (!body.empty() && body.front() == '^') {
-    flags |= 2;
-    body.erase(0, 1);
-  }
-  if (!body.empty() && body.back() == '$') {
-    size_t slashes = 0;
-    while (slashes + 1 < body.size() && body[body.size() - 2 - slashes] == '\\') slashes++;
-    if (slashes % 2 == 0) {
-      flags |= 4;
-      body.pop_back();
-    }
-  }
-  if (flags != 0) {
-    // '^a|b' anchors its first branch only: not expressible with one flag for the whole pattern
-    int depth = 0;
-    bool in_class = false;
-    for (size_t i = 0; i < body.size(); i++) {
-      const char c = body[i];
-      if (c == '\\') { i++; continue; }
-      if (in_class) { if (c == ']') in_class = false; continue; }
-      if (c == '[') { in_class = true; if (i + 1 < body.size() && body[i + 1] == '^') i++; if (i + 1 < body.size() && body[i + 1] == ']') i++; }
-      else if (c == '(') depth++;
-      else if (c == ')') depth--;
-      else if (c == '|' && depth == 0)
-        return Status::CodeGenError("regular expression '" + pattern + "' not supported yet by the HIP backend: an anchor next to a top-level '|' "
-                                    "(write ^(a|b)$)");
+  bool fold = false, dot_nl = false;
+  if (body.compare(0, 2, "(?") == 0) {
+    size_t j = 2;
+    while (j < body.size() && (body[j] == 'i' || body[j] == 's')) j++;
+    if (j > 2 && j < body.size() && body[j] == ')') {
+      for (size_t k = 2; k < j; k++) (body[k] == 'i' ? fold : dot_nl) = true;
+      body.erase(0, j + 1);
     }
   }
   ReP tree;
-  Parser parser(body, fold);
+  Parser parser(body, fold, dot_nl);
   Status st = parser.Parse(&tree);
   if (!st.ok()) {  // (messages quote the pattern as the caller wrote it)
     const std::string quoted = "'" + body + "'";
@@ -421,20 +486,40 @@ Status CompileRegex(const std::string& pattern, std::string* table) {
   }
   Glushkov g;
   const Glushkov::Info top = g.Build(*tree);
-  if (g.overflow)
-    return Status::CodeGenError("regular expression '" + pattern + "' not supported yet by the HIP backend: more than 63 automaton positions");
-  if (top.nullable) flags |= 1;
-  table->assign((3 + 64 + 256) * 8, '\0');
-  uint64_t* t = reinterpret_cast<uint64_t*>(&(*table)[0]);
-  t[0] = top.first;
-  t[1] = top.last;
-  t[2] = flags;
-  for (int p = 0; p < 64; p++) t[3 + p] = g.follow[p];
+  const std::string prefix = "regular expression '" + pattern + "' not supported yet by the HIP backend: ";
+  if (g.overflow) return Status::CodeGenError(prefix + "more than 63 automaton positions");
+  if (g.clash) return Status::CodeGenError(prefix + "more than 7 distinct combinations of assertions (^ $ \\A \\z \\b \\B)");
+  // layout (64-bit words): flags | nullable | predicates[8] | first[8] | last[8] | follow[64][8] | match[256]
+  //   flags bit 0: every way into the pattern asks for the start of the text (nothing can begin behind byte 0);
+  //   bits 8..15: the condition ids that occur at all (the row evaluates only those)
+  //   predicates[c]: the conjunction condition c stands for — 1 word boundary, 2 not one, 4 start of the text, 8 end of it
+  table->assign(kRegexTableWords * 8, '\0');
+  uint64_t* tb = reinterpret_cast<uint64_t*>(&(*table)[0]);
+  uint64_t* const first = tb + 2 + kConds;
+  uint64_t* const last = first + kConds;
+  uint64_t* const follow = last + kConds;
+  uint64_t* const match = follow + 64 * kConds;
+  uint64_t used = 1;
+  bool start_only = true;
+  for (int c = 0; c < kConds; c++) {
+    tb[2 + c] = g.masks[c];
+    first[c] = top.first[c];
+    last[c] = top.last[c];
+    if (top.first[c] != 0 || top.last[c] != 0 || ((top.nullable >> c) & 1)) used |= 1ull << c;
+    if ((g.masks[c] & 4u) == 0 && (top.first[c] != 0 || ((top.nullable >> c) & 1))) start_only = false;
+  }
+  for (int p = 0; p < 64; p++)
+    for (int c = 0; c < kConds; c++) {
+      follow[p * kConds + c] = g.follow[p][c];
+      if (g.follow[p][c] != 0) used |= 1ull << c;
+    }
+  tb[0] = (start_only ? 1u : 0u) | (used << 8);
+  tb[1] = top.nullable;
   for (int b = 0; b < 256; b++) {
     uint64_t m = 0;
     for (int p = 0; p < g.npos; p++)
       if (g.sets[p].test(static_cast<size_t>(b))) m |= 1ull << p;
-    t[3 + 64 + b] = m;
+    match[b] = m;
   }
   return Status::OK();
 }

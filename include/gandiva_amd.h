@@ -563,10 +563,10 @@ int gdv_precompile_filter_project(const gdv_schema_t* schema, gdv_expression_t* 
                                   int num_exprs, int index_mode);
 /* Pattern compilers of the planner, callable on their own (no device): a caller can check a regexp_like / regexp_matches
  * pattern, or a to_date pattern, before building an expression around it; tests drive the device functions' host build with
- * the tables.  gdv_compile_regex: `table` receives GDV_REGEX_TABLE_BYTES bytes (first, last, flags, follow[64], match[256] as
- * 64-bit words: gandiva_amd/csrc/gdv_regex.h).  gdv_compile_date_format: `ops` (capacity `cap`) receives one byte per
+ * the tables.  gdv_compile_regex: `table` receives GDV_REGEX_TABLE_BYTES bytes (flags, nullable, predicates[8], first[8], last[8],
+ * follow[64][8], match[256] as 64-bit words: gandiva_amd/csrc/gdv_regex.h).  gdv_compile_date_format: `ops` (capacity `cap`) receives one byte per
  * strptime directive ('L' c for a literal byte), *n their number.  0 or a status code; gdv_last_error() has the reason. */
-#define GDV_REGEX_TABLE_BYTES 2584
+#define GDV_REGEX_TABLE_BYTES 6352
 int gdv_compile_regex(const char* pattern, int64_t pattern_len, uint8_t* table);
 int gdv_compile_date_format(const char* pattern, int64_t pattern_len, uint8_t* ops, int64_t cap, int64_t* n);
 /* Kernel identity (diagnostics, tests).  A fused kernel is named after a hash of its generated text

@@ -96,8 +96,9 @@
  *         thread list, for the syntax gandiva_amd/csrc/gdv_regex.h lists (no back-references, \b, look-around, flags, inner
  *         anchors); '.' excludes the newline and '$' means the end of the text — checked against RE2 ITSELF (pyarrow.compute's
  *         match_substring_regex: the RE2 linked into this image's libarrow, PartialMatch with default options) and against
- *         Python's re, fixed and random patterns (tests/test_registry_tail.py).  That the lineage's holder uses default
- *         options is the recollection.  regexp_replace: the lineage runs
+ *         Python's re, fixed and random patterns (tests/test_registry_tail.py, tools/regex_fuzz.py: ~4600 random patterns,
+ *         profiles/r05_regex_fuzz.txt), RE2's byte-level rule for \\B inside multi-byte characters included.  That the lineage's
+ *         holder uses default options is the recollection.  regexp_replace: the lineage runs
  *         RE2::GlobalReplace; only the LITERAL SUBSET exists (a metacharacter-free pattern, a replacement without
  *         backslashes: left-to-right non-overlapping replace), with replace's 65535-byte result cap (RE2 has none).
  *
@@ -560,8 +561,8 @@ static int str_cmp(const uint8_t* a, int al, int am, const uint8_t* b, int bl, i
  * parsed into a tree over CODE POINTS (the text is decoded from UTF-8 first), compiled to a Thompson program (char / split /
  * jump / match) and run as a thread list (Pike) — where the device library walks a byte-level position automaton.  The syntax
  * the HIP backend takes (gandiva_amd/csrc/gdv_regex.h); anything else returns -1 (the caller raises). */
-typedef struct rx_node { int kind; /* 0 empty 1 set 2 cat 3 alt 4 star 5 plus 6 opt */ uint8_t ascii[16]; int neg; int32_t lit; int32_t extra[8]; int nextra; struct rx_node *a, *b; } rx_node;
-typedef struct { const uint8_t* p; int n, i, bad, fold; rx_node* pool[4096]; int npool; } rx_parser;
+typedef struct rx_node { int kind; /* 0 empty 1 set 2 cat 3 alt 4 star 5 plus 6 opt 7 assertion (lit = 1 \\b, 2 \\B, 3 start, 4 end) */ uint8_t ascii[16]; int neg; int32_t lit; int32_t extra[8]; int nextra; struct rx_node *a, *b; } rx_node;
+typedef struct { const uint8_t* p; int n, i, bad, fold, dot_nl; rx_node* pool[4096]; int npool; } rx_parser;
 static rx_node* rx_new(rx_parser* P, int kind, rx_node* a, rx_node* b) {
   if (P->npool >= 4096) { P->bad = 1; return P->pool[0]; }
   rx_node* x = (rx_node*)calloc(1, sizeof(rx_node)); x->kind = kind; x->a = a; x->b = b; x->lit = -1; P->pool[P->npool++] = x; return x;
@@ -593,7 +594,15 @@ static rx_node* rx_atom(rx_parser* P) {
   int c = P->p[P->i];
   if (c == '(') {
     P->i++;
-    if (P->i < P->n && P->p[P->i] == '?') { if (P->i + 1 < P->n && P->p[P->i + 1] == ':') P->i += 2; else { P->bad = 1; return rx_new(P, 0, NULL, NULL); } }
+    if (P->i < P->n && P->p[P->i] == '?') {
+      if (P->i + 1 < P->n && P->p[P->i + 1] == ':') P->i += 2;
+      else if (P->i + 2 < P->n && P->p[P->i + 1] == 'P' && P->p[P->i + 2] == '<') {  /* a named group: a group */
+        int j = P->i + 3;
+        while (j < P->n && (isalnum(P->p[j]) || P->p[j] == '_')) j++;
+        if (j == P->i + 3 || j >= P->n || P->p[j] != '>') { P->bad = 1; return rx_new(P, 0, NULL, NULL); }
+        P->i = j + 1;
+      } else { P->bad = 1; return rx_new(P, 0, NULL, NULL); }
+    }
     rx_node* x = rx_alt(P);
     if (P->i >= P->n || P->p[P->i] != ')') P->bad = 1; else P->i++;
     return x;
@@ -606,7 +615,23 @@ static rx_node* rx_atom(rx_parser* P) {
       if (P->i >= P->n) { P->bad = 1; return s; }
       int m = P->p[P->i];
       if (m == ']' && !first) { P->i++; break; }
-      if (m == '[' && P->i + 1 < P->n && P->p[P->i + 1] == ':') { P->bad = 1; return s; }
+      if (m == '[' && P->i + 1 < P->n && P->p[P->i + 1] == ':') {
+        static const char* names[] = {"alpha", "digit", "alnum", "upper", "lower", "space", "blank", "punct", "xdigit", "word", "cntrl", "graph", "print"};
+        int which = -1, nl = 0;
+        for (int q = 0; q < 13 && which < 0; q++) {
+          nl = (int)strlen(names[q]);
+          if (P->i + 2 + nl + 2 <= P->n && !memcmp(P->p + P->i + 2, names[q], (size_t)nl) && P->p[P->i + 2 + nl] == ':' && P->p[P->i + 3 + nl] == ']') which = q;
+        }
+        if (which < 0) { P->bad = 1; return s; }
+        for (int ch = 0; ch < 128; ch++) {
+          int in = which == 0 ? isalpha(ch) : which == 1 ? isdigit(ch) : which == 2 ? isalnum(ch) : which == 3 ? isupper(ch) : which == 4 ? islower(ch)
+                 : which == 5 ? isspace(ch) : which == 6 ? (ch == ' ' || ch == 9) : which == 7 ? ispunct(ch) : which == 8 ? isxdigit(ch)
+                 : which == 9 ? (isalnum(ch) || ch == '_') : which == 10 ? iscntrl(ch) : which == 11 ? isgraph(ch) : isprint(ch);
+          if (in) rx_add(s, ch, ch);
+        }
+        P->i += 2 + nl + 2;
+        continue;
+      }
       if (m >= 0xC2) { /* a non-ASCII member: one code point (not an end of a range, not under (?i), not in a negated class) */
         int len = m >= 0xF0 ? 4 : m >= 0xE0 ? 3 : 2;
         if (P->i + len > P->n || s->nextra >= 8 || P->fold) { P->bad = 1; return s; }
@@ -642,9 +667,14 @@ static rx_node* rx_atom(rx_parser* P) {
     if (s->neg && s->nextra) P->bad = 1;
     return s;
   }
-  if (c == '.') { P->i++; s->neg = 1; rx_add(s, 10, 10); return s; }
-  if (c == '\\') { P->i++; int ng = 0; if (!rx_escape(P, s, &ng)) P->bad = 1; s->neg = ng; return s; }
-  if (c == '^' || c == '$' || c == '*' || c == '+' || c == '?' || c == '{') { P->bad = 1; return s; }
+  if (c == '.') { P->i++; s->neg = 1; if (!P->dot_nl) rx_add(s, 10, 10); return s; }
+  if (c == '\\') {
+    P->i++;
+    if (P->i < P->n && strchr("bBAz", P->p[P->i])) { int k = P->p[P->i++]; s->kind = 7; s->lit = k == 'b' ? 1 : k == 'B' ? 2 : k == 'A' ? 3 : 4; return s; }
+    int ng = 0; if (!rx_escape(P, s, &ng)) P->bad = 1; s->neg = ng; return s;
+  }
+  if (c == '^' || c == '$') { P->i++; s->kind = 7; s->lit = c == '^' ? 3 : 4; return s; }
+  if (c == '*' || c == '+' || c == '?' || c == '{') { P->bad = 1; return s; }
   if (c < 128) { P->i++; rx_add(s, c, c); return s; }
   /* a non-ASCII character of the pattern: one code point */
   int len = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : 2;
@@ -690,7 +720,7 @@ static rx_node* rx_alt(rx_parser* P) {
   while (!P->bad && P->i < P->n && P->p[P->i] == '|') { P->i++; x = rx_new(P, 3, x, rx_cat(P)); }
   return x;
 }
-typedef struct { int op; /* 0 char 1 split 2 jmp 3 match */ int x, y; const rx_node* set; } rx_inst;
+typedef struct { int op; /* 0 char 1 split 2 jmp 3 match 4 assertion (x = the condition) */ int x, y; const rx_node* set; } rx_inst;
 typedef struct { rx_inst* code; int n, cap; } rx_prog;
 static int rx_emit1(rx_prog* g, int op, int x, int y, const rx_node* set) {
   if (g->n == g->cap) { g->cap = g->cap ? g->cap * 2 : 64; g->code = (rx_inst*)realloc(g->code, (size_t)g->cap * sizeof(rx_inst)); }
@@ -700,6 +730,7 @@ static void rx_emit(rx_prog* g, const rx_node* x) {
   switch (x->kind) {
     case 0: break;
     case 1: rx_emit1(g, 0, 0, 0, x); break;
+    case 7: rx_emit1(g, 4, x->lit, 0, NULL); break;
     case 2: rx_emit(g, x->a); rx_emit(g, x->b); break;
     case 3: { int s = rx_emit1(g, 1, 0, 0, NULL); g->code[s].x = g->n; rx_emit(g, x->a); int j = rx_emit1(g, 2, 0, 0, NULL); g->code[s].y = g->n; rx_emit(g, x->b); g->code[j].x = g->n; break; }
     case 4: { int s = rx_emit1(g, 1, 0, 0, NULL); g->code[s].x = g->n; rx_emit(g, x->a); rx_emit1(g, 2, s, 0, NULL); g->code[s].y = g->n; break; }
@@ -707,11 +738,13 @@ static void rx_emit(rx_prog* g, const rx_node* x) {
     default: { int s = rx_emit1(g, 1, 0, 0, NULL); g->code[s].x = g->n; rx_emit(g, x->a); g->code[s].y = g->n; break; }
   }
 }
-static void rx_add_thread(const rx_prog* g, int* list, int* n, uint8_t* on, int pc) {
+/* the closure of pc over jumps, splits and the assertions the gap satisfies (`sat`: bit c = condition c holds) */
+static void rx_add_thread(const rx_prog* g, int* list, int* n, uint8_t* on, int pc, unsigned sat) {
   if (on[pc]) return;
   on[pc] = 1;
-  if (g->code[pc].op == 2) rx_add_thread(g, list, n, on, g->code[pc].x);
-  else if (g->code[pc].op == 1) { rx_add_thread(g, list, n, on, g->code[pc].x); rx_add_thread(g, list, n, on, g->code[pc].y); }
+  if (g->code[pc].op == 2) rx_add_thread(g, list, n, on, g->code[pc].x, sat);
+  else if (g->code[pc].op == 1) { rx_add_thread(g, list, n, on, g->code[pc].x, sat); rx_add_thread(g, list, n, on, g->code[pc].y, sat); }
+  else if (g->code[pc].op == 4) { if ((sat >> g->code[pc].x) & 1) rx_add_thread(g, list, n, on, pc + 1, sat); }
   else list[(*n)++] = pc;
 }
 static int rx_set_has(const rx_node* s, int32_t cp, int fold) {
@@ -722,23 +755,16 @@ static int rx_set_has(const rx_node* s, int32_t cp, int fold) {
   return s->neg ? !in : in;
 }
 /* 1 / 0: the text (bytes read through case map `sm`) does / does not contain a match; -1: pattern not taken */
+static int rx_word_cp(int32_t cp) { return cp < 128 && (isalnum(cp) || cp == '_'); }
 static int regex_search(const uint8_t* s, int sl, int sm, const uint8_t* pat, int pl) {
-  int fold = pl >= 4 && !memcmp(pat, "(?i)", 4);   /* the one flag taken, in front only: ASCII letters in either case */
-  if (fold) { pat += 4; pl -= 4; }
-  int at_start = pl > 0 && pat[0] == '^', at_end = 0;
-  const uint8_t* body = pat + at_start; int bl = pl - at_start;
-  if (bl > 0 && body[bl - 1] == '$') { int sl2 = 0; while (sl2 + 1 < bl && body[bl - 2 - sl2] == '\\') sl2++; if (sl2 % 2 == 0) { at_end = 1; bl--; } }
-  if (at_start || at_end) { /* an anchor next to a top-level '|' binds to one branch: not taken */
-    int depth = 0, in_class = 0;
-    for (int i = 0; i < bl; i++) {
-      int c = body[i];
-      if (c == '\\') { i++; continue; }
-      if (in_class) { if (c == ']') in_class = 0; continue; }
-      if (c == '[') { in_class = 1; if (i + 1 < bl && body[i + 1] == '^') i++; if (i + 1 < bl && body[i + 1] == ']') i++; }
-      else if (c == '(') depth++; else if (c == ')') depth--; else if (c == '|' && depth == 0) return -1;
-    }
+  /* flags, in front only: (?i) ASCII letters in either case, (?s) '.' matches a newline */
+  int fold = 0, dot_nl = 0;
+  if (pl >= 4 && pat[0] == '(' && pat[1] == '?') {
+    int j = 2;
+    while (j < pl && (pat[j] == 'i' || pat[j] == 's')) j++;
+    if (j > 2 && j < pl && pat[j] == ')') { for (int k = 2; k < j; k++) { if (pat[k] == 'i') fold = 1; else dot_nl = 1; } pat += j + 1; pl -= j + 1; }
   }
-  rx_parser P; memset(&P, 0, sizeof P); P.p = body; P.n = bl; P.fold = fold;
+  rx_parser P; memset(&P, 0, sizeof P); P.p = pat; P.n = pl; P.fold = fold; P.dot_nl = dot_nl;
   rx_node* tree = rx_alt(&P);
   int result = -1;
   if (!P.bad && P.i == P.n) {
@@ -752,20 +778,34 @@ static int regex_search(const uint8_t* s, int sl, int sm, const uint8_t* pat, in
       for (int k = 1; k < len; k++) cp = (cp << 6) | (s[i + k] & 0x3F);
       cps[nc++] = cp; i += len;
     }
-    int* cur = (int*)malloc((size_t)g.n * sizeof(int)); int* nxt = (int*)malloc((size_t)g.n * sizeof(int));
+    int* cur = (int*)malloc((size_t)g.n * sizeof(int)); int* pend = (int*)malloc((size_t)g.n * sizeof(int));
     uint8_t* on = (uint8_t*)malloc((size_t)g.n);
-    int ncur = 0; result = 0;
+    int npend = 0; result = 0;
+    /* RE2 walks BYTES and may begin a match at any byte: inside a multi-byte character the gap is "not a word boundary", so a
+     * pattern that matches the empty string under \\B alone (\\B, \\Bx?) is found in any text that holds such a character.  A
+     * match that consumes anything cannot begin there (no atom starts with a continuation byte). */
+    int multibyte = 0;
+    for (int i = 0; i < nc; i++) multibyte |= cps[i] >= 128;
+    if (multibyte) {
+      int ncur = 0; memset(on, 0, (size_t)g.n);
+      rx_add_thread(&g, cur, &ncur, on, 0, 1u | 4u);
+      for (int k = 0; k < ncur; k++) if (g.code[cur[k]].op == 3) result = 1;
+    }
     for (int i = 0; i <= nc && !result; i++) {
-      if (!at_start || i == 0) { memset(on, 0, (size_t)g.n); for (int k = 0; k < ncur; k++) on[cur[k]] = 1; rx_add_thread(&g, cur, &ncur, on, 0); }
-      int nn = 0; memset(on, 0, (size_t)g.n);
+      /* the gap in front of character i: which assertions hold; the threads that survive it (and a new one: a match may start here) */
+      const int pw = i > 0 && rx_word_cp(cps[i - 1]), nw = i < nc && rx_word_cp(cps[i]);
+      const unsigned sat = 1u | (pw != nw ? 2u : 4u) | (i == 0 ? 8u : 0u) | (i == nc ? 16u : 0u);
+      int ncur = 0; memset(on, 0, (size_t)g.n);
+      for (int k = 0; k < npend; k++) rx_add_thread(&g, cur, &ncur, on, pend[k], sat);
+      rx_add_thread(&g, cur, &ncur, on, 0, sat);
+      npend = 0;
       for (int k = 0; k < ncur; k++) {
         const rx_inst* in = &g.code[cur[k]];
-        if (in->op == 3) { if (!at_end || i == nc) result = 1; }
-        else if (i < nc && rx_set_has(in->set, cps[i], fold)) rx_add_thread(&g, nxt, &nn, on, cur[k] + 1);
+        if (in->op == 3) result = 1;
+        else if (i < nc && rx_set_has(in->set, cps[i], fold)) pend[npend++] = cur[k] + 1;
       }
-      int* tswap = cur; cur = nxt; nxt = tswap; ncur = nn;
     }
-    free(cur); free(nxt); free(on); free(cps); free(g.code);
+    free(cur); free(pend); free(on); free(cps); free(g.code);
   }
   for (int k = 0; k < P.npool; k++) free(P.pool[k]);
   return result;
