@@ -80,12 +80,13 @@ class FunctionNode : public Node {
   NodeVector children_;
 };
 
-// Builds a function node; the REGULAR-EXPRESSION functions of the registry are taken in their literal subset
-// (round 5) and rewritten here, once, onto the matchers that exist:
+// Builds a function node; regular-expression functions whose pattern is a plain literal are rewritten here, once, onto
+// the matchers that answer them fastest (round 5):
 //   regexp_like / regexp_matches(s, 'lit' | '^lit' | 'lit$' | '^lit$')  ->  like(s, '%lit%' | 'lit%' | '%lit' | 'lit')
 //   regexp_replace(s, 'lit', 'to')                                      ->  replace(s, 'lit', 'to')
 // where lit is a non-empty literal without regular-expression or LIKE metacharacters and `to` holds no backslash
-// (RE2 rewrite syntax).  Anything else stays a regexp_* node, which the planner refuses with CodeGenError.
+// (RE2 rewrite syntax).  Anything else stays a regexp_* node: regexp_like / regexp_matches are compiled by the planner
+// (gdv_regex.h), regexp_replace beyond a literal pattern is refused there with CodeGenError.
 NodePtr MakeFunctionNode(std::string name, NodeVector children, DataType ret);
 
 class IfNode : public Node {
