@@ -2419,21 +2419,21 @@ GDV_DEV gdv_int64 gdv_parse_date(gdv_ctx ctx, gdv_str s, const gdv_uint8* ops, g
   const gdv_uint32 day3[7] = {0x6e7573, 0x6e6f6d, 0x657574, 0x646577, 0x756874, 0x697266, 0x746173};
   const gdv_uint64 dayr[7] = {0x796164ull, 0x796164ull, 0x79616473ull, 0x79616473656eull, 0x7961647372ull, 0x796164ull, 0x7961647275ull};
   gdv_int32 year = 1900, mon = 1, mday = 0, yday = -1, i = 0, v = 0;
-  bool ok = true, have_mon = false, have_mday = false, have_wday = false;
+  bool ok = true, have_mon = false, have_mday = false, have_wday = false, want_xday = false;  // (glibc's names)
   for (gdv_int32 op = 0; ok && op < nops; op++) {
     const gdv_uint8 c = ops[op];
     if (c == ' ') { while (i < s.len && gdv_c_isspace(gdv_str_at(s, i))) i++; }
     else if (c == 'L') { op++; ok = i < s.len && gdv_str_at(s, i) == ops[op]; i++; }
-    else if (c == 'Y') { ok = gdv_scan_number(s, i, 0, 9999, 4, &v); year = v; }
-    else if (c == 'y') { ok = gdv_scan_number(s, i, 0, 99, 2, &v); year = v >= 69 ? 1900 + v : 2000 + v; }
-    else if (c == 'm') { ok = gdv_scan_number(s, i, 1, 12, 2, &v); mon = v; have_mon = true; }
-    else if (c == 'd') { ok = gdv_scan_number(s, i, 1, 31, 2, &v); mday = v; have_mday = true; }
+    else if (c == 'Y') { ok = gdv_scan_number(s, i, 0, 9999, 4, &v); year = v; want_xday = true; }
+    else if (c == 'y') { ok = gdv_scan_number(s, i, 0, 99, 2, &v); year = v >= 69 ? 1900 + v : 2000 + v; want_xday = true; }
+    else if (c == 'm') { ok = gdv_scan_number(s, i, 1, 12, 2, &v); mon = v; have_mon = true; want_xday = true; }
+    else if (c == 'd') { ok = gdv_scan_number(s, i, 1, 31, 2, &v); mday = v; have_mday = true; want_xday = true; }
     else if (c == 'j') { ok = gdv_scan_number(s, i, 1, 366, 3, &v); yday = v - 1; }
     else if (c == 'H') ok = gdv_scan_number(s, i, 0, 23, 2, &v);
     else if (c == 'I') ok = gdv_scan_number(s, i, 1, 12, 2, &v);
     else if (c == 'M') ok = gdv_scan_number(s, i, 0, 59, 2, &v);
     else if (c == 'S') ok = gdv_scan_number(s, i, 0, 61, 2, &v);
-    else if (c == 'b') { v = gdv_scan_name(s, i, mon3, monr, 12); ok = v >= 0; mon = v + 1; have_mon = true; }
+    else if (c == 'b') { v = gdv_scan_name(s, i, mon3, monr, 12); ok = v >= 0; mon = v + 1; have_mon = true; want_xday = true; }
     else if (c == 'a') { ok = gdv_scan_name(s, i, day3, dayr, 7) >= 0; have_wday = true; }
     else if (c == 'p') {
       ok = i + 2 <= s.len && (gdv_str_at(s, i + 1) | 0x20) == 'm' && ((gdv_str_at(s, i) | 0x20) == 'a' || (gdv_str_at(s, i) | 0x20) == 'p');
@@ -2445,9 +2445,9 @@ GDV_DEV gdv_int64 gdv_parse_date(gdv_ctx ctx, gdv_str s, const gdv_uint8* ops, g
     return 0;
   }
   *out_valid = true;
-  if (yday >= 0 && !have_wday && !(have_mon && have_mday)) {
-    // a day of the year fills in the month and / or the day of the month that the text did not give (glibc's strptime
-    // does this itself, and only when no weekday name was parsed)
+  if (yday >= 0 && want_xday && !have_wday && !(have_mon && have_mday)) {
+    // a day of the year fills in the month and / or the day of the month that the text did not give — glibc's strptime does
+    // this itself, when a year / month / day directive asked for a calendar date at all and no weekday name was parsed
     const bool leap = (year % 4 == 0) && (year % 100 != 0 || year % 400 == 0);
     gdv_int32 t_mon = 1, first = 0;  // month t_mon starts at day-of-year `first`
     for (; t_mon < 12; t_mon++) {

@@ -1078,3 +1078,46 @@ def test_random_patterns_three_engines_agree(hostlib):  # noqa: F811
         assert out.astype(bool).tolist() == want, pat
         assert oracle.project([_regex_expr(b, s, pat)], batch)[0].to_pylist() == want, pat
     assert tried > 100
+
+
+def test_random_to_date_patterns_device_interpreter_agrees_with_strptime(hostlib):  # noqa: F811
+    """token sequences drawn at random (a day of the year with and without a year, names, 12-hour clocks, quoted text): the
+    interpreter of the device library follows glibc's strptime — including when glibc turns a day of the year into month
+    and day (only if a year / month / day directive asked for a calendar date) — on rendered and mutated texts"""
+    rng = np.random.default_rng(31)
+    tokens = [("YYYY", "%Y"), ("YY", "%y"), ("MM", "%m"), ("MON", "%b"), ("MONTH", "%B"), ("DD", "%d"), ("DDD", "%j"), ("DY", "%a"), ("DAY", "%A"),
+              ("HH24", "%H"), ("HH", "%I"), ("HH12", "%I"), ("MI", "%M"), ("SS", "%S"), ("AM", "%p"), ("PM", "%p")]
+    seps = ["-", "/", " ", ":", ", ", ".", "T", " - ", ""]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    b = gandiva.TreeExprBuilder()
+    tried = 0
+    for _ in range(120):
+        k = int(rng.integers(1, 6))
+        pattern = pyfmt = ""
+        for j in range(k):
+            sql, py = tokens[int(rng.integers(0, len(tokens)))]
+            sep = seps[int(rng.integers(0, len(seps)))] if j < k - 1 else ""
+            pattern += sql + ('"T"' if sep == "T" else sep)
+            pyfmt += py + sep
+        texts = []
+        for _ in range(60):
+            t = datetime.datetime(1970, 1, 1) + datetime.timedelta(days=int(rng.integers(-20000, 30000)), seconds=int(rng.integers(0, 86400)))
+            s = t.strftime(pyfmt)
+            if rng.random() < 0.3:
+                pos, kind = int(rng.integers(0, len(s) + 1)), int(rng.integers(0, 4))
+                s = s[:pos] if kind == 0 else s[:pos] + "xX9 -:/"[int(rng.integers(0, 7))] + s[pos + 1:] if kind == 1 else s[:pos] + " " + s[pos:] if kind == 2 else s.upper()
+            texts.append(s)
+        raw, buf, cnt = pattern.encode(), np.zeros(256, np.uint8), C.c_int64(0)
+        if gandiva_capi.lib().gdv_compile_date_format(raw, len(raw), p(buf), 248, C.byref(cnt)) != 0:
+            continue      # (two tokens ran together into letters that are no token: both sides refuse)
+        arr = pa.array(texts, STR)
+        batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+        want = oracle.project([_to_date_exprs(b, b.make_field(batch.schema.field(0)), pattern, 1)], batch)[0].cast(pa.int64()).to_pylist()
+        off = np.frombuffer(arr.buffers()[1], np.int32)[: len(texts) + 1].copy()
+        size = int(off[-1])
+        data = np.concatenate([np.frombuffer(arr.buffers()[2], np.uint8)[:size], np.zeros(64, np.uint8)])
+        out, ov = np.zeros(len(texts), np.int64), np.zeros(len(texts), np.uint8)
+        hostlib.host_parse_date(p(off), p(data), C.c_long(size), C.c_long(len(texts)), p(buf), C.c_int(cnt.value), 1, p(out), p(ov))
+        assert [int(v) if ok else None for v, ok in zip(out, ov)] == want, pattern
+        tried += 1
+    assert tried > 100
