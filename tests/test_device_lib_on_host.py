@@ -419,3 +419,27 @@ def test_device_text_to_integer_casts_raise_and_hexadecimal_on_host(hostlib):
         assert flag[len(good):].tolist() == [1] * (n - len(good)), [b_ for b_, f in zip(texts[len(good):], flag[len(good):]) if not f]
         want = _project_one(name, [pa.array(good, pa.string())], [pa.string()], t).to_pylist()
         assert want == out[: len(good)].tolist(), name
+
+
+def test_random_like_patterns_device_matcher_oracle_and_re2_agree(hostlib):
+    """LIKE patterns drawn at random over literals, '%', '_' and multi-byte characters: the device library's general matcher
+    (host build), the oracle's dynamic program and pyarrow.compute.match_like (RE2 underneath) give the same answers"""
+    import pyarrow.compute as pc
+    rng = np.random.default_rng(8)
+    alpha = ["a", "b", "%", "_", "é", "ab", "%", "_", "語", "-", "a%", "_b"]
+    words = ["", "a", "b", "ab", "ba", "aab", "abab", "é", "aé", "éa", "語", "a語b", "-", "a-b", "abba", "bab", "\n", "a\nb"]
+    texts = ["".join(words[int(rng.integers(0, len(words)))] for _ in range(int(rng.integers(0, 4)))) for _ in range(400)] + words
+    arr = pa.array(texts, pa.string())
+    batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+    off, data, size = _col(arr)
+    b = gandiva.TreeExprBuilder()
+    s = b.make_field(batch.schema.field(0))
+    for _ in range(150):
+        pat = "".join(alpha[int(rng.integers(0, len(alpha)))] for _ in range(int(rng.integers(0, 6))))
+        want = pc.match_like(arr, pat).to_pylist()
+        got = oracle.project_one(b.make_function("like", [s, b.make_literal(pat, pa.string())], pa.bool_()), pa.bool_(), batch).to_pylist()
+        assert got == want, pat
+        pb, pk, plen = _compile_like(pat, None)
+        out = np.zeros(len(texts), dtype=np.uint8)
+        hostlib.host_str_like(_p(off), _p(data), C.c_long(size), C.c_long(len(texts)), _p(pb), _p(pk), plen, 0, _p(out))
+        assert out.astype(bool).tolist() == want, pat
