@@ -36,6 +36,14 @@ for seed in range(lo, hi):
                 else:
                     bad += 1
                     print("FAIL", name, seed, what, rc, msg[:300].replace("\n", " "), flush=True)
+            if name == "numeric":   # ... and as the fused filter -> project operator (both kernel shapes), UINT32 indices
+                plans += 1
+                rc = lib.gdv_precompile_filter_project(sh, cond._h, arr, len(exprs), 2)
+                if rc != 0 and ("not supported yet" in _capi.last_error() or "chain" in _capi.last_error()):
+                    refused += 1
+                elif rc != 0:
+                    bad += 1
+                    print("FAIL", name, seed, "filter-project", rc, _capi.last_error()[:300].replace("\n", " "), flush=True)
             lib.gdv_schema_free(sh)
         except Exception as e:  # noqa: BLE001
             bad += 1
