@@ -5,6 +5,7 @@
 #include <bitset>
 #include <cctype>
 #include <cstring>
+#include <initializer_list>
 #include <memory>
 #include <vector>
 
@@ -69,9 +70,15 @@ ByteSet AnyLead() { return Range(0x00, 0x7F) | Range(0xC2, 0xF4); }
 
 ByteSet Digits() { return Range('0', '9'); }
 ByteSet WordChars() { return Range('0', '9') | Range('a', 'z') | Range('A', 'Z') | Range('_', '_'); }
+// [[:space:]] holds the vertical tab, Perl's \s / \S do not (RE2: \s = [\t\n\f\r ])
 ByteSet Spaces() {
   ByteSet s;
   for (char c : {' ', '\t', '\n', '\r', '\f', '\v'}) s.set(static_cast<unsigned char>(c));
+  return s;
+}
+ByteSet PerlSpaces() {
+  ByteSet s = Spaces();
+  s.reset('\v');
   return s;
 }
 
@@ -82,10 +89,50 @@ ByteSet FoldCase(ByteSet s) {
   return s;
 }
 
+ReP Bytes(std::initializer_list<int> bytes) {
+  ReP seq;
+  for (int k : bytes) seq = seq ? Mk(Re::kCat, std::move(seq), MkSet(Range(k, k))) : MkSet(Range(k, k));
+  return seq;
+}
+// RE2's (?i) is Unicode simple folding.  Two characters outside ASCII fold onto ASCII letters: U+212A KELVIN SIGN (E2 84 AA)
+// onto k, U+017F LATIN SMALL LETTER LONG S (C5 BF) onto s.  A folded set that holds the letter matches the character too ...
+ReP FoldedSet(const ByteSet& folded) {
+  ReP r = MkSet(folded);
+  if (folded.test('k')) r = Mk(Re::kAlt, std::move(r), Bytes({0xE2, 0x84, 0xAA}));
+  if (folded.test('s')) r = Mk(Re::kAlt, std::move(r), Bytes({0xC5, 0xBF}));
+  return r;
+}
+// ... and "one character that is NOT in the (folded) set" leaves the two out when the set holds their letters
+ReP WholeCharacterOutside(const ByteSet& excluded, bool fold) {
+  ByteSet lead = AnyLead() & ~excluded;
+  const bool kelvin = fold && excluded.test('k'), long_s = fold && excluded.test('s');
+  if (kelvin) lead.reset(0xE2);
+  if (long_s) lead.reset(0xC5);
+  ReP r = WholeCharacter(lead);
+  auto tail = [] { return Mk(Re::kStar, MkSet(ContinuationBytes())); };
+  auto cont_but = [](int b) { ByteSet s = ContinuationBytes(); s.reset(static_cast<size_t>(b)); return MkSet(s); };
+  if (kelvin) {
+    r = Mk(Re::kAlt, std::move(r), Mk(Re::kCat, Mk(Re::kCat, Bytes({0xE2}), cont_but(0x84)), tail()));
+    r = Mk(Re::kAlt, std::move(r), Mk(Re::kCat, Mk(Re::kCat, Bytes({0xE2, 0x84}), cont_but(0xAA)), tail()));
+  }
+  if (long_s) r = Mk(Re::kAlt, std::move(r), Mk(Re::kCat, Mk(Re::kCat, Bytes({0xC5}), cont_but(0xBF)), tail()));
+  return r;
+}
+
+// Bounds on what the parser will build (patterns arrive from user SQL): the automaton has 63 positions, so a longer tree can
+// only end in the "more than 63 positions" error — say so before building it.  Nesting and the number of atoms are capped too:
+// the tree is walked recursively (Build, Clone, the destructors), empty groups and assertions add depth without positions.
+constexpr size_t kMaxPatternBytes = 4096;
+constexpr int kMaxNesting = 64;
+constexpr int kMaxAtoms = 512;
+
 class Parser {
  public:
   Parser(const std::string& p, bool fold, bool dot_nl) : p_(p), fold_(fold), dot_nl_(dot_nl) {}
   Status Parse(ReP* out) {
+    if (p_.size() > kMaxPatternBytes)
+      return Status::CodeGenError("regular expression of " + std::to_string(p_.size()) + " bytes not supported by the HIP backend: longer than " +
+                                  std::to_string(kMaxPatternBytes) + " bytes");
     GDV_RETURN_NOT_OK(Alt(out));
     if (i_ < p_.size()) return Bad(p_[i_] == ')' ? "unmatched ')'" : "unexpected character");
     return Status::OK();
@@ -97,13 +144,16 @@ class Parser {
                                 std::to_string(i_) + ")");
   }
   bool More() const { return i_ < p_.size(); }
+  Status TooManyPositions() { return Bad("more than 63 automaton positions"); }
   Status Alt(ReP* out) {
     ReP left;
     GDV_RETURN_NOT_OK(Cat(&left));
+    int leaves = Leaves(*left);
     while (More() && p_[i_] == '|') {
       i_++;
       ReP right;
       GDV_RETURN_NOT_OK(Cat(&right));
+      if ((leaves += Leaves(*right)) > 63) return TooManyPositions();
       left = Mk(Re::kAlt, std::move(left), std::move(right));
     }
     *out = std::move(left);
@@ -111,9 +161,11 @@ class Parser {
   }
   Status Cat(ReP* out) {
     ReP left = Mk(Re::kEmpty);
+    int leaves = 0;
     while (More() && p_[i_] != '|' && p_[i_] != ')') {
       ReP piece;
       GDV_RETURN_NOT_OK(Repeat(&piece));
+      if ((leaves += Leaves(*piece)) > 63) return TooManyPositions();
       left = left->kind == Re::kEmpty ? std::move(piece) : Mk(Re::kCat, std::move(left), std::move(piece));
     }
     *out = std::move(left);
@@ -126,6 +178,7 @@ class Parser {
       const char c = p_[i_];
       if (c == '*' || c == '+' || c == '?') {
         i_++;
+        if (++atoms_ > kMaxAtoms) return Bad("more than " + std::to_string(kMaxAtoms) + " atoms and quantifiers");
         atom = Mk(c == '*' ? Re::kStar : c == '+' ? Re::kPlus : Re::kOpt, std::move(atom));
       } else if (c == '{') {
         size_t j = i_ + 1;
@@ -173,10 +226,10 @@ class Parser {
     switch (c) {
       case 'd': *set = Digits(); return Status::OK();
       case 'w': *set = WordChars(); return Status::OK();
-      case 's': *set = Spaces(); return Status::OK();
+      case 's': *set = PerlSpaces(); return Status::OK();
       case 'D': *set = ~Digits(); negated_escape_ = true; return Status::OK();
       case 'W': *set = ~WordChars(); negated_escape_ = true; return Status::OK();
-      case 'S': *set = ~Spaces(); negated_escape_ = true; return Status::OK();
+      case 'S': *set = ~PerlSpaces(); negated_escape_ = true; return Status::OK();
       case 't': *set = Range('\t', '\t'); return Status::OK();
       case 'n': *set = Range('\n', '\n'); return Status::OK();
       case 'r': *set = Range('\r', '\r'); return Status::OK();
@@ -280,10 +333,10 @@ class Parser {
     if (fold_) set = FoldCase(set);
     if (negate) {
       if (!extras.empty()) return Bad("negated character class with non-ASCII members");
-      *out = WholeCharacter(AnyLead() & ~set);
+      *out = WholeCharacterOutside(set, fold_);
       return Status::OK();
     }
-    ReP all = set.any() || extras.empty() ? MkSet(set) : nullptr;
+    ReP all = set.any() || extras.empty() ? (fold_ ? FoldedSet(set) : MkSet(set)) : nullptr;
     for (const std::string& x : extras) {
       ReP seq;
       for (unsigned char k : x) seq = seq ? Mk(Re::kCat, std::move(seq), MkSet(Range(k, k))) : MkSet(Range(k, k));
@@ -294,9 +347,11 @@ class Parser {
   }
   Status Atom(ReP* out) {
     const unsigned char c = static_cast<unsigned char>(p_[i_]);
+    if (++atoms_ > kMaxAtoms) return Bad("more than " + std::to_string(kMaxAtoms) + " atoms and quantifiers");
     switch (c) {
       case '(': {
         i_++;
+        if (depth_ >= kMaxNesting) return Bad("groups nested deeper than " + std::to_string(kMaxNesting));
         if (More() && p_[i_] == '?') {
           if (i_ + 1 < p_.size() && p_[i_ + 1] == ':') {
             i_ += 2;
@@ -309,7 +364,9 @@ class Parser {
             return Bad("group flags inside the pattern / look-around");
           }
         }
+        depth_++;
         GDV_RETURN_NOT_OK(Alt(out));
+        depth_--;
         if (!More() || p_[i_] != ')') return Bad("unmatched '('");
         i_++;
         return Status::OK();
@@ -335,7 +392,7 @@ class Parser {
         negated_escape_ = false;
         GDV_RETURN_NOT_OK(Escape(&set));
         if (fold_) set = negated_escape_ ? ~FoldCase(~set) : FoldCase(set);
-        *out = negated_escape_ ? WholeCharacter(AnyLead() & set) : MkSet(set);
+        *out = negated_escape_ ? WholeCharacterOutside(~set, fold_) : fold_ ? FoldedSet(set) : MkSet(set);
         return Status::OK();
       }
       case '^':
@@ -354,7 +411,7 @@ class Parser {
       default: {
         i_++;
         if (fold_ && c >= 0x80) return Bad("(?i) with a non-ASCII character");
-        ReP atom = MkSet(fold_ ? FoldCase(Range(c, c)) : Range(c, c));
+        ReP atom = fold_ ? FoldedSet(FoldCase(Range(c, c))) : MkSet(Range(c, c));
         // a non-ASCII character of the pattern is ONE atom (a quantifier behind it repeats the character): its lead byte
         // and the continuation bytes that follow, one position each
         if (c >= 0xC2)
@@ -371,6 +428,7 @@ class Parser {
   const std::string& p_;
   size_t i_ = 0;
   bool negated_escape_ = false;
+  int depth_ = 0, atoms_ = 0;
   bool fold_ = false;    // (?i): ASCII letters match in either case
   bool dot_nl_ = false;  // (?s): '.' matches a newline too
 };

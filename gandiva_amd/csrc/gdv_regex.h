@@ -13,11 +13,15 @@
 // Syntax taken: literals, '.', classes [a-z0-9_] and [^...] (ASCII members; non-ASCII characters as members of a positive
 // class), POSIX classes [[:alpha:]] ... inside brackets, \d \D \w \W \s \S, \t \n \r \f \v \xHH and escaped punctuation,
 // groups ( ), (?: ) and (?P<name> ), alternation |, quantifiers * + ? {m} {m,} {m,n} (and their lazy forms), the assertions
-// ^ $ \A \z \b \B anywhere, the flags (?i) (ASCII letters in either case) and (?s) ('.' matches a newline) in front of
-// everything.  '.' and negated classes consume a whole UTF-8 character (a lead byte and its continuation bytes); \b is
+// ^ $ \A \z \b \B anywhere, the flags (?i) (ASCII letters in either case — and, as RE2's simple folding has it, U+212A KELVIN
+// SIGN with k and U+017F LONG S with s, in positive and negated sets alike) and (?s) ('.' matches a newline) in front of
+// everything.  \s / \S are Perl's [\t\n\f\r ] (no vertical tab); [[:space:]] holds it.  '.' and negated classes consume a whole UTF-8 character (a lead byte and its continuation bytes); \b is
 // RE2's ASCII word boundary.  Anything else — back-references and look-around (RE2 has neither), flags inside the pattern,
 // Unicode classes \p{..}, non-ASCII range ends or negated classes with non-ASCII members, (?i) next to non-ASCII characters,
-// more than 7 distinct combinations of assertions, more than 63 positions — is refused with a message, not guessed.
+// more than 7 distinct combinations of assertions, more than 63 positions — is refused with a message, not guessed; so are
+// patterns beyond 4096 bytes, 64 levels of nesting or 512 atoms and quantifiers (the tree is walked recursively; patterns come from user SQL).
+// Texts that are not valid UTF-8: '.' and negated classes take "a lead byte and whatever continuation bytes follow" as one
+// character, which RE2 does not — the two agree on valid UTF-8 only.
 #pragma once
 #include <string>
 

@@ -580,7 +580,7 @@ static int rx_escape(rx_parser* P, rx_node* set, int* negated) { /* one escape i
   switch (c) {
     case 'D': *negated = 1; /* fall through */ case 'd': rx_add(set, '0', '9'); return 1;
     case 'W': *negated = 1; /* fall through */ case 'w': rx_add(set, '0', '9'); rx_add(set, 'a', 'z'); rx_add(set, 'A', 'Z'); rx_add(set, '_', '_'); return 1;
-    case 'S': *negated = 1; /* fall through */ case 's': rx_add(set, ' ', ' '); rx_add(set, 9, 13); return 1;
+    case 'S': *negated = 1; /* fall through */ case 's': rx_add(set, ' ', ' '); rx_add(set, 9, 10); rx_add(set, 12, 13); return 1;  /* RE2: \\s = [\\t\\n\\f\\r ], no \\v ([[:space:]] has it) */
     case 't': rx_add(set, 9, 9); return 1; case 'n': rx_add(set, 10, 10); return 1; case 'r': rx_add(set, 13, 13); return 1;
     case 'f': rx_add(set, 12, 12); return 1; case 'v': rx_add(set, 11, 11); return 1;
     case 'x': {
@@ -751,6 +751,8 @@ static int rx_set_has(const rx_node* s, int32_t cp, int fold) {
   if (s->lit >= 0) return cp == s->lit;
   int in = cp < 128 && (s->ascii[cp >> 3] & (1 << (cp & 7)));
   if (!in && fold && cp < 128 && isalpha(cp)) { int o = cp ^ 32; in = (s->ascii[o >> 3] & (1 << (o & 7))) != 0; }  /* (?i) */
+  /* RE2's (?i) is Unicode simple folding: U+212A KELVIN SIGN folds onto k, U+017F LONG S onto s */
+  if (!in && fold && (cp == 0x212A || cp == 0x17F)) { int lo = cp == 0x212A ? 'k' : 's'; in = ((s->ascii[lo >> 3] & (1 << (lo & 7))) | (s->ascii[(lo - 32) >> 3] & (1 << ((lo - 32) & 7)))) != 0; }
   for (int k = 0; k < s->nextra && !in; k++) in = cp == s->extra[k];
   return s->neg ? !in : in;
 }

@@ -928,9 +928,11 @@ REGEX_PATTERNS = [r"\d+", r"^a.*3$", r"a.b", r"^$", r"[^a-z]+", r"(foo|bar)\.ba?
                   r"colou?r", r"\W", r"^\D*$", r"(?:ab){2,}", r"a+?b", r"[a-c-]+x", r"[]x]+y", r"\x41\x2e", r"^(\d+|[a-f]+)(\.\d*)?$", r".\n.", r"é+$",
                   r"(?i)spark", r"(?i)^[a-c]+\d?$", r"(?i)colou?r|HELLO", r"(?i)[^a]b", r"[é語x]+", r"^[日é][本é]", r"(?i)\W[A-Z]",
                   r"\bab\b", r"\Bb", r"^a|c$", r"(^|-)a", r"a(b|$)", r"\Aab", r"r\z", r"(?s)a.b", r"(?is)A.B", r"(?P<w>[a-z]+)\.(?P<x>b)", r"[[:alpha:]]+\d",
-                  r"^[[:upper:]][[:lower:]]+$", r"[[:punct:][:space:]]{2}", r"\b\d+\b", r"x\b.", r"(\b|z)z", r"^$|^-$", r"é\b", r"\bé", r"^\bx", r"\B$", r"^\b\w+\b$", r"\B", r".\B", r"\Bx?", r"(?i)[^a]?\S\B"]
+                  r"^[[:upper:]][[:lower:]]+$", r"[[:punct:][:space:]]{2}", r"\b\d+\b", r"x\b.", r"(\b|z)z", r"^$|^-$", r"é\b", r"\bé", r"^\bx", r"\B$", r"^\b\w+\b$", r"\B", r".\B", r"\Bx?", r"(?i)[^a]?\S\B",
+                  # round 6 (advisor): \s / \S are Perl's (no vertical tab; [[:space:]] has it); (?i) folds U+212A onto k and U+017F onto s
+                  r"\s", r"^\S+$", r"[[:space:]]", r"[\s]x?$", r"(?i)k", r"(?i)s", r"(?i)^[^k]$", r"(?i)^[^s]+$", r"(?i)\w", r"(?i)^\W$", r"(?i)spar[k]", r"(?i)[j-l]\b", r"k", r"[^k]"]
 REGEX_WORDS = ["ab", "abc", "a", "3", "2021-03-04", "foo.bar", "bar.br", "xyzyzy", "é", "éé", "日本語", "日x語", " ", "\n", "spark", "sperk7", "Color", "colour",
-               "x@y.com", "A.", "-", "]", "c", "zz", "Hello", "0.5", "ff.", "aab", "b-a-x", "]]xy", "\t", "c日x語a"]
+               "x@y.com", "A.", "-", "]", "c", "zz", "Hello", "0.5", "ff.", "aab", "b-a-x", "]]xy", "\t", "c日x語a", "\x0b", "\u212a", "\u017f", "spar\u212a", "\u017fpark"]
 
 
 def _regex_texts(n, seed):
@@ -974,7 +976,8 @@ def _regex_want(p, texts):
     if rx is not None:
         # (RE2 is the reference where the two differ on \\B: Python's does not match in an empty text; RE2 evaluates assertions between
         # BYTES and may begin a match inside a multi-byte character, where the gap is "not a word boundary")
-        keep = [i for i, t in enumerate(texts) if "\\B" not in p or (t and t.isascii())]
+        # (round 6: Python's \s holds the vertical tab, RE2's does not; under re.ASCII Python's (?i) does not fold U+212A / U+017F, RE2's does)
+        keep = [i for i, t in enumerate(texts) if ("\\B" not in p or (t and t.isascii())) and not any(c in t for c in "\x0b\u212a\u017f")]
         assert [want[i] for i in keep] == [rx.search(texts[i]) is not None for i in keep], f"RE2 and Python's re disagree on {p!r}"
     return want
 
@@ -1017,7 +1020,8 @@ def test_regular_expressions_outside_the_syntax_are_refused_with_a_reason():
     table = np.zeros(6360, np.uint8)
     for pat, why in ((r"(a)\1", "escape"), (r"\pL", "escape"), (r"a(?i)b", "group flags"),
                      (r"[^é]", "non-ASCII"), (r"[à-ÿ]", "non-ASCII"), (r"(?i)é", "non-ASCII"), (r"(?m)^a", "group flags"), (r"(ab", "unmatched"),
-                     (r"a{3,2}", "n < m"), (r"(abcdefgh){9}", "63"), (r"a*+", "possessive"), (r"(?=x)", "look-around"), (r"[[:foo:]]", "POSIX")):
+                     (r"a{3,2}", "n < m"), (r"(abcdefgh){9}", "63"), ("a." * 20000, "longer than"), ("(" * 3000, "nested deeper"), ("a." * 40, "63"),
+                     ("()" * 600, "atoms"), ("a" + "*" * 600, "atoms"), ("^" * 600, "atoms"), (r"a*+", "possessive"), (r"(?=x)", "look-around"), (r"[[:foo:]]", "POSIX")):
         raw = pat.encode()
         assert lib.lib().gdv_compile_regex(raw, C.c_int64(len(raw)), table.ctypes.data_as(C.c_void_p)) != 0, pat
         assert why in lib.last_error(), (pat, lib.last_error())

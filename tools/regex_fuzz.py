@@ -14,7 +14,7 @@ seed=int(sys.argv[1]); N=int(sys.argv[2])
 rng=np.random.default_rng(seed)
 atoms=["a","b","c",".","\\d","\\w","\\s","\\S","\\W","\\D","[ab]","[^a]","[a-c]","é","語","x","\\.","(ab|c)","(a|b)","(?:bc)","\\b","\\B","(^|-)","($|b)","^","$","\\A","\\z","[[:alpha:]]","[é語]","(?P<n>a|\\d)","-"," ","(é|\\b)","[^\\d]"]
 quants=["","","","*","+","?","{2}","{1,3}","{2,}","*?","+?"]
-texts=T._regex_texts(500,seed=seed)+T.REGEX_WORDS+["abcabc","aab","ccc","a.c","bcbc","é.é","a-b","ab ab","-a","b-","a\nb","語é語","é語a","aé","éa"]
+texts=T._regex_texts(500,seed=seed)+T.REGEX_WORDS+["abcabc","aab","ccc","a.c","bcbc","é.é","a-b","ab ab","-a","b-","a\nb","語é語","é語a","aé","éa","\x0b","a\x0bb","\u212a","\u017f"]
 arr=pa.array(texts,pa.string()); off=np.frombuffer(arr.buffers()[1],np.int32)[:len(texts)+1].copy(); size=int(off[-1])
 data=np.concatenate([np.frombuffer(arr.buffers()[2],np.uint8)[:size],np.zeros(64,np.uint8)])
 batch=pa.RecordBatch.from_arrays([arr],names=["s"]); b=g.TreeExprBuilder(); s=b.make_field(batch.schema.field(0))
