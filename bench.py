@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Headline benchmark: BASELINE.json's metric on BASELINE.json's config.
+"""Headline benchmark: BASELINE.json's metric on BASELINE.json's config — and, in the same line ("workloads"), the
+other BASELINE configs (C1, C3, C4, C5) and the fused filter -> project (K2F), each timed, verified and priced
+against the roofline by the same run (round 6).
 
   metric   million rows/s (+ achieved HBM GB/s in `roofline`) of the 10-expression float64
            Projector with 10 % nulls per column (config C2), 2^28 rows PER GPU.
@@ -17,7 +19,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
   cpu_baseline  the CPU restatement (oracle/, "port") timed on this host's cores on a
                 bounded prefix of the same workload.
 
-Other workloads (not the bench line; for profiling):  --workload c3  (filter, 10^9 rows)
+One workload alone (for profiling):  --workload c3 | c4 | c5 | k2f | c1      --no-extras: the headline without "workloads"
 """
 import argparse
 import json
@@ -36,7 +38,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    p.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "k2f"])
     p.add_argument("--rows", type=int, default=0, help="rows per GPU (default: BASELINE size)")
     p.add_argument("--cpu-rows", type=int, default=1 << 26, help="rows of the cpu_baseline sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -54,8 +56,18 @@ def parse():
     p.add_argument("--no-verify", action="store_true",
                    help="skip the post-loop check of the outputs the timed loop produced")
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                   help="weak: --rows per GPU (default); strong: ONE logical batch of --rows rows "
-                        "row-sharded across the ranks by gandiva_amd.shard (c2 only)")
+                   help="weak: --rows per GPU (default); strong: ONE logical batch of --rows rows (default: BASELINE's size "
+                        "for the workload: C2 2^28, C3 10^9, C4 6*10^9) row-sharded across the ranks by gandiva_amd.shard")
+    p.add_argument("--no-extras", action="store_true",
+                   help="default invocation only: leave out the 'workloads' object (the other BASELINE configs + K2F)")
+    p.add_argument("--extras", default="c1,c3,k2f,c5,c4", help="sub-workloads of the default line, in this order")
+    p.add_argument("--sub-steps", type=int, default=10)
+    p.add_argument("--sub-warmup", type=int, default=2)
+    p.add_argument("--sub-placements", type=int, default=3, help="placement trials of the projection sub-workloads (c1, c4)")
+    p.add_argument("--sub-cpu-seconds", type=float, default=3.0)
+    p.add_argument("--data-c5", default="philox", choices=["philox", "pcg64"],
+                   help="c5 inputs: philox = BASELINE.md §4's distributions from torch's device generator (seconds); "
+                        "pcg64 = its frozen numpy stream (generated on one host core: ~1 min for 10^8 rows)")
     return p.parse_args()
 
 
@@ -176,65 +188,6 @@ def pyarrow_compute_c2(batch):
     return {"engine": f"pyarrow.compute {pa.__version__}, 13 kernel calls per pass, 1 thread",
             "value": round(batch.num_rows * reps / el / 1e6, 2), "unit": "million rows/s",
             "sample": f"{reps} passes over {batch.num_rows} rows, {el:.1f} s"}
-
-
-def cpu_baseline_c3(rows):
-    from gandiva_amd import workloads as W
-    from oracle import oracle
-    cores = effective_cores()
-    batch = W.c3_batch(rows)
-    cond = W.c3_condition()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        oracle.filter_indices(cond, batch, "int32", threads=cores)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
-            break
-    return {"value": round(rows * reps / el / 1e6, 2), "unit": "million rows/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{reps} passes x {rows} rows, {cores} thr predicate + serial index walk, {el:.0f}s",
-            "host": host_description()}
-
-
-def cpu_baseline_c4(rows):
-    from gandiva_amd import workloads as W
-    from oracle import oracle
-    cores = effective_cores()
-    rows = min(rows, 1 << 22)
-    batch = W.c4_batch(rows)
-    exprs = W.c4_expressions()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        oracle.project(exprs, batch, threads=cores)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
-            break
-    return {"value": round(rows * reps / el / 1e6, 2), "unit": "million rows/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{reps} passes x {rows} rows, {cores} thr, {el:.0f}s", "host": host_description()}
-
-
-def cpu_baseline_c5(rows):
-    from gandiva_amd import workloads as W
-    from oracle import oracle
-    rows = min(rows, 1 << 21)
-    batch = W.c5_batch(rows)
-    exprs = W.c5_expressions()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        oracle.project(exprs, batch)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
-            break
-    return {"value": round(rows * reps / el / 1e6, 2), "unit": "million rows/s", "cores": 1,
-            "kind": "port",
-            "sample": f"{reps} passes x {rows} rows, 1 thr, {el:.0f}s", "host": host_description()}
 
 
 def load_traffic(tag, running_kernel):
@@ -407,6 +360,21 @@ def verify_outputs(workload, rows, dbatch, result):
             if not torch.equal(idx[first:first + want.numel()], want) or (
                     first + want.numel() < idx.numel() and int(idx[first + want.numel()]) < lo + m):
                 return {"ok": False, "what": f"C3 selection vector differs from torch.nonzero in rows [{lo}, {lo + m})"}
+        elif workload == "k2f":
+            outs, sel = result
+            a, b = (col.data.view(torch.int64)[lo:lo + m] for col in dbatch.columns)
+            keep = (a > W.C3_K1) & (b < W.C3_K2)
+            want = torch.nonzero(keep).view(-1) + lo
+            count = sel.num_slots
+            idx = sel.indices[:count].view(torch.int32).to(torch.int64) & 0xffffffff
+            first = int(torch.searchsorted(idx, torch.tensor([lo], device=idx.device, dtype=torch.int64)))
+            vals = outs[0].data.view(torch.int64)[first:first + want.numel()]
+            nb = want.numel() // 8
+            vbits = outs[0].validity[(first + 7) // 8:(first + 7) // 8 + max(nb - 2, 0)]
+            if (not torch.equal(idx[first:first + want.numel()], want)
+                    or (first + want.numel() < idx.numel() and int(idx[first + want.numel()]) < lo + m)
+                    or not torch.equal(vals, (a + b)[keep]) or not bool((vbits == 255).all())):
+                return {"ok": False, "what": f"K2F selection vector / compacted a+b differ from torch in rows [{lo}, {lo + m})"}
         elif workload == "c5":
             like, sub, up = result
             off = dbatch.columns[0].offsets.view(torch.int32)[lo:lo + m + 1].to(torch.int64)
@@ -460,7 +428,7 @@ def hbm_ceilings(bytes_per_buffer=4 << 30):
 
 
 # the workload's traffic as (input streams, output streams) of 8-byte elements, for the shape-matched ceiling
-CEILING_SHAPE = {"c1": (3, 1), "c2": (4, 10), "c3": (2, 0), "c4": (7, 5), "c5": (2, 3)}
+CEILING_SHAPE = {"c1": (3, 1), "c2": (4, 10), "c3": (2, 0), "c4": (7, 5), "c5": (2, 3), "k2f": (2, 0)}
 
 
 def stream_ceiling(num_read, num_write, bytes_per_stream=1 << 30):
@@ -589,6 +557,376 @@ def launch_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+# ------------------------------------------------------------------------------------------------
+# workloads: set-up, placement search, timed loop, one (sub-)line each
+
+WORKLOAD_TEXT = {
+    "c1": ("million rows/sec, (a+b)*c int32 Projector", "int32", "C1 shape at scale: (a+b)*c over int32, no nulls"),
+    "c2": ("million rows/sec, 10-expr float64 Projector (10% nulls)", "f64",
+           "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column"),
+    "c3": ("million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)", "int64",
+           "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector"),
+    "c4": ("million rows/sec, TPC-H Q1 projections (decimal128 + datediff)", "decimal128",
+           "C4: ep*(1-disc), ep*(1-disc)*(1+tax) decimal128(15,2) inputs, datediff(1998-12-01, shipdate date32)"),
+    "c5": ("million rows/sec, utf8 like/substr/upper", "u8",
+           "C5: like '%spark%', substr(s,2,5), upper(s) over utf8 lengths U[4,20]"),
+    "k2f": ("million rows/sec, fused Filter -> Projector (a>k1 AND b<k2; a+b; uint32 selection vector)", "int64",
+            "K2F: C3's condition, a + b projected for the selected rows and the uint32 selection vector, ONE kernel "
+            "(SURVEY §8 f3: the selection-vector consumer)"),
+}
+DEFAULT_ROWS = {"c1": 1 << 28, "c2": 1 << 28, "c3": 1_000_000_000, "c4": 750_000_000, "c5": 100_000_000,
+                "k2f": 1_000_000_000}
+# BASELINE.json's logical sizes for --scaling strong: ONE batch of this many rows row-sharded over the ranks
+STRONG_ROWS = {"c1": 1 << 28, "c2": 1 << 28, "c3": 1_000_000_000, "c4": 6_000_000_000, "c5": 100_000_000,
+               "k2f": 1_000_000_000}
+AOT_KERNELS = {"c3": ["ScanReduce", "ScanSpine", "ScanApply", "EmitIndices"], "c5": ["the AOT segmented offsets scan"],
+               "k2f": ["PublishCount"]}
+
+
+def tensors_of(dbatch, outs):
+    ts = []
+    for c in list(dbatch.columns) + list(outs or []):
+        ts += [t for t in (c.validity, c.data, c.offsets) if t is not None]
+    return ts
+
+
+def setup_workload(name, rows, args, rank=0):
+    """Inputs generated in HBM, the operator made, outputs allocated and touched by one evaluation.
+    Returns a namespace: step() = one pass of the hot path over the batch (what is timed)."""
+    import types
+    import torch
+    import gandiva_amd as gandiva
+    from gandiva_amd import workloads as W
+    wl = types.SimpleNamespace(name=name, rows=rows, placeable=name in ("c1", "c2", "c4"), outs=None, out=None,
+                               data_stream="BASELINE.md §4's distributions from torch's device generator (Philox), "
+                                           "not its PCG64 stream")
+    if name == "c2":
+        gen = W.c2_device_batch_pcg64 if args.data == "pcg64" else W.c2_device_batch
+        # every rank: its own shard (rank 0 = BASELINE.md §4's seeds, rank r = seeds + 1000 r)
+        wl.dbatch = gen(rows, seed_offset=1000 * rank)
+        if args.data == "pcg64":
+            wl.data_stream = ("BASELINE.md §4: numpy PCG64, value seeds 42-45, mask seeds 142-145 (rank r: + 1000 r); "
+                              "generated on the host, resident in HBM before the timed region")
+        wl.obj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
+        wl.bytes_per_row, wl.read_per_row = W.C2_BYTES_PER_ROW, 4 * 8 + 4 / 8
+        wl.kernel_desc = "fused 10-expression projection kernel (1 launch per step)"
+    elif name == "c1":
+        g = torch.Generator(device="cuda")
+        cols = []
+        for k in range(3):
+            g.manual_seed(1 + k)
+            data = torch.empty(rows, dtype=torch.int32, device="cuda")
+            data.random_(-(1 << 15), 1 << 15, generator=g)
+            cols.append(gandiva.DeviceColumn(W.c1_schema().field(k).type, rows, None, data.view(torch.uint8)))
+        wl.dbatch = gandiva.DeviceBatch(W.c1_schema(), cols, rows)
+        wl.obj = gandiva.make_projector(W.c1_schema(), W.c1_expressions(), None)
+        wl.bytes_per_row, wl.read_per_row = 16 + 1 / 8, 12
+        wl.kernel_desc = "fused (a+b)*c int32 projection kernel"
+    elif name == "c4":
+        wl.dbatch = W.c4_device_batch(rows)
+        wl.obj = gandiva.make_projector(W.c4_schema(), W.c4_expressions(), None)
+        wl.bytes_per_row = 3 * 16 + 4 + 2 * 16 + 4 + 3 / 8  # inputs carry no validity buffers here
+        wl.read_per_row = 3 * 16 + 4
+        wl.kernel_desc = "fused decimal128 x2 + datediff projection kernel (1 launch per step)"
+    elif name == "c5":
+        wl.dbatch = W.c5_device_batch_philox(rows) if args.data_c5 == "philox" else W.c5_device_batch(rows)
+        if args.data_c5 != "philox":
+            wl.data_stream = "BASELINE.md §4: numpy PCG64 seed 21, generated on the host"
+        wl.obj = gandiva.make_projector(W.c5_schema(), W.c5_expressions(), None)
+        wl.kernel_desc = ("wave-shaped var-len plan: offsets-only pre-pass + offsets scan + main kernel of "
+                          "independent wave tiles (byte sweep per 64-row sub-tile: match bits + LDS mirror of the span, "
+                          "flat output from the sweep's registers, substr staged LDS -> LDS)")
+    elif name == "c3":
+        wl.dbatch = W.c3_device_batch(rows)
+        wl.obj = gandiva.make_filter(W.c3_schema(), W.c3_condition())
+        wl.out = torch.empty(rows, dtype=torch.int32, device="cuda")
+        wl.kernel_desc = "predicate+ballot kernel, offsets scan (3 launches), index emit"
+    elif name == "k2f":
+        wl.dbatch = W.c3_device_batch(rows)
+        wl.obj = gandiva.make_filter_project(W.c3_schema(), W.c3_condition(), W.c3_sum_expression(), "int32")
+        if not wl.obj.fused:
+            raise RuntimeError("the fused filter-project plan was not taken")
+        wl.out = torch.empty(rows, dtype=torch.int32, device="cuda")
+        wl.kernel_desc = ("ONE kernel: predicate, decoupled look-back over workgroup tiles, selected rows' a+b and "
+                          "row indices staged in a wave-private LDS window and stored compacted (+ a one-thread count kernel)")
+    else:
+        raise SystemExit(f"unknown workload {name}")
+
+    if name in ("c1", "c2", "c4", "c5"):
+        wl.outs = wl.obj.evaluate_device(wl.dbatch)       # allocates + first touch
+        wl.result = lambda: wl.outs
+
+        def step():
+            wl.obj.evaluate_device(wl.dbatch, outputs=wl.outs, sync=False)
+        if name == "c5":
+            outs = wl.outs
+            in_bytes = 4 * (rows + 1) + int(sum(o.data_used for o in outs[2:]))  # offsets + data (upper preserves bytes)
+            out_bytes = rows / 8 + sum(4 * (rows + 1) + o.data_used for o in outs[1:]) + 3 * rows / 8
+            wl.bytes_per_row, wl.read_per_row = (in_bytes + out_bytes) / rows, in_bytes / rows
+    elif name == "c3":
+        sel = wl.obj.evaluate_device(wl.dbatch, "int32", out=wl.out)
+        wl.bytes_per_row, wl.read_per_row = 16 + 4 * sel.num_slots / rows, 16
+
+        def step():
+            wl.obj.evaluate_device(wl.dbatch, "int32", out=wl.out)
+
+        def result():
+            wl.out.fill_(-1)       # the indices the check reads are written by THIS call, after the loop's
+            return wl.obj.evaluate_device(wl.dbatch, "int32", out=wl.out)
+        wl.result = result
+    else:  # k2f
+        wl.outs, sel = wl.obj.evaluate_device(wl.dbatch, indices=wl.out)
+        share = sel.num_slots / rows
+        wl.bytes_per_row, wl.read_per_row = 16 + (4 + 8 + 1 / 8) * share, 16
+
+        def step():
+            wl.obj.evaluate_device(wl.dbatch, outputs=wl.outs, indices=wl.out, sync=False)
+
+        def result():
+            wl.out.fill_(-1)
+            wl.outs[0].data.fill_(0)
+            return wl.obj.evaluate_device(wl.dbatch, outputs=wl.outs, indices=wl.out)
+        wl.result = result
+    wl.step = step
+    wl.footprint = sum(t.numel() * t.element_size() for t in tensors_of(wl.dbatch, wl.outs)) + (
+        wl.out.numel() * 4 if wl.out is not None else 0)
+    return wl
+
+
+def kernel_names_of(wl):
+    import re
+    seen = []
+    for m in re.findall(r"gdv_k_[0-9a-f]{16}", wl.obj.llvm_ir or ""):
+        if m not in seen:
+            seen.append(m)
+    return seen
+
+
+def search_placements(wl, wanted):
+    """Placement (round 5).  The same kernel on the same data runs 4.9 .. 7.0 ms per C2 step depending on WHERE the
+    driver placed the buffers — a property of the allocation that stays with it (profiles/r05_box_states.txt).  The
+    columns are copied into, and the outputs allocated as, fresh allocations up to `wanted` times; each placement is
+    timed for 3 steps after 2 untimed, the fastest is kept, and EVERY trial's time goes into the line (the first entry
+    = the first allocation, what a caller who allocates once gets).
+    Round 6: memory is bounded — the best placement, the candidate and ONE loser are alive at a time (the loser stays
+    until the next candidate exists, so that the driver cannot hand the same pages back), and the number of trials is
+    cut to what torch.cuda.mem_get_info() says fits (C4: 66 GB per placement)."""
+    import torch
+    import gandiva_amd as gandiva
+    if wanted <= 1 or not wl.placeable:
+        return None
+
+    def time_placement():
+        for _ in range(2):
+            wl.step()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            wl.step()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / 3
+    for _ in range(40):   # (the first ~0.2 s after the generation are not representative of any placement)
+        wl.step()
+    trials = [round(time_placement(), 4)]
+    best_ms, best, loser = trials[0], (wl.dbatch, wl.outs), None
+    while len(trials) < wanted:
+        free_b, _total = torch.cuda.mem_get_info()
+        if free_b < wl.footprint * 1.05 + (2 << 30):
+            if loser is None:
+                break                     # not even one more placement fits next to the best one
+            loser = None                  # give the loser's memory back first (its pages may come back: still a trial)
+            torch.cuda.empty_cache()
+            if torch.cuda.mem_get_info()[0] < wl.footprint * 1.05 + (2 << 30):
+                break
+        cols = [gandiva.DeviceColumn(c.type, c.length, None if c.validity is None else c.validity.clone(), c.data.clone())
+                for c in best[0].columns]
+        wl.dbatch = gandiva.DeviceBatch(best[0].schema, cols, wl.rows)
+        wl.outs = wl.obj.evaluate_device(wl.dbatch)      # fresh output allocations
+        del cols
+        loser = None
+        torch.cuda.empty_cache()
+        t_ms = time_placement()
+        trials.append(round(t_ms, 4))
+        if t_ms < best_ms:
+            loser, best_ms, best = best, t_ms, (wl.dbatch, wl.outs)
+        else:
+            loser = (wl.dbatch, wl.outs)
+    wl.dbatch, wl.outs = best
+    del best, loser
+    torch.cuda.empty_cache()
+    return trials
+
+
+def timed_loop(wl, steps, warmup, barrier=None, prewarm_s=0.4, sampler=None):
+    """Steady state before anything is counted: the GPU's clocks and power state are still moving for the first few
+    hundred milliseconds of work (round 4, one box, same kernel, same buffers: 5.58 ms per step in the first second after
+    the inputs were generated, 4.90 ms a second later).  ~prewarm_s of untimed steps come first (config.prewarm_steps),
+    THEN the W warm-up steps, then EXACTLY K timed ones between two barriers; HIP events around every step."""
+    import torch
+    torch.cuda.synchronize()
+    t_probe = time.perf_counter()
+    wl.step()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t_probe, 1e-5)
+    prewarm = 0 if os.environ.get("GDV_BENCH_NO_PREWARM") else max(10, min(2000, int(prewarm_s / one)))
+    for _ in range(prewarm):
+        wl.step()
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        wl.step()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    if barrier:
+        barrier()
+    else:
+        torch.cuda.synchronize()
+    if sampler:
+        sampler.start()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        starts[i].record()
+        wl.step()
+        ends[i].record()
+    if barrier:
+        barrier()
+    else:
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if sampler:
+        sampler.stop()
+    return elapsed, [s.elapsed_time(e) for s, e in zip(starts, ends)], prewarm
+
+
+def verify(wl, no_verify):
+    if no_verify:
+        return {"ok": None, "what": "skipped (--no-verify)"}
+    try:
+        return verify_outputs(wl.name, wl.rows, wl.dbatch, wl.result())
+    except Exception as e:  # a check that cannot run is a failed check
+        return {"ok": False, "what": f"verification raised {type(e).__name__}: {e}"}
+
+
+def roofline_of(wl, dev_ms, trials, quote_traffic):
+    mean_ms = sum(dev_ms) / len(dev_ms)
+    achieved = wl.bytes_per_row * wl.rows / (mean_ms * 1e-3) / 1e9
+    names = kernel_names_of(wl)
+    traffic, source = (load_traffic(wl.name, names[0] if names else None) if quote_traffic
+                       else (None, "PMC passes are taken at the BASELINE size only"))
+    r = {
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "traffic_source": source,
+        "kernel_name": names[0] if names else None,
+        "kernel_names": names + AOT_KERNELS.get(wl.name, []),
+        "kernel": wl.kernel_desc,
+        "algorithmic_bytes_per_row": round(wl.bytes_per_row, 3),
+        # SURVEY.md §8d: the read and write shares of `achieved`, separately
+        "read_bytes_per_row": round(wl.read_per_row, 3),
+        "write_bytes_per_row": round(wl.bytes_per_row - wl.read_per_row, 3),
+        "achieved_read": round(achieved * wl.read_per_row / wl.bytes_per_row, 1),
+        "achieved_write": round(achieved * (1 - wl.read_per_row / wl.bytes_per_row), 1),
+        "kernel_ms": round(mean_ms, 4),
+        "kernel_ms_min": round(min(dev_ms), 4),
+        "kernel_ms_max": round(max(dev_ms), 4),
+        # ms per step of every placement tried before the timed loop (first = the first allocation); the
+        # timed loop ran on the fastest.  null: one allocation, no trials
+        "placement_trials_ms": trials,
+    }
+    if trials:
+        # what a caller who allocates ONCE gets (first entry), and the middle of what this box offered
+        alg = wl.bytes_per_row * wl.rows / 1e9
+        med = sorted(trials)[len(trials) // 2] if len(trials) % 2 else sum(sorted(trials)[len(trials) // 2 - 1: len(trials) // 2 + 1]) / 2
+        r["frac_first_allocation"] = round(alg / (trials[0] * 1e-3) / HBM_PEAK_GBS, 4)
+        r["frac_median_placement"] = round(alg / (med * 1e-3) / HBM_PEAK_GBS, 4)
+        r["frac_worst_placement"] = round(alg / (max(trials) * 1e-3) / HBM_PEAK_GBS, 4)
+    return r, achieved, mean_ms
+
+
+def short_cpu_baseline(name, budget_s):
+    """The oracle ("port") on this host's cores on a bounded sample of the same workload (a few seconds)."""
+    from gandiva_amd import workloads as W
+    from oracle import oracle
+    host = host_description()
+    cores = host["usable_cores"]
+    if name == "c1":
+        rows = 1 << 24
+        batch, exprs = W.c1_batch(rows), W.c1_expressions()
+        outs = oracle.alloc_outputs(exprs, rows)
+        fn, thr = (lambda: oracle.project(exprs, batch, threads=cores, out=outs)), cores
+    elif name == "c3":
+        rows = 1 << 25
+        batch, cond = W.c3_batch(rows), W.c3_condition()
+        fn, thr = (lambda: oracle.filter_indices(cond, batch, "int32", threads=cores)), cores
+    elif name == "k2f":
+        rows = 1 << 25
+        batch, cond, exprs = W.c3_batch(rows), W.c3_condition(), W.c3_sum_expression()
+
+        def fn():
+            idx = oracle.filter_indices(cond, batch, "int32", threads=cores)
+            oracle.project(exprs, oracle.take_rows(batch, idx.to_numpy()), threads=cores)
+        thr = cores
+    elif name == "c4":
+        rows = 1 << 22
+        batch, exprs = W.c4_batch(rows), W.c4_expressions()
+        fn, thr = (lambda: oracle.project(exprs, batch, threads=cores)), cores
+    elif name == "c5":
+        rows = 1 << 20
+        batch, exprs = W.c5_batch(rows), W.c5_expressions()
+        fn, thr = (lambda: oracle.project(exprs, batch)), 1
+    else:
+        raise KeyError(name)
+    fn()
+    rate, reps, el = timed_passes(fn, rows, budget_s, 200)
+    return {"value": round(rate / 1e6, 2), "unit": "million rows/s", "cores": thr, "kind": "port",
+            "sample": f"{reps} passes x {rows} rows, {thr} thr, {el:.1f}s", "cpu_model": host["cpu_model"],
+            "loadavg": host["loadavg"]}
+
+
+def sub_line(name, args):
+    """One BASELINE config as a sub-object of the bench line: its own inputs, timed loop (HIP events per step),
+    verification against torch and a short CPU baseline.  Everything it allocated is released on return."""
+    import torch
+    t_wall = time.perf_counter()
+    rows = DEFAULT_ROWS[name]
+    wl = setup_workload(name, rows, args)
+    trials = search_placements(wl, min(args.placements, args.sub_placements))
+    elapsed, dev_ms, prewarm = timed_loop(wl, args.sub_steps, args.sub_warmup, prewarm_s=0.25)
+    verification = verify(wl, args.no_verify)
+    roof, achieved, mean_ms = roofline_of(wl, dev_ms, trials, True)
+    metric, dtype, text = WORKLOAD_TEXT[name]
+    line = {
+        "metric": metric,
+        "value": round(rows * args.sub_steps / elapsed / 1e6, 1),
+        "unit": "million rows/s",
+        "steps": args.sub_steps,
+        "warmup": args.sub_warmup,
+        "ms_per_step": round(elapsed / args.sub_steps * 1e3, 4),
+        "kernel_ms": round(mean_ms, 4),
+        "dtype": dtype,
+        "verified": None if args.no_verify else bool(verification["ok"]),
+        "verification": verification,
+        "config": {"workload": text, "rows": rows, "prewarm_steps": prewarm, "data_stream": wl.data_stream,
+                   "residency": "inputs and outputs in HBM (zero-copy C-ABI path)"},
+        "roofline": roof,
+    }
+    del wl
+    torch.cuda.empty_cache()
+    if not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = short_cpu_baseline(name, args.sub_cpu_seconds)
+        except Exception as e:  # the baseline must never take the bench line down
+            line["cpu_baseline"] = {"value": None, "unit": "million rows/s", "cores": 0, "kind": "port",
+                                    "sample": f"failed: {e}"}
+    line["wall_s"] = round(time.perf_counter() - t_wall, 1)
+    return line
+
+
 def main():
     args = parse()
     if args.inproc:
@@ -597,8 +935,6 @@ def main():
         return launch_ranks(args)
     import torch
     import torch.distributed as dist
-    import gandiva_amd as gandiva
-    from gandiva_amd import workloads as W
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -629,145 +965,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    strong = args.scaling == "strong" and args.workload == "c2"
+    # rows of this rank.  weak: --rows (default: the BASELINE size) PER GPU.  strong: ONE logical batch of the
+    # BASELINE size (C2 2^28, C3 10^9, C4 6*10^9 = 750 M per GPU on 8) row-sharded on 1024-row boundaries: this
+    # rank generates and evaluates only its own range (gdv_shard_bounds; no collective on the data path).
+    strong = args.scaling == "strong"
     logical_rows = None
-    if args.workload == "c2":
-        rows = args.rows or (1 << 28)
-        if strong:
-            # ONE logical batch of `rows` rows, row-sharded on 1024-row boundaries: this rank
-            # generates and evaluates only its own range (no collective on the data path)
-            from gandiva_amd import shard
-            logical_rows = rows
-            lo, hi = shard.shard_bounds(logical_rows, world, rank)
-            rows = max(hi - lo, 1)
-        # every rank: its own shard (rank 0 = BASELINE.md §4's seeds, rank r = seeds + 1000 r)
-        gen = W.c2_device_batch_pcg64 if args.data == "pcg64" else W.c2_device_batch
-        dbatch = gen(rows, seed_offset=1000 * rank)
-        proj = gandiva.make_projector(W.c2_schema(), W.c2_expressions(), None)
-        outs = proj.evaluate_device(dbatch)  # allocates + first touch
-        bytes_per_row = W.C2_BYTES_PER_ROW
-        read_per_row = 4 * 8 + 4 / 8
+    rows = args.rows or DEFAULT_ROWS[args.workload]
+    if strong:
+        from gandiva_amd import shard
+        logical_rows = args.rows or STRONG_ROWS[args.workload]
+        lo, hi = shard.shard_bounds(logical_rows, world, rank)
+        rows = max(hi - lo, 1)
+        if args.workload == "c4" and rows * 89 > 0.9 * torch.cuda.get_device_properties(device_index).total_memory:
+            raise SystemExit(f"bench.py --workload c4 --scaling strong: {logical_rows} rows over {world} GPU(s) = {rows} rows "
+                             f"({rows * 89 / 1e9:.0f} GB) per GPU do not fit its HBM; BASELINE's configuration is 8 GPUs "
+                             f"(750 M rows each) — pass --rows for a smaller logical batch")
+    wl = setup_workload(args.workload, rows, args, rank)
+    placement_trials = search_placements(wl, args.placements)
 
-        def step():
-            proj.evaluate_device(dbatch, outputs=outs, sync=False)
-        kernel_desc = "fused 10-expression projection kernel (1 launch per step)"
-        result = outs
-    elif args.workload == "c1":
-        rows = args.rows or (1 << 28)
-        g = torch.Generator(device="cuda")
-        cols = []
-        for k in range(3):
-            g.manual_seed(1 + k)
-            data = torch.empty(rows, dtype=torch.int32, device="cuda")
-            data.random_(-(1 << 15), 1 << 15, generator=g)
-            cols.append(gandiva.DeviceColumn(W.c1_schema().field(k).type, rows, None, data.view(torch.uint8)))
-        dbatch = gandiva.DeviceBatch(W.c1_schema(), cols, rows)
-        proj = gandiva.make_projector(W.c1_schema(), W.c1_expressions(), None)
-        outs = proj.evaluate_device(dbatch)
-        bytes_per_row = 16 + 1 / 8
-        read_per_row = 12
-        def step():
-            proj.evaluate_device(dbatch, outputs=outs, sync=False)
-        kernel_desc = "fused (a+b)*c int32 projection kernel"
-        result = outs
-    elif args.workload == "c4":
-        rows = args.rows or 750_000_000
-        dbatch = W.c4_device_batch(rows)
-        proj = gandiva.make_projector(W.c4_schema(), W.c4_expressions(), None)
-        outs = proj.evaluate_device(dbatch)
-        bytes_per_row = 3 * 16 + 4 + 2 * 16 + 4 + 3 / 8  # inputs carry no validity buffers here
-        read_per_row = 3 * 16 + 4
-
-        def step():
-            proj.evaluate_device(dbatch, outputs=outs, sync=False)
-        kernel_desc = "fused decimal128 x2 + datediff projection kernel (1 launch per step)"
-        result = outs
-    elif args.workload == "c5":
-        rows = args.rows or 100_000_000
-        dbatch = W.c5_device_batch(rows)
-        proj = gandiva.make_projector(W.c5_schema(), W.c5_expressions(), None)
-        outs = proj.evaluate_device(dbatch)
-        in_bytes = 4 * (rows + 1) + int(sum(o.data_used for o in outs[2:]))  # offsets + data (upper preserves bytes)
-        out_bytes = rows / 8 + sum(4 * (rows + 1) + o.data_used for o in outs[1:]) + 3 * rows / 8
-        bytes_per_row = (in_bytes + out_bytes) / rows
-        read_per_row = in_bytes / rows
-
-        def step():
-            proj.evaluate_device(dbatch, outputs=outs, sync=False)
-        kernel_desc = ("wave-shaped var-len plan: offsets-only pre-pass + offsets scan + main kernel of "
-                       "independent wave tiles (byte sweep per 64-row sub-tile: match bits + LDS mirror of the span, "
-                       "flat output from the sweep's registers, substr staged LDS -> LDS)")
-        result = outs
-    else:
-        rows = args.rows or 1_000_000_000
-        dbatch = W.c3_device_batch(rows)
-        flt = gandiva.make_filter(W.c3_schema(), W.c3_condition())
-        out = torch.empty(rows, dtype=torch.int32, device="cuda")
-        sel = flt.evaluate_device(dbatch, "int32", out=out)
-        bytes_per_row = 16 + 4 * sel.num_slots / rows
-        read_per_row = 16
-
-        def step():
-            flt.evaluate_device(dbatch, "int32", out=out)
-        kernel_desc = "predicate+ballot kernel, offsets scan (3 launches), index emit"
-        result = sel
-
-    # Placement (round 5).  The same kernel on the same data runs 4.9 .. 7.0 ms per C2 step depending on WHERE the
-    # driver placed the buffers — a property of the allocation that stays with it (profiles/r05_box_states.txt: UTCL1
-    # misses identical, write latency at the memory interface and DRAM write credit stalls follow the slow
-    # placements; alignment and staggering do not help).  A service that keeps its buffers would keep a good
-    # placement; the bench does the same, in the open: the columns are copied into, and the outputs allocated
-    # as, fresh allocations up to --placements times, each placement is timed for 3 steps after 2 untimed, the
-    # fastest one is kept for everything below, and EVERY trial's time goes into the line.
-    placement_trials = None
-    if args.placements > 1 and args.workload in ("c1", "c2", "c4"):
-        def time_placement():
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3):
-                step()
-            b.record()
-            torch.cuda.synchronize()
-            return a.elapsed_time(b) / 3
-        for _ in range(40):   # (the first ~0.2 s after the generation are not representative of any placement)
-            step()
-        placement_trials = [round(time_placement(), 4)]
-        best_ms, best = placement_trials[0], (dbatch, outs)
-        for _ in range(args.placements - 1):
-            cols = [gandiva.DeviceColumn(c.type, c.length, None if c.validity is None else c.validity.clone(), c.data.clone())
-                    for c in best[0].columns]
-            dbatch = gandiva.DeviceBatch(best[0].schema, cols, rows)
-            outs = proj.evaluate_device(dbatch)      # fresh output allocations (the previous sets are still alive)
-            t_ms = time_placement()
-            placement_trials.append(round(t_ms, 4))
-            if t_ms < best_ms:
-                best_ms, best = t_ms, (dbatch, outs)
-        dbatch, outs = best
-        result = outs
-        del best, cols
-        torch.cuda.empty_cache()
-
-    # Steady state before anything is counted: the GPU's clocks and power state are still moving for the
-    # first few hundred milliseconds of work (round 4, one box, same kernel, same buffers: 5.58 ms per
-    # step in the first second after the inputs were generated, 4.90 ms a second later), and 5 warm-up
-    # steps of a 5 ms kernel do not cover that.  ~0.4 s of untimed steps come first (reported as
-    # config.prewarm_steps), THEN the W warm-up steps the command line asks for, then the K timed ones.
-    torch.cuda.synchronize()
-    t_probe = time.perf_counter()
-    step()
-    torch.cuda.synchronize()
-    one = max(time.perf_counter() - t_probe, 1e-5)
-    prewarm = 0 if os.environ.get("GDV_BENCH_NO_PREWARM") else max(10, min(2000, int(0.4 / one)))
-    for _ in range(prewarm):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     try:
         bus = torch.cuda.get_device_properties(device_index).pci_bus_id
         bus_id = f"{int(bus):02x}:" if isinstance(bus, int) else str(bus)
@@ -776,34 +991,13 @@ def main():
     sampler = BoxSampler(bus_id if rank == 0 else None) if rank == 0 and os.environ.get("GDV_BENCH_NO_TELEMETRY") is None else None
     if sampler is not None and sampler.dev is None:
         sampler = BoxSampler(None)   # bus id did not match a sysfs path: take the first amdgpu card
-    barrier()
-    if sampler:
-        sampler.start()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record()
-        step()
-        ends[i].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if sampler:
-        sampler.stop()
-    dev_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
-    mean_dev_ms = sum(dev_ms) / len(dev_ms)
+    elapsed, dev_ms, prewarm = timed_loop(wl, args.steps, args.warmup, barrier=barrier, sampler=sampler)
 
     # what did the timed loop leave behind?  (outside the timed region; every rank checks its own shard)
-    if args.no_verify:
-        verification = {"ok": None, "what": "skipped (--no-verify)"}
-    else:
-        try:
-            if args.workload == "c3":
-                out.fill_(-1)          # the indices the check reads are written by THIS call, after the loop's
-                result = flt.evaluate_device(dbatch, "int32", out=out)
-            verification = verify_outputs(args.workload, rows, dbatch, result)
-        except Exception as e:  # a check that cannot run is a failed check
-            verification = {"ok": False, "what": f"verification raised {type(e).__name__}: {e}"}
+    verification = verify(wl, args.no_verify)
     bad = 0.0 if verification["ok"] in (True, None) else 1.0
 
+    roof, achieved, mean_dev_ms = roofline_of(wl, dev_ms, placement_trials, not args.rows and not strong)
     t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
     k = torch.tensor([mean_dev_ms], dtype=torch.float64, device=reduce_device)
     f = torch.tensor([bad], dtype=torch.float64, device=reduce_device)
@@ -813,21 +1007,17 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
     any_rank_failed = float(f.item()) > 0
     elapsed = float(t.item())
-    mean_dev_ms = float(k.item())
+    if float(k.item()) != mean_dev_ms:        # the slowest rank's kernel time prices the roofline
+        mean_dev_ms = float(k.item())
+        achieved = wl.bytes_per_row * rows / (mean_dev_ms * 1e-3) / 1e9
+        roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(mean_dev_ms, 4)})
 
-    running_kernel = kernel_name_of(flt if args.workload == "c3" else proj)
     if rank == 0:
         total_rows = logical_rows if strong else rows * world
-        traffic, traffic_source = (load_traffic(args.workload, running_kernel) if not args.rows
-                                   else (None, "PMC passes are taken at the BASELINE size only"))
+        metric, dtype, text = WORKLOAD_TEXT[args.workload]
         value = total_rows * args.steps / elapsed / 1e6
-        achieved = bytes_per_row * rows / (mean_dev_ms * 1e-3) / 1e9
         line = {
-            "metric": {"c1": "million rows/sec, (a+b)*c int32 Projector",
-                       "c2": "million rows/sec, 10-expr float64 Projector (10% nulls)",
-                       "c3": "million rows/sec, Filter a>k1 AND b<k2 -> SelectionVector (int64)",
-                       "c4": "million rows/sec, TPC-H Q1 projections (decimal128 + datediff)",
-                       "c5": "million rows/sec, utf8 like/substr/upper"}[args.workload],
+            "metric": metric,
             "value": round(value, 1),
             "unit": "million rows/s",
             "n_gpus": world,
@@ -837,51 +1027,23 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": {"c1": "int32", "c2": "f64", "c3": "int64", "c4": "decimal128", "c5": "u8"}[args.workload],
+            "dtype": dtype,
             "data": "synthetic",
             "verified": (None if args.no_verify else not any_rank_failed),
             "verification": verification if not any_rank_failed or not verification["ok"] else
                             {"ok": False, "what": "another rank's check failed"},
             "config": {
-                "workload": {"c1": "C1 shape at scale: (a+b)*c over int32, no nulls",
-                             "c2": "C2: 10 float64 arithmetic expressions over 4 columns, 10% nulls per column",
-                             "c3": "C3: filter a>499 AND b<250, int64 U[0,1000), uint32 selection vector",
-                             "c4": "C4: ep*(1-disc), ep*(1-disc)*(1+tax) decimal128(15,2) inputs, "
-                                   "datediff(1998-12-01, shipdate date32)",
-                             "c5": "C5: like '%spark%', substr(s,2,5), upper(s) over utf8 lengths U[4,20]"}[args.workload],
+                "workload": text,
                 "rows_per_gpu": rows,
                 "total_rows": total_rows,
                 "prewarm_steps": prewarm,
-                "data_stream": ("BASELINE.md §4: numpy PCG64, value seeds 42-45, mask seeds 142-145 (rank r: + 1000 r); "
-                                "generated on the host, resident in HBM before the timed region"
-                                if args.workload == "c2" and args.data == "pcg64" else
-                                "BASELINE.md §4's distributions from torch's device generator (Philox), not its PCG64 stream"),
-                "sharding": f"row-range x{world}, no collective",
+                "data_stream": wl.data_stream,
+                "sharding": f"row-range x{world}, no collective" + (
+                    f"; strong: ONE logical batch of {logical_rows} rows, shard r = rows [r n/N, (r+1) n/N) on 1024-row bounds" if strong else
+                    "; weak: every rank evaluates its own batch of rows_per_gpu rows"),
                 "residency": "inputs and outputs in HBM (zero-copy C-ABI path)",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "traffic_source": traffic_source,
-                "kernel_name": running_kernel,
-                "kernel": kernel_desc,
-                "algorithmic_bytes_per_row": round(bytes_per_row, 3),
-                # the read and write shares of `achieved`, separately
-                "read_bytes_per_row": round(read_per_row, 3),
-                "write_bytes_per_row": round(bytes_per_row - read_per_row, 3),
-                "achieved_read": round(achieved * read_per_row / bytes_per_row, 1),
-                "achieved_write": round(achieved * (1 - read_per_row / bytes_per_row), 1),
-                "kernel_ms": round(mean_dev_ms, 4),
-                "kernel_ms_min": round(min(dev_ms), 4),
-                "kernel_ms_max": round(max(dev_ms), 4),
-                # ms per step of every placement tried before the timed loop (first = the first allocation); the
-                # timed loop ran on the fastest.  null: one allocation, no trials
-                "placement_trials_ms": placement_trials,
-            },
+            "roofline": roof,
         }
         # the box this number was taken on: telemetry during the timed loop + what plain streaming
         # kernels reach here, now, in this process
@@ -896,16 +1058,16 @@ def main():
         try:
             if args.workload == "c2":
                 # the headline: the ceiling is taken on the very buffers the timed loop read and wrote
-                shaped = stream_ceiling_on([c.data for c in dbatch.columns], [o.data for o in outs], rows)
+                shaped = stream_ceiling_on([c.data for c in wl.dbatch.columns], [o.data for o in wl.outs], rows)
             else:
                 nr, nw = CEILING_SHAPE[args.workload]
-                per_stream = max(1 << 28, min(1 << 32, int(bytes_per_row * rows / (nr + nw)) & ~8191))
+                per_stream = max(1 << 28, min(1 << 32, int(wl.bytes_per_row * rows / (nr + nw)) & ~8191))
                 shaped = stream_ceiling(nr, nw, per_stream)
         except Exception as e:
             box["ceiling_error"] = str(e)
         if ceil:
             box["ceiling"] = ceil
-            rshare = read_per_row / bytes_per_row
+            rshare = wl.read_per_row / wl.bytes_per_row
             mixed = 1.0 / (rshare / ceil["read"] + (1.0 - rshare) / ceil["write"])
             box["ceiling_for_this_read_write_mix"] = round(mixed, 1)
             # the ceiling = the best ANY of the streaming instruments reaches for this traffic: the
@@ -924,14 +1086,33 @@ def main():
         line["roofline"]["box"] = box
         if world == 1 and not args.no_cpu_baseline:
             try:
-                fn = {"c1": lambda r: {"value": None, "unit": "million rows/s", "cores": 0, "kind": "port",
-                                       "sample": "not timed for c1"},
-                      "c2": cpu_baseline_c2, "c3": cpu_baseline_c3, "c4": cpu_baseline_c4,
-                      "c5": cpu_baseline_c5}[args.workload]
-                line["cpu_baseline"] = fn(args.cpu_rows)
+                if args.workload == "c2":
+                    line["cpu_baseline"] = cpu_baseline_c2(args.cpu_rows)
+                else:
+                    line["cpu_baseline"] = short_cpu_baseline(args.workload, 8.0)
             except Exception as e:  # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"value": None, "unit": "million rows/s", "cores": 0,
                                         "kind": "port", "sample": f"failed: {e}"}
+        # Round 6: the other BASELINE configs (and the fused filter -> project) in the SAME line, so that the driver's
+        # one run times them all: "workloads": {c1, c3, k2f, c5, c4} — each with ms_per_step, kernel_ms (HIP events),
+        # kernel names, roofline.frac on §8(d)'s algorithmic bytes, PMC traffic where a pass on the running kernel is
+        # committed, verified, and a short cpu_baseline.  Only for the default invocation (one GPU, C2, BASELINE size).
+        if world == 1 and args.workload == "c2" and not args.rows and not strong and not args.no_extras:
+            del wl
+            torch.cuda.empty_cache()
+            subs = {}
+            for name in args.extras.split(","):
+                try:
+                    subs[name] = sub_line(name, args)
+                except Exception as e:  # one workload's failure is reported, not fatal to the headline
+                    subs[name] = {"verified": False, "error": f"{type(e).__name__}: {e}"}
+                    torch.cuda.empty_cache()
+            line["workloads"] = subs
+            if not args.no_verify and not all(v.get("verified") for v in subs.values()):
+                any_rank_failed = True
+                verification = {"ok": False, "what": "a sub-workload failed: " + ", ".join(
+                    k for k, v in subs.items() if not v.get("verified"))}
+                line["verified"] = False
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -50,6 +50,11 @@ class gdv_selection_t(C.Structure):
     _fields_ = [("mode", C.c_int32), ("indices", C.c_void_p), ("num_slots", C.c_int64)]
 
 
+class gdv_shard_t(C.Structure):
+    _fields_ = [("device", C.c_int32), ("cols", C.POINTER(gdv_column_t)), ("outs", C.POINTER(gdv_out_column_t)),
+                ("out_indices", C.c_void_p), ("max_slots", C.c_int64), ("num_selected", C.c_int64)]
+
+
 # every symbol include/gandiva_amd.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 PROTOTYPES = [
@@ -120,6 +125,14 @@ PROTOTYPES = [
     ("gdv_set_device", C.c_int, [C.c_int]),
     ("gdv_get_device", C.c_int, []),
     ("gdv_shard_bounds", C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("gdv_projector_evaluate_sharded", C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(gdv_shard_t), C.c_int, C.c_uint32]),
+    ("gdv_filter_evaluate_sharded", C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.POINTER(gdv_shard_t), C.c_int, C.c_uint32,
+                                              C.POINTER(C.c_int64)]),
+    ("gdv_filter_gather_sharded", C.c_int, [C.POINTER(gdv_shard_t), C.c_int, C.c_int, C.c_int, _P, C.c_int64]),
+    ("gdv_projector_evaluate_host_sharded", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int,
+                                                      C.POINTER(gdv_out_column_t), C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    ("gdv_filter_evaluate_host_sharded", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.c_int, _P, C.c_int64,
+                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int]),
     ("gdv_device_num_cus", C.c_int, []),
     ("gdv_device_arch", C.c_char_p, []),
     ("gdv_device_alloc", C.c_int, [C.c_int64, C.POINTER(_P)]),

@@ -8,6 +8,7 @@
 #include <exception>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gdv_engine.h"
@@ -819,6 +820,246 @@ int gdv_shard_bounds(int64_t num_rows, int num_shards, int shard, int64_t* lo, i
   *lo = std::min(lo_tile * align, num_rows);
   *hi = std::min(hi_tile * align, num_rows);
   return GDV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One call, all devices (round 6): one host thread per shard, each on its own device context and stream.
+}  // extern "C"
+namespace {
+void ShardBounds(int64_t num_rows, int num_shards, int shard, int64_t* lo, int64_t* hi) {
+  (void)gdv_shard_bounds(num_rows, num_shards, shard, lo, hi);
+}
+// body(shard, stream) runs on device devices[shard]; returns the first failing shard's status
+template <typename Fn>
+int RunShards(int n, const int32_t* devices, Fn&& body) {
+  const int before = Runtime::SelectedDevice();
+  std::vector<Status> st(static_cast<size_t>(n));
+  auto work = [&](int s) {
+    try {
+      Status sel = Runtime::SelectDevice(devices[s]);
+      if (!sel.ok()) { st[s] = sel; return; }
+      Runtime& rt = Runtime::Get();
+      Status dev = rt.EnsureDevice();
+      if (!dev.ok()) { st[s] = dev; return; }
+      hipStream_t stream = nullptr;
+      Status a = rt.AcquireStream(&stream);
+      if (!a.ok()) { st[s] = a; return; }
+      st[s] = body(s, stream);
+      (void)hipStreamSynchronize(stream);
+      rt.ReleaseStream(stream);
+    } catch (const std::bad_alloc&) {
+      st[s] = Status::OutOfMemory("host allocation failed");
+    } catch (const std::exception& e) {
+      st[s] = Status::ExecutionError(std::string("internal error: ") + e.what());
+    }
+  };
+  std::vector<std::thread> threads;
+  threads.reserve(n > 1 ? n - 1 : 0);
+  for (int s = 1; s < n; s++) threads.emplace_back(work, s);
+  work(0);
+  for (auto& t : threads) t.join();
+  if (before >= 0) (void)Runtime::SelectDevice(before);
+  for (int s = 0; s < n; s++)
+    if (!st[s].ok())
+      return Fail(Status(st[s].code, "shard " + std::to_string(s) + " (device " + std::to_string(devices[s]) + "): " + st[s].msg));
+  return GDV_OK;
+}
+std::vector<OutputBuffers> ToOutputs(const gdv_out_column_t* outs, int n) {
+  std::vector<OutputBuffers> o(n > 0 ? n : 0);
+  for (int i = 0; i < n; i++) {
+    o[i].validity = outs[i].validity; o[i].validity_size = outs[i].validity_size;
+    o[i].data = outs[i].data; o[i].data_size = outs[i].data_size;
+    o[i].offsets = outs[i].offsets; o[i].offsets_size = outs[i].offsets_size;
+  }
+  return o;
+}
+int IndexWidth(SelectionMode m) { return m == SelectionMode::kUInt16 ? 2 : m == SelectionMode::kUInt32 ? 4 : 8; }
+}  // namespace
+extern "C" {
+
+int gdv_projector_evaluate_sharded(const gdv_projector_t* p, int64_t num_rows, int num_cols, int num_outs,
+                                   gdv_shard_t* shards, int num_shards, uint32_t flags) {
+  return Guarded([&]() -> int {
+  (void)flags;
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (num_shards < 1 || !shards || num_rows < 0) return Fail(Status::Invalid("bad shard list"));
+  if (p->p->plan().mode != SelectionMode::kNone) return Fail(Status::Invalid("sharded evaluation takes row-mode projectors"));
+  std::vector<int32_t> devices(num_shards);
+  for (int s = 0; s < num_shards; s++) {
+    devices[s] = shards[s].device;
+    if ((num_cols > 0 && !shards[s].cols) || !shards[s].outs) return Fail(Status::Invalid("shard without columns / outputs"));
+  }
+  return RunShards(num_shards, devices.data(), [&](int s, hipStream_t stream) -> Status {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(num_rows, num_shards, s, &lo, &hi);
+    if (hi == lo) return Status::OK();
+    std::vector<ColumnBuffers> c = ToColumns(shards[s].cols, num_cols);
+    std::vector<OutputBuffers> o = ToOutputs(shards[s].outs, num_outs);
+    Status st = p->p->Evaluate(hi - lo, c.data(), num_cols, nullptr, o.data(), num_outs, MemKind::kDevice, stream, 0);
+    for (int i = 0; i < num_outs; i++) shards[s].outs[i].data_size = o[i].data_size;  // var-len: bytes produced / needed
+    return st;
+  });
+  });
+}
+
+int gdv_filter_evaluate_sharded(const gdv_filter_t* f, int64_t num_rows, int num_cols, int selection_mode,
+                                gdv_shard_t* shards, int num_shards, uint32_t flags, int64_t* total_selected) {
+  return Guarded([&]() -> int {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  if (num_shards < 1 || !shards || num_rows < 0) return Fail(Status::Invalid("bad shard list"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode) || mode == SelectionMode::kNone) return Fail(Status::Invalid("bad selection mode"));
+  std::vector<int32_t> devices(num_shards);
+  for (int s = 0; s < num_shards; s++) {
+    devices[s] = shards[s].device;
+    shards[s].num_selected = 0;
+    if ((num_cols > 0 && !shards[s].cols) || !shards[s].out_indices) return Fail(Status::Invalid("shard without columns / indices"));
+  }
+  const bool global = (flags & GDV_SHARD_GLOBAL_INDICES) != 0;
+  int rc = RunShards(num_shards, devices.data(), [&](int s, hipStream_t stream) -> Status {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(num_rows, num_shards, s, &lo, &hi);
+    if (hi == lo) return Status::OK();
+    std::vector<ColumnBuffers> c = ToColumns(shards[s].cols, num_cols);
+    return f->f->Evaluate(hi - lo, c.data(), num_cols, mode, shards[s].out_indices, shards[s].max_slots,
+                          &shards[s].num_selected, MemKind::kDevice, stream, 0, nullptr, global ? lo : 0);
+  });
+  if (rc != GDV_OK) return rc;
+  if (total_selected) {
+    *total_selected = 0;
+    for (int s = 0; s < num_shards; s++) *total_selected += shards[s].num_selected;
+  }
+  return GDV_OK;
+  });
+}
+
+int gdv_filter_gather_sharded(const gdv_shard_t* shards, int num_shards, int selection_mode, int dst_device,
+                              void* dst_indices, int64_t dst_slots) {
+  return Guarded([&]() -> int {
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode) || mode == SelectionMode::kNone) return Fail(Status::Invalid("bad selection mode"));
+  if (num_shards < 1 || !shards || !dst_indices) return Fail(Status::Invalid("bad shard list"));
+  const int w = IndexWidth(mode);
+  int64_t total = 0;
+  for (int s = 0; s < num_shards; s++) total += shards[s].num_selected;
+  if (total > dst_slots) return Fail(Status::Invalid("gathered selection vector needs " + std::to_string(total) + " slots"));
+  const int before = Runtime::SelectedDevice();
+  Status st = Runtime::SelectDevice(dst_device);
+  if (!st.ok()) return Fail(st);
+  Runtime& dst = Runtime::Get();
+  st = dst.EnsureDevice();
+  hipStream_t stream = nullptr;
+  if (st.ok()) st = dst.AcquireStream(&stream);
+  if (st.ok()) {
+    int64_t at = 0;
+    for (int s = 0; s < num_shards && st.ok(); s++) {
+      const int64_t n = shards[s].num_selected;
+      if (n > 0) {
+        // (virtual devices share a physical one: the copy is then an ordinary device-to-device one)
+        const int src_phys = Runtime::ForDevice(shards[s].device).physical();
+        hipError_t e = src_phys == dst.physical()
+                           ? hipMemcpyAsync(static_cast<char*>(dst_indices) + at * w, shards[s].out_indices, n * w, hipMemcpyDeviceToDevice, stream)
+                           : hipMemcpyPeerAsync(static_cast<char*>(dst_indices) + at * w, dst.physical(), shards[s].out_indices, src_phys, n * w, stream);
+        if (e != hipSuccess) st = Status::ExecutionError(std::string("gather: ") + hipGetErrorString(e));
+      }
+      at += n;
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess && st.ok()) st = Status::ExecutionError("gather: stream synchronisation failed");
+    dst.ReleaseStream(stream);
+  }
+  if (before >= 0) (void)Runtime::SelectDevice(before);
+  return Check(st);
+  });
+}
+
+int gdv_projector_evaluate_host_sharded(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                        gdv_out_column_t* outs, int num_outs, const int32_t* devices, int num_devices) {
+  return Guarded([&]() -> int {
+  if (!p) return Fail(Status::Invalid("null projector"));
+  if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
+  if (!outs || !devices || num_devices < 1) return Fail(Status::Invalid("outputs and a device list are required"));
+  if (p->p->plan().mode != SelectionMode::kNone) return Fail(Status::Invalid("sharded evaluation takes row-mode projectors"));
+  if (num_outs != p->p->num_outputs()) return Fail(Status::Invalid("number of outputs does not match the projector"));
+  bool varlen_out = false;
+  for (int i = 0; i < num_outs; i++) varlen_out |= p->p->output_type(i).is_varlen();
+  // var-len outputs: byte positions depend on the shards before -> one device; tiny batches: not worth the threads
+  const int n = (varlen_out || num_rows < 2048) ? 1 : num_devices;
+  if (n == 1) {
+    const int before = Runtime::SelectedDevice();
+    Status sel = Runtime::SelectDevice(devices[0]);
+    if (!sel.ok()) return Fail(sel);
+    int rc = ProjectorEvaluate(p, num_rows, cols, num_cols, nullptr, nullptr, outs, num_outs, GDV_MEM_HOST, nullptr, 0);
+    if (before >= 0) (void)Runtime::SelectDevice(before);
+    return rc;
+  }
+  for (int i = 0; i < num_outs; i++) {
+    const DataType& t = p->p->output_type(i);
+    const int64_t vneed = (num_rows + 7) / 8, dneed = t.id == kBool ? (num_rows + 7) / 8 : Projector::DataBytes(t, num_rows);
+    if (!outs[i].validity || !outs[i].data || outs[i].validity_size < vneed || outs[i].data_size < dneed)
+      return Fail(Status::Invalid("output buffer " + std::to_string(i) + " too small"));
+  }
+  return RunShards(n, devices, [&](int s, hipStream_t stream) -> Status {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(num_rows, n, s, &lo, &hi);
+    if (hi == lo) return Status::OK();
+    // a slice of the caller's batch: array offset + lo (var-len columns keep their whole byte buffer)
+    std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+    for (auto& col : c) col.offset += lo;
+    std::vector<OutputBuffers> o(num_outs);
+    for (int i = 0; i < num_outs; i++) {
+      const DataType& t = p->p->output_type(i);
+      // lo is a multiple of 1024: whole bytes of every bitmap
+      o[i].validity = static_cast<char*>(outs[i].validity) + lo / 8;
+      o[i].validity_size = (hi - lo + 7) / 8;
+      if (t.id == kBool) {
+        o[i].data = static_cast<char*>(outs[i].data) + lo / 8;
+        o[i].data_size = (hi - lo + 7) / 8;
+      } else {
+        o[i].data = static_cast<char*>(outs[i].data) + lo * t.byte_width();
+        o[i].data_size = (hi - lo) * t.byte_width();
+      }
+    }
+    return p->p->Evaluate(hi - lo, c.data(), num_cols, nullptr, o.data(), num_outs, MemKind::kHost, stream, 0);
+  });
+  });
+}
+
+int gdv_filter_evaluate_host_sharded(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                     int selection_mode, void* out_indices, int64_t max_slots, int64_t* num_selected,
+                                     const int32_t* devices, int num_devices) {
+  return Guarded([&]() -> int {
+  if (!f) return Fail(Status::Invalid("null filter"));
+  if (num_cols > 0 && !cols) return Fail(Status::Invalid("null column array"));
+  if (!out_indices || !num_selected || !devices || num_devices < 1) return Fail(Status::Invalid("Selection vector cannot be null"));
+  SelectionMode mode;
+  if (!ToSelectionMode(selection_mode, &mode) || mode == SelectionMode::kNone) return Fail(Status::Invalid("bad selection mode"));
+  if (max_slots < num_rows)
+    return Fail(Status::Invalid("Selection vector too small: max slots " + std::to_string(max_slots) + " < rows " + std::to_string(num_rows)));
+  const int n = num_rows < 2048 ? 1 : num_devices;
+  const int w = IndexWidth(mode);
+  std::vector<int64_t> counts(n, 0);
+  int rc = RunShards(n, devices, [&](int s, hipStream_t stream) -> Status {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(num_rows, n, s, &lo, &hi);
+    if (hi == lo) return Status::OK();
+    std::vector<ColumnBuffers> c = ToColumns(cols, num_cols);
+    for (auto& col : c) col.offset += lo;
+    // shard s can select at most hi - lo rows: its part of the vector is [lo, hi), closed up below
+    return f->f->Evaluate(hi - lo, c.data(), num_cols, mode, static_cast<char*>(out_indices) + lo * w, hi - lo, &counts[s],
+                          MemKind::kHost, stream, 0, nullptr, lo);
+  });
+  if (rc != GDV_OK) return rc;
+  int64_t at = 0;
+  for (int s = 0; s < n; s++) {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(num_rows, n, s, &lo, &hi);
+    if (counts[s] > 0 && at != lo)
+      std::memmove(static_cast<char*>(out_indices) + at * w, static_cast<char*>(out_indices) + lo * w, static_cast<size_t>(counts[s]) * w);
+    at += counts[s];
+  }
+  *num_selected = at;
+  return GDV_OK;
+  });
 }
 int gdv_device_num_cus(void) { return Runtime::Get().num_cus(); }
 const char* gdv_device_arch(void) { return Runtime::Get().arch().c_str(); }

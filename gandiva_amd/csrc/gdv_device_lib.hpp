@@ -3277,7 +3277,8 @@ GDV_DEV gdv_uint64 gdv_lb_wait(const gdv_uint64* pre, gdv_int64 ntiles, gdv_int6
 // relaxed agent-scope atomics, the granule is its own flag.  ONE wave per workgroup looks back (the
 // waves' counts meet in LDS first): tools/proto/k2_proto.hip measured the per-wave window at 4.3 ms
 // and this workgroup-level form at 3.56 ms on the 10^9-row filter (profiles/r02_k2_singlepass_proto.txt).
-// Workgroups are dispatched in index order and wait only for lower indices: no deadlock.
+// A workgroup's tile is the TICKET it drew when it started (round 6; rounds 4-5: its block index) and it waits only for
+// lower tiles — workgroups that drew earlier, hence already running: no deadlock under any dispatch order.
 #define GDV_FP_AGG (1ull << 62)
 #define GDV_FP_PFX (2ull << 62)
 #define GDV_FP_VAL ((1ull << 62) - 1)

@@ -378,6 +378,15 @@ Status BindInputs(const KernelPlan& plan, const Schema& schema, const ColumnBuff
           // zeroed 64-byte padding covers it; a buffer that ends flush with its range is staged as before).
           void* dof = (reinterpret_cast<uintptr_t>(osrc) & 3) == 0 ? HostRegistry::Get().View(osrc, (num_rows + 1) * 4) : nullptr;
           void* dd = c.data_size >= 8 ? HostRegistry::Get().View(c.data, c.data_size + 16) : nullptr;
+          if (dd != nullptr) {
+            // (round 6: the sweep reads the last piece up to its 16-byte boundary; the staged copy zeroes what lies behind
+            // the last byte, a caller's own registered buffer need not — a stale byte >= 0x80 there would send an ASCII
+            // batch to the exact string kernels for nothing.  Host memory: look, and stage when the tail is not clean.)
+            const unsigned char* end = static_cast<const unsigned char*>(c.data) + c.data_size;
+            const unsigned char* stop = reinterpret_cast<const unsigned char*>((reinterpret_cast<uintptr_t>(end) + 15) & ~uintptr_t{15});
+            for (const unsigned char* q = end; q < stop; q++)
+              if (*q & 0x80) { dd = nullptr; break; }
+          }
           if (dof == nullptr) GDV_RETURN_NOT_OK(st->In(osrc, (num_rows + 1) * 4, (num_rows + 1) * 4, stream, &dof));
           // (16 zero bytes behind the last byte: the byte sweep reads whole 16-byte pieces, and whatever
           // the block held before must not look like a byte >= 0x80 — it would send an ASCII batch to
@@ -1650,8 +1659,10 @@ static void AdvanceInputs(const KernelPlan& plan, const Schema& schema, const Ar
 Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                         SelectionMode mode, void* out_indices, int64_t max_slots,
                         int64_t* num_selected, MemKind mem, hipStream_t stream, uint32_t flags,
-                        void* count_out) const {
+                        void* count_out, int64_t row_base) const {
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
+  if (row_base < 0) return Status::Invalid("negative row base");
+  if (row_base != 0) flags |= kEvalNoSmall;  // (the one-workgroup kernel emits local positions)
   if (out_indices == nullptr || (num_selected == nullptr && count_out == nullptr))
     return Status::Invalid("Selection vector cannot be null");
   if (mode == SelectionMode::kNone) return Status::Invalid("Selection vector type cannot be NONE");
@@ -1659,10 +1670,10 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     return Status::Invalid("Selection vector too small: max slots " + std::to_string(max_slots) +
                            " < rows " + std::to_string(num_rows));
   const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
-  if (w == 2 && num_rows > 65536)
-    return Status::Invalid("uint16 selection vector cannot address " + std::to_string(num_rows) + " rows");
-  if (w == 4 && num_rows > (int64_t(1) << 32))
-    return Status::Invalid("uint32 selection vector cannot address " + std::to_string(num_rows) + " rows");
+  if (w == 2 && row_base + num_rows > 65536)
+    return Status::Invalid("uint16 selection vector cannot address " + std::to_string(row_base + num_rows) + " rows");
+  if (w == 4 && row_base + num_rows > (int64_t(1) << 32))
+    return Status::Invalid("uint32 selection vector cannot address " + std::to_string(row_base + num_rows) + " rows");
   // small HBM-resident batches: predicate + scan + emission by one workgroup in one launch
   // (one workgroup is the right tool up to a few thousand rows; beyond that the three-launch path,
   // which spreads the predicate over the chip, is faster for a single batch —
@@ -1793,7 +1804,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
                                             offsets.as<uint64_t>() + lo / tile_rows, totals.as<uint64_t>() + c + 1, s2,
                                             c == 0 ? nullptr : totals.as<uint64_t>() + c));
     GDV_HIP_RETURN_NOT_OK(LaunchEmitIndices(mask.as<uint64_t>() + lo / 64, offsets.as<uint64_t>() + lo / tile_rows,
-                                            words, plan_.opts.subtiles, lo, w, dev_out, rt.num_cus(), s2));
+                                            words, plan_.opts.subtiles, row_base + lo, w, dev_out, rt.num_cus(), s2));
   }
   if (chunks > 1) {  // `stream` continues only after the side stream's last emission
     hipEvent_t e = nullptr;
@@ -1893,11 +1904,17 @@ Status FilterProject::EvaluateChain(int64_t num_rows, const ColumnBuffers* cols,
   const SelectionMode mode = plan_.mode != SelectionMode::kNone ? plan_.mode
                              : (num_rows <= (int64_t{1} << 32) ? SelectionMode::kUInt32 : SelectionMode::kUInt64);
   const int w = mode == SelectionMode::kUInt16 ? 2 : mode == SelectionMode::kUInt32 ? 4 : 8;
+  // (the two operators are held through locals: a concurrent call that needs the other index width replaces
+  // chain_projector_ under the lock, and must not free the one this call is still evaluating)
+  std::shared_ptr<Filter> chain_filter;
+  std::shared_ptr<Projector> chain_projector;
   {
     std::lock_guard<std::mutex> lock(chain_mu_);
     if (chain_filter_ == nullptr) GDV_RETURN_NOT_OK(Filter::Make(schema_, condition_, Configuration{}, &chain_filter_));
     if (chain_projector_ == nullptr || chain_projector_->plan().mode != mode)
       GDV_RETURN_NOT_OK(Projector::Make(schema_, exprs_, mode, Configuration{}, &chain_projector_));
+    chain_filter = chain_filter_;
+    chain_projector = chain_projector_;
   }
   std::vector<char> host_idx;
   DeviceBuffer dev_idx;
@@ -1913,14 +1930,14 @@ Status FilterProject::EvaluateChain(int64_t num_rows, const ColumnBuffers* cols,
     max_slots = num_rows;
   }
   int64_t count = 0;
-  GDV_RETURN_NOT_OK(chain_filter_->Evaluate(num_rows, cols, num_cols, mode, idx, max_slots, &count, mem, stream, 0, count_out));
+  GDV_RETURN_NOT_OK(chain_filter->Evaluate(num_rows, cols, num_cols, mode, idx, max_slots, &count, mem, stream, 0, count_out));
   if (count > 0) {
     SelectionView sel;
     sel.mode = mode;
     sel.indices = idx;
     sel.num_slots = count;
     // the projector sizes its checks for `count` rows; the caller's buffers hold num_rows
-    GDV_RETURN_NOT_OK(chain_projector_->Evaluate(num_rows, cols, num_cols, &sel, outs, num_outs, mem, stream, 0));
+    GDV_RETURN_NOT_OK(chain_projector->Evaluate(num_rows, cols, num_cols, &sel, outs, num_outs, mem, stream, 0));
   }
   if (num_selected != nullptr) *num_selected = count;
   return Status::OK();
@@ -1951,7 +1968,7 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
 
   ArgBlock args(plan_.layout);
   Staging st;
-  DeviceBuffer scratch;                      // look-back granules | count | error word
+  DeviceBuffer scratch;                      // look-back granules | count | error word | tile ticket
   std::vector<DeviceBuffer> staged(mem == MemKind::kHost ? 2 * num_outs + 1 : 0);  // host path: results are produced in HBM first
   StreamDrain drain{stream, !async};         // declared last: drains before any pooled block is freed
   if (num_rows == 0) {
@@ -1965,8 +1982,8 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   args.Set64(ArgLayout::kOffN, static_cast<uint64_t>(num_rows));
 
   if (int64_t* seen = pinned_count_.load(std::memory_order_relaxed)) {  // what an earlier asynchronous call selected
-    const int64_t c = *reinterpret_cast<volatile int64_t*>(seen), r = pinned_rows_.load(std::memory_order_relaxed);
-    if (c >= 0 && r > 0 && c <= r) selected_per_1024_.store(static_cast<int>(c * 1024 / r), std::memory_order_relaxed);
+    const int64_t share = *reinterpret_cast<volatile int64_t*>(seen);  // rows selected per 1024, written by one launch
+    if (share >= 0 && share <= 1024) selected_per_1024_.store(static_cast<int>(share), std::memory_order_relaxed);
   }
   // which shape: the windowed kernel unless recent batches selected more rows than its LDS window holds (the
   // direct kernel takes the same argument block: PlanFilterProject checks that its literals and constants are a
@@ -1991,7 +2008,7 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   const size_t state_b = up(static_cast<size_t>(grid) * 8);
   GDV_RETURN_NOT_OK(scratch.Allocate(state_b + 256));
   char* const base = scratch.as<char>();
-  // granules, count and error word start at zero (one memset)
+  // granules, count (+0), error word (+64) and the tile ticket (+128, round 6) start at zero (one memset)
   GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(base, 0, state_b + 256, stream));
   drain.armed = true;  // from here on an error return must wait for what was enqueued (re-disarmed on the async exit)
   args.SetPtr(ArgLayout::kOffMask, base);
@@ -2050,11 +2067,10 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
         (void)hipGetLastError();
       }
     }
-    pinned_rows_.store(num_rows, std::memory_order_relaxed);
   }
   if (count_out != nullptr || telemetry != nullptr)
     GDV_HIP_RETURN_NOT_OK(LaunchPublishCount(static_cast<int64_t*>(count_out), reinterpret_cast<const int64_t*>(count_dev),
-                                             reinterpret_cast<const uint32_t*>(base + state_b + 64), kErrStall, stream, telemetry));
+                                             reinterpret_cast<const uint32_t*>(base + state_b + 64), kErrStall, stream, telemetry, num_rows));
   if (async) {
     if (num_selected != nullptr) *num_selected = -1;
     scratch.release_after(stream);

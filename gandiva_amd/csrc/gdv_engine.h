@@ -213,9 +213,12 @@ class Filter {
   // flags & kEvalAsync (device buffers, plans that cannot raise): enqueue on `stream` and return;
   // the count then arrives in *count_out (8 bytes of device or pinned memory, int64) in stream
   // order and *num_selected is set to -1.  count_out may also be given to a synchronous call.
+  // row_base (round 6, sharded evaluation): added to every emitted position — shard s of a logical batch emits
+  // lo_s + local position, so the shards' vectors concatenate into a globally ascending one without a pass of their own
+  // (the index type must address row_base + num_rows).
   Status Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols, SelectionMode mode,
                   void* out_indices, int64_t max_slots, int64_t* num_selected, MemKind mem,
-                  hipStream_t stream, uint32_t flags = 0, void* count_out = nullptr) const;
+                  hipStream_t stream, uint32_t flags = 0, void* count_out = nullptr, int64_t row_base = 0) const;
 
   // Many small HBM-resident batches in ONE launch (round 3): every batch is filtered by one
   // workgroup that runs predicate, offsets scan and index emission back to back
@@ -314,7 +317,6 @@ class FilterProject {
   // asynchronous evaluations never see their count on the host: the count also lands in this pinned word, and the NEXT
   // call reads what the previous one left there (one batch late is early enough to pick the kernel shape)
   mutable std::atomic<int64_t*> pinned_count_{nullptr};
-  mutable std::atomic<int64_t> pinned_rows_{0};
   mutable std::atomic<int> resident_per_cu_{0};
   std::atomic<int> pinned_kernel_{-1};  // pipelined shape: workgroups of the kernel one CU holds at once (queried once)
   mutable std::mutex chain_mu_;

@@ -45,10 +45,11 @@ hipError_t LaunchStageGate(const uint64_t* stage_result, int num_outputs, const 
 hipError_t LaunchPublishStatus(uint64_t* result, const uint32_t* err, uint32_t clear, hipStream_t stream);
 // *dst = (*err & fatal) ? -1 : *count — the selected-row count of a fused filter-project launch as an asynchronous
 // caller sees it: negative when the launch did not complete (its look-back gave up)
-// (also: a second destination, may be null — the operator's own pinned word, through which an asynchronous caller's
-// counts reach the host one call late: enough to choose the kernel shape of the next batch)
+// (share: may be null — the operator's own pinned word; receives the rows selected per 1024 rows of THIS launch (`rows` of
+// them), through which an asynchronous caller's selectivity reaches the host one call late: enough to choose the kernel
+// shape of the next batch.  One word, written by one launch: count and row number cannot come from different batches.)
 hipError_t LaunchPublishCount(int64_t* dst, const int64_t* count, const uint32_t* err, uint32_t fatal, hipStream_t stream,
-                              int64_t* also = nullptr);
+                              int64_t* share = nullptr, int64_t rows = 0);
 // result[0] |= *status
 hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream);
 

@@ -529,17 +529,19 @@ hipError_t LaunchPublishStatus(uint64_t* result, const uint32_t* err, uint32_t c
   hipLaunchKernelGGL(PublishStatus, dim3(1), dim3(64), 0, stream, result, err, clear);
   return hipGetLastError();
 }
-__global__ void PublishCount(int64_t* __restrict__ dst, int64_t* __restrict__ also, const int64_t* __restrict__ count,
-                             const uint32_t* __restrict__ err, uint32_t fatal) {
+// `share` (optional) receives the selected rows per 1024 of THIS batch — count and row number of one launch, so that a reader
+// never pairs the count of one batch with the rows of another (-1: the launch did not complete)
+__global__ void PublishCount(int64_t* __restrict__ dst, int64_t* __restrict__ share, const int64_t* __restrict__ count,
+                             const uint32_t* __restrict__ err, uint32_t fatal, int64_t rows) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int64_t v = (err[0] & fatal) != 0 ? int64_t{-1} : count[0];
     if (dst != nullptr) dst[0] = v;
-    if (also != nullptr) also[0] = v;
+    if (share != nullptr) share[0] = v < 0 || rows <= 0 ? int64_t{-1} : v * 1024 / rows;
   }
 }
 hipError_t LaunchPublishCount(int64_t* dst, const int64_t* count, const uint32_t* err, uint32_t fatal, hipStream_t stream,
-                              int64_t* also) {
-  hipLaunchKernelGGL(PublishCount, dim3(1), dim3(64), 0, stream, dst, also, count, err, fatal);
+                              int64_t* share, int64_t rows) {
+  hipLaunchKernelGGL(PublishCount, dim3(1), dim3(64), 0, stream, dst, share, count, err, fatal, rows);
   return hipGetLastError();
 }
 hipError_t LaunchOrStatus(uint64_t* result, const uint64_t* status, hipStream_t stream) {

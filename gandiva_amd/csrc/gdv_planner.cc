@@ -3296,7 +3296,22 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
   }
   s << "  const int lane = threadIdx.x & 63;\n"
     << "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
-    << "  const gdv_int64 tile = (gdv_int64)blockIdx.x;  // one workgroup tile = GDV_WAVES x GDV_FP_K x GDV_U x 64 rows; index order = row order\n"
+    << "  // one workgroup tile = GDV_WAVES x GDV_FP_K x GDV_U x 64 rows; tile order = row order.  Round 6: the tile comes from an\n"
+    << "  // atomic TICKET (one agent-scope fetch-add per workgroup, the word behind the count and the error word), not from\n"
+    << "  // blockIdx: the look-back waits only for tiles with LOWER tickets, whose workgroups have already started — no\n"
+    << "  // deadlock whatever order the dispatcher starts workgroups in.\n"
+    << (opts.fp_experiment == 3
+            // EXPERIMENT (GDV_FP_EXPERIMENT=3; tools only): round 5's tile = blockIdx, to price the ticket
+            ? "  const gdv_int64 tile = (gdv_int64)blockIdx.x;\n"
+            : std::string(opts.fp_experiment == 2
+                              // GDV_FP_EXPERIMENT=2 (tests): workgroups with LOW block indices arrive late — every group of 256
+                              // consecutive block indices takes its tickets in (roughly) reversed order; results must not change
+                              ? "  if (threadIdx.x == 0) for (int z = 0; z < (int)(255u - (blockIdx.x & 255u)) * 4; z++) __builtin_amdgcn_s_sleep(32);\n"
+                              : "") +
+                  "  __shared__ gdv_uint32 wg_ticket;\n"
+                  "  if (threadIdx.x == 0) wg_ticket = __hip_atomic_fetch_add((gdv_uint32*)A.counts + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+                  "  __syncthreads();\n"
+                  "  const gdv_int64 tile = (gdv_int64)wg_ticket;\n")
     << "  // (workgroup-uniform branch: the barriers inside are reached by every wave of the workgroup)\n"
     << "  if ((tile + 1) * (GDV_WAVES * GDV_FP_K * GDV_U * 64) <= GDV_ROWS(A)) gdv_fused_tile<true>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"
     << "  else gdv_fused_tile<false>(A, tile, lane, wave, wg_cnt, &wg_excl" << win_args << ");\n"

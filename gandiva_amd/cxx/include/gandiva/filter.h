@@ -21,6 +21,7 @@ class Filter {
   std::string DumpIR();
 
  private:
+  friend class ShardedFilter;
   Filter(gdv_filter* h, SchemaPtr schema) : handle_(h), schema_(std::move(schema)) {}
   gdv_filter* handle_;
   SchemaPtr schema_;

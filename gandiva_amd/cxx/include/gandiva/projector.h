@@ -42,6 +42,7 @@ class Projector {
   std::string DumpIR();
 
  private:
+  friend class ShardedProjector;
   Projector(gdv_projector* h, SchemaPtr schema, FieldVector outs, SelectionVector::Mode mode)
       : handle_(h), schema_(std::move(schema)), output_fields_(std::move(outs)), mode_(mode) {}
   gdv_projector* handle_;

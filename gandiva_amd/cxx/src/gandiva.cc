@@ -16,6 +16,7 @@
 #include "gandiva/expression_registry.h"
 #include "gandiva/filter.h"
 #include "gandiva/filter_project.h"
+#include "gandiva/sharded.h"
 #include "gandiva/function_signature.h"
 #include "gandiva/host_memory.h"
 #include "gandiva/node.h"
@@ -776,6 +777,190 @@ std::string Filter::DumpIR() {
   std::string r = s ? s : "";
   gdv_free_string(s);
   return r;
+}
+
+// ------------------------------------------------------------------ one call, all GPUs (round 6)
+
+void ShardBounds(int64_t num_rows, int num_shards, int shard, int64_t* lo, int64_t* hi) {
+  if (gdv_shard_bounds(num_rows, num_shards, shard, lo, hi) != GDV_OK) *lo = *hi = 0;
+}
+int DeviceCount() { return gdv_device_count(); }
+
+static std::vector<int> AllDevicesIfEmpty(std::vector<int> devices) {
+  if (devices.empty())
+    for (int d = 0; d < std::max(gdv_device_count(), 1); d++) devices.push_back(d);
+  return devices;
+}
+
+Status ShardedProjector::Make(SchemaPtr schema, const ExpressionVector& exprs, std::vector<int> devices,
+                              std::shared_ptr<Configuration> configuration, std::shared_ptr<ShardedProjector>* out) {
+  if (!out) return Status::Invalid("ShardedProjector output cannot be null");
+  std::shared_ptr<ShardedProjector> sp(new ShardedProjector());
+  ARROW_RETURN_NOT_OK(Projector::Make(schema, exprs, SelectionVector::MODE_NONE, configuration, &sp->projector_));
+  sp->devices_ = AllDevicesIfEmpty(std::move(devices));
+  *out = sp;
+  return Status::OK();
+}
+
+Status ShardedProjector::Evaluate(const arrow::RecordBatch& batch, arrow::MemoryPool* pool, ArrayVector* output) const {
+  if (!output) return Status::Invalid("Output array vector cannot be null");
+  const Projector& p = *projector_;
+  std::vector<gdv_column_t> cols;
+  bool device = false;
+  std::shared_ptr<arrow::MemoryManager> mm;
+  ARROW_RETURN_NOT_OK(MarshalBatch(batch, p.schema_, &cols, &device, &mm));
+  if (device) return Status::Invalid("a device-resident batch is already on one GPU: pass one batch per device (the shards overload)");
+  for (auto& f : p.output_fields_)
+    if (IsVarlen(*f->type())) return p.Evaluate(batch, pool, output);  // byte positions depend on the rows before: one device
+  const int n_out = static_cast<int>(p.output_fields_.size());
+  const int64_t rows = batch.num_rows();
+  std::vector<gdv_out_column_t> outs(n_out);
+  std::vector<std::shared_ptr<arrow::Buffer>> vbuf(n_out), dbuf(n_out);
+  for (int e = 0; e < n_out; e++) {
+    int64_t vbytes = 0, dbytes = 0;
+    GDV_CXX_RETURN_NOT_OK(gdv_projector_output_sizes(p.handle_, e, rows, GDV_MEM_HOST, &vbytes, &dbytes));
+    ARROW_ASSIGN_OR_RAISE(vbuf[e], AllocOut(vbytes, false, pool, mm));
+    ARROW_ASSIGN_OR_RAISE(dbuf[e], AllocOut(dbytes, false, pool, mm));
+    std::memset(&outs[e], 0, sizeof(outs[e]));
+    outs[e].validity = reinterpret_cast<void*>(vbuf[e]->address());
+    outs[e].validity_size = Room(*vbuf[e]);
+    outs[e].data = reinterpret_cast<void*>(dbuf[e]->address());
+    outs[e].data_size = Room(*dbuf[e]);
+  }
+  std::vector<int32_t> devs(devices_.begin(), devices_.end());
+  GDV_CXX_RETURN_NOT_OK(gdv_projector_evaluate_host_sharded(p.handle_, rows, cols.data(), static_cast<int>(cols.size()), outs.data(),
+                                                            n_out, devs.data(), static_cast<int>(devs.size())));
+  for (int e = 0; e < n_out; e++)
+    output->push_back(arrow::MakeArray(arrow::ArrayData::Make(p.output_fields_[e]->type(), rows, {vbuf[e], dbuf[e]})));
+  return Status::OK();
+}
+
+Status ShardedProjector::Evaluate(const std::vector<std::shared_ptr<arrow::RecordBatch>>& shards,
+                                  std::vector<ArrayVector>* outputs) const {
+  if (!outputs) return Status::Invalid("Output vector cannot be null");
+  const Projector& p = *projector_;
+  const int n = static_cast<int>(shards.size());
+  if (n < 1 || n > static_cast<int>(devices_.size()))
+    return Status::Invalid("expected between 1 and ", devices_.size(), " shards, got ", n);
+  const int n_out = static_cast<int>(p.output_fields_.size());
+  int64_t rows = 0;
+  for (auto& b : shards) {
+    if (!b) return Status::Invalid("null shard");
+    rows += b->num_rows();
+  }
+  std::vector<std::vector<gdv_column_t>> cols(n);
+  std::vector<std::vector<gdv_out_column_t>> outs(n, std::vector<gdv_out_column_t>(n_out));
+  std::vector<std::vector<std::shared_ptr<arrow::Buffer>>> vbuf(n), dbuf(n), obuf(n);
+  std::vector<gdv_shard_t> sh(n);
+  for (int s = 0; s < n; s++) {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(rows, n, s, &lo, &hi);
+    if (shards[s]->num_rows() != hi - lo)
+      return Status::Invalid("shard ", s, " holds ", shards[s]->num_rows(), " rows; gdv_shard_bounds gives ", hi - lo);
+    bool device = false;
+    std::shared_ptr<arrow::MemoryManager> mm;
+    ARROW_RETURN_NOT_OK(MarshalBatch(*shards[s], p.schema_, &cols[s], &device, &mm));
+    if (!device) return Status::Invalid("shard ", s, " is host-resident: pass ONE host batch to the other overload");
+    vbuf[s].resize(n_out); dbuf[s].resize(n_out); obuf[s].resize(n_out);
+    int64_t varlen_guess = 64;
+    for (auto& c : cols[s]) if (c.offsets) varlen_guess += c.data_size;
+    for (int e = 0; e < n_out; e++) {
+      const bool varlen = IsVarlen(*p.output_fields_[e]->type());
+      int64_t vbytes = 0, dbytes = 0;
+      GDV_CXX_RETURN_NOT_OK(gdv_projector_output_sizes(p.handle_, e, hi - lo, GDV_MEM_DEVICE, &vbytes, &dbytes));
+      if (varlen) dbytes = std::max(dbytes, varlen_guess);
+      ARROW_ASSIGN_OR_RAISE(vbuf[s][e], AllocOut(vbytes, true, nullptr, mm));
+      ARROW_ASSIGN_OR_RAISE(dbuf[s][e], AllocOut(dbytes, true, nullptr, mm));
+      std::memset(&outs[s][e], 0, sizeof(gdv_out_column_t));
+      outs[s][e].validity = reinterpret_cast<void*>(vbuf[s][e]->address());
+      outs[s][e].validity_size = Room(*vbuf[s][e]);
+      outs[s][e].data = reinterpret_cast<void*>(dbuf[s][e]->address());
+      outs[s][e].data_size = varlen ? dbuf[s][e]->size() : Room(*dbuf[s][e]);
+      if (varlen) {
+        ARROW_ASSIGN_OR_RAISE(obuf[s][e], AllocOut((hi - lo + 1) * 4, true, nullptr, mm));
+        outs[s][e].offsets = reinterpret_cast<void*>(obuf[s][e]->address());
+        outs[s][e].offsets_size = obuf[s][e]->size();
+      }
+    }
+    std::memset(&sh[s], 0, sizeof(gdv_shard_t));
+    sh[s].device = devices_[s];
+    sh[s].cols = cols[s].data();
+    sh[s].outs = outs[s].data();
+  }
+  GDV_CXX_RETURN_NOT_OK(gdv_projector_evaluate_sharded(p.handle_, rows, static_cast<int>(cols[0].size()), n_out, sh.data(), n, 0));
+  outputs->assign(n, {});
+  for (int s = 0; s < n; s++)
+    for (int e = 0; e < n_out; e++) {
+      std::vector<std::shared_ptr<arrow::Buffer>> bufs;
+      if (obuf[s][e]) bufs = {vbuf[s][e], obuf[s][e], arrow::SliceBuffer(dbuf[s][e], 0, outs[s][e].data_size)};
+      else bufs = {vbuf[s][e], dbuf[s][e]};
+      (*outputs)[s].push_back(arrow::MakeArray(arrow::ArrayData::Make(p.output_fields_[e]->type(), shards[s]->num_rows(), std::move(bufs))));
+    }
+  return Status::OK();
+}
+
+Status ShardedFilter::Make(SchemaPtr schema, ConditionPtr condition, std::vector<int> devices,
+                           std::shared_ptr<Configuration> configuration, std::shared_ptr<ShardedFilter>* out) {
+  if (!out) return Status::Invalid("ShardedFilter output cannot be null");
+  std::shared_ptr<ShardedFilter> sf(new ShardedFilter());
+  ARROW_RETURN_NOT_OK(Filter::Make(schema, condition, configuration, &sf->filter_));
+  sf->devices_ = AllDevicesIfEmpty(std::move(devices));
+  *out = sf;
+  return Status::OK();
+}
+
+Status ShardedFilter::Evaluate(const arrow::RecordBatch& batch, std::shared_ptr<SelectionVector> out) const {
+  if (!out) return Status::Invalid("Selection vector cannot be null");
+  std::vector<gdv_column_t> cols;
+  bool device = false;
+  std::shared_ptr<arrow::MemoryManager> mm;
+  ARROW_RETURN_NOT_OK(MarshalBatch(batch, filter_->schema_, &cols, &device, &mm));
+  if (device || !out->GetBuffer().is_cpu()) return Status::Invalid("the one-batch overload takes host-resident batches and vectors");
+  if (out->GetMaxSlots() < batch.num_rows())
+    return Status::Invalid("Selection vector too small: max slots ", out->GetMaxSlots(), " < number of rows ", batch.num_rows());
+  int64_t count = 0;
+  std::vector<int32_t> devs(devices_.begin(), devices_.end());
+  GDV_CXX_RETURN_NOT_OK(gdv_filter_evaluate_host_sharded(filter_->handle_, batch.num_rows(), cols.data(), static_cast<int>(cols.size()),
+                                                         static_cast<int>(out->GetMode()), reinterpret_cast<void*>(out->GetBuffer().address()),
+                                                         out->GetMaxSlots(), &count, devs.data(), static_cast<int>(devs.size())));
+  out->SetNumSlots(count);
+  return Status::OK();
+}
+
+Status ShardedFilter::Evaluate(const std::vector<std::shared_ptr<arrow::RecordBatch>>& shards,
+                               const std::vector<std::shared_ptr<SelectionVector>>& outs, int64_t* total) const {
+  const int n = static_cast<int>(shards.size());
+  if (n < 1 || n > static_cast<int>(devices_.size()) || outs.size() != shards.size())
+    return Status::Invalid("expected between 1 and ", devices_.size(), " shards and one selection vector per shard");
+  int64_t rows = 0;
+  for (auto& b : shards) {
+    if (!b) return Status::Invalid("null shard");
+    rows += b->num_rows();
+  }
+  std::vector<std::vector<gdv_column_t>> cols(n);
+  std::vector<gdv_shard_t> sh(n);
+  for (int s = 0; s < n; s++) {
+    int64_t lo = 0, hi = 0;
+    ShardBounds(rows, n, s, &lo, &hi);
+    if (shards[s]->num_rows() != hi - lo)
+      return Status::Invalid("shard ", s, " holds ", shards[s]->num_rows(), " rows; gdv_shard_bounds gives ", hi - lo);
+    bool device = false;
+    std::shared_ptr<arrow::MemoryManager> mm;
+    ARROW_RETURN_NOT_OK(MarshalBatch(*shards[s], filter_->schema_, &cols[s], &device, &mm));
+    if (!outs[s] || outs[s]->GetMode() != outs[0]->GetMode()) return Status::Invalid("selection vectors of one mode are required");
+    if (!device || outs[s]->GetBuffer().is_cpu()) return Status::Invalid("shard ", s, ": batch and selection vector must be device-resident");
+    std::memset(&sh[s], 0, sizeof(gdv_shard_t));
+    sh[s].device = devices_[s];
+    sh[s].cols = cols[s].data();
+    sh[s].out_indices = reinterpret_cast<void*>(outs[s]->GetBuffer().address());
+    sh[s].max_slots = outs[s]->GetMaxSlots();
+  }
+  int64_t sum = 0;
+  GDV_CXX_RETURN_NOT_OK(gdv_filter_evaluate_sharded(filter_->handle_, rows, static_cast<int>(cols[0].size()), static_cast<int>(outs[0]->GetMode()),
+                                                    sh.data(), n, GDV_SHARD_GLOBAL_INDICES, &sum));
+  for (int s = 0; s < n; s++) outs[s]->SetNumSlots(sh[s].num_selected);
+  if (total) *total = sum;
+  return Status::OK();
 }
 
 // ------------------------------------------------------------------ FilterProject (fused, round 4)

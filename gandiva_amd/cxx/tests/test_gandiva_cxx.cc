@@ -14,9 +14,11 @@
 #include "gandiva/expression_registry.h"
 #include "gandiva/filter.h"
 #include "gandiva/filter_project.h"
+#include "gandiva/sharded.h"
 #include "gandiva/host_memory.h"
 #include "gandiva/projector.h"
 #include "gandiva/tree_expr_builder.h"
+#include "gandiva_amd.h"  // gdv_set_virtual_devices: N device contexts on the one GPU of the test box
 
 using namespace gandiva;
 
@@ -342,6 +344,45 @@ int main(int argc, char** argv) {
     CHECK_OK(SelectionVector::MakeInt32(6, pool, &selc));
     CHECK_OK(fpc->Evaluate(*batch, pool, &outc, selc));
     CHECK(outc.size() == 1 && outc[0]->Equals(MakeArr<arrow::StringBuilder, std::string>({"10", "21", "29"})));
+  }
+  {  // round 6: ONE call over several devices (virtual contexts of the one GPU here): ShardedProjector / ShardedFilter over
+     // a host-resident batch give what Projector / Filter give
+    gdv_set_virtual_devices(3);
+    const int64_t n = 10000;
+    arrow::Int32Builder ba, bb, bc;
+    for (int64_t i = 0; i < n; i++) {
+      (void)ba.Append(static_cast<int32_t>((i * 7919) % 1000 - 500));
+      if (i % 11 == 3) (void)bb.AppendNull(); else (void)bb.Append(static_cast<int32_t>((i * 104729) % 777));
+      (void)bc.Append(static_cast<int32_t>(i % 13));
+    }
+    std::shared_ptr<arrow::Array> xa, xb, xc;
+    (void)ba.Finish(&xa); (void)bb.Finish(&xb); (void)bc.Finish(&xc);
+    auto big = arrow::RecordBatch::Make(schema, n, {xa, xb, xc});
+    auto sum = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeFunction("add", {na, nb}, arrow::int32()), arrow::field("s", arrow::int32()));
+    auto lt = TreeExprBuilder::MakeExpression(TreeExprBuilder::MakeFunction("less_than", {nb, nc}, arrow::boolean()), arrow::field("lt", arrow::boolean()));
+    std::shared_ptr<Projector> one;
+    std::shared_ptr<ShardedProjector> many;
+    CHECK_OK(Projector::Make(schema, {sum, lt}, &one));
+    CHECK_OK(ShardedProjector::Make(schema, {sum, lt}, {}, ConfigurationBuilder::DefaultConfiguration(), &many));
+    CHECK(many->devices().size() == 3);
+    ArrayVector o1, oN;
+    CHECK_OK(one->Evaluate(*big, pool, &o1));
+    CHECK_OK(many->Evaluate(*big, pool, &oN));
+    CHECK(oN.size() == 2 && oN[0]->Equals(o1[0]) && oN[1]->Equals(o1[1]));
+    auto fcond = TreeExprBuilder::MakeCondition(TreeExprBuilder::MakeFunction("greater_than", {na, nb}, arrow::boolean()));
+    std::shared_ptr<Filter> f1;
+    std::shared_ptr<ShardedFilter> fN;
+    CHECK_OK(Filter::Make(schema, fcond, &f1));
+    CHECK_OK(ShardedFilter::Make(schema, fcond, {0, 1, 2}, ConfigurationBuilder::DefaultConfiguration(), &fN));
+    std::shared_ptr<SelectionVector> s1, sN;
+    CHECK_OK(SelectionVector::MakeInt32(n, pool, &s1));
+    CHECK_OK(SelectionVector::MakeInt32(n, pool, &sN));
+    CHECK_OK(f1->Evaluate(*big, s1));
+    CHECK_OK(fN->Evaluate(*big, sN));
+    CHECK(s1->GetNumSlots() > 0 && sN->GetNumSlots() == s1->GetNumSlots() && sN->ToArray()->Equals(s1->ToArray()));
+    int64_t lo = -1, hi = -1;
+    ShardBounds(n, 3, 1, &lo, &hi);
+    CHECK(lo == 4096 && hi == 7168);
   }
   std::printf(failures ? "FAILED\n" : "OK\n");
   return failures ? 1 : 0;

@@ -355,3 +355,32 @@ def c5_device_batch(n, device="cuda", non_ascii_fraction=0.0):
     dat_t = pad(torch.from_numpy(data)).to(device)
     col = gdv.DeviceColumn(pa.string(), n, None, dat_t, off_t)
     return gdv.DeviceBatch(c5_schema(), [col], n)
+
+
+def c5_device_batch_philox(n, device="cuda", seed=21, chunk=1 << 27):
+    """C5's column generated in HBM (torch Philox): BASELINE.md §4's distributions — lengths U[4,20], ASCII
+    letters, "spark" planted in ~5 % of the rows — not its PCG64 stream (c5_numpy draws 1.2 * 10^9 letters on one
+    host core).  Seconds for 10^8 rows; parity against the oracle runs on c5_batch-sized inputs."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lens = torch.randint(4, 21, (n,), generator=g, device=device, dtype=torch.int64)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=offsets[1:])
+    total = int(offsets[-1])
+    assert total < (1 << 31), "int32 offsets"
+    letters = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"), dtype=torch.uint8, device=device)
+    data = torch.zeros(total + (-total) % 64 + 64, dtype=torch.uint8, device=device)
+    for lo in range(0, total, chunk):
+        m = min(chunk, total - lo)
+        data[lo:lo + m] = letters[torch.randint(0, 52, (m,), generator=g, device=device)]
+    pick = torch.nonzero((torch.rand(n, generator=g, device=device) < 0.05) & (lens >= 5)).view(-1)
+    pos = offsets[pick] + (torch.rand(pick.numel(), generator=g, device=device) * (lens[pick] - 4).to(torch.float32)).to(torch.int64)
+    pos = torch.minimum(pos, offsets[pick] + lens[pick] - 5)
+    for k, ch in enumerate(b"spark"):
+        data[pos + k] = ch
+    off32 = offsets.to(torch.int32)
+    off_t = torch.zeros((n + 1) * 4 + (-(n + 1) * 4) % 64 + 64, dtype=torch.uint8, device=device)
+    off_t[:(n + 1) * 4] = off32.view(torch.uint8)
+    col = gdv.DeviceColumn(pa.string(), n, None, data, off_t)
+    return gdv.DeviceBatch(c5_schema(), [col], n)

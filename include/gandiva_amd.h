@@ -377,6 +377,52 @@ int gdv_filter_project_kernel_shape(const gdv_filter_project_t* fp);
 int gdv_filter_project_set_tuning(gdv_filter_project_t* fp, const char* key, int64_t value);
 void gdv_filter_project_free(gdv_filter_project_t* fp);
 
+/* ---- One call, all the GPUs of a node (round 6) -------------------------
+ * The reference's Projector::Evaluate(batch, ...) / Filter::Evaluate(batch, ...) are ONE call (PA:218-226, 246-248).
+ * These entry points keep it one call on an N-GPU node: the logical batch of num_rows rows is cut into num_shards
+ * row ranges by gdv_shard_bounds (1024-row bounds: no validity word or cache line straddles two shards), shard s is
+ * evaluated on device shards[s].device by a host thread of its own — own device context, own stream; shard 0 on the
+ * calling thread — and nothing is exchanged between the shards: the path has no collective.  The call returns when
+ * every shard has finished; the first failing shard's status is returned (its device named in gdv_last_error()).
+ *
+ * Device-resident shards (gdv_*_evaluate_sharded): shards[s].cols / outs describe buffers in the HBM of
+ * shards[s].device that hold ONLY the shard's rows [lo_s, hi_s) — row 0 of these buffers is row lo_s of the batch —
+ * exactly what one-process-per-GPU ranks hold.  Projector outputs stay sharded (the logical result is their
+ * concatenation in shard order; var-len outputs: per-shard offsets, rebased by the consumer that joins them).
+ * Filter: shards[s].out_indices receives the shard's ascending positions, num_selected its count; with
+ * GDV_SHARD_GLOBAL_INDICES the positions are lo_s + local (written so by the index-emission kernel, no extra pass),
+ * and the shards' vectors concatenate into the globally ascending selection vector; *total_selected = the sum.
+ * gdv_filter_gather_sharded lays them end to end on one device (hipMemcpyPeerAsync; the only inter-device traffic,
+ * optional).
+ *
+ * Host-resident batches (gdv_*_evaluate_host_sharded): the caller passes ONE batch in host memory (what
+ * gandiva::Projector::Evaluate receives from Arrow C++ callers); the library slices it (array offset + lo_s, output
+ * pointers advanced to the shard's rows), stages every shard through its own device and writes the results into the
+ * caller's ONE set of output buffers: N PCIe links instead of one.  Plans with var-len OUTPUTS are not sliced
+ * (their byte positions depend on the shards before them): they run on devices[0] alone.  The filter's vector is
+ * global and ascending; shards write into disjoint parts of out_indices and are closed up on the host. */
+typedef struct {
+  int32_t device;           /* gdv_set_device numbering (virtual devices included) */
+  const gdv_column_t* cols; /* num_cols entries: the shard's rows, resident on `device` */
+  gdv_out_column_t* outs;   /* projector: num_outs entries on `device`, sized for the shard's rows */
+  void* out_indices;        /* filter: max_slots (>= the shard's rows) elements on `device` */
+  int64_t max_slots;
+  int64_t num_selected;     /* filter, out: rows this shard selected */
+} gdv_shard_t;
+#define GDV_SHARD_GLOBAL_INDICES 2u
+int gdv_projector_evaluate_sharded(const gdv_projector_t* p, int64_t num_rows, int num_cols, int num_outs,
+                                   gdv_shard_t* shards, int num_shards, uint32_t flags);
+int gdv_filter_evaluate_sharded(const gdv_filter_t* f, int64_t num_rows, int num_cols, int selection_mode,
+                                gdv_shard_t* shards, int num_shards, uint32_t flags, int64_t* total_selected);
+/* dst_indices: dst_slots (>= the total) elements of the selection mode's width on device dst_device */
+int gdv_filter_gather_sharded(const gdv_shard_t* shards, int num_shards, int selection_mode, int dst_device,
+                              void* dst_indices, int64_t dst_slots);
+int gdv_projector_evaluate_host_sharded(const gdv_projector_t* p, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                        gdv_out_column_t* outs, int num_outs, const int32_t* devices, int num_devices);
+int gdv_filter_evaluate_host_sharded(const gdv_filter_t* f, int64_t num_rows, const gdv_column_t* cols, int num_cols,
+                                     int selection_mode, void* out_indices, int64_t max_slots, int64_t* num_selected,
+                                     const int32_t* devices, int num_devices);
+
 /* ---- function registry ------------------------------------------------------------ */
 int gdv_registry_size(void);
 /* name: borrowed pointer valid for the process lifetime; params: up to max_params entries
