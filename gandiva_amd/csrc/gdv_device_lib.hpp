@@ -388,6 +388,19 @@ GDV_DEV gdv_float64 castFLOAT8_int64(gdv_int64 a) { return (gdv_float64)a; }
 GDV_DEV gdv_float64 castFLOAT8_float32(gdv_float32 a) { return (gdv_float64)a; }
 // float -> integer casts round half away from zero and saturate (out-of-range and NaN
 // inputs are undefined on the reference's CPU path; saturation / 0 keeps them defined).
+// GDV_CAST_X86_INDEFINITE (set at Make through the environment variable of that name; round 6): what the reference's JIT
+// yields on x86 for such inputs instead — cvttsd2si's "indefinite integer", 0x8000...0 of the destination width, for NaN
+// and for everything outside the destination's range (bit-exactness with the CPU path where a caller depends on it).
+#ifdef GDV_CAST_X86_INDEFINITE
+GDV_DEV gdv_int64 gdv_sat_i64(gdv_float64 r) {
+  if (!(r < 9223372036854775808.0 && r >= -9223372036854775808.0)) return (gdv_int64)0x8000000000000000ULL;
+  return (gdv_int64)r;
+}
+GDV_DEV gdv_int32 gdv_sat_i32(gdv_float64 r) {
+  if (!(r < 2147483648.0 && r > -2147483649.0)) return (gdv_int32)0x80000000u;
+  return (gdv_int32)r;
+}
+#else
 GDV_DEV gdv_int64 gdv_sat_i64(gdv_float64 r) {
   if (r != r) return 0;
   if (r >= 9223372036854775808.0) return 0x7fffffffffffffffLL;
@@ -400,6 +413,7 @@ GDV_DEV gdv_int32 gdv_sat_i32(gdv_float64 r) {
   if (r <= -2147483648.0) return (gdv_int32)0x80000000u;
   return (gdv_int32)r;
 }
+#endif
 // round half away from zero the way the reference writes it (precompiled extended_math_ops:
 // `trunc(x + (x >= 0 ? 0.5 : -0.5))`), NOT C round(): the sum is itself rounded to nearest even,
 // so 0.49999999999999994 -> 1 and odd integers in [2^52, 2^53) move to the next even one.

@@ -39,6 +39,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.prepass_rolled = std::getenv("GDV_PREPASS_ROLLED") != nullptr;
   o.no_sel_wave = std::getenv("GDV_NO_SEL_WAVE") != nullptr;
   if (const char* s = std::getenv("GDV_PREPASS_AHEAD")) o.prepass_ahead = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_CAST_X86_INDEFINITE")) o.cast_x86_indefinite = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_FP_EXPERIMENT")) o.fp_experiment = atoi(s);
   if (const char* s = std::getenv("GDV_FP_K")) o.fp_rounds = std::max(1, std::min(8, atoi(s)));
   if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
@@ -50,7 +51,7 @@ std::string CodegenOptions::Key() const {
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
          (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (prepass_ahead ? "" : "npa") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_rounds != 3 ? "k" + std::to_string(fp_rounds) : "") +
-         (fp_window_bytes != 9984 ? "fw" + std::to_string(fp_window_bytes) : "");
+         (fp_window_bytes != 9984 ? "fw" + std::to_string(fp_window_bytes) : "") + (cast_x86_indefinite ? "xi" : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -1152,6 +1153,7 @@ struct Assembler {
     if (cg.unroll_rows_) src << "#define GDV_UNROLL_ROWS 1\n";
     src << "#define GDV_U " << plan->opts.subtiles << "\n";
     src << "#define GDV_WAVES " << plan->opts.waves << "\n";
+    if (plan->opts.cast_x86_indefinite) src << "#define GDV_CAST_X86_INDEFINITE 1\n";
     src << "#include \"gdv_device_lib.hpp\"\n";
     const int nin = std::max<int>(1, plan->input_fields.size());
     const int nout = std::max<int>(1, plan->output_types.size());

@@ -47,6 +47,7 @@ struct CodegenOptions {
   // count from the device word aux2 points at when there is one — an asynchronous evaluation's gate writes 0
   // there when the first stage did not complete, and the second stage then touches nothing.
   bool rows_word = false;
+  bool cast_x86_indefinite = false;    // GDV_CAST_X86_INDEFINITE=1 at Make: float -> integer casts of NaN / out-of-range values give the x86 "indefinite integer" (0x80..0) instead of saturating
   // Fused filter-project, windowed shape (round 5): bytes of LDS window per wave tile (every windowed output + the
   // row index, GDV_FP_CAP rows of them); 0 = the direct round-4 shape only.  GDV_FP_WINDOW=<bytes>.
   int fp_window_bytes = 9984;

@@ -516,13 +516,19 @@ static void eval(const node* n, ctx* c, int64_t row0, int cnt, const uint8_t* ac
  * the same function].  NOT C round(): the addition rounds to nearest even first, so
  * 0.49999999999999994 gives 1 and 2^52 + 1 gives 2^52 + 2. */
 static double rnd(double x) { return trunc(x + (x >= 0 ? 0.5 : -0.5)); }
+/* gdv_oracle_cast_indefinite(1): the x86 JIT's result for NaN / out-of-range inputs (cvttsd2si's "indefinite integer")
+ * instead of saturation — the restatement of the product's GDV_CAST_X86_INDEFINITE=1 */
+static int g_cast_indefinite = 0;
+void gdv_oracle_cast_indefinite(int on) { g_cast_indefinite = on; }
 static int64_t sat_i64(double r) {
+  if (g_cast_indefinite) return (r < 9223372036854775808.0 && r >= -9223372036854775808.0) ? (int64_t)r : INT64_MIN;
   if (r != r) return 0;
   if (r >= 9223372036854775808.0) return INT64_MAX;
   if (r <= -9223372036854775808.0) return INT64_MIN;
   return (int64_t)r;
 }
 static int32_t sat_i32(double r) {
+  if (g_cast_indefinite) return (r < 2147483648.0 && r > -2147483649.0) ? (int32_t)r : INT32_MIN;
   if (r != r) return 0;
   if (r >= 2147483647.0) return INT32_MAX;
   if (r <= -2147483648.0) return INT32_MIN;

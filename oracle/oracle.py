@@ -161,6 +161,11 @@ def _raise(err):
     raise OracleError(f"oracle error bits {err:#x}")
 
 
+def cast_indefinite(on):
+    """float -> integer casts of NaN / out-of-range values: the x86 "indefinite integer" (True) or saturation (False, default)."""
+    lib().gdv_oracle_cast_indefinite(int(bool(on)))
+
+
 def force_generic(on):
     """Disable (True) / enable (False) the float64 fast path: for the agreement test."""
     lib().gdv_oracle_force_generic(int(bool(on)))

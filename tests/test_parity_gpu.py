@@ -184,6 +184,36 @@ def test_round_and_float_casts_on_the_edges_of_the_rule():
     _check_project(exprs, batch)
 
 
+def test_float_to_integer_casts_can_follow_the_x86_jit_on_nan_and_out_of_range_values(monkeypatch):
+    """Round 6 (PARITY.md): by default a float -> integer cast saturates and sends NaN to 0; the reference's JIT on
+    x86 yields cvttsd2si's "indefinite integer" (0x80..0 of the destination width) for NaN and for everything
+    outside the destination's range.  GDV_CAST_X86_INDEFINITE=1 at Make selects that; the oracle restates both."""
+    vals = [float("nan"), float("inf"), float("-inf"), 9.3e18, -9.3e18, 2147483647.4, 2147483647.6, 2147483648.0, -2147483648.4,
+            -2147483648.6, 3e9, -3e9, 1e300, -1e300, 0.5, -0.5, 123456.5, 9223372036854775807.0, -9223372036854775808.0]
+    batch = pa.RecordBatch.from_arrays([pa.array(vals, pa.float64()), pa.array(np.array(vals).astype(np.float32), pa.float32())],
+                                       names=["d", "f"])
+    b = gandiva.TreeExprBuilder()
+    d, f = b.make_field(batch.schema.field(0)), b.make_field(batch.schema.field(1))
+    exprs = [b.make_expression(b.make_function("castBIGINT", [d], pa.int64()), pa.field("b", pa.int64())),
+             b.make_expression(b.make_function("castINT", [d], pa.int32()), pa.field("i", pa.int32())),
+             b.make_expression(b.make_function("castBIGINT", [f], pa.int64()), pa.field("bf", pa.int64())),
+             b.make_expression(b.make_function("castINT", [f], pa.int32()), pa.field("if", pa.int32()))]
+    saturating = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    assert saturating[0].to_pylist()[:5] == [0, 2**63 - 1, -2**63, 2**63 - 1, -2**63]
+    assert saturating[1].to_pylist()[:3] == [0, 2**31 - 1, -2**31]
+    monkeypatch.setenv("GDV_CAST_X86_INDEFINITE", "1")
+    indefinite = gandiva.make_projector(batch.schema, exprs, None).evaluate(batch)
+    oracle.cast_indefinite(True)
+    try:
+        want = oracle.project(exprs, batch)
+    finally:
+        oracle.cast_indefinite(False)
+    for g, w, e in zip(indefinite, want, "b i bf if".split()):
+        assert_bit_exact(g, w, "x86 indefinite, " + e)
+    assert indefinite[0].to_pylist()[:5] == [-2**63] * 5 and indefinite[1].to_pylist()[:3] == [-2**31] * 3
+    assert indefinite[1].to_pylist()[5:8] == [2147483647, -2**31, -2**31]    # 2147483647.4 rounds inside, .6 and 2^31 do not fit
+
+
 def test_math_functions_within_one_ulp():
     """exp/log/pow/cbrt come from math libraries on both sides (ROCm device libs / host
     libm), so they are not bit-comparable with each other.  north_star's tolerance is 1 ulp:

@@ -114,6 +114,38 @@ def test_oracle_strings_match_arrow_compute():
     assert got["substr6"].to_pylist() == [None if v is None else "" if len(v) < 400 else v[len(v) - 400:len(v) - 397] for v in py]
 
 
+def test_upper_lower_differ_from_utf8proc_exactly_on_rows_with_cased_non_ascii_letters():
+    """PARITY.md, `upper lower`: this backend maps ASCII letters only (the lineage's earlier precompiled byte loop); the
+    Arrow-era lineage maps every cased code point through utf8proc — which pyarrow.compute.utf8_upper / utf8_lower
+    (the same utf8proc, linked into this image's libarrow) restate.  The divergence is exactly the rows that hold a
+    non-ASCII letter utf8proc would change; everywhere else the two agree byte for byte.  And the reason it stays: the
+    simple case map is not length-preserving."""
+    rng = np.random.default_rng(12)
+    alphabet = list("abcXYZ 09-_") + ["é", "É", "ß", "ñ", "Ω", "ω", "я", "Я", "ı", "ſ", "ÿ", "µ", "日", "本", "€", "ǆ", "ɐ"]
+    rows = ["".join(alphabet[int(k)] for k in rng.integers(0, len(alphabet), int(rng.integers(0, 12)))) for _ in range(4000)]
+    arr = pa.array(rows + [None], pa.string())
+    batch = pa.RecordBatch.from_arrays([arr], names=["s"])
+    b = gandiva.TreeExprBuilder()
+    f = b.make_field(batch.schema.field(0))
+    e = [b.make_expression(b.make_function("upper", [f], pa.string()), pa.field("u", pa.string())),
+         b.make_expression(b.make_function("lower", [f], pa.string()), pa.field("l", pa.string()))]
+    up, lo = oracle.project(e, batch)
+    assert up.equals(pc.ascii_upper(arr)) and lo.equals(pc.ascii_lower(arr))
+    want_up, want_lo = pc.utf8_upper(arr).to_pylist(), pc.utf8_lower(arr).to_pylist()
+    changes_up = {c for c in alphabet if ord(c[0]) > 127 and pc.utf8_upper(pa.scalar(c)).as_py() != c}
+    changes_lo = {c for c in alphabet if ord(c[0]) > 127 and pc.utf8_lower(pa.scalar(c)).as_py() != c}
+    assert {"é", "ω", "я", "ı", "ſ", "ÿ", "µ", "ɐ"} <= changes_up and {"É", "Ω", "Я"} <= changes_lo
+    differs = 0
+    for r, u, l, wu, wl in zip(rows, up.to_pylist(), lo.to_pylist(), want_up, want_lo):
+        assert (u != wu) == any(c in changes_up for c in r), r
+        assert (l != wl) == any(c in changes_lo for c in r), r
+        differs += u != wu
+    assert differs > 1000
+    # not length-preserving: why `upper` cannot stay on the flat path (output offsets = input offsets) if it followed utf8proc
+    lengths = {c: (len(c.encode()), len(pc.utf8_upper(pa.scalar(c)).as_py().encode())) for c in ("ı", "ſ", "ɐ", "é")}
+    assert lengths["ı"] == (2, 1) and lengths["ſ"] == (2, 1) and lengths["ɐ"] == (2, 3) and lengths["é"] == (2, 2)
+
+
 def test_oracle_c5_matches_arrow_compute():
     batch = W.c5_batch(50000, 0.1)
     out = oracle.project(W.c5_expressions(), batch)
