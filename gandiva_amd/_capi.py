@@ -154,6 +154,8 @@ PROTOTYPES = [
     ("gdv_filter_evaluate_flat", C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int,
                                            C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int]),
     ("gdv_projector_evaluate_export", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), _P, _P, _P]),
+    ("gdv_tier0_program", _P, [_P, C.POINTER(_P), C.c_int, C.c_int]),
+    ("gdv_tier0_launches", C.c_int64, []),
     ("gdv_precompile_projector", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_precompile_filter", C.c_int, [_P, _P]),
     ("gdv_kernel_library_tag", _P, [C.c_char_p, C.c_char_p]),

@@ -1507,6 +1507,25 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const ArrowDeviceArr
 }
 
 // ---------------------------------------------------------------- build support
+char* gdv_tier0_program(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs, int is_condition) {
+  return GuardedPtr([&]() -> char* {
+    if (!schema || !exprs || num_exprs < 1) return FailPtr<char>("schema and expressions are required");
+    std::vector<ExpressionPtr> v;
+    for (int i = 0; i < num_exprs; i++) {
+      if (!exprs[i]) return FailPtr<char>("null expression");
+      v.push_back(exprs[i]->expr);
+    }
+    std::string text;
+    Status st = Tier0Describe(schema->fields, v, is_condition != 0, &text);
+    if (!st.ok()) {
+      Fail(st);
+      return nullptr;
+    }
+    return DupString(text);
+  });
+}
+int64_t gdv_tier0_launches(void) { return Tier0Launches(); }
+
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
                              int num_exprs, int selection_mode) {
   return Guarded([&]() -> int {

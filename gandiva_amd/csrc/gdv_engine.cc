@@ -172,6 +172,8 @@ struct EngineKnobs {
   int grid_mult = 0;               // GDV_GRID_MULT: workgroups per CU of the grid-stride launch (0: default)
   bool fp_window_only = false;     // GDV_FP_WINDOW_ONLY: fused filter-project never moves to its direct kernel (tests, sweeps)
   bool fp_force_stall = false;     // GDV_FP_FORCE_STALL: treat every fused launch as stalled (exercises the chain re-run)
+  bool no_tier0 = false;           // GDV_NO_TIER0: Make waits for the specialised kernel as before round 6
+  bool force_tier0 = false;        // GDV_FORCE_TIER0: every plan that has a tier-0 program runs on it, always (tests)
   static const EngineKnobs& Get() {
     static const EngineKnobs k = [] {
       EngineKnobs x;
@@ -181,6 +183,8 @@ struct EngineKnobs {
       x.no_small_filter = std::getenv("GDV_NO_SMALL_FILTER") != nullptr;
       x.fp_window_only = std::getenv("GDV_FP_WINDOW_ONLY") != nullptr;
       x.fp_force_stall = std::getenv("GDV_FP_FORCE_STALL") != nullptr;
+      x.no_tier0 = std::getenv("GDV_NO_TIER0") != nullptr;
+      x.force_tier0 = std::getenv("GDV_FORCE_TIER0") != nullptr;
       if (const char* s = std::getenv("GDV_GRID_MULT")) x.grid_mult = std::max(1, atoi(s));
       if (const char* s = std::getenv("GDV_FILTER_CHUNKS")) x.filter_chunks = std::max(1, std::min(64, atoi(s)));
       return x;
@@ -517,27 +521,30 @@ void BindLiterals(const KernelPlan& plan, const DeviceBuffer& consts, ArgBlock* 
 
 }  // namespace
 
-Status PlanDeviceStates::Get(const KernelPlan& plan, const PlanDeviceState** out) const {
+Status PlanDeviceStates::Get(const KernelPlan& plan, const PlanDeviceState** out, bool need_kernel) const {
   Runtime& rt = Runtime::Get();
   const int id = rt.id();
-  if (PlanDeviceState* s = slots_[id].load(std::memory_order_acquire)) {
-    *out = s;
+  PlanDeviceState* have = slots_[id].load(std::memory_order_acquire);
+  if (have != nullptr && (!need_kernel || have->kernel.load(std::memory_order_acquire) != nullptr)) {
+    *out = have;
     return Status::OK();
   }
   std::lock_guard<std::mutex> g(mu_);
-  if (PlanDeviceState* s = slots_[id].load(std::memory_order_acquire)) {
-    *out = s;
-    return Status::OK();
+  have = slots_[id].load(std::memory_order_acquire);
+  if (have == nullptr) {
+    std::unique_ptr<PlanDeviceState> st(new PlanDeviceState);
+    GDV_RETURN_NOT_OK(UploadConstBlock(plan, &st->consts));
+    if (plan.prepass) GDV_RETURN_NOT_OK(UploadConstBlock(*plan.prepass, &st->consts_pre));
+    have = st.release();
+    slots_[id].store(have, std::memory_order_release);
   }
-  std::unique_ptr<PlanDeviceState> st(new PlanDeviceState);
-  GDV_RETURN_NOT_OK(rt.GetKernel(plan.source, plan.kernel_name, &st->kernel));
-  GDV_RETURN_NOT_OK(UploadConstBlock(plan, &st->consts));
-  if (plan.prepass) {
-    GDV_RETURN_NOT_OK(rt.GetKernel(plan.prepass->source, plan.prepass->kernel_name, &st->kernel_pre));
-    GDV_RETURN_NOT_OK(UploadConstBlock(*plan.prepass, &st->consts_pre));
+  if (need_kernel && have->kernel.load(std::memory_order_acquire) == nullptr) {
+    if (plan.prepass) GDV_RETURN_NOT_OK(rt.GetKernel(plan.prepass->source, plan.prepass->kernel_name, &have->kernel_pre));
+    const CompiledKernel* k = nullptr;
+    GDV_RETURN_NOT_OK(rt.GetKernel(plan.source, plan.kernel_name, &k));
+    have->kernel.store(k, std::memory_order_release);
   }
-  *out = st.get();
-  slots_[id].store(st.release(), std::memory_order_release);
+  *out = have;
   return Status::OK();
 }
 
@@ -694,11 +701,41 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
                                   mode == SelectionMode::kNone ? 0x7fffffff : static_cast<int>(schema.size())));
   p->out_bytes_x16_ = std::vector<std::atomic<int64_t>>(exprs.size());
   const PlanDeviceState* st = nullptr;
-  GDV_RETURN_NOT_OK(p->states_.Get(p->plan_, &st));  // compiles + loads on the calling thread's device
+  // Tier 0 (round 6): a plan the ahead-of-time interpreter takes, whose specialised kernel is not at hand yet, does not
+  // wait for hipRTC (0.25-0.9 s): the compilation is queued, Make returns, and Evaluate runs the plan's post-fix program
+  // until the code object is there.  GDV_NO_TIER0=1: as before.  GDV_FORCE_TIER0=1 (tests): tier 0 always.
+  GDV_RETURN_NOT_OK(Runtime::Get().EnsureDevice());
+  if (!EngineKnobs::Get().no_tier0 && p->pre_ == nullptr && mode == SelectionMode::kNone) {
+    std::unique_ptr<tier0::Args> prog(new tier0::Args);
+    if (BuildTier0Program(schema, exprs, /*filter=*/false, p->plan_, prog.get(), nullptr)) {
+      const int state = EngineKnobs::Get().force_tier0 ? 0 : Runtime::Get().CodeObjectState(p->plan_.kernel_name);
+      if (state == 0 || EngineKnobs::Get().force_tier0) {
+        p->tier0_ = std::move(prog);
+        p->tier0_pending_.store(true);
+        if (!EngineKnobs::Get().force_tier0) Runtime::Get().CompileInBackground(p->plan_.source, p->plan_.kernel_name);
+      }
+    }
+  }
+  if (!p->tier0_) GDV_RETURN_NOT_OK(p->states_.Get(p->plan_, &st));  // compiles + loads on the calling thread's device
   ProjectorCache().Put(key, p);
   *out = p;
   return Status::OK();
 }
+
+// Tier 0 is on while the plan has a program and its specialised code object has not arrived (or always, under
+// GDV_FORCE_TIER0).  A background compilation that failed turns it off: the blocking path then reports the error.
+static bool Tier0Active(const tier0::Args* prog, std::atomic<bool>* pending, const std::string& kernel_name) {
+  if (prog == nullptr) return false;
+  if (EngineKnobs::Get().force_tier0) return true;
+  if (!pending->load(std::memory_order_relaxed)) return false;
+  if (Runtime::Get().CodeObjectState(kernel_name, /*memory_only=*/true) != 0) {
+    pending->store(false, std::memory_order_relaxed);
+    return false;
+  }
+  return true;
+}
+bool Projector::UseTier0() const { return Tier0Active(tier0_.get(), &tier0_pending_, plan_.kernel_name); }
+bool Filter::UseTier0() const { return Tier0Active(tier0_.get(), &tier0_pending_, plan_.kernel_name); }
 
 Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_cols,
                            const SelectionView* sel, OutputBuffers* outs, int num_outs,
@@ -729,7 +766,9 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
   const PlanDeviceState* dev = nullptr;
-  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+  // tier 0: while the specialised kernel is still compiling this evaluation interprets the plan's program instead
+  const bool tier0 = UseTier0() && !has_sel && rows_word == nullptr && err_word == nullptr;
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev, /*need_kernel=*/!tier0));
 
   ArgBlock args(plan_.layout);
   Staging st;
@@ -832,13 +871,19 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
   }
 
   GDV_RETURN_NOT_OK(st.FlushIn(stream));
-  EvalTrace trace("project", plan_.kernel_name, out_rows, stream);
+  EvalTrace trace(tier0 ? "project (tier 0: interpreted)" : "project", plan_.kernel_name, out_rows, stream);
   std::vector<uint64_t> totals(num_outs, 0);
   uint32_t err_bits = 0;
   if (nv == 0) {
-    if (out_rows > 0)
-      GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
+    if (out_rows > 0 && tier0) {
+      tier0::Args t0 = *tier0_;
+      std::memcpy(t0.block, args.data(), args.size());
+      GDV_HIP_RETURN_NOT_OK(LaunchTier0(t0, out_rows, rt.num_cus(), stream));
+      CountTier0Launch();
+    } else if (out_rows > 0) {
+      GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel.load(), GridFor(plan_, out_rows), plan_.opts.waves * 64, args.data(),
                                   args.size(), stream));
+    }
   } else if (out_rows > 0) {
     // Scanner shape — single launch: workgroup 0 scans the tile totals (granules: tile_starts;
     // grand totals: tile_counts), workers post one granule and poll one.  Wave shape (plans whose
@@ -865,7 +910,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     for (int e = 0; e < num_outs; e++)
       if (plan_.output_types[e].is_varlen()) vl.push_back(e);
     std::vector<uint64_t> seg(2 * ng, 0);
-    const CompiledKernel* active = dev->kernel;
+    const CompiledKernel* active = dev->kernel.load();
     char* state = nullptr;
     size_t state_bytes = 0;
     auto run = [&](int64_t grid) -> Status {  // scanner shape
@@ -906,7 +951,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
       return Status::OK();
     };
     auto run_wave = [&](bool exact) -> Status {
-      const CompiledKernel* k_main = dev->kernel;
+      const CompiledKernel* k_main = dev->kernel.load();
       const CompiledKernel* k_pre = dev->kernel_pre;
       if (exact) {
         GDV_RETURN_NOT_OK(exact_kernels());
@@ -992,7 +1037,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
     const int64_t scanner_grid = std::max<int64_t>(1, ntiles) + 1;  // one workgroup per tile + the scanner
     auto launch = [&]() -> Status {
       if (!has_optimistic) {
-        active = dev->kernel;
+        active = dev->kernel.load();
         GDV_RETURN_NOT_OK(run(scanner_grid));
       } else {
         int path = EngineKnobs::Get().no_optflat ? 2 : path_hint_.load(std::memory_order_relaxed);
@@ -1004,7 +1049,7 @@ Status Projector::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_
           if (plan_.wave_tiles) {
             GDV_RETURN_NOT_OK(run_wave(false));
           } else {
-            active = dev->kernel;
+            active = dev->kernel.load();
             GDV_RETURN_NOT_OK(run(scanner_grid));
           }
           if ((err_bits & kNotAscii) && !(err_bits & kNotFlat) && has_exact) path = 1;
@@ -1109,7 +1154,7 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
   const PlanDeviceState* dev = nullptr;
   GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
   const size_t stride = static_cast<size_t>(plan_.layout.total());
-  const bool one_launch = plan_.has_many_entry && dev->kernel->function_many != nullptr && pre_ == nullptr &&
+  const bool one_launch = plan_.has_many_entry && dev->kernel.load()->function_many != nullptr && pre_ == nullptr &&
                           plan_.num_varlen_outputs == 0 && !plan_.string_skeleton &&
                           stride * static_cast<size_t>(nb) <= Runtime::kPinnedBlock && nb <= 65535 &&
                           !EngineKnobs::Get().no_evaluate_many;
@@ -1162,7 +1207,7 @@ Status Projector::EvaluateMany(const BatchView* batches, int nb, hipStream_t str
   drain.armed = true;
   if (plan_.can_raise) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(err.get(), 0, 8, stream));
   GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(table.get(), pin, stride * nb, hipMemcpyHostToDevice, stream));
-  GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel, grid, nb, plan_.opts.waves * 64, table.get(), stream));
+  GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel.load(), grid, nb, plan_.opts.waves * 64, table.get(), stream));
   uint32_t err_bits = 0;
   if (plan_.can_raise)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(&err_bits, err.get(), 4, hipMemcpyDeviceToHost, stream));
@@ -1349,7 +1394,7 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
   EvalTrace trace("project-async", plan_.kernel_name, out_rows, stream);
   if (path != 2 && plan_.wave_tiles) {
     // ---- wave shape: pre-pass -> offsets scan -> main kernel (the optimistic pair or its exact variant)
-    const CompiledKernel* k_main = dev->kernel;
+    const CompiledKernel* k_main = dev->kernel.load();
     const CompiledKernel* k_pre = dev->kernel_pre;
     const KernelPlan* pp = plan_.prepass.get();
     if (path == 1) {
@@ -1424,7 +1469,7 @@ Status Projector::EvaluateAsyncStage(int64_t num_rows, const ColumnBuffers* cols
     }
   } else {
     // ---- scanner shape: one launch (selection-mode plans; plans without a wave shape; path 2: the general kernel)
-    const CompiledKernel* active = dev->kernel;
+    const CompiledKernel* active = dev->kernel.load();
     if (has_optimistic && path == 2) {
       if (dev->kernel_general.load() == nullptr) {
         const CompiledKernel* k = nullptr;
@@ -1491,7 +1536,19 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
   }
   GDV_RETURN_NOT_OK(PlanFilter(f->plan_schema_, planned, opts, &f->plan_));
   const PlanDeviceState* st = nullptr;
-  GDV_RETURN_NOT_OK(f->states_.Get(f->plan_, &st));  // compiles + loads on the calling thread's device
+  GDV_RETURN_NOT_OK(Runtime::Get().EnsureDevice());
+  if (!EngineKnobs::Get().no_tier0 && f->pre_ == nullptr) {  // tier 0, as Projector::Make
+    std::unique_ptr<tier0::Args> prog(new tier0::Args);
+    if (BuildTier0Program(schema, {condition}, /*filter=*/true, f->plan_, prog.get(), nullptr)) {
+      const int state = EngineKnobs::Get().force_tier0 ? 0 : Runtime::Get().CodeObjectState(f->plan_.kernel_name);
+      if (state == 0 || EngineKnobs::Get().force_tier0) {
+        f->tier0_ = std::move(prog);
+        f->tier0_pending_.store(true);
+        if (!EngineKnobs::Get().force_tier0) Runtime::Get().CompileInBackground(f->plan_.source, f->plan_.kernel_name);
+      }
+    }
+  }
+  if (!f->tier0_) GDV_RETURN_NOT_OK(f->states_.Get(f->plan_, &st));  // compiles + loads on the calling thread's device
   FilterCache().Put(key, f);
   *out = f;
   return Status::OK();
@@ -1536,7 +1593,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
   GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
   const int64_t cap_rows = SmallBatchRows();
   const size_t stride = static_cast<size_t>(plan_.layout.total());
-  bool fused = cap_rows > 0 && dev->kernel->function_small != nullptr && nb <= 65535 &&
+  bool fused = cap_rows > 0 && dev->kernel.load()->function_small != nullptr && nb <= 65535 &&
                stride * static_cast<size_t>(nb) <= Runtime::kPinnedBlock / 2 &&
                small_filter_.load(std::memory_order_relaxed);
   for (int b = 0; fused && b < nb; b++) fused = batches[b].num_rows <= cap_rows;
@@ -1578,7 +1635,7 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
   GDV_RETURN_NOT_OK(block.Allocate(scratch));
   char* const base = block.as<char>();
   // one batch: its argument block goes by value; several: a table, staged through a pinned block
-  const bool by_value = nb == 1 && dev->kernel->function_small1 != nullptr;
+  const bool by_value = nb == 1 && dev->kernel.load()->function_small1 != nullptr;
   const bool small_pin = stride * static_cast<size_t>(nb) <= Runtime::kPinnedSmall;
   char* pin = nullptr;
   std::vector<char> one(by_value ? stride : 0);
@@ -1609,10 +1666,10 @@ Status Filter::EvaluateMany(const BatchView* batches, int nb, SelectionMode mode
   drain.armed = true;
   if (plan_.can_raise) GDV_HIP_RETURN_NOT_OK(hipMemsetAsync(base + err_off, 0, 8, stream));
   if (by_value) {
-    GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, 1, plan_.opts.waves * 64, pin, stride, stream, dev->kernel->function_small1));
+    GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel.load(), 1, plan_.opts.waves * 64, pin, stride, stream, dev->kernel.load()->function_small1));
   } else {
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(base, pin, stride * nb, hipMemcpyHostToDevice, stream));
-    GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel, 1, nb, plan_.opts.waves * 64, base, stream, /*small=*/true));
+    GDV_RETURN_NOT_OK(rt.LaunchMany(*dev->kernel.load(), 1, nb, plan_.opts.waves * 64, base, stream, /*small=*/true));
   }
   if (counts_device != nullptr)
     GDV_HIP_RETURN_NOT_OK(hipMemcpyAsync(counts_device, base + cnt_off, 8 * static_cast<size_t>(nb), hipMemcpyDefault, stream));
@@ -1663,6 +1720,8 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   if (num_rows <= 0) return Status::Invalid("RecordBatch must be non-empty.");
   if (row_base < 0) return Status::Invalid("negative row base");
   if (row_base != 0) flags |= kEvalNoSmall;  // (the one-workgroup kernel emits local positions)
+  const bool tier0 = UseTier0();  // the predicate is interpreted; scan and index emission are the ahead-of-time kernels anyway
+  if (tier0) flags |= kEvalNoSmall;
   if (out_indices == nullptr || (num_selected == nullptr && count_out == nullptr))
     return Status::Invalid("Selection vector cannot be null");
   if (mode == SelectionMode::kNone) return Status::Invalid("Selection vector type cannot be NONE");
@@ -1690,7 +1749,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
   Runtime& rt = Runtime::Get();
   GDV_RETURN_NOT_OK(rt.EnsureDevice());
   const PlanDeviceState* dev = nullptr;
-  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev));
+  GDV_RETURN_NOT_OK(states_.Get(plan_, &dev, /*need_kernel=*/!tier0));
   // Asynchronous evaluation (device buffers; plans that cannot raise, no first stage): everything is
   // enqueued on `stream`, nothing waits, the selected-row count lands in *count_out (8 bytes of
   // device or pinned memory) in stream order — a selection-mode Projector can take it from there
@@ -1762,7 +1821,7 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     dev_out = staged_out.get();
   }
 
-  EvalTrace trace("filter", plan_.kernel_name, num_rows, stream);
+  EvalTrace trace(tier0 ? "filter (tier 0: interpreted predicate)" : "filter", plan_.kernel_name, num_rows, stream);
   // From here on kernels that write `scratch` are in flight: an error return must not hand the block
   // back to the pool (another thread could be given it) before the streams have passed them.  The
   // drain is armed for every exit; the one successful asynchronous exit disarms it again and releases
@@ -1789,7 +1848,14 @@ Status Filter::Evaluate(int64_t num_rows, const ColumnBuffers* cols, int num_col
     cargs.Set64(ArgLayout::kOffN, static_cast<uint64_t>(n));
     cargs.SetPtr(ArgLayout::kOffMask, mask.as<uint64_t>() + lo / 64);
     cargs.SetPtr(ArgLayout::kOffCounts, counts.as<uint32_t>() + lo / tile_rows);
-    GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel, GridFor(plan_, n), plan_.opts.waves * 64, cargs.data(), cargs.size(), stream));
+    if (tier0) {
+      tier0::Args t0 = *tier0_;
+      std::memcpy(t0.block, cargs.data(), cargs.size());
+      GDV_HIP_RETURN_NOT_OK(LaunchTier0(t0, n, rt.num_cus(), stream));
+      CountTier0Launch();
+    } else {
+      GDV_RETURN_NOT_OK(rt.Launch(*dev->kernel.load(), GridFor(plan_, n), plan_.opts.waves * 64, cargs.data(), cargs.size(), stream));
+    }
     hipStream_t s2 = stream;
     if (chunks > 1) {
       hipEvent_t e = nullptr;
@@ -1988,7 +2054,7 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   // which shape: the windowed kernel unless recent batches selected more rows than its LDS window holds (the
   // direct kernel takes the same argument block: PlanFilterProject checks that its literals and constants are a
   // prefix of the windowed plan's)
-  const CompiledKernel* kernel = dev->kernel;
+  const CompiledKernel* kernel = dev->kernel.load();
   const KernelPlan* running = &plan_;
   if (which_kernel() == 1 && !EngineKnobs::Get().fp_window_only) {
     PlanDeviceState* d = const_cast<PlanDeviceState*>(dev);
@@ -2101,6 +2167,26 @@ Status FilterProject::EvaluateFused(int64_t num_rows, const ColumnBuffers* cols,
   }
   drain.armed = false;
   if (num_selected != nullptr) *num_selected = count;
+  return Status::OK();
+}
+
+// ------------------------------------------------------------------ tier 0: the program of a plan as text (no device)
+
+Status Tier0Describe(const Schema& schema, const std::vector<ExpressionPtr>& exprs, bool is_condition, std::string* text) {
+  KernelPlan plan;
+  StagedExpressions staged;
+  StageMaterialisedValues(schema, exprs, &staged);
+  if (!staged.pre.empty()) return Status::NotImplemented("no tier 0: the plan materialises values in a first stage");
+  if (is_condition) {
+    if (exprs.size() != 1) return Status::Invalid("one condition expected");
+    GDV_RETURN_NOT_OK(PlanFilter(schema, exprs[0], CodegenOptions::FromEnv(), &plan));
+  } else {
+    GDV_RETURN_NOT_OK(PlanProjector(schema, exprs, SelectionMode::kNone, CodegenOptions::FromEnv(), &plan));
+  }
+  std::unique_ptr<tier0::Args> prog(new tier0::Args);
+  std::string why;
+  if (!BuildTier0Program(schema, exprs, is_condition, plan, prog.get(), &why)) return Status::NotImplemented("no tier 0: " + why);
+  *text = DescribeTier0Program(*prog);
   return Status::OK();
 }
 

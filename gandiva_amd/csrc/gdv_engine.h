@@ -14,6 +14,7 @@
 #include "gdv_node.h"
 #include "gdv_planner.h"
 #include "gdv_runtime.h"
+#include "gdv_tier0.h"
 
 namespace gdv {
 
@@ -68,7 +69,8 @@ enum EvalFlags : uint32_t {
 // threads that have selected different devices; each context loads the code objects and holds
 // the constant block on its own GPU, lazily, the first time the plan runs there).
 struct PlanDeviceState {
-  const CompiledKernel* kernel = nullptr;
+  // (atomic since round 6: a tier-0 plan's state exists before its kernel is compiled; the kernel is loaded into it later)
+  std::atomic<const CompiledKernel*> kernel{nullptr};
   std::atomic<const CompiledKernel*> kernel_general{nullptr};  // fallback variant (compiled on demand)
   const CompiledKernel* kernel_pre = nullptr;  // wave-shaped plans: the pre-pass kernel
   // the exact variant of a wave-shaped plan (main + pre-pass), compiled when a batch first needs it
@@ -80,7 +82,9 @@ class PlanDeviceStates {
   PlanDeviceStates() { for (auto& s : slots_) s.store(nullptr); }
   ~PlanDeviceStates() { for (auto& s : slots_) delete s.load(); }
   // the state of `plan` on the calling thread's context, created on first use
-  Status Get(const KernelPlan& plan, const PlanDeviceState** out) const;
+  // need_kernel = false (tier 0): the state may come back without its specialised kernel (kernel == nullptr: still
+  // compiling); a later call with need_kernel = true compiles / loads it
+  Status Get(const KernelPlan& plan, const PlanDeviceState** out, bool need_kernel = true) const;
 
  private:
   mutable std::mutex mu_;
@@ -169,6 +173,11 @@ class Projector {
   // output; the optimistic kernels are tried again every 16th batch).
   mutable std::atomic<int> path_hint_{0};
   mutable std::atomic<uint32_t> general_batches_{0};
+  // Tier 0 (round 6): the post-fix program of this plan for the ahead-of-time interpreter kernel (null: the plan has
+  // none), and whether the specialised kernel is still being compiled in the background
+  std::unique_ptr<tier0::Args> tier0_;
+  mutable std::atomic<bool> tier0_pending_{false};
+  bool UseTier0() const;
 
  public:
   int path_hint() const { return path_hint_.load(std::memory_order_relaxed); }
@@ -251,6 +260,9 @@ class Filter {
  private:
   std::atomic<int> chunks_{1};
   std::atomic<bool> small_filter_{true};
+  std::unique_ptr<tier0::Args> tier0_;  // as Projector's
+  mutable std::atomic<bool> tier0_pending_{false};
+  bool UseTier0() const;
   Schema schema_;
   KernelPlan plan_;
   PlanDeviceStates states_;  // code objects + constant block per device context
@@ -329,6 +341,8 @@ class FilterProject {
 Status PrecompileProjector(const Schema& schema, const std::vector<ExpressionPtr>& exprs,
                            SelectionMode mode);
 Status PrecompileFilter(const Schema& schema, const ExpressionPtr& condition);
+// tier 0 (round 6): the post-fix program the interpreter kernel would run for these expressions / this condition
+Status Tier0Describe(const Schema& schema, const std::vector<ExpressionPtr>& exprs, bool is_condition, std::string* text);
 Status PrecompileFilterProject(const Schema& schema, const ExpressionPtr& condition,
                                const std::vector<ExpressionPtr>& exprs, SelectionMode index_mode);
 

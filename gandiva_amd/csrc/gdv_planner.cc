@@ -3301,7 +3301,9 @@ Status PlanFilterProjectShape(const Schema& schema, const ExpressionPtr& conditi
     << "  // one workgroup tile = GDV_WAVES x GDV_FP_K x GDV_U x 64 rows; tile order = row order.  Round 6: the tile comes from an\n"
     << "  // atomic TICKET (one agent-scope fetch-add per workgroup, the word behind the count and the error word), not from\n"
     << "  // blockIdx: the look-back waits only for tiles with LOWER tickets, whose workgroups have already started — no\n"
-    << "  // deadlock whatever order the dispatcher starts workgroups in.\n"
+    << "  // deadlock whatever order the dispatcher starts workgroups in.  One fetch-add + one barrier per 24576 rows: 0.09 ms\n"
+    << "  // of 3.44 at 10^9 rows (profiles/r06_ticket_cost.txt; a workgroup walking several tiles — next ticket drawn ahead, or\n"
+    << "  // behind the look-back — measured 4.3 / 3.65 ms: a drawn-but-unstarted tile stalls every tile behind it).\n"
     << (opts.fp_experiment == 3
             // EXPERIMENT (GDV_FP_EXPERIMENT=3; tools only): round 5's tile = blockIdx, to price the ticket
             ? "  const gdv_int64 tile = (gdv_int64)blockIdx.x;\n"

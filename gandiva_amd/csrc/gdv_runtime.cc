@@ -10,7 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <set>
+#include <thread>
 
 namespace gdv {
 
@@ -193,21 +197,95 @@ static uint64_t Fnv(const char* s, size_t n) {
   return h;
 }
 
+namespace {
+std::mutex& CodeCacheMutex() { static std::mutex m; return m; }
+std::map<std::string, std::vector<char>>& CodeCache() { static std::map<std::string, std::vector<char>> c; return c; }
+std::set<std::string>& FailedCompilations() { static std::set<std::string> s; return s; }
+std::string LibraryHashTag() {  // the on-disk cache is keyed by the hash of the whole device library as well
+  static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
+  char tag[40];
+  snprintf(tag, sizeof(tag), "%016llx", static_cast<unsigned long long>(lib_hash));
+  return tag;
+}
+
+// The process's one background compiler thread (tier 0): compilations are serialised anyway (CompileToCodeObject), a
+// queue keeps Make from waiting for them.  Joined at exit: a detached thread inside hipRTC while the statics of the
+// process are torn down is a crash.
+class BackgroundCompiler {
+ public:
+  static BackgroundCompiler& Get() { static BackgroundCompiler b; return b; }
+  void Push(std::string source, std::string name) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (stop_) return;
+    for (auto& j : jobs_) if (j.second == name) return;
+    jobs_.emplace_back(std::move(source), std::move(name));
+    if (!started_) { started_ = true; worker_ = std::thread([this] { Run(); }); }
+    cv_.notify_one();
+  }
+  ~BackgroundCompiler() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; jobs_.clear(); }
+    cv_.notify_all();
+    if (worker_.joinable()) worker_.join();
+  }
+
+ private:
+  void Run() {
+    for (;;) {
+      std::pair<std::string, std::string> job;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return stop_ || !jobs_.empty(); });
+        if (stop_) return;
+        job = std::move(jobs_.front());
+        jobs_.pop_front();
+      }
+      std::vector<char> code;
+      Status st = Runtime::ForDevice(0).CompileToCodeObject(job.first, job.second, &code);
+      if (!st.ok()) {
+        std::lock_guard<std::mutex> g(CodeCacheMutex());
+        FailedCompilations().insert(job.second);
+      }
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::pair<std::string, std::string>> jobs_;
+  std::thread worker_;
+  bool started_ = false, stop_ = false;
+};
+}  // namespace
+
+int Runtime::CodeObjectState(const std::string& kernel_name, bool memory_only) {
+  const std::string a = arch();
+  {
+    std::lock_guard<std::mutex> g(CodeCacheMutex());
+    if (CodeCache().count(kernel_name + "." + a)) return 1;
+    if (FailedCompilations().count(kernel_name)) return -1;
+  }
+  if (memory_only || std::getenv("GDV_NO_DISK_CACHE") != nullptr) return 0;
+  const std::string dir = cache_dir();
+  if (dir.empty()) return 0;
+  const std::string path = dir + "/" + kernel_name + "." + LibraryHashTag() + "." + a + ".hsaco";
+  return access(path.c_str(), R_OK) == 0 ? 1 : 0;
+}
+
+void Runtime::CompileInBackground(const std::string& source, const std::string& kernel_name) {
+  BackgroundCompiler::Get().Push(source, kernel_name);
+}
+
 Status Runtime::CompileToCodeObject(const std::string& source, const std::string& kernel_name,
                                     std::vector<char>* code, bool* from_cache,
                                     bool ignore_cached) {
   const std::string a = arch();
-  static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
-  char tag[40];
-  snprintf(tag, sizeof(tag), "%016llx", static_cast<unsigned long long>(lib_hash));
+  const std::string tag = LibraryHashTag();
   if (std::getenv("GDV_DUMP_SOURCE")) {
     const std::string d = cache_dir();
     std::ofstream f((d.empty() ? std::string("/tmp") : d) + "/" + kernel_name + ".hip");
     f << source;
   }
   // every context loads the same code object: compiled (or read from disk) once per process
-  static std::mutex code_mu;
-  static std::map<std::string, std::vector<char>> code_cache;
+  std::mutex& code_mu = CodeCacheMutex();
+  std::map<std::string, std::vector<char>>& code_cache = CodeCache();
   const std::string mem_key = kernel_name + "." + a;
   if (!ignore_cached) {
     std::lock_guard<std::mutex> g(code_mu);
@@ -244,6 +322,15 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
   // temporary-file handling has no need to be exercised concurrently
   static std::mutex compile_mu;
   std::lock_guard<std::mutex> compile_guard(compile_mu);
+  if (!ignore_cached) {  // (another thread — the background compiler of tier 0 — may have produced it while this one waited)
+    std::lock_guard<std::mutex> g(code_mu);
+    auto it = code_cache.find(mem_key);
+    if (it != code_cache.end()) {
+      *code = it->second;
+      if (from_cache) *from_cache = true;
+      return Status::OK();
+    }
+  }
   hiprtcProgram prog;
   const char* hdr_src[] = {gdv_device_lib_src};
   const char* hdr_name[] = {"gdv_device_lib.hpp"};

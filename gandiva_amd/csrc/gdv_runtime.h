@@ -71,6 +71,11 @@ class Runtime {
   Status CompileToCodeObject(const std::string& source, const std::string& kernel_name,
                              std::vector<char>* code, bool* from_cache = nullptr,
                              bool ignore_cached = false);
+  // Tier 0 (round 6).  CodeObjectState: 1 = the code object of `kernel_name` is at hand (in memory, or on disk: a load
+  // away), 0 = not yet, -1 = a background compilation of it failed (the blocking path will report why).
+  // CompileInBackground: queue the compilation on the process's one compiler thread and return at once.
+  int CodeObjectState(const std::string& kernel_name, bool memory_only = false);
+  void CompileInBackground(const std::string& source, const std::string& kernel_name);
   // CompileToCodeObject + hipModuleLoadData on this context's device; cached per context.
   Status GetKernel(const std::string& source, const std::string& kernel_name,
                    const CompiledKernel** out);

@@ -600,6 +600,22 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDe
                                   const gdv_selection_t* sel, void* stream,
                                   struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
 
+/* ---- tier 0 (round 6) ---------------------------------------------------------------
+ * Make of an unseen tree used to wait for hipRTC (0.25-0.9 s; the reference's LLVM JIT takes tens of milliseconds).
+ * Plans inside the fixed-width core — add / subtract / multiply, the six comparisons, not / isnull / isnotnull, the numeric
+ * casts, if / else, AND / OR, literals, over bool / integer / float / date / time columns, row mode — now come with a
+ * post-fix PROGRAM for an ahead-of-time interpreter kernel: gdv_projector_make / gdv_filter_make queue the compilation on a
+ * background thread and return (milliseconds); evaluations interpret the program until the specialised code object
+ * has arrived and then switch to it.  Same argument block, same device functions, same flags: results are
+ * bit-identical, the interpreted evaluation is slower.  Other plans wait for their compilation as before.
+ * Environment, read once per process: GDV_NO_TIER0=1 (Make waits, as before round 6), GDV_FORCE_TIER0=1 (plans that
+ * have a program always run on it: how the parity suite is held to tier 0).
+ * gdv_tier0_program: the program of a projector's expressions (is_condition = 0) or a filter's condition (1) as text,
+ * one instruction per line — or NULL, with the reason why the plan has no tier 0 in gdv_last_error().  No device needed.
+ * gdv_tier0_launches: evaluations that ran on tier 0 so far (process-wide, cumulative). */
+char* gdv_tier0_program(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs, int is_condition);
+int64_t gdv_tier0_launches(void);
+
 /* ---- build support ----------------------------------------------------------------- */
 /* Plan + compile to a gfx950 code object without a device; fills the on-disk kernel cache. */
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
