@@ -8,7 +8,7 @@ Package layout (only what the hot path needs):
                thread per device context inside one process)
 """
 from .gandiva import (  # noqa: F401
-    Condition, Configuration, DeviceBatch, DeviceColumn, Expression, Filter, FilterProject, FunctionSignature,
+    Condition, Configuration, DeviceBatch, DeviceColumn, DevicePool, Expression, Filter, FilterProject, FunctionSignature,
     GandivaError, HostArena, Node, Projector, SelectionVector, TreeExprBuilder, host_staged_bytes,
     device_count, get_device, get_registered_function_signatures, make_filter, make_filter_project, make_projector,
     physical_device_count, set_device, set_virtual_devices,

@@ -133,6 +133,14 @@ PROTOTYPES = [
                                                       C.POINTER(gdv_out_column_t), C.c_int, C.POINTER(C.c_int32), C.c_int]),
     ("gdv_filter_evaluate_host_sharded", C.c_int, [_P, C.c_int64, C.POINTER(gdv_column_t), C.c_int, C.c_int, _P, C.c_int64,
                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int]),
+    ("gdv_device_pool_create", C.c_int, [C.POINTER(_P)]),
+    ("gdv_device_pool_destroy", None, [_P]),
+    ("gdv_device_pool_reserve_set", C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.POINTER(_P), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_int)]),
+    ("gdv_device_pool_alloc", C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    ("gdv_device_pool_free", C.c_int, [_P, _P]),
+    ("gdv_device_pool_trim", C.c_int, [_P]),
+    ("gdv_device_pool_bytes", C.c_int64, [_P, C.POINTER(C.c_int64)]),
     ("gdv_device_num_cus", C.c_int, []),
     ("gdv_device_arch", C.c_char_p, []),
     ("gdv_device_alloc", C.c_int, [C.c_int64, C.POINTER(_P)]),

@@ -14,6 +14,7 @@
 #include "gdv_engine.h"
 #include "gdv_kernels.h"
 #include "gdv_libtag.h"
+#include "gdv_pool.h"
 #include "gdv_proto.h"
 #include "gdv_regex.h"
 
@@ -28,6 +29,7 @@ struct gdv_projector {
 };
 struct gdv_filter { std::shared_ptr<Filter> f; };
 struct gdv_filter_project { std::shared_ptr<FilterProject> fp; };
+struct gdv_device_pool { DevicePool pool; };
 
 namespace {
 
@@ -1068,6 +1070,42 @@ int gdv_device_alloc(int64_t bytes, void** ptr) {
   return Check(Runtime::Get().Alloc(static_cast<size_t>(bytes ? bytes : 1), ptr));
 }
 int gdv_device_free(void* ptr) { Runtime::Get().Free(ptr); return GDV_OK; }
+int gdv_device_pool_create(gdv_device_pool_t** out) {
+  return Guarded([&]() -> int {
+    if (!out) return Fail(Status::Invalid("null output pointer"));
+    Status st = Runtime::Get().EnsureDevice();
+    if (!st.ok()) return Fail(st);
+    *out = new gdv_device_pool();
+    return GDV_OK;
+  });
+}
+void gdv_device_pool_destroy(gdv_device_pool_t* pool) { delete pool; }
+int gdv_device_pool_reserve_set(gdv_device_pool_t* pool, int count, int64_t bytes, int candidates, void** ptrs, double* rates,
+                                int* tried, int* kept) {
+  return Guarded([&]() -> int {
+    if (!pool) return Fail(Status::Invalid("null pool"));
+    return Check(pool->pool.ReserveSet(count, bytes, candidates, ptrs, rates, tried, kept));
+  });
+}
+int gdv_device_pool_alloc(gdv_device_pool_t* pool, int64_t bytes, void** ptr) {
+  return Guarded([&]() -> int {
+    if (!pool) return Fail(Status::Invalid("null pool"));
+    return Check(pool->pool.Alloc(bytes, ptr));
+  });
+}
+int gdv_device_pool_free(gdv_device_pool_t* pool, void* ptr) {
+  return Guarded([&]() -> int {
+    if (!pool) return Fail(Status::Invalid("null pool"));
+    return Check(pool->pool.Free(ptr));
+  });
+}
+int gdv_device_pool_trim(gdv_device_pool_t* pool) {
+  return Guarded([&]() -> int {
+    if (!pool) return Fail(Status::Invalid("null pool"));
+    return Check(pool->pool.Trim());
+  });
+}
+int64_t gdv_device_pool_bytes(const gdv_device_pool_t* pool, int64_t* in_use) { return pool ? pool->pool.bytes_held(in_use) : 0; }
 int gdv_memcpy_h2d(void* dst, const void* src, int64_t bytes) {
   hipError_t e = hipMemcpy(dst, src, static_cast<size_t>(bytes), hipMemcpyHostToDevice);
   return e == hipSuccess ? GDV_OK : Fail(Status::ExecutionError(hipGetErrorString(e)));

@@ -7,6 +7,10 @@
 namespace gdv {
 
 // Number of scan workgroups (= entries of `chunk_sums`) for m counts.
+// placement probe of the device pool (round 6): GB/s of a non-temporal write sweep over `count` buffers of bytes_each bytes,
+// all written at the same offsets at the same time (minimum of three timed launches after one warm-up; default stream)
+hipError_t MeasureWriteSet(void* const* bufs, int count, size_t bytes_each, int num_cus, double* gbs);
+
 int64_t ScanChunks(int64_t m);
 
 // offsets[i] = sum(counts[0..i)) for i < m; *total = sum of all counts.

@@ -389,6 +389,49 @@ hipError_t MeasureStreamCeiling(void* const* streams, int nr, int nw, size_t ele
   return hipErrorInvalidValue;
 }
 
+// ---- placement probe of the device pool (round 6).  Where the driver puts a set of buffers that are streamed together
+// decides what a projection over them runs at (profiles/r05_box_states.txt: 4.9 .. 7.0 ms for the same C2 kernel), and a
+// non-temporal WRITE sweep over the set — every buffer at the same offset at the same time, as the projection kernel
+// writes its output columns — predicts it (profiles/r06_placement_probe.txt: rank correlation 0.98 with the kernel's time).
+struct ProbePointers { unsigned long long* p[32]; };
+__global__ void __launch_bounds__(256) ProbeWriteSet(const ProbePointers P, int count, size_t elems) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t ntiles = elems / (256 * U);
+  for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const size_t base = t * (256 * U) + (size_t)wave * (64 * U) + lane;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      for (int w = 0; w < count; w++) __builtin_nontemporal_store((unsigned long long)(t + w), P.p[w] + base + 64 * u);
+  }
+}
+hipError_t MeasureWriteSet(void* const* bufs, int count, size_t bytes_each, int num_cus, double* gbs) {
+  if (count < 1 || count > 32) return hipErrorInvalidValue;
+  ProbePointers P;
+  for (int i = 0; i < 32; i++) P.p[i] = i < count ? static_cast<unsigned long long*>(bufs[i]) : nullptr;
+  const size_t elems = bytes_each / 8;
+  hipEvent_t e0, e1;
+  hipError_t err = hipEventCreate(&e0);
+  if (err != hipSuccess) return err;
+  err = hipEventCreate(&e1);
+  if (err != hipSuccess) { (void)hipEventDestroy(e0); return err; }
+  const int grid = num_cus * 8;
+  float best = 1e30f;
+  for (int rep = 0; rep < 4 && err == hipSuccess; rep++) {  // the first launch warms up; the minimum of the others counts
+    err = hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(ProbeWriteSet, dim3(grid), dim3(256), 0, nullptr, P, count, elems);
+    if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float ms = 1e30f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (err == hipSuccess) *gbs = (double)count * (double)(elems / 1024 * 1024) * 8.0 / (best * 1e-3) / 1e9;
+  return err;
+}
+
 int64_t ScanChunks(int64_t m) { return (m + kScanChunk - 1) / kScanChunk; }
 
 namespace {

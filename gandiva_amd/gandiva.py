@@ -484,6 +484,103 @@ def host_staged_bytes():
     return int(_capi.lib().gdv_host_staged_bytes())
 
 
+class _PoolBlock:
+    """`nbytes` of a DevicePool buffer, seen by torch through __cuda_array_interface__ (zero-copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class DevicePool:
+    """gdv_device_pool_*: library-owned, placement-aware HBM for buffers that are streamed together (include/gandiva_amd.h).
+    ``reserve_outputs`` hands a Projector's output columns for batches of ``rows`` rows out of the best of several
+    candidate placements (probed with a write sweep by the library) and ``release`` puts them back INTO THE POOL, where
+    the next ``reserve_outputs`` of the same shape finds them: a good placement, found once, is kept."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(_capi.lib().gdv_device_pool_create(C.byref(self._h)))
+        self.last_probe = None
+
+    def close(self):
+        if self._h:
+            _capi.lib().gdv_device_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _tensor(self, ptr, nbytes):
+        import torch
+        return torch.as_tensor(_PoolBlock(ptr, nbytes), device="cuda")
+
+    def reserve_set(self, count, nbytes, candidates=8):
+        """-> (pointers, {"rates_gbs": [...], "kept": index}): `count` buffers of `nbytes` each, the best of up to `candidates` placements."""
+        ptrs = (C.c_void_p * count)()
+        rates = (C.c_double * max(candidates, 1))()
+        tried, kept = C.c_int(0), C.c_int(0)
+        _check(_capi.lib().gdv_device_pool_reserve_set(self._h, count, nbytes, candidates, ptrs, rates, C.byref(tried), C.byref(kept)))
+        return [int(p) for p in ptrs], {"rates_gbs": [round(rates[i], 1) for i in range(tried.value)], "kept": kept.value}
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(_capi.lib().gdv_device_pool_alloc(self._h, nbytes, C.byref(p)))
+        return int(p.value)
+
+    def free(self, ptr):
+        _check(_capi.lib().gdv_device_pool_free(self._h, C.c_void_p(ptr)))
+
+    def trim(self):
+        _check(_capi.lib().gdv_device_pool_trim(self._h))
+
+    def bytes_held(self):
+        used = C.c_int64(0)
+        total = _capi.lib().gdv_device_pool_bytes(self._h, C.byref(used))
+        return total, used.value
+
+    def reserve_outputs(self, projector, rows, candidates=8):
+        """DeviceColumns for every (fixed-width / bool) output of ``projector`` over ``rows`` rows.  Outputs of one size
+        are reserved as ONE set (they are written together); the validity bitmaps, a 64th of the traffic, are plain pool
+        allocations.  ``last_probe`` holds what the library measured."""
+        lib = _capi.lib()
+        sizes = []
+        for i, t in enumerate(projector._out_types):
+            if pa.types.is_string(t) or pa.types.is_binary(t):
+                raise TypeError("DevicePool.reserve_outputs: fixed-width outputs only")
+            vb, db = C.c_int64(), C.c_int64()
+            _check(lib.gdv_projector_output_sizes(projector._h, i, rows, GDV_MEM_DEVICE, vb, db))
+            sizes.append((_pad64(max(vb.value, 1)), _pad64(max(db.value, 1))))
+        data_ptr = [None] * len(sizes)
+        self.last_probe = []
+        for nbytes in sorted({d for _, d in sizes}, reverse=True):
+            members = [i for i, (_, d) in enumerate(sizes) if d == nbytes]
+            for lo in range(0, len(members), 32):
+                group = members[lo:lo + 32]
+                ptrs, probe = self.reserve_set(len(group), nbytes, candidates)
+                probe["buffers"], probe["bytes_each"] = len(group), nbytes
+                self.last_probe.append(probe)
+                for i, p in zip(group, ptrs):
+                    data_ptr[i] = p
+        cols = []
+        for i, t in enumerate(projector._out_types):
+            vbytes, dbytes = sizes[i]
+            col = DeviceColumn(t, rows, self._tensor(self.alloc(vbytes), vbytes), self._tensor(data_ptr[i], dbytes))
+            col._pool_ptrs = (col.validity.data_ptr(), data_ptr[i])
+            cols.append(col)
+        return cols
+
+    def release(self, columns):
+        """The columns' buffers go back into the pool (they stay allocated there).  The tensors must not be used afterwards."""
+        for c in columns:
+            for p in getattr(c, "_pool_ptrs", ()):
+                self.free(p)
+            c._pool_ptrs = ()
+
+
 class DeviceBatch:
     """A record batch resident in the HBM of the current device (Arrow layout, buffers
     padded to 64 bytes).  Build with ``DeviceBatch.from_arrow`` (uploads) or directly from

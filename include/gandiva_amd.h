@@ -600,6 +600,34 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDe
                                   const gdv_selection_t* sel, void* stream,
                                   struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
 
+/* ---- device pool (round 6): placement-aware, retaining HBM for buffers that are streamed together ----------------
+ * Where the driver puts a set of large buffers decides what a kernel over them runs at, and the placement stays with the
+ * buffers: the same C2 kernel takes 4.88 .. 6.30 ms per Evaluate over ten fresh allocations of its ten output columns on
+ * one box (profiles/r06_placement_probe.txt; rounds 4-5 saw 4.9 .. 7.0).  A caller that allocates its outputs once —
+ * arrow::MemoryPool (pyarrow/include/arrow/memory_pool.h:120-124, the pool argument of Projector::Evaluate), a JNI caller's
+ * allocator — gets whichever it gets.  The pool owns that choice:
+ *   gdv_device_pool_reserve_set   `count` buffers of `bytes` each (the output columns of a projection over a batch of
+ *       that size): up to `candidates` placements of the WHOLE SET are allocated, each is timed with a non-temporal write
+ *       sweep over the set (all buffers at the same offset at the same time, as the projection kernel writes them; rank
+ *       correlation 0.98 with that kernel's time), the fastest is kept, the others go back to the driver.  Costs a few
+ *       milliseconds per candidate; the kept set, the candidate and one more are alive at a time (bounded by free memory).
+ *       rates (may be NULL; capacity `candidates`): every candidate's sweep in GB/s; *tried, *kept (may be NULL).
+ *       Sets of buffers below 64 MiB are allocated without a search.
+ *   gdv_device_pool_free          the buffer goes back TO THE POOL and stays there: a later alloc / reserve_set of the
+ *       same size gets it back — the placement found once serves every later batch of that shape.
+ *   gdv_device_pool_alloc         one buffer: a retained one of exactly this size, else a fresh allocation.
+ *   gdv_device_pool_trim / _destroy   retained buffers / everything go back to the driver.
+ * A pool belongs to the device the calling thread had selected when it was created.  Thread-safe. */
+typedef struct gdv_device_pool gdv_device_pool_t;
+int gdv_device_pool_create(gdv_device_pool_t** out);
+void gdv_device_pool_destroy(gdv_device_pool_t* pool);
+int gdv_device_pool_reserve_set(gdv_device_pool_t* pool, int count, int64_t bytes, int candidates, void** ptrs,
+                                double* rates, int* tried, int* kept);
+int gdv_device_pool_alloc(gdv_device_pool_t* pool, int64_t bytes, void** ptr);
+int gdv_device_pool_free(gdv_device_pool_t* pool, void* ptr);
+int gdv_device_pool_trim(gdv_device_pool_t* pool);
+int64_t gdv_device_pool_bytes(const gdv_device_pool_t* pool, int64_t* in_use);
+
 /* ---- tier 0 (round 6) ---------------------------------------------------------------
  * Make of an unseen tree used to wait for hipRTC (0.25-0.9 s; the reference's LLVM JIT takes tens of milliseconds).
  * Plans inside the fixed-width core — add / subtract / multiply, the six comparisons, not / isnull / isnotnull, the numeric
