@@ -793,9 +793,10 @@ def time_steps(wl, warm, steps):
 
 def pool_outputs(wl, candidates):
     """Round 6 (verdict item 2): the placement search belongs to the product.  The output columns of a projection workload
-    are taken from the library's device pool: gdv_device_pool_reserve_set allocates up to `candidates` placements of the
-    whole set, times a non-temporal write sweep over each (rank correlation 0.98 with the projection kernel's time,
-    profiles/r06_placement_probe.txt), keeps the fastest and returns the others to the driver.  What a caller gets WITHOUT
+    are taken from the library's device pool: gdv_device_pool_reserve_set allocates four times the set as single buffers,
+    forms candidates from every fourth one (members spread over a wide span of allocations: what is slow is a set of
+    neighbours), times a non-temporal write sweep over each candidate (profiles/r06_placement_*.txt), keeps the fastest
+    and returns everything else to the driver.  What a caller gets WITHOUT
     the pool — the first plain allocation — is timed first and reported next to it.  Returns the `placement` object."""
     import torch
     import gandiva_amd as gandiva
@@ -804,17 +805,14 @@ def pool_outputs(wl, candidates):
     first_ms = time_steps(wl, 40, 3)      # (the first ~0.2 s after the generation are not representative of any placement)
     wl.outs = None
     torch.cuda.empty_cache()
-    free_b = torch.cuda.mem_get_info()[0]
-    out_bytes = wl.rows * (wl.bytes_per_row - wl.read_per_row)
-    candidates = int(max(1, min(candidates, (free_b - (4 << 30)) // max(out_bytes, 1))))
     t0 = time.perf_counter()
     wl.pool = gandiva.DevicePool()
     wl.outs = wl.pool.reserve_outputs(wl.obj, wl.rows, candidates)
     setup_ms = (time.perf_counter() - t0) * 1e3
     wl.step()                             # first touch of the kept set by the product kernel
     torch.cuda.synchronize()
-    return {"by": "the library's device pool: gdv_device_pool_reserve_set (candidate placements of the whole output set, "
-                  "probed with a non-temporal write sweep, fastest kept, the others returned to the driver)",
+    return {"by": "the library's device pool: gdv_device_pool_reserve_set (4x the output set allocated as single buffers, candidates = "
+                  "every 4th one, probed with a non-temporal write sweep, fastest kept, everything else returned to the driver)",
             "sets": wl.pool.last_probe, "reserve_ms": round(setup_ms, 1),
             "first_plain_allocation_ms": round(first_ms, 4)}
 

@@ -92,66 +92,58 @@ Status DevicePool::ReserveSet(int count, int64_t bytes, int candidates, void** p
   candidates = std::max(1, candidates);
   // small sets are not worth a search (the sweep needs at least a few MiB per buffer to say anything)
   if (bytes < (int64_t{64} << 20)) candidates = 1;
-  using Set = std::vector<void*>;
-  auto release = [](Set* s) {
-    for (void* p : *s) (void)hipFree(p);
-    s->clear();
+  // What is slow is a set whose members are NEIGHBOURS in the driver's allocation order (one region of the HBM address
+  // map: ten such columns run C2 at 5.1 .. 6.4 ms depending on the region, whatever the spacing between them —
+  // profiles/r06_placement_stagger.txt); members SPREAD over a wide span of allocations run at 4.81 .. 5.36, strided picks
+  // at 4.91 .. 4.93 (profiles/r06_placement_subsets.txt), and how fast a buffer is alone says nothing about the set
+  // (profiles/r06_placement_map.txt).  So: allocate `spread` times the set as single buffers, take every spread-th one
+  // (candidate k = buffers k, k + spread, k + 2 spread ...), probe the candidates with the write sweep, keep the best,
+  // give everything else back.
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const int64_t room = (static_cast<int64_t>(free_b) - (int64_t{4} << 30)) / std::max<int64_t>(bytes, 1);
+  int spread = candidates > 1 ? 4 : 1;
+  while (spread > 1 && static_cast<int64_t>(count) * spread > room) spread--;
+  std::vector<void*> all;
+  auto release_all = [&](const std::vector<void*>& keep) {
+    for (void* p : all)
+      if (std::find(keep.begin(), keep.end(), p) == keep.end()) (void)hipFree(p);
+    all.clear();
   };
-  auto allocate = [&](Set* s) -> Status {
-    for (int i = 0; i < count; i++) {
-      void* p = nullptr;
-      Status st = Raw(bytes, &p);
-      if (!st.ok()) {
-        release(s);
-        return st;
-      }
-      s->push_back(p);
-    }
-    return Status::OK();
-  };
-  const int64_t need = static_cast<int64_t>(count) * bytes;
-  Set best, loser;
-  double best_rate = -1;
-  int n = 0;
-  for (int c = 0; c < candidates; c++) {
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    if (static_cast<int64_t>(free_b) < need + (int64_t{2} << 30)) {
-      if (loser.empty()) break;  // not even one more placement fits next to the best one
-      release(&loser);           // (its pages may come straight back: still a candidate)
-      (void)hipMemGetInfo(&free_b, &total_b);
-      if (static_cast<int64_t>(free_b) < need + (int64_t{2} << 30)) break;
-    }
-    Set cand;
-    Status st = allocate(&cand);
+  for (int i = 0; i < count * spread; i++) {
+    void* p = nullptr;
+    Status st = Raw(bytes, &p);
     if (!st.ok()) {
-      if (best.empty()) { release(&loser); return st; }
-      break;
+      if (static_cast<int>(all.size()) >= count) break;  // (less spread than hoped for)
+      release_all({});
+      return st;
     }
-    release(&loser);  // the previous loser stayed until this candidate existed: the driver could not hand its pages back
+    all.push_back(p);
+  }
+  spread = static_cast<int>(all.size()) / count;
+  const int ncand = std::min(candidates, spread);
+  std::vector<void*> best;
+  double best_rate = -1;
+  for (int k = 0; k < ncand; k++) {
+    std::vector<void*> cand;
+    for (int i = 0; i < count; i++) cand.push_back(all[static_cast<size_t>(k + i * spread)]);
     double rate = 0;
-    if (candidates > 1) {
+    if (ncand > 1) {
       hipError_t e = MeasureWriteSet(cand.data(), count, static_cast<size_t>(bytes), rt_->num_cus(), &rate);
       if (e != hipSuccess) {
-        release(&cand);
-        release(&best);
+        release_all({});
         return Status::ExecutionError(std::string("device pool: placement probe failed: ") + hipGetErrorString(e));
       }
     }
-    if (rates) rates[n] = rate;
+    if (rates) rates[k] = rate;
     if (rate > best_rate) {
-      loser.swap(best);
-      best.swap(cand);
       best_rate = rate;
-      if (kept) *kept = n;
-    } else {
-      loser.swap(cand);
+      best = cand;
+      if (kept) *kept = k;
     }
-    n++;
   }
-  release(&loser);
-  if (best.empty()) return Status::OutOfMemory("device pool: no room for " + std::to_string(need) + " bytes");
-  if (tried) *tried = n;
+  if (tried) *tried = ncand;
+  release_all(best);
   std::lock_guard<std::mutex> g(mu_);
   for (int i = 0; i < count; i++) {
     ptrs[i] = best[i];

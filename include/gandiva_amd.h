@@ -607,12 +607,15 @@ int gdv_projector_evaluate_export(const gdv_projector_t* p, const struct ArrowDe
  * arrow::MemoryPool (pyarrow/include/arrow/memory_pool.h:120-124, the pool argument of Projector::Evaluate), a JNI caller's
  * allocator — gets whichever it gets.  The pool owns that choice:
  *   gdv_device_pool_reserve_set   `count` buffers of `bytes` each (the output columns of a projection over a batch of
- *       that size): up to `candidates` placements of the WHOLE SET are allocated, each is timed with a non-temporal write
- *       sweep over the set (all buffers at the same offset at the same time, as the projection kernel writes them; rank
- *       correlation 0.98 with that kernel's time), the fastest is kept, the others go back to the driver.  Costs a few
- *       milliseconds per candidate; the kept set, the candidate and one more are alive at a time (bounded by free memory).
+ *       that size).  What is slow is a set whose members are NEIGHBOURS in the driver's allocation order (one region of
+ *       the HBM address map; 5.1 .. 6.4 ms for C2 depending on the region, whatever the spacing inside it), members
+ *       spread over a wide span of allocations are fast (4.81 .. 5.36, strided picks 4.91 .. 4.93 — profiles/
+ *       r06_placement_{map,stagger,subsets}.txt).  So: four times the set is allocated as single buffers, candidate k =
+ *       buffers k, k + 4, k + 8 ..., up to min(candidates, 4) candidates are timed with a non-temporal write sweep over
+ *       the whole set (all buffers at the same offset at the same time, as the projection kernel writes them), the
+ *       fastest is kept, everything else goes back to the driver.  Tens of milliseconds per GiB reserved, once.
  *       rates (may be NULL; capacity `candidates`): every candidate's sweep in GB/s; *tried, *kept (may be NULL).
- *       Sets of buffers below 64 MiB are allocated without a search.
+ *       Sets of buffers below 64 MiB, and candidates = 1, are plain allocations.
  *   gdv_device_pool_free          the buffer goes back TO THE POOL and stays there: a later alloc / reserve_set of the
  *       same size gets it back — the placement found once serves every later batch of that shape.
  *   gdv_device_pool_alloc         one buffer: a retained one of exactly this size, else a fresh allocation.
