@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgandiva_amd.so")
+# (GANDIVA_AMD_LIB: another build of the same library — the sanitizer build of tools/sanitize_cpu_suite.sh)
+LIB_PATH = os.environ.get("GANDIVA_AMD_LIB") or os.path.join(_HERE, "libgandiva_amd.so")
 
 
 class gdv_type_t(C.Structure):

@@ -1782,10 +1782,12 @@ GDV_DEV void gdv_stage_copy(gdv_lds_u8* dst, const gdv_str& s) {
     if (r & 1) dst[i] = (gdv_uint8)w;
   }
 }
-// Wave-shaped kernels sweep one sub-tile (64 rows) at a time and keep its span in LDS: GDV_SUB_SPAN =
-// bytes of span the match bitmaps and the mirror cover (32 per row on average; longer spans —
-// wave-uniform — take the per-row search and read HBM).
+// Wave-shaped kernels sweep one sub-tile (64 rows) — since round 6 a group of GDV_SG sub-tiles — at a time and keep its
+// span in LDS: GDV_SUB_SPAN = bytes of span the match bitmaps and the mirror cover (32 per row on average for one
+// sub-tile, 20 for a group of four; longer spans — wave-uniform — take the per-row search and read HBM).
+#ifndef GDV_SUB_SPAN
 #define GDV_SUB_SPAN 2048
+#endif
 typedef __attribute__((address_space(3))) gdv_uint64 gdv_lds_u64;
 // 8 bytes at byte offset d of the LDS mirror (base 16-byte aligned, readable 16 bytes past any
 // valid offset): two ALIGNED words and a funnel shift — no unaligned LDS read

@@ -40,6 +40,7 @@ CodegenOptions CodegenOptions::FromEnv() {
   o.no_sel_wave = std::getenv("GDV_NO_SEL_WAVE") != nullptr;
   if (const char* s = std::getenv("GDV_PREPASS_AHEAD")) o.prepass_ahead = atoi(s) != 0;
   if (const char* s = std::getenv("GDV_CAST_X86_INDEFINITE")) o.cast_x86_indefinite = atoi(s) != 0;
+  if (const char* s = std::getenv("GDV_SWEEP_GROUP")) o.sweep_group = std::max(1, std::min(8, atoi(s)));
   if (const char* s = std::getenv("GDV_FP_EXPERIMENT")) o.fp_experiment = atoi(s);
   if (const char* s = std::getenv("GDV_FP_K")) o.fp_rounds = std::max(1, std::min(8, atoi(s)));
   if (const char* s = std::getenv("GDV_FP_WINDOW")) o.fp_window_bytes = std::max(0, std::min(16384, atoi(s)));
@@ -51,7 +52,7 @@ std::string CodegenOptions::Key() const {
          (nt_loads ? "ntl" : "") + (lds_mirror ? "" : "nm") + (subtiles_forced ? "U" : "") + (waves_forced ? "W" : "") +
          (no_inline_string_args ? "ni" : "") + (no_wave_shape ? "nw" : "") + (wave_bytefree_only ? "bf" : "") +
          (ablation ? "abl" : "") + (runtime_needles ? "rn" : "") + (prepass_rolled ? "pr" : "") + (rows_word ? "rw" : "") + (no_sel_wave ? "nsw" : "") + (prepass_ahead ? "" : "npa") + (fp_experiment ? "fx" + std::to_string(fp_experiment) : "") + (fp_rounds != 3 ? "k" + std::to_string(fp_rounds) : "") +
-         (fp_window_bytes != 9984 ? "fw" + std::to_string(fp_window_bytes) : "") + (cast_x86_indefinite ? "xi" : "");
+         (fp_window_bytes != 9984 ? "fw" + std::to_string(fp_window_bytes) : "") + (cast_x86_indefinite ? "xi" : "") + (sweep_group != 1 ? "sg" + std::to_string(sweep_group) : "");
 }
 
 // ------------------------------------------------------------------ validation
@@ -1136,6 +1137,7 @@ struct Assembler {
   CodeGen& cg;
   KernelPlan* plan;
   std::ostringstream src;
+  int sweep_group_ = 1;  // > 1: wave-shaped main kernel whose byte sweep takes this many sub-tiles' spans at a time
 
   void Header(const std::vector<std::string>& expr_strings) {
     src << "// generated by gandiva_amd (gdv_planner.cc) — fused "
@@ -1154,6 +1156,10 @@ struct Assembler {
     src << "#define GDV_U " << plan->opts.subtiles << "\n";
     src << "#define GDV_WAVES " << plan->opts.waves << "\n";
     if (plan->opts.cast_x86_indefinite) src << "#define GDV_CAST_X86_INDEFINITE 1\n";
+    if (sweep_group_ > 1)
+      // (wave-shaped main kernels, round 6: the byte sweep covers GDV_SG sub-tiles' spans at a time; the LDS mirror and the
+      // match bitmaps hold that much)
+      src << "#define GDV_SG " << sweep_group_ << "\n#define GDV_SUB_SPAN " << 1024 * sweep_group_ << "\n";
     src << "#include \"gdv_device_lib.hpp\"\n";
     const int nin = std::max<int>(1, plan->input_fields.size());
     const int nout = std::max<int>(1, plan->output_types.size());
@@ -1693,8 +1699,12 @@ struct WaveSweepText {
   std::string per_sub;    // top of the row loop's body (u = the sub-tile)
   std::string epilogue;   // after the row loop
 };
-void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass, WaveSweepText* out) {
+// sg (round 6): sub-tiles whose spans ONE sweep covers (GDV_SG; 1 = one sub-tile at a time, rounds 3-5).  A 64-row span of
+// 12-byte rows fills three quarters of a 1024-byte step; four of them fill three steps exactly.
+void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass, WaveSweepText* out, int sg = 1) {
   std::ostringstream s, b, e;
+  const bool grouped = sg > 1;
+  const std::string SG = std::to_string(sg);
   const int nin = plan->layout.n_in;
   const int nhook = static_cast<int>(cg.contains_hooks_.size());
   for (int k = 0; k < nin; k++) {
@@ -1746,7 +1756,7 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
     s << "  gdv_uint64 wn" << K << "[2] = {0ull, 0ull};\n"
       << (hooks.empty() ? "" : "  gdv_uint64 tn" + K + " = 0;  // lane 63's halo (the 8 bytes behind its piece), loaded WITH the piece\n")
       << "  {\n"
-      << "    const gdv_int32 e0 = GDV_U > 1 ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+      << "    const gdv_int32 e0 = GDV_U > " << SG << " ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > " << SG << " ? " << SG << " : 0]) : sp1" << K << ";\n"
       << "    const gdv_int32 b0 = sp0" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + sp0" << K << ") & 15);\n"
       << "    if (" << AblNot(64) << "b0 + 16 * lane < e0) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
       << " + b0 + 16 * lane, 16), 16);\n"
@@ -1773,13 +1783,27 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
       s << "  const gdv_int32 sfl" << K << " = inb" << K << ";\n";
 
     // ---- per sub-tile
-    b << "    // byte sweep of this sub-tile's span of input " << k << "\n"
-      << "    const gdv_int32 ss" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
-      << "    const gdv_int32 se" << K << " = u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
-      << "    const gdv_int32 sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
-      << "    const bool hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap / mirror\n"
-      << "    (void)hm_ok" << K << ";\n"
-      << "    for (gdv_int32 c = sb" << K << "; c < " << AblSel(64, "sb" + K, "se" + K) << "; c += 1024) {\n"
+    if (grouped) {
+      // the span of a GROUP of GDV_SG sub-tiles, swept when its first sub-tile comes up; ssK / seK / sbK / hm_okK stay what
+      // they are for the group's other sub-tiles (the rows address the mirror and the bitmaps relative to sbK)
+      s << "  gdv_int32 ss" << K << " = 0, se" << K << " = 0, sb" << K << " = 0;\n"
+        << "  bool hm_ok" << K << " = false;\n"
+        << "  (void)ss" << K << "; (void)hm_ok" << K << ";\n";
+      b << "    // byte sweep of the span of this group of " << SG << " sub-tiles of input " << k << " (every " << SG << "th iteration)\n"
+        << "    if ((u & (" << SG << " - 1)) == 0) {\n"
+        << "    ss" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+        << "    se" << K << " = u + " << SG << " < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > " << SG << " ? " << SG << " : 0]) : sp1" << K << ";\n"
+        << "    sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
+        << "    hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap / mirror\n";
+    } else {
+      b << "    // byte sweep of this sub-tile's span of input " << k << "\n"
+        << "    const gdv_int32 ss" << K << " = __builtin_amdgcn_readfirstlane(oa" << K << "[0]);\n"
+        << "    const gdv_int32 se" << K << " = u + 1 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 1 ? 1 : 0]) : sp1" << K << ";\n"
+        << "    const gdv_int32 sb" << K << " = ss" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + ss" << K << ") & 15);\n"
+        << "    const bool hm_ok" << K << " = se" << K << " - sb" << K << " <= GDV_SUB_SPAN;  // wave-uniform: the span fits the LDS bitmap / mirror\n"
+        << "    (void)hm_ok" << K << ";\n";
+    }
+    b << "    for (gdv_int32 c = sb" << K << "; c < " << AblSel(64, "sb" + K, "se" + K) << "; c += 1024) {\n"
       << "      const gdv_int32 a = c + 16 * lane;\n"
       << "      const gdv_uint64 w[2] = {wn" << K << "[0], wn" << K << "[1]};\n"
       << "      wn" << K << "[0] = 0ull; wn" << K << "[1] = 0ull;\n"
@@ -1816,9 +1840,10 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
     for (auto* vo : flats)
       b << "      " << AblIf(8) << "gdv_sweep_store32(outd" << vo->e << ", a - so0_" << K
         << ", w, " << vo->flat_map << ", a >= sp0" << K << " && a + 16 <= se" << K << ", fcap" << vo->e << ");\n";
+    const std::string SG2 = std::to_string(2 * sg);
     b << "    }\n"
-      << "    if (u + 1 < GDV_U) {  // the first piece of the next sub-tile's span\n"
-      << "      const gdv_int32 e2 = u + 2 < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > 2 ? 2 : 0]) : sp1" << K << ";\n"
+      << "    if (u + " << SG << " < GDV_U) {  // the first piece of the next " << (grouped ? "group's" : "sub-tile's") << " span\n"
+      << "      const gdv_int32 e2 = u + " << SG2 << " < GDV_U ? __builtin_amdgcn_readfirstlane(oa" << K << "[GDV_U > " << SG2 << " ? " << SG2 << " : 0]) : sp1" << K << ";\n"
       << "      const gdv_int32 nb = se" << K << " - (gdv_int32)((gdv_uint64)(sd" << K << " + se" << K << ") & 15);\n"
       << "      if (" << AblNot(64) << "nb + 16 * lane < e2) __builtin_memcpy(wn" << K << ", __builtin_assume_aligned(sd" << K
       << " + nb + 16 * lane, 16), 16);\n"
@@ -1831,6 +1856,7 @@ void EmitWaveSweep(CodeGen& cg, KernelPlan* plan, int mirror_slot, bool prepass,
         << "    sawhi" << K << " |= sacc" << K << ";\n"
         << "    sacc" << K << " = 0;\n";
     if (!hooks.empty() || mirror || (want_ascii && cg.exact_ascii_)) b << "    __builtin_amdgcn_wave_barrier();\n";
+    if (grouped) b << "    }  // (group's first sub-tile)\n";
 
     // ---- after the loop
     if (want_ascii && cg.exact_ascii_ && !prepass)
@@ -2206,6 +2232,10 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
     cg.unroll_rows_ = true;
 
   Assembler as{cg, plan, {}};
+  // round 6: the main kernel's per-sub-tile sweep (the one with the LDS mirror) takes GDV_SG sub-tiles' spans at a time
+  if (!prepass && mirror_slot >= 0 && !cg.selection() && plan->opts.sweep_group > 1 &&
+      plan->opts.subtiles % plan->opts.sweep_group == 0 && plan->opts.subtiles > plan->opts.sweep_group)
+    as.sweep_group_ = plan->opts.sweep_group;
   as.Header(expr_strings);
   std::ostringstream& s = as.src;
   s << "// " << (prepass ? (cg.exact_ascii_ ? "pre-pass: byte totals per wave tile (exact variant: ASCII flags from a sweep of the bytes)"
@@ -2376,7 +2406,7 @@ Status AssembleStringsWave(CodeGen& cg, KernelPlan* plan, const std::vector<std:
           << (cg.ascii_slots_.count(k) ? " | GDV_STR_ASCII" : "") << ";\n";
     }
   } else if (mirror_slot >= 0) {
-    EmitWaveSweep(cg, plan, mirror_slot, prepass, &sweep);
+    EmitWaveSweep(cg, plan, mirror_slot, prepass, &sweep, as.sweep_group_);
     s << sweep.prologue;
   } else {
     EmitWaveTileSweep(s, cg, plan, &sweep.epilogue);

@@ -47,6 +47,7 @@ struct CodegenOptions {
   // count from the device word aux2 points at when there is one — an asynchronous evaluation's gate writes 0
   // there when the first stage did not complete, and the second stage then touches nothing.
   bool rows_word = false;
+  int sweep_group = 1;                 // GDV_SWEEP_GROUP: sub-tiles whose spans a wave-shaped main kernel sweeps in ONE go (1 = rounds 3-5: one at a time; 4: three full 1024-byte steps per four sub-tiles of 12-byte rows instead of four three-quarter-full ones)
   bool cast_x86_indefinite = false;    // GDV_CAST_X86_INDEFINITE=1 at Make: float -> integer casts of NaN / out-of-range values give the x86 "indefinite integer" (0x80..0) instead of saturating
   // Fused filter-project, windowed shape (round 5): bytes of LDS window per wave tile (every windowed output + the
   // row index, GDV_FP_CAP rows of them); 0 = the direct round-4 shape only.  GDV_FP_WINDOW=<bytes>.

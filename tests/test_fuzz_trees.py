@@ -130,8 +130,10 @@ def test_generated_trees_validate_and_compile(seed):
     assert [len(g) for g in got] == [257] * len(exprs)
 
 
+# (round 6, verdict item 8: the GPU suite had grown to 10.5 of its 20 minutes; the fuzzers keep the seeds that cover every
+# batch length once — more seeds run offline: tools/fuzz_offline.py, profiles/r05_fuzz_offline.txt)
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(16))
 def test_fuzzed_projector_and_filter_match_oracle(seed):
     exprs, cond = _expressions(seed)
     n = [1, 63, 64, 65, 1000, 4097, 70001, 100003][seed % 8]
@@ -261,7 +263,7 @@ def test_generated_string_trees_validate_and_compile(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(8))
 def test_fuzzed_string_trees_match_oracle(seed):
     exprs, cond = _string_expressions(seed)
     n = [1, 63, 64, 65, 257, 1000, 4097, 30011][seed % 8]
@@ -329,7 +331,7 @@ def test_generated_trees_with_materialised_values_compile(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(6))
 def test_fuzzed_trees_with_materialised_values_match_oracle(seed):
     exprs, cond = _tail_expressions(seed)
     n = [1, 64, 257, 1000, 4097, 12011][seed % 6]

@@ -7,7 +7,7 @@ import gandiva_amd as gandiva
 from gandiva_amd import workloads as W
 
 n = 100_000_000
-db = W.c5_device_batch(n)
+db = W.c5_device_batch_philox(n)
 ex = W.c5_expressions()
 b = gandiva.TreeExprBuilder()
 s = b.make_field(W.c5_schema().field(0))
