@@ -198,9 +198,11 @@ static uint64_t Fnv(const char* s, size_t n) {
 }
 
 namespace {
-std::mutex& CodeCacheMutex() { static std::mutex m; return m; }
-std::map<std::string, std::vector<char>>& CodeCache() { static std::map<std::string, std::vector<char>> c; return c; }
-std::set<std::string>& FailedCompilations() { static std::set<std::string> s; return s; }
+// (never destroyed: the background compiler thread may still be inside CompileToCodeObject while the process's statics are
+// torn down — it is joined by ~BackgroundCompiler, which can run AFTER these would have been destroyed)
+std::mutex& CodeCacheMutex() { static std::mutex* m = new std::mutex; return *m; }
+std::map<std::string, std::vector<char>>& CodeCache() { static auto* c = new std::map<std::string, std::vector<char>>; return *c; }
+std::set<std::string>& FailedCompilations() { static auto* s = new std::set<std::string>; return *s; }
 std::string LibraryHashTag() {  // the on-disk cache is keyed by the hash of the whole device library as well
   static const uint64_t lib_hash = Fnv(gdv_device_lib_src, strlen(gdv_device_lib_src));
   char tag[40];
@@ -320,7 +322,7 @@ Status Runtime::CompileToCodeObject(const std::string& source, const std::string
 
   // one compilation at a time: they are rare (cached in memory and on disk) and comgr's
   // temporary-file handling has no need to be exercised concurrently
-  static std::mutex compile_mu;
+  static std::mutex& compile_mu = *new std::mutex;  // (leaked on purpose: see CodeCacheMutex)
   std::lock_guard<std::mutex> compile_guard(compile_mu);
   if (!ignore_cached) {  // (another thread — the background compiler of tier 0 — may have produced it while this one waited)
     std::lock_guard<std::mutex> g(code_mu);

@@ -159,3 +159,21 @@ def test_the_core_parity_tests_pass_with_every_plan_forced_onto_tier_0():
              "print('LAUNCHES', _capi.lib().gdv_tier0_launches())" % ROOT)
     r = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=300)
     assert "LAUNCHES 1" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_a_process_that_exits_while_its_kernels_are_still_compiling_exits_cleanly(tmp_path):
+    """Make queues the compilation on the library's background thread and returns; a process that is done before hipRTC
+    is must not crash in the teardown of its statics (the thread is joined, the caches it touches are never destroyed)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import gandiva_amd as g; from gandiva_amd import workloads as W\n"
+            "p = g.make_projector(W.c2_schema(), W.c2_expressions(), None); f = g.make_filter(W.c3_schema(), W.c3_condition())\n"
+            "print('MADE')\n" % ROOT)
+    env = dict(os.environ, GANDIVA_AMD_CACHE_DIR=str(tmp_path))
+    env.pop("GDV_FORCE_TIER0", None)
+    env.pop("GDV_NO_TIER0", None)
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "MADE" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+        for f in os.listdir(tmp_path):          # (cold again for the next round)
+            os.remove(os.path.join(tmp_path, f))
