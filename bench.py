@@ -70,6 +70,8 @@ def parse():
     p.add_argument("--sub-warmup", type=int, default=2)
     p.add_argument("--sub-placements", type=int, default=3, help="placement trials of the projection sub-workloads (c1, c4)")
     p.add_argument("--sub-cpu-seconds", type=float, default=3.0)
+    p.add_argument("--c5-sync", action="store_true",
+                   help="c5: time the synchronous entry point (reads the byte totals back every step) instead of gdv_projector_evaluate_async")
     p.add_argument("--data-c5", default="philox", choices=["philox", "pcg64"],
                    help="c5 inputs: philox = BASELINE.md §4's distributions from torch's device generator (seconds); "
                         "pcg64 = its frozen numpy stream (generated on one host core: ~1 min for 10^8 rows)")
@@ -663,6 +665,22 @@ def setup_workload(name, rows, args, rank=0):
 
         def step():
             wl.obj.evaluate_device(wl.dbatch, outputs=wl.outs, sync=False)
+        if name == "c5" and not args.c5_sync:
+            # A var-len plan's synchronous entry reads the byte totals back before it returns: the GPU idles while the host
+            # turns around (0.03-0.07 ms of a 1.05 ms step).  gdv_projector_evaluate_async enqueues pre-pass, scan and main
+            # kernel and returns; status word and byte totals land in a device block, checked after the loop.
+            wl.kernel_desc_suffix = "; step = gdv_projector_evaluate_async (no host wait: status word + byte totals stay on the device, checked after the timed loop)"
+
+            def step():  # noqa: F811
+                wl.outs, wl.last_result = wl.obj.evaluate_device_async(wl.dbatch, outputs=wl.outs)
+
+            def result():
+                torch.cuda.synchronize()
+                st = int(wl.last_result[0])
+                if st != 0:
+                    raise RuntimeError(f"the asynchronous evaluations left status {st:#x}: outputs not complete")
+                return wl.outs
+            wl.result = result
         if name == "c5":
             outs = wl.outs
             in_bytes = 4 * (rows + 1) + int(sum(o.data_used for o in outs[2:]))  # offsets + data (upper preserves bytes)
@@ -882,7 +900,7 @@ def roofline_of(wl, dev_ms, trials, quote_traffic, placement=None):
         "traffic_source": source,
         "kernel_name": names[0] if names else None,
         "kernel_names": names + AOT_KERNELS.get(wl.name, []),
-        "kernel": wl.kernel_desc,
+        "kernel": wl.kernel_desc + getattr(wl, "kernel_desc_suffix", ""),
         "algorithmic_bytes_per_row": round(wl.bytes_per_row, 3),
         # the read and write shares of `achieved`, separately
         "read_bytes_per_row": round(wl.read_per_row, 3),

@@ -165,6 +165,7 @@ PROTOTYPES = [
     ("gdv_projector_evaluate_export", C.c_int, [_P, _P, C.POINTER(gdv_selection_t), _P, _P, _P]),
     ("gdv_tier0_program", _P, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_tier0_launches", C.c_int64, []),
+    ("gdv_shutdown", None, []),
     ("gdv_precompile_projector", C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int]),
     ("gdv_precompile_filter", C.c_int, [_P, _P]),
     ("gdv_kernel_library_tag", _P, [C.c_char_p, C.c_char_p]),
@@ -230,6 +231,10 @@ def lib():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = l
+        # the background compiler (tier 0) is stopped before the interpreter goes away: deterministic, whatever order the
+        # process's shared libraries are torn down in
+        import atexit
+        atexit.register(l.gdv_shutdown)
     return _lib
 
 

@@ -1563,6 +1563,7 @@ char* gdv_tier0_program(const gdv_schema_t* schema, gdv_expression_t* const* exp
   });
 }
 int64_t gdv_tier0_launches(void) { return Tier0Launches(); }
+void gdv_shutdown(void) { Runtime::ShutdownBackgroundCompiler(); }
 
 int gdv_precompile_projector(const gdv_schema_t* schema, gdv_expression_t* const* exprs,
                              int num_exprs, int selection_mode) {

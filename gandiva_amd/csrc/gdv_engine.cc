@@ -710,9 +710,10 @@ Status Projector::Make(const Schema& schema, const std::vector<ExpressionPtr>& e
     if (BuildTier0Program(schema, exprs, /*filter=*/false, p->plan_, prog.get(), nullptr)) {
       const int state = EngineKnobs::Get().force_tier0 ? 0 : Runtime::Get().CodeObjectState(p->plan_.kernel_name);
       if (state == 0 || EngineKnobs::Get().force_tier0) {
-        p->tier0_ = std::move(prog);
-        p->tier0_pending_.store(true);
-        if (!EngineKnobs::Get().force_tier0) Runtime::Get().CompileInBackground(p->plan_.source, p->plan_.kernel_name);
+        if (EngineKnobs::Get().force_tier0 || Runtime::Get().CompileInBackground(p->plan_.source, p->plan_.kernel_name)) {
+          p->tier0_ = std::move(prog);
+          p->tier0_pending_.store(true);
+        }  // (else: the background compiler was shut down — Make waits for the compilation below, as before round 6)
       }
     }
   }
@@ -1542,9 +1543,10 @@ Status Filter::Make(const Schema& schema, const ExpressionPtr& condition,
     if (BuildTier0Program(schema, {condition}, /*filter=*/true, f->plan_, prog.get(), nullptr)) {
       const int state = EngineKnobs::Get().force_tier0 ? 0 : Runtime::Get().CodeObjectState(f->plan_.kernel_name);
       if (state == 0 || EngineKnobs::Get().force_tier0) {
-        f->tier0_ = std::move(prog);
-        f->tier0_pending_.store(true);
-        if (!EngineKnobs::Get().force_tier0) Runtime::Get().CompileInBackground(f->plan_.source, f->plan_.kernel_name);
+        if (EngineKnobs::Get().force_tier0 || Runtime::Get().CompileInBackground(f->plan_.source, f->plan_.kernel_name)) {
+          f->tier0_ = std::move(prog);
+          f->tier0_pending_.store(true);
+        }
       }
     }
   }

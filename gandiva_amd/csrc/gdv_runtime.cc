@@ -215,20 +215,31 @@ std::string LibraryHashTag() {  // the on-disk cache is keyed by the hash of the
 // process are torn down is a crash.
 class BackgroundCompiler {
  public:
-  static BackgroundCompiler& Get() { static BackgroundCompiler b; return b; }
-  void Push(std::string source, std::string name) {
-    std::lock_guard<std::mutex> g(mu_);
-    if (stop_) return;
-    for (auto& j : jobs_) if (j.second == name) return;
-    jobs_.emplace_back(std::move(source), std::move(name));
-    if (!started_) { started_ = true; worker_ = std::thread([this] { Run(); }); }
-    cv_.notify_one();
+  // hipRTC loads its compiler (libamd_comgr) with dlopen on first use, i.e. from the worker thread, AFTER this object
+  // exists: comgr's static destructors would then run BEFORE this object's at exit — while the worker may still be
+  // compiling inside it (SIGSEGV at exit of any process that ends within a few hundred milliseconds of a Make; found by
+  // tests/test_tier0.py and the C++ acceptance binary).  Loading comgr here, in the constructor, registers its
+  // teardown first: this object's destructor — which stops the queue and JOINS the worker — runs before it.
+  BackgroundCompiler() {
+    for (const char* name : {"libamd_comgr.so.3", "libamd_comgr.so"}) (void)dlopen(name, RTLD_NOW | RTLD_GLOBAL);
   }
-  ~BackgroundCompiler() {
+  static BackgroundCompiler& Get() { static BackgroundCompiler b; return b; }
+  // stop accepting work, forget what is queued, wait for the compilation in flight (gdv_shutdown; also the destructor)
+  void Shutdown() {
     { std::lock_guard<std::mutex> g(mu_); stop_ = true; jobs_.clear(); }
     cv_.notify_all();
     if (worker_.joinable()) worker_.join();
   }
+  bool Push(std::string source, std::string name) {  // false: shut down — the caller compiles on its own thread
+    std::lock_guard<std::mutex> g(mu_);
+    if (stop_) return false;
+    for (auto& j : jobs_) if (j.second == name) return true;
+    jobs_.emplace_back(std::move(source), std::move(name));
+    if (!started_) { started_ = true; worker_ = std::thread([this] { Run(); }); }
+    cv_.notify_one();
+    return true;
+  }
+  ~BackgroundCompiler() { Shutdown(); }
 
  private:
   void Run() {
@@ -271,9 +282,10 @@ int Runtime::CodeObjectState(const std::string& kernel_name, bool memory_only) {
   return access(path.c_str(), R_OK) == 0 ? 1 : 0;
 }
 
-void Runtime::CompileInBackground(const std::string& source, const std::string& kernel_name) {
-  BackgroundCompiler::Get().Push(source, kernel_name);
+bool Runtime::CompileInBackground(const std::string& source, const std::string& kernel_name) {
+  return BackgroundCompiler::Get().Push(source, kernel_name);
 }
+void Runtime::ShutdownBackgroundCompiler() { BackgroundCompiler::Get().Shutdown(); }
 
 Status Runtime::CompileToCodeObject(const std::string& source, const std::string& kernel_name,
                                     std::vector<char>* code, bool* from_cache,

@@ -75,7 +75,10 @@ class Runtime {
   // away), 0 = not yet, -1 = a background compilation of it failed (the blocking path will report why).
   // CompileInBackground: queue the compilation on the process's one compiler thread and return at once.
   int CodeObjectState(const std::string& kernel_name, bool memory_only = false);
-  void CompileInBackground(const std::string& source, const std::string& kernel_name);
+  bool CompileInBackground(const std::string& source, const std::string& kernel_name);  // false after ShutdownBackgroundCompiler
+  // stops the background compiler: queued compilations are dropped, the one in flight is waited for.  Plans whose
+  // compilation was dropped compile on their next blocking use.  Safe to call more than once.
+  static void ShutdownBackgroundCompiler();
   // CompileToCodeObject + hipModuleLoadData on this context's device; cached per context.
   Status GetKernel(const std::string& source, const std::string& kernel_name,
                    const CompiledKernel** out);

@@ -646,6 +646,11 @@ int64_t gdv_device_pool_bytes(const gdv_device_pool_t* pool, int64_t* in_use);
  * gdv_tier0_launches: evaluations that ran on tier 0 so far (process-wide, cumulative). */
 char* gdv_tier0_program(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs, int is_condition);
 int64_t gdv_tier0_launches(void);
+/* Stops the background compiler: queued compilations are dropped, the one in flight is waited for (<= ~1 s).  The library
+ * does this itself when the process exits normally (its compiler thread is joined before hipRTC's own teardown); call it
+ * from JNI_OnUnload / before dlclose, or from an embedder that tears the process down in an order of its own.  Later Makes
+ * wait for their compilation as before round 6. */
+void gdv_shutdown(void);
 
 /* ---- build support ----------------------------------------------------------------- */
 /* Plan + compile to a gfx950 code object without a device; fills the on-disk kernel cache. */

@@ -177,3 +177,18 @@ def test_a_process_that_exits_while_its_kernels_are_still_compiling_exits_cleanl
         assert r.returncode == 0 and "MADE" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
         for f in os.listdir(tmp_path):          # (cold again for the next round)
             os.remove(os.path.join(tmp_path, f))
+
+
+@pytest.mark.gpu
+def test_after_gdv_shutdown_make_waits_for_its_compilation_again(tmp_path):
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import gandiva_amd as g; from gandiva_amd import _capi, workloads as W\n"
+            "lib = _capi.lib(); lib.gdv_shutdown(); lib.gdv_shutdown()\n"
+            "t = time.perf_counter(); p = g.make_projector(W.c1_schema(), W.c1_expressions(), None); ms = (time.perf_counter() - t) * 1e3\n"
+            "b = lib.gdv_tier0_launches(); p.evaluate(W.c1_batch(1000)); print('MS %%.1f TIER0 %%d' %% (ms, lib.gdv_tier0_launches() - b))\n" % ROOT)
+    env = dict(os.environ, GANDIVA_AMD_CACHE_DIR=str(tmp_path))
+    env.pop("GDV_FORCE_TIER0", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ms, tier0 = [l for l in r.stdout.splitlines() if l.startswith("MS ")][0].split()[1::2]
+    assert float(ms) > 100 and int(tier0) == 0        # (hipRTC on the caller's thread; the evaluation runs the specialised kernel)
