@@ -63,6 +63,25 @@ int main(int argc, char** argv) {
     gdv_node_free(bad);
   }
 
+  /* round 6: the tier-0 program of the same tree (what its first evaluations run on while hipRTC compiles), and the
+   * refusals of the new entry points, still without a device */
+  {
+    char* prog = gdv_tier0_program(schema, exprs, 1, 0);
+    CHECK(prog != NULL);
+    CHECK(strcmp(prog, "load in0 int32\nload in1 int32\ncompare gt int32\nload in0 int32\nload in1 int32\nif\nout0 int32\n") == 0);
+    gdv_free_string(prog);
+    CHECK(gdv_projector_evaluate_sharded(NULL, 10, 2, 1, NULL, 0, 0) != GDV_OK);
+    CHECK(gdv_filter_evaluate_host_sharded(NULL, 10, NULL, 0, GDV_SEL_UINT32, NULL, 0, NULL, NULL, 0) != GDV_OK);
+    CHECK(gdv_device_pool_alloc(NULL, 16, NULL) != GDV_OK);
+    CHECK(gdv_device_pool_bytes(NULL, NULL) == 0);
+    {
+      int64_t lo = -1, hi = -1;
+      CHECK(gdv_shard_bounds(10000, 3, 1, &lo, &hi) == GDV_OK && lo == 4096 && hi == 7168);
+    }
+    gdv_shutdown(); /* (idempotent; a later Make waits for its compilation) */
+    gdv_shutdown();
+  }
+
   if (!host_only) {
     gdv_projector_t* proj = NULL;
     CHECK(gdv_projector_make(schema, exprs, 1, GDV_SEL_NONE, NULL, &proj) == GDV_OK);
@@ -88,6 +107,26 @@ int main(int argc, char** argv) {
     printf("%d %d %d %d  validity %#x\n", result[0], result[1], result[2], result[3], validity[0]);
     CHECK(result[0] == 10 && result[1] == 15 && result[2] == 15 && result[3] == 17);
     CHECK((validity[0] & 0xf) == 0xf);
+    /* round 6: the same batch through the one-call multi-device entry point (one device here) and into a pool-owned buffer */
+    {
+      const int32_t devs[1] = {0};
+      int32_t result2[4] = {0, 0, 0, 0};
+      uint8_t validity2[8] = {0};
+      gdv_out_column_t out2;
+      memset(&out2, 0, sizeof(out2));
+      out2.validity = validity2; out2.validity_size = sizeof(validity2);
+      out2.data = result2; out2.data_size = sizeof(result2);
+      CHECK(gdv_projector_evaluate_host_sharded(proj, 4, cols, 2, &out2, 1, devs, 1) == GDV_OK);
+      CHECK(memcmp(result, result2, sizeof(result)) == 0 && (validity2[0] & 0xf) == 0xf);
+      gdv_device_pool_t* pool = NULL;
+      void* bufs[2];
+      int tried = 0, kept = -1;
+      CHECK(gdv_device_pool_create(&pool) == GDV_OK);
+      CHECK(gdv_device_pool_reserve_set(pool, 2, 1 << 20, 4, bufs, NULL, &tried, &kept) == GDV_OK);
+      CHECK(bufs[0] != NULL && bufs[1] != NULL && bufs[0] != bufs[1] && tried == 1);
+      CHECK(gdv_device_pool_free(pool, bufs[0]) == GDV_OK && gdv_device_pool_free(pool, bufs[1]) == GDV_OK);
+      gdv_device_pool_destroy(pool);
+    }
     gdv_projector_free(proj);
   }
 
