@@ -857,8 +857,15 @@ int RunShards(int n, const int32_t* devices, Fn&& body) {
   };
   std::vector<std::thread> threads;
   threads.reserve(n > 1 ? n - 1 : 0);
-  for (int s = 1; s < n; s++) threads.emplace_back(work, s);
+  int started = 1;  // (shard 0 runs on the calling thread)
+  try {
+    for (int s = 1; s < n; s++, started++) threads.emplace_back(work, s);
+  } catch (const std::exception&) {
+    // the process is out of threads: the shards that got none run here, one after the other (a joinable std::thread
+    // must never be destroyed — the ones that did start are joined below whatever happens)
+  }
   work(0);
+  for (int s = started; s < n; s++) work(s);
   for (auto& t : threads) t.join();
   if (before >= 0) (void)Runtime::SelectDevice(before);
   for (int s = 0; s < n; s++)
