@@ -446,8 +446,8 @@ def stream_ceiling(num_read, num_write, bytes_per_stream=1 << 30):
     g, wg, nt = C.c_double(), C.c_int(), C.c_int()
     if _capi.lib().gdv_device_stream_ceiling(bytes_per_stream, num_read, num_write, C.byref(g), C.byref(wg), C.byref(nt)) != 0:
         return None
-    return {"reads": num_read, "writes": num_write, "GB/s": round(g.value, 1), "workgroups_per_cu": wg.value,
-            "nontemporal": bool(nt.value), "bytes_per_stream": bytes_per_stream}
+    return {"reads": num_read, "writes": num_write, "GB/s": round(g.value, 1), "workgroups_per_cu": wg.value % 100,
+            "subtiles_per_wave": 16 if wg.value > 100 else 4, "nontemporal": bool(nt.value), "bytes_per_stream": bytes_per_stream}
 
 
 def stream_ceiling_on(read_tensors, write_tensors, elems):
@@ -460,8 +460,9 @@ def stream_ceiling_on(read_tensors, write_tensors, elems):
     if _capi.lib().gdv_device_stream_ceiling_on(ptrs, len(read_tensors), len(write_tensors), elems, C.byref(g), C.byref(wg),
                                                 C.byref(nt)) != 0:
         return None
-    return {"reads": len(read_tensors), "writes": len(write_tensors), "GB/s": round(g.value, 1), "workgroups_per_cu": wg.value,
-            "nontemporal": bool(nt.value), "bytes_per_stream": elems * 8, "buffers": "the timed loop's own"}
+    return {"reads": len(read_tensors), "writes": len(write_tensors), "GB/s": round(g.value, 1), "workgroups_per_cu": wg.value % 100,
+            "subtiles_per_wave": 16 if wg.value > 100 else 4, "nontemporal": bool(nt.value), "bytes_per_stream": elems * 8,
+            "buffers": "the timed loop's own"}
 
 
 def kernel_name_of(obj):

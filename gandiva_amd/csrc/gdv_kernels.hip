@@ -293,9 +293,9 @@ struct CeilPointers {
   const unsigned long long* in[10];
   unsigned long long* out[10];
 };
-template <int NR, int NW, bool NT>
+// (U sub-tiles per wave: 4 = the projection kernels' shape of rounds 1-5, 16 = round 6's for elements of up to 8 bytes)
+template <int NR, int NW, bool NT, int U = 4>
 __global__ void __launch_bounds__(256) CeilStream(const CeilPointers P, size_t n) {
-  constexpr int U = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t ntiles = n / (256 * U);
   for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -334,10 +334,15 @@ hipError_t StreamCeilingFor(const CeilPointers& P, size_t n, int num_cus, double
   err = hipEventCreate(&e1);
   if (err != hipSuccess) { (void)hipEventDestroy(e0); return err; }
   const double moved = (double)(NR + NW) * 8.0 * (double)(n / 1024 * 1024);
+  // (per_cu > 100: the 16-sub-tile shape, workgroups per CU = per_cu - 100 — one more axis of the sweep, kept in the one integer
+  // the callers report)
   auto time_once = [&](int per_cu, int nt) -> float {
-    const int grid = num_cus * per_cu;
+    const bool wide = per_cu > 100;
+    const int grid = num_cus * (wide ? per_cu - 100 : per_cu);
     if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
-    if (nt) hipLaunchKernelGGL((CeilStream<NR, NW, true>), dim3(grid), dim3(256), 0, nullptr, P, n);
+    if (wide && nt) hipLaunchKernelGGL((CeilStream<NR, NW, true, 16>), dim3(grid), dim3(256), 0, nullptr, P, n);
+    else if (wide) hipLaunchKernelGGL((CeilStream<NR, NW, false, 16>), dim3(grid), dim3(256), 0, nullptr, P, n);
+    else if (nt) hipLaunchKernelGGL((CeilStream<NR, NW, true>), dim3(grid), dim3(256), 0, nullptr, P, n);
     else hipLaunchKernelGGL((CeilStream<NR, NW, false>), dim3(grid), dim3(256), 0, nullptr, P, n);
     if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
     if (err == hipSuccess) err = hipEventSynchronize(e1);
@@ -350,11 +355,14 @@ hipError_t StreamCeilingFor(const CeilPointers& P, size_t n, int num_cus, double
   // are still moving is not a measurement (round 4: 5.3 .. 6.2 TB/s for the same configuration within
   // one second on one box)
   struct Cfg { int per_cu, nt; float ms; };
-  Cfg cfgs[10];
+  Cfg cfgs[20];
   int nc = 0;
   (void)time_once(8, 0);
   for (int nt = 0; nt < 2; nt++)
     for (int per_cu = 2; per_cu <= 32; per_cu *= 2) cfgs[nc++] = Cfg{per_cu, nt, time_once(per_cu, nt)};
+  if (NR * 16 * 2 <= 160)  // (the wide shape keeps NR x 16 eight-byte values in registers)
+    for (int nt = 0; nt < 2; nt++)
+      for (int per_cu = 2; per_cu <= 32; per_cu *= 2) cfgs[nc++] = Cfg{100 + per_cu, nt, time_once(100 + per_cu, nt)};
   for (int i = 0; i < nc; i++)
     for (int j = i + 1; j < nc; j++)
       if (cfgs[j].ms < cfgs[i].ms) { const Cfg t = cfgs[i]; cfgs[i] = cfgs[j]; cfgs[j] = t; }

@@ -2811,6 +2811,17 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
     if (!any_varlen && in_bytes > 0) {
       int u = 4;
       while (u < 16 && 64 * u * in_bytes < 8192 && 2 * u * in_bytes <= 512) u <<= 1;
+      // Round 6: SIXTEEN sub-tiles per wave wherever the loaded values fit the registers (in_bytes x 16 <= 512: 128 VGPRs) and
+      // no element is wider than 8 bytes.  A wave then reads and writes 64 x 16 consecutive elements of every stream — 4-8 KiB
+      // per stream and wave instead of 1-2 — and the DRAM sees longer runs per stream between the 14 interleaved ones:
+      // C2 4.75-4.82 ms against 4.96-5.10 (U = 4) on one box, 4.78-4.90 against 4.96-5.14 on another; C1 0.733-0.735 against
+      // 0.776-0.780 (U = 4) and 0.81-0.85 (U = 8, what the rule above chose for it); decimal128 columns (C4): no difference,
+      // they stay at 4 (profiles/r06_tile_shape.txt).  Occupancy drops to two or three waves per SIMD: it does not matter here.
+      int max_width = 0;
+      for (size_t k = 0; k < cg.input_fields_.size(); k++)
+        if (cg.needs_values_[k]) max_width = std::max(max_width, schema[cg.input_fields_[k]].type.byte_width());
+      for (auto& e : exprs) max_width = std::max(max_width, e->result().type.byte_width());
+      if (in_bytes * 16 <= 512 && max_width <= 8) u = 16;
       plan->opts.subtiles = u;
     }
   }

@@ -480,7 +480,8 @@ int gdv_device_hbm_ceilings(int64_t bytes, double* read_gbs, double* write_gbs, 
 /* Round 4: the ceiling for a given TRAFFIC SHAPE — num_read input streams and num_write output streams of
  * 8-byte elements, bytes_per_stream each, moved by the projection kernel's own skeleton without its
  * arithmetic; the best rate over a sweep of grid sizes (2..32 workgroups per CU) x {plain, non-temporal}
- * accesses, and where it was found.  Shapes: (1,0) (2,0) (4,0) (0,1) (0,4) (0,10) (2,1) (3,1) (4,10) (7,5)
+ * accesses x {4, 16} sub-tiles per wave (round 6; *workgroups_per_cu is reported + 100 for the 16-sub-tile shape),
+ * and where it was found.  Shapes: (1,0) (2,0) (4,0) (0,1) (0,4) (0,10) (2,1) (3,1) (4,10) (7,5)
  * (2,3).  A product kernel of that shape should not beat it: achieved / ceiling <= 1 on every box. */
 int gdv_device_stream_ceiling(int64_t bytes_per_stream, int num_read, int num_write, double* gbs, int* workgroups_per_cu,
                               int* nontemporal);
