@@ -1,0 +1,183 @@
+// Round-6 experiment: what separates C3's predicate kernel (2.36-2.65 ms of a 2.57-2.86 ms Filter::Evaluate at 10^9 rows) from the
+// two-stream read skeleton (2.19-2.39 ms on the same buffers)?  The skeleton, then the predicate's pieces added one at a time.
+//   hipcc --offload-arch=gfx950 -O3 -o predicate_probe predicate_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+struct Args { const long long* a; const long long* b; const unsigned long long* va; const unsigned long long* vb; unsigned long long* mask; unsigned* counts; unsigned long long* sink; long long k1, k2; };
+// V: 0 skeleton; 1 + compare / ballot / popcount / count store; 2 + match words stored (non-temporal, 16 lanes x 8 bytes per wave tile);
+//    3 + validity words loaded per tile (one 8-byte load per lane < U per column, all-ones words) and ANDed in
+template <int U, int W, int V>
+__global__ void __launch_bounds__(W * 64) K(const Args A, size_t ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t t = (size_t)blockIdx.x * W + wave; t < ntiles; t += (size_t)gridDim.x * W) {
+    const size_t base = t * (64 * U) + lane;
+    long long x[U], y[U];
+    unsigned long long wa = ~0ull, wb = ~0ull;
+    if (V >= 3) {
+      const size_t w = lane < U ? t * U + lane : t * U;
+      wa = A.va[w]; wb = A.vb[w];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) { x[u] = __builtin_nontemporal_load(A.a + base + 64 * u); y[u] = __builtin_nontemporal_load(A.b + base + 64 * u); }
+    if (V == 0) {
+      long long acc = 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) acc |= x[u] ^ y[u];
+      if (acc == 0x12345678abcdefll) A.sink[0] = acc;
+    } else {
+      unsigned cnt = 0;
+      unsigned long long fm = 0;
+      const unsigned long long wv = wa & wb;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        unsigned long long m = __ballot(x[u] > A.k1 && y[u] < A.k2);
+        if (V >= 3) m &= __shfl(wv, u);
+        cnt += __popcll(m);
+        if (lane == u) fm = m;
+      }
+      if (V >= 2 && lane < U) __builtin_nontemporal_store(fm, A.mask + t * U + lane);
+      if (lane == 0) A.counts[t] = cnt;
+    }
+  }
+}
+// P: the predicate with the stores of tile k issued BEHIND the loads of tile k + 1 (vmcnt counts in order: a wave that waits for
+// its next loads then does not wait for the write acknowledgements of the tile before).  NOSTORE: compare / ballot only.
+template <int U, int W, bool NOSTORE>
+__global__ void __launch_bounds__(W * 64) P(const Args A, size_t ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long pfm = 0; unsigned pcnt = 0; size_t pt = ~(size_t)0;
+  unsigned total = 0;
+  for (size_t t = (size_t)blockIdx.x * W + wave; t < ntiles; t += (size_t)gridDim.x * W) {
+    const size_t base = t * (64 * U) + lane;
+    long long x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { x[u] = __builtin_nontemporal_load(A.a + base + 64 * u); y[u] = __builtin_nontemporal_load(A.b + base + 64 * u); }
+    if (!NOSTORE && pt != ~(size_t)0) {
+      if (lane < U) __builtin_nontemporal_store(pfm, A.mask + pt * U + lane);
+      if (lane == 0) A.counts[pt] = pcnt;
+    }
+    unsigned cnt = 0;
+    unsigned long long fm = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const unsigned long long m = __ballot(x[u] > A.k1 && y[u] < A.k2);
+      cnt += __popcll(m);
+      if (lane == u) fm = m;
+    }
+    pfm = fm; pcnt = cnt; pt = t; total += cnt;
+  }
+  if (NOSTORE) { if (total == 0x7fffffffu) A.counts[0] = total; }
+  else if (pt != ~(size_t)0) {
+    if (lane < U) __builtin_nontemporal_store(pfm, A.mask + pt * U + lane);
+    if (lane == 0) A.counts[pt] = pcnt;
+  }
+}
+// Q: a wave takes G CONSECUTIVE tiles of U sub-tiles per grid-stride step, keeps their G x U match words in lanes 0 .. G*U-1 and
+// stores them at once (G x 128 bytes) with ONE count: G times fewer write transactions among the reads.
+template <int U, int W, int G>
+__global__ void __launch_bounds__(W * 64) Q(const Args A, size_t ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t ngroups = ntiles / G;
+  for (size_t t = (size_t)blockIdx.x * W + wave; t < ngroups; t += (size_t)gridDim.x * W) {
+    unsigned cnt = 0;
+    unsigned long long fm = 0;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+      const size_t base = (t * G + g) * (64 * U) + lane;
+      long long x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { x[u] = __builtin_nontemporal_load(A.a + base + 64 * u); y[u] = __builtin_nontemporal_load(A.b + base + 64 * u); }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const unsigned long long m = __ballot(x[u] > A.k1 && y[u] < A.k2);
+        cnt += __popcll(m);
+        if (lane == g * U + u) fm = m;
+      }
+    }
+    if (lane < G * U) __builtin_nontemporal_store(fm, A.mask + t * (G * U) + lane);
+    if (lane == 0) A.counts[t] = cnt;
+  }
+}
+// L: as Q, with the G x U match words and G counts of a wave staged in LDS and flushed as one contiguous run (G x 128 bytes of
+// words, G x 4 bytes of counts) — large, rare write bursts instead of a trickle.
+template <int U, int W, int G>
+__global__ void __launch_bounds__(W * 64) L(const Args A, size_t ntiles) {
+  __shared__ unsigned long long words[W][G * U];
+  __shared__ unsigned counts[W][G];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t ngroups = ntiles / G;
+  for (size_t t = (size_t)blockIdx.x * W + wave; t < ngroups; t += (size_t)gridDim.x * W) {
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {
+      const size_t base = (t * G + g) * (64 * U) + lane;
+      long long x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { x[u] = __builtin_nontemporal_load(A.a + base + 64 * u); y[u] = __builtin_nontemporal_load(A.b + base + 64 * u); }
+      unsigned cnt = 0;
+      unsigned long long fm = 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const unsigned long long m = __ballot(x[u] > A.k1 && y[u] < A.k2);
+        cnt += __popcll(m);
+        if (lane == u) fm = m;
+      }
+      if (lane < U) words[wave][g * U + lane] = fm;
+      if (lane == 0) counts[wave][g] = cnt;
+    }
+    for (int i = lane; i < G * U; i += 64) __builtin_nontemporal_store(words[wave][i], A.mask + t * (G * U) + i);
+    for (int i = lane; i < G; i += 64) A.counts[t * G + i] = counts[wave][i];
+  }
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+template <int U, int W, int V> float Run(const Args& A, size_t n, int per_cu, hipEvent_t a, hipEvent_t b) {
+  std::vector<float> ms;
+  for (int it = 0; it < 9; it++) {
+    CK(hipEventRecord(a));
+    if (V >= 100) hipLaunchKernelGGL((L<U, W, (V >= 100 ? V - 100 : 1)>), dim3(256 * per_cu), dim3(W * 64), 0, 0, A, n / (64 * U));
+    else if (V >= 10) hipLaunchKernelGGL((Q<U, W, (V >= 10 && V < 100 ? V - 10 : 1)>), dim3(256 * per_cu), dim3(W * 64), 0, 0, A, n / (64 * U));
+    else if (V == 4) hipLaunchKernelGGL((P<U, W, false>), dim3(256 * per_cu), dim3(W * 64), 0, 0, A, n / (64 * U));
+    else if (V == 5) hipLaunchKernelGGL((P<U, W, true>), dim3(256 * per_cu), dim3(W * 64), 0, 0, A, n / (64 * U));
+    else hipLaunchKernelGGL((K<U, W, V>), dim3(256 * per_cu), dim3(W * 64), 0, 0, A, n / (64 * U));
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float m; CK(hipEventElapsedTime(&m, a, b)); if (it >= 2) ms.push_back(m);
+  }
+  std::sort(ms.begin(), ms.end());
+  return ms[ms.size() / 2];
+}
+int main() {
+  const size_t n = 976562ull * 1024;
+  Args A;
+  void* p;
+  CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 1, n * 8)); A.a = (const long long*)p;
+  CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 2, n * 8)); A.b = (const long long*)p;
+  CK(hipMalloc(&p, n / 8 + 64)); CK(hipMemset(p, 0xff, n / 8 + 64)); A.va = (const unsigned long long*)p;
+  CK(hipMalloc(&p, n / 8 + 64)); CK(hipMemset(p, 0xff, n / 8 + 64)); A.vb = (const unsigned long long*)p;
+  CK(hipMalloc(&p, n / 8 + 64)); A.mask = (unsigned long long*)p;
+  CK(hipMalloc(&p, n / 64 * 4 + 64)); A.counts = (unsigned*)p;
+  CK(hipMalloc(&p, 64)); A.sink = (unsigned long long*)p;
+  A.k1 = 499; A.k2 = 250;
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int rep = 0; rep < 3; rep++) {
+    printf("rep %d\n", rep);
+#define R(U, W, V, G, what) { float m = Run<U, W, V>(A, n, G, a, b); printf("  U=%-2d W=%d grid x%-2d %-58s %.4f ms  %.3f of 8 TB/s\n", U, W, G, what, m, 16.0 * n / (m * 1e-3) / 8e12); }
+    R(4, 4, 0, 2, "skeleton");
+    R(16, 4, 0, 8, "skeleton");
+    R(16, 4, 1, 8, "+ compare, ballot, popcount, count per wave tile");
+    R(16, 4, 2, 8, "+ match words stored");
+    R(16, 4, 3, 8, "+ validity words loaded and ANDed (real bitmaps)");
+    R(16, 4, 5, 8, "compare, ballot, popcount; nothing stored per tile");
+    R(16, 4, 4, 8, "all of it, stores of tile k behind the loads of tile k + 1");
+    R(16, 4, 12, 8, "2 consecutive tiles per wave, one 256-byte store + one count");
+    R(16, 4, 14, 8, "4 consecutive tiles per wave, one 512-byte store + one count");
+    R(16, 4, 116, 8, "16 consecutive tiles per wave through LDS: 2 KiB of words + 64 bytes of counts at once");
+    R(16, 4, 164, 8, "64 consecutive tiles per wave through LDS: 8 KiB of words + 256 bytes of counts at once");
+    R(16, 4, 164, 2, "64 consecutive tiles per wave through LDS: 8 KiB of words + 256 bytes of counts at once");
+    R(16, 4, 14, 2, "4 consecutive tiles per wave, one 512-byte store + one count");
+    R(8, 4, 18, 8, "8 consecutive tiles of 8 per wave, one 512-byte store");
+    R(4, 4, 26, 8, "16 consecutive tiles of 4 per wave, one 512-byte store");
+  }
+  return 0;
+}
