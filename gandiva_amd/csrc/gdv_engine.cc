@@ -487,6 +487,9 @@ int64_t GridFor(const KernelPlan& plan, int64_t rows) {
   // as many, smaller shares of the grid-stride loop even out the tail (C5: 2.26 -> 2.01 ms;
   // fixed-width plans measured best at the base value)
   if (plan.has_varlen_input || plan.has_varlen_output) blocks_per_cu *= 4;
+  // (read-dominated 16-sub-tile plans, PlanProjectorShape / PlanFilter: fewer resident workgroups stream better — once every
+  // workgroup has a long loop to run; a batch of a few tiles per CU is over sooner with all of them in flight)
+  else if (plan.grid_blocks_per_cu > 0 && ntiles >= 64LL * Runtime::Get().num_cus()) blocks_per_cu = plan.grid_blocks_per_cu;
   if (EngineKnobs::Get().grid_mult > 0) blocks_per_cu = EngineKnobs::Get().grid_mult;
   int64_t cap = static_cast<int64_t>(Runtime::Get().num_cus()) * blocks_per_cu;
   return std::max<int64_t>(1, std::min(ntiles, cap));

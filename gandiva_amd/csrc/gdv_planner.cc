@@ -2823,6 +2823,14 @@ Status PlanProjectorShape(const Schema& schema, const std::vector<ExpressionPtr>
       for (auto& e : exprs) max_width = std::max(max_width, e->result().type.byte_width());
       if (in_bytes * 16 <= 512 && max_width <= 8) u = 16;
       plan->opts.subtiles = u;
+      // ... and ONE workgroup per CU for such a plan when it reads at least twice what it writes (row mode): with sixteen
+      // sub-tiles a wave has 16 x in_bytes x 64 bytes in flight, four waves keep a CU's share of the HBM busy, and every further
+      // resident workgroup only interleaves more read streams at the DRAM — C1 0.705-0.711 ms against 0.743-0.757 at eight per
+      // CU (and 0.745-0.754 at two) in three alternations on one box, 0.673-0.709 against 0.706-0.738 in four on another; write-dominated plans (C2) and 4-sub-tile plans (C4)
+      // measure the same at 1 / 2 / 8 and keep the default (profiles/r06_grid_density.txt)
+      int out_bytes = 0;
+      for (auto& e : exprs) out_bytes += std::max(1, e->result().type.byte_width());
+      if (u == 16 && mode == SelectionMode::kNone && in_bytes >= 2 * out_bytes) plan->grid_blocks_per_cu = 1;
     }
   }
   return Assemble(cg, plan, strings, accs, before_loop.str(), after_loop.str());
@@ -2961,6 +2969,9 @@ Status PlanFilter(const Schema& schema, const ExpressionPtr& condition,
     int u = 16;
     while (u > 4 && u * std::max(in_bytes, 1) > 512) u >>= 1;
     plan->opts.subtiles = u;
+    // (Round 6: ONE workgroup per CU — what the read skeleton prefers — measured 2.64-2.70 ms per Filter::Evaluate against
+    // 2.69-2.80 at eight per CU in five alternations on one box and 2.97-2.98 against 2.92-2.94 in four on another: the grid
+    // stays at the engine's default, profiles/r06_grid_density.txt)
   }
   std::ostringstream after;
   // the match words are written once and read by the index-emission kernel much later: non-temporal

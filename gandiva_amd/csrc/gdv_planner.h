@@ -124,6 +124,7 @@ struct KernelPlan {
   std::vector<int> wave_segments;
   int fp_rounds = 1;  // fused filter-project: rounds of `subtiles` sub-tiles per wave tile (windowed shape: GDV_FP_K; direct: 1)
   int fp_window_rows = 0;  // fused filter-project, windowed shape: GDV_FP_CAP (0: the direct shape); `exact` = the direct shape
+  int grid_blocks_per_cu = 0;  // workgroups per CU of the grid-stride launch the planner asks for (0: the engine's default)
   int general_subtiles = 0, general_waves = 0;  // tile of the scanner-shaped fallback (0: opts')
   int rows_per_tile() const { return 64 * opts.subtiles * (wave_tiles ? 1 : opts.waves); }
 };
