@@ -160,6 +160,33 @@ int main() {
   CK(hipMalloc(&p, 64)); A.sink = (unsigned long long*)p;
   A.k1 = 499; A.k2 = 250;
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  if (getenv("PROBE_PLACEMENT")) {
+    // does the placement of the two small WRITTEN buffers (match words, counts) relative to the inputs matter?  Eight placements of
+    // the pair (junk allocations of varying size in between), same inputs; then eight placements of the inputs, same small buffers.
+    unsigned long long* masks[8]; unsigned* cnts[8];
+    for (int i = 0; i < 8; i++) {
+      void* junk; CK(hipMalloc(&junk, (size_t)(37 + 61 * i) << 20));
+      CK(hipMalloc(&p, n / 8 + 64)); masks[i] = (unsigned long long*)p;
+      CK(hipMalloc(&junk, (size_t)(5 + 13 * i) << 20));
+      CK(hipMalloc(&p, n / 64 * 4 + 64)); cnts[i] = (unsigned*)p;
+    }
+    for (int rep = 0; rep < 2; rep++)
+      for (int i = 0; i < 8; i++) {
+        Args B = A; B.mask = masks[i]; B.counts = cnts[i];
+        printf("small buffers %d @ %p %p: skeleton %.4f ms, predicate %.4f ms\n", i, (void*)B.mask, (void*)B.counts, Run<16, 4, 0>(B, n, 8, a, b), Run<16, 4, 2>(B, n, 8, a, b));
+      }
+    const long long* ia[6]; const long long* ib[6];
+    for (int i = 0; i < 6; i++) {
+      CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 1, n * 8)); ia[i] = (const long long*)p;
+      CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 2, n * 8)); ib[i] = (const long long*)p;
+    }
+    for (int rep = 0; rep < 2; rep++)
+      for (int i = 0; i < 6; i++) {
+        Args B = A; B.a = ia[i]; B.b = ib[i];
+        printf("inputs %d @ %p %p: skeleton %.4f ms, predicate %.4f ms\n", i, (void*)B.a, (void*)B.b, Run<16, 4, 0>(B, n, 8, a, b), Run<16, 4, 2>(B, n, 8, a, b));
+      }
+    return 0;
+  }
   for (int rep = 0; rep < 3; rep++) {
     printf("rep %d\n", rep);
 #define R(U, W, V, G, what) { float m = Run<U, W, V>(A, n, G, a, b); printf("  U=%-2d W=%d grid x%-2d %-58s %.4f ms  %.3f of 8 TB/s\n", U, W, G, what, m, 16.0 * n / (m * 1e-3) / 8e12); }
