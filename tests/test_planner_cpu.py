@@ -217,3 +217,30 @@ def test_replace_is_answered_by_the_sweep_only_where_matches_cannot_overlap(monk
         pre, main, general = kernels(frm, f"b{k}")
         for t in (pre, main, general):
             assert "gdv_replace_hits(" not in t and "gdv_replace(" in t, frm
+
+
+def test_the_wave_tile_of_a_fixed_width_projection_follows_the_width_of_its_values(monkeypatch, tmp_path):
+    """Round 6 (profiles/r06_tile_shape.txt): 16 sub-tiles of 64 rows per wave where 16 rows of loaded values fit 512 bytes of
+    registers per lane and no element is wider than 8 bytes (C1, C2); decimal128 plans (C4) keep 4; predicate kernels 16."""
+    def shape(d, w, cond=False):
+        files = _precompile(monkeypatch, tmp_path / d, getattr(W, w + "_schema")(),
+                            None if cond else getattr(W, w + "_expressions")(), W.c3_condition() if cond else None)
+        text = open(os.path.join(tmp_path / d, files[0])).read()
+        return int(re.search(r"#define GDV_U (\d+)", text).group(1)), int(re.search(r"#define GDV_WAVES (\d+)", text).group(1))
+    for d in ("c1", "c2", "c4", "c3"):
+        (tmp_path / d).mkdir()
+    assert shape("c1", "c1") == (16, 4)
+    assert shape("c2", "c2") == (16, 4)
+    assert shape("c4", "c4") == (4, 4)
+    assert shape("c3", "c3", cond=True) == (16, 4)
+    # forty bytes of inputs per row: 16 sub-tiles would need 640 bytes per lane -> the rule of rounds 1-5
+    b = gandiva.TreeExprBuilder()
+    sch = pa.schema([pa.field(c, pa.float64()) for c in "pqrst"])
+    f = [b.make_field(x) for x in sch]
+    s = f[0]
+    for x in f[1:]:
+        s = b.make_function("add", [s, x], pa.float64())
+    (tmp_path / "wide").mkdir()
+    files = _precompile(monkeypatch, tmp_path / "wide", sch, [b.make_expression(s, pa.field("o", pa.float64()))])
+    text = open(os.path.join(tmp_path / "wide", files[0])).read()
+    assert int(re.search(r"#define GDV_U (\d+)", text).group(1)) == 4
