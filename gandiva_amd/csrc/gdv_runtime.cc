@@ -1,6 +1,7 @@
 #include "gdv_runtime.h"
 
 #include <dlfcn.h>
+#include <sys/syscall.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -258,8 +259,14 @@ class BackgroundCompiler {
         std::lock_guard<std::mutex> g(CodeCacheMutex());
         FailedCompilations().insert(job.second);
       }
+      // (the compiler's function-local statics that THIS compilation constructed are torn down, at exit, after a handler
+      // registered now — see ExitHook)
+      (void)std::atexit(&BackgroundCompiler::ExitHook);
     }
   }
+ public:
+  static void ExitHook() { Get().Shutdown(); }
+ private:
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::pair<std::string, std::string>> jobs_;
@@ -282,7 +289,29 @@ int Runtime::CodeObjectState(const std::string& kernel_name, bool memory_only) {
   return access(path.c_str(), R_OK) == 0 ? 1 : 0;
 }
 
+// Process exit with a compilation in flight.  exit() runs the exit handlers newest first, and the compiler (LLVM inside
+// libamd_comgr) registers the destructors of its function-local statics as it first executes them, i.e. DURING compilations:
+// they are newer than anything this library registered before, so at exit they are torn down first — under a worker that is
+// still compiling (round 6, found with a cold code-object cache: the C++ acceptance binary, which finishes on tier 0 within a
+// second of its first Make, crashed or hung in its exit).  Three layers:
+//  * exit() destroys the CALLING thread's thread_local objects before it runs any handler: a guard object on every thread that
+//    queues a compilation stops the queue and joins the worker from there when that thread is the process's main thread;
+//  * a handler registered after every finished compilation (BackgroundCompiler::ExitHook) orders the join ahead of the teardown
+//    of everything earlier compilations constructed — for processes whose main thread never called Make;
+//  * gdv_shutdown() for embedders that can call it (the Python package does, from atexit).
+namespace {
+struct MainThreadExitGuard {
+  MainThreadExitGuard() : tid(static_cast<long>(syscall(SYS_gettid))) {}
+  ~MainThreadExitGuard() {
+    if (tid == static_cast<long>(getpid())) Runtime::ShutdownBackgroundCompiler();
+  }
+  long tid;
+};
+}  // namespace
+
 bool Runtime::CompileInBackground(const std::string& source, const std::string& kernel_name) {
+  thread_local MainThreadExitGuard guard;
+  (void)guard.tid;
   return BackgroundCompiler::Get().Push(source, kernel_name);
 }
 void Runtime::ShutdownBackgroundCompiler() { BackgroundCompiler::Get().Shutdown(); }
