@@ -648,8 +648,10 @@ int64_t gdv_device_pool_bytes(const gdv_device_pool_t* pool, int64_t* in_use);
 char* gdv_tier0_program(const gdv_schema_t* schema, gdv_expression_t* const* exprs, int num_exprs, int is_condition);
 int64_t gdv_tier0_launches(void);
 /* Stops the background compiler: queued compilations are dropped, the one in flight is waited for (<= ~1 s).  The library
- * does this itself when the process exits normally (its compiler thread is joined before hipRTC's own teardown); call it
- * from JNI_OnUnload / before dlclose, or from an embedder that tears the process down in an order of its own.  Later Makes
+ * does this itself when the process exits through its MAIN thread and that thread has called a Make (a thread_local guard,
+ * which exit() destroys before it runs any exit handler, joins the compiler thread: the compiler's own statics — registered
+ * while it compiles, hence torn down first — are then no longer in use); a process whose main thread never calls Make, a
+ * JNI_OnUnload, a dlclose, or an embedder that tears the process down in an order of its own calls this before.  Later Makes
  * wait for their compilation as before round 6. */
 void gdv_shutdown(void);
 
