@@ -148,6 +148,7 @@ def test_the_core_parity_tests_pass_with_every_plan_forced_onto_tier_0():
     densities, array offsets, if / else + three-valued logic, misaligned bitmaps, > 2^32 rows excluded for time —
     against the oracle.  (The whole GPU suite under the same switch: profiles/r06_pytest_gpu_tier0.txt.)"""
     env = dict(os.environ, GDV_FORCE_TIER0="1")
+    env.pop("GDV_NO_TIER0", None)   # (the suite itself may be running with tier 0 switched off)
     sel = ("test_c1_int32_plumbing or test_c2_ten_float64_expressions or test_c3_filter or test_arithmetic_and_compare or "
            "test_array_offsets or test_if_else_and_boolean_3vl or test_device_path_with_array_offsets_and_misaligned_bitmaps or "
            "test_uint_and_narrow_types_in_filters or test_device_resident_batches_match_host_path")
