@@ -66,8 +66,8 @@ def parse():
     p.add_argument("--no-extras", action="store_true",
                    help="default invocation only: leave out the 'workloads' object (the other BASELINE configs + K2F)")
     p.add_argument("--extras", default="c1,c3,k2f,c5,c4", help="sub-workloads of the default line, in this order")
-    p.add_argument("--sub-steps", type=int, default=10)
-    p.add_argument("--sub-warmup", type=int, default=2)
+    p.add_argument("--sub-steps", type=int, default=30)
+    p.add_argument("--sub-warmup", type=int, default=3)
     p.add_argument("--sub-placements", type=int, default=3, help="placement trials of the projection sub-workloads (c1, c4)")
     p.add_argument("--sub-cpu-seconds", type=float, default=3.0)
     p.add_argument("--c5-sync", action="store_true",
@@ -692,7 +692,9 @@ def setup_workload(name, rows, args, rank=0):
         wl.bytes_per_row, wl.read_per_row = 16 + 4 * sel.num_slots / rows, 16
 
         def step():
-            wl.obj.evaluate_device(wl.dbatch, "int32", out=wl.out)
+            # (asynchronous, like the other workloads' steps: the slot count stays in device memory, where a selection-mode
+            # Projector reads it — no host wait between steps, so a host thread that loses its core does not idle the GPU)
+            wl.obj.evaluate_device(wl.dbatch, "int32", out=wl.out, sync=False)
 
         def result():
             wl.out.fill_(-1)       # the indices the check reads are written by THIS call, after the loop's
@@ -911,6 +913,10 @@ def roofline_of(wl, dev_ms, trials, quote_traffic, placement=None):
         "kernel_ms": round(mean_ms, 4),
         "kernel_ms_min": round(min(dev_ms), 4),
         "kernel_ms_max": round(max(dev_ms), 4),
+        # (`frac` is on the MEAN of the timed steps, as the contract asks; the median next to it shows when one step of a
+        # short loop was stretched — a synchronous Evaluate launches from the host several times per step, and a host
+        # thread that loses its core for a few milliseconds leaves the GPU idle between two of those launches)
+        "kernel_ms_median": round(sorted(dev_ms)[len(dev_ms) // 2], 4),
         # ms per step of every placement tried before the timed loop (first = the first allocation); the
         # timed loop ran on the fastest.  null: one allocation, no trials
         "placement_trials_ms": trials,
