@@ -917,6 +917,7 @@ def roofline_of(wl, dev_ms, trials, quote_traffic, placement=None):
         # short loop was stretched — a synchronous Evaluate launches from the host several times per step, and a host
         # thread that loses its core for a few milliseconds leaves the GPU idle between two of those launches)
         "kernel_ms_median": round(sorted(dev_ms)[len(dev_ms) // 2], 4),
+        **({"kernel_ms_steps": [round(x, 3) for x in dev_ms]} if os.environ.get("GDV_BENCH_STEP_TIMES") else {}),
         # ms per step of every placement tried before the timed loop (first = the first allocation); the
         # timed loop ran on the fastest.  null: one allocation, no trials
         "placement_trials_ms": trials,

@@ -563,6 +563,37 @@ Status Runtime::Alloc(size_t bytes, void** ptr) {
       return Status::OK();
     }
   }
+  // Bounded run-ahead (round 6).  An asynchronous caller enqueues faster than the GPU completes: every call would find the
+  // blocks of the calls before it still in flight and take NEW ones from the driver — unbounded memory, and a hipMalloc that
+  // has to map fresh memory stalls the kernels that are running (C5's asynchronous Evaluate as the fourth workload of one
+  // process: a 3-5 ms gap every 13-14 calls, profiles/r06_bench_step_outliers.txt).  With kMaxDeferredPerSize blocks of this
+  // size already waiting for their streams, wait for the oldest of them instead and take that one.
+  constexpr int kMaxDeferredPerSize = 8;
+  {
+    hipEvent_t oldest = nullptr;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      int pending = 0;
+      for (auto& d : deferred_) {
+        auto it = live_blocks_.find(d.second);
+        if (it != live_blocks_.end() && it->second == sz && pending++ == 0) oldest = d.first;
+      }
+      if (pending < kMaxDeferredPerSize) oldest = nullptr;
+    }
+    if (oldest != nullptr) {
+      if (hipEventSynchronize(oldest) != hipSuccess) (void)hipGetLastError();
+      Reap(false);
+      std::lock_guard<std::mutex> g(mu_);
+      auto it = free_blocks_.find(sz);
+      if (it != free_blocks_.end()) {
+        *ptr = it->second;
+        free_blocks_.erase(it);
+        cached_bytes_ -= sz;
+        live_blocks_[*ptr] = sz;
+        return Status::OK();
+      }
+    }
+  }
   hipError_t e = hipMalloc(ptr, sz);
   if (e != hipSuccess) {
     (void)hipGetLastError();
